@@ -1,0 +1,155 @@
+/*
+ * gr4pm_oracle.h -- CPU oracle for the gr4-packet-modem RX hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library, and there only as the checker / reported baseline.
+ *
+ * This is a from-scratch restatement (plain C++17, no dependencies) of the
+ * reference algorithms; every function cites the reference file:line it follows
+ * (paths relative to /root/reference/blocks/include/gnuradio-4.0/packet-modem/).
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *  - firdes / pfb_arb_taps / packet_transmitter_rrc_taps: pinned bit-exact against the
+ *    reference's own standalone headers compiled into oracle/_ref/ (oracle/Makefile)
+ *    and against the 65-tap literal of test/qa_firdes.cpp:11-34.
+ *  - every block: pinned against the known-answer expectations of the reference's own
+ *    tests (test/qa_*.cpp), restated in tests/test_oracle_*.py with the same stimulus
+ *    and the same assertions.
+ *  - the FFT inside SyncwordDetection is FFTW3f reached through gnuradio4's
+ *    gr::algorithm::FFTw (git submodule `gnuradio4`, no pinned commit visible, absent
+ *    from /root/reference).  Its published contract (forward sign, un-normalised,
+ *    out-of-place) is restated here as a Stockham radix-4 float32 FFT; raw FFT bits are
+ *    NOT pinned by any reference test, so FFT-derived float values are compared with a
+ *    tolerance while indices / freq_bin / pass-through are compared exactly.
+ *  - the gr::Block runtime (gnuradio4) is absent, so the reference blocks themselves
+ *    cannot be built here without writing stand-ins: no reference block executable exists.
+ */
+#ifndef GR4PM_ORACLE_H
+#define GR4PM_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { float re, im; } orc_c64;
+
+/* syncword_detection.hpp:106-114 -- the seven tag keys, plus the output index */
+typedef struct {
+    uint64_t index;        /* absolute output item index the tag is attached to */
+    float amplitude;       /* syncword_amplitude */
+    float phase;           /* syncword_phase */
+    double freq;           /* syncword_freq */
+    int32_t freq_bin;      /* syncword_freq_bin */
+    float noise_power;     /* syncword_noise_power */
+    float esn0_db;         /* syncword_esn0_db */
+    float time_est;        /* syncword_time_est */
+    int32_t flags;         /* bit0: carries syncword_* keys; bit1: carries other keys */
+} orc_tag;
+
+/* firdes.hpp:29-76; returns number of taps written (ntaps|1) */
+size_t orc_rrc_taps(double gain, double fs, double symbol_rate, double alpha, size_t ntaps,
+                    float* out);
+/* packet_transmitter_rrc_taps.hpp:8-28 */
+size_t orc_tx_rrc_taps(size_t sps, float* out);
+/* forward, un-normalised complex FFT, n a power of two >= 2 (FFTW contract restated) */
+void orc_fft(const orc_c64* in, orc_c64* out, size_t n);
+
+/* ---- SyncwordDetection (syncword_detection.hpp:32-357) ---- */
+typedef struct orc_sd orc_sd;
+orc_sd* orc_sd_create(size_t fft_size, size_t sps, const float* rrc_taps, size_t n_taps,
+                      const uint8_t* syncword, size_t n_syncword, const orc_c64* constellation,
+                      size_t n_constellation, int min_freq_bin, int max_freq_bin,
+                      uint64_t time_threshold, float power_threshold);
+void orc_sd_destroy(orc_sd*);
+size_t orc_sd_syncword_samples_size(const orc_sd*);
+float orc_sd_self_corr(const orc_sd*);
+/* copies template bin `b` (conj FFT of shifted syncword), fft_size values */
+void orc_sd_template(const orc_sd*, size_t b, orc_c64* out);
+/* processBulk :204-356.  Returns 0 OK, 1 INSUFFICIENT_INPUT_ITEMS.  *n_done = items
+ * consumed == published.  zpow_dbg (optional, n_in floats) receives the per-sample
+ * best-bin correlation power, bin_dbg (optional) the best bin index. */
+int orc_sd_process(orc_sd*, const orc_c64* in, size_t n_in, orc_c64* out, size_t* n_done,
+                   orc_tag* tags, size_t tags_cap, size_t* n_tags, float* zpow_dbg,
+                   int32_t* bin_dbg);
+
+/* ---- SyncwordDetectionFilter (syncword_detection_filter.hpp:54-210) ----
+ * One call == one processBulk call.  tag_flags: 0 no tag at in[0], else orc_tag.flags.
+ * n_headers / header_*: pending parsed_header messages (packet_length, or invalid);
+ * n_ignored: pending ignored_syncword messages.  Outputs consumed counts. */
+typedef struct orc_sdf orc_sdf;
+orc_sdf* orc_sdf_create(size_t sps, size_t syncword_size, size_t header_size);
+void orc_sdf_destroy(orc_sdf*);
+int orc_sdf_process(orc_sdf*, const orc_c64* in, size_t n_in, orc_c64* out, size_t out_cap,
+                    int tag_flags, size_t n_headers, const uint64_t* header_packet_length,
+                    const uint8_t* header_invalid, size_t n_ignored, size_t* consumed,
+                    size_t* header_consumed, size_t* ignored_consumed, int* tag_out_flags);
+
+/* ---- CoarseFrequencyCorrection (coarse_frequency_correction.hpp:50-98) ----
+ * Whole-stream driver: tags sorted by index; the stream is cut at tag indices exactly as
+ * the runtime presents one tag at the head of a chunk. */
+typedef struct orc_cfc orc_cfc;
+orc_cfc* orc_cfc_create(size_t delay);
+void orc_cfc_destroy(orc_cfc*);
+void orc_cfc_process(orc_cfc*, const orc_c64* in, size_t n, orc_c64* out,
+                     const uint64_t* tag_index, const double* tag_freq, size_t n_tags);
+
+/* ---- Rotator (rotator.hpp:44-65) ---- */
+typedef struct orc_rot orc_rot;
+orc_rot* orc_rot_create(float phase_incr);
+void orc_rot_destroy(orc_rot*);
+void orc_rot_process(orc_rot*, const orc_c64* in, size_t n, orc_c64* out);
+
+/* ---- CostasLoop (costas_loop.hpp:52-148); constellation 0 PILOT 1 BPSK 2 QPSK ---- */
+typedef struct orc_costas orc_costas;
+orc_costas* orc_costas_create(double loop_bandwidth, int constellation);
+void orc_costas_destroy(orc_costas*);
+void orc_costas_coeffs(const orc_costas*, float* k1, float* k2);
+void orc_costas_process(orc_costas*, const orc_c64* in, size_t n, orc_c64* out,
+                        const uint64_t* tag_index, const float* tag_phase, size_t n_tags);
+
+/* ---- SyncwordWipeoff (syncword_wipeoff.hpp:38-90) ---- */
+typedef struct orc_wipe orc_wipe;
+orc_wipe* orc_wipe_create(const float* syncword, size_t n);
+void orc_wipe_destroy(orc_wipe*);
+void orc_wipe_process(orc_wipe*, const orc_c64* in, size_t n, orc_c64* out,
+                      const uint64_t* tag_index, size_t n_tags);
+
+/* ---- InterpolatingFirFilter (interpolating_fir_filter.hpp:42-102) ---- */
+typedef struct orc_ifir orc_ifir;
+orc_ifir* orc_ifir_create(size_t interpolation, const float* taps, size_t n_taps);
+void orc_ifir_destroy(orc_ifir*);
+void orc_ifir_process_c64(orc_ifir*, const orc_c64* in, size_t n, orc_c64* out);
+void orc_ifir_process_f32(orc_ifir*, const float* in, size_t n, float* out);
+/* stateless integer instantiation used by test/qa_interpolating_fir_filter.cpp */
+void orc_ifir_int(size_t interpolation, const int* taps, size_t n_taps, const int* in, size_t n,
+                  int* out);
+
+/* ---- SymbolFilter (symbol_filter.hpp:64-252) ----
+ * Whole-stream driver; tags (sorted) carry amplitude/time_est/phase/freq and flags.
+ * Output tags are re-timed to symbol indices (:204-228); returns produced symbols. */
+typedef struct orc_symf orc_symf;
+orc_symf* orc_symf_create(size_t sps, const float* taps, size_t n_taps, size_t num_arms,
+                          size_t delay);
+void orc_symf_destroy(orc_symf*);
+size_t orc_symf_process_c64(orc_symf*, const orc_c64* in, size_t n, orc_c64* out, size_t out_cap,
+                            const orc_tag* tags_in, size_t n_tags_in, orc_tag* tags_out,
+                            size_t tags_cap, size_t* n_tags_out, size_t* consumed);
+size_t orc_symf_process_f32(orc_symf*, const float* in, size_t n, float* out, size_t out_cap,
+                            size_t* consumed);
+
+/* ---- PfbArbResampler (pfb_arb_resampler.hpp:67-182); rate_is_double selects TRate ---- */
+typedef struct orc_arb orc_arb;
+orc_arb* orc_arb_create(double rate, int rate_is_double, const float* taps, size_t n_taps,
+                        size_t filter_size);
+void orc_arb_destroy(orc_arb*);
+size_t orc_arb_process(orc_arb*, const orc_c64* in, size_t n, orc_c64* out, size_t out_cap,
+                       size_t* consumed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
