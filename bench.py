@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py -- RX Msamples/s of the gr4-packet-modem receiver hot path on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched under
+torch.distributed.run, one rank per GPU.  Prints ONE JSON line on rank 0.
+
+Workload (BASELINE.json configs[1]): one channel per GPU, SyncwordDetection (overlap-save FFT
+correlator, 9 frequency bins, detector, tags, delayed pass-through) on a synthetic
+3.2 Msps-shaped burst stream (64-symbol BPSK syncword + 128-symbol header + QPSK payload,
+45-tap unit-norm RRC at 4 samples/symbol, per-packet CFO, AWGN) already resident in HBM.
+A step is one process() call over one batch of `--items` samples; the stream state carries
+from step to step exactly as in the reference block.  With N GPUs every rank runs its own
+channel (the path shards by channel, no data-path collective): weak scaling.
+
+Extra objects on the JSON line:
+  roofline      the dominant kernel (k_correlate) timed alone with HIP events on the launch
+                stream; achieved = 8 B/sample (HBM read, SURVEY.md 8(d) read-only variant)
+                x samples per launch / mean launch time, against the 8 TB/s HBM peak.
+  cpu_baseline  the CPU oracle (kind "port": the reference cannot be built here) on a bounded
+                sample of the same stream, one thread.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import __graft_entry__ as ge  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_PEAK_TFLOPS = 157.3
+N_FFT, SPS, BINS = 2048, 4, 4
+SYNCWORD = np.array(
+    [0, 0, 0, 0, 0, 0, 1, 1, 0, 1, 0, 0, 0, 1, 1, 1, 0, 1, 1, 1, 0, 1, 1, 0, 1, 1, 0, 0, 0, 1, 1, 1,
+     0, 0, 1, 0, 0, 1, 1, 1, 0, 0, 1, 0, 1, 0, 0, 0, 1, 0, 0, 1, 0, 1, 0, 1, 1, 0, 1, 1, 0, 0, 0, 0],
+    dtype=np.uint8)
+
+
+def unit_norm_rrc(pkg):
+    """packet_receiver.hpp:60-74"""
+    t = pkg.root_raised_cosine(1.0, float(SPS), 1.0, 0.35, SPS * 11)
+    norm = np.float32(0.0)
+    for v in t:
+        norm = np.float32(norm + np.float32(v * v))
+    return (t / np.float32(np.sqrt(norm))).astype(np.float32)
+
+
+def burst_stream(n_items, rrc, seed, device):
+    """synthetic 3.2 Msps-shaped bursts, generated on the GPU:
+    packets of 64 (BPSK syncword) + 128 (header) + 1504*4 (payload) QPSK symbols, gaps of 500
+    zero symbols, CFO uniform in +-0.03 rad/sample per packet, AWGN at Es/N0 = 10 dB."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    pkt_syms, gap = 64 + 128 + 1504 * 4, 500
+    period = pkt_syms + gap
+    n_sym = n_items // SPS + 64
+    n_pkt = n_sym // period + 1
+    a = np.float32(np.sqrt(0.5))
+    bits_i = torch.randint(0, 2, (n_pkt, period), generator=g, device=device)
+    bits_q = torch.randint(0, 2, (n_pkt, period), generator=g, device=device)
+    sym = torch.complex((1 - 2 * bits_i).float() * a, (1 - 2 * bits_q).float() * a)
+    sw = torch.from_numpy(np.where(SYNCWORD == 1, -1.0, 1.0).astype(np.float32)).to(device)
+    sym[:, :64] = torch.complex(sw, torch.zeros_like(sw))
+    sym[:, pkt_syms:] = 0
+    sym = sym.reshape(-1)[:n_sym]
+    taps = torch.from_numpy(rrc).to(device)
+    w = taps.flip(0).reshape(1, 1, -1)
+
+    def shape(v):
+        up = torch.zeros(v.numel() * SPS, device=device)
+        up[::SPS] = v
+        return torch.nn.functional.conv1d(up.reshape(1, 1, -1), w, padding=taps.numel() - 1).reshape(-1)[: v.numel() * SPS]
+
+    x = torch.complex(shape(sym.real.contiguous()), shape(sym.imag.contiguous()))[:n_items]
+    cfo = (torch.rand(n_pkt, generator=g, device=device) * 0.06 - 0.03).repeat_interleave(period * SPS)[:n_items]
+    k = torch.arange(n_items, device=device) % (period * SPS)
+    x = x * torch.polar(torch.ones_like(cfo), cfo * k)
+    sigma = np.float32(np.sqrt(0.1 / 2.0))  # Es = 1 per symbol -> N0 = 0.1
+    noise = torch.complex(torch.randn(n_items, generator=g, device=device) * sigma,
+                          torch.randn(n_items, generator=g, device=device) * sigma)
+    return (x + noise).to(torch.complex64).contiguous(), n_pkt
+
+
+def cpu_baseline(x_host, rrc, seconds_target=15.0):
+    import _oracle as orc
+    bpsk = np.array([1, -1], dtype=np.complex64)
+    sd = orc.SyncwordDetection(rrc, SYNCWORD, bpsk, -BINS, BINS, power_threshold=9.5)
+    # calibrate on a small piece, then run a sample sized for ~seconds_target
+    t0 = time.perf_counter()
+    sd.process(x_host[: 1 << 19])
+    rate = (1 << 19) / (time.perf_counter() - t0)
+    n = int(min(x_host.size, max(1 << 20, rate * seconds_target)))
+    sd = orc.SyncwordDetection(rrc, SYNCWORD, bpsk, -BINS, BINS, power_threshold=9.5)
+    t0 = time.perf_counter()
+    _, out, tags = sd.process(x_host[:n])
+    dt = time.perf_counter() - t0
+    return {"value": round(out.size / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": f"first {n} samples of the same burst stream, CPU oracle (oracle/gr4pm_oracle.cpp), "
+                      f"{tags.size} tags, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--items", type=int, default=1 << 26, help="samples per step per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    pkg = ge.load_package()
+
+    rrc = unit_norm_rrc(pkg)
+    bpsk = np.array([1, -1], dtype=np.complex64)
+    n_items = args.items
+    x, n_pkt = burst_stream(n_items, rrc, seed=1 + rank, device=device)
+    sd = pkg.SyncwordDetection(rrc, SYNCWORD, bpsk, -BINS, BINS, power_threshold=9.5, max_items=n_items)
+    out_keep = None
+
+    def step():
+        nonlocal out_keep
+        st, out, tags, n = sd.process_bulk(x, want_output=True, tags_cap=max(64, 2 * n_pkt + 64))
+        out_keep = out
+        return n, tags.size
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    consumed = 0
+    n_tags = 0
+    for _ in range(args.steps):
+        n, nt = step()
+        consumed += n
+        n_tags += nt
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tot = torch.tensor([dt, float(consumed)], dtype=torch.float64, device=device)
+    if dist:
+        tmax = tot[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        csum = tot[1:].clone()
+        dist.all_reduce(csum, op=dist.ReduceOp.SUM)
+        dt, total = tmax.item(), csum.item()
+    else:
+        total = float(consumed)
+
+    # ---- roofline of the dominant kernel: HIP events on the stream the kernel runs on
+    roofline = None
+    cpu = None
+    if rank == 0:
+        reps = 10
+        sd.correlate_only(x)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            sd.correlate_only(x)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        n_blocks = (n_items - N_FFT) // 1752 + 1
+        samples = n_blocks * 1752
+        alg_bytes = 8.0 * samples
+        achieved = alg_bytes / (ms * 1e-3) / 1e9
+        flops = 710.0 * samples  # (1+B) 5N log2 N + 6BN + 1.5N + 4BS per stride, B = 9
+        roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "kernel": "k_correlate", "launch_ms": round(ms, 4), "samples_per_launch": samples,
+                    "alg_bytes_per_sample": 8,
+                    "fp32_tflops": round(flops / (ms * 1e-3) / 1e12, 2),
+                    "fp32_frac": round(flops / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)}
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(x[: min(n_items, 1 << 27)].cpu().numpy(), rrc)
+    if rank == 0:
+        line = {
+            "metric": "RX Msamples/s (syncword-detect + RRC chain)",
+            "value": round(total / dt / 1e6, 2),
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: 1 channel/GPU, SyncwordDetection 9 bins (FFT 2048, 64-sym syncword, "
+                                   "4 sps RRC) on resident burst+AWGN stream",
+                       "items_per_step_per_gpu": n_items, "freq_bins": 2 * BINS + 1, "tags_per_step": n_tags // max(args.steps, 1),
+                       "parallelism": f"channel-per-gpu x{world}"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,21 @@
+"""gr4-packet-modem RX hot path for MI355X (gfx950): hand-written HIP kernels behind the
+C-ABI of include/gr4pm_hip.h, plus the host-side mirror of the reference's block interface.
+
+The directory name carries a hyphen (it is the repo's prescribed name); import it through
+`__graft_entry__.load_package()` which registers it as `gr4_packet_modem_amd`."""
+import os
+
+import numpy as np
+
+from ._abi import (EXPORTS, LIB_PATH, TAG_DTYPE, TAG_OTHER, TAG_SYNCWORD, Gr4pmError, lib)  # noqa: F401
+from .blocks import (CoarseFrequencyCorrection, CostasLoop, InterpolatingFirFilter, PfbArbResampler,  # noqa: F401
+                     Rotator, SymbolFilter, SyncwordDetection, SyncwordDetectionFilter, SyncwordWipeoff,
+                     root_raised_cosine)
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+
+
+def default_pfb_arb_taps():
+    """the default prototype of PfbArbResampler (pfb_arb_taps.hpp:12): 1280 float32 taps,
+    shipped as a data blob (data/pfb_arb_taps.f32, see tests/golden/make_golden.py)"""
+    return np.fromfile(os.path.join(_DATA, "pfb_arb_taps.f32"), dtype="<f4")

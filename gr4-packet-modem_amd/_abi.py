@@ -1,0 +1,200 @@
+"""ctypes declarations of include/gr4pm_hip.h (the C-ABI of libgr4pm_hip.so).
+
+The library is HIP only: there is no CPU fallback anywhere in this package.  Importing works
+without a GPU (so the symbol table can be checked), creating any block without one raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgr4pm_hip.so")
+
+OK = 0
+INSUFFICIENT_INPUT_ITEMS = 1
+INSUFFICIENT_OUTPUT_ITEMS = 2
+TAG_SYNCWORD = 1
+TAG_OTHER = 2
+
+TAG_DTYPE = np.dtype(
+    [
+        ("index", "<u8"),
+        ("amplitude", "<f4"),
+        ("phase", "<f4"),
+        ("freq", "<f8"),
+        ("freq_bin", "<i4"),
+        ("noise_power", "<f4"),
+        ("esn0_db", "<f4"),
+        ("time_est", "<f4"),
+        ("flags", "<i4"),
+    ],
+    align=True,
+)
+
+
+class SyncwordDetectionParams(C.Structure):
+    _fields_ = [
+        ("fft_size", C.c_size_t),
+        ("samples_per_symbol", C.c_size_t),
+        ("rrc_taps", C.c_void_p),
+        ("n_rrc_taps", C.c_size_t),
+        ("syncword", C.c_void_p),
+        ("n_syncword", C.c_size_t),
+        ("constellation", C.c_void_p),
+        ("n_constellation", C.c_size_t),
+        ("min_freq_bin", C.c_int),
+        ("max_freq_bin", C.c_int),
+        ("time_threshold", C.c_uint64),
+        ("power_threshold", C.c_float),
+        ("n_channels", C.c_size_t),
+        ("max_items", C.c_size_t),
+        ("stream", C.c_void_p),
+    ]
+
+
+class SdfParams(C.Structure):
+    _fields_ = [("samples_per_symbol", C.c_size_t), ("syncword_size", C.c_size_t),
+                ("header_size", C.c_size_t), ("stream", C.c_void_p)]
+
+
+class HeaderMsg(C.Structure):
+    _fields_ = [("packet_length", C.c_uint64), ("invalid_header", C.c_int32)]
+
+
+class RotatorParams(C.Structure):
+    _fields_ = [("mode", C.c_int), ("phase_incr", C.c_float), ("delay", C.c_size_t),
+                ("n_channels", C.c_size_t), ("stream", C.c_void_p)]
+
+
+class CostasParams(C.Structure):
+    _fields_ = [("loop_bandwidth", C.c_double), ("constellation", C.c_int), ("n_channels", C.c_size_t),
+                ("stream", C.c_void_p)]
+
+
+class WipeoffParams(C.Structure):
+    _fields_ = [("syncword", C.c_void_p), ("n_syncword", C.c_size_t), ("stream", C.c_void_p)]
+
+
+class InterpFirParams(C.Structure):
+    _fields_ = [("interpolation", C.c_size_t), ("taps", C.c_void_p), ("n_taps", C.c_size_t),
+                ("item_kind", C.c_int), ("stream", C.c_void_p)]
+
+
+class SymbolFilterParams(C.Structure):
+    _fields_ = [("samples_per_symbol", C.c_size_t), ("taps", C.c_void_p), ("n_taps", C.c_size_t),
+                ("num_arms", C.c_size_t), ("delay", C.c_size_t), ("item_kind", C.c_int),
+                ("stream", C.c_void_p)]
+
+
+class PfbArbParams(C.Structure):
+    _fields_ = [("rate", C.c_double), ("rate_is_double", C.c_int), ("taps", C.c_void_p),
+                ("n_taps", C.c_size_t), ("filter_size", C.c_size_t), ("stream", C.c_void_p)]
+
+
+# every symbol include/gr4pm_hip.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "gr4pm_last_error", "gr4pm_version", "gr4pm_device_count",
+    "gr4pm_syncword_detection_create", "gr4pm_syncword_detection_destroy",
+    "gr4pm_syncword_detection_reset", "gr4pm_syncword_detection_syncword_samples_size",
+    "gr4pm_syncword_detection_self_corr", "gr4pm_syncword_detection_items_consumed",
+    "gr4pm_syncword_detection_process", "gr4pm_syncword_detection_last_zpow",
+    "gr4pm_syncword_detection_correlate_only",
+    "gr4pm_syncword_detection_filter_create", "gr4pm_syncword_detection_filter_destroy",
+    "gr4pm_syncword_detection_filter_reset", "gr4pm_syncword_detection_filter_process",
+    "gr4pm_rotator_create", "gr4pm_rotator_destroy", "gr4pm_rotator_reset", "gr4pm_rotator_process",
+    "gr4pm_costas_loop_create", "gr4pm_costas_loop_destroy", "gr4pm_costas_loop_reset",
+    "gr4pm_costas_loop_coeffs", "gr4pm_costas_loop_set", "gr4pm_costas_loop_process",
+    "gr4pm_syncword_wipeoff_create", "gr4pm_syncword_wipeoff_destroy", "gr4pm_syncword_wipeoff_reset",
+    "gr4pm_syncword_wipeoff_process",
+    "gr4pm_interp_fir_create", "gr4pm_interp_fir_destroy", "gr4pm_interp_fir_reset",
+    "gr4pm_interp_fir_process",
+    "gr4pm_symbol_filter_create", "gr4pm_symbol_filter_destroy", "gr4pm_symbol_filter_reset",
+    "gr4pm_symbol_filter_process",
+    "gr4pm_pfb_arb_resampler_create", "gr4pm_pfb_arb_resampler_destroy", "gr4pm_pfb_arb_resampler_reset",
+    "gr4pm_pfb_arb_resampler_process",
+    "gr4pm_firdes_root_raised_cosine",
+]
+
+_lib = None
+
+
+class Gr4pmError(RuntimeError):
+    """what the reference raises as gr::exception"""
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, sz, szp = C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)
+    L.gr4pm_last_error.restype = C.c_char_p
+    L.gr4pm_version.restype = C.c_char_p
+    L.gr4pm_device_count.restype = C.c_int
+    L.gr4pm_syncword_detection_create.argtypes = [C.POINTER(SyncwordDetectionParams), C.POINTER(vp)]
+    L.gr4pm_syncword_detection_destroy.argtypes = [vp]
+    L.gr4pm_syncword_detection_destroy.restype = None
+    L.gr4pm_syncword_detection_reset.argtypes = [vp]
+    L.gr4pm_syncword_detection_syncword_samples_size.argtypes = [vp]
+    L.gr4pm_syncword_detection_syncword_samples_size.restype = sz
+    L.gr4pm_syncword_detection_self_corr.argtypes = [vp]
+    L.gr4pm_syncword_detection_self_corr.restype = C.c_float
+    L.gr4pm_syncword_detection_items_consumed.argtypes = [vp]
+    L.gr4pm_syncword_detection_items_consumed.restype = C.c_uint64
+    L.gr4pm_syncword_detection_process.argtypes = [vp, vp, sz, sz, vp, sz, szp, vp, sz, vp]
+    L.gr4pm_syncword_detection_last_zpow.argtypes = [vp, vp, sz]
+    L.gr4pm_syncword_detection_correlate_only.argtypes = [vp, vp, sz, sz]
+    L.gr4pm_syncword_detection_filter_create.argtypes = [C.POINTER(SdfParams), C.POINTER(vp)]
+    L.gr4pm_syncword_detection_filter_destroy.argtypes = [vp]
+    L.gr4pm_syncword_detection_filter_destroy.restype = None
+    L.gr4pm_syncword_detection_filter_reset.argtypes = [vp]
+    L.gr4pm_syncword_detection_filter_process.argtypes = [vp, vp, sz, vp, sz, C.c_int, vp, sz, sz, szp, szp, szp,
+                                                          C.POINTER(C.c_int)]
+    L.gr4pm_rotator_create.argtypes = [C.POINTER(RotatorParams), C.POINTER(vp)]
+    L.gr4pm_rotator_destroy.argtypes = [vp]
+    L.gr4pm_rotator_destroy.restype = None
+    L.gr4pm_rotator_reset.argtypes = [vp]
+    L.gr4pm_rotator_process.argtypes = [vp, vp, sz, sz, vp, vp, vp, sz]
+    L.gr4pm_costas_loop_create.argtypes = [C.POINTER(CostasParams), C.POINTER(vp)]
+    L.gr4pm_costas_loop_destroy.argtypes = [vp]
+    L.gr4pm_costas_loop_destroy.restype = None
+    L.gr4pm_costas_loop_reset.argtypes = [vp]
+    L.gr4pm_costas_loop_coeffs.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.gr4pm_costas_loop_coeffs.restype = None
+    L.gr4pm_costas_loop_set.argtypes = [vp, C.c_double, C.c_int]
+    L.gr4pm_costas_loop_process.argtypes = [vp, vp, sz, sz, vp, vp, vp, sz]
+    L.gr4pm_syncword_wipeoff_create.argtypes = [C.POINTER(WipeoffParams), C.POINTER(vp)]
+    L.gr4pm_syncword_wipeoff_destroy.argtypes = [vp]
+    L.gr4pm_syncword_wipeoff_destroy.restype = None
+    L.gr4pm_syncword_wipeoff_reset.argtypes = [vp]
+    L.gr4pm_syncword_wipeoff_process.argtypes = [vp, vp, sz, vp, vp, sz]
+    L.gr4pm_interp_fir_create.argtypes = [C.POINTER(InterpFirParams), C.POINTER(vp)]
+    L.gr4pm_interp_fir_destroy.argtypes = [vp]
+    L.gr4pm_interp_fir_destroy.restype = None
+    L.gr4pm_interp_fir_reset.argtypes = [vp]
+    L.gr4pm_interp_fir_process.argtypes = [vp, vp, sz, vp]
+    L.gr4pm_symbol_filter_create.argtypes = [C.POINTER(SymbolFilterParams), C.POINTER(vp)]
+    L.gr4pm_symbol_filter_destroy.argtypes = [vp]
+    L.gr4pm_symbol_filter_destroy.restype = None
+    L.gr4pm_symbol_filter_reset.argtypes = [vp]
+    L.gr4pm_symbol_filter_process.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, sz, szp, szp, szp]
+    L.gr4pm_pfb_arb_resampler_create.argtypes = [C.POINTER(PfbArbParams), C.POINTER(vp)]
+    L.gr4pm_pfb_arb_resampler_destroy.argtypes = [vp]
+    L.gr4pm_pfb_arb_resampler_destroy.restype = None
+    L.gr4pm_pfb_arb_resampler_reset.argtypes = [vp]
+    L.gr4pm_pfb_arb_resampler_process.argtypes = [vp, vp, sz, vp, sz, szp, szp]
+    L.gr4pm_firdes_root_raised_cosine.argtypes = [C.c_double] * 4 + [sz, vp]
+    L.gr4pm_firdes_root_raised_cosine.restype = sz
+    _lib = L
+    return L
+
+
+def check(status, what):
+    """negative status == the reference's `throw gr::exception(...)`"""
+    if status < 0:
+        raise Gr4pmError(f"{what}: status {status}: {lib().gr4pm_last_error().decode()}")
+    return status

@@ -1,0 +1,390 @@
+"""Host-side mirror of the reference's block interface for the RX hot path, over the C-ABI.
+
+Same block names, setting names, defaults and error behaviour as the reference's
+gr::Block<T> classes (cited per class; paths relative to
+/root/reference/blocks/include/gnuradio-4.0/packet-modem/).  `start()` mirrors
+gr::Block::start(), `process_bulk()` mirrors processBulk(); samples are torch tensors
+resident in HBM (torch is only plumbing: device memory + the current HIP stream), tags are
+numpy records (TAG_DTYPE) with explicit indices instead of the runtime's chunk-head tags.
+The C++ gr::Block wrappers in host/ are the drop-in for the reference's flowgraphs; this
+module is what the parity tests and bench.py drive."""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from ._abi import TAG_DTYPE, TAG_OTHER, TAG_SYNCWORD, Gr4pmError, check, lib
+
+CONSTELLATIONS = {"PILOT": 0, "BPSK": 1, "QPSK": 2}  # constellation.hpp:6
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _stream_handle():
+    torch = _torch()
+    if not torch.cuda.is_available():
+        raise Gr4pmError("no HIP device: the gr4pm blocks have no CPU fallback")
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev_c64(x, what="in"):
+    torch = _torch()
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.complex64 and x.is_contiguous()):
+        raise TypeError(f"{what} must be a contiguous complex64 CUDA tensor")
+    return x
+
+
+def _tags_array(tags):
+    if tags is None:
+        return np.zeros(0, dtype=TAG_DTYPE)
+    return np.ascontiguousarray(tags, dtype=TAG_DTYPE)
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def root_raised_cosine(gain, sampling_freq, symbol_rate, alpha, ntaps):
+    """firdes::root_raised_cosine<float>, firdes.hpp:29-76"""
+    out = np.zeros(ntaps | 1, dtype=np.float32)
+    n = lib().gr4pm_firdes_root_raised_cosine(gain, sampling_freq, symbol_rate, alpha, ntaps, _np_ptr(out))
+    return out[:n]
+
+
+class SyncwordDetection:
+    """syncword_detection.hpp:32-357.  Settings :133-141 keep their names and defaults."""
+
+    def __init__(self, rrc_taps, syncword, constellation, min_freq_bin=0, max_freq_bin=0, fft_size=2048,
+                 samples_per_symbol=4, time_threshold=768, power_threshold=9.5, n_channels=1,
+                 max_items=1 << 22):
+        self.fft_size = fft_size
+        self.samples_per_symbol = samples_per_symbol
+        self.rrc_taps = np.ascontiguousarray(rrc_taps, dtype=np.float32)
+        self.syncword = np.ascontiguousarray(syncword, dtype=np.uint8)
+        self.constellation = np.ascontiguousarray(constellation, dtype=np.complex64)
+        self.min_freq_bin = min_freq_bin
+        self.max_freq_bin = max_freq_bin
+        self.time_threshold = time_threshold
+        self.power_threshold = power_threshold
+        self.n_channels = n_channels
+        self.max_items = max_items
+        self._h = None
+        self.start()
+
+    def start(self):
+        """start(), :143-202; raises Gr4pmError where the reference throws gr::exception"""
+        self._destroy()
+        p = _abi.SyncwordDetectionParams(
+            self.fft_size, self.samples_per_symbol, _np_ptr(self.rrc_taps), self.rrc_taps.size,
+            _np_ptr(self.syncword), self.syncword.size, _np_ptr(self.constellation), self.constellation.size,
+            self.min_freq_bin, self.max_freq_bin, self.time_threshold, self.power_threshold, self.n_channels,
+            self.max_items, _stream_handle())
+        h = C.c_void_p()
+        check(lib().gr4pm_syncword_detection_create(C.byref(p), C.byref(h)), "SyncwordDetection.start")
+        self._h = h
+        self._syncword_samples_size = lib().gr4pm_syncword_detection_syncword_samples_size(h)
+        self._syncword_self_corr = lib().gr4pm_syncword_detection_self_corr(h)
+
+    @property
+    def _items_consumed(self):
+        return lib().gr4pm_syncword_detection_items_consumed(self._h)
+
+    def process_bulk(self, x, want_output=True, tags_cap=1024):
+        """processBulk(), :204-356.  x: [n] or [n_channels, n] complex64 on the GPU.
+        Returns (status, out, tags): out holds the n_done published items (delayed input),
+        tags a list (one per channel) of TAG_DTYPE records, index relative to out[0]."""
+        torch = _torch()
+        x = _dev_c64(x)
+        x2 = x.reshape(1, -1) if x.dim() == 1 else x
+        assert x2.shape[0] == self.n_channels
+        n_in = x2.shape[1]
+        out = torch.empty_like(x2) if want_output else None
+        n_done = C.c_size_t(0)
+        tags = np.zeros((self.n_channels, tags_cap), dtype=TAG_DTYPE)
+        n_tags = (C.c_size_t * self.n_channels)()
+        st = lib().gr4pm_syncword_detection_process(
+            self._h, x2.data_ptr(), x2.stride(0), n_in, out.data_ptr() if want_output else None,
+            out.stride(0) if want_output else 0, C.byref(n_done), _np_ptr(tags), tags_cap, n_tags)
+        check(st, "SyncwordDetection.processBulk")
+        n = n_done.value
+        tag_list = [tags[c, : n_tags[c]].copy() for c in range(self.n_channels)]
+        if want_output:
+            out = out[:, :n]
+            if x.dim() == 1:
+                out = out[0]
+        if x.dim() == 1:
+            tag_list = tag_list[0]
+        return st, out, tag_list, n
+
+    def correlate_only(self, x):
+        """measurement hook: only the overlap-save correlator kernel (bench.py roofline leg)"""
+        x2 = x.reshape(1, -1) if x.dim() == 1 else x
+        check(lib().gr4pm_syncword_detection_correlate_only(self._h, x2.data_ptr(), x2.stride(0), x2.shape[1]),
+              "correlate_only")
+
+    def last_zpow(self, n_done):
+        torch = _torch()
+        z = torch.empty((self.n_channels, n_done), dtype=torch.float32, device="cuda")
+        check(lib().gr4pm_syncword_detection_last_zpow(self._h, z.data_ptr(), z.stride(0)), "last_zpow")
+        return z
+
+    def _destroy(self):
+        if getattr(self, "_h", None):
+            lib().gr4pm_syncword_detection_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self._destroy()
+        except Exception:
+            pass
+
+
+class SyncwordDetectionFilter:
+    """syncword_detection_filter.hpp:10-211"""
+
+    def __init__(self, samples_per_symbol=4, syncword_size=64, header_size=128):
+        self.samples_per_symbol, self.syncword_size, self.header_size = samples_per_symbol, syncword_size, header_size
+        p = _abi.SdfParams(samples_per_symbol, syncword_size, header_size, _stream_handle())
+        self._h = C.c_void_p()
+        check(lib().gr4pm_syncword_detection_filter_create(C.byref(p), C.byref(self._h)), "SyncwordDetectionFilter")
+
+    def start(self):
+        check(lib().gr4pm_syncword_detection_filter_reset(self._h), "start")
+
+    def process_bulk(self, x, out, head_tag_flags=0, headers=(), n_ignored=0):
+        """one processBulk (:54-210). headers: sequence of packet_length or None (invalid_header).
+        Returns (consumed, headers_consumed, ignored_consumed, tag_out_flags)."""
+        x = _dev_c64(x)
+        msgs = (_abi.HeaderMsg * max(len(headers), 1))()
+        for i, hm in enumerate(headers):
+            msgs[i].packet_length = 0 if hm is None else hm
+            msgs[i].invalid_header = 1 if hm is None else 0
+        c, hc, ic, tf = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0), C.c_int(0)
+        check(lib().gr4pm_syncword_detection_filter_process(
+            self._h, x.data_ptr(), x.numel(), out.data_ptr(), out.numel(), head_tag_flags, msgs, len(headers),
+            n_ignored, C.byref(c), C.byref(hc), C.byref(ic), C.byref(tf)), "SyncwordDetectionFilter.processBulk")
+        return c.value, hc.value, ic.value, tf.value
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().gr4pm_syncword_detection_filter_destroy(self._h)
+            self._h = None
+
+
+class _RotatorBase:
+    def _create(self, mode, phase_incr, delay, n_channels):
+        p = _abi.RotatorParams(mode, phase_incr, delay, n_channels, _stream_handle())
+        self._h = C.c_void_p()
+        self.n_channels = n_channels
+        check(lib().gr4pm_rotator_create(C.byref(p), C.byref(self._h)), type(self).__name__)
+
+    def start(self):
+        check(lib().gr4pm_rotator_reset(self._h), "start")
+
+    def process_bulk(self, x, tags=None, tag_channel=None):
+        torch = _torch()
+        x = _dev_c64(x)
+        x2 = x.reshape(1, -1) if x.dim() == 1 else x
+        out = torch.empty_like(x2)
+        t = _tags_array(tags)
+        tc = None if tag_channel is None else np.ascontiguousarray(tag_channel, dtype=np.uint32)
+        check(lib().gr4pm_rotator_process(self._h, x2.data_ptr(), x2.stride(0), x2.shape[1], out.data_ptr(),
+                                          _np_ptr(t), None if tc is None else _np_ptr(tc), t.size),
+              type(self).__name__ + ".processBulk")
+        return out.reshape(x.shape)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().gr4pm_rotator_destroy(self._h)
+            self._h = None
+
+
+class Rotator(_RotatorBase):
+    """rotator.hpp:20-65"""
+
+    def __init__(self, phase_incr=0.0, n_channels=1):
+        self.phase_incr = np.float32(phase_incr)
+        self._create(0, float(self.phase_incr), 0, n_channels)
+
+
+class CoarseFrequencyCorrection(_RotatorBase):
+    """coarse_frequency_correction.hpp:20-99"""
+
+    def __init__(self, delay=0, n_channels=1):
+        self.delay = delay
+        self._create(1, 0.0, delay, n_channels)
+
+
+class CostasLoop:
+    """costas_loop.hpp:15-149"""
+
+    def __init__(self, loop_bandwidth=0.01, constellation="BPSK", n_channels=1):
+        self.loop_bandwidth = loop_bandwidth
+        self.constellation = constellation
+        if constellation.upper() not in CONSTELLATIONS:
+            raise Gr4pmError(f"unknown constellation {constellation}")  # enum_cast(...).value() throws
+        p = _abi.CostasParams(loop_bandwidth, CONSTELLATIONS[constellation.upper()], n_channels, _stream_handle())
+        self._h = C.c_void_p()
+        check(lib().gr4pm_costas_loop_create(C.byref(p), C.byref(self._h)), "CostasLoop")
+
+    @property
+    def coeffs(self):
+        k1, k2 = C.c_float(0), C.c_float(0)
+        lib().gr4pm_costas_loop_coeffs(self._h, C.byref(k1), C.byref(k2))
+        return k1.value, k2.value
+
+    def settings_changed(self, loop_bandwidth=None, constellation=None):
+        """settingsChanged(), :52-88"""
+        if loop_bandwidth is not None:
+            self.loop_bandwidth = loop_bandwidth
+        if constellation is not None:
+            self.constellation = constellation
+        check(lib().gr4pm_costas_loop_set(self._h, self.loop_bandwidth, CONSTELLATIONS[self.constellation.upper()]),
+              "settingsChanged")
+
+    def process_bulk(self, x, tags=None, tag_channel=None):
+        torch = _torch()
+        x = _dev_c64(x)
+        x2 = x.reshape(1, -1) if x.dim() == 1 else x
+        out = torch.empty_like(x2)
+        t = _tags_array(tags)
+        tc = None if tag_channel is None else np.ascontiguousarray(tag_channel, dtype=np.uint32)
+        check(lib().gr4pm_costas_loop_process(self._h, x2.data_ptr(), x2.stride(0), x2.shape[1], out.data_ptr(),
+                                              _np_ptr(t), None if tc is None else _np_ptr(tc), t.size),
+              "CostasLoop.processBulk")
+        return out.reshape(x.shape)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().gr4pm_costas_loop_destroy(self._h)
+            self._h = None
+
+
+class SyncwordWipeoff:
+    """syncword_wipeoff.hpp:12-91"""
+
+    def __init__(self, syncword):
+        self.syncword = np.ascontiguousarray(syncword, dtype=np.float32)
+        p = _abi.WipeoffParams(_np_ptr(self.syncword), self.syncword.size, _stream_handle())
+        self._h = C.c_void_p()
+        check(lib().gr4pm_syncword_wipeoff_create(C.byref(p), C.byref(self._h)), "SyncwordWipeoff")
+
+    def process_bulk(self, x, tags=None):
+        torch = _torch()
+        x = _dev_c64(x)
+        out = torch.empty_like(x)
+        t = _tags_array(tags)
+        check(lib().gr4pm_syncword_wipeoff_process(self._h, x.data_ptr(), x.numel(), out.data_ptr(), _np_ptr(t),
+                                                   t.size), "SyncwordWipeoff.processBulk")
+        return out
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().gr4pm_syncword_wipeoff_destroy(self._h)
+            self._h = None
+
+
+def _item_kind(x):
+    torch = _torch()
+    if x.dtype == torch.complex64:
+        return 0
+    if x.dtype == torch.float32:
+        return 1
+    raise TypeError("items must be complex64 or float32")
+
+
+class InterpolatingFirFilter:
+    """interpolating_fir_filter.hpp:14-103 (TIn = TOut in {c64, float}, TTaps = float)"""
+
+    def __init__(self, interpolation, taps, item_dtype="complex64"):
+        self.interpolation = interpolation
+        self.taps = np.ascontiguousarray(taps, dtype=np.float32)
+        self.item_kind = 0 if item_dtype == "complex64" else 1
+        p = _abi.InterpFirParams(interpolation, _np_ptr(self.taps), self.taps.size, self.item_kind, _stream_handle())
+        self._h = C.c_void_p()
+        check(lib().gr4pm_interp_fir_create(C.byref(p), C.byref(self._h)), "InterpolatingFirFilter")
+
+    def process_bulk(self, x):
+        torch = _torch()
+        assert x.is_cuda and x.is_contiguous() and _item_kind(x) == self.item_kind
+        out = torch.empty(x.numel() * self.interpolation, dtype=x.dtype, device=x.device)
+        check(lib().gr4pm_interp_fir_process(self._h, x.data_ptr(), x.numel(), out.data_ptr()),
+              "InterpolatingFirFilter.processBulk")
+        return out
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().gr4pm_interp_fir_destroy(self._h)
+            self._h = None
+
+
+class SymbolFilter:
+    """symbol_filter.hpp:13-253"""
+
+    def __init__(self, taps, num_arms, samples_per_symbol, delay=0, item_dtype="complex64"):
+        self.taps = np.ascontiguousarray(taps, dtype=np.float32)
+        self.num_arms, self.samples_per_symbol, self.delay = num_arms, samples_per_symbol, delay
+        self.item_kind = 0 if item_dtype == "complex64" else 1
+        p = _abi.SymbolFilterParams(samples_per_symbol, _np_ptr(self.taps), self.taps.size, num_arms, delay,
+                                    self.item_kind, _stream_handle())
+        self._h = C.c_void_p()
+        check(lib().gr4pm_symbol_filter_create(C.byref(p), C.byref(self._h)), "SymbolFilter")
+
+    def start(self):
+        check(lib().gr4pm_symbol_filter_reset(self._h), "start")
+
+    def process_bulk(self, x, tags=None, out_cap=None):
+        """returns (symbols, tags_out, consumed)"""
+        torch = _torch()
+        assert x.is_cuda and x.is_contiguous() and _item_kind(x) == self.item_kind
+        t = _tags_array(tags)
+        if out_cap is None:
+            out_cap = x.numel() // self.samples_per_symbol + t.size + 2
+        out = torch.empty(max(out_cap, 1), dtype=x.dtype, device=x.device)
+        tout = np.zeros(t.size + 64, dtype=TAG_DTYPE)
+        nto, cons, prod = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        check(lib().gr4pm_symbol_filter_process(self._h, x.data_ptr(), x.numel(), out.data_ptr(), out_cap, _np_ptr(t),
+                                                t.size, _np_ptr(tout), tout.size, C.byref(nto), C.byref(cons),
+                                                C.byref(prod)), "SymbolFilter.processBulk")
+        return out[: prod.value], tout[: nto.value].copy(), cons.value
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().gr4pm_symbol_filter_destroy(self._h)
+            self._h = None
+
+
+class PfbArbResampler:
+    """pfb_arb_resampler.hpp:23-183 (<c64, c64, float, TRate>)"""
+
+    def __init__(self, rate=1.0, taps=None, filter_size=32, rate_dtype="float32"):
+        if taps is None:
+            from . import default_pfb_arb_taps
+            taps = default_pfb_arb_taps()
+        self.rate, self.filter_size = rate, filter_size
+        self.taps = np.ascontiguousarray(taps, dtype=np.float32)
+        p = _abi.PfbArbParams(rate, 1 if rate_dtype == "float64" else 0, _np_ptr(self.taps), self.taps.size,
+                              filter_size, _stream_handle())
+        self._h = C.c_void_p()
+        check(lib().gr4pm_pfb_arb_resampler_create(C.byref(p), C.byref(self._h)), "PfbArbResampler")
+
+    def process_bulk(self, x, out_cap=None):
+        """returns (out, consumed)"""
+        torch = _torch()
+        x = _dev_c64(x)
+        if out_cap is None:
+            out_cap = int(x.numel() * self.rate) + 64
+        out = torch.empty(out_cap, dtype=x.dtype, device=x.device)
+        cons, prod = C.c_size_t(0), C.c_size_t(0)
+        check(lib().gr4pm_pfb_arb_resampler_process(self._h, x.data_ptr(), x.numel(), out.data_ptr(), out_cap,
+                                                    C.byref(cons), C.byref(prod)), "PfbArbResampler.processBulk")
+        return out[: prod.value], cons.value
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().gr4pm_pfb_arb_resampler_destroy(self._h)
+            self._h = None

@@ -1,0 +1,104 @@
+// common.hpp -- shared host-side plumbing of libgr4pm_hip.so (status codes, error text,
+// HIP call checking, small RAII device buffer).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/gr4pm_hip.h"
+
+namespace gr4pm {
+
+void set_error(const char* fmt, ...);
+
+#define GR4PM_HIP_TRY(expr)                                                                  \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            ::gr4pm::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),        \
+                               __FILE__, __LINE__);                                          \
+            return GR4PM_ERR_HIP;                                                            \
+        }                                                                                    \
+    } while (0)
+
+#define GR4PM_TRY(expr)                                                                      \
+    do {                                                                                     \
+        gr4pm_status _s = (expr);                                                            \
+        if (_s != GR4PM_OK) return _s;                                                       \
+    } while (0)
+
+// the product has no CPU fallback: every create() goes through this first
+gr4pm_status require_device();
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    gr4pm_status alloc(size_t count)
+    {
+        release();
+        if (count == 0) count = 1;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+        if (e != hipSuccess) {
+            p = nullptr;
+            set_error("hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+            return GR4PM_ERR_NOMEM;
+        }
+        n = count;
+        return GR4PM_OK;
+    }
+    gr4pm_status zero(hipStream_t s)
+    {
+        GR4PM_HIP_TRY(hipMemsetAsync(p, 0, n * sizeof(T), s));
+        return GR4PM_OK;
+    }
+    gr4pm_status upload(const T* host, size_t count, hipStream_t s)
+    {
+        GR4PM_HIP_TRY(hipMemcpyAsync(p, host, count * sizeof(T), hipMemcpyHostToDevice, s));
+        return GR4PM_OK;
+    }
+};
+
+template <typename T>
+struct PinnedBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf&) = delete;
+    PinnedBuf& operator=(const PinnedBuf&) = delete;
+    ~PinnedBuf()
+    {
+        if (p) (void)hipHostFree(p);
+    }
+    gr4pm_status alloc(size_t count)
+    {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        if (count == 0) count = 1;
+        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p), count * sizeof(T), hipHostMallocDefault);
+        if (e != hipSuccess) {
+            p = nullptr;
+            set_error("hipHostMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+            return GR4PM_ERR_NOMEM;
+        }
+        n = count;
+        return GR4PM_OK;
+    }
+};
+
+inline size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
+
+} // namespace gr4pm

@@ -1,0 +1,247 @@
+// fft2048_wave.hpp -- 2048-point complex FFT executed by ONE 64-lane wavefront, 32 points
+// per lane, two LDS exchanges per transform and no workgroup barrier.
+//
+// Two schedules are provided so that the correlator never re-distributes a spectrum:
+//   FFT-1 (16 x 16 x 8): input read straight from HBM as 16-byte loads
+//                         (lane l owns samples 2l, 2l+1 (+128 n1)); output X[k] lands with
+//                         k = k1 + 16 k2 + 256 k3, (k1, k2) = (l/16 + 4q, l%16), k3 = 0..7.
+//   FFT-2 (8 x 16 x 16): takes its input in exactly FFT-1's output distribution (so the
+//                         product X * template needs no exchange) and leaves output index
+//                         k = l + 64 q + 128 k3: consecutive lanes hold consecutive lags, so
+//                         the correlation power is stored to HBM coalesced.
+// Replaces: gr::algorithm::FFTw<c64,c64>::compute as used by
+//   syncword_detection.hpp:184,239-241,250-251 (forward, un-normalised, e^{-j 2 pi nk/N}).
+//
+// Every phase is a plain function of (lane, registers, LDS) and is compiled for host too
+// (tests/ emulate the 64 lanes on the CPU to check the index algebra without a GPU).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define GR4PM_HD __host__ __device__ __forceinline__
+#else
+#define GR4PM_HD inline
+#endif
+
+namespace gr4pm {
+
+struct cf {
+    float x, y;
+};
+GR4PM_HD cf operator+(cf a, cf b) { return { a.x + b.x, a.y + b.y }; }
+GR4PM_HD cf operator-(cf a, cf b) { return { a.x - b.x, a.y - b.y }; }
+GR4PM_HD cf cmul(cf a, cf b) { return { a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x }; }
+GR4PM_HD cf mul_mj(cf a) { return { a.y, -a.x }; } // a * (-j)
+GR4PM_HD float cnorm(cf a) { return a.x * a.x + a.y * a.y; }
+
+constexpr int kFftN = 2048;
+constexpr int kLanes = 64;
+constexpr int kPtsPerLane = 32;
+// LDS footprint of one wave's exchange buffer, in complex items (see row strides below)
+constexpr int kS1 = 136; // FFT-1 exchange 1: 16 rows [k1] of 128 (+8 pad)
+constexpr int kS2 = 18;  // FFT-1 exchange 2: 128 rows [k1][m] of 16 (+2 pad)
+constexpr int kSA = 17;  // FFT-2 exchange A: 128 rows [ka][m] of 16 (+1 pad)
+constexpr int kSB = 18;  // FFT-2 exchange B: 128 rows [k2][ka] of 16 (+2 pad)
+constexpr int kExchangeItems = 128 * 18; // 2304 complex = 18 KiB
+
+// ---- small DFTs, forward sign, natural-order output, everything in registers ----
+GR4PM_HD void dft4(cf& a0, cf& a1, cf& a2, cf& a3)
+{
+    const cf t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = mul_mj(a1 - a3);
+    a0 = t0 + t2;
+    a1 = t1 + t3;
+    a2 = t0 - t2;
+    a3 = t1 - t3;
+}
+GR4PM_HD void dft8(cf* v)
+{
+    constexpr float c = 0.70710678118654752440f;
+    dft4(v[0], v[2], v[4], v[6]);
+    dft4(v[1], v[3], v[5], v[7]);
+    const cf e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+    const cf o0 = v[1];
+    const cf o1 = { c * (v[3].x + v[3].y), c * (v[3].y - v[3].x) };  // * W8^1
+    const cf o2 = mul_mj(v[5]);                                      // * W8^2
+    const cf o3 = { c * (v[7].y - v[7].x), -c * (v[7].x + v[7].y) }; // * W8^3
+    v[0] = e0 + o0;
+    v[1] = e1 + o1;
+    v[2] = e2 + o2;
+    v[3] = e3 + o3;
+    v[4] = e0 - o0;
+    v[5] = e1 - o1;
+    v[6] = e2 - o2;
+    v[7] = e3 - o3;
+}
+GR4PM_HD void dft16(cf* v)
+{
+    constexpr float c8 = 0.70710678118654752440f;
+    constexpr float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f; // pi/8
+    cf e[8], o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        e[i] = v[2 * i];
+        o[i] = v[2 * i + 1];
+    }
+    dft8(e);
+    dft8(o);
+    // o[k] *= W16^k = cos(pi k/8) - j sin(pi k/8)
+    o[1] = cmul(o[1], cf{ c1, -s1 });
+    o[2] = cf{ c8 * (o[2].x + o[2].y), c8 * (o[2].y - o[2].x) };
+    o[3] = cmul(o[3], cf{ s1, -c1 });
+    o[4] = mul_mj(o[4]);
+    o[5] = cmul(o[5], cf{ -s1, -c1 });
+    o[6] = cf{ c8 * (o[6].y - o[6].x), -c8 * (o[6].x + o[6].y) };
+    o[7] = cmul(o[7], cf{ -c1, -s1 });
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        v[k] = e[k] + o[k];
+        v[k + 8] = e[k] - o[k];
+    }
+}
+
+// ======================================================================= FFT-1
+// r[2*n1 + e] = x[2*lane + e + 128*n1] on entry.
+// tw: tw[k] = exp(-j 2 pi k / 2048), k < 2048.
+GR4PM_HD void fft1_pass1(int lane, cf* r, const cf* tw)
+{
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        cf v[16];
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) v[n1] = r[2 * n1 + e];
+        dft16(v);
+        const int n2 = 2 * lane + e;
+        r[e] = v[0];
+#pragma unroll
+        for (int k1 = 1; k1 < 16; ++k1) r[2 * k1 + e] = cmul(v[k1], tw[n2 * k1]);
+    }
+}
+GR4PM_HD void fft1_store1(int lane, const cf* r, cf* lds)
+{
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) {
+        lds[k1 * kS1 + 2 * lane] = r[2 * k1];
+        lds[k1 * kS1 + 2 * lane + 1] = r[2 * k1 + 1];
+    }
+}
+GR4PM_HD void fft1_load2(int lane, cf* r, const cf* lds)
+{
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int c = lane + 64 * q, k1 = c >> 3, m = c & 7;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) r[16 * q + i] = lds[k1 * kS1 + m + 8 * i];
+    }
+}
+GR4PM_HD void fft1_pass2(int lane, cf* r, const cf* tw)
+{
+    const int m = lane & 7;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        dft16(r + 16 * q);
+#pragma unroll
+        for (int k2 = 1; k2 < 16; ++k2) r[16 * q + k2] = cmul(r[16 * q + k2], tw[16 * m * k2]);
+    }
+}
+GR4PM_HD void fft1_store2(int lane, const cf* r, cf* lds)
+{
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int c = lane + 64 * q; // row = k1*8 + m = c
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) lds[c * kS2 + k2] = r[16 * q + k2];
+    }
+}
+GR4PM_HD void fft1_load3(int lane, cf* r, const cf* lds)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = lane + 64 * q, k1 = c >> 4, k2 = c & 15;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) r[8 * q + m] = lds[(k1 * 8 + m) * kS2 + k2];
+    }
+}
+// on exit r[8*q + k3] = X[k1 + 16*k2 + 256*k3], (k1, k2) = ((lane + 64 q) / 16, lane % 16)
+GR4PM_HD void fft1_pass3(cf* r)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dft8(r + 8 * q);
+}
+// index of the spectrum bin held in r[j] after FFT-1 (== input index expected by FFT-2)
+GR4PM_HD int fft1_out_index(int lane, int j)
+{
+    const int q = j >> 3, k3 = j & 7;
+    return (lane >> 4) + 4 * q + 16 * (lane & 15) + 256 * k3;
+}
+
+// ======================================================================= FFT-2
+// r[8*q + n1] = P[n2 + 256*n1], n2 = (lane/16 + 4q) + 16*(lane%16) on entry.
+GR4PM_HD void fft2_passA(int lane, cf* r, const cf* tw)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        dft8(r + 8 * q);
+        const int n2 = (lane >> 4) + 4 * q + 16 * (lane & 15);
+#pragma unroll
+        for (int ka = 1; ka < 8; ++ka) r[8 * q + ka] = cmul(r[8 * q + ka], tw[n2 * ka]);
+    }
+}
+GR4PM_HD void fft2_storeA(int lane, const cf* r, cf* lds)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int m = (lane >> 4) + 4 * q, i = lane & 15;
+#pragma unroll
+        for (int ka = 0; ka < 8; ++ka) lds[(ka * 16 + m) * kSA + i] = r[8 * q + ka];
+    }
+}
+GR4PM_HD void fft2_loadB(int lane, cf* r, const cf* lds)
+{
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int c = lane + 64 * q; // row = ka*16 + m = c
+#pragma unroll
+        for (int i = 0; i < 16; ++i) r[16 * q + i] = lds[c * kSA + i];
+    }
+}
+GR4PM_HD void fft2_passB(int lane, cf* r, const cf* tw)
+{
+    const int m = lane & 15;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        dft16(r + 16 * q);
+#pragma unroll
+        for (int k2 = 1; k2 < 16; ++k2) r[16 * q + k2] = cmul(r[16 * q + k2], tw[8 * m * k2]);
+    }
+}
+GR4PM_HD void fft2_storeB(int lane, const cf* r, cf* lds)
+{
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int c = lane + 64 * q, ka = c >> 4, m = c & 15;
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) lds[(k2 * 8 + ka) * kSB + m] = r[16 * q + k2];
+    }
+}
+GR4PM_HD void fft2_loadC(int lane, cf* r, const cf* lds)
+{
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int c = lane + 64 * q; // row = k2*8 + ka = c
+#pragma unroll
+        for (int m = 0; m < 16; ++m) r[16 * q + m] = lds[c * kSB + m];
+    }
+}
+// on exit r[16*q + k3] = C[lane + 64*q + 128*k3]
+GR4PM_HD void fft2_passC(cf* r)
+{
+#pragma unroll
+    for (int q = 0; q < 2; ++q) dft16(r + 16 * q);
+}
+GR4PM_HD int fft2_out_index(int lane, int j)
+{
+    const int q = j >> 4, k3 = j & 15;
+    return lane + 64 * q + 128 * k3;
+}
+
+} // namespace gr4pm

@@ -1,0 +1,1361 @@
+// stream_blocks.hip -- the sample-rate / symbol-rate blocks around the correlator:
+//   Rotator, CoarseFrequencyCorrection, CostasLoop, SyncwordWipeoff, SyncwordDetectionFilter,
+//   InterpolatingFirFilter, SymbolFilter, PfbArbResampler
+// (reference headers cited at each entry point; paths relative to
+//  /root/reference/blocks/include/gnuradio-4.0/packet-modem/).
+//
+// This translation unit is compiled with -ffp-contract=off: the reference evaluates every
+// product and sum separately (baseline x86-64, std::inner_product / std::complex), and the
+// FIR outputs here are bit-exact with that order.
+//
+// Pattern shared by all blocks: tags are sparse, so the tag-driven control flow of the
+// reference (which is per-chunk C++ on the CPU) is replayed on the host over the TAG LIST
+// only -- never over samples -- and turned into a small table of segments/runs; the kernels
+// then process every sample / symbol of the call in parallel from that table.  Recurrences
+// whose float rounding makes them order dependent (rotator phasor, Costas PLL, resampler
+// phase accumulator) run serially per independent segment (one lane each).
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <deque>
+#include <vector>
+
+#include "common.hpp"
+
+namespace gr4pm {
+namespace {
+
+struct cf {
+    float x, y;
+};
+__host__ __device__ __forceinline__ cf cmul(cf a, cf b)
+{
+    return { a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x };
+}
+__host__ __device__ __forceinline__ cf cadd(cf a, cf b) { return { a.x + b.x, a.y + b.y }; }
+__host__ __device__ __forceinline__ cf fmulc(float t, cf z) { return { t * z.x, t * z.y }; }
+
+// std::abs(std::complex<float>) == hypotf; glibc evaluates it as
+// (float)sqrt((double)x*x + (double)y*y), reproduced here with IEEE double ops.
+__device__ __forceinline__ float hypot_like_glibc(float x, float y)
+{
+    const double dx = x, dy = y;
+    return static_cast<float>(sqrt(dx * dx + dy * dy));
+}
+
+size_t bit_ceil_sz(size_t v)
+{
+    size_t c = 1;
+    while (c < v) c <<= 1;
+    return c;
+}
+
+// =====================================================================================
+// Rotator (rotator.hpp:44-65) and CoarseFrequencyCorrection
+// (coarse_frequency_correction.hpp:50-98): y = x * e; e *= e_incr; renormalise every 512.
+// =====================================================================================
+struct RotState {
+    cf exp, incr;
+    unsigned counter;
+    unsigned pad;
+};
+struct RotSeg {
+    unsigned long long start; // offset inside the channel row
+    unsigned long long len;
+    unsigned channel;
+    unsigned ck0;  // first checkpoint slot of this segment
+    int mode;      // 0 continue from state[channel]; 1 set_freq: (exp0, incr)
+    int last;      // writes state[channel] back
+    cf exp0, incr;
+};
+constexpr unsigned kRotChunk = 8; // samples per checkpoint
+
+// serial: one lane per segment, phasor checkpoints every kRotChunk samples
+__global__ void k_rot_checkpoints(const RotSeg* __restrict__ segs, unsigned n_segs,
+                                  RotState* __restrict__ state, cf* __restrict__ ck,
+                                  cf* __restrict__ seg_incr, unsigned* __restrict__ seg_counter0)
+{
+    const unsigned s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_segs) return;
+    const RotSeg g = segs[s];
+    cf e, inc;
+    unsigned counter;
+    if (g.mode == 0) {
+        const RotState st = state[g.channel];
+        e = st.exp;
+        inc = st.incr;
+        counter = st.counter;
+    } else {
+        e = g.exp0;
+        inc = g.incr;
+        counter = 0;
+    }
+    seg_incr[s] = inc;
+    seg_counter0[s] = counter;
+    for (unsigned long long j = 0; j < g.len; ++j) {
+        if ((j % kRotChunk) == 0) ck[g.ck0 + j / kRotChunk] = e;
+        e = cmul(e, inc);
+        if ((++counter % 512u) == 0) {
+            const float r = hypot_like_glibc(e.x, e.y);
+            e = { e.x / r, e.y / r };
+        }
+    }
+    if (g.last) {
+        RotState st;
+        st.exp = e;
+        st.incr = inc;
+        st.counter = counter;
+        st.pad = 0;
+        state[g.channel] = st;
+    }
+}
+
+// parallel: one lane per (segment, chunk of kRotChunk samples)
+__global__ void k_rot_apply(const RotSeg* __restrict__ segs, unsigned n_segs, unsigned n_chunks,
+                            const cf* __restrict__ ck, const cf* __restrict__ seg_incr,
+                            const unsigned* __restrict__ seg_counter0, const cf* __restrict__ in,
+                            cf* __restrict__ out, size_t stride)
+{
+    const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    // segment of chunk c: last s with segs[s].ck0 <= c
+    unsigned lo = 0, hi = n_segs - 1;
+    while (lo < hi) {
+        const unsigned mid = (lo + hi + 1) >> 1;
+        if (segs[mid].ck0 <= c) lo = mid;
+        else hi = mid - 1;
+    }
+    const RotSeg g = segs[lo];
+    const unsigned long long j0 = static_cast<unsigned long long>(c - g.ck0) * kRotChunk;
+    const unsigned long long j1 = min(j0 + kRotChunk, g.len);
+    cf e = ck[c];
+    const cf inc = seg_incr[lo];
+    unsigned counter = seg_counter0[lo] + static_cast<unsigned>(j0);
+    const size_t base = static_cast<size_t>(g.channel) * stride + g.start;
+    for (unsigned long long j = j0; j < j1; ++j) {
+        out[base + j] = cmul(in[base + j], e);
+        e = cmul(e, inc);
+        if ((++counter % 512u) == 0) {
+            const float r = hypot_like_glibc(e.x, e.y);
+            e = { e.x / r, e.y / r };
+        }
+    }
+}
+
+// =====================================================================================
+// CostasLoop (costas_loop.hpp:92-148): serial per segment (state fully reset by a
+// syncword_phase tag, :35-42), one lane per segment.
+// =====================================================================================
+struct CostasState {
+    float phase, freq;
+};
+struct CostasSeg {
+    unsigned long long start;
+    unsigned len;
+    unsigned channel;
+    int mode; // 0 continue, 1 set_phase(phase0)
+    int last;
+    float phase0;
+    float pad;
+};
+
+__global__ void k_costas(const CostasSeg* __restrict__ segs, unsigned n_segs,
+                         CostasState* __restrict__ state, float k1, float k2, int constellation,
+                         const cf* __restrict__ in, cf* __restrict__ out, size_t stride)
+{
+    const unsigned s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_segs) return;
+    const CostasSeg g = segs[s];
+    float phase, freq;
+    if (g.mode == 0) {
+        phase = state[g.channel].phase;
+        freq = state[g.channel].freq;
+    } else {
+        phase = g.phase0;
+        freq = 0.0f;
+    }
+    const float pi_f = 3.14159265358979323846f;
+    const size_t base = static_cast<size_t>(g.channel) * stride + g.start;
+    for (unsigned j = 0; j < g.len; ++j) {
+        // cosf/sinf of the reference are correctly rounded in all but rare cases; evaluating
+        // in double and rounding once reproduces that
+        double sd, cd;
+        sincos(static_cast<double>(phase), &sd, &cd);
+        const cf lo = { static_cast<float>(cd), -static_cast<float>(sd) };
+        const cf z = cmul(in[base + j], lo);
+        out[base + j] = z;
+        float error;
+        if (constellation == 0) error = z.y;
+        else if (constellation == 1) error = z.x * z.y;
+        else error = (z.x > 0 ? z.y : -z.y) + (z.y > 0 ? -z.x : z.x);
+        freq += k2 * error;
+        phase += k1 * error + freq;
+        if (phase >= pi_f) phase -= 2.0f * pi_f;
+        else if (phase < -pi_f) phase += 2.0f * pi_f;
+    }
+    if (g.last) {
+        state[g.channel].phase = phase;
+        state[g.channel].freq = freq;
+    }
+}
+
+// =====================================================================================
+// SyncwordWipeoff (syncword_wipeoff.hpp:66-82): copy, then x[pos] *= syncword[pos] on spans
+// =====================================================================================
+struct WipeSpan {
+    unsigned long long start; // first item of the span inside this call
+    unsigned first;           // first syncword position
+    unsigned len;
+};
+__global__ void k_wipe(const WipeSpan* __restrict__ spans, const float* __restrict__ syncword,
+                       const cf* __restrict__ in, cf* __restrict__ out)
+{
+    const WipeSpan w = spans[blockIdx.x];
+    for (unsigned i = threadIdx.x; i < w.len; i += blockDim.x)
+        out[w.start + i] = fmulc(syncword[w.first + i], in[w.start + i]);
+}
+
+template <typename T>
+__global__ void k_copy(const T* __restrict__ in, T* __restrict__ out, size_t n)
+{
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * blockDim.x)
+        out[i] = in[i];
+}
+
+// =====================================================================================
+// FIR family.  x(i) for i < 0 comes from the carried history (last `cap` items of the
+// previous calls, zero at start: the reference pre-fills its HistoryBuffer with zeros).
+// =====================================================================================
+template <typename T>
+__device__ __forceinline__ T item_at(const T* cur, const T* carry, unsigned cap, long long i)
+{
+    return i >= 0 ? cur[i] : carry[static_cast<long long>(cap) + i];
+}
+__device__ __forceinline__ cf mac(cf acc, float t, cf x) { return cadd(acc, fmulc(t, x)); }
+__device__ __forceinline__ float mac(float acc, float t, float x) { return acc + t * x; }
+__device__ __forceinline__ cf scale_item(float s, cf v) { return fmulc(s, v); }
+__device__ __forceinline__ float scale_item(float s, float v) { return s * v; }
+__device__ __forceinline__ cf zero_item(cf) { return { 0.f, 0.f }; }
+__device__ __forceinline__ float zero_item(float) { return 0.f; }
+
+template <typename T>
+__global__ void k_update_hist(const T* __restrict__ in, const T* __restrict__ carry,
+                              T* __restrict__ carry_next, unsigned cap, size_t n)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap) return;
+    carry_next[i] = item_at(in, carry, cap, static_cast<long long>(n) - cap + i);
+}
+
+// InterpolatingFirFilter::processBulk (interpolating_fir_filter.hpp:93-99): taps laid out
+// [arm][arm_stride]; out[n*L + j] = sum_m arm_j[m] * x[n - m], m ascending, acc from 0.
+template <typename T>
+__global__ void k_interp_fir(const T* __restrict__ in, const T* __restrict__ carry, unsigned cap,
+                             const float* __restrict__ taps, const unsigned* __restrict__ arm_len,
+                             unsigned arm_stride, unsigned L, size_t n_out, T* __restrict__ out)
+{
+    extern __shared__ float s_taps[];
+    for (unsigned i = threadIdx.x; i < L * arm_stride; i += blockDim.x) s_taps[i] = taps[i];
+    __syncthreads();
+    for (size_t o = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; o < n_out;
+         o += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        const long long n = static_cast<long long>(o / L);
+        const unsigned j = static_cast<unsigned>(o % L);
+        const float* arm = s_taps + j * arm_stride;
+        const unsigned len = arm_len[j];
+        T acc = zero_item(T{});
+        for (unsigned m = 0; m < len; ++m) acc = mac(acc, arm[m], item_at(in, carry, cap, n - m));
+        out[o] = acc;
+    }
+}
+
+// SymbolFilter (symbol_filter.hpp:208-214): y = scale * sum_m arm[m] * x[idx - m]
+struct SymRun {
+    long long in0;  // input index of the newest sample of the run's first output
+    unsigned out0;  // first output index
+    unsigned count; // outputs, spaced samples_per_symbol apart
+    unsigned arm;
+    float scale;
+};
+template <typename T>
+__global__ void k_symbol_filter(const T* __restrict__ in, const T* __restrict__ carry, unsigned cap,
+                                const float* __restrict__ taps, unsigned arm_size, unsigned sps,
+                                const SymRun* __restrict__ runs, unsigned n_runs, unsigned n_out,
+                                T* __restrict__ out)
+{
+    const unsigned o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n_out) return;
+    unsigned lo = 0, hi = n_runs - 1;
+    while (lo < hi) {
+        const unsigned mid = (lo + hi + 1) >> 1;
+        if (runs[mid].out0 <= o) lo = mid;
+        else hi = mid - 1;
+    }
+    const SymRun r = runs[lo];
+    const long long idx = r.in0 + static_cast<long long>(o - r.out0) * sps;
+    const float* arm = taps + static_cast<size_t>(r.arm) * arm_size;
+    T acc = zero_item(T{});
+    for (unsigned m = 0; m < arm_size; ++m) acc = mac(acc, arm[m], item_at(in, carry, cap, idx - m));
+    out[o] = scale_item(r.scale, acc);
+}
+
+// PfbArbResampler (pfb_arb_resampler.hpp:134-167).  The accumulator recurrence decides which
+// input and which arm every output uses; it is float/double rounding dependent, so one lane
+// replays it serially and writes a plan; the two inner products per output run in parallel.
+struct ArbState {
+    unsigned long long last_filter;
+    double phase_acc_d;
+    float phase_acc_f;
+    unsigned produced;
+    unsigned long long consumed;
+};
+template <typename TRate>
+__global__ void k_arb_plan(ArbState* __restrict__ st, unsigned long long n_in, unsigned out_cap,
+                           unsigned filter_size, unsigned long long decim_rate, TRate filt_rate,
+                           int* __restrict__ plan_idx, unsigned* __restrict__ plan_arm,
+                           float* __restrict__ plan_pa)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    unsigned long long last_filter = st->last_filter;
+    TRate phase_acc = sizeof(TRate) == 8 ? static_cast<TRate>(st->phase_acc_d)
+                                         : static_cast<TRate>(st->phase_acc_f);
+    unsigned long long ii = 0;
+    unsigned oi = 0;
+    while (ii < n_in && oi < out_cap) {
+        while (last_filter >= filter_size && ii < n_in) {
+            ++ii;
+            last_filter -= filter_size;
+        }
+        if (last_filter >= filter_size) break;
+        plan_idx[oi] = static_cast<int>(static_cast<long long>(ii) - 1);
+        plan_arm[oi] = static_cast<unsigned>(last_filter);
+        plan_pa[oi] = static_cast<float>(phase_acc);
+        ++oi;
+        phase_acc += filt_rate;
+        last_filter += decim_rate;
+        if (phase_acc > TRate{ 1 }) {
+            phase_acc -= TRate{ 1 };
+            ++last_filter;
+        }
+    }
+    st->last_filter = last_filter;
+    st->phase_acc_d = static_cast<double>(phase_acc);
+    st->phase_acc_f = static_cast<float>(phase_acc);
+    st->produced = oi;
+    st->consumed = ii;
+}
+__global__ void k_arb_filter(const cf* __restrict__ in, const cf* __restrict__ carry, unsigned cap,
+                             const float* __restrict__ taps, const float* __restrict__ diff_taps,
+                             unsigned arm_size, const ArbState* __restrict__ st,
+                             const int* __restrict__ plan_idx, const unsigned* __restrict__ plan_arm,
+                             const float* __restrict__ plan_pa, cf* __restrict__ out)
+{
+    const unsigned n_out = st->produced;
+    for (unsigned o = blockIdx.x * blockDim.x + threadIdx.x; o < n_out; o += gridDim.x * blockDim.x) {
+        const long long idx = plan_idx[o];
+        const float* arm = taps + static_cast<size_t>(plan_arm[o]) * arm_size;
+        const float* darm = diff_taps + static_cast<size_t>(plan_arm[o]) * arm_size;
+        cf filt = { 0.f, 0.f }, diff = { 0.f, 0.f };
+        for (unsigned m = 0; m < arm_size; ++m) filt = mac(filt, arm[m], item_at(in, carry, cap, idx - m));
+        for (unsigned m = 0; m < arm_size; ++m) diff = mac(diff, darm[m], item_at(in, carry, cap, idx - m));
+        out[o] = cadd(filt, fmulc(plan_pa[o], diff)); // :153-160
+    }
+}
+// history after the call: last cap items of (carry ++ in[0..consumed))
+__global__ void k_arb_update_hist(const cf* __restrict__ in, const cf* __restrict__ carry,
+                                  cf* __restrict__ carry_next, unsigned cap,
+                                  const ArbState* __restrict__ st)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap) return;
+    carry_next[i] = item_at(in, carry, cap, static_cast<long long>(st->consumed) - cap + i);
+}
+
+template <typename T>
+gr4pm_status upload_vec(DevBuf<T>& buf, const std::vector<T>& v, hipStream_t s)
+{
+    if (buf.n < v.size()) GR4PM_TRY(buf.alloc(std::max<size_t>(v.size() * 2, 64)));
+    if (!v.empty())
+        GR4PM_HIP_TRY(hipMemcpyAsync(buf.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    return GR4PM_OK;
+}
+
+unsigned grid_for(size_t n, unsigned block, unsigned cap = 65535u * 16u)
+{
+    const size_t g = (n + block - 1) / block;
+    return static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(g, cap)));
+}
+
+} // namespace
+} // namespace gr4pm
+
+using namespace gr4pm;
+
+// ------------------------------------------------------------------------ Rotator / CFC
+struct gr4pm_rotator {
+    int mode;
+    float phase_incr;
+    size_t delay, n_channels;
+    hipStream_t stream;
+    DevBuf<RotState> state;
+    DevBuf<RotSeg> segs;
+    DevBuf<cf> ck, seg_incr;
+    DevBuf<unsigned> seg_counter0;
+    std::vector<float> next_freq;     // per channel, coarse_frequency_correction.hpp:44
+    std::vector<long> next_freq_delay; // :45
+};
+
+static gr4pm_status rotator_reset_impl(gr4pm_rotator* h)
+{
+    std::vector<RotState> st(h->n_channels);
+    for (auto& s : st) {
+        s.exp = { 1.0f, 0.0f };
+        s.counter = 0;
+        s.pad = 0;
+        if (h->mode == 0) // rotator.hpp:44-48 settingsChanged + :50-54 start
+            s.incr = { std::cos(h->phase_incr), std::sin(h->phase_incr) };
+        else
+            s.incr = { 1.0f, 0.0f };
+    }
+    GR4PM_HIP_TRY(hipMemcpyAsync(h->state.p, st.data(), st.size() * sizeof(RotState), hipMemcpyHostToDevice,
+                                 h->stream));
+    GR4PM_HIP_TRY(hipStreamSynchronize(h->stream));
+    h->next_freq.assign(h->n_channels, 0.0f);
+    h->next_freq_delay.assign(h->n_channels, 0); // :45 -> set_freq(0) on the first item
+    return GR4PM_OK;
+}
+
+extern "C" {
+
+gr4pm_status gr4pm_rotator_create(const gr4pm_rotator_params* p, gr4pm_rotator** out)
+{
+    if (!p || !out || p->n_channels == 0 || (p->mode != 0 && p->mode != 1)) return GR4PM_ERR_INVALID;
+    *out = nullptr;
+    GR4PM_TRY(require_device());
+    auto* h = new (std::nothrow) gr4pm_rotator;
+    if (!h) return GR4PM_ERR_NOMEM;
+    h->mode = p->mode;
+    h->phase_incr = p->phase_incr;
+    h->delay = p->delay;
+    h->n_channels = p->n_channels;
+    h->stream = static_cast<hipStream_t>(p->stream);
+    gr4pm_status s = h->state.alloc(h->n_channels);
+    if (s == GR4PM_OK) s = rotator_reset_impl(h);
+    if (s != GR4PM_OK) {
+        delete h;
+        return s;
+    }
+    *out = h;
+    return GR4PM_OK;
+}
+void gr4pm_rotator_destroy(gr4pm_rotator* h)
+{
+    if (!h) return;
+    (void)hipStreamSynchronize(h->stream);
+    delete h;
+}
+gr4pm_status gr4pm_rotator_reset(gr4pm_rotator* h) { return h ? rotator_reset_impl(h) : GR4PM_ERR_INVALID; }
+
+gr4pm_status gr4pm_rotator_process(gr4pm_rotator* h, const gr4pm_c64* in, size_t stride, size_t n,
+                                   gr4pm_c64* out, const gr4pm_tag* tags, const uint32_t* tag_channel,
+                                   size_t n_tags)
+{
+    if (!h || !in || !out) return GR4PM_ERR_INVALID;
+    if (n == 0) return GR4PM_OK;
+    std::vector<RotSeg> segs;
+    unsigned ck = 0;
+    for (size_t c = 0; c < h->n_channels; ++c) {
+        // set_freq events (item, freq) of this channel: coarse_frequency_correction.hpp:76-96
+        struct Ev {
+            size_t at;
+            float freq;
+        };
+        std::vector<Ev> evs;
+        bool pending = false;
+        size_t pending_at = 0;
+        float pending_freq = 0.0f;
+        if (h->mode == 1) {
+            if (h->next_freq_delay[c] >= 0) {
+                pending = true;
+                pending_at = static_cast<size_t>(h->next_freq_delay[c]);
+                pending_freq = h->next_freq[c];
+            }
+            for (size_t t = 0; t < n_tags; ++t) {
+                const size_t tc = tag_channel ? tag_channel[t] : 0;
+                if (tc != c || !(tags[t].flags & GR4PM_TAG_SYNCWORD) || tags[t].index >= n) continue;
+                const size_t i = static_cast<size_t>(tags[t].index);
+                // a countdown that has not reached zero when the next tag arrives is
+                // overwritten (:79-80 runs before the item loop of that chunk)
+                if (pending && pending_at < i) evs.push_back({ pending_at, pending_freq });
+                pending = true;
+                pending_at = i + h->delay;
+                pending_freq = static_cast<float>(tags[t].freq); // :79 cast to float
+            }
+            if (pending && pending_at < n) {
+                evs.push_back({ pending_at, pending_freq });
+                pending = false;
+            }
+            h->next_freq[c] = pending_freq;
+            h->next_freq_delay[c] = pending ? static_cast<long>(pending_at - n) : -1;
+        }
+        // pieces of this channel: [0, first event) continues the carried phasor; every event
+        // starts a piece with a fresh phasor (set_freq resets _exp and _counter, :55-58)
+        size_t pos = 0;
+        auto push = [&](size_t start, size_t end, int mode, float freq) {
+            if (end <= start) return;
+            RotSeg g{};
+            g.start = start;
+            g.len = end - start;
+            g.channel = static_cast<unsigned>(c);
+            g.ck0 = ck;
+            g.mode = mode;
+            g.last = 0;
+            if (mode == 1) { // set_freq(), :50-59 (float cos/sin of the host libm)
+                const float d = static_cast<float>(h->delay);
+                g.exp0 = { std::cos(freq * d), -std::sin(freq * d) };
+                g.incr = { std::cos(freq), -std::sin(freq) };
+            }
+            ck += static_cast<unsigned>((g.len + kRotChunk - 1) / kRotChunk);
+            segs.push_back(g);
+        };
+        for (size_t k = 0; k < evs.size(); ++k) {
+            if (evs[k].at > pos) push(pos, evs[k].at, 0, 0.0f); // only possible for k == 0
+            const size_t end = k + 1 < evs.size() ? evs[k + 1].at : n;
+            push(evs[k].at, end, 1, evs[k].freq);
+            pos = end;
+        }
+        if (pos < n) push(pos, n, 0, 0.0f);
+        segs.back().last = 1; // the channel's final piece writes the carried state
+    }
+    hipStream_t s = h->stream;
+    const unsigned n_segs = static_cast<unsigned>(segs.size());
+    GR4PM_TRY(upload_vec(h->segs, segs, s));
+    if (h->ck.n < ck) GR4PM_TRY(h->ck.alloc(static_cast<size_t>(ck) * 2));
+    if (h->seg_incr.n < n_segs) {
+        GR4PM_TRY(h->seg_incr.alloc(n_segs * 2));
+        GR4PM_TRY(h->seg_counter0.alloc(n_segs * 2));
+    }
+    hipLaunchKernelGGL(k_rot_checkpoints, dim3(grid_for(n_segs, 64)), dim3(64), 0, s, h->segs.p, n_segs,
+                       h->state.p, h->ck.p, h->seg_incr.p, h->seg_counter0.p);
+    hipLaunchKernelGGL(k_rot_apply, dim3(grid_for(ck, 256)), dim3(256), 0, s, h->segs.p, n_segs, ck, h->ck.p,
+                       h->seg_incr.p, h->seg_counter0.p, reinterpret_cast<const cf*>(in),
+                       reinterpret_cast<cf*>(out), stride);
+    GR4PM_HIP_TRY(hipGetLastError());
+    GR4PM_HIP_TRY(hipStreamSynchronize(s));
+    return GR4PM_OK;
+}
+
+} // extern "C"
+
+// ------------------------------------------------------------------------ CostasLoop
+struct gr4pm_costas_loop {
+    double loop_bandwidth;
+    int constellation;
+    float k1, k2;
+    size_t n_channels;
+    hipStream_t stream;
+    DevBuf<CostasState> state;
+    DevBuf<CostasSeg> segs;
+};
+
+static void costas_coeffs(gr4pm_costas_loop* h)
+{
+    // settingsChanged(), costas_loop.hpp:62-87
+    double gain = 1.0;
+    if (h->constellation == 2) gain = 1.41421356237309504880;
+    const double bw = h->loop_bandwidth, bw2 = bw * bw, bw3 = bw2 * bw, bw4 = bw2 * bw2;
+    const double s = std::cbrt(36.0 * bw2 +
+                               std::sqrt(3.0) * std::sqrt(432.0 * bw4 + 848.0 * bw3 + 624.0 * bw2 +
+                                                          204.0 * bw + 25.0) +
+                               36.0 * bw + 9.0);
+    const double z = -(-12.0 * bw - 6.0) / (3.0 * std::cbrt(6.0) * (2.0 * bw + 1.0) * s) +
+                     (std::cbrt(2.0) * s) / (std::cbrt(9.0) * (2.0 * bw + 1.0)) - 1.0;
+    h->k1 = static_cast<float>((1.0 - z * z) / gain);
+    h->k2 = static_cast<float>(((1.0 - z) * (1.0 - z)) / gain);
+}
+
+extern "C" {
+
+gr4pm_status gr4pm_costas_loop_create(const gr4pm_costas_loop_params* p, gr4pm_costas_loop** out)
+{
+    if (!p || !out || p->n_channels == 0 || p->constellation < 0 || p->constellation > 2)
+        return GR4PM_ERR_INVALID;
+    *out = nullptr;
+    GR4PM_TRY(require_device());
+    auto* h = new (std::nothrow) gr4pm_costas_loop;
+    if (!h) return GR4PM_ERR_NOMEM;
+    h->loop_bandwidth = p->loop_bandwidth;
+    h->constellation = p->constellation;
+    h->n_channels = p->n_channels;
+    h->stream = static_cast<hipStream_t>(p->stream);
+    costas_coeffs(h);
+    gr4pm_status s = h->state.alloc(h->n_channels);
+    if (s == GR4PM_OK) s = h->state.zero(h->stream);
+    if (s == GR4PM_OK && hipStreamSynchronize(h->stream) != hipSuccess) s = GR4PM_ERR_HIP;
+    if (s != GR4PM_OK) {
+        delete h;
+        return s;
+    }
+    *out = h;
+    return GR4PM_OK;
+}
+void gr4pm_costas_loop_destroy(gr4pm_costas_loop* h)
+{
+    if (!h) return;
+    (void)hipStreamSynchronize(h->stream);
+    delete h;
+}
+gr4pm_status gr4pm_costas_loop_reset(gr4pm_costas_loop* h)
+{
+    if (!h) return GR4PM_ERR_INVALID;
+    GR4PM_TRY(h->state.zero(h->stream));
+    GR4PM_HIP_TRY(hipStreamSynchronize(h->stream));
+    return GR4PM_OK;
+}
+void gr4pm_costas_loop_coeffs(const gr4pm_costas_loop* h, float* k1, float* k2)
+{
+    *k1 = h->k1;
+    *k2 = h->k2;
+}
+gr4pm_status gr4pm_costas_loop_set(gr4pm_costas_loop* h, double loop_bandwidth, int constellation)
+{
+    if (!h || constellation < 0 || constellation > 2) return GR4PM_ERR_INVALID;
+    h->loop_bandwidth = loop_bandwidth;
+    h->constellation = constellation;
+    costas_coeffs(h);
+    return GR4PM_OK;
+}
+
+gr4pm_status gr4pm_costas_loop_process(gr4pm_costas_loop* h, const gr4pm_c64* in, size_t stride, size_t n,
+                                       gr4pm_c64* out, const gr4pm_tag* tags, const uint32_t* tag_channel,
+                                       size_t n_tags)
+{
+    if (!h || !in || !out) return GR4PM_ERR_INVALID;
+    if (n == 0) return GR4PM_OK;
+    std::vector<CostasSeg> segs;
+    for (size_t c = 0; c < h->n_channels; ++c) {
+        size_t pos = 0;
+        int mode = 0;
+        float phase0 = 0.0f;
+        auto push = [&](size_t end) {
+            if (end <= pos) return;
+            CostasSeg g{};
+            g.start = pos;
+            g.len = static_cast<unsigned>(end - pos);
+            g.channel = static_cast<unsigned>(c);
+            g.mode = mode;
+            g.phase0 = phase0;
+            g.last = 0;
+            segs.push_back(g);
+            pos = end;
+        };
+        for (size_t t = 0; t < n_tags; ++t) {
+            const size_t tc = tag_channel ? tag_channel[t] : 0;
+            if (tc != c || !(tags[t].flags & GR4PM_TAG_SYNCWORD) || tags[t].index >= n) continue;
+            const size_t i = static_cast<size_t>(tags[t].index);
+            push(i);
+            if (i == pos) { // set_phase at the head of the chunk, costas_loop.hpp:101-106
+                mode = 1;
+                phase0 = tags[t].phase;
+            }
+        }
+        push(n);
+        if (!segs.empty() && segs.back().channel == c) segs.back().last = 1;
+    }
+    hipStream_t s = h->stream;
+    GR4PM_TRY(upload_vec(h->segs, segs, s));
+    hipLaunchKernelGGL(k_costas, dim3(grid_for(segs.size(), 64)), dim3(64), 0, s, h->segs.p,
+                       static_cast<unsigned>(segs.size()), h->state.p, h->k1, h->k2, h->constellation,
+                       reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(out), stride);
+    GR4PM_HIP_TRY(hipGetLastError());
+    GR4PM_HIP_TRY(hipStreamSynchronize(s));
+    return GR4PM_OK;
+}
+
+} // extern "C"
+
+// ------------------------------------------------------------------------ SyncwordWipeoff
+struct gr4pm_syncword_wipeoff {
+    std::vector<float> syncword;
+    hipStream_t stream;
+    DevBuf<float> d_syncword;
+    DevBuf<WipeSpan> spans;
+    bool in_syncword = false; // syncword_wipeoff.hpp:27-28
+    size_t position = 0;
+};
+
+extern "C" {
+
+gr4pm_status gr4pm_syncword_wipeoff_create(const gr4pm_syncword_wipeoff_params* p,
+                                           gr4pm_syncword_wipeoff** out)
+{
+    if (!p || !out || !p->syncword || p->n_syncword == 0) return GR4PM_ERR_INVALID;
+    *out = nullptr;
+    GR4PM_TRY(require_device());
+    auto* h = new (std::nothrow) gr4pm_syncword_wipeoff;
+    if (!h) return GR4PM_ERR_NOMEM;
+    h->syncword.assign(p->syncword, p->syncword + p->n_syncword);
+    h->stream = static_cast<hipStream_t>(p->stream);
+    gr4pm_status s = h->d_syncword.alloc(p->n_syncword);
+    if (s == GR4PM_OK) s = h->d_syncword.upload(h->syncword.data(), h->syncword.size(), h->stream);
+    if (s == GR4PM_OK && hipStreamSynchronize(h->stream) != hipSuccess) s = GR4PM_ERR_HIP;
+    if (s != GR4PM_OK) {
+        delete h;
+        return s;
+    }
+    *out = h;
+    return GR4PM_OK;
+}
+void gr4pm_syncword_wipeoff_destroy(gr4pm_syncword_wipeoff* h)
+{
+    if (!h) return;
+    (void)hipStreamSynchronize(h->stream);
+    delete h;
+}
+gr4pm_status gr4pm_syncword_wipeoff_reset(gr4pm_syncword_wipeoff* h)
+{
+    if (!h) return GR4PM_ERR_INVALID;
+    h->in_syncword = false;
+    h->position = 0;
+    return GR4PM_OK;
+}
+
+gr4pm_status gr4pm_syncword_wipeoff_process(gr4pm_syncword_wipeoff* h, const gr4pm_c64* in, size_t n,
+                                            gr4pm_c64* out, const gr4pm_tag* tags, size_t n_tags)
+{
+    if (!h || !in || !out) return GR4PM_ERR_INVALID;
+    if (n == 0) return GR4PM_OK;
+    // replay syncword_wipeoff.hpp:53-75 over the tag list
+    std::vector<WipeSpan> spans;
+    size_t pos = 0, t = 0;
+    const size_t L = h->syncword.size();
+    while (pos < n) {
+        while (t < n_tags && tags[t].index < pos) ++t;
+        const bool has_tag = t < n_tags && tags[t].index == pos && (tags[t].flags & GR4PM_TAG_SYNCWORD);
+        if (!h->in_syncword && has_tag) {
+            h->in_syncword = true;
+            h->position = 0;
+        }
+        size_t end = n;
+        for (size_t u = t; u < n_tags; ++u)
+            if (tags[u].index > pos) {
+                end = std::min<size_t>(end, tags[u].index);
+                break;
+            }
+        if (h->in_syncword) {
+            const size_t m = std::min(end - pos, L - h->position);
+            spans.push_back({ pos, static_cast<unsigned>(h->position), static_cast<unsigned>(m) });
+            h->position += m;
+            if (h->position == L) h->in_syncword = false;
+        }
+        pos = end;
+        if (t < n_tags && tags[t].index < pos) ++t;
+    }
+    hipStream_t s = h->stream;
+    hipLaunchKernelGGL(k_copy<cf>, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s,
+                       reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(out), n);
+    if (!spans.empty()) {
+        GR4PM_TRY(upload_vec(h->spans, spans, s));
+        hipLaunchKernelGGL(k_wipe, dim3(static_cast<unsigned>(spans.size())), dim3(64), 0, s, h->spans.p,
+                           h->d_syncword.p, reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(out));
+    }
+    GR4PM_HIP_TRY(hipGetLastError());
+    GR4PM_HIP_TRY(hipStreamSynchronize(s));
+    return GR4PM_OK;
+}
+
+} // extern "C"
+
+// ------------------------------------------------------------------ SyncwordDetectionFilter
+struct gr4pm_syncword_detection_filter {
+    size_t sps, syncword_size, header_size, allowed_margin = 16; // :44-47
+    hipStream_t stream;
+    bool in_packet = false; // :35-37
+    size_t position = 0, block_until = 0;
+};
+
+extern "C" {
+
+gr4pm_status gr4pm_syncword_detection_filter_create(const gr4pm_syncword_detection_filter_params* p,
+                                                    gr4pm_syncword_detection_filter** out)
+{
+    if (!p || !out) return GR4PM_ERR_INVALID;
+    *out = nullptr;
+    GR4PM_TRY(require_device());
+    auto* h = new (std::nothrow) gr4pm_syncword_detection_filter;
+    if (!h) return GR4PM_ERR_NOMEM;
+    h->sps = p->samples_per_symbol;
+    h->syncword_size = p->syncword_size;
+    h->header_size = p->header_size;
+    h->stream = static_cast<hipStream_t>(p->stream);
+    *out = h;
+    return GR4PM_OK;
+}
+void gr4pm_syncword_detection_filter_destroy(gr4pm_syncword_detection_filter* h) { delete h; }
+gr4pm_status gr4pm_syncword_detection_filter_reset(gr4pm_syncword_detection_filter* h)
+{
+    if (!h) return GR4PM_ERR_INVALID;
+    h->in_packet = false; // start(), :52
+    return GR4PM_OK;
+}
+
+gr4pm_status gr4pm_syncword_detection_filter_process(gr4pm_syncword_detection_filter* h, const gr4pm_c64* in,
+                                                     size_t n_in, gr4pm_c64* out, size_t out_cap,
+                                                     int head_tag_flags, const gr4pm_header_msg* headers,
+                                                     size_t n_headers, size_t n_ignored, size_t* consumed_,
+                                                     size_t* headers_consumed, size_t* ignored_consumed,
+                                                     int* tag_out_flags)
+{
+    if (!h || !consumed_ || !headers_consumed || !ignored_consumed || !tag_out_flags) return GR4PM_ERR_INVALID;
+    *consumed_ = *headers_consumed = *ignored_consumed = 0;
+    *tag_out_flags = 0;
+    auto copy = [&](size_t off, size_t n) -> gr4pm_status {
+        if (n == 0) return GR4PM_OK;
+        GR4PM_HIP_TRY(hipMemcpyAsync(out + off, in + off, n * sizeof(gr4pm_c64), hipMemcpyDeviceToDevice,
+                                     h->stream));
+        return GR4PM_OK;
+    };
+    if (head_tag_flags) { // :75-105
+        int of = 0;
+        bool new_in_packet = false;
+        if ((head_tag_flags & GR4PM_TAG_SYNCWORD) && !h->in_packet) {
+            new_in_packet = true;
+            of |= GR4PM_TAG_SYNCWORD;
+        }
+        if (head_tag_flags & GR4PM_TAG_OTHER) of |= GR4PM_TAG_OTHER;
+        if (new_in_packet) {
+            h->in_packet = true;
+            h->position = 0;
+            h->block_until = 0;
+        }
+        *tag_out_flags = of;
+    }
+    if (!h->in_packet) { // :107-130
+        const size_t n = std::min(n_in, out_cap);
+        GR4PM_TRY(copy(0, n));
+        *consumed_ = n;
+        GR4PM_HIP_TRY(hipStreamSynchronize(h->stream));
+        return GR4PM_OK;
+    }
+    if (h->block_until == 0 && n_headers > 0) { // :134-153
+        *headers_consumed = 1;
+        if (headers[0].invalid_header) {
+            h->block_until = 1;
+        } else {
+            if (headers[0].packet_length == 0) {
+                set_error("received packet_length = 0"); // :143-145
+                return GR4PM_ERR_INVALID;
+            }
+            const size_t payload_symbols = (headers[0].packet_length + 4) * 4;
+            h->block_until = h->sps * (h->header_size + h->syncword_size - h->allowed_margin + payload_symbols);
+        }
+    }
+    if (h->block_until == 0 && n_ignored > 0) { // :157-160
+        *ignored_consumed = 1;
+        h->block_until = 1;
+    }
+    size_t consumed = 0;
+    const size_t allowed = h->sps * (h->syncword_size + h->header_size + h->allowed_margin);
+    if (h->position < allowed) { // :166-172
+        const size_t n = std::min({ n_in, out_cap, allowed - h->position });
+        GR4PM_TRY(copy(0, n));
+        h->position += n;
+        consumed = n;
+    }
+    if (h->position >= allowed && h->block_until != 0) { // :174-185
+        const size_t n = std::min(n_in, out_cap) - consumed;
+        GR4PM_TRY(copy(consumed, n));
+        h->position += n;
+        consumed += n;
+        if (h->position >= h->block_until) h->in_packet = false;
+    }
+    *consumed_ = consumed;
+    GR4PM_HIP_TRY(hipStreamSynchronize(h->stream));
+    return GR4PM_OK;
+}
+
+} // extern "C"
+
+// ------------------------------------------------------------------ InterpolatingFirFilter
+struct gr4pm_interp_fir {
+    size_t L, n_taps;
+    int item_kind;
+    unsigned cap, arm_stride;
+    hipStream_t stream;
+    DevBuf<float> taps;
+    DevBuf<unsigned> arm_len;
+    DevBuf<char> carry[2];
+    int cur = 0;
+};
+
+template <typename T>
+static gr4pm_status interp_fir_run(gr4pm_interp_fir* h, const void* in, size_t n_in, void* out)
+{
+    hipStream_t s = h->stream;
+    const size_t n_out = n_in * h->L;
+    const T* carry = reinterpret_cast<const T*>(h->carry[h->cur].p);
+    T* carry_next = reinterpret_cast<T*>(h->carry[h->cur ^ 1].p);
+    hipLaunchKernelGGL(k_interp_fir<T>, dim3(grid_for(n_out, 256, 16384)), dim3(256),
+                       h->L * h->arm_stride * sizeof(float), s, static_cast<const T*>(in), carry, h->cap,
+                       h->taps.p, h->arm_len.p, h->arm_stride, static_cast<unsigned>(h->L), n_out,
+                       static_cast<T*>(out));
+    hipLaunchKernelGGL(k_update_hist<T>, dim3((h->cap + 63) / 64), dim3(64), 0, s, static_cast<const T*>(in),
+                       carry, carry_next, h->cap, n_in);
+    GR4PM_HIP_TRY(hipGetLastError());
+    GR4PM_HIP_TRY(hipStreamSynchronize(s));
+    h->cur ^= 1;
+    return GR4PM_OK;
+}
+
+extern "C" {
+
+gr4pm_status gr4pm_interp_fir_create(const gr4pm_interp_fir_params* p, gr4pm_interp_fir** out)
+{
+    if (!p || !out || !p->taps) return GR4PM_ERR_INVALID;
+    *out = nullptr;
+    if (p->interpolation == 0) { // interpolating_fir_filter.hpp:45-47
+        set_error("interpolation cannot be zero");
+        return GR4PM_ERR_INVALID;
+    }
+    GR4PM_TRY(require_device());
+    auto* h = new (std::nothrow) gr4pm_interp_fir;
+    if (!h) return GR4PM_ERR_NOMEM;
+    h->L = p->interpolation;
+    h->n_taps = p->n_taps;
+    h->item_kind = p->item_kind;
+    h->stream = static_cast<hipStream_t>(p->stream);
+    const size_t arm_max = (p->n_taps + h->L - 1) / h->L;
+    h->arm_stride = static_cast<unsigned>(std::max<size_t>(arm_max, 1));
+    h->cap = static_cast<unsigned>(bit_ceil_sz(std::max<size_t>(arm_max, 1))); // :63-64
+    std::vector<float> taps(h->L * h->arm_stride, 0.0f);
+    std::vector<unsigned> arm_len(h->L, 0);
+    for (size_t j = 0; j < h->L; ++j)
+        for (size_t k = j; k < p->n_taps; k += h->L) taps[j * h->arm_stride + arm_len[j]++] = p->taps[k]; // :54-60
+    const size_t isz = p->item_kind == 0 ? sizeof(cf) : sizeof(float);
+    gr4pm_status s = h->taps.alloc(taps.size());
+    if (s == GR4PM_OK) s = h->arm_len.alloc(arm_len.size());
+    for (int i = 0; i < 2 && s == GR4PM_OK; ++i) {
+        s = h->carry[i].alloc(h->cap * isz);
+        if (s == GR4PM_OK) s = h->carry[i].zero(h->stream);
+    }
+    if (s == GR4PM_OK) s = h->taps.upload(taps.data(), taps.size(), h->stream);
+    if (s == GR4PM_OK) s = h->arm_len.upload(arm_len.data(), arm_len.size(), h->stream);
+    if (s == GR4PM_OK && hipStreamSynchronize(h->stream) != hipSuccess) s = GR4PM_ERR_HIP;
+    if (s != GR4PM_OK) {
+        delete h;
+        return s;
+    }
+    *out = h;
+    return GR4PM_OK;
+}
+void gr4pm_interp_fir_destroy(gr4pm_interp_fir* h)
+{
+    if (!h) return;
+    (void)hipStreamSynchronize(h->stream);
+    delete h;
+}
+gr4pm_status gr4pm_interp_fir_reset(gr4pm_interp_fir* h)
+{
+    if (!h) return GR4PM_ERR_INVALID;
+    for (int i = 0; i < 2; ++i) GR4PM_TRY(h->carry[i].zero(h->stream));
+    GR4PM_HIP_TRY(hipStreamSynchronize(h->stream));
+    return GR4PM_OK;
+}
+gr4pm_status gr4pm_interp_fir_process(gr4pm_interp_fir* h, const void* in, size_t n_in, void* out)
+{
+    if (!h || !in || !out) return GR4PM_ERR_INVALID;
+    if (n_in == 0) return GR4PM_OK;
+    return h->item_kind == 0 ? interp_fir_run<cf>(h, in, n_in, out) : interp_fir_run<float>(h, in, n_in, out);
+}
+
+} // extern "C"
+
+// ------------------------------------------------------------------ SymbolFilter
+struct SymQueued {
+    long value; // gr::Tag::index as counted down in symbol_filter.hpp:183-185,235-237
+    gr4pm_tag tag;
+};
+struct gr4pm_symbol_filter {
+    size_t sps, num_arms, delay, arm_size;
+    int item_kind;
+    unsigned cap;
+    hipStream_t stream;
+    DevBuf<float> taps;
+    DevBuf<char> carry[2];
+    DevBuf<SymRun> runs;
+    int cur = 0;
+    // host replica of the tag-driven state (symbol_filter.hpp:44-50)
+    size_t clock_phase = 0, reset_clock_phase = 0, pfb_arm = 0;
+    float scale = 1.0f;
+    std::deque<SymQueued> queue;
+};
+
+extern "C" {
+
+gr4pm_status gr4pm_symbol_filter_create(const gr4pm_symbol_filter_params* p, gr4pm_symbol_filter** out)
+{
+    if (!p || !out || !p->taps) return GR4PM_ERR_INVALID;
+    *out = nullptr;
+    if (p->samples_per_symbol == 0) { // symbol_filter.hpp:67-69
+        set_error("samples_per_symbol cannot be zero");
+        return GR4PM_ERR_INVALID;
+    }
+    if (p->num_arms == 0) { // :71-73
+        set_error("num_arms cannot be zero");
+        return GR4PM_ERR_INVALID;
+    }
+    GR4PM_TRY(require_device());
+    auto* h = new (std::nothrow) gr4pm_symbol_filter;
+    if (!h) return GR4PM_ERR_NOMEM;
+    h->sps = p->samples_per_symbol;
+    h->num_arms = p->num_arms;
+    h->delay = p->delay;
+    h->item_kind = p->item_kind;
+    h->stream = static_cast<hipStream_t>(p->stream);
+    // polyphase split, :84-90; inner products run over arm 0's length for every arm is NOT
+    // what the reference does: each arm has its own length (taps[k], k = j, j+arms, ...)
+    h->arm_size = (p->n_taps + p->num_arms - 1) / p->num_arms;
+    std::vector<float> taps(h->num_arms * h->arm_size, 0.0f); // shorter arms zero padded
+    for (size_t j = 0; j < h->num_arms; ++j) {
+        size_t m = 0;
+        for (size_t k = j; k < p->n_taps; k += h->num_arms) taps[j * h->arm_size + m++] = p->taps[k];
+    }
+    const size_t arm0 = (p->n_taps + p->num_arms - 1) / p->num_arms; // _taps[0].size(), :93
+    h->cap = static_cast<unsigned>(bit_ceil_sz(std::max<size_t>(arm0, 1)));
+    h->reset_clock_phase = (h->sps - (h->delay % h->sps)) % h->sps; // :106-107
+    const size_t isz = p->item_kind == 0 ? sizeof(cf) : sizeof(float);
+    gr4pm_status s = h->taps.alloc(taps.size());
+    for (int i = 0; i < 2 && s == GR4PM_OK; ++i) {
+        s = h->carry[i].alloc(h->cap * isz);
+        if (s == GR4PM_OK) s = h->carry[i].zero(h->stream);
+    }
+    if (s == GR4PM_OK) s = h->taps.upload(taps.data(), taps.size(), h->stream);
+    if (s == GR4PM_OK && hipStreamSynchronize(h->stream) != hipSuccess) s = GR4PM_ERR_HIP;
+    if (s != GR4PM_OK) {
+        delete h;
+        return s;
+    }
+    *out = h;
+    return GR4PM_OK;
+}
+void gr4pm_symbol_filter_destroy(gr4pm_symbol_filter* h)
+{
+    if (!h) return;
+    (void)hipStreamSynchronize(h->stream);
+    delete h;
+}
+gr4pm_status gr4pm_symbol_filter_reset(gr4pm_symbol_filter* h)
+{
+    if (!h) return GR4PM_ERR_INVALID;
+    h->clock_phase = 0; // start(), :110
+    return GR4PM_OK;
+}
+
+gr4pm_status gr4pm_symbol_filter_process(gr4pm_symbol_filter* h, const void* in, size_t n_in, void* out,
+                                         size_t out_cap, const gr4pm_tag* tags_in, size_t n_tags_in,
+                                         gr4pm_tag* tags_out, size_t tags_cap, size_t* n_tags_out,
+                                         size_t* consumed_, size_t* produced_)
+{
+    if (!h || !in || !out || !consumed_ || !produced_) return GR4PM_ERR_INVALID;
+    *consumed_ = *produced_ = 0;
+    if (n_tags_out) *n_tags_out = 0;
+    const size_t sps = h->sps;
+    const long half = static_cast<long>(sps / 2);
+    std::vector<SymRun> runs;
+    size_t pos = 0, produced = 0, n_pub = 0;
+    bool tag_overflow = false;
+    auto publish = [&](const gr4pm_tag& t, size_t out_index) {
+        if (tags_out && n_pub < tags_cap) {
+            tags_out[n_pub] = t;
+            tags_out[n_pub].index = out_index;
+        } else {
+            tag_overflow = true;
+        }
+        ++n_pub;
+    };
+    // main loop of :208-238 over k items without tag events; returns items actually consumed
+    auto advance = [&](size_t k) -> size_t {
+        size_t done = 0;
+        while (done < k && produced < out_cap) {
+            if (h->clock_phase >= sps) { // only reachable through the sps <= 2 corner of :182,:194
+                ++h->clock_phase;
+                if (h->clock_phase >= sps) h->clock_phase = 0;
+                for (auto& q : h->queue) --q.value;
+                ++done;
+                ++pos;
+                continue;
+            }
+            const size_t span = k - done;
+            const size_t u0 = (sps - h->clock_phase) % sps; // offset of the first output
+            size_t count = u0 < span ? (span - u0 + sps - 1) / sps : 0;
+            size_t eff = span;
+            if (produced + count > out_cap) { // :208 stops once the output is full
+                count = out_cap - produced;
+                eff = u0 + (count - 1) * sps + 1;
+            }
+            if (count > 0) {
+                SymRun r;
+                r.in0 = static_cast<long long>(pos + u0);
+                r.out0 = static_cast<unsigned>(produced);
+                r.count = static_cast<unsigned>(count);
+                r.arm = static_cast<unsigned>(h->pfb_arm);
+                r.scale = h->scale;
+                runs.push_back(r);
+                // tags leave on the first output whose countdown is below sps/2 (:218-228)
+                while (!h->queue.empty()) {
+                    const long v = h->queue.front().value;
+                    const long umin = std::max<long>(0, v - half + 1);
+                    size_t tix = 0;
+                    if (static_cast<size_t>(umin) > u0) tix = (static_cast<size_t>(umin) - u0 + sps - 1) / sps;
+                    if (tix >= count) break;
+                    publish(h->queue.front().tag, produced + tix);
+                    h->queue.pop_front();
+                }
+            }
+            h->clock_phase = (h->clock_phase + eff) % sps;
+            for (auto& q : h->queue) q.value -= static_cast<long>(eff);
+            produced += count;
+            pos += eff;
+            done += eff;
+            if (eff < span) break; // output full
+        }
+        return done;
+    };
+    size_t t = 0;
+    bool full = false;
+    while (pos < n_in && !full) {
+        while (t < n_tags_in && tags_in[t].index < pos) ++t; // tags inside consumed specials
+        if (t < n_tags_in && tags_in[t].index == pos) {
+            gr4pm_tag tag = tags_in[t++];
+            long adjust = 0;
+            if (tag.flags & GR4PM_TAG_SYNCWORD) { // :130-203
+                size_t new_cp = h->reset_clock_phase;
+                h->scale = 1.0f / tag.amplitude;
+                float time_est = tag.time_est;
+                if (time_est < 0.0f) { // :148-156
+                    new_cp = (new_cp + 1) % sps;
+                    time_est += 1.0f;
+                    tag.phase = static_cast<float>(static_cast<double>(tag.phase) - tag.freq);
+                }
+                if (h->clock_phase == 0 && new_cp == 1) { // :160-189
+                    SymRun r;
+                    r.in0 = static_cast<long long>(pos);
+                    r.out0 = static_cast<unsigned>(produced);
+                    r.count = 1;
+                    r.arm = static_cast<unsigned>(h->pfb_arm); // arm not yet updated (:199)
+                    r.scale = h->scale;
+                    runs.push_back(r);
+                    while (!h->queue.empty() && h->queue.front().value < half) {
+                        publish(h->queue.front().tag, produced);
+                        h->queue.pop_front();
+                    }
+                    ++produced;
+                    ++new_cp;
+                    for (auto& q : h->queue) --q.value;
+                    adjust = -1;
+                    ++pos;
+                } else if (h->clock_phase == 1 && new_cp == 0) { // :192-195
+                    ++pos;
+                    ++new_cp;
+                }
+                h->clock_phase = new_cp;
+                const float a = std::round(static_cast<float>(h->num_arms) * time_est);
+                h->pfb_arm = std::min(static_cast<size_t>(a), h->num_arms - 1); // :199-202
+            }
+            h->queue.push_back({ static_cast<long>(h->delay) + adjust, tag }); // :204-205
+        }
+        size_t end = n_in;
+        if (t < n_tags_in && tags_in[t].index < end) end = std::max<size_t>(pos, tags_in[t].index);
+        if (end > pos) {
+            const size_t want = end - pos;
+            if (advance(want) < want) full = true;
+        }
+        if (produced >= out_cap && pos < n_in) full = true;
+    }
+    hipStream_t s = h->stream;
+    if (!runs.empty()) {
+        GR4PM_TRY(upload_vec(h->runs, runs, s));
+        const unsigned n_out = static_cast<unsigned>(produced);
+        if (h->item_kind == 0) {
+            hipLaunchKernelGGL(k_symbol_filter<cf>, dim3((n_out + 255) / 256), dim3(256), 0, s,
+                               static_cast<const cf*>(in), reinterpret_cast<const cf*>(h->carry[h->cur].p),
+                               h->cap, h->taps.p, static_cast<unsigned>(h->arm_size), static_cast<unsigned>(sps),
+                               h->runs.p, static_cast<unsigned>(runs.size()), n_out, static_cast<cf*>(out));
+        } else {
+            hipLaunchKernelGGL(k_symbol_filter<float>, dim3((n_out + 255) / 256), dim3(256), 0, s,
+                               static_cast<const float*>(in),
+                               reinterpret_cast<const float*>(h->carry[h->cur].p), h->cap, h->taps.p,
+                               static_cast<unsigned>(h->arm_size), static_cast<unsigned>(sps), h->runs.p,
+                               static_cast<unsigned>(runs.size()), n_out, static_cast<float*>(out));
+        }
+    }
+    if (pos > 0) {
+        if (h->item_kind == 0)
+            hipLaunchKernelGGL(k_update_hist<cf>, dim3((h->cap + 63) / 64), dim3(64), 0, s,
+                               static_cast<const cf*>(in), reinterpret_cast<const cf*>(h->carry[h->cur].p),
+                               reinterpret_cast<cf*>(h->carry[h->cur ^ 1].p), h->cap, pos);
+        else
+            hipLaunchKernelGGL(k_update_hist<float>, dim3((h->cap + 63) / 64), dim3(64), 0, s,
+                               static_cast<const float*>(in),
+                               reinterpret_cast<const float*>(h->carry[h->cur].p),
+                               reinterpret_cast<float*>(h->carry[h->cur ^ 1].p), h->cap, pos);
+        h->cur ^= 1;
+    }
+    GR4PM_HIP_TRY(hipGetLastError());
+    GR4PM_HIP_TRY(hipStreamSynchronize(s));
+    *consumed_ = pos;
+    *produced_ = produced;
+    if (n_tags_out) *n_tags_out = n_pub;
+    if (tag_overflow) {
+        set_error("tags_cap too small");
+        return GR4PM_ERR_OVERFLOW;
+    }
+    return GR4PM_OK;
+}
+
+} // extern "C"
+
+// ------------------------------------------------------------------ PfbArbResampler
+struct gr4pm_pfb_arb_resampler {
+    size_t filter_size, arm_size, n_taps;
+    int rate_is_double;
+    unsigned long long decim_rate;
+    double filt_rate_d;
+    float filt_rate_f;
+    unsigned cap, plan_cap = 0;
+    hipStream_t stream;
+    DevBuf<float> taps, diff_taps;
+    DevBuf<cf> carry[2];
+    DevBuf<ArbState> st;
+    DevBuf<int> plan_idx;
+    DevBuf<unsigned> plan_arm;
+    DevBuf<float> plan_pa;
+    PinnedBuf<ArbState> st_host;
+    int cur = 0;
+};
+
+static gr4pm_status arb_reset_impl(gr4pm_pfb_arb_resampler* h)
+{
+    ArbState st{};
+    st.last_filter = (h->n_taps / 2) % h->filter_size; // pfb_arb_resampler.hpp:119
+    st.phase_acc_d = 0.0;                              // :118
+    st.phase_acc_f = 0.0f;
+    *h->st_host.p = st;
+    GR4PM_HIP_TRY(hipMemcpyAsync(h->st.p, h->st_host.p, sizeof(ArbState), hipMemcpyHostToDevice, h->stream));
+    for (int i = 0; i < 2; ++i) GR4PM_TRY(h->carry[i].zero(h->stream));
+    GR4PM_HIP_TRY(hipStreamSynchronize(h->stream));
+    return GR4PM_OK;
+}
+
+extern "C" {
+
+gr4pm_status gr4pm_pfb_arb_resampler_create(const gr4pm_pfb_arb_resampler_params* p,
+                                            gr4pm_pfb_arb_resampler** out)
+{
+    if (!p || !out) return GR4PM_ERR_INVALID;
+    *out = nullptr;
+    if (p->filter_size == 0) { // :70-72
+        set_error("filter_size cannot be 0");
+        return GR4PM_ERR_INVALID;
+    }
+    if (!p->taps || p->n_taps < 2) {
+        set_error("taps required (the default prototype is supplied by the host wrapper)");
+        return GR4PM_ERR_INVALID;
+    }
+    GR4PM_TRY(require_device());
+    auto* h = new (std::nothrow) gr4pm_pfb_arb_resampler;
+    if (!h) return GR4PM_ERR_NOMEM;
+    h->filter_size = p->filter_size;
+    h->n_taps = p->n_taps;
+    h->rate_is_double = p->rate_is_double;
+    h->stream = static_cast<hipStream_t>(p->stream);
+    h->arm_size = (p->n_taps + p->filter_size - 1) / p->filter_size; // :74
+    std::vector<float> taps(h->filter_size * h->arm_size, 0.0f), diff(h->filter_size * h->arm_size, 0.0f);
+    for (size_t j = 0; j < h->filter_size; ++j) { // :77-102
+        size_t m = 0;
+        for (size_t k = j; k < p->n_taps; k += h->filter_size) taps[j * h->arm_size + m++] = p->taps[k];
+        m = 0;
+        for (size_t k = j; k < p->n_taps - 1; k += h->filter_size)
+            diff[j * h->arm_size + m++] = p->taps[k + 1] - p->taps[k];
+    }
+    h->cap = static_cast<unsigned>(bit_ceil_sz(h->arm_size)); // :105
+    if (h->rate_is_double) { // :115-117
+        const double fr = static_cast<double>(h->filter_size) / p->rate;
+        h->decim_rate = static_cast<unsigned long long>(std::floor(fr));
+        h->filt_rate_d = fr - static_cast<double>(h->decim_rate);
+        h->filt_rate_f = 0.0f;
+    } else {
+        const float fr = static_cast<float>(h->filter_size) / static_cast<float>(p->rate);
+        h->decim_rate = static_cast<unsigned long long>(std::floor(fr));
+        h->filt_rate_f = fr - static_cast<float>(h->decim_rate);
+        h->filt_rate_d = 0.0;
+    }
+    gr4pm_status s = h->taps.alloc(taps.size());
+    if (s == GR4PM_OK) s = h->diff_taps.alloc(diff.size());
+    if (s == GR4PM_OK) s = h->st.alloc(1);
+    if (s == GR4PM_OK) s = h->st_host.alloc(1);
+    for (int i = 0; i < 2 && s == GR4PM_OK; ++i) s = h->carry[i].alloc(h->cap);
+    if (s == GR4PM_OK) s = h->taps.upload(taps.data(), taps.size(), h->stream);
+    if (s == GR4PM_OK) s = h->diff_taps.upload(diff.data(), diff.size(), h->stream);
+    if (s == GR4PM_OK && hipStreamSynchronize(h->stream) != hipSuccess) s = GR4PM_ERR_HIP;
+    if (s == GR4PM_OK) s = arb_reset_impl(h);
+    if (s != GR4PM_OK) {
+        delete h;
+        return s;
+    }
+    *out = h;
+    return GR4PM_OK;
+}
+void gr4pm_pfb_arb_resampler_destroy(gr4pm_pfb_arb_resampler* h)
+{
+    if (!h) return;
+    (void)hipStreamSynchronize(h->stream);
+    delete h;
+}
+gr4pm_status gr4pm_pfb_arb_resampler_reset(gr4pm_pfb_arb_resampler* h)
+{
+    return h ? arb_reset_impl(h) : GR4PM_ERR_INVALID;
+}
+
+gr4pm_status gr4pm_pfb_arb_resampler_process(gr4pm_pfb_arb_resampler* h, const gr4pm_c64* in, size_t n_in,
+                                             gr4pm_c64* out, size_t out_cap, size_t* consumed, size_t* produced)
+{
+    if (!h || !in || !out || !consumed || !produced) return GR4PM_ERR_INVALID;
+    *consumed = *produced = 0;
+    if (n_in == 0 || out_cap == 0) return GR4PM_OK;
+    if (out_cap > 0xffffffffull || n_in > 0x7fffffffull) return GR4PM_ERR_INVALID;
+    hipStream_t s = h->stream;
+    if (h->plan_cap < out_cap) {
+        GR4PM_TRY(h->plan_idx.alloc(out_cap));
+        GR4PM_TRY(h->plan_arm.alloc(out_cap));
+        GR4PM_TRY(h->plan_pa.alloc(out_cap));
+        h->plan_cap = static_cast<unsigned>(out_cap);
+    }
+    if (h->rate_is_double)
+        hipLaunchKernelGGL(k_arb_plan<double>, dim3(1), dim3(64), 0, s, h->st.p,
+                           static_cast<unsigned long long>(n_in), static_cast<unsigned>(out_cap),
+                           static_cast<unsigned>(h->filter_size), h->decim_rate, h->filt_rate_d, h->plan_idx.p,
+                           h->plan_arm.p, h->plan_pa.p);
+    else
+        hipLaunchKernelGGL(k_arb_plan<float>, dim3(1), dim3(64), 0, s, h->st.p,
+                           static_cast<unsigned long long>(n_in), static_cast<unsigned>(out_cap),
+                           static_cast<unsigned>(h->filter_size), h->decim_rate, h->filt_rate_f, h->plan_idx.p,
+                           h->plan_arm.p, h->plan_pa.p);
+    const cf* carry = h->carry[h->cur].p;
+    hipLaunchKernelGGL(k_arb_filter, dim3(grid_for(out_cap, 256, 8192)), dim3(256), 0, s,
+                       reinterpret_cast<const cf*>(in), carry, h->cap, h->taps.p, h->diff_taps.p,
+                       static_cast<unsigned>(h->arm_size), h->st.p, h->plan_idx.p, h->plan_arm.p, h->plan_pa.p,
+                       reinterpret_cast<cf*>(out));
+    hipLaunchKernelGGL(k_arb_update_hist, dim3((h->cap + 63) / 64), dim3(64), 0, s,
+                       reinterpret_cast<const cf*>(in), carry, h->carry[h->cur ^ 1].p, h->cap, h->st.p);
+    GR4PM_HIP_TRY(hipMemcpyAsync(h->st_host.p, h->st.p, sizeof(ArbState), hipMemcpyDeviceToHost, s));
+    GR4PM_HIP_TRY(hipGetLastError());
+    GR4PM_HIP_TRY(hipStreamSynchronize(s));
+    h->cur ^= 1;
+    *consumed = h->st_host.p->consumed;
+    *produced = h->st_host.p->produced;
+    return GR4PM_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,918 @@
+// syncword_detection.hip -- MI355X implementation of gr::packet_modem::SyncwordDetection
+// (reference: syncword_detection.hpp:32-357) behind the C ABI of include/gr4pm_hip.h.
+//
+// Data flow of one process() call (all kernels on the handle's stream, nothing leaves HBM
+// except the sparse tag records):
+//
+//   k_correlate      overlap-save correlator: one 64-lane wave per 2048-sample block; FFT,
+//                    x B templates, FFT, |.|^2, max over bins, all in registers/LDS; reads
+//                    8 B/sample, writes the 4 B/sample correlation power `zpow`
+//                    (hpp:238-252,300-313)
+//   k_candidates     B(p) = zpow[p] >= max(zpow[p+1..p+T]) as a bitmap (sliding max)
+//   k_tile_tables    for every tile and every possible entry point, where the greedy peak
+//   k_tile_entries   scan of hpp:267-298,314-317 leaves the tile; then the entry point of each
+//   k_tile_detect    tile; then the scan itself per tile + the median test (hpp:273-295)
+//   k_tags           recomputes the FFT block of every detection that is emitted in this call
+//                    and writes a raw record (correlation, neighbour bins, noise power)
+//   k_delay_copy     out[i] = in[i - (2T+1)] (hpp:318-319,342)
+//
+// Why the detector can be parallel although the reference is a sequential greedy scan:
+// with r the item after the last reset (hpp:296-297), the next item whose history is tested
+// is the FIRST p >= r with zpow[p] >= max(zpow[p+1..p+T]) ("candidate"), and the following
+// reset happens at p+T+1 (proof in DESIGN.md).  Candidates are a per-item predicate; the
+// scan is a monotone map r -> r' that composes tile by tile.
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <cstdint>
+#include <vector>
+
+#include "common.hpp"
+#include "fft2048_wave.hpp"
+
+namespace gr4pm {
+
+namespace {
+
+constexpr int kWavesPerWg = 4;
+constexpr int kMaxBins = 64;
+constexpr uint32_t kTileW = 32768; // items per detector tile
+
+struct RawTag { // device -> host
+    uint64_t pos; // absolute item index of the detection
+    float zx, zy; // correlation at pos, best bin
+    float zpow, left, right, prev, next, noise;
+    int32_t bin_idx; // 0-based
+    int32_t pad;
+};
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    // LDS operations of one wave execute in order; only the compiler must not reorder
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ void fft1_wave(int lane, cf* r, cf* lds, const cf* tw)
+{
+    fft1_pass1(lane, r, tw);
+    fft1_store1(lane, r, lds);
+    wave_lds_sync();
+    fft1_load2(lane, r, lds);
+    wave_lds_sync();
+    fft1_pass2(lane, r, tw);
+    fft1_store2(lane, r, lds);
+    wave_lds_sync();
+    fft1_load3(lane, r, lds);
+    wave_lds_sync();
+    fft1_pass3(r);
+}
+__device__ __forceinline__ void fft2_wave(int lane, cf* r, cf* lds, const cf* tw)
+{
+    fft2_passA(lane, r, tw);
+    fft2_storeA(lane, r, lds);
+    wave_lds_sync();
+    fft2_loadB(lane, r, lds);
+    wave_lds_sync();
+    fft2_passB(lane, r, tw);
+    fft2_storeB(lane, r, lds);
+    wave_lds_sync();
+    fft2_loadC(lane, r, lds);
+    wave_lds_sync();
+    fft2_passC(r);
+}
+
+// templates are stored per bin as [16][64 lanes] float4 = (T[k(lane, 2jp)], T[k(lane, 2jp+1)])
+// with k = fft1_out_index(lane, j): each lane reads its 32 values with 16 coalesced loads.
+__device__ __forceinline__ void mul_template(int lane, const cf* X, cf* r, const float4* tp)
+{
+#pragma unroll
+    for (int jp = 0; jp < 16; ++jp) {
+        const float4 t = tp[jp * 64 + lane];
+        r[2 * jp] = cmul(X[2 * jp], cf{ t.x, t.y });
+        r[2 * jp + 1] = cmul(X[2 * jp + 1], cf{ t.z, t.w });
+    }
+}
+
+// ------------------------------------------------------------------ k_correlate
+// grid (ceil(n_blocks / 4), n_channels), 256 threads = 4 independent waves.
+__global__ __launch_bounds__(256) void k_correlate(const cf* __restrict__ in, size_t in_stride,
+                                                   uint32_t n_blocks, uint32_t stride_s,
+                                                   int n_bins, const float4* __restrict__ tmpl,
+                                                   const cf* __restrict__ tw,
+                                                   float* __restrict__ zpow, size_t z_stride)
+{
+    __shared__ cf lds_all[kWavesPerWg * kExchangeItems];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint32_t b = blockIdx.x * kWavesPerWg + wave;
+    if (b >= n_blocks) return;
+    cf* lds = lds_all + wave * kExchangeItems;
+    const cf* x = in + static_cast<size_t>(blockIdx.y) * in_stride + static_cast<size_t>(b) * stride_s;
+    float* zo = zpow + static_cast<size_t>(blockIdx.y) * z_stride + static_cast<size_t>(b) * stride_s;
+
+    cf r[32];
+    if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        const float4* xp = reinterpret_cast<const float4*>(x);
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) {
+            const float4 v = xp[lane + 64 * n1];
+            r[2 * n1] = cf{ v.x, v.y };
+            r[2 * n1 + 1] = cf{ v.z, v.w };
+        }
+    } else {
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) {
+            r[2 * n1] = x[2 * lane + 128 * n1];
+            r[2 * n1 + 1] = x[2 * lane + 1 + 128 * n1];
+        }
+    }
+    fft1_wave(lane, r, lds, tw);
+    cf X[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) X[j] = r[j];
+    float zmax[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) zmax[j] = -1.0f; // hpp:303
+    for (int bin = 0; bin < n_bins; ++bin) {
+        wave_lds_sync();
+        mul_template(lane, X, r, tmpl + static_cast<size_t>(bin) * 1024); // hpp:247-249
+        fft2_wave(lane, r, lds, tw);                                      // hpp:250-251
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const float p = cnorm(r[j]); // hpp:307
+            zmax[j] = p > zmax[j] ? p : zmax[j]; // strict >, first bin wins (hpp:308)
+        }
+    }
+    // lag k <-> correlation index (N - k) mod N (hpp:300); lanes hold consecutive indices
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const int k = fft2_out_index(lane, j);
+        const uint32_t lag = static_cast<uint32_t>((kFftN - k) & (kFftN - 1));
+        if (lag < stride_s) zo[lag] = zmax[j];
+    }
+}
+
+// ------------------------------------------------------------------ k_candidates
+// B(p) for local positions [0, cnt) of a channel; z points at local position 0 and is
+// readable up to cnt + T - 1.  One workgroup handles 1024 positions.
+__global__ __launch_bounds__(256) void k_candidates(const float* __restrict__ zbase, size_t z_stride,
+                                                    uint32_t cnt, uint32_t T,
+                                                    unsigned long long* __restrict__ bitmap,
+                                                    size_t bm_stride)
+{
+    extern __shared__ float sm[];
+    const uint32_t tile0 = blockIdx.x * 1024u;
+    const float* z = zbase + static_cast<size_t>(blockIdx.y) * z_stride;
+    unsigned long long* bm = bitmap + static_cast<size_t>(blockIdx.y) * bm_stride;
+    const uint32_t span = 1024u + T;           // values needed: local [tile0, tile0 + span)
+    const uint32_t nblk = (span + 63u) / 64u;  // 64-item blocks
+    float* s = sm;                              // values
+    float* pre = sm + nblk * 64;                // inclusive prefix max inside each block
+    float* suf = pre + nblk * 64;               // inclusive suffix max inside each block
+    const uint32_t avail = cnt + T;             // readable items
+    for (uint32_t i = threadIdx.x; i < nblk * 64; i += 256) {
+        const uint32_t g = tile0 + i;
+        s[i] = (i < span && g < avail) ? z[g] : -INFINITY;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t blk = wave; blk < nblk; blk += 4) {
+        float v = s[blk * 64 + lane];
+        float p = v, q = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const float up = __shfl_up(p, d);
+            if (lane >= d) p = fmaxf(p, up);
+            const float dn = __shfl_down(q, d);
+            if (lane + d < 64) q = fmaxf(q, dn);
+        }
+        pre[blk * 64 + lane] = p;
+        suf[blk * 64 + lane] = q;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rep = 0; rep < 4; ++rep) {
+        const uint32_t i = rep * 256 + threadIdx.x; // local to tile
+        const uint32_t g = tile0 + i;
+        bool flag = false;
+        if (g < cnt) {
+            const float v = s[i];
+            float m = -INFINITY;
+            if (T > 0) {
+                const uint32_t a = i + 1, b = i + T;
+                const uint32_t ba = a >> 6, bb = b >> 6;
+                if (ba == bb) {
+                    for (uint32_t u = a; u <= b; ++u) m = fmaxf(m, s[u]);
+                } else {
+                    m = fmaxf(suf[a], pre[b]);
+                    for (uint32_t k = ba + 1; k < bb; ++k) m = fmaxf(m, pre[k * 64 + 63]);
+                }
+            }
+            flag = v >= m;
+        }
+        const unsigned long long word = __ballot(flag);
+        if (lane == 0) bm[(tile0 + rep * 256 + wave * 64) >> 6] = word;
+    }
+}
+
+// first set bit at local position >= r and < hi, or hi if none
+__device__ __forceinline__ uint32_t next_candidate(const unsigned long long* bm, uint32_t r, uint32_t hi)
+{
+    if (r >= hi) return hi;
+    uint32_t w = r >> 6;
+    unsigned long long word = bm[w] & (~0ull << (r & 63));
+    const uint32_t wlast = (hi - 1) >> 6;
+    while (true) {
+        if (word) {
+            const uint32_t p = (w << 6) + static_cast<uint32_t>(__ffsll(static_cast<long long>(word)) - 1);
+            return p < hi ? p : hi;
+        }
+        if (w == wlast) return hi;
+        word = bm[++w];
+    }
+}
+
+// table[tile][e], e in [0, T]: entering tile at local lo + e, the scan leaves it wanting to
+// resume at hi + table (>= hi).  One thread per (tile, e).
+__global__ void k_tile_tables(const unsigned long long* __restrict__ bitmap, size_t bm_stride,
+                              uint32_t cnt, uint32_t T, uint32_t n_tiles,
+                              uint32_t* __restrict__ table, size_t table_stride)
+{
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t tile = blockIdx.y;
+    if (e > T) return;
+    const unsigned long long* bm = bitmap + static_cast<size_t>(blockIdx.z) * bm_stride;
+    const uint32_t lo = tile * kTileW;
+    const uint32_t hi = min(lo + kTileW, cnt);
+    uint32_t r = lo + e;
+    while (r < hi) {
+        const uint32_t p = next_candidate(bm, r, hi);
+        if (p >= hi) {
+            r = hi;
+            break;
+        }
+        r = p + T + 1;
+    }
+    table[static_cast<size_t>(blockIdx.z) * table_stride + static_cast<size_t>(tile) * (T + 1) + e] = r - hi;
+    (void)n_tiles;
+}
+
+struct ChanState {
+    unsigned long long r;        // absolute item where the greedy scan resumes
+    unsigned int det_cnt;        // pending detections
+    unsigned int rec_cnt;        // raw tag records written by the current call
+    unsigned int overflow;
+    unsigned int pad;
+};
+
+// one thread per channel: walk the tiles with the tables, record each tile's entry
+__global__ void k_tile_entries(ChanState* __restrict__ st, unsigned long long A0, uint32_t cnt,
+                               uint32_t T, uint32_t n_tiles, const uint32_t* __restrict__ table,
+                               size_t table_stride, int32_t* __restrict__ entry, int n_channels)
+{
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= n_channels) return;
+    const unsigned long long rabs = st[ch].r;
+    unsigned long long r = rabs > A0 ? rabs - A0 : 0; // local; may exceed cnt
+    for (uint32_t t = 0; t < n_tiles; ++t) {
+        const uint32_t lo = t * kTileW;
+        const uint32_t hi = min(lo + kTileW, cnt);
+        if (r >= hi) {
+            entry[ch * n_tiles + t] = -1;
+            continue;
+        }
+        const uint32_t e = r > lo ? static_cast<uint32_t>(r) - lo : 0; // <= T by construction
+        entry[ch * n_tiles + t] = static_cast<int32_t>(e);
+        r = hi + table[static_cast<size_t>(ch) * table_stride + static_cast<size_t>(t) * (T + 1) + e];
+    }
+    const unsigned long long rnew = A0 + (r > cnt ? r : cnt);
+    st[ch].r = rnew > rabs ? rnew : rabs;
+}
+
+// one wave per (tile, channel): redo the scan from the known entry and run the median test
+// of hpp:273-295 on every visited candidate.  zloc points at local position 0 of the
+// channel (and is readable T items before it).
+__global__ __launch_bounds__(64) void k_tile_detect(const unsigned long long* __restrict__ bitmap,
+                                                    size_t bm_stride, const float* __restrict__ zloc,
+                                                    size_t z_stride, unsigned long long A0,
+                                                    uint32_t cnt, uint32_t T, float power_threshold,
+                                                    uint32_t n_tiles, const int32_t* __restrict__ entry,
+                                                    ChanState* __restrict__ st,
+                                                    unsigned long long* __restrict__ det,
+                                                    uint32_t det_cap)
+{
+    const uint32_t tile = blockIdx.x, ch = blockIdx.y;
+    const int32_t e = entry[ch * n_tiles + tile];
+    if (e < 0) return;
+    const int lane = threadIdx.x;
+    const unsigned long long* bm = bitmap + static_cast<size_t>(ch) * bm_stride;
+    const float* z = zloc + static_cast<size_t>(ch) * z_stride;
+    const uint32_t lo = tile * kTileW;
+    const uint32_t hi = min(lo + kTileW, cnt);
+    uint32_t r = lo + static_cast<uint32_t>(e);
+    const uint32_t hist = 2 * T + 1;
+    while (r < hi) {
+        const uint32_t p = next_candidate(bm, r, hi);
+        if (p >= hi) break;
+        const float best = z[p];
+        const float thr = best / power_threshold; // hpp:275
+        uint32_t below = 0;
+        const long long base = static_cast<long long>(p) - static_cast<long long>(T);
+        for (uint32_t u = lane; u < hist; u += 64) below += z[base + u] < thr ? 1u : 0u;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) below += __shfl_xor(below, d);
+        if (2 * below >= hist && lane == 0) { // hpp:279
+            const unsigned int slot = atomicAdd(&st[ch].det_cnt, 1u);
+            if (slot < det_cap) det[static_cast<size_t>(ch) * det_cap + slot] = A0 + p;
+            else st[ch].overflow = 1;
+        }
+        r = p + T + 1;
+    }
+}
+
+// sample at signed offset `o` relative to the first item of this call
+__device__ __forceinline__ cf sample_at(const cf* cur, const cf* carry, uint32_t xc, long long o)
+{
+    return o >= 0 ? cur[o] : carry[static_cast<long long>(xc) + o];
+}
+
+// ------------------------------------------------------------------ k_tags
+// one wave per pending detection; emits a raw record when the tag leaves in this call, i.e.
+// pos + hist in [E0, E1).  Same arithmetic as k_correlate for the block containing pos.
+__global__ __launch_bounds__(64) void k_tags(const cf* __restrict__ in, size_t in_stride,
+                                             const cf* __restrict__ carry, size_t carry_stride,
+                                             uint32_t xc, unsigned long long E0, unsigned long long E1,
+                                             uint32_t hist, uint32_t stride_s, int n_bins,
+                                             const float4* __restrict__ tmpl, const cf* __restrict__ tw,
+                                             const float* __restrict__ zcur, size_t z_stride,
+                                             ChanState* __restrict__ st,
+                                             const unsigned long long* __restrict__ det, uint32_t det_cap,
+                                             RawTag* __restrict__ rec, uint32_t rec_cap)
+{
+    __shared__ cf lds[kExchangeItems];
+    __shared__ cf zbin[kMaxBins];
+    const uint32_t ch = blockIdx.y;
+    const uint32_t idx = blockIdx.x;
+    const uint32_t n_det = min(st[ch].det_cnt, det_cap);
+    if (idx >= n_det) return;
+    const unsigned long long pos = det[static_cast<size_t>(ch) * det_cap + idx];
+    const unsigned long long c = pos + hist;
+    if (c < E0 || c >= E1) return;
+    const int lane = threadIdx.x;
+    const unsigned long long blk = pos / stride_s;
+    const uint32_t lag = static_cast<uint32_t>(pos - blk * stride_s);
+    const long long o = static_cast<long long>(blk * stride_s) - static_cast<long long>(E0);
+    const cf* cur = in + static_cast<size_t>(ch) * in_stride;
+    const cf* car = carry + static_cast<size_t>(ch) * carry_stride;
+    cf r[32];
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+        r[2 * n1] = sample_at(cur, car, xc, o + 2 * lane + 128 * n1);
+        r[2 * n1 + 1] = sample_at(cur, car, xc, o + 2 * lane + 1 + 128 * n1);
+    }
+    fft1_wave(lane, r, lds, tw);
+    cf X[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) X[j] = r[j];
+    // noise power: bins N/4 .. 3N/4-1 == k3 in {2,3,4,5} (hpp:257-265)
+    float noise = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k3 = 2; k3 < 6; ++k3) noise += cnorm(X[8 * q + k3]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) noise += __shfl_xor(noise, d);
+    noise /= static_cast<float>(kFftN / 2) * static_cast<float>(kFftN);
+
+    const int kt = static_cast<int>((kFftN - lag) & (kFftN - 1)); // hpp:300
+    const int lane_t = kt & 63, j_t = ((kt >> 6) & 1) * 16 + (kt >> 7);
+    for (int bin = 0; bin < n_bins; ++bin) {
+        wave_lds_sync();
+        mul_template(lane, X, r, tmpl + static_cast<size_t>(bin) * 1024);
+        fft2_wave(lane, r, lds, tw);
+        cf sel = { 0.f, 0.f };
+#pragma unroll
+        for (int j = 0; j < 32; ++j)
+            if (j == j_t) sel = r[j];
+        if (lane == lane_t) zbin[bin] = sel;
+    }
+    wave_lds_sync();
+    if (lane == 0) {
+        int best = 0;
+        cf z = { 0.f, 0.f };
+        float zp = -1.0f;
+        for (int bin = 0; bin < n_bins; ++bin) { // hpp:305-313
+            const float p = cnorm(zbin[bin]);
+            if (p > zp) {
+                best = bin;
+                z = zbin[bin];
+                zp = p;
+            }
+        }
+        RawTag t;
+        t.pos = pos;
+        t.zx = z.x;
+        t.zy = z.y;
+        t.zpow = zp;
+        t.left = best > 0 ? cnorm(zbin[best - 1]) : 0.0f;          // hpp:329-333
+        t.right = best < n_bins - 1 ? cnorm(zbin[best + 1]) : 0.0f; // hpp:334-338
+        const float* z0 = zcur + static_cast<size_t>(ch) * z_stride; // z0[0] <-> item E0
+        const long long rel = static_cast<long long>(pos) - static_cast<long long>(E0);
+        t.prev = z0[rel - 1]; // hpp:322 _history[_history_size]
+        t.next = z0[rel + 1]; // hpp:323 _history[_history_size - 2]
+        t.noise = noise;
+        t.bin_idx = best;
+        t.pad = 0;
+        const unsigned int slot = atomicAdd(&st[ch].rec_cnt, 1u);
+        if (slot < rec_cap) rec[static_cast<size_t>(ch) * rec_cap + slot] = t;
+        else st[ch].overflow = 1;
+    }
+}
+
+// drop emitted detections (pos + hist < E1) from the pending list; one thread per channel
+__global__ void k_compact_pending(ChanState* __restrict__ st, unsigned long long* __restrict__ det,
+                                  uint32_t det_cap, unsigned long long E1, uint32_t hist, int n_channels)
+{
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= n_channels) return;
+    unsigned long long* d = det + static_cast<size_t>(ch) * det_cap;
+    const uint32_t n = min(st[ch].det_cnt, det_cap);
+    uint32_t w = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const unsigned long long p = d[i];
+        if (p + hist >= E1) d[w++] = p;
+    }
+    st[ch].det_cnt = w;
+}
+
+// out[i] = item (i - hist) of the stream: the 2T+1 delay of hpp:318-319,342
+__global__ __launch_bounds__(256) void k_delay_copy(const cf* __restrict__ in, size_t in_stride,
+                                                    const cf* __restrict__ carry, size_t carry_stride,
+                                                    uint32_t xc, uint32_t hist, size_t n,
+                                                    cf* __restrict__ out, size_t out_stride)
+{
+    const cf* cur = in + static_cast<size_t>(blockIdx.y) * in_stride;
+    const cf* car = carry + static_cast<size_t>(blockIdx.y) * carry_stride;
+    cf* o = out + static_cast<size_t>(blockIdx.y) * out_stride;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        o[i] = sample_at(cur, car, xc, static_cast<long long>(i) - static_cast<long long>(hist));
+    }
+}
+
+// next carry = last xc items of (carry ++ in[0..n))
+__global__ void k_update_carry(const cf* __restrict__ in, size_t in_stride, const cf* __restrict__ carry,
+                               cf* __restrict__ carry_next, size_t carry_stride, uint32_t xc, size_t n)
+{
+    const cf* cur = in + static_cast<size_t>(blockIdx.y) * in_stride;
+    const cf* car = carry + static_cast<size_t>(blockIdx.y) * carry_stride;
+    cf* nx = carry_next + static_cast<size_t>(blockIdx.y) * carry_stride;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= xc) return;
+    nx[i] = sample_at(cur, car, xc, static_cast<long long>(n) - static_cast<long long>(xc) + i);
+}
+
+// zcur head (zc items before item E0) = tail of the previous call's z buffer
+__global__ void k_update_zcarry(const float* __restrict__ zprev, float* __restrict__ zcur, size_t z_stride,
+                                uint32_t zc, size_t n_prev)
+{
+    const float* p = zprev + static_cast<size_t>(blockIdx.y) * z_stride;
+    float* c = zcur + static_cast<size_t>(blockIdx.y) * z_stride;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= zc) return;
+    c[i] = p[n_prev + i]; // prev layout: [zc carry][n_prev items]; take its last zc entries
+}
+
+// double precision radix-2 FFT for the one-time template build
+void fft_double(std::vector<std::complex<double>>& a)
+{
+    const size_t n = a.size();
+    for (size_t i = 1, j = 0; i < n; ++i) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) std::swap(a[i], a[j]);
+    }
+    for (size_t len = 2; len <= n; len <<= 1) {
+        for (size_t i = 0; i < n; i += len) {
+            for (size_t k = 0; k < len / 2; ++k) {
+                const double ang = -2.0 * M_PI * static_cast<double>(k) / static_cast<double>(len);
+                const std::complex<double> w(std::cos(ang), std::sin(ang));
+                const auto u = a[i + k], v = a[i + k + len / 2] * w;
+                a[i + k] = u + v;
+                a[i + k + len / 2] = u - v;
+            }
+        }
+    }
+}
+
+} // namespace
+} // namespace gr4pm
+
+using namespace gr4pm;
+
+struct gr4pm_syncword_detection {
+    // settings
+    size_t fft_size, sps, n_channels, max_items;
+    int min_bin, max_bin, n_bins;
+    uint64_t T;
+    float power_threshold;
+    hipStream_t stream;
+    // derived (hpp:148-164,194,236)
+    size_t L, S, hist;
+    float self_corr;
+    // geometry of carried state
+    uint32_t xc, zc;
+    size_t z_stride, bm_stride, table_stride;
+    uint32_t max_tiles, det_cap, rec_cap;
+    // device
+    DevBuf<float4> tmpl;
+    DevBuf<cf> tw;
+    DevBuf<cf> carry[2];
+    DevBuf<float> z[2];
+    DevBuf<unsigned long long> bitmap;
+    DevBuf<uint32_t> table;
+    DevBuf<int32_t> entry;
+    DevBuf<ChanState> st;
+    DevBuf<unsigned long long> det;
+    DevBuf<RawTag> rec;
+    PinnedBuf<ChanState> st_host;
+    PinnedBuf<RawTag> rec_host;
+    // stream position
+    uint64_t items_consumed = 0;
+    int cur = 0;          // which of carry[]/z[] is current
+    size_t last_done = 0; // items of the last call (for the z carry)
+};
+
+namespace {
+
+gr4pm_status sd_reset(gr4pm_syncword_detection* h)
+{
+    h->items_consumed = 0;
+    h->cur = 0;
+    h->last_done = 0;
+    for (int i = 0; i < 2; ++i) {
+        GR4PM_TRY(h->carry[i].zero(h->stream));
+        GR4PM_TRY(h->z[i].zero(h->stream));
+    }
+    GR4PM_TRY(h->st.zero(h->stream));
+    GR4PM_TRY(h->det.zero(h->stream));
+    GR4PM_HIP_TRY(hipStreamSynchronize(h->stream));
+    return GR4PM_OK;
+}
+
+// output_tag(), hpp:56-115, evaluated on the host with the C library the reference uses
+void finish_tag(const gr4pm_syncword_detection* h, const RawTag& t, uint64_t out_index, gr4pm_tag* o)
+{
+    const int freq_bin = h->min_bin + t.bin_idx;
+    const double bin_spacing = M_PI / static_cast<double>(h->L);
+    double syncword_freq = static_cast<double>(freq_bin) * bin_spacing;
+    float syncword_phase = std::arg(std::complex<float>(t.zx, t.zy));
+    float correlation_power;
+    const float pi_f = 3.14159265358979323846f;
+    if (freq_bin > h->min_bin && freq_bin < h->max_bin) {
+        const double a = t.left, b = t.zpow, c = t.right;
+        const double quad = std::clamp((c - a) / (2.0 * (2.0 * b - (a + c))), -0.5, 0.5);
+        const double delta_freq = quad * bin_spacing;
+        syncword_freq += delta_freq;
+        syncword_phase -= static_cast<float>(delta_freq * 0.5 * static_cast<double>(h->L));
+        if (syncword_phase >= pi_f) {
+            syncword_phase -= 2.0f * pi_f;
+        } else if (syncword_phase < -pi_f) {
+            syncword_phase += 2.0f * pi_f;
+        }
+        correlation_power = static_cast<float>(b + (c - a) * (c - a) / (16.0 * (b - 0.5 * (a + c))));
+    } else {
+        correlation_power = t.zpow;
+    }
+    const float amplitude =
+        std::sqrt(correlation_power) / (static_cast<float>(h->fft_size) * h->self_corr);
+    const float syncword_power = amplitude * amplitude * h->self_corr;
+    const float esn0_db =
+        10.0f * std::log10((syncword_power * static_cast<float>(h->sps)) /
+                           (t.noise * static_cast<float>(h->L)));
+    const double a = t.prev, b = t.zpow, c = t.next;
+    const float time_est =
+        static_cast<float>(std::clamp((c - a) / (2.0 * (2.0 * b - (a + c))), -0.5, 0.5));
+    o->index = out_index;
+    o->amplitude = amplitude;
+    o->phase = syncword_phase;
+    o->freq = syncword_freq;
+    o->freq_bin = freq_bin;
+    o->noise_power = t.noise;
+    o->esn0_db = esn0_db;
+    o->time_est = time_est;
+    o->flags = GR4PM_TAG_SYNCWORD;
+}
+
+gr4pm_status launch_correlate(gr4pm_syncword_detection* h, const gr4pm_c64* in, size_t in_stride,
+                              uint32_t n_blocks, float* zout)
+{
+    dim3 grid((n_blocks + kWavesPerWg - 1) / kWavesPerWg, static_cast<unsigned>(h->n_channels));
+    hipLaunchKernelGGL(k_correlate, grid, dim3(256), 0, h->stream, reinterpret_cast<const cf*>(in),
+                       in_stride, n_blocks, static_cast<uint32_t>(h->S), h->n_bins, h->tmpl.p, h->tw.p,
+                       zout, h->z_stride);
+    GR4PM_HIP_TRY(hipGetLastError());
+    return GR4PM_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_params* p,
+                                             gr4pm_syncword_detection** out)
+{
+    if (!p || !out) return GR4PM_ERR_INVALID;
+    *out = nullptr;
+    if (p->min_freq_bin > p->max_freq_bin) { // hpp:145-147
+        set_error("min_freq_bin is greater than max_freq_bin");
+        return GR4PM_ERR_INVALID;
+    }
+    if (!p->rrc_taps || !p->syncword || !p->constellation || p->n_syncword == 0 ||
+        p->n_rrc_taps == 0 || p->samples_per_symbol == 0 || p->n_channels == 0) {
+        set_error("missing setting");
+        return GR4PM_ERR_INVALID;
+    }
+    const size_t L = (p->n_syncword - 1) * p->samples_per_symbol + p->n_rrc_taps; // hpp:148-149
+    if (L > p->fft_size) { // hpp:150-152
+        set_error("fft_size too small");
+        return GR4PM_ERR_INVALID;
+    }
+    for (size_t j = 0; j < p->n_syncword; ++j)
+        if (p->syncword[j] >= p->n_constellation) {
+            set_error("syncword symbol outside constellation");
+            return GR4PM_ERR_INVALID;
+        }
+    if (p->fft_size != static_cast<size_t>(kFftN)) {
+        set_error("fft_size %zu not built (supported: 2048)", p->fft_size);
+        return GR4PM_ERR_UNSUPPORTED;
+    }
+    const int n_bins = p->max_freq_bin - p->min_freq_bin + 1;
+    if (n_bins > kMaxBins || p->time_threshold > 8192 || p->time_threshold == 0) {
+        set_error("n_bins %d (max %d) or time_threshold %llu (1..8192) not built", n_bins, kMaxBins,
+                  static_cast<unsigned long long>(p->time_threshold));
+        return GR4PM_ERR_UNSUPPORTED;
+    }
+    GR4PM_TRY(require_device());
+    auto* h = new (std::nothrow) gr4pm_syncword_detection;
+    if (!h) return GR4PM_ERR_NOMEM;
+    h->fft_size = p->fft_size;
+    h->sps = p->samples_per_symbol;
+    h->n_channels = p->n_channels;
+    h->min_bin = p->min_freq_bin;
+    h->max_bin = p->max_freq_bin;
+    h->n_bins = n_bins;
+    h->T = p->time_threshold;
+    h->power_threshold = p->power_threshold;
+    h->stream = static_cast<hipStream_t>(p->stream);
+    h->L = L;
+    h->S = p->fft_size - L + 1; // hpp:236
+    h->hist = 2 * h->T + 1;     // hpp:194
+    h->max_items = std::max(p->max_items, p->fft_size);
+
+    // start(), hpp:154-189: shaped syncword, self correlation, frequency-shifted templates
+    using c64 = std::complex<float>;
+    std::vector<c64> sw(L);
+    for (size_t j = 0; j < p->n_syncword; ++j) {
+        const gr4pm_c64 cc = p->constellation[p->syncword[j]];
+        for (size_t k = 0; k < p->n_rrc_taps; ++k) {
+            const float t = p->rrc_taps[k];
+            sw[j * h->sps + k] += c64(cc.re * t, cc.im * t); // complex * float, hpp:157-158
+        }
+    }
+    float self_corr = 0.0f;
+    for (auto x : sw) self_corr += x.real() * x.real() + x.imag() * x.imag(); // hpp:161-164
+    h->self_corr = self_corr;
+    std::vector<float4> tmpl(static_cast<size_t>(n_bins) * 1024);
+    for (int b = 0; b < n_bins; ++b) {
+        const int freq_bin = p->min_freq_bin + b;
+        double phase = 0.0;
+        const double phase_incr = static_cast<double>(freq_bin) * M_PI / static_cast<double>(L);
+        std::vector<std::complex<double>> a(p->fft_size);
+        for (size_t i = 0; i < L; ++i) {
+            const float c = static_cast<float>(std::cos(phase)), s = static_cast<float>(std::sin(phase));
+            const float xr = sw[i].real(), xi = sw[i].imag();
+            a[i] = { static_cast<double>(xr * c - xi * s), static_cast<double>(xr * s + xi * c) };
+            phase += phase_incr;
+            if (phase >= M_PI) { // hpp:177-181, including the `< pi` quirk
+                phase -= 2.0 * M_PI;
+            } else if (phase < M_PI) {
+                phase += 2.0 * M_PI;
+            }
+        }
+        fft_double(a);
+        // conj (hpp:185-187), rounded to float32, laid out in FFT-1's output distribution
+        for (int lane = 0; lane < 64; ++lane)
+            for (int jp = 0; jp < 16; ++jp) {
+                const auto t0 = std::conj(a[fft1_out_index(lane, 2 * jp)]);
+                const auto t1 = std::conj(a[fft1_out_index(lane, 2 * jp + 1)]);
+                tmpl[static_cast<size_t>(b) * 1024 + jp * 64 + lane] =
+                    make_float4(static_cast<float>(t0.real()), static_cast<float>(t0.imag()),
+                                static_cast<float>(t1.real()), static_cast<float>(t1.imag()));
+            }
+    }
+    std::vector<cf> tw(kFftN);
+    for (int k = 0; k < kFftN; ++k) {
+        const double ang = -2.0 * M_PI * k / kFftN;
+        tw[k] = { static_cast<float>(std::cos(ang)), static_cast<float>(std::sin(ang)) };
+    }
+
+    h->xc = static_cast<uint32_t>(round_up(h->hist + h->S + 2, 64));
+    h->zc = static_cast<uint32_t>(round_up(2 * h->T + 2, 64));
+    h->z_stride = h->zc + round_up(h->max_items, 64) + 64;
+    const size_t max_cnt = h->max_items + h->T;
+    h->bm_stride = round_up(max_cnt, 1024) / 64 + 16;
+    h->max_tiles = static_cast<uint32_t>((max_cnt + kTileW - 1) / kTileW);
+    h->table_stride = static_cast<size_t>(h->max_tiles) * (h->T + 1);
+    h->det_cap = static_cast<uint32_t>(h->max_items / (h->T + 1) + 16);
+    h->rec_cap = h->det_cap;
+    gr4pm_status s = GR4PM_OK;
+    auto ok = [&](gr4pm_status r) {
+        if (s == GR4PM_OK) s = r;
+    };
+    ok(h->tmpl.alloc(tmpl.size()));
+    ok(h->tw.alloc(tw.size()));
+    for (int i = 0; i < 2; ++i) {
+        ok(h->carry[i].alloc(static_cast<size_t>(h->xc) * h->n_channels));
+        ok(h->z[i].alloc(h->z_stride * h->n_channels));
+    }
+    ok(h->bitmap.alloc(h->bm_stride * h->n_channels));
+    ok(h->table.alloc(h->table_stride * h->n_channels));
+    ok(h->entry.alloc(static_cast<size_t>(h->max_tiles) * h->n_channels));
+    ok(h->st.alloc(h->n_channels));
+    ok(h->det.alloc(static_cast<size_t>(h->det_cap) * h->n_channels));
+    ok(h->rec.alloc(static_cast<size_t>(h->rec_cap) * h->n_channels));
+    ok(h->st_host.alloc(h->n_channels));
+    ok(h->rec_host.alloc(static_cast<size_t>(h->rec_cap) * h->n_channels));
+    if (s == GR4PM_OK) s = h->tmpl.upload(tmpl.data(), tmpl.size(), h->stream);
+    if (s == GR4PM_OK) s = h->tw.upload(tw.data(), tw.size(), h->stream);
+    if (s == GR4PM_OK && hipStreamSynchronize(h->stream) != hipSuccess) s = GR4PM_ERR_HIP;
+    if (s == GR4PM_OK) s = sd_reset(h);
+    if (s != GR4PM_OK) {
+        delete h;
+        return s;
+    }
+    *out = h;
+    return GR4PM_OK;
+}
+
+void gr4pm_syncword_detection_destroy(gr4pm_syncword_detection* h)
+{
+    if (!h) return;
+    (void)hipStreamSynchronize(h->stream);
+    delete h;
+}
+
+gr4pm_status gr4pm_syncword_detection_reset(gr4pm_syncword_detection* h)
+{
+    return h ? sd_reset(h) : GR4PM_ERR_INVALID;
+}
+size_t gr4pm_syncword_detection_syncword_samples_size(const gr4pm_syncword_detection* h) { return h->L; }
+float gr4pm_syncword_detection_self_corr(const gr4pm_syncword_detection* h) { return h->self_corr; }
+uint64_t gr4pm_syncword_detection_items_consumed(const gr4pm_syncword_detection* h)
+{
+    return h->items_consumed;
+}
+
+gr4pm_status gr4pm_syncword_detection_correlate_only(gr4pm_syncword_detection* h, const gr4pm_c64* in,
+                                                     size_t in_stride, size_t n_in)
+{
+    if (!h || !in) return GR4PM_ERR_INVALID;
+    if (n_in < h->fft_size) return GR4PM_INSUFFICIENT_INPUT_ITEMS;
+    if (n_in > h->max_items) {
+        set_error("n_in %zu exceeds max_items %zu", n_in, h->max_items);
+        return GR4PM_ERR_INVALID;
+    }
+    const uint32_t n_blocks = static_cast<uint32_t>((n_in - h->fft_size) / h->S + 1);
+    return launch_correlate(h, in, in_stride, n_blocks, h->z[h->cur].p + h->zc);
+}
+
+gr4pm_status gr4pm_syncword_detection_process(gr4pm_syncword_detection* h, const gr4pm_c64* in,
+                                              size_t in_stride, size_t n_in, gr4pm_c64* out,
+                                              size_t out_stride, size_t* n_done, gr4pm_tag* tags,
+                                              size_t tags_cap, size_t* n_tags)
+{
+    if (!h || !in || !n_done) return GR4PM_ERR_INVALID;
+    *n_done = 0;
+    if (n_tags)
+        for (size_t c = 0; c < h->n_channels; ++c) n_tags[c] = 0;
+    if (n_in < h->fft_size) return GR4PM_INSUFFICIENT_INPUT_ITEMS; // hpp:215-227
+    if (n_in > h->max_items) {
+        set_error("n_in %zu exceeds max_items %zu", n_in, h->max_items);
+        return GR4PM_ERR_INVALID;
+    }
+    const uint32_t n_blocks = static_cast<uint32_t>((n_in - h->fft_size) / h->S + 1); // hpp:238
+    const size_t J = static_cast<size_t>(n_blocks) * h->S;
+    const uint64_t E0 = h->items_consumed, E1 = E0 + J;
+    const uint32_t T = static_cast<uint32_t>(h->T);
+    const int cur = h->cur ^ 1, prev = h->cur; // ping-pong: this call writes `cur`
+    const unsigned nch = static_cast<unsigned>(h->n_channels);
+    hipStream_t s = h->stream;
+    float* zcur = h->z[cur].p;        // [zc carry][J items] per channel
+    const cf* carry = h->carry[prev].p; // last xc items before E0
+
+    // z carry: positions E0-zc .. E0-1
+    hipLaunchKernelGGL(k_update_zcarry, dim3((h->zc + 255) / 256, nch), dim3(256), 0, s, h->z[prev].p,
+                       zcur, h->z_stride, h->zc, h->last_done);
+    GR4PM_TRY(launch_correlate(h, in, in_stride, n_blocks, zcur + h->zc));
+
+    // detector over candidate range [A0, A1)
+    const uint64_t A0 = E0 > T ? E0 - T : 0, A1 = E1 > T ? E1 - T : 0;
+    const uint32_t cnt = static_cast<uint32_t>(A1 - A0);
+    // local position 0 <-> absolute A0 <-> zcur[zc + (A0 - E0)]
+    const float* zloc = zcur + h->zc - static_cast<ptrdiff_t>(E0 - A0);
+    if (cnt > 0) {
+        const uint32_t n_wg = (cnt + 1023) / 1024;
+        const size_t smem = static_cast<size_t>((1024 + T + 63) / 64) * 64 * 3 * sizeof(float);
+        hipLaunchKernelGGL(k_candidates, dim3(n_wg, nch), dim3(256), smem, s, zloc, h->z_stride, cnt, T,
+                           h->bitmap.p, h->bm_stride);
+        const uint32_t n_tiles = (cnt + kTileW - 1) / kTileW;
+        hipLaunchKernelGGL(k_tile_tables, dim3((T + 1 + 127) / 128, n_tiles, nch), dim3(128), 0, s,
+                           h->bitmap.p, h->bm_stride, cnt, T, n_tiles, h->table.p, h->table_stride);
+        hipLaunchKernelGGL(k_tile_entries, dim3((nch + 63) / 64), dim3(64), 0, s, h->st.p,
+                           static_cast<unsigned long long>(A0), cnt, T, n_tiles, h->table.p,
+                           h->table_stride, h->entry.p, static_cast<int>(nch));
+        hipLaunchKernelGGL(k_tile_detect, dim3(n_tiles, nch), dim3(64), 0, s, h->bitmap.p, h->bm_stride,
+                           zloc, h->z_stride, static_cast<unsigned long long>(A0), cnt, T,
+                           h->power_threshold, n_tiles, h->entry.p, h->st.p, h->det.p, h->det_cap);
+    }
+    // tags leaving in this call
+    hipLaunchKernelGGL(k_tags, dim3(h->det_cap, nch), dim3(64), 0, s, reinterpret_cast<const cf*>(in),
+                       in_stride, carry, static_cast<size_t>(h->xc), h->xc,
+                       static_cast<unsigned long long>(E0), static_cast<unsigned long long>(E1),
+                       static_cast<uint32_t>(h->hist), static_cast<uint32_t>(h->S), h->n_bins, h->tmpl.p,
+                       h->tw.p, zcur + h->zc, h->z_stride, h->st.p, h->det.p, h->det_cap, h->rec.p,
+                       h->rec_cap);
+    GR4PM_HIP_TRY(hipMemcpyAsync(h->st_host.p, h->st.p, sizeof(ChanState) * nch, hipMemcpyDeviceToHost, s));
+    hipLaunchKernelGGL(k_compact_pending, dim3((nch + 63) / 64), dim3(64), 0, s, h->st.p, h->det.p,
+                       h->det_cap, static_cast<unsigned long long>(E1), static_cast<uint32_t>(h->hist),
+                       static_cast<int>(nch));
+    if (out) {
+        const unsigned gx = static_cast<unsigned>(std::min<size_t>((J + 255) / 256, 4096));
+        hipLaunchKernelGGL(k_delay_copy, dim3(gx, nch), dim3(256), 0, s, reinterpret_cast<const cf*>(in),
+                           in_stride, carry, static_cast<size_t>(h->xc), h->xc,
+                           static_cast<uint32_t>(h->hist), J, reinterpret_cast<cf*>(out), out_stride);
+    }
+    hipLaunchKernelGGL(k_update_carry, dim3((h->xc + 255) / 256, nch), dim3(256), 0, s,
+                       reinterpret_cast<const cf*>(in), in_stride, carry, h->carry[cur].p,
+                       static_cast<size_t>(h->xc), h->xc, J);
+    GR4PM_HIP_TRY(hipGetLastError());
+    GR4PM_HIP_TRY(hipStreamSynchronize(s));
+
+    // collect raw records, finish the tag arithmetic on the host, reset per-call counters
+    bool overflow = false, any = false;
+    for (unsigned c = 0; c < nch; ++c) {
+        overflow |= h->st_host.p[c].overflow != 0;
+        any |= h->st_host.p[c].rec_cnt != 0;
+    }
+    if (any) {
+        GR4PM_HIP_TRY(hipMemcpyAsync(h->rec_host.p, h->rec.p, sizeof(RawTag) * h->rec_cap * nch,
+                                     hipMemcpyDeviceToHost, s));
+        GR4PM_HIP_TRY(hipStreamSynchronize(s));
+        // zero rec_cnt (field offset inside ChanState) for the next call
+        for (unsigned c = 0; c < nch; ++c) {
+            GR4PM_HIP_TRY(hipMemsetAsync(reinterpret_cast<char*>(h->st.p + c) + offsetof(ChanState, rec_cnt),
+                                         0, sizeof(unsigned int), s));
+        }
+    }
+    h->items_consumed = E1;
+    h->cur = cur;
+    h->last_done = J;
+    *n_done = J;
+    if (overflow) {
+        set_error("detection list overflow");
+        return GR4PM_ERR_OVERFLOW;
+    }
+    gr4pm_status ret = GR4PM_OK;
+    for (unsigned c = 0; c < nch && any; ++c) {
+        const uint32_t n = std::min(h->st_host.p[c].rec_cnt, h->rec_cap);
+        RawTag* r = h->rec_host.p + static_cast<size_t>(c) * h->rec_cap;
+        std::sort(r, r + n, [](const RawTag& a, const RawTag& b) { return a.pos < b.pos; });
+        if (n_tags) n_tags[c] = n;
+        for (uint32_t i = 0; i < n; ++i) {
+            if (!tags || i >= tags_cap) {
+                ret = GR4PM_ERR_OVERFLOW;
+                break;
+            }
+            finish_tag(h, r[i], r[i].pos + h->hist - E0, &tags[static_cast<size_t>(c) * tags_cap + i]);
+        }
+    }
+    if (ret == GR4PM_ERR_OVERFLOW) set_error("tags_cap too small");
+    return ret;
+}
+
+gr4pm_status gr4pm_syncword_detection_last_zpow(gr4pm_syncword_detection* h, float* zpow, size_t stride)
+{
+    if (!h || !zpow) return GR4PM_ERR_INVALID;
+    for (size_t c = 0; c < h->n_channels; ++c) {
+        GR4PM_HIP_TRY(hipMemcpyAsync(zpow + c * stride, h->z[h->cur].p + c * h->z_stride + h->zc,
+                                     h->last_done * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    }
+    GR4PM_HIP_TRY(hipStreamSynchronize(h->stream));
+    return GR4PM_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,283 @@
+/*
+ * gr4pm_hip.h -- C ABI of the MI355X-native gr4-packet-modem RX hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch types.  The
+ * gr::Block<T> wrappers in gr4-packet-modem_amd/host/ (and the ctypes binding used by the
+ * tests) call exactly these entry points.  Each entry point cites the reference interface
+ * it replaces; paths are relative to
+ *   /root/reference/blocks/include/gnuradio-4.0/packet-modem/
+ *
+ * Conventions
+ *  - Sample pointers (`in`, `out`) are DEVICE pointers (HBM resident) unless a function
+ *    says otherwise; complex samples are interleaved float32 pairs == std::complex<float>.
+ *  - Tag arrays, message arrays, settings and counters are HOST pointers.
+ *  - Tags are passed with explicit item indices relative to in[0] of the call (the GR4
+ *    runtime presents a tag only at the head of a chunk; the wrapper passes index 0).
+ *  - One handle == one HIP stream == single-threaded use, like one gr::Block instance.
+ *  - No exceptions cross the ABI.  Negative status == what the reference block throws as
+ *    gr::exception; positive status == gr::work::Status other than OK.
+ *  - Batched handles (n_channels > 1) process independent channels laid out as
+ *    [channel][stride] in one launch; every channel has its own state.
+ */
+#ifndef GR4PM_HIP_H
+#define GR4PM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { float re, im; } gr4pm_c64;
+
+typedef enum {
+    GR4PM_OK = 0,
+    GR4PM_INSUFFICIENT_INPUT_ITEMS = 1,  /* gr::work::Status::INSUFFICIENT_INPUT_ITEMS */
+    GR4PM_INSUFFICIENT_OUTPUT_ITEMS = 2, /* gr::work::Status::INSUFFICIENT_OUTPUT_ITEMS */
+    GR4PM_ERR_INVALID = -1,              /* invalid settings (reference: throw gr::exception) */
+    GR4PM_ERR_UNSUPPORTED = -2,          /* valid in the reference, not built here yet */
+    GR4PM_ERR_HIP = -3,                  /* HIP runtime failure, see gr4pm_last_error() */
+    GR4PM_ERR_NOMEM = -4,
+    GR4PM_ERR_OVERFLOW = -5,             /* a caller-provided tag/record array was too small */
+    GR4PM_ERR_NO_DEVICE = -6             /* no HIP device: the product has no CPU fallback */
+} gr4pm_status;
+
+/* Human readable text of the last failure on the calling thread. */
+const char* gr4pm_last_error(void);
+/* Library version / build info; also proves the HIP code objects are loaded. */
+const char* gr4pm_version(void);
+/* Number of visible HIP devices (0 when none; does not create a context). */
+int gr4pm_device_count(void);
+
+/* The `syncword_*` tag set published by SyncwordDetection (syncword_detection.hpp:106-114)
+ * and consumed downstream (symbol_filter.hpp:130-156, coarse_frequency_correction.hpp:78-80,
+ * costas_loop.hpp:101-106, syncword_wipeoff.hpp:53-62). */
+typedef struct {
+    uint64_t index;    /* item index the tag is attached to */
+    float amplitude;   /* "syncword_amplitude" */
+    float phase;       /* "syncword_phase" */
+    double freq;       /* "syncword_freq" (double in the reference) */
+    int32_t freq_bin;  /* "syncword_freq_bin" */
+    float noise_power; /* "syncword_noise_power" */
+    float esn0_db;     /* "syncword_esn0_db" */
+    float time_est;    /* "syncword_time_est" */
+    int32_t flags;     /* GR4PM_TAG_* */
+} gr4pm_tag;
+#define GR4PM_TAG_SYNCWORD 1 /* carries the syncword_* keys */
+#define GR4PM_TAG_OTHER 2    /* carries other (opaque, wrapper-held) keys */
+
+/* ------------------------------------------------------------------------------------
+ * SyncwordDetection -- syncword_detection.hpp:32-357
+ *   settings  :133-141      start() :143-202      processBulk() :204-356
+ * ---------------------------------------------------------------------------------- */
+typedef struct gr4pm_syncword_detection gr4pm_syncword_detection;
+typedef struct {
+    size_t fft_size;           /* :133, default 2048 (supported here: 2048) */
+    size_t samples_per_symbol; /* :134 */
+    const float* rrc_taps;     /* :135 host */
+    size_t n_rrc_taps;
+    const uint8_t* syncword;   /* :136 host */
+    size_t n_syncword;
+    const gr4pm_c64* constellation; /* :137 host */
+    size_t n_constellation;
+    int min_freq_bin;          /* :138 */
+    int max_freq_bin;          /* :139 */
+    uint64_t time_threshold;   /* :140 */
+    float power_threshold;     /* :141 */
+    size_t n_channels;         /* independent channels per call (>= 1) */
+    size_t max_items;          /* largest n_in per channel per call (workspace sizing) */
+    void* stream;              /* hipStream_t, NULL = default stream */
+} gr4pm_syncword_detection_params;
+
+gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_params* params,
+                                             gr4pm_syncword_detection** out);
+void gr4pm_syncword_detection_destroy(gr4pm_syncword_detection* h);
+/* == start(): clears _best/_best_idx/_items_consumed/_history (:191-199) */
+gr4pm_status gr4pm_syncword_detection_reset(gr4pm_syncword_detection* h);
+/* public state the reference exposes and its tests read (test/qa_syncword_detection.cpp:101-133) */
+size_t gr4pm_syncword_detection_syncword_samples_size(const gr4pm_syncword_detection* h);
+float gr4pm_syncword_detection_self_corr(const gr4pm_syncword_detection* h);
+uint64_t gr4pm_syncword_detection_items_consumed(const gr4pm_syncword_detection* h);
+/* == processBulk().  in: [n_channels][in_stride] items, n_in valid per channel.
+ * out: [n_channels][out_stride] or NULL (skip the delayed pass-through copy when the
+ * consumer reads the input ring itself).  *n_done = items consumed == published per channel
+ * (whole strides only, :238,346-350).  tags: host [n_channels][tags_cap], n_tags: host
+ * [n_channels]; tag.index is relative to out[0] of this call.  Returns
+ * GR4PM_INSUFFICIENT_INPUT_ITEMS when n_in < fft_size (:215-227). */
+gr4pm_status gr4pm_syncword_detection_process(gr4pm_syncword_detection* h, const gr4pm_c64* in,
+                                              size_t in_stride, size_t n_in, gr4pm_c64* out,
+                                              size_t out_stride, size_t* n_done, gr4pm_tag* tags,
+                                              size_t tags_cap, size_t* n_tags);
+/* debug / measurement: copies the per-sample best-bin correlation power of the last call
+ * (device [n_channels][n_done] floats, items_consumed-relative) into `zpow` (device). */
+gr4pm_status gr4pm_syncword_detection_last_zpow(gr4pm_syncword_detection* h, float* zpow,
+                                                size_t stride);
+/* measurement hook: runs ONLY the overlap-save correlator kernel on [n_channels][in_stride]
+ * input (no detector, no copy); used by bench.py to time the dominant kernel in isolation. */
+gr4pm_status gr4pm_syncword_detection_correlate_only(gr4pm_syncword_detection* h,
+                                                     const gr4pm_c64* in, size_t in_stride,
+                                                     size_t n_in);
+
+/* ------------------------------------------------------------------------------------
+ * SyncwordDetectionFilter<T = c64> -- syncword_detection_filter.hpp:10-211
+ * One call == one processBulk() (:54-210) with the messages pending on the two async
+ * ports.  Samples are copied device-to-device; the tag gate runs on the host.
+ * ---------------------------------------------------------------------------------- */
+typedef struct gr4pm_syncword_detection_filter gr4pm_syncword_detection_filter;
+typedef struct {
+    size_t samples_per_symbol; /* :44 */
+    size_t syncword_size;      /* :45 */
+    size_t header_size;        /* :46 */
+    void* stream;
+} gr4pm_syncword_detection_filter_params;
+typedef struct {
+    uint64_t packet_length; /* "packet_length" of a parsed_header message */
+    int32_t invalid_header; /* message carries "invalid_header" */
+} gr4pm_header_msg;
+gr4pm_status gr4pm_syncword_detection_filter_create(
+    const gr4pm_syncword_detection_filter_params* params, gr4pm_syncword_detection_filter** out);
+void gr4pm_syncword_detection_filter_destroy(gr4pm_syncword_detection_filter* h);
+gr4pm_status gr4pm_syncword_detection_filter_reset(gr4pm_syncword_detection_filter* h);
+/* head_tag_flags: GR4PM_TAG_* of the tag at in[0], 0 if none.  *tag_out_flags: which key
+ * classes are published at out[0] (:82-104). */
+gr4pm_status gr4pm_syncword_detection_filter_process(
+    gr4pm_syncword_detection_filter* h, const gr4pm_c64* in, size_t n_in, gr4pm_c64* out,
+    size_t out_cap, int head_tag_flags, const gr4pm_header_msg* headers, size_t n_headers,
+    size_t n_ignored, size_t* consumed, size_t* headers_consumed, size_t* ignored_consumed,
+    int* tag_out_flags);
+
+/* ------------------------------------------------------------------------------------
+ * CoarseFrequencyCorrection<float> -- coarse_frequency_correction.hpp:20-99
+ * Rotator<float>                   -- rotator.hpp:20-65
+ * ---------------------------------------------------------------------------------- */
+typedef struct gr4pm_rotator gr4pm_rotator;
+typedef struct {
+    int mode;          /* 0: Rotator (phase_incr), 1: CoarseFrequencyCorrection (delay) */
+    float phase_incr;  /* rotator.hpp:42 */
+    size_t delay;      /* coarse_frequency_correction.hpp:43 */
+    size_t n_channels; /* independent channels, state per channel */
+    void* stream;
+} gr4pm_rotator_params;
+gr4pm_status gr4pm_rotator_create(const gr4pm_rotator_params* params, gr4pm_rotator** out);
+void gr4pm_rotator_destroy(gr4pm_rotator* h);
+gr4pm_status gr4pm_rotator_reset(gr4pm_rotator* h);
+/* Rotator: tags ignored.  CFC: every tag with GR4PM_TAG_SYNCWORD re-loads the frequency
+ * `delay` items later (:50-59,76-96).  tags: host, sorted by index, channel 0 only when
+ * n_channels == 1; for batches use tag_channel[] to address channels. */
+gr4pm_status gr4pm_rotator_process(gr4pm_rotator* h, const gr4pm_c64* in, size_t stride,
+                                   size_t n, gr4pm_c64* out, const gr4pm_tag* tags,
+                                   const uint32_t* tag_channel, size_t n_tags);
+
+/* ------------------------------------------------------------------------------------
+ * CostasLoop<float,float> -- costas_loop.hpp:15-149
+ * ---------------------------------------------------------------------------------- */
+typedef struct gr4pm_costas_loop gr4pm_costas_loop;
+typedef struct {
+    double loop_bandwidth; /* :48 */
+    int constellation;     /* constellation.hpp: 0 PILOT, 1 BPSK, 2 QPSK */
+    size_t n_channels;
+    void* stream;
+} gr4pm_costas_loop_params;
+gr4pm_status gr4pm_costas_loop_create(const gr4pm_costas_loop_params* params,
+                                      gr4pm_costas_loop** out);
+void gr4pm_costas_loop_destroy(gr4pm_costas_loop* h);
+gr4pm_status gr4pm_costas_loop_reset(gr4pm_costas_loop* h);
+void gr4pm_costas_loop_coeffs(const gr4pm_costas_loop* h, float* k1, float* k2);
+/* settingsChanged() (:52-88): new constellation / loop bandwidth from tags or messages */
+gr4pm_status gr4pm_costas_loop_set(gr4pm_costas_loop* h, double loop_bandwidth,
+                                   int constellation);
+gr4pm_status gr4pm_costas_loop_process(gr4pm_costas_loop* h, const gr4pm_c64* in, size_t stride,
+                                       size_t n, gr4pm_c64* out, const gr4pm_tag* tags,
+                                       const uint32_t* tag_channel, size_t n_tags);
+
+/* ------------------------------------------------------------------------------------
+ * SyncwordWipeoff<c64,float> -- syncword_wipeoff.hpp:12-91
+ * ---------------------------------------------------------------------------------- */
+typedef struct gr4pm_syncword_wipeoff gr4pm_syncword_wipeoff;
+typedef struct {
+    const float* syncword; /* :37 host */
+    size_t n_syncword;
+    void* stream;
+} gr4pm_syncword_wipeoff_params;
+gr4pm_status gr4pm_syncword_wipeoff_create(const gr4pm_syncword_wipeoff_params* params,
+                                           gr4pm_syncword_wipeoff** out);
+void gr4pm_syncword_wipeoff_destroy(gr4pm_syncword_wipeoff* h);
+gr4pm_status gr4pm_syncword_wipeoff_reset(gr4pm_syncword_wipeoff* h);
+gr4pm_status gr4pm_syncword_wipeoff_process(gr4pm_syncword_wipeoff* h, const gr4pm_c64* in,
+                                            size_t n, gr4pm_c64* out, const gr4pm_tag* tags,
+                                            size_t n_tags);
+
+/* ------------------------------------------------------------------------------------
+ * InterpolatingFirFilter<TIn,TOut,float> -- interpolating_fir_filter.hpp:14-103
+ *   item_kind: 0 = std::complex<float>, 1 = float
+ * ---------------------------------------------------------------------------------- */
+typedef struct gr4pm_interp_fir gr4pm_interp_fir;
+typedef struct {
+    size_t interpolation; /* :39 */
+    const float* taps;    /* :40 host */
+    size_t n_taps;
+    int item_kind;
+    void* stream;
+} gr4pm_interp_fir_params;
+gr4pm_status gr4pm_interp_fir_create(const gr4pm_interp_fir_params* params,
+                                     gr4pm_interp_fir** out);
+void gr4pm_interp_fir_destroy(gr4pm_interp_fir* h);
+gr4pm_status gr4pm_interp_fir_reset(gr4pm_interp_fir* h);
+/* consumes n_in items, produces n_in * interpolation items (:91-99) */
+gr4pm_status gr4pm_interp_fir_process(gr4pm_interp_fir* h, const void* in, size_t n_in,
+                                      void* out);
+
+/* ------------------------------------------------------------------------------------
+ * SymbolFilter<TIn,TOut,float> -- symbol_filter.hpp:13-253
+ * ---------------------------------------------------------------------------------- */
+typedef struct gr4pm_symbol_filter gr4pm_symbol_filter;
+typedef struct {
+    size_t samples_per_symbol; /* :55 */
+    const float* taps;         /* :56 host, prototype PFB taps */
+    size_t n_taps;
+    size_t num_arms;           /* :58 */
+    size_t delay;              /* :59 */
+    int item_kind;             /* 0 complex, 1 float */
+    void* stream;
+} gr4pm_symbol_filter_params;
+gr4pm_status gr4pm_symbol_filter_create(const gr4pm_symbol_filter_params* params,
+                                        gr4pm_symbol_filter** out);
+void gr4pm_symbol_filter_destroy(gr4pm_symbol_filter* h);
+gr4pm_status gr4pm_symbol_filter_reset(gr4pm_symbol_filter* h);
+/* tags_in: host, sorted, indices relative to in[0]; tags_out: host, indices relative to
+ * out[0] (re-timed to symbols, :204-228; syncword_phase adjusted when time_est < 0,
+ * :148-156).  Stops when out_cap symbols were produced (:208). */
+gr4pm_status gr4pm_symbol_filter_process(gr4pm_symbol_filter* h, const void* in, size_t n_in,
+                                         void* out, size_t out_cap, const gr4pm_tag* tags_in,
+                                         size_t n_tags_in, gr4pm_tag* tags_out, size_t tags_cap,
+                                         size_t* n_tags_out, size_t* consumed, size_t* produced);
+
+/* ------------------------------------------------------------------------------------
+ * PfbArbResampler<c64,c64,float,TRate> -- pfb_arb_resampler.hpp:23-183
+ * ---------------------------------------------------------------------------------- */
+typedef struct gr4pm_pfb_arb_resampler gr4pm_pfb_arb_resampler;
+typedef struct {
+    double rate;        /* :63 */
+    int rate_is_double; /* TRate: 0 float (default), 1 double */
+    const float* taps;  /* :64 host; NULL = the built-in default prototype */
+    size_t n_taps;
+    size_t filter_size; /* :65 */
+    void* stream;
+} gr4pm_pfb_arb_resampler_params;
+gr4pm_status gr4pm_pfb_arb_resampler_create(const gr4pm_pfb_arb_resampler_params* params,
+                                            gr4pm_pfb_arb_resampler** out);
+void gr4pm_pfb_arb_resampler_destroy(gr4pm_pfb_arb_resampler* h);
+gr4pm_status gr4pm_pfb_arb_resampler_reset(gr4pm_pfb_arb_resampler* h);
+gr4pm_status gr4pm_pfb_arb_resampler_process(gr4pm_pfb_arb_resampler* h, const gr4pm_c64* in,
+                                             size_t n_in, gr4pm_c64* out, size_t out_cap,
+                                             size_t* consumed, size_t* produced);
+
+/* firdes::root_raised_cosine<float> -- firdes.hpp:29-76 (host helper; out: ntaps|1 floats) */
+size_t gr4pm_firdes_root_raised_cosine(double gain, double sampling_freq, double symbol_rate,
+                                       double alpha, size_t ntaps, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GR4PM_HIP_H */

@@ -1,0 +1,104 @@
+// Host emulation of the one-wave FFT schedules (gr4-packet-modem_amd/csrc/fft2048_wave.hpp):
+// runs the 64 lanes phase by phase on the CPU and prints the max relative error of FFT-1 and
+// of FFT-2(FFT-1(x) .* t) against a double-precision DFT.  Built and run by
+// tests/test_fft_wave_emulation.py (no GPU needed).
+#include <cmath>
+#include <complex>
+#include <cstdio>
+#include <random>
+#include <vector>
+#include "fft2048_wave.hpp"
+
+using namespace gr4pm;
+using cd = std::complex<double>;
+
+static std::vector<cd> dft(const std::vector<cd>& x)
+{
+    const size_t n = x.size();
+    std::vector<cd> X(n);
+    // O(n^2) with exact-angle reduction
+    for (size_t k = 0; k < n; ++k) {
+        cd acc = 0;
+        for (size_t i = 0; i < n; ++i) {
+            const size_t ph = (i * k) % n;
+            const double a = -2.0 * M_PI * static_cast<double>(ph) / static_cast<double>(n);
+            acc += x[i] * cd(std::cos(a), std::sin(a));
+        }
+        X[k] = acc;
+    }
+    return X;
+}
+
+int main()
+{
+    std::vector<cf> tw(kFftN);
+    for (int k = 0; k < kFftN; ++k) {
+        const double a = -2.0 * M_PI * k / kFftN;
+        tw[k] = { static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a)) };
+    }
+    std::mt19937 rng(42);
+    std::normal_distribution<float> g(0.f, 1.f);
+    std::vector<cf> x(kFftN), t(kFftN);
+    for (auto& v : x) v = { g(rng), g(rng) };
+    for (auto& v : t) v = { g(rng), g(rng) };
+
+    std::vector<cf> lds(kExchangeItems);
+    std::vector<std::vector<cf>> r(kLanes, std::vector<cf>(kPtsPerLane));
+    // ---- FFT-1
+    for (int l = 0; l < kLanes; ++l)
+        for (int n1 = 0; n1 < 16; ++n1)
+            for (int e = 0; e < 2; ++e) r[l][2 * n1 + e] = x[2 * l + e + 128 * n1];
+    for (int l = 0; l < kLanes; ++l) fft1_pass1(l, r[l].data(), tw.data());
+    for (int l = 0; l < kLanes; ++l) fft1_store1(l, r[l].data(), lds.data());
+    for (int l = 0; l < kLanes; ++l) fft1_load2(l, r[l].data(), lds.data());
+    for (int l = 0; l < kLanes; ++l) fft1_pass2(l, r[l].data(), tw.data());
+    for (int l = 0; l < kLanes; ++l) fft1_store2(l, r[l].data(), lds.data());
+    for (int l = 0; l < kLanes; ++l) fft1_load3(l, r[l].data(), lds.data());
+    for (int l = 0; l < kLanes; ++l) fft1_pass3(r[l].data());
+
+    std::vector<cd> xd(kFftN);
+    for (int i = 0; i < kFftN; ++i) xd[i] = cd(x[i].x, x[i].y);
+    const auto X = dft(xd);
+    double maxref = 0, maxerr = 0;
+    std::vector<int> seen(kFftN, 0);
+    for (int l = 0; l < kLanes; ++l)
+        for (int j = 0; j < kPtsPerLane; ++j) {
+            const int k = fft1_out_index(l, j);
+            seen[k]++;
+            maxref = std::max(maxref, std::abs(X[k]));
+            maxerr = std::max(maxerr, std::abs(cd(r[l][j].x, r[l][j].y) - X[k]));
+        }
+    int bad = 0;
+    for (int k = 0; k < kFftN; ++k) bad += seen[k] != 1;
+    std::printf("fft1 relerr %.3e coverage_bad %d\n", maxerr / maxref, bad);
+
+    // ---- product in FFT-1's distribution, then FFT-2
+    std::vector<cd> P(kFftN);
+    for (int l = 0; l < kLanes; ++l)
+        for (int j = 0; j < kPtsPerLane; ++j) {
+            const int k = fft1_out_index(l, j);
+            r[l][j] = cmul(r[l][j], t[k]);
+            P[k] = cd(r[l][j].x, r[l][j].y);
+        }
+    for (int l = 0; l < kLanes; ++l) fft2_passA(l, r[l].data(), tw.data());
+    for (int l = 0; l < kLanes; ++l) fft2_storeA(l, r[l].data(), lds.data());
+    for (int l = 0; l < kLanes; ++l) fft2_loadB(l, r[l].data(), lds.data());
+    for (int l = 0; l < kLanes; ++l) fft2_passB(l, r[l].data(), tw.data());
+    for (int l = 0; l < kLanes; ++l) fft2_storeB(l, r[l].data(), lds.data());
+    for (int l = 0; l < kLanes; ++l) fft2_loadC(l, r[l].data(), lds.data());
+    for (int l = 0; l < kLanes; ++l) fft2_passC(r[l].data());
+    const auto C = dft(P);
+    maxref = maxerr = 0;
+    std::fill(seen.begin(), seen.end(), 0);
+    for (int l = 0; l < kLanes; ++l)
+        for (int j = 0; j < kPtsPerLane; ++j) {
+            const int k = fft2_out_index(l, j);
+            seen[k]++;
+            maxref = std::max(maxref, std::abs(C[k]));
+            maxerr = std::max(maxerr, std::abs(cd(r[l][j].x, r[l][j].y) - C[k]));
+        }
+    bad = 0;
+    for (int k = 0; k < kFftN; ++k) bad += seen[k] != 1;
+    std::printf("fft2 relerr %.3e coverage_bad %d\n", maxerr / maxref, bad);
+    return 0;
+}

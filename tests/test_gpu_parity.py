@@ -1,0 +1,393 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle on the same
+seeded inputs, plus the reference's own qa_*.cpp expectations re-run on the GPU output.
+
+Bars: indices / freq_bin / pass-through / FIR outputs bit-exact; FFT-derived float tag
+values within 1e-4 relative (FFTW's own bits are unpinned, see oracle/gr4pm_oracle.h);
+recurrences (rotator, CFC) bit-exact; Costas within 1e-5 (device sincos vs glibc)."""
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+import _oracle as orc
+import _signals as sig
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return ge.load_package()
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint64) if a.dtype == np.complex64 else a.view(np.uint32)
+
+
+def assert_tags_match(tags, ref, rtol=1e-4):
+    assert np.array_equal(tags["index"], ref["index"]), (tags["index"], ref["index"])
+    assert np.array_equal(tags["freq_bin"], ref["freq_bin"])
+    for key in ("amplitude", "noise_power"):
+        assert np.allclose(tags[key], ref[key], rtol=rtol, atol=0), key
+    assert np.allclose(tags["freq"], ref["freq"], rtol=0, atol=2e-6)
+    dphi = np.angle(np.exp(1j * (tags["phase"].astype(np.float64) - ref["phase"].astype(np.float64))))
+    assert np.max(np.abs(dphi), initial=0) < 2e-4
+    assert np.allclose(tags["esn0_db"], ref["esn0_db"], rtol=0, atol=2e-3)
+    assert np.allclose(tags["time_est"], ref["time_est"], rtol=0, atol=2e-4)
+
+
+# ------------------------------------------------------------------ SyncwordDetection
+@pytest.mark.parametrize("freq_error", [0.0, 0.005, 0.015, -0.005, -0.015])
+def test_syncword_detection_vs_oracle_and_reference_qa(pkg, freq_error):
+    """test/qa_syncword_detection.cpp:21-151 at 200k symbols + oracle comparison"""
+    locations = [100, 1000, 1250, 10000, 13721, 43124, 58000, 127018, 180000 - 64]
+    x, rrc = sig.qa_syncword_stream(200000, locations, freq_error, seed=21)
+    ref = orc.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, power_threshold=20.0)
+    st0, ref_out, ref_tags, ref_zpow, _ = ref.process(x, debug=True)
+    sd = pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, power_threshold=20.0, max_items=x.size)
+    st, out, tags, n = sd.process_bulk(dev(x))
+    assert st == st0 == 0 and n == ref_out.size
+    assert sd._syncword_samples_size == 297 and abs(sd._syncword_self_corr - ref._syncword_self_corr) < 1e-5
+    out = host(out)
+    delay = 2 * sd.time_threshold + 1
+    assert np.all(out[:delay] == 0)                                        # qa :108-110
+    assert np.array_equal(bits(out[delay:]), bits(x[: n - delay]))         # qa :111-113
+    assert np.array_equal(bits(out), bits(ref_out))
+    assert tags.size == len(locations)
+    for tag, loc in zip(tags, locations):
+        assert tag["index"] == delay + 4 * loc                             # qa :117-120
+        assert 0.95 < tag["amplitude"] < 1.01 and tag["esn0_db"] >= 30.0
+        assert abs(np.float32(tag["freq"]) - np.float32(freq_error)) < 5e-4
+        assert tag["noise_power"] < 5e-4 and abs(tag["time_est"]) < 0.05
+        if freq_error == 0.0:
+            assert abs(tag["phase"]) < 1e-6
+    assert_tags_match(tags, ref_tags)
+    zpow = host(sd.last_zpow(n))[0]
+    scale = np.max(ref_zpow)
+    assert np.max(np.abs(zpow - ref_zpow)) / scale < 2e-6
+
+
+def test_syncword_detection_streaming_chunks_match_single_call(pkg):
+    """state carried across calls (hpp:191-199,349): arbitrary chunking == one call == oracle"""
+    locations = [100, 1000, 1250, 10000, 13721, 43124, 58000 - 64]
+    x, rrc = sig.qa_syncword_stream(60000, locations, 0.005, seed=5)
+    ref = orc.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, power_threshold=20.0)
+    _, ref_out, ref_tags = ref.process(x)
+    sd = pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, power_threshold=20.0, max_items=1 << 16)
+    xd = dev(x)
+    rng = np.random.default_rng(3)
+    pos, outs, all_tags = 0, [], []
+    while pos + 2048 <= x.size:
+        n_req = int(rng.integers(2048, 30000))
+        st, o, t, n = sd.process_bulk(xd[pos:pos + n_req].contiguous())
+        assert st == 0 and n > 0
+        t = t.copy()
+        t["index"] += pos
+        outs.append(host(o))
+        all_tags.append(t)
+        pos += n
+    out = np.concatenate(outs)
+    tags = np.concatenate(all_tags)
+    assert np.array_equal(bits(out), bits(ref_out[: out.size]))
+    k = tags.size
+    assert k >= 6
+    assert_tags_match(tags, ref_tags[:k])
+
+
+def test_syncword_detection_awgn_threshold_and_noise_only(pkg):
+    """default threshold 9.5, bursts in AWGN: same detections (incl. none on noise) as the oracle"""
+    rng = np.random.default_rng(77)
+    locations = [500, 9000, 20000, 33000]
+    x, rrc = sig.qa_syncword_stream(40000, locations, -0.012, seed=8)
+    x = (0.5 * x + sig.awgn(x.size, 0.3, 9)).astype(np.complex64)
+    x[70000:110000] = sig.awgn(40000, 0.3, 10)  # noise-only stretch
+    ref = orc.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, power_threshold=9.5)
+    _, ref_out, ref_tags, ref_zpow, _ = ref.process(x, debug=True)
+    sd = pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, power_threshold=9.5, max_items=x.size)
+    st, out, tags, n = sd.process_bulk(dev(x))
+    assert n == ref_out.size and np.array_equal(bits(host(out)), bits(ref_out))
+    assert_tags_match(tags, ref_tags, rtol=2e-4)
+    assert tags.size >= 3
+
+
+def test_syncword_detection_zero_input_and_short_input(pkg):
+    """benchmark_syncword_detection.cpp feeds zeros: no tags, zeros out; < fft_size -> INSUFFICIENT"""
+    rrc, _ = orc.unit_norm_rrc(4)
+    sd = pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, max_items=1 << 17)
+    st, out, tags, n = sd.process_bulk(torch.zeros(2047, dtype=torch.complex64, device="cuda"))
+    assert st == 1 and n == 0                                              # hpp:215-227
+    z = torch.zeros(100000, dtype=torch.complex64, device="cuda")
+    st, out, tags, n = sd.process_bulk(z)
+    assert st == 0 and n == ((100000 - 2048) // 1752 + 1) * 1752 and tags.size == 0
+    assert torch.count_nonzero(out).item() == 0
+
+
+def test_syncword_detection_invalid_settings_raise(pkg):
+    rrc, _ = orc.unit_norm_rrc(4)
+    with pytest.raises(pkg.Gr4pmError, match="min_freq_bin"):             # hpp:145-147
+        pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, 2, 1)
+    with pytest.raises(pkg.Gr4pmError, match="fft_size too small"):       # hpp:150-152
+        pkg.SyncwordDetection(rrc, np.tile(sig.SYNCWORD, 9), sig.BPSK, 0, 0)
+
+
+def test_syncword_detection_multichannel_batch(pkg):
+    """independent channels in one launch == each channel alone"""
+    chans, refs = [], []
+    rrc, _ = orc.unit_norm_rrc(4)
+    for c in range(3):
+        x, _ = sig.qa_syncword_stream(30000, [200 + 700 * c, 9000 + 13 * c, 20000], 0.004 * (c - 1), seed=40 + c)
+        chans.append(x)
+        ref = orc.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, power_threshold=20.0)
+        refs.append(ref.process(x))
+    X = np.stack(chans)
+    sd = pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, power_threshold=20.0, n_channels=3,
+                               max_items=X.shape[1])
+    st, out, tags, n = sd.process_bulk(dev(X))
+    out = host(out)
+    for c in range(3):
+        _, ref_out, ref_tags = refs[c]
+        assert n == ref_out.size and np.array_equal(bits(out[c]), bits(ref_out))
+        assert_tags_match(tags[c], ref_tags)
+
+
+# ------------------------------------------------------------------ rotators
+def test_rotator_bit_exact_and_reference_qa(pkg):
+    """test/qa_rotator.cpp:16-45 + bit-exact vs the oracle's serial recurrence"""
+    n = 100000
+    x = np.ones(n, dtype=np.complex64)
+    y = host(pkg.Rotator(0.1).process_bulk(dev(x)))
+    assert np.max(np.abs(y - np.exp(1j * np.float64(np.float32(0.1)) * np.arange(n)))) < 5e-4
+    assert np.array_equal(bits(y), bits(orc.rotator(x, np.float32(0.1))))
+    rng = np.random.default_rng(1)
+    x = (rng.standard_normal(5000) + 1j * rng.standard_normal(5000)).astype(np.complex64)
+    r = pkg.Rotator(-0.3217)
+    y1 = host(r.process_bulk(dev(x[:1237])))
+    y2 = host(r.process_bulk(dev(x[1237:])))                               # state carried across calls
+    assert np.array_equal(bits(np.concatenate([y1, y2])), bits(orc.rotator(x, np.float32(-0.3217))))
+
+
+@pytest.mark.parametrize("delay", [0, 26])
+def test_coarse_frequency_correction(pkg, delay):
+    """test/qa_coarse_frequency_correction.cpp:15-92 (delay 0) and the receiver's delay 26"""
+    n = 10000
+    x = np.ones(n, dtype=np.complex64)
+    tags = np.zeros(5, dtype=pkg.TAG_DTYPE)
+    tags["index"] = [100, 1000, 1500, 5000, 6500]
+    tags["freq"] = [0.1, 0.1, 0.1, 0.0, 0.2]
+    tags["flags"] = pkg.TAG_SYNCWORD
+    y = host(pkg.CoarseFrequencyCorrection(delay).process_bulk(dev(x), tags))
+    want = orc.coarse_frequency_correction(x, tags["index"], tags["freq"], delay=delay)
+    assert np.array_equal(bits(y), bits(want))
+    if delay == 0:
+        assert np.all(y[:100] == 1.0) and np.all(y[5000:6500] == 1.0)
+        for start, end, fr in [(100, 1000, 0.1), (1000, 1500, 0.1), (1500, 5000, 0.1), (6500, n, 0.2)]:
+            k = np.arange(end - start)
+            assert np.max(np.abs(y[start:end] - np.exp(-1j * np.float64(np.float32(fr)) * k))) < 1e-3
+
+
+def test_coarse_frequency_correction_pending_delay_across_calls(pkg):
+    rng = np.random.default_rng(2)
+    x = (rng.standard_normal(4000) + 1j * rng.standard_normal(4000)).astype(np.complex64)
+    idx, fr = np.array([990, 2000, 2010], dtype=np.uint64), np.array([0.05, -0.02, 0.07])
+    want = orc.coarse_frequency_correction(x, idx, fr, delay=26)
+    cfc = pkg.CoarseFrequencyCorrection(26)
+    outs = []
+    for a, b in [(0, 1000), (1000, 2005), (2005, 4000)]:
+        t = np.zeros(0, dtype=pkg.TAG_DTYPE)
+        sel = (idx >= a) & (idx < b)
+        t = np.zeros(sel.sum(), dtype=pkg.TAG_DTYPE)
+        t["index"], t["freq"], t["flags"] = idx[sel] - a, fr[sel], pkg.TAG_SYNCWORD
+        outs.append(host(cfc.process_bulk(dev(x[a:b]), t)))
+    assert np.array_equal(bits(np.concatenate(outs)), bits(want))
+
+
+# ------------------------------------------------------------------ Costas
+@pytest.mark.parametrize("constellation", ["PILOT", "BPSK", "QPSK"])
+def test_costas_loop(pkg, constellation):
+    """test/qa_costas_loop.cpp:17-65 + oracle comparison"""
+    rng = np.random.default_rng(13)
+    n = 100000
+    if constellation == "PILOT":
+        x = np.ones(n, dtype=np.complex64)
+    elif constellation == "BPSK":
+        x = np.where(rng.integers(0, 2, n) == 0, 1.0, -1.0).astype(np.complex64)
+    else:
+        a = np.float32(np.sqrt(0.5))
+        x = (np.where(rng.integers(0, 2, n) == 0, a, -a) + 1j * np.where(rng.integers(0, 2, n) == 0, a, -a)).astype(np.complex64)
+    rot = orc.rotator(x, np.float32(0.01))
+    cl = pkg.CostasLoop(0.01, constellation)
+    assert cl.coeffs == orc.costas_coeffs(0.01, constellation)
+    y = host(cl.process_bulk(dev(rot)))
+    assert np.all(np.abs(y[1000:] * np.conj(x[1000:]) - 1.0) < 1e-2)       # qa :56-62
+    assert np.max(np.abs(y - orc.costas_loop(rot, constellation))) < 1e-5
+
+
+def test_costas_loop_phase_tags_and_carry(pkg):
+    rng = np.random.default_rng(14)
+    n = 20000
+    x = np.where(rng.integers(0, 2, n) == 0, 1.0, -1.0).astype(np.complex64)
+    x = (x * np.exp(1j * 0.7) + sig.awgn(n, 0.1, 15)).astype(np.complex64)
+    idx = np.array([0, 5000, 5001, 12000], dtype=np.uint64)
+    ph = np.array([0.7, 0.6, 0.8, -2.4], dtype=np.float32)
+    want = orc.costas_loop(x, "BPSK", 0.01, idx, ph)
+    cl = pkg.CostasLoop(0.01, "BPSK")
+    outs = []
+    for a, b in [(0, 7000), (7000, n)]:
+        sel = (idx >= a) & (idx < b)
+        t = np.zeros(sel.sum(), dtype=pkg.TAG_DTYPE)
+        t["index"], t["phase"], t["flags"] = idx[sel] - a, ph[sel], pkg.TAG_SYNCWORD
+        outs.append(host(cl.process_bulk(dev(x[a:b]), t)))
+    assert np.max(np.abs(np.concatenate(outs) - want)) < 1e-5
+
+
+# ------------------------------------------------------------------ wipe-off / SDF
+def test_syncword_wipeoff(pkg):
+    """test/qa_syncword_wipeoff.cpp:13-48 (c64 items)"""
+    n = 1000
+    ramp = np.arange(n).astype(np.complex64)
+    bipolar = np.where(sig.SYNCWORD == 1, -1.0, 1.0).astype(np.float32)
+    v = ramp.copy()
+    idx = [10, 100, 250]
+    for i in idx:
+        v[i:i + 64] *= bipolar
+    tags = np.zeros(4, dtype=pkg.TAG_DTYPE)
+    tags["index"], tags["flags"] = idx + [260], pkg.TAG_SYNCWORD           # 260: inside a syncword -> ignored
+    w = pkg.SyncwordWipeoff(bipolar)
+    y = np.concatenate([host(w.process_bulk(dev(v[:270]), tags)),          # call boundary inside the 3rd syncword
+                        host(w.process_bulk(dev(v[270:]), None))])
+    assert np.array_equal(y, ramp)
+    assert np.array_equal(bits(y), bits(orc.syncword_wipeoff(v, bipolar, idx + [260])))
+
+
+def test_syncword_detection_filter(pkg):
+    """test/qa_syncword_detection_filter.cpp:14-61"""
+    num_items = 100000
+    v = np.arange(num_items).astype(np.complex64)
+    vd = dev(v)
+    tag_idx = [12345, 14345]
+    f = pkg.SyncwordDetectionFilter()
+    out = torch.zeros(num_items, dtype=torch.complex64, device="cuda")
+    out_tags, pos = [], 0
+    bounds = sorted(set([0] + tag_idx + [num_items]))
+    while pos < num_items:
+        nxt = min(b for b in bounds if b > pos)
+        flags = pkg.TAG_SYNCWORD if pos in tag_idx else 0
+        c, hc, ic, tf = f.process_bulk(vd[pos:nxt], out[pos:nxt], flags, headers=[1500])
+        if tf:
+            out_tags.append((pos, tf))
+        assert c > 0
+        pos += c
+    assert np.array_equal(host(out), v)
+    assert out_tags == [(12345, pkg.TAG_SYNCWORD)]
+
+
+# ------------------------------------------------------------------ FIR family
+def test_interpolating_fir_filter(pkg):
+    """test/qa_interpolating_fir_filter.cpp:16-55 (exact vs zero-stuffed convolution, integer-valued
+    floats) + bit-exact vs the oracle on c64 with the RRC taps, state carried across calls"""
+    rng = np.random.default_rng(12)
+    n, interp = 100000, 5
+    v = rng.integers(-8, 9, n).astype(np.float32)
+    taps = np.arange(1, 24, dtype=np.float32)
+    got = host(pkg.InterpolatingFirFilter(interp, taps, "float32").process_bulk(dev(v)))
+    stuffed = np.zeros(n * interp)
+    stuffed[::interp] = v
+    assert np.array_equal(got.astype(np.float64), np.convolve(stuffed, taps.astype(np.float64))[: n * interp])
+    rrc, _ = orc.unit_norm_rrc(4)
+    x = (rng.standard_normal(30000) + 1j * rng.standard_normal(30000)).astype(np.complex64)
+    f = pkg.InterpolatingFirFilter(4, rrc)
+    y = np.concatenate([host(f.process_bulk(dev(x[:7]))), host(f.process_bulk(dev(x[7:11111]))),
+                        host(f.process_bulk(dev(x[11111:])))])
+    assert np.array_equal(bits(y), bits(orc.interpolating_fir(x, 4, rrc)))
+
+
+def test_symbol_filter_free_running_reference_qa(pkg):
+    """test/qa_symbol_filter.cpp:17-63 (float items, no tags) + bit-exact vs oracle"""
+    num_symbols = 200000
+    rng = np.random.default_rng(11)
+    sym = np.where(rng.integers(0, 2, num_symbols) == 0, 1.0, -1.0).astype(np.float32)
+    x = orc.interpolating_fir(sym, 4, orc.rrc_taps(1.0, 4.0, 1.0, 0.35, 44))
+    pfb = orc.rrc_taps(32.0, 128.0, 1.0, 0.35, 32 * 4 * 11)
+    y, _, consumed = pkg.SymbolFilter(pfb, 32, 4, 0, "float32").process_bulk(dev(x))
+    y = host(y)
+    assert y.size == num_symbols and consumed == x.size
+    assert np.all(np.abs(np.abs(y[11:]) - 0.24819523) < 5e-3)
+    want, _, _ = orc.symbol_filter(x, pfb, 32, 4, 0)
+    assert np.array_equal(bits(y), bits(want))
+
+
+def _receiver_pfb():
+    rrc, norm = orc.unit_norm_rrc(4)
+    pfb = orc.rrc_taps(32.0 / float(norm), 128.0, 1.0, 0.35, 32 * 4 * 11)[:-1]  # packet_receiver.hpp:100-110
+    return rrc, pfb
+
+
+@pytest.mark.parametrize("split", [None, 2501])
+def test_symbol_filter_with_tags_all_clock_phase_cases(pkg, split):
+    """tag-driven path (symbol_filter.hpp:130-206), untested upstream: all special cases of the
+    clock phase, negative time_est, tag re-timing; c64 items as in the receiver"""
+    rrc, pfb = _receiver_pfb()
+    rng = np.random.default_rng(31)
+    n = 12000
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    idx = [0, 1001, 2002, 2500, 3000, 3003, 4444, 5557, 7000, 7001, 9998]
+    tags = np.zeros(len(idx), dtype=pkg.TAG_DTYPE)
+    tags["index"] = idx
+    tags["amplitude"] = rng.uniform(0.5, 2.0, len(idx))
+    tags["time_est"] = [0.1, -0.2, 0.49, -0.5, 0.0, -0.01, 0.3, -0.3, 0.5, 0.2, -0.45]
+    tags["phase"] = rng.uniform(-3, 3, len(idx))
+    tags["freq"] = rng.uniform(-0.03, 0.03, len(idx))
+    tags["flags"] = pkg.TAG_SYNCWORD
+    tags["flags"][4] = pkg.TAG_OTHER                                       # a non-syncword tag is only re-timed
+    otags = tags.astype(orc.TAG_DTYPE)
+    want, want_tags, want_cons = orc.symbol_filter(x, pfb, 32, 4, 44, tags=otags)
+    f = pkg.SymbolFilter(pfb, 32, 4, 44)
+    if split is None:
+        y, t, cons = f.process_bulk(dev(x), tags)
+        y = host(y)
+    else:
+        ta = tags[tags["index"] < split]
+        tb = tags[tags["index"] >= split].copy()
+        tb["index"] -= split
+        y1, t1, c1 = f.process_bulk(dev(x[:split]), ta)
+        y2, t2, c2 = f.process_bulk(dev(x[split:]), tb)
+        assert c1 == split
+        t2 = t2.copy()
+        t2["index"] += y1.numel()
+        y, t, cons = np.concatenate([host(y1), host(y2)]), np.concatenate([t1, t2]), c1 + c2
+    assert cons == want_cons == n and y.size == want.size
+    assert np.array_equal(bits(y), bits(want))
+    assert t.size == want_tags.size
+    for k in ("index", "amplitude", "phase", "freq", "time_est", "flags"):
+        assert np.array_equal(t[k], want_tags[k]), k
+
+
+def test_pfb_arb_resampler(pkg):
+    """test/qa_pfb_arb_resampler.cpp:16-70 (TRate = double) + bit-exact vs oracle, both TRate"""
+    n, rate, f = 100000, 1.1234, 0.01
+    taps = pkg.default_pfb_arb_taps()
+    x = np.exp(1j * f * np.arange(n)).astype(np.complex64)
+    y, cons = pkg.PfbArbResampler(rate, None, 32, "float64").process_bulk(dev(x))
+    y = host(y)
+    assert abs(y.size - n * rate) <= 5                                      # qa :45-49
+    k = np.arange(1000, y.size)
+    phase0 = np.angle(y[1000])
+    assert np.max(np.abs(y[1000:] - np.exp(1j * (phase0 + (f / rate) * (k - 1000))))) < 3e-3   # qa :50-69
+    want, wcons = orc.pfb_arb_resampler(x, rate, taps, 32, rate_is_double=True)
+    assert cons == wcons and np.array_equal(bits(y), bits(want))
+    r = pkg.PfbArbResampler(1.0 + 1.2e-6, taps, 32, "float32")
+    y1, c1 = r.process_bulk(dev(x[:40001]))
+    y2, c2 = r.process_bulk(dev(x[c1:]))
+    want, _ = orc.pfb_arb_resampler(x, 1.0 + 1.2e-6, taps, 32, rate_is_double=False)
+    got = np.concatenate([host(y1), host(y2)])
+    assert np.array_equal(bits(got), bits(want[: got.size])) and abs(got.size - want.size) <= 1
