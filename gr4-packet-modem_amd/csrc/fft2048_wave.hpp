@@ -37,12 +37,38 @@ GR4PM_HD float cnorm(cf a) { return a.x * a.x + a.y * a.y; }
 constexpr int kFftN = 2048;
 constexpr int kLanes = 64;
 constexpr int kPtsPerLane = 32;
-// LDS footprint of one wave's exchange buffer, in complex items (see row strides below)
-constexpr int kS1 = 136; // FFT-1 exchange 1: 16 rows [k1] of 128 (+8 pad)
-constexpr int kS2 = 18;  // FFT-1 exchange 2: 128 rows [k1][m] of 16 (+2 pad)
-constexpr int kSA = 17;  // FFT-2 exchange A: 128 rows [ka][m] of 16 (+1 pad)
-constexpr int kSB = 18;  // FFT-2 exchange B: 128 rows [k2][ka] of 16 (+2 pad)
-constexpr int kExchangeItems = 128 * 18; // 2304 complex = 18 KiB
+// Row strides (complex items) of the LDS exchange layouts; every exchange runs in two
+// half-rounds (8 of 16 rows / 64 of 128 rows at a time) so one wave needs 9 KiB, not 18.
+constexpr int kS1 = 136; // FFT-1 exchange 1: 8 rows [k1] of 128 (+8 pad) per half
+constexpr int kS2 = 18;  // FFT-1 exchange 2: 64 rows [k1][m] of 16 (+2 pad) per half
+constexpr int kSA = 17;  // FFT-2 exchange A: 64 rows [ka][m] of 16 (+1 pad) per half
+constexpr int kSB = 18;  // FFT-2 exchange B: 64 rows [k2][ka] of 16 (+2 pad) per half
+constexpr int kExchangeItems = 64 * 18; // 1152 complex = 9 KiB per wave
+
+// Per-lane-ordered twiddle tables (built once on the host, double -> float):
+//   tw1a[(k1-1)*2 + e][lane] = W2048^((2 lane + e) k1)      k1 = 1..15   (30 x 64)
+//   tw1b[(k2-1)][m]          = W128^(m k2)                   k2 = 1..15, m < 8
+//   twA[(ka-1)*4 + q][lane]  = W2048^(n2 ka), n2 = lane/16 + 4q + 16 (lane%16), ka = 1..7 (28 x 64)
+//   twB[(k2-1)][m]           = W256^(m k2)                   k2 = 1..15, m < 16
+constexpr int kTw1aItems = 30 * 64, kTw1bItems = 15 * 8, kTwAItems = 28 * 64, kTwBItems = 15 * 16;
+// fills the four tables; w(k) must return exp(-j 2 pi k / 2048) as cf
+template <typename W>
+inline void build_twiddle_tables(W w, cf* tw1a, cf* tw1b, cf* twA, cf* twB)
+{
+    for (int k1 = 1; k1 < 16; ++k1)
+        for (int e = 0; e < 2; ++e)
+            for (int lane = 0; lane < 64; ++lane) tw1a[((k1 - 1) * 2 + e) * 64 + lane] = w(((2 * lane + e) * k1) % kFftN);
+    for (int k2 = 1; k2 < 16; ++k2)
+        for (int m = 0; m < 8; ++m) tw1b[(k2 - 1) * 8 + m] = w((16 * m * k2) % kFftN);
+    for (int ka = 1; ka < 8; ++ka)
+        for (int q = 0; q < 4; ++q)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int n2 = (lane >> 4) + 4 * q + 16 * (lane & 15);
+                twA[((ka - 1) * 4 + q) * 64 + lane] = w((n2 * ka) % kFftN);
+            }
+    for (int k2 = 1; k2 < 16; ++k2)
+        for (int m = 0; m < 16; ++m) twB[(k2 - 1) * 16 + m] = w((8 * m * k2) % kFftN);
+}
 
 // ---- small DFTs, forward sign, natural-order output, everything in registers ----
 GR4PM_HD void dft4(cf& a0, cf& a1, cf& a2, cf& a3)
@@ -101,8 +127,7 @@ GR4PM_HD void dft16(cf* v)
 
 // ======================================================================= FFT-1
 // r[2*n1 + e] = x[2*lane + e + 128*n1] on entry.
-// tw: tw[k] = exp(-j 2 pi k / 2048), k < 2048.
-GR4PM_HD void fft1_pass1(int lane, cf* r, const cf* tw)
+GR4PM_HD void fft1_pass1(int lane, cf* r, const cf* tw1a)
 {
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -110,55 +135,53 @@ GR4PM_HD void fft1_pass1(int lane, cf* r, const cf* tw)
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) v[n1] = r[2 * n1 + e];
         dft16(v);
-        const int n2 = 2 * lane + e;
         r[e] = v[0];
 #pragma unroll
-        for (int k1 = 1; k1 < 16; ++k1) r[2 * k1 + e] = cmul(v[k1], tw[n2 * k1]);
+        for (int k1 = 1; k1 < 16; ++k1) r[2 * k1 + e] = cmul(v[k1], tw1a[((k1 - 1) * 2 + e) * 64 + lane]);
     }
 }
-GR4PM_HD void fft1_store1(int lane, const cf* r, cf* lds)
+// half h: rows k1 in [8h, 8h+8)
+GR4PM_HD void fft1_store1(int lane, const cf* r, cf* lds, int h)
 {
 #pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) {
-        lds[k1 * kS1 + 2 * lane] = r[2 * k1];
-        lds[k1 * kS1 + 2 * lane + 1] = r[2 * k1 + 1];
+    for (int kk = 0; kk < 8; ++kk) {
+        const int k1 = 8 * h + kk;
+        lds[kk * kS1 + 2 * lane] = r[2 * k1];
+        lds[kk * kS1 + 2 * lane + 1] = r[2 * k1 + 1];
     }
 }
-GR4PM_HD void fft1_load2(int lane, cf* r, const cf* lds)
+// half h fills r[16h .. 16h+16): combo c = lane + 64h, k1 = c/8, m = c%8
+GR4PM_HD void fft1_load2(int lane, cf* r, const cf* lds, int h)
 {
+    const int kk = lane >> 3, m = lane & 7;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int c = lane + 64 * q, k1 = c >> 3, m = c & 7;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) r[16 * q + i] = lds[k1 * kS1 + m + 8 * i];
-    }
+    for (int i = 0; i < 16; ++i) r[16 * h + i] = lds[kk * kS1 + m + 8 * i];
 }
-GR4PM_HD void fft1_pass2(int lane, cf* r, const cf* tw)
+GR4PM_HD void fft1_pass2(int lane, cf* r, const cf* tw1b)
 {
     const int m = lane & 7;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         dft16(r + 16 * q);
 #pragma unroll
-        for (int k2 = 1; k2 < 16; ++k2) r[16 * q + k2] = cmul(r[16 * q + k2], tw[16 * m * k2]);
+        for (int k2 = 1; k2 < 16; ++k2) r[16 * q + k2] = cmul(r[16 * q + k2], tw1b[(k2 - 1) * 8 + m]);
     }
 }
-GR4PM_HD void fft1_store2(int lane, const cf* r, cf* lds)
+// half h: rows (k1*8 + m) with k1 in [8h, 8h+8) == combo c = lane + 64h -> local row = lane
+GR4PM_HD void fft1_store2(int lane, const cf* r, cf* lds, int h)
 {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int c = lane + 64 * q; // row = k1*8 + m = c
-#pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) lds[c * kS2 + k2] = r[16 * q + k2];
-    }
+    for (int k2 = 0; k2 < 16; ++k2) lds[lane * kS2 + k2] = r[16 * h + k2];
 }
-GR4PM_HD void fft1_load3(int lane, cf* r, const cf* lds)
+// half h fills r[8q .. 8q+8) for q in {2h, 2h+1}: k1 = lane/16 + 4q, k2 = lane%16
+GR4PM_HD void fft1_load3(int lane, cf* r, const cf* lds, int h)
 {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int c = lane + 64 * q, k1 = c >> 4, k2 = c & 15;
+    for (int qq = 0; qq < 2; ++qq) {
+        const int q = 2 * h + qq;
+        const int k1loc = (lane >> 4) + 4 * qq, k2 = lane & 15;
 #pragma unroll
-        for (int m = 0; m < 8; ++m) r[8 * q + m] = lds[(k1 * 8 + m) * kS2 + k2];
+        for (int m = 0; m < 8; ++m) r[8 * q + m] = lds[(k1loc * 8 + m) * kS2 + k2];
     }
 }
 // on exit r[8*q + k3] = X[k1 + 16*k2 + 256*k3], (k1, k2) = ((lane + 64 q) / 16, lane % 16)
@@ -176,61 +199,56 @@ GR4PM_HD int fft1_out_index(int lane, int j)
 
 // ======================================================================= FFT-2
 // r[8*q + n1] = P[n2 + 256*n1], n2 = (lane/16 + 4q) + 16*(lane%16) on entry.
-GR4PM_HD void fft2_passA(int lane, cf* r, const cf* tw)
+GR4PM_HD void fft2_passA(int lane, cf* r, const cf* twA)
 {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         dft8(r + 8 * q);
-        const int n2 = (lane >> 4) + 4 * q + 16 * (lane & 15);
 #pragma unroll
-        for (int ka = 1; ka < 8; ++ka) r[8 * q + ka] = cmul(r[8 * q + ka], tw[n2 * ka]);
+        for (int ka = 1; ka < 8; ++ka) r[8 * q + ka] = cmul(r[8 * q + ka], twA[((ka - 1) * 4 + q) * 64 + lane]);
     }
 }
-GR4PM_HD void fft2_storeA(int lane, const cf* r, cf* lds)
+// half h: rows (ka*16 + m) with ka in [4h, 4h+4)
+GR4PM_HD void fft2_storeA(int lane, const cf* r, cf* lds, int h)
 {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int m = (lane >> 4) + 4 * q, i = lane & 15;
 #pragma unroll
-        for (int ka = 0; ka < 8; ++ka) lds[(ka * 16 + m) * kSA + i] = r[8 * q + ka];
+        for (int kk = 0; kk < 4; ++kk) lds[(kk * 16 + m) * kSA + i] = r[8 * q + 4 * h + kk];
     }
 }
-GR4PM_HD void fft2_loadB(int lane, cf* r, const cf* lds)
+// half h fills r[16h .. 16h+16): combo c = lane + 64h -> local row = lane
+GR4PM_HD void fft2_loadB(int lane, cf* r, const cf* lds, int h)
 {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int c = lane + 64 * q; // row = ka*16 + m = c
-#pragma unroll
-        for (int i = 0; i < 16; ++i) r[16 * q + i] = lds[c * kSA + i];
-    }
+    for (int i = 0; i < 16; ++i) r[16 * h + i] = lds[lane * kSA + i];
 }
-GR4PM_HD void fft2_passB(int lane, cf* r, const cf* tw)
+GR4PM_HD void fft2_passB(int lane, cf* r, const cf* twB)
 {
     const int m = lane & 15;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         dft16(r + 16 * q);
 #pragma unroll
-        for (int k2 = 1; k2 < 16; ++k2) r[16 * q + k2] = cmul(r[16 * q + k2], tw[8 * m * k2]);
+        for (int k2 = 1; k2 < 16; ++k2) r[16 * q + k2] = cmul(r[16 * q + k2], twB[(k2 - 1) * 16 + m]);
     }
 }
-GR4PM_HD void fft2_storeB(int lane, const cf* r, cf* lds)
+// half h: rows (k2*8 + ka) with k2 in [8h, 8h+8)
+GR4PM_HD void fft2_storeB(int lane, const cf* r, cf* lds, int h)
 {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int c = lane + 64 * q, ka = c >> 4, m = c & 15;
 #pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) lds[(k2 * 8 + ka) * kSB + m] = r[16 * q + k2];
+        for (int kk = 0; kk < 8; ++kk) lds[(kk * 8 + ka) * kSB + m] = r[16 * q + 8 * h + kk];
     }
 }
-GR4PM_HD void fft2_loadC(int lane, cf* r, const cf* lds)
+// half h fills r[16h .. 16h+16): combo c = lane + 64h -> local row = lane
+GR4PM_HD void fft2_loadC(int lane, cf* r, const cf* lds, int h)
 {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int c = lane + 64 * q; // row = k2*8 + ka = c
-#pragma unroll
-        for (int m = 0; m < 16; ++m) r[16 * q + m] = lds[c * kSB + m];
-    }
+    for (int m = 0; m < 16; ++m) r[16 * h + m] = lds[lane * kSB + m];
 }
 // on exit r[16*q + k3] = C[lane + 64*q + 128*k3]
 GR4PM_HD void fft2_passC(cf* r)

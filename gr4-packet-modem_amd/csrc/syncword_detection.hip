@@ -34,7 +34,7 @@ namespace gr4pm {
 
 namespace {
 
-constexpr int kWavesPerWg = 4;
+constexpr int kWavesPerWg = 8; // 512 threads: 2 waves per SIMD on one CU
 constexpr int kMaxBins = 64;
 constexpr uint32_t kTileW = 32768; // items per detector tile
 
@@ -54,37 +54,54 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ void fft1_wave(int lane, cf* r, cf* lds, const cf* tw)
+// FFT-1: natural-order block in r (see fft1_pass1) -> X in FFT-1's output distribution.
+// Exchanges run in two half-rounds through the wave's 9 KiB LDS buffer.
+__device__ __forceinline__ void fft1_wave(int lane, cf* r, cf* lds, const cf* tw1a, const cf* tw1b)
 {
-    fft1_pass1(lane, r, tw);
-    fft1_store1(lane, r, lds);
-    wave_lds_sync();
-    fft1_load2(lane, r, lds);
-    wave_lds_sync();
-    fft1_pass2(lane, r, tw);
-    fft1_store2(lane, r, lds);
-    wave_lds_sync();
-    fft1_load3(lane, r, lds);
-    wave_lds_sync();
+    fft1_pass1(lane, r, tw1a);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        wave_lds_sync();
+        fft1_store1(lane, r, lds, h);
+        wave_lds_sync();
+        fft1_load2(lane, r, lds, h);
+    }
+    fft1_pass2(lane, r, tw1b);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        wave_lds_sync();
+        fft1_store2(lane, r, lds, h);
+        wave_lds_sync();
+        fft1_load3(lane, r, lds, h);
+    }
     fft1_pass3(r);
 }
-__device__ __forceinline__ void fft2_wave(int lane, cf* r, cf* lds, const cf* tw)
+// FFT-2: r (FFT-1's distribution) -> out (consecutive indices on consecutive lanes)
+__device__ __forceinline__ void fft2_wave(int lane, cf* r, cf* out, cf* lds, const cf* twA, const cf* twB)
 {
-    fft2_passA(lane, r, tw);
-    fft2_storeA(lane, r, lds);
-    wave_lds_sync();
-    fft2_loadB(lane, r, lds);
-    wave_lds_sync();
-    fft2_passB(lane, r, tw);
-    fft2_storeB(lane, r, lds);
-    wave_lds_sync();
-    fft2_loadC(lane, r, lds);
-    wave_lds_sync();
-    fft2_passC(r);
+    fft2_passA(lane, r, twA);
+    cf b[32];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        wave_lds_sync();
+        fft2_storeA(lane, r, lds, h);
+        wave_lds_sync();
+        fft2_loadB(lane, b, lds, h);
+    }
+    fft2_passB(lane, b, twB);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        wave_lds_sync();
+        fft2_storeB(lane, b, lds, h);
+        wave_lds_sync();
+        fft2_loadC(lane, out, lds, h);
+    }
+    fft2_passC(out);
 }
 
 // templates are stored per bin as [16][64 lanes] float4 = (T[k(lane, 2jp)], T[k(lane, 2jp+1)])
-// with k = fft1_out_index(lane, j): each lane reads its 32 values with 16 coalesced loads.
+// with k = fft1_out_index(lane, j): each lane reads its 32 values with 16 conflict-free /
+// coalesced 16-byte reads (from the LDS copy in k_correlate, from global in k_tags).
 __device__ __forceinline__ void mul_template(int lane, const cf* X, cf* r, const float4* tp)
 {
 #pragma unroll
@@ -95,22 +112,44 @@ __device__ __forceinline__ void mul_template(int lane, const cf* X, cf* r, const
     }
 }
 
+// LDS map of k_correlate (one array, 16-byte aligned), in float4 units:
+//   [0, 2048)              two template buffers (double buffered across bins), 32 KiB
+//   [2048, 2048+896)       twA  (28 x 64 cf = 14 KiB)
+//   [2944, 2944+120)       twB  (15 x 16 cf = 1.9 KiB)
+//   [3064, 3064+8*576)     eight per-wave exchange buffers of 1152 cf (9 KiB) each
+constexpr int kLdsTmpl = 0, kLdsTwA = 2048, kLdsTwB = kLdsTwA + kTwAItems / 2, kLdsExch = kLdsTwB + kTwBItems / 2;
+constexpr int kLdsTotal = kLdsExch + kWavesPerWg * (kExchangeItems / 2); // float4 units
+static_assert(kLdsTotal * 16 <= 160 * 1024, "LDS budget");
+
 // ------------------------------------------------------------------ k_correlate
-// grid (ceil(n_blocks / 4), n_channels), 256 threads = 4 independent waves.
-__global__ __launch_bounds__(256) void k_correlate(const cf* __restrict__ in, size_t in_stride,
-                                                   uint32_t n_blocks, uint32_t stride_s,
-                                                   int n_bins, const float4* __restrict__ tmpl,
-                                                   const cf* __restrict__ tw,
-                                                   float* __restrict__ zpow, size_t z_stride)
+// grid (ceil(n_blocks / 8), n_channels), 512 threads = 8 waves, one overlap-save block per
+// wave; the 8 waves walk the B templates in lockstep so each template is staged into LDS once
+// per workgroup (issue-early / write-late through 2 float4 registers per thread).
+__global__ __launch_bounds__(512, 2) void k_correlate(const cf* __restrict__ in, size_t in_stride,
+                                                      uint32_t n_blocks, uint32_t stride_s,
+                                                      int n_bins, const float4* __restrict__ tmpl,
+                                                      const cf* __restrict__ tw1a,
+                                                      const cf* __restrict__ tw1b,
+                                                      const float4* __restrict__ twAB,
+                                                      float* __restrict__ zpow, size_t z_stride)
 {
-    __shared__ cf lds_all[kWavesPerWg * kExchangeItems];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const uint32_t b = blockIdx.x * kWavesPerWg + wave;
-    if (b >= n_blocks) return;
-    cf* lds = lds_all + wave * kExchangeItems;
+    __shared__ float4 lds4[kLdsTotal];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const uint32_t b_raw = blockIdx.x * kWavesPerWg + wave;
+    const bool active = b_raw < n_blocks;
+    const uint32_t b = active ? b_raw : n_blocks - 1; // idle waves shadow the last block
+    cf* lds = reinterpret_cast<cf*>(lds4 + kLdsExch) + wave * kExchangeItems;
+    const cf* twA = reinterpret_cast<const cf*>(lds4 + kLdsTwA);
+    const cf* twB = reinterpret_cast<const cf*>(lds4 + kLdsTwB);
     const cf* x = in + static_cast<size_t>(blockIdx.y) * in_stride + static_cast<size_t>(b) * stride_s;
     float* zo = zpow + static_cast<size_t>(blockIdx.y) * z_stride + static_cast<size_t>(b) * stride_s;
+
+    // stage the FFT-2 twiddle tables (twA ++ twB contiguous in global) and template 0
+    for (int i = tid; i < (kTwAItems + kTwBItems) / 2; i += 512) lds4[kLdsTwA + i] = twAB[i];
+    lds4[kLdsTmpl + tid] = tmpl[tid];
+    lds4[kLdsTmpl + 512 + tid] = tmpl[512 + tid];
 
     cf r[32];
     if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
@@ -128,23 +167,39 @@ __global__ __launch_bounds__(256) void k_correlate(const cf* __restrict__ in, si
             r[2 * n1 + 1] = x[2 * lane + 1 + 128 * n1];
         }
     }
-    fft1_wave(lane, r, lds, tw);
+    fft1_wave(lane, r, lds, tw1a, tw1b);
     cf X[32];
 #pragma unroll
     for (int j = 0; j < 32; ++j) X[j] = r[j];
     float zmax[32];
 #pragma unroll
     for (int j = 0; j < 32; ++j) zmax[j] = -1.0f; // hpp:303
+    __syncthreads();
     for (int bin = 0; bin < n_bins; ++bin) {
-        wave_lds_sync();
-        mul_template(lane, X, r, tmpl + static_cast<size_t>(bin) * 1024); // hpp:247-249
-        fft2_wave(lane, r, lds, tw);                                      // hpp:250-251
+        const int buf = bin & 1;
+        // issue next template's loads now, write them to the other LDS buffer after the FFT
+        float4 t0, t1;
+        const bool more = bin + 1 < n_bins;
+        if (more) {
+            const float4* tn = tmpl + static_cast<size_t>(bin + 1) * 1024;
+            t0 = tn[tid];
+            t1 = tn[512 + tid];
+        }
+        cf p[32], c[32];
+        mul_template(lane, X, p, lds4 + kLdsTmpl + buf * 1024); // hpp:247-249
+        fft2_wave(lane, p, c, lds, twA, twB);                   // hpp:250-251
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
-            const float p = cnorm(r[j]); // hpp:307
-            zmax[j] = p > zmax[j] ? p : zmax[j]; // strict >, first bin wins (hpp:308)
+            const float pw = cnorm(c[j]);          // hpp:307
+            zmax[j] = pw > zmax[j] ? pw : zmax[j]; // strict >, first bin wins (hpp:308)
         }
+        if (more) {
+            lds4[kLdsTmpl + (buf ^ 1) * 1024 + tid] = t0;
+            lds4[kLdsTmpl + (buf ^ 1) * 1024 + 512 + tid] = t1;
+        }
+        __syncthreads(); // next template complete; everyone done with this one
     }
+    if (!active) return;
     // lag k <-> correlation index (N - k) mod N (hpp:300); lanes hold consecutive indices
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
@@ -345,7 +400,9 @@ __global__ __launch_bounds__(64) void k_tags(const cf* __restrict__ in, size_t i
                                              const cf* __restrict__ carry, size_t carry_stride,
                                              uint32_t xc, unsigned long long E0, unsigned long long E1,
                                              uint32_t hist, uint32_t stride_s, int n_bins,
-                                             const float4* __restrict__ tmpl, const cf* __restrict__ tw,
+                                             const float4* __restrict__ tmpl, const cf* __restrict__ tw1a,
+                                             const cf* __restrict__ tw1b, const cf* __restrict__ twA,
+                                             const cf* __restrict__ twB,
                                              const float* __restrict__ zcur, size_t z_stride,
                                              ChanState* __restrict__ st,
                                              const unsigned long long* __restrict__ det, uint32_t det_cap,
@@ -372,7 +429,7 @@ __global__ __launch_bounds__(64) void k_tags(const cf* __restrict__ in, size_t i
         r[2 * n1] = sample_at(cur, car, xc, o + 2 * lane + 128 * n1);
         r[2 * n1 + 1] = sample_at(cur, car, xc, o + 2 * lane + 1 + 128 * n1);
     }
-    fft1_wave(lane, r, lds, tw);
+    fft1_wave(lane, r, lds, tw1a, tw1b);
     cf X[32];
 #pragma unroll
     for (int j = 0; j < 32; ++j) X[j] = r[j];
@@ -390,12 +447,13 @@ __global__ __launch_bounds__(64) void k_tags(const cf* __restrict__ in, size_t i
     const int lane_t = kt & 63, j_t = ((kt >> 6) & 1) * 16 + (kt >> 7);
     for (int bin = 0; bin < n_bins; ++bin) {
         wave_lds_sync();
+        cf c[32];
         mul_template(lane, X, r, tmpl + static_cast<size_t>(bin) * 1024);
-        fft2_wave(lane, r, lds, tw);
+        fft2_wave(lane, r, c, lds, twA, twB);
         cf sel = { 0.f, 0.f };
 #pragma unroll
         for (int j = 0; j < 32; ++j)
-            if (j == j_t) sel = r[j];
+            if (j == j_t) sel = c[j];
         if (lane == lane_t) zbin[bin] = sel;
     }
     wave_lds_sync();
@@ -529,7 +587,7 @@ struct gr4pm_syncword_detection {
     uint32_t max_tiles, det_cap, rec_cap;
     // device
     DevBuf<float4> tmpl;
-    DevBuf<cf> tw;
+    DevBuf<cf> tw; // tw1a ++ tw1b ++ twA ++ twB (fft2048_wave.hpp)
     DevBuf<cf> carry[2];
     DevBuf<float> z[2];
     DevBuf<unsigned long long> bitmap;
@@ -611,9 +669,12 @@ gr4pm_status launch_correlate(gr4pm_syncword_detection* h, const gr4pm_c64* in, 
                               uint32_t n_blocks, float* zout)
 {
     dim3 grid((n_blocks + kWavesPerWg - 1) / kWavesPerWg, static_cast<unsigned>(h->n_channels));
-    hipLaunchKernelGGL(k_correlate, grid, dim3(256), 0, h->stream, reinterpret_cast<const cf*>(in),
-                       in_stride, n_blocks, static_cast<uint32_t>(h->S), h->n_bins, h->tmpl.p, h->tw.p,
-                       zout, h->z_stride);
+    const cf* tw1a = h->tw.p;
+    const cf* tw1b = tw1a + kTw1aItems;
+    const cf* twA = tw1b + kTw1bItems;
+    hipLaunchKernelGGL(k_correlate, grid, dim3(512), 0, h->stream, reinterpret_cast<const cf*>(in),
+                       in_stride, n_blocks, static_cast<uint32_t>(h->S), h->n_bins, h->tmpl.p, tw1a, tw1b,
+                       reinterpret_cast<const float4*>(twA), zout, h->z_stride);
     GR4PM_HIP_TRY(hipGetLastError());
     return GR4PM_OK;
 }
@@ -714,11 +775,14 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
                                 static_cast<float>(t1.real()), static_cast<float>(t1.imag()));
             }
     }
-    std::vector<cf> tw(kFftN);
-    for (int k = 0; k < kFftN; ++k) {
-        const double ang = -2.0 * M_PI * k / kFftN;
-        tw[k] = { static_cast<float>(std::cos(ang)), static_cast<float>(std::sin(ang)) };
-    }
+    std::vector<cf> tw(kTw1aItems + kTw1bItems + kTwAItems + kTwBItems);
+    build_twiddle_tables(
+        [](int k) {
+            const double ang = -2.0 * M_PI * k / kFftN;
+            return cf{ static_cast<float>(std::cos(ang)), static_cast<float>(std::sin(ang)) };
+        },
+        tw.data(), tw.data() + kTw1aItems, tw.data() + kTw1aItems + kTw1bItems,
+        tw.data() + kTw1aItems + kTw1bItems + kTwAItems);
 
     h->xc = static_cast<uint32_t>(round_up(h->hist + h->S + 2, 64));
     h->zc = static_cast<uint32_t>(round_up(2 * h->T + 2, 64));
@@ -844,8 +908,9 @@ gr4pm_status gr4pm_syncword_detection_process(gr4pm_syncword_detection* h, const
                        in_stride, carry, static_cast<size_t>(h->xc), h->xc,
                        static_cast<unsigned long long>(E0), static_cast<unsigned long long>(E1),
                        static_cast<uint32_t>(h->hist), static_cast<uint32_t>(h->S), h->n_bins, h->tmpl.p,
-                       h->tw.p, zcur + h->zc, h->z_stride, h->st.p, h->det.p, h->det_cap, h->rec.p,
-                       h->rec_cap);
+                       h->tw.p, h->tw.p + kTw1aItems, h->tw.p + kTw1aItems + kTw1bItems,
+                       h->tw.p + kTw1aItems + kTw1bItems + kTwAItems, zcur + h->zc, h->z_stride, h->st.p,
+                       h->det.p, h->det_cap, h->rec.p, h->rec_cap);
     GR4PM_HIP_TRY(hipMemcpyAsync(h->st_host.p, h->st.p, sizeof(ChanState) * nch, hipMemcpyDeviceToHost, s));
     hipLaunchKernelGGL(k_compact_pending, dim3((nch + 63) / 64), dim3(64), 0, s, h->st.p, h->det.p,
                        h->det_cap, static_cast<unsigned long long>(E1), static_cast<uint32_t>(h->hist),

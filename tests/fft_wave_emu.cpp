@@ -31,11 +31,13 @@ static std::vector<cd> dft(const std::vector<cd>& x)
 
 int main()
 {
-    std::vector<cf> tw(kFftN);
-    for (int k = 0; k < kFftN; ++k) {
-        const double a = -2.0 * M_PI * k / kFftN;
-        tw[k] = { static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a)) };
-    }
+    std::vector<cf> tw1a(kTw1aItems), tw1b(kTw1bItems), twA(kTwAItems), twB(kTwBItems);
+    build_twiddle_tables(
+        [](int k) {
+            const double a = -2.0 * M_PI * k / kFftN;
+            return cf{ static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a)) };
+        },
+        tw1a.data(), tw1b.data(), twA.data(), twB.data());
     std::mt19937 rng(42);
     std::normal_distribution<float> g(0.f, 1.f);
     std::vector<cf> x(kFftN), t(kFftN);
@@ -48,12 +50,18 @@ int main()
     for (int l = 0; l < kLanes; ++l)
         for (int n1 = 0; n1 < 16; ++n1)
             for (int e = 0; e < 2; ++e) r[l][2 * n1 + e] = x[2 * l + e + 128 * n1];
-    for (int l = 0; l < kLanes; ++l) fft1_pass1(l, r[l].data(), tw.data());
-    for (int l = 0; l < kLanes; ++l) fft1_store1(l, r[l].data(), lds.data());
-    for (int l = 0; l < kLanes; ++l) fft1_load2(l, r[l].data(), lds.data());
-    for (int l = 0; l < kLanes; ++l) fft1_pass2(l, r[l].data(), tw.data());
-    for (int l = 0; l < kLanes; ++l) fft1_store2(l, r[l].data(), lds.data());
-    for (int l = 0; l < kLanes; ++l) fft1_load3(l, r[l].data(), lds.data());
+    // every phase runs for all 64 lanes before the next one starts (what the in-order LDS
+    // pipeline of one wave guarantees on the GPU); exchanges run in two half-rounds
+    for (int l = 0; l < kLanes; ++l) fft1_pass1(l, r[l].data(), tw1a.data());
+    for (int h = 0; h < 2; ++h) {
+        for (int l = 0; l < kLanes; ++l) fft1_store1(l, r[l].data(), lds.data(), h);
+        for (int l = 0; l < kLanes; ++l) fft1_load2(l, r[l].data(), lds.data(), h);
+    }
+    for (int l = 0; l < kLanes; ++l) fft1_pass2(l, r[l].data(), tw1b.data());
+    for (int h = 0; h < 2; ++h) {
+        for (int l = 0; l < kLanes; ++l) fft1_store2(l, r[l].data(), lds.data(), h);
+        for (int l = 0; l < kLanes; ++l) fft1_load3(l, r[l].data(), lds.data(), h);
+    }
     for (int l = 0; l < kLanes; ++l) fft1_pass3(r[l].data());
 
     std::vector<cd> xd(kFftN);
@@ -80,12 +88,24 @@ int main()
             r[l][j] = cmul(r[l][j], t[k]);
             P[k] = cd(r[l][j].x, r[l][j].y);
         }
-    for (int l = 0; l < kLanes; ++l) fft2_passA(l, r[l].data(), tw.data());
-    for (int l = 0; l < kLanes; ++l) fft2_storeA(l, r[l].data(), lds.data());
-    for (int l = 0; l < kLanes; ++l) fft2_loadB(l, r[l].data(), lds.data());
-    for (int l = 0; l < kLanes; ++l) fft2_passB(l, r[l].data(), tw.data());
-    for (int l = 0; l < kLanes; ++l) fft2_storeB(l, r[l].data(), lds.data());
-    for (int l = 0; l < kLanes; ++l) fft2_loadC(l, r[l].data(), lds.data());
+    for (int l = 0; l < kLanes; ++l) fft2_passA(l, r[l].data(), twA.data());
+    {
+        // loadB overwrites r[16h..] while storeA of the second half still needs r[8q+4..8q+7]:
+        // the kernel keeps the pass-A results in a second register set, emulate that
+        auto ra = r;
+        for (int h = 0; h < 2; ++h) {
+            for (int l = 0; l < kLanes; ++l) fft2_storeA(l, ra[l].data(), lds.data(), h);
+            for (int l = 0; l < kLanes; ++l) fft2_loadB(l, r[l].data(), lds.data(), h);
+        }
+    }
+    for (int l = 0; l < kLanes; ++l) fft2_passB(l, r[l].data(), twB.data());
+    {
+        auto rb = r;
+        for (int h = 0; h < 2; ++h) {
+            for (int l = 0; l < kLanes; ++l) fft2_storeB(l, rb[l].data(), lds.data(), h);
+            for (int l = 0; l < kLanes; ++l) fft2_loadC(l, r[l].data(), lds.data(), h);
+        }
+    }
     for (int l = 0; l < kLanes; ++l) fft2_passC(r[l].data());
     const auto C = dft(P);
     maxref = maxerr = 0;
