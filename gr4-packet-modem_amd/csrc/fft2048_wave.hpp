@@ -25,14 +25,73 @@
 
 namespace gr4pm {
 
+// complex<float> as a 2-lane vector so that every complex add / twiddle multiply maps onto
+// one or two packed VALU instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 with
+// op_sel / neg modifiers) instead of scalar pairs plus register shuffles.
+#if defined(__clang__)
+typedef float cf __attribute__((ext_vector_type(2)));
+GR4PM_HD cf mk(float x, float y) { return cf{ x, y }; }
+GR4PM_HD cf swap_xy(cf a) { return a.yx; }
+GR4PM_HD cf dup_x(cf a) { return a.xx; }
+GR4PM_HD cf dup_y(cf a) { return a.yy; }
+#else
 struct cf {
     float x, y;
 };
+GR4PM_HD cf mk(float x, float y) { return cf{ x, y }; }
 GR4PM_HD cf operator+(cf a, cf b) { return { a.x + b.x, a.y + b.y }; }
 GR4PM_HD cf operator-(cf a, cf b) { return { a.x - b.x, a.y - b.y }; }
-GR4PM_HD cf cmul(cf a, cf b) { return { a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x }; }
-GR4PM_HD cf mul_mj(cf a) { return { a.y, -a.x }; } // a * (-j)
-GR4PM_HD float cnorm(cf a) { return a.x * a.x + a.y * a.y; }
+GR4PM_HD cf operator*(cf a, cf b) { return { a.x * b.x, a.y * b.y }; }
+GR4PM_HD cf operator*(float a, cf b) { return { a * b.x, a * b.y }; }
+GR4PM_HD cf swap_xy(cf a) { return { a.y, a.x }; }
+GR4PM_HD cf dup_x(cf a) { return { a.x, a.x }; }
+GR4PM_HD cf dup_y(cf a) { return { a.y, a.y }; }
+#endif
+// (x, y) -> (x, -y) and (-x, y)
+GR4PM_HD cf neg_y(cf a) { return mk(a.x, -a.y); }
+GR4PM_HD cf neg_x(cf a) { return mk(-a.x, a.y); }
+GR4PM_HD cf mul_mj(cf a) { return neg_y(swap_xy(a)); } // a * (-j) = (a.y, -a.x)
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// The swizzle (op_sel) and per-half sign (neg_lo / neg_hi) source modifiers of the packed
+// FP32 instructions make "b +- (-j) a" one instruction and a full complex multiply two; hipcc
+// does not fold a per-half negation by itself (it emits v_xor), hence the explicit forms.
+// b + (-j) a = (b.x + a.y, b.y - a.x)
+__device__ __forceinline__ cf add_mj(cf b, cf a)
+{
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(b), "v"(a));
+    return r;
+}
+// b - (-j) a = (b.x - a.y, b.y + a.x)
+__device__ __forceinline__ cf sub_mj(cf b, cf a)
+{
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(b), "v"(a));
+    return r;
+}
+// a * w = (a.x w.x - a.y w.y, a.x w.y + a.y w.x) for a run-time twiddle w
+__device__ __forceinline__ cf cmul(cf a, cf w)
+{
+    cf t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+        : "=v"(r)
+        : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+#else
+GR4PM_HD cf add_mj(cf b, cf a) { return b + mul_mj(a); }
+GR4PM_HD cf sub_mj(cf b, cf a) { return b - mul_mj(a); }
+GR4PM_HD cf cmul(cf a, cf w) { return dup_x(a) * w + dup_y(a) * neg_x(swap_xy(w)); }
+#endif
+// multiply by a compile-time constant twiddle: plain arithmetic, the compiler folds the signs
+GR4PM_HD cf cmulc(cf a, cf w) { return dup_x(a) * w + dup_y(a) * neg_x(swap_xy(w)); }
+GR4PM_HD float cnorm(cf a)
+{
+    const cf s = a * a;
+    return s.x + s.y;
+}
 
 constexpr int kFftN = 2048;
 constexpr int kLanes = 64;
@@ -41,7 +100,7 @@ constexpr int kPtsPerLane = 32;
 // half-rounds (8 of 16 rows / 64 of 128 rows at a time) so one wave needs 9 KiB, not 18.
 constexpr int kS1 = 136; // FFT-1 exchange 1: 8 rows [k1] of 128 (+8 pad) per half
 constexpr int kS2 = 18;  // FFT-1 exchange 2: 64 rows [k1][m] of 16 (+2 pad) per half
-constexpr int kSA = 17;  // FFT-2 exchange A: 64 rows [ka][m] of 16 (+1 pad) per half
+constexpr int kSA = 18;  // FFT-2 exchange A: 64 rows [ka][m] of 16 (+2 pad) per half
 constexpr int kSB = 18;  // FFT-2 exchange B: 64 rows [k2][ka] of 16 (+2 pad) per half
 constexpr int kExchangeItems = 64 * 18; // 1152 complex = 9 KiB per wave
 
@@ -73,11 +132,11 @@ inline void build_twiddle_tables(W w, cf* tw1a, cf* tw1b, cf* twA, cf* twB)
 // ---- small DFTs, forward sign, natural-order output, everything in registers ----
 GR4PM_HD void dft4(cf& a0, cf& a1, cf& a2, cf& a3)
 {
-    const cf t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = mul_mj(a1 - a3);
+    const cf t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, d = a1 - a3;
     a0 = t0 + t2;
-    a1 = t1 + t3;
+    a1 = add_mj(t1, d); // t1 + (-j) d
     a2 = t0 - t2;
-    a3 = t1 - t3;
+    a3 = sub_mj(t1, d);
 }
 GR4PM_HD void dft8(cf* v)
 {
@@ -85,17 +144,16 @@ GR4PM_HD void dft8(cf* v)
     dft4(v[0], v[2], v[4], v[6]);
     dft4(v[1], v[3], v[5], v[7]);
     const cf e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
-    const cf o0 = v[1];
-    const cf o1 = { c * (v[3].x + v[3].y), c * (v[3].y - v[3].x) };  // * W8^1
-    const cf o2 = mul_mj(v[5]);                                      // * W8^2
-    const cf o3 = { c * (v[7].y - v[7].x), -c * (v[7].x + v[7].y) }; // * W8^3
+    const cf o0 = v[1], o2s = v[5];
+    const cf o1 = c * add_mj(v[3], v[3]);    // * W8^1 = c (1 - j)
+    const cf o3 = (-c) * sub_mj(v[7], v[7]); // * W8^3 = -c (1 + j)
     v[0] = e0 + o0;
     v[1] = e1 + o1;
-    v[2] = e2 + o2;
+    v[2] = add_mj(e2, o2s); // * W8^2 = -j
     v[3] = e3 + o3;
     v[4] = e0 - o0;
     v[5] = e1 - o1;
-    v[6] = e2 - o2;
+    v[6] = sub_mj(e2, o2s);
     v[7] = e3 - o3;
 }
 GR4PM_HD void dft16(cf* v)
@@ -111,17 +169,21 @@ GR4PM_HD void dft16(cf* v)
     dft8(e);
     dft8(o);
     // o[k] *= W16^k = cos(pi k/8) - j sin(pi k/8)
-    o[1] = cmul(o[1], cf{ c1, -s1 });
-    o[2] = cf{ c8 * (o[2].x + o[2].y), c8 * (o[2].y - o[2].x) };
-    o[3] = cmul(o[3], cf{ s1, -c1 });
-    o[4] = mul_mj(o[4]);
-    o[5] = cmul(o[5], cf{ -s1, -c1 });
-    o[6] = cf{ c8 * (o[6].y - o[6].x), -c8 * (o[6].x + o[6].y) };
-    o[7] = cmul(o[7], cf{ -c1, -s1 });
+    o[1] = cmulc(o[1], mk(c1, -s1));
+    o[2] = c8 * add_mj(o[2], o[2]);
+    o[3] = cmulc(o[3], mk(s1, -c1));
+    o[5] = cmulc(o[5], mk(-s1, -c1));
+    o[6] = (-c8) * sub_mj(o[6], o[6]);
+    o[7] = cmulc(o[7], mk(-c1, -s1));
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        v[k] = e[k] + o[k];
-        v[k + 8] = e[k] - o[k];
+        if (k == 4) { // W16^4 = -j
+            v[4] = add_mj(e[4], o[4]);
+            v[12] = sub_mj(e[4], o[4]);
+        } else {
+            v[k] = e[k] + o[k];
+            v[k + 8] = e[k] - o[k];
+        }
     }
 }
 

@@ -107,8 +107,8 @@ __device__ __forceinline__ void mul_template(int lane, const cf* X, cf* r, const
 #pragma unroll
     for (int jp = 0; jp < 16; ++jp) {
         const float4 t = tp[jp * 64 + lane];
-        r[2 * jp] = cmul(X[2 * jp], cf{ t.x, t.y });
-        r[2 * jp + 1] = cmul(X[2 * jp + 1], cf{ t.z, t.w });
+        r[2 * jp] = cmul(X[2 * jp], mk(t.x, t.y));
+        r[2 * jp + 1] = cmul(X[2 * jp + 1], mk(t.z, t.w));
     }
 }
 
@@ -157,8 +157,8 @@ __global__ __launch_bounds__(512, 2) void k_correlate(const cf* __restrict__ in,
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
             const float4 v = xp[lane + 64 * n1];
-            r[2 * n1] = cf{ v.x, v.y };
-            r[2 * n1 + 1] = cf{ v.z, v.w };
+            r[2 * n1] = mk(v.x, v.y);
+            r[2 * n1 + 1] = mk(v.z, v.w);
         }
     } else {
 #pragma unroll
@@ -190,8 +190,9 @@ __global__ __launch_bounds__(512, 2) void k_correlate(const cf* __restrict__ in,
         fft2_wave(lane, p, c, lds, twA, twB);                   // hpp:250-251
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
-            const float pw = cnorm(c[j]);          // hpp:307
-            zmax[j] = pw > zmax[j] ? pw : zmax[j]; // strict >, first bin wins (hpp:308)
+            // hpp:307-308: the best bin's power; max() == the strict-> scan for the VALUE (the
+            // bin index is recomputed by k_tags for detections only)
+            zmax[j] = fmaxf(zmax[j], cnorm(c[j]));
         }
         if (more) {
             lds4[kLdsTmpl + (buf ^ 1) * 1024 + tid] = t0;
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(64) void k_tags(const cf* __restrict__ in, size_t i
         cf c[32];
         mul_template(lane, X, r, tmpl + static_cast<size_t>(bin) * 1024);
         fft2_wave(lane, r, c, lds, twA, twB);
-        cf sel = { 0.f, 0.f };
+        cf sel = mk(0.f, 0.f);
 #pragma unroll
         for (int j = 0; j < 32; ++j)
             if (j == j_t) sel = c[j];
@@ -459,7 +460,7 @@ __global__ __launch_bounds__(64) void k_tags(const cf* __restrict__ in, size_t i
     wave_lds_sync();
     if (lane == 0) {
         int best = 0;
-        cf z = { 0.f, 0.f };
+        cf z = mk(0.f, 0.f);
         float zp = -1.0f;
         for (int bin = 0; bin < n_bins; ++bin) { // hpp:305-313
             const float p = cnorm(zbin[bin]);
@@ -779,7 +780,7 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
     build_twiddle_tables(
         [](int k) {
             const double ang = -2.0 * M_PI * k / kFftN;
-            return cf{ static_cast<float>(std::cos(ang)), static_cast<float>(std::sin(ang)) };
+            return mk(static_cast<float>(std::cos(ang)), static_cast<float>(std::sin(ang)));
         },
         tw.data(), tw.data() + kTw1aItems, tw.data() + kTw1aItems + kTw1bItems,
         tw.data() + kTw1aItems + kTw1bItems + kTwAItems);

@@ -35,14 +35,14 @@ int main()
     build_twiddle_tables(
         [](int k) {
             const double a = -2.0 * M_PI * k / kFftN;
-            return cf{ static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a)) };
+            return mk(static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a)));
         },
         tw1a.data(), tw1b.data(), twA.data(), twB.data());
     std::mt19937 rng(42);
     std::normal_distribution<float> g(0.f, 1.f);
     std::vector<cf> x(kFftN), t(kFftN);
-    for (auto& v : x) v = { g(rng), g(rng) };
-    for (auto& v : t) v = { g(rng), g(rng) };
+    for (auto& v : x) v = mk(g(rng), g(rng));
+    for (auto& v : t) v = mk(g(rng), g(rng));
 
     std::vector<cf> lds(kExchangeItems);
     std::vector<std::vector<cf>> r(kLanes, std::vector<cf>(kPtsPerLane));
