@@ -4,9 +4,11 @@
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched under
 torch.distributed.run, one rank per GPU.  Prints ONE JSON line on rank 0.
 
-Workload (BASELINE.json configs[1]): one channel per GPU, SyncwordDetection (overlap-save FFT
-correlator, 9 frequency bins, detector, tags, delayed pass-through) on a synthetic
-3.2 Msps-shaped burst stream (64-symbol BPSK syncword + 128-symbol header + QPSK payload,
+Workload (BASELINE.json configs[1]): one channel per GPU, the full RX front end of
+PacketReceiver (packet_receiver.hpp:34-127): SyncwordDetection (overlap-save FFT correlator,
+9 frequency bins, detector, tags, delayed pass-through) -> SyncwordDetectionFilter (tag gate)
+-> CoarseFrequencyCorrection -> SymbolFilter (32-arm RRC PFB, /4) -> SyncwordWipeoff ->
+CostasLoop, on a synthetic 3.2 Msps-shaped burst stream (64-symbol BPSK syncword + 128-symbol header + QPSK payload,
 45-tap unit-norm RRC at 4 samples/symbol, per-packet CFO, AWGN) already resident in HBM.
 A step is one process() call over one batch of `--items` samples; the stream state carries
 from step to step exactly as in the reference block.  With N GPUs every rank runs its own
@@ -113,6 +115,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--items", type=int, default=1 << 26, help="samples per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--detector-only", action="store_true", help="time SyncwordDetection alone")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -130,14 +133,19 @@ def main():
     bpsk = np.array([1, -1], dtype=np.complex64)
     n_items = args.items
     x, n_pkt = burst_stream(n_items, rrc, seed=1 + rank, device=device)
-    sd = pkg.SyncwordDetection(rrc, SYNCWORD, bpsk, -BINS, BINS, power_threshold=9.5, max_items=n_items)
+    rx = pkg.PacketReceiver(SPS, BINS, 9.5, "QPSK", max_items=n_items)
+    sd = rx.syncword_detection
     out_keep = None
 
     def step():
         nonlocal out_keep
-        st, out, tags, n = sd.process_bulk(x, want_output=True, tags_cap=max(64, 2 * n_pkt + 64))
-        out_keep = out
-        return n, tags.size
+        if args.detector_only:
+            st, out, tags, n = sd.process_bulk(x, want_output=True, tags_cap=max(64, 2 * n_pkt + 64))
+            out_keep = out
+            return n, tags.size
+        res = rx.process_bulk(x, 1500, tags_cap=max(64, 2 * n_pkt + 64))  # payload length of the generator
+        out_keep = res["symbols"]
+        return res["consumed"], res["tags"].size
 
     for _ in range(args.warmup):
         step()
@@ -208,8 +216,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: 1 channel/GPU, SyncwordDetection 9 bins (FFT 2048, 64-sym syncword, "
-                                   "4 sps RRC) on resident burst+AWGN stream",
+            "config": {"workload": ("SyncwordDetection only" if args.detector_only else
+                                    "configs[1]: 1 channel/GPU, full RX front end (SyncwordDetection 9 bins FFT 2048 + tag "
+                                    "gate + CFC + 32-arm RRC SymbolFilter + wipe-off + Costas)") +
+                                   " on resident burst+AWGN stream",
                        "items_per_step_per_gpu": n_items, "freq_bins": 2 * BINS + 1, "tags_per_step": n_tags // max(args.steps, 1),
                        "parallelism": f"channel-per-gpu x{world}"},
             "roofline": roofline,

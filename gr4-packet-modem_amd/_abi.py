@@ -101,6 +101,7 @@ EXPORTS = [
     "gr4pm_syncword_detection_correlate_only",
     "gr4pm_syncword_detection_filter_create", "gr4pm_syncword_detection_filter_destroy",
     "gr4pm_syncword_detection_filter_reset", "gr4pm_syncword_detection_filter_process",
+    "gr4pm_syncword_detection_filter_gate",
     "gr4pm_rotator_create", "gr4pm_rotator_destroy", "gr4pm_rotator_reset", "gr4pm_rotator_process",
     "gr4pm_costas_loop_create", "gr4pm_costas_loop_destroy", "gr4pm_costas_loop_reset",
     "gr4pm_costas_loop_coeffs", "gr4pm_costas_loop_set", "gr4pm_costas_loop_process",
@@ -154,6 +155,7 @@ def lib():
     L.gr4pm_syncword_detection_filter_reset.argtypes = [vp]
     L.gr4pm_syncword_detection_filter_process.argtypes = [vp, vp, sz, vp, sz, C.c_int, vp, sz, sz, szp, szp, szp,
                                                           C.POINTER(C.c_int)]
+    L.gr4pm_syncword_detection_filter_gate.argtypes = [vp, vp, sz, vp, sz, C.c_int, vp, szp]
     L.gr4pm_rotator_create.argtypes = [C.POINTER(RotatorParams), C.POINTER(vp)]
     L.gr4pm_rotator_destroy.argtypes = [vp]
     L.gr4pm_rotator_destroy.restype = None

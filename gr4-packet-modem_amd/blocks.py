@@ -169,6 +169,22 @@ class SyncwordDetectionFilter:
             n_ignored, C.byref(c), C.byref(hc), C.byref(ic), C.byref(tf)), "SyncwordDetectionFilter.processBulk")
         return c.value, hc.value, ic.value, tf.value
 
+    def gate(self, tag_index, headers=(), per_tag=False):
+        """tag gate without the copy (device-resident chains): which syncword tags pass.
+        headers[k] answers the k-th accepted tag (per_tag: tag k if accepted): packet_length, or
+        None for invalid_header."""
+        idx = np.ascontiguousarray(tag_index, dtype=np.uint64)
+        msgs = (_abi.HeaderMsg * max(len(headers), 1))()
+        for i, hm in enumerate(headers):
+            msgs[i].packet_length = 0 if hm is None else int(hm)
+            msgs[i].invalid_header = 1 if hm is None else 0
+        acc = np.zeros(max(idx.size, 1), dtype=np.uint8)
+        used = C.c_size_t(0)
+        check(lib().gr4pm_syncword_detection_filter_gate(self._h, _np_ptr(idx), idx.size, msgs, len(headers),
+                                                         1 if per_tag else 0, _np_ptr(acc), C.byref(used)),
+              "SyncwordDetectionFilter.gate")
+        return acc[: idx.size].astype(bool), used.value
+
     def __del__(self):
         if getattr(self, "_h", None):
             lib().gr4pm_syncword_detection_filter_destroy(self._h)
@@ -388,3 +404,62 @@ class PfbArbResampler:
         if getattr(self, "_h", None):
             lib().gr4pm_pfb_arb_resampler_destroy(self._h)
             self._h = None
+
+
+# CCSDS syncword of the modem, packet_receiver.hpp:45-59
+SYNCWORD = np.array(
+    [0, 0, 0, 0, 0, 0, 1, 1, 0, 1, 0, 0, 0, 1, 1, 1, 0, 1, 1, 1, 0, 1, 1, 0, 1, 1, 0, 0, 0, 1, 1, 1,
+     0, 0, 1, 0, 0, 1, 1, 1, 0, 0, 1, 0, 1, 0, 0, 0, 1, 0, 0, 1, 0, 1, 0, 1, 1, 0, 1, 1, 0, 0, 0, 0],
+    dtype=np.uint8)
+
+
+class PacketReceiver:
+    """The sample-rate / symbol-rate front half of gr::packet_modem::PacketReceiver
+    (packet_receiver.hpp:34-127,191-232): SyncwordDetection -> SyncwordDetectionFilter ->
+    CoarseFrequencyCorrection -> SymbolFilter -> SyncwordWipeoff -> CostasLoop, with every
+    constant the reference constructor fixes.  Everything after CostasLoop (header decode,
+    LDPC, CRC) is outside the hot path; the `parsed_header` feedback that the filter waits for
+    is supplied by the caller (`header_fn(tag) -> packet_length | None`, or a constant)."""
+
+    def __init__(self, samples_per_symbol=4, syncword_freq_bins=4, syncword_threshold=9.5,
+                 costas_constellation="QPSK", max_items=1 << 22):
+        sps = samples_per_symbol
+        self.samples_per_symbol = sps
+        rrc = root_raised_cosine(1.0, float(sps), 1.0, 0.35, sps * 11)            # :60-65
+        norm = np.float32(0.0)
+        for v in rrc:                                                            # :67-74 (float accumulate)
+            norm = np.float32(norm + np.float32(v * v))
+        norm = np.float32(np.sqrt(norm))
+        self.rrc_taps = (rrc / norm).astype(np.float32)
+        bpsk = np.array([1, -1], dtype=np.complex64)
+        self.syncword_detection = SyncwordDetection(                              # :76-83
+            self.rrc_taps, SYNCWORD, bpsk, -syncword_freq_bins, syncword_freq_bins,
+            samples_per_symbol=sps, power_threshold=syncword_threshold, max_items=max_items)
+        self.syncword_detection_filter = SyncwordDetectionFilter(sps)             # :84-85
+        self.freq_correction = CoarseFrequencyCorrection((self.rrc_taps.size - 1) // 2 + sps)  # :94-95
+        arms = 32                                                                 # :96
+        pfb = root_raised_cosine(float(arms) / float(norm), float(arms * sps), 1.0, 0.35, arms * sps * 11)[:-1]  # :100-110
+        self.symbol_filter = SymbolFilter(pfb, arms, sps, self.rrc_taps.size - 1)  # :111-115
+        self.syncword_wipeoff = SyncwordWipeoff(np.where(SYNCWORD == 1, -1.0, 1.0).astype(np.float32))  # :117-122
+        self.costas_loop = CostasLoop(0.01, costas_constellation)                 # :125
+
+    def process_bulk(self, x, header_fn=None, tags_cap=4096):
+        """x: complex64 CUDA tensor.  Returns dict(consumed, symbols, tags, detector_tags):
+        symbols = CostasLoop output (one per symbol), tags = symbol-rate tags."""
+        st, y, det_tags, n = self.syncword_detection.process_bulk(x, want_output=True, tags_cap=tags_cap)
+        if st != 0:
+            return {"status": st, "consumed": 0, "symbols": None, "tags": det_tags, "detector_tags": det_tags}
+        base = self.syncword_detection._items_consumed - n        # absolute index of y[0]
+        # SyncwordDetectionFilter: gate the tags; the samples pass unchanged
+        if callable(header_fn):
+            headers = [header_fn(t) for t in det_tags]
+        else:  # a constant packet_length (or None == every header invalid)
+            headers = [header_fn] * det_tags.size
+        acc, _ = self.syncword_detection_filter.gate(base + det_tags["index"], headers, per_tag=True)
+        tags = det_tags[acc]
+        z = self.freq_correction.process_bulk(y, tags)
+        sym, sym_tags, consumed = self.symbol_filter.process_bulk(z, tags)
+        w = self.syncword_wipeoff.process_bulk(sym, sym_tags)
+        c = self.costas_loop.process_bulk(w, sym_tags)
+        return {"status": 0, "consumed": n, "symbols": c, "tags": sym_tags, "detector_tags": det_tags,
+                "accepted": acc}

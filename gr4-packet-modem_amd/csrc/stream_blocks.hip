@@ -773,6 +773,11 @@ struct gr4pm_syncword_detection_filter {
     hipStream_t stream;
     bool in_packet = false; // :35-37
     size_t position = 0, block_until = 0;
+    // gate(): absolute item index where the current packet span ends (exclusive)
+    bool gate_in_packet = false;
+    uint64_t gate_start = 0, gate_end = 0;
+    bool gate_end_known = false;
+    size_t gate_hdr_idx = static_cast<size_t>(-1); // per-tag mode: header slot of the open packet
 };
 
 extern "C" {
@@ -797,6 +802,7 @@ gr4pm_status gr4pm_syncword_detection_filter_reset(gr4pm_syncword_detection_filt
 {
     if (!h) return GR4PM_ERR_INVALID;
     h->in_packet = false; // start(), :52
+    h->gate_in_packet = false;
     return GR4PM_OK;
 }
 
@@ -876,6 +882,79 @@ gr4pm_status gr4pm_syncword_detection_filter_process(gr4pm_syncword_detection_fi
 }
 
 } // extern "C"
+
+extern "C" gr4pm_status gr4pm_syncword_detection_filter_gate(gr4pm_syncword_detection_filter* h,
+                                                             const uint64_t* tag_index, size_t n_tags,
+                                                             const gr4pm_header_msg* headers, size_t n_headers,
+                                                             int headers_per_tag, uint8_t* accepted,
+                                                             size_t* headers_used)
+{
+    if (!h || !accepted || !headers_used) return GR4PM_ERR_INVALID;
+    if (headers_per_tag && n_headers != n_tags) return GR4PM_ERR_INVALID;
+    *headers_used = 0;
+    const uint64_t allowed = h->sps * (h->syncword_size + h->header_size + h->allowed_margin); // :164-165
+    size_t hu = 0;
+    for (size_t i = 0; i < n_tags; ++i) {
+        const uint64_t at = tag_index[i];
+        if (h->gate_in_packet) {
+            // resolve the pending header before looking at this tag: the reference cannot get
+            // past `allowed` items of the packet without it (:166-185)
+            if (!h->gate_end_known && (headers_per_tag ? h->gate_hdr_idx < n_headers : hu < n_headers)) {
+                const gr4pm_header_msg& m = headers_per_tag ? headers[h->gate_hdr_idx] : headers[hu];
+                ++hu;
+                uint64_t block_until = 1; // invalid header / ignored syncword, :139,:159
+                if (!m.invalid_header) {
+                    if (m.packet_length == 0) {
+                        set_error("received packet_length = 0");
+                        return GR4PM_ERR_INVALID;
+                    }
+                    block_until = h->sps * (h->header_size + h->syncword_size - h->allowed_margin +
+                                            (m.packet_length + 4) * 4); // :146-151
+                }
+                h->gate_end = h->gate_start + std::max<uint64_t>(allowed, block_until);
+                h->gate_end_known = true;
+            }
+            // inside the first `allowed` items the span is open whatever the header says
+            const uint64_t end = h->gate_end_known ? h->gate_end : h->gate_start + allowed;
+            if (at < end) {
+                accepted[i] = 0; // :83-88 dropped while _in_packet
+                continue;
+            }
+            if (!h->gate_end_known) {
+                // a tag beyond `allowed` with the header still unknown: the caller has not
+                // supplied the message the reference would be waiting for
+                set_error("parsed_header message missing for the packet at item %llu",
+                          static_cast<unsigned long long>(h->gate_start));
+                return GR4PM_INSUFFICIENT_INPUT_ITEMS;
+            }
+            h->gate_in_packet = false;
+        }
+        accepted[i] = 1; // :85-97
+        h->gate_in_packet = true;
+        h->gate_start = at;
+        h->gate_end_known = false;
+        h->gate_hdr_idx = i;
+    }
+    if (headers_per_tag && h->gate_in_packet && !h->gate_end_known && h->gate_hdr_idx < n_headers) {
+        // resolve the last accepted tag of this call now: its header will not be re-presented
+        const gr4pm_header_msg& m = headers[h->gate_hdr_idx];
+        uint64_t block_until = 1;
+        if (!m.invalid_header) {
+            if (m.packet_length == 0) {
+                set_error("received packet_length = 0");
+                return GR4PM_ERR_INVALID;
+            }
+            block_until =
+                h->sps * (h->header_size + h->syncword_size - h->allowed_margin + (m.packet_length + 4) * 4);
+        }
+        h->gate_end = h->gate_start + std::max<uint64_t>(allowed, block_until);
+        h->gate_end_known = true;
+        ++hu;
+    }
+    h->gate_hdr_idx = static_cast<size_t>(-1);
+    *headers_used = hu;
+    return GR4PM_OK;
+}
 
 // ------------------------------------------------------------------ InterpolatingFirFilter
 struct gr4pm_interp_fir {

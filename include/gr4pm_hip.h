@@ -147,6 +147,19 @@ gr4pm_status gr4pm_syncword_detection_filter_process(
     size_t n_ignored, size_t* consumed, size_t* headers_consumed, size_t* ignored_consumed,
     int* tag_out_flags);
 
+/* Tag gate only (no sample copy), for device-resident chains where the filter's copy is folded
+ * into its neighbours: replays :75-105,134-185 over a sorted list of syncword tag indices
+ * (absolute item indices of the stream).  headers_per_tag == 0: headers[k] is the parsed_header
+ * message that answers the k-th ACCEPTED tag; != 0: headers[i] answers tag i if it is accepted
+ * (n_headers == n_tags).  The reference blocks the stream until that message arrives
+ * (:164-185), so the outcome does not depend on message timing.  accepted[i] = 1 when tag i
+ * passes.  State (in-packet span) carries across calls.  *headers_used = messages consumed. */
+gr4pm_status gr4pm_syncword_detection_filter_gate(gr4pm_syncword_detection_filter* h,
+                                                  const uint64_t* tag_index, size_t n_tags,
+                                                  const gr4pm_header_msg* headers, size_t n_headers,
+                                                  int headers_per_tag, uint8_t* accepted,
+                                                  size_t* headers_used);
+
 /* ------------------------------------------------------------------------------------
  * CoarseFrequencyCorrection<float> -- coarse_frequency_correction.hpp:20-99
  * Rotator<float>                   -- rotator.hpp:20-65

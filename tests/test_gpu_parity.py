@@ -391,3 +391,88 @@ def test_pfb_arb_resampler(pkg):
     want, _ = orc.pfb_arb_resampler(x, 1.0 + 1.2e-6, taps, 32, rate_is_double=False)
     got = np.concatenate([host(y1), host(y2)])
     assert np.array_equal(bits(got), bits(want[: got.size])) and abs(got.size - want.size) <= 1
+
+
+# ------------------------------------------------------------------ SDF gate + receiver chain
+def test_syncword_detection_filter_gate_matches_process(pkg):
+    """the copy-free tag gate == the per-chunk state machine (syncword_detection_filter.hpp:75-185)
+    driven chunk by chunk with the header message of the open packet pending"""
+    rng = np.random.default_rng(5)
+    total = 400000
+    idx = np.sort(rng.choice(total - 10, 60, replace=False) + 1).astype(np.uint64)
+    lens = [int(rng.integers(1, 3000)) if rng.random() > 0.2 else None for _ in idx]
+    acc, _ = pkg.SyncwordDetectionFilter().gate(idx, lens, per_tag=True)
+    f = orc.SyncwordDetectionFilter()
+    want, pending = [], []
+    bounds = [0] + [int(i) for i in idx] + [total]
+    for k in range(len(bounds) - 1):
+        a, b = bounds[k], bounds[k + 1]
+        first = True
+        while a < b:
+            flags = 1 if (k > 0 and first) else 0
+            st, o, c, hc, ic, tf = f.process(np.zeros(b - a, np.complex64), b - a, flags, headers=pending, n_ignored=0)
+            if flags:
+                want.append(bool(tf & 1))
+                if tf & 1:  # accepted: from now on the decoder's answer for THIS packet is pending
+                    pending = [lens[k - 1]]
+                    hc = 0
+            if hc:
+                pending = []
+            first = False
+            a += c
+            if c == 0:  # stalled waiting for the header of the packet just accepted
+                assert pending
+    assert acc.tolist() == want
+
+
+def test_packet_receiver_front_end_chain(pkg):
+    """PacketReceiver wiring (packet_receiver.hpp:34-127): every stage bit-exact against the oracle
+    stage fed with the same tags; detector tags against the oracle detector within tolerance"""
+    rng = np.random.default_rng(91)
+    sps, n_pkt = 4, 6
+    rrc, _ = orc.unit_norm_rrc(sps)
+    a = np.float32(np.sqrt(0.5))
+    syms, starts = [], []
+    for k in range(n_pkt):
+        gap = np.zeros(int(rng.integers(300, 900)), dtype=np.complex64)
+        payload_len = int(rng.integers(10, 200))
+        nb = 128 + (payload_len + 4) * 4
+        body = (np.where(rng.integers(0, 2, nb) == 0, a, -a) + 1j * np.where(rng.integers(0, 2, nb) == 0, a, -a)).astype(np.complex64)
+        syms += [gap, sig.BPSK[sig.SYNCWORD], body]
+        starts.append((sum(len(s) for s in syms[:-2]), payload_len))
+    syms.append(np.zeros(1500, dtype=np.complex64))
+    x = orc.interpolating_fir(np.concatenate(syms), sps, rrc)
+    x = (orc.rotator(x, np.float32(0.011)) + sig.awgn(x.size, 0.05, 92)).astype(np.complex64)
+    rx = pkg.PacketReceiver(max_items=x.size)
+
+    def header_fn(tag):
+        # the header decode is outside the hot path: look the length up from the known layout
+        sym_idx = (int(tag["index"]) - 1537) / sps
+        k = int(np.argmin([abs(s - sym_idx) for s, _ in starts]))
+        return starts[k][1]
+
+    res = rx.process_bulk(dev(x), header_fn)
+    det = res["detector_tags"]
+    assert det.size == n_pkt and np.all(res["accepted"])
+    assert np.array_equal(det["index"], [1537 + sps * s for s, _ in starts])
+    # detector vs oracle detector
+    ref = orc.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, power_threshold=9.5)
+    _, ref_out, ref_tags = ref.process(x)
+    assert_tags_match(det, ref_tags, rtol=2e-4)
+    # downstream stages: oracle fed with the GPU's own tags must agree (Costas: device sincos)
+    otags = det.astype(orc.TAG_DTYPE)
+    z = orc.coarse_frequency_correction(ref_out, det["index"], det["freq"], delay=26)
+    pfb = orc.rrc_taps(32.0 / float(orc.unit_norm_rrc(sps)[1]), 128.0, 1.0, 0.35, 32 * sps * 11)[:-1]
+    sym, sym_tags, _ = orc.symbol_filter(z, pfb, 32, sps, 44, tags=otags)
+    bipolar = np.where(sig.SYNCWORD == 1, -1.0, 1.0).astype(np.float32)
+    w = orc.syncword_wipeoff(sym, bipolar, sym_tags["index"])
+    c = orc.costas_loop(w, "QPSK", 0.01, sym_tags["index"], sym_tags["phase"])
+    got = host(res["symbols"])
+    assert got.size == c.size
+    assert np.array_equal(res["tags"]["index"], sym_tags["index"])
+    assert np.max(np.abs(got - c)) < 2e-5
+    # and the chain does its job: once the loop has locked, payload symbols sit on the QPSK points
+    for t in sym_tags:
+        s0 = int(t["index"]) + 64 + 40
+        pts = got[s0:s0 + 60]
+        assert np.max(np.abs(np.abs(pts.real) - a)) < 0.3 and np.max(np.abs(np.abs(pts.imag) - a)) < 0.3
