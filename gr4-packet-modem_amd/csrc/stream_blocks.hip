@@ -70,7 +70,19 @@ struct RotSeg {
 };
 constexpr unsigned kRotChunk = 8; // samples per checkpoint
 
-// serial: one lane per segment, phasor checkpoints every kRotChunk samples
+// one step of the phasor recurrence (rotator.hpp:58-63): e *= inc; renormalise when the
+// incremented counter is a multiple of 512
+__device__ __forceinline__ void rot_step(cf& e, cf inc, unsigned& counter)
+{
+    e = cmul(e, inc);
+    if ((++counter & 511u) == 0) {
+        const float r = hypot_like_glibc(e.x, e.y);
+        e = { e.x / r, e.y / r };
+    }
+}
+
+// serial: one lane per segment, phasor checkpoints every kRotChunk samples.  The chain of
+// dependent complex multiplies is the whole cost, so the loop body is kept to exactly that.
 __global__ void k_rot_checkpoints(const RotSeg* __restrict__ segs, unsigned n_segs,
                                   RotState* __restrict__ state, cf* __restrict__ ck,
                                   cf* __restrict__ seg_incr, unsigned* __restrict__ seg_counter0)
@@ -92,13 +104,23 @@ __global__ void k_rot_checkpoints(const RotSeg* __restrict__ segs, unsigned n_se
     }
     seg_incr[s] = inc;
     seg_counter0[s] = counter;
-    for (unsigned long long j = 0; j < g.len; ++j) {
-        if ((j % kRotChunk) == 0) ck[g.ck0 + j / kRotChunk] = e;
-        e = cmul(e, inc);
-        if ((++counter % 512u) == 0) {
-            const float r = hypot_like_glibc(e.x, e.y);
-            e = { e.x / r, e.y / r };
+    const unsigned long long n_full = g.len / kRotChunk;
+    cf* ckp = ck + g.ck0;
+    for (unsigned long long c = 0; c < n_full; ++c) {
+        ckp[c] = e;
+        if ((counter & 511u) < 512u - kRotChunk) { // no renormalisation inside this chunk
+#pragma unroll
+            for (unsigned j = 0; j < kRotChunk; ++j) e = cmul(e, inc);
+            counter += kRotChunk;
+        } else {
+#pragma unroll
+            for (unsigned j = 0; j < kRotChunk; ++j) rot_step(e, inc, counter);
         }
+    }
+    const unsigned rem = static_cast<unsigned>(g.len - n_full * kRotChunk);
+    if (rem) {
+        ckp[n_full] = e;
+        for (unsigned j = 0; j < rem; ++j) rot_step(e, inc, counter);
     }
     if (g.last) {
         RotState st;
@@ -110,36 +132,29 @@ __global__ void k_rot_checkpoints(const RotSeg* __restrict__ segs, unsigned n_se
     }
 }
 
-// parallel: one lane per (segment, chunk of kRotChunk samples)
-__global__ void k_rot_apply(const RotSeg* __restrict__ segs, unsigned n_segs, unsigned n_chunks,
-                            const cf* __restrict__ ck, const cf* __restrict__ seg_incr,
-                            const unsigned* __restrict__ seg_counter0, const cf* __restrict__ in,
-                            cf* __restrict__ out, size_t stride)
+// parallel: one lane per SAMPLE (coalesced 8-byte accesses); the lane replays at most
+// kRotChunk-1 steps of the recurrence from its chunk's checkpoint, in the reference's order
+__global__ __launch_bounds__(256) void k_rot_apply(const RotSeg* __restrict__ segs, unsigned n_segs,
+                                                   const cf* __restrict__ ck, const cf* __restrict__ seg_incr,
+                                                   const unsigned* __restrict__ seg_counter0,
+                                                   const cf* __restrict__ in, cf* __restrict__ out,
+                                                   size_t stride)
 {
-    const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_chunks) return;
-    // segment of chunk c: last s with segs[s].ck0 <= c
-    unsigned lo = 0, hi = n_segs - 1;
-    while (lo < hi) {
-        const unsigned mid = (lo + hi + 1) >> 1;
-        if (segs[mid].ck0 <= c) lo = mid;
-        else hi = mid - 1;
-    }
-    const RotSeg g = segs[lo];
-    const unsigned long long j0 = static_cast<unsigned long long>(c - g.ck0) * kRotChunk;
-    const unsigned long long j1 = min(j0 + kRotChunk, g.len);
-    cf e = ck[c];
-    const cf inc = seg_incr[lo];
-    unsigned counter = seg_counter0[lo] + static_cast<unsigned>(j0);
+    // blockIdx.y = segment; grid-stride over the segment's samples
+    const RotSeg g = segs[blockIdx.y];
+    const cf inc = seg_incr[blockIdx.y];
+    const unsigned c0 = seg_counter0[blockIdx.y];
     const size_t base = static_cast<size_t>(g.channel) * stride + g.start;
-    for (unsigned long long j = j0; j < j1; ++j) {
+    for (unsigned long long j = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x; j < g.len;
+         j += static_cast<unsigned long long>(gridDim.x) * blockDim.x) {
+        const unsigned long long c = j / kRotChunk;
+        const unsigned steps = static_cast<unsigned>(j - c * kRotChunk);
+        cf e = ck[g.ck0 + c];
+        unsigned counter = c0 + static_cast<unsigned>(c * kRotChunk);
+        for (unsigned t = 0; t < steps; ++t) rot_step(e, inc, counter);
         out[base + j] = cmul(in[base + j], e);
-        e = cmul(e, inc);
-        if ((++counter % 512u) == 0) {
-            const float r = hypot_like_glibc(e.x, e.y);
-            e = { e.x / r, e.y / r };
-        }
     }
+    (void)n_segs;
 }
 
 // =====================================================================================
@@ -159,6 +174,48 @@ struct CostasSeg {
     float pad;
 };
 
+// cos/sin of the loop phase.  The reference calls glibc cosf/sinf (correctly rounded in all
+// but rare cases).  |phase| <= pi here, so a double-precision polynomial after a quadrant
+// reduction, rounded once to float, reproduces that at a fraction of the cost of the generic
+// double sincos.
+__device__ __forceinline__ void sincos_pi(float phase, float* s_out, float* c_out)
+{
+    const double x = static_cast<double>(phase);
+    const double two_over_pi = 0.63661977236758134308;
+    const double kd = rint(x * two_over_pi);
+    const int k = static_cast<int>(kd);
+    // pi/2 split in two parts (Cody-Waite); |k| <= 2 so two terms are exact enough for double
+    const double r = fma(-kd, 6.12323399573676603587e-17, fma(-kd, 1.57079632679489655800, x));
+    const double r2 = r * r;
+    // minimax-quality Taylor tails on |r| <= pi/4 (error < 1e-16)
+    double sp = -7.6471637318198164759e-13;
+    sp = fma(sp, r2, 1.6059043836821614599e-10);
+    sp = fma(sp, r2, -2.5052108385441718775e-08);
+    sp = fma(sp, r2, 2.7557319223985890653e-06);
+    sp = fma(sp, r2, -1.9841269841269841270e-04);
+    sp = fma(sp, r2, 8.3333333333333333333e-03);
+    sp = fma(sp, r2, -1.6666666666666666667e-01);
+    const double sn = fma(sp * r2, r, r);
+    double cp = 4.7794773323873852974e-14;
+    cp = fma(cp, r2, -1.1470745597729724714e-11);
+    cp = fma(cp, r2, 2.0876756987868098979e-09);
+    cp = fma(cp, r2, -2.7557319223985890653e-07);
+    cp = fma(cp, r2, 2.4801587301587301587e-05);
+    cp = fma(cp, r2, -1.3888888888888888889e-03);
+    cp = fma(cp, r2, 4.1666666666666666667e-02);
+    cp = fma(cp, r2, -0.5);
+    const double cs = fma(cp, r2, 1.0);
+    double sv, cv;
+    switch (k & 3) {
+    case 0: sv = sn; cv = cs; break;
+    case 1: sv = cs; cv = -sn; break;
+    case 2: sv = -sn; cv = -cs; break;
+    default: sv = -cs; cv = sn; break;
+    }
+    *s_out = static_cast<float>(sv);
+    *c_out = static_cast<float>(cv);
+}
+
 __global__ void k_costas(const CostasSeg* __restrict__ segs, unsigned n_segs,
                          CostasState* __restrict__ state, float k1, float k2, int constellation,
                          const cf* __restrict__ in, cf* __restrict__ out, size_t stride)
@@ -176,14 +233,11 @@ __global__ void k_costas(const CostasSeg* __restrict__ segs, unsigned n_segs,
     }
     const float pi_f = 3.14159265358979323846f;
     const size_t base = static_cast<size_t>(g.channel) * stride + g.start;
-    for (unsigned j = 0; j < g.len; ++j) {
-        // cosf/sinf of the reference are correctly rounded in all but rare cases; evaluating
-        // in double and rounding once reproduces that
-        double sd, cd;
-        sincos(static_cast<double>(phase), &sd, &cd);
-        const cf lo = { static_cast<float>(cd), -static_cast<float>(sd) };
-        const cf z = cmul(in[base + j], lo);
-        out[base + j] = z;
+    auto step = [&](cf x) -> cf {
+        float sn, cs;
+        sincos_pi(phase, &sn, &cs);
+        const cf lo = { cs, -sn }; // costas_loop.hpp:114-115
+        const cf z = cmul(x, lo);
         float error;
         if (constellation == 0) error = z.y;
         else if (constellation == 1) error = z.x * z.y;
@@ -192,7 +246,20 @@ __global__ void k_costas(const CostasSeg* __restrict__ segs, unsigned n_segs,
         phase += k1 * error + freq;
         if (phase >= pi_f) phase -= 2.0f * pi_f;
         else if (phase < -pi_f) phase += 2.0f * pi_f;
+        return z;
+    };
+    // the loads do not depend on the loop state: fetch 8 symbols ahead, then run the PLL
+    unsigned j = 0;
+    for (; j + 8 <= g.len; j += 8) {
+        cf x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = in[base + j + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = step(x[u]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) out[base + j + u] = x[u];
     }
+    for (; j < g.len; ++j) out[base + j] = step(in[base + j]);
     if (g.last) {
         state[g.channel].phase = phase;
         state[g.channel].freq = freq;
@@ -278,21 +345,52 @@ struct SymRun {
     unsigned arm;
     float scale;
 };
+// One workgroup = 256 consecutive output symbols.  Inside one run the inputs of those symbols
+// are one contiguous span (256*sps + arm_size items): it is staged into LDS with coalesced
+// loads and every thread then reads its arm_size items from LDS (the MAC order of the
+// reference, std::inner_product, m ascending, is kept: bit-exact).  Workgroups that straddle
+// a run boundary (a handful per call) fall back to direct reads.
 template <typename T>
-__global__ void k_symbol_filter(const T* __restrict__ in, const T* __restrict__ carry, unsigned cap,
-                                const float* __restrict__ taps, unsigned arm_size, unsigned sps,
-                                const SymRun* __restrict__ runs, unsigned n_runs, unsigned n_out,
-                                T* __restrict__ out)
+__global__ __launch_bounds__(256) void k_symbol_filter(const T* __restrict__ in, const T* __restrict__ carry,
+                                                       unsigned cap, const float* __restrict__ taps,
+                                                       unsigned arm_size, unsigned sps,
+                                                       const SymRun* __restrict__ runs, unsigned n_runs,
+                                                       unsigned n_out, T* __restrict__ out)
 {
-    const unsigned o = blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= n_out) return;
-    unsigned lo = 0, hi = n_runs - 1;
-    while (lo < hi) {
-        const unsigned mid = (lo + hi + 1) >> 1;
-        if (runs[mid].out0 <= o) lo = mid;
-        else hi = mid - 1;
+    extern __shared__ unsigned char s_raw[];
+    T* tile = reinterpret_cast<T*>(s_raw);
+    const unsigned o0 = blockIdx.x * 256u;
+    const unsigned o = o0 + threadIdx.x;
+    const unsigned o_last = min(o0 + 255u, n_out - 1);
+    // run of the first and of the last symbol of this workgroup
+    auto find = [&](unsigned oo) {
+        unsigned lo = 0, hi = n_runs - 1;
+        while (lo < hi) {
+            const unsigned mid = (lo + hi + 1) >> 1;
+            if (runs[mid].out0 <= oo) lo = mid;
+            else hi = mid - 1;
+        }
+        return lo;
+    };
+    const unsigned r_first = find(o0), r_last = find(o_last);
+    if (r_first == r_last) {
+        const SymRun r = runs[r_first];
+        const long long idx0 = r.in0 + static_cast<long long>(o0 - r.out0) * sps; // newest item of symbol o0
+        const long long lo_item = idx0 - (arm_size - 1);
+        const unsigned span = (o_last - o0) * sps + arm_size;
+        for (unsigned i = threadIdx.x; i < span; i += 256) tile[i] = item_at(in, carry, cap, lo_item + i);
+        __syncthreads();
+        if (o < n_out) {
+            const float* arm = taps + static_cast<size_t>(r.arm) * arm_size;
+            const unsigned top = (o - o0) * sps + arm_size - 1; // tile index of this symbol's newest item
+            T acc = zero_item(T{});
+            for (unsigned m = 0; m < arm_size; ++m) acc = mac(acc, arm[m], tile[top - m]);
+            out[o] = scale_item(r.scale, acc);
+        }
+        return;
     }
-    const SymRun r = runs[lo];
+    if (o >= n_out) return;
+    const SymRun r = runs[find(o)];
     const long long idx = r.in0 + static_cast<long long>(o - r.out0) * sps;
     const float* arm = taps + static_cast<size_t>(r.arm) * arm_size;
     T acc = zero_item(T{});
@@ -538,9 +636,18 @@ gr4pm_status gr4pm_rotator_process(gr4pm_rotator* h, const gr4pm_c64* in, size_t
     }
     hipLaunchKernelGGL(k_rot_checkpoints, dim3(grid_for(n_segs, 64)), dim3(64), 0, s, h->segs.p, n_segs,
                        h->state.p, h->ck.p, h->seg_incr.p, h->seg_counter0.p);
-    hipLaunchKernelGGL(k_rot_apply, dim3(grid_for(ck, 256)), dim3(256), 0, s, h->segs.p, n_segs, ck, h->ck.p,
-                       h->seg_incr.p, h->seg_counter0.p, reinterpret_cast<const cf*>(in),
-                       reinterpret_cast<cf*>(out), stride);
+    {
+        size_t longest = 0;
+        for (const auto& g : segs) longest = std::max<size_t>(longest, g.len);
+        const unsigned gx = static_cast<unsigned>(std::min<size_t>((longest + 255) / 256, 4096));
+        // grid.y = segment (at most 65535 per launch)
+        for (unsigned s0 = 0; s0 < n_segs; s0 += 65535u) {
+            const unsigned ns = std::min(65535u, n_segs - s0);
+            hipLaunchKernelGGL(k_rot_apply, dim3(gx, ns), dim3(256), 0, s, h->segs.p + s0, ns, h->ck.p,
+                               h->seg_incr.p + s0, h->seg_counter0.p + s0, reinterpret_cast<const cf*>(in),
+                               reinterpret_cast<cf*>(out), stride);
+        }
+    }
     GR4PM_HIP_TRY(hipGetLastError());
     GR4PM_HIP_TRY(hipStreamSynchronize(s));
     return GR4PM_OK;
@@ -1257,12 +1364,14 @@ gr4pm_status gr4pm_symbol_filter_process(gr4pm_symbol_filter* h, const void* in,
         GR4PM_TRY(upload_vec(h->runs, runs, s));
         const unsigned n_out = static_cast<unsigned>(produced);
         if (h->item_kind == 0) {
-            hipLaunchKernelGGL(k_symbol_filter<cf>, dim3((n_out + 255) / 256), dim3(256), 0, s,
+            hipLaunchKernelGGL(k_symbol_filter<cf>, dim3((n_out + 255) / 256), dim3(256),
+                               (256 * sps + h->arm_size) * sizeof(cf), s,
                                static_cast<const cf*>(in), reinterpret_cast<const cf*>(h->carry[h->cur].p),
                                h->cap, h->taps.p, static_cast<unsigned>(h->arm_size), static_cast<unsigned>(sps),
                                h->runs.p, static_cast<unsigned>(runs.size()), n_out, static_cast<cf*>(out));
         } else {
-            hipLaunchKernelGGL(k_symbol_filter<float>, dim3((n_out + 255) / 256), dim3(256), 0, s,
+            hipLaunchKernelGGL(k_symbol_filter<float>, dim3((n_out + 255) / 256), dim3(256),
+                               (256 * sps + h->arm_size) * sizeof(float), s,
                                static_cast<const float*>(in),
                                reinterpret_cast<const float*>(h->carry[h->cur].p), h->cap, h->taps.p,
                                static_cast<unsigned>(h->arm_size), static_cast<unsigned>(sps), h->runs.p,
