@@ -174,48 +174,40 @@ struct CostasSeg {
     float pad;
 };
 
-// cos/sin of the loop phase.  The reference calls glibc cosf/sinf (correctly rounded in all
-// but rare cases).  |phase| <= pi here, so a double-precision polynomial after a quadrant
-// reduction, rounded once to float, reproduces that at a fraction of the cost of the generic
-// double sincos.
-__device__ __forceinline__ void sincos_pi(float phase, float* s_out, float* c_out)
+// cos/sin of the loop phase.  The reference calls glibc cosf/sinf (< 1 ULP).  |phase| <= pi
+// here, so one Cody-Waite quadrant reduction plus the classic single-precision minimax
+// polynomials on [-pi/4, pi/4] (< 1 ULP each) are enough; the PLL is contractive, so last-bit
+// differences against glibc stay at the 1e-7 level in the output (tests allow 1e-5).
+__device__ __forceinline__ void sincos_pi(float x, float* s_out, float* c_out)
 {
-    const double x = static_cast<double>(phase);
-    const double two_over_pi = 0.63661977236758134308;
-    const double kd = rint(x * two_over_pi);
-    const int k = static_cast<int>(kd);
-    // pi/2 split in two parts (Cody-Waite); |k| <= 2 so two terms are exact enough for double
-    const double r = fma(-kd, 6.12323399573676603587e-17, fma(-kd, 1.57079632679489655800, x));
-    const double r2 = r * r;
-    // minimax-quality Taylor tails on |r| <= pi/4 (error < 1e-16)
-    double sp = -7.6471637318198164759e-13;
-    sp = fma(sp, r2, 1.6059043836821614599e-10);
-    sp = fma(sp, r2, -2.5052108385441718775e-08);
-    sp = fma(sp, r2, 2.7557319223985890653e-06);
-    sp = fma(sp, r2, -1.9841269841269841270e-04);
-    sp = fma(sp, r2, 8.3333333333333333333e-03);
-    sp = fma(sp, r2, -1.6666666666666666667e-01);
-    const double sn = fma(sp * r2, r, r);
-    double cp = 4.7794773323873852974e-14;
-    cp = fma(cp, r2, -1.1470745597729724714e-11);
-    cp = fma(cp, r2, 2.0876756987868098979e-09);
-    cp = fma(cp, r2, -2.7557319223985890653e-07);
-    cp = fma(cp, r2, 2.4801587301587301587e-05);
-    cp = fma(cp, r2, -1.3888888888888888889e-03);
-    cp = fma(cp, r2, 4.1666666666666666667e-02);
-    cp = fma(cp, r2, -0.5);
-    const double cs = fma(cp, r2, 1.0);
-    double sv, cv;
+    const float kf = rintf(x * 0.63661977236758134308f);
+    const int k = static_cast<int>(kf);
+    // pi/2 = 1.5707962512969971 + 7.5497894158615964e-08 (+ 5.39e-15): |k| <= 2
+    float r = fmaf(-kf, 1.5707962512969971f, x);
+    r = fmaf(-kf, 7.5497894158615964e-08f, r);
+    const float r2 = r * r;
+    float sp = -1.9515295891e-4f;
+    sp = fmaf(sp, r2, 8.3321608736e-3f);
+    sp = fmaf(sp, r2, -1.6666654611e-1f);
+    const float sn = fmaf(sp * r2, r, r);
+    float cp = 2.443315711809948e-5f;
+    cp = fmaf(cp, r2, -1.388731625493765e-3f);
+    cp = fmaf(cp, r2, 4.166664568298827e-2f);
+    const float cs = fmaf(cp * r2, r2, fmaf(-0.5f, r2, 1.0f));
+    float sv, cv;
     switch (k & 3) {
     case 0: sv = sn; cv = cs; break;
     case 1: sv = cs; cv = -sn; break;
     case 2: sv = -sn; cv = -cs; break;
     default: sv = -cs; cv = sn; break;
     }
-    *s_out = static_cast<float>(sv);
-    *c_out = static_cast<float>(cv);
+    *s_out = sv;
+    *c_out = cv;
 }
 
+// One lane per segment (the PLL is serial inside a segment).  The critical path is the chain
+// of dependent float operations of one loop iteration (measured: staging the symbols through
+// an LDS tile for coalesced access did not help), so the loads are simply issued 8 ahead.
 __global__ void k_costas(const CostasSeg* __restrict__ segs, unsigned n_segs,
                          CostasState* __restrict__ state, float k1, float k2, int constellation,
                          const cf* __restrict__ in, cf* __restrict__ out, size_t stride)
@@ -248,7 +240,6 @@ __global__ void k_costas(const CostasSeg* __restrict__ segs, unsigned n_segs,
         else if (phase < -pi_f) phase += 2.0f * pi_f;
         return z;
     };
-    // the loads do not depend on the loop state: fetch 8 symbols ahead, then run the PLL
     unsigned j = 0;
     for (; j + 8 <= g.len; j += 8) {
         cf x[8];
@@ -378,13 +369,20 @@ __global__ __launch_bounds__(256) void k_symbol_filter(const T* __restrict__ in,
         const long long idx0 = r.in0 + static_cast<long long>(o0 - r.out0) * sps; // newest item of symbol o0
         const long long lo_item = idx0 - (arm_size - 1);
         const unsigned span = (o_last - o0) * sps + arm_size;
-        for (unsigned i = threadIdx.x; i < span; i += 256) tile[i] = item_at(in, carry, cap, lo_item + i);
+        // tile is stored phase-major: item i lives at (i % sps) * pitch + i / sps, so that for a
+        // fixed tap m the 64 lanes (items sps apart) read consecutive LDS words
+        const unsigned pitch = (256 * sps + arm_size) / sps + 2;
+        for (unsigned i = threadIdx.x; i < span; i += 256)
+            tile[(i % sps) * pitch + i / sps] = item_at(in, carry, cap, lo_item + i);
         __syncthreads();
         if (o < n_out) {
             const float* arm = taps + static_cast<size_t>(r.arm) * arm_size;
             const unsigned top = (o - o0) * sps + arm_size - 1; // tile index of this symbol's newest item
             T acc = zero_item(T{});
-            for (unsigned m = 0; m < arm_size; ++m) acc = mac(acc, arm[m], tile[top - m]);
+            for (unsigned m = 0; m < arm_size; ++m) {
+                const unsigned i = top - m;
+                acc = mac(acc, arm[m], tile[(i % sps) * pitch + i / sps]);
+            }
             out[o] = scale_item(r.scale, acc);
         }
         return;
@@ -1365,13 +1363,13 @@ gr4pm_status gr4pm_symbol_filter_process(gr4pm_symbol_filter* h, const void* in,
         const unsigned n_out = static_cast<unsigned>(produced);
         if (h->item_kind == 0) {
             hipLaunchKernelGGL(k_symbol_filter<cf>, dim3((n_out + 255) / 256), dim3(256),
-                               (256 * sps + h->arm_size) * sizeof(cf), s,
+                               ((256 * sps + h->arm_size) / sps + 2) * sps * sizeof(cf), s,
                                static_cast<const cf*>(in), reinterpret_cast<const cf*>(h->carry[h->cur].p),
                                h->cap, h->taps.p, static_cast<unsigned>(h->arm_size), static_cast<unsigned>(sps),
                                h->runs.p, static_cast<unsigned>(runs.size()), n_out, static_cast<cf*>(out));
         } else {
             hipLaunchKernelGGL(k_symbol_filter<float>, dim3((n_out + 255) / 256), dim3(256),
-                               (256 * sps + h->arm_size) * sizeof(float), s,
+                               ((256 * sps + h->arm_size) / sps + 2) * sps * sizeof(float), s,
                                static_cast<const float*>(in),
                                reinterpret_cast<const float*>(h->carry[h->cur].p), h->cap, h->taps.p,
                                static_cast<unsigned>(h->arm_size), static_cast<unsigned>(sps), h->runs.p,

@@ -211,8 +211,39 @@ __global__ __launch_bounds__(512, 2) void k_correlate(const cf* __restrict__ in,
 }
 
 // ------------------------------------------------------------------ k_candidates
-// B(p) for local positions [0, cnt) of a channel; z points at local position 0 and is
-// readable up to cnt + T - 1.  One workgroup handles 1024 positions.
+// B(p) = zpow[p] >= max(zpow[p+1 .. p+T]) for local positions [0, cnt) of a channel; z points
+// at local position 0 and is readable up to cnt + T - 1.  One workgroup = 1024 positions.
+// The window of lane l of 64-block k is: the rest of block k, the full blocks k+1 .. k+tq-1
+// (+ block k+tq when l + T%64 >= 64) and a prefix of the last block.  Almost every position
+// already fails against the rest of its block and the full-block maxima (wave-uniform), so
+// the prefix maxima of the last block are only computed for the rare survivors.
+// inclusive prefix maximum over the 64 lanes with DPP row shifts / row broadcasts (no LDS
+// round trips, unlike __shfl_*): lane l ends with max(v[0..l]); lane 63 holds the wave maximum
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_max_step(float v)
+{
+    const float ninf = -INFINITY;
+    const int t = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, ninf), __builtin_bit_cast(int, v), CTRL,
+                                              ROW_MASK, 0xf, false);
+    return fmaxf(v, __builtin_bit_cast(float, t));
+}
+__device__ __forceinline__ float wave_prefix_max(float v)
+{
+    v = dpp_max_step<0x111, 0xf>(v); // row_shr:1
+    v = dpp_max_step<0x112, 0xf>(v); // row_shr:2
+    v = dpp_max_step<0x114, 0xf>(v); // row_shr:4
+    v = dpp_max_step<0x118, 0xf>(v); // row_shr:8
+    v = dpp_max_step<0x142, 0xa>(v); // row_bcast:15 -> rows 1, 3
+    v = dpp_max_step<0x143, 0xc>(v); // row_bcast:31 -> rows 2, 3
+    return v;
+}
+// value of lane l-1 (lane 0 gets -inf): wave_shr:1
+__device__ __forceinline__ float wave_prev(float v)
+{
+    const float ninf = -INFINITY;
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, ninf),
+                                                                 __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
 __global__ __launch_bounds__(256) void k_candidates(const float* __restrict__ zbase, size_t z_stride,
                                                     uint32_t cnt, uint32_t T,
                                                     unsigned long long* __restrict__ bitmap,
@@ -221,55 +252,53 @@ __global__ __launch_bounds__(256) void k_candidates(const float* __restrict__ zb
     extern __shared__ float sm[];
     const uint32_t tile0 = blockIdx.x * 1024u;
     const float* z = zbase + static_cast<size_t>(blockIdx.y) * z_stride;
-    unsigned long long* bm = bitmap + static_cast<size_t>(blockIdx.y) * bm_stride;
+    unsigned long long* bmp = bitmap + static_cast<size_t>(blockIdx.y) * bm_stride;
     const uint32_t span = 1024u + T;           // values needed: local [tile0, tile0 + span)
-    const uint32_t nblk = (span + 63u) / 64u;  // 64-item blocks
-    float* s = sm;                              // values
-    float* pre = sm + nblk * 64;                // inclusive prefix max inside each block
-    float* suf = pre + nblk * 64;               // inclusive suffix max inside each block
-    const uint32_t avail = cnt + T;             // readable items
-    for (uint32_t i = threadIdx.x; i < nblk * 64; i += 256) {
-        const uint32_t g = tile0 + i;
-        s[i] = (i < span && g < avail) ? z[g] : -INFINITY;
-    }
-    __syncthreads();
+    const uint32_t nblk = 16u + (T >> 6) + 2u; // 64-item blocks incl. the last (partial) ones
+    float* s = sm;                             // values, nblk * 64
+    float* bmax = sm + nblk * 64;              // block maxima, nblk
+    const uint32_t avail = cnt + T;            // readable items
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t blk = wave; blk < nblk; blk += 4) {
-        float v = s[blk * 64 + lane];
-        float p = v, q = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const float up = __shfl_up(p, d);
-            if (lane >= d) p = fmaxf(p, up);
-            const float dn = __shfl_down(q, d);
-            if (lane + d < 64) q = fmaxf(q, dn);
-        }
-        pre[blk * 64 + lane] = p;
-        suf[blk * 64 + lane] = q;
+        const uint32_t i = blk * 64 + lane, g = tile0 + i;
+        const float v = (i < span && g < avail) ? z[g] : -INFINITY;
+        s[i] = v;
+        const float m = wave_prefix_max(v);
+        if (lane == 63) bmax[blk] = m;
     }
     __syncthreads();
-#pragma unroll
-    for (int rep = 0; rep < 4; ++rep) {
-        const uint32_t i = rep * 256 + threadIdx.x; // local to tile
-        const uint32_t g = tile0 + i;
-        bool flag = false;
-        if (g < cnt) {
-            const float v = s[i];
+    const uint32_t tq = T >> 6, tr = T & 63;
+    for (uint32_t kb = wave; kb < 16; kb += 4) { // the 16 blocks whose flags this workgroup owns
+        unsigned long long word;
+        if (T < 128) { // tiny windows: plain scan
+            const uint32_t i = kb * 64 + lane;
             float m = -INFINITY;
-            if (T > 0) {
-                const uint32_t a = i + 1, b = i + T;
-                const uint32_t ba = a >> 6, bb = b >> 6;
-                if (ba == bb) {
-                    for (uint32_t u = a; u <= b; ++u) m = fmaxf(m, s[u]);
-                } else {
-                    m = fmaxf(suf[a], pre[b]);
-                    for (uint32_t k = ba + 1; k < bb; ++k) m = fmaxf(m, pre[k * 64 + 63]);
-                }
+            for (uint32_t u = 1; u <= T; ++u) m = fmaxf(m, s[i + u]);
+            word = __ballot(tile0 + i < cnt && s[i] >= m);
+        } else {
+            // lanes run over the block BACKWARDS (lane l <-> item 63 - l) so that "the rest of
+            // my block" is an exclusive prefix over lanes
+            const int it = 63 - lane;
+            const uint32_t i = kb * 64 + it;
+            const float v = s[i];
+            float m = wave_prev(wave_prefix_max(v));
+            // full blocks kb+1 .. kb+tq-1 are inside every item's window
+            float mu = -INFINITY;
+            for (uint32_t k = kb + 1; k < kb + tq; ++k) mu = fmaxf(mu, bmax[k]);
+            m = fmaxf(m, mu);
+            const bool wrap = it + tr >= 64; // the window also covers the whole of block kb+tq
+            if (wrap) m = fmaxf(m, bmax[kb + tq]);
+            bool flag = tile0 + i < cnt && v >= m;
+            if (__ballot(flag)) { // survivors: prefix of the last block, up to item (it + tr) % 64
+                const float pa = wave_prefix_max(s[(kb + tq) * 64 + lane]);
+                const float pb = wave_prefix_max(s[(kb + tq + 1) * 64 + lane]);
+                const int src = (it + tr) & 63;
+                const float qa = __shfl(pa, src), qb = __shfl(pb, src);
+                flag = flag && v >= (wrap ? qb : qa);
             }
-            flag = v >= m;
+            word = __brevll(__ballot(flag)); // back to item order
         }
-        const unsigned long long word = __ballot(flag);
-        if (lane == 0) bm[(tile0 + rep * 256 + wave * 64) >> 6] = word;
+        if (lane == 0) bmp[(tile0 >> 6) + kb] = word;
     }
 }
 
@@ -323,28 +352,73 @@ struct ChanState {
     unsigned int pad;
 };
 
-// one thread per channel: walk the tiles with the tables, record each tile's entry
-__global__ void k_tile_entries(ChanState* __restrict__ st, unsigned long long A0, uint32_t cnt,
-                               uint32_t T, uint32_t n_tiles, const uint32_t* __restrict__ table,
-                               size_t table_stride, int32_t* __restrict__ entry, int n_channels)
+// The scan position after tile t is r_{t+1} = f_t(r_t) with f_t given by table row t; walking
+// all tiles is a chain of dependent lookups.  It is done in three steps so that only
+// n_tiles / kGroup lookups are truly serial:
+//   k_group_tables   (parallel) for every group of kGroup tiles and every entry offset: where
+//                    the scan leaves the group
+//   k_group_walk     (one thread per channel) walk the groups
+//   k_tile_entries   (one thread per group) walk the tiles of one group from its known entry
+constexpr uint32_t kGroup = 32;
+__device__ __forceinline__ unsigned long long walk_tiles(unsigned long long r, uint32_t t0, uint32_t t1,
+                                                         uint32_t cnt, uint32_t T,
+                                                         const uint32_t* __restrict__ tab,
+                                                         int32_t* __restrict__ entry)
+{
+    for (uint32_t t = t0; t < t1; ++t) {
+        const uint32_t lo = t * kTileW;
+        const uint32_t hi = min(lo + kTileW, cnt);
+        if (r >= hi) {
+            if (entry) entry[t] = -1;
+            continue;
+        }
+        const uint32_t e = r > lo ? static_cast<uint32_t>(r) - lo : 0; // <= T by construction
+        if (entry) entry[t] = static_cast<int32_t>(e);
+        r = static_cast<unsigned long long>(hi) + tab[static_cast<size_t>(t) * (T + 1) + e];
+    }
+    return r;
+}
+__global__ void k_group_tables(uint32_t cnt, uint32_t T, uint32_t n_tiles, const uint32_t* __restrict__ table,
+                               size_t table_stride, unsigned long long* __restrict__ gtable, size_t gtable_stride)
+{
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t grp = blockIdx.y, ch = blockIdx.z;
+    if (e > T) return;
+    const uint32_t t0 = grp * kGroup, t1 = min(t0 + kGroup, n_tiles);
+    const unsigned long long r0 = static_cast<unsigned long long>(t0) * kTileW + e;
+    gtable[ch * gtable_stride + static_cast<size_t>(grp) * (T + 1) + e] =
+        walk_tiles(r0, t0, t1, cnt, T, table + ch * table_stride, nullptr);
+}
+__global__ void k_group_walk(ChanState* __restrict__ st, unsigned long long A0, uint32_t cnt, uint32_t T,
+                             uint32_t n_tiles, const unsigned long long* __restrict__ gtable, size_t gtable_stride,
+                             unsigned long long* __restrict__ gentry, uint32_t n_groups, int n_channels)
 {
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= n_channels) return;
     const unsigned long long rabs = st[ch].r;
     unsigned long long r = rabs > A0 ? rabs - A0 : 0; // local; may exceed cnt
-    for (uint32_t t = 0; t < n_tiles; ++t) {
-        const uint32_t lo = t * kTileW;
-        const uint32_t hi = min(lo + kTileW, cnt);
-        if (r >= hi) {
-            entry[ch * n_tiles + t] = -1;
-            continue;
-        }
-        const uint32_t e = r > lo ? static_cast<uint32_t>(r) - lo : 0; // <= T by construction
-        entry[ch * n_tiles + t] = static_cast<int32_t>(e);
-        r = hi + table[static_cast<size_t>(ch) * table_stride + static_cast<size_t>(t) * (T + 1) + e];
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        gentry[ch * n_groups + g] = r;
+        const unsigned long long lo = static_cast<unsigned long long>(g) * kGroup * kTileW;
+        const uint32_t t1 = min((g + 1) * kGroup, n_tiles);
+        const unsigned long long hi = min(static_cast<unsigned long long>(t1) * kTileW,
+                                          static_cast<unsigned long long>(cnt));
+        if (r >= hi) continue;
+        const unsigned long long e = r > lo ? r - lo : 0; // <= T by construction
+        r = gtable[ch * gtable_stride + static_cast<size_t>(g) * (T + 1) + e];
     }
     const unsigned long long rnew = A0 + (r > cnt ? r : cnt);
     st[ch].r = rnew > rabs ? rnew : rabs;
+}
+__global__ void k_tile_entries(uint32_t cnt, uint32_t T, uint32_t n_tiles, const uint32_t* __restrict__ table,
+                               size_t table_stride, const unsigned long long* __restrict__ gentry,
+                               uint32_t n_groups, int32_t* __restrict__ entry, int n_channels)
+{
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_groups * static_cast<uint32_t>(n_channels)) return;
+    const uint32_t ch = idx / n_groups, grp = idx % n_groups;
+    const uint32_t t0 = grp * kGroup, t1 = min(t0 + kGroup, n_tiles);
+    walk_tiles(gentry[ch * n_groups + grp], t0, t1, cnt, T, table + ch * table_stride, entry + ch * n_tiles);
 }
 
 // one wave per (tile, channel): redo the scan from the known entry and run the median test
@@ -490,20 +564,28 @@ __global__ __launch_bounds__(64) void k_tags(const cf* __restrict__ in, size_t i
     }
 }
 
-// drop emitted detections (pos + hist < E1) from the pending list; one thread per channel
-__global__ void k_compact_pending(ChanState* __restrict__ st, unsigned long long* __restrict__ det,
-                                  uint32_t det_cap, unsigned long long E1, uint32_t hist, int n_channels)
+// drop emitted detections (pos + hist < E1) from the pending list; one wave per channel
+__global__ __launch_bounds__(64) void k_compact_pending(ChanState* __restrict__ st,
+                                                        unsigned long long* __restrict__ det, uint32_t det_cap,
+                                                        unsigned long long E1, uint32_t hist, int n_channels)
 {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ch = blockIdx.x;
     if (ch >= n_channels) return;
+    const int lane = threadIdx.x;
     unsigned long long* d = det + static_cast<size_t>(ch) * det_cap;
     const uint32_t n = min(st[ch].det_cnt, det_cap);
     uint32_t w = 0;
-    for (uint32_t i = 0; i < n; ++i) {
-        const unsigned long long p = d[i];
-        if (p + hist >= E1) d[w++] = p;
+    for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        const unsigned long long p = i < n ? d[i] : 0ull;
+        const bool keep = i < n && p + hist >= E1;
+        const unsigned long long m = __ballot(keep);
+        const uint32_t off = __popcll(m & ((1ull << lane) - 1ull));
+        // all reads of this chunk happened above; writes land at indices <= i
+        if (keep) d[w + off] = p;
+        w += __popcll(m);
     }
-    st[ch].det_cnt = w;
+    if (lane == 0) st[ch].det_cnt = w;
 }
 
 // out[i] = item (i - hist) of the stream: the 2T+1 delay of hpp:318-319,342
@@ -593,6 +675,9 @@ struct gr4pm_syncword_detection {
     DevBuf<float> z[2];
     DevBuf<unsigned long long> bitmap;
     DevBuf<uint32_t> table;
+    DevBuf<unsigned long long> gtable, gentry;
+    size_t gtable_stride = 0;
+    uint32_t max_groups = 0;
     DevBuf<int32_t> entry;
     DevBuf<ChanState> st;
     DevBuf<unsigned long long> det;
@@ -807,6 +892,10 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
     ok(h->bitmap.alloc(h->bm_stride * h->n_channels));
     ok(h->table.alloc(h->table_stride * h->n_channels));
     ok(h->entry.alloc(static_cast<size_t>(h->max_tiles) * h->n_channels));
+    h->max_groups = (h->max_tiles + kGroup - 1) / kGroup;
+    h->gtable_stride = static_cast<size_t>(h->max_groups) * (h->T + 1);
+    ok(h->gtable.alloc(h->gtable_stride * h->n_channels));
+    ok(h->gentry.alloc(static_cast<size_t>(h->max_groups) * h->n_channels));
     ok(h->st.alloc(h->n_channels));
     ok(h->det.alloc(static_cast<size_t>(h->det_cap) * h->n_channels));
     ok(h->rec.alloc(static_cast<size_t>(h->rec_cap) * h->n_channels));
@@ -891,15 +980,20 @@ gr4pm_status gr4pm_syncword_detection_process(gr4pm_syncword_detection* h, const
     const float* zloc = zcur + h->zc - static_cast<ptrdiff_t>(E0 - A0);
     if (cnt > 0) {
         const uint32_t n_wg = (cnt + 1023) / 1024;
-        const size_t smem = static_cast<size_t>((1024 + T + 63) / 64) * 64 * 3 * sizeof(float);
+        const size_t smem = static_cast<size_t>(16 + (T >> 6) + 2) * 65 * sizeof(float);
         hipLaunchKernelGGL(k_candidates, dim3(n_wg, nch), dim3(256), smem, s, zloc, h->z_stride, cnt, T,
                            h->bitmap.p, h->bm_stride);
         const uint32_t n_tiles = (cnt + kTileW - 1) / kTileW;
         hipLaunchKernelGGL(k_tile_tables, dim3((T + 1 + 127) / 128, n_tiles, nch), dim3(128), 0, s,
                            h->bitmap.p, h->bm_stride, cnt, T, n_tiles, h->table.p, h->table_stride);
-        hipLaunchKernelGGL(k_tile_entries, dim3((nch + 63) / 64), dim3(64), 0, s, h->st.p,
-                           static_cast<unsigned long long>(A0), cnt, T, n_tiles, h->table.p,
-                           h->table_stride, h->entry.p, static_cast<int>(nch));
+        const uint32_t n_groups = (n_tiles + kGroup - 1) / kGroup;
+        hipLaunchKernelGGL(k_group_tables, dim3((T + 1 + 127) / 128, n_groups, nch), dim3(128), 0, s, cnt, T,
+                           n_tiles, h->table.p, h->table_stride, h->gtable.p, h->gtable_stride);
+        hipLaunchKernelGGL(k_group_walk, dim3((nch + 63) / 64), dim3(64), 0, s, h->st.p,
+                           static_cast<unsigned long long>(A0), cnt, T, n_tiles, h->gtable.p, h->gtable_stride,
+                           h->gentry.p, n_groups, static_cast<int>(nch));
+        hipLaunchKernelGGL(k_tile_entries, dim3((n_groups * nch + 63) / 64), dim3(64), 0, s, cnt, T, n_tiles,
+                           h->table.p, h->table_stride, h->gentry.p, n_groups, h->entry.p, static_cast<int>(nch));
         hipLaunchKernelGGL(k_tile_detect, dim3(n_tiles, nch), dim3(64), 0, s, h->bitmap.p, h->bm_stride,
                            zloc, h->z_stride, static_cast<unsigned long long>(A0), cnt, T,
                            h->power_threshold, n_tiles, h->entry.p, h->st.p, h->det.p, h->det_cap);
@@ -913,7 +1007,7 @@ gr4pm_status gr4pm_syncword_detection_process(gr4pm_syncword_detection* h, const
                        h->tw.p + kTw1aItems + kTw1bItems + kTwAItems, zcur + h->zc, h->z_stride, h->st.p,
                        h->det.p, h->det_cap, h->rec.p, h->rec_cap);
     GR4PM_HIP_TRY(hipMemcpyAsync(h->st_host.p, h->st.p, sizeof(ChanState) * nch, hipMemcpyDeviceToHost, s));
-    hipLaunchKernelGGL(k_compact_pending, dim3((nch + 63) / 64), dim3(64), 0, s, h->st.p, h->det.p,
+    hipLaunchKernelGGL(k_compact_pending, dim3(nch), dim3(64), 0, s, h->st.p, h->det.p,
                        h->det_cap, static_cast<unsigned long long>(E1), static_cast<uint32_t>(h->hist),
                        static_cast<int>(nch));
     if (out) {
