@@ -108,6 +108,19 @@ def cpu_baseline(x_host, rrc, seconds_target=15.0):
                       f"{tags.size} tags, {dt:.1f} s"}
 
 
+def aggregate(dist, dt, consumed, device):
+    """whole-job numbers over all ranks: time = MAX over ranks, items = SUM over ranks (each
+    rank runs its own channel: weak scaling, no data-path collective).  Works with any
+    torch.distributed backend (RCCL on the GPUs, gloo in the CPU test)."""
+    if dist is None:
+        return dt, consumed
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    csum = torch.tensor([consumed], dtype=torch.float64, device=device)
+    dist.all_reduce(csum, op=dist.ReduceOp.SUM)
+    return tmax.item(), csum.item()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,6 +129,8 @@ def main():
     ap.add_argument("--items", type=int, default=1 << 26, help="samples per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--detector-only", action="store_true", help="time SyncwordDetection alone")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="run the two halves of the chain back to back on one stream")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -133,7 +148,7 @@ def main():
     bpsk = np.array([1, -1], dtype=np.complex64)
     n_items = args.items
     x, n_pkt = burst_stream(n_items, rrc, seed=1 + rank, device=device)
-    rx = pkg.PacketReceiver(SPS, BINS, 9.5, "QPSK", max_items=n_items)
+    rx = pkg.PacketReceiver(SPS, BINS, 9.5, "QPSK", max_items=n_items, pipelined=not args.no_pipeline)
     sd = rx.syncword_detection
     out_keep = None
 
@@ -144,11 +159,22 @@ def main():
             out_keep = out
             return n, tags.size
         res = rx.process_bulk(x, 1500, tags_cap=max(64, 2 * n_pkt + 64))  # payload length of the generator
+        if res is None:  # pipelined: first call has no finished batch yet
+            return 0, 0
+        out_keep = res["symbols"]
+        return res["consumed"], res["tags"].size
+
+    def drain():
+        nonlocal out_keep
+        res = rx.flush() if not args.detector_only else None
+        if res is None:
+            return 0, 0
         out_keep = res["symbols"]
         return res["consumed"], res["tags"].size
 
     for _ in range(args.warmup):
         step()
+    drain()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -160,20 +186,15 @@ def main():
         n, nt = step()
         consumed += n
         n_tags += nt
+    n, nt = drain()  # pipelined: the last batch finishes inside the timed region
+    consumed += n
+    n_tags += nt
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    tot = torch.tensor([dt, float(consumed)], dtype=torch.float64, device=device)
-    if dist:
-        tmax = tot[:1].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        csum = tot[1:].clone()
-        dist.all_reduce(csum, op=dist.ReduceOp.SUM)
-        dt, total = tmax.item(), csum.item()
-    else:
-        total = float(consumed)
+    dt, total = aggregate(dist, dt, float(consumed), device)
 
     # ---- roofline of the dominant kernel: HIP events on the stream the kernel runs on
     roofline = None
@@ -195,7 +216,10 @@ def main():
         achieved = alg_bytes / (ms * 1e-3) / 1e9
         flops = 710.0 * samples  # (1+B) 5N log2 N + 6BN + 1.5N + 4BS per stride, B = 9
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 5),
+                    # HBM bytes per launch from the PMC passes of profiles/r1_k_correlate_hbm_traffic.json
+                    # (2 x FETCH_SIZE + WRITE_SIZE = 12.57 B/sample), scaled to this launch
+                    "traffic": round(12.569 * samples),
                     "kernel": "k_correlate", "launch_ms": round(ms, 4), "samples_per_launch": samples,
                     "alg_bytes_per_sample": 8,
                     "fp32_tflops": round(flops / (ms * 1e-3) / 1e12, 2),
@@ -221,7 +245,8 @@ def main():
                                     "gate + CFC + 32-arm RRC SymbolFilter + wipe-off + Costas)") +
                                    " on resident burst+AWGN stream",
                        "items_per_step_per_gpu": n_items, "freq_bins": 2 * BINS + 1, "tags_per_step": n_tags // max(args.steps, 1),
-                       "parallelism": f"channel-per-gpu x{world}"},
+                       "parallelism": f"channel-per-gpu x{world}",
+                       "pipelined_streams": 1 if (args.no_pipeline or args.detector_only) else 2},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

@@ -476,3 +476,53 @@ def test_packet_receiver_front_end_chain(pkg):
         s0 = int(t["index"]) + 64 + 40
         pts = got[s0:s0 + 60]
         assert np.max(np.abs(np.abs(pts.real) - a)) < 0.3 and np.max(np.abs(np.abs(pts.imag) - a)) < 0.3
+
+
+# ------------------------------------------------------------------ full-size properties
+def test_syncword_detection_full_size_properties(pkg):
+    """BASELINE size (2^28 samples, one call): properties that need no oracle --
+    every inserted syncword is found at exactly delay + 4*loc with the right freq_bin, nothing
+    else is found, the pass-through is the input delayed by 2T+1 (checksum of checksums), and
+    processing the same stream in two calls gives the same tags (state carry at scale)."""
+    n = 1 << 28
+    sps, L = 4, 297
+    rrc, _ = orc.unit_norm_rrc(sps)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(123)
+    # AWGN floor well below the threshold + one clean shaped syncword every ~1e6 samples
+    x = torch.complex(torch.randn(n, generator=g, device="cuda"), torch.randn(n, generator=g, device="cuda")) * 0.05
+    sw = orc.interpolating_fir(np.concatenate([sig.BPSK[sig.SYNCWORD], np.zeros(11, np.complex64)]), sps, rrc)[:L]
+    rng = np.random.default_rng(9)
+    locs = np.sort(rng.choice(np.arange(5000, n - 5000, 999_983), 200, replace=False)) // 4 * 4
+    freqs = rng.uniform(-0.03, 0.03, locs.size)  # inside bins -3..3: edge bins are not interpolated (hpp:65)
+    swd = dev(sw)
+    k = torch.arange(L, device="cuda")
+    for loc, f in zip(locs, freqs):
+        x[loc:loc + L] += swd * torch.polar(torch.ones(L, device="cuda"), f * k)
+    x = x.contiguous()
+    sd = pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, power_threshold=9.5, max_items=n)
+    st, out, tags, done = sd.process_bulk(x, tags_cap=4096)
+    delay = 2 * sd.time_threshold + 1
+    found = locs[locs + delay < done]
+    assert tags.size == found.size
+    assert np.array_equal(tags["index"], found + delay)
+    assert np.array_equal(tags["freq_bin"], np.round(freqs[: found.size] / (np.pi / L)).astype(np.int32))
+    assert np.all(np.abs(tags["freq"] - freqs[: found.size]) < 1e-3) and np.all(np.abs(tags["amplitude"] - 1.0) < 0.05)
+    # pass-through: out == input delayed, compared through 64-bit checksums of 2^20-sample blocks
+    xi = x.view(torch.float32).view(torch.int64)[: done - delay]
+    oi = out.view(torch.float32).view(torch.int64)[delay:done]
+    blk = 1 << 20
+    m = (xi.numel() // blk) * blk
+    assert torch.equal(xi[:m].view(-1, blk).sum(1), oi[:m].view(-1, blk).sum(1))
+    assert torch.equal(xi[m:], oi[m:]) and torch.count_nonzero(out[:delay]).item() == 0
+    del out
+    # the same stream in two calls
+    sd2 = pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, power_threshold=9.5, max_items=n)
+    cut = (n // 3) // 1752 * 1752 + 2048
+    st, _, t1, d1 = sd2.process_bulk(x[:cut].contiguous(), want_output=False, tags_cap=4096)
+    st, _, t2, d2 = sd2.process_bulk(x[d1:].contiguous(), want_output=False, tags_cap=4096)
+    t2 = t2.copy()
+    t2["index"] += d1
+    both = np.concatenate([t1, t2])
+    assert d1 + d2 == done and np.array_equal(both["index"], tags["index"])
+    assert np.array_equal(both["amplitude"], tags["amplitude"]) and np.array_equal(both["phase"], tags["phase"])
