@@ -227,7 +227,12 @@ __global__ void k_costas(const CostasSeg* __restrict__ segs, unsigned n_segs,
     const size_t base = static_cast<size_t>(g.channel) * stride + g.start;
     auto step = [&](cf x) -> cf {
         float sn, cs;
+#ifdef GR4PM_COSTAS_HW_SINCOS
+        sn = __sinf(phase);
+        cs = __cosf(phase);
+#else
         sincos_pi(phase, &sn, &cs);
+#endif
         const cf lo = { cs, -sn }; // costas_loop.hpp:114-115
         const cf z = cmul(x, lo);
         float error;
