@@ -30,11 +30,15 @@
 #include "common.hpp"
 #include "fft2048_wave.hpp"
 
+#ifndef GR4PM_ABL
+#define GR4PM_ABL 0
+#endif
+
 namespace gr4pm {
 
 namespace {
 
-constexpr int kWavesPerWg = 8; // 512 threads: 2 waves per SIMD on one CU
+constexpr int kWavesPerWg = 4; // 256 threads; two workgroups per CU (68 KiB LDS each) = 2 waves per SIMD
 constexpr int kMaxBins = 64;
 constexpr uint32_t kTileW = 32768; // items per detector tile
 
@@ -48,10 +52,13 @@ struct RawTag { // device -> host
 
 __device__ __forceinline__ void wave_lds_sync()
 {
-    // LDS operations of one wave execute in order; only the compiler must not reorder
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    // The LDS pipeline executes the DS instructions of one wave in issue order, so a read of
+    // another lane's write needs no hardware wait, only the guarantee that the COMPILER keeps
+    // the program order.  (A wavefront-scope fence would also cover global memory and make
+    // hipcc drain the prefetched template loads with s_waitcnt vmcnt(0) at every exchange.)
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    asm volatile("" ::: "memory");
 }
 
 // FFT-1: natural-order block in r (see fft1_pass1) -> X in FFT-1's output distribution.
@@ -81,6 +88,10 @@ __device__ __forceinline__ void fft2_wave(int lane, cf* r, cf* out, cf* lds, con
 {
     fft2_passA(lane, r, twA);
     cf b[32];
+#if GR4PM_ABL == 1 /* timing-only ablation: no LDS exchanges */
+#pragma unroll
+    for (int j = 0; j < 32; ++j) b[j] = r[(j * 5 + 3) & 31];
+#else
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         wave_lds_sync();
@@ -88,7 +99,12 @@ __device__ __forceinline__ void fft2_wave(int lane, cf* r, cf* out, cf* lds, con
         wave_lds_sync();
         fft2_loadB(lane, b, lds, h);
     }
+#endif
     fft2_passB(lane, b, twB);
+#if GR4PM_ABL == 1
+#pragma unroll
+    for (int j = 0; j < 32; ++j) out[j] = b[(j * 7 + 1) & 31];
+#else
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         wave_lds_sync();
@@ -96,6 +112,7 @@ __device__ __forceinline__ void fft2_wave(int lane, cf* r, cf* out, cf* lds, con
         wave_lds_sync();
         fft2_loadC(lane, out, lds, h);
     }
+#endif
     fft2_passC(out);
 }
 
@@ -113,25 +130,29 @@ __device__ __forceinline__ void mul_template(int lane, const cf* X, cf* r, const
 }
 
 // LDS map of k_correlate (one array, 16-byte aligned), in float4 units:
-//   [0, 2048)              two template buffers (double buffered across bins), 32 KiB
-//   [2048, 2048+896)       twA  (28 x 64 cf = 14 KiB)
-//   [2944, 2944+120)       twB  (15 x 16 cf = 1.9 KiB)
-//   [3064, 3064+8*576)     eight per-wave exchange buffers of 1152 cf (9 KiB) each
-constexpr int kLdsTmpl = 0, kLdsTwA = 2048, kLdsTwB = kLdsTwA + kTwAItems / 2, kLdsExch = kLdsTwB + kTwBItems / 2;
+//   [0, 1024)              the current template (16 KiB)
+//   [1024, 1024+896)       twA  (28 x 64 cf = 14 KiB)
+//   [1920, 1920+120)       twB  (15 x 16 cf = 1.9 KiB)
+//   [2040, 2040+4*576)     four per-wave exchange buffers of 1152 cf (9 KiB) each
+// = 68 KiB per workgroup -> two workgroups per CU.  They run out of phase, so one's prologue
+// (HBM loads, FFT-1) and barriers are covered by the other's transforms.
+constexpr int kLdsTmpl = 0, kLdsTwA = 1024, kLdsTwB = kLdsTwA + kTwAItems / 2, kLdsExch = kLdsTwB + kTwBItems / 2;
 constexpr int kLdsTotal = kLdsExch + kWavesPerWg * (kExchangeItems / 2); // float4 units
-static_assert(kLdsTotal * 16 <= 160 * 1024, "LDS budget");
+static_assert(2 * kLdsTotal * 16 <= 160 * 1024, "LDS budget for two workgroups per CU");
+constexpr int kCorrThreads = kWavesPerWg * 64;
+constexpr int kTmplPerThread = 1024 / kCorrThreads; // float4 per thread per template
 
 // ------------------------------------------------------------------ k_correlate
-// grid (ceil(n_blocks / 8), n_channels), 512 threads = 8 waves, one overlap-save block per
-// wave; the 8 waves walk the B templates in lockstep so each template is staged into LDS once
-// per workgroup (issue-early / write-late through 2 float4 registers per thread).
-__global__ __launch_bounds__(512, 2) void k_correlate(const cf* __restrict__ in, size_t in_stride,
-                                                      uint32_t n_blocks, uint32_t stride_s,
-                                                      int n_bins, const float4* __restrict__ tmpl,
-                                                      const cf* __restrict__ tw1a,
-                                                      const cf* __restrict__ tw1b,
-                                                      const float4* __restrict__ twAB,
-                                                      float* __restrict__ zpow, size_t z_stride)
+// grid (ceil(n_blocks / 4), n_channels), 256 threads = 4 waves, one overlap-save block per
+// wave; the waves walk the B templates together so each template is staged into LDS once per
+// workgroup (global loads issued a whole transform ahead, written to LDS between two barriers).
+__global__ __launch_bounds__(kCorrThreads, 2) void k_correlate(const cf* __restrict__ in, size_t in_stride,
+                                                               uint32_t n_blocks, uint32_t stride_s,
+                                                               int n_bins, const float4* __restrict__ tmpl,
+                                                               const cf* __restrict__ tw1a,
+                                                               const cf* __restrict__ tw1b,
+                                                               const float4* __restrict__ twAB,
+                                                               float* __restrict__ zpow, size_t z_stride)
 {
     __shared__ float4 lds4[kLdsTotal];
     const int tid = threadIdx.x;
@@ -147,9 +168,9 @@ __global__ __launch_bounds__(512, 2) void k_correlate(const cf* __restrict__ in,
     float* zo = zpow + static_cast<size_t>(blockIdx.y) * z_stride + static_cast<size_t>(b) * stride_s;
 
     // stage the FFT-2 twiddle tables (twA ++ twB contiguous in global) and template 0
-    for (int i = tid; i < (kTwAItems + kTwBItems) / 2; i += 512) lds4[kLdsTwA + i] = twAB[i];
-    lds4[kLdsTmpl + tid] = tmpl[tid];
-    lds4[kLdsTmpl + 512 + tid] = tmpl[512 + tid];
+    for (int i = tid; i < (kTwAItems + kTwBItems) / 2; i += kCorrThreads) lds4[kLdsTwA + i] = twAB[i];
+#pragma unroll
+    for (int u = 0; u < kTmplPerThread; ++u) lds4[kLdsTmpl + u * kCorrThreads + tid] = tmpl[u * kCorrThreads + tid];
 
     cf r[32];
     if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
@@ -176,29 +197,33 @@ __global__ __launch_bounds__(512, 2) void k_correlate(const cf* __restrict__ in,
     for (int j = 0; j < 32; ++j) zmax[j] = -1.0f; // hpp:303
     __syncthreads();
     for (int bin = 0; bin < n_bins; ++bin) {
-        const int buf = bin & 1;
-        // issue next template's loads now, write them to the other LDS buffer after the FFT
-        float4 t0, t1;
+        // next template: global loads now, LDS write once everybody has consumed this one
+        float4 tn[kTmplPerThread];
         const bool more = bin + 1 < n_bins;
         if (more) {
-            const float4* tn = tmpl + static_cast<size_t>(bin + 1) * 1024;
-            t0 = tn[tid];
-            t1 = tn[512 + tid];
+            const float4* tg = tmpl + static_cast<size_t>(bin + 1) * 1024;
+#pragma unroll
+            for (int u = 0; u < kTmplPerThread; ++u) tn[u] = tg[u * kCorrThreads + tid];
         }
         cf p[32], c[32];
-        mul_template(lane, X, p, lds4 + kLdsTmpl + buf * 1024); // hpp:247-249
-        fft2_wave(lane, p, c, lds, twA, twB);                   // hpp:250-251
+        mul_template(lane, X, p, lds4 + kLdsTmpl); // hpp:247-249
+        if (more) {
+#if GR4PM_ABL != 2
+            __syncthreads(); // every wave has read the current template
+#endif
+#pragma unroll
+            for (int u = 0; u < kTmplPerThread; ++u) lds4[kLdsTmpl + u * kCorrThreads + tid] = tn[u];
+        }
+        fft2_wave(lane, p, c, lds, twA, twB); // hpp:250-251
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
             // hpp:307-308: the best bin's power; max() == the strict-> scan for the VALUE (the
             // bin index is recomputed by k_tags for detections only)
             zmax[j] = fmaxf(zmax[j], cnorm(c[j]));
         }
-        if (more) {
-            lds4[kLdsTmpl + (buf ^ 1) * 1024 + tid] = t0;
-            lds4[kLdsTmpl + (buf ^ 1) * 1024 + 512 + tid] = t1;
-        }
-        __syncthreads(); // next template complete; everyone done with this one
+#if GR4PM_ABL != 2
+        if (more) __syncthreads(); // next template complete
+#endif
     }
     if (!active) return;
     // lag k <-> correlation index (N - k) mod N (hpp:300); lanes hold consecutive indices
@@ -758,7 +783,7 @@ gr4pm_status launch_correlate(gr4pm_syncword_detection* h, const gr4pm_c64* in, 
     const cf* tw1a = h->tw.p;
     const cf* tw1b = tw1a + kTw1aItems;
     const cf* twA = tw1b + kTw1bItems;
-    hipLaunchKernelGGL(k_correlate, grid, dim3(512), 0, h->stream, reinterpret_cast<const cf*>(in),
+    hipLaunchKernelGGL(k_correlate, grid, dim3(kCorrThreads), 0, h->stream, reinterpret_cast<const cf*>(in),
                        in_stride, n_blocks, static_cast<uint32_t>(h->S), h->n_bins, h->tmpl.p, tw1a, tw1b,
                        reinterpret_cast<const float4*>(twA), zout, h->z_stride);
     GR4PM_HIP_TRY(hipGetLastError());
