@@ -166,11 +166,14 @@ def main():
 
     def drain():
         nonlocal out_keep
-        res = rx.flush() if not args.detector_only else None
-        if res is None:
+        if args.detector_only:
             return 0, 0
-        out_keep = res["symbols"]
-        return res["consumed"], res["tags"].size
+        n = nt = 0
+        for res in rx.flush():
+            out_keep = res["symbols"]
+            n += res["consumed"]
+            nt += res["tags"].size
+        return n, nt
 
     for _ in range(args.warmup):
         step()
@@ -246,7 +249,7 @@ def main():
                                    " on resident burst+AWGN stream",
                        "items_per_step_per_gpu": n_items, "freq_bins": 2 * BINS + 1, "tags_per_step": n_tags // max(args.steps, 1),
                        "parallelism": f"channel-per-gpu x{world}",
-                       "pipelined_streams": 1 if (args.no_pipeline or args.detector_only) else 2},
+                       "pipelined_streams": 1 if (args.no_pipeline or args.detector_only) else 3},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

@@ -421,11 +421,12 @@ class PacketReceiver:
     LDPC, CRC) is outside the hot path; the `parsed_header` feedback that the filter waits for
     is supplied by the caller (`header_fn(tag) -> packet_length | None`, or a constant).
 
-    pipelined=True runs the two halves as the reference's multi-threaded scheduler does
-    (one worker per block, benchmarks/README.md:8-26), here on two HIP streams: the detector of
-    batch i+1 overlaps the per-packet serial kernels (phasor checkpoints, Costas) of batch i,
-    which only occupy a few CUs.  process_bulk() then returns the result of the PREVIOUS batch
-    (None for the first); flush() returns the last one."""
+    pipelined=True runs the chain as the reference's multi-threaded scheduler does (one worker
+    per block, benchmarks/README.md:8-26), here as three stages on three HIP streams --
+    detector | frequency correction + symbol filter + wipe-off | Costas loop -- so that the
+    per-packet serial kernels (phasor checkpoints, PLL), which occupy only a few CUs, overlap
+    the detector of the following batches.  process_bulk() then returns the result of an
+    EARLIER batch (None while the pipeline fills); flush() drains it."""
 
     def __init__(self, samples_per_symbol=4, syncword_freq_bins=4, syncword_threshold=9.5,
                  costas_constellation="QPSK", max_items=1 << 22, pipelined=False):
@@ -440,39 +441,40 @@ class PacketReceiver:
         self.rrc_taps = (rrc / norm).astype(np.float32)
         bpsk = np.array([1, -1], dtype=np.complex64)
         self.pipelined = pipelined
-        self._front_stream = torch.cuda.Stream() if pipelined else torch.cuda.current_stream()
-        self._back_stream = torch.cuda.Stream() if pipelined else torch.cuda.current_stream()
-        with torch.cuda.stream(self._front_stream):
+        cur = torch.cuda.current_stream()
+        self._streams = [torch.cuda.Stream() for _ in range(3)] if pipelined else [cur, cur, cur]
+        with torch.cuda.stream(self._streams[0]):
             self.syncword_detection = SyncwordDetection(                          # :76-83
                 self.rrc_taps, SYNCWORD, bpsk, -syncword_freq_bins, syncword_freq_bins,
                 samples_per_symbol=sps, power_threshold=syncword_threshold, max_items=max_items)
-        with torch.cuda.stream(self._back_stream):
+        with torch.cuda.stream(self._streams[1]):
             self.syncword_detection_filter = SyncwordDetectionFilter(sps)         # :84-85
             self.freq_correction = CoarseFrequencyCorrection((self.rrc_taps.size - 1) // 2 + sps)  # :94-95
             arms = 32                                                             # :96
             pfb = root_raised_cosine(float(arms) / float(norm), float(arms * sps), 1.0, 0.35, arms * sps * 11)[:-1]  # :100-110
             self.symbol_filter = SymbolFilter(pfb, arms, sps, self.rrc_taps.size - 1)  # :111-115
             self.syncword_wipeoff = SyncwordWipeoff(np.where(SYNCWORD == 1, -1.0, 1.0).astype(np.float32))  # :117-122
+        with torch.cuda.stream(self._streams[2]):
             self.costas_loop = CostasLoop(0.01, costas_constellation)             # :125
-        self._worker = None
-        self._pending = None
+        self._workers = None
+        self._inflight = []
         if pipelined:
             import concurrent.futures
-            self._worker = concurrent.futures.ThreadPoolExecutor(max_workers=1)
+            self._workers = [concurrent.futures.ThreadPoolExecutor(max_workers=1) for _ in range(2)]
 
-    # ---- the two halves
-    def _front(self, x, tags_cap):
+    # ---- the three stages
+    def _stage0(self, x, tags_cap):
         torch = _torch()
-        with torch.cuda.stream(self._front_stream):
+        with torch.cuda.stream(self._streams[0]):
             st, y, det_tags, n = self.syncword_detection.process_bulk(x, want_output=True, tags_cap=tags_cap)
         base = self.syncword_detection._items_consumed - n        # absolute index of y[0]
         return st, y, det_tags, n, base
 
-    def _back(self, st, y, det_tags, n, base, header_fn):
+    def _stage1(self, st, y, det_tags, n, base, header_fn):
         torch = _torch()
         if st != 0:
             return {"status": st, "consumed": 0, "symbols": None, "tags": det_tags, "detector_tags": det_tags}
-        with torch.cuda.stream(self._back_stream):
+        with torch.cuda.stream(self._streams[1]):
             # SyncwordDetectionFilter: gate the tags; the samples pass unchanged
             if callable(header_fn):
                 headers = [header_fn(t) for t in det_tags]
@@ -483,25 +485,35 @@ class PacketReceiver:
             z = self.freq_correction.process_bulk(y, tags)
             sym, sym_tags, consumed = self.symbol_filter.process_bulk(z, tags)
             w = self.syncword_wipeoff.process_bulk(sym, sym_tags)
-            c = self.costas_loop.process_bulk(w, sym_tags)
-        return {"status": 0, "consumed": n, "symbols": c, "tags": sym_tags, "detector_tags": det_tags,
+        return {"status": 0, "consumed": n, "symbols": w, "tags": sym_tags, "detector_tags": det_tags,
                 "accepted": acc}
+
+    def _stage2(self, res):
+        torch = _torch()
+        if res["status"] == 0:
+            with torch.cuda.stream(self._streams[2]):
+                res["symbols"] = self.costas_loop.process_bulk(res["symbols"], res["tags"])
+        return res
+
+    def _stage12(self, fut1):
+        return self._stage2(fut1.result())
 
     def process_bulk(self, x, header_fn=None, tags_cap=4096):
         """x: complex64 CUDA tensor.  Returns dict(consumed, symbols, tags, detector_tags):
         symbols = CostasLoop output (one per symbol), tags = symbol-rate tags.  With
-        pipelined=True the dict belongs to the previous batch (None on the first call)."""
-        front = self._front(x, tags_cap)
+        pipelined=True the dict belongs to an earlier batch (None while the pipeline fills)."""
+        front = self._stage0(x, tags_cap)
         if not self.pipelined:
-            return self._back(*front, header_fn)
-        prev = self._pending.result() if self._pending is not None else None
-        self._pending = self._worker.submit(self._back, *front, header_fn)
-        return prev
+            return self._stage2(self._stage1(*front, header_fn))
+        f1 = self._workers[0].submit(self._stage1, *front, header_fn)
+        f2 = self._workers[1].submit(self._stage12, f1)
+        self._inflight.append(f2)
+        if len(self._inflight) > 2:  # keep at most two batches behind the detector
+            return self._inflight.pop(0).result()
+        return None
 
     def flush(self):
-        """pipelined mode: result of the last submitted batch"""
-        if self._pending is None:
-            return None
-        res = self._pending.result()
-        self._pending = None
-        return res
+        """pipelined mode: results of the batches still in flight (oldest first)"""
+        out = [f.result() for f in self._inflight]
+        self._inflight = []
+        return out

@@ -245,15 +245,27 @@ __global__ void k_costas(const CostasSeg* __restrict__ segs, unsigned n_segs,
         else if (phase < -pi_f) phase += 2.0f * pi_f;
         return z;
     };
+    // Lanes walk different segments, so every load instruction touches 64 different cache
+    // lines: use as few (16-byte) instructions as possible and issue them ahead of the PLL.
     unsigned j = 0;
+    if (((base + j) & 1) && j < g.len) { // align to 16 bytes
+        out[base + j] = step(in[base + j]);
+        ++j;
+    }
     for (; j + 8 <= g.len; j += 8) {
-        cf x[8];
+        const float4* ip = reinterpret_cast<const float4*>(in + base + j);
+        float4 v[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) x[u] = in[base + j + u];
+        for (int u = 0; u < 4; ++u) v[u] = ip[u];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) x[u] = step(x[u]);
+        for (int u = 0; u < 4; ++u) {
+            const cf z0 = step(cf{ v[u].x, v[u].y });
+            const cf z1 = step(cf{ v[u].z, v[u].w });
+            v[u] = make_float4(z0.x, z0.y, z1.x, z1.y);
+        }
+        float4* op = reinterpret_cast<float4*>(out + base + j);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) out[base + j + u] = x[u];
+        for (int u = 0; u < 4; ++u) op[u] = v[u];
     }
     for (; j < g.len; ++j) out[base + j] = step(in[base + j]);
     if (g.last) {
