@@ -528,3 +528,18 @@ def test_syncword_detection_full_size_properties(pkg):
     both = np.concatenate([t1, t2])
     assert d1 + d2 == done and np.array_equal(both["index"], tags["index"])
     assert np.array_equal(both["amplitude"], tags["amplitude"]) and np.array_equal(both["phase"], tags["phase"])
+
+
+def test_c_abi_from_cpp(pkg, tmp_path):
+    """the boundary is usable from plain C++ (what a gr::Block wrapper does): build
+    tests/cabi_smoke.cpp against include/gr4pm_hip.h + libgr4pm_hip.so and run it"""
+    import os
+    import subprocess
+    exe = tmp_path / "cabi_smoke"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-Wno-unused-result",
+                           "-I", os.path.join(ge.ROOT, "include"), "-o", str(exe),
+                           os.path.join(ge.ROOT, "tests", "cabi_smoke.cpp"),
+                           "-L" + os.path.dirname(pkg.LIB_PATH), "-lgr4pm_hip",
+                           "-Wl,-rpath," + os.path.dirname(pkg.LIB_PATH)])
+    out = subprocess.check_output([str(exe)]).decode()
+    assert out.startswith("OK"), out
