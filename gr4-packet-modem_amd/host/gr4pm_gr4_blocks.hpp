@@ -21,8 +21,10 @@
 #include <gnuradio-4.0/reflection.hpp>
 #include <hip/hip_runtime.h>
 
+#include <cctype>
 #include <complex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "gr4pm_hip.h"
@@ -228,10 +230,313 @@ public:
     }
 };
 
-// The remaining wrappers (SyncwordDetectionFilter, SymbolFilter, CostasLoop, SyncwordWipeoff,
-// InterpolatingFirFilter, PfbArbResampler) follow the same three steps -- head tag -> gr4pm_tag
-// at index 0, stage, call gr4pm_<block>_process, publish re-timed tags -- and are listed with
-// their exact settings in INTEGRATION.md.
+// ---------------------------------------------------------------- SyncwordDetectionFilter
+// replaces gr::packet_modem::SyncwordDetectionFilter<c64> (syncword_detection_filter.hpp:10-211)
+class SyncwordDetectionFilter : public gr::Block<SyncwordDetectionFilter>
+{
+    using c64 = std::complex<float>;
+    gr4pm_syncword_detection_filter* _h = nullptr;
+    detail::DeviceStage<gr4pm_c64> _din, _dout;
+
+public:
+    gr::PortIn<gr::Message, gr::Async> parsed_header;
+    gr::PortIn<gr::Message, gr::Async> ignored_syncword;
+    gr::PortIn<c64> in;
+    gr::PortOut<c64> out;
+    size_t samples_per_symbol = 4;
+    size_t syncword_size = 64;
+    size_t header_size = 128;
+    constexpr static gr::TagPropagationPolicy tag_policy = gr::TagPropagationPolicy::TPP_CUSTOM;
+
+    ~SyncwordDetectionFilter() { gr4pm_syncword_detection_filter_destroy(_h); }
+    void start()
+    {
+        gr4pm_syncword_detection_filter_destroy(_h);
+        gr4pm_syncword_detection_filter_params p{ samples_per_symbol, syncword_size, header_size, nullptr };
+        detail::check(gr4pm_syncword_detection_filter_create(&p, &_h), "SyncwordDetectionFilter::start");
+    }
+    gr::work::Status processBulk(const gr::ConsumableSpan auto& headerSpan,
+                                 const gr::ConsumableSpan auto& ignoredSpan,
+                                 const gr::ConsumableSpan auto& inSpan, gr::PublishableSpan auto& outSpan)
+    {
+        int head_flags = 0;
+        gr::property_map syncword_keys, other_keys;
+        if (this->input_tags_present()) { // :75-93
+            for (const auto& [key, val] : this->mergedInputTag().map) {
+                if (key.starts_with("syncword_")) {
+                    head_flags |= GR4PM_TAG_SYNCWORD;
+                    syncword_keys[key] = val;
+                } else {
+                    head_flags |= GR4PM_TAG_OTHER;
+                    other_keys[key] = val;
+                }
+            }
+        }
+        std::vector<gr4pm_header_msg> msgs;
+        for (size_t i = 0; i < headerSpan.size(); ++i) { // :134-152
+            const auto& meta = headerSpan[i].data.value();
+            gr4pm_header_msg m{};
+            m.invalid_header = meta.contains("invalid_header") ? 1 : 0;
+            if (!m.invalid_header) m.packet_length = pmtv::cast<uint64_t>(meta.at("packet_length"));
+            msgs.push_back(m);
+        }
+        const size_t n = std::min(inSpan.size(), outSpan.size());
+        gr4pm_c64* din = _din.get(n);
+        gr4pm_c64* dout = _dout.get(n);
+        (void)hipMemcpy(din, &*inSpan.begin(), n * sizeof(c64), hipMemcpyHostToDevice);
+        size_t consumed = 0, hc = 0, ic = 0;
+        int out_flags = 0;
+        detail::check(gr4pm_syncword_detection_filter_process(_h, din, n, dout, n, head_flags, msgs.data(),
+                                                              msgs.size(), ignoredSpan.size(), &consumed, &hc,
+                                                              &ic, &out_flags),
+                      "SyncwordDetectionFilter::processBulk");
+        (void)hipMemcpy(&*outSpan.begin(), dout, consumed * sizeof(c64), hipMemcpyDeviceToHost);
+        gr::property_map output_tags; // :82-104
+        if (out_flags & GR4PM_TAG_SYNCWORD) output_tags.insert(syncword_keys.begin(), syncword_keys.end());
+        if (out_flags & GR4PM_TAG_OTHER) output_tags.insert(other_keys.begin(), other_keys.end());
+        if (!output_tags.empty()) out.publishTag(output_tags, 0);
+        if (!inSpan.consume(consumed)) throw gr::exception("inSpan.consume failed");
+        if (!headerSpan.consume(hc)) throw gr::exception("headerSpan.consume failed");
+        if (!ignoredSpan.consume(ic)) throw gr::exception("ignoredSpan.consume failed");
+        outSpan.publish(consumed);
+        this->_mergedInputTag.map.clear(); // :125,202
+        return gr::work::Status::OK;
+    }
+};
+
+// ---------------------------------------------------------------- SymbolFilter
+// replaces gr::packet_modem::SymbolFilter<c64, c64, float> (symbol_filter.hpp:13-253)
+class SymbolFilter : public gr::Block<SymbolFilter, gr::Resampling<>>
+{
+    using c64 = std::complex<float>;
+    gr4pm_symbol_filter* _h = nullptr;
+    detail::DeviceStage<gr4pm_c64> _din, _dout;
+    std::vector<gr::property_map> _held; // full maps of queued tags (opaque keys travel with them)
+    std::vector<gr4pm_tag> _tags_out;
+
+public:
+    gr::PortIn<c64> in;
+    gr::PortOut<c64> out;
+    size_t samples_per_symbol = 4;
+    std::vector<float> taps;
+    size_t num_arms = 32;
+    size_t delay = 0;
+    constexpr static gr::TagPropagationPolicy tag_policy = gr::TagPropagationPolicy::TPP_CUSTOM;
+
+    ~SymbolFilter() { gr4pm_symbol_filter_destroy(_h); }
+    void settingsChanged(const gr::property_map&, const gr::property_map&)
+    {
+        gr4pm_symbol_filter_destroy(_h);
+        _h = nullptr;
+        gr4pm_symbol_filter_params p{ samples_per_symbol, taps.data(), taps.size(), num_arms, delay, 0, nullptr };
+        detail::check(gr4pm_symbol_filter_create(&p, &_h), "SymbolFilter::settingsChanged"); // :67-73 throw
+        _tags_out.resize(64);
+    }
+    void start() { detail::check(gr4pm_symbol_filter_reset(_h), "SymbolFilter::start"); }
+    gr::work::Status processBulk(const gr::ConsumableSpan auto& inSpan, gr::PublishableSpan auto& outSpan)
+    {
+        gr4pm_tag tag{};
+        size_t n_tags = 0;
+        if (this->input_tags_present()) { // :127-206: the tag refers to inSpan[0]
+            tag = detail::from_map(this->mergedInputTag().map, 0);
+            tag.freq_bin = static_cast<int32_t>(_held.size()); // handle of the full map
+            _held.push_back(this->mergedInputTag().map);
+            n_tags = 1;
+        }
+        const size_t n = inSpan.size();
+        gr4pm_c64* din = _din.get(n);
+        gr4pm_c64* dout = _dout.get(outSpan.size());
+        (void)hipMemcpy(din, &*inSpan.begin(), n * sizeof(c64), hipMemcpyHostToDevice);
+        size_t n_out_tags = 0, consumed = 0, produced = 0;
+        detail::check(gr4pm_symbol_filter_process(_h, din, n, dout, outSpan.size(), &tag, n_tags, _tags_out.data(),
+                                                  _tags_out.size(), &n_out_tags, &consumed, &produced),
+                      "SymbolFilter::processBulk");
+        (void)hipMemcpy(&*outSpan.begin(), dout, produced * sizeof(c64), hipMemcpyDeviceToHost);
+        for (size_t i = 0; i < n_out_tags; ++i) { // :218-228 re-timed tags, :152-155 adjusted phase
+            auto map = _held.at(static_cast<size_t>(_tags_out[i].freq_bin));
+            if (_tags_out[i].flags & GR4PM_TAG_SYNCWORD) map["syncword_phase"] = _tags_out[i].phase;
+            out.publishTag(map, static_cast<ssize_t>(_tags_out[i].index));
+        }
+        if (!inSpan.consume(consumed)) throw gr::exception("consume failed"); // :240-243
+        outSpan.publish(produced);
+        return gr::work::Status::OK;
+    }
+};
+
+// ---------------------------------------------------------------- CostasLoop
+// replaces gr::packet_modem::CostasLoop<float, float> (costas_loop.hpp:15-149)
+class CostasLoop : public gr::Block<CostasLoop>
+{
+    using c64 = std::complex<float>;
+    gr4pm_costas_loop* _h = nullptr;
+    detail::DeviceStage<gr4pm_c64> _din, _dout;
+    static int constellation_id(const std::string& s)
+    {
+        std::string u;
+        for (char c : s) u.push_back(static_cast<char>(std::toupper(c)));
+        if (u == "PILOT") return 0;
+        if (u == "BPSK") return 1;
+        if (u == "QPSK") return 2;
+        throw gr::exception("unknown constellation " + s); // enum_cast(...).value() throws, :59-61
+    }
+
+public:
+    gr::PortIn<c64> in;
+    gr::PortOut<c64> out;
+    double loop_bandwidth = 0.01;
+    std::string constellation = "BPSK";
+
+    ~CostasLoop() { gr4pm_costas_loop_destroy(_h); }
+    void settingsChanged(const gr::property_map&, const gr::property_map&) // :52-88 (also driven by tags)
+    {
+        if (!_h) {
+            gr4pm_costas_loop_params p{ loop_bandwidth, constellation_id(constellation), 1, nullptr };
+            detail::check(gr4pm_costas_loop_create(&p, &_h), "CostasLoop::settingsChanged");
+        } else {
+            detail::check(gr4pm_costas_loop_set(_h, loop_bandwidth, constellation_id(constellation)), "CostasLoop::set");
+        }
+    }
+    gr::work::Status processBulk(const gr::ConsumableSpan auto& inSpan, gr::PublishableSpan auto& outSpan)
+    {
+        gr4pm_tag tag{};
+        size_t n_tags = 0;
+        if (this->input_tags_present() && this->mergedInputTag().map.contains("syncword_phase")) { // :101-106
+            tag.index = 0;
+            tag.flags = GR4PM_TAG_SYNCWORD;
+            tag.phase = pmtv::cast<float>(this->mergedInputTag().map.at("syncword_phase"));
+            n_tags = 1;
+        }
+        const size_t n = std::min(inSpan.size(), outSpan.size());
+        gr4pm_c64* din = _din.get(n);
+        gr4pm_c64* dout = _dout.get(n);
+        (void)hipMemcpy(din, &*inSpan.begin(), n * sizeof(c64), hipMemcpyHostToDevice);
+        detail::check(gr4pm_costas_loop_process(_h, din, n, n, dout, &tag, nullptr, n_tags), "CostasLoop::processBulk");
+        (void)hipMemcpy(&*outSpan.begin(), dout, n * sizeof(c64), hipMemcpyDeviceToHost);
+        if (!inSpan.consume(n)) throw gr::exception("consume failed");
+        outSpan.publish(n);
+        return gr::work::Status::OK;
+    }
+};
+
+// ---------------------------------------------------------------- SyncwordWipeoff
+// replaces gr::packet_modem::SyncwordWipeoff<c64, float> (syncword_wipeoff.hpp:12-91)
+class SyncwordWipeoff : public gr::Block<SyncwordWipeoff>
+{
+    using c64 = std::complex<float>;
+    gr4pm_syncword_wipeoff* _h = nullptr;
+    detail::DeviceStage<gr4pm_c64> _din, _dout;
+
+public:
+    gr::PortIn<c64> in;
+    gr::PortOut<c64> out;
+    std::vector<float> syncword;
+
+    ~SyncwordWipeoff() { gr4pm_syncword_wipeoff_destroy(_h); }
+    void start()
+    {
+        gr4pm_syncword_wipeoff_destroy(_h);
+        gr4pm_syncword_wipeoff_params p{ syncword.data(), syncword.size(), nullptr };
+        detail::check(gr4pm_syncword_wipeoff_create(&p, &_h), "SyncwordWipeoff::start");
+    }
+    gr::work::Status processBulk(const gr::ConsumableSpan auto& inSpan, gr::PublishableSpan auto& outSpan)
+    {
+        gr4pm_tag tag{};
+        size_t n_tags = 0;
+        if (this->input_tags_present() && this->mergedInputTag().map.contains("syncword_amplitude")) { // :53-62
+            tag.index = 0;
+            tag.flags = GR4PM_TAG_SYNCWORD;
+            n_tags = 1;
+        }
+        const size_t n = std::min(inSpan.size(), outSpan.size());
+        gr4pm_c64* din = _din.get(n);
+        gr4pm_c64* dout = _dout.get(n);
+        (void)hipMemcpy(din, &*inSpan.begin(), n * sizeof(c64), hipMemcpyHostToDevice);
+        detail::check(gr4pm_syncword_wipeoff_process(_h, din, n, dout, &tag, n_tags), "SyncwordWipeoff::processBulk");
+        (void)hipMemcpy(&*outSpan.begin(), dout, n * sizeof(c64), hipMemcpyDeviceToHost);
+        if (!inSpan.consume(n)) throw gr::exception("consume failed");
+        outSpan.publish(n);
+        return gr::work::Status::OK;
+    }
+};
+
+// ---------------------------------------------------------------- InterpolatingFirFilter
+// replaces gr::packet_modem::InterpolatingFirFilter<c64, c64, float> (interpolating_fir_filter.hpp:14-103)
+class InterpolatingFirFilter : public gr::Block<InterpolatingFirFilter, gr::Resampling<>>
+{
+    using c64 = std::complex<float>;
+    gr4pm_interp_fir* _h = nullptr;
+    detail::DeviceStage<gr4pm_c64> _din, _dout;
+
+public:
+    gr::PortIn<c64> in;
+    gr::PortOut<c64> out;
+    size_t interpolation = 1;
+    std::vector<float> taps;
+
+    ~InterpolatingFirFilter() { gr4pm_interp_fir_destroy(_h); }
+    void settingsChanged(const gr::property_map&, const gr::property_map&)
+    {
+        gr4pm_interp_fir_destroy(_h);
+        _h = nullptr;
+        gr4pm_interp_fir_params p{ interpolation, taps.data(), taps.size(), 0, nullptr };
+        detail::check(gr4pm_interp_fir_create(&p, &_h), "InterpolatingFirFilter::settingsChanged"); // :45-47
+        this->input_chunk_size = 1; // :50-51
+        this->output_chunk_size = interpolation;
+    }
+    gr::work::Status processBulk(const gr::ConsumableSpan auto& inSpan, gr::PublishableSpan auto& outSpan)
+    {
+        const size_t n = std::min(inSpan.size(), outSpan.size() / interpolation); // :91
+        gr4pm_c64* din = _din.get(n);
+        gr4pm_c64* dout = _dout.get(n * interpolation);
+        (void)hipMemcpy(din, &*inSpan.begin(), n * sizeof(c64), hipMemcpyHostToDevice);
+        detail::check(gr4pm_interp_fir_process(_h, din, n, dout), "InterpolatingFirFilter::processBulk");
+        (void)hipMemcpy(&*outSpan.begin(), dout, n * interpolation * sizeof(c64), hipMemcpyDeviceToHost);
+        if (!inSpan.consume(n)) throw gr::exception("consume failed");
+        outSpan.publish(n * interpolation);
+        return gr::work::Status::OK;
+    }
+};
+
+// ---------------------------------------------------------------- PfbArbResampler
+// replaces gr::packet_modem::PfbArbResampler<c64, c64, float, TRate> (pfb_arb_resampler.hpp:23-183)
+template <typename TRate = float>
+class PfbArbResampler : public gr::Block<PfbArbResampler<TRate>>
+{
+    using c64 = std::complex<float>;
+    gr4pm_pfb_arb_resampler* _h = nullptr;
+    detail::DeviceStage<gr4pm_c64> _din, _dout;
+
+public:
+    gr::PortIn<c64, gr::Async> in;   // :59-62: no rational resampling ratio
+    gr::PortOut<c64, gr::Async> out;
+    TRate rate{ 1.0 };
+    std::vector<float> taps; // the reference's default (pfb_arb_taps.hpp) ships as data/pfb_arb_taps.f32
+    size_t filter_size = 32;
+
+    ~PfbArbResampler() { gr4pm_pfb_arb_resampler_destroy(_h); }
+    void settingsChanged(const gr::property_map&, const gr::property_map&)
+    {
+        gr4pm_pfb_arb_resampler_destroy(_h);
+        _h = nullptr;
+        gr4pm_pfb_arb_resampler_params p{ static_cast<double>(rate), std::is_same_v<TRate, double> ? 1 : 0,
+                                          taps.data(), taps.size(), filter_size, nullptr };
+        detail::check(gr4pm_pfb_arb_resampler_create(&p, &_h), "PfbArbResampler::settingsChanged"); // :70-72
+    }
+    gr::work::Status processBulk(const gr::ConsumableSpan auto& inSpan, gr::PublishableSpan auto& outSpan)
+    {
+        const size_t n = inSpan.size();
+        gr4pm_c64* din = _din.get(n);
+        gr4pm_c64* dout = _dout.get(outSpan.size());
+        (void)hipMemcpy(din, &*inSpan.begin(), n * sizeof(c64), hipMemcpyHostToDevice);
+        size_t consumed = 0, produced = 0;
+        detail::check(gr4pm_pfb_arb_resampler_process(_h, din, n, dout, outSpan.size(), &consumed, &produced),
+                      "PfbArbResampler::processBulk");
+        (void)hipMemcpy(&*outSpan.begin(), dout, produced * sizeof(c64), hipMemcpyDeviceToHost);
+        if (!inSpan.consume(consumed)) throw gr::exception("consume failed"); // :169-172
+        outSpan.publish(produced);
+        return gr::work::Status::OK;
+    }
+};
 
 } // namespace gr::packet_modem::hip
 
@@ -239,3 +544,10 @@ ENABLE_REFLECTION(gr::packet_modem::hip::SyncwordDetection, in, out, fft_size, s
                   syncword, constellation, min_freq_bin, max_freq_bin, time_threshold, power_threshold);
 ENABLE_REFLECTION(gr::packet_modem::hip::Rotator, in, out, phase_incr);
 ENABLE_REFLECTION(gr::packet_modem::hip::CoarseFrequencyCorrection, in, out, delay);
+ENABLE_REFLECTION(gr::packet_modem::hip::SyncwordDetectionFilter, parsed_header, ignored_syncword, in, out,
+                  samples_per_symbol, syncword_size, header_size);
+ENABLE_REFLECTION(gr::packet_modem::hip::SymbolFilter, in, out, samples_per_symbol, taps, num_arms, delay);
+ENABLE_REFLECTION(gr::packet_modem::hip::CostasLoop, in, out, loop_bandwidth, constellation);
+ENABLE_REFLECTION(gr::packet_modem::hip::SyncwordWipeoff, in, out, syncword);
+ENABLE_REFLECTION(gr::packet_modem::hip::InterpolatingFirFilter, in, out, interpolation, taps);
+ENABLE_REFLECTION_FOR_TEMPLATE(gr::packet_modem::hip::PfbArbResampler, in, out, rate, taps, filter_size);
