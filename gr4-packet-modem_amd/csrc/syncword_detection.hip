@@ -589,6 +589,148 @@ __global__ __launch_bounds__(64) void k_tags(const cf* __restrict__ in, size_t i
     }
 }
 
+// =====================================================================================
+// Generic power-of-two block size (fft_size != 2048): one 256-thread workgroup per block,
+// in-place radix-2 FFT in LDS (bit-reversed load, log2 N stages).  Same arithmetic contract
+// as the tuned path (forward, un-normalised), far less tuned: it exists so that `fft_size`
+// stays the free setting it is in the reference (syncword_detection.hpp:133).
+// LDS: X (N cf) + work (N cf).  Templates natural order [bin][N]; twiddles tw[k] = W_N^k, k < N/2.
+// =====================================================================================
+__device__ __forceinline__ uint32_t bitrev(uint32_t v, int bits) { return __brev(v) >> (32 - bits); }
+
+// in-place DIT FFT of `a` (already bit-reversed), all threads of the workgroup
+__device__ __forceinline__ void wg_fft_inplace(cf* a, const cf* __restrict__ tw, uint32_t N, int log2n)
+{
+    for (int s = 1; s <= log2n; ++s) {
+        const uint32_t half = 1u << (s - 1);
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < N / 2; t += blockDim.x) {
+            const uint32_t grp = t >> (s - 1), j = t & (half - 1);
+            const uint32_t i0 = (grp << s) + j, i1 = i0 + half;
+            const cf w = tw[j << (log2n - s)];
+            const cf u = a[i0], v = cmulc(a[i1], w);
+            a[i0] = u + v;
+            a[i1] = u - v;
+        }
+    }
+    __syncthreads();
+}
+
+// mode 0: zpow for all lags of block blockIdx.x.  mode 1 (k_tags_generic): see below.
+__global__ __launch_bounds__(256) void k_correlate_generic(const cf* __restrict__ in, size_t in_stride,
+                                                           uint32_t n_blocks, uint32_t stride_s, uint32_t N,
+                                                           int log2n, int n_bins, const cf* __restrict__ tmpl,
+                                                           const cf* __restrict__ tw, float* __restrict__ zpow,
+                                                           size_t z_stride)
+{
+    extern __shared__ cf gl[];
+    cf* X = gl;
+    cf* W = gl + N;
+    const uint32_t b = blockIdx.x;
+    const cf* x = in + static_cast<size_t>(blockIdx.y) * in_stride + static_cast<size_t>(b) * stride_s;
+    float* zo = zpow + static_cast<size_t>(blockIdx.y) * z_stride + static_cast<size_t>(b) * stride_s;
+    for (uint32_t i = threadIdx.x; i < N; i += 256) X[bitrev(i, log2n)] = x[i];
+    wg_fft_inplace(X, tw, N, log2n);
+    constexpr int kMaxPer = 32; // N <= 8192
+    float zmax[kMaxPer];
+#pragma unroll
+    for (int u = 0; u < kMaxPer; ++u) zmax[u] = -1.0f;
+    for (int bin = 0; bin < n_bins; ++bin) {
+        const cf* t = tmpl + static_cast<size_t>(bin) * N;
+        for (uint32_t i = threadIdx.x; i < N; i += 256) W[bitrev(i, log2n)] = cmulc(X[i], t[i]);
+        wg_fft_inplace(W, tw, N, log2n);
+#pragma unroll
+        for (int u = 0; u < kMaxPer; ++u) {
+            const uint32_t lag = u * 256 + threadIdx.x;
+            if (lag < stride_s) zmax[u] = fmaxf(zmax[u], cnorm(W[(N - lag) & (N - 1)]));
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < kMaxPer; ++u) {
+        const uint32_t lag = u * 256 + threadIdx.x;
+        if (lag < stride_s) zo[lag] = zmax[u];
+    }
+    (void)n_blocks;
+}
+
+// generic-size counterpart of k_tags: one 256-thread workgroup per pending detection
+__global__ __launch_bounds__(256) void k_tags_generic(const cf* __restrict__ in, size_t in_stride,
+                                                      const cf* __restrict__ carry, size_t carry_stride,
+                                                      uint32_t xc, unsigned long long E0, unsigned long long E1,
+                                                      uint32_t hist, uint32_t stride_s, uint32_t N, int log2n,
+                                                      int n_bins, const cf* __restrict__ tmpl,
+                                                      const cf* __restrict__ tw, const float* __restrict__ zcur,
+                                                      size_t z_stride, ChanState* __restrict__ st,
+                                                      const unsigned long long* __restrict__ det, uint32_t det_cap,
+                                                      RawTag* __restrict__ rec, uint32_t rec_cap)
+{
+    extern __shared__ cf gl[];
+    __shared__ cf zbin[kMaxBins];
+    __shared__ float red[256];
+    cf* X = gl;
+    cf* W = gl + N;
+    const uint32_t ch = blockIdx.y, idx = blockIdx.x;
+    const uint32_t n_det = min(st[ch].det_cnt, det_cap);
+    if (idx >= n_det) return;
+    const unsigned long long pos = det[static_cast<size_t>(ch) * det_cap + idx];
+    const unsigned long long c = pos + hist;
+    if (c < E0 || c >= E1) return;
+    const unsigned long long blk = pos / stride_s;
+    const uint32_t lag = static_cast<uint32_t>(pos - blk * stride_s);
+    const long long o = static_cast<long long>(blk * stride_s) - static_cast<long long>(E0);
+    const cf* cur = in + static_cast<size_t>(ch) * in_stride;
+    const cf* car = carry + static_cast<size_t>(ch) * carry_stride;
+    for (uint32_t i = threadIdx.x; i < N; i += 256) X[bitrev(i, log2n)] = sample_at(cur, car, xc, o + i);
+    wg_fft_inplace(X, tw, N, log2n);
+    float noise = 0.0f; // hpp:257-265
+    for (uint32_t k = N / 4 + threadIdx.x; k < 3 * N / 4; k += 256) noise += cnorm(X[k]);
+    red[threadIdx.x] = noise;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if (static_cast<int>(threadIdx.x) < d) red[threadIdx.x] += red[threadIdx.x + d];
+        __syncthreads();
+    }
+    noise = red[0] / (static_cast<float>(N / 2) * static_cast<float>(N));
+    for (int bin = 0; bin < n_bins; ++bin) {
+        const cf* t = tmpl + static_cast<size_t>(bin) * N;
+        for (uint32_t i = threadIdx.x; i < N; i += 256) W[bitrev(i, log2n)] = cmulc(X[i], t[i]);
+        wg_fft_inplace(W, tw, N, log2n);
+        if (threadIdx.x == 0) zbin[bin] = W[(N - lag) & (N - 1)];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int best = 0;
+        cf z = mk(0.f, 0.f);
+        float zp = -1.0f;
+        for (int bin = 0; bin < n_bins; ++bin) {
+            const float p = cnorm(zbin[bin]);
+            if (p > zp) {
+                best = bin;
+                z = zbin[bin];
+                zp = p;
+            }
+        }
+        RawTag t;
+        t.pos = pos;
+        t.zx = z.x;
+        t.zy = z.y;
+        t.zpow = zp;
+        t.left = best > 0 ? cnorm(zbin[best - 1]) : 0.0f;
+        t.right = best < n_bins - 1 ? cnorm(zbin[best + 1]) : 0.0f;
+        const float* z0 = zcur + static_cast<size_t>(ch) * z_stride;
+        const long long rel = static_cast<long long>(pos) - static_cast<long long>(E0);
+        t.prev = z0[rel - 1];
+        t.next = z0[rel + 1];
+        t.noise = noise;
+        t.bin_idx = best;
+        t.pad = 0;
+        const unsigned int slot = atomicAdd(&st[ch].rec_cnt, 1u);
+        if (slot < rec_cap) rec[static_cast<size_t>(ch) * rec_cap + slot] = t;
+        else st[ch].overflow = 1;
+    }
+}
+
 // drop emitted detections (pos + hist < E1) from the pending list; one wave per channel
 __global__ __launch_bounds__(64) void k_compact_pending(ChanState* __restrict__ st,
                                                         unsigned long long* __restrict__ det, uint32_t det_cap,
@@ -696,6 +838,10 @@ struct gr4pm_syncword_detection {
     // device
     DevBuf<float4> tmpl;
     DevBuf<cf> tw; // tw1a ++ tw1b ++ twA ++ twB (fft2048_wave.hpp)
+    // generic block sizes (fft_size != 2048)
+    bool generic = false;
+    int log2n = 0;
+    DevBuf<cf> g_tmpl, g_tw;
     DevBuf<cf> carry[2];
     DevBuf<float> z[2];
     DevBuf<unsigned long long> bitmap;
@@ -779,6 +925,15 @@ void finish_tag(const gr4pm_syncword_detection* h, const RawTag& t, uint64_t out
 gr4pm_status launch_correlate(gr4pm_syncword_detection* h, const gr4pm_c64* in, size_t in_stride,
                               uint32_t n_blocks, float* zout)
 {
+    if (h->generic) {
+        const uint32_t N = static_cast<uint32_t>(h->fft_size);
+        hipLaunchKernelGGL(k_correlate_generic, dim3(n_blocks, static_cast<unsigned>(h->n_channels)), dim3(256),
+                           2 * N * sizeof(cf), h->stream, reinterpret_cast<const cf*>(in), in_stride, n_blocks,
+                           static_cast<uint32_t>(h->S), N, h->log2n, h->n_bins, h->g_tmpl.p, h->g_tw.p, zout,
+                           h->z_stride);
+        GR4PM_HIP_TRY(hipGetLastError());
+        return GR4PM_OK;
+    }
     dim3 grid((n_blocks + kWavesPerWg - 1) / kWavesPerWg, static_cast<unsigned>(h->n_channels));
     const cf* tw1a = h->tw.p;
     const cf* tw1b = tw1a + kTw1aItems;
@@ -818,8 +973,10 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
             set_error("syncword symbol outside constellation");
             return GR4PM_ERR_INVALID;
         }
-    if (p->fft_size != static_cast<size_t>(kFftN)) {
-        set_error("fft_size %zu not built (supported: 2048)", p->fft_size);
+    const bool pow2 = p->fft_size >= 256 && p->fft_size <= 8192 && (p->fft_size & (p->fft_size - 1)) == 0;
+    if (!pow2) {
+        set_error("fft_size %zu not built (supported: powers of two 256..8192; 2048 is the tuned path)",
+                  p->fft_size);
         return GR4PM_ERR_UNSUPPORTED;
     }
     const int n_bins = p->max_freq_bin - p->min_freq_bin + 1;
@@ -832,6 +989,9 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
     auto* h = new (std::nothrow) gr4pm_syncword_detection;
     if (!h) return GR4PM_ERR_NOMEM;
     h->fft_size = p->fft_size;
+    h->generic = p->fft_size != static_cast<size_t>(kFftN);
+    h->log2n = 0;
+    while ((size_t{ 1 } << h->log2n) < p->fft_size) ++h->log2n;
     h->sps = p->samples_per_symbol;
     h->n_channels = p->n_channels;
     h->min_bin = p->min_freq_bin;
@@ -858,7 +1018,8 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
     float self_corr = 0.0f;
     for (auto x : sw) self_corr += x.real() * x.real() + x.imag() * x.imag(); // hpp:161-164
     h->self_corr = self_corr;
-    std::vector<float4> tmpl(static_cast<size_t>(n_bins) * 1024);
+    std::vector<float4> tmpl(h->generic ? 1 : static_cast<size_t>(n_bins) * 1024);
+    std::vector<cf> g_tmpl(h->generic ? static_cast<size_t>(n_bins) * p->fft_size : 0);
     for (int b = 0; b < n_bins; ++b) {
         const int freq_bin = p->min_freq_bin + b;
         double phase = 0.0;
@@ -876,6 +1037,12 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
             }
         }
         fft_double(a);
+        if (h->generic) { // conj (hpp:185-187), natural order
+            for (size_t k = 0; k < p->fft_size; ++k)
+                g_tmpl[static_cast<size_t>(b) * p->fft_size + k] =
+                    mk(static_cast<float>(a[k].real()), static_cast<float>(-a[k].imag()));
+            continue;
+        }
         // conj (hpp:185-187), rounded to float32, laid out in FFT-1's output distribution
         for (int lane = 0; lane < 64; ++lane)
             for (int jp = 0; jp < 16; ++jp) {
@@ -910,6 +1077,23 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
     };
     ok(h->tmpl.alloc(tmpl.size()));
     ok(h->tw.alloc(tw.size()));
+    std::vector<cf> g_tw(h->generic ? p->fft_size / 2 : 0);
+    for (size_t k = 0; k < g_tw.size(); ++k) {
+        const double ang = -2.0 * M_PI * static_cast<double>(k) / static_cast<double>(p->fft_size);
+        g_tw[k] = mk(static_cast<float>(std::cos(ang)), static_cast<float>(std::sin(ang)));
+    }
+    if (h->generic) {
+        ok(h->g_tmpl.alloc(g_tmpl.size()));
+        ok(h->g_tw.alloc(g_tw.size()));
+        const int lds_bytes = static_cast<int>(2 * p->fft_size * sizeof(cf)) + 2048;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_correlate_generic),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_tags_generic),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) {
+            set_error("cannot reserve %d bytes of LDS for fft_size %zu", lds_bytes, p->fft_size);
+            ok(GR4PM_ERR_HIP);
+        }
+    }
     for (int i = 0; i < 2; ++i) {
         ok(h->carry[i].alloc(static_cast<size_t>(h->xc) * h->n_channels));
         ok(h->z[i].alloc(h->z_stride * h->n_channels));
@@ -926,6 +1110,8 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
     ok(h->rec.alloc(static_cast<size_t>(h->rec_cap) * h->n_channels));
     ok(h->st_host.alloc(h->n_channels));
     ok(h->rec_host.alloc(static_cast<size_t>(h->rec_cap) * h->n_channels));
+    if (s == GR4PM_OK && h->generic) s = h->g_tmpl.upload(g_tmpl.data(), g_tmpl.size(), h->stream);
+    if (s == GR4PM_OK && h->generic) s = h->g_tw.upload(g_tw.data(), g_tw.size(), h->stream);
     if (s == GR4PM_OK) s = h->tmpl.upload(tmpl.data(), tmpl.size(), h->stream);
     if (s == GR4PM_OK) s = h->tw.upload(tw.data(), tw.size(), h->stream);
     if (s == GR4PM_OK && hipStreamSynchronize(h->stream) != hipSuccess) s = GR4PM_ERR_HIP;
@@ -1024,6 +1210,15 @@ gr4pm_status gr4pm_syncword_detection_process(gr4pm_syncword_detection* h, const
                            h->power_threshold, n_tiles, h->entry.p, h->st.p, h->det.p, h->det_cap);
     }
     // tags leaving in this call
+    if (h->generic) {
+        const uint32_t N = static_cast<uint32_t>(h->fft_size);
+        hipLaunchKernelGGL(k_tags_generic, dim3(h->det_cap, nch), dim3(256), 2 * N * sizeof(cf), s,
+                           reinterpret_cast<const cf*>(in), in_stride, carry, static_cast<size_t>(h->xc), h->xc,
+                           static_cast<unsigned long long>(E0), static_cast<unsigned long long>(E1),
+                           static_cast<uint32_t>(h->hist), static_cast<uint32_t>(h->S), N, h->log2n, h->n_bins,
+                           h->g_tmpl.p, h->g_tw.p, zcur + h->zc, h->z_stride, h->st.p, h->det.p, h->det_cap,
+                           h->rec.p, h->rec_cap);
+    } else
     hipLaunchKernelGGL(k_tags, dim3(h->det_cap, nch), dim3(64), 0, s, reinterpret_cast<const cf*>(in),
                        in_stride, carry, static_cast<size_t>(h->xc), h->xc,
                        static_cast<unsigned long long>(E0), static_cast<unsigned long long>(E1),

@@ -73,7 +73,8 @@ typedef struct {
  * ---------------------------------------------------------------------------------- */
 typedef struct gr4pm_syncword_detection gr4pm_syncword_detection;
 typedef struct {
-    size_t fft_size;           /* :133, default 2048 (supported here: 2048) */
+    size_t fft_size;           /* :133, default 2048 (tuned one-wave path); other powers of two
+                                  256..8192 run the generic workgroup-per-block path */
     size_t samples_per_symbol; /* :134 */
     const float* rrc_taps;     /* :135 host */
     size_t n_rrc_taps;

@@ -543,3 +543,49 @@ def test_c_abi_from_cpp(pkg, tmp_path):
                            "-Wl,-rpath," + os.path.dirname(pkg.LIB_PATH)])
     out = subprocess.check_output([str(exe)]).decode()
     assert out.startswith("OK"), out
+
+
+@pytest.mark.parametrize("fft_size,ntaps_req", [(4096, 1024), (1024, 44), (512, 44)])
+def test_syncword_detection_other_fft_sizes(pkg, fft_size, ntaps_req):
+    """fft_size is a free setting in the reference (hpp:133); BASELINE config 5 shape: N = 4096 with
+    a 1024-tap RRC (1025 taps -> L = 63*4 + 1025 = 1277, stride 2820).  Generic-size kernels."""
+    sps = 4
+    rrc = orc.rrc_taps(1.0, float(sps), 1.0, 0.35, ntaps_req)
+    rrc = (rrc / np.sqrt(np.sum(rrc.astype(np.float64) ** 2))).astype(np.float32)
+    rng = np.random.default_rng(fft_size)
+    nsym = 40000
+    symbols = rng.integers(0, 2, nsym).astype(np.uint8)
+    locs = [300, 5000, 12000, 25000, 33000]
+    for loc in locs:
+        symbols[loc:loc + 64] = sig.SYNCWORD
+    x = orc.interpolating_fir(sig.BPSK[symbols], sps, rrc)
+    x = (orc.rotator(x, np.float32(0.004)) + sig.awgn(x.size, 0.05, 7)).astype(np.complex64)
+    L = 63 * sps + rrc.size
+    if L > fft_size:
+        pytest.skip("syncword longer than the block")
+    kw = dict(fft_size=fft_size, power_threshold=15.0)
+    ref = orc.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -2, 2, **kw)
+    st0, ref_out, ref_tags, ref_zpow, _ = ref.process(x, debug=True)
+    sd = pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -2, 2, max_items=x.size, **kw)
+    assert sd._syncword_samples_size == L
+    st, out, tags, n = sd.process_bulk(dev(x))
+    assert st == st0 == 0 and n == ref_out.size
+    assert np.array_equal(bits(host(out)), bits(ref_out))
+    assert ref_tags.size >= 4
+    assert_tags_match(tags, ref_tags, rtol=3e-4)
+    zpow = host(sd.last_zpow(n))[0]
+    assert np.max(np.abs(zpow - ref_zpow)) / np.max(ref_zpow) < 5e-6
+    # streaming in two calls gives the same tags
+    sd2 = pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -2, 2, max_items=x.size, **kw)
+    cut = x.size // 2
+    _, _, t1, d1 = sd2.process_bulk(dev(x[:cut]), want_output=False)
+    _, _, t2, d2 = sd2.process_bulk(dev(x[d1:]), want_output=False)
+    t2 = t2.copy()
+    t2["index"] += d1
+    assert d1 + d2 == n and np.array_equal(np.concatenate([t1, t2])["index"], tags["index"])
+
+
+def test_syncword_detection_unsupported_fft_size_is_reported(pkg):
+    rrc, _ = orc.unit_norm_rrc(4)
+    with pytest.raises(pkg.Gr4pmError, match="not built"):
+        pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, 0, 0, fft_size=3000)
