@@ -54,7 +54,7 @@ def unit_norm_rrc(pkg):
     return (t / np.float32(np.sqrt(norm))).astype(np.float32)
 
 
-def burst_stream(n_items, rrc, seed, device):
+def burst_stream(pkg, n_items, rrc, seed, device):
     """synthetic 3.2 Msps-shaped bursts, generated on the GPU:
     packets of 64 (BPSK syncword) + 128 (header) + 1504*4 (payload) QPSK symbols, gaps of 500
     zero symbols, CFO uniform in +-0.03 rad/sample per packet, AWGN at Es/N0 = 10 dB."""
@@ -72,15 +72,9 @@ def burst_stream(n_items, rrc, seed, device):
     sym[:, :64] = torch.complex(sw, torch.zeros_like(sw))
     sym[:, pkt_syms:] = 0
     sym = sym.reshape(-1)[:n_sym]
-    taps = torch.from_numpy(rrc).to(device)
-    w = taps.flip(0).reshape(1, 1, -1)
-
-    def shape(v):
-        up = torch.zeros(v.numel() * SPS, device=device)
-        up[::SPS] = v
-        return torch.nn.functional.conv1d(up.reshape(1, 1, -1), w, padding=taps.numel() - 1).reshape(-1)[: v.numel() * SPS]
-
-    x = torch.complex(shape(sym.real.contiguous()), shape(sym.imag.contiguous()))[:n_items]
+    # pulse shaping with this package's own InterpolatingFirFilter kernel (the TX-side block the
+    # reference uses to make its test signals, interpolating_fir_filter.hpp)
+    x = pkg.InterpolatingFirFilter(SPS, rrc).process_bulk(sym.to(torch.complex64).contiguous())[:n_items]
     cfo = (torch.rand(n_pkt, generator=g, device=device) * 0.06 - 0.03).repeat_interleave(period * SPS)[:n_items]
     k = torch.arange(n_items, device=device) % (period * SPS)
     x = x * torch.polar(torch.ones_like(cfo), cfo * k)
@@ -134,6 +128,9 @@ def main():
     ap.add_argument("--items", type=int, default=1 << 26, help="samples per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--detector-only", action="store_true", help="time SyncwordDetection alone")
+    ap.add_argument("--channels", type=int, default=1,
+                    help="config 3: C independent channels batched in one SyncwordDetection handle "
+                         "(detector only; --items is per channel)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the two halves of the chain back to back on one stream")
     args = ap.parse_args()
@@ -152,16 +149,32 @@ def main():
     rrc = unit_norm_rrc(pkg)
     bpsk = np.array([1, -1], dtype=np.complex64)
     n_items = args.items
-    x, n_pkt = burst_stream(n_items, rrc, seed=1 + rank, device=device)
+    x, n_pkt = burst_stream(pkg, n_items, rrc, seed=1 + rank, device=device)
     rx = pkg.PacketReceiver(SPS, BINS, 9.5, "QPSK", max_items=n_items, pipelined=not args.no_pipeline)
     sd = rx.syncword_detection
     out_keep = None
+    if args.channels > 1:
+        # config 3: per-channel CFO sweep -0.04 .. +0.04 rad/sample on top of the burst stream
+        args.detector_only = True
+        C = args.channels
+        k = torch.arange(n_items, device=device, dtype=torch.float32)
+        xs = torch.empty((C, n_items), dtype=torch.complex64, device=device)
+        for c in range(C):
+            f = -0.04 + 0.08 * c / max(C - 1, 1)
+            xs[c] = x.roll(997 * c) * torch.polar(torch.ones_like(k), (f * k) % (2 * np.pi))
+        x = xs
+        with torch.cuda.stream(rx._streams[0]):
+            sd = pkg.SyncwordDetection(rrc, SYNCWORD, bpsk, -BINS, BINS, power_threshold=9.5, n_channels=C,
+                                       max_items=n_items)
 
     def step():
         nonlocal out_keep
         if args.detector_only:
-            st, out, tags, n = sd.process_bulk(x, want_output=True, tags_cap=max(64, 2 * n_pkt + 64))
+            with torch.cuda.stream(rx._streams[0]):
+                st, out, tags, n = sd.process_bulk(x, want_output=True, tags_cap=max(64, 2 * n_pkt + 64))
             out_keep = out
+            if args.channels > 1:
+                return n * args.channels, sum(t.size for t in tags)
             return n, tags.size
         res = rx.process_bulk(x, 1500, tags_cap=max(64, 2 * n_pkt + 64))  # payload length of the generator
         if res is None:  # pipelined: first call has no finished batch yet
@@ -222,7 +235,7 @@ def main():
             torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
         n_blocks = (n_items - N_FFT) // 1752 + 1
-        samples = n_blocks * 1752
+        samples = n_blocks * 1752 * args.channels
         alg_bytes = 8.0 * samples
         achieved = alg_bytes / (ms * 1e-3) / 1e9
         flops = 710.0 * samples  # (1+B) 5N log2 N + 6BN + 1.5N + 4BS per stride, B = 9
@@ -236,7 +249,7 @@ def main():
                     "fp32_tflops": round(flops / (ms * 1e-3) / 1e12, 2),
                     "fp32_frac": round(flops / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)}
         if not args.no_cpu_baseline:
-            cpu = cpu_baseline(x[: min(n_items, 1 << 27)].cpu().numpy(), rrc)
+            cpu = cpu_baseline((x[0] if args.channels > 1 else x)[: min(n_items, 1 << 27)].cpu().numpy(), rrc)
     if rank == 0:
         line = {
             "metric": "RX Msamples/s (syncword-detect + RRC chain)",
@@ -255,7 +268,7 @@ def main():
                                     "configs[1]: 1 channel/GPU, full RX front end (SyncwordDetection 9 bins FFT 2048 + tag "
                                     "gate + CFC + 32-arm RRC SymbolFilter + wipe-off + Costas)") +
                                    " on resident burst+AWGN stream",
-                       "items_per_step_per_gpu": n_items, "freq_bins": 2 * BINS + 1, "tags_per_step": n_tags // max(args.steps, 1),
+                       "items_per_step_per_gpu": n_items * args.channels, "channels_per_gpu": args.channels, "freq_bins": 2 * BINS + 1, "tags_per_step": n_tags // max(args.steps, 1),
                        "parallelism": f"channel-per-gpu x{world}",
                        "pipelined_streams": 1 if (args.no_pipeline or args.detector_only) else 3},
             "roofline": roofline,
