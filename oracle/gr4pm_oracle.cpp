@@ -1,7 +1,8 @@
 /*
  * gr4pm_oracle.cpp -- CPU oracle (test infrastructure only; see gr4pm_oracle.h).
  *
- * Build: g++ -O3 -march=native -ffp-contract=off -std=c++17 -shared -fPIC (oracle/Makefile).
+ * Build: g++ -O3 -march=x86-64-v3 -ffp-contract=off -std=c++17 -shared -fPIC (oracle/Makefile; v3 = AVX2, so the
+ * .so built in the build container also runs on the GPU box's host CPU).
  * -ffp-contract=off matters: the reference is built for baseline x86-64 (no FMA), so every
  * product and sum below rounds separately, in the order the reference source evaluates them.
  *
