@@ -589,3 +589,33 @@ def test_syncword_detection_unsupported_fft_size_is_reported(pkg):
     rrc, _ = orc.unit_norm_rrc(4)
     with pytest.raises(pkg.Gr4pmError, match="not built"):
         pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, 0, 0, fft_size=3000)
+
+
+def test_syncword_detection_64_channels_cfo_sweep(pkg):
+    """BASELINE config 3 shape at test size: 64 channels in one handle, per-channel CFO sweep
+    -0.04 .. +0.04 rad/sample; every channel must equal the oracle run on that channel alone"""
+    C, nsym, sps = 64, 6000, 4
+    rrc, _ = orc.unit_norm_rrc(sps)
+    rng = np.random.default_rng(64)
+    X, refs = [], []
+    for c in range(C):
+        symbols = rng.integers(0, 2, nsym).astype(np.uint8)
+        locs = [200 + 13 * c, 2500 + 7 * c, 4800]
+        for loc in locs:
+            symbols[loc:loc + 64] = sig.SYNCWORD
+        f = -0.04 + 0.08 * c / (C - 1)
+        x = orc.rotator(orc.interpolating_fir(sig.BPSK[symbols], sps, rrc), np.float32(f))
+        x = (x + sig.awgn(x.size, 0.05, 1000 + c)).astype(np.complex64)
+        X.append(x)
+        ref = orc.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, power_threshold=9.5)
+        refs.append(ref.process(x))
+    X = np.stack(X)
+    sd = pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, power_threshold=9.5, n_channels=C,
+                               max_items=X.shape[1])
+    st, out, tags, n = sd.process_bulk(dev(X))
+    out = host(out)
+    for c in range(C):
+        _, ref_out, ref_tags = refs[c]
+        assert n == ref_out.size and np.array_equal(bits(out[c]), bits(ref_out)), c
+        assert ref_tags.size >= 3  # the three inserted syncwords (+ whatever the oracle also finds)
+        assert_tags_match(tags[c], ref_tags, rtol=3e-4)
