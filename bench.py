@@ -131,6 +131,8 @@ def main():
     ap.add_argument("--channels", type=int, default=1,
                     help="config 3: C independent channels batched in one SyncwordDetection handle "
                          "(detector only; --items is per channel)")
+    ap.add_argument("--copy-delay", action="store_true",
+                    help="materialise SyncwordDetection's delayed output instead of reading the ring in place")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the two halves of the chain back to back on one stream")
     args = ap.parse_args()
@@ -150,6 +152,14 @@ def main():
     bpsk = np.array([1, -1], dtype=np.complex64)
     n_items = args.items
     x, n_pkt = burst_stream(pkg, n_items, rrc, seed=1 + rank, device=device)
+    # the stream lives in a device ring: [the 2T+1 items before the window | the window].  Every
+    # step presents the same window, so the items "before" it are the window's own tail.
+    HIST = 2 * 768 + 1
+    ring = torch.empty(HIST + 1 + n_items, dtype=torch.complex64, device=device)  # +1: keep x 16-byte aligned
+    ring[1:1 + HIST] = x[-HIST:]
+    ring[1 + HIST:] = x
+    x = ring[1 + HIST:]
+    history = ring[1:1 + HIST]
     rx = pkg.PacketReceiver(SPS, BINS, 9.5, "QPSK", max_items=n_items, pipelined=not args.no_pipeline)
     sd = rx.syncword_detection
     out_keep = None
@@ -176,7 +186,8 @@ def main():
             if args.channels > 1:
                 return n * args.channels, sum(t.size for t in tags)
             return n, tags.size
-        res = rx.process_bulk(x, 1500, tags_cap=max(64, 2 * n_pkt + 64))  # payload length of the generator
+        res = rx.process_bulk(x, 1500, tags_cap=max(64, 2 * n_pkt + 64),  # payload length of the generator
+                              history=None if args.copy_delay else history)
         if res is None:  # pipelined: first call has no finished batch yet
             return 0, 0
         out_keep = res["symbols"]

@@ -463,10 +463,18 @@ class PacketReceiver:
             self._workers = [concurrent.futures.ThreadPoolExecutor(max_workers=1) for _ in range(2)]
 
     # ---- the three stages
-    def _stage0(self, x, tags_cap):
+    def _stage0(self, x, tags_cap, history):
         torch = _torch()
         with torch.cuda.stream(self._streams[0]):
-            st, y, det_tags, n = self.syncword_detection.process_bulk(x, want_output=True, tags_cap=tags_cap)
+            st, y, det_tags, n = self.syncword_detection.process_bulk(x, want_output=history is None,
+                                                                      tags_cap=tags_cap)
+        if history is not None:
+            # device-ring input: the delayed stream (hpp:318-319: out[i] = in[i - (2T+1)]) is read in
+            # place from the ring instead of being copied
+            d = 2 * self.syncword_detection.time_threshold + 1
+            assert history.numel() >= d and history.data_ptr() + history.numel() * 8 == x.data_ptr(), \
+                "history must be the ring contents that directly precede x"
+            y = torch.as_strided(history, (n,), (1,), history.numel() - d)
         base = self.syncword_detection._items_consumed - n        # absolute index of y[0]
         return st, y, det_tags, n, base
 
@@ -498,11 +506,13 @@ class PacketReceiver:
     def _stage12(self, fut1):
         return self._stage2(fut1.result())
 
-    def process_bulk(self, x, header_fn=None, tags_cap=4096):
+    def process_bulk(self, x, header_fn=None, tags_cap=4096, history=None):
         """x: complex64 CUDA tensor.  Returns dict(consumed, symbols, tags, detector_tags):
         symbols = CostasLoop output (one per symbol), tags = symbol-rate tags.  With
-        pipelined=True the dict belongs to an earlier batch (None while the pipeline fills)."""
-        front = self._stage0(x, tags_cap)
+        pipelined=True the dict belongs to an earlier batch (None while the pipeline fills).
+        history: when x is a window of a device ring buffer, the view of the >= 2T+1 items that
+        precede x in the ring; the chain then reads the delayed stream in place (no copy)."""
+        front = self._stage0(x, tags_cap, history)
         if not self.pipelined:
             return self._stage2(self._stage1(*front, header_fn))
         f1 = self._workers[0].submit(self._stage1, *front, header_fn)

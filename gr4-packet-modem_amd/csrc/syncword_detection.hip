@@ -284,13 +284,27 @@ __global__ __launch_bounds__(256) void k_candidates(const float* __restrict__ zb
     float* bmax = sm + nblk * 64;              // block maxima, nblk
     const uint32_t avail = cnt + T;            // readable items
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t blk = wave; blk < nblk; blk += 4) {
-        const uint32_t i = blk * 64 + lane, g = tile0 + i;
-        const float v = (i < span && g < avail) ? z[g] : -INFINITY;
-        s[i] = v;
-        const float m = wave_prefix_max(v);
-        if (lane == 63) bmax[blk] = m;
+    // all global loads of this wave are issued before the first one is used
+    constexpr int kMaxBlkPerWave = 37; // nblk <= 16 + 128 + 2 for T <= 8192
+    for (uint32_t b0 = wave; b0 < nblk; b0 += 4 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t blk = b0 + 4 * u;
+            const uint32_t i = blk * 64 + lane, g = tile0 + i;
+            v[u] = (blk < nblk && i < span && g < avail) ? z[g] : -INFINITY;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t blk = b0 + 4 * u;
+            if (blk < nblk) {
+                s[blk * 64 + lane] = v[u];
+                const float m = wave_prefix_max(v[u]);
+                if (lane == 63) bmax[blk] = m;
+            }
+        }
     }
+    (void)kMaxBlkPerWave;
     __syncthreads();
     const uint32_t tq = T >> 6, tr = T & 63;
     for (uint32_t kb = wave; kb < 16; kb += 4) { // the 16 blocks whose flags this workgroup owns
