@@ -307,6 +307,14 @@ __global__ __launch_bounds__(256) void k_candidates(const float* __restrict__ zb
     (void)kMaxBlkPerWave;
     __syncthreads();
     const uint32_t tq = T >> 6, tr = T & 63;
+    // maximum of the full blocks kb+1 .. kb+tq-1 (inside every item's window), once per block
+    float* mfull = bmax + nblk;
+    if (threadIdx.x < 16 && T >= 128) {
+        float mu = -INFINITY;
+        for (uint32_t k = threadIdx.x + 1; k < threadIdx.x + tq; ++k) mu = fmaxf(mu, bmax[k]);
+        mfull[threadIdx.x] = mu;
+    }
+    __syncthreads();
     for (uint32_t kb = wave; kb < 16; kb += 4) { // the 16 blocks whose flags this workgroup owns
         unsigned long long word;
         if (T < 128) { // tiny windows: plain scan
@@ -321,10 +329,7 @@ __global__ __launch_bounds__(256) void k_candidates(const float* __restrict__ zb
             const uint32_t i = kb * 64 + it;
             const float v = s[i];
             float m = wave_prev(wave_prefix_max(v));
-            // full blocks kb+1 .. kb+tq-1 are inside every item's window
-            float mu = -INFINITY;
-            for (uint32_t k = kb + 1; k < kb + tq; ++k) mu = fmaxf(mu, bmax[k]);
-            m = fmaxf(m, mu);
+            m = fmaxf(m, mfull[kb]);
             const bool wrap = it + tr >= 64; // the window also covers the whole of block kb+tq
             if (wrap) m = fmaxf(m, bmax[kb + tq]);
             bool flag = tile0 + i < cnt && v >= m;
@@ -359,27 +364,96 @@ __device__ __forceinline__ uint32_t next_candidate(const unsigned long long* bm,
 }
 
 // table[tile][e], e in [0, T]: entering tile at local lo + e, the scan leaves it wanting to
-// resume at hi + table (>= hi).  One thread per (tile, e).
-__global__ void k_tile_tables(const unsigned long long* __restrict__ bitmap, size_t bm_stride,
-                              uint32_t cnt, uint32_t T, uint32_t n_tiles,
-                              uint32_t* __restrict__ table, size_t table_stride)
+// resume at hi + table (>= hi).  All entries that meet the same first candidate share one walk,
+// so one wave handles a tile: every candidate inside the entry window [lo, lo+T] gets a lane
+// that walks from it, plus one walk for the entries behind the window's last candidate.
+// wave-cooperative version for wave-uniform r: 64 bitmap words (4096 positions) per load
+__device__ __forceinline__ uint32_t next_candidate_wave(const unsigned long long* bm, uint32_t r, uint32_t hi,
+                                                        int lane)
 {
-    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t tile = blockIdx.y;
-    if (e > T) return;
-    const unsigned long long* bm = bitmap + static_cast<size_t>(blockIdx.z) * bm_stride;
-    const uint32_t lo = tile * kTileW;
-    const uint32_t hi = min(lo + kTileW, cnt);
-    uint32_t r = lo + e;
-    while (r < hi) {
-        const uint32_t p = next_candidate(bm, r, hi);
-        if (p >= hi) {
-            r = hi;
-            break;
+    if (r >= hi) return hi;
+    const uint32_t wlast = (hi - 1) >> 6;
+    for (uint32_t w = r >> 6; w <= wlast; w += 64) {
+        unsigned long long word = (w + lane <= wlast) ? bm[w + lane] : 0ull;
+        if (w == (r >> 6) && lane == 0) word &= ~0ull << (r & 63);
+        const unsigned long long any = __ballot(word != 0ull);
+        if (any) {
+            const int src = __ffsll(static_cast<long long>(any)) - 1;
+            const unsigned long long hit = __shfl(word, src);
+            const uint32_t p = ((w + src) << 6) + static_cast<uint32_t>(__ffsll(static_cast<long long>(hit)) - 1);
+            return p < hi ? p : hi;
         }
+    }
+    return hi;
+}
+__device__ __forceinline__ uint32_t walk_from_candidate_wave(const unsigned long long* bm, uint32_t c, uint32_t hi,
+                                                             uint32_t T, int lane)
+{
+    uint32_t r = c + T + 1;
+    while (r < hi) {
+        const uint32_t p = next_candidate_wave(bm, r, hi, lane);
+        if (p >= hi) return 0;
         r = p + T + 1;
     }
-    table[static_cast<size_t>(blockIdx.z) * table_stride + static_cast<size_t>(tile) * (T + 1) + e] = r - hi;
+    return r - hi;
+}
+__device__ __forceinline__ uint32_t walk_from_candidate(const unsigned long long* bm, uint32_t c, uint32_t hi,
+                                                        uint32_t T)
+{
+    uint32_t r = c + T + 1;
+    while (r < hi) {
+        const uint32_t p = next_candidate(bm, r, hi);
+        if (p >= hi) return 0; // scan position ends at hi
+        r = p + T + 1;
+    }
+    return r - hi;
+}
+__global__ __launch_bounds__(64) void k_tile_tables(const unsigned long long* __restrict__ bitmap,
+                                                    size_t bm_stride, uint32_t cnt, uint32_t T, uint32_t n_tiles,
+                                                    uint32_t* __restrict__ table, size_t table_stride)
+{
+    const uint32_t tile = blockIdx.x;
+    const int lane = threadIdx.x;
+    const unsigned long long* bm = bitmap + static_cast<size_t>(blockIdx.y) * bm_stride;
+    uint32_t* tab = table + static_cast<size_t>(blockIdx.y) * table_stride + static_cast<size_t>(tile) * (T + 1);
+    const uint32_t lo = tile * kTileW;
+    const uint32_t hi = min(lo + kTileW, cnt);
+    const uint32_t wend = min(lo + T + 1, hi); // entry window [lo, wend)
+    // entries that start at or beyond hi keep their position: table = (lo + e) - hi
+    for (uint32_t e = (hi - lo) + lane; e <= T; e += 64) tab[e] = lo + e - hi;
+    uint32_t prev = lo; // first entry position not yet filled
+    for (uint32_t w0 = lo; w0 < wend; w0 += 64) { // kTileW is a multiple of 64: words are aligned
+        unsigned long long word = bm[w0 >> 6];
+        if (wend - w0 < 64) word &= (1ull << (wend - w0)) - 1ull;
+        if (!word) continue;
+        const bool mine = (word >> lane) & 1ull;
+        uint32_t res = 0;
+        if (__popcll(word) <= 4) {
+            // few candidates (the usual case on noise): walk them one after the other with the
+            // whole wave scanning the bitmap, 4096 positions per load
+            unsigned long long rest = word;
+            while (rest) {
+                const int bit = __ffsll(static_cast<long long>(rest)) - 1;
+                rest &= rest - 1;
+                const uint32_t rr = walk_from_candidate_wave(bm, w0 + bit, hi, T, lane);
+                if (lane == bit) res = rr;
+            }
+        } else if (mine) { // dense candidates (e.g. all-zero input): every step hits at once
+            res = walk_from_candidate(bm, w0 + lane, hi, T);
+        }
+        // lane's entry range: (previous candidate, this candidate]
+        const unsigned long long below = word & ((1ull << lane) - 1ull);
+        const uint32_t first = below ? w0 + (63 - __clzll(below)) + 1 : prev;
+        if (mine)
+            for (uint32_t p = first; p <= w0 + lane; ++p) tab[p - lo] = res;
+        prev = w0 + (63 - __clzll(word)) + 1;
+    }
+    if (prev < wend) { // entries behind the last candidate of the window share the next candidate
+        uint32_t res = 0;
+        const uint32_t c = next_candidate_wave(bm, prev, hi, lane);
+        if (c < hi) res = walk_from_candidate_wave(bm, c, hi, T, lane);
+        for (uint32_t p = prev + lane; p < wend; p += 64) tab[p - lo] = res;
+    }
     (void)n_tiles;
 }
 
@@ -483,7 +557,7 @@ __global__ __launch_bounds__(64) void k_tile_detect(const unsigned long long* __
     uint32_t r = lo + static_cast<uint32_t>(e);
     const uint32_t hist = 2 * T + 1;
     while (r < hi) {
-        const uint32_t p = next_candidate(bm, r, hi);
+        const uint32_t p = next_candidate_wave(bm, r, hi, lane);
         if (p >= hi) break;
         const float best = z[p];
         const float thr = best / power_threshold; // hpp:275
@@ -1205,12 +1279,12 @@ gr4pm_status gr4pm_syncword_detection_process(gr4pm_syncword_detection* h, const
     const float* zloc = zcur + h->zc - static_cast<ptrdiff_t>(E0 - A0);
     if (cnt > 0) {
         const uint32_t n_wg = (cnt + 1023) / 1024;
-        const size_t smem = static_cast<size_t>(16 + (T >> 6) + 2) * 65 * sizeof(float);
+        const size_t smem = (static_cast<size_t>(16 + (T >> 6) + 2) * 65 + 16) * sizeof(float);
         hipLaunchKernelGGL(k_candidates, dim3(n_wg, nch), dim3(256), smem, s, zloc, h->z_stride, cnt, T,
                            h->bitmap.p, h->bm_stride);
         const uint32_t n_tiles = (cnt + kTileW - 1) / kTileW;
-        hipLaunchKernelGGL(k_tile_tables, dim3((T + 1 + 127) / 128, n_tiles, nch), dim3(128), 0, s,
-                           h->bitmap.p, h->bm_stride, cnt, T, n_tiles, h->table.p, h->table_stride);
+        hipLaunchKernelGGL(k_tile_tables, dim3(n_tiles, nch), dim3(64), 0, s, h->bitmap.p, h->bm_stride, cnt, T,
+                           n_tiles, h->table.p, h->table_stride);
         const uint32_t n_groups = (n_tiles + kGroup - 1) / kGroup;
         hipLaunchKernelGGL(k_group_tables, dim3((T + 1 + 127) / 128, n_groups, nch), dim3(128), 0, s, cnt, T,
                            n_tiles, h->table.p, h->table_stride, h->gtable.p, h->gtable_stride);
