@@ -574,8 +574,12 @@ gr4pm_status gr4pm_rotator_process(gr4pm_rotator* h, const gr4pm_c64* in, size_t
                                    gr4pm_c64* out, const gr4pm_tag* tags, const uint32_t* tag_channel,
                                    size_t n_tags)
 {
-    if (!h || !in || !out) return GR4PM_ERR_INVALID;
-    if (n == 0) return GR4PM_OK;
+    if (!h) return GR4PM_ERR_INVALID;
+    if (n == 0) return GR4PM_OK; // an empty chunk is legal (and may come with null pointers)
+    if (!in || !out) {
+        set_error("null sample pointer");
+        return GR4PM_ERR_INVALID;
+    }
     std::vector<RotSeg> segs;
     unsigned ck = 0;
     for (size_t c = 0; c < h->n_channels; ++c) {
@@ -753,8 +757,12 @@ gr4pm_status gr4pm_costas_loop_process(gr4pm_costas_loop* h, const gr4pm_c64* in
                                        gr4pm_c64* out, const gr4pm_tag* tags, const uint32_t* tag_channel,
                                        size_t n_tags)
 {
-    if (!h || !in || !out) return GR4PM_ERR_INVALID;
+    if (!h) return GR4PM_ERR_INVALID;
     if (n == 0) return GR4PM_OK;
+    if (!in || !out) {
+        set_error("null sample pointer");
+        return GR4PM_ERR_INVALID;
+    }
     std::vector<CostasSeg> segs;
     for (size_t c = 0; c < h->n_channels; ++c) {
         size_t pos = 0;
@@ -846,8 +854,12 @@ gr4pm_status gr4pm_syncword_wipeoff_reset(gr4pm_syncword_wipeoff* h)
 gr4pm_status gr4pm_syncword_wipeoff_process(gr4pm_syncword_wipeoff* h, const gr4pm_c64* in, size_t n,
                                             gr4pm_c64* out, const gr4pm_tag* tags, size_t n_tags)
 {
-    if (!h || !in || !out) return GR4PM_ERR_INVALID;
+    if (!h) return GR4PM_ERR_INVALID;
     if (n == 0) return GR4PM_OK;
+    if (!in || !out) {
+        set_error("null sample pointer");
+        return GR4PM_ERR_INVALID;
+    }
     // replay syncword_wipeoff.hpp:53-75 over the tag list
     std::vector<WipeSpan> spans;
     size_t pos = 0, t = 0;
@@ -1165,8 +1177,12 @@ gr4pm_status gr4pm_interp_fir_reset(gr4pm_interp_fir* h)
 }
 gr4pm_status gr4pm_interp_fir_process(gr4pm_interp_fir* h, const void* in, size_t n_in, void* out)
 {
-    if (!h || !in || !out) return GR4PM_ERR_INVALID;
+    if (!h) return GR4PM_ERR_INVALID;
     if (n_in == 0) return GR4PM_OK;
+    if (!in || !out) {
+        set_error("null sample pointer");
+        return GR4PM_ERR_INVALID;
+    }
     return h->item_kind == 0 ? interp_fir_run<cf>(h, in, n_in, out) : interp_fir_run<float>(h, in, n_in, out);
 }
 
@@ -1258,9 +1274,14 @@ gr4pm_status gr4pm_symbol_filter_process(gr4pm_symbol_filter* h, const void* in,
                                          gr4pm_tag* tags_out, size_t tags_cap, size_t* n_tags_out,
                                          size_t* consumed_, size_t* produced_)
 {
-    if (!h || !in || !out || !consumed_ || !produced_) return GR4PM_ERR_INVALID;
+    if (!h || !consumed_ || !produced_) return GR4PM_ERR_INVALID;
     *consumed_ = *produced_ = 0;
     if (n_tags_out) *n_tags_out = 0;
+    if (n_in == 0) return GR4PM_OK; // nothing consumed, nothing produced, queued tags keep waiting
+    if (!in || !out) {
+        set_error("null sample pointer");
+        return GR4PM_ERR_INVALID;
+    }
     const size_t sps = h->sps;
     const long half = static_cast<long>(sps / 2);
     std::vector<SymRun> runs;
@@ -1524,9 +1545,13 @@ gr4pm_status gr4pm_pfb_arb_resampler_reset(gr4pm_pfb_arb_resampler* h)
 gr4pm_status gr4pm_pfb_arb_resampler_process(gr4pm_pfb_arb_resampler* h, const gr4pm_c64* in, size_t n_in,
                                              gr4pm_c64* out, size_t out_cap, size_t* consumed, size_t* produced)
 {
-    if (!h || !in || !out || !consumed || !produced) return GR4PM_ERR_INVALID;
+    if (!h || !consumed || !produced) return GR4PM_ERR_INVALID;
     *consumed = *produced = 0;
     if (n_in == 0 || out_cap == 0) return GR4PM_OK;
+    if (!in || !out) {
+        set_error("null sample pointer");
+        return GR4PM_ERR_INVALID;
+    }
     if (out_cap > 0xffffffffull || n_in > 0x7fffffffull) return GR4PM_ERR_INVALID;
     hipStream_t s = h->stream;
     if (h->plan_cap < out_cap) {

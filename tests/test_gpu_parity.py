@@ -619,3 +619,94 @@ def test_syncword_detection_64_channels_cfo_sweep(pkg):
         assert n == ref_out.size and np.array_equal(bits(out[c]), bits(ref_out)), c
         assert ref_tags.size >= 3  # the three inserted syncwords (+ whatever the oracle also finds)
         assert_tags_match(tags[c], ref_tags, rtol=3e-4)
+
+
+# ------------------------------------------------------------------ settings matrix
+@pytest.mark.parametrize("sps,ntaps_req,tthr,bins,thr", [
+    (4, 44, 100, (-2, 5), 12.0),     # short window (T not a multiple of 64), asymmetric bins
+    (4, 44, 1000, (0, 0), 9.5),      # one bin, long window with a partial last block
+    (3, 33, 768, (-4, 4), 15.0),     # L = 63*3+33 = 222 -> stride 1827 (odd): 8-byte-aligned loads path
+    (2, 22, 500, (-1, 1), 15.0),     # sps 2, L = 149
+    (8, 88, 768, (-3, 3), 15.0),     # sps 8, L = 593
+])
+def test_syncword_detection_settings_matrix(pkg, sps, ntaps_req, tthr, bins, thr):
+    rrc = orc.rrc_taps(1.0, float(sps), 1.0, 0.35, ntaps_req)
+    rrc = (rrc / np.sqrt(np.sum(rrc.astype(np.float64) ** 2))).astype(np.float32)
+    rng = np.random.default_rng(sps * 1000 + tthr)
+    nsym = 120000 // sps
+    symbols = rng.integers(0, 2, nsym).astype(np.uint8)
+    locs = [nsym // 10, nsym // 3, nsym // 2 + 17, (4 * nsym) // 5]
+    for loc in locs:
+        symbols[loc:loc + 64] = sig.SYNCWORD
+    L = 63 * sps + rrc.size
+    f = 0.5 * (bins[0] + bins[1]) * np.pi / L + 0.002
+    x = orc.rotator(orc.interpolating_fir(sig.BPSK[symbols], sps, rrc), np.float32(f))
+    x = (x + sig.awgn(x.size, 0.1, tthr)).astype(np.complex64)
+    kw = dict(samples_per_symbol=sps, time_threshold=tthr, power_threshold=thr)
+    ref = orc.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, bins[0], bins[1], **kw)
+    _, ref_out, ref_tags, ref_zpow, _ = ref.process(x, debug=True)
+    sd = pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, bins[0], bins[1], max_items=x.size, **kw)
+    st, out, tags, n = sd.process_bulk(dev(x))
+    assert n == ref_out.size and np.array_equal(bits(host(out)), bits(ref_out))
+    assert ref_tags.size >= 3
+    assert_tags_match(tags, ref_tags, rtol=3e-4)
+    assert np.max(np.abs(host(sd.last_zpow(n))[0] - ref_zpow)) / np.max(ref_zpow) < 5e-6
+    # chunked
+    sd2 = pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, bins[0], bins[1], max_items=x.size, **kw)
+    pos, got = 0, []
+    for size in (2048, 5000, 2048 + 3 * (2048 - L + 1), 40000, x.size):
+        if pos + 2048 > x.size:
+            break
+        _, _, t, d = sd2.process_bulk(dev(x[pos:pos + size]), want_output=False)
+        t = t.copy()
+        t["index"] += pos
+        got.append(t)
+        pos += d
+    got = np.concatenate(got)
+    assert np.array_equal(got["index"], tags["index"][: got.size]) and got.size >= tags.size - 1
+
+
+def test_rotator_and_costas_multichannel(pkg):
+    """batched handles: independent state per channel (== each channel alone)"""
+    rng = np.random.default_rng(3)
+    C, n = 5, 30000
+    x = (rng.standard_normal((C, n)) + 1j * rng.standard_normal((C, n))).astype(np.complex64)
+    cfc = pkg.CoarseFrequencyCorrection(26, n_channels=C)
+    tags = np.zeros(7, dtype=pkg.TAG_DTYPE)
+    tags["index"] = [10, 5000, 100, 9000, 20000, 0, 29990]
+    tags["freq"] = [0.01, -0.02, 0.03, 0.0, 0.015, -0.007, 0.02]
+    tags["phase"] = [0.1, -0.2, 0.3, 1.0, -1.5, 2.0, -3.0]
+    tags["flags"] = pkg.TAG_SYNCWORD
+    chan = np.array([0, 0, 1, 2, 2, 4, 4], dtype=np.uint32)
+    order = np.lexsort((tags["index"], chan))
+    y = host(cfc.process_bulk(dev(x), tags[order], chan[order]))
+    cl = pkg.CostasLoop(0.01, "QPSK", n_channels=C)
+    z = host(cl.process_bulk(dev(x), tags[order], chan[order]))
+    for c in range(C):
+        sel = chan == c
+        idx = np.sort(tags["index"][sel])
+        o = np.argsort(tags["index"][sel])
+        want = orc.coarse_frequency_correction(x[c], idx, tags["freq"][sel][o], delay=26)
+        assert np.array_equal(bits(y[c]), bits(want)), c
+        wantz = orc.costas_loop(x[c], "QPSK", 0.01, idx, tags["phase"][sel][o])
+        assert np.max(np.abs(z[c] - wantz)) < 2e-5, c
+
+
+def test_stream_blocks_empty_and_tiny_inputs(pkg):
+    """empty / one-item calls and calls without tags are legal and keep the state"""
+    e = torch.zeros(0, dtype=torch.complex64, device="cuda")
+    one = dev(np.array([1 + 2j], dtype=np.complex64))
+    r = pkg.Rotator(0.5)
+    assert r.process_bulk(e).numel() == 0
+    a = host(r.process_bulk(one))
+    b = host(r.process_bulk(one))
+    want = orc.rotator(np.array([1 + 2j, 1 + 2j], np.complex64), np.float32(0.5))
+    assert np.array_equal(bits(np.concatenate([a, b])), bits(want))
+    assert pkg.CostasLoop().process_bulk(e).numel() == 0
+    assert pkg.SyncwordWipeoff(np.ones(4, np.float32)).process_bulk(e).numel() == 0
+    assert pkg.InterpolatingFirFilter(4, np.ones(5, np.float32)).process_bulk(e).numel() == 0
+    rrc, pfb = _receiver_pfb()
+    y, t, c = pkg.SymbolFilter(pfb, 32, 4, 44).process_bulk(e)
+    assert y.numel() == 0 and c == 0
+    y, c = pkg.PfbArbResampler(1.1).process_bulk(e)
+    assert y.numel() == 0 and c == 0
