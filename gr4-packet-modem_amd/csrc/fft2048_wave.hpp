@@ -267,7 +267,12 @@ GR4PM_HD void fft2_passA(int lane, cf* r, const cf* twA)
     for (int q = 0; q < 4; ++q) {
         dft8(r + 8 * q);
 #pragma unroll
-        for (int ka = 1; ka < 8; ++ka) r[8 * q + ka] = cmul(r[8 * q + ka], twA[((ka - 1) * 4 + q) * 64 + lane]);
+        for (int ka = 1; ka < 8; ++ka)
+#if defined(GR4PM_ABL) && GR4PM_ABL == 3
+            r[8 * q + ka] = cmul(r[8 * q + ka], mk(0.7f + ka, 0.7f - q));
+#else
+            r[8 * q + ka] = cmul(r[8 * q + ka], twA[((ka - 1) * 4 + q) * 64 + lane]);
+#endif
     }
 }
 // half h: rows (ka*16 + m) with ka in [4h, 4h+4)
@@ -293,7 +298,12 @@ GR4PM_HD void fft2_passB(int lane, cf* r, const cf* twB)
     for (int q = 0; q < 2; ++q) {
         dft16(r + 16 * q);
 #pragma unroll
-        for (int k2 = 1; k2 < 16; ++k2) r[16 * q + k2] = cmul(r[16 * q + k2], twB[(k2 - 1) * 16 + m]);
+        for (int k2 = 1; k2 < 16; ++k2)
+#if defined(GR4PM_ABL) && GR4PM_ABL == 3
+            r[16 * q + k2] = cmul(r[16 * q + k2], mk(0.5f + k2, 0.25f));
+#else
+            r[16 * q + k2] = cmul(r[16 * q + k2], twB[(k2 - 1) * 16 + m]);
+#endif
     }
 }
 // half h: rows (k2*8 + ka) with k2 in [8h, 8h+8)

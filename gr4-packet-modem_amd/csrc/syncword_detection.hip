@@ -88,7 +88,7 @@ __device__ __forceinline__ void fft2_wave(int lane, cf* r, cf* out, cf* lds, con
 {
     fft2_passA(lane, r, twA);
     cf b[32];
-#if GR4PM_ABL == 1 /* timing-only ablation: no LDS exchanges */
+#if GR4PM_ABL == 1 || GR4PM_ABL == 3 /* timing-only ablation: no LDS exchanges */
 #pragma unroll
     for (int j = 0; j < 32; ++j) b[j] = r[(j * 5 + 3) & 31];
 #else
@@ -101,7 +101,7 @@ __device__ __forceinline__ void fft2_wave(int lane, cf* r, cf* out, cf* lds, con
     }
 #endif
     fft2_passB(lane, b, twB);
-#if GR4PM_ABL == 1
+#if GR4PM_ABL == 1 || GR4PM_ABL == 3
 #pragma unroll
     for (int j = 0; j < 32; ++j) out[j] = b[(j * 7 + 1) & 31];
 #else
@@ -206,9 +206,14 @@ __global__ __launch_bounds__(kCorrThreads, 2) void k_correlate(const cf* __restr
             for (int u = 0; u < kTmplPerThread; ++u) tn[u] = tg[u * kCorrThreads + tid];
         }
         cf p[32], c[32];
+#if GR4PM_ABL == 3 /* timing only: no template reads either */
+#pragma unroll
+        for (int j = 0; j < 32; ++j) p[j] = cmul(X[j], X[(j + 1) & 31]);
+#else
         mul_template(lane, X, p, lds4 + kLdsTmpl); // hpp:247-249
+#endif
         if (more) {
-#if GR4PM_ABL != 2
+#if GR4PM_ABL != 2 && GR4PM_ABL != 3
             __syncthreads(); // every wave has read the current template
 #endif
 #pragma unroll
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(kCorrThreads, 2) void k_correlate(const cf* __restr
             // bin index is recomputed by k_tags for detections only)
             zmax[j] = fmaxf(zmax[j], cnorm(c[j]));
         }
-#if GR4PM_ABL != 2
+#if GR4PM_ABL != 2 && GR4PM_ABL != 3
         if (more) __syncthreads(); // next template complete
 #endif
     }
@@ -599,13 +604,12 @@ __global__ __launch_bounds__(64) void k_tags(const cf* __restrict__ in, size_t i
     __shared__ cf lds[kExchangeItems];
     __shared__ cf zbin[kMaxBins];
     const uint32_t ch = blockIdx.y;
-    const uint32_t idx = blockIdx.x;
     const uint32_t n_det = min(st[ch].det_cnt, det_cap);
-    if (idx >= n_det) return;
+    const int lane = threadIdx.x;
+    for (uint32_t idx = blockIdx.x; idx < n_det; idx += gridDim.x) {
     const unsigned long long pos = det[static_cast<size_t>(ch) * det_cap + idx];
     const unsigned long long c = pos + hist;
-    if (c < E0 || c >= E1) return;
-    const int lane = threadIdx.x;
+    if (c < E0 || c >= E1) continue;
     const unsigned long long blk = pos / stride_s;
     const uint32_t lag = static_cast<uint32_t>(pos - blk * stride_s);
     const long long o = static_cast<long long>(blk * stride_s) - static_cast<long long>(E0);
@@ -675,6 +679,8 @@ __global__ __launch_bounds__(64) void k_tags(const cf* __restrict__ in, size_t i
         if (slot < rec_cap) rec[static_cast<size_t>(ch) * rec_cap + slot] = t;
         else st[ch].overflow = 1;
     }
+    wave_lds_sync(); // zbin / lds are reused by the next detection of this wave
+    } // grid-stride loop over the pending detections
 }
 
 // =====================================================================================
@@ -758,12 +764,12 @@ __global__ __launch_bounds__(256) void k_tags_generic(const cf* __restrict__ in,
     __shared__ float red[256];
     cf* X = gl;
     cf* W = gl + N;
-    const uint32_t ch = blockIdx.y, idx = blockIdx.x;
+    const uint32_t ch = blockIdx.y;
     const uint32_t n_det = min(st[ch].det_cnt, det_cap);
-    if (idx >= n_det) return;
+    for (uint32_t idx = blockIdx.x; idx < n_det; idx += gridDim.x) { // uniform per workgroup
     const unsigned long long pos = det[static_cast<size_t>(ch) * det_cap + idx];
     const unsigned long long c = pos + hist;
-    if (c < E0 || c >= E1) return;
+    if (c < E0 || c >= E1) continue;
     const unsigned long long blk = pos / stride_s;
     const uint32_t lag = static_cast<uint32_t>(pos - blk * stride_s);
     const long long o = static_cast<long long>(blk * stride_s) - static_cast<long long>(E0);
@@ -817,6 +823,8 @@ __global__ __launch_bounds__(256) void k_tags_generic(const cf* __restrict__ in,
         if (slot < rec_cap) rec[static_cast<size_t>(ch) * rec_cap + slot] = t;
         else st[ch].overflow = 1;
     }
+    __syncthreads();
+    } // grid-stride loop over the pending detections
 }
 
 // drop emitted detections (pos + hist < E1) from the pending list; one wave per channel
@@ -1300,14 +1308,16 @@ gr4pm_status gr4pm_syncword_detection_process(gr4pm_syncword_detection* h, const
     // tags leaving in this call
     if (h->generic) {
         const uint32_t N = static_cast<uint32_t>(h->fft_size);
-        hipLaunchKernelGGL(k_tags_generic, dim3(h->det_cap, nch), dim3(256), 2 * N * sizeof(cf), s,
+        hipLaunchKernelGGL(k_tags_generic, dim3(std::min<uint32_t>(h->det_cap, 1024u), nch), dim3(256),
+                           2 * N * sizeof(cf), s,
                            reinterpret_cast<const cf*>(in), in_stride, carry, static_cast<size_t>(h->xc), h->xc,
                            static_cast<unsigned long long>(E0), static_cast<unsigned long long>(E1),
                            static_cast<uint32_t>(h->hist), static_cast<uint32_t>(h->S), N, h->log2n, h->n_bins,
                            h->g_tmpl.p, h->g_tw.p, zcur + h->zc, h->z_stride, h->st.p, h->det.p, h->det_cap,
                            h->rec.p, h->rec_cap);
     } else
-    hipLaunchKernelGGL(k_tags, dim3(h->det_cap, nch), dim3(64), 0, s, reinterpret_cast<const cf*>(in),
+    hipLaunchKernelGGL(k_tags, dim3(std::min<uint32_t>(h->det_cap, 8192u), nch), dim3(64), 0, s,
+                       reinterpret_cast<const cf*>(in),
                        in_stride, carry, static_cast<size_t>(h->xc), h->xc,
                        static_cast<unsigned long long>(E0), static_cast<unsigned long long>(E1),
                        static_cast<uint32_t>(h->hist), static_cast<uint32_t>(h->S), h->n_bins, h->tmpl.p,
@@ -1337,8 +1347,13 @@ gr4pm_status gr4pm_syncword_detection_process(gr4pm_syncword_detection* h, const
         any |= h->st_host.p[c].rec_cnt != 0;
     }
     if (any) {
-        GR4PM_HIP_TRY(hipMemcpyAsync(h->rec_host.p, h->rec.p, sizeof(RawTag) * h->rec_cap * nch,
-                                     hipMemcpyDeviceToHost, s));
+        for (unsigned c = 0; c < nch; ++c) { // only the records that exist
+            const uint32_t n = std::min(h->st_host.p[c].rec_cnt, h->rec_cap);
+            if (n)
+                GR4PM_HIP_TRY(hipMemcpyAsync(h->rec_host.p + static_cast<size_t>(c) * h->rec_cap,
+                                             h->rec.p + static_cast<size_t>(c) * h->rec_cap, sizeof(RawTag) * n,
+                                             hipMemcpyDeviceToHost, s));
+        }
         GR4PM_HIP_TRY(hipStreamSynchronize(s));
         // zero rec_cnt (field offset inside ChanState) for the next call
         for (unsigned c = 0; c < nch; ++c) {
