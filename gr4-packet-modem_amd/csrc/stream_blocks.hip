@@ -393,7 +393,9 @@ __global__ __launch_bounds__(256) void k_symbol_filter(const T* __restrict__ in,
             tile[(i % sps) * pitch + i / sps] = item_at(in, carry, cap, lo_item + i);
         __syncthreads();
         if (o < n_out) {
-            const float* arm = taps + static_cast<size_t>(r.arm) * arm_size;
+            // the arm is the same for the whole workgroup: make that visible so the taps are
+            // fetched with scalar loads instead of 64 identical vector loads
+            const float* arm = taps + static_cast<size_t>(__builtin_amdgcn_readfirstlane(r.arm)) * arm_size;
             const unsigned top = (o - o0) * sps + arm_size - 1; // tile index of this symbol's newest item
             T acc = zero_item(T{});
             for (unsigned m = 0; m < arm_size; ++m) {

@@ -604,12 +604,13 @@ __global__ __launch_bounds__(64) void k_tags(const cf* __restrict__ in, size_t i
     __shared__ cf lds[kExchangeItems];
     __shared__ cf zbin[kMaxBins];
     const uint32_t ch = blockIdx.y;
+    const uint32_t idx = blockIdx.x;
     const uint32_t n_det = min(st[ch].det_cnt, det_cap);
-    const int lane = threadIdx.x;
-    for (uint32_t idx = blockIdx.x; idx < n_det; idx += gridDim.x) {
+    if (idx >= n_det) return;
     const unsigned long long pos = det[static_cast<size_t>(ch) * det_cap + idx];
     const unsigned long long c = pos + hist;
-    if (c < E0 || c >= E1) continue;
+    if (c < E0 || c >= E1) return;
+    const int lane = threadIdx.x;
     const unsigned long long blk = pos / stride_s;
     const uint32_t lag = static_cast<uint32_t>(pos - blk * stride_s);
     const long long o = static_cast<long long>(blk * stride_s) - static_cast<long long>(E0);
@@ -679,8 +680,6 @@ __global__ __launch_bounds__(64) void k_tags(const cf* __restrict__ in, size_t i
         if (slot < rec_cap) rec[static_cast<size_t>(ch) * rec_cap + slot] = t;
         else st[ch].overflow = 1;
     }
-    wave_lds_sync(); // zbin / lds are reused by the next detection of this wave
-    } // grid-stride loop over the pending detections
 }
 
 // =====================================================================================
@@ -1316,7 +1315,7 @@ gr4pm_status gr4pm_syncword_detection_process(gr4pm_syncword_detection* h, const
                            h->g_tmpl.p, h->g_tw.p, zcur + h->zc, h->z_stride, h->st.p, h->det.p, h->det_cap,
                            h->rec.p, h->rec_cap);
     } else
-    hipLaunchKernelGGL(k_tags, dim3(std::min<uint32_t>(h->det_cap, 8192u), nch), dim3(64), 0, s,
+    hipLaunchKernelGGL(k_tags, dim3(h->det_cap, nch), dim3(64), 0, s,
                        reinterpret_cast<const cf*>(in),
                        in_stride, carry, static_cast<size_t>(h->xc), h->xc,
                        static_cast<unsigned long long>(E0), static_cast<unsigned long long>(E1),
