@@ -358,15 +358,36 @@ struct SymRun {
 // loads and every thread then reads its arm_size items from LDS (the MAC order of the
 // reference, std::inner_product, m ascending, is kept: bit-exact).  Workgroups that straddle
 // a run boundary (a handful per call) fall back to direct reads.
-template <typename T>
+// run index of the first symbol of every 256-symbol workgroup (a binary search per workgroup
+// inside k_symbol_filter would put ~12 dependent L2 round trips in front of each workgroup)
+__global__ void k_symf_wg_runs(const SymRun* __restrict__ runs, unsigned n_runs, unsigned n_wg,
+                               unsigned* __restrict__ wg_run)
+{
+    const unsigned w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_wg) return;
+    const unsigned oo = w * 256u;
+    unsigned lo = 0, hi = n_runs - 1;
+    while (lo < hi) {
+        const unsigned mid = (lo + hi + 1) >> 1;
+        if (runs[mid].out0 <= oo) lo = mid;
+        else hi = mid - 1;
+    }
+    wg_run[w] = lo;
+}
+
+// SPS > 0: samples_per_symbol known at compile time (divisions become shifts / constants);
+// SPS == 0: run-time value.
+template <typename T, int SPS>
 __global__ __launch_bounds__(256) void k_symbol_filter(const T* __restrict__ in, const T* __restrict__ carry,
                                                        unsigned cap, const float* __restrict__ taps,
-                                                       unsigned arm_size, unsigned sps,
+                                                       unsigned arm_size, unsigned sps_rt,
                                                        const SymRun* __restrict__ runs, unsigned n_runs,
+                                                       const unsigned* __restrict__ wg_run,
                                                        unsigned n_out, T* __restrict__ out)
 {
     extern __shared__ unsigned char s_raw[];
     T* tile = reinterpret_cast<T*>(s_raw);
+    const unsigned sps = SPS > 0 ? static_cast<unsigned>(SPS) : sps_rt;
     const unsigned o0 = blockIdx.x * 256u;
     const unsigned o = o0 + threadIdx.x;
     const unsigned o_last = min(o0 + 255u, n_out - 1);
@@ -380,8 +401,10 @@ __global__ __launch_bounds__(256) void k_symbol_filter(const T* __restrict__ in,
         }
         return lo;
     };
-    const unsigned r_first = find(o0), r_last = find(o_last);
-    if (r_first == r_last) {
+    // the workgroup lies inside one run iff the next run starts behind its last symbol
+    const unsigned r_first = wg_run[blockIdx.x];
+    const bool one_run = r_first + 1 >= n_runs || runs[r_first + 1].out0 > o_last;
+    if (one_run) {
         const SymRun r = runs[r_first];
         const long long idx0 = r.in0 + static_cast<long long>(o0 - r.out0) * sps; // newest item of symbol o0
         const long long lo_item = idx0 - (arm_size - 1);
@@ -391,16 +414,19 @@ __global__ __launch_bounds__(256) void k_symbol_filter(const T* __restrict__ in,
         const unsigned pitch = (256 * sps + arm_size) / sps + 2;
         for (unsigned i = threadIdx.x; i < span; i += 256)
             tile[(i % sps) * pitch + i / sps] = item_at(in, carry, cap, lo_item + i);
+        // the arm is the same for the whole workgroup: its taps go to LDS (broadcast reads)
+        float* s_arm = reinterpret_cast<float*>(tile + pitch * sps);
+        for (unsigned m = threadIdx.x; m < arm_size; m += 256) s_arm[m] = taps[static_cast<size_t>(r.arm) * arm_size + m];
         __syncthreads();
         if (o < n_out) {
-            // the arm is the same for the whole workgroup: make that visible so the taps are
-            // fetched with scalar loads instead of 64 identical vector loads
-            const float* arm = taps + static_cast<size_t>(__builtin_amdgcn_readfirstlane(r.arm)) * arm_size;
-            const unsigned top = (o - o0) * sps + arm_size - 1; // tile index of this symbol's newest item
+            const float* arm = s_arm;
+            // tile index of tap m of this symbol: (o - o0) * sps + j with j = arm_size - 1 - m;
+            // j % sps and j / sps are the same for every thread
+            const unsigned base = o - o0;
             T acc = zero_item(T{});
             for (unsigned m = 0; m < arm_size; ++m) {
-                const unsigned i = top - m;
-                acc = mac(acc, arm[m], tile[(i % sps) * pitch + i / sps]);
+                const unsigned j = arm_size - 1 - m;
+                acc = mac(acc, arm[m], tile[(j % sps) * pitch + j / sps + base]);
             }
             out[o] = scale_item(r.scale, acc);
         }
@@ -413,6 +439,27 @@ __global__ __launch_bounds__(256) void k_symbol_filter(const T* __restrict__ in,
     T acc = zero_item(T{});
     for (unsigned m = 0; m < arm_size; ++m) acc = mac(acc, arm[m], item_at(in, carry, cap, idx - m));
     out[o] = scale_item(r.scale, acc);
+}
+
+template <typename T>
+static void launch_symbol_filter(hipStream_t s, unsigned n_out, size_t smem, unsigned sps, const T* in,
+                                 const T* carry, unsigned cap, const float* taps, unsigned arm_size,
+                                 const SymRun* runs, unsigned n_runs, unsigned* wg_run, T* out)
+{
+    const dim3 grid((n_out + 255) / 256), block(256);
+    hipLaunchKernelGGL(k_symf_wg_runs, dim3((grid.x + 255) / 256), dim3(256), 0, s, runs, n_runs, grid.x, wg_run);
+    if (sps == 4)
+        hipLaunchKernelGGL((k_symbol_filter<T, 4>), grid, block, smem, s, in, carry, cap, taps, arm_size, sps, runs,
+                           n_runs, wg_run, n_out, out);
+    else if (sps == 2)
+        hipLaunchKernelGGL((k_symbol_filter<T, 2>), grid, block, smem, s, in, carry, cap, taps, arm_size, sps, runs,
+                           n_runs, wg_run, n_out, out);
+    else if (sps == 8)
+        hipLaunchKernelGGL((k_symbol_filter<T, 8>), grid, block, smem, s, in, carry, cap, taps, arm_size, sps, runs,
+                           n_runs, wg_run, n_out, out);
+    else
+        hipLaunchKernelGGL((k_symbol_filter<T, 0>), grid, block, smem, s, in, carry, cap, taps, arm_size, sps, runs,
+                           n_runs, wg_run, n_out, out);
 }
 
 // PfbArbResampler (pfb_arb_resampler.hpp:134-167).  The accumulator recurrence decides which
@@ -1203,6 +1250,7 @@ struct gr4pm_symbol_filter {
     DevBuf<float> taps;
     DevBuf<char> carry[2];
     DevBuf<SymRun> runs;
+    DevBuf<unsigned> wg_run;
     int cur = 0;
     // host replica of the tag-driven state (symbol_filter.hpp:44-50)
     size_t clock_phase = 0, reset_clock_phase = 0, pfb_arm = 0;
@@ -1401,20 +1449,20 @@ gr4pm_status gr4pm_symbol_filter_process(gr4pm_symbol_filter* h, const void* in,
     if (!runs.empty()) {
         GR4PM_TRY(upload_vec(h->runs, runs, s));
         const unsigned n_out = static_cast<unsigned>(produced);
-        if (h->item_kind == 0) {
-            hipLaunchKernelGGL(k_symbol_filter<cf>, dim3((n_out + 255) / 256), dim3(256),
-                               ((256 * sps + h->arm_size) / sps + 2) * sps * sizeof(cf), s,
-                               static_cast<const cf*>(in), reinterpret_cast<const cf*>(h->carry[h->cur].p),
-                               h->cap, h->taps.p, static_cast<unsigned>(h->arm_size), static_cast<unsigned>(sps),
-                               h->runs.p, static_cast<unsigned>(runs.size()), n_out, static_cast<cf*>(out));
-        } else {
-            hipLaunchKernelGGL(k_symbol_filter<float>, dim3((n_out + 255) / 256), dim3(256),
-                               ((256 * sps + h->arm_size) / sps + 2) * sps * sizeof(float), s,
-                               static_cast<const float*>(in),
-                               reinterpret_cast<const float*>(h->carry[h->cur].p), h->cap, h->taps.p,
-                               static_cast<unsigned>(h->arm_size), static_cast<unsigned>(sps), h->runs.p,
-                               static_cast<unsigned>(runs.size()), n_out, static_cast<float*>(out));
-        }
+        const size_t pitch = (256 * sps + h->arm_size) / sps + 2;
+        const size_t n_wg = (n_out + 255) / 256;
+        if (h->wg_run.n < n_wg) GR4PM_TRY(h->wg_run.alloc(n_wg * 2));
+        if (h->item_kind == 0)
+            launch_symbol_filter<cf>(s, n_out, pitch * sps * sizeof(cf) + h->arm_size * sizeof(float), static_cast<unsigned>(sps),
+                                     static_cast<const cf*>(in), reinterpret_cast<const cf*>(h->carry[h->cur].p),
+                                     h->cap, h->taps.p, static_cast<unsigned>(h->arm_size), h->runs.p,
+                                     static_cast<unsigned>(runs.size()), h->wg_run.p, static_cast<cf*>(out));
+        else
+            launch_symbol_filter<float>(s, n_out, pitch * sps * sizeof(float) + h->arm_size * sizeof(float), static_cast<unsigned>(sps),
+                                        static_cast<const float*>(in),
+                                        reinterpret_cast<const float*>(h->carry[h->cur].p), h->cap, h->taps.p,
+                                        static_cast<unsigned>(h->arm_size), h->runs.p,
+                                        static_cast<unsigned>(runs.size()), h->wg_run.p, static_cast<float*>(out));
     }
     if (pos > 0) {
         if (h->item_kind == 0)
