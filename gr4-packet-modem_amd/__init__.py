@@ -10,7 +10,7 @@ import numpy as np
 from ._abi import (EXPORTS, LIB_PATH, TAG_DTYPE, TAG_OTHER, TAG_SYNCWORD, Gr4pmError, lib)  # noqa: F401
 from .blocks import (SYNCWORD, CoarseFrequencyCorrection, CostasLoop, InterpolatingFirFilter,  # noqa: F401
                      PacketReceiver, PfbArbResampler, Rotator, SymbolFilter, SyncwordDetection, SyncwordDetectionFilter, SyncwordWipeoff,
-                     root_raised_cosine)
+                     cfc_symbol_filter, root_raised_cosine)
 
 _DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
 

@@ -110,7 +110,7 @@ EXPORTS = [
     "gr4pm_interp_fir_create", "gr4pm_interp_fir_destroy", "gr4pm_interp_fir_reset",
     "gr4pm_interp_fir_process",
     "gr4pm_symbol_filter_create", "gr4pm_symbol_filter_destroy", "gr4pm_symbol_filter_reset",
-    "gr4pm_symbol_filter_process",
+    "gr4pm_symbol_filter_process", "gr4pm_cfc_symbol_filter_process",
     "gr4pm_pfb_arb_resampler_create", "gr4pm_pfb_arb_resampler_destroy", "gr4pm_pfb_arb_resampler_reset",
     "gr4pm_pfb_arb_resampler_process",
     "gr4pm_firdes_root_raised_cosine",
@@ -184,6 +184,7 @@ def lib():
     L.gr4pm_symbol_filter_destroy.restype = None
     L.gr4pm_symbol_filter_reset.argtypes = [vp]
     L.gr4pm_symbol_filter_process.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, sz, szp, szp, szp]
+    L.gr4pm_cfc_symbol_filter_process.argtypes = [vp, vp, vp, sz, vp, sz, vp, sz, vp, sz, szp, szp, szp]
     L.gr4pm_pfb_arb_resampler_create.argtypes = [C.POINTER(PfbArbParams), C.POINTER(vp)]
     L.gr4pm_pfb_arb_resampler_destroy.argtypes = [vp]
     L.gr4pm_pfb_arb_resampler_destroy.restype = None

@@ -374,6 +374,24 @@ class SymbolFilter:
             self._h = None
 
 
+def cfc_symbol_filter(cfc, symf, x, tags=None, out_cap=None):
+    """CoarseFrequencyCorrection -> SymbolFilter in one pass (gr4pm_cfc_symbol_filter_process):
+    identical results and state updates, the rotated stream is not materialised.
+    Returns (symbols, tags_out, consumed)."""
+    torch = _torch()
+    x = _dev_c64(x)
+    t = _tags_array(tags)
+    if out_cap is None:
+        out_cap = x.numel() // symf.samples_per_symbol + t.size + 2
+    out = torch.empty(max(out_cap, 1), dtype=x.dtype, device=x.device)
+    tout = np.zeros(t.size + 64, dtype=TAG_DTYPE)
+    nto, cons, prod = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+    check(lib().gr4pm_cfc_symbol_filter_process(cfc._h, symf._h, x.data_ptr(), x.numel(), out.data_ptr(), out_cap,
+                                                _np_ptr(t), t.size, _np_ptr(tout), tout.size, C.byref(nto),
+                                                C.byref(cons), C.byref(prod)), "cfc_symbol_filter")
+    return out[: prod.value], tout[: nto.value].copy(), cons.value
+
+
 class PfbArbResampler:
     """pfb_arb_resampler.hpp:23-183 (<c64, c64, float, TRate>)"""
 
@@ -429,8 +447,9 @@ class PacketReceiver:
     EARLIER batch (None while the pipeline fills); flush() drains it."""
 
     def __init__(self, samples_per_symbol=4, syncword_freq_bins=4, syncword_threshold=9.5,
-                 costas_constellation="QPSK", max_items=1 << 22, pipelined=False):
+                 costas_constellation="QPSK", max_items=1 << 22, pipelined=False, fused=True):
         torch = _torch()
+        self.fused = fused  # CFC applied while the symbol filter stages its input
         sps = samples_per_symbol
         self.samples_per_symbol = sps
         rrc = root_raised_cosine(1.0, float(sps), 1.0, 0.35, sps * 11)            # :60-65
@@ -490,8 +509,11 @@ class PacketReceiver:
                 headers = [header_fn] * det_tags.size
             acc, _ = self.syncword_detection_filter.gate(base + det_tags["index"], headers, per_tag=True)
             tags = det_tags[acc]
-            z = self.freq_correction.process_bulk(y, tags)
-            sym, sym_tags, consumed = self.symbol_filter.process_bulk(z, tags)
+            if self.fused:
+                sym, sym_tags, consumed = cfc_symbol_filter(self.freq_correction, self.symbol_filter, y, tags)
+            else:
+                z = self.freq_correction.process_bulk(y, tags)
+                sym, sym_tags, consumed = self.symbol_filter.process_bulk(z, tags)
             w = self.syncword_wipeoff.process_bulk(sym, sym_tags)
         return {"status": 0, "consumed": n, "symbols": w, "tags": sym_tags, "detector_tags": det_tags,
                 "accepted": acc}

@@ -358,6 +358,61 @@ struct SymRun {
 // loads and every thread then reads its arm_size items from LDS (the MAC order of the
 // reference, std::inner_product, m ascending, is kept: bit-exact).  Workgroups that straddle
 // a run boundary (a handful per call) fall back to direct reads.
+// Fused CoarseFrequencyCorrection: when the symbol filter is fed by a CFC block, the rotation
+// is applied while the filter stages its input (the rotated stream is never written to HBM).
+struct CfcDev {
+    const RotSeg* segs;   // this call's segments of channel 0, sorted by start
+    const cf* ck;         // phasor checkpoints every kRotChunk items
+    const cf* seg_incr;
+    const unsigned* seg_counter0;
+    unsigned n_segs;
+};
+// rotated item idx (>= 0) of the current call; `seg` is a running hint (items visited upwards)
+__device__ __forceinline__ cf cfc_item(const CfcDev& f, const cf* in, long long idx, unsigned& seg)
+{
+    while (seg + 1 < f.n_segs && static_cast<unsigned long long>(idx) >= f.segs[seg + 1].start) ++seg;
+    const unsigned long long j = static_cast<unsigned long long>(idx) - f.segs[seg].start;
+    const unsigned long long c = j / kRotChunk;
+    cf e = f.ck[f.segs[seg].ck0 + c];
+    const cf inc = f.seg_incr[seg];
+    unsigned counter = f.seg_counter0[seg] + static_cast<unsigned>(c * kRotChunk);
+    const unsigned steps = static_cast<unsigned>(j - c * kRotChunk);
+    for (unsigned t = 0; t < steps; ++t) rot_step(e, inc, counter);
+    return cmul(in[idx], e); // coarse_frequency_correction.hpp:87
+}
+__device__ __forceinline__ unsigned cfc_find_seg(const CfcDev& f, long long idx)
+{
+    unsigned lo = 0, hi = f.n_segs - 1;
+    const unsigned long long u = idx < 0 ? 0ull : static_cast<unsigned long long>(idx);
+    while (lo < hi) {
+        const unsigned mid = (lo + hi + 1) >> 1;
+        if (f.segs[mid].start <= u) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+template <bool CFC, typename T>
+__device__ __forceinline__ T fetch_item(const T* in, const T* carry, unsigned cap, long long idx, const CfcDev& f,
+                                        unsigned& seg)
+{
+    if constexpr (CFC) {
+        if (idx < 0) return carry[static_cast<long long>(cap) + idx]; // history is stored rotated
+        return cfc_item(f, in, idx, seg);
+    } else {
+        return item_at(in, carry, cap, idx);
+    }
+}
+// history after a fused call: last cap ROTATED items
+__global__ void k_update_hist_cfc(const cf* __restrict__ in, const cf* __restrict__ carry, cf* __restrict__ carry_next,
+                                  unsigned cap, size_t n, CfcDev f)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap) return;
+    const long long idx = static_cast<long long>(n) - cap + i;
+    unsigned seg = cfc_find_seg(f, idx);
+    carry_next[i] = fetch_item<true, cf>(in, carry, cap, idx, f, seg);
+}
+
 // run index of the first symbol of every 256-symbol workgroup (a binary search per workgroup
 // inside k_symbol_filter would put ~12 dependent L2 round trips in front of each workgroup)
 __global__ void k_symf_wg_runs(const SymRun* __restrict__ runs, unsigned n_runs, unsigned n_wg,
@@ -377,13 +432,13 @@ __global__ void k_symf_wg_runs(const SymRun* __restrict__ runs, unsigned n_runs,
 
 // SPS > 0: samples_per_symbol known at compile time (divisions become shifts / constants);
 // SPS == 0: run-time value.
-template <typename T, int SPS>
+template <typename T, int SPS, bool CFC>
 __global__ __launch_bounds__(256) void k_symbol_filter(const T* __restrict__ in, const T* __restrict__ carry,
                                                        unsigned cap, const float* __restrict__ taps,
                                                        unsigned arm_size, unsigned sps_rt,
                                                        const SymRun* __restrict__ runs, unsigned n_runs,
                                                        const unsigned* __restrict__ wg_run,
-                                                       unsigned n_out, T* __restrict__ out)
+                                                       unsigned n_out, T* __restrict__ out, CfcDev cfc)
 {
     extern __shared__ unsigned char s_raw[];
     T* tile = reinterpret_cast<T*>(s_raw);
@@ -412,8 +467,10 @@ __global__ __launch_bounds__(256) void k_symbol_filter(const T* __restrict__ in,
         // tile is stored phase-major: item i lives at (i % sps) * pitch + i / sps, so that for a
         // fixed tap m the 64 lanes (items sps apart) read consecutive LDS words
         const unsigned pitch = (256 * sps + arm_size) / sps + 2;
+        unsigned seg = 0;
+        if constexpr (CFC) seg = cfc_find_seg(cfc, lo_item + threadIdx.x);
         for (unsigned i = threadIdx.x; i < span; i += 256)
-            tile[(i % sps) * pitch + i / sps] = item_at(in, carry, cap, lo_item + i);
+            tile[(i % sps) * pitch + i / sps] = fetch_item<CFC, T>(in, carry, cap, lo_item + i, cfc, seg);
         // the arm is the same for the whole workgroup: its taps go to LDS (broadcast reads)
         float* s_arm = reinterpret_cast<float*>(tile + pitch * sps);
         for (unsigned m = threadIdx.x; m < arm_size; m += 256) s_arm[m] = taps[static_cast<size_t>(r.arm) * arm_size + m];
@@ -437,29 +494,33 @@ __global__ __launch_bounds__(256) void k_symbol_filter(const T* __restrict__ in,
     const long long idx = r.in0 + static_cast<long long>(o - r.out0) * sps;
     const float* arm = taps + static_cast<size_t>(r.arm) * arm_size;
     T acc = zero_item(T{});
-    for (unsigned m = 0; m < arm_size; ++m) acc = mac(acc, arm[m], item_at(in, carry, cap, idx - m));
+    for (unsigned m = 0; m < arm_size; ++m) {
+        unsigned seg = 0;
+        if constexpr (CFC) seg = cfc_find_seg(cfc, idx - m);
+        acc = mac(acc, arm[m], fetch_item<CFC, T>(in, carry, cap, idx - m, cfc, seg));
+    }
     out[o] = scale_item(r.scale, acc);
 }
 
-template <typename T>
+template <typename T, bool CFC>
 static void launch_symbol_filter(hipStream_t s, unsigned n_out, size_t smem, unsigned sps, const T* in,
                                  const T* carry, unsigned cap, const float* taps, unsigned arm_size,
-                                 const SymRun* runs, unsigned n_runs, unsigned* wg_run, T* out)
+                                 const SymRun* runs, unsigned n_runs, unsigned* wg_run, T* out, CfcDev cfc)
 {
     const dim3 grid((n_out + 255) / 256), block(256);
     hipLaunchKernelGGL(k_symf_wg_runs, dim3((grid.x + 255) / 256), dim3(256), 0, s, runs, n_runs, grid.x, wg_run);
     if (sps == 4)
-        hipLaunchKernelGGL((k_symbol_filter<T, 4>), grid, block, smem, s, in, carry, cap, taps, arm_size, sps, runs,
-                           n_runs, wg_run, n_out, out);
+        hipLaunchKernelGGL((k_symbol_filter<T, 4, CFC>), grid, block, smem, s, in, carry, cap, taps, arm_size, sps,
+                           runs, n_runs, wg_run, n_out, out, cfc);
     else if (sps == 2)
-        hipLaunchKernelGGL((k_symbol_filter<T, 2>), grid, block, smem, s, in, carry, cap, taps, arm_size, sps, runs,
-                           n_runs, wg_run, n_out, out);
+        hipLaunchKernelGGL((k_symbol_filter<T, 2, CFC>), grid, block, smem, s, in, carry, cap, taps, arm_size, sps,
+                           runs, n_runs, wg_run, n_out, out, cfc);
     else if (sps == 8)
-        hipLaunchKernelGGL((k_symbol_filter<T, 8>), grid, block, smem, s, in, carry, cap, taps, arm_size, sps, runs,
-                           n_runs, wg_run, n_out, out);
+        hipLaunchKernelGGL((k_symbol_filter<T, 8, CFC>), grid, block, smem, s, in, carry, cap, taps, arm_size, sps,
+                           runs, n_runs, wg_run, n_out, out, cfc);
     else
-        hipLaunchKernelGGL((k_symbol_filter<T, 0>), grid, block, smem, s, in, carry, cap, taps, arm_size, sps, runs,
-                           n_runs, wg_run, n_out, out);
+        hipLaunchKernelGGL((k_symbol_filter<T, 0, CFC>), grid, block, smem, s, in, carry, cap, taps, arm_size, sps,
+                           runs, n_runs, wg_run, n_out, out, cfc);
 }
 
 // PfbArbResampler (pfb_arb_resampler.hpp:134-167).  The accumulator recurrence decides which
@@ -619,17 +680,13 @@ void gr4pm_rotator_destroy(gr4pm_rotator* h)
 }
 gr4pm_status gr4pm_rotator_reset(gr4pm_rotator* h) { return h ? rotator_reset_impl(h) : GR4PM_ERR_INVALID; }
 
-gr4pm_status gr4pm_rotator_process(gr4pm_rotator* h, const gr4pm_c64* in, size_t stride, size_t n,
-                                   gr4pm_c64* out, const gr4pm_tag* tags, const uint32_t* tag_channel,
-                                   size_t n_tags)
+} // extern "C"
+
+// host replay of the tag-driven control flow + the serial phasor checkpoints; leaves the segment
+// table, checkpoints, increments and counters of this call on the device (h->segs, h->ck, ...)
+static gr4pm_status rotator_plan(gr4pm_rotator* h, size_t n, const gr4pm_tag* tags, const uint32_t* tag_channel,
+                                 size_t n_tags, std::vector<RotSeg>& segs)
 {
-    if (!h) return GR4PM_ERR_INVALID;
-    if (n == 0) return GR4PM_OK; // an empty chunk is legal (and may come with null pointers)
-    if (!in || !out) {
-        set_error("null sample pointer");
-        return GR4PM_ERR_INVALID;
-    }
-    std::vector<RotSeg> segs;
     unsigned ck = 0;
     for (size_t c = 0; c < h->n_channels; ++c) {
         // set_freq events (item, freq) of this channel: coarse_frequency_correction.hpp:76-96
@@ -696,6 +753,8 @@ gr4pm_status gr4pm_rotator_process(gr4pm_rotator* h, const gr4pm_c64* in, size_t
     }
     hipStream_t s = h->stream;
     const unsigned n_segs = static_cast<unsigned>(segs.size());
+    unsigned ck_total = 0;
+    for (const auto& g : segs) ck_total = std::max<unsigned>(ck_total, g.ck0 + static_cast<unsigned>((g.len + kRotChunk - 1) / kRotChunk));
     GR4PM_TRY(upload_vec(h->segs, segs, s));
     if (h->ck.n < ck) GR4PM_TRY(h->ck.alloc(static_cast<size_t>(ck) * 2));
     if (h->seg_incr.n < n_segs) {
@@ -704,6 +763,26 @@ gr4pm_status gr4pm_rotator_process(gr4pm_rotator* h, const gr4pm_c64* in, size_t
     }
     hipLaunchKernelGGL(k_rot_checkpoints, dim3(grid_for(n_segs, 64)), dim3(64), 0, s, h->segs.p, n_segs,
                        h->state.p, h->ck.p, h->seg_incr.p, h->seg_counter0.p);
+    GR4PM_HIP_TRY(hipGetLastError());
+    return GR4PM_OK;
+}
+
+extern "C" {
+
+gr4pm_status gr4pm_rotator_process(gr4pm_rotator* h, const gr4pm_c64* in, size_t stride, size_t n,
+                                   gr4pm_c64* out, const gr4pm_tag* tags, const uint32_t* tag_channel,
+                                   size_t n_tags)
+{
+    if (!h) return GR4PM_ERR_INVALID;
+    if (n == 0) return GR4PM_OK; // an empty chunk is legal (and may come with null pointers)
+    if (!in || !out) {
+        set_error("null sample pointer");
+        return GR4PM_ERR_INVALID;
+    }
+    std::vector<RotSeg> segs;
+    GR4PM_TRY(rotator_plan(h, n, tags, tag_channel, n_tags, segs));
+    hipStream_t s = h->stream;
+    const unsigned n_segs = static_cast<unsigned>(segs.size());
     {
         size_t longest = 0;
         for (const auto& g : segs) longest = std::max<size_t>(longest, g.len);
@@ -1319,10 +1398,13 @@ gr4pm_status gr4pm_symbol_filter_reset(gr4pm_symbol_filter* h)
     return GR4PM_OK;
 }
 
-gr4pm_status gr4pm_symbol_filter_process(gr4pm_symbol_filter* h, const void* in, size_t n_in, void* out,
-                                         size_t out_cap, const gr4pm_tag* tags_in, size_t n_tags_in,
-                                         gr4pm_tag* tags_out, size_t tags_cap, size_t* n_tags_out,
-                                         size_t* consumed_, size_t* produced_)
+} // extern "C"
+
+// fuse == nullptr: plain SymbolFilter.  Otherwise the input is rotated by the CFC plan on the fly.
+static gr4pm_status symbol_filter_impl(gr4pm_symbol_filter* h, const void* in, size_t n_in, void* out,
+                                       size_t out_cap, const gr4pm_tag* tags_in, size_t n_tags_in,
+                                       gr4pm_tag* tags_out, size_t tags_cap, size_t* n_tags_out,
+                                       size_t* consumed_, size_t* produced_, const CfcDev* fuse)
 {
     if (!h || !consumed_ || !produced_) return GR4PM_ERR_INVALID;
     *consumed_ = *produced_ = 0;
@@ -1452,20 +1534,34 @@ gr4pm_status gr4pm_symbol_filter_process(gr4pm_symbol_filter* h, const void* in,
         const size_t pitch = (256 * sps + h->arm_size) / sps + 2;
         const size_t n_wg = (n_out + 255) / 256;
         if (h->wg_run.n < n_wg) GR4PM_TRY(h->wg_run.alloc(n_wg * 2));
-        if (h->item_kind == 0)
-            launch_symbol_filter<cf>(s, n_out, pitch * sps * sizeof(cf) + h->arm_size * sizeof(float), static_cast<unsigned>(sps),
-                                     static_cast<const cf*>(in), reinterpret_cast<const cf*>(h->carry[h->cur].p),
-                                     h->cap, h->taps.p, static_cast<unsigned>(h->arm_size), h->runs.p,
-                                     static_cast<unsigned>(runs.size()), h->wg_run.p, static_cast<cf*>(out));
+        if (fuse)
+            launch_symbol_filter<cf, true>(s, n_out, pitch * sps * sizeof(cf) + h->arm_size * sizeof(float),
+                                           static_cast<unsigned>(sps), static_cast<const cf*>(in),
+                                           reinterpret_cast<const cf*>(h->carry[h->cur].p), h->cap, h->taps.p,
+                                           static_cast<unsigned>(h->arm_size), h->runs.p,
+                                           static_cast<unsigned>(runs.size()), h->wg_run.p, static_cast<cf*>(out),
+                                           *fuse);
+        else if (h->item_kind == 0)
+            launch_symbol_filter<cf, false>(s, n_out, pitch * sps * sizeof(cf) + h->arm_size * sizeof(float),
+                                            static_cast<unsigned>(sps), static_cast<const cf*>(in),
+                                            reinterpret_cast<const cf*>(h->carry[h->cur].p), h->cap, h->taps.p,
+                                            static_cast<unsigned>(h->arm_size), h->runs.p,
+                                            static_cast<unsigned>(runs.size()), h->wg_run.p, static_cast<cf*>(out),
+                                            CfcDev{});
         else
-            launch_symbol_filter<float>(s, n_out, pitch * sps * sizeof(float) + h->arm_size * sizeof(float), static_cast<unsigned>(sps),
-                                        static_cast<const float*>(in),
-                                        reinterpret_cast<const float*>(h->carry[h->cur].p), h->cap, h->taps.p,
-                                        static_cast<unsigned>(h->arm_size), h->runs.p,
-                                        static_cast<unsigned>(runs.size()), h->wg_run.p, static_cast<float*>(out));
+            launch_symbol_filter<float, false>(s, n_out, pitch * sps * sizeof(float) + h->arm_size * sizeof(float),
+                                               static_cast<unsigned>(sps), static_cast<const float*>(in),
+                                               reinterpret_cast<const float*>(h->carry[h->cur].p), h->cap, h->taps.p,
+                                               static_cast<unsigned>(h->arm_size), h->runs.p,
+                                               static_cast<unsigned>(runs.size()), h->wg_run.p,
+                                               static_cast<float*>(out), CfcDev{});
     }
     if (pos > 0) {
-        if (h->item_kind == 0)
+        if (fuse)
+            hipLaunchKernelGGL(k_update_hist_cfc, dim3((h->cap + 63) / 64), dim3(64), 0, s,
+                               static_cast<const cf*>(in), reinterpret_cast<const cf*>(h->carry[h->cur].p),
+                               reinterpret_cast<cf*>(h->carry[h->cur ^ 1].p), h->cap, pos, *fuse);
+        else if (h->item_kind == 0)
             hipLaunchKernelGGL(k_update_hist<cf>, dim3((h->cap + 63) / 64), dim3(64), 0, s,
                                static_cast<const cf*>(in), reinterpret_cast<const cf*>(h->carry[h->cur].p),
                                reinterpret_cast<cf*>(h->carry[h->cur ^ 1].p), h->cap, pos);
@@ -1486,6 +1582,57 @@ gr4pm_status gr4pm_symbol_filter_process(gr4pm_symbol_filter* h, const void* in,
         return GR4PM_ERR_OVERFLOW;
     }
     return GR4PM_OK;
+}
+
+extern "C" {
+
+gr4pm_status gr4pm_symbol_filter_process(gr4pm_symbol_filter* h, const void* in, size_t n_in, void* out,
+                                         size_t out_cap, const gr4pm_tag* tags_in, size_t n_tags_in,
+                                         gr4pm_tag* tags_out, size_t tags_cap, size_t* n_tags_out,
+                                         size_t* consumed, size_t* produced)
+{
+    return symbol_filter_impl(h, in, n_in, out, out_cap, tags_in, n_tags_in, tags_out, tags_cap, n_tags_out,
+                              consumed, produced, nullptr);
+}
+
+gr4pm_status gr4pm_cfc_symbol_filter_process(gr4pm_rotator* cfc, gr4pm_symbol_filter* sf, const gr4pm_c64* in,
+                                             size_t n_in, gr4pm_c64* out, size_t out_cap,
+                                             const gr4pm_tag* tags_in, size_t n_tags_in, gr4pm_tag* tags_out,
+                                             size_t tags_cap, size_t* n_tags_out, size_t* consumed,
+                                             size_t* produced)
+{
+    if (!cfc || !sf || !consumed || !produced) return GR4PM_ERR_INVALID;
+    *consumed = *produced = 0;
+    if (n_tags_out) *n_tags_out = 0;
+    if (cfc->mode != 1 || cfc->n_channels != 1 || sf->item_kind != 0 || cfc->stream != sf->stream) {
+        set_error("fused call needs a single-channel CoarseFrequencyCorrection and a complex SymbolFilter on one stream");
+        return GR4PM_ERR_INVALID;
+    }
+    if (n_in == 0) return GR4PM_OK;
+    if (!in || !out) {
+        set_error("null sample pointer");
+        return GR4PM_ERR_INVALID;
+    }
+    // the rotation plan covers all n_in items, so the filter must be able to consume them all
+    if (out_cap < n_in / sf->sps + n_tags_in + 2) {
+        set_error("out_cap too small for a fused call");
+        return GR4PM_INSUFFICIENT_OUTPUT_ITEMS;
+    }
+    std::vector<RotSeg> segs;
+    GR4PM_TRY(rotator_plan(cfc, n_in, tags_in, nullptr, n_tags_in, segs)); // checkpoints on the shared stream
+    CfcDev f;
+    f.segs = cfc->segs.p;
+    f.ck = cfc->ck.p;
+    f.seg_incr = cfc->seg_incr.p;
+    f.seg_counter0 = cfc->seg_counter0.p;
+    f.n_segs = static_cast<unsigned>(segs.size());
+    const gr4pm_status st = symbol_filter_impl(sf, in, n_in, out, out_cap, tags_in, n_tags_in, tags_out, tags_cap,
+                                               n_tags_out, consumed, produced, &f);
+    if (st == GR4PM_OK && *consumed != n_in) {
+        set_error("fused call consumed %zu of %zu items", *consumed, n_in);
+        return GR4PM_ERR_INVALID;
+    }
+    return st;
 }
 
 } // extern "C"

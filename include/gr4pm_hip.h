@@ -267,6 +267,17 @@ gr4pm_status gr4pm_symbol_filter_process(gr4pm_symbol_filter* h, const void* in,
                                          size_t n_tags_in, gr4pm_tag* tags_out, size_t tags_cap,
                                          size_t* n_tags_out, size_t* consumed, size_t* produced);
 
+/* Fused CoarseFrequencyCorrection -> SymbolFilter (packet_receiver.hpp:221-224 connects them
+ * back to back): same results and same state updates as gr4pm_rotator_process (mode 1) followed
+ * by gr4pm_symbol_filter_process with the same tags, but the rotated stream is never written
+ * to memory.  Both handles must be single-channel / complex and share one stream; out_cap must
+ * cover all n_in items (n_in / samples_per_symbol + n_tags_in + 2). */
+gr4pm_status gr4pm_cfc_symbol_filter_process(gr4pm_rotator* cfc, gr4pm_symbol_filter* sf,
+                                             const gr4pm_c64* in, size_t n_in, gr4pm_c64* out,
+                                             size_t out_cap, const gr4pm_tag* tags_in, size_t n_tags_in,
+                                             gr4pm_tag* tags_out, size_t tags_cap, size_t* n_tags_out,
+                                             size_t* consumed, size_t* produced);
+
 /* ------------------------------------------------------------------------------------
  * PfbArbResampler<c64,c64,float,TRate> -- pfb_arb_resampler.hpp:23-183
  * ---------------------------------------------------------------------------------- */

@@ -710,3 +710,44 @@ def test_stream_blocks_empty_and_tiny_inputs(pkg):
     assert y.numel() == 0 and c == 0
     y, c = pkg.PfbArbResampler(1.1).process_bulk(e)
     assert y.numel() == 0 and c == 0
+
+
+def test_fused_cfc_symbol_filter_equals_separate_blocks(pkg):
+    """gr4pm_cfc_symbol_filter_process == CoarseFrequencyCorrection then SymbolFilter, bit for bit,
+    including the carried state over several calls (tags near call boundaries, pending delays)"""
+    rrc, pfb = _receiver_pfb()
+    rng = np.random.default_rng(77)
+    n = 40000
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    idx = np.array([3, 5000, 9990, 10010, 17000, 17003, 25000, 39990], dtype=np.uint64)
+    tags = np.zeros(idx.size, dtype=pkg.TAG_DTYPE)
+    tags["index"] = idx
+    tags["amplitude"] = rng.uniform(0.5, 2.0, idx.size)
+    tags["time_est"] = rng.uniform(-0.5, 0.5, idx.size)
+    tags["phase"] = rng.uniform(-3, 3, idx.size)
+    tags["freq"] = rng.uniform(-0.03, 0.03, idx.size)
+    tags["flags"] = pkg.TAG_SYNCWORD
+    cuts = [0, 10000, 10001, 26000, n]
+    a_cfc, a_sf = pkg.CoarseFrequencyCorrection(26), pkg.SymbolFilter(pfb, 32, 4, 44)
+    b_cfc, b_sf = pkg.CoarseFrequencyCorrection(26), pkg.SymbolFilter(pfb, 32, 4, 44)
+    ya, ta, yb, tb = [], [], [], []
+    oa = ob = 0
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        t = tags[(tags["index"] >= lo) & (tags["index"] < hi)].copy()
+        t["index"] -= lo
+        xd = dev(x[lo:hi])
+        y, tt, c = a_sf.process_bulk(a_cfc.process_bulk(xd, t), t)
+        assert c == hi - lo
+        tt = tt.copy(); tt["index"] += oa; oa += y.numel()
+        ya.append(host(y)); ta.append(tt)
+        y, tt, c = pkg.cfc_symbol_filter(b_cfc, b_sf, xd, t)
+        assert c == hi - lo
+        tt = tt.copy(); tt["index"] += ob; ob += y.numel()
+        yb.append(host(y)); tb.append(tt)
+    ya, yb, ta, tb = np.concatenate(ya), np.concatenate(yb), np.concatenate(ta), np.concatenate(tb)
+    assert np.array_equal(bits(ya), bits(yb))
+    assert np.array_equal(ta, tb)
+    # and against the oracle
+    z = orc.coarse_frequency_correction(x, tags["index"], tags["freq"], delay=26)
+    want, want_tags, _ = orc.symbol_filter(z, pfb, 32, 4, 44, tags=tags.astype(orc.TAG_DTYPE))
+    assert np.array_equal(bits(yb), bits(want)) and np.array_equal(tb["index"], want_tags["index"])
