@@ -61,6 +61,10 @@ class HeaderMsg(C.Structure):
     _fields_ = [("packet_length", C.c_uint64), ("invalid_header", C.c_int32)]
 
 
+HEADER_MSG_DTYPE = np.dtype([("packet_length", "<u8"), ("invalid_header", "<i4")], align=True)
+assert HEADER_MSG_DTYPE.itemsize == C.sizeof(HeaderMsg)
+
+
 class RotatorParams(C.Structure):
     _fields_ = [("mode", C.c_int), ("phase_incr", C.c_float), ("delay", C.c_size_t),
                 ("n_channels", C.c_size_t), ("stream", C.c_void_p)]

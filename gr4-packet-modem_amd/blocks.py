@@ -174,13 +174,18 @@ class SyncwordDetectionFilter:
         headers[k] answers the k-th accepted tag (per_tag: tag k if accepted): packet_length, or
         None for invalid_header."""
         idx = np.ascontiguousarray(tag_index, dtype=np.uint64)
-        msgs = (_abi.HeaderMsg * max(len(headers), 1))()
-        for i, hm in enumerate(headers):
-            msgs[i].packet_length = 0 if hm is None else int(hm)
-            msgs[i].invalid_header = 1 if hm is None else 0
+        msgs = np.zeros(max(len(headers), 1), dtype=_abi.HEADER_MSG_DTYPE)
+        if len(headers):
+            if isinstance(headers, np.ndarray) and headers.dtype.kind in "iu":
+                msgs["packet_length"][: len(headers)] = headers
+            else:
+                inval = np.fromiter((h is None for h in headers), dtype=bool, count=len(headers))
+                msgs["invalid_header"][: len(headers)] = inval
+                msgs["packet_length"][: len(headers)] = np.fromiter((0 if h is None else h for h in headers),
+                                                                    dtype=np.uint64, count=len(headers))
         acc = np.zeros(max(idx.size, 1), dtype=np.uint8)
         used = C.c_size_t(0)
-        check(lib().gr4pm_syncword_detection_filter_gate(self._h, _np_ptr(idx), idx.size, msgs, len(headers),
+        check(lib().gr4pm_syncword_detection_filter_gate(self._h, _np_ptr(idx), idx.size, _np_ptr(msgs), len(headers),
                                                          1 if per_tag else 0, _np_ptr(acc), C.byref(used)),
               "SyncwordDetectionFilter.gate")
         return acc[: idx.size].astype(bool), used.value
@@ -505,8 +510,10 @@ class PacketReceiver:
             # SyncwordDetectionFilter: gate the tags; the samples pass unchanged
             if callable(header_fn):
                 headers = [header_fn(t) for t in det_tags]
-            else:  # a constant packet_length (or None == every header invalid)
-                headers = [header_fn] * det_tags.size
+            elif header_fn is None:  # every header invalid
+                headers = [None] * det_tags.size
+            else:  # a constant packet_length
+                headers = np.full(det_tags.size, int(header_fn), dtype=np.uint64)
             acc, _ = self.syncword_detection_filter.gate(base + det_tags["index"], headers, per_tag=True)
             tags = det_tags[acc]
             if self.fused:
