@@ -268,7 +268,7 @@ GR4PM_HD void fft2_passA(int lane, cf* r, const cf* twA)
         dft8(r + 8 * q);
 #pragma unroll
         for (int ka = 1; ka < 8; ++ka)
-#if defined(GR4PM_ABL) && GR4PM_ABL == 3
+#if defined(GR4PM_ABL) && (GR4PM_ABL == 3 || GR4PM_ABL == 4)
             r[8 * q + ka] = cmul(r[8 * q + ka], mk(0.7f + ka, 0.7f - q));
 #else
             r[8 * q + ka] = cmul(r[8 * q + ka], twA[((ka - 1) * 4 + q) * 64 + lane]);
@@ -299,7 +299,7 @@ GR4PM_HD void fft2_passB(int lane, cf* r, const cf* twB)
         dft16(r + 16 * q);
 #pragma unroll
         for (int k2 = 1; k2 < 16; ++k2)
-#if defined(GR4PM_ABL) && GR4PM_ABL == 3
+#if defined(GR4PM_ABL) && (GR4PM_ABL == 3 || GR4PM_ABL == 4)
             r[16 * q + k2] = cmul(r[16 * q + k2], mk(0.5f + k2, 0.25f));
 #else
             r[16 * q + k2] = cmul(r[16 * q + k2], twB[(k2 - 1) * 16 + m]);

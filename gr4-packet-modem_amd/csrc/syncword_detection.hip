@@ -88,7 +88,7 @@ __device__ __forceinline__ void fft2_wave(int lane, cf* r, cf* out, cf* lds, con
 {
     fft2_passA(lane, r, twA);
     cf b[32];
-#if GR4PM_ABL == 1 || GR4PM_ABL == 3 /* timing-only ablation: no LDS exchanges */
+#if GR4PM_ABL == 1 || GR4PM_ABL == 3 || GR4PM_ABL == 4 /* timing-only ablation: no LDS exchanges */
 #pragma unroll
     for (int j = 0; j < 32; ++j) b[j] = r[(j * 5 + 3) & 31];
 #else
@@ -101,7 +101,7 @@ __device__ __forceinline__ void fft2_wave(int lane, cf* r, cf* out, cf* lds, con
     }
 #endif
     fft2_passB(lane, b, twB);
-#if GR4PM_ABL == 1 || GR4PM_ABL == 3
+#if GR4PM_ABL == 1 || GR4PM_ABL == 3 || GR4PM_ABL == 4
 #pragma unroll
     for (int j = 0; j < 32; ++j) out[j] = b[(j * 7 + 1) & 31];
 #else
@@ -196,17 +196,17 @@ __global__ __launch_bounds__(kCorrThreads, 2) void k_correlate(const cf* __restr
 #pragma unroll
     for (int j = 0; j < 32; ++j) zmax[j] = -1.0f; // hpp:303
     __syncthreads();
+    // Template pipeline: as soon as every wave has consumed template `bin`, template bin+1 is
+    // copied global -> LDS by the DMA path (global_load_lds: no VGPRs, no ds_write) while the
+    // transform runs; the barrier at the end of the iteration (vmcnt(0) + s_barrier) publishes it.
     for (int bin = 0; bin < n_bins; ++bin) {
-        // next template: global loads now, LDS write once everybody has consumed this one
-        float4 tn[kTmplPerThread];
+#if GR4PM_ABL == 4 || GR4PM_ABL == 5 || GR4PM_ABL == 6 /* timing only: no template staging */
+        const bool more = false;
+#else
         const bool more = bin + 1 < n_bins;
-        if (more) {
-            const float4* tg = tmpl + static_cast<size_t>(bin + 1) * 1024;
-#pragma unroll
-            for (int u = 0; u < kTmplPerThread; ++u) tn[u] = tg[u * kCorrThreads + tid];
-        }
+#endif
         cf p[32], c[32];
-#if GR4PM_ABL == 3 /* timing only: no template reads either */
+#if GR4PM_ABL == 3 || GR4PM_ABL == 4 || GR4PM_ABL == 5 /* timing only: no template reads */
 #pragma unroll
         for (int j = 0; j < 32; ++j) p[j] = cmul(X[j], X[(j + 1) & 31]);
 #else
@@ -216,8 +216,15 @@ __global__ __launch_bounds__(kCorrThreads, 2) void k_correlate(const cf* __restr
 #if GR4PM_ABL != 2 && GR4PM_ABL != 3
             __syncthreads(); // every wave has read the current template
 #endif
+            const float4* tg = tmpl + static_cast<size_t>(bin + 1) * 1024;
 #pragma unroll
-            for (int u = 0; u < kTmplPerThread; ++u) lds4[kLdsTmpl + u * kCorrThreads + tid] = tn[u];
+            for (int u = 0; u < kTmplPerThread; ++u) {
+                // LDS destination = wave-uniform base + lane * 16 bytes
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(tg + u * kCorrThreads + tid),
+                    (__attribute__((address_space(3))) void*)(lds4 + kLdsTmpl + u * kCorrThreads + wave * 64),
+                    16, 0, 0);
+            }
         }
         fft2_wave(lane, p, c, lds, twA, twB); // hpp:250-251
 #pragma unroll
