@@ -8,7 +8,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgr4pm_hip.so")
+# GR4PM_LIB: A/B builds of the same ABI (tools/); the default is the in-tree library
+LIB_PATH = os.environ.get("GR4PM_LIB") or os.path.join(_HERE, "libgr4pm_hip.so")
 
 OK = 0
 INSUFFICIENT_INPUT_ITEMS = 1

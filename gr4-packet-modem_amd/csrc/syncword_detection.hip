@@ -84,7 +84,12 @@ __device__ __forceinline__ void fft1_wave(int lane, cf* r, cf* lds, const cf* tw
     fft1_pass3(r);
 }
 // FFT-2: r (FFT-1's distribution) -> out (consecutive indices on consecutive lanes)
-__device__ __forceinline__ void fft2_wave(int lane, cf* r, cf* out, cf* lds, const cf* twA, const cf* twB)
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+template <typename Hook = NoHook>
+__device__ __forceinline__ void fft2_wave(int lane, cf* r, cf* out, cf* lds, const cf* twA, const cf* twB,
+                                          Hook mid = Hook{})
 {
     fft2_passA(lane, r, twA);
     cf b[32];
@@ -101,6 +106,7 @@ __device__ __forceinline__ void fft2_wave(int lane, cf* r, cf* out, cf* lds, con
     }
 #endif
     fft2_passB(lane, b, twB);
+    mid(); // the caller's mid-transform work (template hand-off in k_correlate)
 #if GR4PM_ABL == 1 || GR4PM_ABL == 3 || GR4PM_ABL == 4
 #pragma unroll
     for (int j = 0; j < 32; ++j) out[j] = b[(j * 7 + 1) & 31];
@@ -137,7 +143,8 @@ __device__ __forceinline__ void mul_template(int lane, const cf* X, cf* r, const
 // = 68 KiB per workgroup -> two workgroups per CU.  They run out of phase, so one's prologue
 // (HBM loads, FFT-1) and barriers are covered by the other's transforms.
 constexpr int kLdsTmpl = 0, kLdsTwA = 1024, kLdsTwB = kLdsTwA + kTwAItems / 2, kLdsExch = kLdsTwB + kTwBItems / 2;
-constexpr int kLdsTotal = kLdsExch + kWavesPerWg * (kExchangeItems / 2); // float4 units
+constexpr int kLdsCtl = kLdsExch + kWavesPerWg * (kExchangeItems / 2);   // one float4: hand-off words
+constexpr int kLdsTotal = kLdsCtl + 1;                                  // float4 units
 static_assert(2 * kLdsTotal * 16 <= 160 * 1024, "LDS budget for two workgroups per CU");
 constexpr int kCorrThreads = kWavesPerWg * 64;
 constexpr int kTmplPerThread = 1024 / kCorrThreads; // float4 per thread per template
@@ -195,47 +202,55 @@ __global__ __launch_bounds__(kCorrThreads, 2) void k_correlate(const cf* __restr
     float zmax[32];
 #pragma unroll
     for (int j = 0; j < 32; ++j) zmax[j] = -1.0f; // hpp:303
+    // Template hand-off without workgroup barriers.  Two monotonic words in LDS:
+    //   consumed = number of (wave, bin) template reads finished      (ds_add by every wave)
+    //   ready    = index of the template currently in the LDS buffer  (written by wave 0)
+    // Wave 0 copies template bin+1 global -> LDS with the DMA path (global_load_lds: no VGPRs,
+    // no ds_write) in the middle of its own transform, once consumed == 4 (bin + 1); everybody
+    // waits for ready >= bin before reading.  LDS operations of a wave execute in order, so
+    // the ds_add of a wave is performed after its template reads.  All spins are bounded.
+    unsigned* ctl = reinterpret_cast<unsigned*>(lds4 + kLdsCtl);
+    if (tid == 0) {
+        ctl[0] = 0; // consumed
+        ctl[1] = 0; // ready
+    }
     __syncthreads();
-    // Template pipeline: as soon as every wave has consumed template `bin`, template bin+1 is
-    // copied global -> LDS by the DMA path (global_load_lds: no VGPRs, no ds_write) while the
-    // transform runs; the barrier at the end of the iteration (vmcnt(0) + s_barrier) publishes it.
+    auto wait_ge = [&](int word, unsigned v) {
+        for (int guard = 0; guard < (1 << 20); ++guard) {
+            if (__hip_atomic_load(ctl + word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= v) return;
+            __builtin_amdgcn_s_sleep(2);
+        }
+    };
     for (int bin = 0; bin < n_bins; ++bin) {
-#if GR4PM_ABL == 4 || GR4PM_ABL == 5 || GR4PM_ABL == 6 /* timing only: no template staging */
-        const bool more = false;
-#else
         const bool more = bin + 1 < n_bins;
-#endif
         cf p[32], c[32];
-#if GR4PM_ABL == 3 || GR4PM_ABL == 4 || GR4PM_ABL == 5 /* timing only: no template reads */
-#pragma unroll
-        for (int j = 0; j < 32; ++j) p[j] = cmul(X[j], X[(j + 1) & 31]);
-#else
+        wait_ge(1, static_cast<unsigned>(bin));
         mul_template(lane, X, p, lds4 + kLdsTmpl); // hpp:247-249
-#endif
-        if (more) {
-#if GR4PM_ABL != 2 && GR4PM_ABL != 3
-            __syncthreads(); // every wave has read the current template
-#endif
+        wave_lds_sync(); // keep the template reads ahead of the counter update in program order
+        if (lane == 0) __hip_atomic_fetch_add(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        auto hand_off = [&]() {
+            if (!more || wave != 0) return; // wave-uniform
+            wait_ge(0, static_cast<unsigned>(kWavesPerWg * (bin + 1)));
             const float4* tg = tmpl + static_cast<size_t>(bin + 1) * 1024;
 #pragma unroll
-            for (int u = 0; u < kTmplPerThread; ++u) {
-                // LDS destination = wave-uniform base + lane * 16 bytes
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(tg + u * kCorrThreads + tid),
-                    (__attribute__((address_space(3))) void*)(lds4 + kLdsTmpl + u * kCorrThreads + wave * 64),
-                    16, 0, 0);
+            for (int u = 0; u < 16; ++u) {
+                // one wave moves the whole 16 KiB template: 16 x 1 KiB, LDS dst = base + lane * 16 B
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tg + u * 64 + lane),
+                                                 (__attribute__((address_space(3))) void*)(lds4 + kLdsTmpl + u * 64), 16,
+                                                 0, 0);
             }
-        }
-        fft2_wave(lane, p, c, lds, twA, twB); // hpp:250-251
+        };
+        fft2_wave(lane, p, c, lds, twA, twB, hand_off); // hpp:250-251
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
             // hpp:307-308: the best bin's power; max() == the strict-> scan for the VALUE (the
             // bin index is recomputed by k_tags for detections only)
             zmax[j] = fmaxf(zmax[j], cnorm(c[j]));
         }
-#if GR4PM_ABL != 2 && GR4PM_ABL != 3
-        if (more) __syncthreads(); // next template complete
-#endif
+        if (more && wave == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the DMA has landed in LDS
+            if (lane == 0) __hip_atomic_store(ctl + 1, static_cast<unsigned>(bin + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
     }
     if (!active) return;
     // lag k <-> correlation index (N - k) mod N (hpp:300); lanes hold consecutive indices
