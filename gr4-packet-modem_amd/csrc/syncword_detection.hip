@@ -244,8 +244,10 @@ __global__ __launch_bounds__(kCorrThreads, 2) void k_correlate(const cf* __restr
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
             // hpp:307-308: the best bin's power; max() == the strict-> scan for the VALUE (the
-            // bin index is recomputed by k_tags for detections only)
-            zmax[j] = fmaxf(zmax[j], cnorm(c[j]));
+            // bin index is recomputed by k_tags for detections only).  One v_max_f32 (fmaxf would
+            // add a canonicalising second one).
+            const float pw = fmaf(c[j].y, c[j].y, c[j].x * c[j].x);
+            asm("v_max_f32 %0, %1, %2" : "=v"(zmax[j]) : "v"(zmax[j]), "v"(pw));
         }
         if (more && wave == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the DMA has landed in LDS
