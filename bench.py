@@ -107,6 +107,20 @@ def cpu_baseline(x_host, rrc, seconds_target=12.0):
                       f"SyncwordDetection, 1 thread"}
 
 
+def scatter_channels(dist, make_all, n_items, device, rank, world):
+    """the only collective of this workload is the initial sample scatter -- rank 0
+    holds every channel's samples ([world, n_items] complex64) and sends one channel to each
+    rank (RCCL send/recv over xGMI on the GPUs; any torch.distributed backend works)."""
+    mine = torch.empty(n_items, dtype=torch.complex64, device=device)
+    if rank == 0:
+        allx = make_all()
+        assert allx.shape == (world, n_items)
+        dist.scatter(mine, [allx[r].contiguous() for r in range(world)], src=0)
+    else:
+        dist.scatter(mine, None, src=0)
+    return mine
+
+
 def aggregate(dist, dt, consumed, device):
     """whole-job numbers over all ranks: time = MAX over ranks, items = SUM over ranks (each
     rank runs its own channel: weak scaling, no data-path collective).  Works with any
@@ -133,6 +147,8 @@ def main():
                          "(detector only; --items is per channel)")
     ap.add_argument("--copy-delay", action="store_true",
                     help="materialise SyncwordDetection's delayed output instead of reading the ring in place")
+    ap.add_argument("--no-scatter", action="store_true",
+                    help="N > 1: let every rank generate its own channel instead of the RCCL scatter from rank 0")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the two halves of the chain back to back on one stream")
     args = ap.parse_args()
@@ -151,7 +167,18 @@ def main():
     rrc = unit_norm_rrc(pkg)
     bpsk = np.array([1, -1], dtype=np.complex64)
     n_items = args.items
+    input_mode = "generated on each GPU"
     x, n_pkt = burst_stream(pkg, n_items, rrc, seed=1 + rank, device=device)
+    if dist and not args.no_scatter:
+        # multi-channel receive: rank 0 owns the sample ring of all channels and scatters it
+        try:
+            def make_all():
+                chans = [x] + [burst_stream(pkg, n_items, rrc, seed=1 + r, device=device)[0] for r in range(1, world)]
+                return torch.stack(chans)
+            x = scatter_channels(dist, make_all, n_items, device, rank, world)
+            input_mode = "rank 0 -> all ranks, torch.distributed scatter (RCCL)"
+        except Exception as e:  # keep the benchmark alive: fall back to local generation
+            input_mode = f"generated on each GPU (scatter failed: {type(e).__name__})"
     # the stream lives in a device ring: [the 2T+1 items before the window | the window].  Every
     # step presents the same window, so the items "before" it are the window's own tail.
     HIST = 2 * 768 + 1
@@ -280,7 +307,7 @@ def main():
                                     "gate + CFC + 32-arm RRC SymbolFilter + wipe-off + Costas)") +
                                    " on resident burst+AWGN stream",
                        "items_per_step_per_gpu": n_items * args.channels, "channels_per_gpu": args.channels, "freq_bins": 2 * BINS + 1, "tags_per_step": n_tags // max(args.steps, 1),
-                       "parallelism": f"channel-per-gpu x{world}",
+                       "parallelism": f"channel-per-gpu x{world}", "input": input_mode,
                        "pipelined_streams": 1 if (args.no_pipeline or args.detector_only) else 3},
             "roofline": roofline,
             "cpu_baseline": cpu,

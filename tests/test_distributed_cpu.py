@@ -24,7 +24,12 @@ def _worker(rank, world, port, out):
     import bench
     # rank r "measured" dt = 1 + r seconds and consumed 1000 * (r + 1) items
     dt, total = bench.aggregate(dist, 1.0 + rank, 1000.0 * (rank + 1), torch.device("cpu"))
-    out[rank] = (dt, total)
+    # the initial channel scatter (the workload's only collective)
+    n = 1000
+    def make_all():
+        return torch.stack([torch.full((n,), complex(r + 1, -r), dtype=torch.complex64) for r in range(world)])
+    mine = bench.scatter_channels(dist, make_all, n, torch.device("cpu"), rank, world)
+    out[rank] = (dt, total, complex(mine[0].item()), bool((mine == mine[0]).all()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -36,9 +41,10 @@ def test_two_rank_aggregation_gloo():
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert len(out) == world
     for r in range(world):
-        dt, total = out[r]
+        dt, total, first, uniform = out[r]
         assert dt == 2.0          # MAX over ranks
         assert total == 3000.0    # SUM over ranks
+        assert first == complex(r + 1, -r) and uniform   # every rank received its own channel
 
 
 def test_single_rank_aggregation_is_identity():
