@@ -352,34 +352,33 @@ struct SymRun {
     unsigned count; // outputs, spaced samples_per_symbol apart
     unsigned arm;
     float scale;
+    unsigned wg0;   // first workgroup of the run (workgroups never straddle runs)
+    unsigned pad;
 };
-// One workgroup = 256 consecutive output symbols.  Inside one run the inputs of those symbols
-// are one contiguous span (256*sps + arm_size items): it is staged into LDS with coalesced
+// One workgroup = up to 256 consecutive output symbols of ONE run.  The inputs of those symbols
+// are one contiguous span (255*sps + arm_size items): it is staged into LDS with coalesced
 // loads and every thread then reads its arm_size items from LDS (the MAC order of the
-// reference, std::inner_product, m ascending, is kept: bit-exact).  Workgroups that straddle
-// a run boundary (a handful per call) fall back to direct reads.
+// reference, std::inner_product, m ascending, is kept: bit-exact).
+// Everything a workgroup needs is resolved once by k_symf_wg_plan (a binary search inside the
+// filter kernel would put ~12 dependent L2 round trips in front of each workgroup).
+struct SymWg {
+    long long lo_item; // oldest input item of the span (negative: inside the carried history)
+    unsigned o0;       // first output symbol
+    unsigned count;    // symbols (<= 256)
+    unsigned arm;
+    float scale;
+    unsigned seg;      // fused CFC: segment of max(lo_item, 0)
+    unsigned pad;
+};
 // Fused CoarseFrequencyCorrection: when the symbol filter is fed by a CFC block, the rotation
 // is applied while the filter stages its input (the rotated stream is never written to HBM).
 struct CfcDev {
-    const RotSeg* segs;   // this call's segments of channel 0, sorted by start
+    const RotSeg* segs;   // this call's segments of channel 0, sorted by start, tiling [0, n_in)
     const cf* ck;         // phasor checkpoints every kRotChunk items
     const cf* seg_incr;
     const unsigned* seg_counter0;
     unsigned n_segs;
 };
-// rotated item idx (>= 0) of the current call; `seg` is a running hint (items visited upwards)
-__device__ __forceinline__ cf cfc_item(const CfcDev& f, const cf* in, long long idx, unsigned& seg)
-{
-    while (seg + 1 < f.n_segs && static_cast<unsigned long long>(idx) >= f.segs[seg + 1].start) ++seg;
-    const unsigned long long j = static_cast<unsigned long long>(idx) - f.segs[seg].start;
-    const unsigned long long c = j / kRotChunk;
-    cf e = f.ck[f.segs[seg].ck0 + c];
-    const cf inc = f.seg_incr[seg];
-    unsigned counter = f.seg_counter0[seg] + static_cast<unsigned>(c * kRotChunk);
-    const unsigned steps = static_cast<unsigned>(j - c * kRotChunk);
-    for (unsigned t = 0; t < steps; ++t) rot_step(e, inc, counter);
-    return cmul(in[idx], e); // coarse_frequency_correction.hpp:87
-}
 __device__ __forceinline__ unsigned cfc_find_seg(const CfcDev& f, long long idx)
 {
     unsigned lo = 0, hi = f.n_segs - 1;
@@ -391,16 +390,18 @@ __device__ __forceinline__ unsigned cfc_find_seg(const CfcDev& f, long long idx)
     }
     return lo;
 }
-template <bool CFC, typename T>
-__device__ __forceinline__ T fetch_item(const T* in, const T* carry, unsigned cap, long long idx, const CfcDev& f,
-                                        unsigned& seg)
+// rotated item idx (>= 0) of the current call: the lane replays at most kRotChunk-1 steps of
+// the recurrence from its chunk's checkpoint
+__device__ __forceinline__ cf cfc_item(const CfcDev& f, const cf* in, long long idx, unsigned seg)
 {
-    if constexpr (CFC) {
-        if (idx < 0) return carry[static_cast<long long>(cap) + idx]; // history is stored rotated
-        return cfc_item(f, in, idx, seg);
-    } else {
-        return item_at(in, carry, cap, idx);
-    }
+    const unsigned long long j = static_cast<unsigned long long>(idx) - f.segs[seg].start;
+    const unsigned long long c = j / kRotChunk;
+    cf e = f.ck[f.segs[seg].ck0 + c];
+    const cf inc = f.seg_incr[seg];
+    unsigned counter = f.seg_counter0[seg] + static_cast<unsigned>(c * kRotChunk);
+    const unsigned steps = static_cast<unsigned>(j - c * kRotChunk);
+    for (unsigned t = 0; t < steps; ++t) rot_step(e, inc, counter);
+    return cmul(in[idx], e); // coarse_frequency_correction.hpp:87
 }
 // history after a fused call: last cap ROTATED items
 __global__ void k_update_hist_cfc(const cf* __restrict__ in, const cf* __restrict__ carry, cf* __restrict__ carry_next,
@@ -409,26 +410,37 @@ __global__ void k_update_hist_cfc(const cf* __restrict__ in, const cf* __restric
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= cap) return;
     const long long idx = static_cast<long long>(n) - cap + i;
-    unsigned seg = cfc_find_seg(f, idx);
-    carry_next[i] = fetch_item<true, cf>(in, carry, cap, idx, f, seg);
+    carry_next[i] = idx < 0 ? carry[static_cast<long long>(cap) + idx] // history is stored rotated
+                            : cfc_item(f, in, idx, cfc_find_seg(f, idx));
 }
 
-// run index of the first symbol of every 256-symbol workgroup (a binary search per workgroup
-// inside k_symbol_filter would put ~12 dependent L2 round trips in front of each workgroup)
-__global__ void k_symf_wg_runs(const SymRun* __restrict__ runs, unsigned n_runs, unsigned n_wg,
-                               unsigned* __restrict__ wg_run)
+__global__ void k_symf_wg_plan(const SymRun* __restrict__ runs, unsigned n_runs, unsigned n_wg, unsigned sps,
+                               unsigned arm_size, CfcDev cfc, SymWg* __restrict__ plan)
 {
     const unsigned w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= n_wg) return;
-    const unsigned oo = w * 256u;
     unsigned lo = 0, hi = n_runs - 1;
     while (lo < hi) {
         const unsigned mid = (lo + hi + 1) >> 1;
-        if (runs[mid].out0 <= oo) lo = mid;
+        if (runs[mid].wg0 <= w) lo = mid;
         else hi = mid - 1;
     }
-    wg_run[w] = lo;
+    const SymRun r = runs[lo];
+    const unsigned first = (w - r.wg0) * 256u;
+    SymWg p;
+    p.o0 = r.out0 + first;
+    p.count = min(256u, r.count - first);
+    p.lo_item = r.in0 + static_cast<long long>(first) * sps - (arm_size - 1);
+    p.arm = r.arm;
+    p.scale = r.scale;
+    p.seg = cfc.n_segs ? cfc_find_seg(cfc, p.lo_item) : 0u;
+    p.pad = 0;
+    plan[w] = p;
 }
+
+// LDS slot of raw (unrotated) item i of the span: one pad item per kRotChunk, so that lanes
+// reading one chunk each (stride 9 items = 18 words) do not collide
+__device__ __forceinline__ unsigned raw_slot(unsigned i) { return i + i / kRotChunk; }
 
 // SPS > 0: samples_per_symbol known at compile time (divisions become shifts / constants);
 // SPS == 0: run-time value.
@@ -436,91 +448,98 @@ template <typename T, int SPS, bool CFC>
 __global__ __launch_bounds__(256) void k_symbol_filter(const T* __restrict__ in, const T* __restrict__ carry,
                                                        unsigned cap, const float* __restrict__ taps,
                                                        unsigned arm_size, unsigned sps_rt,
-                                                       const SymRun* __restrict__ runs, unsigned n_runs,
-                                                       const unsigned* __restrict__ wg_run,
-                                                       unsigned n_out, T* __restrict__ out, CfcDev cfc)
+                                                       const SymWg* __restrict__ plan, T* __restrict__ out,
+                                                       CfcDev cfc)
 {
     extern __shared__ unsigned char s_raw[];
     T* tile = reinterpret_cast<T*>(s_raw);
     const unsigned sps = SPS > 0 ? static_cast<unsigned>(SPS) : sps_rt;
-    const unsigned o0 = blockIdx.x * 256u;
-    const unsigned o = o0 + threadIdx.x;
-    const unsigned o_last = min(o0 + 255u, n_out - 1);
-    // run of the first and of the last symbol of this workgroup
-    auto find = [&](unsigned oo) {
-        unsigned lo = 0, hi = n_runs - 1;
-        while (lo < hi) {
-            const unsigned mid = (lo + hi + 1) >> 1;
-            if (runs[mid].out0 <= oo) lo = mid;
-            else hi = mid - 1;
+    const SymWg p = plan[blockIdx.x];
+    const unsigned span = (p.count - 1) * sps + arm_size;
+    // tile is stored phase-major: item i lives at (i % sps) * pitch + i / sps, so that for a
+    // fixed tap m the 64 lanes (items sps apart) read consecutive LDS words
+    const unsigned pitch = (256 * sps + arm_size) / sps + 2;
+    // the arm is the same for the whole workgroup: its taps go to LDS (broadcast reads)
+    float* s_arm = reinterpret_cast<float*>(tile + pitch * sps);
+    for (unsigned m = threadIdx.x; m < arm_size; m += 256) s_arm[m] = taps[static_cast<size_t>(p.arm) * arm_size + m];
+    if constexpr (CFC) {
+        // 1. raw items, coalesced, into LDS (history items are stored rotated: straight to the tile)
+        cf* raw = reinterpret_cast<cf*>(s_arm + ((arm_size + 1) & ~1u));
+        for (unsigned i = threadIdx.x; i < span; i += 256) {
+            const long long idx = p.lo_item + i;
+            if (idx < 0) tile[(i % sps) * pitch + i / sps] = carry[static_cast<long long>(cap) + idx];
+            else raw[raw_slot(i)] = in[idx];
         }
-        return lo;
-    };
-    // the workgroup lies inside one run iff the next run starts behind its last symbol
-    const unsigned r_first = wg_run[blockIdx.x];
-    const bool one_run = r_first + 1 >= n_runs || runs[r_first + 1].out0 > o_last;
-    if (one_run) {
-        const SymRun r = runs[r_first];
-        const long long idx0 = r.in0 + static_cast<long long>(o0 - r.out0) * sps; // newest item of symbol o0
-        const long long lo_item = idx0 - (arm_size - 1);
-        const unsigned span = (o_last - o0) * sps + arm_size;
-        // tile is stored phase-major: item i lives at (i % sps) * pitch + i / sps, so that for a
-        // fixed tap m the 64 lanes (items sps apart) read consecutive LDS words
-        const unsigned pitch = (256 * sps + arm_size) / sps + 2;
-        unsigned seg = 0;
-        if constexpr (CFC) seg = cfc_find_seg(cfc, lo_item + threadIdx.x);
-        for (unsigned i = threadIdx.x; i < span; i += 256)
-            tile[(i % sps) * pitch + i / sps] = fetch_item<CFC, T>(in, carry, cap, lo_item + i, cfc, seg);
-        // the arm is the same for the whole workgroup: its taps go to LDS (broadcast reads)
-        float* s_arm = reinterpret_cast<float*>(tile + pitch * sps);
-        for (unsigned m = threadIdx.x; m < arm_size; m += 256) s_arm[m] = taps[static_cast<size_t>(r.arm) * arm_size + m];
         __syncthreads();
-        if (o < n_out) {
-            const float* arm = s_arm;
-            // tile index of tap m of this symbol: (o - o0) * sps + j with j = arm_size - 1 - m;
-            // j % sps and j / sps are the same for every thread
-            const unsigned base = o - o0;
-            T acc = zero_item(T{});
-            for (unsigned m = 0; m < arm_size; ++m) {
-                const unsigned j = arm_size - 1 - m;
-                acc = mac(acc, arm[m], tile[(j % sps) * pitch + j / sps + base]);
+        // 2. one lane per checkpoint chunk: the phasor recurrence of the chunk is replayed once
+        //    (kRotChunk-1 steps for kRotChunk items), segment by segment (usually one)
+        const long long lo = p.lo_item < 0 ? 0 : p.lo_item;
+        const long long hi = p.lo_item + span;
+        for (unsigned sg = p.seg; sg < cfc.n_segs; ++sg) {
+            const RotSeg g = cfc.segs[sg];
+            const long long a = max(static_cast<long long>(g.start), lo);
+            const long long b = min(static_cast<long long>(g.start + g.len), hi);
+            if (a < b) {
+                const cf inc = cfc.seg_incr[sg];
+                const unsigned c0 = cfc.seg_counter0[sg];
+                const unsigned long long c_first = static_cast<unsigned long long>(a - g.start) / kRotChunk;
+                const unsigned n_chunks =
+                    static_cast<unsigned>(static_cast<unsigned long long>(b - 1 - g.start) / kRotChunk - c_first) + 1;
+                for (unsigned ch = threadIdx.x; ch < n_chunks; ch += 256) {
+                    const unsigned long long c = c_first + ch;
+                    cf e = cfc.ck[g.ck0 + c];
+                    unsigned counter = c0 + static_cast<unsigned>(c * kRotChunk);
+                    const long long idx0 = static_cast<long long>(g.start + c * kRotChunk);
+#pragma unroll
+                    for (unsigned t = 0; t < kRotChunk; ++t) {
+                        const long long idx = idx0 + t;
+                        if (idx >= a && idx < b) {
+                            const unsigned i = static_cast<unsigned>(idx - p.lo_item);
+                            tile[(i % sps) * pitch + i / sps] = cmul(raw[raw_slot(i)], e); // hpp:87
+                        }
+                        if (t + 1 < kRotChunk) rot_step(e, inc, counter);
+                    }
+                }
             }
-            out[o] = scale_item(r.scale, acc);
+            if (static_cast<long long>(g.start + g.len) >= hi) break;
         }
-        return;
+    } else {
+        for (unsigned i = threadIdx.x; i < span; i += 256)
+            tile[(i % sps) * pitch + i / sps] = item_at(in, carry, cap, p.lo_item + i);
     }
-    if (o >= n_out) return;
-    const SymRun r = runs[find(o)];
-    const long long idx = r.in0 + static_cast<long long>(o - r.out0) * sps;
-    const float* arm = taps + static_cast<size_t>(r.arm) * arm_size;
-    T acc = zero_item(T{});
-    for (unsigned m = 0; m < arm_size; ++m) {
-        unsigned seg = 0;
-        if constexpr (CFC) seg = cfc_find_seg(cfc, idx - m);
-        acc = mac(acc, arm[m], fetch_item<CFC, T>(in, carry, cap, idx - m, cfc, seg));
+    __syncthreads();
+    if (threadIdx.x < p.count) {
+        // tile index of tap m of this symbol: tid * sps + j with j = arm_size - 1 - m;
+        // j % sps and j / sps are the same for every thread
+        T acc = zero_item(T{});
+        for (unsigned m = 0; m < arm_size; ++m) {
+            const unsigned j = arm_size - 1 - m;
+            acc = mac(acc, s_arm[m], tile[(j % sps) * pitch + j / sps + threadIdx.x]);
+        }
+        out[p.o0 + threadIdx.x] = scale_item(p.scale, acc);
     }
-    out[o] = scale_item(r.scale, acc);
 }
 
 template <typename T, bool CFC>
-static void launch_symbol_filter(hipStream_t s, unsigned n_out, size_t smem, unsigned sps, const T* in,
+static void launch_symbol_filter(hipStream_t s, unsigned n_wg, size_t smem, unsigned sps, const T* in,
                                  const T* carry, unsigned cap, const float* taps, unsigned arm_size,
-                                 const SymRun* runs, unsigned n_runs, unsigned* wg_run, T* out, CfcDev cfc)
+                                 const SymRun* runs, unsigned n_runs, SymWg* plan, T* out, CfcDev cfc)
 {
-    const dim3 grid((n_out + 255) / 256), block(256);
-    hipLaunchKernelGGL(k_symf_wg_runs, dim3((grid.x + 255) / 256), dim3(256), 0, s, runs, n_runs, grid.x, wg_run);
+    const dim3 grid(n_wg), block(256);
+    hipLaunchKernelGGL(k_symf_wg_plan, dim3((n_wg + 255) / 256), dim3(256), 0, s, runs, n_runs, n_wg, sps, arm_size,
+                       cfc, plan);
     if (sps == 4)
         hipLaunchKernelGGL((k_symbol_filter<T, 4, CFC>), grid, block, smem, s, in, carry, cap, taps, arm_size, sps,
-                           runs, n_runs, wg_run, n_out, out, cfc);
+                           plan, out, cfc);
     else if (sps == 2)
         hipLaunchKernelGGL((k_symbol_filter<T, 2, CFC>), grid, block, smem, s, in, carry, cap, taps, arm_size, sps,
-                           runs, n_runs, wg_run, n_out, out, cfc);
+                           plan, out, cfc);
     else if (sps == 8)
         hipLaunchKernelGGL((k_symbol_filter<T, 8, CFC>), grid, block, smem, s, in, carry, cap, taps, arm_size, sps,
-                           runs, n_runs, wg_run, n_out, out, cfc);
+                           plan, out, cfc);
     else
         hipLaunchKernelGGL((k_symbol_filter<T, 0, CFC>), grid, block, smem, s, in, carry, cap, taps, arm_size, sps,
-                           runs, n_runs, wg_run, n_out, out, cfc);
+                           plan, out, cfc);
 }
 
 // PfbArbResampler (pfb_arb_resampler.hpp:134-167).  The accumulator recurrence decides which
@@ -1329,7 +1348,7 @@ struct gr4pm_symbol_filter {
     DevBuf<float> taps;
     DevBuf<char> carry[2];
     DevBuf<SymRun> runs;
-    DevBuf<unsigned> wg_run;
+    DevBuf<SymWg> wg_plan;
     int cur = 0;
     // host replica of the tag-driven state (symbol_filter.hpp:44-50)
     size_t clock_phase = 0, reset_clock_phase = 0, pfb_arm = 0;
@@ -1529,31 +1548,35 @@ static gr4pm_status symbol_filter_impl(gr4pm_symbol_filter* h, const void* in, s
     }
     hipStream_t s = h->stream;
     if (!runs.empty()) {
+        unsigned n_wg = 0;
+        for (auto& r : runs) { // workgroups never straddle runs
+            r.wg0 = n_wg;
+            r.pad = 0;
+            n_wg += (r.count + 255u) / 256u;
+        }
         GR4PM_TRY(upload_vec(h->runs, runs, s));
-        const unsigned n_out = static_cast<unsigned>(produced);
         const size_t pitch = (256 * sps + h->arm_size) / sps + 2;
-        const size_t n_wg = (n_out + 255) / 256;
-        if (h->wg_run.n < n_wg) GR4PM_TRY(h->wg_run.alloc(n_wg * 2));
+        if (h->wg_plan.n < n_wg) GR4PM_TRY(h->wg_plan.alloc(static_cast<size_t>(n_wg) * 2));
+        const size_t span_max = 255 * sps + h->arm_size;
+        const size_t arm_bytes = ((h->arm_size + 1) & ~size_t{ 1 }) * sizeof(float);
+        const unsigned n_runs = static_cast<unsigned>(runs.size());
         if (fuse)
-            launch_symbol_filter<cf, true>(s, n_out, pitch * sps * sizeof(cf) + h->arm_size * sizeof(float),
-                                           static_cast<unsigned>(sps), static_cast<const cf*>(in),
-                                           reinterpret_cast<const cf*>(h->carry[h->cur].p), h->cap, h->taps.p,
-                                           static_cast<unsigned>(h->arm_size), h->runs.p,
-                                           static_cast<unsigned>(runs.size()), h->wg_run.p, static_cast<cf*>(out),
-                                           *fuse);
+            launch_symbol_filter<cf, true>(
+                s, n_wg, pitch * sps * sizeof(cf) + arm_bytes + (span_max + span_max / kRotChunk + 2) * sizeof(cf),
+                static_cast<unsigned>(sps), static_cast<const cf*>(in),
+                reinterpret_cast<const cf*>(h->carry[h->cur].p), h->cap, h->taps.p,
+                static_cast<unsigned>(h->arm_size), h->runs.p, n_runs, h->wg_plan.p, static_cast<cf*>(out), *fuse);
         else if (h->item_kind == 0)
-            launch_symbol_filter<cf, false>(s, n_out, pitch * sps * sizeof(cf) + h->arm_size * sizeof(float),
-                                            static_cast<unsigned>(sps), static_cast<const cf*>(in),
+            launch_symbol_filter<cf, false>(s, n_wg, pitch * sps * sizeof(cf) + arm_bytes, static_cast<unsigned>(sps),
+                                            static_cast<const cf*>(in),
                                             reinterpret_cast<const cf*>(h->carry[h->cur].p), h->cap, h->taps.p,
-                                            static_cast<unsigned>(h->arm_size), h->runs.p,
-                                            static_cast<unsigned>(runs.size()), h->wg_run.p, static_cast<cf*>(out),
-                                            CfcDev{});
+                                            static_cast<unsigned>(h->arm_size), h->runs.p, n_runs, h->wg_plan.p,
+                                            static_cast<cf*>(out), CfcDev{});
         else
-            launch_symbol_filter<float, false>(s, n_out, pitch * sps * sizeof(float) + h->arm_size * sizeof(float),
+            launch_symbol_filter<float, false>(s, n_wg, pitch * sps * sizeof(float) + arm_bytes,
                                                static_cast<unsigned>(sps), static_cast<const float*>(in),
                                                reinterpret_cast<const float*>(h->carry[h->cur].p), h->cap, h->taps.p,
-                                               static_cast<unsigned>(h->arm_size), h->runs.p,
-                                               static_cast<unsigned>(runs.size()), h->wg_run.p,
+                                               static_cast<unsigned>(h->arm_size), h->runs.p, n_runs, h->wg_plan.p,
                                                static_cast<float*>(out), CfcDev{});
     }
     if (pos > 0) {
