@@ -149,6 +149,8 @@ def main():
                     help="materialise SyncwordDetection's delayed output instead of reading the ring in place")
     ap.add_argument("--no-scatter", action="store_true",
                     help="N > 1: let every rank generate its own channel instead of the RCCL scatter from rank 0")
+    ap.add_argument("--no-lookahead", action="store_true",
+                    help="do not announce the next window to SyncwordDetection (no correlator look-ahead)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the two halves of the chain back to back on one stream")
     args = ap.parse_args()
@@ -179,14 +181,21 @@ def main():
             input_mode = "rank 0 -> all ranks, torch.distributed scatter (RCCL)"
         except Exception as e:  # keep the benchmark alive: fall back to local generation
             input_mode = f"generated on each GPU (scatter failed: {type(e).__name__})"
-    # the stream lives in a device ring: [the 2T+1 items before the window | the window].  Every
-    # step presents the same window, so the items "before" it are the window's own tail.
+    # the stream lives in a device ring [.. | window A | window B]: two different stretches of the
+    # burst stream that the steps present alternately, each preceded in memory by the 2T+1 items
+    # "before" it (for A: a copy of B's tail, for B: A's tail itself).  While one window is being
+    # processed the detector is told which one comes next (look-ahead of the correlator).
     HIST = 2 * 768 + 1
-    ring = torch.empty(HIST + 1 + n_items, dtype=torch.complex64, device=device)  # +1: keep x 16-byte aligned
-    ring[1:1 + HIST] = x[-HIST:]
-    ring[1 + HIST:] = x
-    x = ring[1 + HIST:]
-    history = ring[1:1 + HIST]
+    xb, n_pkt_b = burst_stream(pkg, n_items, rrc, seed=1001 + rank, device=device)
+    ring = torch.empty(HIST + 1 + 2 * n_items, dtype=torch.complex64, device=device)  # +1: keep A 16-byte aligned
+    ring[1:1 + HIST] = xb[-HIST:]
+    ring[1 + HIST:1 + HIST + n_items] = x
+    ring[1 + HIST + n_items:] = xb
+    del xb
+    x = ring[1 + HIST:1 + HIST + n_items]
+    windows = [(x, ring[1:1 + HIST]),
+               (ring[1 + HIST + n_items:], ring[1 + n_items:1 + HIST + n_items])]
+    n_pkt = max(n_pkt, n_pkt_b)
     rx = pkg.PacketReceiver(SPS, BINS, 9.5, "QPSK", max_items=n_items, pipelined=not args.no_pipeline)
     sd = rx.syncword_detection
     out_keep = None
@@ -200,21 +209,30 @@ def main():
             f = -0.04 + 0.08 * c / max(C - 1, 1)
             xs[c] = x.roll(997 * c) * torch.polar(torch.ones_like(k), (f * k) % (2 * np.pi))
         x = xs
+        windows = [(xs, None), (xs, None)]
         with torch.cuda.stream(rx._streams[0]):
             sd = pkg.SyncwordDetection(rrc, SYNCWORD, bpsk, -BINS, BINS, power_threshold=9.5, n_channels=C,
                                        max_items=n_items)
 
-    def step():
-        nonlocal out_keep
+    step_no = 0
+
+    def step(last=False):
+        """one pass over one window; `last`: no further step follows (no look-ahead launched, so
+        that exactly `steps` correlator launches fall inside the timed region)"""
+        nonlocal out_keep, step_no
+        w, history = windows[step_no % 2]
+        w_next = None if (last or args.no_lookahead) else windows[(step_no + 1) % 2][0]
+        step_no += 1
         if args.detector_only:
             with torch.cuda.stream(rx._streams[0]):
-                st, out, tags, n = sd.process_bulk(x, want_output=True, tags_cap=max(64, 2 * n_pkt + 64))
+                st, out, tags, n = sd.process_bulk(w, want_output=True, tags_cap=max(64, 2 * n_pkt + 64),
+                                                   next_x=w_next)
             out_keep = out
             if args.channels > 1:
                 return n * args.channels, sum(t.size for t in tags)
             return n, tags.size
-        res = rx.process_bulk(x, 1500, tags_cap=max(64, 2 * n_pkt + 64),  # payload length of the generator
-                              history=None if args.copy_delay else history)
+        res = rx.process_bulk(w, 1500, tags_cap=max(64, 2 * n_pkt + 64),  # payload length of the generator
+                              history=None if args.copy_delay else history, next_x=w_next)
         if res is None:  # pipelined: first call has no finished batch yet
             return 0, 0
         out_keep = res["symbols"]
@@ -231,8 +249,8 @@ def main():
             nt += res["tags"].size
         return n, nt
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(last=i == args.warmup - 1)
     drain()
     torch.cuda.synchronize()
     if dist:
@@ -241,8 +259,8 @@ def main():
     t0 = time.perf_counter()
     consumed = 0
     n_tags = 0
-    for _ in range(args.steps):
-        n, nt = step()
+    for i in range(args.steps):
+        n, nt = step(last=i == args.steps - 1)
         consumed += n
         n_tags += nt
     n, nt = drain()  # pipelined: the last batch finishes inside the timed region
@@ -308,7 +326,8 @@ def main():
                                    " on resident burst+AWGN stream",
                        "items_per_step_per_gpu": n_items * args.channels, "channels_per_gpu": args.channels, "freq_bins": 2 * BINS + 1, "tags_per_step": n_tags // max(args.steps, 1),
                        "parallelism": f"channel-per-gpu x{world}", "input": input_mode,
-                       "pipelined_streams": 1 if (args.no_pipeline or args.detector_only) else 3},
+                       "pipelined_streams": 1 if (args.no_pipeline or args.detector_only) else 3,
+                       "windows": 2, "correlator_lookahead": not args.no_lookahead},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

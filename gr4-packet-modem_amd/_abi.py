@@ -104,6 +104,7 @@ EXPORTS = [
     "gr4pm_syncword_detection_self_corr", "gr4pm_syncword_detection_items_consumed",
     "gr4pm_syncword_detection_process", "gr4pm_syncword_detection_last_zpow",
     "gr4pm_syncword_detection_correlate_only",
+    "gr4pm_syncword_detection_hint_next",
     "gr4pm_syncword_detection_filter_create", "gr4pm_syncword_detection_filter_destroy",
     "gr4pm_syncword_detection_filter_reset", "gr4pm_syncword_detection_filter_process",
     "gr4pm_syncword_detection_filter_gate",
@@ -154,6 +155,7 @@ def lib():
     L.gr4pm_syncword_detection_process.argtypes = [vp, vp, sz, sz, vp, sz, szp, vp, sz, vp]
     L.gr4pm_syncword_detection_last_zpow.argtypes = [vp, vp, sz]
     L.gr4pm_syncword_detection_correlate_only.argtypes = [vp, vp, sz, sz]
+    L.gr4pm_syncword_detection_hint_next.argtypes = [vp, vp, sz, sz]
     L.gr4pm_syncword_detection_filter_create.argtypes = [C.POINTER(SdfParams), C.POINTER(vp)]
     L.gr4pm_syncword_detection_filter_destroy.argtypes = [vp]
     L.gr4pm_syncword_detection_filter_destroy.restype = None

@@ -92,15 +92,28 @@ class SyncwordDetection:
     def _items_consumed(self):
         return lib().gr4pm_syncword_detection_items_consumed(self._h)
 
-    def process_bulk(self, x, want_output=True, tags_cap=1024):
+    def reset(self):
+        """back to the state right after start() without rebuilding the templates"""
+        check(lib().gr4pm_syncword_detection_reset(self._h), "SyncwordDetection.reset")
+
+    def process_bulk(self, x, want_output=True, tags_cap=1024, next_x=None):
         """processBulk(), :204-356.  x: [n] or [n_channels, n] complex64 on the GPU.
         Returns (status, out, tags): out holds the n_done published items (delayed input),
-        tags a list (one per channel) of TAG_DTYPE records, index relative to out[0]."""
+        tags a list (one per channel) of TAG_DTYPE records, index relative to out[0].
+        next_x (optional look-ahead): the tensor the NEXT call will be given; its correlator
+        then runs on a second stream behind this call's.  The caller keeps next_x alive and
+        unchanged until that call (a device ring does)."""
         torch = _torch()
         x = _dev_c64(x)
         x2 = x.reshape(1, -1) if x.dim() == 1 else x
         assert x2.shape[0] == self.n_channels
         n_in = x2.shape[1]
+        if next_x is not None:
+            nx = _dev_c64(next_x)
+            nx2 = nx.reshape(1, -1) if nx.dim() == 1 else nx
+            assert nx2.shape[0] == self.n_channels
+            check(lib().gr4pm_syncword_detection_hint_next(self._h, nx2.data_ptr(), nx2.stride(0), nx2.shape[1]),
+                  "SyncwordDetection.hint_next")
         out = torch.empty_like(x2) if want_output else None
         n_done = C.c_size_t(0)
         tags = np.zeros((self.n_channels, tags_cap), dtype=TAG_DTYPE)
@@ -487,11 +500,11 @@ class PacketReceiver:
             self._workers = [concurrent.futures.ThreadPoolExecutor(max_workers=1) for _ in range(2)]
 
     # ---- the three stages
-    def _stage0(self, x, tags_cap, history):
+    def _stage0(self, x, tags_cap, history, next_x=None):
         torch = _torch()
         with torch.cuda.stream(self._streams[0]):
             st, y, det_tags, n = self.syncword_detection.process_bulk(x, want_output=history is None,
-                                                                      tags_cap=tags_cap)
+                                                                      tags_cap=tags_cap, next_x=next_x)
         if history is not None:
             # device-ring input: the delayed stream (hpp:318-319: out[i] = in[i - (2T+1)]) is read in
             # place from the ring instead of being copied
@@ -535,13 +548,14 @@ class PacketReceiver:
     def _stage12(self, fut1):
         return self._stage2(fut1.result())
 
-    def process_bulk(self, x, header_fn=None, tags_cap=4096, history=None):
+    def process_bulk(self, x, header_fn=None, tags_cap=4096, history=None, next_x=None):
         """x: complex64 CUDA tensor.  Returns dict(consumed, symbols, tags, detector_tags):
         symbols = CostasLoop output (one per symbol), tags = symbol-rate tags.  With
         pipelined=True the dict belongs to an earlier batch (None while the pipeline fills).
         history: when x is a window of a device ring buffer, the view of the >= 2T+1 items that
-        precede x in the ring; the chain then reads the delayed stream in place (no copy)."""
-        front = self._stage0(x, tags_cap, history)
+        precede x in the ring; the chain then reads the delayed stream in place (no copy).
+        next_x: the window the next call will present (SyncwordDetection look-ahead)."""
+        front = self._stage0(x, tags_cap, history, next_x)
         if not self.pipelined:
             return self._stage2(self._stage1(*front, header_fn))
         f1 = self._workers[0].submit(self._stage1, *front, header_fn)

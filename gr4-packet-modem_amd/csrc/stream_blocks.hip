@@ -194,26 +194,53 @@ __device__ __forceinline__ void sincos_pi(float x, float* s_out, float* c_out)
     cp = fmaf(cp, r2, -1.388731625493765e-3f);
     cp = fmaf(cp, r2, 4.166664568298827e-2f);
     const float cs = fmaf(cp * r2, r2, fmaf(-0.5f, r2, 1.0f));
-    float sv, cv;
-    switch (k & 3) {
-    case 0: sv = sn; cv = cs; break;
-    case 1: sv = cs; cv = -sn; break;
-    case 2: sv = -sn; cv = -cs; break;
-    default: sv = -cs; cv = sn; break;
-    }
-    *s_out = sv;
-    *c_out = cv;
+    // quadrant fix-up without branches: odd k swaps sin/cos, the signs follow k and k+1
+    const unsigned ku = static_cast<unsigned>(k);
+    const bool swap = (ku & 1u) != 0;
+    const float s0 = swap ? cs : sn;
+    const float c0 = swap ? sn : cs;
+    *s_out = __uint_as_float(__float_as_uint(s0) ^ ((ku & 2u) << 30));
+    *c_out = __uint_as_float(__float_as_uint(c0) ^ (((ku + 1u) & 2u) << 30));
 }
 
-// One lane per segment (the PLL is serial inside a segment).  The critical path is the chain
-// of dependent float operations of one loop iteration (measured: staging the symbols through
-// an LDS tile for coalesced access did not help), so the loads are simply issued 8 ahead.
+// one PLL iteration, costas_loop.hpp:112-146.  Everything is straight-line code (selects, no
+// exec-mask branches): the chain of dependent float operations of one iteration is the whole
+// cost of the block.
+template <int CONSTELLATION>
+__device__ __forceinline__ cf costas_step(cf x, float& phase, float& freq, float k1, float k2)
+{
+    const float pi_f = 3.14159265358979323846f;
+    float sn, cs;
+#ifdef GR4PM_COSTAS_HW_SINCOS
+    sn = __sinf(phase);
+    cs = __cosf(phase);
+#else
+    sincos_pi(phase, &sn, &cs);
+#endif
+    const cf lo = { cs, -sn }; // :114-115
+    const cf z = cmul(x, lo);
+    float error;
+    if constexpr (CONSTELLATION == 0) error = z.y;
+    else if constexpr (CONSTELLATION == 1) error = z.x * z.y;
+    else error = (z.x > 0 ? z.y : -z.y) + (z.y > 0 ? -z.x : z.x);
+    freq += k2 * error;
+    phase += k1 * error + freq;
+    const float down = phase - 2.0f * pi_f, up = phase + 2.0f * pi_f;
+    phase = phase >= pi_f ? down : (phase < -pi_f ? up : phase);
+    return z;
+}
+
+// One lane per segment (the PLL is serial inside a segment).  Lanes walk different segments,
+// so every load instruction touches 64 different cache lines: whole 128-byte lines are loaded
+// with 16-byte instructions, one iteration (16 symbols) ahead of the PLL.
+template <int CONSTELLATION>
 __global__ void k_costas(const CostasSeg* __restrict__ segs, unsigned n_segs,
-                         CostasState* __restrict__ state, float k1, float k2, int constellation,
+                         CostasState* __restrict__ state, float k1, float k2,
                          const cf* __restrict__ in, cf* __restrict__ out, size_t stride)
 {
     const unsigned s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_segs) return;
+    __builtin_amdgcn_s_setprio(3); // a few latency-bound waves among throughput kernels
     const CostasSeg g = segs[s];
     float phase, freq;
     if (g.mode == 0) {
@@ -223,49 +250,51 @@ __global__ void k_costas(const CostasSeg* __restrict__ segs, unsigned n_segs,
         phase = g.phase0;
         freq = 0.0f;
     }
-    const float pi_f = 3.14159265358979323846f;
     const size_t base = static_cast<size_t>(g.channel) * stride + g.start;
-    auto step = [&](cf x) -> cf {
-        float sn, cs;
-#ifdef GR4PM_COSTAS_HW_SINCOS
-        sn = __sinf(phase);
-        cs = __cosf(phase);
-#else
-        sincos_pi(phase, &sn, &cs);
-#endif
-        const cf lo = { cs, -sn }; // costas_loop.hpp:114-115
-        const cf z = cmul(x, lo);
-        float error;
-        if (constellation == 0) error = z.y;
-        else if (constellation == 1) error = z.x * z.y;
-        else error = (z.x > 0 ? z.y : -z.y) + (z.y > 0 ? -z.x : z.x);
-        freq += k2 * error;
-        phase += k1 * error + freq;
-        if (phase >= pi_f) phase -= 2.0f * pi_f;
-        else if (phase < -pi_f) phase += 2.0f * pi_f;
-        return z;
-    };
-    // Lanes walk different segments, so every load instruction touches 64 different cache
-    // lines: use as few (16-byte) instructions as possible and issue them ahead of the PLL.
+    auto step = [&](cf x) -> cf { return costas_step<CONSTELLATION>(x, phase, freq, k1, k2); };
+    constexpr int kV = 8;            // float4 per chunk
+    constexpr unsigned kC = 2 * kV;  // symbols per chunk
     unsigned j = 0;
     if (((base + j) & 1) && j < g.len) { // align to 16 bytes
         out[base + j] = step(in[base + j]);
         ++j;
     }
-    for (; j + 8 <= g.len; j += 8) {
+    // two register sets: while the PLL walks one chunk, the loads of the next one are in flight
+    const unsigned n_chunks = (g.len - j) / kC;
+    if (n_chunks > 0) {
         const float4* ip = reinterpret_cast<const float4*>(in + base + j);
-        float4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = ip[u];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const cf z0 = step(cf{ v[u].x, v[u].y });
-            const cf z1 = step(cf{ v[u].z, v[u].w });
-            v[u] = make_float4(z0.x, z0.y, z1.x, z1.y);
-        }
         float4* op = reinterpret_cast<float4*>(out + base + j);
+        float4 a[kV], b[kV];
+        auto load = [&](float4(&v)[kV], unsigned c) {
+            const float4* p = ip + static_cast<size_t>(min(c, n_chunks - 1)) * kV; // clamped: no branch
 #pragma unroll
-        for (int u = 0; u < 4; ++u) op[u] = v[u];
+            for (int u = 0; u < kV; ++u) v[u] = p[u];
+            // keep the loads up here: hipcc otherwise sinks them to their first use, or lets the
+            // PLL arithmetic overtake them.  The empty asm orders the loads (memory clobber) and
+            // makes the PLL state, where every chain of arithmetic starts, depend on it.
+            asm volatile("" : "+v"(phase), "+v"(freq) : : "memory");
+        };
+        auto run = [&](float4(&v)[kV], unsigned c) {
+#pragma unroll
+            for (int u = 0; u < kV; ++u) {
+                const cf z0 = step(cf{ v[u].x, v[u].y });
+                const cf z1 = step(cf{ v[u].z, v[u].w });
+                v[u] = make_float4(z0.x, z0.y, z1.x, z1.y);
+            }
+            float4* q = op + static_cast<size_t>(c) * kV;
+#pragma unroll
+            for (int u = 0; u < kV; ++u) q[u] = v[u];
+        };
+        load(a, 0);
+        unsigned c = 0;
+        for (; c + 2 <= n_chunks; c += 2) {
+            load(b, c + 1);
+            run(a, c);
+            load(a, c + 2);
+            run(b, c + 1);
+        }
+        if (c < n_chunks) run(a, c);
+        j += n_chunks * kC;
     }
     for (; j < g.len; ++j) out[base + j] = step(in[base + j]);
     if (g.last) {
@@ -942,9 +971,17 @@ gr4pm_status gr4pm_costas_loop_process(gr4pm_costas_loop* h, const gr4pm_c64* in
     }
     hipStream_t s = h->stream;
     GR4PM_TRY(upload_vec(h->segs, segs, s));
-    hipLaunchKernelGGL(k_costas, dim3(grid_for(segs.size(), 64)), dim3(64), 0, s, h->segs.p,
-                       static_cast<unsigned>(segs.size()), h->state.p, h->k1, h->k2, h->constellation,
-                       reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(out), stride);
+    const dim3 grid(grid_for(segs.size(), 64)), block(64);
+    const unsigned n_segs = static_cast<unsigned>(segs.size());
+    if (h->constellation == 0)
+        hipLaunchKernelGGL(k_costas<0>, grid, block, 0, s, h->segs.p, n_segs, h->state.p, h->k1, h->k2,
+                           reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(out), stride);
+    else if (h->constellation == 1)
+        hipLaunchKernelGGL(k_costas<1>, grid, block, 0, s, h->segs.p, n_segs, h->state.p, h->k1, h->k2,
+                           reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(out), stride);
+    else
+        hipLaunchKernelGGL(k_costas<2>, grid, block, 0, s, h->segs.p, n_segs, h->state.p, h->k1, h->k2,
+                           reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(out), stride);
     GR4PM_HIP_TRY(hipGetLastError());
     GR4PM_HIP_TRY(hipStreamSynchronize(s));
     return GR4PM_OK;

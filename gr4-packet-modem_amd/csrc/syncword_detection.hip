@@ -978,6 +978,24 @@ struct gr4pm_syncword_detection {
     uint64_t items_consumed = 0;
     int cur = 0;          // which of carry[]/z[] is current
     size_t last_done = 0; // items of the last call (for the z carry)
+    // look-ahead (gr4pm_syncword_detection_hint_next): the correlator of the NEXT call runs on a
+    // second stream while this call's detector kernels and tag read-back are in flight
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_zcarry = nullptr, ev_corr = nullptr;
+    const gr4pm_c64* hint_in = nullptr; // announced input of the next call
+    size_t hint_stride = 0, hint_n = 0;
+    const gr4pm_c64* pre_in = nullptr;  // input whose powers are (being) written to z[cur ^ 1]
+    size_t pre_stride = 0, pre_n = 0;
+    bool pre_valid = false;
+    ~gr4pm_syncword_detection()
+    {
+        if (stream2) {
+            (void)hipStreamSynchronize(stream2);
+            (void)hipStreamDestroy(stream2);
+        }
+        if (ev_zcarry) (void)hipEventDestroy(ev_zcarry);
+        if (ev_corr) (void)hipEventDestroy(ev_corr);
+    }
 };
 
 namespace {
@@ -987,6 +1005,9 @@ gr4pm_status sd_reset(gr4pm_syncword_detection* h)
     h->items_consumed = 0;
     h->cur = 0;
     h->last_done = 0;
+    if (h->stream2) GR4PM_HIP_TRY(hipStreamSynchronize(h->stream2));
+    h->pre_valid = false;
+    h->hint_in = nullptr;
     for (int i = 0; i < 2; ++i) {
         GR4PM_TRY(h->carry[i].zero(h->stream));
         GR4PM_TRY(h->z[i].zero(h->stream));
@@ -1041,13 +1062,13 @@ void finish_tag(const gr4pm_syncword_detection* h, const RawTag& t, uint64_t out
     o->flags = GR4PM_TAG_SYNCWORD;
 }
 
-gr4pm_status launch_correlate(gr4pm_syncword_detection* h, const gr4pm_c64* in, size_t in_stride,
-                              uint32_t n_blocks, float* zout)
+gr4pm_status launch_correlate(gr4pm_syncword_detection* h, hipStream_t stream, const gr4pm_c64* in,
+                              size_t in_stride, uint32_t n_blocks, float* zout)
 {
     if (h->generic) {
         const uint32_t N = static_cast<uint32_t>(h->fft_size);
         hipLaunchKernelGGL(k_correlate_generic, dim3(n_blocks, static_cast<unsigned>(h->n_channels)), dim3(256),
-                           2 * N * sizeof(cf), h->stream, reinterpret_cast<const cf*>(in), in_stride, n_blocks,
+                           2 * N * sizeof(cf), stream, reinterpret_cast<const cf*>(in), in_stride, n_blocks,
                            static_cast<uint32_t>(h->S), N, h->log2n, h->n_bins, h->g_tmpl.p, h->g_tw.p, zout,
                            h->z_stride);
         GR4PM_HIP_TRY(hipGetLastError());
@@ -1057,7 +1078,7 @@ gr4pm_status launch_correlate(gr4pm_syncword_detection* h, const gr4pm_c64* in, 
     const cf* tw1a = h->tw.p;
     const cf* tw1b = tw1a + kTw1aItems;
     const cf* twA = tw1b + kTw1bItems;
-    hipLaunchKernelGGL(k_correlate, grid, dim3(kCorrThreads), 0, h->stream, reinterpret_cast<const cf*>(in),
+    hipLaunchKernelGGL(k_correlate, grid, dim3(kCorrThreads), 0, stream, reinterpret_cast<const cf*>(in),
                        in_stride, n_blocks, static_cast<uint32_t>(h->S), h->n_bins, h->tmpl.p, tw1a, tw1b,
                        reinterpret_cast<const float4*>(twA), zout, h->z_stride);
     GR4PM_HIP_TRY(hipGetLastError());
@@ -1271,7 +1292,28 @@ gr4pm_status gr4pm_syncword_detection_correlate_only(gr4pm_syncword_detection* h
         return GR4PM_ERR_INVALID;
     }
     const uint32_t n_blocks = static_cast<uint32_t>((n_in - h->fft_size) / h->S + 1);
-    return launch_correlate(h, in, in_stride, n_blocks, h->z[h->cur].p + h->zc);
+    return launch_correlate(h, h->stream, in, in_stride, n_blocks, h->z[h->cur].p + h->zc);
+}
+
+gr4pm_status gr4pm_syncword_detection_hint_next(gr4pm_syncword_detection* h, const gr4pm_c64* in_next,
+                                                size_t in_stride, size_t n_next)
+{
+    if (!h) return GR4PM_ERR_INVALID;
+    if (in_next && !h->stream2) {
+        int least = 0, greatest = 0;
+        GR4PM_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        (void)greatest;
+        // lowest priority: look-ahead work yields to the current call's detector kernels, and a
+        // priority of its own also gives the stream a hardware queue of its own (streams of one
+        // priority share GPU_MAX_HW_QUEUES = 4 queues; a shared queue serialises its kernels)
+        GR4PM_HIP_TRY(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, least));
+        GR4PM_HIP_TRY(hipEventCreateWithFlags(&h->ev_zcarry, hipEventDisableTiming));
+        GR4PM_HIP_TRY(hipEventCreateWithFlags(&h->ev_corr, hipEventDisableTiming));
+    }
+    h->hint_in = in_next;
+    h->hint_stride = in_stride;
+    h->hint_n = n_next;
+    return GR4PM_OK;
 }
 
 gr4pm_status gr4pm_syncword_detection_process(gr4pm_syncword_detection* h, const gr4pm_c64* in,
@@ -1301,7 +1343,29 @@ gr4pm_status gr4pm_syncword_detection_process(gr4pm_syncword_detection* h, const
     // z carry: positions E0-zc .. E0-1
     hipLaunchKernelGGL(k_update_zcarry, dim3((h->zc + 255) / 256, nch), dim3(256), 0, s, h->z[prev].p,
                        zcur, h->z_stride, h->zc, h->last_done);
-    GR4PM_TRY(launch_correlate(h, in, in_stride, n_blocks, zcur + h->zc));
+    // the correlation powers of this input may already be there (or on their way) from the
+    // look-ahead of the previous call; a look-ahead that does not match is waited for and dropped
+    bool have_z = false;
+    if (h->pre_valid) {
+        GR4PM_HIP_TRY(hipStreamWaitEvent(s, h->ev_corr, 0));
+        have_z = h->pre_in == in && h->pre_stride == in_stride && h->pre_n == n_in;
+        h->pre_valid = false;
+    }
+    if (!have_z) GR4PM_TRY(launch_correlate(h, s, in, in_stride, n_blocks, zcur + h->zc));
+    if (h->hint_in && h->hint_n >= h->fft_size && h->hint_n <= h->max_items) {
+        // next call: writes z[prev] behind its carry; the only reader of z[prev] in this call is
+        // k_update_zcarry above
+        GR4PM_HIP_TRY(hipEventRecord(h->ev_zcarry, s));
+        GR4PM_HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_zcarry, 0));
+        const uint32_t nb_next = static_cast<uint32_t>((h->hint_n - h->fft_size) / h->S + 1);
+        GR4PM_TRY(launch_correlate(h, h->stream2, h->hint_in, h->hint_stride, nb_next, h->z[prev].p + h->zc));
+        GR4PM_HIP_TRY(hipEventRecord(h->ev_corr, h->stream2));
+        h->pre_in = h->hint_in;
+        h->pre_stride = h->hint_stride;
+        h->pre_n = h->hint_n;
+        h->pre_valid = true;
+    }
+    h->hint_in = nullptr;
 
     // detector over candidate range [A0, A1)
     const uint64_t A0 = E0 > T ? E0 - T : 0, A1 = E1 > T ? E1 - T : 0;

@@ -110,6 +110,16 @@ gr4pm_status gr4pm_syncword_detection_process(gr4pm_syncword_detection* h, const
                                               size_t in_stride, size_t n_in, gr4pm_c64* out,
                                               size_t out_stride, size_t* n_done, gr4pm_tag* tags,
                                               size_t tags_cap, size_t* n_tags);
+/* Optional look-ahead for callers that own a device ring (no reference counterpart: the
+ * reference's scheduler overlaps blocks across worker threads instead).  Announces the input
+ * of the call AFTER the next process(): that process() then also launches the correlator for
+ * `in_next` on a second stream, where it overlaps the detector kernels and the tag read-back,
+ * and the following process(in_next, in_stride, n_next) finds its correlation powers ready.
+ * The items must not change between the two calls.  A following call with other arguments
+ * simply recomputes; results are identical either way.  in_next == NULL clears the hint. */
+gr4pm_status gr4pm_syncword_detection_hint_next(gr4pm_syncword_detection* h,
+                                                const gr4pm_c64* in_next, size_t in_stride,
+                                                size_t n_next);
 /* debug / measurement: copies the per-sample best-bin correlation power of the last call
  * (device [n_channels][n_done] floats, items_consumed-relative) into `zpow` (device). */
 gr4pm_status gr4pm_syncword_detection_last_zpow(gr4pm_syncword_detection* h, float* zpow,

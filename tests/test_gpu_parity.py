@@ -104,6 +104,64 @@ def test_syncword_detection_streaming_chunks_match_single_call(pkg):
     assert_tags_match(tags, ref_tags[:k])
 
 
+def same_tags(a, b):
+    """field-wise bit equality (the records carry padding bytes)"""
+    return a.size == b.size and all(a[f].tobytes() == b[f].tobytes() for f in a.dtype.names)
+
+
+def test_syncword_detection_lookahead_matches_plain_calls(pkg):
+    """gr4pm_syncword_detection_hint_next: announcing the next input (right, wrong, or with a
+    different length) never changes out/tags; compared chunk by chunk with a plain handle and
+    with the oracle"""
+    locations = [100, 1000, 1250, 10000, 13721, 43124, 58000 - 64]
+    x, rrc = sig.qa_syncword_stream(60000, locations, 0.005, seed=5)
+    ref = orc.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, power_threshold=20.0)
+    _, ref_out, ref_tags = ref.process(x)
+    plain = pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, power_threshold=20.0, max_items=1 << 16)
+    ahead = pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, power_threshold=20.0, max_items=1 << 16)
+    xd = dev(x)
+    S = 2048 - 297 + 1
+    rng = np.random.default_rng(11)
+    # chunk boundaries are known up front (consumed = whole strides, hpp:238)
+    chunks, pos = [], 0
+    while pos + 2048 <= x.size:
+        n_req = min(int(rng.integers(2048, 20000)), x.size - pos)
+        chunks.append((pos, n_req))
+        pos += ((n_req - 2048) // S + 1) * S
+    outs, all_tags = [], []
+    for i, (pos, n_req) in enumerate(chunks):
+        nxt = None
+        if i + 1 < len(chunks):
+            p2, n2 = chunks[i + 1]
+            kind = i % 4
+            if kind == 0 or kind == 1:
+                nxt = xd[p2:p2 + n2]                 # the right announcement
+            elif kind == 2:
+                nxt = xd[p2 + 8:p2 + 8 + n2 - 8]     # a wrong one: dropped, recomputed
+            # kind 3: none
+        st, o, t, n = ahead.process_bulk(xd[pos:pos + n_req], next_x=nxt)
+        st2, o2, t2, n2_ = plain.process_bulk(xd[pos:pos + n_req])
+        assert st == 0 and n == n2_ and n > 0
+        assert np.array_equal(bits(host(o)), bits(host(o2)))
+        assert same_tags(t, t2)
+        t = t.copy()
+        t["index"] += pos
+        outs.append(host(o))
+        all_tags.append(t)
+    out = np.concatenate(outs)
+    tags = np.concatenate(all_tags)
+    assert np.array_equal(bits(out), bits(ref_out[: out.size]))
+    assert tags.size >= 6
+    assert_tags_match(tags, ref_tags[: tags.size])
+    # reset() forgets a pending look-ahead
+    ahead.process_bulk(xd[:8192], next_x=xd[7008:20000])
+    ahead.reset() if hasattr(ahead, "reset") else ahead.start()
+    plain.start()
+    st, o, t, n = ahead.process_bulk(xd[7008:20000])
+    st2, o2, t2, n2_ = plain.process_bulk(xd[7008:20000])
+    assert n == n2_ and np.array_equal(bits(host(o)), bits(host(o2))) and same_tags(t, t2)
+
+
 def test_syncword_detection_awgn_threshold_and_noise_only(pkg):
     """default threshold 9.5, bursts in AWGN: same detections (incl. none on noise) as the oracle"""
     rng = np.random.default_rng(77)
