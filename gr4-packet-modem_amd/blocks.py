@@ -30,6 +30,14 @@ def _stream_handle():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _release(name, h):
+    """destroy a C handle; silent when the interpreter is already tearing the module down"""
+    try:
+        getattr(lib(), name)(h)
+    except Exception:
+        pass
+
+
 def _dev_c64(x, what="in"):
     torch = _torch()
     if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.complex64 and x.is_contiguous()):
@@ -146,7 +154,7 @@ class SyncwordDetection:
 
     def _destroy(self):
         if getattr(self, "_h", None):
-            lib().gr4pm_syncword_detection_destroy(self._h)
+            _release("gr4pm_syncword_detection_destroy", self._h)
             self._h = None
 
     def __del__(self):
@@ -204,9 +212,12 @@ class SyncwordDetectionFilter:
         return acc[: idx.size].astype(bool), used.value
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().gr4pm_syncword_detection_filter_destroy(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                _release("gr4pm_syncword_detection_filter_destroy", self._h)
+                self._h = None
+        except Exception:  # interpreter shutdown
+            pass
 
 
 class _RotatorBase:
@@ -232,9 +243,12 @@ class _RotatorBase:
         return out.reshape(x.shape)
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().gr4pm_rotator_destroy(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                _release("gr4pm_rotator_destroy", self._h)
+                self._h = None
+        except Exception:  # interpreter shutdown
+            pass
 
 
 class Rotator(_RotatorBase):
@@ -293,9 +307,12 @@ class CostasLoop:
         return out.reshape(x.shape)
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().gr4pm_costas_loop_destroy(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                _release("gr4pm_costas_loop_destroy", self._h)
+                self._h = None
+        except Exception:  # interpreter shutdown
+            pass
 
 
 class SyncwordWipeoff:
@@ -317,9 +334,12 @@ class SyncwordWipeoff:
         return out
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().gr4pm_syncword_wipeoff_destroy(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                _release("gr4pm_syncword_wipeoff_destroy", self._h)
+                self._h = None
+        except Exception:  # interpreter shutdown
+            pass
 
 
 def _item_kind(x):
@@ -351,9 +371,12 @@ class InterpolatingFirFilter:
         return out
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().gr4pm_interp_fir_destroy(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                _release("gr4pm_interp_fir_destroy", self._h)
+                self._h = None
+        except Exception:  # interpreter shutdown
+            pass
 
 
 class SymbolFilter:
@@ -387,9 +410,12 @@ class SymbolFilter:
         return out[: prod.value], tout[: nto.value].copy(), cons.value
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().gr4pm_symbol_filter_destroy(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                _release("gr4pm_symbol_filter_destroy", self._h)
+                self._h = None
+        except Exception:  # interpreter shutdown
+            pass
 
 
 def cfc_symbol_filter(cfc, symf, x, tags=None, out_cap=None):
@@ -437,9 +463,12 @@ class PfbArbResampler:
         return out[: prod.value], cons.value
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().gr4pm_pfb_arb_resampler_destroy(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                _release("gr4pm_pfb_arb_resampler_destroy", self._h)
+                self._h = None
+        except Exception:  # interpreter shutdown
+            pass
 
 
 # CCSDS syncword of the modem, packet_receiver.hpp:45-59

@@ -37,10 +37,18 @@ template <typename T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
+    // pinned staging area of upload_staged(): a copy from pageable memory would be staged (or
+    // pinned on the fly) inside the runtime, under locks other host threads' HIP calls wait for
+    T* stage = nullptr;
+    size_t stage_n = 0;
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
-    ~DevBuf() { release(); }
+    ~DevBuf()
+    {
+        release();
+        if (stage) (void)hipHostFree(stage);
+    }
     void release()
     {
         if (p) (void)hipFree(p);
@@ -68,6 +76,28 @@ struct DevBuf {
     gr4pm_status upload(const T* host, size_t count, hipStream_t s)
     {
         GR4PM_HIP_TRY(hipMemcpyAsync(p, host, count * sizeof(T), hipMemcpyHostToDevice, s));
+        return GR4PM_OK;
+    }
+    // per-call tables: through the pinned staging area, truly asynchronous.  The caller
+    // synchronises the stream before the next upload_staged() of this buffer.
+    gr4pm_status upload_staged(const T* host, size_t count, hipStream_t s)
+    {
+        if (count == 0) return GR4PM_OK;
+        if (stage_n < count) {
+            if (stage) (void)hipHostFree(stage);
+            stage = nullptr;
+            stage_n = 0;
+            const size_t want = count * 2;
+            hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&stage), want * sizeof(T), hipHostMallocDefault);
+            if (e != hipSuccess) {
+                stage = nullptr;
+                set_error("hipHostMalloc(%zu bytes) failed: %s", want * sizeof(T), hipGetErrorString(e));
+                return GR4PM_ERR_NOMEM;
+            }
+            stage_n = want;
+        }
+        memcpy(stage, host, count * sizeof(T));
+        GR4PM_HIP_TRY(hipMemcpyAsync(p, stage, count * sizeof(T), hipMemcpyHostToDevice, s));
         return GR4PM_OK;
     }
 };

@@ -647,9 +647,7 @@ template <typename T>
 gr4pm_status upload_vec(DevBuf<T>& buf, const std::vector<T>& v, hipStream_t s)
 {
     if (buf.n < v.size()) GR4PM_TRY(buf.alloc(std::max<size_t>(v.size() * 2, 64)));
-    if (!v.empty())
-        GR4PM_HIP_TRY(hipMemcpyAsync(buf.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
-    return GR4PM_OK;
+    return buf.upload_staged(v.data(), v.size(), s);
 }
 
 unsigned grid_for(size_t n, unsigned block, unsigned cap = 65535u * 16u)

@@ -22,6 +22,7 @@
 // reset happens at p+T+1 (proof in DESIGN.md).  Candidates are a per-item predicate; the
 // scan is a monotone map r -> r' that composes tile by tile.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <complex>
 #include <cstdint>
@@ -871,7 +872,10 @@ __global__ __launch_bounds__(64) void k_compact_pending(ChanState* __restrict__ 
         if (keep) d[w + off] = p;
         w += __popcll(m);
     }
-    if (lane == 0) st[ch].det_cnt = w;
+    if (lane == 0) {
+        st[ch].det_cnt = w;
+        st[ch].rec_cnt = 0; // the host copy of ChanState was queued before this kernel
+    }
 }
 
 // out[i] = item (i - hist) of the stream: the 2T+1 delay of hpp:318-319,342
@@ -971,9 +975,8 @@ struct gr4pm_syncword_detection {
     DevBuf<int32_t> entry;
     DevBuf<ChanState> st;
     DevBuf<unsigned long long> det;
-    DevBuf<RawTag> rec;
     PinnedBuf<ChanState> st_host;
-    PinnedBuf<RawTag> rec_host;
+    PinnedBuf<RawTag> rec_host; // written by k_tags through the device-visible mapping
     // stream position
     uint64_t items_consumed = 0;
     int cur = 0;          // which of carry[]/z[] is current
@@ -1247,7 +1250,6 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
     ok(h->gentry.alloc(static_cast<size_t>(h->max_groups) * h->n_channels));
     ok(h->st.alloc(h->n_channels));
     ok(h->det.alloc(static_cast<size_t>(h->det_cap) * h->n_channels));
-    ok(h->rec.alloc(static_cast<size_t>(h->rec_cap) * h->n_channels));
     ok(h->st_host.alloc(h->n_channels));
     ok(h->rec_host.alloc(static_cast<size_t>(h->rec_cap) * h->n_channels));
     if (s == GR4PM_OK && h->generic) s = h->g_tmpl.upload(g_tmpl.data(), g_tmpl.size(), h->stream);
@@ -1330,6 +1332,11 @@ gr4pm_status gr4pm_syncword_detection_process(gr4pm_syncword_detection* h, const
         set_error("n_in %zu exceeds max_items %zu", n_in, h->max_items);
         return GR4PM_ERR_INVALID;
     }
+#ifdef GR4PM_TIMING
+    static double t_acc[4] = { 0, 0, 0, 0 };
+    static int t_calls = 0;
+    const auto tp0 = std::chrono::steady_clock::now();
+#endif
     const uint32_t n_blocks = static_cast<uint32_t>((n_in - h->fft_size) / h->S + 1); // hpp:238
     const size_t J = static_cast<size_t>(n_blocks) * h->S;
     const uint64_t E0 = h->items_consumed, E1 = E0 + J;
@@ -1401,7 +1408,7 @@ gr4pm_status gr4pm_syncword_detection_process(gr4pm_syncword_detection* h, const
                            static_cast<unsigned long long>(E0), static_cast<unsigned long long>(E1),
                            static_cast<uint32_t>(h->hist), static_cast<uint32_t>(h->S), N, h->log2n, h->n_bins,
                            h->g_tmpl.p, h->g_tw.p, zcur + h->zc, h->z_stride, h->st.p, h->det.p, h->det_cap,
-                           h->rec.p, h->rec_cap);
+                           h->rec_host.p, h->rec_cap);
     } else
     hipLaunchKernelGGL(k_tags, dim3(h->det_cap, nch), dim3(64), 0, s,
                        reinterpret_cast<const cf*>(in),
@@ -1410,7 +1417,7 @@ gr4pm_status gr4pm_syncword_detection_process(gr4pm_syncword_detection* h, const
                        static_cast<uint32_t>(h->hist), static_cast<uint32_t>(h->S), h->n_bins, h->tmpl.p,
                        h->tw.p, h->tw.p + kTw1aItems, h->tw.p + kTw1aItems + kTw1bItems,
                        h->tw.p + kTw1aItems + kTw1bItems + kTwAItems, zcur + h->zc, h->z_stride, h->st.p,
-                       h->det.p, h->det_cap, h->rec.p, h->rec_cap);
+                       h->det.p, h->det_cap, h->rec_host.p, h->rec_cap);
     GR4PM_HIP_TRY(hipMemcpyAsync(h->st_host.p, h->st.p, sizeof(ChanState) * nch, hipMemcpyDeviceToHost, s));
     hipLaunchKernelGGL(k_compact_pending, dim3(nch), dim3(64), 0, s, h->st.p, h->det.p,
                        h->det_cap, static_cast<unsigned long long>(E1), static_cast<uint32_t>(h->hist),
@@ -1425,29 +1432,25 @@ gr4pm_status gr4pm_syncword_detection_process(gr4pm_syncword_detection* h, const
                        reinterpret_cast<const cf*>(in), in_stride, carry, h->carry[cur].p,
                        static_cast<size_t>(h->xc), h->xc, J);
     GR4PM_HIP_TRY(hipGetLastError());
+#ifdef GR4PM_TIMING
+    const auto tp1 = std::chrono::steady_clock::now();
+#endif
     GR4PM_HIP_TRY(hipStreamSynchronize(s));
+#ifdef GR4PM_TIMING
+    const auto tp2 = std::chrono::steady_clock::now();
+#endif
 
-    // collect raw records, finish the tag arithmetic on the host, reset per-call counters
+    // the raw records were written by k_tags straight into pinned host memory (a handful of
+    // 48-byte records per call: no second copy, no second synchronisation); the tag arithmetic
+    // is finished on the host below
     bool overflow = false, any = false;
     for (unsigned c = 0; c < nch; ++c) {
         overflow |= h->st_host.p[c].overflow != 0;
         any |= h->st_host.p[c].rec_cnt != 0;
     }
-    if (any) {
-        for (unsigned c = 0; c < nch; ++c) { // only the records that exist
-            const uint32_t n = std::min(h->st_host.p[c].rec_cnt, h->rec_cap);
-            if (n)
-                GR4PM_HIP_TRY(hipMemcpyAsync(h->rec_host.p + static_cast<size_t>(c) * h->rec_cap,
-                                             h->rec.p + static_cast<size_t>(c) * h->rec_cap, sizeof(RawTag) * n,
-                                             hipMemcpyDeviceToHost, s));
-        }
-        GR4PM_HIP_TRY(hipStreamSynchronize(s));
-        // zero rec_cnt (field offset inside ChanState) for the next call
-        for (unsigned c = 0; c < nch; ++c) {
-            GR4PM_HIP_TRY(hipMemsetAsync(reinterpret_cast<char*>(h->st.p + c) + offsetof(ChanState, rec_cnt),
-                                         0, sizeof(unsigned int), s));
-        }
-    }
+#ifdef GR4PM_TIMING
+    const auto tp3 = std::chrono::steady_clock::now();
+#endif
     h->items_consumed = E1;
     h->cur = cur;
     h->last_done = J;
@@ -1471,6 +1474,19 @@ gr4pm_status gr4pm_syncword_detection_process(gr4pm_syncword_detection* h, const
         }
     }
     if (ret == GR4PM_ERR_OVERFLOW) set_error("tags_cap too small");
+#ifdef GR4PM_TIMING
+    {
+        const auto tp4 = std::chrono::steady_clock::now();
+        auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        t_acc[0] += us(tp0, tp1);
+        t_acc[1] += us(tp1, tp2);
+        t_acc[2] += us(tp2, tp3);
+        t_acc[3] += us(tp3, tp4);
+        if (++t_calls % 8 == 0)
+            fprintf(stderr, "[gr4pm timing] launch %.0f us, sync %.0f us, records %.0f us, finish %.0f us (mean of %d)\n",
+                    t_acc[0] / t_calls, t_acc[1] / t_calls, t_acc[2] / t_calls, t_acc[3] / t_calls, t_calls);
+    }
+#endif
     return ret;
 }
 
