@@ -33,6 +33,24 @@ TAG_DTYPE = np.dtype(
 )
 
 
+# gr4pm_packet_tag: the control tags of the symbol-rate chain behind SyncwordWipeoff
+PKT_SYNCWORD, PKT_HEADER_START, PKT_PAYLOAD = 1, 2, 3
+PACKET_TAG_DTYPE = np.dtype(
+    [
+        ("index", "<u8"),
+        ("kind", "<i4"),
+        ("constellation", "<i4"),
+        ("loop_bandwidth", "<f8"),
+        ("packet_length", "<u8"),
+        ("payload_symbols", "<u8"),
+        ("payload_bits", "<u8"),
+        ("syncword", TAG_DTYPE),
+    ],
+    align=True,
+)
+assert PACKET_TAG_DTYPE.itemsize == 96
+
+
 class SyncwordDetectionParams(C.Structure):
     _fields_ = [
         ("fft_size", C.c_size_t),
@@ -91,6 +109,20 @@ class SymbolFilterParams(C.Structure):
                 ("stream", C.c_void_p)]
 
 
+class PmiParams(C.Structure):
+    _fields_ = [("syncword_size", C.c_size_t), ("header_size", C.c_size_t),
+                ("syncword_costas_loop_bandwidth", C.c_double), ("header_costas_loop_bandwidth", C.c_double),
+                ("payload_costas_loop_bandwidth", C.c_double), ("stream", C.c_void_p)]
+
+
+class SyncwordRemoveParams(C.Structure):
+    _fields_ = [("syncword_size", C.c_size_t), ("stream", C.c_void_p)]
+
+
+class LlrParams(C.Structure):
+    _fields_ = [("noise_sigma", C.c_float), ("constellation", C.c_int), ("stream", C.c_void_p)]
+
+
 class PfbArbParams(C.Structure):
     _fields_ = [("rate", C.c_double), ("rate_is_double", C.c_int), ("taps", C.c_void_p),
                 ("n_taps", C.c_size_t), ("filter_size", C.c_size_t), ("stream", C.c_void_p)]
@@ -120,6 +152,13 @@ EXPORTS = [
     "gr4pm_pfb_arb_resampler_create", "gr4pm_pfb_arb_resampler_destroy", "gr4pm_pfb_arb_resampler_reset",
     "gr4pm_pfb_arb_resampler_process",
     "gr4pm_firdes_root_raised_cosine",
+    "gr4pm_payload_metadata_insert_create", "gr4pm_payload_metadata_insert_destroy",
+    "gr4pm_payload_metadata_insert_reset", "gr4pm_payload_metadata_insert_process",
+    "gr4pm_costas_loop_process_packets",
+    "gr4pm_syncword_remove_create", "gr4pm_syncword_remove_destroy", "gr4pm_syncword_remove_reset",
+    "gr4pm_syncword_remove_process",
+    "gr4pm_constellation_llr_decoder_create", "gr4pm_constellation_llr_decoder_destroy",
+    "gr4pm_constellation_llr_decoder_process",
 ]
 
 _lib = None
@@ -197,6 +236,22 @@ def lib():
     L.gr4pm_pfb_arb_resampler_destroy.restype = None
     L.gr4pm_pfb_arb_resampler_reset.argtypes = [vp]
     L.gr4pm_pfb_arb_resampler_process.argtypes = [vp, vp, sz, vp, sz, szp, szp]
+    L.gr4pm_payload_metadata_insert_create.argtypes = [C.POINTER(PmiParams), C.POINTER(vp)]
+    L.gr4pm_payload_metadata_insert_destroy.argtypes = [vp]
+    L.gr4pm_payload_metadata_insert_destroy.restype = None
+    L.gr4pm_payload_metadata_insert_reset.argtypes = [vp]
+    L.gr4pm_payload_metadata_insert_process.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, sz, vp, sz,
+                                                        szp, szp, szp, szp, szp]
+    L.gr4pm_costas_loop_process_packets.argtypes = [vp, vp, sz, vp, vp, sz]
+    L.gr4pm_syncword_remove_create.argtypes = [C.POINTER(SyncwordRemoveParams), C.POINTER(vp)]
+    L.gr4pm_syncword_remove_destroy.argtypes = [vp]
+    L.gr4pm_syncword_remove_destroy.restype = None
+    L.gr4pm_syncword_remove_reset.argtypes = [vp]
+    L.gr4pm_syncword_remove_process.argtypes = [vp, vp, sz, vp, vp, sz, vp, sz, szp, szp]
+    L.gr4pm_constellation_llr_decoder_create.argtypes = [C.POINTER(LlrParams), C.POINTER(vp)]
+    L.gr4pm_constellation_llr_decoder_destroy.argtypes = [vp]
+    L.gr4pm_constellation_llr_decoder_destroy.restype = None
+    L.gr4pm_constellation_llr_decoder_process.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, sz, szp, szp]
     L.gr4pm_firdes_root_raised_cosine.argtypes = [C.c_double] * 4 + [sz, vp]
     L.gr4pm_firdes_root_raised_cosine.restype = sz
     _lib = L

@@ -13,7 +13,7 @@ import ctypes as C
 import numpy as np
 
 from . import _abi
-from ._abi import TAG_DTYPE, TAG_OTHER, TAG_SYNCWORD, Gr4pmError, check, lib
+from ._abi import PACKET_TAG_DTYPE, TAG_DTYPE, TAG_OTHER, TAG_SYNCWORD, Gr4pmError, check, lib
 
 CONSTELLATIONS = {"PILOT": 0, "BPSK": 1, "QPSK": 2}  # constellation.hpp:6
 
@@ -49,6 +49,23 @@ def _tags_array(tags):
     if tags is None:
         return np.zeros(0, dtype=TAG_DTYPE)
     return np.ascontiguousarray(tags, dtype=TAG_DTYPE)
+
+
+def _ptags_array(tags):
+    if tags is None:
+        return np.zeros(0, dtype=PACKET_TAG_DTYPE)
+    return np.ascontiguousarray(tags, dtype=PACKET_TAG_DTYPE)
+
+
+def _header_msgs(headers):
+    """parsed_header messages: packet_length, or None for an "invalid_header" message"""
+    msgs = np.zeros(max(len(headers), 1), dtype=_abi.HEADER_MSG_DTYPE)
+    for i, h in enumerate(headers):
+        if h is None:
+            msgs[i]["invalid_header"] = 1
+        else:
+            msgs[i]["packet_length"] = int(h)
+    return msgs
 
 
 def _np_ptr(a):
@@ -306,6 +323,18 @@ class CostasLoop:
               "CostasLoop.processBulk")
         return out.reshape(x.shape)
 
+    def process_packets(self, x, tags):
+        """processBulk() behind PayloadMetadataInsert: tags are PACKET_TAG_DTYPE records whose
+        "constellation" / "loop_bandwidth" keys update the settings (:52-88) from the tagged item
+        on and whose syncword_phase sets the phase (:101-106)"""
+        torch = _torch()
+        x = _dev_c64(x)
+        out = torch.empty_like(x)
+        t = _ptags_array(tags)
+        check(lib().gr4pm_costas_loop_process_packets(self._h, x.data_ptr(), x.numel(), out.data_ptr(), _np_ptr(t),
+                                                      t.size), "CostasLoop.processBulk")
+        return out
+
     def __del__(self):
         try:
             if getattr(self, "_h", None):
@@ -337,6 +366,113 @@ class SyncwordWipeoff:
         try:
             if getattr(self, "_h", None):
                 _release("gr4pm_syncword_wipeoff_destroy", self._h)
+                self._h = None
+        except Exception:  # interpreter shutdown
+            pass
+
+
+class PayloadMetadataInsert:
+    """payload_metadata_insert.hpp:12-324"""
+
+    def __init__(self, syncword_size=64, header_size=128, syncword_costas_loop_bandwidth=0.02,
+                 header_costas_loop_bandwidth=0.01, payload_costas_loop_bandwidth=0.005):
+        self.syncword_size, self.header_size = syncword_size, header_size
+        p = _abi.PmiParams(syncword_size, header_size, syncword_costas_loop_bandwidth, header_costas_loop_bandwidth,
+                           payload_costas_loop_bandwidth, _stream_handle())
+        self._h = C.c_void_p()
+        check(lib().gr4pm_payload_metadata_insert_create(C.byref(p), C.byref(self._h)), "PayloadMetadataInsert")
+
+    def start(self):
+        check(lib().gr4pm_payload_metadata_insert_reset(self._h), "PayloadMetadataInsert.start")
+
+    def process_bulk(self, x, tags=None, headers=(), out_cap=None, tags_cap=None):
+        """x: symbols with syncword tags (TAG_DTYPE); headers: the pending parsed_header messages
+        (packet_length, None = invalid header).  Returns dict(out, tags, consumed, headers_used,
+        ignored): consumed < len(x) where the block waits for a header message."""
+        torch = _torch()
+        x = _dev_c64(x)
+        t = _tags_array(tags)
+        out_cap = x.numel() if out_cap is None else out_cap
+        out = torch.empty(max(out_cap, 1), dtype=x.dtype, device=x.device)
+        tags_cap = 3 * t.size + 8 if tags_cap is None else tags_cap
+        tout = np.zeros(tags_cap, dtype=PACKET_TAG_DTYPE)
+        msgs = _header_msgs(headers)
+        v = [C.c_size_t(0) for _ in range(5)]
+        check(lib().gr4pm_payload_metadata_insert_process(
+            self._h, x.data_ptr(), x.numel(), out.data_ptr(), out_cap, _np_ptr(t), t.size, _np_ptr(msgs),
+            len(headers), _np_ptr(tout), tags_cap, *[C.byref(c) for c in v]), "PayloadMetadataInsert.processBulk")
+        n_tags, consumed, produced, used, ignored = [c.value for c in v]
+        return {"out": out[:produced], "tags": tout[:n_tags].copy(), "consumed": consumed, "headers_used": used,
+                "ignored": ignored}
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _release("gr4pm_payload_metadata_insert_destroy", self._h)
+                self._h = None
+        except Exception:  # interpreter shutdown
+            pass
+
+
+class SyncwordRemove:
+    """syncword_remove.hpp:11-112"""
+
+    def __init__(self, syncword_size=64):
+        self.syncword_size = syncword_size
+        p = _abi.SyncwordRemoveParams(syncword_size, _stream_handle())
+        self._h = C.c_void_p()
+        check(lib().gr4pm_syncword_remove_create(C.byref(p), C.byref(self._h)), "SyncwordRemove")
+
+    def process_bulk(self, x, tags=None):
+        torch = _torch()
+        x = _dev_c64(x)
+        t = _ptags_array(tags)
+        out = torch.empty(max(x.numel(), 1), dtype=x.dtype, device=x.device)
+        tout = np.zeros(t.size + 1, dtype=PACKET_TAG_DTYPE)
+        nt, produced = C.c_size_t(0), C.c_size_t(0)
+        check(lib().gr4pm_syncword_remove_process(self._h, x.data_ptr(), x.numel(), out.data_ptr(), _np_ptr(t),
+                                                  t.size, _np_ptr(tout), tout.size, C.byref(nt), C.byref(produced)),
+              "SyncwordRemove.processBulk")
+        return out[: produced.value], tout[: nt.value].copy()
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _release("gr4pm_syncword_remove_destroy", self._h)
+                self._h = None
+        except Exception:  # interpreter shutdown
+            pass
+
+
+class ConstellationLLRDecoder:
+    """constellation_llr_decoder.hpp:13-142"""
+
+    def __init__(self, noise_sigma=1.0, constellation="BPSK"):
+        self.noise_sigma, self.constellation = noise_sigma, constellation
+        if constellation.upper() not in CONSTELLATIONS:
+            raise Gr4pmError(f"unknown constellation {constellation}")
+        p = _abi.LlrParams(noise_sigma, CONSTELLATIONS[constellation.upper()], _stream_handle())
+        self._h = C.c_void_p()
+        check(lib().gr4pm_constellation_llr_decoder_create(C.byref(p), C.byref(self._h)),
+              "ConstellationLLRDecoder")  # PILOT: "constellation not supported", :72-74
+
+    def process_bulk(self, x, tags=None):
+        """returns (llr float32 tensor, tags re-indexed to LLR positions)"""
+        torch = _torch()
+        x = _dev_c64(x)
+        t = _ptags_array(tags)
+        out = torch.empty(max(2 * x.numel(), 1), dtype=torch.float32, device=x.device)
+        tout = np.zeros(t.size + 1, dtype=PACKET_TAG_DTYPE)
+        nt, produced = C.c_size_t(0), C.c_size_t(0)
+        check(lib().gr4pm_constellation_llr_decoder_process(
+            self._h, x.data_ptr(), x.numel(), out.data_ptr(), out.numel(), _np_ptr(t), t.size, _np_ptr(tout),
+            tout.size, C.byref(nt), C.byref(produced)), "ConstellationLLRDecoder.processBulk")
+        return out[: produced.value], tout[: nt.value].copy()
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _release("gr4pm_constellation_llr_decoder_destroy", self._h)
                 self._h = None
         except Exception:  # interpreter shutdown
             pass

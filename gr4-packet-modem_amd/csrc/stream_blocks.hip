@@ -84,7 +84,8 @@ __device__ __forceinline__ void rot_step(cf& e, cf inc, unsigned& counter)
 // serial: one lane per segment, phasor checkpoints every kRotChunk samples.  The chain of
 // dependent complex multiplies is the whole cost, so the loop body is kept to exactly that.
 __global__ void k_rot_checkpoints(const RotSeg* __restrict__ segs, unsigned n_segs,
-                                  RotState* __restrict__ state, cf* __restrict__ ck,
+                                  const RotState* __restrict__ state, RotState* __restrict__ state_next,
+                                  cf* __restrict__ ck,
                                   cf* __restrict__ seg_incr, unsigned* __restrict__ seg_counter0)
 {
     const unsigned s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -128,7 +129,7 @@ __global__ void k_rot_checkpoints(const RotSeg* __restrict__ segs, unsigned n_se
         st.incr = inc;
         st.counter = counter;
         st.pad = 0;
-        state[g.channel] = st;
+        state_next[g.channel] = st; // ping-pong: another lane may still have to read `state`
     }
 }
 
@@ -230,37 +231,23 @@ __device__ __forceinline__ cf costas_step(cf x, float& phase, float& freq, float
     return z;
 }
 
-// One lane per segment (the PLL is serial inside a segment).  Lanes walk different segments,
-// so every load instruction touches 64 different cache lines: whole 128-byte lines are loaded
-// with 16-byte instructions, one iteration (16 symbols) ahead of the PLL.
+// The PLL over `len` items starting at item `base` (one lane).  Lanes walk different
+// segments, so every load instruction touches 64 different cache lines: whole 128-byte
+// lines are loaded with 16-byte instructions, one chunk (16 symbols) ahead of the PLL.
 template <int CONSTELLATION>
-__global__ void k_costas(const CostasSeg* __restrict__ segs, unsigned n_segs,
-                         CostasState* __restrict__ state, float k1, float k2,
-                         const cf* __restrict__ in, cf* __restrict__ out, size_t stride)
+__device__ __forceinline__ void costas_run(const cf* __restrict__ in, cf* __restrict__ out, size_t base,
+                                           unsigned len, float& phase, float& freq, float k1, float k2)
 {
-    const unsigned s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_segs) return;
-    __builtin_amdgcn_s_setprio(3); // a few latency-bound waves among throughput kernels
-    const CostasSeg g = segs[s];
-    float phase, freq;
-    if (g.mode == 0) {
-        phase = state[g.channel].phase;
-        freq = state[g.channel].freq;
-    } else {
-        phase = g.phase0;
-        freq = 0.0f;
-    }
-    const size_t base = static_cast<size_t>(g.channel) * stride + g.start;
     auto step = [&](cf x) -> cf { return costas_step<CONSTELLATION>(x, phase, freq, k1, k2); };
     constexpr int kV = 8;            // float4 per chunk
     constexpr unsigned kC = 2 * kV;  // symbols per chunk
     unsigned j = 0;
-    if (((base + j) & 1) && j < g.len) { // align to 16 bytes
+    if (((base + j) & 1) && j < len) { // align to 16 bytes
         out[base + j] = step(in[base + j]);
         ++j;
     }
     // two register sets: while the PLL walks one chunk, the loads of the next one are in flight
-    const unsigned n_chunks = (g.len - j) / kC;
+    const unsigned n_chunks = (len - j) / kC;
     if (n_chunks > 0) {
         const float4* ip = reinterpret_cast<const float4*>(in + base + j);
         float4* op = reinterpret_cast<float4*>(out + base + j);
@@ -296,10 +283,79 @@ __global__ void k_costas(const CostasSeg* __restrict__ segs, unsigned n_segs,
         if (c < n_chunks) run(a, c);
         j += n_chunks * kC;
     }
-    for (; j < g.len; ++j) out[base + j] = step(in[base + j]);
-    if (g.last) {
-        state[g.channel].phase = phase;
-        state[g.channel].freq = freq;
+    for (; j < len; ++j) out[base + j] = step(in[base + j]);
+}
+
+// One lane per segment (the PLL is serial inside a segment).
+template <int CONSTELLATION>
+__global__ void k_costas(const CostasSeg* __restrict__ segs, unsigned n_segs,
+                         const CostasState* __restrict__ state, CostasState* __restrict__ state_next,
+                         float k1, float k2,
+                         const cf* __restrict__ in, cf* __restrict__ out, size_t stride)
+{
+    const unsigned s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_segs) return;
+    __builtin_amdgcn_s_setprio(3); // a few latency-bound waves among throughput kernels
+    const CostasSeg g = segs[s];
+    float phase, freq;
+    if (g.mode == 0) {
+        phase = state[g.channel].phase;
+        freq = state[g.channel].freq;
+    } else {
+        phase = g.phase0;
+        freq = 0.0f;
+    }
+    costas_run<CONSTELLATION>(in, out, static_cast<size_t>(g.channel) * stride + g.start, g.len, phase, freq, k1,
+                              k2);
+    if (g.last) { // ping-pong: another lane may still have to read `state`
+        state_next[g.channel].phase = phase;
+        state_next[g.channel].freq = freq;
+    }
+}
+
+// Tag-driven settings (gr4pm_costas_loop_process_packets): a chain is the run of items between
+// two set_phase events; it consists of pieces with their own constellation and loop
+// coefficients (syncword: PILOT, header and payload: QPSK with different bandwidths); phase
+// and frequency flow from piece to piece.  One lane per chain.
+struct CostasPiece {
+    unsigned long long start;
+    unsigned len;
+    int constellation;
+    float k1, k2;
+};
+struct CostasChain {
+    unsigned piece0, n_pieces;
+    int mode; // 0 continue from the carried state, 1 set_phase(phase0)
+    int last;
+    float phase0;
+    unsigned pad;
+};
+__global__ void k_costas_chains(const CostasChain* __restrict__ chains, unsigned n_chains,
+                                const CostasPiece* __restrict__ pieces, const CostasState* __restrict__ state,
+                                CostasState* __restrict__ state_next, const cf* __restrict__ in,
+                                cf* __restrict__ out)
+{
+    const unsigned s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_chains) return;
+    __builtin_amdgcn_s_setprio(3);
+    const CostasChain ch = chains[s];
+    float phase, freq;
+    if (ch.mode == 0) {
+        phase = state[0].phase;
+        freq = state[0].freq;
+    } else {
+        phase = ch.phase0;
+        freq = 0.0f;
+    }
+    for (unsigned q = 0; q < ch.n_pieces; ++q) {
+        const CostasPiece pc = pieces[ch.piece0 + q];
+        if (pc.constellation == 0) costas_run<0>(in, out, pc.start, pc.len, phase, freq, pc.k1, pc.k2);
+        else if (pc.constellation == 1) costas_run<1>(in, out, pc.start, pc.len, phase, freq, pc.k1, pc.k2);
+        else costas_run<2>(in, out, pc.start, pc.len, phase, freq, pc.k1, pc.k2);
+    }
+    if (ch.last) {
+        state_next[0].phase = phase;
+        state_next[0].freq = freq;
     }
 }
 
@@ -667,7 +723,8 @@ struct gr4pm_rotator {
     float phase_incr;
     size_t delay, n_channels;
     hipStream_t stream;
-    DevBuf<RotState> state;
+    DevBuf<RotState> state; // [2][n_channels], st_cur selects the current half
+    int st_cur = 0;
     DevBuf<RotSeg> segs;
     DevBuf<cf> ck, seg_incr;
     DevBuf<unsigned> seg_counter0;
@@ -690,6 +747,7 @@ static gr4pm_status rotator_reset_impl(gr4pm_rotator* h)
     GR4PM_HIP_TRY(hipMemcpyAsync(h->state.p, st.data(), st.size() * sizeof(RotState), hipMemcpyHostToDevice,
                                  h->stream));
     GR4PM_HIP_TRY(hipStreamSynchronize(h->stream));
+    h->st_cur = 0;
     h->next_freq.assign(h->n_channels, 0.0f);
     h->next_freq_delay.assign(h->n_channels, 0); // :45 -> set_freq(0) on the first item
     return GR4PM_OK;
@@ -709,7 +767,7 @@ gr4pm_status gr4pm_rotator_create(const gr4pm_rotator_params* p, gr4pm_rotator**
     h->delay = p->delay;
     h->n_channels = p->n_channels;
     h->stream = static_cast<hipStream_t>(p->stream);
-    gr4pm_status s = h->state.alloc(h->n_channels);
+    gr4pm_status s = h->state.alloc(2 * h->n_channels); // ping-pong halves
     if (s == GR4PM_OK) s = rotator_reset_impl(h);
     if (s != GR4PM_OK) {
         delete h;
@@ -808,8 +866,10 @@ static gr4pm_status rotator_plan(gr4pm_rotator* h, size_t n, const gr4pm_tag* ta
         GR4PM_TRY(h->seg_counter0.alloc(n_segs * 2));
     }
     hipLaunchKernelGGL(k_rot_checkpoints, dim3(grid_for(n_segs, 64)), dim3(64), 0, s, h->segs.p, n_segs,
-                       h->state.p, h->ck.p, h->seg_incr.p, h->seg_counter0.p);
+                       h->state.p + h->st_cur * h->n_channels, h->state.p + (h->st_cur ^ 1) * h->n_channels,
+                       h->ck.p, h->seg_incr.p, h->seg_counter0.p);
     GR4PM_HIP_TRY(hipGetLastError());
+    h->st_cur ^= 1;
     return GR4PM_OK;
 }
 
@@ -855,8 +915,11 @@ struct gr4pm_costas_loop {
     float k1, k2;
     size_t n_channels;
     hipStream_t stream;
-    DevBuf<CostasState> state;
+    DevBuf<CostasState> state; // [2][n_channels], st_cur selects the current half
+    int st_cur = 0;
     DevBuf<CostasSeg> segs;
+    DevBuf<CostasChain> chains;
+    DevBuf<CostasPiece> pieces;
 };
 
 static void costas_coeffs(gr4pm_costas_loop* h)
@@ -890,7 +953,7 @@ gr4pm_status gr4pm_costas_loop_create(const gr4pm_costas_loop_params* p, gr4pm_c
     h->n_channels = p->n_channels;
     h->stream = static_cast<hipStream_t>(p->stream);
     costas_coeffs(h);
-    gr4pm_status s = h->state.alloc(h->n_channels);
+    gr4pm_status s = h->state.alloc(2 * h->n_channels); // ping-pong halves
     if (s == GR4PM_OK) s = h->state.zero(h->stream);
     if (s == GR4PM_OK && hipStreamSynchronize(h->stream) != hipSuccess) s = GR4PM_ERR_HIP;
     if (s != GR4PM_OK) {
@@ -911,6 +974,7 @@ gr4pm_status gr4pm_costas_loop_reset(gr4pm_costas_loop* h)
     if (!h) return GR4PM_ERR_INVALID;
     GR4PM_TRY(h->state.zero(h->stream));
     GR4PM_HIP_TRY(hipStreamSynchronize(h->stream));
+    h->st_cur = 0;
     return GR4PM_OK;
 }
 void gr4pm_costas_loop_coeffs(const gr4pm_costas_loop* h, float* k1, float* k2)
@@ -971,15 +1035,94 @@ gr4pm_status gr4pm_costas_loop_process(gr4pm_costas_loop* h, const gr4pm_c64* in
     GR4PM_TRY(upload_vec(h->segs, segs, s));
     const dim3 grid(grid_for(segs.size(), 64)), block(64);
     const unsigned n_segs = static_cast<unsigned>(segs.size());
+    const CostasState* st_in = h->state.p + h->st_cur * h->n_channels;
+    CostasState* st_out = h->state.p + (h->st_cur ^ 1) * h->n_channels;
+    h->st_cur ^= 1;
     if (h->constellation == 0)
-        hipLaunchKernelGGL(k_costas<0>, grid, block, 0, s, h->segs.p, n_segs, h->state.p, h->k1, h->k2,
+        hipLaunchKernelGGL(k_costas<0>, grid, block, 0, s, h->segs.p, n_segs, st_in, st_out, h->k1, h->k2,
                            reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(out), stride);
     else if (h->constellation == 1)
-        hipLaunchKernelGGL(k_costas<1>, grid, block, 0, s, h->segs.p, n_segs, h->state.p, h->k1, h->k2,
+        hipLaunchKernelGGL(k_costas<1>, grid, block, 0, s, h->segs.p, n_segs, st_in, st_out, h->k1, h->k2,
                            reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(out), stride);
     else
-        hipLaunchKernelGGL(k_costas<2>, grid, block, 0, s, h->segs.p, n_segs, h->state.p, h->k1, h->k2,
+        hipLaunchKernelGGL(k_costas<2>, grid, block, 0, s, h->segs.p, n_segs, st_in, st_out, h->k1, h->k2,
                            reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(out), stride);
+    GR4PM_HIP_TRY(hipGetLastError());
+    GR4PM_HIP_TRY(hipStreamSynchronize(s));
+    return GR4PM_OK;
+}
+
+gr4pm_status gr4pm_costas_loop_process_packets(gr4pm_costas_loop* h, const gr4pm_c64* in, size_t n,
+                                               gr4pm_c64* out, const gr4pm_packet_tag* tags, size_t n_tags)
+{
+    if (!h) return GR4PM_ERR_INVALID;
+    if (h->n_channels != 1) {
+        set_error("process_packets needs a single-channel CostasLoop");
+        return GR4PM_ERR_INVALID;
+    }
+    if (n == 0) return GR4PM_OK;
+    if (!in || !out) {
+        set_error("null sample pointer");
+        return GR4PM_ERR_INVALID;
+    }
+    std::vector<CostasChain> chains;
+    std::vector<CostasPiece> pieces;
+    CostasChain cur{};
+    cur.piece0 = 0;
+    cur.mode = 0;
+    size_t pos = 0;
+    auto close_piece = [&](size_t end) {
+        if (end <= pos) return;
+        CostasPiece pc{};
+        pc.start = pos;
+        pc.len = static_cast<unsigned>(end - pos);
+        pc.constellation = h->constellation;
+        pc.k1 = h->k1;
+        pc.k2 = h->k2;
+        pieces.push_back(pc);
+        pos = end;
+    };
+    auto close_chain = [&]() {
+        cur.n_pieces = static_cast<unsigned>(pieces.size()) - cur.piece0;
+        if (cur.n_pieces) chains.push_back(cur);
+        cur = CostasChain{};
+        cur.piece0 = static_cast<unsigned>(pieces.size());
+    };
+    for (size_t t = 0; t < n_tags; ++t) {
+        if (tags[t].index >= n) break;
+        close_piece(static_cast<size_t>(tags[t].index));
+        // keys naming settings are applied before the chunk, then settingsChanged(), :52-88
+        bool changed = false;
+        if (tags[t].constellation >= 0) {
+            if (tags[t].constellation > 2) {
+                set_error("constellation %d", tags[t].constellation);
+                return GR4PM_ERR_INVALID;
+            }
+            h->constellation = tags[t].constellation;
+            changed = true;
+        }
+        if (tags[t].loop_bandwidth >= 0.0) {
+            h->loop_bandwidth = tags[t].loop_bandwidth;
+            changed = true;
+        }
+        if (changed) costas_coeffs(h);
+        if (tags[t].kind == GR4PM_PKT_SYNCWORD && (tags[t].syncword.flags & GR4PM_TAG_SYNCWORD)) { // :101-106
+            close_chain();
+            cur.mode = 1;
+            cur.phase0 = tags[t].syncword.phase;
+        }
+    }
+    close_piece(n);
+    close_chain();
+    if (chains.empty()) return GR4PM_OK;
+    chains.back().last = 1;
+    hipStream_t s = h->stream;
+    GR4PM_TRY(upload_vec(h->chains, chains, s));
+    GR4PM_TRY(upload_vec(h->pieces, pieces, s));
+    hipLaunchKernelGGL(k_costas_chains, dim3(grid_for(chains.size(), 64)), dim3(64), 0, s, h->chains.p,
+                       static_cast<unsigned>(chains.size()), h->pieces.p, h->state.p + h->st_cur,
+                       h->state.p + (h->st_cur ^ 1), reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(out));
+    h->st_cur ^= 1;
     GR4PM_HIP_TRY(hipGetLastError());
     GR4PM_HIP_TRY(hipStreamSynchronize(s));
     return GR4PM_OK;
@@ -1838,6 +1981,440 @@ gr4pm_status gr4pm_pfb_arb_resampler_process(gr4pm_pfb_arb_resampler* h, const g
     h->cur ^= 1;
     *consumed = h->st_host.p->consumed;
     *produced = h->st_host.p->produced;
+    return GR4PM_OK;
+}
+
+} // extern "C"
+
+// =====================================================================================
+// Symbol-rate control blocks behind SyncwordWipeoff (include/gr4pm_hip.h).
+// The per-item work of PayloadMetadataInsert and SyncwordRemove is a gather of item spans;
+// which spans is decided by a host replay of the blocks' state machines over the tags.
+// =====================================================================================
+namespace gr4pm {
+namespace {
+
+struct CopySpan {
+    unsigned long long src, dst, len;
+};
+// grid (x, n_spans): the blocks of a row walk their span with coalesced 8-byte accesses
+__global__ __launch_bounds__(256) void k_gather_spans(const CopySpan* __restrict__ spans, const cf* __restrict__ in,
+                                                      cf* __restrict__ out)
+{
+    const CopySpan sp = spans[blockIdx.y];
+    const cf* src = in + sp.src;
+    cf* dst = out + sp.dst;
+    for (unsigned long long i = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < sp.len;
+         i += static_cast<unsigned long long>(gridDim.x) * blockDim.x)
+        dst[i] = src[i];
+}
+gr4pm_status launch_gather(hipStream_t s, DevBuf<CopySpan>& buf, const std::vector<CopySpan>& spans, const cf* in,
+                           cf* out)
+{
+    if (spans.empty()) return GR4PM_OK;
+    GR4PM_TRY(upload_vec(buf, spans, s));
+    unsigned long long longest = 0;
+    for (const auto& sp : spans) longest = std::max(longest, sp.len);
+    const unsigned gx = static_cast<unsigned>(std::min<unsigned long long>((longest + 2047) / 2048, 1024));
+    for (size_t first = 0; first < spans.size(); first += 65535) { // gridDim.y limit
+        const unsigned rows = static_cast<unsigned>(std::min<size_t>(65535, spans.size() - first));
+        hipLaunchKernelGGL(k_gather_spans, dim3(std::max(gx, 1u), rows), dim3(256), 0, s, buf.p + first, in, out);
+    }
+    GR4PM_HIP_TRY(hipGetLastError());
+    return GR4PM_OK;
+}
+
+// LLR mapping of one run of symbols with one constellation: BPSK scale * re, QPSK
+// (scale * re, scale * im) = a scaled copy of the interleaved floats
+struct LlrRun {
+    unsigned long long in0, out0, n_out;
+    int qpsk;
+    int pad;
+};
+__global__ __launch_bounds__(256) void k_llr(const LlrRun* __restrict__ runs, float scale,
+                                             const float* __restrict__ in, float* __restrict__ out)
+{
+    const LlrRun r = runs[blockIdx.y];
+    const float* src = in + 2 * r.in0;
+    float* dst = out + r.out0;
+    for (unsigned long long i = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < r.n_out;
+         i += static_cast<unsigned long long>(gridDim.x) * blockDim.x)
+        dst[i] = scale * src[r.qpsk ? i : 2 * i]; // constellation_llr_decoder.hpp:106-116
+}
+
+} // namespace
+} // namespace gr4pm
+
+struct gr4pm_payload_metadata_insert {
+    size_t syncword_size, header_size;
+    double syncword_bw, header_bw, payload_bw;
+    hipStream_t stream;
+    bool in_packet = false;     // payload_metadata_insert.hpp:37
+    uint64_t position = 0;      // :38
+    size_t payload_symbols = 0; // :39
+    uint64_t num_packet = 0;    // :40
+    DevBuf<CopySpan> spans;
+};
+struct gr4pm_syncword_remove {
+    size_t syncword_size;
+    hipStream_t stream;
+    bool in_syncword = false; // syncword_remove.hpp:25
+    size_t position = 0;      // :26
+    DevBuf<CopySpan> spans;
+};
+struct gr4pm_constellation_llr_decoder {
+    float noise_sigma, scale;
+    int constellation;
+    hipStream_t stream;
+    DevBuf<LlrRun> runs;
+};
+
+extern "C" {
+
+gr4pm_status gr4pm_payload_metadata_insert_create(const gr4pm_payload_metadata_insert_params* p,
+                                                  gr4pm_payload_metadata_insert** out)
+{
+    if (!p || !out) return GR4PM_ERR_INVALID;
+    *out = nullptr;
+    GR4PM_TRY(require_device());
+    auto* h = new (std::nothrow) gr4pm_payload_metadata_insert;
+    if (!h) return GR4PM_ERR_NOMEM;
+    h->syncword_size = p->syncword_size;
+    h->header_size = p->header_size;
+    h->syncword_bw = p->syncword_costas_loop_bandwidth;
+    h->header_bw = p->header_costas_loop_bandwidth;
+    h->payload_bw = p->payload_costas_loop_bandwidth;
+    h->stream = static_cast<hipStream_t>(p->stream);
+    *out = h;
+    return GR4PM_OK;
+}
+void gr4pm_payload_metadata_insert_destroy(gr4pm_payload_metadata_insert* h)
+{
+    if (!h) return;
+    (void)hipStreamSynchronize(h->stream);
+    delete h;
+}
+gr4pm_status gr4pm_payload_metadata_insert_reset(gr4pm_payload_metadata_insert* h)
+{
+    if (!h) return GR4PM_ERR_INVALID;
+    h->in_packet = false; // start(), :71-75
+    h->position = 0;
+    return GR4PM_OK;
+}
+
+gr4pm_status gr4pm_payload_metadata_insert_process(
+    gr4pm_payload_metadata_insert* h, const gr4pm_c64* in, size_t n_in, gr4pm_c64* out, size_t out_cap,
+    const gr4pm_tag* tags_in, size_t n_tags_in, const gr4pm_header_msg* headers, size_t n_headers,
+    gr4pm_packet_tag* tags_out, size_t tags_cap, size_t* n_tags_out, size_t* consumed, size_t* produced,
+    size_t* headers_used, size_t* ignored_syncwords)
+{
+    if (!h || !n_tags_out || !consumed || !produced || !headers_used || !ignored_syncwords) return GR4PM_ERR_INVALID;
+    *n_tags_out = *consumed = *produced = *headers_used = *ignored_syncwords = 0;
+    if (n_in == 0) return GR4PM_OK;
+    if (!in || !out) {
+        set_error("null sample pointer");
+        return GR4PM_ERR_INVALID;
+    }
+    std::vector<CopySpan> spans;
+    size_t n_pub = 0, hdr = 0, ignored = 0;
+    bool tag_overflow = false;
+    auto publish = [&](const gr4pm_packet_tag& t) {
+        if (tags_out && n_pub < tags_cap) tags_out[n_pub] = t;
+        else tag_overflow = true;
+        ++n_pub;
+    };
+    size_t ipos = 0, opos = 0; // items consumed / produced so far
+    auto pass = [&](size_t want) { // move up to `want` items from the input to the output
+        spans.push_back({ ipos, opos, want });
+        ipos += want;
+        opos += want;
+        h->position += want;
+    };
+    const size_t sw = h->syncword_size, hs = h->header_size;
+    size_t t = 0;
+    bool stop = false;
+    while (ipos < n_in && !stop) {
+        // one processBulk() call: the chunk [ipos, end) with at most one tag, at its head
+        while (t < n_tags_in && tags_in[t].index < ipos) ++t;
+        const bool head_tag = t < n_tags_in && tags_in[t].index == ipos;
+        const bool has_tag = head_tag && (tags_in[t].flags & GR4PM_TAG_SYNCWORD); // syncword_amplitude key
+        size_t end = n_in;
+        if (const size_t u = head_tag ? t + 1 : t; u < n_tags_in) end = std::min<size_t>(end, tags_in[u].index);
+        const size_t chunk0 = ipos;
+        if (has_tag) { // :96-149
+            if (!h->in_packet) {
+                h->in_packet = true;
+                h->position = 0;
+                ++h->num_packet;
+                gr4pm_packet_tag pt{};
+                pt.index = opos;
+                pt.kind = GR4PM_PKT_SYNCWORD;
+                pt.constellation = 0; // the syncword modulation has been wiped off: pure pilot
+                pt.loop_bandwidth = h->syncword_bw;
+                pt.syncword = tags_in[t];
+                publish(pt);
+            } else {
+                ++ignored;
+            }
+        }
+        if (!h->in_packet) { // :150-169
+            ipos = end;
+            if (head_tag) ++t;
+            continue;
+        }
+        while (opos < out_cap && ipos < end) { // :174
+            if (h->position < sw) pass(std::min({ end - ipos, out_cap - opos, static_cast<size_t>(sw - h->position) }));
+            if (h->position == sw) { // :186-194
+                gr4pm_packet_tag pt{};
+                pt.index = opos;
+                pt.kind = GR4PM_PKT_HEADER_START;
+                pt.constellation = 2;
+                pt.loop_bandwidth = h->header_bw;
+                publish(pt);
+            }
+            if (sw <= h->position && h->position < sw + hs)
+                pass(std::min({ end - ipos, out_cap - opos, static_cast<size_t>(sw + hs - h->position) }));
+            if (h->position == sw + hs && opos < out_cap && ipos < end) {
+                if (hdr < n_headers) { // :207-242
+                    if (headers[hdr].invalid_header) {
+                        h->in_packet = false;
+                        ipos = end;
+                        ++hdr;
+                        break;
+                    }
+                    const uint64_t packet_length = headers[hdr].packet_length;
+                    if (packet_length == 0) {
+                        set_error("received packet_length = 0"); // :224-226
+                        return GR4PM_ERR_INVALID;
+                    }
+                    h->payload_symbols = static_cast<size_t>((packet_length + 4) * 4); // + CRC-32, QPSK
+                    gr4pm_packet_tag pt{};
+                    pt.index = opos;
+                    pt.kind = GR4PM_PKT_PAYLOAD;
+                    pt.constellation = -1;
+                    pt.loop_bandwidth = h->payload_bw;
+                    pt.packet_length = packet_length;
+                    pt.payload_symbols = h->payload_symbols;
+                    pt.payload_bits = 2 * static_cast<uint64_t>(h->payload_symbols);
+                    publish(pt);
+                    pass(std::min({ end - ipos, out_cap - opos, h->payload_symbols }));
+                    ++hdr;
+                } else { // :243-247: return and wait for the header
+                    stop = true;
+                    break;
+                }
+            }
+            if (sw + hs < h->position && h->position < sw + hs + h->payload_symbols)
+                pass(std::min({ end - ipos, out_cap - opos,
+                                static_cast<size_t>(sw + hs + h->payload_symbols - h->position) }));
+            if (h->position >= sw + hs + h->payload_symbols) { // :263-267
+                h->in_packet = false;
+                ipos = end;
+            }
+        }
+        if (head_tag && ipos > chunk0) ++t;
+        if (ipos == chunk0) stop = true; // no progress: waiting for a header or output full
+        else if (opos >= out_cap && ipos < end) stop = true;
+    }
+    // spans of length 0 come from the min() above when a stage has nothing to move
+    spans.erase(std::remove_if(spans.begin(), spans.end(), [](const CopySpan& c) { return c.len == 0; }),
+                spans.end());
+    GR4PM_TRY(launch_gather(h->stream, h->spans, spans, reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(out)));
+    GR4PM_HIP_TRY(hipStreamSynchronize(h->stream));
+    *n_tags_out = n_pub;
+    *consumed = ipos;
+    *produced = opos;
+    *headers_used = hdr;
+    *ignored_syncwords = ignored;
+    if (tag_overflow) {
+        set_error("tags_cap too small");
+        return GR4PM_ERR_OVERFLOW;
+    }
+    return GR4PM_OK;
+}
+
+gr4pm_status gr4pm_syncword_remove_create(const gr4pm_syncword_remove_params* p, gr4pm_syncword_remove** out)
+{
+    if (!p || !out) return GR4PM_ERR_INVALID;
+    *out = nullptr;
+    GR4PM_TRY(require_device());
+    auto* h = new (std::nothrow) gr4pm_syncword_remove;
+    if (!h) return GR4PM_ERR_NOMEM;
+    h->syncword_size = p->syncword_size;
+    h->stream = static_cast<hipStream_t>(p->stream);
+    *out = h;
+    return GR4PM_OK;
+}
+void gr4pm_syncword_remove_destroy(gr4pm_syncword_remove* h)
+{
+    if (!h) return;
+    (void)hipStreamSynchronize(h->stream);
+    delete h;
+}
+gr4pm_status gr4pm_syncword_remove_reset(gr4pm_syncword_remove* h)
+{
+    if (!h) return GR4PM_ERR_INVALID;
+    h->in_syncword = false;
+    h->position = 0;
+    return GR4PM_OK;
+}
+gr4pm_status gr4pm_syncword_remove_process(gr4pm_syncword_remove* h, const gr4pm_c64* in, size_t n, gr4pm_c64* out,
+                                           const gr4pm_packet_tag* tags_in, size_t n_tags_in,
+                                           gr4pm_packet_tag* tags_out, size_t tags_cap, size_t* n_tags_out,
+                                           size_t* produced)
+{
+    if (!h || !produced) return GR4PM_ERR_INVALID;
+    *produced = 0;
+    if (n_tags_out) *n_tags_out = 0;
+    if (n == 0) return GR4PM_OK;
+    if (!in || !out) {
+        set_error("null sample pointer");
+        return GR4PM_ERR_INVALID;
+    }
+    std::vector<CopySpan> spans;
+    size_t pos = 0, opos = 0, t = 0, n_pub = 0;
+    bool tag_overflow = false;
+    while (pos < n) {
+        while (t < n_tags_in && tags_in[t].index < pos) ++t;
+        // the tags sitting on the chunk's first item (one merged map in the reference)
+        size_t t1 = t;
+        bool syncword = false;
+        while (t1 < n_tags_in && tags_in[t1].index == pos) syncword |= tags_in[t1++].kind == GR4PM_PKT_SYNCWORD;
+        const size_t end = t1 < n_tags_in ? std::min<size_t>(n, tags_in[t1].index) : n;
+        if (!h->in_syncword && t1 > t) { // :51-64
+            if (syncword) {
+                h->in_syncword = true;
+                h->position = 0;
+            } else {
+                for (size_t u = t; u < t1; ++u) {
+                    if (tags_out && n_pub < tags_cap) {
+                        tags_out[n_pub] = tags_in[u];
+                        tags_out[n_pub].index = opos;
+                    } else {
+                        tag_overflow = true;
+                    }
+                    ++n_pub;
+                }
+            }
+        }
+        size_t from = pos;
+        if (h->in_syncword) { // :67-74
+            const size_t m = std::min(end - pos, h->syncword_size - h->position);
+            from += m;
+            h->position += m;
+            if (h->position >= h->syncword_size) h->in_syncword = false;
+        }
+        if (!h->in_syncword && end > from) { // :76-81
+            spans.push_back({ from, opos, end - from });
+            opos += end - from;
+        }
+        t = t1;
+        pos = end;
+    }
+    GR4PM_TRY(launch_gather(h->stream, h->spans, spans, reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(out)));
+    GR4PM_HIP_TRY(hipStreamSynchronize(h->stream));
+    *produced = opos;
+    if (n_tags_out) *n_tags_out = n_pub;
+    if (tag_overflow) {
+        set_error("tags_cap too small");
+        return GR4PM_ERR_OVERFLOW;
+    }
+    return GR4PM_OK;
+}
+
+gr4pm_status gr4pm_constellation_llr_decoder_create(const gr4pm_constellation_llr_decoder_params* p,
+                                                    gr4pm_constellation_llr_decoder** out)
+{
+    if (!p || !out) return GR4PM_ERR_INVALID;
+    *out = nullptr;
+    if (p->constellation != 1 && p->constellation != 2) { // :72-74
+        set_error("constellation %d not supported", p->constellation);
+        return GR4PM_ERR_INVALID;
+    }
+    GR4PM_TRY(require_device());
+    auto* h = new (std::nothrow) gr4pm_constellation_llr_decoder;
+    if (!h) return GR4PM_ERR_NOMEM;
+    h->noise_sigma = p->noise_sigma;
+    h->scale = 2.0f / (p->noise_sigma * p->noise_sigma); // :77
+    h->constellation = p->constellation;
+    h->stream = static_cast<hipStream_t>(p->stream);
+    *out = h;
+    return GR4PM_OK;
+}
+void gr4pm_constellation_llr_decoder_destroy(gr4pm_constellation_llr_decoder* h)
+{
+    if (!h) return;
+    (void)hipStreamSynchronize(h->stream);
+    delete h;
+}
+gr4pm_status gr4pm_constellation_llr_decoder_process(gr4pm_constellation_llr_decoder* h, const gr4pm_c64* in,
+                                                     size_t n, float* out, size_t out_cap,
+                                                     const gr4pm_packet_tag* tags_in, size_t n_tags_in,
+                                                     gr4pm_packet_tag* tags_out, size_t tags_cap,
+                                                     size_t* n_tags_out, size_t* produced)
+{
+    if (!h || !produced) return GR4PM_ERR_INVALID;
+    *produced = 0;
+    if (n_tags_out) *n_tags_out = 0;
+    if (n == 0) return GR4PM_OK;
+    if (!in || !out) {
+        set_error("null sample pointer");
+        return GR4PM_ERR_INVALID;
+    }
+    std::vector<LlrRun> runs;
+    size_t pos = 0, opos = 0, n_pub = 0;
+    bool tag_overflow = false;
+    auto close_run = [&](size_t end) {
+        if (end <= pos) return;
+        LlrRun r{};
+        r.in0 = pos;
+        r.out0 = opos;
+        r.qpsk = h->constellation == 2;
+        r.n_out = (end - pos) * (r.qpsk ? 2 : 1);
+        runs.push_back(r);
+        opos += r.n_out;
+        pos = end;
+    };
+    for (size_t t = 0; t < n_tags_in; ++t) {
+        if (tags_in[t].index >= n) break;
+        close_run(static_cast<size_t>(tags_in[t].index));
+        if (tags_in[t].constellation >= 0) {
+            if (tags_in[t].constellation != 1 && tags_in[t].constellation != 2) {
+                set_error("constellation %d not supported", tags_in[t].constellation);
+                return GR4PM_ERR_INVALID;
+            }
+            h->constellation = tags_in[t].constellation;
+        }
+        if (tags_out && n_pub < tags_cap) { // :93-99
+            tags_out[n_pub] = tags_in[t];
+            tags_out[n_pub].index = opos;
+        } else {
+            tag_overflow = true;
+        }
+        ++n_pub;
+    }
+    close_run(n);
+    if (opos > out_cap) {
+        set_error("out_cap %zu < %zu LLRs", out_cap, opos);
+        return GR4PM_INSUFFICIENT_OUTPUT_ITEMS;
+    }
+    GR4PM_TRY(upload_vec(h->runs, runs, h->stream));
+    unsigned long long longest = 0;
+    for (const auto& r : runs) longest = std::max(longest, r.n_out);
+    const unsigned gx = static_cast<unsigned>(std::min<unsigned long long>((longest + 2047) / 2048, 1024));
+    for (size_t first = 0; first < runs.size(); first += 65535) {
+        const unsigned rows = static_cast<unsigned>(std::min<size_t>(65535, runs.size() - first));
+        hipLaunchKernelGGL(k_llr, dim3(std::max(gx, 1u), rows), dim3(256), 0, h->stream, h->runs.p + first, h->scale,
+                           reinterpret_cast<const float*>(in), out);
+    }
+    GR4PM_HIP_TRY(hipGetLastError());
+    GR4PM_HIP_TRY(hipStreamSynchronize(h->stream));
+    *produced = opos;
+    if (n_tags_out) *n_tags_out = n_pub;
+    if (tag_overflow) {
+        set_error("tags_cap too small");
+        return GR4PM_ERR_OVERFLOW;
+    }
     return GR4PM_OK;
 }
 

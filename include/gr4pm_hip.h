@@ -308,6 +308,105 @@ gr4pm_status gr4pm_pfb_arb_resampler_process(gr4pm_pfb_arb_resampler* h, const g
                                              size_t n_in, gr4pm_c64* out, size_t out_cap,
                                              size_t* consumed, size_t* produced);
 
+/* ====================================================================================
+ * Symbol-rate control blocks behind SyncwordWipeoff: the immediate
+ * consumers of the path's tags, closing the chain to soft bits on the device.
+ * ================================================================================== */
+
+/* Tags of this part of the chain (payload_metadata_insert.hpp:44-51).  Keys that name a
+ * setting of a downstream block ("constellation", "loop_bandwidth") change that setting from
+ * the tagged item on, like the reference's tag-driven settings. */
+typedef struct {
+    uint64_t index;           /* item index the tag is attached to */
+    int32_t kind;             /* GR4PM_PKT_* */
+    int32_t constellation;    /* "constellation": 0 PILOT, 1 BPSK, 2 QPSK; < 0: key absent */
+    double loop_bandwidth;    /* "loop_bandwidth"; < 0: key absent */
+    uint64_t packet_length;   /* GR4PM_PKT_PAYLOAD: "packet_length" of the parsed header */
+    uint64_t payload_symbols; /* GR4PM_PKT_PAYLOAD: "payload_symbols" */
+    uint64_t payload_bits;    /* GR4PM_PKT_PAYLOAD: "payload_bits" */
+    gr4pm_tag syncword;       /* GR4PM_PKT_SYNCWORD: the syncword_* keys travelling along */
+} gr4pm_packet_tag;
+#define GR4PM_PKT_SYNCWORD 1     /* start of the (wiped-off) syncword, :104-112 */
+#define GR4PM_PKT_HEADER_START 2 /* "header_start", :186-194 */
+#define GR4PM_PKT_PAYLOAD 3      /* parsed header + payload sizes, :222-234 */
+
+/* ------------------------------------------------------------------------------------
+ * PayloadMetadataInsert<c64> -- payload_metadata_insert.hpp:12-324
+ * One call == the processBulk() calls (:77-307) the runtime would make over n_in items, cut at
+ * the syncword tags, with `headers` = the parsed_header messages pending, oldest first.  The
+ * packet symbols are gathered device-to-device; everything between packets is dropped.
+ * Where the reference returns to wait for a header (:243-247) the call stops: *consumed < n_in,
+ * and the caller presents the rest again when the message is there.
+ * ---------------------------------------------------------------------------------- */
+typedef struct gr4pm_payload_metadata_insert gr4pm_payload_metadata_insert;
+typedef struct {
+    size_t syncword_size;                  /* :60 */
+    size_t header_size;                    /* :61 */
+    double syncword_costas_loop_bandwidth; /* :62 */
+    double header_costas_loop_bandwidth;   /* :63 */
+    double payload_costas_loop_bandwidth;  /* :64 */
+    void* stream;
+} gr4pm_payload_metadata_insert_params;
+gr4pm_status gr4pm_payload_metadata_insert_create(const gr4pm_payload_metadata_insert_params* params,
+                                                  gr4pm_payload_metadata_insert** out);
+void gr4pm_payload_metadata_insert_destroy(gr4pm_payload_metadata_insert* h);
+gr4pm_status gr4pm_payload_metadata_insert_reset(gr4pm_payload_metadata_insert* h); /* start(), :71-75 */
+/* tags_in: host, sorted, index relative to in[0]; only GR4PM_TAG_SYNCWORD tags matter.
+ * tags_out: host, index relative to out[0].  *ignored_syncwords: syncwords seen inside a
+ * packet (:126-147, the ignored_syncword messages). */
+gr4pm_status gr4pm_payload_metadata_insert_process(
+    gr4pm_payload_metadata_insert* h, const gr4pm_c64* in, size_t n_in, gr4pm_c64* out, size_t out_cap,
+    const gr4pm_tag* tags_in, size_t n_tags_in, const gr4pm_header_msg* headers, size_t n_headers,
+    gr4pm_packet_tag* tags_out, size_t tags_cap, size_t* n_tags_out, size_t* consumed, size_t* produced,
+    size_t* headers_used, size_t* ignored_syncwords);
+
+/* CostasLoop fed by PayloadMetadataInsert (packet_receiver.hpp wiring): "constellation" and
+ * "loop_bandwidth" keys re-run settingsChanged() (costas_loop.hpp:52-88) from the tagged item
+ * on, GR4PM_PKT_SYNCWORD tags with the syncword_* keys set the phase (:101-106).  The new
+ * settings stay in the handle.  Single channel. */
+gr4pm_status gr4pm_costas_loop_process_packets(gr4pm_costas_loop* h, const gr4pm_c64* in, size_t n,
+                                               gr4pm_c64* out, const gr4pm_packet_tag* tags,
+                                               size_t n_tags);
+
+/* ------------------------------------------------------------------------------------
+ * SyncwordRemove<c64> -- syncword_remove.hpp:11-112
+ * ---------------------------------------------------------------------------------- */
+typedef struct gr4pm_syncword_remove gr4pm_syncword_remove;
+typedef struct {
+    size_t syncword_size; /* :34 */
+    void* stream;
+} gr4pm_syncword_remove_params;
+gr4pm_status gr4pm_syncword_remove_create(const gr4pm_syncword_remove_params* params,
+                                          gr4pm_syncword_remove** out);
+void gr4pm_syncword_remove_destroy(gr4pm_syncword_remove* h);
+gr4pm_status gr4pm_syncword_remove_reset(gr4pm_syncword_remove* h);
+/* out holds n - (dropped syncword items) <= n items; GR4PM_PKT_SYNCWORD tags start a syncword
+ * and are swallowed (:51-58), the others pass, re-indexed (:59-62). */
+gr4pm_status gr4pm_syncword_remove_process(gr4pm_syncword_remove* h, const gr4pm_c64* in, size_t n,
+                                           gr4pm_c64* out, const gr4pm_packet_tag* tags_in,
+                                           size_t n_tags_in, gr4pm_packet_tag* tags_out, size_t tags_cap,
+                                           size_t* n_tags_out, size_t* produced);
+
+/* ------------------------------------------------------------------------------------
+ * ConstellationLLRDecoder<float> -- constellation_llr_decoder.hpp:13-142
+ * ---------------------------------------------------------------------------------- */
+typedef struct gr4pm_constellation_llr_decoder gr4pm_constellation_llr_decoder;
+typedef struct {
+    float noise_sigma; /* :45 */
+    int constellation; /* :46-47: 1 BPSK, 2 QPSK (0 PILOT is rejected like :72-74) */
+    void* stream;
+} gr4pm_constellation_llr_decoder_params;
+gr4pm_status gr4pm_constellation_llr_decoder_create(const gr4pm_constellation_llr_decoder_params* params,
+                                                    gr4pm_constellation_llr_decoder** out);
+void gr4pm_constellation_llr_decoder_destroy(gr4pm_constellation_llr_decoder* h);
+/* out: device floats, out_cap >= 2 n is always enough.  "constellation" keys switch the mapping
+ * from the tagged item on; tags leave at the LLR index of their item (:93-99). */
+gr4pm_status gr4pm_constellation_llr_decoder_process(gr4pm_constellation_llr_decoder* h, const gr4pm_c64* in,
+                                                     size_t n, float* out, size_t out_cap,
+                                                     const gr4pm_packet_tag* tags_in, size_t n_tags_in,
+                                                     gr4pm_packet_tag* tags_out, size_t tags_cap,
+                                                     size_t* n_tags_out, size_t* produced);
+
 /* firdes::root_raised_cosine<float> -- firdes.hpp:29-76 (host helper; out: ntaps|1 floats) */
 size_t gr4pm_firdes_root_raised_cosine(double gain, double sampling_freq, double symbol_rate,
                                        double alpha, size_t ntaps, float* out);

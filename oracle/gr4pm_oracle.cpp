@@ -629,14 +629,14 @@ void orc_rot_process(orc_rot* r, const orc_c64* in_, size_t n, orc_c64* out_)
 struct orc_costas {
     float phase = 0.0f, freq = 0.0f, k1 = 0.0f, k2 = 0.0f;
     int constellation = 1;
+    double loop_bandwidth = 0.01;
 };
-orc_costas* orc_costas_create(double loop_bandwidth, int constellation)
+/* settingsChanged(), :52-88 */
+static void costas_settings_changed(orc_costas* c)
 {
-    auto* c = new orc_costas;
-    c->constellation = constellation;
     double discriminant_gain = 1.0; /* :62-65 */
-    if (constellation == 2) discriminant_gain = 1.41421356237309504880;
-    const double bw = loop_bandwidth;
+    if (c->constellation == 2) discriminant_gain = 1.41421356237309504880;
+    const double bw = c->loop_bandwidth;
     const double bw2 = bw * bw, bw3 = bw2 * bw, bw4 = bw2 * bw2;
     const double s = std::cbrt(36.0 * bw2 +
                                std::sqrt(3.0) * std::sqrt(432.0 * bw4 + 848.0 * bw3 +
@@ -648,6 +648,13 @@ orc_costas* orc_costas_create(double loop_bandwidth, int constellation)
     const double k2 = (1.0 - z) * (1.0 - z);
     c->k1 = static_cast<float>(k1 / discriminant_gain);
     c->k2 = static_cast<float>(k2 / discriminant_gain);
+}
+orc_costas* orc_costas_create(double loop_bandwidth, int constellation)
+{
+    auto* c = new orc_costas;
+    c->constellation = constellation;
+    c->loop_bandwidth = loop_bandwidth;
+    costas_settings_changed(c);
     return c;
 }
 void orc_costas_destroy(orc_costas* c) { delete c; }
@@ -656,6 +663,7 @@ void orc_costas_coeffs(const orc_costas* c, float* k1, float* k2)
     *k1 = c->k1;
     *k2 = c->k2;
 }
+static inline void costas_item(orc_costas* c, const c64* in, c64* out, size_t j);
 void orc_costas_process(orc_costas* c, const orc_c64* in_, size_t n, orc_c64* out_,
                         const uint64_t* tag_index, const float* tag_phase, size_t n_tags)
 {
@@ -669,6 +677,41 @@ void orc_costas_process(orc_costas* c, const orc_c64* in_, size_t n, orc_c64* ou
             c->freq = 0.0f;
             ++t;
         }
+        costas_item(c, in, out, j);
+    }
+}
+void orc_costas_process_packets(orc_costas* c, const orc_c64* in_, size_t n, orc_c64* out_,
+                                const orc_ptag* tags, size_t n_tags)
+{
+    const c64* in = reinterpret_cast<const c64*>(in_);
+    c64* out = reinterpret_cast<c64*>(out_);
+    size_t t = 0;
+    for (size_t j = 0; j < n; ++j) {
+        while (t < n_tags && tags[t].index < j) ++t;
+        for (; t < n_tags && tags[t].index == j; ++t) {
+            /* keys that name settings are applied before the chunk is processed, then
+             * settingsChanged() runs (:52-88) */
+            bool changed = false;
+            if (tags[t].constellation >= 0) {
+                c->constellation = tags[t].constellation;
+                changed = true;
+            }
+            if (tags[t].loop_bandwidth >= 0.0) {
+                c->loop_bandwidth = tags[t].loop_bandwidth;
+                changed = true;
+            }
+            if (changed) costas_settings_changed(c);
+            if (tags[t].kind == 1 && (tags[t].syncword.flags & 1)) { /* :101-106 */
+                c->phase = tags[t].syncword.phase;
+                c->freq = 0.0f;
+            }
+        }
+        costas_item(c, in, out, j);
+    }
+}
+static inline void costas_item(orc_costas* c, const c64* in, c64* out, size_t j)
+{
+    {
         const c64 lo = { std::cos(c->phase), -std::sin(c->phase) }; /* :114-115 */
         const c64 z = cmul(in[j], lo);
         out[j] = z;
@@ -1032,6 +1075,332 @@ size_t orc_arb_process(orc_arb* r, const orc_c64* in_, size_t n, orc_c64* out_, 
         }
     }
     if (consumed) *consumed = ii;
+    return oi;
+}
+
+
+/* --------------------------------------- payload_metadata_insert.hpp:37-307 */
+struct orc_pmi {
+    size_t syncword_size, header_size;
+    double syncword_bw, header_bw, payload_bw;
+    bool in_packet = false;     /* :37 */
+    uint64_t position = 0;      /* :38 */
+    size_t payload_symbols = 0; /* :39 */
+    uint64_t num_packet = 0;    /* :40 */
+};
+orc_pmi* orc_pmi_create(size_t syncword_size, size_t header_size, double syncword_bw,
+                        double header_bw, double payload_bw)
+{
+    auto* p = new orc_pmi;
+    p->syncword_size = syncword_size;
+    p->header_size = header_size;
+    p->syncword_bw = syncword_bw;
+    p->header_bw = header_bw;
+    p->payload_bw = payload_bw;
+    return p;
+}
+void orc_pmi_destroy(orc_pmi* p) { delete p; }
+
+namespace {
+struct PmiIo {
+    const uint64_t* header_packet_length;
+    const uint8_t* header_invalid;
+    size_t n_headers, header_pos = 0;
+    orc_ptag* tags_out;
+    size_t tags_cap, n_tags = 0;
+    size_t ignored = 0;
+    bool overflow = false;
+    void publish(const orc_ptag& t)
+    {
+        if (tags_out && n_tags < tags_cap) tags_out[n_tags] = t;
+        else overflow = true;
+        ++n_tags;
+    }
+};
+/* one processBulk() call, :77-307.  tag: the syncword tag at in[0] or nullptr.  out_base:
+ * absolute index of out[0].  Returns false when the call made no progress because the
+ * header message is missing (the block returns and waits, :243-247). */
+bool pmi_chunk(orc_pmi* p, const c64* in, size_t n_in, c64* out, size_t n_out, uint64_t out_base,
+               const orc_tag* tag, PmiIo& io, size_t* consumed, size_t* produced)
+{
+    *consumed = *produced = 0;
+    if (tag && (tag->flags & 1)) { /* :96-149 */
+        if (!p->in_packet) {
+            p->in_packet = true;
+            p->position = 0;
+            ++p->num_packet;
+            orc_ptag t{};
+            t.index = out_base;
+            t.kind = 1;
+            t.constellation = 0; /* PILOT: the syncword modulation has been wiped off */
+            t.loop_bandwidth = p->syncword_bw;
+            t.syncword = *tag;
+            io.publish(t);
+        } else {
+            ++io.ignored; /* :126-147 (the message itself is only sent when `log` is set) */
+        }
+    }
+    if (!p->in_packet) { /* :150-169: discard all the input */
+        *consumed = n_in;
+        return true;
+    }
+    size_t ii = 0, oi = 0;
+    bool waiting = false;
+    while (oi < n_out && ii < n_in) { /* :174 */
+        if (p->position < p->syncword_size) { /* :175-184 */
+            const size_t n = std::min({ n_in - ii, n_out - oi,
+                                        static_cast<size_t>(p->syncword_size - p->position) });
+            std::copy_n(in + ii, n, out + oi);
+            ii += n;
+            oi += n;
+            p->position += n;
+        }
+        if (p->position == p->syncword_size) { /* :186-194 */
+            orc_ptag t{};
+            t.index = out_base + oi;
+            t.kind = 2;
+            t.constellation = 2; /* QPSK */
+            t.loop_bandwidth = p->header_bw;
+            io.publish(t);
+        }
+        if (p->syncword_size <= p->position && p->position < p->syncword_size + p->header_size) {
+            const size_t n = std::min({ n_in - ii, n_out - oi,
+                                        static_cast<size_t>(p->syncword_size + p->header_size -
+                                                            p->position) });
+            std::copy_n(in + ii, n, out + oi); /* :196-205 */
+            ii += n;
+            oi += n;
+            p->position += n;
+        }
+        if (p->position == p->syncword_size + p->header_size && oi < n_out && ii < n_in) {
+            if (io.header_pos < io.n_headers) { /* :207-242 */
+                const size_t hd = io.header_pos;
+                if (io.header_invalid[hd]) { /* :212-221 */
+                    p->in_packet = false;
+                    ii = n_in;
+                    ++io.header_pos;
+                    break;
+                }
+                const uint64_t packet_length = io.header_packet_length[hd];
+                if (packet_length == 0) return false; /* :224-226 throws */
+                constexpr size_t crc_size_bytes = 4;
+                p->payload_symbols = (packet_length + crc_size_bytes) * 4;
+                orc_ptag t{};
+                t.index = out_base + oi;
+                t.kind = 3;
+                t.constellation = -1;
+                t.loop_bandwidth = p->payload_bw;
+                t.packet_length = packet_length;
+                t.payload_symbols = p->payload_symbols;
+                t.payload_bits = p->payload_symbols * 2;
+                io.publish(t);
+                const size_t n = std::min({ n_in - ii, n_out - oi, p->payload_symbols });
+                std::copy_n(in + ii, n, out + oi);
+                ii += n;
+                oi += n;
+                p->position += n;
+                ++io.header_pos;
+            } else { /* :243-247: wait for the header to be decoded */
+                waiting = true;
+                break;
+            }
+        }
+        if (p->syncword_size + p->header_size < p->position &&
+            p->position < p->syncword_size + p->header_size + p->payload_symbols) { /* :250-261 */
+            const size_t n =
+                std::min({ n_in - ii, n_out - oi,
+                           static_cast<size_t>(p->syncword_size + p->header_size +
+                                               p->payload_symbols - p->position) });
+            std::copy_n(in + ii, n, out + oi);
+            ii += n;
+            oi += n;
+            p->position += n;
+        }
+        if (p->position >= p->syncword_size + p->header_size + p->payload_symbols) { /* :263-267 */
+            p->in_packet = false;
+            ii = n_in;
+        }
+    }
+    *consumed = ii;
+    *produced = oi;
+    return !(waiting && ii == 0);
+}
+} // namespace
+
+int orc_pmi_process(orc_pmi* p, const orc_c64* in_, size_t n_in, orc_c64* out_, size_t out_cap,
+                    const orc_tag* tags_in, size_t n_tags_in, const uint64_t* header_packet_length,
+                    const uint8_t* header_invalid, size_t n_headers, orc_ptag* tags_out,
+                    size_t tags_cap, size_t* n_tags_out, size_t* consumed, size_t* produced,
+                    size_t* headers_used, size_t* ignored_syncwords)
+{
+    const c64* in = reinterpret_cast<const c64*>(in_);
+    c64* out = reinterpret_cast<c64*>(out_);
+    PmiIo io{ header_packet_length, header_invalid, n_headers, 0, tags_out, tags_cap };
+    size_t pos = 0, opos = 0, t = 0;
+    while (pos < n_in) {
+        while (t < n_tags_in && tags_in[t].index < pos) ++t;
+        const bool has_tag = t < n_tags_in && tags_in[t].index == pos;
+        size_t end = n_in;
+        const size_t nt = has_tag ? t + 1 : t;
+        if (nt < n_tags_in && tags_in[nt].index < end) end = tags_in[nt].index;
+        size_t c = 0, q = 0;
+        const bool ok = pmi_chunk(p, in + pos, end - pos, out + opos, out_cap - opos, opos,
+                                  has_tag ? &tags_in[t] : nullptr, io, &c, &q);
+        if (has_tag && (c > 0 || !p->in_packet)) ++t; /* the tag is consumed with its item */
+        pos += c;
+        opos += q;
+        if (!ok || c == 0) break; /* waiting for a header (or output full) */
+    }
+    *n_tags_out = io.n_tags;
+    *consumed = pos;
+    *produced = opos;
+    *headers_used = io.header_pos;
+    *ignored_syncwords = io.ignored;
+    return io.overflow ? -1 : 0;
+}
+
+/* ------------------------------------------------ syncword_remove.hpp:25-105 */
+struct orc_sr {
+    size_t syncword_size;
+    bool in_syncword = false; /* :25 */
+    size_t position = 0;      /* :26 */
+};
+orc_sr* orc_sr_create(size_t syncword_size)
+{
+    auto* r = new orc_sr;
+    r->syncword_size = syncword_size;
+    return r;
+}
+void orc_sr_destroy(orc_sr* r) { delete r; }
+extern "C++" {
+namespace {
+/* one processBulk() call, :39-105; tag_kind: 0 none, 1 syncword_amplitude tag, else other.
+ * Returns the number of items copied to out; *pass_tag = the tag goes out at out[0]. */
+template <typename T>
+size_t sr_chunk(orc_sr* r, const T* in, size_t n, T* out, int tag_kind, bool* pass_tag)
+{
+    *pass_tag = false;
+    if (!r->in_syncword && tag_kind != 0) { /* :51-64 */
+        if (tag_kind == 1) {
+            r->in_syncword = true;
+            r->position = 0;
+        } else {
+            *pass_tag = true;
+        }
+    }
+    size_t ii = 0;
+    if (r->in_syncword) { /* :67-74 */
+        const size_t m = std::min(n, r->syncword_size - r->position);
+        ii += m;
+        r->position += m;
+        if (r->position >= r->syncword_size) r->in_syncword = false;
+    }
+    size_t produced = 0;
+    if (!r->in_syncword) { /* :76-81 */
+        produced = n - ii;
+        std::copy_n(in + ii, produced, out);
+    }
+    return produced;
+}
+} // namespace
+} // extern "C++"
+size_t orc_sr_process(orc_sr* r, const orc_c64* in_, size_t n, orc_c64* out_, const orc_ptag* tags_in,
+                      size_t n_tags_in, orc_ptag* tags_out, size_t tags_cap, size_t* n_tags_out)
+{
+    const c64* in = reinterpret_cast<const c64*>(in_);
+    c64* out = reinterpret_cast<c64*>(out_);
+    size_t pos = 0, opos = 0, t = 0, n_out_tags = 0;
+    while (pos < n) {
+        while (t < n_tags_in && tags_in[t].index < pos) ++t;
+        /* tags on the same item are merged by the runtime into one map: a syncword_amplitude key
+         * anywhere in it makes the chunk a syncword chunk */
+        size_t t1 = t;
+        int kind = 0;
+        while (t1 < n_tags_in && tags_in[t1].index == pos) {
+            if (tags_in[t1].kind == 1) kind = 1;
+            else if (kind == 0) kind = 2;
+            ++t1;
+        }
+        size_t end = n;
+        if (t1 < n_tags_in && tags_in[t1].index < end) end = tags_in[t1].index;
+        bool pass = false;
+        const size_t q = sr_chunk(r, in + pos, end - pos, out + opos, kind, &pass);
+        if (pass) {
+            for (size_t u = t; u < t1; ++u) {
+                if (tags_out && n_out_tags < tags_cap) {
+                    tags_out[n_out_tags] = tags_in[u];
+                    tags_out[n_out_tags].index = opos;
+                }
+                ++n_out_tags;
+            }
+        }
+        t = t1;
+        pos = end;
+        opos += q;
+    }
+    if (n_tags_out) *n_tags_out = n_out_tags;
+    return opos;
+}
+size_t orc_sr_process_int(orc_sr* r, const int* in, size_t n, int* out, const uint64_t* tag_index,
+                          size_t n_tags)
+{
+    size_t pos = 0, opos = 0, t = 0;
+    while (pos < n) {
+        while (t < n_tags && tag_index[t] < pos) ++t;
+        const bool has_tag = t < n_tags && tag_index[t] == pos;
+        size_t end = n;
+        const size_t nt = has_tag ? t + 1 : t;
+        if (nt < n_tags && tag_index[nt] < end) end = tag_index[nt];
+        bool pass = false;
+        opos += sr_chunk(r, in + pos, end - pos, out + opos, has_tag ? 1 : 0, &pass);
+        if (has_tag) ++t;
+        pos = end;
+    }
+    return opos;
+}
+
+/* ------------------------------------- constellation_llr_decoder.hpp:33-134 */
+struct orc_llr {
+    float noise_sigma, scale;
+    int constellation;
+};
+orc_llr* orc_llr_create(float noise_sigma, int constellation)
+{
+    auto* d = new orc_llr;
+    d->noise_sigma = noise_sigma;
+    d->constellation = constellation;
+    d->scale = 2.0f / (noise_sigma * noise_sigma); /* :77 */
+    return d;
+}
+void orc_llr_destroy(orc_llr* d) { delete d; }
+size_t orc_llr_process(orc_llr* d, const orc_c64* in_, size_t n, float* out, const orc_ptag* tags_in,
+                       size_t n_tags_in, orc_ptag* tags_out, size_t tags_cap, size_t* n_tags_out)
+{
+    const c64* in = reinterpret_cast<const c64*>(in_);
+    size_t t = 0, oi = 0, n_out_tags = 0;
+    if (d->constellation != 1 && d->constellation != 2) return static_cast<size_t>(-1); /* :72-74 */
+    for (size_t j = 0; j < n; ++j) {
+        for (; t < n_tags_in && tags_in[t].index <= j; ++t) {
+            if (tags_in[t].index < j) continue;
+            if (tags_in[t].constellation >= 0) { /* "constellation" names a setting, :22-23 */
+                if (tags_in[t].constellation != 1 && tags_in[t].constellation != 2)
+                    return static_cast<size_t>(-1);
+                d->constellation = tags_in[t].constellation;
+            }
+            if (tags_out && n_out_tags < tags_cap) { /* :93-99: out.publishTag(tag.map, 0) */
+                tags_out[n_out_tags] = tags_in[t];
+                tags_out[n_out_tags].index = oi;
+            }
+            ++n_out_tags;
+        }
+        if (d->constellation == 1) { /* :106-110 */
+            out[oi++] = d->scale * in[j].real();
+        } else { /* :111-116 */
+            out[oi++] = d->scale * in[j].real();
+            out[oi++] = d->scale * in[j].imag();
+        }
+    }
+    if (n_tags_out) *n_tags_out = n_out_tags;
     return oi;
 }
 

@@ -149,6 +149,60 @@ void orc_arb_destroy(orc_arb*);
 size_t orc_arb_process(orc_arb*, const orc_c64* in, size_t n, orc_c64* out, size_t out_cap,
                        size_t* consumed);
 
+/* ---- symbol-rate control tags behind SyncwordWipeoff (payload_metadata_insert.hpp:44-51) ----
+ * kind 1: start of syncword ("constellation": PILOT, "loop_bandwidth", + the syncword_* keys)
+ * kind 2: start of header   ("constellation": QPSK, "header_start", "loop_bandwidth")
+ * kind 3: start of payload  (the parsed header + "payload_symbols", "payload_bits",
+ *         "loop_bandwidth"; no "constellation" key)
+ * constellation < 0 / loop_bandwidth < 0: key absent. */
+typedef struct {
+    uint64_t index;
+    int32_t kind;
+    int32_t constellation;
+    double loop_bandwidth;
+    uint64_t packet_length;
+    uint64_t payload_symbols;
+    uint64_t payload_bits;
+    orc_tag syncword;
+} orc_ptag;
+
+/* ---- PayloadMetadataInsert (payload_metadata_insert.hpp:77-307) ----
+ * Whole-stream driver: the stream is cut at the (sorted) syncword tags exactly as the runtime
+ * presents one tag at the head of a chunk; headers = pending parsed_header messages in order.
+ * Stops (consumed < n_in) where the block would wait for a header that is not there. */
+typedef struct orc_pmi orc_pmi;
+orc_pmi* orc_pmi_create(size_t syncword_size, size_t header_size, double syncword_bw,
+                        double header_bw, double payload_bw);
+void orc_pmi_destroy(orc_pmi*);
+int orc_pmi_process(orc_pmi*, const orc_c64* in, size_t n_in, orc_c64* out, size_t out_cap,
+                    const orc_tag* tags_in, size_t n_tags_in, const uint64_t* header_packet_length,
+                    const uint8_t* header_invalid, size_t n_headers, orc_ptag* tags_out,
+                    size_t tags_cap, size_t* n_tags_out, size_t* consumed, size_t* produced,
+                    size_t* headers_used, size_t* ignored_syncwords);
+
+/* ---- CostasLoop driven by the control tags: "constellation" / "loop_bandwidth" update the
+ * settings (costas_loop.hpp:52-88), "syncword_phase" sets the phase (:101-106) ---- */
+void orc_costas_process_packets(orc_costas*, const orc_c64* in, size_t n, orc_c64* out,
+                                const orc_ptag* tags, size_t n_tags);
+
+/* ---- SyncwordRemove (syncword_remove.hpp:39-105): whole-stream driver ---- */
+typedef struct orc_sr orc_sr;
+orc_sr* orc_sr_create(size_t syncword_size);
+void orc_sr_destroy(orc_sr*);
+size_t orc_sr_process(orc_sr*, const orc_c64* in, size_t n, orc_c64* out, const orc_ptag* tags_in,
+                      size_t n_tags_in, orc_ptag* tags_out, size_t tags_cap, size_t* n_tags_out);
+/* the int instantiation test/qa_syncword_remove.cpp uses (tags: kind 1 at tag_index[]) */
+size_t orc_sr_process_int(orc_sr*, const int* in, size_t n, int* out, const uint64_t* tag_index,
+                          size_t n_tags);
+
+/* ---- ConstellationLLRDecoder (constellation_llr_decoder.hpp:55-134); returns LLRs written,
+ * or (size_t)-1 for a constellation the block rejects (:72-74) ---- */
+typedef struct orc_llr orc_llr;
+orc_llr* orc_llr_create(float noise_sigma, int constellation);
+void orc_llr_destroy(orc_llr*);
+size_t orc_llr_process(orc_llr*, const orc_c64* in, size_t n, float* out, const orc_ptag* tags_in,
+                       size_t n_tags_in, orc_ptag* tags_out, size_t tags_cap, size_t* n_tags_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,6 +44,22 @@ TAG_DTYPE = np.dtype(
 )
 assert TAG_DTYPE.itemsize == C.sizeof(OrcTag)
 
+# symbol-rate control tags (orc_ptag == gr4pm_packet_tag): kind 1 syncword / 2 header / 3 payload
+PTAG_DTYPE = np.dtype(
+    [
+        ("index", "<u8"),
+        ("kind", "<i4"),
+        ("constellation", "<i4"),
+        ("loop_bandwidth", "<f8"),
+        ("packet_length", "<u8"),
+        ("payload_symbols", "<u8"),
+        ("payload_bits", "<u8"),
+        ("syncword", TAG_DTYPE),
+    ],
+    align=True,
+)
+assert PTAG_DTYPE.itemsize == 48 + TAG_DTYPE.itemsize
+
 
 def build(force=False):
     src = os.path.join(ORACLE_DIR, "gr4pm_oracle.cpp")
@@ -123,6 +139,24 @@ def lib():
         L.orc_arb_destroy.argtypes = [vp]
         L.orc_arb_process.restype = sz
         L.orc_arb_process.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
+        szp = C.POINTER(sz)
+        L.orc_pmi_create.restype = vp
+        L.orc_pmi_create.argtypes = [sz, sz, C.c_double, C.c_double, C.c_double]
+        L.orc_pmi_destroy.argtypes = [vp]
+        L.orc_pmi_process.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, vp, sz, vp, sz, szp, szp, szp, szp, szp]
+        L.orc_costas_process_packets.argtypes = [vp, vp, sz, vp, vp, sz]
+        L.orc_sr_create.restype = vp
+        L.orc_sr_create.argtypes = [sz]
+        L.orc_sr_destroy.argtypes = [vp]
+        L.orc_sr_process.restype = sz
+        L.orc_sr_process.argtypes = [vp, vp, sz, vp, vp, sz, vp, sz, szp]
+        L.orc_sr_process_int.restype = sz
+        L.orc_sr_process_int.argtypes = [vp, vp, sz, vp, vp, sz]
+        L.orc_llr_create.restype = vp
+        L.orc_llr_create.argtypes = [C.c_float, C.c_int]
+        L.orc_llr_destroy.argtypes = [vp]
+        L.orc_llr_process.restype = sz
+        L.orc_llr_process.argtypes = [vp, vp, sz, vp, vp, sz, vp, sz, szp]
     return _lib
 
 
@@ -275,6 +309,107 @@ def costas_loop(x, constellation="BPSK", loop_bandwidth=0.01, tag_index=(), tag_
     lib().orc_costas_process(h, _p(x), x.size, _p(out), _p(ti), _p(tp), ti.size)
     lib().orc_costas_destroy(h)
     return out
+
+
+class CostasLoop:
+    """stateful CostasLoop driven by control tags (PTAG_DTYPE), costas_loop.hpp:52-148"""
+
+    def __init__(self, loop_bandwidth=0.01, constellation="BPSK"):
+        self._h = lib().orc_costas_create(loop_bandwidth, CONSTELLATIONS[constellation])
+
+    def process(self, x, tags):
+        x = _c64(x)
+        out = np.empty_like(x)
+        tags = np.ascontiguousarray(tags, dtype=PTAG_DTYPE)
+        lib().orc_costas_process_packets(self._h, _p(x), x.size, _p(out), _p(tags), tags.size)
+        return out
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_costas_destroy(self._h)
+            self._h = None
+
+
+class PayloadMetadataInsert:
+    """payload_metadata_insert.hpp:77-307; headers: packet_length per packet, None = invalid"""
+
+    def __init__(self, syncword_size=64, header_size=128, syncword_bw=0.02, header_bw=0.01, payload_bw=0.005):
+        self._h = lib().orc_pmi_create(syncword_size, header_size, syncword_bw, header_bw, payload_bw)
+
+    def process(self, x, tags, headers=(), out_cap=None, tags_cap=None):
+        x = _c64(x)
+        tags = np.ascontiguousarray(tags, dtype=TAG_DTYPE)
+        out_cap = x.size if out_cap is None else out_cap
+        out = np.zeros(max(out_cap, 1), dtype=np.complex64)
+        tags_cap = 3 * tags.size + 8 if tags_cap is None else tags_cap
+        tout = np.zeros(tags_cap, dtype=PTAG_DTYPE)
+        hl = np.array([0 if h is None else int(h) for h in headers], dtype=np.uint64)
+        hi = np.array([1 if h is None else 0 for h in headers], dtype=np.uint8)
+        vals = [C.c_size_t(0) for _ in range(5)]
+        rc = lib().orc_pmi_process(self._h, _p(x), x.size, _p(out), out_cap, _p(tags), tags.size, _p(hl), _p(hi),
+                                   hl.size, _p(tout), tags_cap, *[C.byref(v) for v in vals])
+        n_tags, consumed, produced, used, ignored = [v.value for v in vals]
+        assert rc == 0, "tags_cap too small"
+        return {"out": out[:produced], "tags": tout[:n_tags], "consumed": consumed, "headers_used": used,
+                "ignored": ignored}
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_pmi_destroy(self._h)
+            self._h = None
+
+
+class SyncwordRemove:
+    """syncword_remove.hpp:39-105"""
+
+    def __init__(self, syncword_size=64):
+        self._h = lib().orc_sr_create(syncword_size)
+
+    def process(self, x, tags):
+        x = _c64(x)
+        tags = np.ascontiguousarray(tags, dtype=PTAG_DTYPE)
+        out = np.empty_like(x)
+        tout = np.zeros(tags.size + 1, dtype=PTAG_DTYPE)
+        nt = C.c_size_t(0)
+        n = lib().orc_sr_process(self._h, _p(x), x.size, _p(out), _p(tags), tags.size, _p(tout), tout.size,
+                                 C.byref(nt))
+        return out[:n], tout[: nt.value]
+
+    def process_int(self, x, tag_index):
+        x = np.ascontiguousarray(x, dtype=np.int32)
+        ti = np.ascontiguousarray(tag_index, dtype=np.uint64)
+        out = np.empty_like(x)
+        n = lib().orc_sr_process_int(self._h, _p(x), x.size, _p(out), _p(ti), ti.size)
+        return out[:n]
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_sr_destroy(self._h)
+            self._h = None
+
+
+class ConstellationLLRDecoder:
+    """constellation_llr_decoder.hpp:55-134"""
+
+    def __init__(self, noise_sigma=1.0, constellation="BPSK"):
+        self._h = lib().orc_llr_create(noise_sigma, CONSTELLATIONS[constellation])
+
+    def process(self, x, tags=None):
+        x = _c64(x)
+        tags = np.zeros(0, dtype=PTAG_DTYPE) if tags is None else np.ascontiguousarray(tags, dtype=PTAG_DTYPE)
+        out = np.empty(2 * x.size, dtype=np.float32)
+        tout = np.zeros(tags.size + 1, dtype=PTAG_DTYPE)
+        nt = C.c_size_t(0)
+        n = lib().orc_llr_process(self._h, _p(x), x.size, _p(out), _p(tags), tags.size, _p(tout), tout.size,
+                                  C.byref(nt))
+        if n == C.c_size_t(-1).value:
+            raise ValueError("constellation not supported")
+        return out[:n], tout[: nt.value]
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_llr_destroy(self._h)
+            self._h = None
 
 
 def syncword_wipeoff(x, syncword, tag_index):

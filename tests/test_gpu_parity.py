@@ -809,3 +809,193 @@ def test_fused_cfc_symbol_filter_equals_separate_blocks(pkg):
     z = orc.coarse_frequency_correction(x, tags["index"], tags["freq"], delay=26)
     want, want_tags, _ = orc.symbol_filter(z, pfb, 32, 4, 44, tags=tags.astype(orc.TAG_DTYPE))
     assert np.array_equal(bits(yb), bits(want)) and np.array_equal(tb["index"], want_tags["index"])
+
+
+# ------------------------------------------------------------------ SURVEY 8(f) rank 1:
+# PayloadMetadataInsert, CostasLoop with control tags, SyncwordRemove, ConstellationLLRDecoder
+def _sync_tags(pkg, index, amplitude=0.1, phase=0.0):
+    t = np.zeros(len(index), dtype=pkg.TAG_DTYPE)
+    t["index"], t["amplitude"], t["phase"], t["flags"] = index, amplitude, phase, pkg.TAG_SYNCWORD
+    return t
+
+
+def same_ptags(a, b):
+    """field-wise equality of control tags (records carry padding bytes)"""
+    if a.size != b.size:
+        return False
+    for f in a.dtype.names:
+        if f == "syncword":
+            if not all(a[f][g].tobytes() == b[f][g].tobytes() for g in a[f].dtype.names):
+                return False
+        elif a[f].tobytes() != b[f].tobytes():
+            return False
+    return True
+
+
+def test_payload_metadata_insert_reference_qa(pkg):
+    """test/qa_payload_metadata_insert.cpp:15-157 through the C-ABI, item for item with the oracle"""
+    v = np.arange(100000).astype(np.complex64)
+    tags = _sync_tags(pkg, [12345])
+    r = pkg.PayloadMetadataInsert(64, 128).process_bulk(dev(v), tags)                 # header never arrives
+    assert r["out"].numel() == 192 and np.array_equal(host(r["out"]), v[12345:12345 + 192])
+    assert r["consumed"] == 12345 + 192 and [int(k) for k in r["tags"]["kind"]] == [1, 2]
+    r = pkg.PayloadMetadataInsert(64, 128).process_bulk(dev(v), tags, headers=[100])   # packet_length 100
+    want = orc.PayloadMetadataInsert(64, 128).process(v, tags, headers=[100])
+    assert r["out"].numel() == 192 + 416 and np.array_equal(bits(host(r["out"])), bits(want["out"]))
+    assert same_ptags(r["tags"], want["tags"]) and r["consumed"] == want["consumed"] == v.size
+    pt = r["tags"][2]
+    assert pt["index"] == 192 and pt["payload_bits"] == 832 and pt["payload_symbols"] == 416 and pt["constellation"] < 0
+
+
+def test_payload_metadata_insert_chunks_late_and_invalid_headers(pkg):
+    """random chunking, headers delivered only when the block stalls for them (:243-247), an invalid
+    header (:212-221), a syncword inside a packet (:126-147): GPU == oracle call by call"""
+    rng = np.random.default_rng(21)
+    n = 200000
+    v = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    idx = [1000, 1100, 9000, 20000, 60000, 61000, 150000]
+    tags = _sync_tags(pkg, idx, amplitude=np.linspace(0.1, 0.7, len(idx)), phase=np.linspace(-1, 1, len(idx)))
+    pending = [300, None, 50, 1500, 1]
+    gpu, ref = pkg.PayloadMetadataInsert(64, 128), orc.PayloadMetadataInsert(64, 128)
+    pos, headers, out_g, tags_g, ignored = 0, [], [], [], 0
+    xd = dev(v)
+    while pos < n:
+        m = min(int(rng.integers(1, 30000)), n - pos)
+        tt = tags[(tags["index"] >= pos) & (tags["index"] < pos + m)].copy()
+        tt["index"] -= pos
+        g = gpu.process_bulk(xd[pos:pos + m], tt, headers=headers)
+        w = ref.process(v[pos:pos + m], tt, headers=headers)
+        assert g["consumed"] == w["consumed"] and g["headers_used"] == w["headers_used"] and g["ignored"] == w["ignored"]
+        assert np.array_equal(bits(host(g["out"])), bits(w["out"])) and same_ptags(g["tags"], w["tags"])
+        out_g.append(host(g["out"]))
+        ignored += g["ignored"]
+        headers = headers[g["headers_used"]:]
+        if g["consumed"] == 0 and pending:
+            headers.append(pending.pop(0))
+        elif g["consumed"] == 0:
+            break
+        pos += g["consumed"]
+    assert not pending and ignored >= 1
+    total = np.concatenate(out_g)
+    assert total.size == 192 + 1216 + 192 + 192 + 216 + 192 + 6016 + 192 + 20
+
+
+def test_syncword_remove(pkg):
+    """test/qa_syncword_remove.cpp:13-45 on c64 items + tag handling (syncword_remove.hpp:51-64)"""
+    v = np.arange(1000).astype(np.complex64)
+    tags = np.zeros(3, dtype=pkg.PACKET_TAG_DTYPE)
+    tags["index"], tags["kind"] = [10, 100, 250], pkg.PKT_SYNCWORD
+    out, tout = pkg.SyncwordRemove(64).process_bulk(dev(v), tags)
+    expected = np.delete(v, np.concatenate([np.arange(i, i + 64) for i in [10, 100, 250]]))
+    assert np.array_equal(host(out), expected) and tout.size == 0
+    # with header/payload tags, chunked with carried state, against the oracle
+    rng = np.random.default_rng(4)
+    n = 50000
+    v = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    tags = np.zeros(9, dtype=pkg.PACKET_TAG_DTYPE)
+    tags["index"] = [100, 164, 292, 3000, 3020, 3064, 3192, 40000, 40064]
+    tags["kind"] = [1, 2, 3, 1, 1, 2, 3, 1, 2]
+    tags["payload_symbols"] = np.arange(9)
+    gpu, ref = pkg.SyncwordRemove(64), orc.SyncwordRemove(64)
+    pos = 0
+    for m in [120, 30, 2900, 5, 37000, 9945]:
+        tt = tags[(tags["index"] >= pos) & (tags["index"] < pos + m)].copy()
+        tt["index"] -= pos
+        o, t = gpu.process_bulk(dev(v[pos:pos + m]), tt)
+        wo, wt = ref.process(v[pos:pos + m], tt)
+        assert np.array_equal(bits(host(o)), bits(wo)) and same_ptags(t, wt)
+        pos += m
+    assert pos == n
+
+
+@pytest.mark.parametrize("constellation", ["BPSK", "QPSK"])
+def test_constellation_llr_decoder(pkg, constellation):
+    """test/qa_constellation_llr_decoder.cpp:15-62 (noise_sigma 1 -> scale 2), bit-exact"""
+    rng = np.random.default_rng(3)
+    n = 100000
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    y, tags = pkg.ConstellationLLRDecoder(1.0, constellation).process_bulk(dev(x))
+    y = y.cpu().numpy()
+    if constellation == "BPSK":
+        assert y.size == n and np.array_equal(y, np.float32(2.0) * x.real)
+    else:
+        assert y.size == 2 * n and np.array_equal(y[0::2], np.float32(2) * x.real) and np.array_equal(y[1::2], np.float32(2) * x.imag)
+    assert tags.size == 0
+    want, _ = orc.ConstellationLLRDecoder(1.0, constellation).process(x)
+    assert y.tobytes() == want.tobytes()
+
+
+def test_constellation_llr_decoder_tags_and_pilot(pkg):
+    rng = np.random.default_rng(8)
+    x = (rng.standard_normal(5000) + 1j * rng.standard_normal(5000)).astype(np.complex64)
+    tags = np.zeros(4, dtype=pkg.PACKET_TAG_DTYPE)
+    tags["index"], tags["kind"] = [0, 128, 1000, 1128], [2, 3, 2, 3]
+    tags["constellation"], tags["loop_bandwidth"] = [2, -1, 1, 2], -1.0
+    y, tout = pkg.ConstellationLLRDecoder(0.7, "BPSK").process_bulk(dev(x), tags)
+    wy, wt = orc.ConstellationLLRDecoder(0.7, "BPSK").process(x, tags)
+    assert y.cpu().numpy().tobytes() == wy.tobytes() and same_ptags(tout, wt)
+    assert [int(i) for i in tout["index"]] == [0, 256, 2000, 2128]
+    with pytest.raises(pkg.Gr4pmError):
+        pkg.ConstellationLLRDecoder(1.0, "PILOT")
+
+
+def test_symbol_rate_chain_to_llrs(pkg):
+    """wiped-off symbols -> PayloadMetadataInsert -> CostasLoop (tag-driven PILOT/QPSK and loop
+    bandwidths) -> SyncwordRemove -> ConstellationLLRDecoder, GPU against the oracle chain; the
+    hard decisions of the payload LLRs recover the transmitted bits"""
+    rng = np.random.default_rng(31)
+    lengths = [100, 20, 1500, 7, 400]
+    gap = 300
+    a = np.float32(np.sqrt(0.5))
+    sym, idx, bits_tx, pos = [], [], [], 50
+    stream = [np.zeros(50, np.complex64)]
+    for k, plen in enumerate(lengths):
+        n_sym = 128 + (plen + 4) * 4
+        b = rng.integers(0, 2, (n_sym, 2))
+        q = ((1 - 2 * b[:, 0]) * a + 1j * (1 - 2 * b[:, 1]) * a).astype(np.complex64)
+        pkt = np.concatenate([np.ones(64, np.complex64), q])   # syncword already wiped off: pure pilot
+        ph = rng.uniform(-3, 3)
+        pkt = pkt * np.exp(1j * (ph + 0.003 * (k - 2) * np.arange(pkt.size)))
+        idx.append(pos)
+        bits_tx.append(b)
+        stream.append(pkt.astype(np.complex64))
+        stream.append(np.zeros(gap, np.complex64))
+        pos += pkt.size + gap
+        sym.append(ph)
+    x = np.concatenate(stream)
+    x = (x + sig.awgn(x.size, 0.05, 77)).astype(np.complex64)
+    tags = _sync_tags(pkg, idx, amplitude=1.0, phase=np.array(sym, dtype=np.float32))
+    # oracle chain
+    o1 = orc.PayloadMetadataInsert(64, 128).process(x, tags, headers=lengths)
+    o2 = orc.CostasLoop(0.01, "BPSK").process(o1["out"], o1["tags"])
+    o3, o3t = orc.SyncwordRemove(64).process(o2, o1["tags"])
+    o4, o4t = orc.ConstellationLLRDecoder(0.7, "QPSK").process(o3, o3t)
+    # GPU chain, input in two pieces
+    pmi, cl, sr, dec = (pkg.PayloadMetadataInsert(64, 128), pkg.CostasLoop(0.01, "BPSK"), pkg.SyncwordRemove(64),
+                        pkg.ConstellationLLRDecoder(0.7, "QPSK"))
+    llr, ltags, cut, headers, base = [], [], 5000, list(lengths), 0
+    for lo, hi in [(0, cut), (cut, x.size)]:
+        tt = tags[(tags["index"] >= lo) & (tags["index"] < hi)].copy()
+        tt["index"] -= lo
+        g1 = pmi.process_bulk(dev(x[lo:hi]), tt, headers=headers)
+        assert g1["consumed"] == hi - lo
+        headers = headers[g1["headers_used"]:]
+        g2 = cl.process_packets(g1["out"], g1["tags"])
+        g3, g3t = sr.process_bulk(g2, g1["tags"])
+        g4, g4t = dec.process_bulk(g3, g3t)
+        g4t["index"] += base
+        base += g4.numel()
+        llr.append(g4.cpu().numpy())
+        ltags.append(g4t)
+    llr, ltags = np.concatenate(llr), np.concatenate(ltags)
+    assert llr.size == o4.size == 2 * sum(128 + (p + 4) * 4 for p in lengths)
+    err = np.max(np.abs(llr - o4))
+    print("chain to LLRs: max |gpu - oracle| =", err, "of scale", np.max(np.abs(o4)))
+    assert err < 1e-4                       # 2 / 0.7^2 = 4.08 x the Costas tolerance of 1e-5
+    assert same_ptags(ltags, o4t)
+    # payload bits (LLR > 0 <-> bit 0, constellation_llr_decoder.hpp:24-26)
+    p = 0
+    for b in bits_tx:
+        hard = (llr[p:p + 2 * b.shape[0]] < 0).astype(int).reshape(-1, 2)
+        assert np.array_equal(hard[64:], b[64:])   # the loop has settled after the first symbols
+        p += 2 * b.shape[0]
