@@ -151,6 +151,9 @@ def main():
                     help="N > 1: let every rank generate its own channel instead of the RCCL scatter from rank 0")
     ap.add_argument("--no-lookahead", action="store_true",
                     help="do not announce the next window to SyncwordDetection (no correlator look-ahead)")
+    ap.add_argument("--soft-bits", action="store_true",
+                    help="continue the chain to LLRs: PayloadMetadataInsert -> tag-driven CostasLoop -> "
+                         "SyncwordRemove -> ConstellationLLRDecoder (SURVEY.md 8(f) rank 1; not the headline workload)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the two halves of the chain back to back on one stream")
     args = ap.parse_args()
@@ -196,7 +199,8 @@ def main():
     windows = [(x, ring[1:1 + HIST]),
                (ring[1 + HIST + n_items:], ring[1 + n_items:1 + HIST + n_items])]
     n_pkt = max(n_pkt, n_pkt_b)
-    rx = pkg.PacketReceiver(SPS, BINS, 9.5, "QPSK", max_items=n_items, pipelined=not args.no_pipeline)
+    rx = pkg.PacketReceiver(SPS, BINS, 9.5, "QPSK", max_items=n_items, pipelined=not args.no_pipeline,
+                            soft_bits=args.soft_bits)
     sd = rx.syncword_detection
     out_keep = None
     if args.channels > 1:
@@ -323,6 +327,7 @@ def main():
             "config": {"workload": ("SyncwordDetection only" if args.detector_only else
                                     "configs[1]: 1 channel/GPU, full RX front end (SyncwordDetection 9 bins FFT 2048 + tag "
                                     "gate + CFC + 32-arm RRC SymbolFilter + wipe-off + Costas)") +
+                                   (" + PayloadMetadataInsert + SyncwordRemove + LLR decoder" if args.soft_bits else "") +
                                    " on resident burst+AWGN stream",
                        "items_per_step_per_gpu": n_items * args.channels, "channels_per_gpu": args.channels, "freq_bins": 2 * BINS + 1, "tags_per_step": n_tags // max(args.steps, 1),
                        "parallelism": f"channel-per-gpu x{world}", "input": input_mode,

@@ -240,7 +240,7 @@ def lib():
     L.gr4pm_payload_metadata_insert_destroy.argtypes = [vp]
     L.gr4pm_payload_metadata_insert_destroy.restype = None
     L.gr4pm_payload_metadata_insert_reset.argtypes = [vp]
-    L.gr4pm_payload_metadata_insert_process.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, sz, vp, sz,
+    L.gr4pm_payload_metadata_insert_process.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, sz, C.c_int, vp, sz,
                                                         szp, szp, szp, szp, szp]
     L.gr4pm_costas_loop_process_packets.argtypes = [vp, vp, sz, vp, vp, sz]
     L.gr4pm_syncword_remove_create.argtypes = [C.POINTER(SyncwordRemoveParams), C.POINTER(vp)]

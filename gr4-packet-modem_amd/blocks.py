@@ -385,10 +385,11 @@ class PayloadMetadataInsert:
     def start(self):
         check(lib().gr4pm_payload_metadata_insert_reset(self._h), "PayloadMetadataInsert.start")
 
-    def process_bulk(self, x, tags=None, headers=(), out_cap=None, tags_cap=None):
+    def process_bulk(self, x, tags=None, headers=(), out_cap=None, tags_cap=None, per_tag=False):
         """x: symbols with syncword tags (TAG_DTYPE); headers: the pending parsed_header messages
-        (packet_length, None = invalid header).  Returns dict(out, tags, consumed, headers_used,
-        ignored): consumed < len(x) where the block waits for a header message."""
+        (packet_length, None = invalid header), or with per_tag one message per tag.  Returns
+        dict(out, tags, consumed, headers_used, ignored): consumed < len(x) where the block waits
+        for a header message."""
         torch = _torch()
         x = _dev_c64(x)
         t = _tags_array(tags)
@@ -400,7 +401,8 @@ class PayloadMetadataInsert:
         v = [C.c_size_t(0) for _ in range(5)]
         check(lib().gr4pm_payload_metadata_insert_process(
             self._h, x.data_ptr(), x.numel(), out.data_ptr(), out_cap, _np_ptr(t), t.size, _np_ptr(msgs),
-            len(headers), _np_ptr(tout), tags_cap, *[C.byref(c) for c in v]), "PayloadMetadataInsert.processBulk")
+            len(headers), 1 if per_tag else 0, _np_ptr(tout), tags_cap, *[C.byref(c) for c in v]),
+            "PayloadMetadataInsert.processBulk")
         n_tags, consumed, produced, used, ignored = [c.value for c in v]
         return {"out": out[:produced], "tags": tout[:n_tags].copy(), "consumed": consumed, "headers_used": used,
                 "ignored": ignored}
@@ -627,12 +629,20 @@ class PacketReceiver:
     detector | frequency correction + symbol filter + wipe-off | Costas loop -- so that the
     per-packet serial kernels (phasor checkpoints, PLL), which occupy only a few CUs, overlap
     the detector of the following batches.  process_bulk() then returns the result of an
-    EARLIER batch (None while the pipeline fills); flush() drains it."""
+    EARLIER batch (None while the pipeline fills); flush() drains it.
+
+    soft_bits=True continues as packet_receiver.hpp:123-131 does: SyncwordWipeoff ->
+    PayloadMetadataInsert (drops everything between packets, marks syncword / header / payload
+    with "constellation" and "loop_bandwidth" tags) -> CostasLoop (those tags drive its settings)
+    -> SyncwordRemove -> ConstellationLLRDecoder (noise_sigma 0.7, QPSK): the result then also
+    carries "llr" (float32, two per symbol) and "llr_tags"."""
 
     def __init__(self, samples_per_symbol=4, syncword_freq_bins=4, syncword_threshold=9.5,
-                 costas_constellation="QPSK", max_items=1 << 22, pipelined=False, fused=True):
+                 costas_constellation="QPSK", max_items=1 << 22, pipelined=False, fused=True,
+                 soft_bits=False):
         torch = _torch()
         self.fused = fused  # CFC applied while the symbol filter stages its input
+        self.soft_bits = soft_bits
         sps = samples_per_symbol
         self.samples_per_symbol = sps
         rrc = root_raised_cosine(1.0, float(sps), 1.0, 0.35, sps * 11)            # :60-65
@@ -658,6 +668,11 @@ class PacketReceiver:
             self.syncword_wipeoff = SyncwordWipeoff(np.where(SYNCWORD == 1, -1.0, 1.0).astype(np.float32))  # :117-122
         with torch.cuda.stream(self._streams[2]):
             self.costas_loop = CostasLoop(0.01, costas_constellation)             # :125
+            if soft_bits:
+                self.payload_metadata_insert = PayloadMetadataInsert()            # :123-124
+                self.costas_loop = CostasLoop()                                   # :125 (BPSK until the first tag)
+                self.syncword_remove = SyncwordRemove()                           # :126
+                self.constellation_decoder = ConstellationLLRDecoder(0.7, "QPSK")  # :129-130
         self._workers = None
         self._inflight = []
         if pipelined:
@@ -701,13 +716,24 @@ class PacketReceiver:
                 sym, sym_tags, consumed = self.symbol_filter.process_bulk(z, tags)
             w = self.syncword_wipeoff.process_bulk(sym, sym_tags)
         return {"status": 0, "consumed": n, "symbols": w, "tags": sym_tags, "detector_tags": det_tags,
-                "accepted": acc}
+                "accepted": acc, "headers": [headers[i] for i in np.nonzero(acc)[0]]}
 
     def _stage2(self, res):
         torch = _torch()
-        if res["status"] == 0:
-            with torch.cuda.stream(self._streams[2]):
+        if res["status"] != 0:
+            return res
+        with torch.cuda.stream(self._streams[2]):
+            if not self.soft_bits:
                 res["symbols"] = self.costas_loop.process_bulk(res["symbols"], res["tags"])
+                return res
+            hdrs = [None if h is None else int(h) for h in res["headers"]]
+            pm = self.payload_metadata_insert.process_bulk(res["symbols"], res["tags"], hdrs, per_tag=True)
+            assert pm["consumed"] == res["symbols"].numel()  # every packet's header is known up front
+            z = self.costas_loop.process_packets(pm["out"], pm["tags"])
+            data, data_tags = self.syncword_remove.process_bulk(z, pm["tags"])
+            llr, llr_tags = self.constellation_decoder.process_bulk(data, data_tags)
+            res.update(symbols=z, packet_tags=pm["tags"], llr=llr, llr_tags=llr_tags,
+                       ignored_syncwords=pm["ignored"])
         return res
 
     def _stage12(self, fut1):

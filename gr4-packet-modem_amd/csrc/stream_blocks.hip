@@ -2053,6 +2053,9 @@ struct gr4pm_payload_metadata_insert {
     uint64_t position = 0;      // :38
     size_t payload_symbols = 0; // :39
     uint64_t num_packet = 0;    // :40
+    // headers_per_tag mode: the message that answers the syncword which opened the packet
+    gr4pm_header_msg held{};
+    bool has_held = false;
     DevBuf<CopySpan> spans;
 };
 struct gr4pm_syncword_remove {
@@ -2099,17 +2102,22 @@ gr4pm_status gr4pm_payload_metadata_insert_reset(gr4pm_payload_metadata_insert* 
     if (!h) return GR4PM_ERR_INVALID;
     h->in_packet = false; // start(), :71-75
     h->position = 0;
+    h->has_held = false;
     return GR4PM_OK;
 }
 
 gr4pm_status gr4pm_payload_metadata_insert_process(
     gr4pm_payload_metadata_insert* h, const gr4pm_c64* in, size_t n_in, gr4pm_c64* out, size_t out_cap,
     const gr4pm_tag* tags_in, size_t n_tags_in, const gr4pm_header_msg* headers, size_t n_headers,
-    gr4pm_packet_tag* tags_out, size_t tags_cap, size_t* n_tags_out, size_t* consumed, size_t* produced,
-    size_t* headers_used, size_t* ignored_syncwords)
+    int headers_per_tag, gr4pm_packet_tag* tags_out, size_t tags_cap, size_t* n_tags_out, size_t* consumed,
+    size_t* produced, size_t* headers_used, size_t* ignored_syncwords)
 {
     if (!h || !n_tags_out || !consumed || !produced || !headers_used || !ignored_syncwords) return GR4PM_ERR_INVALID;
     *n_tags_out = *consumed = *produced = *headers_used = *ignored_syncwords = 0;
+    if (headers_per_tag && n_headers != n_tags_in) {
+        set_error("headers_per_tag needs one message per tag (%zu != %zu)", n_headers, n_tags_in);
+        return GR4PM_ERR_INVALID;
+    }
     if (n_in == 0) return GR4PM_OK;
     if (!in || !out) {
         set_error("null sample pointer");
@@ -2153,6 +2161,10 @@ gr4pm_status gr4pm_payload_metadata_insert_process(
                 pt.loop_bandwidth = h->syncword_bw;
                 pt.syncword = tags_in[t];
                 publish(pt);
+                if (headers_per_tag) {
+                    h->held = headers[t];
+                    h->has_held = true;
+                }
             } else {
                 ++ignored;
             }
@@ -2175,14 +2187,16 @@ gr4pm_status gr4pm_payload_metadata_insert_process(
             if (sw <= h->position && h->position < sw + hs)
                 pass(std::min({ end - ipos, out_cap - opos, static_cast<size_t>(sw + hs - h->position) }));
             if (h->position == sw + hs && opos < out_cap && ipos < end) {
-                if (hdr < n_headers) { // :207-242
-                    if (headers[hdr].invalid_header) {
+                if (headers_per_tag ? h->has_held : hdr < n_headers) { // :207-242
+                    const gr4pm_header_msg msg = headers_per_tag ? h->held : headers[hdr];
+                    h->has_held = false;
+                    if (msg.invalid_header) {
                         h->in_packet = false;
                         ipos = end;
                         ++hdr;
                         break;
                     }
-                    const uint64_t packet_length = headers[hdr].packet_length;
+                    const uint64_t packet_length = msg.packet_length;
                     if (packet_length == 0) {
                         set_error("received packet_length = 0"); // :224-226
                         return GR4PM_ERR_INVALID;

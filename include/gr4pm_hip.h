@@ -352,13 +352,17 @@ gr4pm_status gr4pm_payload_metadata_insert_create(const gr4pm_payload_metadata_i
 void gr4pm_payload_metadata_insert_destroy(gr4pm_payload_metadata_insert* h);
 gr4pm_status gr4pm_payload_metadata_insert_reset(gr4pm_payload_metadata_insert* h); /* start(), :71-75 */
 /* tags_in: host, sorted, index relative to in[0]; only GR4PM_TAG_SYNCWORD tags matter.
- * tags_out: host, index relative to out[0].  *ignored_syncwords: syncwords seen inside a
- * packet (:126-147, the ignored_syncword messages). */
+ * headers_per_tag == 0: `headers` is the message queue, oldest first, one message per packet the
+ * block opens.  != 0 (n_headers == n_tags_in): headers[i] answers tags_in[i] if that syncword
+ * opens a packet, for callers that know every detection's header up front (same convention as
+ * gr4pm_syncword_detection_filter_gate); the message of a packet still open at the end of the
+ * call is kept.  tags_out: host, index relative to out[0].  *headers_used = messages consumed.
+ * *ignored_syncwords: syncwords seen inside a packet (:126-147, the ignored_syncword messages). */
 gr4pm_status gr4pm_payload_metadata_insert_process(
     gr4pm_payload_metadata_insert* h, const gr4pm_c64* in, size_t n_in, gr4pm_c64* out, size_t out_cap,
     const gr4pm_tag* tags_in, size_t n_tags_in, const gr4pm_header_msg* headers, size_t n_headers,
-    gr4pm_packet_tag* tags_out, size_t tags_cap, size_t* n_tags_out, size_t* consumed, size_t* produced,
-    size_t* headers_used, size_t* ignored_syncwords);
+    int headers_per_tag, gr4pm_packet_tag* tags_out, size_t tags_cap, size_t* n_tags_out, size_t* consumed,
+    size_t* produced, size_t* headers_used, size_t* ignored_syncwords);
 
 /* CostasLoop fed by PayloadMetadataInsert (packet_receiver.hpp wiring): "constellation" and
  * "loop_bandwidth" keys re-run settingsChanged() (costas_loop.hpp:52-88) from the tagged item
