@@ -58,14 +58,21 @@ def _ptags_array(tags):
 
 
 def _header_msgs(headers):
-    """parsed_header messages: packet_length, or None for an "invalid_header" message"""
-    msgs = np.zeros(max(len(headers), 1), dtype=_abi.HEADER_MSG_DTYPE)
+    """parsed_header messages: packet_length, or None for an "invalid_header" message; returns
+    (HEADER_MSG_DTYPE array with at least one slot, number of messages)"""
+    if isinstance(headers, np.ndarray) and headers.dtype == _abi.HEADER_MSG_DTYPE:
+        return (headers if headers.size else np.zeros(1, dtype=_abi.HEADER_MSG_DTYPE)), headers.size
+    n = len(headers)
+    msgs = np.zeros(max(n, 1), dtype=_abi.HEADER_MSG_DTYPE)
+    if isinstance(headers, np.ndarray):  # all valid
+        msgs["packet_length"][:n] = headers
+        return msgs, n
     for i, h in enumerate(headers):
         if h is None:
             msgs[i]["invalid_header"] = 1
         else:
             msgs[i]["packet_length"] = int(h)
-    return msgs
+    return msgs, n
 
 
 def _np_ptr(a):
@@ -396,15 +403,15 @@ class PayloadMetadataInsert:
         out_cap = x.numel() if out_cap is None else out_cap
         out = torch.empty(max(out_cap, 1), dtype=x.dtype, device=x.device)
         tags_cap = 3 * t.size + 8 if tags_cap is None else tags_cap
-        tout = np.zeros(tags_cap, dtype=PACKET_TAG_DTYPE)
-        msgs = _header_msgs(headers)
+        tout = np.empty(tags_cap, dtype=PACKET_TAG_DTYPE)  # the first n_tags records are written whole
+        msgs, n_msgs = _header_msgs(headers)
         v = [C.c_size_t(0) for _ in range(5)]
         check(lib().gr4pm_payload_metadata_insert_process(
             self._h, x.data_ptr(), x.numel(), out.data_ptr(), out_cap, _np_ptr(t), t.size, _np_ptr(msgs),
-            len(headers), 1 if per_tag else 0, _np_ptr(tout), tags_cap, *[C.byref(c) for c in v]),
+            n_msgs, 1 if per_tag else 0, _np_ptr(tout), tags_cap, *[C.byref(c) for c in v]),
             "PayloadMetadataInsert.processBulk")
         n_tags, consumed, produced, used, ignored = [c.value for c in v]
-        return {"out": out[:produced], "tags": tout[:n_tags].copy(), "consumed": consumed, "headers_used": used,
+        return {"out": out[:produced], "tags": tout[:n_tags], "consumed": consumed, "headers_used": used,
                 "ignored": ignored}
 
     def __del__(self):
@@ -430,12 +437,12 @@ class SyncwordRemove:
         x = _dev_c64(x)
         t = _ptags_array(tags)
         out = torch.empty(max(x.numel(), 1), dtype=x.dtype, device=x.device)
-        tout = np.zeros(t.size + 1, dtype=PACKET_TAG_DTYPE)
+        tout = np.empty(t.size + 1, dtype=PACKET_TAG_DTYPE)
         nt, produced = C.c_size_t(0), C.c_size_t(0)
         check(lib().gr4pm_syncword_remove_process(self._h, x.data_ptr(), x.numel(), out.data_ptr(), _np_ptr(t),
                                                   t.size, _np_ptr(tout), tout.size, C.byref(nt), C.byref(produced)),
               "SyncwordRemove.processBulk")
-        return out[: produced.value], tout[: nt.value].copy()
+        return out[: produced.value], tout[: nt.value]
 
     def __del__(self):
         try:
@@ -464,12 +471,12 @@ class ConstellationLLRDecoder:
         x = _dev_c64(x)
         t = _ptags_array(tags)
         out = torch.empty(max(2 * x.numel(), 1), dtype=torch.float32, device=x.device)
-        tout = np.zeros(t.size + 1, dtype=PACKET_TAG_DTYPE)
+        tout = np.empty(t.size + 1, dtype=PACKET_TAG_DTYPE)
         nt, produced = C.c_size_t(0), C.c_size_t(0)
         check(lib().gr4pm_constellation_llr_decoder_process(
             self._h, x.data_ptr(), x.numel(), out.data_ptr(), out.numel(), _np_ptr(t), t.size, _np_ptr(tout),
             tout.size, C.byref(nt), C.byref(produced)), "ConstellationLLRDecoder.processBulk")
-        return out[: produced.value], tout[: nt.value].copy()
+        return out[: produced.value], tout[: nt.value]
 
     def __del__(self):
         try:
@@ -716,7 +723,7 @@ class PacketReceiver:
                 sym, sym_tags, consumed = self.symbol_filter.process_bulk(z, tags)
             w = self.syncword_wipeoff.process_bulk(sym, sym_tags)
         return {"status": 0, "consumed": n, "symbols": w, "tags": sym_tags, "detector_tags": det_tags,
-                "accepted": acc, "headers": [headers[i] for i in np.nonzero(acc)[0]]}
+                "accepted": acc, "headers": _header_msgs(headers)[0][: det_tags.size][acc]}
 
     def _stage2(self, res):
         torch = _torch()
@@ -726,8 +733,8 @@ class PacketReceiver:
             if not self.soft_bits:
                 res["symbols"] = self.costas_loop.process_bulk(res["symbols"], res["tags"])
                 return res
-            hdrs = [None if h is None else int(h) for h in res["headers"]]
-            pm = self.payload_metadata_insert.process_bulk(res["symbols"], res["tags"], hdrs, per_tag=True)
+            pm = self.payload_metadata_insert.process_bulk(res["symbols"], res["tags"], res["headers"],
+                                                           per_tag=True)
             assert pm["consumed"] == res["symbols"].numel()  # every packet's header is known up front
             z = self.costas_loop.process_packets(pm["out"], pm["tags"])
             data, data_tags = self.syncword_remove.process_bulk(z, pm["tags"])

@@ -915,6 +915,13 @@ struct gr4pm_costas_loop {
     float k1, k2;
     size_t n_channels;
     hipStream_t stream;
+    struct Memo {
+        bool valid = false;
+        double bw = 0.0;
+        int constellation = 0;
+        float k1 = 0.0f, k2 = 0.0f;
+    } memo[4];
+    unsigned memo_next = 0;
     DevBuf<CostasState> state; // [2][n_channels], st_cur selects the current half
     int st_cur = 0;
     DevBuf<CostasSeg> segs;
@@ -924,6 +931,14 @@ struct gr4pm_costas_loop {
 
 static void costas_coeffs(gr4pm_costas_loop* h)
 {
+    // tag-driven settings alternate between a handful of (bandwidth, constellation) pairs, three
+    // times per packet: remember the last few results instead of redoing the cube roots
+    for (const auto& m : h->memo)
+        if (m.valid && m.bw == h->loop_bandwidth && m.constellation == h->constellation) {
+            h->k1 = m.k1;
+            h->k2 = m.k2;
+            return;
+        }
     // settingsChanged(), costas_loop.hpp:62-87
     double gain = 1.0;
     if (h->constellation == 2) gain = 1.41421356237309504880;
@@ -936,6 +951,8 @@ static void costas_coeffs(gr4pm_costas_loop* h)
                      (std::cbrt(2.0) * s) / (std::cbrt(9.0) * (2.0 * bw + 1.0)) - 1.0;
     h->k1 = static_cast<float>((1.0 - z * z) / gain);
     h->k2 = static_cast<float>(((1.0 - z) * (1.0 - z)) / gain);
+    auto& slot = h->memo[h->memo_next++ % 4];
+    slot = { true, h->loop_bandwidth, h->constellation, h->k1, h->k2 };
 }
 
 extern "C" {

@@ -51,3 +51,20 @@ for rep in range(5):
     c = rx.costas_loop.process_bulk(w, sym_tags)
     t4 = tic()
 print("gate %.3f  cfc+symf %.3f  wipeoff %.3f  costas %.3f ms" % ((t1-t0)*1e3, (t2-t1)*1e3, (t3-t2)*1e3, (t4-t3)*1e3))
+
+# the soft-bit tail, call by call
+rs = pkg.PacketReceiver(max_items=n, pipelined=False, soft_bits=True)
+for rep in range(4):
+    front = rs._stage0(x, cap, hist)
+    r1 = rs._stage1(*front, 1500)
+    t0 = tic()
+    pm = rs.payload_metadata_insert.process_bulk(r1["symbols"], r1["tags"], r1["headers"], per_tag=True)
+    t1 = tic()
+    z = rs.costas_loop.process_packets(pm["out"], pm["tags"])
+    t2 = tic()
+    data, data_tags = rs.syncword_remove.process_bulk(z, pm["tags"])
+    t3 = tic()
+    llr, llr_tags = rs.constellation_decoder.process_bulk(data, data_tags)
+    t4 = tic()
+print("soft-bit tail: PayloadMetadataInsert %.3f  Costas(tags) %.3f  SyncwordRemove %.3f  LLR %.3f ms"
+      % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3))
