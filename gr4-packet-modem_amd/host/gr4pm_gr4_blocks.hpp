@@ -538,6 +538,196 @@ public:
     }
 };
 
+// ---------------------------------------------------------------- PayloadMetadataInsert
+// replaces gr::packet_modem::PayloadMetadataInsert<c64> (payload_metadata_insert.hpp:12-324)
+class PayloadMetadataInsert : public gr::Block<PayloadMetadataInsert>
+{
+    using c64 = std::complex<float>;
+    gr4pm_payload_metadata_insert* _h = nullptr;
+    detail::DeviceStage<gr4pm_c64> _din, _dout;
+    std::vector<gr4pm_packet_tag> _tags;
+    gr::property_map _syncword_map; // every key of the syncword tag travels on (:104-112)
+    static const char* constellation_name(int c) { return c == 0 ? "PILOT" : c == 1 ? "BPSK" : "QPSK"; }
+
+public:
+    gr::PortIn<gr::Message, gr::Async> parsed_header;
+    gr::PortIn<c64> in;
+    gr::PortOut<c64> out;
+    gr::PortOut<gr::Message, gr::Async> ignored_syncword;
+    size_t syncword_size = 64;
+    size_t header_size = 128;
+    double syncword_costas_loop_bandwidth = 0.02;
+    double header_costas_loop_bandwidth = 0.01;
+    double payload_costas_loop_bandwidth = 0.005;
+    bool log = false;
+    constexpr static gr::TagPropagationPolicy tag_policy = gr::TagPropagationPolicy::TPP_CUSTOM;
+
+    ~PayloadMetadataInsert() { gr4pm_payload_metadata_insert_destroy(_h); }
+    void start() // :71-75
+    {
+        gr4pm_payload_metadata_insert_destroy(_h);
+        gr4pm_payload_metadata_insert_params p{ syncword_size, header_size, syncword_costas_loop_bandwidth,
+                                                header_costas_loop_bandwidth, payload_costas_loop_bandwidth, nullptr };
+        detail::check(gr4pm_payload_metadata_insert_create(&p, &_h), "PayloadMetadataInsert::start");
+    }
+    gr::work::Status processBulk(const gr::ConsumableSpan auto& headerSpan, const gr::ConsumableSpan auto& inSpan,
+                                 gr::PublishableSpan auto& outSpan, gr::PublishableSpan auto& ignoredSpan)
+    {
+        gr4pm_tag tag{};
+        size_t n_tags = 0;
+        if (this->input_tags_present()) {
+            tag = detail::from_map(this->mergedInputTag().map, 0);
+            if (tag.flags & GR4PM_TAG_SYNCWORD) _syncword_map = this->mergedInputTag().map;
+            n_tags = 1;
+        }
+        std::vector<gr4pm_header_msg> msgs;
+        std::vector<gr::property_map> metas;
+        for (const auto& m : headerSpan) { // :207-242
+            const auto& meta = m.data.value();
+            gr4pm_header_msg hm{};
+            hm.invalid_header = meta.contains("invalid_header") ? 1 : 0;
+            if (!hm.invalid_header) hm.packet_length = pmtv::cast<uint64_t>(meta.at("packet_length"));
+            msgs.push_back(hm);
+            metas.push_back(meta);
+        }
+        const size_t n = inSpan.size(), cap = outSpan.size();
+        gr4pm_c64* din = _din.get(n);
+        gr4pm_c64* dout = _dout.get(cap);
+        (void)hipMemcpy(din, &*inSpan.begin(), n * sizeof(c64), hipMemcpyHostToDevice);
+        _tags.resize(8);
+        size_t n_out_tags = 0, consumed = 0, produced = 0, used = 0, ignored = 0;
+        detail::check(gr4pm_payload_metadata_insert_process(_h, din, n, dout, cap, &tag, n_tags, msgs.data(),
+                                                            msgs.size(), 0, _tags.data(), _tags.size(), &n_out_tags,
+                                                            &consumed, &produced, &used, &ignored),
+                      "PayloadMetadataInsert::processBulk");
+        (void)hipMemcpy(&*outSpan.begin(), dout, produced * sizeof(c64), hipMemcpyDeviceToHost);
+        size_t hdr = 0;
+        for (size_t i = 0; i < n_out_tags; ++i) {
+            const auto& t = _tags[i];
+            gr::property_map m;
+            if (t.kind == GR4PM_PKT_SYNCWORD) m = _syncword_map;                    // :104-112
+            if (t.kind == GR4PM_PKT_HEADER_START) m["header_start"] = pmtv::pmt_null(); // :186-194
+            if (t.kind == GR4PM_PKT_PAYLOAD) {                                       // :222-234
+                while (hdr < used && metas[hdr].contains("invalid_header")) ++hdr;
+                m = metas[hdr++];
+                m["payload_symbols"] = pmtv::pmt(t.payload_symbols);
+                m["payload_bits"] = pmtv::pmt(t.payload_bits);
+            }
+            if (t.constellation >= 0) m["constellation"] = std::string(constellation_name(t.constellation));
+            if (t.loop_bandwidth >= 0) m["loop_bandwidth"] = t.loop_bandwidth;
+            out.publishTag(m, static_cast<ssize_t>(t.index));
+        }
+        size_t ignored_published = 0;
+        if (log && ignored > 0 && ignoredSpan.size() > 0) { // :126-147
+            ignoredSpan[0] = {};
+            ignored_published = 1;
+        }
+        if (!headerSpan.consume(used)) throw gr::exception("consume failed");
+        if (!inSpan.consume(consumed)) throw gr::exception("consume failed");
+        ignoredSpan.publish(ignored_published);
+        outSpan.publish(produced);
+        if (consumed != 0) this->_mergedInputTag.map.clear(); // :288-295
+        return gr::work::Status::OK;
+    }
+};
+
+// ---------------------------------------------------------------- SyncwordRemove
+// replaces gr::packet_modem::SyncwordRemove<c64> (syncword_remove.hpp:11-112)
+class SyncwordRemove : public gr::Block<SyncwordRemove>
+{
+    using c64 = std::complex<float>;
+    gr4pm_syncword_remove* _h = nullptr;
+    detail::DeviceStage<gr4pm_c64> _din, _dout;
+
+public:
+    gr::PortIn<c64> in;
+    gr::PortOut<c64> out;
+    size_t syncword_size = 64;
+    constexpr static gr::TagPropagationPolicy tag_policy = gr::TagPropagationPolicy::TPP_CUSTOM;
+
+    ~SyncwordRemove() { gr4pm_syncword_remove_destroy(_h); }
+    void start()
+    {
+        gr4pm_syncword_remove_destroy(_h);
+        gr4pm_syncword_remove_params p{ syncword_size, nullptr };
+        detail::check(gr4pm_syncword_remove_create(&p, &_h), "SyncwordRemove::start");
+    }
+    gr::work::Status processBulk(const gr::ConsumableSpan auto& inSpan, gr::PublishableSpan auto& outSpan)
+    {
+        gr4pm_packet_tag tag{}, tout[2];
+        size_t n_tags = 0;
+        if (this->input_tags_present()) { // :51-64
+            tag.index = 0;
+            tag.kind = this->mergedInputTag().map.contains("syncword_amplitude") ? GR4PM_PKT_SYNCWORD
+                                                                                 : GR4PM_PKT_HEADER_START;
+            tag.constellation = -1;
+            tag.loop_bandwidth = -1.0;
+            n_tags = 1;
+        }
+        const size_t n = std::min(inSpan.size(), outSpan.size());
+        gr4pm_c64* din = _din.get(n);
+        gr4pm_c64* dout = _dout.get(n);
+        (void)hipMemcpy(din, &*inSpan.begin(), n * sizeof(c64), hipMemcpyHostToDevice);
+        size_t n_out_tags = 0, produced = 0;
+        detail::check(gr4pm_syncword_remove_process(_h, din, n, dout, &tag, n_tags, tout, 2, &n_out_tags, &produced),
+                      "SyncwordRemove::processBulk");
+        (void)hipMemcpy(&*outSpan.begin(), dout, produced * sizeof(c64), hipMemcpyDeviceToHost);
+        if (n_out_tags) out.publishTag(this->mergedInputTag().map, static_cast<ssize_t>(tout[0].index)); // :59-62
+        if (!inSpan.consume(n)) throw gr::exception("consume failed");
+        outSpan.publish(produced);
+        if (n != 0) this->_mergedInputTag.map.clear(); // :95-102
+        return gr::work::Status::OK;
+    }
+};
+
+// ---------------------------------------------------------------- ConstellationLLRDecoder
+// replaces gr::packet_modem::ConstellationLLRDecoder<float> (constellation_llr_decoder.hpp:13-142)
+class ConstellationLLRDecoder : public gr::Block<ConstellationLLRDecoder, gr::Resampling<>>
+{
+    using c64 = std::complex<float>;
+    gr4pm_constellation_llr_decoder* _h = nullptr;
+    detail::DeviceStage<gr4pm_c64> _din;
+    detail::DeviceStage<float> _dout;
+
+public:
+    gr::PortIn<c64> in;
+    gr::PortOut<float> out;
+    float noise_sigma = 1.0f;
+    std::string constellation = "BPSK";
+    constexpr static gr::TagPropagationPolicy tag_policy = gr::TagPropagationPolicy::TPP_CUSTOM;
+
+    ~ConstellationLLRDecoder() { gr4pm_constellation_llr_decoder_destroy(_h); }
+    void settingsChanged(const gr::property_map&, const gr::property_map&) // :55-78 (also driven by tags)
+    {
+        std::string u;
+        for (char c : constellation) u.push_back(static_cast<char>(std::toupper(c)));
+        const int id = u == "BPSK" ? 1 : u == "QPSK" ? 2 : 0;
+        if (id == 0) throw gr::exception("constellation " + constellation + " not supported"); // :72-74
+        this->input_chunk_size = 1;
+        this->output_chunk_size = static_cast<size_t>(id); // :64-71
+        gr4pm_constellation_llr_decoder_destroy(_h);
+        _h = nullptr;
+        gr4pm_constellation_llr_decoder_params p{ noise_sigma, id, nullptr };
+        detail::check(gr4pm_constellation_llr_decoder_create(&p, &_h), "ConstellationLLRDecoder::settingsChanged");
+    }
+    gr::work::Status processBulk(const gr::ConsumableSpan auto& inSpan, gr::PublishableSpan auto& outSpan)
+    {
+        if (this->input_tags_present()) out.publishTag(this->mergedInputTag().map, 0); // :93-99
+        const size_t n = std::min(inSpan.size(), outSpan.size() / this->output_chunk_size);
+        gr4pm_c64* din = _din.get(n);
+        float* dout = _dout.get(2 * n);
+        (void)hipMemcpy(din, &*inSpan.begin(), n * sizeof(c64), hipMemcpyHostToDevice);
+        size_t produced = 0;
+        detail::check(gr4pm_constellation_llr_decoder_process(_h, din, n, dout, 2 * n, nullptr, 0, nullptr, 0, nullptr,
+                                                              &produced),
+                      "ConstellationLLRDecoder::processBulk");
+        (void)hipMemcpy(&*outSpan.begin(), dout, produced * sizeof(float), hipMemcpyDeviceToHost);
+        if (!inSpan.consume(n)) throw gr::exception("consume failed");
+        outSpan.publish(produced);
+        return gr::work::Status::OK;
+    }
+};
+
 } // namespace gr::packet_modem::hip
 
 ENABLE_REFLECTION(gr::packet_modem::hip::SyncwordDetection, in, out, fft_size, samples_per_symbol, rrc_taps,
@@ -551,3 +741,8 @@ ENABLE_REFLECTION(gr::packet_modem::hip::CostasLoop, in, out, loop_bandwidth, co
 ENABLE_REFLECTION(gr::packet_modem::hip::SyncwordWipeoff, in, out, syncword);
 ENABLE_REFLECTION(gr::packet_modem::hip::InterpolatingFirFilter, in, out, interpolation, taps);
 ENABLE_REFLECTION_FOR_TEMPLATE(gr::packet_modem::hip::PfbArbResampler, in, out, rate, taps, filter_size);
+ENABLE_REFLECTION(gr::packet_modem::hip::PayloadMetadataInsert, parsed_header, in, out, ignored_syncword,
+                  syncword_size, header_size, syncword_costas_loop_bandwidth, header_costas_loop_bandwidth,
+                  payload_costas_loop_bandwidth, log);
+ENABLE_REFLECTION(gr::packet_modem::hip::SyncwordRemove, in, out, syncword_size);
+ENABLE_REFLECTION(gr::packet_modem::hip::ConstellationLLRDecoder, in, out, noise_sigma, constellation);
