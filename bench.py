@@ -112,12 +112,13 @@ def scatter_channels(dist, make_all, n_items, device, rank, world):
     holds every channel's samples ([world, n_items] complex64) and sends one channel to each
     rank (RCCL send/recv over xGMI on the GPUs; any torch.distributed backend works)."""
     mine = torch.empty(n_items, dtype=torch.complex64, device=device)
+    mine_f = torch.view_as_real(mine)  # interleaved float32 pairs: every backend moves floats
     if rank == 0:
         allx = make_all()
         assert allx.shape == (world, n_items)
-        dist.scatter(mine, [allx[r].contiguous() for r in range(world)], src=0)
+        dist.scatter(mine_f, [torch.view_as_real(allx[r].contiguous()) for r in range(world)], src=0)
     else:
-        dist.scatter(mine, None, src=0)
+        dist.scatter(mine_f, None, src=0)
     return mine
 
 

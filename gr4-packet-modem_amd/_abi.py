@@ -123,6 +123,19 @@ class LlrParams(C.Structure):
     _fields_ = [("noise_sigma", C.c_float), ("constellation", C.c_int), ("stream", C.c_void_p)]
 
 
+class ScramblerParams(C.Structure):
+    _fields_ = [("mask", C.c_uint64), ("seed", C.c_uint64), ("length", C.c_uint64), ("count", C.c_uint64),
+                ("item_kind", C.c_int), ("stream", C.c_void_p)]
+
+
+class HeaderPayloadSplitParams(C.Structure):
+    _fields_ = [("header_size", C.c_size_t), ("stream", C.c_void_p)]
+
+
+class HeaderFecDecoderParams(C.Structure):
+    _fields_ = [("alist", C.c_char_p), ("max_iterations", C.c_uint32), ("stream", C.c_void_p)]
+
+
 class PfbArbParams(C.Structure):
     _fields_ = [("rate", C.c_double), ("rate_is_double", C.c_int), ("taps", C.c_void_p),
                 ("n_taps", C.c_size_t), ("filter_size", C.c_size_t), ("stream", C.c_void_p)]
@@ -159,6 +172,12 @@ EXPORTS = [
     "gr4pm_syncword_remove_process",
     "gr4pm_constellation_llr_decoder_create", "gr4pm_constellation_llr_decoder_destroy",
     "gr4pm_constellation_llr_decoder_process",
+    "gr4pm_additive_scrambler_create", "gr4pm_additive_scrambler_destroy", "gr4pm_additive_scrambler_reset",
+    "gr4pm_additive_scrambler_process",
+    "gr4pm_header_payload_split_create", "gr4pm_header_payload_split_destroy",
+    "gr4pm_header_payload_split_reset", "gr4pm_header_payload_split_process",
+    "gr4pm_header_fec_decoder_create", "gr4pm_header_fec_decoder_destroy", "gr4pm_header_fec_decoder_process",
+    "gr4pm_header_parse",
 ]
 
 _lib = None
@@ -252,6 +271,22 @@ def lib():
     L.gr4pm_constellation_llr_decoder_destroy.argtypes = [vp]
     L.gr4pm_constellation_llr_decoder_destroy.restype = None
     L.gr4pm_constellation_llr_decoder_process.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, sz, szp, szp]
+    L.gr4pm_additive_scrambler_create.argtypes = [C.POINTER(ScramblerParams), C.POINTER(vp)]
+    L.gr4pm_additive_scrambler_destroy.argtypes = [vp]
+    L.gr4pm_additive_scrambler_destroy.restype = None
+    L.gr4pm_additive_scrambler_reset.argtypes = [vp]
+    L.gr4pm_additive_scrambler_process.argtypes = [vp, vp, sz, vp, vp, sz]
+    L.gr4pm_header_payload_split_create.argtypes = [C.POINTER(HeaderPayloadSplitParams), C.POINTER(vp)]
+    L.gr4pm_header_payload_split_destroy.argtypes = [vp]
+    L.gr4pm_header_payload_split_destroy.restype = None
+    L.gr4pm_header_payload_split_reset.argtypes = [vp]
+    L.gr4pm_header_payload_split_process.argtypes = [vp, vp, sz, vp, szp, vp, szp, vp, sz, vp, szp, vp, szp, sz]
+    L.gr4pm_header_fec_decoder_create.argtypes = [C.POINTER(HeaderFecDecoderParams), C.POINTER(vp)]
+    L.gr4pm_header_fec_decoder_destroy.argtypes = [vp]
+    L.gr4pm_header_fec_decoder_destroy.restype = None
+    L.gr4pm_header_fec_decoder_process.argtypes = [vp, vp, sz, vp, vp]
+    L.gr4pm_header_parse.argtypes = [vp, vp, sz, vp, vp]
+    L.gr4pm_header_parse.restype = None
     L.gr4pm_firdes_root_raised_cosine.argtypes = [C.c_double] * 4 + [sz, vp]
     L.gr4pm_firdes_root_raised_cosine.restype = sz
     _lib = L

@@ -487,6 +487,126 @@ class ConstellationLLRDecoder:
             pass
 
 
+class AdditiveScrambler:
+    """additive_scrambler.hpp:24-100 on float32 soft symbols or uint8 hard symbols (by the
+    dtype of the first tensor it is given, or `dtype=`)"""
+
+    def __init__(self, mask=0x8A, seed=0x7F, length=7, count=0, dtype="float32"):
+        self.mask, self.seed, self.length, self.count = mask, seed, length, count
+        kind = {"float32": 1, "uint8": 2}[str(dtype).replace("torch.", "")]
+        p = _abi.ScramblerParams(mask, seed, length, count, kind, _stream_handle())
+        self._kind = kind
+        self._h = C.c_void_p()
+        check(lib().gr4pm_additive_scrambler_create(C.byref(p), C.byref(self._h)), "AdditiveScrambler")
+
+    def start(self):
+        check(lib().gr4pm_additive_scrambler_reset(self._h), "AdditiveScrambler.start")
+
+    def process_bulk(self, x, reset_index=()):
+        """reset_index: items that carry the reset_tag_key (:78-80)"""
+        torch = _torch()
+        want = torch.float32 if self._kind == 1 else torch.uint8
+        if not x.is_cuda or x.dtype != want:
+            raise Gr4pmError(f"AdditiveScrambler expects a CUDA {want} tensor")
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        ri = np.ascontiguousarray(reset_index, dtype=np.uint64)
+        check(lib().gr4pm_additive_scrambler_process(self._h, x.data_ptr(), x.numel(), out.data_ptr(), _np_ptr(ri),
+                                                     ri.size), "AdditiveScrambler.processBulk")
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _release("gr4pm_additive_scrambler_destroy", self._h)
+                self._h = None
+        except Exception:  # interpreter shutdown
+            pass
+
+
+class HeaderPayloadSplit:
+    """header_payload_split.hpp:9-147 on float32 items"""
+
+    def __init__(self, header_size=256):
+        self.header_size = header_size
+        p = _abi.HeaderPayloadSplitParams(header_size, _stream_handle())
+        self._h = C.c_void_p()
+        check(lib().gr4pm_header_payload_split_create(C.byref(p), C.byref(self._h)), "HeaderPayloadSplit")
+
+    def process_bulk(self, x, tags=None):
+        """returns (header items, payload items, header tags, payload tags)"""
+        torch = _torch()
+        x = x.contiguous()
+        assert x.is_cuda and x.dtype == torch.float32
+        t = _ptags_array(tags)
+        hdr, pay = torch.empty(max(x.numel(), 1), dtype=x.dtype, device=x.device), torch.empty(
+            max(x.numel(), 1), dtype=x.dtype, device=x.device)
+        ht, pt = np.empty(t.size + 1, dtype=PACKET_TAG_DTYPE), np.empty(t.size + 1, dtype=PACKET_TAG_DTYPE)
+        v = [C.c_size_t(0) for _ in range(4)]
+        check(lib().gr4pm_header_payload_split_process(
+            self._h, x.data_ptr(), x.numel(), hdr.data_ptr(), C.byref(v[0]), pay.data_ptr(), C.byref(v[1]),
+            _np_ptr(t), t.size, _np_ptr(ht), C.byref(v[2]), _np_ptr(pt), C.byref(v[3]), t.size + 1),
+            "HeaderPayloadSplit.processBulk")
+        return hdr[: v[0].value], pay[: v[1].value], ht[: v[2].value], pt[: v[3].value]
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _release("gr4pm_header_payload_split_destroy", self._h)
+                self._h = None
+        except Exception:  # interpreter shutdown
+            pass
+
+
+def header_ldpc_alist():
+    """the (128, 32) parity-check matrix of the header code in alist form
+    (header_fec_decoder.hpp:31-258), shipped as data/header_ldpc_128_32.alist"""
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    return open(os.path.join(here, "data", "header_ldpc_128_32.alist")).read()
+
+
+class HeaderFecDecoder:
+    """header_fec_decoder.hpp:13-359: 256 LLRs -> 4 header bytes, or invalid"""
+
+    def __init__(self, alist=None, max_iterations=25):
+        self._alist = (alist or header_ldpc_alist()).encode()
+        p = _abi.HeaderFecDecoderParams(self._alist, max_iterations, _stream_handle())
+        self._h = C.c_void_p()
+        check(lib().gr4pm_header_fec_decoder_create(C.byref(p), C.byref(self._h)), "HeaderFecDecoder.start")
+
+    def process_bulk(self, llrs):
+        """llrs: CUDA float32, 256 per codeword.  Returns (headers [n, 4] uint8, invalid [n] bool)"""
+        torch = _torch()
+        llrs = llrs.contiguous()
+        assert llrs.is_cuda and llrs.dtype == torch.float32
+        n = llrs.numel() // 256
+        out = np.empty((max(n, 1), 4), dtype=np.uint8)
+        inval = np.empty(max(n, 1), dtype=np.uint8)
+        check(lib().gr4pm_header_fec_decoder_process(self._h, llrs.data_ptr(), n, _np_ptr(out), _np_ptr(inval)),
+              "HeaderFecDecoder.processBulk")
+        return out[:n], inval[:n].astype(bool)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _release("gr4pm_header_fec_decoder_destroy", self._h)
+                self._h = None
+        except Exception:  # interpreter shutdown
+            pass
+
+
+def header_parse(headers, invalid=None):
+    """HeaderParser, header_parser.hpp:46-95: [n, 4] bytes (+ the decoder's verdicts) -> the
+    parsed_header messages as a HEADER_MSG_DTYPE array, and the packet types (-1 invalid)"""
+    hd = np.ascontiguousarray(headers, dtype=np.uint8).reshape(-1, 4)
+    inv = np.zeros(hd.shape[0], dtype=np.uint8) if invalid is None else np.ascontiguousarray(invalid, dtype=np.uint8)
+    msgs = np.zeros(max(hd.shape[0], 1), dtype=_abi.HEADER_MSG_DTYPE)
+    ptype = np.zeros(max(hd.shape[0], 1), dtype=np.int32)
+    lib().gr4pm_header_parse(_np_ptr(hd), _np_ptr(inv), hd.shape[0], _np_ptr(msgs), _np_ptr(ptype))
+    return msgs[: hd.shape[0]], ptype[: hd.shape[0]]
+
+
 def _item_kind(x):
     torch = _torch()
     if x.dtype == torch.complex64:

@@ -1,0 +1,633 @@
+// header_blocks.hip -- the header decode loop of the receiver (packet_receiver.hpp:131-139,
+// SURVEY.md 8(f) rank 2) behind the C ABI of include/gr4pm_hip.h:
+//   AdditiveScrambler<float|uint8_t>  additive_scrambler.hpp:58-100
+//   HeaderPayloadSplit<float>         header_payload_split.hpp:38-135
+//   HeaderFecDecoder                  header_fec_decoder.hpp:290-347 (+ the LDPC decoder the
+//                                     reference takes from its Rust dependency ldpc-toolbox)
+//   HeaderParser                      header_parser.hpp:46-95 (host)
+// Compiled with -ffp-contract=off: the LDPC arithmetic is bit-identical to oracle/.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <vector>
+
+#include "common.hpp"
+
+namespace gr4pm {
+namespace {
+
+// ------------------------------------------------------------------ AdditiveScrambler
+// The LFSR output depends only on the number of items since the last reset, so the sequence
+// is tabulated once: `prefix` items, then a cycle of `period` items.
+struct ScrRun {
+    unsigned long long start, len, phase; // items [start, start+len) use sequence index phase, phase+1, ...
+};
+template <typename T>
+__global__ __launch_bounds__(256) void k_scramble(const ScrRun* __restrict__ runs, const uint8_t* __restrict__ seq,
+                                                  unsigned long long prefix, unsigned long long period,
+                                                  const T* __restrict__ in, T* __restrict__ out)
+{
+    const ScrRun r = runs[blockIdx.y];
+    for (unsigned long long i = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < r.len;
+         i += static_cast<unsigned long long>(gridDim.x) * blockDim.x) {
+        unsigned long long q = r.phase + i;
+        if (q >= prefix + period) q = prefix + (q - prefix) % period;
+        const uint8_t bit = seq[q];
+        const T a = in[r.start + i];
+        if constexpr (sizeof(T) == 1) out[r.start + i] = a ^ bit;  // additive_scrambler.hpp:90
+        else out[r.start + i] = bit ? -a : a;                       // :92-93
+    }
+}
+
+// ------------------------------------------------------------------ span gather (float items)
+struct FSpan {
+    unsigned long long src, dst, len;
+};
+__global__ __launch_bounds__(256) void k_gather_f32(const FSpan* __restrict__ spans, const float* __restrict__ in,
+                                                    float* __restrict__ out)
+{
+    const FSpan sp = spans[blockIdx.y];
+    for (unsigned long long i = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < sp.len;
+         i += static_cast<unsigned long long>(gridDim.x) * blockDim.x)
+        out[sp.dst + i] = in[sp.src + i];
+}
+gr4pm_status gather_f32(hipStream_t s, DevBuf<FSpan>& buf, const std::vector<FSpan>& spans, const float* in,
+                        float* out)
+{
+    if (spans.empty()) return GR4PM_OK;
+    if (buf.n < spans.size()) GR4PM_TRY(buf.alloc(spans.size() * 2));
+    GR4PM_TRY(buf.upload_staged(spans.data(), spans.size(), s));
+    unsigned long long longest = 0;
+    for (const auto& sp : spans) longest = std::max(longest, sp.len);
+    const unsigned gx = static_cast<unsigned>(std::max<unsigned long long>(
+        1, std::min<unsigned long long>((longest + 2047) / 2048, 1024)));
+    for (size_t first = 0; first < spans.size(); first += 65535) {
+        const unsigned rows = static_cast<unsigned>(std::min<size_t>(65535, spans.size() - first));
+        hipLaunchKernelGGL(k_gather_f32, dim3(gx, rows), dim3(256), 0, s, buf.p + first, in, out);
+    }
+    GR4PM_HIP_TRY(hipGetLastError());
+    return GR4PM_OK;
+}
+
+// ------------------------------------------------------------------ header FEC decoder
+// One wavefront per codeword.  Posteriors P[n] and check-to-variable messages R[m][kMaxDeg]
+// live in LDS.  Horizontal-layered schedule: the checks are processed in index order; runs of
+// consecutive checks that share no variable are independent and are done in one step, one lane
+// per (check, edge) -- the arithmetic of every check is exactly the serial one.
+constexpr int kMaxDeg = 8;
+constexpr int kMaxN = 256, kMaxM = 192;
+struct LdpcDev {
+    const uint8_t* row_var; // [m][kMaxDeg], 0xFF = unused
+    const uint8_t* row_deg; // [m]
+    const uint16_t* sched;  // [n_steps][64]: check << 3 | edge, 0xFFFF = idle lane
+    const float* corr;      // [64]: ln(1 + e^-x), x = i / 8
+    unsigned n, m, n_steps;
+};
+__device__ __forceinline__ float ldpc_corr(const float* corr, float x) // x >= 0
+{
+    return x >= 8.0f ? 0.0f : corr[static_cast<int>(x * 8.0f)];
+}
+__device__ __forceinline__ float ldpc_boxplus(const float* corr, float a, float b) // magnitudes
+{
+    const float mn = a < b ? a : b;
+    const float r = mn + ldpc_corr(corr, a + b) - ldpc_corr(corr, a < b ? b - a : a - b);
+    return r > 0.0f ? r : 0.0f;
+}
+__global__ __launch_bounds__(64) void k_header_fec(const float* __restrict__ llrs, unsigned n_codewords, LdpcDev d,
+                                                   unsigned max_iterations, unsigned n_llrs_per_codeword,
+                                                   uint8_t* __restrict__ headers, uint8_t* __restrict__ invalid)
+{
+    __shared__ float P[kMaxN];
+    __shared__ float R[kMaxM * kMaxDeg];
+    __shared__ float corr[64];
+    const unsigned cw = blockIdx.x;
+    if (cw >= n_codewords) return;
+    const int lane = threadIdx.x;
+    const float* x = llrs + static_cast<size_t>(cw) * n_llrs_per_codeword;
+    corr[lane] = d.corr[lane];
+    // header_fec_decoder.hpp:308-312: accumulate the two copies of the repetition code
+    for (unsigned v = lane; v < d.n; v += 64) P[v] = x[v] + x[d.n + v];
+    for (unsigned e = lane; e < d.m * kMaxDeg; e += 64) R[e] = 0.0f;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    bool found = false;
+    for (unsigned it = 0; it <= max_iterations; ++it) {
+        // is the hard decision a codeword?
+        bool bad = false;
+        for (unsigned c = lane; c < d.m; c += 64) {
+            unsigned parity = 0;
+            const unsigned dc = d.row_deg[c];
+            for (unsigned j = 0; j < dc; ++j) parity ^= P[d.row_var[c * kMaxDeg + j]] < 0.0f ? 1u : 0u;
+            bad |= parity != 0;
+        }
+        if (!__any(bad)) {
+            found = true;
+            break;
+        }
+        if (it == max_iterations) break;
+        for (unsigned s = 0; s < d.n_steps; ++s) {
+            const unsigned entry = d.sched[s * 64 + lane];
+            float q_own = 0.0f, r_own = 0.0f;
+            unsigned v_own = 0, slot = 0;
+            const bool active = entry != 0xFFFFu;
+            if (active) {
+                const unsigned c = entry >> 3, k = entry & 7u;
+                const unsigned dc = d.row_deg[c];
+                float Q[kMaxDeg];
+                unsigned neg = 0, imin = 0;
+#pragma unroll
+                for (unsigned j = 0; j < kMaxDeg; ++j) {
+                    if (j < dc) {
+                        Q[j] = P[d.row_var[c * kMaxDeg + j]] - R[c * kMaxDeg + j];
+                        if (Q[j] < 0.0f) neg ^= 1u;
+                    } else {
+                        Q[j] = 0.0f;
+                    }
+                }
+                for (unsigned j = 1; j < dc; ++j)
+                    if (fabsf(Q[j]) < fabsf(Q[imin])) imin = j;
+                float others = -1.0f;
+#pragma unroll
+                for (unsigned j = 0; j < kMaxDeg; ++j) {
+                    if (j < dc && j != imin) {
+                        const float a = fabsf(Q[j]);
+                        others = others < 0.0f ? a : ldpc_boxplus(corr, others, a);
+                    }
+                }
+                if (others < 0.0f) others = 0.0f;
+                const float all = ldpc_boxplus(corr, others, fabsf(Q[imin]));
+                float qk = 0.0f;
+#pragma unroll
+                for (unsigned j = 0; j < kMaxDeg; ++j)
+                    if (j == k) qk = Q[j];
+                const float mag = k == imin ? others : all;
+                const unsigned sgn = neg ^ (qk < 0.0f ? 1u : 0u);
+                r_own = sgn ? -mag : mag;
+                q_own = qk;
+                v_own = d.row_var[c * kMaxDeg + k];
+                slot = c * kMaxDeg + k;
+            }
+            // all reads of this step are issued above, all writes below: LDS operations of one
+            // wavefront execute in order
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            if (active) {
+                R[slot] = r_own;
+                P[v_own] = q_own + r_own;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        }
+    }
+    // the first k = n - m bits are the header (systematic), packed MSB first (:329-335)
+    const unsigned k_bits = d.n - d.m;
+    const unsigned long long mask = __ballot(static_cast<unsigned>(lane) < k_bits && P[lane] < 0.0f);
+    if (lane < static_cast<int>(k_bits / 8)) {
+        const unsigned b = static_cast<unsigned>((mask >> (8 * lane)) & 0xFFull);
+        headers[static_cast<size_t>(cw) * (k_bits / 8) + lane] = static_cast<uint8_t>(__brev(b) >> 24);
+    }
+    if (lane == 0) invalid[cw] = found ? 0 : 1;
+}
+
+} // namespace
+} // namespace gr4pm
+
+using namespace gr4pm;
+
+struct gr4pm_additive_scrambler {
+    uint64_t mask, seed, length, count;
+    int item_kind;
+    hipStream_t stream;
+    uint64_t prefix = 0, period = 1; // shape of the tabulated LFSR output
+    bool cyclic = true;              // false: no repeat found, the table just covers `table_len` items
+    uint64_t table_len = 0;
+    uint64_t position = 0;           // items since the last reset (_current_count, :49)
+    DevBuf<uint8_t> seq;
+    DevBuf<ScrRun> runs;
+};
+struct gr4pm_header_payload_split {
+    size_t header_size;
+    hipStream_t stream;
+    bool in_payload = false;    // header_payload_split.hpp:25
+    uint64_t position = 0;      // :26
+    uint64_t payload_items = 0; // :27
+    DevBuf<FSpan> hspans, pspans;
+};
+struct gr4pm_header_fec_decoder {
+    unsigned n = 0, m = 0, n_steps = 0, max_iterations = 25;
+    hipStream_t stream;
+    DevBuf<uint8_t> row_var, row_deg;
+    DevBuf<uint16_t> sched;
+    DevBuf<float> corr;
+    PinnedBuf<uint8_t> headers, invalid;
+};
+
+extern "C" {
+
+gr4pm_status gr4pm_additive_scrambler_create(const gr4pm_additive_scrambler_params* p,
+                                             gr4pm_additive_scrambler** out)
+{
+    if (!p || !out || (p->item_kind != 1 && p->item_kind != 2) || p->length > 63) return GR4PM_ERR_INVALID;
+    *out = nullptr;
+    GR4PM_TRY(require_device());
+    auto* h = new (std::nothrow) gr4pm_additive_scrambler;
+    if (!h) return GR4PM_ERR_NOMEM;
+    h->mask = p->mask;
+    h->seed = p->seed;
+    h->length = p->length;
+    h->count = p->count;
+    h->item_kind = p->item_kind;
+    h->stream = static_cast<hipStream_t>(p->stream);
+    // run the LFSR (additive_scrambler.hpp:84-87) from the seed until a register value repeats
+    // (or `count` items, after which it is reset anyway)
+    std::vector<uint8_t> seq;
+    const uint64_t cap = p->count ? p->count : (1ull << 24);
+    uint64_t reg = p->seed;
+    // Brent's cycle detection keeps this O(prefix + period) without a table of states
+    uint64_t power = 1, lam = 1, tortoise = reg;
+    auto step = [&](uint64_t r) {
+        const uint64_t shift_in = static_cast<uint64_t>(__builtin_parityll(r & p->mask));
+        return (shift_in << p->length) | (r >> 1);
+    };
+    uint64_t hare = step(reg);
+    uint64_t walked = 1;
+    while (tortoise != hare && walked < cap) {
+        if (power == lam) {
+            tortoise = hare;
+            power *= 2;
+            lam = 0;
+        }
+        hare = step(hare);
+        ++lam;
+        ++walked;
+    }
+    uint64_t mu = 0;
+    if (tortoise == hare) {
+        uint64_t a = reg, b = reg;
+        for (uint64_t i = 0; i < lam; ++i) b = step(b);
+        while (a != b) {
+            a = step(a);
+            b = step(b);
+            ++mu;
+        }
+    } else { // no repeat within the cap: tabulate the cap, no cycle needed below it
+        mu = cap;
+        lam = 1;
+        h->cyclic = false;
+    }
+    const uint64_t total = std::min<uint64_t>(mu + lam, cap + 1);
+    seq.resize(total);
+    for (uint64_t i = 0; i < total; ++i) {
+        seq[i] = static_cast<uint8_t>(reg & 1); // :84
+        reg = step(reg);
+    }
+    h->prefix = std::min<uint64_t>(mu, total - 1);
+    h->period = total - h->prefix;
+    h->table_len = total;
+    gr4pm_status s = h->seq.alloc(seq.size());
+    if (s == GR4PM_OK) s = h->seq.upload(seq.data(), seq.size(), h->stream);
+    if (s == GR4PM_OK && hipStreamSynchronize(h->stream) != hipSuccess) s = GR4PM_ERR_HIP;
+    if (s != GR4PM_OK) {
+        delete h;
+        return s;
+    }
+    *out = h;
+    return GR4PM_OK;
+}
+void gr4pm_additive_scrambler_destroy(gr4pm_additive_scrambler* h)
+{
+    if (!h) return;
+    (void)hipStreamSynchronize(h->stream);
+    delete h;
+}
+gr4pm_status gr4pm_additive_scrambler_reset(gr4pm_additive_scrambler* h)
+{
+    if (!h) return GR4PM_ERR_INVALID;
+    h->position = 0;
+    return GR4PM_OK;
+}
+gr4pm_status gr4pm_additive_scrambler_process(gr4pm_additive_scrambler* h, const void* in, size_t n, void* out,
+                                              const uint64_t* reset_index, size_t n_resets)
+{
+    if (!h) return GR4PM_ERR_INVALID;
+    if (n == 0) return GR4PM_OK;
+    if (!in || !out) {
+        set_error("null sample pointer");
+        return GR4PM_ERR_INVALID;
+    }
+    // runs of items between resets (tag resets :78-80, count resets :81)
+    std::vector<ScrRun> runs;
+    size_t pos = 0, t = 0;
+    while (pos < n) {
+        while (t < n_resets && reset_index[t] < pos) ++t;
+        if (t < n_resets && reset_index[t] == pos) {
+            h->position = 0;
+            ++t;
+        }
+        if (h->count != 0 && h->position == h->count) h->position = 0;
+        size_t end = n;
+        if (t < n_resets) end = std::min<size_t>(end, reset_index[t]);
+        if (h->count != 0) end = std::min<size_t>(end, pos + static_cast<size_t>(h->count - h->position));
+        if (!h->cyclic && h->position + (end - pos) > h->table_len) {
+            set_error("LFSR output needed beyond the %llu tabulated items",
+                      static_cast<unsigned long long>(h->table_len));
+            return GR4PM_ERR_INVALID;
+        }
+        runs.push_back({ pos, end - pos, h->position });
+        h->position += end - pos;
+        pos = end;
+    }
+    if (h->cyclic && h->position >= h->prefix + h->period) // keep the counter small
+        h->position = h->prefix + (h->position - h->prefix) % h->period;
+    if (h->runs.n < runs.size()) GR4PM_TRY(h->runs.alloc(runs.size() * 2));
+    GR4PM_TRY(h->runs.upload_staged(runs.data(), runs.size(), h->stream));
+    unsigned long long longest = 0;
+    for (const auto& r : runs) longest = std::max(longest, r.len);
+    const unsigned gx = static_cast<unsigned>(std::max<unsigned long long>(
+        1, std::min<unsigned long long>((longest + 2047) / 2048, 2048)));
+    for (size_t first = 0; first < runs.size(); first += 65535) {
+        const unsigned rows = static_cast<unsigned>(std::min<size_t>(65535, runs.size() - first));
+        if (h->item_kind == 1)
+            hipLaunchKernelGGL(k_scramble<float>, dim3(gx, rows), dim3(256), 0, h->stream, h->runs.p + first, h->seq.p,
+                               h->prefix, h->period, static_cast<const float*>(in), static_cast<float*>(out));
+        else
+            hipLaunchKernelGGL(k_scramble<uint8_t>, dim3(gx, rows), dim3(256), 0, h->stream, h->runs.p + first,
+                               h->seq.p, h->prefix, h->period, static_cast<const uint8_t*>(in),
+                               static_cast<uint8_t*>(out));
+    }
+    GR4PM_HIP_TRY(hipGetLastError());
+    GR4PM_HIP_TRY(hipStreamSynchronize(h->stream));
+    return GR4PM_OK;
+}
+
+gr4pm_status gr4pm_header_payload_split_create(const gr4pm_header_payload_split_params* p,
+                                               gr4pm_header_payload_split** out)
+{
+    if (!p || !out || p->header_size == 0) return GR4PM_ERR_INVALID;
+    *out = nullptr;
+    GR4PM_TRY(require_device());
+    auto* h = new (std::nothrow) gr4pm_header_payload_split;
+    if (!h) return GR4PM_ERR_NOMEM;
+    h->header_size = p->header_size;
+    h->stream = static_cast<hipStream_t>(p->stream);
+    *out = h;
+    return GR4PM_OK;
+}
+void gr4pm_header_payload_split_destroy(gr4pm_header_payload_split* h)
+{
+    if (!h) return;
+    (void)hipStreamSynchronize(h->stream);
+    delete h;
+}
+gr4pm_status gr4pm_header_payload_split_reset(gr4pm_header_payload_split* h)
+{
+    if (!h) return GR4PM_ERR_INVALID;
+    h->in_payload = false; // start(), :41-45
+    h->position = 0;
+    return GR4PM_OK;
+}
+gr4pm_status gr4pm_header_payload_split_process(gr4pm_header_payload_split* h, const float* in, size_t n,
+                                                float* header, size_t* n_header, float* payload,
+                                                size_t* n_payload, const gr4pm_packet_tag* tags_in,
+                                                size_t n_tags_in, gr4pm_packet_tag* header_tags,
+                                                size_t* n_header_tags, gr4pm_packet_tag* payload_tags,
+                                                size_t* n_payload_tags, size_t tags_cap)
+{
+    if (!h || !n_header || !n_payload) return GR4PM_ERR_INVALID;
+    *n_header = *n_payload = 0;
+    if (n_header_tags) *n_header_tags = 0;
+    if (n_payload_tags) *n_payload_tags = 0;
+    if (n == 0) return GR4PM_OK;
+    if (!in || !header || !payload) {
+        set_error("null sample pointer");
+        return GR4PM_ERR_INVALID;
+    }
+    std::vector<FSpan> hs, ps;
+    size_t pos = 0, hp = 0, pp = 0, t = 0, nht = 0, npt = 0;
+    bool overflow = false;
+    while (pos < n) {
+        while (t < n_tags_in && tags_in[t].index < pos) ++t;
+        size_t t1 = t;
+        while (t1 < n_tags_in && tags_in[t1].index == pos) ++t1;
+        const size_t end = t1 < n_tags_in ? std::min<size_t>(n, tags_in[t1].index) : n;
+        for (size_t u = t; u < t1; ++u) // :68-82
+            if (tags_in[u].kind == GR4PM_PKT_PAYLOAD) {
+                if (h->in_payload || h->position != h->header_size) {
+                    set_error("received unexpected payload_bits tag"); // :75-78
+                    return GR4PM_ERR_INVALID;
+                }
+                h->in_payload = true;
+                h->position = 0;
+                h->payload_items = tags_in[u].payload_bits;
+            }
+        for (size_t u = t; u < t1; ++u) { // :83-87
+            gr4pm_packet_tag o = tags_in[u];
+            if (h->in_payload) {
+                o.index = pp;
+                if (payload_tags && npt < tags_cap) payload_tags[npt] = o;
+                else overflow = true;
+                ++npt;
+            } else {
+                o.index = hp;
+                if (header_tags && nht < tags_cap) header_tags[nht] = o;
+                else overflow = true;
+                ++nht;
+            }
+        }
+        t = t1;
+        size_t cur = pos;
+        while (cur < end) {
+            if (!h->in_payload && h->position == h->header_size) h->position = 0; // :90-95
+            if (!h->in_payload) { // :97-109
+                const size_t m = std::min<size_t>(end - cur, h->header_size - h->position);
+                hs.push_back({ cur, hp, m });
+                hp += m;
+                cur += m;
+                h->position += m;
+            } else { // :110-123
+                const size_t m = std::min<size_t>(end - cur, static_cast<size_t>(h->payload_items - h->position));
+                ps.push_back({ cur, pp, m });
+                pp += m;
+                cur += m;
+                h->position += m;
+                if (h->position >= h->payload_items) {
+                    h->in_payload = false;
+                    h->position = 0;
+                }
+            }
+        }
+        pos = end;
+    }
+    // neighbouring spans of one output are contiguous on both sides: merge them
+    auto merge = [](std::vector<FSpan>& v) {
+        std::vector<FSpan> o;
+        for (const auto& s : v) {
+            if (s.len == 0) continue;
+            if (!o.empty() && o.back().src + o.back().len == s.src && o.back().dst + o.back().len == s.dst)
+                o.back().len += s.len;
+            else
+                o.push_back(s);
+        }
+        v.swap(o);
+    };
+    merge(hs);
+    merge(ps);
+    GR4PM_TRY(gather_f32(h->stream, h->hspans, hs, in, header));
+    GR4PM_TRY(gather_f32(h->stream, h->pspans, ps, in, payload));
+    GR4PM_HIP_TRY(hipStreamSynchronize(h->stream));
+    *n_header = hp;
+    *n_payload = pp;
+    if (n_header_tags) *n_header_tags = nht;
+    if (n_payload_tags) *n_payload_tags = npt;
+    if (overflow) {
+        set_error("tags_cap too small");
+        return GR4PM_ERR_OVERFLOW;
+    }
+    return GR4PM_OK;
+}
+
+gr4pm_status gr4pm_header_fec_decoder_create(const gr4pm_header_fec_decoder_params* p, gr4pm_header_fec_decoder** out)
+{
+    if (!p || !out || !p->alist) return GR4PM_ERR_INVALID;
+    *out = nullptr;
+    GR4PM_TRY(require_device());
+    // alist: n m / max column weight, max row weight / column weights / row weights /
+    // column lists / row lists (1-based, optionally zero-padded to the maximum weight)
+    std::vector<long> v;
+    for (const char* c = p->alist; *c;) {
+        if (*c >= '0' && *c <= '9') {
+            char* e;
+            v.push_back(std::strtol(c, &e, 10));
+            c = e;
+        } else {
+            ++c;
+        }
+    }
+    if (v.size() < 4 || v[0] <= 0 || v[1] <= 0 || v[0] > kMaxN || v[1] > kMaxM || v[3] > kMaxDeg || v[1] >= v[0] ||
+        (v[0] - v[1]) % 8 != 0 || v[0] - v[1] > 64) {
+        set_error("alist: unsupported code dimensions");
+        return GR4PM_ERR_INVALID;
+    }
+    const unsigned n = static_cast<unsigned>(v[0]), m = static_cast<unsigned>(v[1]);
+    const unsigned max_col = static_cast<unsigned>(v[2]), max_row = static_cast<unsigned>(v[3]);
+    if (v.size() < 4 + static_cast<size_t>(n) + m) {
+        set_error("alist: truncated");
+        return GR4PM_ERR_INVALID;
+    }
+    size_t i = 4;
+    std::vector<unsigned> colw(n), roww(m);
+    size_t total_col = 0, total_row = 0;
+    for (auto& w : colw) total_col += (w = static_cast<unsigned>(v[i++]));
+    for (auto& w : roww) total_row += (w = static_cast<unsigned>(v[i++]));
+    const size_t remaining = v.size() - i;
+    const bool padded = remaining == static_cast<size_t>(n) * max_col + static_cast<size_t>(m) * max_row;
+    if (!padded && remaining != total_col + total_row) {
+        set_error("alist: %zu list entries, expected %zu", remaining, total_col + total_row);
+        return GR4PM_ERR_INVALID;
+    }
+    i += padded ? static_cast<size_t>(n) * max_col : total_col;
+    std::vector<uint8_t> row_var(static_cast<size_t>(m) * kMaxDeg, 0xFF), row_deg(m, 0);
+    for (unsigned c = 0; c < m; ++c) {
+        const unsigned cnt = padded ? max_row : roww[c];
+        for (unsigned e = 0; e < cnt; ++e) {
+            const long x = v[i++];
+            if (x <= 0) continue;
+            if (x > static_cast<long>(n) || row_deg[c] >= kMaxDeg) {
+                set_error("alist: bad row entry");
+                return GR4PM_ERR_INVALID;
+            }
+            row_var[c * kMaxDeg + row_deg[c]++] = static_cast<uint8_t>(x - 1);
+        }
+    }
+    // steps: maximal runs of consecutive checks that share no variable, at most 64 edges
+    std::vector<uint16_t> sched;
+    unsigned c = 0;
+    while (c < m) {
+        std::vector<uint16_t> step(64, 0xFFFF);
+        std::vector<bool> used(n, false);
+        unsigned lanes = 0;
+        while (c < m) {
+            bool clash = lanes + row_deg[c] > 64;
+            for (unsigned e = 0; e < row_deg[c] && !clash; ++e) clash = used[row_var[c * kMaxDeg + e]];
+            if (clash) break;
+            for (unsigned e = 0; e < row_deg[c]; ++e) {
+                used[row_var[c * kMaxDeg + e]] = true;
+                step[lanes++] = static_cast<uint16_t>((c << 3) | e);
+            }
+            ++c;
+        }
+        sched.insert(sched.end(), step.begin(), step.end());
+    }
+    std::vector<float> corr(64);
+    for (int k = 0; k < 64; ++k) corr[k] = static_cast<float>(std::log1p(std::exp(-k / 8.0)));
+    auto* h = new (std::nothrow) gr4pm_header_fec_decoder;
+    if (!h) return GR4PM_ERR_NOMEM;
+    h->n = n;
+    h->m = m;
+    h->n_steps = static_cast<unsigned>(sched.size() / 64);
+    h->max_iterations = p->max_iterations;
+    h->stream = static_cast<hipStream_t>(p->stream);
+    gr4pm_status s = GR4PM_OK;
+    auto ok = [&](gr4pm_status r) {
+        if (s == GR4PM_OK) s = r;
+    };
+    ok(h->row_var.alloc(row_var.size()));
+    ok(h->row_deg.alloc(row_deg.size()));
+    ok(h->sched.alloc(sched.size()));
+    ok(h->corr.alloc(corr.size()));
+    if (s == GR4PM_OK) s = h->row_var.upload(row_var.data(), row_var.size(), h->stream);
+    if (s == GR4PM_OK) s = h->row_deg.upload(row_deg.data(), row_deg.size(), h->stream);
+    if (s == GR4PM_OK) s = h->sched.upload(sched.data(), sched.size(), h->stream);
+    if (s == GR4PM_OK) s = h->corr.upload(corr.data(), corr.size(), h->stream);
+    if (s == GR4PM_OK && hipStreamSynchronize(h->stream) != hipSuccess) s = GR4PM_ERR_HIP;
+    if (s != GR4PM_OK) {
+        delete h;
+        return s;
+    }
+    *out = h;
+    return GR4PM_OK;
+}
+void gr4pm_header_fec_decoder_destroy(gr4pm_header_fec_decoder* h)
+{
+    if (!h) return;
+    (void)hipStreamSynchronize(h->stream);
+    delete h;
+}
+gr4pm_status gr4pm_header_fec_decoder_process(gr4pm_header_fec_decoder* h, const float* llrs, size_t n_codewords,
+                                              uint8_t* headers, uint8_t* invalid)
+{
+    if (!h) return GR4PM_ERR_INVALID;
+    if (n_codewords == 0) return GR4PM_OK;
+    if (!llrs || !headers || !invalid) {
+        set_error("null pointer");
+        return GR4PM_ERR_INVALID;
+    }
+    const size_t hb = (h->n - h->m) / 8;
+    if (h->headers.n < n_codewords * hb) GR4PM_TRY(h->headers.alloc(n_codewords * hb * 2));
+    if (h->invalid.n < n_codewords) GR4PM_TRY(h->invalid.alloc(n_codewords * 2));
+    LdpcDev d{ h->row_var.p, h->row_deg.p, h->sched.p, h->corr.p, h->n, h->m, h->n_steps };
+    // the kernel writes its few bytes per codeword straight into pinned host memory
+    hipLaunchKernelGGL(k_header_fec, dim3(static_cast<unsigned>(n_codewords)), dim3(64), 0, h->stream, llrs,
+                       static_cast<unsigned>(n_codewords), d, h->max_iterations, 2 * h->n, h->headers.p,
+                       h->invalid.p);
+    GR4PM_HIP_TRY(hipGetLastError());
+    GR4PM_HIP_TRY(hipStreamSynchronize(h->stream));
+    std::copy_n(h->headers.p, n_codewords * hb, headers);
+    std::copy_n(h->invalid.p, n_codewords, invalid);
+    return GR4PM_OK;
+}
+
+void gr4pm_header_parse(const uint8_t* headers, const uint8_t* invalid, size_t n, gr4pm_header_msg* msgs,
+                        int32_t* packet_type)
+{
+    for (size_t i = 0; i < n; ++i) { // header_parser.hpp:56-85
+        const uint8_t* hd = headers + 4 * i;
+        bool valid = !(invalid && invalid[i]);
+        const uint64_t packet_length = (static_cast<uint64_t>(hd[0]) << 8) | hd[1];
+        if (packet_length == 0) valid = false;
+        if (hd[2] != 0x00 && hd[2] != 0x01) valid = false;
+        msgs[i].packet_length = valid ? packet_length : 0;
+        msgs[i].invalid_header = valid ? 0 : 1;
+        if (packet_type) packet_type[i] = valid ? hd[2] : -1;
+    }
+}
+
+} // extern "C"

@@ -411,6 +411,80 @@ gr4pm_status gr4pm_constellation_llr_decoder_process(gr4pm_constellation_llr_dec
                                                      gr4pm_packet_tag* tags_out, size_t tags_cap,
                                                      size_t* n_tags_out, size_t* produced);
 
+/* ====================================================================================
+ * Header decode loop (packet_receiver.hpp:131-139): descrambler ->
+ * header/payload split -> header FEC decoder -> header parser.  It produces the parsed_header
+ * messages SyncwordDetectionFilter and PayloadMetadataInsert wait for.
+ * ================================================================================== */
+
+/* ------------------------------------------------------------------------------------
+ * AdditiveScrambler<float | uint8_t> -- additive_scrambler.hpp:24-100
+ * ---------------------------------------------------------------------------------- */
+typedef struct gr4pm_additive_scrambler gr4pm_additive_scrambler;
+typedef struct {
+    uint64_t mask;   /* :61 */
+    uint64_t seed;   /* :62 */
+    uint64_t length; /* :63 */
+    uint64_t count;  /* :64, 0 = never reset by count */
+    int item_kind;   /* 1: float soft symbols (sign flip), 2: uint8_t hard symbols (XOR) */
+    void* stream;
+} gr4pm_additive_scrambler_params;
+gr4pm_status gr4pm_additive_scrambler_create(const gr4pm_additive_scrambler_params* params,
+                                             gr4pm_additive_scrambler** out);
+void gr4pm_additive_scrambler_destroy(gr4pm_additive_scrambler* h);
+gr4pm_status gr4pm_additive_scrambler_reset(gr4pm_additive_scrambler* h); /* start(), :68 */
+/* reset_index: host, sorted item indices that carry the reset_tag_key (:78-83) */
+gr4pm_status gr4pm_additive_scrambler_process(gr4pm_additive_scrambler* h, const void* in, size_t n,
+                                              void* out, const uint64_t* reset_index, size_t n_resets);
+
+/* ------------------------------------------------------------------------------------
+ * HeaderPayloadSplit<float> -- header_payload_split.hpp:9-147
+ * ---------------------------------------------------------------------------------- */
+typedef struct gr4pm_header_payload_split gr4pm_header_payload_split;
+typedef struct {
+    size_t header_size; /* :33 */
+    void* stream;
+} gr4pm_header_payload_split_params;
+gr4pm_status gr4pm_header_payload_split_create(const gr4pm_header_payload_split_params* params,
+                                               gr4pm_header_payload_split** out);
+void gr4pm_header_payload_split_destroy(gr4pm_header_payload_split* h);
+gr4pm_status gr4pm_header_payload_split_reset(gr4pm_header_payload_split* h); /* start(), :41-45 */
+/* GR4PM_PKT_PAYLOAD tags carry "payload_bits" (:70-82).  header / payload: device, each with
+ * room for n items.  Tags leave on the output their item goes to (:83-87).  A payload tag in
+ * the wrong place is the reference's exception (:75-78): GR4PM_ERR_INVALID. */
+gr4pm_status gr4pm_header_payload_split_process(gr4pm_header_payload_split* h, const float* in, size_t n,
+                                                float* header, size_t* n_header, float* payload,
+                                                size_t* n_payload, const gr4pm_packet_tag* tags_in,
+                                                size_t n_tags_in, gr4pm_packet_tag* header_tags,
+                                                size_t* n_header_tags, gr4pm_packet_tag* payload_tags,
+                                                size_t* n_payload_tags, size_t tags_cap);
+
+/* ------------------------------------------------------------------------------------
+ * HeaderFecDecoder -- header_fec_decoder.hpp:13-359: 256 LLRs (rate-1/2 repetition of a
+ * (128, 32) LDPC codeword) -> 4 header bytes, or "invalid_header".
+ * The reference hands the LDPC decoding to its Rust dependency ldpc-toolbox
+ * (ldpc_toolbox_decoder_ctor_alist_string(alist, "HLAminstari8", ""), :276, and
+ * ldpc_toolbox_decoder_decode_f32, :315-321, 25 iterations).  `alist` is that same string.
+ * ---------------------------------------------------------------------------------- */
+typedef struct gr4pm_header_fec_decoder gr4pm_header_fec_decoder;
+typedef struct {
+    const char* alist;       /* parity-check matrix, alist text (:31-258) */
+    uint32_t max_iterations; /* :314, 25 */
+    void* stream;
+} gr4pm_header_fec_decoder_params;
+gr4pm_status gr4pm_header_fec_decoder_create(const gr4pm_header_fec_decoder_params* params,
+                                             gr4pm_header_fec_decoder** out);
+void gr4pm_header_fec_decoder_destroy(gr4pm_header_fec_decoder* h);
+/* llrs: device, 256 per codeword.  headers: host, 4 bytes per codeword; invalid: host, one
+ * flag per codeword (the "invalid_header" tag of :322-326). */
+gr4pm_status gr4pm_header_fec_decoder_process(gr4pm_header_fec_decoder* h, const float* llrs,
+                                              size_t n_codewords, uint8_t* headers, uint8_t* invalid);
+
+/* HeaderParser -- header_parser.hpp:46-95 (host): 4 bytes (+ the decoder's verdict) -> the
+ * parsed_header message; packet_type: 0 USER_DATA, 1 IDLE, -1 when invalid. */
+void gr4pm_header_parse(const uint8_t* headers, const uint8_t* invalid, size_t n, gr4pm_header_msg* msgs,
+                        int32_t* packet_type);
+
 /* firdes::root_raised_cosine<float> -- firdes.hpp:29-76 (host helper; out: ntaps|1 floats) */
 size_t gr4pm_firdes_root_raised_cosine(double gain, double sampling_freq, double symbol_rate,
                                        double alpha, size_t ntaps, float* out);

@@ -1404,4 +1404,270 @@ size_t orc_llr_process(orc_llr* d, const orc_c64* in_, size_t n, float* out, con
     return oi;
 }
 
+
+/* --------------------------------------------- additive_scrambler.hpp:45-100 */
+struct orc_scr {
+    uint64_t mask, seed, length, count;
+    uint64_t reg, current_count;
+};
+orc_scr* orc_scr_create(uint64_t mask, uint64_t seed, uint64_t length, uint64_t count)
+{
+    auto* s = new orc_scr{ mask, seed, length, count, seed, 0 }; /* start(): reset_lfsr(), :68-74 */
+    return s;
+}
+void orc_scr_destroy(orc_scr* s) { delete s; }
+static inline uint8_t scr_step(orc_scr* s, bool tag_reset)
+{
+    if (tag_reset || (s->count != 0 && s->current_count == s->count)) { /* :78-83 */
+        s->reg = s->seed;
+        s->current_count = 0;
+    }
+    const uint8_t lfsr_bit = s->reg & 1; /* :84-87 */
+    const uint64_t shift_in = static_cast<uint64_t>(__builtin_parityl(s->reg & s->mask));
+    s->reg = (shift_in << s->length) | (s->reg >> 1);
+    ++s->current_count;
+    return lfsr_bit;
+}
+void orc_scr_process_f32(orc_scr* s, const float* in, size_t n, float* out, const uint64_t* reset_index,
+                         size_t n_resets)
+{
+    size_t t = 0;
+    for (size_t j = 0; j < n; ++j) {
+        while (t < n_resets && reset_index[t] < j) ++t;
+        const bool reset = t < n_resets && reset_index[t] == j;
+        out[j] = scr_step(s, reset) ? -in[j] : in[j]; /* :92-93 */
+    }
+}
+void orc_scr_process_u8(orc_scr* s, const uint8_t* in, size_t n, uint8_t* out, const uint64_t* reset_index,
+                        size_t n_resets)
+{
+    size_t t = 0;
+    for (size_t j = 0; j < n; ++j) {
+        while (t < n_resets && reset_index[t] < j) ++t;
+        const bool reset = t < n_resets && reset_index[t] == j;
+        out[j] = in[j] ^ scr_step(s, reset); /* :90 */
+    }
+}
+
+/* ------------------------------------------ header_payload_split.hpp:25-135 */
+struct orc_hps {
+    size_t header_size;
+    bool in_payload = false;   /* :25 */
+    uint64_t position = 0;     /* :26 */
+    uint64_t payload_items = 0; /* :27 */
+};
+orc_hps* orc_hps_create(size_t header_size)
+{
+    auto* h = new orc_hps;
+    h->header_size = header_size;
+    return h;
+}
+void orc_hps_destroy(orc_hps* h) { delete h; }
+int orc_hps_process(orc_hps* h, const float* in, size_t n, float* header, size_t* n_header, float* payload,
+                    size_t* n_payload, const orc_ptag* tags, size_t n_tags, orc_ptag* header_tags,
+                    size_t* n_header_tags, orc_ptag* payload_tags, size_t* n_payload_tags, size_t tags_cap)
+{
+    size_t pos = 0, hp = 0, pp = 0, t = 0, nht = 0, npt = 0;
+    while (pos < n) {
+        /* one processBulk() call (:51-135): chunk = [pos, next tag) -- and the block handles one
+         * of the two outputs per call, so a chunk may take several calls */
+        while (t < n_tags && tags[t].index < pos) ++t;
+        size_t t1 = t;
+        while (t1 < n_tags && tags[t1].index == pos) ++t1;
+        const size_t end = t1 < n_tags ? std::min<size_t>(n, tags[t1].index) : n;
+        for (size_t u = t; u < t1; ++u) { /* :68-88 */
+            if (tags[u].kind == 3) {
+                if (h->in_payload || h->position != h->header_size) return -1;
+                h->in_payload = true;
+                h->position = 0;
+                h->payload_items = tags[u].payload_bits;
+            }
+        }
+        for (size_t u = t; u < t1; ++u) {
+            orc_ptag o = tags[u];
+            if (h->in_payload) {
+                o.index = pp;
+                if (payload_tags && npt < tags_cap) payload_tags[npt] = o;
+                ++npt;
+            } else {
+                o.index = hp;
+                if (header_tags && nht < tags_cap) header_tags[nht] = o;
+                ++nht;
+            }
+        }
+        t = t1;
+        size_t cur = pos;
+        while (cur < end) {
+            if (!h->in_payload && h->position == h->header_size) h->position = 0; /* :90-95 */
+            if (!h->in_payload) { /* :97-109 */
+                const size_t m = std::min<size_t>(end - cur, h->header_size - h->position);
+                std::copy_n(in + cur, m, header + hp);
+                hp += m;
+                cur += m;
+                h->position += m;
+            } else { /* :110-123 */
+                const size_t m = std::min<size_t>(end - cur, h->payload_items - h->position);
+                std::copy_n(in + cur, m, payload + pp);
+                pp += m;
+                cur += m;
+                h->position += m;
+                if (h->position >= h->payload_items) {
+                    h->in_payload = false;
+                    h->position = 0;
+                }
+            }
+        }
+        pos = end;
+    }
+    *n_header = hp;
+    *n_payload = pp;
+    if (n_header_tags) *n_header_tags = nht;
+    if (n_payload_tags) *n_payload_tags = npt;
+    return 0;
+}
+
+/* ------------------------------------------- header_fec_encoder.hpp:60-107 */
+void orc_header_fec_encode(const uint32_t* generator, const uint8_t* in, size_t n_codewords, uint8_t* out)
+{
+    for (size_t c = 0; c < n_codewords; ++c, in += 4, out += 32) {
+        std::copy_n(in, 4, out); /* systematic, :80-81 */
+        const uint32_t info = (static_cast<uint32_t>(in[0]) << 24) | (static_cast<uint32_t>(in[1]) << 16) |
+                              (static_cast<uint32_t>(in[2]) << 8) | static_cast<uint32_t>(in[3]);
+        for (int k = 0; k < 12; ++k) { /* :86-96 */
+            uint8_t parity_bits = 0;
+            for (int l = 0; l < 8; ++l)
+                parity_bits = static_cast<uint8_t>(parity_bits << 1) |
+                              static_cast<uint8_t>(__builtin_parity(info & generator[8 * k + l]));
+            out[4 + k] = parity_bits;
+        }
+        std::copy_n(out, 16, out + 16); /* repetition, :98-99 */
+    }
+}
+
+/* -------- LDPC: horizontal layered A-Min*-BP (restated family of ldpc-toolbox "HLAminstar") */
+struct orc_ldpc {
+    unsigned n = 0, m = 0;
+    std::vector<std::vector<unsigned>> rows; /* variable indices of every check */
+    float corr[64];                          /* ln(1 + e^-x), x = i / 8 */
+};
+orc_ldpc* orc_ldpc_create(const char* alist)
+{
+    std::vector<long> v;
+    for (const char* p = alist; *p;) {
+        if ((*p >= '0' && *p <= '9')) {
+            char* e;
+            v.push_back(std::strtol(p, &e, 10));
+            p = e;
+        } else {
+            ++p;
+        }
+    }
+    if (v.size() < 4) return nullptr;
+    auto* d = new orc_ldpc;
+    d->n = static_cast<unsigned>(v[0]);
+    d->m = static_cast<unsigned>(v[1]);
+    const unsigned max_col = static_cast<unsigned>(v[2]), max_row = static_cast<unsigned>(v[3]);
+    size_t i = 4;
+    std::vector<unsigned> colw(d->n), roww(d->m);
+    for (auto& w : colw) w = static_cast<unsigned>(v[i++]);
+    for (auto& w : roww) w = static_cast<unsigned>(v[i++]);
+    /* column lists: skipped (either exactly the weight or padded to max_col with zeros) */
+    size_t total_col = 0;
+    for (auto w : colw) total_col += w;
+    const size_t remaining = v.size() - i;
+    size_t total_row = 0;
+    for (auto w : roww) total_row += w;
+    const bool padded = remaining == static_cast<size_t>(d->n) * max_col + static_cast<size_t>(d->m) * max_row;
+    i += padded ? static_cast<size_t>(d->n) * max_col : total_col;
+    d->rows.resize(d->m);
+    for (unsigned c = 0; c < d->m; ++c) {
+        const unsigned cnt = padded ? max_row : roww[c];
+        for (unsigned e = 0; e < cnt; ++e) {
+            const long x = v[i++];
+            if (x > 0) d->rows[c].push_back(static_cast<unsigned>(x - 1));
+        }
+    }
+    for (int k = 0; k < 64; ++k) d->corr[k] = static_cast<float>(std::log1p(std::exp(-k / 8.0)));
+    return d;
+}
+void orc_ldpc_destroy(orc_ldpc* d) { delete d; }
+static inline float ldpc_corr(const orc_ldpc* d, float x) /* x >= 0 */
+{
+    return x >= 8.0f ? 0.0f : d->corr[static_cast<int>(x * 8.0f)];
+}
+/* |a| [+] |b| in the magnitude domain */
+static inline float ldpc_boxplus(const orc_ldpc* d, float a, float b)
+{
+    const float mn = a < b ? a : b;
+    const float r = mn + ldpc_corr(d, a + b) - ldpc_corr(d, a < b ? b - a : a - b);
+    return r > 0.0f ? r : 0.0f;
+}
+int orc_ldpc_decode(orc_ldpc* d, const float* llrs, uint8_t* bits_k, unsigned max_iterations)
+{
+    const unsigned k = d->n - d->m;
+    std::vector<float> P(llrs, llrs + d->n);
+    std::vector<std::vector<float>> R(d->m);
+    for (unsigned c = 0; c < d->m; ++c) R[c].assign(d->rows[c].size(), 0.0f);
+    auto is_codeword = [&]() {
+        for (unsigned c = 0; c < d->m; ++c) {
+            unsigned parity = 0;
+            for (unsigned v : d->rows[c]) parity ^= P[v] < 0.0f ? 1u : 0u;
+            if (parity) return false;
+        }
+        return true;
+    };
+    int used = -1;
+    for (unsigned it = 0; it <= max_iterations; ++it) {
+        if (is_codeword()) {
+            used = static_cast<int>(it);
+            break;
+        }
+        if (it == max_iterations) break;
+        for (unsigned c = 0; c < d->m; ++c) { /* one layer = one check */
+            const auto& vs = d->rows[c];
+            const size_t dc = vs.size();
+            float Q[16] = {};
+            unsigned neg = 0;
+            size_t imin = 0;
+            for (size_t e = 0; e < dc; ++e) {
+                Q[e] = P[vs[e]] - R[c][e];
+                if (Q[e] < 0.0f) neg ^= 1u;
+                if (std::fabs(Q[e]) < std::fabs(Q[imin])) imin = e;
+            }
+            float others = -1.0f; /* [+] over all edges but the minimum */
+            for (size_t e = 0; e < dc; ++e) {
+                if (e == imin) continue;
+                const float a = std::fabs(Q[e]);
+                others = others < 0.0f ? a : ldpc_boxplus(d, others, a);
+            }
+            if (others < 0.0f) others = 0.0f; /* degree-1 check */
+            const float all = ldpc_boxplus(d, others, std::fabs(Q[imin]));
+            for (size_t e = 0; e < dc; ++e) {
+                const float mag = e == imin ? others : all;
+                const unsigned s = neg ^ (Q[e] < 0.0f ? 1u : 0u);
+                const float r = s ? -mag : mag;
+                R[c][e] = r;
+                P[vs[e]] = Q[e] + r;
+            }
+        }
+    }
+    for (unsigned b = 0; b < k; ++b) bits_k[b] = P[b] < 0.0f ? 1 : 0;
+    return used;
+}
+void orc_header_fec_decode(orc_ldpc* d, const float* llrs, size_t n_codewords, uint8_t* bytes, uint8_t* invalid)
+{
+    for (size_t c = 0; c < n_codewords; ++c, llrs += 256) {
+        float acc[128];
+        for (int k = 0; k < 128; ++k) acc[k] = llrs[k] + llrs[128 + k]; /* :308-312 */
+        uint8_t bits[32];
+        const int ret = orc_ldpc_decode(d, acc, bits, 25); /* :315-321 */
+        invalid[c] = ret < 0 ? 1 : 0;
+        for (int k = 0; k < 4; ++k) { /* :329-335 */
+            uint8_t byte = 0;
+            for (int b = 0; b < 8; ++b) byte = static_cast<uint8_t>(byte << 1) | bits[8 * k + b];
+            bytes[4 * c + k] = byte;
+        }
+    }
+}
+
 } /* extern "C" */

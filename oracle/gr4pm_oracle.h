@@ -203,6 +203,47 @@ void orc_llr_destroy(orc_llr*);
 size_t orc_llr_process(orc_llr*, const orc_c64* in, size_t n, float* out, const orc_ptag* tags_in,
                        size_t n_tags_in, orc_ptag* tags_out, size_t tags_cap, size_t* n_tags_out);
 
+/* ==== header decode loop (packet_receiver.hpp:131-139) ==== */
+
+/* ---- AdditiveScrambler<float|uint8_t> (additive_scrambler.hpp:58-100): LFSR (mask, seed,
+ * length) as in GNU Radio 3.10; soft symbols change sign where the LFSR bit is 1, hard symbols
+ * are XORed.  Reset by `count` items or at the items listed in reset_index (reset_tag_key). ---- */
+typedef struct orc_scr orc_scr;
+orc_scr* orc_scr_create(uint64_t mask, uint64_t seed, uint64_t length, uint64_t count);
+void orc_scr_destroy(orc_scr*);
+void orc_scr_process_f32(orc_scr*, const float* in, size_t n, float* out, const uint64_t* reset_index,
+                         size_t n_resets);
+void orc_scr_process_u8(orc_scr*, const uint8_t* in, size_t n, uint8_t* out, const uint64_t* reset_index,
+                        size_t n_resets);
+
+/* ---- HeaderPayloadSplit<float> (header_payload_split.hpp:38-135): whole-stream driver.
+ * tags: orc_ptag; kind 3 carries "payload_bits".  Returns 0, or -1 for the "received
+ * unexpected payload_bits tag" exception (:75-78). ---- */
+typedef struct orc_hps orc_hps;
+orc_hps* orc_hps_create(size_t header_size);
+void orc_hps_destroy(orc_hps*);
+int orc_hps_process(orc_hps*, const float* in, size_t n, float* header, size_t* n_header, float* payload,
+                    size_t* n_payload, const orc_ptag* tags, size_t n_tags, orc_ptag* header_tags,
+                    size_t* n_header_tags, orc_ptag* payload_tags, size_t* n_payload_tags, size_t tags_cap);
+
+/* ---- HeaderFecEncoder (header_fec_encoder.hpp:60-107): 4 bytes -> 32 bytes; `generator` = the
+ * 96 rows of the dense generator (tests/golden/header_ldpc_generator.npy) ---- */
+void orc_header_fec_encode(const uint32_t* generator, const uint8_t* in, size_t n_codewords, uint8_t* out);
+
+/* ---- HeaderFecDecoder (header_fec_decoder.hpp:290-347): 256 LLRs -> 4 bytes + invalid flag.
+ * The LDPC decoder itself lives in the reference's Rust dependency ldpc-toolbox (absent from
+ * /root/reference; decoder implementation "HLAminstari8", :276): restated here as the
+ * horizontal-layered A-Min*-BP schedule in float32 with the correction term ln(1+e^-x) tabulated
+ * in steps of 1/8 -- NOT its 8-bit arithmetic: parity with the reference decoder is pinned only
+ * on the reference's own QA vectors (valid codewords decode, random words are rejected). ---- */
+typedef struct orc_ldpc orc_ldpc;
+orc_ldpc* orc_ldpc_create(const char* alist);
+void orc_ldpc_destroy(orc_ldpc*);
+/* returns iterations used (0 = the input already was a codeword), -1 = no codeword found */
+int orc_ldpc_decode(orc_ldpc*, const float* llrs, uint8_t* bits_k, unsigned max_iterations);
+void orc_header_fec_decode(orc_ldpc*, const float* llrs, size_t n_codewords, uint8_t* bytes,
+                           uint8_t* invalid);
+
 #ifdef __cplusplus
 }
 #endif

@@ -157,6 +157,22 @@ def lib():
         L.orc_llr_destroy.argtypes = [vp]
         L.orc_llr_process.restype = sz
         L.orc_llr_process.argtypes = [vp, vp, sz, vp, vp, sz, vp, sz, szp]
+        u64 = C.c_uint64
+        L.orc_scr_create.restype = vp
+        L.orc_scr_create.argtypes = [u64, u64, u64, u64]
+        L.orc_scr_destroy.argtypes = [vp]
+        L.orc_scr_process_f32.argtypes = [vp, vp, sz, vp, vp, sz]
+        L.orc_scr_process_u8.argtypes = [vp, vp, sz, vp, vp, sz]
+        L.orc_hps_create.restype = vp
+        L.orc_hps_create.argtypes = [sz]
+        L.orc_hps_destroy.argtypes = [vp]
+        L.orc_hps_process.argtypes = [vp, vp, sz, vp, szp, vp, szp, vp, sz, vp, szp, vp, szp, sz]
+        L.orc_header_fec_encode.argtypes = [vp, vp, sz, vp]
+        L.orc_ldpc_create.restype = vp
+        L.orc_ldpc_create.argtypes = [C.c_char_p]
+        L.orc_ldpc_destroy.argtypes = [vp]
+        L.orc_ldpc_decode.argtypes = [vp, vp, vp, C.c_uint]
+        L.orc_header_fec_decode.argtypes = [vp, vp, sz, vp, vp]
     return _lib
 
 
@@ -410,6 +426,103 @@ class ConstellationLLRDecoder:
         if getattr(self, "_h", None):
             lib().orc_llr_destroy(self._h)
             self._h = None
+
+
+class AdditiveScrambler:
+    """additive_scrambler.hpp:58-100 (float soft symbols or uint8 hard symbols)"""
+
+    def __init__(self, mask=0x8A, seed=0x7F, length=7, count=0):
+        self._h = lib().orc_scr_create(mask, seed, length, count)
+
+    def process(self, x, reset_index=()):
+        ri = np.ascontiguousarray(reset_index, dtype=np.uint64)
+        if np.asarray(x).dtype == np.uint8:
+            x = np.ascontiguousarray(x, dtype=np.uint8)
+            out = np.empty_like(x)
+            lib().orc_scr_process_u8(self._h, _p(x), x.size, _p(out), _p(ri), ri.size)
+        else:
+            x = _f32(x)
+            out = np.empty_like(x)
+            lib().orc_scr_process_f32(self._h, _p(x), x.size, _p(out), _p(ri), ri.size)
+        return out
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_scr_destroy(self._h)
+            self._h = None
+
+
+class HeaderPayloadSplit:
+    """header_payload_split.hpp:38-135 on float items; tags: PTAG_DTYPE (kind 3 = payload_bits)"""
+
+    def __init__(self, header_size=256):
+        self._h = lib().orc_hps_create(header_size)
+
+    def process(self, x, tags):
+        x = _f32(x)
+        tags = np.ascontiguousarray(tags, dtype=PTAG_DTYPE)
+        header, payload = np.empty_like(x), np.empty_like(x)
+        ht, pt = np.zeros(tags.size + 1, dtype=PTAG_DTYPE), np.zeros(tags.size + 1, dtype=PTAG_DTYPE)
+        v = [C.c_size_t(0) for _ in range(4)]
+        rc = lib().orc_hps_process(self._h, _p(x), x.size, _p(header), C.byref(v[0]), _p(payload), C.byref(v[1]),
+                                   _p(tags), tags.size, _p(ht), C.byref(v[2]), _p(pt), C.byref(v[3]), tags.size + 1)
+        if rc != 0:
+            raise ValueError("received unexpected payload_bits tag")
+        return header[: v[0].value], payload[: v[1].value], ht[: v[2].value], pt[: v[3].value]
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_hps_destroy(self._h)
+            self._h = None
+
+
+def header_fec_encode(header_bytes, generator):
+    """header_fec_encoder.hpp:60-107: [n, 4] bytes -> [n, 32] bytes"""
+    h = np.ascontiguousarray(header_bytes, dtype=np.uint8).reshape(-1, 4)
+    g = np.ascontiguousarray(generator, dtype=np.uint32)
+    out = np.empty((h.shape[0], 32), dtype=np.uint8)
+    lib().orc_header_fec_encode(_p(g), _p(h), h.shape[0], _p(out))
+    return out
+
+
+class HeaderFecDecoder:
+    """header_fec_decoder.hpp:290-347 with the LDPC decoder restated (see gr4pm_oracle.h)"""
+
+    def __init__(self, alist):
+        self._h = lib().orc_ldpc_create(alist.encode())
+        assert self._h
+
+    def process(self, llrs):
+        x = _f32(llrs)
+        n = x.size // 256
+        out = np.empty((n, 4), dtype=np.uint8)
+        inval = np.empty(n, dtype=np.uint8)
+        lib().orc_header_fec_decode(self._h, _p(x), n, _p(out), _p(inval))
+        return out, inval.astype(bool)
+
+    def decode(self, llrs, max_iterations=25):
+        x = _f32(llrs)
+        bits = np.empty(32, dtype=np.uint8)
+        it = lib().orc_ldpc_decode(self._h, _p(x), _p(bits), max_iterations)
+        return bits, it
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_ldpc_destroy(self._h)
+            self._h = None
+
+
+def header_format(packet_length, packet_type=0):
+    """header_formatter.hpp:104-107: big-endian length, type (0 user data, 1 idle), spare 0x55"""
+    return np.array([(packet_length >> 8) & 0xFF, packet_length & 0xFF, packet_type, 0x55], dtype=np.uint8)
+
+
+def header_parse(header, invalid=False):
+    """header_parser.hpp:56-85: packet_length or None (invalid_header)"""
+    length = (int(header[0]) << 8) | int(header[1])
+    if invalid or length == 0 or header[2] not in (0, 1):
+        return None
+    return length
 
 
 def syncword_wipeoff(x, syncword, tag_index):

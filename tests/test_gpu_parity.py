@@ -4,6 +4,8 @@ seeded inputs, plus the reference's own qa_*.cpp expectations re-run on the GPU 
 Bars: indices / freq_bin / pass-through / FIR outputs bit-exact; FFT-derived float tag
 values within 1e-4 relative (FFTW's own bits are unpinned, see oracle/gr4pm_oracle.h);
 recurrences (rotator, CFC) bit-exact; Costas within 1e-5 (device sincos vs glibc)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -1069,3 +1071,123 @@ def test_symbol_rate_chain_to_llrs(pkg):
         hard = (llr[p:p + 2 * b.shape[0]] < 0).astype(int).reshape(-1, 2)
         assert np.array_equal(hard[64:], b[64:])   # the loop has settled after the first symbols
         p += 2 * b.shape[0]
+
+
+# ------------------------------------------------------------------ header decode loop
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_additive_scrambler(pkg):
+    """test/qa_additive_scrambler.cpp:26-112 through the C-ABI (hard and soft symbols), resets by tag
+    and by count, state carried across calls; bit-exact against the oracle"""
+    ccsds = np.load(os.path.join(GOLDEN, "qa_ccsds_scrambling_sequence.npy"))
+    rng = np.random.default_rng(1)
+    x = rng.integers(0, 2, 100000).astype(np.uint8)
+    y = pkg.AdditiveScrambler(0xA9, 0xFF, 7, dtype="uint8").process_bulk(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert np.array_equal(y, x ^ ccsds[np.arange(x.size) % 255])
+    first40 = np.load(os.path.join(GOLDEN, "qa_ccsds_2023_first40.npy"))
+    z = pkg.AdditiveScrambler(0x4001, 0x18E38, 16, dtype="uint8").process_bulk(torch.zeros(40, dtype=torch.uint8).cuda())
+    assert np.array_equal(z.cpu().numpy(), first40)
+    z = pkg.AdditiveScrambler(0xA9, 0xFF, 7, dtype="uint8").process_bulk(torch.zeros(100000, dtype=torch.uint8).cuda(),
+                                                                          np.arange(0, 100000, 100))
+    assert np.array_equal(z.cpu().numpy(), ccsds[np.arange(100000) % 100])
+    # the receiver's descrambler (packet_receiver.hpp:131-135) on soft symbols, in pieces, vs the oracle
+    llr = rng.standard_normal(300000).astype(np.float32)
+    resets = np.sort(rng.choice(300000, 40, replace=False))
+    want = orc.AdditiveScrambler(0x4001, 0x18E38, 16).process(llr, resets)
+    gpu = pkg.AdditiveScrambler(0x4001, 0x18E38, 16)
+    got, pos = [], 0
+    for m in [1, 70000, 131071, 98928]:
+        r = resets[(resets >= pos) & (resets < pos + m)] - pos
+        got.append(gpu.process_bulk(torch.from_numpy(llr[pos:pos + m]).cuda(), r).cpu().numpy())
+        pos += m
+    assert pos == llr.size and np.concatenate(got).tobytes() == want.tobytes()
+    c = pkg.AdditiveScrambler(0xA9, 0xFF, 7, count=100).process_bulk(torch.ones(1000).cuda()).cpu().numpy()
+    assert np.array_equal(c, 1.0 - 2.0 * ccsds[np.arange(1000) % 100])
+
+
+@pytest.mark.parametrize("header_size,payload_bits", [(256, 1500), (128, 1500), (256, 1), (64, 17321)])
+def test_header_payload_split(pkg, header_size, payload_bits):
+    """test/qa_header_payload_split.cpp:14-57"""
+    v = np.arange(header_size + payload_bits).astype(np.float32)
+    tags = np.zeros(1, dtype=pkg.PACKET_TAG_DTYPE)
+    tags["index"], tags["kind"], tags["payload_bits"] = header_size, pkg.PKT_PAYLOAD, payload_bits
+    h, p, ht, pt = pkg.HeaderPayloadSplit(header_size).process_bulk(torch.from_numpy(v).cuda(), tags)
+    assert np.array_equal(h.cpu().numpy(), v[:header_size]) and np.array_equal(p.cpu().numpy(), v[header_size:])
+    assert ht.size == 0 and pt.size == 1 and pt[0]["index"] == 0
+
+
+def test_header_payload_split_stream_vs_oracle(pkg):
+    """packets back to back, failed headers (no payload tag), chunked calls with carried state"""
+    rng = np.random.default_rng(6)
+    items, tags, pos = [], [], 0
+    for k in range(60):
+        items.append(rng.standard_normal(256).astype(np.float32))
+        pos += 256
+        t = np.zeros(1, dtype=pkg.PACKET_TAG_DTYPE)
+        t["index"], t["kind"] = pos - 256, pkg.PKT_HEADER_START
+        tags.append(t)
+        if k % 5 != 3:   # header decoded: a payload follows
+            n = int(rng.integers(1, 3000))
+            t = np.zeros(1, dtype=pkg.PACKET_TAG_DTYPE)
+            t["index"], t["kind"], t["payload_bits"] = pos, pkg.PKT_PAYLOAD, n
+            tags.append(t)
+            items.append(rng.standard_normal(n).astype(np.float32))
+            pos += n
+    x, tags = np.concatenate(items), np.concatenate(tags)
+    gpu, ref = pkg.HeaderPayloadSplit(256), orc.HeaderPayloadSplit(256)
+    p0 = 0
+    while p0 < x.size:
+        m = min(int(rng.integers(1, 20000)), x.size - p0)
+        tt = tags[(tags["index"] >= p0) & (tags["index"] < p0 + m)].copy()
+        tt["index"] -= p0
+        h, p, ht, pt = gpu.process_bulk(torch.from_numpy(x[p0:p0 + m]).cuda(), tt)
+        wh, wp, wht, wpt = ref.process(x[p0:p0 + m], tt)
+        assert h.cpu().numpy().tobytes() == wh.tobytes() and p.cpu().numpy().tobytes() == wp.tobytes()
+        assert same_ptags(ht, wht) and same_ptags(pt, wpt)
+        p0 += m
+    bad = np.zeros(1, dtype=pkg.PACKET_TAG_DTYPE)
+    bad["index"], bad["kind"], bad["payload_bits"] = 10, pkg.PKT_PAYLOAD, 5
+    with pytest.raises(pkg.Gr4pmError):
+        pkg.HeaderPayloadSplit(256).process_bulk(torch.zeros(100).cuda(), bad)
+
+
+def test_header_fec_decoder_reference_qa(pkg):
+    """test/qa_header_fec_decoder.cpp:16-101 through the C-ABI"""
+    gen = np.load(os.path.join(GOLDEN, "header_ldpc_generator.npy"))
+    v = np.load(os.path.join(GOLDEN, "qa_header_fec_valid_bytes.npy"))
+    llr = 1.0 - 2.0 * np.unpackbits(orc.header_fec_encode(v, gen).ravel()).astype(np.float32)
+    dec = pkg.HeaderFecDecoder()
+    out, invalid = dec.process_bulk(torch.from_numpy(llr).cuda())
+    assert np.array_equal(out.ravel(), v) and not invalid.any()
+    r = np.load(os.path.join(GOLDEN, "qa_header_fec_random_bytes.npy"))
+    out, invalid = dec.process_bulk(torch.from_numpy(1.0 - 2.0 * np.unpackbits(r).astype(np.float32)).cuda())
+    assert out.shape == (8, 4) and invalid.all()
+    msgs, ptype = pkg.header_parse(out, invalid)
+    assert msgs["invalid_header"].all() and (ptype == -1).all()
+
+
+def test_header_fec_decoder_noisy_vs_oracle(pkg):
+    """4000 headers at Es/N0 = 0 dB and -3 dB: decoded bytes and verdicts identical to the oracle's
+    (same schedule, same arithmetic), parser agrees with header_parser.hpp:56-85"""
+    gen = np.load(os.path.join(GOLDEN, "header_ldpc_generator.npy"))
+    rng = np.random.default_rng(12)
+    n = 4000
+    lengths = rng.integers(0, 65536, n)
+    types = rng.integers(0, 3, n)
+    hdr = np.stack([orc.header_format(int(a), int(t)) for a, t in zip(lengths, types)])
+    bits = np.unpackbits(orc.header_fec_encode(hdr, gen).ravel()).astype(np.float32).reshape(n, 256)
+    sigma = np.where(np.arange(n) % 2 == 0, np.sqrt(0.5), 1.0)[:, None]
+    y = (1.0 - 2.0 * bits) * np.sqrt(0.5) + sigma * rng.standard_normal(bits.shape)
+    llr = (2.0 / 0.7**2 * y).astype(np.float32).ravel()    # the receiver's fixed noise_sigma, packet_receiver.hpp:129
+    want, want_inv = orc.HeaderFecDecoder(pkg.header_ldpc_alist()).process(llr)
+    got, got_inv = pkg.HeaderFecDecoder().process_bulk(torch.from_numpy(llr).cuda())
+    assert np.array_equal(got_inv, want_inv) and np.array_equal(got, want)
+    ok = ~got_inv
+    assert ok[0::2].mean() > 0.95 and np.array_equal(got[ok], hdr[ok])
+    msgs, ptype = pkg.header_parse(got, got_inv)
+    for m, pt, h, bad in zip(msgs, ptype, got, got_inv):
+        want_len = orc.header_parse(h, bad)
+        assert (m["invalid_header"] == 1) == (want_len is None)
+        if want_len is not None:
+            assert m["packet_length"] == want_len and pt == h[2]
