@@ -152,7 +152,8 @@ EXPORTS = [
     "gr4pm_syncword_detection_hint_next",
     "gr4pm_syncword_detection_filter_create", "gr4pm_syncword_detection_filter_destroy",
     "gr4pm_syncword_detection_filter_reset", "gr4pm_syncword_detection_filter_process",
-    "gr4pm_syncword_detection_filter_gate",
+    "gr4pm_syncword_detection_filter_gate", "gr4pm_syncword_detection_filter_gate_resolve",
+    "gr4pm_payload_metadata_insert_resolve",
     "gr4pm_rotator_create", "gr4pm_rotator_destroy", "gr4pm_rotator_reset", "gr4pm_rotator_process",
     "gr4pm_costas_loop_create", "gr4pm_costas_loop_destroy", "gr4pm_costas_loop_reset",
     "gr4pm_costas_loop_coeffs", "gr4pm_costas_loop_set", "gr4pm_costas_loop_process",
@@ -262,6 +263,8 @@ def lib():
     L.gr4pm_payload_metadata_insert_process.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, sz, C.c_int, vp, sz,
                                                         szp, szp, szp, szp, szp]
     L.gr4pm_costas_loop_process_packets.argtypes = [vp, vp, sz, vp, vp, sz]
+    L.gr4pm_syncword_detection_filter_gate_resolve.argtypes = [vp, vp]
+    L.gr4pm_payload_metadata_insert_resolve.argtypes = [vp, vp]
     L.gr4pm_syncword_remove_create.argtypes = [C.POINTER(SyncwordRemoveParams), C.POINTER(vp)]
     L.gr4pm_syncword_remove_destroy.argtypes = [vp]
     L.gr4pm_syncword_remove_destroy.restype = None

@@ -220,7 +220,9 @@ class SyncwordDetectionFilter:
         None for invalid_header."""
         idx = np.ascontiguousarray(tag_index, dtype=np.uint64)
         msgs = np.zeros(max(len(headers), 1), dtype=_abi.HEADER_MSG_DTYPE)
-        if len(headers):
+        if isinstance(headers, np.ndarray) and headers.dtype == _abi.HEADER_MSG_DTYPE:
+            msgs = _header_msgs(headers)[0]
+        elif len(headers):
             if isinstance(headers, np.ndarray) and headers.dtype.kind in "iu":
                 msgs["packet_length"][: len(headers)] = headers
             else:
@@ -234,6 +236,11 @@ class SyncwordDetectionFilter:
                                                          1 if per_tag else 0, _np_ptr(acc), C.byref(used)),
               "SyncwordDetectionFilter.gate")
         return acc[: idx.size].astype(bool), used.value
+
+    def gate_resolve(self, msg):
+        """deliver the message of the packet the gate left open with a pending header"""
+        m = np.ascontiguousarray(msg, dtype=_abi.HEADER_MSG_DTYPE).reshape(1)
+        check(lib().gr4pm_syncword_detection_filter_gate_resolve(self._h, _np_ptr(m)), "SyncwordDetectionFilter.gate")
 
     def __del__(self):
         try:
@@ -391,6 +398,11 @@ class PayloadMetadataInsert:
 
     def start(self):
         check(lib().gr4pm_payload_metadata_insert_reset(self._h), "PayloadMetadataInsert.start")
+
+    def resolve(self, msg):
+        """per_tag mode: the message of the packet that was opened with a pending header"""
+        m = np.ascontiguousarray(msg, dtype=_abi.HEADER_MSG_DTYPE).reshape(1)
+        check(lib().gr4pm_payload_metadata_insert_resolve(self._h, _np_ptr(m)), "PayloadMetadataInsert.resolve")
 
     def process_bulk(self, x, tags=None, headers=(), out_cap=None, tags_cap=None, per_tag=False):
         """x: symbols with syncword tags (TAG_DTYPE); headers: the pending parsed_header messages
@@ -743,6 +755,37 @@ SYNCWORD = np.array(
     dtype=np.uint8)
 
 
+class HeaderDecoder:
+    """The header decode loop of packet_receiver.hpp:131-139 as one unit: AdditiveScrambler<float>
+    (CCSDS 131.0-B-5 polynomial, reset at every "header_start") -> HeaderPayloadSplit ->
+    HeaderFecDecoder -> HeaderParser.  Fed with the LLR stream and its tags
+    (ConstellationLLRDecoder output); a header whose 256 LLRs end in a later call is finished
+    there."""
+
+    def __init__(self):
+        self.descrambler = AdditiveScrambler(0x4001, 0x18E38, 16)  # :131-135
+        self.header_payload_split = HeaderPayloadSplit(256)        # :136-137
+        self.header_fec_decoder = HeaderFecDecoder()               # :138
+        self._partial = None
+
+    def process_bulk(self, llr, llr_tags):
+        """returns dict(messages: HEADER_MSG_DTYPE per finished header, packet_type, header_bytes,
+        invalid, payload_llr: descrambled payload LLRs, payload_tags)"""
+        torch = _torch()
+        t = _ptags_array(llr_tags)
+        resets = t["index"][t["kind"] == _abi.PKT_HEADER_START]
+        d = self.descrambler.process_bulk(llr, resets)
+        hdr, pay, _, pay_tags = self.header_payload_split.process_bulk(d, t)
+        if self._partial is not None:
+            hdr = torch.cat([self._partial, hdr])
+        n = hdr.numel() // 256
+        self._partial = hdr[n * 256:].clone() if hdr.numel() % 256 else None
+        hb, inval = self.header_fec_decoder.process_bulk(hdr[: n * 256])
+        msgs, ptype = header_parse(hb, inval)
+        return {"messages": msgs, "packet_type": ptype, "header_bytes": hb, "invalid": inval, "payload_llr": pay,
+                "payload_tags": pay_tags}
+
+
 class PacketReceiver:
     """The sample-rate / symbol-rate front half of gr::packet_modem::PacketReceiver
     (packet_receiver.hpp:34-127,191-232): SyncwordDetection -> SyncwordDetectionFilter ->
@@ -762,13 +805,28 @@ class PacketReceiver:
     PayloadMetadataInsert (drops everything between packets, marks syncword / header / payload
     with "constellation" and "loop_bandwidth" tags) -> CostasLoop (those tags drive its settings)
     -> SyncwordRemove -> ConstellationLLRDecoder (noise_sigma 0.7, QPSK): the result then also
-    carries "llr" (float32, two per symbol) and "llr_tags"."""
+    carries "llr" (float32, two per symbol) and "llr_tags".
+
+    decode_headers=True (implies soft_bits) closes the header feedback loop of
+    packet_receiver.hpp:131-139,233-247 on the device instead of asking the caller for
+    `header_fn`: descrambler -> HeaderPayloadSplit -> HeaderFecDecoder -> HeaderParser supply the
+    parsed_header messages.  The reference resolves that loop packet by packet; a batch resolves
+    it in two passes: (A) every detection that is not inside the syncword + header of an earlier
+    one is taken through a second set of the same blocks up to its header LLRs (its payload is
+    dropped by answering "invalid_header"), which yields every candidate's header; (B) the real
+    chain runs with those messages, and the headers it decodes itself are compared with the ones
+    it was given (`header_mismatches` in the result; its payload LLRs leave descrambled as
+    "payload_llr" / "payload_tags").  A header whose symbols continue in the next batch stays
+    pending until then.  Known limit: a detection that pass A skips because it lies inside another
+    candidate's header window gets no header (reported as invalid)."""
 
     def __init__(self, samples_per_symbol=4, syncword_freq_bins=4, syncword_threshold=9.5,
                  costas_constellation="QPSK", max_items=1 << 22, pipelined=False, fused=True,
-                 soft_bits=False):
+                 soft_bits=False, decode_headers=False):
         torch = _torch()
         self.fused = fused  # CFC applied while the symbol filter stages its input
+        self.decode_headers = decode_headers
+        soft_bits = soft_bits or decode_headers
         self.soft_bits = soft_bits
         sps = samples_per_symbol
         self.samples_per_symbol = sps
@@ -793,6 +851,22 @@ class PacketReceiver:
             pfb = root_raised_cosine(float(arms) / float(norm), float(arms * sps), 1.0, 0.35, arms * sps * 11)[:-1]  # :100-110
             self.symbol_filter = SymbolFilter(pfb, arms, sps, self.rrc_taps.size - 1)  # :111-115
             self.syncword_wipeoff = SyncwordWipeoff(np.where(SYNCWORD == 1, -1.0, 1.0).astype(np.float32))  # :117-122
+            if decode_headers:  # pass A: the same blocks again, up to the header LLRs
+                self._spec = {
+                    "filter": SyncwordDetectionFilter(sps),
+                    "cfc": CoarseFrequencyCorrection((self.rrc_taps.size - 1) // 2 + sps),
+                    "symf": SymbolFilter(pfb, arms, sps, self.rrc_taps.size - 1),
+                    "wipeoff": SyncwordWipeoff(np.where(SYNCWORD == 1, -1.0, 1.0).astype(np.float32)),
+                    "pmi": PayloadMetadataInsert(),
+                    "costas": CostasLoop(),
+                    "remove": SyncwordRemove(),
+                    "llr": ConstellationLLRDecoder(0.7, "QPSK"),
+                    "headers": HeaderDecoder(),
+                }
+                self._awaiting = np.zeros(0, dtype=np.uint64)   # candidates whose header is still on its way
+                self._known_idx = np.zeros(0, dtype=np.uint64)  # candidates with a decoded header ...
+                self._known_msg = np.zeros(0, dtype=_abi.HEADER_MSG_DTYPE)  # ... and the message
+                self._pending_real = None                       # accepted packet waiting for its header
         with torch.cuda.stream(self._streams[2]):
             self.costas_loop = CostasLoop(0.01, costas_constellation)             # :125
             if soft_bits:
@@ -800,6 +874,12 @@ class PacketReceiver:
                 self.costas_loop = CostasLoop()                                   # :125 (BPSK until the first tag)
                 self.syncword_remove = SyncwordRemove()                           # :126
                 self.constellation_decoder = ConstellationLLRDecoder(0.7, "QPSK")  # :129-130
+            if decode_headers:
+                self.header_decoder = HeaderDecoder()                             # :131-139
+                self._used_msgs = np.zeros(0, dtype=_abi.HEADER_MSG_DTYPE)        # given to pass B, not yet verified
+        # messages of accepted tags on their way to PayloadMetadataInsert: the symbol filter can
+        # hold a tag of the last few samples back until the next call (symbol_filter.hpp:204-228)
+        self._hdr_fifo = np.zeros(0, dtype=_abi.HEADER_MSG_DTYPE)
         self._workers = None
         self._inflight = []
         if pipelined:
@@ -826,6 +906,8 @@ class PacketReceiver:
         torch = _torch()
         if st != 0:
             return {"status": st, "consumed": 0, "symbols": None, "tags": det_tags, "detector_tags": det_tags}
+        if self.decode_headers:
+            return self._stage1_decode(y, det_tags, n, base)
         with torch.cuda.stream(self._streams[1]):
             # SyncwordDetectionFilter: gate the tags; the samples pass unchanged
             if callable(header_fn):
@@ -842,8 +924,70 @@ class PacketReceiver:
                 z = self.freq_correction.process_bulk(y, tags)
                 sym, sym_tags, consumed = self.symbol_filter.process_bulk(z, tags)
             w = self.syncword_wipeoff.process_bulk(sym, sym_tags)
+            self._hdr_fifo = np.concatenate([self._hdr_fifo, _header_msgs(headers)[0][: det_tags.size][acc]])
+            hdrs, self._hdr_fifo = self._hdr_fifo[: sym_tags.size], self._hdr_fifo[sym_tags.size:]
         return {"status": 0, "consumed": n, "symbols": w, "tags": sym_tags, "detector_tags": det_tags,
-                "accepted": acc, "headers": _header_msgs(headers)[0][: det_tags.size][acc]}
+                "accepted": acc, "headers": hdrs}
+
+    def _predecode(self, y, det_tags, idx_abs):
+        """pass A: headers of all candidates (see the class docstring); updates the table of known
+        headers"""
+        sp = self._spec
+        n = det_tags.size
+        inv = np.zeros(max(n, 1), dtype=_abi.HEADER_MSG_DTYPE)
+        inv["invalid_header"] = 1
+        acc, _ = sp["filter"].gate(idx_abs, inv[:n], per_tag=True)
+        stags = det_tags[acc]
+        sym, sym_tags, _ = cfc_symbol_filter(sp["cfc"], sp["symf"], y, stags)
+        w = sp["wipeoff"].process_bulk(sym, sym_tags)
+        pm = sp["pmi"].process_bulk(w, sym_tags, inv[: sym_tags.size], per_tag=True)
+        z = sp["costas"].process_packets(pm["out"], pm["tags"])
+        d, dt = sp["remove"].process_bulk(z, pm["tags"])
+        llr, lt = sp["llr"].process_bulk(d, dt)
+        done = sp["headers"].process_bulk(llr, lt)["messages"]
+        self._awaiting = np.concatenate([self._awaiting, idx_abs[acc]])
+        k = done.size
+        self._known_idx = np.concatenate([self._known_idx, self._awaiting[:k]])
+        self._known_msg = np.concatenate([self._known_msg, done])
+        self._awaiting = self._awaiting[k:]
+
+    def _stage1_decode(self, y, det_tags, n, base):
+        torch = _torch()
+        with torch.cuda.stream(self._streams[1]):
+            idx_abs = (base + det_tags["index"]).astype(np.uint64)
+            self._predecode(y, det_tags, idx_abs)
+            resolve = None
+            if self._pending_real is not None:
+                j = np.searchsorted(self._known_idx, self._pending_real)
+                if j < self._known_idx.size and self._known_idx[j] == self._pending_real:
+                    resolve = self._known_msg[j].copy()
+                    self.syncword_detection_filter.gate_resolve(resolve)
+                    self._pending_real = None
+                    waiting = np.nonzero(self._hdr_fifo["invalid_header"] == 2)[0]
+                    if waiting.size:  # its tag has not even reached PayloadMetadataInsert yet
+                        self._hdr_fifo[waiting[0]] = resolve
+                        resolve = None
+            # per-tag messages: decoded / still on its way (2) / never decoded (1)
+            msgs = np.zeros(det_tags.size, dtype=_abi.HEADER_MSG_DTYPE)
+            msgs["invalid_header"] = 1
+            j = np.searchsorted(self._known_idx, idx_abs)
+            jc = np.minimum(j, max(self._known_idx.size - 1, 0))
+            hit = (j < self._known_idx.size) & (self._known_idx[jc] == idx_abs) if self._known_idx.size else \
+                np.zeros(det_tags.size, dtype=bool)
+            msgs[hit] = self._known_msg[jc[hit]]
+            msgs["invalid_header"][np.isin(idx_abs, self._awaiting)] = 2
+            acc, _ = self.syncword_detection_filter.gate(idx_abs, msgs, per_tag=True)
+            tags, headers = det_tags[acc], msgs[acc]
+            if headers.size and headers["invalid_header"][-1] == 2:
+                self._pending_real = idx_abs[acc][-1]
+            keep = self._known_idx + np.uint64(1 << 22) >= np.uint64(base)  # forget old entries
+            self._known_idx, self._known_msg = self._known_idx[keep], self._known_msg[keep]
+            sym, sym_tags, consumed = cfc_symbol_filter(self.freq_correction, self.symbol_filter, y, tags)
+            w = self.syncword_wipeoff.process_bulk(sym, sym_tags)
+            self._hdr_fifo = np.concatenate([self._hdr_fifo, headers])
+            hdrs, self._hdr_fifo = self._hdr_fifo[: sym_tags.size], self._hdr_fifo[sym_tags.size:]
+        return {"status": 0, "consumed": n, "symbols": w, "tags": sym_tags, "detector_tags": det_tags,
+                "accepted": acc, "headers": hdrs, "resolve": resolve}
 
     def _stage2(self, res):
         torch = _torch()
@@ -853,6 +997,12 @@ class PacketReceiver:
             if not self.soft_bits:
                 res["symbols"] = self.costas_loop.process_bulk(res["symbols"], res["tags"])
                 return res
+            if res.get("resolve") is not None:
+                self.payload_metadata_insert.resolve(res["resolve"])
+                if self.decode_headers:
+                    waiting = np.nonzero(self._used_msgs["invalid_header"] == 2)[0]
+                    if waiting.size:
+                        self._used_msgs[waiting[0]] = res["resolve"]
             pm = self.payload_metadata_insert.process_bulk(res["symbols"], res["tags"], res["headers"],
                                                            per_tag=True)
             assert pm["consumed"] == res["symbols"].numel()  # every packet's header is known up front
@@ -861,6 +1011,22 @@ class PacketReceiver:
             llr, llr_tags = self.constellation_decoder.process_bulk(data, data_tags)
             res.update(symbols=z, packet_tags=pm["tags"], llr=llr, llr_tags=llr_tags,
                        ignored_syncwords=pm["ignored"])
+            if self.decode_headers:
+                # the chain's own header decode (packet_receiver.hpp:131-139): descrambled payload
+                # LLRs for the consumers behind, and the check that pass A told the truth
+                hd = self.header_decoder.process_bulk(llr, llr_tags)
+                # messages of the packets PayloadMetadataInsert opened (it ignores syncwords inside a packet)
+                opened_at = pm["tags"]["syncword"]["index"][pm["tags"]["kind"] == _abi.PKT_SYNCWORD]
+                opened = res["headers"][np.isin(res["tags"]["index"], opened_at)]
+                self._used_msgs = np.concatenate([self._used_msgs, opened])
+                k = hd["messages"].size
+                given, self._used_msgs = self._used_msgs[:k], self._used_msgs[k:]
+                got = hd["messages"]
+                same = (given["invalid_header"] == got["invalid_header"]) & \
+                    ((given["packet_length"] == got["packet_length"]) | (got["invalid_header"] == 1))
+                res.update(header_messages=got, header_bytes=hd["header_bytes"], packet_type=hd["packet_type"],
+                           payload_llr=hd["payload_llr"], payload_tags=hd["payload_tags"],
+                           header_mismatches=int(np.sum(~same)))
         return res
 
     def _stage12(self, fut1):

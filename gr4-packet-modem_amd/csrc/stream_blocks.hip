@@ -1375,7 +1375,9 @@ extern "C" gr4pm_status gr4pm_syncword_detection_filter_gate(gr4pm_syncword_dete
         if (h->gate_in_packet) {
             // resolve the pending header before looking at this tag: the reference cannot get
             // past `allowed` items of the packet without it (:166-185)
-            if (!h->gate_end_known && (headers_per_tag ? h->gate_hdr_idx < n_headers : hu < n_headers)) {
+            if (!h->gate_end_known &&
+                (headers_per_tag ? (h->gate_hdr_idx < n_headers && headers[h->gate_hdr_idx].invalid_header != 2)
+                                 : hu < n_headers)) {
                 const gr4pm_header_msg& m = headers_per_tag ? headers[h->gate_hdr_idx] : headers[hu];
                 ++hu;
                 uint64_t block_until = 1; // invalid header / ignored syncword, :139,:159
@@ -1411,8 +1413,10 @@ extern "C" gr4pm_status gr4pm_syncword_detection_filter_gate(gr4pm_syncword_dete
         h->gate_end_known = false;
         h->gate_hdr_idx = i;
     }
-    if (headers_per_tag && h->gate_in_packet && !h->gate_end_known && h->gate_hdr_idx < n_headers) {
+    if (headers_per_tag && h->gate_in_packet && !h->gate_end_known && h->gate_hdr_idx < n_headers &&
+        headers[h->gate_hdr_idx].invalid_header != 2) {
         // resolve the last accepted tag of this call now: its header will not be re-presented
+        // (a pending one, invalid_header == 2, is resolved later by ..._gate_resolve)
         const gr4pm_header_msg& m = headers[h->gate_hdr_idx];
         uint64_t block_until = 1;
         if (!m.invalid_header) {
@@ -1429,6 +1433,25 @@ extern "C" gr4pm_status gr4pm_syncword_detection_filter_gate(gr4pm_syncword_dete
     }
     h->gate_hdr_idx = static_cast<size_t>(-1);
     *headers_used = hu;
+    return GR4PM_OK;
+}
+
+extern "C" gr4pm_status gr4pm_syncword_detection_filter_gate_resolve(gr4pm_syncword_detection_filter* h,
+                                                                     const gr4pm_header_msg* msg)
+{
+    if (!h || !msg) return GR4PM_ERR_INVALID;
+    if (!h->gate_in_packet || h->gate_end_known) return GR4PM_OK; // nothing is waiting
+    const uint64_t allowed = h->sps * (h->syncword_size + h->header_size + h->allowed_margin);
+    uint64_t block_until = 1;
+    if (!msg->invalid_header) {
+        if (msg->packet_length == 0) {
+            set_error("received packet_length = 0");
+            return GR4PM_ERR_INVALID;
+        }
+        block_until = h->sps * (h->header_size + h->syncword_size - h->allowed_margin + (msg->packet_length + 4) * 4);
+    }
+    h->gate_end = h->gate_start + std::max<uint64_t>(allowed, block_until);
+    h->gate_end_known = true;
     return GR4PM_OK;
 }
 
@@ -2180,7 +2203,7 @@ gr4pm_status gr4pm_payload_metadata_insert_process(
                 publish(pt);
                 if (headers_per_tag) {
                     h->held = headers[t];
-                    h->has_held = true;
+                    h->has_held = headers[t].invalid_header != 2; // 2 = pending, see ..._resolve
                 }
             } else {
                 ++ignored;
@@ -2260,6 +2283,16 @@ gr4pm_status gr4pm_payload_metadata_insert_process(
     if (tag_overflow) {
         set_error("tags_cap too small");
         return GR4PM_ERR_OVERFLOW;
+    }
+    return GR4PM_OK;
+}
+
+gr4pm_status gr4pm_payload_metadata_insert_resolve(gr4pm_payload_metadata_insert* h, const gr4pm_header_msg* msg)
+{
+    if (!h || !msg) return GR4PM_ERR_INVALID;
+    if (h->in_packet && !h->has_held) {
+        h->held = *msg;
+        h->has_held = true;
     }
     return GR4PM_OK;
 }

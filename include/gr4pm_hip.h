@@ -144,7 +144,8 @@ typedef struct {
 } gr4pm_syncword_detection_filter_params;
 typedef struct {
     uint64_t packet_length; /* "packet_length" of a parsed_header message */
-    int32_t invalid_header; /* message carries "invalid_header" */
+    int32_t invalid_header; /* 1: message carries "invalid_header"; 2 (headers_per_tag modes only):
+                               no message yet, see ..._gate_resolve / ..._insert_resolve */
 } gr4pm_header_msg;
 gr4pm_status gr4pm_syncword_detection_filter_create(
     const gr4pm_syncword_detection_filter_params* params, gr4pm_syncword_detection_filter** out);
@@ -170,6 +171,11 @@ gr4pm_status gr4pm_syncword_detection_filter_gate(gr4pm_syncword_detection_filte
                                                   const gr4pm_header_msg* headers, size_t n_headers,
                                                   int headers_per_tag, uint8_t* accepted,
                                                   size_t* headers_used);
+/* headers_per_tag mode, header decoded on the device: the message of the LAST accepted tag of a
+ * call may not exist yet when its header symbols continue in the next batch.  Mark it
+ * invalid_header = 2 ("pending") and deliver it with this call before the next gate(). */
+gr4pm_status gr4pm_syncword_detection_filter_gate_resolve(gr4pm_syncword_detection_filter* h,
+                                                          const gr4pm_header_msg* msg);
 
 /* ------------------------------------------------------------------------------------
  * CoarseFrequencyCorrection<float> -- coarse_frequency_correction.hpp:20-99
@@ -363,6 +369,11 @@ gr4pm_status gr4pm_payload_metadata_insert_process(
     const gr4pm_tag* tags_in, size_t n_tags_in, const gr4pm_header_msg* headers, size_t n_headers,
     int headers_per_tag, gr4pm_packet_tag* tags_out, size_t tags_cap, size_t* n_tags_out, size_t* consumed,
     size_t* produced, size_t* headers_used, size_t* ignored_syncwords);
+
+/* headers_per_tag mode: the message of a packet that was opened with a pending header
+ * (invalid_header = 2) in an earlier call, delivered before the call that reaches its payload. */
+gr4pm_status gr4pm_payload_metadata_insert_resolve(gr4pm_payload_metadata_insert* h,
+                                                   const gr4pm_header_msg* msg);
 
 /* CostasLoop fed by PayloadMetadataInsert (packet_receiver.hpp wiring): "constellation" and
  * "loop_bandwidth" keys re-run settingsChanged() (costas_loop.hpp:52-88) from the tagged item

@@ -1191,3 +1191,76 @@ def test_header_fec_decoder_noisy_vs_oracle(pkg):
         assert (m["invalid_header"] == 1) == (want_len is None)
         if want_len is not None:
             assert m["packet_length"] == want_len and pt == h[2]
+
+
+def _tx_packets(rng, lengths, gaps, sps=4, types=None):
+    """transmit side of the header loop for the tests (numpy + oracle helpers): syncword, header
+    (header_formatter.hpp:104-107 -> header_fec_encoder.hpp -> CCSDS 131.0-B-5 scrambler restarted at
+    the header), payload bits under the same running scrambler, QPSK, RRC at 4 samples/symbol"""
+    gen = np.load(os.path.join(GOLDEN, "header_ldpc_generator.npy"))
+    a = np.float32(np.sqrt(0.5))
+    rrc, _ = orc.unit_norm_rrc(sps)
+    syms, starts, payloads = [], [], []
+    for k, (plen, gap) in enumerate(zip(lengths, gaps)):
+        hdr = orc.header_format(plen, 0 if types is None else types[k])
+        coded = np.unpackbits(orc.header_fec_encode(hdr, gen).ravel())
+        payload = rng.integers(0, 2, 8 * (plen + 4)).astype(np.uint8)
+        bits = orc.AdditiveScrambler(0x4001, 0x18E38, 16).process(np.concatenate([coded, payload]))
+        q = ((1 - 2.0 * bits[0::2]) * a + 1j * (1 - 2.0 * bits[1::2]) * a).astype(np.complex64)
+        syms += [np.zeros(gap, np.complex64), sig.BPSK[sig.SYNCWORD], q]
+        starts.append(sum(len(s) for s in syms[:-2]))
+        payloads.append(payload)
+    syms.append(np.zeros(1500, np.complex64))
+    return orc.interpolating_fir(np.concatenate(syms), sps, rrc), starts, payloads
+
+
+@pytest.mark.parametrize("mode", ["one_call", "three_calls", "pipelined"])
+def test_packet_receiver_decodes_its_own_headers(pkg, mode):
+    """PacketReceiver(decode_headers=True): nothing but IQ samples goes in.  Every transmitted header
+    is decoded (length, type), every payload bit comes back from the descrambled payload LLRs, the
+    headers the exact chain decodes agree with the ones it was given, and cutting the stream in
+    the middle of a header (pending message) changes nothing."""
+    rng = np.random.default_rng(401)
+    lengths = [100, 17, 1500, 1, 333, 64, 900]
+    gaps = [int(g) for g in rng.integers(250, 900, len(lengths))]
+    types = [0, 1, 0, 0, 1, 0, 0]
+    x, starts, payloads = _tx_packets(rng, lengths, gaps, types=types)
+    x = (orc.rotator(x, np.float32(-0.013)) * np.exp(1j * 2.1) + sig.awgn(x.size, 0.05, 402)).astype(np.complex64)
+    if mode == "three_calls":
+        # the detector consumes whole strides of 1752 samples and delays by 1537: pad the front so
+        # that a stride boundary falls on symbol 110 of packet 2 (46 symbols into its header)
+        S = 1752
+        target = 4 * (starts[2] + 110) + 1537
+        k1 = target // S + 1
+        pad = k1 * S - target
+        x = np.concatenate([sig.awgn(pad, 0.05, 403).astype(np.complex64), x])
+        c1 = k1 * S + 2048 - S
+        c2 = (k1 + 9) * S + 2048 - S
+    rx = pkg.PacketReceiver(max_items=x.size, pipelined=(mode == "pipelined"), decode_headers=True)
+    results = []
+    xd = dev(x)
+    if mode == "three_calls":
+        pos = 0
+        for want in [c1, c2 - k1 * S, x.size]:
+            r = rx.process_bulk(xd[pos:min(pos + want, x.size)])
+            if not results:  # the first cut is inside packet 2's header: its message is still pending
+                assert rx._pending_real is not None and r["headers"]["invalid_header"][-1] == 2
+            results.append(r)
+            pos += r["consumed"]
+            if pos + 2048 > x.size:
+                break
+    else:
+        r = rx.process_bulk(xd)
+        results = rx.flush() if mode == "pipelined" else [r]
+    msgs = np.concatenate([r["header_messages"] for r in results])
+    ptype = np.concatenate([r["packet_type"] for r in results])
+    assert sum(r["header_mismatches"] for r in results) == 0
+    good = msgs[msgs["invalid_header"] == 0]
+    assert [int(v) for v in good["packet_length"]] == lengths
+    assert [int(t) for t in ptype[msgs["invalid_header"] == 0]] == types
+    pay = np.concatenate([r["payload_llr"].cpu().numpy() for r in results])
+    want_bits = np.concatenate(payloads)
+    assert pay.size == want_bits.size
+    assert np.array_equal((pay < 0).astype(np.uint8), want_bits)
+    if mode == "three_calls":
+        assert len(results) == 3
