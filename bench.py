@@ -54,7 +54,27 @@ def unit_norm_rrc(pkg):
     return (t / np.float32(np.sqrt(norm))).astype(np.float32)
 
 
-def burst_stream(pkg, n_items, rrc, seed, device):
+def header_symbols(packet_length):
+    """the 128 QPSK symbols of a valid packet header (used by --decode-headers): header bytes
+    (header_formatter.hpp:104-107), (128, 32) LDPC + repetition (header_fec_encoder.hpp:60-107,
+    generator = tests/golden/header_ldpc_generator.npy), CCSDS 131.0-B-5 scrambler from its seed
+    (packet_transmitter_pdu.hpp wiring), bit pairs -> (I, Q), 0 -> +"""
+    gen = np.load(os.path.join(ROOT, "tests", "golden", "header_ldpc_generator.npy"))
+    hdr = [(packet_length >> 8) & 0xFF, packet_length & 0xFF, 0x00, 0x55]
+    info = (hdr[0] << 24) | (hdr[1] << 16) | (hdr[2] << 8) | hdr[3]
+    bits = [(info >> (31 - i)) & 1 for i in range(32)]
+    bits += [bin(info & int(g)).count("1") & 1 for g in gen]
+    bits = np.array(bits + bits, dtype=np.uint8)
+    reg, seq = 0x18E38, []
+    for _ in range(256):
+        seq.append(reg & 1)
+        reg = ((bin(reg & 0x4001).count("1") & 1) << 16) | (reg >> 1)
+    bits ^= np.array(seq, dtype=np.uint8)
+    a = np.float32(np.sqrt(0.5))
+    return ((1 - 2.0 * bits[0::2]) * a + 1j * (1 - 2.0 * bits[1::2]) * a).astype(np.complex64)
+
+
+def burst_stream(pkg, n_items, rrc, seed, device, header=None):
     """synthetic 3.2 Msps-shaped bursts, generated on the GPU:
     packets of 64 (BPSK syncword) + 128 (header) + 1504*4 (payload) QPSK symbols, gaps of 500
     zero symbols, CFO uniform in +-0.03 rad/sample per packet, AWGN at Es/N0 = 10 dB."""
@@ -70,6 +90,8 @@ def burst_stream(pkg, n_items, rrc, seed, device):
     sym = torch.complex((1 - 2 * bits_i).float() * a, (1 - 2 * bits_q).float() * a)
     sw = torch.from_numpy(np.where(SYNCWORD == 1, -1.0, 1.0).astype(np.float32)).to(device)
     sym[:, :64] = torch.complex(sw, torch.zeros_like(sw))
+    if header is not None:
+        sym[:, 64:192] = torch.from_numpy(header).to(device)
     sym[:, pkt_syms:] = 0
     sym = sym.reshape(-1)[:n_sym]
     # pulse shaping with this package's own InterpolatingFirFilter kernel (the TX-side block the
@@ -155,6 +177,9 @@ def main():
     ap.add_argument("--soft-bits", action="store_true",
                     help="continue the chain to LLRs: PayloadMetadataInsert -> tag-driven CostasLoop -> "
                          "SyncwordRemove -> ConstellationLLRDecoder (SURVEY.md 8(f) rank 1; not the headline workload)")
+    ap.add_argument("--decode-headers", action="store_true",
+                    help="--soft-bits plus the header decode loop on the device (descrambler, header/payload split, "
+                         "LDPC header decoder, parser) instead of a given packet length (SURVEY.md 8(f) rank 2)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the two halves of the chain back to back on one stream")
     args = ap.parse_args()
@@ -174,12 +199,14 @@ def main():
     bpsk = np.array([1, -1], dtype=np.complex64)
     n_items = args.items
     input_mode = "generated on each GPU"
-    x, n_pkt = burst_stream(pkg, n_items, rrc, seed=1 + rank, device=device)
+    hdr_syms = header_symbols(1500) if args.decode_headers else None
+    x, n_pkt = burst_stream(pkg, n_items, rrc, seed=1 + rank, device=device, header=hdr_syms)
     if dist and not args.no_scatter:
         # multi-channel receive: rank 0 owns the sample ring of all channels and scatters it
         try:
             def make_all():
-                chans = [x] + [burst_stream(pkg, n_items, rrc, seed=1 + r, device=device)[0] for r in range(1, world)]
+                chans = [x] + [burst_stream(pkg, n_items, rrc, seed=1 + r, device=device, header=hdr_syms)[0]
+                               for r in range(1, world)]
                 return torch.stack(chans)
             x = scatter_channels(dist, make_all, n_items, device, rank, world)
             input_mode = "rank 0 -> all ranks, torch.distributed scatter (RCCL)"
@@ -190,7 +217,7 @@ def main():
     # "before" it (for A: a copy of B's tail, for B: A's tail itself).  While one window is being
     # processed the detector is told which one comes next (look-ahead of the correlator).
     HIST = 2 * 768 + 1
-    xb, n_pkt_b = burst_stream(pkg, n_items, rrc, seed=1001 + rank, device=device)
+    xb, n_pkt_b = burst_stream(pkg, n_items, rrc, seed=1001 + rank, device=device, header=hdr_syms)
     ring = torch.empty(HIST + 1 + 2 * n_items, dtype=torch.complex64, device=device)  # +1: keep A 16-byte aligned
     ring[1:1 + HIST] = xb[-HIST:]
     ring[1 + HIST:1 + HIST + n_items] = x
@@ -201,7 +228,7 @@ def main():
                (ring[1 + HIST + n_items:], ring[1 + n_items:1 + HIST + n_items])]
     n_pkt = max(n_pkt, n_pkt_b)
     rx = pkg.PacketReceiver(SPS, BINS, 9.5, "QPSK", max_items=n_items, pipelined=not args.no_pipeline,
-                            soft_bits=args.soft_bits)
+                            soft_bits=args.soft_bits, decode_headers=args.decode_headers)
     sd = rx.syncword_detection
     out_keep = None
     if args.channels > 1:
@@ -220,6 +247,17 @@ def main():
                                        max_items=n_items)
 
     step_no = 0
+    hdr_stats = {"decoded": 0, "valid_1500": 0, "mismatches": 0}
+
+    def note_headers(res):
+        if args.decode_headers and "header_messages" in res:
+            m = res["header_messages"]
+            hdr_stats["decoded"] += int(m.size)
+            hdr_stats["valid_1500"] += int(np.sum((m["invalid_header"] == 0) & (m["packet_length"] == 1500)))
+            hdr_stats["mismatches"] += int(res["header_mismatches"])
+            if os.environ.get("GR4PM_BENCH_DEBUG"):
+                bad = np.nonzero(~((m["invalid_header"] == 0) & (m["packet_length"] == 1500)))[0]
+                print("batch headers", m.size, "bad", bad.size, bad[:6], bad[-3:], m[bad[:3]], file=sys.stderr)
 
     def step(last=False):
         """one pass over one window; `last`: no further step follows (no look-ahead launched, so
@@ -241,6 +279,7 @@ def main():
         if res is None:  # pipelined: first call has no finished batch yet
             return 0, 0
         out_keep = res["symbols"]
+        note_headers(res)
         return res["consumed"], res["tags"].size
 
     def drain():
@@ -250,6 +289,7 @@ def main():
         n = nt = 0
         for res in rx.flush():
             out_keep = res["symbols"]
+            note_headers(res)
             n += res["consumed"]
             nt += res["tags"].size
         return n, nt
@@ -328,12 +368,14 @@ def main():
             "config": {"workload": ("SyncwordDetection only" if args.detector_only else
                                     "configs[1]: 1 channel/GPU, full RX front end (SyncwordDetection 9 bins FFT 2048 + tag "
                                     "gate + CFC + 32-arm RRC SymbolFilter + wipe-off + Costas)") +
-                                   (" + PayloadMetadataInsert + SyncwordRemove + LLR decoder" if args.soft_bits else "") +
+                                   (" + PayloadMetadataInsert + SyncwordRemove + LLR decoder" if (args.soft_bits or args.decode_headers) else "") +
+                                   (" + header decode loop" if args.decode_headers else "") +
                                    " on resident burst+AWGN stream",
                        "items_per_step_per_gpu": n_items * args.channels, "channels_per_gpu": args.channels, "freq_bins": 2 * BINS + 1, "tags_per_step": n_tags // max(args.steps, 1),
                        "parallelism": f"channel-per-gpu x{world}", "input": input_mode,
                        "pipelined_streams": 1 if (args.no_pipeline or args.detector_only) else 3,
-                       "windows": 2, "correlator_lookahead": not args.no_lookahead},
+                       "windows": 2, "correlator_lookahead": not args.no_lookahead,
+                       **({"headers": hdr_stats} if args.decode_headers else {})},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

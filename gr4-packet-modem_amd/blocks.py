@@ -898,7 +898,8 @@ class PacketReceiver:
             d = 2 * self.syncword_detection.time_threshold + 1
             assert history.numel() >= d and history.data_ptr() + history.numel() * 8 == x.data_ptr(), \
                 "history must be the ring contents that directly precede x"
-            y = torch.as_strided(history, (n,), (1,), history.numel() - d)
+            # as_strided takes the offset inside the STORAGE, not inside the view
+            y = torch.as_strided(history, (n,), (1,), history.storage_offset() + history.numel() - d)
         base = self.syncword_detection._items_consumed - n        # absolute index of y[0]
         return st, y, det_tags, n, base
 

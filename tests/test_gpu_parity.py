@@ -1214,6 +1214,39 @@ def _tx_packets(rng, lengths, gaps, sps=4, types=None):
     return orc.interpolating_fir(np.concatenate(syms), sps, rrc), starts, payloads
 
 
+def test_packet_receiver_device_ring_equals_copy(pkg):
+    """history= (the chain reads SyncwordDetection's delayed stream in place from the caller's ring,
+    syncword_detection.hpp:318-319) gives exactly the symbols of the copying path, for windows at
+    different offsets of one ring"""
+    rng = np.random.default_rng(77)
+    xs = []
+    for seed in (1, 2):
+        x, _, _ = _tx_packets(np.random.default_rng(seed), [50, 200, 9], [400, 700, 350])
+        x = np.concatenate([x, np.zeros(30000, np.complex64)])[:30000]
+        xs.append((x + sig.awgn(30000, 0.05, 80 + seed)).astype(np.complex64))
+    H = 1537
+    ring = torch.zeros(3 + H + 2 * 30000, dtype=torch.complex64, device="cuda")
+    a0, b0 = 3 + H, 3 + H + 30000
+    ring[a0:a0 + 30000] = dev(xs[0])
+    ring[b0:b0 + 30000] = dev(xs[1])
+    ring[a0 - H:a0] = 0          # the stream starts with window A: zeros before it (empty history)
+    plain = pkg.PacketReceiver(max_items=30000)
+    inring = pkg.PacketReceiver(max_items=30000)
+    for lo in (a0, b0):
+        w = ring[lo:lo + 30000]
+        want = plain.process_bulk(w, 100)
+        got = inring.process_bulk(w, 100, history=ring[lo - H:lo])
+        assert got["consumed"] == want["consumed"] and got["tags"].size == want["tags"].size > 0
+        assert np.array_equal(bits(host(got["symbols"])), bits(host(want["symbols"])))
+        # the next window continues the stream: its history is the tail of this one, which is what
+        # the ring holds in front of window B only for the samples the detector consumed
+        if lo == a0:
+            c = want["consumed"]
+            ring[b0:b0 + 30000 - c] = ring[a0 + c:a0 + 30000].clone()   # unconsumed tail of A comes first
+            ring[b0 + 30000 - c:b0 + 30000] = dev(xs[1])[:c]
+            ring[b0 - H:b0] = ring[a0 + c - H:a0 + c].clone()
+
+
 @pytest.mark.parametrize("mode", ["one_call", "three_calls", "pipelined"])
 def test_packet_receiver_decodes_its_own_headers(pkg, mode):
     """PacketReceiver(decode_headers=True): nothing but IQ samples goes in.  Every transmitted header
