@@ -72,15 +72,22 @@ gr4pm_status gather_f32(hipStream_t s, DevBuf<FSpan>& buf, const std::vector<FSp
 
 // ------------------------------------------------------------------ header FEC decoder
 // One wavefront per codeword.  Posteriors P[n] and check-to-variable messages R[m][kMaxDeg]
-// live in LDS.  Horizontal-layered schedule: the checks are processed in index order; runs of
-// consecutive checks that share no variable are independent and are done in one step, one lane
-// per (check, edge) -- the arithmetic of every check is exactly the serial one.
+// live in LDS.  Horizontal-layered schedule.  The layers are built greedily: scan the checks
+// not yet placed in index order and take every one that shares no variable with the checks
+// already taken in this pass (at most 64 edges); a pass = one layer = one step of the kernel,
+// one lane per (check, edge).  Checks of a layer touch disjoint variables, so doing them at
+// once is exactly the serial layered decoder that visits the checks layer by layer (the order
+// oracle/ uses); for the header code that is 8 steps per iteration instead of 96.
 constexpr int kMaxDeg = 8;
-constexpr int kMaxN = 256, kMaxM = 192;
+constexpr int kMaxN = 256, kMaxM = 192, kMaxSteps = 24;
+// one schedule entry = everything a lane needs for its (check, edge): the check's variables
+// (bytes 0-4 ... kMaxDeg-1 would not fit: degrees above 5 use bytes 0-4 + the table), its degree,
+// the lane's edge and the check index, so that a step starts with ONE 8-byte LDS read
+constexpr int kPackDeg = 5;
 struct LdpcDev {
     const uint8_t* row_var; // [m][kMaxDeg], 0xFF = unused
     const uint8_t* row_deg; // [m]
-    const uint16_t* sched;  // [n_steps][64]: check << 3 | edge, 0xFFFF = idle lane
+    const unsigned long long* sched; // [n_steps][64]: see pack_entry(); all ones = idle lane
     const float* corr;      // [64]: ln(1 + e^-x), x = i / 8
     unsigned n, m, n_steps;
 };
@@ -99,13 +106,20 @@ __global__ __launch_bounds__(64) void k_header_fec(const float* __restrict__ llr
                                                    uint8_t* __restrict__ headers, uint8_t* __restrict__ invalid)
 {
     __shared__ float P[kMaxN];
-    __shared__ float R[kMaxM * kMaxDeg];
+    __shared__ __attribute__((aligned(16))) float R[kMaxM * kMaxDeg];
     __shared__ float corr[64];
+    // the code's tables, once per wavefront, so that no step waits for global memory
+    __shared__ __attribute__((aligned(8))) uint8_t s_var[kMaxM * kMaxDeg];
+    __shared__ uint8_t s_deg[kMaxM];
+    __shared__ unsigned long long s_sched[kMaxSteps * 64];
     const unsigned cw = blockIdx.x;
     if (cw >= n_codewords) return;
     const int lane = threadIdx.x;
     const float* x = llrs + static_cast<size_t>(cw) * n_llrs_per_codeword;
     corr[lane] = d.corr[lane];
+    for (unsigned e = lane; e < d.m * kMaxDeg; e += 64) s_var[e] = d.row_var[e];
+    for (unsigned e = lane; e < d.m; e += 64) s_deg[e] = d.row_deg[e];
+    for (unsigned e = lane; e < d.n_steps * 64; e += 64) s_sched[e] = d.sched[e];
     // header_fec_decoder.hpp:308-312: accumulate the two copies of the repetition code
     for (unsigned v = lane; v < d.n; v += 64) P[v] = x[v] + x[d.n + v];
     for (unsigned e = lane; e < d.m * kMaxDeg; e += 64) R[e] = 0.0f;
@@ -116,8 +130,10 @@ __global__ __launch_bounds__(64) void k_header_fec(const float* __restrict__ llr
         bool bad = false;
         for (unsigned c = lane; c < d.m; c += 64) {
             unsigned parity = 0;
-            const unsigned dc = d.row_deg[c];
-            for (unsigned j = 0; j < dc; ++j) parity ^= P[d.row_var[c * kMaxDeg + j]] < 0.0f ? 1u : 0u;
+            const unsigned dc = s_deg[c];
+#pragma unroll
+            for (unsigned j = 0; j < kMaxDeg; ++j)
+                if (j < dc) parity ^= P[s_var[c * kMaxDeg + j]] < 0.0f ? 1u : 0u;
             bad |= parity != 0;
         }
         if (!__any(bad)) {
@@ -126,26 +142,38 @@ __global__ __launch_bounds__(64) void k_header_fec(const float* __restrict__ llr
         }
         if (it == max_iterations) break;
         for (unsigned s = 0; s < d.n_steps; ++s) {
-            const unsigned entry = d.sched[s * 64 + lane];
+            const unsigned long long entry = s_sched[s * 64 + lane];
             float q_own = 0.0f, r_own = 0.0f;
             unsigned v_own = 0, slot = 0;
-            const bool active = entry != 0xFFFFu;
+            const bool active = entry != ~0ull;
             if (active) {
-                const unsigned c = entry >> 3, k = entry & 7u;
-                const unsigned dc = d.row_deg[c];
+                const unsigned c = static_cast<unsigned>(entry >> 48) & 0xFFu;
+                const unsigned dc = static_cast<unsigned>(entry >> 40) & 0xFu;
+                const unsigned k = static_cast<unsigned>(entry >> 44) & 0xFu;
+                // everything below is indexed with compile-time constants (registers, no scratch)
                 float Q[kMaxDeg];
-                unsigned neg = 0, imin = 0;
+                unsigned neg = 0;
+                const float4 r0 = *reinterpret_cast<const float4*>(R + c * kMaxDeg);
+                const float4 r1 = *reinterpret_cast<const float4*>(R + c * kMaxDeg + 4);
+                const float rr[kMaxDeg] = { r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w };
 #pragma unroll
                 for (unsigned j = 0; j < kMaxDeg; ++j) {
+                    Q[j] = 0.0f;
                     if (j < dc) {
-                        Q[j] = P[d.row_var[c * kMaxDeg + j]] - R[c * kMaxDeg + j];
+                        const unsigned v = j < kPackDeg ? static_cast<unsigned>(entry >> (8 * j)) & 0xFFu
+                                                        : s_var[c * kMaxDeg + j];
+                        Q[j] = P[v] - rr[j];
                         if (Q[j] < 0.0f) neg ^= 1u;
-                    } else {
-                        Q[j] = 0.0f;
                     }
                 }
-                for (unsigned j = 1; j < dc; ++j)
-                    if (fabsf(Q[j]) < fabsf(Q[imin])) imin = j;
+                unsigned imin = 0;
+                float minabs = fabsf(Q[0]);
+#pragma unroll
+                for (unsigned j = 1; j < kMaxDeg; ++j)
+                    if (j < dc && fabsf(Q[j]) < minabs) { // strict <: the first minimum, like the oracle
+                        minabs = fabsf(Q[j]);
+                        imin = j;
+                    }
                 float others = -1.0f;
 #pragma unroll
                 for (unsigned j = 0; j < kMaxDeg; ++j) {
@@ -155,7 +183,7 @@ __global__ __launch_bounds__(64) void k_header_fec(const float* __restrict__ llr
                     }
                 }
                 if (others < 0.0f) others = 0.0f;
-                const float all = ldpc_boxplus(corr, others, fabsf(Q[imin]));
+                const float all = ldpc_boxplus(corr, others, minabs);
                 float qk = 0.0f;
 #pragma unroll
                 for (unsigned j = 0; j < kMaxDeg; ++j)
@@ -164,7 +192,7 @@ __global__ __launch_bounds__(64) void k_header_fec(const float* __restrict__ llr
                 const unsigned sgn = neg ^ (qk < 0.0f ? 1u : 0u);
                 r_own = sgn ? -mag : mag;
                 q_own = qk;
-                v_own = d.row_var[c * kMaxDeg + k];
+                v_own = k < kPackDeg ? static_cast<unsigned>(entry >> (8 * k)) & 0xFFu : s_var[c * kMaxDeg + k];
                 slot = c * kMaxDeg + k;
             }
             // all reads of this step are issued above, all writes below: LDS operations of one
@@ -215,9 +243,10 @@ struct gr4pm_header_fec_decoder {
     unsigned n = 0, m = 0, n_steps = 0, max_iterations = 25;
     hipStream_t stream;
     DevBuf<uint8_t> row_var, row_deg;
-    DevBuf<uint16_t> sched;
+    DevBuf<unsigned long long> sched;
     DevBuf<float> corr;
-    PinnedBuf<uint8_t> headers, invalid;
+    DevBuf<uint8_t> d_out;      // [n][hb] header bytes ++ [n] verdicts
+    PinnedBuf<uint8_t> h_out;
 };
 
 extern "C" {
@@ -537,24 +566,41 @@ gr4pm_status gr4pm_header_fec_decoder_create(const gr4pm_header_fec_decoder_para
             row_var[c * kMaxDeg + row_deg[c]++] = static_cast<uint8_t>(x - 1);
         }
     }
-    // steps: maximal runs of consecutive checks that share no variable, at most 64 edges
-    std::vector<uint16_t> sched;
-    unsigned c = 0;
-    while (c < m) {
-        std::vector<uint16_t> step(64, 0xFFFF);
+    // layers (see the kernel's comment)
+    std::vector<unsigned long long> sched;
+    std::vector<bool> placed(m, false);
+    unsigned n_placed = 0;
+    while (n_placed < m) {
+        std::vector<unsigned long long> step(64, ~0ull);
         std::vector<bool> used(n, false);
         unsigned lanes = 0;
-        while (c < m) {
+        for (unsigned c = 0; c < m; ++c) {
+            if (placed[c]) continue;
             bool clash = lanes + row_deg[c] > 64;
             for (unsigned e = 0; e < row_deg[c] && !clash; ++e) clash = used[row_var[c * kMaxDeg + e]];
-            if (clash) break;
+            if (clash) continue;
             for (unsigned e = 0; e < row_deg[c]; ++e) {
                 used[row_var[c * kMaxDeg + e]] = true;
-                step[lanes++] = static_cast<uint16_t>((c << 3) | e);
+                unsigned long long pk = 0;
+                for (unsigned j = 0; j < static_cast<unsigned>(kPackDeg); ++j)
+                    pk |= static_cast<unsigned long long>(row_var[c * kMaxDeg + j]) << (8 * j);
+                pk |= static_cast<unsigned long long>(row_deg[c]) << 40;
+                pk |= static_cast<unsigned long long>(e) << 44;
+                pk |= static_cast<unsigned long long>(c) << 48;
+                step[lanes++] = pk; // bits 56-63 stay 0: never equal to the idle pattern
             }
-            ++c;
+            placed[c] = true;
+            ++n_placed;
+        }
+        if (lanes == 0) { // a check wider than a wavefront cannot be scheduled
+            set_error("alist: row weight above 64");
+            return GR4PM_ERR_INVALID;
         }
         sched.insert(sched.end(), step.begin(), step.end());
+    }
+    if (sched.size() > static_cast<size_t>(kMaxSteps) * 64) {
+        set_error("alist: %zu schedule steps do not fit the kernel's table", sched.size() / 64);
+        return GR4PM_ERR_INVALID;
     }
     std::vector<float> corr(64);
     for (int k = 0; k < 64; ++k) corr[k] = static_cast<float>(std::log1p(std::exp(-k / 8.0)));
@@ -601,17 +647,19 @@ gr4pm_status gr4pm_header_fec_decoder_process(gr4pm_header_fec_decoder* h, const
         return GR4PM_ERR_INVALID;
     }
     const size_t hb = (h->n - h->m) / 8;
-    if (h->headers.n < n_codewords * hb) GR4PM_TRY(h->headers.alloc(n_codewords * hb * 2));
-    if (h->invalid.n < n_codewords) GR4PM_TRY(h->invalid.alloc(n_codewords * 2));
+    const size_t bytes = n_codewords * (hb + 1);
+    if (h->d_out.n < bytes) GR4PM_TRY(h->d_out.alloc(bytes * 2));
+    if (h->h_out.n < bytes) GR4PM_TRY(h->h_out.alloc(bytes * 2));
     LdpcDev d{ h->row_var.p, h->row_deg.p, h->sched.p, h->corr.p, h->n, h->m, h->n_steps };
-    // the kernel writes its few bytes per codeword straight into pinned host memory
+    uint8_t* d_headers = h->d_out.p;
+    uint8_t* d_invalid = h->d_out.p + n_codewords * hb;
     hipLaunchKernelGGL(k_header_fec, dim3(static_cast<unsigned>(n_codewords)), dim3(64), 0, h->stream, llrs,
-                       static_cast<unsigned>(n_codewords), d, h->max_iterations, 2 * h->n, h->headers.p,
-                       h->invalid.p);
+                       static_cast<unsigned>(n_codewords), d, h->max_iterations, 2 * h->n, d_headers, d_invalid);
     GR4PM_HIP_TRY(hipGetLastError());
+    GR4PM_HIP_TRY(hipMemcpyAsync(h->h_out.p, h->d_out.p, bytes, hipMemcpyDeviceToHost, h->stream));
     GR4PM_HIP_TRY(hipStreamSynchronize(h->stream));
-    std::copy_n(h->headers.p, n_codewords * hb, headers);
-    std::copy_n(h->invalid.p, n_codewords, invalid);
+    std::copy_n(h->h_out.p, n_codewords * hb, headers);
+    std::copy_n(h->h_out.p + n_codewords * hb, n_codewords, invalid);
     return GR4PM_OK;
 }
 

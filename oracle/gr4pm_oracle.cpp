@@ -1548,6 +1548,7 @@ void orc_header_fec_encode(const uint32_t* generator, const uint8_t* in, size_t 
 struct orc_ldpc {
     unsigned n = 0, m = 0;
     std::vector<std::vector<unsigned>> rows; /* variable indices of every check */
+    std::vector<unsigned> order;             /* the order the layered schedule visits the checks in */
     float corr[64];                          /* ln(1 + e^-x), x = i / 8 */
 };
 orc_ldpc* orc_ldpc_create(const char* alist)
@@ -1588,6 +1589,26 @@ orc_ldpc* orc_ldpc_create(const char* alist)
         }
     }
     for (int k = 0; k < 64; ++k) d->corr[k] = static_cast<float>(std::log1p(std::exp(-k / 8.0)));
+    /* layers: scan the checks not yet placed in index order, take every one that shares no
+     * variable with those already taken in this pass (at most 64 edges per pass); the checks
+     * are visited pass by pass.  (A parallel decoder can do a whole pass at once.) */
+    std::vector<bool> placed(d->m, false);
+    while (d->order.size() < d->m) {
+        std::vector<bool> used(d->n, false);
+        size_t lanes = 0;
+        const size_t before = d->order.size();
+        for (unsigned c = 0; c < d->m; ++c) {
+            if (placed[c]) continue;
+            bool clash = lanes + d->rows[c].size() > 64;
+            for (unsigned vv : d->rows[c]) clash = clash || used[vv];
+            if (clash) continue;
+            for (unsigned vv : d->rows[c]) used[vv] = true;
+            lanes += d->rows[c].size();
+            placed[c] = true;
+            d->order.push_back(c);
+        }
+        if (d->order.size() == before) break;
+    }
     return d;
 }
 void orc_ldpc_destroy(orc_ldpc* d) { delete d; }
@@ -1623,7 +1644,7 @@ int orc_ldpc_decode(orc_ldpc* d, const float* llrs, uint8_t* bits_k, unsigned ma
             break;
         }
         if (it == max_iterations) break;
-        for (unsigned c = 0; c < d->m; ++c) { /* one layer = one check */
+        for (unsigned c : d->order) { /* check by check, layer by layer */
             const auto& vs = d->rows[c];
             const size_t dc = vs.size();
             float Q[16] = {};
