@@ -811,14 +811,14 @@ class PacketReceiver:
     packet_receiver.hpp:131-139,233-247 on the device instead of asking the caller for
     `header_fn`: descrambler -> HeaderPayloadSplit -> HeaderFecDecoder -> HeaderParser supply the
     parsed_header messages.  The reference resolves that loop packet by packet; a batch resolves
-    it in two passes: (A) every detection that is not inside the syncword + header of an earlier
-    one is taken through a second set of the same blocks up to its header LLRs (its payload is
-    dropped by answering "invalid_header"), which yields every candidate's header; (B) the real
+    it in two passes: (A) every detection is taken through a second set of the same blocks up to
+    its header LLRs (its payload is dropped by answering "invalid_header"), which yields every
+    candidate's header; (B) the real
     chain runs with those messages, and the headers it decodes itself are compared with the ones
     it was given (`header_mismatches` in the result; its payload LLRs leave descrambled as
-    "payload_llr" / "payload_tags").  A header whose symbols continue in the next batch stays
-    pending until then.  Known limit: a detection that pass A skips because it lies inside another
-    candidate's header window gets no header (reported as invalid)."""
+    "payload_llr" / "payload_tags").  Pass A runs on a compact stream of one 912-sample window
+    per detection, so it costs a few percent of the real pass.  A header whose symbols continue in
+    the next batch stays pending until then."""
 
     def __init__(self, samples_per_symbol=4, syncword_freq_bins=4, syncword_threshold=9.5,
                  costas_constellation="QPSK", max_items=1 << 22, pipelined=False, fused=True,
@@ -853,7 +853,6 @@ class PacketReceiver:
             self.syncword_wipeoff = SyncwordWipeoff(np.where(SYNCWORD == 1, -1.0, 1.0).astype(np.float32))  # :117-122
             if decode_headers:  # pass A: the same blocks again, up to the header LLRs
                 self._spec = {
-                    "filter": SyncwordDetectionFilter(sps),
                     "cfc": CoarseFrequencyCorrection((self.rrc_taps.size - 1) // 2 + sps),
                     "symf": SymbolFilter(pfb, arms, sps, self.rrc_taps.size - 1),
                     "wipeoff": SyncwordWipeoff(np.where(SYNCWORD == 1, -1.0, 1.0).astype(np.float32)),
@@ -863,7 +862,11 @@ class PacketReceiver:
                     "llr": ConstellationLLRDecoder(0.7, "QPSK"),
                     "headers": HeaderDecoder(),
                 }
-                self._awaiting = np.zeros(0, dtype=np.uint64)   # candidates whose header is still on its way
+                self._awaiting = np.zeros(0, dtype=np.uint64)   # detections whose window continues next batch
+                self._awaiting_tags = np.zeros(0, dtype=TAG_DTYPE)
+                self._spec_order = np.zeros(0, dtype=np.uint64)  # detections in pass A, header not out yet
+                self._spec_fifo = np.zeros(0, dtype=_abi.HEADER_MSG_DTYPE)
+                self._tail = torch.zeros(self._SPEC_W + self._SPEC_PRE, dtype=torch.complex64, device="cuda")
                 self._known_idx = np.zeros(0, dtype=np.uint64)  # candidates with a decoded header ...
                 self._known_msg = np.zeros(0, dtype=_abi.HEADER_MSG_DTYPE)  # ... and the message
                 self._pending_real = None                       # accepted packet waiting for its header
@@ -930,33 +933,67 @@ class PacketReceiver:
         return {"status": 0, "consumed": n, "symbols": w, "tags": sym_tags, "detector_tags": det_tags,
                 "accepted": acc, "headers": hdrs}
 
-    def _predecode(self, y, det_tags, idx_abs):
-        """pass A: headers of all candidates (see the class docstring); updates the table of known
-        headers"""
+    # pass A works on a compact stream: one window of _SPEC_W samples per detection, starting
+    # _SPEC_PRE samples before the tagged one (room for the matched filter's history) and long
+    # enough for syncword + header behind the filter delay: 16 + 11 + 192 < 228 symbols
+    _SPEC_PRE = 64
+    _SPEC_W = 912
+
+    def _predecode(self, y, det_tags, idx_abs, base):
+        """pass A: the header of every detection (see the class docstring); updates the table of
+        known headers.  A detection whose window runs past the end of this batch waits in
+        self._awaiting and is decoded with the next batch (its first samples come from the saved
+        tail of this one)."""
+        torch = _torch()
         sp = self._spec
-        n = det_tags.size
-        inv = np.zeros(max(n, 1), dtype=_abi.HEADER_MSG_DTYPE)
-        inv["invalid_header"] = 1
-        acc, _ = sp["filter"].gate(idx_abs, inv[:n], per_tag=True)
-        stags = det_tags[acc]
-        sym, sym_tags, _ = cfc_symbol_filter(sp["cfc"], sp["symf"], y, stags)
-        w = sp["wipeoff"].process_bulk(sym, sym_tags)
-        pm = sp["pmi"].process_bulk(w, sym_tags, inv[: sym_tags.size], per_tag=True)
-        z = sp["costas"].process_packets(pm["out"], pm["tags"])
-        d, dt = sp["remove"].process_bulk(z, pm["tags"])
-        llr, lt = sp["llr"].process_bulk(d, dt)
-        done = sp["headers"].process_bulk(llr, lt)["messages"]
-        self._awaiting = np.concatenate([self._awaiting, idx_abs[acc]])
-        k = done.size
-        self._known_idx = np.concatenate([self._known_idx, self._awaiting[:k]])
-        self._known_msg = np.concatenate([self._known_msg, done])
-        self._awaiting = self._awaiting[k:]
+        n, W, pre = y.numel(), self._SPEC_W, self._SPEC_PRE
+        # window starts relative to y[0]: waiting detections of the last batch first (negative)
+        old = self._awaiting.astype(np.int64) - np.int64(base) - pre
+        new = det_tags["index"].astype(np.int64) - pre
+        fits = new + W <= n
+        starts = np.concatenate([old, new[fits]])
+        tags = np.concatenate([self._awaiting_tags, det_tags[fits]])
+        self._awaiting, self._awaiting_tags = idx_abs[~fits], det_tags[~fits].copy()
+        k = starts.size
+        if k:
+            st = torch.from_numpy(starts).to(y.device)
+            ar = torch.arange(W, device=y.device)
+            inside = st >= 0
+            compact = torch.empty((k, W), dtype=y.dtype, device=y.device)
+            if bool(inside.all()):
+                compact = y[st[:, None] + ar]
+            else:  # a few windows begin in the previous batch: read them from [saved tail | head of y]
+                head = torch.cat([self._tail, y[: W]])
+                compact[inside] = y[st[inside][:, None] + ar]
+                compact[~inside] = head[(st[~inside] + self._tail.numel())[:, None] + ar]
+            ctags = tags.copy()
+            ctags["index"] = np.arange(k, dtype=np.uint64) * np.uint64(W) + np.uint64(pre)
+            inv = np.zeros(k, dtype=_abi.HEADER_MSG_DTYPE)
+            inv["invalid_header"] = 1
+            sym, sym_tags, _ = cfc_symbol_filter(sp["cfc"], sp["symf"], compact.reshape(-1), ctags)
+            w = sp["wipeoff"].process_bulk(sym, sym_tags)
+            self._spec_fifo = np.concatenate([self._spec_fifo, inv])
+            hdrs, self._spec_fifo = self._spec_fifo[: sym_tags.size], self._spec_fifo[sym_tags.size:]
+            pm = sp["pmi"].process_bulk(w, sym_tags, hdrs, per_tag=True)
+            z = sp["costas"].process_packets(pm["out"], pm["tags"])
+            d, dt = sp["remove"].process_bulk(z, pm["tags"])
+            llr, lt = sp["llr"].process_bulk(d, dt)
+            done = sp["headers"].process_bulk(llr, lt)["messages"]
+            self._spec_order = np.concatenate([self._spec_order, np.concatenate([
+                (old + np.int64(base) + pre).astype(np.uint64), idx_abs[fits]])])
+            m = done.size
+            self._known_idx = np.concatenate([self._known_idx, self._spec_order[:m]])
+            self._known_msg = np.concatenate([self._known_msg, done])
+            self._spec_order = self._spec_order[m:]
+            order = np.argsort(self._known_idx, kind="stable")
+            self._known_idx, self._known_msg = self._known_idx[order], self._known_msg[order]
+        self._tail = y[-(W + pre):].clone()
 
     def _stage1_decode(self, y, det_tags, n, base):
         torch = _torch()
         with torch.cuda.stream(self._streams[1]):
             idx_abs = (base + det_tags["index"]).astype(np.uint64)
-            self._predecode(y, det_tags, idx_abs)
+            self._predecode(y, det_tags, idx_abs, base)
             resolve = None
             if self._pending_real is not None:
                 j = np.searchsorted(self._known_idx, self._pending_real)
@@ -976,7 +1013,7 @@ class PacketReceiver:
             hit = (j < self._known_idx.size) & (self._known_idx[jc] == idx_abs) if self._known_idx.size else \
                 np.zeros(det_tags.size, dtype=bool)
             msgs[hit] = self._known_msg[jc[hit]]
-            msgs["invalid_header"][np.isin(idx_abs, self._awaiting)] = 2
+            msgs["invalid_header"][np.isin(idx_abs, self._awaiting) | np.isin(idx_abs, self._spec_order)] = 2
             acc, _ = self.syncword_detection_filter.gate(idx_abs, msgs, per_tag=True)
             tags, headers = det_tags[acc], msgs[acc]
             if headers.size and headers["invalid_header"][-1] == 2:
