@@ -728,6 +728,158 @@ public:
     }
 };
 
+// ---------------------------------------------------------------- AdditiveScrambler
+// replaces gr::packet_modem::AdditiveScrambler<float> / <uint8_t> (additive_scrambler.hpp:24-100)
+template <typename T>
+class AdditiveScrambler : public gr::Block<AdditiveScrambler<T>>
+{
+    static_assert(std::is_same_v<T, float> || std::is_same_v<T, uint8_t>);
+    gr4pm_additive_scrambler* _h = nullptr;
+    detail::DeviceStage<T> _din, _dout;
+
+public:
+    gr::PortIn<T> in;
+    gr::PortOut<T> out;
+    uint64_t mask = 0x8a, seed = 0x7f, length = 7, count = 0; // :61-64
+    std::string reset_tag_key = "";
+
+    ~AdditiveScrambler() { gr4pm_additive_scrambler_destroy(_h); }
+    void start() // :68
+    {
+        gr4pm_additive_scrambler_destroy(_h);
+        gr4pm_additive_scrambler_params p{ mask, seed, length, count, std::is_same_v<T, float> ? 1 : 2, nullptr };
+        detail::check(gr4pm_additive_scrambler_create(&p, &_h), "AdditiveScrambler::start");
+    }
+    gr::work::Status processBulk(const gr::ConsumableSpan auto& inSpan, gr::PublishableSpan auto& outSpan)
+    {
+        const uint64_t zero = 0;
+        const bool reset = !reset_tag_key.empty() && this->input_tags_present() &&
+                           this->mergedInputTag().map.contains(reset_tag_key); // :78-80
+        const size_t n = std::min(inSpan.size(), outSpan.size());
+        T* din = _din.get(n);
+        T* dout = _dout.get(n);
+        (void)hipMemcpy(din, &*inSpan.begin(), n * sizeof(T), hipMemcpyHostToDevice);
+        detail::check(gr4pm_additive_scrambler_process(_h, din, n, dout, &zero, reset ? 1 : 0),
+                      "AdditiveScrambler::processBulk");
+        (void)hipMemcpy(&*outSpan.begin(), dout, n * sizeof(T), hipMemcpyDeviceToHost);
+        if (!inSpan.consume(n)) throw gr::exception("consume failed");
+        outSpan.publish(n);
+        return gr::work::Status::OK;
+    }
+};
+
+// ---------------------------------------------------------------- HeaderPayloadSplit
+// replaces gr::packet_modem::HeaderPayloadSplit<float> (header_payload_split.hpp:9-147)
+class HeaderPayloadSplit : public gr::Block<HeaderPayloadSplit>
+{
+    gr4pm_header_payload_split* _h = nullptr;
+    detail::DeviceStage<float> _din, _dhdr, _dpay;
+
+public:
+    gr::PortIn<float> in;
+    gr::PortOut<float> header;
+    gr::PortOut<float> payload;
+    size_t header_size = 256;
+    std::string packet_len_tag_key = "packet_len";
+    std::string payload_length_key = "payload_bits";
+    constexpr static gr::TagPropagationPolicy tag_policy = gr::TagPropagationPolicy::TPP_CUSTOM;
+
+    ~HeaderPayloadSplit() { gr4pm_header_payload_split_destroy(_h); }
+    void start() // :41-45
+    {
+        gr4pm_header_payload_split_destroy(_h);
+        gr4pm_header_payload_split_params p{ header_size, nullptr };
+        detail::check(gr4pm_header_payload_split_create(&p, &_h), "HeaderPayloadSplit::start");
+    }
+    gr::work::Status processBulk(const gr::ConsumableSpan auto& inSpan, gr::PublishableSpan auto& headerSpan,
+                                 gr::PublishableSpan auto& payloadSpan)
+    {
+        gr4pm_packet_tag tag{}, ht[2], pt[2];
+        size_t n_tags = 0;
+        gr::property_map map;
+        if (this->input_tags_present()) { // :68-88
+            map = this->mergedInputTag().map;
+            tag.kind = GR4PM_PKT_HEADER_START;
+            tag.constellation = -1;
+            tag.loop_bandwidth = -1.0;
+            if (map.contains(payload_length_key)) {
+                tag.kind = GR4PM_PKT_PAYLOAD;
+                tag.payload_bits = pmtv::cast<uint64_t>(map.at(payload_length_key));
+                map[packet_len_tag_key] = pmtv::pmt(tag.payload_bits); // :81
+            }
+            n_tags = 1;
+        }
+        // one output per call, like the reference (:97-123)
+        const size_t n = std::min({ inSpan.size(), headerSpan.size(), payloadSpan.size() });
+        float* din = _din.get(n);
+        float* dh = _dhdr.get(n);
+        float* dp = _dpay.get(n);
+        (void)hipMemcpy(din, &*inSpan.begin(), n * sizeof(float), hipMemcpyHostToDevice);
+        size_t nh = 0, np = 0, nht = 0, npt = 0;
+        detail::check(gr4pm_header_payload_split_process(_h, din, n, dh, &nh, dp, &np, &tag, n_tags, ht, &nht, pt, &npt, 2),
+                      "HeaderPayloadSplit::processBulk"); // the unexpected-tag exception of :75-78 included
+        (void)hipMemcpy(&*headerSpan.begin(), dh, nh * sizeof(float), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&*payloadSpan.begin(), dp, np * sizeof(float), hipMemcpyDeviceToHost);
+        if (nht) header.publishTag(map, 0);
+        if (npt) payload.publishTag(map, 0);
+        if (!inSpan.consume(n)) throw gr::exception("consume failed");
+        headerSpan.publish(nh);
+        payloadSpan.publish(np);
+        this->_mergedInputTag.map.clear(); // :125-131
+        return gr::work::Status::OK;
+    }
+};
+
+// ---------------------------------------------------------------- HeaderFecDecoder
+// replaces gr::packet_modem::HeaderFecDecoder (header_fec_decoder.hpp:13-359) and with it the
+// reference's calls into ldpc-toolbox (:276,285,315-321)
+class HeaderFecDecoder : public gr::Block<HeaderFecDecoder, gr::Resampling<1U, 64U, true>>
+{
+    gr4pm_header_fec_decoder* _h = nullptr;
+    detail::DeviceStage<float> _din;
+    std::vector<uint8_t> _bytes, _invalid;
+
+public:
+    gr::PortIn<float> in;
+    gr::PortOut<uint8_t> out;
+    std::string alist; // the text of header_fec_decoder.hpp:31-258 (data/header_ldpc_128_32.alist)
+
+    ~HeaderFecDecoder() { gr4pm_header_fec_decoder_destroy(_h); }
+    void start() // :268-280
+    {
+        if (_h) throw gr::exception("an LDPC decoder already exists");
+        gr4pm_header_fec_decoder_params p{ alist.c_str(), 25, nullptr };
+        detail::check(gr4pm_header_fec_decoder_create(&p, &_h), "HeaderFecDecoder::start");
+    }
+    void stop() // :282-288
+    {
+        gr4pm_header_fec_decoder_destroy(_h);
+        _h = nullptr;
+    }
+    gr::work::Status processBulk(const gr::ConsumableSpan auto& inSpan, gr::PublishableSpan auto& outSpan)
+    {
+        const size_t codewords = std::min(inSpan.size() / 256, outSpan.size() / 4); // :293-294
+        if (codewords == 0) { // :296-304
+            std::ignore = inSpan.consume(0);
+            outSpan.publish(0);
+            return inSpan.size() < 256 ? gr::work::Status::INSUFFICIENT_INPUT_ITEMS
+                                       : gr::work::Status::INSUFFICIENT_OUTPUT_ITEMS;
+        }
+        float* din = _din.get(codewords * 256);
+        (void)hipMemcpy(din, &*inSpan.begin(), codewords * 256 * sizeof(float), hipMemcpyHostToDevice);
+        _bytes.resize(codewords * 4);
+        _invalid.resize(codewords);
+        detail::check(gr4pm_header_fec_decoder_process(_h, din, codewords, _bytes.data(), _invalid.data()),
+                      "HeaderFecDecoder::processBulk");
+        std::copy(_bytes.begin(), _bytes.end(), outSpan.begin());
+        for (size_t c = 0; c < codewords; ++c)
+            if (_invalid[c]) out.publishTag({ { "invalid_header", pmtv::pmt_null() } }, static_cast<ssize_t>(4 * c)); // :322-326
+        if (!inSpan.consume(codewords * 256)) throw gr::exception("consume failed");
+        outSpan.publish(codewords * 4);
+        return gr::work::Status::OK;
+    }
+};
+
 } // namespace gr::packet_modem::hip
 
 ENABLE_REFLECTION(gr::packet_modem::hip::SyncwordDetection, in, out, fft_size, samples_per_symbol, rrc_taps,
@@ -746,3 +898,8 @@ ENABLE_REFLECTION(gr::packet_modem::hip::PayloadMetadataInsert, parsed_header, i
                   payload_costas_loop_bandwidth, log);
 ENABLE_REFLECTION(gr::packet_modem::hip::SyncwordRemove, in, out, syncword_size);
 ENABLE_REFLECTION(gr::packet_modem::hip::ConstellationLLRDecoder, in, out, noise_sigma, constellation);
+ENABLE_REFLECTION_FOR_TEMPLATE(gr::packet_modem::hip::AdditiveScrambler, in, out, mask, seed, length, count,
+                               reset_tag_key);
+ENABLE_REFLECTION(gr::packet_modem::hip::HeaderPayloadSplit, in, header, payload, header_size, packet_len_tag_key,
+                  payload_length_key);
+ENABLE_REFLECTION(gr::packet_modem::hip::HeaderFecDecoder, in, out, alist);
