@@ -136,6 +136,13 @@ class HeaderFecDecoderParams(C.Structure):
     _fields_ = [("alist", C.c_char_p), ("max_iterations", C.c_uint32), ("stream", C.c_void_p)]
 
 
+class CrcCheckParams(C.Structure):
+    _fields_ = [("num_bits", C.c_uint), ("poly", C.c_uint64), ("initial_value", C.c_uint64),
+                ("final_xor", C.c_uint64), ("input_reflected", C.c_int), ("result_reflected", C.c_int),
+                ("swap_endianness", C.c_int), ("discard_crc", C.c_int), ("skip_header_bytes", C.c_uint64),
+                ("stream", C.c_void_p)]
+
+
 class PfbArbParams(C.Structure):
     _fields_ = [("rate", C.c_double), ("rate_is_double", C.c_int), ("taps", C.c_void_p),
                 ("n_taps", C.c_size_t), ("filter_size", C.c_size_t), ("stream", C.c_void_p)]
@@ -179,6 +186,8 @@ EXPORTS = [
     "gr4pm_header_payload_split_reset", "gr4pm_header_payload_split_process",
     "gr4pm_header_fec_decoder_create", "gr4pm_header_fec_decoder_destroy", "gr4pm_header_fec_decoder_process",
     "gr4pm_header_parse",
+    "gr4pm_binary_slicer_process", "gr4pm_pack_bits_process", "gr4pm_slice_pack_process",
+    "gr4pm_crc_check_create", "gr4pm_crc_check_destroy", "gr4pm_crc_check_compute", "gr4pm_crc_check_process",
 ]
 
 _lib = None
@@ -290,6 +299,15 @@ def lib():
     L.gr4pm_header_fec_decoder_process.argtypes = [vp, vp, sz, vp, vp]
     L.gr4pm_header_parse.argtypes = [vp, vp, sz, vp, vp]
     L.gr4pm_header_parse.restype = None
+    L.gr4pm_binary_slicer_process.argtypes = [vp, sz, vp, C.c_int, vp]
+    L.gr4pm_pack_bits_process.argtypes = [vp, sz, vp, sz, C.c_uint, C.c_int, vp]
+    L.gr4pm_slice_pack_process.argtypes = [vp, sz, vp, vp]
+    L.gr4pm_crc_check_create.argtypes = [C.POINTER(CrcCheckParams), C.POINTER(vp)]
+    L.gr4pm_crc_check_destroy.argtypes = [vp]
+    L.gr4pm_crc_check_destroy.restype = None
+    L.gr4pm_crc_check_compute.argtypes = [vp, vp, sz]
+    L.gr4pm_crc_check_compute.restype = C.c_uint64
+    L.gr4pm_crc_check_process.argtypes = [vp, vp, vp, vp, sz, vp, vp, szp]
     L.gr4pm_firdes_root_raised_cosine.argtypes = [C.c_double] * 4 + [sz, vp]
     L.gr4pm_firdes_root_raised_cosine.restype = sz
     _lib = L

@@ -755,6 +755,81 @@ SYNCWORD = np.array(
     dtype=np.uint8)
 
 
+def binary_slicer(x, invert=False):
+    """BinarySlicer<invert>, binary_slicer.hpp:10-35: float32 soft symbols -> uint8 hard symbols"""
+    torch = _torch()
+    x = x.contiguous()
+    assert x.is_cuda and x.dtype == torch.float32
+    out = torch.empty(x.numel(), dtype=torch.uint8, device=x.device)
+    check(lib().gr4pm_binary_slicer_process(x.data_ptr(), x.numel(), out.data_ptr(), 1 if invert else 0,
+                                            _stream_handle()), "BinarySlicer")
+    return out
+
+
+def pack_bits(x, inputs_per_output=8, bits_per_input=1, msb_first=True):
+    """PackBits<MSB|LSB, uint8_t, uint8_t>, pack_bits.hpp"""
+    torch = _torch()
+    x = x.contiguous()
+    assert x.is_cuda and x.dtype == torch.uint8
+    if x.numel() % inputs_per_output:
+        raise Gr4pmError("input size not divisible by inputs_per_output")
+    n_out = x.numel() // inputs_per_output
+    out = torch.empty(n_out, dtype=torch.uint8, device=x.device)
+    check(lib().gr4pm_pack_bits_process(x.data_ptr(), n_out, out.data_ptr(), inputs_per_output, bits_per_input,
+                                        1 if msb_first else 0, _stream_handle()), "PackBits")
+    return out
+
+
+def slice_pack(llr):
+    """BinarySlicer<true> + PackBits<>(8, 1) in one kernel (packet_receiver.hpp:140-144)"""
+    torch = _torch()
+    llr = llr.contiguous()
+    assert llr.is_cuda and llr.dtype == torch.float32 and llr.numel() % 8 == 0
+    out = torch.empty(llr.numel() // 8, dtype=torch.uint8, device=llr.device)
+    check(lib().gr4pm_slice_pack_process(llr.data_ptr(), out.numel(), out.data_ptr(), _stream_handle()), "slice_pack")
+    return out
+
+
+class CrcCheck:
+    """crc_check.hpp:22-239 (defaults = CRC-32, :61-66)"""
+
+    def __init__(self, num_bits=32, poly=0x4C11DB7, initial_value=0xFFFFFFFF, final_xor=0xFFFFFFFF,
+                 input_reflected=True, result_reflected=True, swap_endianness=False, discard_crc=False,
+                 skip_header_bytes=0):
+        p = _abi.CrcCheckParams(num_bits, poly, initial_value, final_xor, int(input_reflected), int(result_reflected),
+                                int(swap_endianness), int(discard_crc), skip_header_bytes, _stream_handle())
+        self._h = C.c_void_p()
+        check(lib().gr4pm_crc_check_create(C.byref(p), C.byref(self._h)), "CrcCheck")
+
+    def compute(self, data):
+        d = np.ascontiguousarray(data, dtype=np.uint8)
+        return int(lib().gr4pm_crc_check_compute(self._h, _np_ptr(d), d.size))
+
+    def process_bulk(self, x, packet_len, packet_offset=None):
+        """x: CUDA uint8 packets ("packet_len" tags = packet_len[], laid back to back unless
+        packet_offset is given).  Returns (bytes of the packets that pass, out_len per packet)"""
+        torch = _torch()
+        x = x.contiguous()
+        assert x.is_cuda and x.dtype == torch.uint8
+        pl = np.ascontiguousarray(packet_len, dtype=np.uint64)
+        po = (np.concatenate([[0], np.cumsum(pl)[:-1]]).astype(np.uint64) if packet_offset is None
+              else np.ascontiguousarray(packet_offset, dtype=np.uint64))
+        out = torch.empty(max(x.numel(), 1), dtype=torch.uint8, device=x.device)
+        ol = np.zeros(max(pl.size, 1), dtype=np.uint64)
+        n = C.c_size_t(0)
+        check(lib().gr4pm_crc_check_process(self._h, x.data_ptr(), _np_ptr(po), _np_ptr(pl), pl.size, out.data_ptr(),
+                                            _np_ptr(ol), C.byref(n)), "CrcCheck.processBulk")
+        return out[: n.value], ol[: pl.size]
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _release("gr4pm_crc_check_destroy", self._h)
+                self._h = None
+        except Exception:  # interpreter shutdown
+            pass
+
+
 class HeaderDecoder:
     """The header decode loop of packet_receiver.hpp:131-139 as one unit: AdditiveScrambler<float>
     (CCSDS 131.0-B-5 polynomial, reset at every "header_start") -> HeaderPayloadSplit ->
@@ -818,7 +893,9 @@ class PacketReceiver:
     it was given (`header_mismatches` in the result; its payload LLRs leave descrambled as
     "payload_llr" / "payload_tags").  Pass A runs on a compact stream of one 912-sample window
     per detection, so it costs a few percent of the real pass.  A header whose symbols continue in
-    the next batch stays pending until then."""
+    the next batch stays pending until then.  The payload tail follows (:140-147): BinarySlicer<true>,
+    PackBits, CrcCheck(discard_crc) -- "packets" holds the bytes of the packets whose CRC-32 matches,
+    "packet_lengths" their lengths (0 = dropped)."""
 
     def __init__(self, samples_per_symbol=4, syncword_freq_bins=4, syncword_threshold=9.5,
                  costas_constellation="QPSK", max_items=1 << 22, pipelined=False, fused=True,
@@ -879,6 +956,9 @@ class PacketReceiver:
                 self.constellation_decoder = ConstellationLLRDecoder(0.7, "QPSK")  # :129-130
             if decode_headers:
                 self.header_decoder = HeaderDecoder()                             # :131-139
+                self.payload_crc_check = CrcCheck(discard_crc=True)               # :145-147
+                self._payload_carry = None   # soft bits of a payload that continues in the next batch
+                self._payload_lens = np.zeros(0, dtype=np.uint64)  # bits of the payloads not finished yet
                 self._used_msgs = np.zeros(0, dtype=_abi.HEADER_MSG_DTYPE)        # given to pass B, not yet verified
         # messages of accepted tags on their way to PayloadMetadataInsert: the symbol filter can
         # hold a tag of the last few samples back until the next call (symbol_filter.hpp:204-228)
@@ -1065,6 +1145,19 @@ class PacketReceiver:
                 res.update(header_messages=got, header_bytes=hd["header_bytes"], packet_type=hd["packet_type"],
                            payload_llr=hd["payload_llr"], payload_tags=hd["payload_tags"],
                            header_mismatches=int(np.sum(~same)))
+                # payload tail, packet_receiver.hpp:140-147: BinarySlicer<true> -> PackBits -> CrcCheck
+                # (which needs whole packets: an unfinished one waits for the next batch)
+                soft = hd["payload_llr"] if self._payload_carry is None else torch.cat([self._payload_carry,
+                                                                                       hd["payload_llr"]])
+                lens = np.concatenate([self._payload_lens, hd["payload_tags"]["payload_bits"].astype(np.uint64)])
+                ends = np.cumsum(lens)
+                whole = int(np.searchsorted(ends, soft.numel(), side="right"))
+                used = int(ends[whole - 1]) if whole else 0
+                packed = slice_pack(soft[:used])
+                data, out_len = self.payload_crc_check.process_bulk(packed, lens[:whole] // 8)
+                self._payload_carry = soft[used:].clone() if used < soft.numel() else None
+                self._payload_lens = lens[whole:]
+                res.update(packets=data, packet_lengths=out_len, crc_ok=out_len > 0)
         return res
 
     def _stage12(self, fut1):

@@ -215,10 +215,130 @@ __global__ __launch_bounds__(64) void k_header_fec(const float* __restrict__ llr
     if (lane == 0) invalid[cw] = found ? 0 : 1;
 }
 
+// ------------------------------------------------------------------ payload tail
+__global__ __launch_bounds__(256) void k_slice(const float* __restrict__ in, size_t n, uint8_t* __restrict__ out,
+                                               int invert)
+{
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * blockDim.x)
+        out[i] = invert ? in[i] < 0.0f : in[i] > 0.0f; // binary_slicer.hpp:28-33
+}
+__global__ __launch_bounds__(256) void k_pack(const uint8_t* __restrict__ in, size_t n_out, uint8_t* __restrict__ out,
+                                              unsigned per, unsigned bits, int msb_first)
+{
+    const unsigned mask = (1u << bits) - 1u;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n_out;
+         i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        unsigned join = 0, shift = 0;
+        for (unsigned k = 0; k < per; ++k) { // pack_bits.hpp: MSB: first input in the top bits
+            const unsigned chunk = in[i * per + k] & mask;
+            if (msb_first) join = (join << bits) | chunk;
+            else {
+                join |= chunk << shift;
+                shift += bits;
+            }
+        }
+        out[i] = static_cast<uint8_t>(join);
+    }
+}
+// BinarySlicer<true> + PackBits<MSB>(8 x 1 bit): one thread per output byte, two 16-byte loads
+__global__ __launch_bounds__(256) void k_slice_pack(const float* __restrict__ in, size_t n_out,
+                                                    uint8_t* __restrict__ out)
+{
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n_out;
+         i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        unsigned b = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) b = (b << 1) | (in[i * 8 + k] < 0.0f ? 1u : 0u);
+        out[i] = static_cast<uint8_t>(b);
+    }
+}
+// CrcCheck: one lane per packet (table-driven, byte by byte, crc.hpp:130-147); the table sits in
+// LDS.  ok[i] = the CRC at the end of the packet matches.
+struct CrcPacket {
+    unsigned long long offset, len;
+};
+__global__ __launch_bounds__(64) void k_crc_check(const uint8_t* __restrict__ in, const CrcPacket* __restrict__ pk,
+                                                  unsigned n_packets, const unsigned long long* __restrict__ table,
+                                                  unsigned num_bits, unsigned long long mask,
+                                                  unsigned long long initial_value, unsigned long long final_xor,
+                                                  int input_reflected, int result_reflected, int swap_endianness,
+                                                  unsigned long long skip, uint8_t* __restrict__ ok)
+{
+    __shared__ unsigned long long t[256];
+    for (int i = threadIdx.x; i < 256; i += 64) t[i] = table[i];
+    __syncthreads();
+    const unsigned p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_packets) return;
+    const CrcPacket q = pk[p];
+    const unsigned crc_bytes = num_bits / 8;
+    if (q.len <= crc_bytes) { // too short, crc_check.hpp:152-161
+        ok[p] = 0;
+        return;
+    }
+    const unsigned long long payload = q.len - crc_bytes;
+    const uint8_t* d = in + q.offset;
+    unsigned long long rem = initial_value;
+    const unsigned long long first = skip < payload ? skip : payload;
+    if (input_reflected) {
+        for (unsigned long long k = first; k < payload; ++k) rem = t[(rem ^ d[k]) & 0xff] ^ (rem >> 8);
+    } else {
+        for (unsigned long long k = first; k < payload; ++k)
+            rem = (t[((rem >> (num_bits - 8)) ^ d[k]) & 0xff] ^ (rem << 8)) & mask;
+    }
+    if (input_reflected != result_reflected) { // reflect(), crc.hpp:44-53
+        unsigned long long w = rem, r = w & 1;
+        for (unsigned i = 1; i < num_bits; ++i) {
+            w >>= 1;
+            r = (r << 1) | (w & 1);
+        }
+        rem = r;
+    }
+    rem ^= final_xor;
+    unsigned long long in_packet = 0; // :167-178
+    if (swap_endianness) {
+        for (unsigned long long i = q.len; i-- > payload;) in_packet = (in_packet << 8) | d[i];
+    } else {
+        for (unsigned long long i = payload; i < q.len; ++i) in_packet = (in_packet << 8) | d[i];
+    }
+    ok[p] = in_packet == rem ? 1 : 0;
+}
+struct BSpan {
+    unsigned long long src, dst, len;
+};
+__global__ __launch_bounds__(256) void k_gather_u8(const BSpan* __restrict__ spans, const uint8_t* __restrict__ in,
+                                                   uint8_t* __restrict__ out)
+{
+    const BSpan sp = spans[blockIdx.y];
+    for (unsigned long long i = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < sp.len;
+         i += static_cast<unsigned long long>(gridDim.x) * blockDim.x)
+        out[sp.dst + i] = in[sp.src + i];
+}
+
 } // namespace
 } // namespace gr4pm
 
 using namespace gr4pm;
+
+struct gr4pm_crc_check {
+    gr4pm_crc_check_params p;
+    unsigned long long table[256];
+    unsigned long long mask;
+    DevBuf<unsigned long long> d_table;
+    DevBuf<CrcPacket> pk;
+    DevBuf<uint8_t> ok;
+    PinnedBuf<uint8_t> ok_host;
+    DevBuf<BSpan> spans;
+    unsigned long long reflect(unsigned long long word) const
+    {
+        unsigned long long ret = word & 1;
+        for (unsigned i = 1; i < p.num_bits; ++i) {
+            word >>= 1;
+            ret = (ret << 1) | (word & 1);
+        }
+        return ret;
+    }
+};
 
 struct gr4pm_additive_scrambler {
     uint64_t mask, seed, length, count;
@@ -676,6 +796,173 @@ void gr4pm_header_parse(const uint8_t* headers, const uint8_t* invalid, size_t n
         msgs[i].invalid_header = valid ? 0 : 1;
         if (packet_type) packet_type[i] = valid ? hd[2] : -1;
     }
+}
+
+static unsigned grid1d(size_t n) { return static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>((n + 255) / 256, 65535 * 4))); }
+
+gr4pm_status gr4pm_binary_slicer_process(const float* in, size_t n, uint8_t* out, int invert, void* stream)
+{
+    if (n == 0) return GR4PM_OK;
+    if (!in || !out) return GR4PM_ERR_INVALID;
+    GR4PM_TRY(require_device());
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_slice, dim3(grid1d(n)), dim3(256), 0, s, in, n, out, invert);
+    GR4PM_HIP_TRY(hipGetLastError());
+    GR4PM_HIP_TRY(hipStreamSynchronize(s));
+    return GR4PM_OK;
+}
+gr4pm_status gr4pm_pack_bits_process(const uint8_t* in, size_t n_out, uint8_t* out, size_t inputs_per_output,
+                                     unsigned bits_per_input, int msb_first, void* stream)
+{
+    if (inputs_per_output == 0 || bits_per_input == 0 || inputs_per_output * bits_per_input > 8) {
+        set_error("inputs_per_output %zu x bits_per_input %u does not fit a byte", inputs_per_output, bits_per_input);
+        return GR4PM_ERR_INVALID;
+    }
+    if (n_out == 0) return GR4PM_OK;
+    if (!in || !out) return GR4PM_ERR_INVALID;
+    GR4PM_TRY(require_device());
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_pack, dim3(grid1d(n_out)), dim3(256), 0, s, in, n_out, out,
+                       static_cast<unsigned>(inputs_per_output), bits_per_input, msb_first);
+    GR4PM_HIP_TRY(hipGetLastError());
+    GR4PM_HIP_TRY(hipStreamSynchronize(s));
+    return GR4PM_OK;
+}
+gr4pm_status gr4pm_slice_pack_process(const float* in, size_t n_out, uint8_t* out, void* stream)
+{
+    if (n_out == 0) return GR4PM_OK;
+    if (!in || !out) return GR4PM_ERR_INVALID;
+    GR4PM_TRY(require_device());
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_slice_pack, dim3(grid1d(n_out)), dim3(256), 0, s, in, n_out, out);
+    GR4PM_HIP_TRY(hipGetLastError());
+    GR4PM_HIP_TRY(hipStreamSynchronize(s));
+    return GR4PM_OK;
+}
+
+gr4pm_status gr4pm_crc_check_create(const gr4pm_crc_check_params* p, gr4pm_crc_check** out)
+{
+    if (!p || !out) return GR4PM_ERR_INVALID;
+    *out = nullptr;
+    if (p->num_bits < 8 || p->num_bits > 64 || p->num_bits % 8 != 0) {
+        set_error("CRC number of bits must be a multiple of 8 between 8 and 64"); // crc.hpp:80-83, crc_check.hpp:79-81
+        return GR4PM_ERR_INVALID;
+    }
+    GR4PM_TRY(require_device());
+    auto* h = new (std::nothrow) gr4pm_crc_check;
+    if (!h) return GR4PM_ERR_NOMEM;
+    h->p = *p;
+    h->mask = p->num_bits == 64 ? ~0ull : ((1ull << p->num_bits) - 1);
+    // table, crc.hpp:84-116
+    unsigned long long poly = p->poly;
+    h->table[0] = 0;
+    if (p->input_reflected) {
+        poly = h->reflect(poly);
+        unsigned long long crc = 1;
+        size_t i = 128;
+        do {
+            crc = (crc & 1) ? (crc >> 1) ^ poly : crc >> 1;
+            for (size_t j = 0; j < 256; j += 2 * i) h->table[i + j] = (crc ^ h->table[j]) & h->mask;
+            i >>= 1;
+        } while (i > 0);
+    } else {
+        const unsigned long long msb = 1ull << (p->num_bits - 1);
+        unsigned long long crc = msb;
+        size_t i = 1;
+        do {
+            crc = (crc & msb) ? (crc << 1) ^ poly : crc << 1;
+            for (size_t j = 0; j < i; ++j) h->table[i + j] = (crc ^ h->table[j]) & h->mask;
+            i <<= 1;
+        } while (i < 256);
+    }
+    hipStream_t s = static_cast<hipStream_t>(p->stream);
+    gr4pm_status st = h->d_table.alloc(256);
+    if (st == GR4PM_OK) st = h->d_table.upload(h->table, 256, s);
+    if (st == GR4PM_OK && hipStreamSynchronize(s) != hipSuccess) st = GR4PM_ERR_HIP;
+    if (st != GR4PM_OK) {
+        delete h;
+        return st;
+    }
+    *out = h;
+    return GR4PM_OK;
+}
+void gr4pm_crc_check_destroy(gr4pm_crc_check* h)
+{
+    if (!h) return;
+    (void)hipStreamSynchronize(static_cast<hipStream_t>(h->p.stream));
+    delete h;
+}
+uint64_t gr4pm_crc_check_compute(const gr4pm_crc_check* h, const uint8_t* data, size_t n)
+{
+    unsigned long long rem = h->p.initial_value & h->mask; // crc.hpp:119-156
+    if (h->p.input_reflected) {
+        for (size_t k = 0; k < n; ++k) rem = h->table[(rem ^ data[k]) & 0xff] ^ (rem >> 8);
+    } else {
+        for (size_t k = 0; k < n; ++k)
+            rem = (h->table[((rem >> (h->p.num_bits - 8)) ^ data[k]) & 0xff] ^ (rem << 8)) & h->mask;
+    }
+    if ((h->p.input_reflected != 0) != (h->p.result_reflected != 0)) rem = h->reflect(rem);
+    return rem ^ (h->p.final_xor & h->mask);
+}
+gr4pm_status gr4pm_crc_check_process(gr4pm_crc_check* h, const uint8_t* in, const uint64_t* packet_offset,
+                                     const uint64_t* packet_len, size_t n_packets, uint8_t* out,
+                                     uint64_t* out_len, size_t* n_out_bytes)
+{
+    if (!h || !n_out_bytes) return GR4PM_ERR_INVALID;
+    *n_out_bytes = 0;
+    if (n_packets == 0) return GR4PM_OK;
+    if (!in || !out || !packet_offset || !packet_len || !out_len) {
+        set_error("null pointer");
+        return GR4PM_ERR_INVALID;
+    }
+    hipStream_t s = static_cast<hipStream_t>(h->p.stream);
+    std::vector<CrcPacket> pk(n_packets);
+    for (size_t i = 0; i < n_packets; ++i) {
+        if (packet_len[i] == 0) {
+            set_error("received packet-length equal to zero"); // crc_check.hpp:131-136
+            return GR4PM_ERR_INVALID;
+        }
+        pk[i] = { packet_offset[i], packet_len[i] };
+    }
+    if (h->pk.n < n_packets) GR4PM_TRY(h->pk.alloc(n_packets * 2));
+    if (h->ok.n < n_packets) GR4PM_TRY(h->ok.alloc(n_packets * 2));
+    if (h->ok_host.n < n_packets) GR4PM_TRY(h->ok_host.alloc(n_packets * 2));
+    GR4PM_TRY(h->pk.upload_staged(pk.data(), n_packets, s));
+    hipLaunchKernelGGL(k_crc_check, dim3(static_cast<unsigned>((n_packets + 63) / 64)), dim3(64), 0, s, in, h->pk.p,
+                       static_cast<unsigned>(n_packets), h->d_table.p, h->p.num_bits, h->mask,
+                       h->p.initial_value & h->mask, h->p.final_xor & h->mask, h->p.input_reflected ? 1 : 0,
+                       h->p.result_reflected ? 1 : 0, h->p.swap_endianness ? 1 : 0, h->p.skip_header_bytes, h->ok.p);
+    GR4PM_HIP_TRY(hipGetLastError());
+    GR4PM_HIP_TRY(hipMemcpyAsync(h->ok_host.p, h->ok.p, n_packets, hipMemcpyDeviceToHost, s));
+    GR4PM_HIP_TRY(hipStreamSynchronize(s));
+    // passing packets leave back to back (:180-202)
+    std::vector<BSpan> spans;
+    const size_t crc_bytes = h->p.num_bits / 8;
+    size_t opos = 0;
+    unsigned long long longest = 0;
+    for (size_t i = 0; i < n_packets; ++i) {
+        out_len[i] = 0;
+        if (!h->ok_host.p[i]) continue;
+        const unsigned long long n = h->p.discard_crc ? packet_len[i] - crc_bytes : packet_len[i];
+        spans.push_back({ packet_offset[i], opos, n });
+        out_len[i] = n;
+        opos += n;
+        longest = std::max(longest, n);
+    }
+    if (!spans.empty()) {
+        if (h->spans.n < spans.size()) GR4PM_TRY(h->spans.alloc(spans.size() * 2));
+        GR4PM_TRY(h->spans.upload_staged(spans.data(), spans.size(), s));
+        const unsigned gx = static_cast<unsigned>(std::max<unsigned long long>(
+            1, std::min<unsigned long long>((longest + 2047) / 2048, 1024)));
+        for (size_t first = 0; first < spans.size(); first += 65535) {
+            const unsigned rows = static_cast<unsigned>(std::min<size_t>(65535, spans.size() - first));
+            hipLaunchKernelGGL(k_gather_u8, dim3(gx, rows), dim3(256), 0, s, h->spans.p + first, in, out);
+        }
+        GR4PM_HIP_TRY(hipGetLastError());
+        GR4PM_HIP_TRY(hipStreamSynchronize(s));
+    }
+    *n_out_bytes = opos;
+    return GR4PM_OK;
 }
 
 } // extern "C"

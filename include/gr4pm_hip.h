@@ -496,6 +496,45 @@ gr4pm_status gr4pm_header_fec_decoder_process(gr4pm_header_fec_decoder* h, const
 void gr4pm_header_parse(const uint8_t* headers, const uint8_t* invalid, size_t n, gr4pm_header_msg* msgs,
                         int32_t* packet_type);
 
+/* ====================================================================================
+ * Payload tail (packet_receiver.hpp:140-147): BinarySlicer<true> -> PackBits<> -> CrcCheck<>.
+ * ================================================================================== */
+
+/* BinarySlicer<invert, float, uint8_t> -- binary_slicer.hpp:10-35: out = invert ? in < 0 : in > 0 */
+gr4pm_status gr4pm_binary_slicer_process(const float* in, size_t n, uint8_t* out, int invert, void* stream);
+/* PackBits<MSB|LSB, uint8_t, uint8_t> -- pack_bits.hpp: n_out outputs, each joins
+ * inputs_per_output inputs of bits_per_input bits (inputs_per_output * bits_per_input <= 8) */
+gr4pm_status gr4pm_pack_bits_process(const uint8_t* in, size_t n_out, uint8_t* out, size_t inputs_per_output,
+                                     unsigned bits_per_input, int msb_first, void* stream);
+/* both at once for the receiver's wiring (invert = true, 8 x 1 bit, MSB first): n_out bytes from
+ * 8 n_out soft bits */
+gr4pm_status gr4pm_slice_pack_process(const float* in, size_t n_out, uint8_t* out, void* stream);
+
+/* CrcCheck<uint64_t> -- crc_check.hpp:22-239 with Crc<uint64_t> -- crc.hpp:31-156 */
+typedef struct gr4pm_crc_check gr4pm_crc_check;
+typedef struct {
+    unsigned num_bits;          /* crc_check.hpp:61, multiple of 8 */
+    uint64_t poly;              /* :62 */
+    uint64_t initial_value;     /* :63 */
+    uint64_t final_xor;         /* :64 */
+    int input_reflected;        /* :65 */
+    int result_reflected;       /* :66 */
+    int swap_endianness;        /* :67 */
+    int discard_crc;            /* :68 */
+    uint64_t skip_header_bytes; /* :69 */
+    void* stream;
+} gr4pm_crc_check_params;
+gr4pm_status gr4pm_crc_check_create(const gr4pm_crc_check_params* params, gr4pm_crc_check** out);
+void gr4pm_crc_check_destroy(gr4pm_crc_check* h);
+/* host helper: Crc::compute over host bytes (crc.hpp:119-156) */
+uint64_t gr4pm_crc_check_compute(const gr4pm_crc_check* h, const uint8_t* data, size_t n);
+/* in: device bytes; packet i occupies [packet_offset[i], packet_offset[i] + packet_len[i]) ("packet_len"
+ * tags).  Packets whose CRC matches are copied to `out` (device) back to back, without the CRC
+ * when discard_crc; out_len[i] (host) = bytes written for packet i, 0 = dropped (:152-208). */
+gr4pm_status gr4pm_crc_check_process(gr4pm_crc_check* h, const uint8_t* in, const uint64_t* packet_offset,
+                                     const uint64_t* packet_len, size_t n_packets, uint8_t* out,
+                                     uint64_t* out_len, size_t* n_out_bytes);
+
 /* firdes::root_raised_cosine<float> -- firdes.hpp:29-76 (host helper; out: ntaps|1 floats) */
 size_t gr4pm_firdes_root_raised_cosine(double gain, double sampling_freq, double symbol_rate,
                                        double alpha, size_t ntaps, float* out);

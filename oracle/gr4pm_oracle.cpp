@@ -1691,4 +1691,99 @@ void orc_header_fec_decode(orc_ldpc* d, const float* llrs, size_t n_codewords, u
     }
 }
 
+
+/* ----------------------------------------------------------- crc.hpp:31-156 */
+namespace {
+struct OrcCrc {
+    uint64_t table[256];
+    unsigned num_bits;
+    uint64_t mask, initial_value, final_xor, rem = 0;
+    bool input_reflected, result_reflected;
+    uint64_t reflect(uint64_t word) const /* :44-53 */
+    {
+        uint64_t ret = word & 1;
+        for (unsigned i = 1; i < num_bits; ++i) {
+            word >>= 1;
+            ret = (ret << 1) | (word & 1);
+        }
+        return ret;
+    }
+    explicit OrcCrc(const orc_crc_params& p)
+        : num_bits(p.num_bits), mask(p.num_bits == 64 ? ~uint64_t{ 0 } : ((uint64_t{ 1 } << p.num_bits) - 1)),
+          initial_value(p.initial_value & mask), final_xor(p.final_xor & mask),
+          input_reflected(p.input_reflected != 0), result_reflected(p.result_reflected != 0)
+    {
+        uint64_t poly = p.poly;
+        table[0] = 0;
+        if (input_reflected) { /* :87-100 */
+            poly = reflect(poly);
+            uint64_t crc = 1;
+            size_t i = 128;
+            do {
+                crc = (crc & 1) ? (crc >> 1) ^ poly : crc >> 1;
+                for (size_t j = 0; j < 256; j += 2 * i) table[i + j] = (crc ^ table[j]) & mask;
+                i >>= 1;
+            } while (i > 0);
+        } else { /* :101-116 */
+            const uint64_t msb = uint64_t{ 1 } << (num_bits - 1);
+            uint64_t crc = msb;
+            size_t i = 1;
+            do {
+                crc = (crc & msb) ? (crc << 1) ^ poly : crc << 1;
+                for (size_t j = 0; j < i; ++j) table[i + j] = (crc ^ table[j]) & mask;
+                i <<= 1;
+            } while (i < 256);
+        }
+    }
+    uint64_t compute(const uint8_t* data, size_t n) /* :119-156 */
+    {
+        rem = initial_value;
+        if (input_reflected) {
+            for (size_t k = 0; k < n; ++k) rem = table[(rem ^ data[k]) & 0xff] ^ (rem >> 8);
+        } else {
+            for (size_t k = 0; k < n; ++k)
+                rem = (table[((rem >> (num_bits - 8)) ^ data[k]) & 0xff] ^ (rem << 8)) & mask;
+        }
+        if (input_reflected != result_reflected) rem = reflect(rem);
+        return rem ^ final_xor;
+    }
+};
+} // namespace
+uint64_t orc_crc_compute(const orc_crc_params* p, const uint8_t* data, size_t n)
+{
+    OrcCrc c(*p);
+    return c.compute(data, n);
+}
+size_t orc_crc_check(const orc_crc_params* p, int swap_endianness, int discard_crc, uint64_t skip_header_bytes,
+                     const uint8_t* in, const uint64_t* packet_len, size_t n_packets, uint8_t* out,
+                     uint64_t* out_len)
+{
+    OrcCrc c(*p);
+    const size_t crc_bytes = p->num_bits / 8;
+    size_t ipos = 0, opos = 0;
+    for (size_t k = 0; k < n_packets; ++k) { /* crc_check.hpp:152-208 */
+        const size_t len = packet_len[k];
+        out_len[k] = 0;
+        if (len > crc_bytes) {
+            const size_t payload = len - crc_bytes;
+            const size_t skip = std::min<size_t>(skip_header_bytes, payload);
+            const uint64_t computed = c.compute(in + ipos + skip, payload - skip);
+            uint64_t in_packet = 0;
+            if (swap_endianness) {
+                for (size_t i = len; i-- > payload;) in_packet = (in_packet << 8) | in[ipos + i];
+            } else {
+                for (size_t i = payload; i < len; ++i) in_packet = (in_packet << 8) | in[ipos + i];
+            }
+            if (in_packet == computed) {
+                const size_t n_out = discard_crc ? payload : len;
+                std::copy_n(in + ipos, n_out, out + opos);
+                out_len[k] = n_out;
+                opos += n_out;
+            }
+        }
+        ipos += len;
+    }
+    return opos;
+}
+
 } /* extern "C" */

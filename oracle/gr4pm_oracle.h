@@ -244,6 +244,20 @@ int orc_ldpc_decode(orc_ldpc*, const float* llrs, uint8_t* bits_k, unsigned max_
 void orc_header_fec_decode(orc_ldpc*, const float* llrs, size_t n_codewords, uint8_t* bytes,
                            uint8_t* invalid);
 
+/* ---- Crc<uint64_t> (crc.hpp:31-156) and CrcCheck (crc_check.hpp:75-216) ---- */
+typedef struct {
+    unsigned num_bits;
+    uint64_t poly, initial_value, final_xor;
+    int input_reflected, result_reflected;
+} orc_crc_params;
+uint64_t orc_crc_compute(const orc_crc_params*, const uint8_t* data, size_t n);
+/* packets back to back in `in`, lengths in packet_len[]; passing packets are copied to `out`
+ * (without the CRC when discard_crc); out_len[i] = bytes written for packet i (0: dropped).
+ * Returns the number of output bytes. */
+size_t orc_crc_check(const orc_crc_params*, int swap_endianness, int discard_crc, uint64_t skip_header_bytes,
+                     const uint8_t* in, const uint64_t* packet_len, size_t n_packets, uint8_t* out,
+                     uint64_t* out_len);
+
 #ifdef __cplusplus
 }
 #endif

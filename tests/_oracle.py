@@ -28,6 +28,15 @@ class OrcTag(C.Structure):
     ]
 
 
+class OrcCrcParams(C.Structure):
+    _fields_ = [("num_bits", C.c_uint), ("poly", C.c_uint64), ("initial_value", C.c_uint64),
+                ("final_xor", C.c_uint64), ("input_reflected", C.c_int), ("result_reflected", C.c_int)]
+
+
+CRC32 = dict(num_bits=32, poly=0x4C11DB7, initial_value=0xFFFFFFFF, final_xor=0xFFFFFFFF, input_reflected=True,
+             result_reflected=True)  # crc_check.hpp:61-66 defaults
+
+
 TAG_DTYPE = np.dtype(
     [
         ("index", "<u8"),
@@ -173,6 +182,10 @@ def lib():
         L.orc_ldpc_destroy.argtypes = [vp]
         L.orc_ldpc_decode.argtypes = [vp, vp, vp, C.c_uint]
         L.orc_header_fec_decode.argtypes = [vp, vp, sz, vp, vp]
+        L.orc_crc_compute.restype = C.c_uint64
+        L.orc_crc_compute.argtypes = [C.POINTER(OrcCrcParams), vp, sz]
+        L.orc_crc_check.restype = sz
+        L.orc_crc_check.argtypes = [C.POINTER(OrcCrcParams), C.c_int, C.c_int, C.c_uint64, vp, vp, sz, vp, vp]
     return _lib
 
 
@@ -523,6 +536,27 @@ def header_parse(header, invalid=False):
     if invalid or length == 0 or header[2] not in (0, 1):
         return None
     return length
+
+
+def crc_compute(data, **params):
+    """Crc<uint64_t>::compute, crc.hpp:119-156"""
+    pr = OrcCrcParams(*[int(params[k]) for k in ("num_bits", "poly", "initial_value", "final_xor",
+                                                  "input_reflected", "result_reflected")])
+    d = np.ascontiguousarray(data, dtype=np.uint8)
+    return int(lib().orc_crc_compute(C.byref(pr), _p(d), d.size))
+
+
+def crc_check(data, packet_len, swap_endianness=False, discard_crc=False, skip_header_bytes=0, **params):
+    """CrcCheck over packets laid back to back, crc_check.hpp:152-208.  Returns (out bytes, out_len per packet)"""
+    pr = OrcCrcParams(*[int(params[k]) for k in ("num_bits", "poly", "initial_value", "final_xor",
+                                                  "input_reflected", "result_reflected")])
+    d = np.ascontiguousarray(data, dtype=np.uint8)
+    pl = np.ascontiguousarray(packet_len, dtype=np.uint64)
+    out = np.empty(max(d.size, 1), dtype=np.uint8)
+    ol = np.zeros(max(pl.size, 1), dtype=np.uint64)
+    n = lib().orc_crc_check(C.byref(pr), int(swap_endianness), int(discard_crc), skip_header_bytes, _p(d), _p(pl),
+                            pl.size, _p(out), _p(ol))
+    return out[:n], ol[: pl.size]
 
 
 def syncword_wipeoff(x, syncword, tag_index):

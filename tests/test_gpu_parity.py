@@ -1297,3 +1297,93 @@ def test_packet_receiver_decodes_its_own_headers(pkg, mode):
     assert np.array_equal((pay < 0).astype(np.uint8), want_bits)
     if mode == "three_calls":
         assert len(results) == 3
+
+
+# ------------------------------------------------------------------ payload tail (packet_receiver.hpp:140-147)
+def test_binary_slicer_pack_bits_crc(pkg):
+    """test/qa_binary_slicer.cpp (both polarities), pack_bits.hpp (MSB / LSB), test/qa_crc.cpp:17-21 and the
+    CRC-32 / CRC-16 / CRC-8 check values through the C-ABI; CrcCheck against the oracle"""
+    import zlib
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(100000).astype(np.float32)
+    x[:3] = [0.0, -0.0, 1e-30]
+    xd = torch.from_numpy(x).cuda()
+    assert np.array_equal(pkg.binary_slicer(xd).cpu().numpy(), (x > 0).astype(np.uint8))
+    assert np.array_equal(pkg.binary_slicer(xd, invert=True).cpu().numpy(), (x < 0).astype(np.uint8))
+    bits = rng.integers(0, 2, 80000).astype(np.uint8)
+    bd = torch.from_numpy(bits).cuda()
+    assert np.array_equal(pkg.pack_bits(bd).cpu().numpy(), np.packbits(bits))
+    assert np.array_equal(pkg.pack_bits(bd, msb_first=False).cpu().numpy(), np.packbits(bits, bitorder="little"))
+    two = rng.integers(0, 4, 40000).astype(np.uint8)
+    want = (two[0::4] << 6) | (two[1::4] << 4) | (two[2::4] << 2) | two[3::4]
+    assert np.array_equal(pkg.pack_bits(torch.from_numpy(two).cuda(), 4, 2).cpu().numpy(), want)
+    assert np.array_equal(pkg.slice_pack(xd[:80000]).cpu().numpy(), np.packbits((x[:80000] < 0).astype(np.uint8)))
+    crc16 = pkg.CrcCheck(16, 0x1021, 0xFFFF, 0xFFFF, True, True)
+    assert crc16.compute(np.zeros(10, np.uint8)) == 0x6378
+    msg = np.frombuffer(b"123456789", dtype=np.uint8)
+    assert pkg.CrcCheck().compute(msg) == 0xCBF43926
+    assert pkg.CrcCheck(16, 0x1021, 0xFFFF, 0, False, False).compute(msg) == 0x29B1
+    # packets: good, corrupted, too short; CRC-32 big-endian at the end (crc_check.hpp:167-178)
+    pk, lens = [], []
+    for k, n in enumerate([100, 1, 1500, 3, 64, 65535, 4, 2, 777]):
+        body = rng.integers(0, 256, n).astype(np.uint8)
+        if n <= 4 and k >= 6:
+            pk.append(body)
+            lens.append(n)
+            continue
+        crc = zlib.crc32(body.tobytes())
+        tail = np.array([(crc >> s) & 0xFF for s in (24, 16, 8, 0)], dtype=np.uint8)
+        if k in (2, 8):
+            body = body.copy()
+            body[n // 2] ^= 0x40
+        pk.append(np.concatenate([body, tail]))
+        lens.append(n + 4)
+    stream = np.concatenate(pk)
+    for discard in (False, True):
+        want, want_len = orc.crc_check(stream, lens, discard_crc=discard, **orc.CRC32)
+        got, got_len = pkg.CrcCheck(discard_crc=discard).process_bulk(torch.from_numpy(stream).cuda(), lens)
+        assert np.array_equal(got.cpu().numpy(), want) and np.array_equal(got_len, want_len)
+    assert [int(v > 0) for v in want_len] == [1, 1, 0, 1, 1, 1, 0, 0, 0]
+
+
+@pytest.mark.parametrize("mode", ["one_call", "three_calls"])
+def test_packet_receiver_iq_to_packets(pkg, mode):
+    """the whole receive chain of packet_receiver.hpp on the device: IQ samples in, the bytes of every
+    packet whose CRC-32 matches out (payload = user bytes + CRC-32, crc_append on the transmit side)"""
+    import zlib
+    rng = np.random.default_rng(501)
+    lengths = [100, 17, 1500, 1, 333, 64, 900]
+    gaps = [int(g) for g in rng.integers(250, 900, len(lengths))]
+    gen = np.load(os.path.join(GOLDEN, "header_ldpc_generator.npy"))
+    a = np.float32(np.sqrt(0.5))
+    rrc, _ = orc.unit_norm_rrc(4)
+    syms, user = [], []
+    for k, (plen, gap) in enumerate(zip(lengths, gaps)):
+        data = rng.integers(0, 256, plen).astype(np.uint8)
+        crc = zlib.crc32(data.tobytes())
+        if k == 4:
+            crc ^= 0x00010000                                     # this one arrives damaged
+        body = np.concatenate([data, np.array([(crc >> s) & 0xFF for s in (24, 16, 8, 0)], dtype=np.uint8)])
+        coded = np.unpackbits(orc.header_fec_encode(orc.header_format(plen), gen).ravel())
+        bits = orc.AdditiveScrambler(0x4001, 0x18E38, 16).process(np.concatenate([coded, np.unpackbits(body)]))
+        q = ((1 - 2.0 * bits[0::2]) * a + 1j * (1 - 2.0 * bits[1::2]) * a).astype(np.complex64)
+        syms += [np.zeros(gap, np.complex64), sig.BPSK[sig.SYNCWORD], q]
+        user.append(data)
+    syms.append(np.zeros(1500, np.complex64))
+    x = orc.interpolating_fir(np.concatenate(syms), 4, rrc)
+    x = (orc.rotator(x, np.float32(0.007)) * np.exp(-1j * 0.9) + sig.awgn(x.size, 0.05, 502)).astype(np.complex64)
+    rx = pkg.PacketReceiver(max_items=x.size, decode_headers=True)
+    xd = dev(x)
+    results = []
+    if mode == "one_call":
+        results.append(rx.process_bulk(xd))
+    else:
+        pos = 0
+        for want in [7 * 1752 + 296, 30 * 1752 + 296, x.size]:   # cuts land inside payloads
+            r = rx.process_bulk(xd[pos:min(pos + want, x.size)])
+            results.append(r)
+            pos += r["consumed"]
+    out = np.concatenate([r["packets"].cpu().numpy() for r in results])
+    out_len = np.concatenate([r["packet_lengths"] for r in results])
+    assert [int(v) for v in out_len] == [0 if k == 4 else n for k, n in enumerate(lengths)]
+    assert np.array_equal(out, np.concatenate([u for k, u in enumerate(user) if k != 4]))
