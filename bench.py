@@ -183,6 +183,10 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the two halves of the chain back to back on one stream")
     args = ap.parse_args()
+    # three host threads drive the three pipeline stages and spend most of their time inside the
+    # C library (GIL released); when one comes back it should not wait 5 ms (the default switch
+    # interval) for whichever thread is running Python glue at that moment
+    sys.setswitchinterval(float(os.environ.get("GR4PM_SWITCH_INTERVAL", "5e-5")))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
