@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""MI355X counterpart of the reference's apps/packet_receiver_file.cpp (apps/README.md:5-24):
+
+    packet_receiver_file.py input_file [syncword_freq_bins=4] [syncword_threshold=9.5] [--out packets.bin]
+
+reads IQ samples from `input_file` in raw little-endian complex64 (std::complex<float>, what
+FileSource<c64> freads, file_source.hpp:32,53) at 4 samples/symbol, runs the whole receiver on
+the GPU (PacketReceiver(decode_headers=True): detection ... header decode ... CRC check) and
+hands over the packets whose CRC-32 matches.  The reference writes them to a TUN device (needs
+root and a network namespace); here they go to `--out` as records of a big-endian uint16 length
+followed by the bytes, or are just counted.
+
+The file is streamed: host chunks are staged in pinned memory and copied to the device on a
+copy stream while the previous chunk is being processed; the samples the detector leaves
+unconsumed (less than one FFT block) are presented again in front of the next chunk."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+
+def receive_file(path, syncword_freq_bins=4, syncword_threshold=9.5, chunk_items=1 << 24, out=None, pkg=None):
+    """returns dict(packets: list of bytes, items, seconds, headers, invalid_headers, crc_failures)"""
+    pkg = pkg or ge.load_package()
+    n_file = os.path.getsize(path) // 8
+    dev = torch.device("cuda", torch.cuda.current_device())
+    rx = pkg.PacketReceiver(4, syncword_freq_bins, syncword_threshold, max_items=chunk_items + 4096,
+                            decode_headers=True)
+    fft = rx.syncword_detection.fft_size
+    pinned = [torch.empty(chunk_items, dtype=torch.complex64).pin_memory() for _ in range(2)]
+    staged = [torch.empty(chunk_items, dtype=torch.complex64, device=dev) for _ in range(2)]
+    work = torch.empty(chunk_items + 4096, dtype=torch.complex64, device=dev)
+    copy_stream = torch.cuda.Stream()
+    events = [torch.cuda.Event(), torch.cuda.Event()]
+    packets, stats = [], {"headers": 0, "invalid_headers": 0, "crc_failures": 0}
+    fh = open(path, "rb")
+
+    def load(slot):
+        """file -> pinned -> device (asynchronously on the copy stream); returns items read"""
+        view = pinned[slot].numpy().view(np.uint8)
+        got = fh.readinto(memoryview(view)) // 8
+        if got:
+            with torch.cuda.stream(copy_stream):
+                staged[slot][:got].copy_(pinned[slot][:got], non_blocking=True)
+                events[slot].record(copy_stream)
+        return got
+
+    def deliver(res):
+        m = res["header_messages"]
+        stats["headers"] += int(m.size)
+        stats["invalid_headers"] += int(np.sum(m["invalid_header"] != 0))
+        lens = res["packet_lengths"]
+        stats["crc_failures"] += int(np.sum(lens == 0))
+        data = res["packets"].cpu().numpy()
+        pos = 0
+        for n in lens[lens > 0]:
+            n = int(n)
+            packets.append(data[pos:pos + n].tobytes())
+            pos += n
+
+    t0 = time.perf_counter()
+    slot, left, done = 0, 0, 0
+    got = load(slot)
+    while got or left >= fft:
+        nxt = 0
+        if got:
+            torch.cuda.current_stream().wait_event(events[slot])
+            work[left:left + got].copy_(staged[slot][:got])
+            nxt = load(slot ^ 1)          # the next chunk travels while this one is processed
+        n = left + got
+        if n < fft:
+            break
+        res = rx.process_bulk(work[:n])
+        deliver(res)
+        c = res["consumed"]
+        done += c
+        left = n - c
+        if left:
+            work[:left].copy_(work[c:n].clone())
+        slot ^= 1
+        got = nxt
+        if not got and left < fft:
+            break
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    fh.close()
+    if out:
+        with open(out, "wb") as f:
+            for p in packets:
+                f.write(len(p).to_bytes(2, "big"))
+                f.write(p)
+    return {"packets": packets, "items": done, "file_items": n_file, "seconds": dt, **stats}
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("input_file")
+    ap.add_argument("syncword_freq_bins", nargs="?", type=int, default=4)   # packet_receiver_file.cpp:25
+    ap.add_argument("syncword_threshold", nargs="?", type=float, default=9.5)  # :26
+    ap.add_argument("--out", help="write the received packets here (uint16 big-endian length + bytes each)")
+    ap.add_argument("--chunk-items", type=int, default=1 << 24)
+    a = ap.parse_args()
+    r = receive_file(a.input_file, a.syncword_freq_bins, a.syncword_threshold, a.chunk_items, a.out)
+    print(f"{r['items']} of {r['file_items']} samples in {r['seconds']:.3f} s = {r['items'] / r['seconds'] / 1e6:.1f} Msps "
+          f"(file and PCIe included); headers {r['headers']} ({r['invalid_headers']} invalid), packets "
+          f"{len(r['packets'])} ({r['crc_failures']} CRC failures), {sum(len(p) for p in r['packets'])} bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1387,3 +1387,46 @@ def test_packet_receiver_iq_to_packets(pkg, mode):
     out_len = np.concatenate([r["packet_lengths"] for r in results])
     assert [int(v) for v in out_len] == [0 if k == 4 else n for k, n in enumerate(lengths)]
     assert np.array_equal(out, np.concatenate([u for k, u in enumerate(user) if k != 4]))
+
+
+def test_packet_receiver_file_app(pkg, tmp_path):
+    """apps/packet_receiver_file.py (the reference's apps/packet_receiver_file.cpp): a raw complex64 IQ
+    file in, the transmitted packets out, streamed in chunks that cut packets anywhere"""
+    import importlib.util
+    import zlib
+    spec = importlib.util.spec_from_file_location("packet_receiver_file",
+                                                  os.path.join(os.path.dirname(GOLDEN), "..", "apps", "packet_receiver_file.py"))
+    app = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(app)
+    rng = np.random.default_rng(601)
+    lengths = [int(v) for v in rng.integers(1, 600, 40)]
+    gaps = [int(g) for g in rng.integers(250, 700, len(lengths))]
+    gen = np.load(os.path.join(GOLDEN, "header_ldpc_generator.npy"))
+    a = np.float32(np.sqrt(0.5))
+    rrc, _ = orc.unit_norm_rrc(4)
+    syms, user = [], []
+    for plen, gap in zip(lengths, gaps):
+        data = rng.integers(0, 256, plen).astype(np.uint8)
+        crc = zlib.crc32(data.tobytes())
+        body = np.concatenate([data, np.array([(crc >> s) & 0xFF for s in (24, 16, 8, 0)], dtype=np.uint8)])
+        coded = np.unpackbits(orc.header_fec_encode(orc.header_format(plen), gen).ravel())
+        bits = orc.AdditiveScrambler(0x4001, 0x18E38, 16).process(np.concatenate([coded, np.unpackbits(body)]))
+        q = ((1 - 2.0 * bits[0::2]) * a + 1j * (1 - 2.0 * bits[1::2]) * a).astype(np.complex64)
+        syms += [np.zeros(gap, np.complex64), sig.BPSK[sig.SYNCWORD], q]
+        user.append(data.tobytes())
+    syms.append(np.zeros(2500, np.complex64))
+    x = orc.interpolating_fir(np.concatenate(syms), 4, rrc)
+    x = (orc.rotator(x, np.float32(-0.004)) + sig.awgn(x.size, 0.05, 602)).astype(np.complex64)
+    path = tmp_path / "iq.c64"
+    x.astype("<c8").tofile(path)                      # raw interleaved float32 I/Q, file_source.hpp:53
+    out = tmp_path / "packets.bin"
+    r = app.receive_file(str(path), chunk_items=50000, out=str(out), pkg=pkg)
+    assert r["packets"] == user and r["crc_failures"] == 0 and r["invalid_headers"] == 0
+    assert r["items"] > x.size - 4096
+    blob = out.read_bytes()
+    pos, got = 0, []
+    while pos < len(blob):
+        n = int.from_bytes(blob[pos:pos + 2], "big")
+        got.append(blob[pos + 2:pos + 2 + n])
+        pos += 2 + n
+    assert got == user
