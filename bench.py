@@ -180,6 +180,9 @@ def main():
     ap.add_argument("--decode-headers", action="store_true",
                     help="--soft-bits plus the header decode loop on the device (descrambler, header/payload split, "
                          "LDPC header decoder, parser) instead of a given packet length (SURVEY.md 8(f) rank 2)")
+    ap.add_argument("--python-pipeline", action="store_true",
+                    help="drive the three stages from Python threads (blocks.py PacketReceiver) instead of the "
+                         "native composition gr4pm_packet_receiver (identical results)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the two halves of the chain back to back on one stream")
     args = ap.parse_args()
@@ -231,9 +234,15 @@ def main():
     windows = [(x, ring[1:1 + HIST]),
                (ring[1 + HIST + n_items:], ring[1 + n_items:1 + HIST + n_items])]
     n_pkt = max(n_pkt, n_pkt_b)
-    rx = pkg.PacketReceiver(SPS, BINS, 9.5, "QPSK", max_items=n_items, pipelined=not args.no_pipeline,
-                            soft_bits=args.soft_bits, decode_headers=args.decode_headers)
-    sd = rx.syncword_detection
+    native = not (args.python_pipeline or args.decode_headers or args.detector_only or args.channels > 1)
+    if native:
+        rx = pkg.NativePacketReceiver(SPS, BINS, 9.5, "QPSK", max_items=n_items, tags_cap=max(64, 2 * n_pkt + 64),
+                                      pipelined=not args.no_pipeline, soft_bits=args.soft_bits)
+        sd = None
+    else:
+        rx = pkg.PacketReceiver(SPS, BINS, 9.5, "QPSK", max_items=n_items, pipelined=not args.no_pipeline,
+                                soft_bits=args.soft_bits, decode_headers=args.decode_headers)
+        sd = rx.syncword_detection
     out_keep = None
     if args.channels > 1:
         # config 3: per-channel CFO sweep -0.04 .. +0.04 rad/sample on top of the burst stream
@@ -327,9 +336,13 @@ def main():
     cpu = None
     if rank == 0:
         reps = 10
-        # HIP events must sit on the stream the kernel is launched on: the detector's handle was
-        # created on the receiver's stage-0 stream
-        with torch.cuda.stream(rx._streams[0]):
+        # HIP events must sit on the stream the kernel is launched on: a detector handle created
+        # under that stream (the native receiver keeps its own detector inside the library, so the
+        # roofline leg uses a second, identically configured one)
+        roof_stream = torch.cuda.Stream() if sd is None else rx._streams[0]
+        with torch.cuda.stream(roof_stream):
+            if sd is None:
+                sd = pkg.SyncwordDetection(rrc, SYNCWORD, bpsk, -BINS, BINS, power_threshold=9.5, max_items=n_items)
             sd.correlate_only(x)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -378,6 +391,7 @@ def main():
                        "items_per_step_per_gpu": n_items * args.channels, "channels_per_gpu": args.channels, "freq_bins": 2 * BINS + 1, "tags_per_step": n_tags // max(args.steps, 1),
                        "parallelism": f"channel-per-gpu x{world}", "input": input_mode,
                        "pipelined_streams": 1 if (args.no_pipeline or args.detector_only) else 3,
+                       "pipeline_driver": "native (gr4pm_packet_receiver)" if native else "python threads",
                        "windows": 2, "correlator_lookahead": not args.no_lookahead,
                        **({"headers": hdr_stats} if args.decode_headers else {})},
             "roofline": roofline,

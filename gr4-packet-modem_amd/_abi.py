@@ -143,6 +143,20 @@ class CrcCheckParams(C.Structure):
                 ("stream", C.c_void_p)]
 
 
+class PacketReceiverParams(C.Structure):
+    _fields_ = [("samples_per_symbol", C.c_size_t), ("syncword_freq_bins", C.c_int), ("syncword_threshold", C.c_float),
+                ("costas_constellation", C.c_int), ("max_items", C.c_size_t), ("tags_cap", C.c_size_t),
+                ("pipelined", C.c_int), ("soft_bits", C.c_int)]
+
+
+class PacketReceiverResult(C.Structure):
+    _fields_ = [("consumed", C.c_size_t), ("symbols", C.c_void_p), ("n_symbols", C.c_size_t), ("llr", C.c_void_p),
+                ("n_llr", C.c_size_t), ("detector_tags", C.c_void_p), ("n_detector_tags", C.c_size_t),
+                ("accepted", C.c_void_p), ("tags", C.c_void_p), ("n_tags", C.c_size_t),
+                ("packet_tags", C.c_void_p), ("n_packet_tags", C.c_size_t), ("llr_tags", C.c_void_p),
+                ("n_llr_tags", C.c_size_t), ("ignored_syncwords", C.c_size_t)]
+
+
 class PfbArbParams(C.Structure):
     _fields_ = [("rate", C.c_double), ("rate_is_double", C.c_int), ("taps", C.c_void_p),
                 ("n_taps", C.c_size_t), ("filter_size", C.c_size_t), ("stream", C.c_void_p)]
@@ -188,6 +202,8 @@ EXPORTS = [
     "gr4pm_header_parse",
     "gr4pm_binary_slicer_process", "gr4pm_pack_bits_process", "gr4pm_slice_pack_process",
     "gr4pm_crc_check_create", "gr4pm_crc_check_destroy", "gr4pm_crc_check_compute", "gr4pm_crc_check_process",
+    "gr4pm_packet_receiver_create", "gr4pm_packet_receiver_destroy", "gr4pm_packet_receiver_submit",
+    "gr4pm_packet_receiver_collect", "gr4pm_packet_receiver_inflight",
 ]
 
 _lib = None
@@ -308,6 +324,13 @@ def lib():
     L.gr4pm_crc_check_compute.argtypes = [vp, vp, sz]
     L.gr4pm_crc_check_compute.restype = C.c_uint64
     L.gr4pm_crc_check_process.argtypes = [vp, vp, vp, vp, sz, vp, vp, szp]
+    L.gr4pm_packet_receiver_create.argtypes = [C.POINTER(PacketReceiverParams), C.POINTER(vp)]
+    L.gr4pm_packet_receiver_destroy.argtypes = [vp]
+    L.gr4pm_packet_receiver_destroy.restype = None
+    L.gr4pm_packet_receiver_submit.argtypes = [vp, vp, sz, vp, vp, sz, C.c_uint64, vp, sz, vp, sz]
+    L.gr4pm_packet_receiver_collect.argtypes = [vp, C.POINTER(PacketReceiverResult)]
+    L.gr4pm_packet_receiver_inflight.argtypes = [vp]
+    L.gr4pm_packet_receiver_inflight.restype = sz
     L.gr4pm_firdes_root_raised_cosine.argtypes = [C.c_double] * 4 + [sz, vp]
     L.gr4pm_firdes_root_raised_cosine.restype = sz
     _lib = L

@@ -1185,3 +1185,85 @@ class PacketReceiver:
         out = [f.result() for f in self._inflight]
         self._inflight = []
         return out
+
+
+class NativePacketReceiver:
+    """gr4pm_packet_receiver: the same chain as PacketReceiver (front end, or soft_bits up to the
+    LLR decoder) composed and pipelined in the C++ library -- stage threads, streams and
+    intermediate buffers live there, so no Python runs between the kernels of a batch.
+    Identical outputs (tests compare bit for bit).  parsed_header feedback: a constant
+    packet_length per call (None: every header invalid)."""
+
+    def __init__(self, samples_per_symbol=4, syncword_freq_bins=4, syncword_threshold=9.5,
+                 costas_constellation="QPSK", max_items=1 << 22, tags_cap=4096, pipelined=False, soft_bits=False):
+        self.samples_per_symbol, self.pipelined, self.soft_bits = samples_per_symbol, pipelined, soft_bits
+        self.time_threshold = 768
+        p = _abi.PacketReceiverParams(samples_per_symbol, syncword_freq_bins, syncword_threshold,
+                                      CONSTELLATIONS[costas_constellation.upper()], max_items, tags_cap,
+                                      1 if pipelined else 0, 1 if soft_bits else 0)
+        self._h = C.c_void_p()
+        check(lib().gr4pm_packet_receiver_create(C.byref(p), C.byref(self._h)), "PacketReceiver")
+        self._keep = []  # (input tensors, output tensors) of the batches in flight
+
+    def submit(self, x, packet_length=None, history=None, next_x=None):
+        torch = _torch()
+        x = _dev_c64(x)
+        n = x.numel()
+        sym = torch.empty(n // self.samples_per_symbol + 4160, dtype=torch.complex64, device=x.device)
+        llr = torch.empty(2 * sym.numel() if self.soft_bits else 1, dtype=torch.float32, device=x.device)
+        delayed = None
+        if history is not None:
+            d = 2 * self.time_threshold + 1
+            assert history.numel() >= d and history.data_ptr() + history.numel() * 8 == x.data_ptr(), \
+                "history must be the ring contents that directly precede x"
+            delayed = x.data_ptr() - 8 * d
+        nx = None if next_x is None else _dev_c64(next_x)
+        check(lib().gr4pm_packet_receiver_submit(
+            self._h, x.data_ptr(), n, delayed, None if nx is None else nx.data_ptr(), 0 if nx is None else nx.numel(),
+            0 if packet_length is None else int(packet_length), sym.data_ptr(), sym.numel(),
+            llr.data_ptr() if self.soft_bits else None, llr.numel()), "PacketReceiver.submit")
+        self._keep.append((x, history, nx, sym, llr))
+
+    def collect(self):
+        r = _abi.PacketReceiverResult()
+        st = lib().gr4pm_packet_receiver_collect(self._h, C.byref(r))
+        x, history, nx, sym, llr = self._keep.pop(0)
+        check(st, "PacketReceiver")
+
+        def records(ptr, n, dtype):
+            if not n:
+                return np.zeros(0, dtype=dtype)
+            buf = (C.c_char * (n * dtype.itemsize)).from_address(ptr)
+            return np.frombuffer(buf, dtype=dtype, count=n).copy()
+
+        res = {"status": 0, "consumed": r.consumed, "symbols": sym[: r.n_symbols],
+               "tags": records(r.tags, r.n_tags, TAG_DTYPE),
+               "detector_tags": records(r.detector_tags, r.n_detector_tags, TAG_DTYPE),
+               "accepted": records(r.accepted, r.n_detector_tags, np.dtype(np.uint8)).astype(bool)}
+        if self.soft_bits:
+            res.update(llr=llr[: r.n_llr], llr_tags=records(r.llr_tags, r.n_llr_tags, PACKET_TAG_DTYPE),
+                       packet_tags=records(r.packet_tags, r.n_packet_tags, PACKET_TAG_DTYPE),
+                       ignored_syncwords=r.ignored_syncwords)
+        return res
+
+    def process_bulk(self, x, header_fn=None, tags_cap=None, history=None, next_x=None):
+        """same calling convention as PacketReceiver.process_bulk (header_fn: None or a constant
+        packet_length); pipelined: returns the result of an earlier batch, None while filling"""
+        self.submit(x, header_fn, history, next_x)
+        if not self.pipelined or lib().gr4pm_packet_receiver_inflight(self._h) > 2:
+            return self.collect()
+        return None
+
+    def flush(self):
+        out = []
+        while lib().gr4pm_packet_receiver_inflight(self._h):
+            out.append(self.collect())
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _release("gr4pm_packet_receiver_destroy", self._h)
+                self._h = None
+        except Exception:  # interpreter shutdown
+            pass

@@ -535,6 +535,62 @@ gr4pm_status gr4pm_crc_check_process(gr4pm_crc_check* h, const uint8_t* in, cons
                                      const uint64_t* packet_len, size_t n_packets, uint8_t* out,
                                      uint64_t* out_len, size_t* n_out_bytes);
 
+/* ====================================================================================
+ * PacketReceiver -- packet_receiver.hpp:34-147,191-247: the composition itself, native.
+ * The reference wires the blocks into a flowgraph and runs them with the multi-threaded
+ * scheduler (one worker per block).  This object owns the blocks of the chain up to the Costas
+ * loop (soft_bits: up to the LLR decoder), three HIP streams and two worker threads; batches are
+ * submitted and collected, up to three in flight:
+ *   stage 0 (caller's thread, inside submit): SyncwordDetection (+ look-ahead of the next batch)
+ *   stage 1: SyncwordDetectionFilter gate, CoarseFrequencyCorrection + SymbolFilter, SyncwordWipeoff
+ *   stage 2: CostasLoop [PayloadMetadataInsert, tag-driven CostasLoop, SyncwordRemove, LLR decoder]
+ * The parsed_header feedback is a constant packet_length per submit (0 = every header invalid);
+ * the header decode loop on the device is driven from the host layer (blocks.py) for now.
+ * ================================================================================== */
+typedef struct gr4pm_packet_receiver gr4pm_packet_receiver;
+typedef struct {
+    size_t samples_per_symbol; /* packet_receiver.hpp:49 */
+    int syncword_freq_bins;    /* :54 */
+    float syncword_threshold;  /* :55 */
+    int costas_constellation;  /* CostasLoop setting when soft_bits == 0 (0 PILOT 1 BPSK 2 QPSK) */
+    size_t max_items;          /* largest batch */
+    size_t tags_cap;           /* most detections per batch */
+    int pipelined;             /* 0: submit() runs the three stages itself */
+    int soft_bits;             /* continue to the LLR decoder (:123-131) */
+} gr4pm_packet_receiver_params;
+typedef struct {
+    size_t consumed;                    /* items of the batch SyncwordDetection consumed */
+    const gr4pm_c64* symbols;           /* == out_symbols of the submit */
+    size_t n_symbols;
+    const float* llr;                   /* == out_llr of the submit (soft_bits) */
+    size_t n_llr;
+    const gr4pm_tag* detector_tags;     /* host; valid until the next collect() */
+    size_t n_detector_tags;
+    const uint8_t* accepted;            /* per detector tag: passed the filter */
+    const gr4pm_tag* tags;              /* symbol-rate tags of the accepted detections */
+    size_t n_tags;
+    const gr4pm_packet_tag* packet_tags; /* soft_bits: PayloadMetadataInsert's tags (symbol index) */
+    size_t n_packet_tags;
+    const gr4pm_packet_tag* llr_tags;   /* soft_bits: tags at LLR positions */
+    size_t n_llr_tags;
+    size_t ignored_syncwords;
+} gr4pm_packet_receiver_result;
+gr4pm_status gr4pm_packet_receiver_create(const gr4pm_packet_receiver_params* params,
+                                          gr4pm_packet_receiver** out);
+void gr4pm_packet_receiver_destroy(gr4pm_packet_receiver* h);
+/* in: device, n_in items.  delayed: NULL, or the address of item -(2 time_threshold + 1) of the
+ * stream relative to in[0] when `in` is a window of a device ring (the chain then reads the
+ * delayed stream in place).  next_in/next_n: the following batch (look-ahead) or NULL.
+ * out_symbols (device, out_cap >= n_in / samples_per_symbol + tags + 2) and out_llr (device,
+ * soft_bits, 2 floats per symbol) stay the caller's; the result points at them. */
+gr4pm_status gr4pm_packet_receiver_submit(gr4pm_packet_receiver* h, const gr4pm_c64* in, size_t n_in,
+                                          const gr4pm_c64* delayed, const gr4pm_c64* next_in,
+                                          size_t next_n, uint64_t packet_length, gr4pm_c64* out_symbols,
+                                          size_t out_cap, float* out_llr, size_t llr_cap);
+/* waits for the oldest batch; returns its status (the error text of a failed stage included) */
+gr4pm_status gr4pm_packet_receiver_collect(gr4pm_packet_receiver* h, gr4pm_packet_receiver_result* result);
+size_t gr4pm_packet_receiver_inflight(const gr4pm_packet_receiver* h);
+
 /* firdes::root_raised_cosine<float> -- firdes.hpp:29-76 (host helper; out: ntaps|1 floats) */
 size_t gr4pm_firdes_root_raised_cosine(double gain, double sampling_freq, double symbol_rate,
                                        double alpha, size_t ntaps, float* out);

@@ -1430,3 +1430,43 @@ def test_packet_receiver_file_app(pkg, tmp_path):
         got.append(blob[pos + 2:pos + 2 + n])
         pos += 2 + n
     assert got == user
+
+
+@pytest.mark.parametrize("pipelined", [False, True])
+@pytest.mark.parametrize("soft_bits", [False, True])
+def test_native_packet_receiver_equals_python_composition(pkg, pipelined, soft_bits):
+    """gr4pm_packet_receiver (the chain composed and pipelined inside the C++ library) gives exactly what
+    the block-by-block composition in blocks.py gives: symbols, LLRs and every tag, over several batches
+    of a device ring with look-ahead"""
+    rng = np.random.default_rng(700)
+    H, n = 1537, 60000
+    wins = []
+    for seed in (1, 2, 3):
+        x, _, _ = _tx_packets(np.random.default_rng(seed), [120, 120, 120, 120], [300, 500, 420, 610])
+        x = np.concatenate([x, np.zeros(n, np.complex64)])[:n]
+        wins.append((x + sig.awgn(n, 0.05, 710 + seed)).astype(np.complex64))
+    ring = torch.zeros(2 + H + 3 * n, dtype=torch.complex64, device="cuda")
+    for k, w in enumerate(wins):
+        ring[2 + H + k * n:2 + H + (k + 1) * n] = dev(w)
+    ref = pkg.PacketReceiver(max_items=n, pipelined=False, soft_bits=soft_bits)
+    nat = pkg.NativePacketReceiver(max_items=n, pipelined=pipelined, soft_bits=soft_bits)
+    want, got = [], []
+    for k in range(3):
+        lo = 2 + H + k * n
+        w, hist = ring[lo:lo + n], ring[lo - H:lo]
+        nxt = ring[lo + n:lo + 2 * n] if k < 2 else None
+        want.append(ref.process_bulk(w, 120, history=hist, next_x=nxt))
+        r = nat.process_bulk(w, 120, history=hist, next_x=nxt)
+        if r is not None:
+            got.append(r)
+    got += nat.flush()
+    assert len(got) == 3
+    for a, b in zip(want, got):
+        assert a["consumed"] == b["consumed"] and same_tags(a["detector_tags"], b["detector_tags"])
+        assert np.array_equal(a["accepted"], b["accepted"]) and same_tags(a["tags"], b["tags"])
+        assert np.array_equal(bits(host(a["symbols"])), bits(host(b["symbols"])))
+        if soft_bits:
+            assert a["llr"].cpu().numpy().tobytes() == b["llr"].cpu().numpy().tobytes()
+            assert same_ptags(a["llr_tags"], b["llr_tags"]) and same_ptags(a["packet_tags"], b["packet_tags"])
+    assert sum(r["tags"].size for r in got) >= 8
+    assert np.array_equal(pkg.SYNCWORD, np.unpackbits(np.frombuffer(bytes.fromhex("034776C7272895B0"), dtype=np.uint8)))
