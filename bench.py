@@ -234,10 +234,11 @@ def main():
     windows = [(x, ring[1:1 + HIST]),
                (ring[1 + HIST + n_items:], ring[1 + n_items:1 + HIST + n_items])]
     n_pkt = max(n_pkt, n_pkt_b)
-    native = not (args.python_pipeline or args.decode_headers or args.detector_only or args.channels > 1)
+    native = not (args.python_pipeline or args.detector_only or args.channels > 1)
     if native:
         rx = pkg.NativePacketReceiver(SPS, BINS, 9.5, "QPSK", max_items=n_items, tags_cap=max(64, 2 * n_pkt + 64),
-                                      pipelined=not args.no_pipeline, soft_bits=args.soft_bits)
+                                      pipelined=not args.no_pipeline, soft_bits=args.soft_bits,
+                                      decode_headers=args.decode_headers)
         sd = None
     else:
         rx = pkg.PacketReceiver(SPS, BINS, 9.5, "QPSK", max_items=n_items, pipelined=not args.no_pipeline,

@@ -146,7 +146,8 @@ class CrcCheckParams(C.Structure):
 class PacketReceiverParams(C.Structure):
     _fields_ = [("samples_per_symbol", C.c_size_t), ("syncword_freq_bins", C.c_int), ("syncword_threshold", C.c_float),
                 ("costas_constellation", C.c_int), ("max_items", C.c_size_t), ("tags_cap", C.c_size_t),
-                ("pipelined", C.c_int), ("soft_bits", C.c_int)]
+                ("pipelined", C.c_int), ("soft_bits", C.c_int), ("decode_headers", C.c_int),
+                ("header_alist", C.c_char_p)]
 
 
 class PacketReceiverResult(C.Structure):
@@ -154,7 +155,11 @@ class PacketReceiverResult(C.Structure):
                 ("n_llr", C.c_size_t), ("detector_tags", C.c_void_p), ("n_detector_tags", C.c_size_t),
                 ("accepted", C.c_void_p), ("tags", C.c_void_p), ("n_tags", C.c_size_t),
                 ("packet_tags", C.c_void_p), ("n_packet_tags", C.c_size_t), ("llr_tags", C.c_void_p),
-                ("n_llr_tags", C.c_size_t), ("ignored_syncwords", C.c_size_t)]
+                ("n_llr_tags", C.c_size_t), ("ignored_syncwords", C.c_size_t),
+                ("header_messages", C.c_void_p), ("packet_type", C.c_void_p), ("n_header_messages", C.c_size_t),
+                ("header_mismatches", C.c_size_t), ("payload_llr", C.c_void_p), ("n_payload_llr", C.c_size_t),
+                ("payload_tags", C.c_void_p), ("n_payload_tags", C.c_size_t), ("packets", C.c_void_p),
+                ("n_packet_bytes", C.c_size_t), ("packet_lengths", C.c_void_p), ("n_packets", C.c_size_t)]
 
 
 class PfbArbParams(C.Structure):
@@ -327,7 +332,7 @@ def lib():
     L.gr4pm_packet_receiver_create.argtypes = [C.POINTER(PacketReceiverParams), C.POINTER(vp)]
     L.gr4pm_packet_receiver_destroy.argtypes = [vp]
     L.gr4pm_packet_receiver_destroy.restype = None
-    L.gr4pm_packet_receiver_submit.argtypes = [vp, vp, sz, vp, vp, sz, C.c_uint64, vp, sz, vp, sz]
+    L.gr4pm_packet_receiver_submit.argtypes = [vp, vp, sz, vp, vp, sz, C.c_uint64, vp, sz, vp, sz, vp, sz]
     L.gr4pm_packet_receiver_collect.argtypes = [vp, C.POINTER(PacketReceiverResult)]
     L.gr4pm_packet_receiver_inflight.argtypes = [vp]
     L.gr4pm_packet_receiver_inflight.restype = sz

@@ -1187,6 +1187,18 @@ class PacketReceiver:
         return out
 
 
+def _hip_memcpy_d2d(dst, src, nbytes):
+    """device-to-device copy through the HIP runtime the library is linked against"""
+    import ctypes.util
+    global _hiprt
+    try:
+        _hiprt
+    except NameError:
+        _hiprt = C.CDLL("libamdhip64.so")
+        _hiprt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    return 0 if _hiprt.hipMemcpy(dst, src, nbytes, 3) == 0 else -3
+
+
 class NativePacketReceiver:
     """gr4pm_packet_receiver: the same chain as PacketReceiver (front end, or soft_bits up to the
     LLR decoder) composed and pipelined in the C++ library -- stage threads, streams and
@@ -1195,12 +1207,17 @@ class NativePacketReceiver:
     packet_length per call (None: every header invalid)."""
 
     def __init__(self, samples_per_symbol=4, syncword_freq_bins=4, syncword_threshold=9.5,
-                 costas_constellation="QPSK", max_items=1 << 22, tags_cap=4096, pipelined=False, soft_bits=False):
+                 costas_constellation="QPSK", max_items=1 << 22, tags_cap=4096, pipelined=False, soft_bits=False,
+                 decode_headers=False):
+        soft_bits = soft_bits or decode_headers
         self.samples_per_symbol, self.pipelined, self.soft_bits = samples_per_symbol, pipelined, soft_bits
+        self.decode_headers = decode_headers
         self.time_threshold = 768
+        self._alist = header_ldpc_alist().encode() if decode_headers else None
         p = _abi.PacketReceiverParams(samples_per_symbol, syncword_freq_bins, syncword_threshold,
                                       CONSTELLATIONS[costas_constellation.upper()], max_items, tags_cap,
-                                      1 if pipelined else 0, 1 if soft_bits else 0)
+                                      1 if pipelined else 0, 1 if soft_bits else 0, 1 if decode_headers else 0,
+                                      self._alist)
         self._h = C.c_void_p()
         check(lib().gr4pm_packet_receiver_create(C.byref(p), C.byref(self._h)), "PacketReceiver")
         self._keep = []  # (input tensors, output tensors) of the batches in flight
@@ -1211,6 +1228,7 @@ class NativePacketReceiver:
         n = x.numel()
         sym = torch.empty(n // self.samples_per_symbol + 4160, dtype=torch.complex64, device=x.device)
         llr = torch.empty(2 * sym.numel() if self.soft_bits else 1, dtype=torch.float32, device=x.device)
+        pk = torch.empty(n // 16 + 65536 if self.decode_headers else 1, dtype=torch.uint8, device=x.device)
         delayed = None
         if history is not None:
             d = 2 * self.time_threshold + 1
@@ -1221,13 +1239,14 @@ class NativePacketReceiver:
         check(lib().gr4pm_packet_receiver_submit(
             self._h, x.data_ptr(), n, delayed, None if nx is None else nx.data_ptr(), 0 if nx is None else nx.numel(),
             0 if packet_length is None else int(packet_length), sym.data_ptr(), sym.numel(),
-            llr.data_ptr() if self.soft_bits else None, llr.numel()), "PacketReceiver.submit")
-        self._keep.append((x, history, nx, sym, llr))
+            llr.data_ptr() if self.soft_bits else None, llr.numel(),
+            pk.data_ptr() if self.decode_headers else None, pk.numel()), "PacketReceiver.submit")
+        self._keep.append((x, history, nx, sym, llr, pk))
 
     def collect(self):
         r = _abi.PacketReceiverResult()
         st = lib().gr4pm_packet_receiver_collect(self._h, C.byref(r))
-        x, history, nx, sym, llr = self._keep.pop(0)
+        x, history, nx, sym, llr, pk = self._keep.pop(0)
         check(st, "PacketReceiver")
 
         def records(ptr, n, dtype):
@@ -1244,6 +1263,18 @@ class NativePacketReceiver:
             res.update(llr=llr[: r.n_llr], llr_tags=records(r.llr_tags, r.n_llr_tags, PACKET_TAG_DTYPE),
                        packet_tags=records(r.packet_tags, r.n_packet_tags, PACKET_TAG_DTYPE),
                        ignored_syncwords=r.ignored_syncwords)
+        if self.decode_headers:
+            torch = _torch()
+            pay = torch.empty(r.n_payload_llr, dtype=torch.float32, device=llr.device)
+            if r.n_payload_llr:  # the library's buffer is recycled at the next collect(): take a copy
+                check(_hip_memcpy_d2d(pay.data_ptr(), r.payload_llr, 4 * r.n_payload_llr), "payload_llr")
+            res.update(header_messages=records(r.header_messages, r.n_header_messages, _abi.HEADER_MSG_DTYPE),
+                       packet_type=records(r.packet_type, r.n_header_messages, np.dtype(np.int32)),
+                       header_mismatches=r.header_mismatches, payload_llr=pay,
+                       payload_tags=records(r.payload_tags, r.n_payload_tags, PACKET_TAG_DTYPE),
+                       packets=pk[: r.n_packet_bytes],
+                       packet_lengths=records(r.packet_lengths, r.n_packets, np.dtype(np.uint64)))
+            res["crc_ok"] = res["packet_lengths"] > 0
         return res
 
     def process_bulk(self, x, header_fn=None, tags_cap=None, history=None, next_x=None):

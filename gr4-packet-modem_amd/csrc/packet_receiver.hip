@@ -43,6 +43,20 @@ struct Slot {
     std::vector<gr4pm_packet_tag> packet_tags, data_tags, llr_tags;
     size_t n_det = 0, n_tags = 0, n_sym_tags = 0, n_packet_tags = 0, n_llr_tags = 0, ignored = 0;
     DevBuf<gr4pm_c64> y, sym, w, pm, z, data;
+    // decode_headers
+    std::vector<gr4pm_header_msg> hdrs;      // per symbol-rate tag, for PayloadMetadataInsert
+    bool has_resolve = false;
+    gr4pm_header_msg resolve{};
+    std::vector<gr4pm_header_msg> header_messages;
+    std::vector<int32_t> packet_type;
+    std::vector<uint64_t> packet_lengths;
+    size_t header_mismatches = 0, n_packet_bytes = 0;
+    uint8_t* out_packets = nullptr;
+    size_t packets_cap = 0;
+    DevBuf<float> payload_llr;
+    size_t n_payload_llr = 0;
+    std::vector<gr4pm_packet_tag> payload_tags;
+    size_t n_payload_tags = 0;
 };
 
 template <typename T>
@@ -75,6 +89,94 @@ public:
     }
 };
 
+// pass A of the header loop: one window of W items per detection, gathered into a compact stream.
+// starts[j] is relative to y[0]; negative starts read the saved tail of the previous batch, which
+// `head` holds in front of the first W items of y.
+__global__ __launch_bounds__(256) void k_gather_windows(const gr4pm_c64* __restrict__ y,
+                                                        const gr4pm_c64* __restrict__ head, long long tail_len,
+                                                        const long long* __restrict__ starts, unsigned W,
+                                                        gr4pm_c64* __restrict__ out)
+{
+    const long long st = starts[blockIdx.x];
+    const gr4pm_c64* src = st >= 0 ? y + st : head + (st + tail_len);
+    gr4pm_c64* dst = out + static_cast<size_t>(blockIdx.x) * W;
+    for (unsigned i = threadIdx.x; i < W; i += blockDim.x) dst[i] = src[i];
+}
+
+// everything one of the two header loops needs: descrambler -> split -> FEC decoder -> parser,
+// with the header LLRs of an unfinished codeword carried to the next batch
+struct HeaderLoop {
+    gr4pm_additive_scrambler* scr = nullptr;
+    gr4pm_header_payload_split* split = nullptr;
+    gr4pm_header_fec_decoder* fec = nullptr;
+    hipStream_t stream = nullptr;
+    DevBuf<float> desc, hdr, pay, acc; // acc: header LLRs waiting for a complete codeword
+    size_t acc_n = 0;
+    std::vector<uint8_t> bytes, invalid;
+    std::vector<gr4pm_packet_tag> hdr_tags, pay_tags;
+    size_t n_pay = 0, n_pay_tags = 0;
+
+    gr4pm_status create(const char* alist, hipStream_t s)
+    {
+        stream = s;
+        gr4pm_additive_scrambler_params sp{ 0x4001, 0x18E38, 16, 0, 1, s }; // packet_receiver.hpp:131-135
+        GR4PM_TRY(gr4pm_additive_scrambler_create(&sp, &scr));
+        gr4pm_header_payload_split_params hp{ 256, s }; // :136-137
+        GR4PM_TRY(gr4pm_header_payload_split_create(&hp, &split));
+        gr4pm_header_fec_decoder_params fp{ alist, 25, s }; // :138
+        return gr4pm_header_fec_decoder_create(&fp, &fec);
+    }
+    void destroy()
+    {
+        gr4pm_additive_scrambler_destroy(scr);
+        gr4pm_header_payload_split_destroy(split);
+        gr4pm_header_fec_decoder_destroy(fec);
+    }
+    // llr + tags in; appends the parsed_header messages of the codewords finished by this batch
+    gr4pm_status run(const float* llr, size_t n, const gr4pm_packet_tag* tags, size_t n_tags,
+                     std::vector<gr4pm_header_msg>& msgs, std::vector<int32_t>& ptype)
+    {
+        n_pay = n_pay_tags = 0;
+        std::vector<uint64_t> resets;
+        for (size_t i = 0; i < n_tags; ++i)
+            if (tags[i].kind == GR4PM_PKT_HEADER_START) resets.push_back(tags[i].index);
+        if (desc.n < n + 1) GR4PM_TRY(desc.alloc(n + 1));
+        if (hdr.n < n + 1) GR4PM_TRY(hdr.alloc(n + 1));
+        if (pay.n < n + 1) GR4PM_TRY(pay.alloc(n + 1));
+        GR4PM_TRY(gr4pm_additive_scrambler_process(scr, llr, n, desc.p, resets.data(), resets.size()));
+        hdr_tags.resize(n_tags + 1);
+        pay_tags.resize(n_tags + 1);
+        size_t n_hdr = 0, nht = 0;
+        GR4PM_TRY(gr4pm_header_payload_split_process(split, desc.p, n, hdr.p, &n_hdr, pay.p, &n_pay, tags, n_tags,
+                                                     hdr_tags.data(), &nht, pay_tags.data(), &n_pay_tags, n_tags + 1));
+        if (acc.n < acc_n + n_hdr + 256) {
+            DevBuf<float> bigger;
+            GR4PM_TRY(bigger.alloc((acc_n + n_hdr + 256) * 2));
+            if (acc_n) GR4PM_HIP_TRY(hipMemcpyAsync(bigger.p, acc.p, acc_n * sizeof(float), hipMemcpyDeviceToDevice, stream));
+            GR4PM_HIP_TRY(hipStreamSynchronize(stream));
+            std::swap(acc.p, bigger.p);
+            std::swap(acc.n, bigger.n);
+        }
+        if (n_hdr) GR4PM_HIP_TRY(hipMemcpyAsync(acc.p + acc_n, hdr.p, n_hdr * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        acc_n += n_hdr;
+        const size_t cw = acc_n / 256;
+        bytes.resize(std::max<size_t>(cw, 1) * 4);
+        invalid.resize(std::max<size_t>(cw, 1));
+        GR4PM_TRY(gr4pm_header_fec_decoder_process(fec, acc.p, cw, bytes.data(), invalid.data()));
+        const size_t rest = acc_n - cw * 256;
+        if (cw && rest) { // move the unfinished codeword to the front (regions cannot overlap: rest < 256 <= cw * 256)
+            GR4PM_HIP_TRY(hipMemcpyAsync(acc.p, acc.p + cw * 256, rest * sizeof(float), hipMemcpyDeviceToDevice, stream));
+            GR4PM_HIP_TRY(hipStreamSynchronize(stream));
+        }
+        acc_n = rest;
+        const size_t at = msgs.size();
+        msgs.resize(at + cw);
+        ptype.resize(at + cw);
+        gr4pm_header_parse(bytes.data(), invalid.data(), cw, msgs.data() + at, ptype.data() + at);
+        return GR4PM_OK;
+    }
+};
+
 } // namespace
 
 struct gr4pm_packet_receiver {
@@ -91,6 +193,34 @@ struct gr4pm_packet_receiver {
     gr4pm_constellation_llr_decoder* llr = nullptr;
     uint64_t hist = 0;
     std::deque<gr4pm_header_msg> hdr_fifo; // gate -> PayloadMetadataInsert (stage 1 -> 2, in the slot)
+    // ---- decode_headers: pass A (stage 1 thread) ----
+    static constexpr unsigned kPre = 64, kW = 912; // window: 64 items before the tag, 228 symbols in all
+    gr4pm_rotator* a_cfc = nullptr;
+    gr4pm_symbol_filter* a_symf = nullptr;
+    gr4pm_syncword_wipeoff* a_wipe = nullptr;
+    gr4pm_payload_metadata_insert* a_pmi = nullptr;
+    gr4pm_costas_loop* a_costas = nullptr;
+    gr4pm_syncword_remove* a_remove = nullptr;
+    gr4pm_constellation_llr_decoder* a_llr = nullptr;
+    HeaderLoop a_loop, b_loop; // b_loop: the real chain's own header loop (stage 2 thread)
+    gr4pm_crc_check* crc = nullptr;
+    DevBuf<gr4pm_c64> a_tail, a_head, a_compact, a_sym, a_w, a_pm, a_z, a_data;
+    DevBuf<float> a_llrbuf;
+    DevBuf<long long> a_starts;
+    std::vector<uint64_t> awaiting_idx;     // detections whose window continues in the next batch
+    std::vector<gr4pm_tag> awaiting_tags;
+    std::deque<uint64_t> a_order;           // detections inside pass A whose header is not out yet
+    size_t a_fifo = 0;                      // invalid messages owed to pass A's PayloadMetadataInsert
+    std::vector<std::pair<uint64_t, gr4pm_header_msg>> known; // decoded headers by detection index
+    bool pending_real = false;              // an accepted packet waits for its header
+    uint64_t pending_idx = 0;
+    std::deque<gr4pm_header_msg> s1_fifo;   // accepted tags' messages on their way to stage 2
+    // ---- decode_headers: stage 2 thread ----
+    std::deque<gr4pm_header_msg> used_msgs; // given to PayloadMetadataInsert, not yet verified
+    DevBuf<float> soft, soft_tmp;           // payload soft bits of packets not finished yet
+    size_t soft_n = 0;
+    std::deque<uint64_t> payload_bits;      // their lengths
+    DevBuf<uint8_t> packed;
     Slot slots[kSlots];
     Channel<int> free_slots, to_stage1, to_stage2, done;
     std::thread workers[2];
@@ -105,6 +235,9 @@ struct gr4pm_packet_receiver {
     void stage0(Slot& s, const gr4pm_c64* next_in, size_t next_n);
     void stage1(Slot& s);
     void stage2(Slot& s);
+    gr4pm_status predecode(Slot& s, const gr4pm_c64* y);
+    gr4pm_status stage1_decode(Slot& s, const gr4pm_c64* y);
+    gr4pm_status stage2_decode(Slot& s);
 };
 
 void gr4pm_packet_receiver::stage0(Slot& s, const gr4pm_c64* next_in, size_t next_n)
@@ -128,6 +261,11 @@ void gr4pm_packet_receiver::stage1(Slot& s)
 {
     if (s.status != GR4PM_OK) return;
     const gr4pm_c64* y = s.delayed ? s.delayed : s.y.p;
+    if (p.decode_headers) {
+        const gr4pm_status st = stage1_decode(s, y);
+        if (st != GR4PM_OK) fail(s, st);
+        return;
+    }
     // SyncwordDetectionFilter: the samples pass unchanged, the tags are gated
     std::vector<uint64_t> idx(s.n_det);
     s.msgs.assign(std::max<size_t>(s.n_det, 1), gr4pm_header_msg{ s.packet_length, s.packet_length == 0 ? 1 : 0 });
@@ -156,6 +294,11 @@ void gr4pm_packet_receiver::stage1(Slot& s)
 void gr4pm_packet_receiver::stage2(Slot& s)
 {
     if (s.status != GR4PM_OK) return;
+    if (p.decode_headers) {
+        const gr4pm_status st = stage2_decode(s);
+        if (st != GR4PM_OK) fail(s, st);
+        return;
+    }
     if (!p.soft_bits) {
         if (s.out_cap < s.n_symbols) {
             set_error("out_cap %zu < %zu symbols", s.out_cap, s.n_symbols);
@@ -207,6 +350,318 @@ void gr4pm_packet_receiver::stage2(Slot& s)
     if (st != GR4PM_OK) return fail(s, st);
     s.n_llr_tags = n_lt;
     s.n_llr = n_llr;
+}
+
+// pass A (see blocks.py PacketReceiver._predecode, which this mirrors): the header of every detection
+gr4pm_status gr4pm_packet_receiver::predecode(Slot& s, const gr4pm_c64* y)
+{
+    hipStream_t st1 = streams[1];
+    const long long n = static_cast<long long>(s.consumed);
+    std::vector<long long> starts;
+    std::vector<gr4pm_tag> tags;
+    std::vector<uint64_t> order;
+    for (size_t i = 0; i < awaiting_idx.size(); ++i) { // waiting detections of the last batch first
+        starts.push_back(static_cast<long long>(awaiting_idx[i]) - static_cast<long long>(s.base) - kPre);
+        tags.push_back(awaiting_tags[i]);
+        order.push_back(awaiting_idx[i]);
+    }
+    awaiting_idx.clear();
+    awaiting_tags.clear();
+    for (size_t i = 0; i < s.n_det; ++i) {
+        const long long st = static_cast<long long>(s.det_tags[i].index) - kPre;
+        if (st + kW <= n) {
+            starts.push_back(st);
+            tags.push_back(s.det_tags[i]);
+            order.push_back(s.base + s.det_tags[i].index);
+        } else {
+            awaiting_idx.push_back(s.base + s.det_tags[i].index);
+            awaiting_tags.push_back(s.det_tags[i]);
+        }
+    }
+    const size_t k = starts.size();
+    const size_t tail_len = kW + kPre;
+    if (k) {
+        if (a_starts.n < k) GR4PM_TRY(a_starts.alloc(k * 2));
+        if (a_compact.n < k * kW) GR4PM_TRY(a_compact.alloc(k * kW * 2));
+        GR4PM_TRY(a_starts.upload_staged(starts.data(), k, st1));
+        // [saved tail | first W items of y] for the windows that begin in the previous batch
+        GR4PM_HIP_TRY(hipMemcpyAsync(a_head.p, a_tail.p, tail_len * sizeof(gr4pm_c64), hipMemcpyDeviceToDevice, st1));
+        GR4PM_HIP_TRY(hipMemcpyAsync(a_head.p + tail_len, y, kW * sizeof(gr4pm_c64), hipMemcpyDeviceToDevice, st1));
+        hipLaunchKernelGGL(k_gather_windows, dim3(static_cast<unsigned>(k)), dim3(256), 0, st1, y, a_head.p,
+                           static_cast<long long>(tail_len), a_starts.p, kW, a_compact.p);
+        GR4PM_HIP_TRY(hipGetLastError());
+        for (size_t j = 0; j < k; ++j) tags[j].index = j * kW + kPre;
+        const size_t n_items = k * kW, cap = n_items / p.samples_per_symbol + k + 2;
+        if (a_sym.n < cap) {
+            GR4PM_TRY(a_sym.alloc(cap * 2));
+            GR4PM_TRY(a_w.alloc(cap * 2));
+            GR4PM_TRY(a_pm.alloc(cap * 2));
+            GR4PM_TRY(a_z.alloc(cap * 2));
+            GR4PM_TRY(a_data.alloc(cap * 2));
+            GR4PM_TRY(a_llrbuf.alloc(cap * 4));
+        }
+        std::vector<gr4pm_tag> sym_tags(k + 64);
+        size_t n_st = 0, consumed = 0, produced = 0;
+        GR4PM_TRY(gr4pm_cfc_symbol_filter_process(a_cfc, a_symf, a_compact.p, n_items, a_sym.p, cap, tags.data(), k,
+                                                  sym_tags.data(), sym_tags.size(), &n_st, &consumed, &produced));
+        GR4PM_TRY(gr4pm_syncword_wipeoff_process(a_wipe, a_sym.p, produced, a_w.p, sym_tags.data(), n_st));
+        a_fifo += k; // one "invalid_header" per detection: only syncword + header pass
+        std::vector<gr4pm_header_msg> inv(std::max<size_t>(n_st, 1), gr4pm_header_msg{ 0, 1 });
+        a_fifo -= std::min(a_fifo, n_st);
+        std::vector<gr4pm_packet_tag> ptags(3 * n_st + 8), dtags(3 * n_st + 8), ltags(3 * n_st + 8);
+        size_t n_pt = 0, c2 = 0, n_pm = 0, used = 0, ignored = 0;
+        GR4PM_TRY(gr4pm_payload_metadata_insert_process(a_pmi, a_w.p, produced, a_pm.p, cap, sym_tags.data(), n_st,
+                                                        inv.data(), n_st, 1, ptags.data(), ptags.size(), &n_pt, &c2,
+                                                        &n_pm, &used, &ignored));
+        GR4PM_TRY(gr4pm_costas_loop_process_packets(a_costas, a_pm.p, n_pm, a_z.p, ptags.data(), n_pt));
+        size_t n_dt = 0, n_data = 0, n_lt = 0, n_llr = 0;
+        GR4PM_TRY(gr4pm_syncword_remove_process(a_remove, a_z.p, n_pm, a_data.p, ptags.data(), n_pt, dtags.data(),
+                                                dtags.size(), &n_dt, &n_data));
+        GR4PM_TRY(gr4pm_constellation_llr_decoder_process(a_llr, a_data.p, n_data, a_llrbuf.p, a_llrbuf.n, dtags.data(),
+                                                          n_dt, ltags.data(), ltags.size(), &n_lt, &n_llr));
+        std::vector<gr4pm_header_msg> done;
+        std::vector<int32_t> ptype;
+        GR4PM_TRY(a_loop.run(a_llrbuf.p, n_llr, ltags.data(), n_lt, done, ptype));
+        for (uint64_t o : order) a_order.push_back(o);
+        for (const auto& m : done) {
+            if (a_order.empty()) break;
+            known.emplace_back(a_order.front(), m);
+            a_order.pop_front();
+        }
+        std::sort(known.begin(), known.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+    }
+    if (n >= static_cast<long long>(tail_len))
+        GR4PM_HIP_TRY(hipMemcpyAsync(a_tail.p, y + (n - tail_len), tail_len * sizeof(gr4pm_c64), hipMemcpyDeviceToDevice,
+                                     st1));
+    GR4PM_HIP_TRY(hipStreamSynchronize(st1));
+    return GR4PM_OK;
+}
+
+gr4pm_status gr4pm_packet_receiver::stage1_decode(Slot& s, const gr4pm_c64* y)
+{
+    GR4PM_TRY(predecode(s, y));
+    auto lookup = [&](uint64_t idx) -> const gr4pm_header_msg* {
+        auto it = std::lower_bound(known.begin(), known.end(), idx, [](const auto& a, uint64_t v) { return a.first < v; });
+        return it != known.end() && it->first == idx ? &it->second : nullptr;
+    };
+    s.has_resolve = false;
+    if (pending_real)
+        if (const gr4pm_header_msg* m = lookup(pending_idx)) {
+            GR4PM_TRY(gr4pm_syncword_detection_filter_gate_resolve(sdf, m));
+            pending_real = false;
+            bool patched = false;
+            for (auto& f : s1_fifo)
+                if (f.invalid_header == 2) { // its tag has not even reached PayloadMetadataInsert yet
+                    f = *m;
+                    patched = true;
+                    break;
+                }
+            if (!patched) {
+                s.has_resolve = true;
+                s.resolve = *m;
+            }
+        }
+    // per-tag messages: decoded / still on its way (2)
+    std::vector<uint64_t> idx(s.n_det);
+    s.msgs.assign(std::max<size_t>(s.n_det, 1), gr4pm_header_msg{ 0, 1 });
+    for (size_t i = 0; i < s.n_det; ++i) {
+        idx[i] = s.base + s.det_tags[i].index;
+        if (const gr4pm_header_msg* m = lookup(idx[i])) s.msgs[i] = *m;
+        else if (std::find(awaiting_idx.begin(), awaiting_idx.end(), idx[i]) != awaiting_idx.end() ||
+                 std::find(a_order.begin(), a_order.end(), idx[i]) != a_order.end())
+            s.msgs[i].invalid_header = 2;
+    }
+    s.accepted.assign(std::max<size_t>(s.n_det, 1), 0);
+    size_t used = 0;
+    GR4PM_TRY(gr4pm_syncword_detection_filter_gate(sdf, idx.data(), s.n_det, s.msgs.data(), s.n_det, 1,
+                                                   s.accepted.data(), &used));
+    s.n_tags = 0;
+    for (size_t i = 0; i < s.n_det; ++i)
+        if (s.accepted[i]) {
+            s.tags[s.n_tags++] = s.det_tags[i];
+            s1_fifo.push_back(s.msgs[i]);
+            if (s.msgs[i].invalid_header == 2) {
+                pending_real = true;
+                pending_idx = idx[i];
+            }
+        }
+    known.erase(known.begin(), std::find_if(known.begin(), known.end(), [&](const auto& e) {
+                    return e.first + (1ull << 22) >= s.base; // forget old entries
+                }));
+    const size_t cap = s.consumed / p.samples_per_symbol + s.n_tags + 2;
+    if (s.sym.n < cap) GR4PM_TRY(s.sym.alloc(cap));
+    if (s.w.n < cap) GR4PM_TRY(s.w.alloc(cap));
+    size_t n_out_tags = 0, consumed = 0, produced = 0;
+    GR4PM_TRY(gr4pm_cfc_symbol_filter_process(cfc, symf, y, s.consumed, s.sym.p, cap, s.tags.data(), s.n_tags,
+                                              s.sym_tags.data(), s.sym_tags.size(), &n_out_tags, &consumed, &produced));
+    s.n_sym_tags = n_out_tags;
+    s.n_symbols = produced;
+    GR4PM_TRY(gr4pm_syncword_wipeoff_process(wipe, s.sym.p, produced, s.w.p, s.sym_tags.data(), n_out_tags));
+    s.hdrs.assign(std::max<size_t>(n_out_tags, 1), gr4pm_header_msg{ 0, 1 });
+    for (size_t i = 0; i < n_out_tags && !s1_fifo.empty(); ++i) {
+        s.hdrs[i] = s1_fifo.front();
+        s1_fifo.pop_front();
+    }
+    return GR4PM_OK;
+}
+
+#ifdef GR4PM_TIMING
+#include <chrono>
+namespace {
+struct StageTimer { // wall time of the calls of one stage, printed every 8 batches (make EXTRA=-DGR4PM_TIMING)
+    const char* name;
+    std::vector<std::pair<const char*, double>> acc;
+    std::chrono::steady_clock::time_point t;
+    int batches = 0;
+    size_t at = 0;
+    void begin() { t = std::chrono::steady_clock::now(); at = 0; }
+    void mark(const char* what)
+    {
+        const auto now = std::chrono::steady_clock::now();
+        const double us = std::chrono::duration<double, std::micro>(now - t).count();
+        if (at >= acc.size()) acc.emplace_back(what, 0.0);
+        acc[at++].second += us;
+        t = now;
+    }
+    void end()
+    {
+        if (++batches % 8) return;
+        fprintf(stderr, "[gr4pm timing] %s:", name);
+        for (auto& a : acc) fprintf(stderr, " %s %.0f", a.first, a.second / batches);
+        fprintf(stderr, " us (mean of %d)\n", batches);
+    }
+};
+StageTimer g_t2{ "stage 2", {}, {}, 0, 0 };
+}
+#define T2_BEGIN() g_t2.begin()
+#define T2_MARK(x) g_t2.mark(x)
+#define T2_END() g_t2.end()
+#else
+#define T2_BEGIN()
+#define T2_MARK(x)
+#define T2_END()
+#endif
+
+gr4pm_status gr4pm_packet_receiver::stage2_decode(Slot& s)
+{
+    hipStream_t st2 = streams[2];
+    T2_BEGIN();
+    if (s.has_resolve) {
+        GR4PM_TRY(gr4pm_payload_metadata_insert_resolve(pmi, &s.resolve));
+        for (auto& m : used_msgs)
+            if (m.invalid_header == 2) {
+                m = s.resolve;
+                break;
+            }
+    }
+    const size_t n = s.n_symbols;
+    if (s.pm.n < n + 1) GR4PM_TRY(s.pm.alloc(n + 1));
+    if (s.data.n < n + 1) GR4PM_TRY(s.data.alloc(n + 1));
+    s.packet_tags.resize(3 * s.n_sym_tags + 8);
+    s.data_tags.resize(s.packet_tags.size());
+    s.llr_tags.resize(s.packet_tags.size());
+    size_t n_pt = 0, consumed = 0, produced = 0, used = 0, ignored = 0;
+    GR4PM_TRY(gr4pm_payload_metadata_insert_process(pmi, s.w.p, n, s.pm.p, n + 1, s.sym_tags.data(), s.n_sym_tags,
+                                                    s.hdrs.data(), s.n_sym_tags, 1, s.packet_tags.data(),
+                                                    s.packet_tags.size(), &n_pt, &consumed, &produced, &used, &ignored));
+    if (consumed != n) {
+        set_error("PayloadMetadataInsert stalled at symbol %zu of %zu: a header message is missing", consumed, n);
+        return GR4PM_ERR_INVALID;
+    }
+    s.n_packet_tags = n_pt;
+    s.ignored = ignored;
+    T2_MARK("pmi");
+    if (s.out_cap < produced) {
+        set_error("out_cap %zu < %zu symbols", s.out_cap, produced);
+        return GR4PM_INSUFFICIENT_OUTPUT_ITEMS;
+    }
+    GR4PM_TRY(gr4pm_costas_loop_process_packets(costas, s.pm.p, produced, s.out_symbols, s.packet_tags.data(), n_pt));
+    T2_MARK("costas");
+    s.n_symbols = produced;
+    size_t n_dt = 0, n_data = 0, n_lt = 0, n_llr = 0;
+    GR4PM_TRY(gr4pm_syncword_remove_process(remove, s.out_symbols, produced, s.data.p, s.packet_tags.data(), n_pt,
+                                            s.data_tags.data(), s.data_tags.size(), &n_dt, &n_data));
+    T2_MARK("remove");
+    GR4PM_TRY(gr4pm_constellation_llr_decoder_process(llr, s.data.p, n_data, s.out_llr, s.llr_cap, s.data_tags.data(),
+                                                      n_dt, s.llr_tags.data(), s.llr_tags.size(), &n_lt, &n_llr));
+    T2_MARK("llr");
+    s.n_llr_tags = n_lt;
+    s.n_llr = n_llr;
+    // the chain's own header loop: verification of pass A + descrambled payload
+    for (size_t i = 0, j = 0; i < n_pt; ++i)
+        if (s.packet_tags[i].kind == GR4PM_PKT_SYNCWORD) { // a packet PayloadMetadataInsert opened: both lists ascend
+            while (j < s.n_sym_tags && s.sym_tags[j].index < s.packet_tags[i].syncword.index) ++j;
+            if (j < s.n_sym_tags && s.sym_tags[j].index == s.packet_tags[i].syncword.index) used_msgs.push_back(s.hdrs[j]);
+        }
+    s.header_messages.clear();
+    s.packet_type.clear();
+    GR4PM_TRY(b_loop.run(s.out_llr, n_llr, s.llr_tags.data(), n_lt, s.header_messages, s.packet_type));
+    T2_MARK("header_loop");
+    s.header_mismatches = 0;
+    for (const auto& got : s.header_messages) {
+        if (used_msgs.empty()) break;
+        const gr4pm_header_msg given = used_msgs.front();
+        used_msgs.pop_front();
+        const bool same = given.invalid_header == got.invalid_header &&
+                          (got.invalid_header == 1 || given.packet_length == got.packet_length);
+        if (!same) ++s.header_mismatches;
+    }
+    // descrambled payload LLRs of this batch, kept for the caller
+    s.n_payload_llr = b_loop.n_pay;
+    if (s.payload_llr.n < b_loop.n_pay + 1) GR4PM_TRY(s.payload_llr.alloc(b_loop.n_pay + 1));
+    if (b_loop.n_pay)
+        GR4PM_HIP_TRY(hipMemcpyAsync(s.payload_llr.p, b_loop.pay.p, b_loop.n_pay * sizeof(float),
+                                     hipMemcpyDeviceToDevice, st2));
+    s.n_payload_tags = b_loop.n_pay_tags;
+    s.payload_tags.assign(b_loop.pay_tags.begin(), b_loop.pay_tags.begin() + b_loop.n_pay_tags);
+    // payload tail, packet_receiver.hpp:140-147 (whole packets only; the rest waits)
+    if (soft.n < soft_n + b_loop.n_pay + 8) {
+        DevBuf<float> bigger;
+        GR4PM_TRY(bigger.alloc((soft_n + b_loop.n_pay + 8) * 2));
+        if (soft_n) GR4PM_HIP_TRY(hipMemcpyAsync(bigger.p, soft.p, soft_n * sizeof(float), hipMemcpyDeviceToDevice, st2));
+        GR4PM_HIP_TRY(hipStreamSynchronize(st2));
+        std::swap(soft.p, bigger.p);
+        std::swap(soft.n, bigger.n);
+    }
+    if (b_loop.n_pay)
+        GR4PM_HIP_TRY(hipMemcpyAsync(soft.p + soft_n, b_loop.pay.p, b_loop.n_pay * sizeof(float), hipMemcpyDeviceToDevice,
+                                     st2));
+    soft_n += b_loop.n_pay;
+    for (size_t i = 0; i < b_loop.n_pay_tags; ++i) payload_bits.push_back(b_loop.pay_tags[i].payload_bits);
+    std::vector<uint64_t> lens, offs;
+    size_t used_bits = 0;
+    while (!payload_bits.empty() && used_bits + payload_bits.front() <= soft_n) {
+        offs.push_back(used_bits / 8);
+        lens.push_back(payload_bits.front() / 8);
+        used_bits += payload_bits.front();
+        payload_bits.pop_front();
+    }
+    s.packet_lengths.assign(lens.size(), 0);
+    s.n_packet_bytes = 0;
+    if (!lens.empty()) {
+        if (packed.n < used_bits / 8 + 1) GR4PM_TRY(packed.alloc(used_bits / 8 * 2 + 1));
+        GR4PM_TRY(gr4pm_slice_pack_process(soft.p, used_bits / 8, packed.p, st2));
+        if (s.packets_cap < used_bits / 8) {
+            set_error("packets_cap %zu < %zu bytes", s.packets_cap, used_bits / 8);
+            return GR4PM_INSUFFICIENT_OUTPUT_ITEMS;
+        }
+        GR4PM_TRY(gr4pm_crc_check_process(crc, packed.p, offs.data(), lens.data(), lens.size(), s.out_packets,
+                                          s.packet_lengths.data(), &s.n_packet_bytes));
+    }
+    if (used_bits && used_bits < soft_n) { // keep the unfinished payload (through a bounce: the ranges may overlap)
+        // (a persistent buffer: hipMalloc / hipFree per batch would synchronise the whole device)
+        if (soft_tmp.n < soft_n - used_bits) GR4PM_TRY(soft_tmp.alloc((soft_n - used_bits) * 2));
+        GR4PM_HIP_TRY(hipMemcpyAsync(soft_tmp.p, soft.p + used_bits, (soft_n - used_bits) * sizeof(float),
+                                     hipMemcpyDeviceToDevice, st2));
+        GR4PM_HIP_TRY(hipMemcpyAsync(soft.p, soft_tmp.p, (soft_n - used_bits) * sizeof(float), hipMemcpyDeviceToDevice,
+                                     st2));
+        GR4PM_HIP_TRY(hipStreamSynchronize(st2));
+    }
+    soft_n -= used_bits;
+    GR4PM_HIP_TRY(hipStreamSynchronize(st2));
+    T2_MARK("payload_tail");
+    T2_END();
+    return GR4PM_OK;
 }
 
 extern "C" {
@@ -283,6 +738,37 @@ gr4pm_status gr4pm_packet_receiver_create(const gr4pm_packet_receiver_params* p,
         gr4pm_constellation_llr_decoder_params lp{ 0.7f, 2, h->streams[2] }; // :127-130
         if ((st = gr4pm_constellation_llr_decoder_create(&lp, &h->llr)) != GR4PM_OK) return bail(st);
     }
+    if (p->decode_headers) {
+        if (!p->soft_bits || !p->header_alist) {
+            set_error("decode_headers needs soft_bits and the header code's alist");
+            return bail(GR4PM_ERR_INVALID);
+        }
+        // pass A: the same blocks a second time (stage 1's stream)
+        hipStream_t s1 = h->streams[1], s2 = h->streams[2];
+        gr4pm_rotator_params rp2{ 1, 0.0f, (rrc.size() - 1) / 2 + sps, 1, s1 };
+        if ((st = gr4pm_rotator_create(&rp2, &h->a_cfc)) != GR4PM_OK) return bail(st);
+        gr4pm_symbol_filter_params fsp2{ sps, pfb.data(), pfb.size(), arms, rrc.size() - 1, 0, s1 };
+        if ((st = gr4pm_symbol_filter_create(&fsp2, &h->a_symf)) != GR4PM_OK) return bail(st);
+        gr4pm_syncword_wipeoff_params wp2{ bipolar, 64, s1 };
+        if ((st = gr4pm_syncword_wipeoff_create(&wp2, &h->a_wipe)) != GR4PM_OK) return bail(st);
+        gr4pm_payload_metadata_insert_params pp2{ 64, 128, 0.02, 0.01, 0.005, s1 };
+        if ((st = gr4pm_payload_metadata_insert_create(&pp2, &h->a_pmi)) != GR4PM_OK) return bail(st);
+        gr4pm_costas_loop_params cp2{ 0.01, 1, 1, s1 };
+        if ((st = gr4pm_costas_loop_create(&cp2, &h->a_costas)) != GR4PM_OK) return bail(st);
+        gr4pm_syncword_remove_params sr2{ 64, s1 };
+        if ((st = gr4pm_syncword_remove_create(&sr2, &h->a_remove)) != GR4PM_OK) return bail(st);
+        gr4pm_constellation_llr_decoder_params lp2{ 0.7f, 2, s1 };
+        if ((st = gr4pm_constellation_llr_decoder_create(&lp2, &h->a_llr)) != GR4PM_OK) return bail(st);
+        if ((st = h->a_loop.create(p->header_alist, s1)) != GR4PM_OK) return bail(st);
+        if ((st = h->b_loop.create(p->header_alist, s2)) != GR4PM_OK) return bail(st); // :131-139
+        gr4pm_crc_check_params cc{ 32, 0x4C11DB7, 0xFFFFFFFF, 0xFFFFFFFF, 1, 1, 0, 1, 0, s2 }; // :145-147
+        if ((st = gr4pm_crc_check_create(&cc, &h->crc)) != GR4PM_OK) return bail(st);
+        const size_t tail_len = gr4pm_packet_receiver::kW + gr4pm_packet_receiver::kPre;
+        if ((st = h->a_tail.alloc(tail_len)) != GR4PM_OK) return bail(st);
+        if ((st = h->a_tail.zero(s1)) != GR4PM_OK) return bail(st);
+        if ((st = h->a_head.alloc(tail_len + gr4pm_packet_receiver::kW)) != GR4PM_OK) return bail(st);
+        if (hipStreamSynchronize(s1) != hipSuccess) return bail(GR4PM_ERR_HIP);
+    }
     const size_t tags_cap = std::max<size_t>(p->tags_cap, 64);
     for (int i = 0; i < kSlots; ++i) {
         h->slots[i].det_tags.resize(tags_cap);
@@ -330,6 +816,16 @@ void gr4pm_packet_receiver_destroy(gr4pm_packet_receiver* h)
     gr4pm_payload_metadata_insert_destroy(h->pmi);
     gr4pm_syncword_remove_destroy(h->remove);
     gr4pm_constellation_llr_decoder_destroy(h->llr);
+    gr4pm_rotator_destroy(h->a_cfc);
+    gr4pm_symbol_filter_destroy(h->a_symf);
+    gr4pm_syncword_wipeoff_destroy(h->a_wipe);
+    gr4pm_payload_metadata_insert_destroy(h->a_pmi);
+    gr4pm_costas_loop_destroy(h->a_costas);
+    gr4pm_syncword_remove_destroy(h->a_remove);
+    gr4pm_constellation_llr_decoder_destroy(h->a_llr);
+    h->a_loop.destroy();
+    h->b_loop.destroy();
+    gr4pm_crc_check_destroy(h->crc);
     for (auto s : h->streams)
         if (s) (void)hipStreamDestroy(s);
     delete h;
@@ -340,9 +836,15 @@ size_t gr4pm_packet_receiver_inflight(const gr4pm_packet_receiver* h) { return h
 gr4pm_status gr4pm_packet_receiver_submit(gr4pm_packet_receiver* h, const gr4pm_c64* in, size_t n_in,
                                           const gr4pm_c64* delayed, const gr4pm_c64* next_in, size_t next_n,
                                           uint64_t packet_length, gr4pm_c64* out_symbols, size_t out_cap,
-                                          float* out_llr, size_t llr_cap)
+                                          float* out_llr, size_t llr_cap, uint8_t* out_packets, size_t packets_cap)
 {
-    if (!h || !in || !out_symbols || (h->p.soft_bits && !out_llr)) return GR4PM_ERR_INVALID;
+    if (!h || !in || !out_symbols || (h->p.soft_bits && !out_llr) || (h->p.decode_headers && !out_packets))
+        return GR4PM_ERR_INVALID;
+    if (h->p.decode_headers && n_in < gr4pm_packet_receiver::kW + gr4pm_packet_receiver::kPre + 2048) {
+        set_error("decode_headers needs batches of at least %u items",
+                  gr4pm_packet_receiver::kW + gr4pm_packet_receiver::kPre + 2048);
+        return GR4PM_ERR_INVALID;
+    }
     if (h->inflight >= static_cast<size_t>(kSlots - 1)) {
         set_error("%zu batches in flight: collect one first", h->inflight);
         return GR4PM_ERR_INVALID;
@@ -357,6 +859,12 @@ gr4pm_status gr4pm_packet_receiver_submit(gr4pm_packet_receiver* h, const gr4pm_
     s.out_llr = out_llr;
     s.llr_cap = llr_cap;
     s.packet_length = packet_length;
+    s.out_packets = out_packets;
+    s.packets_cap = packets_cap;
+    s.header_mismatches = s.n_packet_bytes = s.n_payload_llr = s.n_payload_tags = 0;
+    s.header_messages.clear();
+    s.packet_type.clear();
+    s.packet_lengths.clear();
     s.status = GR4PM_OK;
     s.error[0] = 0;
     s.consumed = s.n_symbols = s.n_llr = s.n_det = s.n_tags = s.n_sym_tags = s.n_packet_tags = s.n_llr_tags = 0;
@@ -403,6 +911,18 @@ gr4pm_status gr4pm_packet_receiver_collect(gr4pm_packet_receiver* h, gr4pm_packe
     r->ignored_syncwords = s.ignored;
     r->symbols = s.out_symbols;
     r->llr = s.out_llr;
+    r->header_messages = s.header_messages.data();
+    r->packet_type = s.packet_type.data();
+    r->n_header_messages = s.header_messages.size();
+    r->header_mismatches = s.header_mismatches;
+    r->payload_llr = s.payload_llr.p;
+    r->n_payload_llr = s.n_payload_llr;
+    r->payload_tags = s.payload_tags.data();
+    r->n_payload_tags = s.n_payload_tags;
+    r->packets = s.out_packets;
+    r->n_packet_bytes = s.n_packet_bytes;
+    r->packet_lengths = s.packet_lengths.data();
+    r->n_packets = s.packet_lengths.size();
     if (s.status != GR4PM_OK) set_error("%s", s.error);
     return s.status;
 }

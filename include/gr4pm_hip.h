@@ -544,8 +544,8 @@ gr4pm_status gr4pm_crc_check_process(gr4pm_crc_check* h, const uint8_t* in, cons
  *   stage 0 (caller's thread, inside submit): SyncwordDetection (+ look-ahead of the next batch)
  *   stage 1: SyncwordDetectionFilter gate, CoarseFrequencyCorrection + SymbolFilter, SyncwordWipeoff
  *   stage 2: CostasLoop [PayloadMetadataInsert, tag-driven CostasLoop, SyncwordRemove, LLR decoder]
- * The parsed_header feedback is a constant packet_length per submit (0 = every header invalid);
- * the header decode loop on the device is driven from the host layer (blocks.py) for now.
+ * The parsed_header feedback is a constant packet_length per submit (0 = every header invalid),
+ * or with decode_headers the header decode loop on the device.
  * ================================================================================== */
 typedef struct gr4pm_packet_receiver gr4pm_packet_receiver;
 typedef struct {
@@ -557,6 +557,12 @@ typedef struct {
     size_t tags_cap;           /* most detections per batch */
     int pipelined;             /* 0: submit() runs the three stages itself */
     int soft_bits;             /* continue to the LLR decoder (:123-131) */
+    int decode_headers;        /* (needs soft_bits) close the header feedback loop on the device and run the
+                                  payload tail: descrambler, HeaderPayloadSplit, HeaderFecDecoder, HeaderParser
+                                  (:131-139) answer SyncwordDetectionFilter and PayloadMetadataInsert instead of
+                                  packet_length; BinarySlicer, PackBits, CrcCheck (:140-147) deliver the packets.
+                                  Two passes per batch, see DESIGN.md 5c. */
+    const char* header_alist;  /* decode_headers: the header code, header_fec_decoder.hpp:31-258 */
 } gr4pm_packet_receiver_params;
 typedef struct {
     size_t consumed;                    /* items of the batch SyncwordDetection consumed */
@@ -574,6 +580,19 @@ typedef struct {
     const gr4pm_packet_tag* llr_tags;   /* soft_bits: tags at LLR positions */
     size_t n_llr_tags;
     size_t ignored_syncwords;
+    /* decode_headers */
+    const gr4pm_header_msg* header_messages; /* the headers the chain decoded in this batch, in order */
+    const int32_t* packet_type;
+    size_t n_header_messages;
+    size_t header_mismatches;           /* of those, how many differ from the message pass A had supplied */
+    const float* payload_llr;           /* device: descrambled payload LLRs of this batch */
+    size_t n_payload_llr;
+    const gr4pm_packet_tag* payload_tags;
+    size_t n_payload_tags;
+    const uint8_t* packets;             /* == out_packets: bytes of the packets whose CRC-32 matches */
+    size_t n_packet_bytes;
+    const uint64_t* packet_lengths;     /* per finished packet: bytes delivered, 0 = CRC failure */
+    size_t n_packets;
 } gr4pm_packet_receiver_result;
 gr4pm_status gr4pm_packet_receiver_create(const gr4pm_packet_receiver_params* params,
                                           gr4pm_packet_receiver** out);
@@ -582,11 +601,13 @@ void gr4pm_packet_receiver_destroy(gr4pm_packet_receiver* h);
  * stream relative to in[0] when `in` is a window of a device ring (the chain then reads the
  * delayed stream in place).  next_in/next_n: the following batch (look-ahead) or NULL.
  * out_symbols (device, out_cap >= n_in / samples_per_symbol + tags + 2) and out_llr (device,
- * soft_bits, 2 floats per symbol) stay the caller's; the result points at them. */
+ * soft_bits, 2 floats per symbol) and out_packets (device, decode_headers, n_in / 16 bytes is
+ * always enough) stay the caller's; the result points at them. */
 gr4pm_status gr4pm_packet_receiver_submit(gr4pm_packet_receiver* h, const gr4pm_c64* in, size_t n_in,
                                           const gr4pm_c64* delayed, const gr4pm_c64* next_in,
                                           size_t next_n, uint64_t packet_length, gr4pm_c64* out_symbols,
-                                          size_t out_cap, float* out_llr, size_t llr_cap);
+                                          size_t out_cap, float* out_llr, size_t llr_cap, uint8_t* out_packets,
+                                          size_t packets_cap);
 /* waits for the oldest batch; returns its status (the error text of a failed stage included) */
 gr4pm_status gr4pm_packet_receiver_collect(gr4pm_packet_receiver* h, gr4pm_packet_receiver_result* result);
 size_t gr4pm_packet_receiver_inflight(const gr4pm_packet_receiver* h);

@@ -1470,3 +1470,61 @@ def test_native_packet_receiver_equals_python_composition(pkg, pipelined, soft_b
             assert same_ptags(a["llr_tags"], b["llr_tags"]) and same_ptags(a["packet_tags"], b["packet_tags"])
     assert sum(r["tags"].size for r in got) >= 8
     assert np.array_equal(pkg.SYNCWORD, np.unpackbits(np.frombuffer(bytes.fromhex("034776C7272895B0"), dtype=np.uint8)))
+
+
+@pytest.mark.parametrize("mode", ["one_call", "three_calls", "pipelined"])
+def test_native_packet_receiver_decodes_headers_and_packets(pkg, mode):
+    """gr4pm_packet_receiver with decode_headers: the whole receiver inside the C++ library, IQ samples
+    in, CRC-checked packets out; same results as the host-layer composition"""
+    import zlib
+    rng = np.random.default_rng(801)
+    lengths = [100, 17, 1500, 1, 333, 64, 900, 250, 40]
+    gaps = [int(g) for g in rng.integers(250, 900, len(lengths))]
+    gen = np.load(os.path.join(GOLDEN, "header_ldpc_generator.npy"))
+    a = np.float32(np.sqrt(0.5))
+    rrc, _ = orc.unit_norm_rrc(4)
+    syms, user = [], []
+    for k, (plen, gap) in enumerate(zip(lengths, gaps)):
+        data = rng.integers(0, 256, plen).astype(np.uint8)
+        crc = zlib.crc32(data.tobytes()) ^ (0x100 if k == 6 else 0)     # packet 6 arrives damaged
+        body = np.concatenate([data, np.array([(crc >> s) & 0xFF for s in (24, 16, 8, 0)], dtype=np.uint8)])
+        coded = np.unpackbits(orc.header_fec_encode(orc.header_format(plen, k % 2), gen).ravel())
+        bits_ = orc.AdditiveScrambler(0x4001, 0x18E38, 16).process(np.concatenate([coded, np.unpackbits(body)]))
+        q = ((1 - 2.0 * bits_[0::2]) * a + 1j * (1 - 2.0 * bits_[1::2]) * a).astype(np.complex64)
+        syms += [np.zeros(gap, np.complex64), sig.BPSK[sig.SYNCWORD], q]
+        user.append(data)
+    syms.append(np.zeros(2000, np.complex64))
+    x = orc.interpolating_fir(np.concatenate(syms), 4, rrc)
+    x = (orc.rotator(x, np.float32(0.011)) * np.exp(1j * 0.4) + sig.awgn(x.size, 0.05, 802)).astype(np.complex64)
+    xd = dev(x)
+    ref = pkg.PacketReceiver(max_items=x.size, decode_headers=True)
+    nat = pkg.NativePacketReceiver(max_items=x.size, pipelined=(mode == "pipelined"), decode_headers=True)
+    cuts = [x.size] if mode != "three_calls" else [9 * 1752 + 296, 25 * 1752 + 296, x.size]
+    want, got, pos = [], [], 0
+    for c in cuts:
+        piece = xd[pos:min(pos + c, x.size)]
+        w = ref.process_bulk(piece)
+        want.append(w)
+        r = nat.process_bulk(piece)
+        if r is not None:
+            got.append(r)
+        pos += w["consumed"]
+        if pos + 4096 > x.size:
+            break
+    got += nat.flush()
+    assert len(got) == len(want)
+    for w, g in zip(want, got):
+        assert w["consumed"] == g["consumed"] and g["header_mismatches"] == 0
+        assert np.array_equal(bits(host(w["symbols"])), bits(host(g["symbols"])))
+        assert w["llr"].cpu().numpy().tobytes() == g["llr"].cpu().numpy().tobytes()
+        assert w["header_messages"].tobytes() == g["header_messages"].tobytes()
+        assert np.array_equal(w["packet_type"], g["packet_type"])
+        assert w["payload_llr"].cpu().numpy().tobytes() == g["payload_llr"].cpu().numpy().tobytes()
+        assert np.array_equal(w["packet_lengths"], g["packet_lengths"])
+        assert np.array_equal(w["packets"].cpu().numpy(), g["packets"].cpu().numpy())
+    out = np.concatenate([g["packets"].cpu().numpy() for g in got])
+    lens = np.concatenate([g["packet_lengths"] for g in got])
+    assert [int(v) for v in lens] == [0 if k == 6 else n for k, n in enumerate(lengths)]
+    assert np.array_equal(out, np.concatenate([u for k, u in enumerate(user) if k != 6]))
+    msgs = np.concatenate([g["header_messages"] for g in got])
+    assert [int(v) for v in msgs["packet_length"][msgs["invalid_header"] == 0]] == lengths
