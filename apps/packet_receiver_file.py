@@ -5,7 +5,7 @@
 
 reads IQ samples from `input_file` in raw little-endian complex64 (std::complex<float>, what
 FileSource<c64> freads, file_source.hpp:32,53) at 4 samples/symbol, runs the whole receiver on
-the GPU (PacketReceiver(decode_headers=True): detection ... header decode ... CRC check) and
+the GPU (gr4pm_packet_receiver, decode_headers: detection ... header decode ... CRC check) and
 hands over the packets whose CRC-32 matches.  The reference writes them to a TUN device (needs
 root and a network namespace); here they go to `--out` as records of a big-endian uint16 length
 followed by the bytes, or are just counted.
@@ -31,9 +31,9 @@ def receive_file(path, syncword_freq_bins=4, syncword_threshold=9.5, chunk_items
     pkg = pkg or ge.load_package()
     n_file = os.path.getsize(path) // 8
     dev = torch.device("cuda", torch.cuda.current_device())
-    rx = pkg.PacketReceiver(4, syncword_freq_bins, syncword_threshold, max_items=chunk_items + 4096,
-                            decode_headers=True)
-    fft = rx.syncword_detection.fft_size
+    rx = pkg.NativePacketReceiver(4, syncword_freq_bins, syncword_threshold, max_items=chunk_items + 4096,
+                                  tags_cap=chunk_items // 768 + 64, decode_headers=True)
+    fft = 3072  # smallest batch the receiver takes in this mode (one header window + one FFT block)
     pinned = [torch.empty(chunk_items, dtype=torch.complex64).pin_memory() for _ in range(2)]
     staged = [torch.empty(chunk_items, dtype=torch.complex64, device=dev) for _ in range(2)]
     work = torch.empty(chunk_items + 4096, dtype=torch.complex64, device=dev)
