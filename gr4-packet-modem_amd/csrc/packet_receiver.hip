@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -678,8 +679,14 @@ gr4pm_status gr4pm_packet_receiver_create(const gr4pm_packet_receiver_params* p,
         gr4pm_packet_receiver_destroy(h);
         return st;
     };
-    for (auto& s : h->streams)
-        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return bail(GR4PM_ERR_HIP);
+    // the detector's small, latency-bound kernels set the pace of the pipeline: they get the highest
+    // stream priority (its big kernel, the correlator, runs on the detector's own low-priority
+    // look-ahead stream)
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return bail(GR4PM_ERR_HIP);
+    for (int i = 0; i < 3; ++i)
+        if (hipStreamCreateWithPriority(&h->streams[i], hipStreamNonBlocking, i == 0 ? greatest : 0) != hipSuccess)
+            return bail(GR4PM_ERR_HIP);
     const size_t sps = p->samples_per_symbol;
     // packet_receiver.hpp:60-74: RRC taps normalised to unit RMS norm (float accumulation)
     std::vector<float> rrc(((sps * 11) | 1));

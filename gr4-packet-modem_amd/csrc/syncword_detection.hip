@@ -445,6 +445,9 @@ __global__ __launch_bounds__(64) void k_tile_tables(const unsigned long long* __
                                                     size_t bm_stride, uint32_t cnt, uint32_t T, uint32_t n_tiles,
                                                     uint32_t* __restrict__ table, size_t table_stride)
 {
+#ifndef GR4PM_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3); // latency-bound, few waves: win the issue arbitration against throughput kernels
+#endif
     const uint32_t tile = blockIdx.x;
     const int lane = threadIdx.x;
     const unsigned long long* bm = bitmap + static_cast<size_t>(blockIdx.y) * bm_stride;
@@ -527,6 +530,9 @@ __device__ __forceinline__ unsigned long long walk_tiles(unsigned long long r, u
 __global__ void k_group_tables(uint32_t cnt, uint32_t T, uint32_t n_tiles, const uint32_t* __restrict__ table,
                                size_t table_stride, unsigned long long* __restrict__ gtable, size_t gtable_stride)
 {
+#ifndef GR4PM_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3); // latency-bound, few waves: win the issue arbitration against throughput kernels
+#endif
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t grp = blockIdx.y, ch = blockIdx.z;
     if (e > T) return;
@@ -539,6 +545,9 @@ __global__ void k_group_walk(ChanState* __restrict__ st, unsigned long long A0, 
                              uint32_t n_tiles, const unsigned long long* __restrict__ gtable, size_t gtable_stride,
                              unsigned long long* __restrict__ gentry, uint32_t n_groups, int n_channels)
 {
+#ifndef GR4PM_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3); // latency-bound, few waves: win the issue arbitration against throughput kernels
+#endif
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= n_channels) return;
     const unsigned long long rabs = st[ch].r;
@@ -560,6 +569,9 @@ __global__ void k_tile_entries(uint32_t cnt, uint32_t T, uint32_t n_tiles, const
                                size_t table_stride, const unsigned long long* __restrict__ gentry,
                                uint32_t n_groups, int32_t* __restrict__ entry, int n_channels)
 {
+#ifndef GR4PM_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3); // latency-bound, few waves: win the issue arbitration against throughput kernels
+#endif
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_groups * static_cast<uint32_t>(n_channels)) return;
     const uint32_t ch = idx / n_groups, grp = idx % n_groups;
@@ -579,6 +591,9 @@ __global__ __launch_bounds__(64) void k_tile_detect(const unsigned long long* __
                                                     unsigned long long* __restrict__ det,
                                                     uint32_t det_cap)
 {
+#ifndef GR4PM_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3); // latency-bound, few waves: win the issue arbitration against throughput kernels
+#endif
     const uint32_t tile = blockIdx.x, ch = blockIdx.y;
     const int32_t e = entry[ch * n_tiles + tile];
     if (e < 0) return;
@@ -629,6 +644,9 @@ __global__ __launch_bounds__(64) void k_tags(const cf* __restrict__ in, size_t i
                                              const unsigned long long* __restrict__ det, uint32_t det_cap,
                                              RawTag* __restrict__ rec, uint32_t rec_cap)
 {
+#ifndef GR4PM_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3); // latency-bound, few waves: win the issue arbitration against throughput kernels
+#endif
     __shared__ cf lds[kExchangeItems];
     __shared__ cf zbin[kMaxBins];
     const uint32_t ch = blockIdx.y;
