@@ -226,6 +226,14 @@ def lib():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # PyTorch ships its own copy of the HIP runtime (torch/lib/libamdhip64.so); this library
+    # links against the same soname.  Two copies in one process do not share the device: let
+    # torch's be the one that is loaded (tensors come from there), also when the library is
+    # loaded before anything has imported torch (build() followed by smoke() in one process).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, sz, szp = C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)
     L.gr4pm_last_error.restype = C.c_char_p
