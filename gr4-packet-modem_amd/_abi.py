@@ -207,6 +207,7 @@ EXPORTS = [
     "gr4pm_header_parse",
     "gr4pm_binary_slicer_process", "gr4pm_pack_bits_process", "gr4pm_slice_pack_process",
     "gr4pm_crc_check_create", "gr4pm_crc_check_destroy", "gr4pm_crc_check_compute", "gr4pm_crc_check_process",
+    "gr4pm_mapper_process", "gr4pm_burst_shaper_process",
     "gr4pm_packet_receiver_create", "gr4pm_packet_receiver_destroy", "gr4pm_packet_receiver_submit",
     "gr4pm_packet_receiver_collect", "gr4pm_packet_receiver_inflight",
 ]
@@ -337,6 +338,8 @@ def lib():
     L.gr4pm_crc_check_compute.argtypes = [vp, vp, sz]
     L.gr4pm_crc_check_compute.restype = C.c_uint64
     L.gr4pm_crc_check_process.argtypes = [vp, vp, vp, vp, sz, vp, vp, szp]
+    L.gr4pm_mapper_process.argtypes = [vp, sz, vp, vp, sz, C.c_int, vp]
+    L.gr4pm_burst_shaper_process.argtypes = [vp, sz, vp, C.c_int, vp, sz, vp, sz, vp, vp, sz, vp]
     L.gr4pm_packet_receiver_create.argtypes = [C.POINTER(PacketReceiverParams), C.POINTER(vp)]
     L.gr4pm_packet_receiver_destroy.argtypes = [vp]
     L.gr4pm_packet_receiver_destroy.restype = None

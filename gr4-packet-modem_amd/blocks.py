@@ -1187,6 +1187,140 @@ class PacketReceiver:
         return out
 
 
+def mapper(x, map_values):
+    """Mapper<uint8_t, c64 | float>, mapper.hpp:13-51: out[i] = map[x[i] & (len(map) - 1)]"""
+    torch = _torch()
+    x = x.contiguous()
+    assert x.is_cuda and x.dtype == torch.uint8
+    m = np.ascontiguousarray(map_values)
+    kind = 0 if np.iscomplexobj(m) else 1
+    m = m.astype(np.complex64 if kind == 0 else np.float32)
+    out = torch.empty(x.numel(), dtype=torch.complex64 if kind == 0 else torch.float32, device=x.device)
+    check(lib().gr4pm_mapper_process(x.data_ptr(), x.numel(), out.data_ptr(), _np_ptr(m), m.size, kind,
+                                     _stream_handle()), "Mapper")
+    return out
+
+
+def burst_shaper(x, leading_shape, trailing_shape, packet_len, packet_offset=None):
+    """BurstShaper, burst_shaper.hpp:47-126 over whole packets ("packet_len" tags = packet_len[],
+    back to back unless packet_offset is given)"""
+    torch = _torch()
+    x = x.contiguous()
+    assert x.is_cuda and x.dtype in (torch.complex64, torch.float32)
+    lead = np.ascontiguousarray(leading_shape, dtype=np.float32)
+    trail = np.ascontiguousarray(trailing_shape, dtype=np.float32)
+    pl = np.ascontiguousarray(packet_len, dtype=np.uint64)
+    po = (np.concatenate([[0], np.cumsum(pl)[:-1]]).astype(np.uint64) if packet_offset is None
+          else np.ascontiguousarray(packet_offset, dtype=np.uint64))
+    out = torch.empty_like(x)
+    check(lib().gr4pm_burst_shaper_process(x.data_ptr(), x.numel(), out.data_ptr(), 0 if x.dtype == torch.complex64 else 1,
+                                           _np_ptr(lead), lead.size, _np_ptr(trail), trail.size, _np_ptr(po), _np_ptr(pl),
+                                           pl.size, _stream_handle()), "BurstShaper")
+    return out
+
+
+class BurstGenerator:
+    """The burst path of PacketTransmitterPdu (packet_transmitter_pdu.hpp:84-337, stream_mode = false)
+    plus the channel of apps/packet_transceiver.cpp:48-78, on the device, as a test-signal source:
+
+        payload bytes + CRC-32  ->  [header (formatter, (128,32) LDPC + repetition) | payload] bits
+        -> AdditiveScrambler (CCSDS 131.0-B-5, restarted per packet) -> PackBits(2) -> Mapper(QPSK)
+        -> [syncword (BPSK) | header | payload | 9 ramp-down symbols | 11 zero symbols]
+        -> InterpolatingFirFilter (4 samples/symbol, the transmitter's RRC) -> BurstShaper (sine ramps)
+        -> gaps, Rotator (carrier offset), AWGN.
+
+    Header formatting and its FEC encoding (32 bits per packet) and the CRC run on the host."""
+
+    RAMP_DOWN, FLUSH = 9, 11   # :213-216, :209
+
+    def __init__(self, samples_per_symbol=4, generator=None):
+        import os
+        self.sps = samples_per_symbol
+        here = os.path.dirname(os.path.abspath(__file__))
+        self.generator = np.fromfile(os.path.join(here, "data", "header_ldpc_generator.u32"), dtype="<u4") \
+            if generator is None else np.ascontiguousarray(generator, dtype=np.uint32)
+        taps = np.fromfile(os.path.join(here, "data", "tx_rrc_taps_4.f32"), dtype="<f4")
+        assert samples_per_symbol == 4, "the shipped transmit RRC is the 4 samples/symbol one"
+        self.rrc_taps = taps
+        self.fir = InterpolatingFirFilter(samples_per_symbol, taps)
+        self.scrambler = AdditiveScrambler(0x4001, 0x18E38, 16, dtype="uint8")   # :118-122
+        a = np.float32(np.sqrt(np.float32(2.0)) / np.float32(2.0))
+        self.qpsk = np.array([a + 1j * a, a - 1j * a, -a + 1j * a, -a - 1j * a], dtype=np.complex64)  # :131-134
+        ramp, offset = 4 * samples_per_symbol, 4 * samples_per_symbol                              # :296-300
+        n_lead = offset + ramp
+        self.leading = np.sin((np.arange(n_lead) + 1.0) / n_lead * 0.5 * np.pi).astype(np.float32)  # :301-306
+        n_trail = self.FLUSH * samples_per_symbol - offset + ramp
+        self.trailing = np.sin((np.arange(n_trail)[::-1] + 1.0) / n_trail * 0.5 * np.pi).astype(np.float32)  # :307-313
+
+    def header_bits(self, packet_length, packet_type=0):
+        """header_formatter.hpp:104-107 + header_fec_encoder.hpp:60-107 -> 256 bits"""
+        info = ((packet_length >> 8) & 0xFF) << 24 | (packet_length & 0xFF) << 16 | (packet_type & 0xFF) << 8 | 0x55
+        bits = [(info >> (31 - i)) & 1 for i in range(32)]
+        bits += [bin(info & int(g)).count("1") & 1 for g in self.generator]
+        return np.array(bits + bits, dtype=np.uint8)
+
+    def symbols(self, payloads, packet_types=None):
+        """packet symbols (device complex64) back to back, and the length of each packet in symbols"""
+        import zlib
+        torch = _torch()
+        bits, resets, n_syms, pos = [], [], [], 0
+        for k, data in enumerate(payloads):
+            data = bytes(data)
+            crc = zlib.crc32(data)
+            body = np.frombuffer(data + crc.to_bytes(4, "big"), dtype=np.uint8)   # crc_append, :60-69
+            b = np.concatenate([self.header_bits(len(data), 0 if packet_types is None else packet_types[k]),
+                                np.unpackbits(body)])
+            resets.append(pos)
+            bits.append(b)
+            pos += b.size
+            n_syms.append(64 + b.size // 2 + self.RAMP_DOWN + self.FLUSH)
+        allbits = torch.from_numpy(np.concatenate(bits)).cuda()
+        scr = self.scrambler.process_bulk(allbits, np.array(resets, dtype=np.uint64))
+        sym = mapper(pack_bits(scr, 2, 1), self.qpsk)                                           # :135-147
+        sw = torch.from_numpy(np.where(SYNCWORD == 1, -1.0, 1.0).astype(np.complex64)).cuda()   # :158-181
+        rng = np.random.default_rng(12345)
+        parts, at = [], 0
+        for k, b in enumerate(bits):
+            n = b.size // 2
+            ramp = torch.from_numpy(self.qpsk[rng.integers(0, 4, self.RAMP_DOWN)]).cuda()        # :211-247 (any data)
+            parts += [sw, sym[at:at + n], ramp, torch.zeros(self.FLUSH, dtype=torch.complex64, device="cuda")]
+            at += n
+        return torch.cat(parts), np.array(n_syms, dtype=np.uint64)
+
+    def bursts(self, payloads, packet_types=None):
+        """shaped bursts back to back (device complex64) and their lengths in samples"""
+        sym, n_syms = self.symbols(payloads, packet_types)
+        self.fir = InterpolatingFirFilter(self.sps, self.rrc_taps)  # every call starts from a silent filter
+        x = self.fir.process_bulk(sym)                                                           # :286-288
+        lens = n_syms * np.uint64(self.sps)
+        return burst_shaper(x, self.leading, self.trailing, lens), lens                         # :314-316
+
+    def stream(self, payloads, gaps, freq_error=0.0, esn0_db=None, seed=1, tail=4000, packet_types=None):
+        """bursts separated by `gaps` (samples of silence before each burst), rotated by freq_error
+        rad/sample and with AWGN for the given Es/N0 (apps/packet_transceiver.cpp:48-52: tx power 0.32)"""
+        torch = _torch()
+        x, lens = self.bursts(payloads, packet_types)
+        total = int(np.sum(lens)) + int(np.sum(gaps)) + tail
+        out = torch.zeros(total, dtype=torch.complex64, device="cuda")
+        src = dst = 0
+        for n, g in zip(lens, gaps):
+            dst += int(g)
+            out[dst:dst + int(n)] = x[src:src + int(n)]
+            src += int(n)
+            dst += int(n)
+        if freq_error:
+            out = Rotator(np.float32(freq_error)).process_bulk(out)                              # :72-73
+        if esn0_db is not None:
+            n0 = 0.32 * self.sps * 10.0 ** (-0.1 * esn0_db)                                      # :48-52
+            g = torch.Generator(device="cuda")
+            g.manual_seed(seed)
+            # NoiseSource "amplitude" = sqrt(n0) is the standard deviation of the complex noise
+            noise = torch.complex(torch.randn(total, generator=g, device="cuda"),
+                                  torch.randn(total, generator=g, device="cuda")) * np.float32(np.sqrt(n0 / 2.0))
+            out = (out + noise).to(torch.complex64)
+        return out
+
+
 def _hip_memcpy_d2d(dst, src, nbytes):
     """device-to-device copy through the HIP runtime the library is linked against"""
     import ctypes.util

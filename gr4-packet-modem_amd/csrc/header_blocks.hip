@@ -303,6 +303,38 @@ __global__ __launch_bounds__(64) void k_crc_check(const uint8_t* __restrict__ in
     }
     ok[p] = in_packet == rem ? 1 : 0;
 }
+// ------------------------------------------------------------------ burst generator pieces
+__device__ __forceinline__ float2 operator*(float2 a, float t) { return make_float2(a.x * t, a.y * t); }
+template <typename T>
+__global__ __launch_bounds__(256) void k_mapper(const uint8_t* __restrict__ in, size_t n, const T* __restrict__ map,
+                                                unsigned mask, T* __restrict__ out)
+{
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * blockDim.x)
+        out[i] = map[in[i] & mask]; // mapper.hpp:47-50
+}
+struct ShapePacket {
+    unsigned long long offset, len;
+};
+// grid (x, n_packets): the edges of one packet (burst_shaper.hpp:98-124); the body was copied before
+template <typename T>
+__global__ __launch_bounds__(64) void k_burst_edges(const T* __restrict__ in, T* __restrict__ out,
+                                                    const ShapePacket* __restrict__ pk,
+                                                    const float* __restrict__ leading, unsigned n_lead,
+                                                    const float* __restrict__ trailing, unsigned n_trail)
+{
+    const ShapePacket p = pk[blockIdx.x];
+    const unsigned long long lead = p.len < n_lead ? p.len : n_lead; // :98-105
+    for (unsigned long long j = threadIdx.x; j < lead; j += blockDim.x) out[p.offset + j] = in[p.offset + j] * leading[j];
+    // what is left after the leading edge (and an unshaped middle) takes the END of the trailing shape
+    const unsigned long long rest = p.len - lead;
+    const unsigned long long tr = rest < n_trail ? rest : n_trail; // :115-124
+    for (unsigned long long j = threadIdx.x; j < tr; j += blockDim.x) {
+        const unsigned long long i = p.len - tr + j;
+        out[p.offset + i] = in[p.offset + i] * trailing[n_trail - tr + j];
+    }
+}
+
 struct BSpan {
     unsigned long long src, dst, len;
 };
@@ -962,6 +994,83 @@ gr4pm_status gr4pm_crc_check_process(gr4pm_crc_check* h, const uint8_t* in, cons
         GR4PM_HIP_TRY(hipStreamSynchronize(s));
     }
     *n_out_bytes = opos;
+    return GR4PM_OK;
+}
+
+gr4pm_status gr4pm_mapper_process(const uint8_t* in, size_t n, void* out, const void* map_host, size_t map_size,
+                                  int item_kind, void* stream)
+{
+    if (map_size == 0 || (map_size & (map_size - 1)) || map_size > 256) {
+        set_error("the map size must be a power of 2 (got %zu)", map_size); // mapper.hpp:37-41
+        return GR4PM_ERR_INVALID;
+    }
+    if (n == 0) return GR4PM_OK;
+    if (!in || !out || !map_host || (item_kind != 0 && item_kind != 1)) return GR4PM_ERR_INVALID;
+    GR4PM_TRY(require_device());
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t item = item_kind == 0 ? 8 : 4;
+    DevBuf<uint8_t> dmap;
+    GR4PM_TRY(dmap.alloc(map_size * item));
+    GR4PM_TRY(dmap.upload(static_cast<const uint8_t*>(map_host), map_size * item, s));
+    if (item_kind == 0)
+        hipLaunchKernelGGL(k_mapper<float2>, dim3(grid1d(n)), dim3(256), 0, s, in, n,
+                           reinterpret_cast<const float2*>(dmap.p), static_cast<unsigned>(map_size - 1),
+                           static_cast<float2*>(out));
+    else
+        hipLaunchKernelGGL(k_mapper<float>, dim3(grid1d(n)), dim3(256), 0, s, in, n,
+                           reinterpret_cast<const float*>(dmap.p), static_cast<unsigned>(map_size - 1),
+                           static_cast<float*>(out));
+    GR4PM_HIP_TRY(hipGetLastError());
+    GR4PM_HIP_TRY(hipStreamSynchronize(s));
+    return GR4PM_OK;
+}
+
+gr4pm_status gr4pm_burst_shaper_process(const void* in, size_t n, void* out, int item_kind, const float* leading_host,
+                                        size_t leading_n, const float* trailing_host, size_t trailing_n,
+                                        const uint64_t* packet_offset, const uint64_t* packet_len, size_t n_packets,
+                                        void* stream)
+{
+    if (n == 0) return GR4PM_OK;
+    if (!in || !out || (item_kind != 0 && item_kind != 1)) return GR4PM_ERR_INVALID;
+    GR4PM_TRY(require_device());
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t item = item_kind == 0 ? 8 : 4;
+    if (in != out) GR4PM_HIP_TRY(hipMemcpyAsync(out, in, n * item, hipMemcpyDeviceToDevice, s));
+    if (n_packets) {
+        std::vector<ShapePacket> pk(n_packets);
+        for (size_t i = 0; i < n_packets; ++i) {
+            if (packet_len[i] == 0) {
+                set_error("received packet-length equal to zero"); // burst_shaper.hpp:84-89
+                return GR4PM_ERR_INVALID;
+            }
+            if (packet_offset[i] + packet_len[i] > n) {
+                set_error("packet %zu runs past the %zu items of this call", i, n);
+                return GR4PM_ERR_INVALID;
+            }
+            pk[i] = { packet_offset[i], packet_len[i] };
+        }
+        DevBuf<ShapePacket> dpk;
+        DevBuf<float> dl, dt;
+        GR4PM_TRY(dpk.alloc(n_packets));
+        GR4PM_TRY(dl.alloc(std::max<size_t>(leading_n, 1)));
+        GR4PM_TRY(dt.alloc(std::max<size_t>(trailing_n, 1)));
+        GR4PM_TRY(dpk.upload(pk.data(), n_packets, s));
+        if (leading_n) GR4PM_TRY(dl.upload(leading_host, leading_n, s));
+        if (trailing_n) GR4PM_TRY(dt.upload(trailing_host, trailing_n, s));
+        const dim3 grid(static_cast<unsigned>(n_packets));
+        if (item_kind == 0)
+            hipLaunchKernelGGL(k_burst_edges<float2>, grid, dim3(64), 0, s, static_cast<const float2*>(in),
+                               static_cast<float2*>(out), dpk.p, dl.p, static_cast<unsigned>(leading_n), dt.p,
+                               static_cast<unsigned>(trailing_n));
+        else
+            hipLaunchKernelGGL(k_burst_edges<float>, grid, dim3(64), 0, s, static_cast<const float*>(in),
+                               static_cast<float*>(out), dpk.p, dl.p, static_cast<unsigned>(leading_n), dt.p,
+                               static_cast<unsigned>(trailing_n));
+        GR4PM_HIP_TRY(hipGetLastError());
+        GR4PM_HIP_TRY(hipStreamSynchronize(s));
+    } else {
+        GR4PM_HIP_TRY(hipStreamSynchronize(s));
+    }
     return GR4PM_OK;
 }
 

@@ -612,6 +612,25 @@ gr4pm_status gr4pm_packet_receiver_submit(gr4pm_packet_receiver* h, const gr4pm_
 gr4pm_status gr4pm_packet_receiver_collect(gr4pm_packet_receiver* h, gr4pm_packet_receiver_result* result);
 size_t gr4pm_packet_receiver_inflight(const gr4pm_packet_receiver* h);
 
+/* ====================================================================================
+ * Burst generator pieces (packet_transmitter_pdu.hpp:131-337): with
+ * AdditiveScrambler, PackBits, InterpolatingFirFilter, Rotator and PfbArbResampler above they
+ * build the test signal on the device.
+ * ================================================================================== */
+/* Mapper<uint8_t, c64 | float> -- mapper.hpp:13-51: out[i] = map[in[i] & (map_size - 1)];
+ * map_size must be a power of two (:37-41); item_kind 0: c64 map/out, 1: float. */
+gr4pm_status gr4pm_mapper_process(const uint8_t* in, size_t n, void* out, const void* map_host,
+                                  size_t map_size, int item_kind, void* stream);
+/* BurstShaper<c64 | float, ., float> -- burst_shaper.hpp:47-126: the first leading_n items of
+ * every packet are multiplied by leading[], the last trailing_n by trailing[] (short packets:
+ * leading first, :98-124).  Packets: [packet_offset[i], + packet_len[i]) ("packet_len" tags),
+ * whole packets per call; items outside packets are copied. */
+gr4pm_status gr4pm_burst_shaper_process(const void* in, size_t n, void* out, int item_kind,
+                                        const float* leading_host, size_t leading_n,
+                                        const float* trailing_host, size_t trailing_n,
+                                        const uint64_t* packet_offset, const uint64_t* packet_len,
+                                        size_t n_packets, void* stream);
+
 /* firdes::root_raised_cosine<float> -- firdes.hpp:29-76 (host helper; out: ntaps|1 floats) */
 size_t gr4pm_firdes_root_raised_cosine(double gain, double sampling_freq, double symbol_rate,
                                        double alpha, size_t ntaps, float* out);

@@ -60,6 +60,10 @@ def header_code():
     gen = [int(v, 16) for v in re.findall(r"0x[0-9a-fA-F]{8}", src[a:src.index("};", a)])]
     assert len(gen) == 96
     np.save(os.path.join(HERE, "header_ldpc_generator.npy"), np.array(gen, dtype=np.uint32))
+    np.array(gen, dtype="<u4").tofile(os.path.join(data_dir, "header_ldpc_generator.u32"))  # BurstGenerator
+    tx = orc.ref_taps_dump("txrrc", 4)  # packet_transmitter_rrc_taps(4), from the reference's own header
+    assert tx is not None, "build oracle/_ref first (make -C oracle)"
+    tx.astype("<f4").tofile(os.path.join(data_dir, "tx_rrc_taps_4.f32"))
     src = open(os.path.join(REF, "test", "qa_header_fec_decoder.cpp")).read()
     vecs = []
     pos = 0

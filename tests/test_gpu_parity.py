@@ -1528,3 +1528,72 @@ def test_native_packet_receiver_decodes_headers_and_packets(pkg, mode):
     assert np.array_equal(out, np.concatenate([u for k, u in enumerate(user) if k != 6]))
     msgs = np.concatenate([g["header_messages"] for g in got])
     assert [int(v) for v in msgs["packet_length"][msgs["invalid_header"] == 0]] == lengths
+
+
+# ------------------------------------------------------------------ burst generator pieces
+def test_mapper_and_burst_shaper_reference_qa(pkg):
+    """test/qa_mapper.cpp:14-31 and test/qa_burst_shaper.cpp:15-90 through the C-ABI; the shaper also on
+    complex items against a numpy restatement of burst_shaper.hpp:98-124"""
+    mp = np.array([0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8], dtype=np.float32)
+    v = torch.arange(16, dtype=torch.uint8).cuda()
+    assert np.array_equal(pkg.mapper(v, mp).cpu().numpy(), np.concatenate([mp, mp]))
+    with pytest.raises(pkg.Gr4pmError):
+        pkg.mapper(v, mp[:6])                                   # not a power of two, mapper.hpp:37-41
+    lengths = [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 100, 250, 1000, 10000, 100000, 7, 3, 25, 14, 28, 178]
+    leading = np.array([0.1, 0.5, 0.9], dtype=np.float32)
+    trailing = np.array([0.8, 0.2], dtype=np.float32)
+
+    def shaped(x, n_lead, n_trail, lead, trail):
+        y = x.copy()
+        k = min(x.size, n_lead)
+        y[:k] = x[:k] * lead[:k]
+        rest = x.size - k
+        t = min(rest, n_trail)
+        if t:
+            y[x.size - t:] = x[x.size - t:] * trail[n_trail - t:]
+        return y
+
+    ones = torch.ones(sum(lengths)).cuda()
+    got = pkg.burst_shaper(ones, leading, trailing, lengths).cpu().numpy()
+    pos = 0
+    for n in lengths:
+        pdu = got[pos:pos + n]
+        assert np.array_equal(pdu[:3], leading[:n][:3])
+        if n > 5:
+            assert np.all(pdu[3:-2] == 1.0)
+        if n > 3:
+            t = min(n - 3, 2)
+            assert np.array_equal(pdu[-t:], trailing[-t:])
+        pos += n
+    rng = np.random.default_rng(2)
+    x = (rng.standard_normal(sum(lengths)) + 1j * rng.standard_normal(sum(lengths))).astype(np.complex64)
+    lead = rng.random(32).astype(np.float32)
+    trail = rng.random(44).astype(np.float32)
+    got = pkg.burst_shaper(dev(x), lead, trail, lengths).cpu().numpy()
+    want, pos = [], 0
+    for n in lengths:
+        want.append(shaped(x[pos:pos + n], 32, 44, lead, trail))
+        pos += n
+    assert np.array_equal(bits(got), bits(np.concatenate(want)))
+
+
+def test_burst_generator_loopback(pkg):
+    """packet_transmitter_pdu.hpp's burst path and packet_transceiver.cpp's channel on the device, received
+    by the native receiver: every packet comes back byte for byte at Es/N0 = 20 dB with carrier offset"""
+    rng = np.random.default_rng(900)
+    payloads = [rng.integers(0, 256, int(n)).astype(np.uint8).tobytes() for n in rng.integers(1, 1400, 30)]
+    gaps = rng.integers(1200, 4000, len(payloads))
+    gen = pkg.BurstGenerator()
+    x = gen.stream(payloads, gaps, freq_error=0.012, esn0_db=20.0, seed=3)  # the payload is uncoded
+    power = float(torch.mean(torch.abs(gen.bursts(payloads[:4])[0][200:-200]) ** 2))
+    assert 0.25 < power < 0.40                                  # "tx_power = 0.32", packet_transceiver.cpp:48
+    rx = pkg.NativePacketReceiver(max_items=x.numel(), tags_cap=1024, decode_headers=True)
+    r = rx.process_bulk(x)
+    lens = r["packet_lengths"]
+    assert r["header_mismatches"] == 0 and int(np.sum(r["header_messages"]["invalid_header"] == 0)) >= len(payloads)
+    data = r["packets"].cpu().numpy()
+    got, pos = [], 0
+    for n in lens[lens > 0]:
+        got.append(data[pos:pos + int(n)].tobytes())
+        pos += int(n)
+    assert got == payloads
