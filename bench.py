@@ -74,6 +74,19 @@ def header_symbols(packet_length):
     return ((1 - 2.0 * bits[0::2]) * a + 1j * (1 - 2.0 * bits[1::2]) * a).astype(np.complex64)
 
 
+def packet_stream(pkg, n_items, seed, device):
+    """--decode-headers: real packets from the package's BurstGenerator (the reference's burst format,
+    packet_transmitter_pdu.hpp): 1500 random payload bytes + CRC-32 each, 500-symbol gaps, carrier
+    offset 0.01 rad/sample, Es/N0 = 20 dB (the payload is uncoded: at 10 dB no CRC would pass)"""
+    rng = np.random.default_rng(seed)
+    gen = pkg.BurstGenerator()
+    per_packet = (64 + 128 + 1504 * 4 + gen.RAMP_DOWN + gen.FLUSH + 500) * SPS
+    n_pkt = n_items // per_packet + 1
+    payloads = [rng.integers(0, 256, 1500, dtype=np.uint8).tobytes() for _ in range(n_pkt)]
+    x = gen.stream(payloads, np.full(n_pkt, 500 * SPS), freq_error=0.01, esn0_db=20.0, seed=seed, tail=0)
+    return x[:n_items].contiguous(), n_pkt
+
+
 def burst_stream(pkg, n_items, rrc, seed, device, header=None):
     """synthetic 3.2 Msps-shaped bursts, generated on the GPU:
     packets of 64 (BPSK syncword) + 128 (header) + 1504*4 (payload) QPSK symbols, gaps of 500
@@ -206,14 +219,19 @@ def main():
     bpsk = np.array([1, -1], dtype=np.complex64)
     n_items = args.items
     input_mode = "generated on each GPU"
-    hdr_syms = header_symbols(1500) if args.decode_headers else None
-    x, n_pkt = burst_stream(pkg, n_items, rrc, seed=1 + rank, device=device, header=hdr_syms)
+    hdr_syms = None
+
+    def make_stream(seed):
+        if args.decode_headers:
+            return packet_stream(pkg, n_items, seed, device)
+        return burst_stream(pkg, n_items, rrc, seed=seed, device=device, header=hdr_syms)
+
+    x, n_pkt = make_stream(1 + rank)
     if dist and not args.no_scatter:
         # multi-channel receive: rank 0 owns the sample ring of all channels and scatters it
         try:
             def make_all():
-                chans = [x] + [burst_stream(pkg, n_items, rrc, seed=1 + r, device=device, header=hdr_syms)[0]
-                               for r in range(1, world)]
+                chans = [x] + [make_stream(1 + r)[0] for r in range(1, world)]
                 return torch.stack(chans)
             x = scatter_channels(dist, make_all, n_items, device, rank, world)
             input_mode = "rank 0 -> all ranks, torch.distributed scatter (RCCL)"
@@ -224,7 +242,7 @@ def main():
     # "before" it (for A: a copy of B's tail, for B: A's tail itself).  While one window is being
     # processed the detector is told which one comes next (look-ahead of the correlator).
     HIST = 2 * 768 + 1
-    xb, n_pkt_b = burst_stream(pkg, n_items, rrc, seed=1001 + rank, device=device, header=hdr_syms)
+    xb, n_pkt_b = make_stream(1001 + rank)
     ring = torch.empty(HIST + 1 + 2 * n_items, dtype=torch.complex64, device=device)  # +1: keep A 16-byte aligned
     ring[1:1 + HIST] = xb[-HIST:]
     ring[1 + HIST:1 + HIST + n_items] = x
@@ -261,7 +279,7 @@ def main():
                                        max_items=n_items)
 
     step_no = 0
-    hdr_stats = {"decoded": 0, "valid_1500": 0, "mismatches": 0}
+    hdr_stats = {"decoded": 0, "valid_1500": 0, "mismatches": 0, "packets_crc_ok": 0, "packets_crc_failed": 0}
 
     def note_headers(res):
         if args.decode_headers and "header_messages" in res:
@@ -269,6 +287,8 @@ def main():
             hdr_stats["decoded"] += int(m.size)
             hdr_stats["valid_1500"] += int(np.sum((m["invalid_header"] == 0) & (m["packet_length"] == 1500)))
             hdr_stats["mismatches"] += int(res["header_mismatches"])
+            hdr_stats["packets_crc_ok"] += int(np.sum(res["packet_lengths"] > 0))
+            hdr_stats["packets_crc_failed"] += int(np.sum(res["packet_lengths"] == 0))
             if os.environ.get("GR4PM_BENCH_DEBUG"):
                 bad = np.nonzero(~((m["invalid_header"] == 0) & (m["packet_length"] == 1500)))[0]
                 print("batch headers", m.size, "bad", bad.size, bad[:6], bad[-3:], m[bad[:3]], file=sys.stderr)
