@@ -1415,7 +1415,8 @@ class NativePacketReceiver:
         """same calling convention as PacketReceiver.process_bulk (header_fn: None or a constant
         packet_length); pipelined: returns the result of an earlier batch, None while filling"""
         self.submit(x, header_fn, history, next_x)
-        if not self.pipelined or lib().gr4pm_packet_receiver_inflight(self._h) > 2:
+        depth = 3 if self.decode_headers else 2  # stages behind the detector
+        if not self.pipelined or lib().gr4pm_packet_receiver_inflight(self._h) > depth:
             return self.collect()
         return None
 

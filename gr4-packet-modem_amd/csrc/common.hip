@@ -7,6 +7,8 @@
 namespace gr4pm {
 
 static thread_local char g_error[512] = "";
+static thread_local bool g_deferred_sync = false;
+bool deferred_sync() { return g_deferred_sync; }
 
 void set_error(const char* fmt, ...)
 {
@@ -33,6 +35,8 @@ gr4pm_status require_device()
 extern "C" {
 
 const char* gr4pm_last_error(void) { return gr4pm::g_error; }
+
+void gr4pm_set_deferred_sync(int on) { gr4pm::g_deferred_sync = on != 0; }
 
 const char* gr4pm_version(void) { return "gr4pm-hip 0.1 (gfx950, one-wave FFT-2048 correlator)"; }
 

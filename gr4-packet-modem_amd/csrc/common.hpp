@@ -131,4 +131,10 @@ struct PinnedBuf {
 
 inline size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
 
+// The last thing most process() calls do is wait for their stream.  A native caller that chains
+// several handles on ONE stream and reads nothing back in between (csrc/packet_receiver.hip) turns
+// that wait off for its thread (gr4pm_set_deferred_sync) and synchronises once per stage.
+bool deferred_sync();
+inline hipError_t final_sync(hipStream_t s) { return deferred_sync() ? hipSuccess : hipStreamSynchronize(s); }
+
 } // namespace gr4pm

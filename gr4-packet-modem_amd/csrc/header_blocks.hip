@@ -535,7 +535,7 @@ gr4pm_status gr4pm_additive_scrambler_process(gr4pm_additive_scrambler* h, const
                                static_cast<uint8_t*>(out));
     }
     GR4PM_HIP_TRY(hipGetLastError());
-    GR4PM_HIP_TRY(hipStreamSynchronize(h->stream));
+    GR4PM_HIP_TRY(final_sync(h->stream));
     return GR4PM_OK;
 }
 
@@ -653,7 +653,7 @@ gr4pm_status gr4pm_header_payload_split_process(gr4pm_header_payload_split* h, c
     merge(ps);
     GR4PM_TRY(gather_f32(h->stream, h->hspans, hs, in, header));
     GR4PM_TRY(gather_f32(h->stream, h->pspans, ps, in, payload));
-    GR4PM_HIP_TRY(hipStreamSynchronize(h->stream));
+    GR4PM_HIP_TRY(final_sync(h->stream));
     *n_header = hp;
     *n_payload = pp;
     if (n_header_tags) *n_header_tags = nht;
@@ -840,7 +840,7 @@ gr4pm_status gr4pm_binary_slicer_process(const float* in, size_t n, uint8_t* out
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(k_slice, dim3(grid1d(n)), dim3(256), 0, s, in, n, out, invert);
     GR4PM_HIP_TRY(hipGetLastError());
-    GR4PM_HIP_TRY(hipStreamSynchronize(s));
+    GR4PM_HIP_TRY(final_sync(s));
     return GR4PM_OK;
 }
 gr4pm_status gr4pm_pack_bits_process(const uint8_t* in, size_t n_out, uint8_t* out, size_t inputs_per_output,
@@ -857,7 +857,7 @@ gr4pm_status gr4pm_pack_bits_process(const uint8_t* in, size_t n_out, uint8_t* o
     hipLaunchKernelGGL(k_pack, dim3(grid1d(n_out)), dim3(256), 0, s, in, n_out, out,
                        static_cast<unsigned>(inputs_per_output), bits_per_input, msb_first);
     GR4PM_HIP_TRY(hipGetLastError());
-    GR4PM_HIP_TRY(hipStreamSynchronize(s));
+    GR4PM_HIP_TRY(final_sync(s));
     return GR4PM_OK;
 }
 gr4pm_status gr4pm_slice_pack_process(const float* in, size_t n_out, uint8_t* out, void* stream)
@@ -868,7 +868,7 @@ gr4pm_status gr4pm_slice_pack_process(const float* in, size_t n_out, uint8_t* ou
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(k_slice_pack, dim3(grid1d(n_out)), dim3(256), 0, s, in, n_out, out);
     GR4PM_HIP_TRY(hipGetLastError());
-    GR4PM_HIP_TRY(hipStreamSynchronize(s));
+    GR4PM_HIP_TRY(final_sync(s));
     return GR4PM_OK;
 }
 

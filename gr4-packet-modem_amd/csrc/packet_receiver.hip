@@ -21,7 +21,7 @@ using namespace gr4pm;
 
 namespace {
 
-constexpr int kSlots = 4; // detector | stage 1 | stage 2 | held by the caller
+constexpr int kSlots = 5; // detector | stage 1 | stage 2 | stage 3 (decode_headers) | held by the caller
 
 struct Slot {
     // inputs of the batch
@@ -46,6 +46,7 @@ struct Slot {
     DevBuf<gr4pm_c64> y, sym, w, pm, z, data;
     // decode_headers
     std::vector<gr4pm_header_msg> hdrs;      // per symbol-rate tag, for PayloadMetadataInsert
+    std::vector<gr4pm_header_msg> opened;    // messages of the packets PayloadMetadataInsert opened (stage 2 -> 3)
     bool has_resolve = false;
     gr4pm_header_msg resolve{};
     std::vector<gr4pm_header_msg> header_messages;
@@ -182,7 +183,7 @@ struct HeaderLoop {
 
 struct gr4pm_packet_receiver {
     gr4pm_packet_receiver_params p;
-    hipStream_t streams[3] = { nullptr, nullptr, nullptr };
+    hipStream_t streams[4] = { nullptr, nullptr, nullptr, nullptr }; // [3]: header loop + payload tail (stage 3)
     gr4pm_syncword_detection* sd = nullptr;
     gr4pm_syncword_detection_filter* sdf = nullptr;
     gr4pm_rotator* cfc = nullptr;
@@ -223,8 +224,8 @@ struct gr4pm_packet_receiver {
     std::deque<uint64_t> payload_bits;      // their lengths
     DevBuf<uint8_t> packed;
     Slot slots[kSlots];
-    Channel<int> free_slots, to_stage1, to_stage2, done;
-    std::thread workers[2];
+    Channel<int> free_slots, to_stage1, to_stage2, to_stage3, done;
+    std::thread workers[3];
     int held = -1; // slot whose result the caller is looking at
     size_t inflight = 0;
 
@@ -239,6 +240,14 @@ struct gr4pm_packet_receiver {
     gr4pm_status predecode(Slot& s, const gr4pm_c64* y);
     gr4pm_status stage1_decode(Slot& s, const gr4pm_c64* y);
     gr4pm_status stage2_decode(Slot& s);
+    gr4pm_status stage3_decode(Slot& s);
+    void stage3(Slot& s)
+    {
+        if (s.status != GR4PM_OK || !p.decode_headers) return;
+        const gr4pm_status st = stage3_decode(s);
+        (void)hipStreamSynchronize(streams[3]);
+        if (st != GR4PM_OK) fail(s, st);
+    }
 };
 
 void gr4pm_packet_receiver::stage0(Slot& s, const gr4pm_c64* next_in, size_t next_n)
@@ -258,10 +267,17 @@ void gr4pm_packet_receiver::stage0(Slot& s, const gr4pm_c64* next_in, size_t nex
     s.base = gr4pm_syncword_detection_items_consumed(sd) - n_done;
 }
 
+// Stages 1-3 run with deferred synchronisation (gr4pm_set_deferred_sync): the blocks of a stage
+// share one stream, so their kernels queue up behind each other without the host waiting in
+// between; every stage waits once, at its end, before the slot moves on.
 void gr4pm_packet_receiver::stage1(Slot& s)
 {
     if (s.status != GR4PM_OK) return;
     const gr4pm_c64* y = s.delayed ? s.delayed : s.y.p;
+    struct SyncAtEnd {
+        hipStream_t st;
+        ~SyncAtEnd() { (void)hipStreamSynchronize(st); }
+    } sync_at_end{ streams[1] };
     if (p.decode_headers) {
         const gr4pm_status st = stage1_decode(s, y);
         if (st != GR4PM_OK) fail(s, st);
@@ -295,6 +311,10 @@ void gr4pm_packet_receiver::stage1(Slot& s)
 void gr4pm_packet_receiver::stage2(Slot& s)
 {
     if (s.status != GR4PM_OK) return;
+    struct SyncAtEnd {
+        hipStream_t st;
+        ~SyncAtEnd() { (void)hipStreamSynchronize(st); }
+    } sync_at_end{ streams[2] };
     if (p.decode_headers) {
         const gr4pm_status st = stage2_decode(s);
         if (st != GR4PM_OK) fail(s, st);
@@ -532,29 +552,27 @@ struct StageTimer { // wall time of the calls of one stage, printed every 8 batc
         fprintf(stderr, " us (mean of %d)\n", batches);
     }
 };
-StageTimer g_t2{ "stage 2", {}, {}, 0, 0 };
+StageTimer g_t2{ "stage 2", {}, {}, 0, 0 }, g_t3{ "stage 3", {}, {}, 0, 0 };
 }
 #define T2_BEGIN() g_t2.begin()
 #define T2_MARK(x) g_t2.mark(x)
 #define T2_END() g_t2.end()
+#define T3_BEGIN() g_t3.begin()
+#define T3_MARK(x) g_t3.mark(x)
+#define T3_END() g_t3.end()
 #else
 #define T2_BEGIN()
 #define T2_MARK(x)
 #define T2_END()
+#define T3_BEGIN()
+#define T3_MARK(x)
+#define T3_END()
 #endif
 
 gr4pm_status gr4pm_packet_receiver::stage2_decode(Slot& s)
 {
-    hipStream_t st2 = streams[2];
     T2_BEGIN();
-    if (s.has_resolve) {
-        GR4PM_TRY(gr4pm_payload_metadata_insert_resolve(pmi, &s.resolve));
-        for (auto& m : used_msgs)
-            if (m.invalid_header == 2) {
-                m = s.resolve;
-                break;
-            }
-    }
+    if (s.has_resolve) GR4PM_TRY(gr4pm_payload_metadata_insert_resolve(pmi, &s.resolve));
     const size_t n = s.n_symbols;
     if (s.pm.n < n + 1) GR4PM_TRY(s.pm.alloc(n + 1));
     if (s.data.n < n + 1) GR4PM_TRY(s.data.alloc(n + 1));
@@ -588,16 +606,34 @@ gr4pm_status gr4pm_packet_receiver::stage2_decode(Slot& s)
     T2_MARK("llr");
     s.n_llr_tags = n_lt;
     s.n_llr = n_llr;
-    // the chain's own header loop: verification of pass A + descrambled payload
+    s.opened.clear();
     for (size_t i = 0, j = 0; i < n_pt; ++i)
         if (s.packet_tags[i].kind == GR4PM_PKT_SYNCWORD) { // a packet PayloadMetadataInsert opened: both lists ascend
             while (j < s.n_sym_tags && s.sym_tags[j].index < s.packet_tags[i].syncword.index) ++j;
-            if (j < s.n_sym_tags && s.sym_tags[j].index == s.packet_tags[i].syncword.index) used_msgs.push_back(s.hdrs[j]);
+            if (j < s.n_sym_tags && s.sym_tags[j].index == s.packet_tags[i].syncword.index) s.opened.push_back(s.hdrs[j]);
         }
+    T2_END();
+    return GR4PM_OK;
+}
+
+// stage 3 (decode_headers): the chain's own header loop (verification of pass A, descrambled
+// payload) and the payload tail, on their own stream and thread
+gr4pm_status gr4pm_packet_receiver::stage3_decode(Slot& s)
+{
+    hipStream_t st2 = streams[3];
+    T3_BEGIN();
+    const size_t n_llr = s.n_llr, n_lt = s.n_llr_tags;
+    if (s.has_resolve)
+        for (auto& m : used_msgs)
+            if (m.invalid_header == 2) {
+                m = s.resolve;
+                break;
+            }
+    for (const auto& m : s.opened) used_msgs.push_back(m);
     s.header_messages.clear();
     s.packet_type.clear();
     GR4PM_TRY(b_loop.run(s.out_llr, n_llr, s.llr_tags.data(), n_lt, s.header_messages, s.packet_type));
-    T2_MARK("header_loop");
+    T3_MARK("header_loop");
     s.header_mismatches = 0;
     for (const auto& got : s.header_messages) {
         if (used_msgs.empty()) break;
@@ -660,8 +696,8 @@ gr4pm_status gr4pm_packet_receiver::stage2_decode(Slot& s)
     }
     soft_n -= used_bits;
     GR4PM_HIP_TRY(hipStreamSynchronize(st2));
-    T2_MARK("payload_tail");
-    T2_END();
+    T3_MARK("payload_tail");
+    T3_END();
     return GR4PM_OK;
 }
 
@@ -684,7 +720,7 @@ gr4pm_status gr4pm_packet_receiver_create(const gr4pm_packet_receiver_params* p,
     // look-ahead stream)
     int least = 0, greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return bail(GR4PM_ERR_HIP);
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < 4; ++i)
         if (hipStreamCreateWithPriority(&h->streams[i], hipStreamNonBlocking, i == 0 ? greatest : 0) != hipSuccess)
             return bail(GR4PM_ERR_HIP);
     const size_t sps = p->samples_per_symbol;
@@ -751,7 +787,7 @@ gr4pm_status gr4pm_packet_receiver_create(const gr4pm_packet_receiver_params* p,
             return bail(GR4PM_ERR_INVALID);
         }
         // pass A: the same blocks a second time (stage 1's stream)
-        hipStream_t s1 = h->streams[1], s2 = h->streams[2];
+        hipStream_t s1 = h->streams[1], s2 = h->streams[3];
         gr4pm_rotator_params rp2{ 1, 0.0f, (rrc.size() - 1) / 2 + sps, 1, s1 };
         if ((st = gr4pm_rotator_create(&rp2, &h->a_cfc)) != GR4PM_OK) return bail(st);
         gr4pm_symbol_filter_params fsp2{ sps, pfb.data(), pfb.size(), arms, rrc.size() - 1, 0, s1 };
@@ -785,6 +821,7 @@ gr4pm_status gr4pm_packet_receiver_create(const gr4pm_packet_receiver_params* p,
     }
     if (p->pipelined) {
         h->workers[0] = std::thread([h] {
+            gr4pm_set_deferred_sync(getenv("GR4PM_NO_DEFER") ? 0 : 1);
             for (;;) {
                 const int i = h->to_stage1.pop();
                 if (i < 0) break;
@@ -794,10 +831,21 @@ gr4pm_status gr4pm_packet_receiver_create(const gr4pm_packet_receiver_params* p,
             h->to_stage2.push(-1);
         });
         h->workers[1] = std::thread([h] {
+            gr4pm_set_deferred_sync(getenv("GR4PM_NO_DEFER") ? 0 : 1);
             for (;;) {
                 const int i = h->to_stage2.pop();
                 if (i < 0) break;
                 h->stage2(h->slots[i]);
+                h->to_stage3.push(i);
+            }
+            h->to_stage3.push(-1);
+        });
+        h->workers[2] = std::thread([h] {
+            gr4pm_set_deferred_sync(getenv("GR4PM_NO_DEFER") ? 0 : 1);
+            for (;;) {
+                const int i = h->to_stage3.pop();
+                if (i < 0) break;
+                h->stage3(h->slots[i]);
                 h->done.push(i);
             }
         });
@@ -813,6 +861,7 @@ void gr4pm_packet_receiver_destroy(gr4pm_packet_receiver* h)
         h->to_stage1.push(-1);
         h->workers[0].join();
         h->workers[1].join();
+        h->workers[2].join();
     }
     gr4pm_syncword_detection_destroy(h->sd);
     gr4pm_syncword_detection_filter_destroy(h->sdf);
@@ -880,8 +929,12 @@ gr4pm_status gr4pm_packet_receiver_submit(gr4pm_packet_receiver* h, const gr4pm_
     if (h->p.pipelined) {
         h->to_stage1.push(i);
     } else {
+        const bool was = deferred_sync();
+        gr4pm_set_deferred_sync(1);
         h->stage1(s);
         h->stage2(s);
+        h->stage3(s);
+        gr4pm_set_deferred_sync(was ? 1 : 0);
         h->done.push(i);
     }
     return GR4PM_OK;

@@ -1065,7 +1065,7 @@ gr4pm_status gr4pm_costas_loop_process(gr4pm_costas_loop* h, const gr4pm_c64* in
         hipLaunchKernelGGL(k_costas<2>, grid, block, 0, s, h->segs.p, n_segs, st_in, st_out, h->k1, h->k2,
                            reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(out), stride);
     GR4PM_HIP_TRY(hipGetLastError());
-    GR4PM_HIP_TRY(hipStreamSynchronize(s));
+    GR4PM_HIP_TRY(final_sync(s));
     return GR4PM_OK;
 }
 
@@ -1141,7 +1141,7 @@ gr4pm_status gr4pm_costas_loop_process_packets(gr4pm_costas_loop* h, const gr4pm
                        h->state.p + (h->st_cur ^ 1), reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(out));
     h->st_cur ^= 1;
     GR4PM_HIP_TRY(hipGetLastError());
-    GR4PM_HIP_TRY(hipStreamSynchronize(s));
+    GR4PM_HIP_TRY(final_sync(s));
     return GR4PM_OK;
 }
 
@@ -1237,7 +1237,7 @@ gr4pm_status gr4pm_syncword_wipeoff_process(gr4pm_syncword_wipeoff* h, const gr4
                            h->d_syncword.p, reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(out));
     }
     GR4PM_HIP_TRY(hipGetLastError());
-    GR4PM_HIP_TRY(hipStreamSynchronize(s));
+    GR4PM_HIP_TRY(final_sync(s));
     return GR4PM_OK;
 }
 
@@ -1814,7 +1814,7 @@ static gr4pm_status symbol_filter_impl(gr4pm_symbol_filter* h, const void* in, s
         h->cur ^= 1;
     }
     GR4PM_HIP_TRY(hipGetLastError());
-    GR4PM_HIP_TRY(hipStreamSynchronize(s));
+    GR4PM_HIP_TRY(final_sync(s));
     *consumed_ = pos;
     *produced_ = produced;
     if (n_tags_out) *n_tags_out = n_pub;
@@ -2274,7 +2274,7 @@ gr4pm_status gr4pm_payload_metadata_insert_process(
     spans.erase(std::remove_if(spans.begin(), spans.end(), [](const CopySpan& c) { return c.len == 0; }),
                 spans.end());
     GR4PM_TRY(launch_gather(h->stream, h->spans, spans, reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(out)));
-    GR4PM_HIP_TRY(hipStreamSynchronize(h->stream));
+    GR4PM_HIP_TRY(final_sync(h->stream));
     *n_tags_out = n_pub;
     *consumed = ipos;
     *produced = opos;
@@ -2376,7 +2376,7 @@ gr4pm_status gr4pm_syncword_remove_process(gr4pm_syncword_remove* h, const gr4pm
         pos = end;
     }
     GR4PM_TRY(launch_gather(h->stream, h->spans, spans, reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(out)));
-    GR4PM_HIP_TRY(hipStreamSynchronize(h->stream));
+    GR4PM_HIP_TRY(final_sync(h->stream));
     *produced = opos;
     if (n_tags_out) *n_tags_out = n_pub;
     if (tag_overflow) {
@@ -2472,7 +2472,7 @@ gr4pm_status gr4pm_constellation_llr_decoder_process(gr4pm_constellation_llr_dec
                            reinterpret_cast<const float*>(in), out);
     }
     GR4PM_HIP_TRY(hipGetLastError());
-    GR4PM_HIP_TRY(hipStreamSynchronize(h->stream));
+    GR4PM_HIP_TRY(final_sync(h->stream));
     *produced = opos;
     if (n_tags_out) *n_tags_out = n_pub;
     if (tag_overflow) {

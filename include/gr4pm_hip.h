@@ -49,6 +49,13 @@ const char* gr4pm_last_error(void);
 const char* gr4pm_version(void);
 /* Number of visible HIP devices (0 when none; does not create a context). */
 int gr4pm_device_count(void);
+/* For native callers that chain several handles on ONE HIP stream without reading anything back in
+ * between: while on (per calling thread), the process() calls that return nothing device-produced
+ * to the host (symbol filter, wipe-off, Costas loop, PayloadMetadataInsert, SyncwordRemove, LLR
+ * decoder, scrambler, HeaderPayloadSplit, slicer / packer) do not wait for their stream; the
+ * caller synchronises the stream before it reads their outputs, hands them to another stream, or
+ * calls the same handle again. */
+void gr4pm_set_deferred_sync(int on);
 
 /* The `syncword_*` tag set published by SyncwordDetection (syncword_detection.hpp:106-114)
  * and consumed downstream (symbol_filter.hpp:130-156, coarse_frequency_correction.hpp:78-80,
@@ -539,11 +546,13 @@ gr4pm_status gr4pm_crc_check_process(gr4pm_crc_check* h, const uint8_t* in, cons
  * PacketReceiver -- packet_receiver.hpp:34-147,191-247: the composition itself, native.
  * The reference wires the blocks into a flowgraph and runs them with the multi-threaded
  * scheduler (one worker per block).  This object owns the blocks of the chain up to the Costas
- * loop (soft_bits: up to the LLR decoder), three HIP streams and two worker threads; batches are
- * submitted and collected, up to three in flight:
+ * loop (soft_bits: up to the LLR decoder; decode_headers: the whole receiver), its HIP streams and
+ * worker threads; batches are submitted and collected, up to four in flight:
  *   stage 0 (caller's thread, inside submit): SyncwordDetection (+ look-ahead of the next batch)
  *   stage 1: SyncwordDetectionFilter gate, CoarseFrequencyCorrection + SymbolFilter, SyncwordWipeoff
  *   stage 2: CostasLoop [PayloadMetadataInsert, tag-driven CostasLoop, SyncwordRemove, LLR decoder]
+ *   stage 3 (decode_headers): descrambler, HeaderPayloadSplit, HeaderFecDecoder, HeaderParser,
+ *            BinarySlicer, PackBits, CrcCheck
  * The parsed_header feedback is a constant packet_length per submit (0 = every header invalid),
  * or with decode_headers the header decode loop on the device.
  * ================================================================================== */
