@@ -185,6 +185,8 @@ def main():
                     help="materialise SyncwordDetection's delayed output instead of reading the ring in place")
     ap.add_argument("--no-scatter", action="store_true",
                     help="N > 1: let every rank generate its own channel instead of the RCCL scatter from rank 0")
+    ap.add_argument("--lookahead-depth", type=int, default=2,
+                    help="how many calls ahead the detector's front part (correlator, candidates, tables) is launched (max 2)")
     ap.add_argument("--no-lookahead", action="store_true",
                     help="do not announce the next window to SyncwordDetection (no correlator look-ahead)")
     ap.add_argument("--soft-bits", action="store_true",
@@ -279,6 +281,7 @@ def main():
                                        max_items=n_items)
 
     step_no = 0
+    announced_upto = 0
     hdr_stats = {"decoded": 0, "valid_1500": 0, "mismatches": 0, "packets_crc_ok": 0, "packets_crc_failed": 0}
 
     def note_headers(res):
@@ -293,12 +296,20 @@ def main():
                 bad = np.nonzero(~((m["invalid_header"] == 0) & (m["packet_length"] == 1500)))[0]
                 print("batch headers", m.size, "bad", bad.size, bad[:6], bad[-3:], m[bad[:3]], file=sys.stderr)
 
-    def step(last=False):
-        """one pass over one window; `last`: no further step follows (no look-ahead launched, so
-        that exactly `steps` correlator launches fall inside the timed region)"""
-        nonlocal out_keep, step_no
+    def step(left=0):
+        """one pass over one window; `left`: how many further steps follow in this region (the
+        look-ahead never reaches beyond it, so that exactly `steps` correlator launches fall
+        inside the timed region)"""
+        nonlocal out_keep, step_no, announced_upto
         w, history = windows[step_no % 2]
-        w_next = None if (last or args.no_lookahead) else windows[(step_no + 1) % 2][0]
+        w_next = None
+        if not args.no_lookahead:
+            # announce the inputs of the next calls, at most `lookahead_depth` ahead
+            target = step_no + min(left, args.lookahead_depth)
+            announced_upto = max(announced_upto, step_no)
+            while announced_upto < target:
+                announced_upto += 1
+                (sd if args.detector_only else rx).announce(windows[announced_upto % 2][0])
         step_no += 1
         if args.detector_only:
             with torch.cuda.stream(rx._streams[0]):
@@ -329,7 +340,7 @@ def main():
         return n, nt
 
     for i in range(args.warmup):
-        step(last=i == args.warmup - 1)
+        step(left=args.warmup - 1 - i)
     drain()
     torch.cuda.synchronize()
     if dist:
@@ -339,7 +350,7 @@ def main():
     consumed = 0
     n_tags = 0
     for i in range(args.steps):
-        n, nt = step(last=i == args.steps - 1)
+        n, nt = step(left=args.steps - 1 - i)
         consumed += n
         n_tags += nt
     n, nt = drain()  # pipelined: the last batch finishes inside the timed region
@@ -411,9 +422,9 @@ def main():
                                    " on resident burst+AWGN stream",
                        "items_per_step_per_gpu": n_items * args.channels, "channels_per_gpu": args.channels, "freq_bins": 2 * BINS + 1, "tags_per_step": n_tags // max(args.steps, 1),
                        "parallelism": f"channel-per-gpu x{world}", "input": input_mode,
-                       "pipelined_streams": 1 if (args.no_pipeline or args.detector_only) else 3,
+                       "pipelined_streams": 1 if (args.no_pipeline or args.detector_only) else (3 if args.python_pipeline else 4),
                        "pipeline_driver": "native (gr4pm_packet_receiver)" if native else "python threads",
-                       "windows": 2, "correlator_lookahead": not args.no_lookahead,
+                       "windows": 2, "correlator_lookahead": 0 if args.no_lookahead else args.lookahead_depth,
                        **({"headers": hdr_stats} if args.decode_headers else {})},
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -175,7 +175,7 @@ EXPORTS = [
     "gr4pm_syncword_detection_self_corr", "gr4pm_syncword_detection_items_consumed",
     "gr4pm_syncword_detection_process", "gr4pm_syncword_detection_last_zpow",
     "gr4pm_syncword_detection_correlate_only",
-    "gr4pm_syncword_detection_hint_next",
+    "gr4pm_syncword_detection_hint_next", "gr4pm_syncword_detection_announce",
     "gr4pm_syncword_detection_filter_create", "gr4pm_syncword_detection_filter_destroy",
     "gr4pm_syncword_detection_filter_reset", "gr4pm_syncword_detection_filter_process",
     "gr4pm_syncword_detection_filter_gate", "gr4pm_syncword_detection_filter_gate_resolve",
@@ -189,6 +189,7 @@ EXPORTS = [
     "gr4pm_interp_fir_process",
     "gr4pm_symbol_filter_create", "gr4pm_symbol_filter_destroy", "gr4pm_symbol_filter_reset",
     "gr4pm_symbol_filter_process", "gr4pm_cfc_symbol_filter_process",
+    "gr4pm_cfc_symbol_filter_plan", "gr4pm_cfc_symbol_filter_run",
     "gr4pm_pfb_arb_resampler_create", "gr4pm_pfb_arb_resampler_destroy", "gr4pm_pfb_arb_resampler_reset",
     "gr4pm_pfb_arb_resampler_process",
     "gr4pm_firdes_root_raised_cosine",
@@ -208,7 +209,7 @@ EXPORTS = [
     "gr4pm_binary_slicer_process", "gr4pm_pack_bits_process", "gr4pm_slice_pack_process",
     "gr4pm_crc_check_create", "gr4pm_crc_check_destroy", "gr4pm_crc_check_compute", "gr4pm_crc_check_process",
     "gr4pm_mapper_process", "gr4pm_burst_shaper_process",
-    "gr4pm_packet_receiver_create", "gr4pm_packet_receiver_destroy", "gr4pm_packet_receiver_submit",
+    "gr4pm_packet_receiver_create", "gr4pm_packet_receiver_destroy", "gr4pm_packet_receiver_submit", "gr4pm_packet_receiver_announce",
     "gr4pm_packet_receiver_collect", "gr4pm_packet_receiver_inflight",
 ]
 
@@ -254,6 +255,7 @@ def lib():
     L.gr4pm_syncword_detection_last_zpow.argtypes = [vp, vp, sz]
     L.gr4pm_syncword_detection_correlate_only.argtypes = [vp, vp, sz, sz]
     L.gr4pm_syncword_detection_hint_next.argtypes = [vp, vp, sz, sz]
+    L.gr4pm_syncword_detection_announce.argtypes = [vp, vp, sz, sz]
     L.gr4pm_syncword_detection_filter_create.argtypes = [C.POINTER(SdfParams), C.POINTER(vp)]
     L.gr4pm_syncword_detection_filter_destroy.argtypes = [vp]
     L.gr4pm_syncword_detection_filter_destroy.restype = None
@@ -290,6 +292,8 @@ def lib():
     L.gr4pm_symbol_filter_reset.argtypes = [vp]
     L.gr4pm_symbol_filter_process.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, sz, szp, szp, szp]
     L.gr4pm_cfc_symbol_filter_process.argtypes = [vp, vp, vp, sz, vp, sz, vp, sz, vp, sz, szp, szp, szp]
+    L.gr4pm_cfc_symbol_filter_plan.argtypes = [vp, sz, vp, sz, C.POINTER(C.c_int)]
+    L.gr4pm_cfc_symbol_filter_run.argtypes = [vp, C.c_int, vp, vp, sz, vp, sz, vp, sz, vp, sz, szp, szp, szp]
     L.gr4pm_pfb_arb_resampler_create.argtypes = [C.POINTER(PfbArbParams), C.POINTER(vp)]
     L.gr4pm_pfb_arb_resampler_destroy.argtypes = [vp]
     L.gr4pm_pfb_arb_resampler_destroy.restype = None
@@ -344,6 +348,7 @@ def lib():
     L.gr4pm_packet_receiver_destroy.argtypes = [vp]
     L.gr4pm_packet_receiver_destroy.restype = None
     L.gr4pm_packet_receiver_submit.argtypes = [vp, vp, sz, vp, vp, sz, C.c_uint64, vp, sz, vp, sz, vp, sz]
+    L.gr4pm_packet_receiver_announce.argtypes = [vp, vp, sz]
     L.gr4pm_packet_receiver_collect.argtypes = [vp, C.POINTER(PacketReceiverResult)]
     L.gr4pm_packet_receiver_inflight.argtypes = [vp]
     L.gr4pm_packet_receiver_inflight.restype = sz

@@ -128,6 +128,16 @@ class SyncwordDetection:
         """back to the state right after start() without rebuilding the templates"""
         check(lib().gr4pm_syncword_detection_reset(self._h), "SyncwordDetection.reset")
 
+    def announce(self, x):
+        """look-ahead: names the input of a later call (after the ones already announced, at most
+        two calls ahead); everything of that call that does not depend on the scan state runs on
+        other streams behind the calls before it.  The caller keeps x alive and unchanged."""
+        x = _dev_c64(x)
+        x2 = x.reshape(1, -1) if x.dim() == 1 else x
+        assert x2.shape[0] == self.n_channels
+        check(lib().gr4pm_syncword_detection_announce(self._h, x2.data_ptr(), x2.stride(0), x2.shape[1]),
+              "SyncwordDetection.announce")
+
     def process_bulk(self, x, want_output=True, tags_cap=1024, next_x=None):
         """processBulk(), :204-356.  x: [n] or [n_channels, n] complex64 on the GPU.
         Returns (status, out, tags): out holds the n_done published items (delayed input),
@@ -1163,6 +1173,10 @@ class PacketReceiver:
     def _stage12(self, fut1):
         return self._stage2(fut1.result())
 
+    def announce(self, x):
+        """the detector's look-ahead (SyncwordDetection.announce)"""
+        self.syncword_detection.announce(x)
+
     def process_bulk(self, x, header_fn=None, tags_cap=4096, history=None, next_x=None):
         """x: complex64 CUDA tensor.  Returns dict(consumed, symbols, tags, detector_tags):
         symbols = CostasLoop output (one per symbol), tags = symbol-rate tags.  With
@@ -1356,6 +1370,12 @@ class NativePacketReceiver:
         check(lib().gr4pm_packet_receiver_create(C.byref(p), C.byref(self._h)), "PacketReceiver")
         self._keep = []  # (input tensors, output tensors) of the batches in flight
 
+    def announce(self, x):
+        """names the input of a later submit (after the ones already announced): the detector's
+        look-ahead, up to two batches ahead.  The caller keeps x alive and unchanged until then."""
+        x = _dev_c64(x)
+        check(lib().gr4pm_packet_receiver_announce(self._h, x.data_ptr(), x.numel()), "PacketReceiver.announce")
+
     def submit(self, x, packet_length=None, history=None, next_x=None):
         torch = _torch()
         x = _dev_c64(x)
@@ -1415,7 +1435,7 @@ class NativePacketReceiver:
         """same calling convention as PacketReceiver.process_bulk (header_fn: None or a constant
         packet_length); pipelined: returns the result of an earlier batch, None while filling"""
         self.submit(x, header_fn, history, next_x)
-        depth = 3 if self.decode_headers else 2  # stages behind the detector
+        depth = 4 if self.decode_headers else 3  # stages behind the detector
         if not self.pipelined or lib().gr4pm_packet_receiver_inflight(self._h) > depth:
             return self.collect()
         return None

@@ -7,6 +7,8 @@
 // Host code only: every kernel is reached through the gr4pm_* entry points.
 #include <algorithm>
 #include <cmath>
+#include <chrono>
+#include <cstdio>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -21,7 +23,7 @@ using namespace gr4pm;
 
 namespace {
 
-constexpr int kSlots = 5; // detector | stage 1 | stage 2 | stage 3 (decode_headers) | held by the caller
+constexpr int kSlots = 6; // detector | stage 1 | stage 1b | stage 2 | stage 3 (decode_headers) | held by the caller
 
 struct Slot {
     // inputs of the batch
@@ -33,6 +35,7 @@ struct Slot {
     float* out_llr = nullptr;
     size_t llr_cap = 0;
     uint64_t packet_length = 0; // parsed_header answer for every packet (0: "invalid_header")
+    int plan = -1;              // rotation plan made by stage 1, used by stage 1b
     // products
     gr4pm_status status = GR4PM_OK;
     char error[256] = { 0 };
@@ -43,7 +46,7 @@ struct Slot {
     std::vector<gr4pm_header_msg> msgs;
     std::vector<gr4pm_packet_tag> packet_tags, data_tags, llr_tags;
     size_t n_det = 0, n_tags = 0, n_sym_tags = 0, n_packet_tags = 0, n_llr_tags = 0, ignored = 0;
-    DevBuf<gr4pm_c64> y, sym, w, pm, z, data;
+    DevBuf<gr4pm_c64> y, sym, pm, z, data; // sym: symbol filter output, wiped off in place
     // decode_headers
     std::vector<gr4pm_header_msg> hdrs;      // per symbol-rate tag, for PayloadMetadataInsert
     std::vector<gr4pm_header_msg> opened;    // messages of the packets PayloadMetadataInsert opened (stage 2 -> 3)
@@ -181,9 +184,43 @@ struct HeaderLoop {
 
 } // namespace
 
+#ifdef GR4PM_TIMING
+// wall time a stage spends working and waiting for its input queue (make EXTRA=-DGR4PM_TIMING)
+struct StageClock {
+    const char* name;
+    double busy = 0, idle = 0;
+    int n = 0;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void got_work()
+    {
+        const auto now = std::chrono::steady_clock::now();
+        idle += std::chrono::duration<double, std::micro>(now - t).count();
+        t = now;
+    }
+    void done_work()
+    {
+        const auto now = std::chrono::steady_clock::now();
+        busy += std::chrono::duration<double, std::micro>(now - t).count();
+        t = now;
+        if (++n % 8 == 0) {
+            fprintf(stderr, "[gr4pm timing] %s: busy %.0f us, idle %.0f us (mean of the last 8)\n", name, busy / 8, idle / 8);
+            busy = idle = 0;
+        }
+    }
+};
+#define CLK_GOT(c) (c).got_work()
+#define CLK_DONE(c) (c).done_work()
+#else
+struct StageClock { const char* name; };
+#define CLK_GOT(c) (void)(c)
+#define CLK_DONE(c) (void)(c)
+#endif
+
 struct gr4pm_packet_receiver {
+    StageClock clk[5] = { { "stage 0" }, { "stage 1" }, { "stage 2" }, { "stage 3" }, { "stage 1b" } };
     gr4pm_packet_receiver_params p;
-    hipStream_t streams[4] = { nullptr, nullptr, nullptr, nullptr }; // [3]: header loop + payload tail (stage 3)
+    // [3]: header loop + payload tail (stage 3); [4]: symbol filter + wipe-off (stage 1b)
+    hipStream_t streams[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
     gr4pm_syncword_detection* sd = nullptr;
     gr4pm_syncword_detection_filter* sdf = nullptr;
     gr4pm_rotator* cfc = nullptr;
@@ -206,7 +243,7 @@ struct gr4pm_packet_receiver {
     gr4pm_constellation_llr_decoder* a_llr = nullptr;
     HeaderLoop a_loop, b_loop; // b_loop: the real chain's own header loop (stage 2 thread)
     gr4pm_crc_check* crc = nullptr;
-    DevBuf<gr4pm_c64> a_tail, a_head, a_compact, a_sym, a_w, a_pm, a_z, a_data;
+    DevBuf<gr4pm_c64> a_tail, a_head, a_compact, a_sym, a_pm, a_z, a_data;
     DevBuf<float> a_llrbuf;
     DevBuf<long long> a_starts;
     std::vector<uint64_t> awaiting_idx;     // detections whose window continues in the next batch
@@ -217,6 +254,7 @@ struct gr4pm_packet_receiver {
     bool pending_real = false;              // an accepted packet waits for its header
     uint64_t pending_idx = 0;
     std::deque<gr4pm_header_msg> s1_fifo;   // accepted tags' messages on their way to stage 2
+    std::mutex s1_fifo_mutex;               // stage 1 pushes and patches, stage 1b pops
     // ---- decode_headers: stage 2 thread ----
     std::deque<gr4pm_header_msg> used_msgs; // given to PayloadMetadataInsert, not yet verified
     DevBuf<float> soft, soft_tmp;           // payload soft bits of packets not finished yet
@@ -224,8 +262,8 @@ struct gr4pm_packet_receiver {
     std::deque<uint64_t> payload_bits;      // their lengths
     DevBuf<uint8_t> packed;
     Slot slots[kSlots];
-    Channel<int> free_slots, to_stage1, to_stage2, to_stage3, done;
-    std::thread workers[3];
+    Channel<int> free_slots, to_stage1, to_stage1b, to_stage2, to_stage3, done;
+    std::thread workers[4];
     int held = -1; // slot whose result the caller is looking at
     size_t inflight = 0;
 
@@ -236,9 +274,11 @@ struct gr4pm_packet_receiver {
     }
     void stage0(Slot& s, const gr4pm_c64* next_in, size_t next_n);
     void stage1(Slot& s);
+    void stage1b(Slot& s);
     void stage2(Slot& s);
     gr4pm_status predecode(Slot& s, const gr4pm_c64* y);
     gr4pm_status stage1_decode(Slot& s, const gr4pm_c64* y);
+    gr4pm_status filter_and_wipe(Slot& s);
     gr4pm_status stage2_decode(Slot& s);
     gr4pm_status stage3_decode(Slot& s);
     void stage3(Slot& s)
@@ -295,17 +335,43 @@ void gr4pm_packet_receiver::stage1(Slot& s)
     s.n_tags = 0;
     for (size_t i = 0; i < s.n_det; ++i)
         if (s.accepted[i]) s.tags[s.n_tags++] = s.det_tags[i];
-    const size_t cap = s.consumed / p.samples_per_symbol + s.n_tags + 2;
-    if (s.sym.n < cap && s.sym.alloc(cap) != GR4PM_OK) return fail(s, GR4PM_ERR_NOMEM);
-    if (s.w.n < cap && s.w.alloc(cap) != GR4PM_OK) return fail(s, GR4PM_ERR_NOMEM);
-    size_t n_out_tags = 0, consumed = 0, produced = 0;
-    st = gr4pm_cfc_symbol_filter_process(cfc, symf, y, s.consumed, s.sym.p, cap, s.tags.data(), s.n_tags,
-                                         s.sym_tags.data(), s.sym_tags.size(), &n_out_tags, &consumed, &produced);
+    st = gr4pm_cfc_symbol_filter_plan(cfc, s.consumed, s.tags.data(), s.n_tags, &s.plan);
     if (st != GR4PM_OK) return fail(s, st);
+}
+
+// CoarseFrequencyCorrection -> SymbolFilter (the filter half of the fused call) -> SyncwordWipeoff
+gr4pm_status gr4pm_packet_receiver::filter_and_wipe(Slot& s)
+{
+    const gr4pm_c64* y = s.delayed ? s.delayed : s.y.p;
+    const size_t cap = s.consumed / p.samples_per_symbol + s.n_tags + 2;
+    if (s.sym.n < cap) GR4PM_TRY(s.sym.alloc(cap));
+    size_t n_out_tags = 0, consumed = 0, produced = 0;
+    GR4PM_TRY(gr4pm_cfc_symbol_filter_run(cfc, s.plan, symf, y, s.consumed, s.sym.p, cap, s.tags.data(), s.n_tags,
+                                          s.sym_tags.data(), s.sym_tags.size(), &n_out_tags, &consumed, &produced));
     s.n_sym_tags = n_out_tags;
     s.n_symbols = produced;
-    st = gr4pm_syncword_wipeoff_process(wipe, s.sym.p, produced, s.w.p, s.sym_tags.data(), n_out_tags);
-    if (st != GR4PM_OK) return fail(s, st);
+    GR4PM_TRY(gr4pm_syncword_wipeoff_process(wipe, s.sym.p, produced, s.sym.p, s.sym_tags.data(), n_out_tags));
+    if (p.decode_headers) {
+        // the message of every accepted tag waits in a FIFO (filled, and patched, by stage 1) until
+        // the symbol filter lets its tag through
+        std::lock_guard<std::mutex> lk(s1_fifo_mutex);
+        s.hdrs.assign(std::max<size_t>(n_out_tags, 1), gr4pm_header_msg{ 0, 1 });
+        for (size_t i = 0; i < n_out_tags && !s1_fifo.empty(); ++i) {
+            s.hdrs[i] = s1_fifo.front();
+            s1_fifo.pop_front();
+        }
+    }
+    return GR4PM_OK;
+}
+
+// Stage 1b: the symbol filter runs while stage 1 already plans the next batch (the phasor
+// checkpoints are a serial, latency-bound kernel; the filter is a whole-chip one)
+void gr4pm_packet_receiver::stage1b(Slot& s)
+{
+    if (s.status != GR4PM_OK) return;
+    const gr4pm_status st = filter_and_wipe(s);
+    (void)hipStreamSynchronize(streams[4]);
+    if (st != GR4PM_OK) fail(s, st);
 }
 
 void gr4pm_packet_receiver::stage2(Slot& s)
@@ -325,7 +391,7 @@ void gr4pm_packet_receiver::stage2(Slot& s)
             set_error("out_cap %zu < %zu symbols", s.out_cap, s.n_symbols);
             return fail(s, GR4PM_INSUFFICIENT_OUTPUT_ITEMS);
         }
-        const gr4pm_status st = gr4pm_costas_loop_process(costas, s.w.p, s.n_symbols, s.n_symbols, s.out_symbols,
+        const gr4pm_status st = gr4pm_costas_loop_process(costas, s.sym.p, s.n_symbols, s.n_symbols, s.out_symbols,
                                                           s.sym_tags.data(), nullptr, s.n_sym_tags);
         if (st != GR4PM_OK) fail(s, st);
         return;
@@ -347,7 +413,7 @@ void gr4pm_packet_receiver::stage2(Slot& s)
     s.data_tags.resize(s.packet_tags.size());
     s.llr_tags.resize(s.packet_tags.size());
     size_t n_pt = 0, consumed = 0, produced = 0, used = 0, ignored = 0;
-    gr4pm_status st = gr4pm_payload_metadata_insert_process(pmi, s.w.p, n, s.pm.p, n + 1, s.sym_tags.data(),
+    gr4pm_status st = gr4pm_payload_metadata_insert_process(pmi, s.sym.p, n, s.pm.p, n + 1, s.sym_tags.data(),
                                                             s.n_sym_tags, hdrs.data(), s.n_sym_tags, 1,
                                                             s.packet_tags.data(), s.packet_tags.size(), &n_pt,
                                                             &consumed, &produced, &used, &ignored);
@@ -415,7 +481,6 @@ gr4pm_status gr4pm_packet_receiver::predecode(Slot& s, const gr4pm_c64* y)
         const size_t n_items = k * kW, cap = n_items / p.samples_per_symbol + k + 2;
         if (a_sym.n < cap) {
             GR4PM_TRY(a_sym.alloc(cap * 2));
-            GR4PM_TRY(a_w.alloc(cap * 2));
             GR4PM_TRY(a_pm.alloc(cap * 2));
             GR4PM_TRY(a_z.alloc(cap * 2));
             GR4PM_TRY(a_data.alloc(cap * 2));
@@ -425,13 +490,13 @@ gr4pm_status gr4pm_packet_receiver::predecode(Slot& s, const gr4pm_c64* y)
         size_t n_st = 0, consumed = 0, produced = 0;
         GR4PM_TRY(gr4pm_cfc_symbol_filter_process(a_cfc, a_symf, a_compact.p, n_items, a_sym.p, cap, tags.data(), k,
                                                   sym_tags.data(), sym_tags.size(), &n_st, &consumed, &produced));
-        GR4PM_TRY(gr4pm_syncword_wipeoff_process(a_wipe, a_sym.p, produced, a_w.p, sym_tags.data(), n_st));
+        GR4PM_TRY(gr4pm_syncword_wipeoff_process(a_wipe, a_sym.p, produced, a_sym.p, sym_tags.data(), n_st));
         a_fifo += k; // one "invalid_header" per detection: only syncword + header pass
         std::vector<gr4pm_header_msg> inv(std::max<size_t>(n_st, 1), gr4pm_header_msg{ 0, 1 });
         a_fifo -= std::min(a_fifo, n_st);
         std::vector<gr4pm_packet_tag> ptags(3 * n_st + 8), dtags(3 * n_st + 8), ltags(3 * n_st + 8);
         size_t n_pt = 0, c2 = 0, n_pm = 0, used = 0, ignored = 0;
-        GR4PM_TRY(gr4pm_payload_metadata_insert_process(a_pmi, a_w.p, produced, a_pm.p, cap, sym_tags.data(), n_st,
+        GR4PM_TRY(gr4pm_payload_metadata_insert_process(a_pmi, a_sym.p, produced, a_pm.p, cap, sym_tags.data(), n_st,
                                                         inv.data(), n_st, 1, ptags.data(), ptags.size(), &n_pt, &c2,
                                                         &n_pm, &used, &ignored));
         GR4PM_TRY(gr4pm_costas_loop_process_packets(a_costas, a_pm.p, n_pm, a_z.p, ptags.data(), n_pt));
@@ -471,6 +536,7 @@ gr4pm_status gr4pm_packet_receiver::stage1_decode(Slot& s, const gr4pm_c64* y)
             GR4PM_TRY(gr4pm_syncword_detection_filter_gate_resolve(sdf, m));
             pending_real = false;
             bool patched = false;
+            std::lock_guard<std::mutex> lk(s1_fifo_mutex);
             for (auto& f : s1_fifo)
                 if (f.invalid_header == 2) { // its tag has not even reached PayloadMetadataInsert yet
                     f = *m;
@@ -497,6 +563,7 @@ gr4pm_status gr4pm_packet_receiver::stage1_decode(Slot& s, const gr4pm_c64* y)
     GR4PM_TRY(gr4pm_syncword_detection_filter_gate(sdf, idx.data(), s.n_det, s.msgs.data(), s.n_det, 1,
                                                    s.accepted.data(), &used));
     s.n_tags = 0;
+    std::unique_lock<std::mutex> lk(s1_fifo_mutex);
     for (size_t i = 0; i < s.n_det; ++i)
         if (s.accepted[i]) {
             s.tags[s.n_tags++] = s.det_tags[i];
@@ -506,23 +573,11 @@ gr4pm_status gr4pm_packet_receiver::stage1_decode(Slot& s, const gr4pm_c64* y)
                 pending_idx = idx[i];
             }
         }
+    lk.unlock();
     known.erase(known.begin(), std::find_if(known.begin(), known.end(), [&](const auto& e) {
                     return e.first + (1ull << 22) >= s.base; // forget old entries
                 }));
-    const size_t cap = s.consumed / p.samples_per_symbol + s.n_tags + 2;
-    if (s.sym.n < cap) GR4PM_TRY(s.sym.alloc(cap));
-    if (s.w.n < cap) GR4PM_TRY(s.w.alloc(cap));
-    size_t n_out_tags = 0, consumed = 0, produced = 0;
-    GR4PM_TRY(gr4pm_cfc_symbol_filter_process(cfc, symf, y, s.consumed, s.sym.p, cap, s.tags.data(), s.n_tags,
-                                              s.sym_tags.data(), s.sym_tags.size(), &n_out_tags, &consumed, &produced));
-    s.n_sym_tags = n_out_tags;
-    s.n_symbols = produced;
-    GR4PM_TRY(gr4pm_syncword_wipeoff_process(wipe, s.sym.p, produced, s.w.p, s.sym_tags.data(), n_out_tags));
-    s.hdrs.assign(std::max<size_t>(n_out_tags, 1), gr4pm_header_msg{ 0, 1 });
-    for (size_t i = 0; i < n_out_tags && !s1_fifo.empty(); ++i) {
-        s.hdrs[i] = s1_fifo.front();
-        s1_fifo.pop_front();
-    }
+    GR4PM_TRY(gr4pm_cfc_symbol_filter_plan(cfc, s.consumed, s.tags.data(), s.n_tags, &s.plan));
     return GR4PM_OK;
 }
 
@@ -580,7 +635,7 @@ gr4pm_status gr4pm_packet_receiver::stage2_decode(Slot& s)
     s.data_tags.resize(s.packet_tags.size());
     s.llr_tags.resize(s.packet_tags.size());
     size_t n_pt = 0, consumed = 0, produced = 0, used = 0, ignored = 0;
-    GR4PM_TRY(gr4pm_payload_metadata_insert_process(pmi, s.w.p, n, s.pm.p, n + 1, s.sym_tags.data(), s.n_sym_tags,
+    GR4PM_TRY(gr4pm_payload_metadata_insert_process(pmi, s.sym.p, n, s.pm.p, n + 1, s.sym_tags.data(), s.n_sym_tags,
                                                     s.hdrs.data(), s.n_sym_tags, 1, s.packet_tags.data(),
                                                     s.packet_tags.size(), &n_pt, &consumed, &produced, &used, &ignored));
     if (consumed != n) {
@@ -720,7 +775,7 @@ gr4pm_status gr4pm_packet_receiver_create(const gr4pm_packet_receiver_params* p,
     // look-ahead stream)
     int least = 0, greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return bail(GR4PM_ERR_HIP);
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 5; ++i)
         if (hipStreamCreateWithPriority(&h->streams[i], hipStreamNonBlocking, i == 0 ? greatest : 0) != hipSuccess)
             return bail(GR4PM_ERR_HIP);
     const size_t sps = p->samples_per_symbol;
@@ -765,11 +820,11 @@ gr4pm_status gr4pm_packet_receiver_create(const gr4pm_packet_receiver_params* p,
                                                          static_cast<double>(arms * sps), 1.0, 0.35, arms * sps * 11,
                                                          pfb.data());
     pfb.resize(n_pfb - 1); // the design is odd-length: drop the last tap (:108-110)
-    gr4pm_symbol_filter_params fsp{ sps, pfb.data(), pfb.size(), arms, rrc.size() - 1, 0, h->streams[1] };
+    gr4pm_symbol_filter_params fsp{ sps, pfb.data(), pfb.size(), arms, rrc.size() - 1, 0, h->streams[4] };
     if ((st = gr4pm_symbol_filter_create(&fsp, &h->symf)) != GR4PM_OK) return bail(st);
     float bipolar[64];
     for (int i = 0; i < 64; ++i) bipolar[i] = syncword[i] ? -1.0f : 1.0f; // :117-122
-    gr4pm_syncword_wipeoff_params wp{ bipolar, 64, h->streams[1] };
+    gr4pm_syncword_wipeoff_params wp{ bipolar, 64, h->streams[4] };
     if ((st = gr4pm_syncword_wipeoff_create(&wp, &h->wipe)) != GR4PM_OK) return bail(st);
     gr4pm_costas_loop_params cp{ 0.01, p->soft_bits ? 1 : p->costas_constellation, 1, h->streams[2] }; // :125
     if ((st = gr4pm_costas_loop_create(&cp, &h->costas)) != GR4PM_OK) return bail(st);
@@ -825,7 +880,21 @@ gr4pm_status gr4pm_packet_receiver_create(const gr4pm_packet_receiver_params* p,
             for (;;) {
                 const int i = h->to_stage1.pop();
                 if (i < 0) break;
+                CLK_GOT(h->clk[1]);
                 h->stage1(h->slots[i]);
+                CLK_DONE(h->clk[1]);
+                h->to_stage1b.push(i);
+            }
+            h->to_stage1b.push(-1);
+        });
+        h->workers[3] = std::thread([h] {
+            gr4pm_set_deferred_sync(getenv("GR4PM_NO_DEFER") ? 0 : 1);
+            for (;;) {
+                const int i = h->to_stage1b.pop();
+                if (i < 0) break;
+                CLK_GOT(h->clk[4]);
+                h->stage1b(h->slots[i]);
+                CLK_DONE(h->clk[4]);
                 h->to_stage2.push(i);
             }
             h->to_stage2.push(-1);
@@ -835,7 +904,9 @@ gr4pm_status gr4pm_packet_receiver_create(const gr4pm_packet_receiver_params* p,
             for (;;) {
                 const int i = h->to_stage2.pop();
                 if (i < 0) break;
+                CLK_GOT(h->clk[2]);
                 h->stage2(h->slots[i]);
+                CLK_DONE(h->clk[2]);
                 h->to_stage3.push(i);
             }
             h->to_stage3.push(-1);
@@ -845,7 +916,9 @@ gr4pm_status gr4pm_packet_receiver_create(const gr4pm_packet_receiver_params* p,
             for (;;) {
                 const int i = h->to_stage3.pop();
                 if (i < 0) break;
+                CLK_GOT(h->clk[3]);
                 h->stage3(h->slots[i]);
+                CLK_DONE(h->clk[3]);
                 h->done.push(i);
             }
         });
@@ -862,6 +935,7 @@ void gr4pm_packet_receiver_destroy(gr4pm_packet_receiver* h)
         h->workers[0].join();
         h->workers[1].join();
         h->workers[2].join();
+        h->workers[3].join();
     }
     gr4pm_syncword_detection_destroy(h->sd);
     gr4pm_syncword_detection_filter_destroy(h->sdf);
@@ -924,7 +998,9 @@ gr4pm_status gr4pm_packet_receiver_submit(gr4pm_packet_receiver* h, const gr4pm_
     s.status = GR4PM_OK;
     s.error[0] = 0;
     s.consumed = s.n_symbols = s.n_llr = s.n_det = s.n_tags = s.n_sym_tags = s.n_packet_tags = s.n_llr_tags = 0;
+    CLK_GOT(h->clk[0]);
     h->stage0(s, next_in, next_n);
+    CLK_DONE(h->clk[0]);
     ++h->inflight;
     if (h->p.pipelined) {
         h->to_stage1.push(i);
@@ -932,12 +1008,19 @@ gr4pm_status gr4pm_packet_receiver_submit(gr4pm_packet_receiver* h, const gr4pm_
         const bool was = deferred_sync();
         gr4pm_set_deferred_sync(1);
         h->stage1(s);
+        h->stage1b(s);
         h->stage2(s);
         h->stage3(s);
         gr4pm_set_deferred_sync(was ? 1 : 0);
         h->done.push(i);
     }
     return GR4PM_OK;
+}
+
+gr4pm_status gr4pm_packet_receiver_announce(gr4pm_packet_receiver* h, const gr4pm_c64* in, size_t n_in)
+{
+    if (!h || !in) return GR4PM_ERR_INVALID;
+    return gr4pm_syncword_detection_announce(h->sd, in, n_in, n_in);
 }
 
 gr4pm_status gr4pm_packet_receiver_collect(gr4pm_packet_receiver* h, gr4pm_packet_receiver_result* r)

@@ -81,6 +81,30 @@ __device__ __forceinline__ void rot_step(cf& e, cf inc, unsigned& counter)
     }
 }
 
+// kRotChunk steps e *= inc without renormalisation, three packed instructions a step:
+//   a = (e.x * inc.x, e.x * inc.y)   b = (e.y * inc.y, e.y * inc.x)   e = (a.x - b.x, a.y + b.y)
+// which are exactly the four products and two sums of cmul(), each rounded once (the sign of
+// b.x is an input modifier).  The s_nop are the wait state gfx950 needs between a packed
+// result and its packed consumer; hipcc spends seven instructions and four dependent levels a
+// step on the same arithmetic (it builds both a + b and a - b and moves halves around).
+__device__ __forceinline__ cf rot_chunk_pk(cf e, cf inc)
+{
+    static_assert(kRotChunk == 8, "eight unrolled steps below");
+    cf a, b;
+#define GR4PM_ROT_STEP                                                  \
+    "v_pk_mul_f32 %[a], %[e], %[i] op_sel_hi:[0,1]\n"                   \
+    "v_pk_mul_f32 %[b], %[e], %[i] op_sel:[1,1] op_sel_hi:[1,0]\n"      \
+    "s_nop 0\n"                                                         \
+    "v_pk_add_f32 %[e], %[a], %[b] neg_lo:[0,1] neg_hi:[0,0]\n"         \
+    "s_nop 0\n"
+    asm volatile(GR4PM_ROT_STEP GR4PM_ROT_STEP GR4PM_ROT_STEP GR4PM_ROT_STEP GR4PM_ROT_STEP GR4PM_ROT_STEP
+                     GR4PM_ROT_STEP GR4PM_ROT_STEP
+                 : [e] "+v"(e), [a] "=&v"(a), [b] "=&v"(b)
+                 : [i] "v"(inc));
+#undef GR4PM_ROT_STEP
+    return e;
+}
+
 // serial: one lane per segment, phasor checkpoints every kRotChunk samples.  The chain of
 // dependent complex multiplies is the whole cost, so the loop body is kept to exactly that.
 __global__ void k_rot_checkpoints(const RotSeg* __restrict__ segs, unsigned n_segs,
@@ -88,6 +112,7 @@ __global__ void k_rot_checkpoints(const RotSeg* __restrict__ segs, unsigned n_se
                                   cf* __restrict__ ck,
                                   cf* __restrict__ seg_incr, unsigned* __restrict__ seg_counter0)
 {
+    __builtin_amdgcn_s_setprio(3); // latency-bound, few waves
     const unsigned s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_segs) return;
     const RotSeg g = segs[s];
@@ -110,8 +135,7 @@ __global__ void k_rot_checkpoints(const RotSeg* __restrict__ segs, unsigned n_se
     for (unsigned long long c = 0; c < n_full; ++c) {
         ckp[c] = e;
         if ((counter & 511u) < 512u - kRotChunk) { // no renormalisation inside this chunk
-#pragma unroll
-            for (unsigned j = 0; j < kRotChunk; ++j) e = cmul(e, inc);
+            e = rot_chunk_pk(e, inc);
             counter += kRotChunk;
         } else {
 #pragma unroll
@@ -368,7 +392,7 @@ struct WipeSpan {
     unsigned len;
 };
 __global__ void k_wipe(const WipeSpan* __restrict__ spans, const float* __restrict__ syncword,
-                       const cf* __restrict__ in, cf* __restrict__ out)
+                       const cf* in, cf* out) // may be the same buffer
 {
     const WipeSpan w = spans[blockIdx.x];
     for (unsigned i = threadIdx.x; i < w.len; i += blockDim.x)
@@ -725,9 +749,17 @@ struct gr4pm_rotator {
     hipStream_t stream;
     DevBuf<RotState> state; // [2][n_channels], st_cur selects the current half
     int st_cur = 0;
-    DevBuf<RotSeg> segs;
-    DevBuf<cf> ck, seg_incr;
-    DevBuf<unsigned> seg_counter0;
+    // the plan of a call (segment table, phasor checkpoints, increments, counters): two sets, so
+    // that the next call can be planned while the consumer of the last plan is still running
+    // (gr4pm_cfc_symbol_filter_plan / _run)
+    struct Plan {
+        DevBuf<RotSeg> segs;
+        DevBuf<cf> ck, seg_incr;
+        DevBuf<unsigned> seg_counter0;
+        unsigned n_segs = 0;
+        size_t n_in = 0;
+    } plans[2];
+    int plan_cur = 0;
     std::vector<float> next_freq;     // per channel, coarse_frequency_correction.hpp:44
     std::vector<long> next_freq_delay; // :45
 };
@@ -787,7 +819,7 @@ gr4pm_status gr4pm_rotator_reset(gr4pm_rotator* h) { return h ? rotator_reset_im
 } // extern "C"
 
 // host replay of the tag-driven control flow + the serial phasor checkpoints; leaves the segment
-// table, checkpoints, increments and counters of this call on the device (h->segs, h->ck, ...)
+// table, checkpoints, increments and counters of this call on the device (h->plans[h->plan_cur])
 static gr4pm_status rotator_plan(gr4pm_rotator* h, size_t n, const gr4pm_tag* tags, const uint32_t* tag_channel,
                                  size_t n_tags, std::vector<RotSeg>& segs)
 {
@@ -859,15 +891,20 @@ static gr4pm_status rotator_plan(gr4pm_rotator* h, size_t n, const gr4pm_tag* ta
     const unsigned n_segs = static_cast<unsigned>(segs.size());
     unsigned ck_total = 0;
     for (const auto& g : segs) ck_total = std::max<unsigned>(ck_total, g.ck0 + static_cast<unsigned>((g.len + kRotChunk - 1) / kRotChunk));
-    GR4PM_TRY(upload_vec(h->segs, segs, s));
-    if (h->ck.n < ck) GR4PM_TRY(h->ck.alloc(static_cast<size_t>(ck) * 2));
-    if (h->seg_incr.n < n_segs) {
-        GR4PM_TRY(h->seg_incr.alloc(n_segs * 2));
-        GR4PM_TRY(h->seg_counter0.alloc(n_segs * 2));
+    h->plan_cur ^= 1;
+    auto& pl = h->plans[h->plan_cur];
+    pl.n_segs = n_segs;
+    pl.n_in = n;
+    GR4PM_TRY(upload_vec(pl.segs, segs, s));
+    if (pl.ck.n < ck) GR4PM_TRY(pl.ck.alloc(static_cast<size_t>(ck) * 2));
+    if (pl.seg_incr.n < n_segs) {
+        GR4PM_TRY(pl.seg_incr.alloc(n_segs * 2));
+        GR4PM_TRY(pl.seg_counter0.alloc(n_segs * 2));
     }
-    hipLaunchKernelGGL(k_rot_checkpoints, dim3(grid_for(n_segs, 64)), dim3(64), 0, s, h->segs.p, n_segs,
-                       h->state.p + h->st_cur * h->n_channels, h->state.p + (h->st_cur ^ 1) * h->n_channels,
-                       h->ck.p, h->seg_incr.p, h->seg_counter0.p);
+    hipLaunchKernelGGL(k_rot_checkpoints, dim3(grid_for(n_segs, 64)), dim3(64), 0, s, pl.segs.p, n_segs,
+                       h->state.p + static_cast<size_t>(h->st_cur) * h->n_channels,
+                       h->state.p + static_cast<size_t>(h->st_cur ^ 1) * h->n_channels,
+                       pl.ck.p, pl.seg_incr.p, pl.seg_counter0.p);
     GR4PM_HIP_TRY(hipGetLastError());
     h->st_cur ^= 1;
     return GR4PM_OK;
@@ -896,8 +933,9 @@ gr4pm_status gr4pm_rotator_process(gr4pm_rotator* h, const gr4pm_c64* in, size_t
         // grid.y = segment (at most 65535 per launch)
         for (unsigned s0 = 0; s0 < n_segs; s0 += 65535u) {
             const unsigned ns = std::min(65535u, n_segs - s0);
-            hipLaunchKernelGGL(k_rot_apply, dim3(gx, ns), dim3(256), 0, s, h->segs.p + s0, ns, h->ck.p,
-                               h->seg_incr.p + s0, h->seg_counter0.p + s0, reinterpret_cast<const cf*>(in),
+            const auto& pl = h->plans[h->plan_cur];
+            hipLaunchKernelGGL(k_rot_apply, dim3(gx, ns), dim3(256), 0, s, pl.segs.p + s0, ns, pl.ck.p,
+                               pl.seg_incr.p + s0, pl.seg_counter0.p + s0, reinterpret_cast<const cf*>(in),
                                reinterpret_cast<cf*>(out), stride);
         }
     }
@@ -1229,8 +1267,9 @@ gr4pm_status gr4pm_syncword_wipeoff_process(gr4pm_syncword_wipeoff* h, const gr4
         if (t < n_tags && tags[t].index < pos) ++t;
     }
     hipStream_t s = h->stream;
-    hipLaunchKernelGGL(k_copy<cf>, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s,
-                       reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(out), n);
+    if (in != out) // in place: only the syncword spans are touched
+        hipLaunchKernelGGL(k_copy<cf>, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s,
+                           reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(out), n);
     if (!spans.empty()) {
         GR4PM_TRY(upload_vec(h->spans, spans, s));
         hipLaunchKernelGGL(k_wipe, dim3(static_cast<unsigned>(spans.size())), dim3(64), 0, s, h->spans.p,
@@ -1836,20 +1875,40 @@ gr4pm_status gr4pm_symbol_filter_process(gr4pm_symbol_filter* h, const void* in,
                               consumed, produced, nullptr);
 }
 
-gr4pm_status gr4pm_cfc_symbol_filter_process(gr4pm_rotator* cfc, gr4pm_symbol_filter* sf, const gr4pm_c64* in,
-                                             size_t n_in, gr4pm_c64* out, size_t out_cap,
-                                             const gr4pm_tag* tags_in, size_t n_tags_in, gr4pm_tag* tags_out,
-                                             size_t tags_cap, size_t* n_tags_out, size_t* consumed,
-                                             size_t* produced)
+gr4pm_status gr4pm_cfc_symbol_filter_plan(gr4pm_rotator* cfc, size_t n_in, const gr4pm_tag* tags_in,
+                                          size_t n_tags_in, int* plan)
+{
+    if (!cfc || !plan) return GR4PM_ERR_INVALID;
+    *plan = -1;
+    if (cfc->mode != 1 || cfc->n_channels != 1) {
+        set_error("fused call needs a single-channel CoarseFrequencyCorrection");
+        return GR4PM_ERR_INVALID;
+    }
+    if (n_in == 0) return GR4PM_OK;
+    std::vector<RotSeg> segs;
+    GR4PM_TRY(rotator_plan(cfc, n_in, tags_in, nullptr, n_tags_in, segs)); // checkpoints on the CFC's stream
+    *plan = cfc->plan_cur;
+    GR4PM_HIP_TRY(final_sync(cfc->stream));
+    return GR4PM_OK;
+}
+
+gr4pm_status gr4pm_cfc_symbol_filter_run(gr4pm_rotator* cfc, int plan, gr4pm_symbol_filter* sf,
+                                         const gr4pm_c64* in, size_t n_in, gr4pm_c64* out, size_t out_cap,
+                                         const gr4pm_tag* tags_in, size_t n_tags_in, gr4pm_tag* tags_out,
+                                         size_t tags_cap, size_t* n_tags_out, size_t* consumed, size_t* produced)
 {
     if (!cfc || !sf || !consumed || !produced) return GR4PM_ERR_INVALID;
     *consumed = *produced = 0;
     if (n_tags_out) *n_tags_out = 0;
-    if (cfc->mode != 1 || cfc->n_channels != 1 || sf->item_kind != 0 || cfc->stream != sf->stream) {
-        set_error("fused call needs a single-channel CoarseFrequencyCorrection and a complex SymbolFilter on one stream");
+    if (sf->item_kind != 0) {
+        set_error("fused call needs a complex SymbolFilter");
         return GR4PM_ERR_INVALID;
     }
     if (n_in == 0) return GR4PM_OK;
+    if (plan < 0 || plan > 1 || cfc->plans[plan].n_in != n_in) {
+        set_error("no rotation plan for this call");
+        return GR4PM_ERR_INVALID;
+    }
     if (!in || !out) {
         set_error("null sample pointer");
         return GR4PM_ERR_INVALID;
@@ -1859,14 +1918,13 @@ gr4pm_status gr4pm_cfc_symbol_filter_process(gr4pm_rotator* cfc, gr4pm_symbol_fi
         set_error("out_cap too small for a fused call");
         return GR4PM_INSUFFICIENT_OUTPUT_ITEMS;
     }
-    std::vector<RotSeg> segs;
-    GR4PM_TRY(rotator_plan(cfc, n_in, tags_in, nullptr, n_tags_in, segs)); // checkpoints on the shared stream
+    const auto& pl = cfc->plans[plan];
     CfcDev f;
-    f.segs = cfc->segs.p;
-    f.ck = cfc->ck.p;
-    f.seg_incr = cfc->seg_incr.p;
-    f.seg_counter0 = cfc->seg_counter0.p;
-    f.n_segs = static_cast<unsigned>(segs.size());
+    f.segs = pl.segs.p;
+    f.ck = pl.ck.p;
+    f.seg_incr = pl.seg_incr.p;
+    f.seg_counter0 = pl.seg_counter0.p;
+    f.n_segs = pl.n_segs;
     const gr4pm_status st = symbol_filter_impl(sf, in, n_in, out, out_cap, tags_in, n_tags_in, tags_out, tags_cap,
                                                n_tags_out, consumed, produced, &f);
     if (st == GR4PM_OK && *consumed != n_in) {
@@ -1874,6 +1932,38 @@ gr4pm_status gr4pm_cfc_symbol_filter_process(gr4pm_rotator* cfc, gr4pm_symbol_fi
         return GR4PM_ERR_INVALID;
     }
     return st;
+}
+
+gr4pm_status gr4pm_cfc_symbol_filter_process(gr4pm_rotator* cfc, gr4pm_symbol_filter* sf, const gr4pm_c64* in,
+                                             size_t n_in, gr4pm_c64* out, size_t out_cap,
+                                             const gr4pm_tag* tags_in, size_t n_tags_in, gr4pm_tag* tags_out,
+                                             size_t tags_cap, size_t* n_tags_out, size_t* consumed,
+                                             size_t* produced)
+{
+    if (!cfc || !sf || !consumed || !produced) return GR4PM_ERR_INVALID;
+    *consumed = *produced = 0;
+    if (n_tags_out) *n_tags_out = 0;
+    if (cfc->stream != sf->stream) {
+        set_error("fused call needs the CoarseFrequencyCorrection and the SymbolFilter on one stream");
+        return GR4PM_ERR_INVALID;
+    }
+    if (n_in == 0) return GR4PM_OK;
+    if (!in || !out) {
+        set_error("null sample pointer");
+        return GR4PM_ERR_INVALID;
+    }
+    if (out_cap < n_in / sf->sps + n_tags_in + 2) { // checked before the plan consumes the tags
+        set_error("out_cap too small for a fused call");
+        return GR4PM_INSUFFICIENT_OUTPUT_ITEMS;
+    }
+    int plan = -1;
+    const bool was = deferred_sync();
+    gr4pm_set_deferred_sync(1); // same stream: the filter queues up behind the checkpoints
+    const gr4pm_status st = gr4pm_cfc_symbol_filter_plan(cfc, n_in, tags_in, n_tags_in, &plan);
+    gr4pm_set_deferred_sync(was ? 1 : 0);
+    if (st != GR4PM_OK) return st;
+    return gr4pm_cfc_symbol_filter_run(cfc, plan, sf, in, n_in, out, out_cap, tags_in, n_tags_in, tags_out,
+                                       tags_cap, n_tags_out, consumed, produced);
 }
 
 } // extern "C"

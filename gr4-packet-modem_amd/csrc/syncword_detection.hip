@@ -26,6 +26,7 @@
 #include <cmath>
 #include <complex>
 #include <cstdint>
+#include <deque>
 #include <vector>
 
 #include "common.hpp"
@@ -41,7 +42,12 @@ namespace {
 
 constexpr int kWavesPerWg = 4; // 256 threads; two workgroups per CU (68 KiB LDS each) = 2 waves per SIMD
 constexpr int kMaxBins = 64;
-constexpr uint32_t kTileW = 32768; // items per detector tile
+#ifndef GR4PM_TILE_W
+#define GR4PM_TILE_W 32768
+#endif
+constexpr uint32_t kTileW = GR4PM_TILE_W; // items per detector tile
+// look-ahead depth: fronts (correlator, candidates, tables) of up to kAhead future calls in flight
+constexpr int kAhead = 2, kSets = kAhead + 1, kCarry = kAhead + 2;
 
 struct RawTag { // device -> host
     uint64_t pos; // absolute item index of the detection
@@ -508,7 +514,10 @@ struct ChanState {
 //                    the scan leaves the group
 //   k_group_walk     (one thread per channel) walk the groups
 //   k_tile_entries   (one thread per group) walk the tiles of one group from its known entry
-constexpr uint32_t kGroup = 32;
+#ifndef GR4PM_GROUP
+#define GR4PM_GROUP 32
+#endif
+constexpr uint32_t kGroup = GR4PM_GROUP;
 __device__ __forceinline__ unsigned long long walk_tiles(unsigned long long r, uint32_t t0, uint32_t t1,
                                                          uint32_t cnt, uint32_t T,
                                                          const uint32_t* __restrict__ tab,
@@ -541,42 +550,42 @@ __global__ void k_group_tables(uint32_t cnt, uint32_t T, uint32_t n_tiles, const
     gtable[ch * gtable_stride + static_cast<size_t>(grp) * (T + 1) + e] =
         walk_tiles(r0, t0, t1, cnt, T, table + ch * table_stride, nullptr);
 }
-__global__ void k_group_walk(ChanState* __restrict__ st, unsigned long long A0, uint32_t cnt, uint32_t T,
-                             uint32_t n_tiles, const unsigned long long* __restrict__ gtable, size_t gtable_stride,
-                             unsigned long long* __restrict__ gentry, uint32_t n_groups, int n_channels)
+// one workgroup per channel: thread 0 walks the groups (the only truly serial part of a call),
+// then one thread per group walks its tiles from the entry just found
+__global__ __launch_bounds__(256) void k_scan_entries(ChanState* __restrict__ st, unsigned long long A0,
+                                                      uint32_t cnt, uint32_t T, uint32_t n_tiles,
+                                                      const uint32_t* __restrict__ table, size_t table_stride,
+                                                      const unsigned long long* __restrict__ gtable,
+                                                      size_t gtable_stride, unsigned long long* __restrict__ gentry,
+                                                      uint32_t n_groups, int32_t* __restrict__ entry)
 {
 #ifndef GR4PM_NO_SETPRIO
     __builtin_amdgcn_s_setprio(3); // latency-bound, few waves: win the issue arbitration against throughput kernels
 #endif
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= n_channels) return;
-    const unsigned long long rabs = st[ch].r;
-    unsigned long long r = rabs > A0 ? rabs - A0 : 0; // local; may exceed cnt
-    for (uint32_t g = 0; g < n_groups; ++g) {
-        gentry[ch * n_groups + g] = r;
-        const unsigned long long lo = static_cast<unsigned long long>(g) * kGroup * kTileW;
-        const uint32_t t1 = min((g + 1) * kGroup, n_tiles);
-        const unsigned long long hi = min(static_cast<unsigned long long>(t1) * kTileW,
-                                          static_cast<unsigned long long>(cnt));
-        if (r >= hi) continue;
-        const unsigned long long e = r > lo ? r - lo : 0; // <= T by construction
-        r = gtable[ch * gtable_stride + static_cast<size_t>(g) * (T + 1) + e];
+    const uint32_t ch = blockIdx.x;
+    unsigned long long* ge = gentry + static_cast<size_t>(ch) * n_groups;
+    if (threadIdx.x == 0) {
+        const unsigned long long rabs = st[ch].r;
+        unsigned long long r = rabs > A0 ? rabs - A0 : 0; // local; may exceed cnt
+        for (uint32_t g = 0; g < n_groups; ++g) {
+            ge[g] = r;
+            const unsigned long long lo = static_cast<unsigned long long>(g) * kGroup * kTileW;
+            const uint32_t t1 = min((g + 1) * kGroup, n_tiles);
+            const unsigned long long hi = min(static_cast<unsigned long long>(t1) * kTileW,
+                                              static_cast<unsigned long long>(cnt));
+            if (r >= hi) continue;
+            const unsigned long long e = r > lo ? r - lo : 0; // <= T by construction
+            r = gtable[ch * gtable_stride + static_cast<size_t>(g) * (T + 1) + e];
+        }
+        const unsigned long long rnew = A0 + (r > cnt ? r : cnt);
+        st[ch].r = rnew > rabs ? rnew : rabs;
     }
-    const unsigned long long rnew = A0 + (r > cnt ? r : cnt);
-    st[ch].r = rnew > rabs ? rnew : rabs;
-}
-__global__ void k_tile_entries(uint32_t cnt, uint32_t T, uint32_t n_tiles, const uint32_t* __restrict__ table,
-                               size_t table_stride, const unsigned long long* __restrict__ gentry,
-                               uint32_t n_groups, int32_t* __restrict__ entry, int n_channels)
-{
-#ifndef GR4PM_NO_SETPRIO
-    __builtin_amdgcn_s_setprio(3); // latency-bound, few waves: win the issue arbitration against throughput kernels
-#endif
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n_groups * static_cast<uint32_t>(n_channels)) return;
-    const uint32_t ch = idx / n_groups, grp = idx % n_groups;
-    const uint32_t t0 = grp * kGroup, t1 = min(t0 + kGroup, n_tiles);
-    walk_tiles(gentry[ch * n_groups + grp], t0, t1, cnt, T, table + ch * table_stride, entry + ch * n_tiles);
+    __threadfence_block();
+    __syncthreads();
+    for (uint32_t grp = threadIdx.x; grp < n_groups; grp += blockDim.x) {
+        const uint32_t t0 = grp * kGroup, t1 = min(t0 + kGroup, n_tiles);
+        walk_tiles(ge[grp], t0, t1, cnt, T, table + ch * table_stride, entry + static_cast<size_t>(ch) * n_tiles);
+    }
 }
 
 // one wave per (tile, channel): redo the scan from the known entry and run the median test
@@ -874,12 +883,15 @@ __global__ __launch_bounds__(256) void k_tags_generic(const cf* __restrict__ in,
 
 // drop emitted detections (pos + hist < E1) from the pending list; one wave per channel
 __global__ __launch_bounds__(64) void k_compact_pending(ChanState* __restrict__ st,
+                                                        ChanState* __restrict__ st_host,
                                                         unsigned long long* __restrict__ det, uint32_t det_cap,
                                                         unsigned long long E1, uint32_t hist, int n_channels)
 {
     const int ch = blockIdx.x;
     if (ch >= n_channels) return;
     const int lane = threadIdx.x;
+    // the host's view of this call (record count, overflow flag) goes straight to pinned memory
+    if (lane == 0) st_host[ch] = st[ch];
     unsigned long long* d = det + static_cast<size_t>(ch) * det_cap;
     const uint32_t n = min(st[ch].det_cnt, det_cap);
     uint32_t w = 0;
@@ -895,7 +907,7 @@ __global__ __launch_bounds__(64) void k_compact_pending(ChanState* __restrict__ 
     }
     if (lane == 0) {
         st[ch].det_cnt = w;
-        st[ch].rec_cnt = 0; // the host copy of ChanState was queued before this kernel
+        st[ch].rec_cnt = 0; // the host copy of ChanState was written above
     }
 }
 
@@ -986,11 +998,13 @@ struct gr4pm_syncword_detection {
     bool generic = false;
     int log2n = 0;
     DevBuf<cf> g_tmpl, g_tw;
-    DevBuf<cf> carry[2];
-    DevBuf<float> z[2];
-    DevBuf<unsigned long long> bitmap;
-    DevBuf<uint32_t> table;
-    DevBuf<unsigned long long> gtable, gentry;
+    DevBuf<cf> carry[kCarry]; // sample carry before this call, before the calls ahead, and the one being written
+    DevBuf<float> z[kSets];
+    // candidate bitmap, tile tables and group tables exist kSets times like z[]: the look-ahead of
+    // the next calls fills the other sets while this call's scan still reads its own
+    DevBuf<unsigned long long> bitmap[kSets];
+    DevBuf<uint32_t> table[kSets];
+    DevBuf<unsigned long long> gtable[kSets], gentry;
     size_t gtable_stride = 0;
     uint32_t max_groups = 0;
     DevBuf<int32_t> entry;
@@ -1000,25 +1014,37 @@ struct gr4pm_syncword_detection {
     PinnedBuf<RawTag> rec_host; // written by k_tags through the device-visible mapping
     // stream position
     uint64_t items_consumed = 0;
-    int cur = 0;          // which of carry[]/z[] is current
+    int cur = 0;          // which of z[] / bitmap[] / table[] / gtable[] is current
+    int ci = 0;           // carry[ci] = the last xc items before items_consumed
     size_t last_done = 0; // items of the last call (for the z carry)
-    // look-ahead (gr4pm_syncword_detection_hint_next): the correlator of the NEXT call runs on a
-    // second stream while this call's detector kernels and tag read-back are in flight
-    hipStream_t stream2 = nullptr;
-    hipEvent_t ev_zcarry = nullptr, ev_corr = nullptr;
-    const gr4pm_c64* hint_in = nullptr; // announced input of the next call
-    size_t hint_stride = 0, hint_n = 0;
-    const gr4pm_c64* pre_in = nullptr;  // input whose powers are (being) written to z[cur ^ 1]
-    size_t pre_stride = 0, pre_n = 0;
-    bool pre_valid = false;
+    // look-ahead (gr4pm_syncword_detection_announce / _hint_next): the front part of the next
+    // kAhead calls (z carry, correlator, candidates, tables) runs on two more streams while this
+    // call's scan, tag kernels and read-back are in flight
+    hipStream_t stream2 = nullptr, stream3 = nullptr;
+    hipEvent_t ev_zcarry = nullptr, ev_mid[kSets] = {}, ev_front[kSets] = {};
+    struct Ahead {
+        const gr4pm_c64* in;
+        size_t stride, n;
+        uint64_t E0; // first item of that call
+        int set;     // buffer set its front writes
+    };
+    std::deque<Ahead> launched;  // fronts in flight or done, oldest first
+    std::deque<Ahead> announced; // inputs announced but not launched yet
     ~gr4pm_syncword_detection()
     {
         if (stream2) {
             (void)hipStreamSynchronize(stream2);
             (void)hipStreamDestroy(stream2);
         }
+        if (stream3) {
+            (void)hipStreamSynchronize(stream3);
+            (void)hipStreamDestroy(stream3);
+        }
+        for (auto e : ev_mid)
+            if (e) (void)hipEventDestroy(e);
+        for (auto e : ev_front)
+            if (e) (void)hipEventDestroy(e);
         if (ev_zcarry) (void)hipEventDestroy(ev_zcarry);
-        if (ev_corr) (void)hipEventDestroy(ev_corr);
     }
 };
 
@@ -1030,12 +1056,12 @@ gr4pm_status sd_reset(gr4pm_syncword_detection* h)
     h->cur = 0;
     h->last_done = 0;
     if (h->stream2) GR4PM_HIP_TRY(hipStreamSynchronize(h->stream2));
-    h->pre_valid = false;
-    h->hint_in = nullptr;
-    for (int i = 0; i < 2; ++i) {
-        GR4PM_TRY(h->carry[i].zero(h->stream));
-        GR4PM_TRY(h->z[i].zero(h->stream));
-    }
+    if (h->stream3) GR4PM_HIP_TRY(hipStreamSynchronize(h->stream3));
+    h->launched.clear();
+    h->announced.clear();
+    h->ci = 0;
+    for (int i = 0; i < kCarry; ++i) GR4PM_TRY(h->carry[i].zero(h->stream));
+    for (int i = 0; i < kSets; ++i) GR4PM_TRY(h->z[i].zero(h->stream));
     GR4PM_TRY(h->st.zero(h->stream));
     GR4PM_TRY(h->det.zero(h->stream));
     GR4PM_HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1106,6 +1132,75 @@ gr4pm_status launch_correlate(gr4pm_syncword_detection* h, hipStream_t stream, c
                        in_stride, n_blocks, static_cast<uint32_t>(h->S), h->n_bins, h->tmpl.p, tw1a, tw1b,
                        reinterpret_cast<const float4*>(twA), zout, h->z_stride);
     GR4PM_HIP_TRY(hipGetLastError());
+    return GR4PM_OK;
+}
+
+// everything of a call that does not depend on the scan state left by the call before it:
+// z carry (tail of the other z buffer), correlation powers, candidate bitmap, tile tables and
+// group tables, written to buffer set `which`.  `E0` = first item of the call, `n_prev` = items
+// of the call before it, carry[ci] = the samples before E0 (carry[ci + 1] is written).
+gr4pm_status launch_front(gr4pm_syncword_detection* h, hipStream_t stream, int which, int ci,
+                          const gr4pm_c64* in, size_t in_stride, size_t n_in, uint64_t E0, size_t n_prev)
+{
+    const uint32_t n_blocks = static_cast<uint32_t>((n_in - h->fft_size) / h->S + 1); // hpp:238
+    const size_t J = static_cast<size_t>(n_blocks) * h->S;
+    const uint64_t E1 = E0 + J;
+    const uint32_t T = static_cast<uint32_t>(h->T);
+    const unsigned nch = static_cast<unsigned>(h->n_channels);
+    float* zw = h->z[which].p;
+    // z carry: positions E0-zc .. E0-1; sample carry for the call after this one: the last xc
+    // items up to E1
+    hipLaunchKernelGGL(k_update_zcarry, dim3((h->zc + 255) / 256, nch), dim3(256), 0, stream,
+                       h->z[(which + kSets - 1) % kSets].p, zw, h->z_stride, h->zc, n_prev);
+    hipLaunchKernelGGL(k_update_carry, dim3((h->xc + 255) / 256, nch), dim3(256), 0, stream,
+                       reinterpret_cast<const cf*>(in), in_stride, h->carry[ci].p, h->carry[(ci + 1) % kCarry].p,
+                       static_cast<size_t>(h->xc), h->xc, J);
+    GR4PM_TRY(launch_correlate(h, stream, in, in_stride, n_blocks, zw + h->zc));
+    const bool ahead = stream != h->stream;
+    if (ahead) { // look-ahead: the candidate / table kernels run on their own stream
+        GR4PM_HIP_TRY(hipEventRecord(h->ev_mid[which], stream));
+        stream = h->stream3;
+        GR4PM_HIP_TRY(hipStreamWaitEvent(stream, h->ev_mid[which], 0));
+    }
+    const uint64_t A0 = E0 > T ? E0 - T : 0, A1 = E1 > T ? E1 - T : 0;
+    const uint32_t cnt = static_cast<uint32_t>(A1 - A0);
+    if (cnt == 0) {
+        if (ahead) GR4PM_HIP_TRY(hipEventRecord(h->ev_front[which], stream));
+        return GR4PM_OK;
+    }
+    const float* zloc = zw + h->zc - static_cast<ptrdiff_t>(E0 - A0);
+    const uint32_t n_wg = (cnt + kCandTile - 1) / kCandTile;
+    const size_t smem = (static_cast<size_t>(kCandBlocks + (T >> 6) + 2) * 65 + kCandBlocks) * sizeof(float);
+    hipLaunchKernelGGL(k_candidates, dim3(n_wg, nch), dim3(256), smem, stream, zloc, h->z_stride, cnt, T,
+                       h->bitmap[which].p, h->bm_stride);
+    const uint32_t n_tiles = (cnt + kTileW - 1) / kTileW;
+    hipLaunchKernelGGL(k_tile_tables, dim3(n_tiles, nch), dim3(64), 0, stream, h->bitmap[which].p, h->bm_stride,
+                       cnt, T, n_tiles, h->table[which].p, h->table_stride);
+    const uint32_t n_groups = (n_tiles + kGroup - 1) / kGroup;
+    hipLaunchKernelGGL(k_group_tables, dim3((T + 1 + 127) / 128, n_groups, nch), dim3(128), 0, stream, cnt, T,
+                       n_tiles, h->table[which].p, h->table_stride, h->gtable[which].p, h->gtable_stride);
+    GR4PM_HIP_TRY(hipGetLastError());
+    if (ahead) GR4PM_HIP_TRY(hipEventRecord(h->ev_front[which], stream));
+    return GR4PM_OK;
+}
+
+gr4pm_status ensure_ahead_streams(gr4pm_syncword_detection* h)
+{
+    if (h->stream2) return GR4PM_OK;
+    int least = 0, greatest = 0;
+    GR4PM_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    // correlator: lowest priority: look-ahead work yields to the current call's detector kernels,
+    // and a priority of its own also gives the stream a hardware queue of its own (streams of one
+    // priority share GPU_MAX_HW_QUEUES = 4 queues; a shared queue serialises its kernels)
+    GR4PM_HIP_TRY(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, least));
+    // the candidate / table kernels behind it are short and latency-bound and a later call waits
+    // for them: highest priority
+    GR4PM_HIP_TRY(hipStreamCreateWithPriority(&h->stream3, hipStreamNonBlocking, greatest));
+    GR4PM_HIP_TRY(hipEventCreateWithFlags(&h->ev_zcarry, hipEventDisableTiming));
+    for (int i = 0; i < kSets; ++i) {
+        GR4PM_HIP_TRY(hipEventCreateWithFlags(&h->ev_mid[i], hipEventDisableTiming));
+        GR4PM_HIP_TRY(hipEventCreateWithFlags(&h->ev_front[i], hipEventDisableTiming));
+    }
     return GR4PM_OK;
 }
 
@@ -1258,16 +1353,16 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
             ok(GR4PM_ERR_HIP);
         }
     }
-    for (int i = 0; i < 2; ++i) {
-        ok(h->carry[i].alloc(static_cast<size_t>(h->xc) * h->n_channels));
-        ok(h->z[i].alloc(h->z_stride * h->n_channels));
+    for (int i = 0; i < kCarry; ++i) ok(h->carry[i].alloc(static_cast<size_t>(h->xc) * h->n_channels));
+    for (int i = 0; i < kSets; ++i) ok(h->z[i].alloc(h->z_stride * h->n_channels));
+    for (int i = 0; i < kSets; ++i) {
+        ok(h->bitmap[i].alloc(h->bm_stride * h->n_channels));
+        ok(h->table[i].alloc(h->table_stride * h->n_channels));
     }
-    ok(h->bitmap.alloc(h->bm_stride * h->n_channels));
-    ok(h->table.alloc(h->table_stride * h->n_channels));
     ok(h->entry.alloc(static_cast<size_t>(h->max_tiles) * h->n_channels));
     h->max_groups = (h->max_tiles + kGroup - 1) / kGroup;
     h->gtable_stride = static_cast<size_t>(h->max_groups) * (h->T + 1);
-    ok(h->gtable.alloc(h->gtable_stride * h->n_channels));
+    for (int i = 0; i < kSets; ++i) ok(h->gtable[i].alloc(h->gtable_stride * h->n_channels));
     ok(h->gentry.alloc(static_cast<size_t>(h->max_groups) * h->n_channels));
     ok(h->st.alloc(h->n_channels));
     ok(h->det.alloc(static_cast<size_t>(h->det_cap) * h->n_channels));
@@ -1318,25 +1413,24 @@ gr4pm_status gr4pm_syncword_detection_correlate_only(gr4pm_syncword_detection* h
     return launch_correlate(h, h->stream, in, in_stride, n_blocks, h->z[h->cur].p + h->zc);
 }
 
+gr4pm_status gr4pm_syncword_detection_announce(gr4pm_syncword_detection* h, const gr4pm_c64* in,
+                                               size_t in_stride, size_t n_in)
+{
+    if (!h || !in) return GR4PM_ERR_INVALID;
+    GR4PM_TRY(ensure_ahead_streams(h));
+    // one launched front is consumed by the next call before a new one is launched
+    if (h->launched.size() + h->announced.size() < static_cast<size_t>(kAhead) + 1)
+        h->announced.push_back({ in, in_stride, n_in, 0, 0 });
+    return GR4PM_OK;
+}
+
 gr4pm_status gr4pm_syncword_detection_hint_next(gr4pm_syncword_detection* h, const gr4pm_c64* in_next,
                                                 size_t in_stride, size_t n_next)
 {
     if (!h) return GR4PM_ERR_INVALID;
-    if (in_next && !h->stream2) {
-        int least = 0, greatest = 0;
-        GR4PM_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        (void)greatest;
-        // lowest priority: look-ahead work yields to the current call's detector kernels, and a
-        // priority of its own also gives the stream a hardware queue of its own (streams of one
-        // priority share GPU_MAX_HW_QUEUES = 4 queues; a shared queue serialises its kernels)
-        GR4PM_HIP_TRY(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, least));
-        GR4PM_HIP_TRY(hipEventCreateWithFlags(&h->ev_zcarry, hipEventDisableTiming));
-        GR4PM_HIP_TRY(hipEventCreateWithFlags(&h->ev_corr, hipEventDisableTiming));
-    }
-    h->hint_in = in_next;
-    h->hint_stride = in_stride;
-    h->hint_n = n_next;
-    return GR4PM_OK;
+    h->announced.clear();
+    if (!in_next) return GR4PM_OK;
+    return gr4pm_syncword_detection_announce(h, in_next, in_stride, n_next);
 }
 
 gr4pm_status gr4pm_syncword_detection_process(gr4pm_syncword_detection* h, const gr4pm_c64* in,
@@ -1362,61 +1456,45 @@ gr4pm_status gr4pm_syncword_detection_process(gr4pm_syncword_detection* h, const
     const size_t J = static_cast<size_t>(n_blocks) * h->S;
     const uint64_t E0 = h->items_consumed, E1 = E0 + J;
     const uint32_t T = static_cast<uint32_t>(h->T);
-    const int cur = h->cur ^ 1, prev = h->cur; // ping-pong: this call writes `cur`
+    const int cur = (h->cur + 1) % kSets; // the buffer set of this call
     const unsigned nch = static_cast<unsigned>(h->n_channels);
     hipStream_t s = h->stream;
-    float* zcur = h->z[cur].p;        // [zc carry][J items] per channel
-    const cf* carry = h->carry[prev].p; // last xc items before E0
+    float* zcur = h->z[cur].p;          // [zc carry][J items] per channel
+    const cf* carry = h->carry[h->ci].p; // last xc items before E0
 
-    // z carry: positions E0-zc .. E0-1
-    hipLaunchKernelGGL(k_update_zcarry, dim3((h->zc + 255) / 256, nch), dim3(256), 0, s, h->z[prev].p,
-                       zcur, h->z_stride, h->zc, h->last_done);
-    // the correlation powers of this input may already be there (or on their way) from the
-    // look-ahead of the previous call; a look-ahead that does not match is waited for and dropped
-    bool have_z = false;
-    if (h->pre_valid) {
-        GR4PM_HIP_TRY(hipStreamWaitEvent(s, h->ev_corr, 0));
-        have_z = h->pre_in == in && h->pre_stride == in_stride && h->pre_n == n_in;
-        h->pre_valid = false;
+    // the front part of this call (z carry, correlation powers, candidate bitmap, tile and group
+    // tables) may already be there, or on its way, from the look-ahead of an earlier call; fronts
+    // that do not match this call are waited for and dropped
+    bool have_front = false;
+    if (!h->launched.empty()) {
+        const auto& a = h->launched.front();
+        if (a.in == in && a.stride == in_stride && a.n == n_in && a.E0 == E0 && a.set == cur) {
+            GR4PM_HIP_TRY(hipStreamWaitEvent(s, h->ev_front[cur], 0));
+            h->launched.pop_front();
+            have_front = true;
+        } else {
+            for (const auto& l : h->launched) GR4PM_HIP_TRY(hipStreamWaitEvent(s, h->ev_front[l.set], 0));
+            h->launched.clear();
+        }
     }
-    if (!have_z) GR4PM_TRY(launch_correlate(h, s, in, in_stride, n_blocks, zcur + h->zc));
-    if (h->hint_in && h->hint_n >= h->fft_size && h->hint_n <= h->max_items) {
-        // next call: writes z[prev] behind its carry; the only reader of z[prev] in this call is
-        // k_update_zcarry above
-        GR4PM_HIP_TRY(hipEventRecord(h->ev_zcarry, s));
-        GR4PM_HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_zcarry, 0));
-        const uint32_t nb_next = static_cast<uint32_t>((h->hint_n - h->fft_size) / h->S + 1);
-        GR4PM_TRY(launch_correlate(h, h->stream2, h->hint_in, h->hint_stride, nb_next, h->z[prev].p + h->zc));
-        GR4PM_HIP_TRY(hipEventRecord(h->ev_corr, h->stream2));
-        h->pre_in = h->hint_in;
-        h->pre_stride = h->hint_stride;
-        h->pre_n = h->hint_n;
-        h->pre_valid = true;
-    }
-    h->hint_in = nullptr;
+    if (!have_front) GR4PM_TRY(launch_front(h, s, cur, h->ci, in, in_stride, n_in, E0, h->last_done));
+    // fronts launched below read this call's z / sample carry: behind this call's front on the
+    // look-ahead stream already, or ordered by an event when the front was launched here
+    const bool order_by_event = !have_front && !h->announced.empty();
+    if (order_by_event) GR4PM_HIP_TRY(hipEventRecord(h->ev_zcarry, s));
 
-    // detector over candidate range [A0, A1)
+    // the serial part of the detector over candidate range [A0, A1)
     const uint64_t A0 = E0 > T ? E0 - T : 0, A1 = E1 > T ? E1 - T : 0;
     const uint32_t cnt = static_cast<uint32_t>(A1 - A0);
     // local position 0 <-> absolute A0 <-> zcur[zc + (A0 - E0)]
     const float* zloc = zcur + h->zc - static_cast<ptrdiff_t>(E0 - A0);
     if (cnt > 0) {
-        const uint32_t n_wg = (cnt + kCandTile - 1) / kCandTile;
-        const size_t smem = (static_cast<size_t>(kCandBlocks + (T >> 6) + 2) * 65 + kCandBlocks) * sizeof(float);
-        hipLaunchKernelGGL(k_candidates, dim3(n_wg, nch), dim3(256), smem, s, zloc, h->z_stride, cnt, T,
-                           h->bitmap.p, h->bm_stride);
         const uint32_t n_tiles = (cnt + kTileW - 1) / kTileW;
-        hipLaunchKernelGGL(k_tile_tables, dim3(n_tiles, nch), dim3(64), 0, s, h->bitmap.p, h->bm_stride, cnt, T,
-                           n_tiles, h->table.p, h->table_stride);
         const uint32_t n_groups = (n_tiles + kGroup - 1) / kGroup;
-        hipLaunchKernelGGL(k_group_tables, dim3((T + 1 + 127) / 128, n_groups, nch), dim3(128), 0, s, cnt, T,
-                           n_tiles, h->table.p, h->table_stride, h->gtable.p, h->gtable_stride);
-        hipLaunchKernelGGL(k_group_walk, dim3((nch + 63) / 64), dim3(64), 0, s, h->st.p,
-                           static_cast<unsigned long long>(A0), cnt, T, n_tiles, h->gtable.p, h->gtable_stride,
-                           h->gentry.p, n_groups, static_cast<int>(nch));
-        hipLaunchKernelGGL(k_tile_entries, dim3((n_groups * nch + 63) / 64), dim3(64), 0, s, cnt, T, n_tiles,
-                           h->table.p, h->table_stride, h->gentry.p, n_groups, h->entry.p, static_cast<int>(nch));
-        hipLaunchKernelGGL(k_tile_detect, dim3(n_tiles, nch), dim3(64), 0, s, h->bitmap.p, h->bm_stride,
+        hipLaunchKernelGGL(k_scan_entries, dim3(nch), dim3(256), 0, s, h->st.p, static_cast<unsigned long long>(A0),
+                           cnt, T, n_tiles, h->table[cur].p, h->table_stride, h->gtable[cur].p, h->gtable_stride,
+                           h->gentry.p, n_groups, h->entry.p);
+        hipLaunchKernelGGL(k_tile_detect, dim3(n_tiles, nch), dim3(64), 0, s, h->bitmap[cur].p, h->bm_stride,
                            zloc, h->z_stride, static_cast<unsigned long long>(A0), cnt, T,
                            h->power_threshold, n_tiles, h->entry.p, h->st.p, h->det.p, h->det_cap);
     }
@@ -1439,8 +1517,7 @@ gr4pm_status gr4pm_syncword_detection_process(gr4pm_syncword_detection* h, const
                        h->tw.p, h->tw.p + kTw1aItems, h->tw.p + kTw1aItems + kTw1bItems,
                        h->tw.p + kTw1aItems + kTw1bItems + kTwAItems, zcur + h->zc, h->z_stride, h->st.p,
                        h->det.p, h->det_cap, h->rec_host.p, h->rec_cap);
-    GR4PM_HIP_TRY(hipMemcpyAsync(h->st_host.p, h->st.p, sizeof(ChanState) * nch, hipMemcpyDeviceToHost, s));
-    hipLaunchKernelGGL(k_compact_pending, dim3(nch), dim3(64), 0, s, h->st.p, h->det.p,
+    hipLaunchKernelGGL(k_compact_pending, dim3(nch), dim3(64), 0, s, h->st.p, h->st_host.p, h->det.p,
                        h->det_cap, static_cast<unsigned long long>(E1), static_cast<uint32_t>(h->hist),
                        static_cast<int>(nch));
     if (out) {
@@ -1449,10 +1526,43 @@ gr4pm_status gr4pm_syncword_detection_process(gr4pm_syncword_detection* h, const
                            in_stride, carry, static_cast<size_t>(h->xc), h->xc,
                            static_cast<uint32_t>(h->hist), J, reinterpret_cast<cf*>(out), out_stride);
     }
-    hipLaunchKernelGGL(k_update_carry, dim3((h->xc + 255) / 256, nch), dim3(256), 0, s,
-                       reinterpret_cast<const cf*>(in), in_stride, carry, h->carry[cur].p,
-                       static_cast<size_t>(h->xc), h->xc, J);
     GR4PM_HIP_TRY(hipGetLastError());
+    // fronts of the announced calls, queued after this call's own kernels (they are the critical
+    // path).  A front writes the buffer set of a call that has completed (every call ends with a
+    // host-side wait) and reads the set / sample carry of the call before it, which is ahead of it
+    // on the same stream.
+    {
+        uint64_t e0 = E1;
+        size_t j_prev = J;
+        int set = cur, c = h->ci;
+        for (const auto& l : h->launched) {
+            const size_t nb = (l.n - h->fft_size) / h->S + 1;
+            e0 = l.E0 + nb * h->S;
+            j_prev = nb * h->S;
+            set = l.set;
+            c = (c + 1) % kCarry;
+        }
+        bool first = true;
+        while (!h->announced.empty() && h->launched.size() < static_cast<size_t>(kAhead)) {
+            auto a = h->announced.front();
+            h->announced.pop_front();
+            if (a.n < h->fft_size || a.n > h->max_items) { // not a call this handle can run: no look-ahead
+                h->announced.clear();
+                break;
+            }
+            if (first && order_by_event) GR4PM_HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_zcarry, 0));
+            first = false;
+            set = (set + 1) % kSets;
+            c = (c + 1) % kCarry;
+            a.E0 = e0;
+            a.set = set;
+            GR4PM_TRY(launch_front(h, h->stream2, set, c, a.in, a.stride, a.n, e0, j_prev));
+            h->launched.push_back(a);
+            const size_t nb = (a.n - h->fft_size) / h->S + 1;
+            e0 += nb * h->S;
+            j_prev = nb * h->S;
+        }
+    }
 #ifdef GR4PM_TIMING
     const auto tp1 = std::chrono::steady_clock::now();
 #endif
@@ -1474,6 +1584,7 @@ gr4pm_status gr4pm_syncword_detection_process(gr4pm_syncword_detection* h, const
 #endif
     h->items_consumed = E1;
     h->cur = cur;
+    h->ci = (h->ci + 1) % kCarry;
     h->last_done = J;
     *n_done = J;
     if (overflow) {
@@ -1503,9 +1614,11 @@ gr4pm_status gr4pm_syncword_detection_process(gr4pm_syncword_detection* h, const
         t_acc[1] += us(tp1, tp2);
         t_acc[2] += us(tp2, tp3);
         t_acc[3] += us(tp3, tp4);
-        if (++t_calls % 8 == 0)
-            fprintf(stderr, "[gr4pm timing] launch %.0f us, sync %.0f us, records %.0f us, finish %.0f us (mean of %d)\n",
-                    t_acc[0] / t_calls, t_acc[1] / t_calls, t_acc[2] / t_calls, t_acc[3] / t_calls, t_calls);
+        if (++t_calls % 8 == 0) {
+            fprintf(stderr, "[gr4pm timing] launch %.0f us, sync %.0f us, records %.0f us, finish %.0f us (mean of the last 8)\n",
+                    t_acc[0] / 8, t_acc[1] / 8, t_acc[2] / 8, t_acc[3] / 8);
+            t_acc[0] = t_acc[1] = t_acc[2] = t_acc[3] = 0;
+        }
     }
 #endif
     return ret;

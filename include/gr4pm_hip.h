@@ -118,12 +118,20 @@ gr4pm_status gr4pm_syncword_detection_process(gr4pm_syncword_detection* h, const
                                               size_t out_stride, size_t* n_done, gr4pm_tag* tags,
                                               size_t tags_cap, size_t* n_tags);
 /* Optional look-ahead for callers that own a device ring (no reference counterpart: the
- * reference's scheduler overlaps blocks across worker threads instead).  Announces the input
- * of the call AFTER the next process(): that process() then also launches the correlator for
- * `in_next` on a second stream, where it overlaps the detector kernels and the tag read-back,
- * and the following process(in_next, in_stride, n_next) finds its correlation powers ready.
- * The items must not change between the two calls.  A following call with other arguments
- * simply recomputes; results are identical either way.  in_next == NULL clears the hint. */
+ * reference's scheduler overlaps blocks across worker threads instead).  _announce names the
+ * input of a future call: the one after the next process() and after the calls already
+ * announced (at most GR4PM_SD_LOOKAHEAD = 2 calls ahead are kept; further announcements are
+ * ignored).  The next process() then also launches, on two more streams, everything of the
+ * announced calls that does not depend on the scan state of the calls before them (z carry,
+ * correlator, candidate bitmap, tile / group tables), where it overlaps this call's scan, tag
+ * kernels and read-back; the later process(in, in_stride, n_in) with exactly the announced
+ * arguments finds that work done.  The items must not change between the announcement and
+ * their call.  A call with other arguments drops the look-ahead and recomputes; results are
+ * identical either way.  _hint_next is the one-call form: it replaces every announcement not
+ * yet launched (in_next == NULL: just clears them). */
+#define GR4PM_SD_LOOKAHEAD 2
+gr4pm_status gr4pm_syncword_detection_announce(gr4pm_syncword_detection* h, const gr4pm_c64* in,
+                                               size_t in_stride, size_t n_in);
 gr4pm_status gr4pm_syncword_detection_hint_next(gr4pm_syncword_detection* h,
                                                 const gr4pm_c64* in_next, size_t in_stride,
                                                 size_t n_next);
@@ -241,6 +249,7 @@ gr4pm_status gr4pm_syncword_wipeoff_create(const gr4pm_syncword_wipeoff_params* 
                                            gr4pm_syncword_wipeoff** out);
 void gr4pm_syncword_wipeoff_destroy(gr4pm_syncword_wipeoff* h);
 gr4pm_status gr4pm_syncword_wipeoff_reset(gr4pm_syncword_wipeoff* h);
+/* `out` may be `in` (in place: only the syncword items are touched, no copy) */
 gr4pm_status gr4pm_syncword_wipeoff_process(gr4pm_syncword_wipeoff* h, const gr4pm_c64* in,
                                             size_t n, gr4pm_c64* out, const gr4pm_tag* tags,
                                             size_t n_tags);
@@ -300,6 +309,19 @@ gr4pm_status gr4pm_cfc_symbol_filter_process(gr4pm_rotator* cfc, gr4pm_symbol_fi
                                              size_t out_cap, const gr4pm_tag* tags_in, size_t n_tags_in,
                                              gr4pm_tag* tags_out, size_t tags_cap, size_t* n_tags_out,
                                              size_t* consumed, size_t* produced);
+/* The same call in two halves, for callers that pipeline them (the native PacketReceiver runs
+ * them as two stages): _plan replays the CFC's tag handling and computes the phasor checkpoints
+ * of the call on the CFC's stream (the serial part), _run is the filter itself on the
+ * SymbolFilter's stream.  The caller orders them (a _run after its _plan has completed; plans
+ * and runs each in stream order); two plans exist, so the plan of call n+1 may be made while
+ * the run of call n is still in flight.  `plan` is the value _plan returned. */
+gr4pm_status gr4pm_cfc_symbol_filter_plan(gr4pm_rotator* cfc, size_t n_in, const gr4pm_tag* tags_in,
+                                          size_t n_tags_in, int* plan);
+gr4pm_status gr4pm_cfc_symbol_filter_run(gr4pm_rotator* cfc, int plan, gr4pm_symbol_filter* sf,
+                                         const gr4pm_c64* in, size_t n_in, gr4pm_c64* out,
+                                         size_t out_cap, const gr4pm_tag* tags_in, size_t n_tags_in,
+                                         gr4pm_tag* tags_out, size_t tags_cap, size_t* n_tags_out,
+                                         size_t* consumed, size_t* produced);
 
 /* ------------------------------------------------------------------------------------
  * PfbArbResampler<c64,c64,float,TRate> -- pfb_arb_resampler.hpp:23-183
@@ -617,6 +639,10 @@ gr4pm_status gr4pm_packet_receiver_submit(gr4pm_packet_receiver* h, const gr4pm_
                                           size_t next_n, uint64_t packet_length, gr4pm_c64* out_symbols,
                                           size_t out_cap, float* out_llr, size_t llr_cap, uint8_t* out_packets,
                                           size_t packets_cap);
+/* names the input of a later submit (after the ones already announced): forwarded to the
+ * detector's look-ahead, gr4pm_syncword_detection_announce; next_in of _submit is the one-call
+ * form (gr4pm_syncword_detection_hint_next) */
+gr4pm_status gr4pm_packet_receiver_announce(gr4pm_packet_receiver* h, const gr4pm_c64* in, size_t n_in);
 /* waits for the oldest batch; returns its status (the error text of a failed stage included) */
 gr4pm_status gr4pm_packet_receiver_collect(gr4pm_packet_receiver* h, gr4pm_packet_receiver_result* result);
 size_t gr4pm_packet_receiver_inflight(const gr4pm_packet_receiver* h);
