@@ -12,7 +12,8 @@ from ._abi import (EXPORTS, LIB_PATH, PACKET_TAG_DTYPE, PKT_HEADER_START, PKT_PA
 from .blocks import (SYNCWORD, AdditiveScrambler, BurstGenerator, CrcCheck, burst_shaper, mapper, binary_slicer, pack_bits, slice_pack, CoarseFrequencyCorrection, ConstellationLLRDecoder,  # noqa: F401
                      CostasLoop, HeaderDecoder, HeaderFecDecoder, HeaderPayloadSplit, InterpolatingFirFilter, NativePacketReceiver, PacketReceiver,
                      PayloadMetadataInsert, PfbArbResampler, Rotator, SymbolFilter, SyncwordDetection,
-                     SyncwordDetectionFilter, SyncwordRemove, SyncwordWipeoff, cfc_symbol_filter, header_ldpc_alist,
+                     SyncwordDetectionFilter, SyncwordRemove, SyncwordWipeoff, cfc_symbol_filter, cfc_symbol_filter_plan, cfc_symbol_filter_run,
+                     header_ldpc_alist,
                      header_parse, root_raised_cosine)
 
 _DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")

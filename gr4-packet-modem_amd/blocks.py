@@ -377,10 +377,11 @@ class SyncwordWipeoff:
         self._h = C.c_void_p()
         check(lib().gr4pm_syncword_wipeoff_create(C.byref(p), C.byref(self._h)), "SyncwordWipeoff")
 
-    def process_bulk(self, x, tags=None):
+    def process_bulk(self, x, tags=None, in_place=False):
+        """in_place: the syncword items of x itself are multiplied, nothing is copied (x is returned)"""
         torch = _torch()
         x = _dev_c64(x)
-        out = torch.empty_like(x)
+        out = x if in_place else torch.empty_like(x)
         t = _tags_array(tags)
         check(lib().gr4pm_syncword_wipeoff_process(self._h, x.data_ptr(), x.numel(), out.data_ptr(), _np_ptr(t),
                                                    t.size), "SyncwordWipeoff.processBulk")
@@ -720,6 +721,32 @@ def cfc_symbol_filter(cfc, symf, x, tags=None, out_cap=None):
     check(lib().gr4pm_cfc_symbol_filter_process(cfc._h, symf._h, x.data_ptr(), x.numel(), out.data_ptr(), out_cap,
                                                 _np_ptr(t), t.size, _np_ptr(tout), tout.size, C.byref(nto),
                                                 C.byref(cons), C.byref(prod)), "cfc_symbol_filter")
+    return out[: prod.value], tout[: nto.value].copy(), cons.value
+
+
+def cfc_symbol_filter_plan(cfc, n_in, tags=None):
+    """first half of cfc_symbol_filter (gr4pm_cfc_symbol_filter_plan): the CFC's tag handling and the
+    phasor checkpoints of a call of n_in items; returns the plan id for cfc_symbol_filter_run"""
+    t = _tags_array(tags)
+    plan = C.c_int(-1)
+    check(lib().gr4pm_cfc_symbol_filter_plan(cfc._h, n_in, _np_ptr(t), t.size, C.byref(plan)), "cfc_symbol_filter_plan")
+    return plan.value
+
+
+def cfc_symbol_filter_run(cfc, plan, symf, x, tags=None, out_cap=None):
+    """second half (gr4pm_cfc_symbol_filter_run): the filter itself, on the SymbolFilter's stream;
+    the caller makes sure the plan has completed.  Returns (symbols, tags_out, consumed)."""
+    torch = _torch()
+    x = _dev_c64(x)
+    t = _tags_array(tags)
+    if out_cap is None:
+        out_cap = x.numel() // symf.samples_per_symbol + t.size + 2
+    out = torch.empty(max(out_cap, 1), dtype=x.dtype, device=x.device)
+    tout = np.zeros(t.size + 64, dtype=TAG_DTYPE)
+    nto, cons, prod = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+    check(lib().gr4pm_cfc_symbol_filter_run(cfc._h, plan, symf._h, x.data_ptr(), x.numel(), out.data_ptr(), out_cap,
+                                            _np_ptr(t), t.size, _np_ptr(tout), tout.size, C.byref(nto),
+                                            C.byref(cons), C.byref(prod)), "cfc_symbol_filter_run")
     return out[: prod.value], tout[: nto.value].copy(), cons.value
 
 

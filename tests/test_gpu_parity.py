@@ -164,6 +164,59 @@ def test_syncword_detection_lookahead_matches_plain_calls(pkg):
     assert n == n2_ and np.array_equal(bits(host(o)), bits(host(o2))) and same_tags(t, t2)
 
 
+def test_syncword_detection_announced_two_calls_ahead(pkg):
+    """gr4pm_syncword_detection_announce: fronts of up to two future calls in flight (right ones,
+    a wrong one in the middle, more announcements than are kept) never change out/tags"""
+    locations = [100, 1000, 1250, 10000, 13721, 43124, 58000 - 64, 70000, 90500, 118000]
+    x, rrc = sig.qa_syncword_stream(125000, locations, -0.004, seed=6)
+    ref = orc.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, power_threshold=20.0)
+    _, ref_out, ref_tags = ref.process(x)
+    plain = pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, power_threshold=20.0, max_items=1 << 16)
+    ahead = pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, power_threshold=20.0, max_items=1 << 16)
+    xd = dev(x)
+    S = 2048 - 297 + 1
+    rng = np.random.default_rng(12)
+    chunks, pos = [], 0
+    while pos + 2048 <= x.size:
+        n_req = min(int(rng.integers(2048, 12000)), x.size - pos)
+        chunks.append((pos, n_req))
+        pos += ((n_req - 2048) // S + 1) * S
+    assert len(chunks) > 16
+    outs, all_tags = [], []
+    announced = 0    # chunks up to this index have been announced
+    quiet_until = 0  # no announcements before this call
+    for i, (pos, n_req) in enumerate(chunks):
+        if i == 9:
+            # a wrong announcement: launched as the front of call 11, dropped there
+            ahead.announce(xd[chunks[11][0] + 16:chunks[11][0] + 16 + 4096])
+            quiet_until = 12
+        elif i == 15:
+            # more announcements than are kept: only the first one fits, the others are ignored
+            for k in range(announced + 1, min(announced + 5, len(chunks))):
+                ahead.announce(xd[chunks[k][0]:chunks[k][0] + chunks[k][1]])
+            quiet_until = 20
+        elif i >= quiet_until:
+            announced = max(announced, i)
+            while announced < min(i + 2, len(chunks) - 1):
+                announced += 1
+                p2, n2 = chunks[announced]
+                ahead.announce(xd[p2:p2 + n2])
+        st, o, t, n = ahead.process_bulk(xd[pos:pos + n_req])
+        st2, o2, t2, n2_ = plain.process_bulk(xd[pos:pos + n_req])
+        assert st == 0 and n == n2_ and n > 0
+        assert np.array_equal(bits(host(o)), bits(host(o2))), i
+        assert same_tags(t, t2), i
+        t = t.copy()
+        t["index"] += pos
+        outs.append(host(o))
+        all_tags.append(t)
+    out = np.concatenate(outs)
+    tags = np.concatenate(all_tags)
+    assert np.array_equal(bits(out), bits(ref_out[: out.size]))
+    assert tags.size >= 9
+    assert_tags_match(tags, ref_tags[: tags.size])
+
+
 def test_syncword_detection_awgn_threshold_and_noise_only(pkg):
     """default threshold 9.5, bursts in AWGN: same detections (incl. none on noise) as the oracle"""
     rng = np.random.default_rng(77)
@@ -881,6 +934,64 @@ def test_fused_cfc_symbol_filter_equals_separate_blocks(pkg):
     z = orc.coarse_frequency_correction(x, tags["index"], tags["freq"], delay=26)
     want, want_tags, _ = orc.symbol_filter(z, pfb, 32, 4, 44, tags=tags.astype(orc.TAG_DTYPE))
     assert np.array_equal(bits(yb), bits(want)) and np.array_equal(tb["index"], want_tags["index"])
+
+
+def test_cfc_symbol_filter_plan_then_run_equals_fused_call(pkg):
+    """gr4pm_cfc_symbol_filter_plan + _run (the two pipeline stages of the native receiver) ==
+    gr4pm_cfc_symbol_filter_process, bit for bit, also when the plan of the next call is made
+    before the run of the current one (two plans exist)"""
+    rrc, pfb = _receiver_pfb()
+    rng = np.random.default_rng(78)
+    n = 48000
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    idx = np.array([3, 5000, 9990, 10010, 17000, 17003, 25000, 39990, 47990], dtype=np.uint64)
+    tags = np.zeros(idx.size, dtype=pkg.TAG_DTYPE)
+    tags["index"] = idx
+    tags["amplitude"] = rng.uniform(0.5, 2.0, idx.size)
+    tags["time_est"] = rng.uniform(-0.5, 0.5, idx.size)
+    tags["phase"] = rng.uniform(-3, 3, idx.size)
+    tags["freq"] = rng.uniform(-0.03, 0.03, idx.size)
+    tags["flags"] = pkg.TAG_SYNCWORD
+    cuts = [0, 10000, 10001, 26000, 40000, n]
+    a_cfc, a_sf = pkg.CoarseFrequencyCorrection(26), pkg.SymbolFilter(pfb, 32, 4, 44)
+    b_cfc, b_sf = pkg.CoarseFrequencyCorrection(26), pkg.SymbolFilter(pfb, 32, 4, 44)
+    pieces = []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        t = tags[(tags["index"] >= lo) & (tags["index"] < hi)].copy()
+        t["index"] -= lo
+        pieces.append((dev(x[lo:hi]), t))
+    want = [pkg.cfc_symbol_filter(a_cfc, a_sf, xd, t) for xd, t in pieces]
+    # software pipeline: plan(k + 1) is issued before run(k)
+    got = []
+    plan = pkg.cfc_symbol_filter_plan(b_cfc, pieces[0][0].numel(), pieces[0][1])
+    for k, (xd, t) in enumerate(pieces):
+        nxt = None
+        if k + 1 < len(pieces):
+            nxt = pkg.cfc_symbol_filter_plan(b_cfc, pieces[k + 1][0].numel(), pieces[k + 1][1])
+        got.append(pkg.cfc_symbol_filter_run(b_cfc, plan, b_sf, xd, t))
+        plan = nxt
+    for (ya, ta, ca), (yb, tb, cb) in zip(want, got):
+        assert ca == cb and np.array_equal(bits(host(ya)), bits(host(yb))) and np.array_equal(ta, tb)
+    # a run without its plan is refused
+    with pytest.raises(pkg.Gr4pmError):
+        pkg.cfc_symbol_filter_run(b_cfc, 0, b_sf, dev(x[:1234]), None)
+
+
+def test_syncword_wipeoff_in_place(pkg):
+    """out == in: only the syncword items are touched, same result as the copying call"""
+    rng = np.random.default_rng(5)
+    n = 5000
+    v = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    bipolar = np.where(sig.SYNCWORD == 1, -1.0, 1.0).astype(np.float32)
+    tags = np.zeros(4, dtype=pkg.TAG_DTYPE)
+    tags["index"], tags["flags"] = [10, 100, 2250, 4980], pkg.TAG_SYNCWORD  # the last one continues in the next call
+    a, b = pkg.SyncwordWipeoff(bipolar), pkg.SyncwordWipeoff(bipolar)
+    for piece, t in ((v[:n], tags), (v[:300], None)):
+        ya = host(a.process_bulk(dev(piece), t))
+        xb = dev(piece).clone()
+        yb = b.process_bulk(xb, t, in_place=True)
+        assert yb.data_ptr() == xb.data_ptr()
+        assert np.array_equal(bits(ya), bits(host(yb)))
 
 
 # ------------------------------------------------------------------ SURVEY 8(f) rank 1:
