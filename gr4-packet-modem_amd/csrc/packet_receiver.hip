@@ -23,7 +23,7 @@ using namespace gr4pm;
 
 namespace {
 
-constexpr int kSlots = 6; // detector | stage 1 | stage 1b | stage 2 | stage 3 (decode_headers) | held by the caller
+constexpr int kSlots = 7; // detector | pass A (decode_headers) | stage 1 | stage 1b | stage 2 | stage 3 (decode_headers) | held by the caller
 
 struct Slot {
     // inputs of the batch
@@ -36,6 +36,12 @@ struct Slot {
     size_t llr_cap = 0;
     uint64_t packet_length = 0; // parsed_header answer for every packet (0: "invalid_header")
     int plan = -1;              // rotation plan made by stage 1, used by stage 1b
+    // decode_headers, pass A -> stage 1: per detection of this batch, the header pass A decoded for
+    // it ({0, 1} when none) or invalid_header == 2 while its window is still on its way; and every
+    // header pass A finished during this batch (sorted by detection index), for detections of
+    // earlier batches that were still pending when the gate saw them
+    std::vector<gr4pm_header_msg> pre_msgs;
+    std::vector<std::pair<uint64_t, gr4pm_header_msg>> newly_known;
     // products
     gr4pm_status status = GR4PM_OK;
     char error[256] = { 0 };
@@ -217,10 +223,11 @@ struct StageClock { const char* name; };
 #endif
 
 struct gr4pm_packet_receiver {
-    StageClock clk[5] = { { "stage 0" }, { "stage 1" }, { "stage 2" }, { "stage 3" }, { "stage 1b" } };
+    StageClock clk[6] = { { "stage 0" }, { "stage 1" }, { "stage 2" }, { "stage 3" }, { "stage 1b" }, { "stage A" } };
     gr4pm_packet_receiver_params p;
-    // [3]: header loop + payload tail (stage 3); [4]: symbol filter + wipe-off (stage 1b)
-    hipStream_t streams[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
+    // [3]: header loop + payload tail (stage 3); [4]: symbol filter + wipe-off (stage 1b);
+    // [5]: pass A of decode_headers (stage A)
+    hipStream_t streams[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     gr4pm_syncword_detection* sd = nullptr;
     gr4pm_syncword_detection_filter* sdf = nullptr;
     gr4pm_rotator* cfc = nullptr;
@@ -250,7 +257,6 @@ struct gr4pm_packet_receiver {
     std::vector<gr4pm_tag> awaiting_tags;
     std::deque<uint64_t> a_order;           // detections inside pass A whose header is not out yet
     size_t a_fifo = 0;                      // invalid messages owed to pass A's PayloadMetadataInsert
-    std::vector<std::pair<uint64_t, gr4pm_header_msg>> known; // decoded headers by detection index
     bool pending_real = false;              // an accepted packet waits for its header
     uint64_t pending_idx = 0;
     std::deque<gr4pm_header_msg> s1_fifo;   // accepted tags' messages on their way to stage 2
@@ -262,8 +268,8 @@ struct gr4pm_packet_receiver {
     std::deque<uint64_t> payload_bits;      // their lengths
     DevBuf<uint8_t> packed;
     Slot slots[kSlots];
-    Channel<int> free_slots, to_stage1, to_stage1b, to_stage2, to_stage3, done;
-    std::thread workers[4];
+    Channel<int> free_slots, to_stageA, to_stage1, to_stage1b, to_stage2, to_stage3, done;
+    std::thread workers[5];
     int held = -1; // slot whose result the caller is looking at
     size_t inflight = 0;
 
@@ -273,6 +279,7 @@ struct gr4pm_packet_receiver {
         std::strncpy(s.error, gr4pm_last_error(), sizeof(s.error) - 1);
     }
     void stage0(Slot& s, const gr4pm_c64* next_in, size_t next_n);
+    void stageA(Slot& s);
     void stage1(Slot& s);
     void stage1b(Slot& s);
     void stage2(Slot& s);
@@ -305,6 +312,14 @@ void gr4pm_packet_receiver::stage0(Slot& s, const gr4pm_c64* next_in, size_t nex
     s.consumed = n_done;
     s.n_det = n_tags;
     s.base = gr4pm_syncword_detection_items_consumed(sd) - n_done;
+}
+
+// Stage A (decode_headers only): pass A of the two-pass header loop, one batch ahead of the gate
+void gr4pm_packet_receiver::stageA(Slot& s)
+{
+    if (s.status != GR4PM_OK || !p.decode_headers) return;
+    const gr4pm_status st = predecode(s, s.delayed ? s.delayed : s.y.p);
+    if (st != GR4PM_OK) fail(s, st);
 }
 
 // Stages 1-3 run with deferred synchronisation (gr4pm_set_deferred_sync): the blocks of a stage
@@ -442,7 +457,8 @@ void gr4pm_packet_receiver::stage2(Slot& s)
 // pass A (see blocks.py PacketReceiver._predecode, which this mirrors): the header of every detection
 gr4pm_status gr4pm_packet_receiver::predecode(Slot& s, const gr4pm_c64* y)
 {
-    hipStream_t st1 = streams[1];
+    hipStream_t st1 = streams[5];
+    s.newly_known.clear();
     const long long n = static_cast<long long>(s.consumed);
     std::vector<long long> starts;
     std::vector<gr4pm_tag> tags;
@@ -511,10 +527,22 @@ gr4pm_status gr4pm_packet_receiver::predecode(Slot& s, const gr4pm_c64* y)
         for (uint64_t o : order) a_order.push_back(o);
         for (const auto& m : done) {
             if (a_order.empty()) break;
-            known.emplace_back(a_order.front(), m);
+            s.newly_known.emplace_back(a_order.front(), m);
             a_order.pop_front();
         }
-        std::sort(known.begin(), known.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+        std::sort(s.newly_known.begin(), s.newly_known.end(),
+                  [](const auto& a, const auto& b) { return a.first < b.first; });
+    }
+    // what stage 1 will want to know about this batch's own detections
+    s.pre_msgs.assign(std::max<size_t>(s.n_det, 1), gr4pm_header_msg{ 0, 1 });
+    for (size_t i = 0; i < s.n_det; ++i) {
+        const uint64_t idx = s.base + s.det_tags[i].index;
+        auto it = std::lower_bound(s.newly_known.begin(), s.newly_known.end(), idx,
+                                   [](const auto& a, uint64_t v) { return a.first < v; });
+        if (it != s.newly_known.end() && it->first == idx) s.pre_msgs[i] = it->second;
+        else if (std::find(awaiting_idx.begin(), awaiting_idx.end(), idx) != awaiting_idx.end() ||
+                 std::find(a_order.begin(), a_order.end(), idx) != a_order.end())
+            s.pre_msgs[i].invalid_header = 2;
     }
     if (n >= static_cast<long long>(tail_len))
         GR4PM_HIP_TRY(hipMemcpyAsync(a_tail.p, y + (n - tail_len), tail_len * sizeof(gr4pm_c64), hipMemcpyDeviceToDevice,
@@ -525,10 +553,11 @@ gr4pm_status gr4pm_packet_receiver::predecode(Slot& s, const gr4pm_c64* y)
 
 gr4pm_status gr4pm_packet_receiver::stage1_decode(Slot& s, const gr4pm_c64* y)
 {
-    GR4PM_TRY(predecode(s, y));
+    (void)y;
     auto lookup = [&](uint64_t idx) -> const gr4pm_header_msg* {
-        auto it = std::lower_bound(known.begin(), known.end(), idx, [](const auto& a, uint64_t v) { return a.first < v; });
-        return it != known.end() && it->first == idx ? &it->second : nullptr;
+        auto it = std::lower_bound(s.newly_known.begin(), s.newly_known.end(), idx,
+                                   [](const auto& a, uint64_t v) { return a.first < v; });
+        return it != s.newly_known.end() && it->first == idx ? &it->second : nullptr;
     };
     s.has_resolve = false;
     if (pending_real)
@@ -550,14 +579,8 @@ gr4pm_status gr4pm_packet_receiver::stage1_decode(Slot& s, const gr4pm_c64* y)
         }
     // per-tag messages: decoded / still on its way (2)
     std::vector<uint64_t> idx(s.n_det);
-    s.msgs.assign(std::max<size_t>(s.n_det, 1), gr4pm_header_msg{ 0, 1 });
-    for (size_t i = 0; i < s.n_det; ++i) {
-        idx[i] = s.base + s.det_tags[i].index;
-        if (const gr4pm_header_msg* m = lookup(idx[i])) s.msgs[i] = *m;
-        else if (std::find(awaiting_idx.begin(), awaiting_idx.end(), idx[i]) != awaiting_idx.end() ||
-                 std::find(a_order.begin(), a_order.end(), idx[i]) != a_order.end())
-            s.msgs[i].invalid_header = 2;
-    }
+    s.msgs = s.pre_msgs;
+    for (size_t i = 0; i < s.n_det; ++i) idx[i] = s.base + s.det_tags[i].index;
     s.accepted.assign(std::max<size_t>(s.n_det, 1), 0);
     size_t used = 0;
     GR4PM_TRY(gr4pm_syncword_detection_filter_gate(sdf, idx.data(), s.n_det, s.msgs.data(), s.n_det, 1,
@@ -574,9 +597,6 @@ gr4pm_status gr4pm_packet_receiver::stage1_decode(Slot& s, const gr4pm_c64* y)
             }
         }
     lk.unlock();
-    known.erase(known.begin(), std::find_if(known.begin(), known.end(), [&](const auto& e) {
-                    return e.first + (1ull << 22) >= s.base; // forget old entries
-                }));
     GR4PM_TRY(gr4pm_cfc_symbol_filter_plan(cfc, s.consumed, s.tags.data(), s.n_tags, &s.plan));
     return GR4PM_OK;
 }
@@ -775,7 +795,7 @@ gr4pm_status gr4pm_packet_receiver_create(const gr4pm_packet_receiver_params* p,
     // look-ahead stream)
     int least = 0, greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return bail(GR4PM_ERR_HIP);
-    for (int i = 0; i < 5; ++i)
+    for (int i = 0; i < 6; ++i)
         if (hipStreamCreateWithPriority(&h->streams[i], hipStreamNonBlocking, i == 0 ? greatest : 0) != hipSuccess)
             return bail(GR4PM_ERR_HIP);
     const size_t sps = p->samples_per_symbol;
@@ -841,8 +861,8 @@ gr4pm_status gr4pm_packet_receiver_create(const gr4pm_packet_receiver_params* p,
             set_error("decode_headers needs soft_bits and the header code's alist");
             return bail(GR4PM_ERR_INVALID);
         }
-        // pass A: the same blocks a second time (stage 1's stream)
-        hipStream_t s1 = h->streams[1], s2 = h->streams[3];
+        // pass A: the same blocks a second time, on a stream (and pipeline stage) of their own
+        hipStream_t s1 = h->streams[5], s2 = h->streams[3];
         gr4pm_rotator_params rp2{ 1, 0.0f, (rrc.size() - 1) / 2 + sps, 1, s1 };
         if ((st = gr4pm_rotator_create(&rp2, &h->a_cfc)) != GR4PM_OK) return bail(st);
         gr4pm_symbol_filter_params fsp2{ sps, pfb.data(), pfb.size(), arms, rrc.size() - 1, 0, s1 };
@@ -875,6 +895,18 @@ gr4pm_status gr4pm_packet_receiver_create(const gr4pm_packet_receiver_params* p,
         h->free_slots.push(i);
     }
     if (p->pipelined) {
+        h->workers[4] = std::thread([h] {
+            gr4pm_set_deferred_sync(getenv("GR4PM_NO_DEFER") ? 0 : 1);
+            for (;;) {
+                const int i = h->to_stageA.pop();
+                if (i < 0) break;
+                CLK_GOT(h->clk[5]);
+                h->stageA(h->slots[i]);
+                CLK_DONE(h->clk[5]);
+                h->to_stage1.push(i);
+            }
+            h->to_stage1.push(-1);
+        });
         h->workers[0] = std::thread([h] {
             gr4pm_set_deferred_sync(getenv("GR4PM_NO_DEFER") ? 0 : 1);
             for (;;) {
@@ -931,7 +963,8 @@ void gr4pm_packet_receiver_destroy(gr4pm_packet_receiver* h)
 {
     if (!h) return;
     if (h->workers[0].joinable()) {
-        h->to_stage1.push(-1);
+        h->to_stageA.push(-1);
+        h->workers[4].join();
         h->workers[0].join();
         h->workers[1].join();
         h->workers[2].join();
@@ -1003,10 +1036,12 @@ gr4pm_status gr4pm_packet_receiver_submit(gr4pm_packet_receiver* h, const gr4pm_
     CLK_DONE(h->clk[0]);
     ++h->inflight;
     if (h->p.pipelined) {
-        h->to_stage1.push(i);
+        if (h->p.decode_headers) h->to_stageA.push(i);
+        else h->to_stage1.push(i);
     } else {
         const bool was = deferred_sync();
         gr4pm_set_deferred_sync(1);
+        h->stageA(s);
         h->stage1(s);
         h->stage1b(s);
         h->stage2(s);
