@@ -1194,7 +1194,9 @@ gr4pm_status ensure_ahead_streams(gr4pm_syncword_detection* h)
     // priority share GPU_MAX_HW_QUEUES = 4 queues; a shared queue serialises its kernels)
     GR4PM_HIP_TRY(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, least));
     // the candidate / table kernels behind it are short and latency-bound and a later call waits
-    // for them: highest priority
+    // for them: highest priority (measured: the correlator's lowest priority too is as good; the
+    // default priority, which the receiver's other stage streams have, costs 20 %, and so does
+    // any higher priority for the correlator)
     GR4PM_HIP_TRY(hipStreamCreateWithPriority(&h->stream3, hipStreamNonBlocking, greatest));
     GR4PM_HIP_TRY(hipEventCreateWithFlags(&h->ev_zcarry, hipEventDisableTiming));
     for (int i = 0; i < kSets; ++i) {
