@@ -10,8 +10,9 @@
 //                    (hpp:238-252,300-313)
 //   k_candidates     B(p) = zpow[p] >= max(zpow[p+1..p+T]) as a bitmap (sliding max)
 //   k_tile_tables    for every tile and every possible entry point, where the greedy peak
-//   k_tile_entries   scan of hpp:267-298,314-317 leaves the tile; then the entry point of each
-//   k_tile_detect    tile; then the scan itself per tile + the median test (hpp:273-295)
+//   k_group_tables   scan of hpp:267-298,314-317 leaves the tile (then a group of tiles); then
+//   k_scan_entries   the entry point of each tile; then the scan itself per tile + the median
+//   k_tile_detect    test (hpp:273-295)
 //   k_tags           recomputes the FFT block of every detection that is emitted in this call
 //                    and writes a raw record (correlation, neighbour bins, noise power)
 //   k_delay_copy     out[i] = in[i - (2T+1)] (hpp:318-319,342)
@@ -512,8 +513,8 @@ struct ChanState {
 // n_tiles / kGroup lookups are truly serial:
 //   k_group_tables   (parallel) for every group of kGroup tiles and every entry offset: where
 //                    the scan leaves the group
-//   k_group_walk     (one thread per channel) walk the groups
-//   k_tile_entries   (one thread per group) walk the tiles of one group from its known entry
+//   k_scan_entries   (one workgroup per channel) thread 0 walks the groups, then one thread
+//                    per group walks the tiles of its group from its known entry
 #ifndef GR4PM_GROUP
 #define GR4PM_GROUP 32
 #endif
