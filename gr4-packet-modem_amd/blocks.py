@@ -1462,7 +1462,7 @@ class NativePacketReceiver:
         """same calling convention as PacketReceiver.process_bulk (header_fn: None or a constant
         packet_length); pipelined: returns the result of an earlier batch, None while filling"""
         self.submit(x, header_fn, history, next_x)
-        depth = 5 if self.decode_headers else 3  # stages behind the detector
+        depth = 5 if self.decode_headers else (4 if self.soft_bits else 3)  # stages behind the detector
         if not self.pipelined or lib().gr4pm_packet_receiver_inflight(self._h) > depth:
             return self.collect()
         return None

@@ -288,10 +288,11 @@ struct gr4pm_packet_receiver {
     gr4pm_status filter_and_wipe(Slot& s);
     gr4pm_status stage2_decode(Slot& s);
     gr4pm_status stage3_decode(Slot& s);
+    gr4pm_status stage3_soft(Slot& s);
     void stage3(Slot& s)
     {
-        if (s.status != GR4PM_OK || !p.decode_headers) return;
-        const gr4pm_status st = stage3_decode(s);
+        if (s.status != GR4PM_OK || !p.soft_bits) return;
+        const gr4pm_status st = p.decode_headers ? stage3_decode(s) : stage3_soft(s);
         (void)hipStreamSynchronize(streams[3]);
         if (st != GR4PM_OK) fail(s, st);
     }
@@ -441,17 +442,21 @@ void gr4pm_packet_receiver::stage2(Slot& s)
     }
     st = gr4pm_costas_loop_process_packets(costas, s.pm.p, produced, s.out_symbols, s.packet_tags.data(), n_pt);
     if (st != GR4PM_OK) return fail(s, st);
-    s.n_symbols = produced;
-    size_t n_dt = 0, n_data = 0;
-    st = gr4pm_syncword_remove_process(remove, s.out_symbols, produced, s.data.p, s.packet_tags.data(), n_pt,
-                                       s.data_tags.data(), s.data_tags.size(), &n_dt, &n_data);
-    if (st != GR4PM_OK) return fail(s, st);
-    size_t n_lt = 0, n_llr = 0;
-    st = gr4pm_constellation_llr_decoder_process(llr, s.data.p, n_data, s.out_llr, s.llr_cap, s.data_tags.data(), n_dt,
-                                                 s.llr_tags.data(), s.llr_tags.size(), &n_lt, &n_llr);
-    if (st != GR4PM_OK) return fail(s, st);
+    s.n_symbols = produced; // SyncwordRemove and the LLR decoder follow in stage 3
+}
+
+// soft_bits without decode_headers: SyncwordRemove + ConstellationLLRDecoder as stage 3 (stage 2,
+// the tag-driven Costas loop behind PayloadMetadataInsert, is the slowest one of this mode)
+gr4pm_status gr4pm_packet_receiver::stage3_soft(Slot& s)
+{
+    size_t n_dt = 0, n_data = 0, n_lt = 0, n_llr = 0;
+    GR4PM_TRY(gr4pm_syncword_remove_process(remove, s.out_symbols, s.n_symbols, s.data.p, s.packet_tags.data(),
+                                            s.n_packet_tags, s.data_tags.data(), s.data_tags.size(), &n_dt, &n_data));
+    GR4PM_TRY(gr4pm_constellation_llr_decoder_process(llr, s.data.p, n_data, s.out_llr, s.llr_cap, s.data_tags.data(),
+                                                      n_dt, s.llr_tags.data(), s.llr_tags.size(), &n_lt, &n_llr));
     s.n_llr_tags = n_lt;
     s.n_llr = n_llr;
+    return GR4PM_OK;
 }
 
 // pass A (see blocks.py PacketReceiver._predecode, which this mirrors): the header of every detection
@@ -851,9 +856,10 @@ gr4pm_status gr4pm_packet_receiver_create(const gr4pm_packet_receiver_params* p,
     if (p->soft_bits) {
         gr4pm_payload_metadata_insert_params pp{ 64, 128, 0.02, 0.01, 0.005, h->streams[2] }; // :123-124
         if ((st = gr4pm_payload_metadata_insert_create(&pp, &h->pmi)) != GR4PM_OK) return bail(st);
-        gr4pm_syncword_remove_params sr{ 64, h->streams[2] }; // :126
+        hipStream_t tail = p->decode_headers ? h->streams[2] : h->streams[3]; // stage 3 of the soft_bits mode
+        gr4pm_syncword_remove_params sr{ 64, tail }; // :126
         if ((st = gr4pm_syncword_remove_create(&sr, &h->remove)) != GR4PM_OK) return bail(st);
-        gr4pm_constellation_llr_decoder_params lp{ 0.7f, 2, h->streams[2] }; // :127-130
+        gr4pm_constellation_llr_decoder_params lp{ 0.7f, 2, tail }; // :127-130
         if ((st = gr4pm_constellation_llr_decoder_create(&lp, &h->llr)) != GR4PM_OK) return bail(st);
     }
     if (p->decode_headers) {
