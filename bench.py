@@ -179,8 +179,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--detector-only", action="store_true", help="time SyncwordDetection alone")
     ap.add_argument("--channels", type=int, default=1,
-                    help="config 3: C independent channels batched in one SyncwordDetection handle "
-                         "(detector only; --items is per channel)")
+                    help="config 3: C independent channels on one GPU: one batched SyncwordDetection handle and "
+                         "every channel's own chain behind it (with --detector-only: the detector alone); "
+                         "--items is per channel")
+    ap.add_argument("--channel-workers", type=int, default=8,
+                    help="--channels: host threads (each with its own stream) that drive the per-channel chains")
     ap.add_argument("--copy-delay", action="store_true",
                     help="materialise SyncwordDetection's delayed output instead of reading the ring in place")
     ap.add_argument("--no-scatter", action="store_true",
@@ -265,8 +268,10 @@ def main():
                                 soft_bits=args.soft_bits, decode_headers=args.decode_headers)
         sd = rx.syncword_detection
     out_keep = None
+    multi = None
     if args.channels > 1:
         # config 3: per-channel CFO sweep -0.04 .. +0.04 rad/sample on top of the burst stream
+        full_chain = not args.detector_only
         args.detector_only = True
         C = args.channels
         k = torch.arange(n_items, device=device, dtype=torch.float32)
@@ -276,9 +281,15 @@ def main():
             xs[c] = x.roll(997 * c) * torch.polar(torch.ones_like(k), (f * k) % (2 * np.pi))
         x = xs
         windows = [(xs, None), (xs, None)]
-        with torch.cuda.stream(rx._streams[0]):
-            sd = pkg.SyncwordDetection(rrc, SYNCWORD, bpsk, -BINS, BINS, power_threshold=9.5, n_channels=C,
-                                       max_items=n_items)
+        if full_chain:
+            # every channel's own chain behind one batched detector (blocks.py MultiChannelPacketReceiver)
+            multi = pkg.MultiChannelPacketReceiver(C, SPS, BINS, 9.5, "QPSK", max_items=n_items,
+                                                   workers=args.channel_workers)
+            sd = multi.syncword_detection
+        else:
+            with torch.cuda.stream(rx._streams[0]):
+                sd = pkg.SyncwordDetection(rrc, SYNCWORD, bpsk, -BINS, BINS, power_threshold=9.5, n_channels=C,
+                                           max_items=n_items)
 
     step_no = 0
     announced_upto = 0
@@ -311,6 +322,10 @@ def main():
                 announced_upto += 1
                 (sd if args.detector_only else rx).announce(windows[announced_upto % 2][0])
         step_no += 1
+        if multi is not None:
+            res = multi.process_bulk(w, 1500, tags_cap=max(64, 2 * n_pkt + 64))
+            out_keep = res[-1]["symbols"]
+            return sum(r["consumed"] for r in res), sum(r["tags"].size for r in res)
         if args.detector_only:
             with torch.cuda.stream(rx._streams[0]):
                 st, out, tags, n = sd.process_bulk(w, want_output=True, tags_cap=max(64, 2 * n_pkt + 64),
@@ -414,7 +429,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": ("SyncwordDetection only" if args.detector_only else
+            "config": {"workload": (f"configs[2]: {args.channels} channels on one GPU, one batched SyncwordDetection + every "
+                                    "channel's own tag gate + CFC + SymbolFilter + wipe-off + Costas (MultiChannelPacketReceiver)"
+                                    if multi is not None else "SyncwordDetection only" if args.detector_only else
                                     "configs[1]: 1 channel/GPU, full RX front end (SyncwordDetection 9 bins FFT 2048 + tag "
                                     "gate + CFC + 32-arm RRC SymbolFilter + wipe-off + Costas)") +
                                    (" + PayloadMetadataInsert + SyncwordRemove + LLR decoder" if (args.soft_bits or args.decode_headers) else "") +

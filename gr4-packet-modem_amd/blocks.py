@@ -936,7 +936,9 @@ class PacketReceiver:
 
     def __init__(self, samples_per_symbol=4, syncword_freq_bins=4, syncword_threshold=9.5,
                  costas_constellation="QPSK", max_items=1 << 22, pipelined=False, fused=True,
-                 soft_bits=False, decode_headers=False):
+                 soft_bits=False, decode_headers=False, detector=True):
+        """detector=False: only the blocks behind SyncwordDetection are created (the caller feeds
+        _stage1 / _stage2 from a detector of its own: MultiChannelPacketReceiver)"""
         torch = _torch()
         self.fused = fused  # CFC applied while the symbol filter stages its input
         self.decode_headers = decode_headers
@@ -954,10 +956,12 @@ class PacketReceiver:
         self.pipelined = pipelined
         cur = torch.cuda.current_stream()
         self._streams = [torch.cuda.Stream() for _ in range(3)] if pipelined else [cur, cur, cur]
-        with torch.cuda.stream(self._streams[0]):
-            self.syncword_detection = SyncwordDetection(                          # :76-83
-                self.rrc_taps, SYNCWORD, bpsk, -syncword_freq_bins, syncword_freq_bins,
-                samples_per_symbol=sps, power_threshold=syncword_threshold, max_items=max_items)
+        self.syncword_detection = None
+        if detector:
+            with torch.cuda.stream(self._streams[0]):
+                self.syncword_detection = SyncwordDetection(                      # :76-83
+                    self.rrc_taps, SYNCWORD, bpsk, -syncword_freq_bins, syncword_freq_bins,
+                    samples_per_symbol=sps, power_threshold=syncword_threshold, max_items=max_items)
         with torch.cuda.stream(self._streams[1]):
             self.syncword_detection_filter = SyncwordDetectionFilter(sps)         # :84-85
             self.freq_correction = CoarseFrequencyCorrection((self.rrc_taps.size - 1) // 2 + sps)  # :94-95
@@ -1372,6 +1376,68 @@ def _hip_memcpy_d2d(dst, src, nbytes):
         _hiprt = C.CDLL("libamdhip64.so")
         _hiprt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     return 0 if _hiprt.hipMemcpy(dst, src, nbytes, 3) == 0 else -3
+
+
+class MultiChannelPacketReceiver:
+    """BASELINE config 3: `n_channels` independent receive chains on one GPU
+    (packet_receiver.hpp:191-265 couples nothing across receivers).  The detector is ONE batched
+    SyncwordDetection handle (every launch covers all channels, blockIdx.y = channel); behind
+    it every channel has its own SyncwordDetectionFilter / CoarseFrequencyCorrection /
+    SymbolFilter / SyncwordWipeoff / CostasLoop with their carried state, and the channels'
+    chains are spread over `workers` host threads, each with a HIP stream of its own, whose
+    process() calls queue up without waiting in between (gr4pm_set_deferred_sync).
+    process_bulk(x[n_channels, n]) returns one PacketReceiver-style result per channel."""
+
+    def __init__(self, n_channels, samples_per_symbol=4, syncword_freq_bins=4, syncword_threshold=9.5,
+                 costas_constellation="QPSK", max_items=1 << 22, workers=8, soft_bits=False):
+        import concurrent.futures
+        torch = _torch()
+        self.n_channels = n_channels
+        workers = max(1, min(workers, n_channels))
+        self._streams = [torch.cuda.Stream() for _ in range(workers)]
+        self.chains = []
+        for c in range(n_channels):
+            with torch.cuda.stream(self._streams[c % workers]):
+                self.chains.append(PacketReceiver(samples_per_symbol, syncword_freq_bins, syncword_threshold,
+                                                  costas_constellation, soft_bits=soft_bits, detector=False))
+        bpsk = np.array([1, -1], dtype=np.complex64)
+        self.syncword_detection = SyncwordDetection(
+            self.chains[0].rrc_taps, SYNCWORD, bpsk, -syncword_freq_bins, syncword_freq_bins,
+            samples_per_symbol=samples_per_symbol, power_threshold=syncword_threshold, n_channels=n_channels,
+            max_items=max_items)
+        self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=workers)
+
+    def announce(self, x):
+        self.syncword_detection.announce(x)
+
+    def _run_worker(self, w, y, det_tags, n, base, header_fn):
+        torch = _torch()
+        lib().gr4pm_set_deferred_sync(1)  # per thread: the calls below only queue their kernels
+        out = {}
+        try:
+            with torch.cuda.stream(self._streams[w]):
+                for c in range(w, self.n_channels, len(self._streams)):
+                    chain = self.chains[c]
+                    out[c] = chain._stage2(chain._stage1(0, y[c], det_tags[c], n, base, header_fn))
+            self._streams[w].synchronize()
+        finally:
+            lib().gr4pm_set_deferred_sync(0)
+        return out
+
+    def process_bulk(self, x, header_fn=None, tags_cap=4096):
+        """x: [n_channels, n] complex64 on the GPU.  Returns a list (one per channel) of
+        dict(consumed, symbols, tags, detector_tags, ...) as PacketReceiver.process_bulk does."""
+        st, y, det_tags, n = self.syncword_detection.process_bulk(x, want_output=True, tags_cap=tags_cap)
+        if st != 0:
+            return [{"status": st, "consumed": 0, "symbols": None, "tags": t, "detector_tags": t} for t in det_tags]
+        base = self.syncword_detection._items_consumed - n
+        _torch().cuda.current_stream().synchronize()  # y is read on the workers' streams
+        futs = [self._pool.submit(self._run_worker, w, y, det_tags, n, base, header_fn)
+                for w in range(len(self._streams))]
+        res = {}
+        for f in futs:
+            res.update(f.result())
+        return [res[c] for c in range(self.n_channels)]
 
 
 class NativePacketReceiver:

@@ -994,6 +994,34 @@ def test_syncword_wipeoff_in_place(pkg):
         assert np.array_equal(bits(ya), bits(host(yb)))
 
 
+def test_multichannel_packet_receiver_equals_single_channel_receivers(pkg):
+    """BASELINE config 3 (full chain): MultiChannelPacketReceiver (one batched detector, per-channel
+    chains on worker threads) == one PacketReceiver per channel, bit for bit, over two calls
+    (carried state of every block), channels with different CFO and burst positions"""
+    C, n = 5, 1 << 17
+    rng = np.random.default_rng(2024)
+    xs = np.zeros((C, 2 * n), dtype=np.complex64)
+    for c in range(C):
+        locs = sorted(rng.choice(np.arange(2000, 2 * n // 4 - 2500, 2500), size=9, replace=False).tolist())
+        stream, _ = sig.qa_syncword_stream(2 * n // 4, locs, -0.02 + 0.04 * c / (C - 1), seed=40 + c)
+        xs[c] = (0.7 * stream[: 2 * n] + sig.awgn(2 * n, 0.05, 90 + c)).astype(np.complex64)
+    multi = pkg.MultiChannelPacketReceiver(C, max_items=n, workers=3)
+    singles = [pkg.PacketReceiver(max_items=n) for _ in range(C)]
+    xd = dev(xs)
+    total_tags = 0
+    for part in range(2):
+        w = xd[:, part * n:(part + 1) * n].contiguous()
+        got = multi.process_bulk(w, 300, tags_cap=256)
+        for c in range(C):
+            want = singles[c].process_bulk(w[c], 300, tags_cap=256)
+            assert got[c]["consumed"] == want["consumed"] > 0
+            assert same_tags(got[c]["detector_tags"], want["detector_tags"])
+            assert np.array_equal(got[c]["tags"], want["tags"])
+            assert np.array_equal(bits(host(got[c]["symbols"])), bits(host(want["symbols"])))
+            total_tags += got[c]["tags"].size
+    assert total_tags >= 4 * C
+
+
 # ------------------------------------------------------------------ SURVEY 8(f) rank 1:
 # PayloadMetadataInsert, CostasLoop with control tags, SyncwordRemove, ConstellationLLRDecoder
 def _sync_tags(pkg, index, amplitude=0.1, phase=0.0):
