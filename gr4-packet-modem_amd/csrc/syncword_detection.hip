@@ -28,10 +28,12 @@
 #include <complex>
 #include <cstdint>
 #include <deque>
+#include <string>
 #include <vector>
 
 #include "common.hpp"
 #include "fft2048_wave.hpp"
+#include "fft2048_pair.hpp"
 
 #ifndef GR4PM_ABL
 #define GR4PM_ABL 0
@@ -267,6 +269,189 @@ __global__ __launch_bounds__(kCorrThreads, 2) void k_correlate(const cf* __restr
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
         const int k = fft2_out_index(lane, j);
+        const uint32_t lag = static_cast<uint32_t>((kFftN - k) & (kFftN - 1));
+        if (lag < stride_s) zo[lag] = zmax[j];
+    }
+}
+
+// ------------------------------------------------------------------ k_correlate_pair
+// EXPERIMENTAL (GR4PM_CORRELATOR=pair at handle creation; default is k_correlate).  The same
+// correlator with TWO waves per overlap-save block (fft2048_pair.hpp): 16 points per lane, so
+// three workgroups of two blocks (12 waves) fit a CU instead of 8 waves.  The exchanges cross
+// the two waves of a block: every half-round is store | sync | load | sync (workgroup barrier of
+// the 4 waves, or pairwise flag words with -DGR4PM_PAIR_FLAGS).  Template hand-off as in
+// k_correlate.  Bit-identical to k_correlate (tests: host emulation and
+// test_two_waves_per_block_correlator_is_bit_identical).
+// Round-1 status: 1.18 ms per 2^26 samples at 9 bins against 1.01 ms for k_correlate.  The VALU
+// work per block is the same (1132 packed + ~460 other instructions), but hipcc wants 182 VGPRs
+// for it (168 are allowed at three waves per SIMD: 12 dwords spill inside the bin loop), the
+// eight synchronisations per transform cost what the third wave gains, and LDS instructions per
+// block go from 194 to 290.  At two waves per SIMD without spills it runs at 1.17 ms.
+// LDS map (float4 units): [0, 1024) template | [1024, 1920) twAp | [1920, 2040) twB |
+// [2040, 2040 + 2 * 576) two exchange buffers of 9 KiB | control words = 51 KiB per workgroup
+constexpr int kPairWaves = 4, kPairThreads = kPairWaves * 64, kPairBlocksPerWg = kPairWaves / 2;
+constexpr int kPLdsTmpl = 0, kPLdsTwA = 1024, kPLdsTwB = kPLdsTwA + kTwApItems / 2, kPLdsExch = kPLdsTwB + kTwBItems / 2;
+constexpr int kPLdsTotal = kPLdsExch + kPairBlocksPerWg * (kExchangeItems / 2);
+static_assert(3 * (kPLdsTotal + 2) * 16 <= 160 * 1024, "LDS budget for three workgroups per CU");
+
+[[maybe_unused]] __device__ __forceinline__ void pair_sync()
+{
+    // LDS operations of the other wave are not ordered with ours: wait for our own stores /
+    // loads to have been performed, then meet at the barrier
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+__device__ __forceinline__ void mul_template_pair(int L, const cf* X, cf* r, const float4* tp)
+{
+#pragma unroll
+    for (int jp = 0; jp < 8; ++jp) {
+        if ((jp & 1) == 0) asm volatile("" ::: "memory"); // at most two template reads in flight (registers)
+        const float4 t = tp[jp * 128 + L];
+        r[2 * jp] = cmul(X[2 * jp], mk(t.x, t.y));
+        r[2 * jp + 1] = cmul(X[2 * jp + 1], mk(t.z, t.w));
+    }
+}
+
+// pairwise meeting point without a workgroup barrier: two monotonic words per pair in LDS, one
+// per wave.  A wave publishes the step it has reached -- LDS operations of one wave execute in
+// issue order, so the word is written after the stores (or loads) in front of it have been
+// performed -- and waits until its partner has published the same step.
+struct PairSync {
+    unsigned* mine;
+    const unsigned* other;
+    unsigned step = 0;
+    __device__ __forceinline__ void operator()(int lane)
+    {
+        ++step;
+        asm volatile("" ::: "memory");
+        if (lane == 0) __hip_atomic_store(mine, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int guard = 0; guard < (1 << 22); ++guard) {
+            const unsigned v = __hip_atomic_load(other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (__builtin_amdgcn_readfirstlane(v) >= step) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");
+    }
+};
+
+__global__ __launch_bounds__(kPairThreads, 3) void k_correlate_pair(
+    const cf* __restrict__ in, size_t in_stride, uint32_t n_blocks, uint32_t stride_s, int n_bins,
+    const float4* __restrict__ tmplp, const cf* __restrict__ tw1p, const cf* __restrict__ tw1b,
+    const float4* __restrict__ twABp, float* __restrict__ zpow, size_t z_stride)
+{
+    __shared__ float4 lds4[kPLdsTotal + 2];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wv = wave & 1, pair = wave >> 1;
+    const int L = lane + 64 * wv;
+    const uint32_t b_raw = blockIdx.x * kPairBlocksPerWg + pair;
+    const bool active = b_raw < n_blocks;
+    const uint32_t b = active ? b_raw : n_blocks - 1; // idle pairs shadow the last block
+    cf* lds = reinterpret_cast<cf*>(lds4 + kPLdsExch) + pair * kExchangeItems;
+    const cf* twA = reinterpret_cast<const cf*>(lds4 + kPLdsTwA);
+    const cf* twB = reinterpret_cast<const cf*>(lds4 + kPLdsTwB);
+    const cf* x = in + static_cast<size_t>(blockIdx.y) * in_stride + static_cast<size_t>(b) * stride_s;
+    float* zo = zpow + static_cast<size_t>(blockIdx.y) * z_stride + static_cast<size_t>(b) * stride_s;
+    // control words: [0] consumed, [1] ready (template hand-off, as in k_correlate), [4 + 2 pair + wv] pair steps
+    unsigned* ctl = reinterpret_cast<unsigned*>(lds4 + kPLdsTotal);
+
+    for (int i = tid; i < (kTwApItems + kTwBItems) / 2; i += kPairThreads) lds4[kPLdsTwA + i] = twABp[i];
+#pragma unroll
+    for (int u = 0; u < 1024 / kPairThreads; ++u) lds4[kPLdsTmpl + u * kPairThreads + tid] = tmplp[u * kPairThreads + tid];
+    if (tid < 8) ctl[tid] = 0;
+
+    cf r[16], bb[16];
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) r[n1] = x[L + 128 * n1];
+    __syncthreads(); // twiddles, template 0 and control words staged
+#ifdef GR4PM_PAIR_FLAGS /* measured: 1.27 ms per 2^26 samples against 1.18 with the workgroup barrier */
+    PairSync sync{ ctl + 4 + 2 * pair + wv, ctl + 4 + 2 * pair + (wv ^ 1) };
+#else
+    auto sync = [&](int) { pair_sync(); };
+#endif
+    auto wait_ge = [&](int word, unsigned v) {
+        for (int guard = 0; guard < (1 << 20); ++guard) {
+            if (__hip_atomic_load(ctl + word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= v) return;
+            __builtin_amdgcn_s_sleep(2);
+        }
+    };
+    // ---- FFT-1
+    fft1p_pass1(L, r, tw1p);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        fft1p_store1(L, r, lds, h);
+        sync(lane);
+        if (wv == h) fft1p_load2(L, bb, lds);
+        sync(lane);
+    }
+    fft1p_pass2(L, bb, tw1b);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (wv == h) fft1p_store2(L, bb, lds);
+        sync(lane);
+        fft1p_load3(L, r, lds, h);
+        sync(lane);
+    }
+    fft1p_pass3(r);
+    cf X[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) X[j] = r[j];
+    float zmax[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) zmax[j] = -1.0f; // hpp:303
+
+    for (int bin = 0; bin < n_bins; ++bin) {
+        const bool more = bin + 1 < n_bins;
+        cf p[16], c[16];
+        wait_ge(1, static_cast<unsigned>(bin));
+        mul_template_pair(L, X, p, lds4 + kPLdsTmpl); // hpp:247-249
+        wave_lds_sync(); // keep the template reads ahead of the counter update in program order
+        if (lane == 0) __hip_atomic_fetch_add(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        fft2p_passA(L, p, twA);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            fft2p_storeA(L, p, lds, h);
+            sync(lane);
+            if (wv == h) fft2p_loadB(L, bb, lds);
+            sync(lane);
+        }
+        fft2p_passB(L, bb, twB);
+        if (more && wave == 0) {
+            // template hand-off as in k_correlate: once all four waves have read template `bin`, move
+            // template bin + 1 global -> LDS with the DMA path, 16 x 1 KiB
+            wait_ge(0, static_cast<unsigned>(kPairWaves * (bin + 1)));
+            const float4* tg = tmplp + static_cast<size_t>(bin + 1) * 1024;
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tg + u * 64 + lane),
+                                                 (__attribute__((address_space(3))) void*)(lds4 + kPLdsTmpl + u * 64), 16,
+                                                 0, 0);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            fft2p_storeB(L, bb, lds, h);
+            sync(lane);
+            if (wv == h) fft2p_loadC(L, c, lds);
+            sync(lane);
+        }
+        fft2p_passC(c); // hpp:250-251
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float pw = fmaf(c[j].y, c[j].y, c[j].x * c[j].x); // as in k_correlate (hpp:307-308)
+            asm("v_max_f32 %0, %1, %2" : "=v"(zmax[j]) : "v"(zmax[j]), "v"(pw));
+        }
+        if (more && wave == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the DMA has landed in LDS
+            if (lane == 0) __hip_atomic_store(ctl + 1, static_cast<unsigned>(bin + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    if (!active) return;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int k = fft2p_out_index(L, j);
         const uint32_t lag = static_cast<uint32_t>((kFftN - k) & (kFftN - 1));
         if (lag < stride_s) zo[lag] = zmax[j];
     }
@@ -995,6 +1180,11 @@ struct gr4pm_syncword_detection {
     // device
     DevBuf<float4> tmpl;
     DevBuf<cf> tw; // tw1a ++ tw1b ++ twA ++ twB (fft2048_wave.hpp)
+    // the two-waves-per-block correlator (fft2048_pair.hpp): templates in its lane order,
+    // tw1p ++ twAp ++ twB
+    bool use_pair = false;
+    DevBuf<float4> tmplp;
+    DevBuf<cf> twp;
     // generic block sizes (fft_size != 2048)
     bool generic = false;
     int log2n = 0;
@@ -1121,6 +1311,15 @@ gr4pm_status launch_correlate(gr4pm_syncword_detection* h, hipStream_t stream, c
         hipLaunchKernelGGL(k_correlate_generic, dim3(n_blocks, static_cast<unsigned>(h->n_channels)), dim3(256),
                            2 * N * sizeof(cf), stream, reinterpret_cast<const cf*>(in), in_stride, n_blocks,
                            static_cast<uint32_t>(h->S), N, h->log2n, h->n_bins, h->g_tmpl.p, h->g_tw.p, zout,
+                           h->z_stride);
+        GR4PM_HIP_TRY(hipGetLastError());
+        return GR4PM_OK;
+    }
+    if (h->use_pair) {
+        dim3 gridp((n_blocks + kPairBlocksPerWg - 1) / kPairBlocksPerWg, static_cast<unsigned>(h->n_channels));
+        hipLaunchKernelGGL(k_correlate_pair, gridp, dim3(kPairThreads), 0, stream, reinterpret_cast<const cf*>(in),
+                           in_stride, n_blocks, static_cast<uint32_t>(h->S), h->n_bins, h->tmplp.p, h->twp.p,
+                           h->tw.p + kTw1aItems, reinterpret_cast<const float4*>(h->twp.p + kTw1pItems), zout,
                            h->z_stride);
         GR4PM_HIP_TRY(hipGetLastError());
         return GR4PM_OK;
@@ -1281,6 +1480,7 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
     for (auto x : sw) self_corr += x.real() * x.real() + x.imag() * x.imag(); // hpp:161-164
     h->self_corr = self_corr;
     std::vector<float4> tmpl(h->generic ? 1 : static_cast<size_t>(n_bins) * 1024);
+    std::vector<float4> tmplp(tmpl.size());
     std::vector<cf> g_tmpl(h->generic ? static_cast<size_t>(n_bins) * p->fft_size : 0);
     for (int b = 0; b < n_bins; ++b) {
         const int freq_bin = p->min_freq_bin + b;
@@ -1314,6 +1514,14 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
                     make_float4(static_cast<float>(t0.real()), static_cast<float>(t0.imag()),
                                 static_cast<float>(t1.real()), static_cast<float>(t1.imag()));
             }
+        for (int L = 0; L < 128; ++L) // the same values in the pair schedule's lane order
+            for (int jp = 0; jp < 8; ++jp) {
+                const auto t0 = std::conj(a[fft1p_out_index(L, 2 * jp)]);
+                const auto t1 = std::conj(a[fft1p_out_index(L, 2 * jp + 1)]);
+                tmplp[static_cast<size_t>(b) * 1024 + jp * 128 + L] =
+                    make_float4(static_cast<float>(t0.real()), static_cast<float>(t0.imag()),
+                                static_cast<float>(t1.real()), static_cast<float>(t1.imag()));
+            }
     }
     std::vector<cf> tw(kTw1aItems + kTw1bItems + kTwAItems + kTwBItems);
     build_twiddle_tables(
@@ -1323,6 +1531,18 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
         },
         tw.data(), tw.data() + kTw1aItems, tw.data() + kTw1aItems + kTw1bItems,
         tw.data() + kTw1aItems + kTw1bItems + kTwAItems);
+    std::vector<cf> twp(kTw1pItems + kTwApItems + kTwBItems);
+    build_pair_twiddle_tables(
+        [](int k) {
+            const double ang = -2.0 * M_PI * k / kFftN;
+            return mk(static_cast<float>(std::cos(ang)), static_cast<float>(std::sin(ang)));
+        },
+        twp.data(), twp.data() + kTw1pItems);
+    for (int i = 0; i < kTwBItems; ++i) twp[kTw1pItems + kTwApItems + i] = tw[kTw1aItems + kTw1bItems + kTwAItems + i];
+    {
+        const char* e = getenv("GR4PM_CORRELATOR"); // "pair" / "wave": which of the two bit-identical kernels runs
+        h->use_pair = !h->generic && e && std::string(e) == "pair";
+    }
 
     h->xc = static_cast<uint32_t>(round_up(h->hist + h->S + 2, 64));
     h->zc = static_cast<uint32_t>(round_up(2 * h->T + 2, 64));
@@ -1339,6 +1559,8 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
     };
     ok(h->tmpl.alloc(tmpl.size()));
     ok(h->tw.alloc(tw.size()));
+    ok(h->tmplp.alloc(tmplp.size()));
+    ok(h->twp.alloc(twp.size()));
     std::vector<cf> g_tw(h->generic ? p->fft_size / 2 : 0);
     for (size_t k = 0; k < g_tw.size(); ++k) {
         const double ang = -2.0 * M_PI * static_cast<double>(k) / static_cast<double>(p->fft_size);
@@ -1375,6 +1597,8 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
     if (s == GR4PM_OK && h->generic) s = h->g_tw.upload(g_tw.data(), g_tw.size(), h->stream);
     if (s == GR4PM_OK) s = h->tmpl.upload(tmpl.data(), tmpl.size(), h->stream);
     if (s == GR4PM_OK) s = h->tw.upload(tw.data(), tw.size(), h->stream);
+    if (s == GR4PM_OK) s = h->tmplp.upload(tmplp.data(), tmplp.size(), h->stream);
+    if (s == GR4PM_OK) s = h->twp.upload(twp.data(), twp.size(), h->stream);
     if (s == GR4PM_OK && hipStreamSynchronize(h->stream) != hipSuccess) s = GR4PM_ERR_HIP;
     if (s == GR4PM_OK) s = sd_reset(h);
     if (s != GR4PM_OK) {

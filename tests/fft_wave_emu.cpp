@@ -8,6 +8,7 @@
 #include <random>
 #include <vector>
 #include "fft2048_wave.hpp"
+#include "fft2048_pair.hpp"
 
 using namespace gr4pm;
 using cd = std::complex<double>;
@@ -120,5 +121,72 @@ int main()
     bad = 0;
     for (int k = 0; k < kFftN; ++k) bad += seen[k] != 1;
     std::printf("fft2 relerr %.3e coverage_bad %d\n", maxerr / maxref, bad);
+
+    // ================= the same two transforms by a PAIR of waves (fft2048_pair.hpp): 128 lanes,
+    // 16 points each; must give bit-identical values (same arithmetic, other distribution)
+    std::vector<cf> one_wave_C(kFftN);
+    for (int l = 0; l < kLanes; ++l)
+        for (int j = 0; j < kPtsPerLane; ++j) one_wave_C[fft2_out_index(l, j)] = r[l][j];
+    std::vector<cf> tw1p(kTw1pItems), twAp(kTwApItems);
+    build_pair_twiddle_tables(
+        [](int k) {
+            const double a = -2.0 * M_PI * k / kFftN;
+            return mk(static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a)));
+        },
+        tw1p.data(), twAp.data());
+    std::vector<std::vector<cf>> rp(kPairLanes, std::vector<cf>(kPairPts)), bp = rp, cp = rp;
+    for (int L = 0; L < kPairLanes; ++L)
+        for (int n1 = 0; n1 < 16; ++n1) rp[L][n1] = x[L + 128 * n1];
+    for (int L = 0; L < kPairLanes; ++L) fft1p_pass1(L, rp[L].data(), tw1p.data());
+    for (int h = 0; h < 2; ++h) { // barrier between the store and the load phase on the GPU
+        for (int L = 0; L < kPairLanes; ++L) fft1p_store1(L, rp[L].data(), lds.data(), h);
+        for (int L = 64 * h; L < 64 * h + 64; ++L) fft1p_load2(L, bp[L].data(), lds.data());
+    }
+    for (int L = 0; L < kPairLanes; ++L) fft1p_pass2(L, bp[L].data(), tw1b.data());
+    for (int h = 0; h < 2; ++h) {
+        for (int L = 64 * h; L < 64 * h + 64; ++L) fft1p_store2(L, bp[L].data(), lds.data());
+        for (int L = 0; L < kPairLanes; ++L) fft1p_load3(L, rp[L].data(), lds.data(), h);
+    }
+    for (int L = 0; L < kPairLanes; ++L) fft1p_pass3(rp[L].data());
+    maxref = maxerr = 0;
+    std::fill(seen.begin(), seen.end(), 0);
+    for (int L = 0; L < kPairLanes; ++L)
+        for (int j = 0; j < kPairPts; ++j) {
+            const int k = fft1p_out_index(L, j);
+            seen[k]++;
+            maxref = std::max(maxref, std::abs(X[k]));
+            maxerr = std::max(maxerr, std::abs(cd(rp[L][j].x, rp[L][j].y) - X[k]));
+        }
+    bad = 0;
+    for (int k = 0; k < kFftN; ++k) bad += seen[k] != 1;
+    std::printf("fft3 relerr %.3e coverage_bad %d\n", maxerr / maxref, bad); // "fft3" = FFT-1 by a pair
+    for (int L = 0; L < kPairLanes; ++L)
+        for (int j = 0; j < kPairPts; ++j) rp[L][j] = cmul(rp[L][j], t[fft1p_out_index(L, j)]);
+    for (int L = 0; L < kPairLanes; ++L) fft2p_passA(L, rp[L].data(), twAp.data());
+    for (int h = 0; h < 2; ++h) {
+        for (int L = 0; L < kPairLanes; ++L) fft2p_storeA(L, rp[L].data(), lds.data(), h);
+        for (int L = 64 * h; L < 64 * h + 64; ++L) fft2p_loadB(L, bp[L].data(), lds.data());
+    }
+    for (int L = 0; L < kPairLanes; ++L) fft2p_passB(L, bp[L].data(), twB.data());
+    for (int h = 0; h < 2; ++h) {
+        for (int L = 0; L < kPairLanes; ++L) fft2p_storeB(L, bp[L].data(), lds.data(), h);
+        for (int L = 64 * h; L < 64 * h + 64; ++L) fft2p_loadC(L, cp[L].data(), lds.data());
+    }
+    for (int L = 0; L < kPairLanes; ++L) fft2p_passC(cp[L].data());
+    maxref = maxerr = 0;
+    std::fill(seen.begin(), seen.end(), 0);
+    int differ = 0;
+    for (int L = 0; L < kPairLanes; ++L)
+        for (int j = 0; j < kPairPts; ++j) {
+            const int k = fft2p_out_index(L, j);
+            seen[k]++;
+            maxref = std::max(maxref, std::abs(C[k]));
+            maxerr = std::max(maxerr, std::abs(cd(cp[L][j].x, cp[L][j].y) - C[k]));
+            differ += !(cp[L][j].x == one_wave_C[k].x && cp[L][j].y == one_wave_C[k].y);
+        }
+    bad = 0;
+    for (int k = 0; k < kFftN; ++k) bad += seen[k] != 1;
+    std::printf("fft4 relerr %.3e coverage_bad %d\n", maxerr / maxref, bad); // "fft4" = FFT-2 by a pair
+    std::printf("pair_vs_wave_differing_values %d\n", differ);
     return 0;
 }

@@ -66,6 +66,8 @@ def test_one_wave_fft_schedules_host_emulation(tmp_path):
                            os.path.join(ROOT, "tests", "fft_wave_emu.cpp")])
     out = subprocess.check_output([str(exe)]).decode()
     m = re.findall(r"fft(\d) relerr ([0-9.e+-]+) coverage_bad (\d+)", out)
-    assert len(m) == 2
+    assert len(m) == 4  # FFT-1, FFT-2 by one wave; the same by a pair of waves (fft2048_pair.hpp)
     for _, err, bad in m:
         assert float(err) < 5e-7 and int(bad) == 0
+    # the pair schedules do the same arithmetic in another distribution: identical bits
+    assert re.search(r"pair_vs_wave_differing_values 0\b", out)

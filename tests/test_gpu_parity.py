@@ -217,6 +217,32 @@ def test_syncword_detection_announced_two_calls_ahead(pkg):
     assert_tags_match(tags, ref_tags[: tags.size])
 
 
+def test_two_waves_per_block_correlator_is_bit_identical(pkg, monkeypatch):
+    """k_correlate_pair (fft2048_pair.hpp: two waves per overlap-save block, 16 points per lane;
+    selected with GR4PM_CORRELATOR=pair when the handle is created) does the same arithmetic in
+    another distribution: identical correlation powers, identical output and tags"""
+    locations = [100, 1000, 1250, 10000, 13721, 43124, 58000 - 64]
+    x, rrc = sig.qa_syncword_stream(60000, locations, 0.007, seed=15)
+    x = (x + sig.awgn(x.size, 0.2, 16)).astype(np.complex64)
+    xd = dev(x)
+    res = {}
+    for kind in ("wave", "pair"):
+        monkeypatch.setenv("GR4PM_CORRELATOR", kind)
+        sd = pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, power_threshold=9.5, max_items=1 << 18)
+        outs, tags, z = [], [], []
+        for lo, hi in ((0, 100000), (100000 - 1600, x.size)):  # two calls (odd block counts, idle pair at the end)
+            st, o, t, n = sd.process_bulk(xd[lo:hi])
+            assert st == 0 and n > 0
+            outs.append(host(o)); tags.append(t); z.append(host(sd.last_zpow(n)))
+        res[kind] = (outs, tags, z)
+    for a, b in zip(res["wave"][2], res["pair"][2]):
+        assert a.size > 50000 and np.array_equal(bits(a), bits(b))
+    for a, b in zip(res["wave"][0], res["pair"][0]):
+        assert np.array_equal(bits(a), bits(b))
+    for a, b in zip(res["wave"][1], res["pair"][1]):
+        assert a.size >= 2 and same_tags(a, b)
+
+
 def test_syncword_detection_awgn_threshold_and_noise_only(pkg):
     """default threshold 9.5, bursts in AWGN: same detections (incl. none on noise) as the oracle"""
     rng = np.random.default_rng(77)
