@@ -179,8 +179,16 @@ __global__ __launch_bounds__(kCorrThreads, 2) void k_correlate(const cf* __restr
     const bool active = b_raw < n_blocks;
     const uint32_t b = active ? b_raw : n_blocks - 1; // idle waves shadow the last block
     cf* lds = reinterpret_cast<cf*>(lds4 + kLdsExch) + wave * kExchangeItems;
+#if defined(GR4PM_TW_L1) /* experiment: FFT-2 twiddles through L1 instead of LDS */
+    const cf* twA = reinterpret_cast<const cf*>(twAB);
+    const cf* twB = twA + kTwAItems;
+#elif defined(GR4PM_TWA_L1)
+    const cf* twA = reinterpret_cast<const cf*>(twAB);
+    const cf* twB = reinterpret_cast<const cf*>(lds4 + kLdsTwB);
+#else
     const cf* twA = reinterpret_cast<const cf*>(lds4 + kLdsTwA);
     const cf* twB = reinterpret_cast<const cf*>(lds4 + kLdsTwB);
+#endif
     const cf* x = in + static_cast<size_t>(blockIdx.y) * in_stride + static_cast<size_t>(b) * stride_s;
     float* zo = zpow + static_cast<size_t>(blockIdx.y) * z_stride + static_cast<size_t>(b) * stride_s;
 
@@ -367,7 +375,9 @@ __global__ __launch_bounds__(kPairThreads, 3) void k_correlate_pair(
 #pragma unroll
     for (int n1 = 0; n1 < 16; ++n1) r[n1] = x[L + 128 * n1];
     __syncthreads(); // twiddles, template 0 and control words staged
-#ifdef GR4PM_PAIR_FLAGS /* measured: 1.27 ms per 2^26 samples against 1.18 with the workgroup barrier */
+#if defined(GR4PM_PAIR_NOSYNC) /* timing-only ablation: wrong results */
+    auto sync = [&](int) { wave_lds_sync(); };
+#elif defined(GR4PM_PAIR_FLAGS) /* measured: 1.27 ms per 2^26 samples against 1.18 with the workgroup barrier */
     PairSync sync{ ctl + 4 + 2 * pair + wv, ctl + 4 + 2 * pair + (wv ^ 1) };
 #else
     auto sync = [&](int) { pair_sync(); };
