@@ -179,7 +179,9 @@ __global__ __launch_bounds__(kCorrThreads, 2) void k_correlate(const cf* __restr
     const bool active = b_raw < n_blocks;
     const uint32_t b = active ? b_raw : n_blocks - 1; // idle waves shadow the last block
     cf* lds = reinterpret_cast<cf*>(lds4 + kLdsExch) + wave * kExchangeItems;
-#if defined(GR4PM_TW_L1) /* experiment: FFT-2 twiddles through L1 instead of LDS */
+#if defined(GR4PM_TW_L1) /* measured, not adopted: FFT-2 twiddles through L1 instead of LDS (22 % of the LDS
+                            traffic): hipcc hoists the loads, 256 VGPRs + spills, 1.42 ms instead of 1.01;
+                            pass-A table only (GR4PM_TWA_L1): 1.29 ms */
     const cf* twA = reinterpret_cast<const cf*>(twAB);
     const cf* twB = twA + kTwAItems;
 #elif defined(GR4PM_TWA_L1)
