@@ -173,8 +173,8 @@ def aggregate(dist, dt, consumed, device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--items", type=int, default=1 << 26, help="samples per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--detector-only", action="store_true", help="time SyncwordDetection alone")
