@@ -81,6 +81,17 @@ __device__ __forceinline__ void rot_step(cf& e, cf inc, unsigned& counter)
     }
 }
 
+// cmul(a, b) as three packed instructions: (a.x b.x, a.x b.y), (a.y b.y, a.y b.x), then
+// (t.x - u.x, t.y + u.y) -- the same four products and two sums, each rounded once
+__device__ __forceinline__ cf cmul_pk(cf a, cf b)
+{
+    cf t, u, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(u) : "v"(a), "v"(b));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(r) : "v"(t), "v"(u));
+    return r;
+}
+
 // kRotChunk steps e *= inc without renormalisation, three packed instructions a step:
 //   a = (e.x * inc.x, e.x * inc.y)   b = (e.y * inc.y, e.y * inc.x)   e = (a.x - b.x, a.y + b.y)
 // which are exactly the four products and two sums of cmul(), each rounded once (the sign of
@@ -599,6 +610,19 @@ __global__ __launch_bounds__(256) void k_symbol_filter(const T* __restrict__ in,
                     cf e = cfc.ck[g.ck0 + c];
                     unsigned counter = c0 + static_cast<unsigned>(c * kRotChunk);
                     const long long idx0 = static_cast<long long>(g.start + c * kRotChunk);
+                    if (idx0 >= a && idx0 + static_cast<long long>(kRotChunk) <= b &&
+                        (counter & 511u) <= 512u - kRotChunk) {
+                        // whole chunk inside the span and no renormalisation among its 7 steps (the
+                        // usual case): straight-line packed arithmetic, same operations as below
+                        const unsigned i0 = static_cast<unsigned>(idx0 - p.lo_item);
+#pragma unroll
+                        for (unsigned t = 0; t < kRotChunk; ++t) {
+                            const unsigned i = i0 + t;
+                            tile[(i % sps) * pitch + i / sps] = cmul_pk(raw[raw_slot(i)], e); // hpp:87
+                            if (t + 1 < kRotChunk) e = cmul_pk(e, inc);
+                        }
+                        continue;
+                    }
 #pragma unroll
                     for (unsigned t = 0; t < kRotChunk; ++t) {
                         const long long idx = idx0 + t;
