@@ -23,6 +23,7 @@ using namespace gr4pm;
 
 namespace {
 
+static_assert(7 <= GR4PM_CFC_PLANS, "a slot keeps its CFC plan from stage 1 to stage 1b: the plan ring must cover every slot");
 constexpr int kSlots = 7; // detector | pass A (decode_headers) | stage 1 | stage 1b | stage 2 | stage 3 (decode_headers) | held by the caller
 
 struct Slot {

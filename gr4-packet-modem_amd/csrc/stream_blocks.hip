@@ -773,16 +773,16 @@ struct gr4pm_rotator {
     hipStream_t stream;
     DevBuf<RotState> state; // [2][n_channels], st_cur selects the current half
     int st_cur = 0;
-    // the plan of a call (segment table, phasor checkpoints, increments, counters): two sets, so
-    // that the next call can be planned while the consumer of the last plan is still running
-    // (gr4pm_cfc_symbol_filter_plan / _run)
+    // the plan of a call (segment table, phasor checkpoints, increments, counters): a ring of
+    // GR4PM_CFC_PLANS sets, so that the next calls can be planned while the consumers of earlier
+    // plans are still running (gr4pm_cfc_symbol_filter_plan / _run; buffers are allocated on first use)
     struct Plan {
         DevBuf<RotSeg> segs;
         DevBuf<cf> ck, seg_incr;
         DevBuf<unsigned> seg_counter0;
         unsigned n_segs = 0;
         size_t n_in = 0;
-    } plans[2];
+    } plans[GR4PM_CFC_PLANS];
     int plan_cur = 0;
     std::vector<float> next_freq;     // per channel, coarse_frequency_correction.hpp:44
     std::vector<long> next_freq_delay; // :45
@@ -915,7 +915,7 @@ static gr4pm_status rotator_plan(gr4pm_rotator* h, size_t n, const gr4pm_tag* ta
     const unsigned n_segs = static_cast<unsigned>(segs.size());
     unsigned ck_total = 0;
     for (const auto& g : segs) ck_total = std::max<unsigned>(ck_total, g.ck0 + static_cast<unsigned>((g.len + kRotChunk - 1) / kRotChunk));
-    h->plan_cur ^= 1;
+    h->plan_cur = (h->plan_cur + 1) % GR4PM_CFC_PLANS;
     auto& pl = h->plans[h->plan_cur];
     pl.n_segs = n_segs;
     pl.n_in = n;
@@ -1929,7 +1929,7 @@ gr4pm_status gr4pm_cfc_symbol_filter_run(gr4pm_rotator* cfc, int plan, gr4pm_sym
         return GR4PM_ERR_INVALID;
     }
     if (n_in == 0) return GR4PM_OK;
-    if (plan < 0 || plan > 1 || cfc->plans[plan].n_in != n_in) {
+    if (plan < 0 || plan >= GR4PM_CFC_PLANS || cfc->plans[plan].n_in != n_in) {
         set_error("no rotation plan for this call");
         return GR4PM_ERR_INVALID;
     }

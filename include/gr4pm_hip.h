@@ -313,8 +313,10 @@ gr4pm_status gr4pm_cfc_symbol_filter_process(gr4pm_rotator* cfc, gr4pm_symbol_fi
  * them as two stages): _plan replays the CFC's tag handling and computes the phasor checkpoints
  * of the call on the CFC's stream (the serial part), _run is the filter itself on the
  * SymbolFilter's stream.  The caller orders them (a _run after its _plan has completed; plans
- * and runs each in stream order); two plans exist, so the plan of call n+1 may be made while
- * the run of call n is still in flight.  `plan` is the value _plan returned. */
+ * and runs each in stream order).  GR4PM_CFC_PLANS plans exist (a ring): a plan stays valid until
+ * GR4PM_CFC_PLANS - 1 further plans have been made, so that many calls may sit between the two
+ * halves.  `plan` is the value _plan returned. */
+#define GR4PM_CFC_PLANS 8
 gr4pm_status gr4pm_cfc_symbol_filter_plan(gr4pm_rotator* cfc, size_t n_in, const gr4pm_tag* tags_in,
                                           size_t n_tags_in, int* plan);
 gr4pm_status gr4pm_cfc_symbol_filter_run(gr4pm_rotator* cfc, int plan, gr4pm_symbol_filter* sf,
