@@ -1360,20 +1360,24 @@ gr4pm_status launch_front(gr4pm_syncword_detection* h, hipStream_t stream, int w
     const uint32_t T = static_cast<uint32_t>(h->T);
     const unsigned nch = static_cast<unsigned>(h->n_channels);
     float* zw = h->z[which].p;
-    // z carry: positions E0-zc .. E0-1; sample carry for the call after this one: the last xc
-    // items up to E1
+    // the correlator needs nothing but the input; behind it, on the look-ahead's second stream, the
+    // two carries (two tiny kernels that would otherwise sit between consecutive correlator launches)
+    // and the candidate / table kernels
+    GR4PM_TRY(launch_correlate(h, stream, in, in_stride, n_blocks, zw + h->zc));
+    const bool ahead = stream != h->stream;
+    if (ahead) {
+        GR4PM_HIP_TRY(hipEventRecord(h->ev_mid[which], stream));
+        stream = h->stream3;
+        GR4PM_HIP_TRY(hipStreamWaitEvent(stream, h->ev_mid[which], 0));
+    }
+    // z carry: positions E0-zc .. E0-1 (the tail of the call before, complete once this call's
+    // correlator -- behind that call's on its stream -- is); sample carry for the call after this
+    // one: the last xc items up to E1
     hipLaunchKernelGGL(k_update_zcarry, dim3((h->zc + 255) / 256, nch), dim3(256), 0, stream,
                        h->z[(which + kSets - 1) % kSets].p, zw, h->z_stride, h->zc, n_prev);
     hipLaunchKernelGGL(k_update_carry, dim3((h->xc + 255) / 256, nch), dim3(256), 0, stream,
                        reinterpret_cast<const cf*>(in), in_stride, h->carry[ci].p, h->carry[(ci + 1) % kCarry].p,
                        static_cast<size_t>(h->xc), h->xc, J);
-    GR4PM_TRY(launch_correlate(h, stream, in, in_stride, n_blocks, zw + h->zc));
-    const bool ahead = stream != h->stream;
-    if (ahead) { // look-ahead: the candidate / table kernels run on their own stream
-        GR4PM_HIP_TRY(hipEventRecord(h->ev_mid[which], stream));
-        stream = h->stream3;
-        GR4PM_HIP_TRY(hipStreamWaitEvent(stream, h->ev_mid[which], 0));
-    }
     const uint64_t A0 = E0 > T ? E0 - T : 0, A1 = E1 > T ? E1 - T : 0;
     const uint32_t cnt = static_cast<uint32_t>(A1 - A0);
     if (cnt == 0) {
@@ -1795,6 +1799,10 @@ gr4pm_status gr4pm_syncword_detection_process(gr4pm_syncword_detection* h, const
             c = (c + 1) % kCarry;
             a.E0 = e0;
             a.set = set;
+            // this front's correlator overwrites the z buffer whose tail the z carry of the front two
+            // calls before it reads on the other look-ahead stream (set + 1): long done in practice
+            // (a whole correlator launch lies in between), ordered by its event all the same
+            GR4PM_HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_front[(set + 1) % kSets], 0));
             GR4PM_TRY(launch_front(h, h->stream2, set, c, a.in, a.stride, a.n, e0, j_prev));
             h->launched.push_back(a);
             const size_t nb = (a.n - h->fft_size) / h->S + 1;
