@@ -182,7 +182,7 @@ def main():
                     help="config 3: C independent channels on one GPU: one batched SyncwordDetection handle and "
                          "every channel's own chain behind it (with --detector-only: the detector alone); "
                          "--items is per channel")
-    ap.add_argument("--channel-workers", type=int, default=8,
+    ap.add_argument("--channel-workers", type=int, default=12,
                     help="--channels: host threads (each with its own stream) that drive the per-channel chains")
     ap.add_argument("--copy-delay", action="store_true",
                     help="materialise SyncwordDetection's delayed output instead of reading the ring in place")
@@ -283,9 +283,14 @@ def main():
         windows = [(xs, None), (xs, None)]
         if full_chain:
             # every channel's own chain behind one batched detector (blocks.py MultiChannelPacketReceiver)
-            multi = pkg.MultiChannelPacketReceiver(C, SPS, BINS, 9.5, "QPSK", max_items=n_items,
-                                                   workers=args.channel_workers)
-            sd = multi.syncword_detection
+            if args.python_pipeline:  # the same composition from Python threads (host-bound)
+                multi = pkg.MultiChannelPacketReceiver(C, SPS, BINS, 9.5, "QPSK", max_items=n_items,
+                                                       workers=args.channel_workers)
+                sd = multi.syncword_detection
+            else:
+                multi = pkg.NativeMultiChannelReceiver(C, SPS, BINS, 9.5, "QPSK", max_items=n_items,
+                                                       tags_cap=max(64, 2 * n_pkt + 64), workers=args.channel_workers)
+                sd = multi  # announce() goes to the library's detector
         else:
             with torch.cuda.stream(rx._streams[0]):
                 sd = pkg.SyncwordDetection(rrc, SYNCWORD, bpsk, -BINS, BINS, power_threshold=9.5, n_channels=C,
@@ -323,7 +328,8 @@ def main():
                 (sd if args.detector_only else rx).announce(windows[announced_upto % 2][0])
         step_no += 1
         if multi is not None:
-            res = multi.process_bulk(w, 1500, tags_cap=max(64, 2 * n_pkt + 64))
+            res = (multi.process_bulk(w, 1500, tags_cap=max(64, 2 * n_pkt + 64)) if args.python_pipeline
+                   else multi.process_bulk(w, 1500))
             out_keep = res[-1]["symbols"]
             return sum(r["consumed"] for r in res), sum(r["tags"].size for r in res)
         if args.detector_only:
@@ -386,10 +392,12 @@ def main():
         # HIP events must sit on the stream the kernel is launched on: a detector handle created
         # under that stream (the native receiver keeps its own detector inside the library, so the
         # roofline leg uses a second, identically configured one)
-        roof_stream = torch.cuda.Stream() if sd is None else rx._streams[0]
+        own_detector = sd is None or not hasattr(sd, "correlate_only")
+        roof_stream = torch.cuda.Stream() if own_detector else rx._streams[0]
         with torch.cuda.stream(roof_stream):
-            if sd is None:
-                sd = pkg.SyncwordDetection(rrc, SYNCWORD, bpsk, -BINS, BINS, power_threshold=9.5, max_items=n_items)
+            if own_detector:
+                sd = pkg.SyncwordDetection(rrc, SYNCWORD, bpsk, -BINS, BINS, power_threshold=9.5, max_items=n_items,
+                                           n_channels=args.channels)
             sd.correlate_only(x)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -430,7 +438,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": (f"configs[2]: {args.channels} channels on one GPU, one batched SyncwordDetection + every "
-                                    "channel's own tag gate + CFC + SymbolFilter + wipe-off + Costas (MultiChannelPacketReceiver)"
+                                    "channel's own tag gate + CFC + SymbolFilter + wipe-off + Costas (gr4pm_multichannel_receiver)"
                                     if multi is not None else "SyncwordDetection only" if args.detector_only else
                                     "configs[1]: 1 channel/GPU, full RX front end (SyncwordDetection 9 bins FFT 2048 + tag "
                                     "gate + CFC + 32-arm RRC SymbolFilter + wipe-off + Costas)") +

@@ -150,6 +150,12 @@ class PacketReceiverParams(C.Structure):
                 ("header_alist", C.c_char_p)]
 
 
+class MultiChannelReceiverParams(C.Structure):
+    _fields_ = [("n_channels", C.c_size_t), ("samples_per_symbol", C.c_size_t), ("syncword_freq_bins", C.c_int),
+                ("syncword_threshold", C.c_float), ("costas_constellation", C.c_int), ("max_items", C.c_size_t),
+                ("tags_cap", C.c_size_t), ("workers", C.c_int)]
+
+
 class PacketReceiverResult(C.Structure):
     _fields_ = [("consumed", C.c_size_t), ("symbols", C.c_void_p), ("n_symbols", C.c_size_t), ("llr", C.c_void_p),
                 ("n_llr", C.c_size_t), ("detector_tags", C.c_void_p), ("n_detector_tags", C.c_size_t),
@@ -210,6 +216,8 @@ EXPORTS = [
     "gr4pm_crc_check_create", "gr4pm_crc_check_destroy", "gr4pm_crc_check_compute", "gr4pm_crc_check_process",
     "gr4pm_mapper_process", "gr4pm_burst_shaper_process",
     "gr4pm_packet_receiver_create", "gr4pm_packet_receiver_destroy", "gr4pm_packet_receiver_submit", "gr4pm_packet_receiver_announce",
+    "gr4pm_multichannel_receiver_create", "gr4pm_multichannel_receiver_destroy", "gr4pm_multichannel_receiver_announce",
+    "gr4pm_multichannel_receiver_process",
     "gr4pm_packet_receiver_collect", "gr4pm_packet_receiver_inflight",
 ]
 
@@ -349,6 +357,11 @@ def lib():
     L.gr4pm_packet_receiver_destroy.restype = None
     L.gr4pm_packet_receiver_submit.argtypes = [vp, vp, sz, vp, vp, sz, C.c_uint64, vp, sz, vp, sz, vp, sz]
     L.gr4pm_packet_receiver_announce.argtypes = [vp, vp, sz]
+    L.gr4pm_multichannel_receiver_create.argtypes = [C.POINTER(MultiChannelReceiverParams), C.POINTER(vp)]
+    L.gr4pm_multichannel_receiver_destroy.argtypes = [vp]
+    L.gr4pm_multichannel_receiver_destroy.restype = None
+    L.gr4pm_multichannel_receiver_announce.argtypes = [vp, vp, sz, sz]
+    L.gr4pm_multichannel_receiver_process.argtypes = [vp, vp, sz, sz, C.c_uint64, vp, sz, szp, szp, vp, szp, vp, szp]
     L.gr4pm_packet_receiver_collect.argtypes = [vp, C.POINTER(PacketReceiverResult)]
     L.gr4pm_packet_receiver_inflight.argtypes = [vp]
     L.gr4pm_packet_receiver_inflight.restype = sz

@@ -1440,6 +1440,55 @@ class MultiChannelPacketReceiver:
         return [res[c] for c in range(self.n_channels)]
 
 
+class NativeMultiChannelReceiver:
+    """gr4pm_multichannel_receiver: what MultiChannelPacketReceiver composes in Python, inside the
+    library (one batched detector, every channel's own chain on worker threads with a stream each).
+    process_bulk(x[n_channels, n], packet_length) -> one dict per channel."""
+
+    def __init__(self, n_channels, samples_per_symbol=4, syncword_freq_bins=4, syncword_threshold=9.5,
+                 costas_constellation="QPSK", max_items=1 << 22, tags_cap=4096, workers=12):
+        self.n_channels = n_channels
+        self.samples_per_symbol = samples_per_symbol
+        self.tags_cap = max(int(tags_cap), 64)
+        p = _abi.MultiChannelReceiverParams(n_channels, samples_per_symbol, syncword_freq_bins, syncword_threshold,
+                                            {"PILOT": 0, "BPSK": 1, "QPSK": 2}[costas_constellation], max_items,
+                                            self.tags_cap, workers)
+        self._h = C.c_void_p()
+        check(lib().gr4pm_multichannel_receiver_create(C.byref(p), C.byref(self._h)), "MultiChannelReceiver")
+
+    def announce(self, x):
+        x = _dev_c64(x)
+        assert x.dim() == 2 and x.shape[0] == self.n_channels
+        check(lib().gr4pm_multichannel_receiver_announce(self._h, x.data_ptr(), x.stride(0), x.shape[1]),
+              "MultiChannelReceiver.announce")
+
+    def process_bulk(self, x, packet_length=None):
+        torch = _torch()
+        x = _dev_c64(x)
+        assert x.dim() == 2 and x.shape[0] == self.n_channels
+        Cn, n = self.n_channels, x.shape[1]
+        stride = n // self.samples_per_symbol + self.tags_cap + 64
+        sym = torch.empty((Cn, stride), dtype=torch.complex64, device=x.device)
+        consumed = C.c_size_t(0)
+        n_sym, n_tags, n_det = (C.c_size_t * Cn)(), (C.c_size_t * Cn)(), (C.c_size_t * Cn)()
+        tags = np.zeros((Cn, self.tags_cap), dtype=TAG_DTYPE)
+        det = np.zeros((Cn, self.tags_cap), dtype=TAG_DTYPE)
+        check(lib().gr4pm_multichannel_receiver_process(
+            self._h, x.data_ptr(), x.stride(0), n, 0 if packet_length is None else int(packet_length),
+            sym.data_ptr(), stride, C.byref(consumed), n_sym, _np_ptr(tags), n_tags, _np_ptr(det), n_det),
+            "MultiChannelReceiver.process")
+        return [{"status": 0, "consumed": consumed.value, "symbols": sym[c, : n_sym[c]],
+                 "tags": tags[c, : n_tags[c]].copy(), "detector_tags": det[c, : n_det[c]].copy()} for c in range(Cn)]
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _release("gr4pm_multichannel_receiver_destroy", self._h)
+                self._h = None
+        except Exception:  # interpreter shutdown
+            pass
+
+
 class NativePacketReceiver:
     """gr4pm_packet_receiver: the same chain as PacketReceiver (front end, or soft_bits up to the
     LLR decoder) composed and pipelined in the C++ library -- stage threads, streams and

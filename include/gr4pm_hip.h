@@ -649,6 +649,38 @@ gr4pm_status gr4pm_packet_receiver_announce(gr4pm_packet_receiver* h, const gr4p
 gr4pm_status gr4pm_packet_receiver_collect(gr4pm_packet_receiver* h, gr4pm_packet_receiver_result* result);
 size_t gr4pm_packet_receiver_inflight(const gr4pm_packet_receiver* h);
 
+/* gr4pm_multichannel_receiver: BASELINE configs[2] -- n_channels independent receive chains on one
+ * GPU (front-end mode of gr4pm_packet_receiver, channel by channel).  One batched
+ * SyncwordDetection handle for all channels, then every channel's own SyncwordDetectionFilter /
+ * CoarseFrequencyCorrection / SymbolFilter / SyncwordWipeoff / CostasLoop, spread over `workers`
+ * threads with a stream each.  process() is synchronous. */
+typedef struct gr4pm_multichannel_receiver gr4pm_multichannel_receiver;
+typedef struct {
+    size_t n_channels;
+    size_t samples_per_symbol;
+    int syncword_freq_bins;
+    float syncword_threshold;
+    int costas_constellation; /* 0 PILOT, 1 BPSK, 2 QPSK */
+    size_t max_items;         /* per channel and call */
+    size_t tags_cap;          /* per channel and call */
+    int workers;
+} gr4pm_multichannel_receiver_params;
+gr4pm_status gr4pm_multichannel_receiver_create(const gr4pm_multichannel_receiver_params* params,
+                                                gr4pm_multichannel_receiver** out);
+void gr4pm_multichannel_receiver_destroy(gr4pm_multichannel_receiver* h);
+/* the detector's look-ahead (gr4pm_syncword_detection_announce) */
+gr4pm_status gr4pm_multichannel_receiver_announce(gr4pm_multichannel_receiver* h, const gr4pm_c64* in,
+                                                  size_t in_stride, size_t n_in);
+/* in: device [n_channels][in_stride], n_in items per channel.  packet_length: the parsed_header
+ * answer for every packet (0: "invalid_header").  out_symbols: device [n_channels][out_stride]
+ * (out_stride >= n_in / samples_per_symbol + tags + 2); n_symbols, n_tags, n_detector_tags: host
+ * [n_channels]; tags, detector_tags: host [n_channels][tags_cap] (may be NULL). */
+gr4pm_status gr4pm_multichannel_receiver_process(gr4pm_multichannel_receiver* h, const gr4pm_c64* in,
+                                                 size_t in_stride, size_t n_in, uint64_t packet_length,
+                                                 gr4pm_c64* out_symbols, size_t out_stride, size_t* consumed,
+                                                 size_t* n_symbols, gr4pm_tag* tags, size_t* n_tags,
+                                                 gr4pm_tag* detector_tags, size_t* n_detector_tags);
+
 /* ====================================================================================
  * Burst generator pieces (packet_transmitter_pdu.hpp:131-337): with
  * AdditiveScrambler, PackBits, InterpolatingFirFilter, Rotator and PfbArbResampler above they

@@ -1074,18 +1074,21 @@ def test_multichannel_packet_receiver_equals_single_channel_receivers(pkg):
         stream, _ = sig.qa_syncword_stream(2 * n // 4, locs, -0.02 + 0.04 * c / (C - 1), seed=40 + c)
         xs[c] = (0.7 * stream[: 2 * n] + sig.awgn(2 * n, 0.05, 90 + c)).astype(np.complex64)
     multi = pkg.MultiChannelPacketReceiver(C, max_items=n, workers=3)
+    native = pkg.NativeMultiChannelReceiver(C, max_items=n, tags_cap=256, workers=3)  # the same inside the library
     singles = [pkg.PacketReceiver(max_items=n) for _ in range(C)]
     xd = dev(xs)
     total_tags = 0
     for part in range(2):
         w = xd[:, part * n:(part + 1) * n].contiguous()
         got = multi.process_bulk(w, 300, tags_cap=256)
+        got_native = native.process_bulk(w, 300)
         for c in range(C):
             want = singles[c].process_bulk(w[c], 300, tags_cap=256)
-            assert got[c]["consumed"] == want["consumed"] > 0
-            assert same_tags(got[c]["detector_tags"], want["detector_tags"])
-            assert np.array_equal(got[c]["tags"], want["tags"])
-            assert np.array_equal(bits(host(got[c]["symbols"])), bits(host(want["symbols"])))
+            for g in (got[c], got_native[c]):
+                assert g["consumed"] == want["consumed"] > 0
+                assert same_tags(g["detector_tags"], want["detector_tags"])
+                assert same_tags(g["tags"], want["tags"])
+                assert np.array_equal(bits(host(g["symbols"])), bits(host(want["symbols"])))
             total_tags += got[c]["tags"].size
     assert total_tags >= 4 * C
 
