@@ -1,12 +1,15 @@
 // multichannel_receiver.hip -- gr4pm_multichannel_receiver: BASELINE configs[2], n_channels
 // independent receive chains on one GPU (packet_receiver.hpp:191-265 couples nothing across
-// receivers).  ONE batched SyncwordDetection handle (every launch covers all channels,
-// blockIdx.y = channel) followed, per channel, by that channel's own SyncwordDetectionFilter /
-// CoarseFrequencyCorrection + SymbolFilter (fused) / SyncwordWipeoff / CostasLoop handles with
-// their carried state.  The channels' chains are spread over worker threads with a HIP stream
-// each; their process() calls only queue kernels (gr4pm_set_deferred_sync) and a worker waits
-// once, after its last channel.  Front-end mode of gr4pm_packet_receiver, channel by channel:
-// same constants, same results (tests compare with one receiver per channel, bit for bit).
+// receivers).  What is serial per packet and costs the same whatever the batch holds runs ONCE
+// for all channels: one batched SyncwordDetection handle (blockIdx.y = channel), one
+// CoarseFrequencyCorrection handle with n_channels channels (the phasor checkpoints of every
+// channel in one launch, gr4pm_cfc_symbol_filter_plan_channels) and one CostasLoop handle with
+// n_channels channels (gr4pm_costas_loop_process_ragged).  In between, every channel has its
+// own SyncwordDetectionFilter, SymbolFilter (fused with its share of the CFC plan) and
+// SyncwordWipeoff; these are spread over worker threads with a HIP stream each, whose calls
+// only queue kernels (gr4pm_set_deferred_sync).  Front-end mode of gr4pm_packet_receiver,
+// channel by channel: same constants, same results (tests compare with one receiver per
+// channel, bit for bit).
 #include <algorithm>
 #include <cmath>
 #include <condition_variable>
@@ -26,17 +29,23 @@ struct gr4pm_multichannel_receiver {
     hipStream_t sd_stream = nullptr;
     struct Chain {
         gr4pm_syncword_detection_filter* sdf = nullptr;
-        gr4pm_rotator* cfc = nullptr;
         gr4pm_symbol_filter* symf = nullptr;
         gr4pm_syncword_wipeoff* wipe = nullptr;
-        gr4pm_costas_loop* costas = nullptr;
-        DevBuf<gr4pm_c64> sym;
         std::vector<gr4pm_tag> tags, sym_tags;
+        size_t n_acc = 0, n_sym_tags = 0, produced = 0;
         std::vector<uint64_t> idx;
         std::vector<gr4pm_header_msg> msgs;
         std::vector<uint8_t> accepted;
     };
     std::unique_ptr<Chain[]> chains; // [n_channels] (DevBuf members: neither copied nor moved)
+    gr4pm_rotator* cfc = nullptr;      // n_channels channels
+    gr4pm_costas_loop* costas = nullptr; // n_channels channels
+    hipStream_t batch_stream = nullptr;  // the two batched handles
+    int plan = -1;
+    DevBuf<gr4pm_c64> symall;            // symbol filter outputs, [n_channels][out_stride]
+    std::vector<gr4pm_tag> all_tags;     // accepted tags / symbol tags of all channels, concatenated
+    std::vector<uint32_t> all_channel;
+    std::vector<size_t> produced;
     std::vector<hipStream_t> streams; // one per worker
     DevBuf<gr4pm_c64> y;              // SyncwordDetection's delayed output, [n_channels][y_stride]
     size_t y_stride = 0;
@@ -68,36 +77,16 @@ struct gr4pm_multichannel_receiver {
 gr4pm_status gr4pm_multichannel_receiver::run_channel(size_t c)
 {
     Chain& ch = chains[c];
-    const gr4pm_tag* dt = det_tags.data() + c * p.tags_cap;
-    const size_t nd = n_det[c];
-    // SyncwordDetectionFilter: the samples pass unchanged, the tags are gated
-    ch.idx.resize(nd);
-    ch.msgs.assign(std::max<size_t>(nd, 1), gr4pm_header_msg{ job.packet_length, job.packet_length == 0 ? 1 : 0 });
-    for (size_t i = 0; i < nd; ++i) ch.idx[i] = job.base + dt[i].index;
-    ch.accepted.assign(std::max<size_t>(nd, 1), 0);
-    size_t used = 0;
-    GR4PM_TRY(gr4pm_syncword_detection_filter_gate(ch.sdf, ch.idx.data(), nd, ch.msgs.data(), nd, 1, ch.accepted.data(),
-                                                   &used));
-    size_t n_acc = 0;
-    for (size_t i = 0; i < nd; ++i)
-        if (ch.accepted[i]) ch.tags[n_acc++] = dt[i];
-    const size_t cap = job.consumed / p.samples_per_symbol + n_acc + 2;
-    if (ch.sym.n < cap) GR4PM_TRY(ch.sym.alloc(cap));
-    size_t n_out_tags = 0, consumed = 0, produced = 0;
-    GR4PM_TRY(gr4pm_cfc_symbol_filter_process(ch.cfc, ch.symf, y.p + c * y_stride, job.consumed, ch.sym.p, cap,
-                                              ch.tags.data(), n_acc, ch.sym_tags.data(), ch.sym_tags.size(),
-                                              &n_out_tags, &consumed, &produced));
-    GR4PM_TRY(gr4pm_syncword_wipeoff_process(ch.wipe, ch.sym.p, produced, ch.sym.p, ch.sym_tags.data(), n_out_tags));
-    if (job.out_stride < produced) {
-        set_error("out_stride %zu < %zu symbols", job.out_stride, produced);
-        return GR4PM_INSUFFICIENT_OUTPUT_ITEMS;
-    }
-    GR4PM_TRY(gr4pm_costas_loop_process(ch.costas, ch.sym.p, produced, produced, job.out_symbols + c * job.out_stride,
-                                        ch.sym_tags.data(), nullptr, n_out_tags));
-    job.n_symbols[c] = produced;
-    if (job.n_tags) job.n_tags[c] = n_out_tags;
-    if (job.tags)
-        std::memcpy(job.tags + c * p.tags_cap, ch.sym_tags.data(), std::min(n_out_tags, p.tags_cap) * sizeof(gr4pm_tag));
+    const size_t cap = job.out_stride;
+    size_t n_out_tags = 0, consumed = 0, produced_c = 0;
+    GR4PM_TRY(gr4pm_cfc_symbol_filter_run_channel(cfc, plan, c, ch.symf, y.p + c * y_stride, job.consumed,
+                                                  symall.p + c * job.out_stride, cap, ch.tags.data(), ch.n_acc,
+                                                  ch.sym_tags.data(), ch.sym_tags.size(), &n_out_tags, &consumed,
+                                                  &produced_c));
+    GR4PM_TRY(gr4pm_syncword_wipeoff_process(ch.wipe, symall.p + c * job.out_stride, produced_c,
+                                             symall.p + c * job.out_stride, ch.sym_tags.data(), n_out_tags));
+    ch.n_sym_tags = n_out_tags;
+    ch.produced = produced_c;
     return GR4PM_OK;
 }
 
@@ -193,22 +182,24 @@ gr4pm_status gr4pm_multichannel_receiver_create(const gr4pm_multichannel_receive
     for (int i = 0; i < 64; ++i) bipolar[i] = syncword[i] ? -1.0f : 1.0f;
     h->chains.reset(new (std::nothrow) gr4pm_multichannel_receiver::Chain[p->n_channels]);
     if (!h->chains) return bail(GR4PM_ERR_NOMEM);
+    if (hipStreamCreateWithPriority(&h->batch_stream, hipStreamNonBlocking, greatest) != hipSuccess) return bail(GR4PM_ERR_HIP);
+    gr4pm_rotator_params rp{ 1, 0.0f, (rrc.size() - 1) / 2 + sps, p->n_channels, h->batch_stream };
+    if ((st = gr4pm_rotator_create(&rp, &h->cfc)) != GR4PM_OK) return bail(st);
+    gr4pm_costas_loop_params cp{ 0.01, p->costas_constellation, p->n_channels, h->batch_stream };
+    if ((st = gr4pm_costas_loop_create(&cp, &h->costas)) != GR4PM_OK) return bail(st);
     for (size_t c = 0; c < p->n_channels; ++c) {
         auto& ch = h->chains[c];
         hipStream_t s = h->streams[c % n_workers];
         gr4pm_syncword_detection_filter_params fp{ sps, 64, 128, s };
         if ((st = gr4pm_syncword_detection_filter_create(&fp, &ch.sdf)) != GR4PM_OK) return bail(st);
-        gr4pm_rotator_params rp{ 1, 0.0f, (rrc.size() - 1) / 2 + sps, 1, s };
-        if ((st = gr4pm_rotator_create(&rp, &ch.cfc)) != GR4PM_OK) return bail(st);
         gr4pm_symbol_filter_params fsp{ sps, pfb.data(), pfb.size(), arms, rrc.size() - 1, 0, s };
         if ((st = gr4pm_symbol_filter_create(&fsp, &ch.symf)) != GR4PM_OK) return bail(st);
         gr4pm_syncword_wipeoff_params wp{ bipolar, 64, s };
         if ((st = gr4pm_syncword_wipeoff_create(&wp, &ch.wipe)) != GR4PM_OK) return bail(st);
-        gr4pm_costas_loop_params cp{ 0.01, p->costas_constellation, 1, s };
-        if ((st = gr4pm_costas_loop_create(&cp, &ch.costas)) != GR4PM_OK) return bail(st);
         ch.tags.resize(h->p.tags_cap);
         ch.sym_tags.resize(h->p.tags_cap + 64);
     }
+    h->produced.assign(p->n_channels, 0);
     h->y_stride = (p->max_items + 63) & ~size_t{ 63 };
     if ((st = h->y.alloc(h->y_stride * p->n_channels)) != GR4PM_OK) return bail(st);
     h->det_tags.resize(p->n_channels * h->p.tags_cap);
@@ -232,11 +223,12 @@ void gr4pm_multichannel_receiver_destroy(gr4pm_multichannel_receiver* h)
     for (size_t c = 0; h->chains && c < h->p.n_channels; ++c) {
         auto& ch = h->chains[c];
         gr4pm_syncword_detection_filter_destroy(ch.sdf);
-        gr4pm_rotator_destroy(ch.cfc);
         gr4pm_symbol_filter_destroy(ch.symf);
         gr4pm_syncword_wipeoff_destroy(ch.wipe);
-        gr4pm_costas_loop_destroy(ch.costas);
     }
+    gr4pm_rotator_destroy(h->cfc);
+    gr4pm_costas_loop_destroy(h->costas);
+    if (h->batch_stream) (void)hipStreamDestroy(h->batch_stream);
     for (auto s : h->streams)
         if (s) (void)hipStreamDestroy(s);
     if (h->sd_stream) (void)hipStreamDestroy(h->sd_stream);
@@ -275,14 +267,66 @@ gr4pm_status gr4pm_multichannel_receiver_process(gr4pm_multichannel_receiver* h,
     h->job.n_symbols = n_symbols;
     h->job.tags = tags;
     h->job.n_tags = n_tags;
-    std::unique_lock<std::mutex> l(h->m);
-    h->status = GR4PM_OK;
-    h->pending = static_cast<unsigned>(h->workers.size());
-    ++h->generation;
-    h->cv_go.notify_all();
-    h->cv_done.wait(l, [&] { return h->pending == 0; });
-    if (h->status != GR4PM_OK) set_error("%s", h->error);
-    return h->status;
+    const size_t C = h->p.n_channels;
+    if (out_stride < n_done / h->p.samples_per_symbol + h->p.tags_cap + 2) {
+        set_error("out_stride %zu too small for %zu items per channel", out_stride, n_done);
+        return GR4PM_INSUFFICIENT_OUTPUT_ITEMS;
+    }
+    if (h->symall.n < C * out_stride) GR4PM_TRY(h->symall.alloc(C * out_stride));
+    // SyncwordDetectionFilter of every channel (host only): the samples pass unchanged, the tags are gated
+    h->all_tags.clear();
+    h->all_channel.clear();
+    for (size_t c = 0; c < C; ++c) {
+        auto& ch = h->chains[c];
+        const gr4pm_tag* dt = h->det_tags.data() + c * h->p.tags_cap;
+        const size_t nd = h->n_det[c];
+        ch.idx.resize(nd);
+        ch.msgs.assign(std::max<size_t>(nd, 1), gr4pm_header_msg{ packet_length, packet_length == 0 ? 1 : 0 });
+        for (size_t i = 0; i < nd; ++i) ch.idx[i] = h->job.base + dt[i].index;
+        ch.accepted.assign(std::max<size_t>(nd, 1), 0);
+        size_t used = 0;
+        GR4PM_TRY(gr4pm_syncword_detection_filter_gate(ch.sdf, ch.idx.data(), nd, ch.msgs.data(), nd, 1,
+                                                       ch.accepted.data(), &used));
+        ch.n_acc = 0;
+        for (size_t i = 0; i < nd; ++i)
+            if (ch.accepted[i]) {
+                ch.tags[ch.n_acc++] = dt[i];
+                h->all_tags.push_back(dt[i]);
+                h->all_channel.push_back(static_cast<uint32_t>(c));
+            }
+    }
+    // CoarseFrequencyCorrection of all channels: one plan, one launch of the serial checkpoints
+    GR4PM_TRY(gr4pm_cfc_symbol_filter_plan_channels(h->cfc, n_done, h->all_tags.data(), h->all_channel.data(),
+                                                    h->all_tags.size(), &h->plan));
+    // every channel's SymbolFilter + SyncwordWipeoff on the workers
+    {
+        std::unique_lock<std::mutex> l(h->m);
+        h->status = GR4PM_OK;
+        h->pending = static_cast<unsigned>(h->workers.size());
+        ++h->generation;
+        h->cv_go.notify_all();
+        h->cv_done.wait(l, [&] { return h->pending == 0; });
+        if (h->status != GR4PM_OK) {
+            set_error("%s", h->error);
+            return h->status;
+        }
+    }
+    // CostasLoop of all channels: one launch
+    h->all_tags.clear();
+    h->all_channel.clear();
+    for (size_t c = 0; c < C; ++c) {
+        auto& ch = h->chains[c];
+        h->produced[c] = ch.produced;
+        n_symbols[c] = ch.produced;
+        if (n_tags) n_tags[c] = ch.n_sym_tags;
+        if (tags) std::memcpy(tags + c * h->p.tags_cap, ch.sym_tags.data(), std::min(ch.n_sym_tags, h->p.tags_cap) * sizeof(gr4pm_tag));
+        for (size_t i = 0; i < ch.n_sym_tags; ++i) {
+            h->all_tags.push_back(ch.sym_tags[i]);
+            h->all_channel.push_back(static_cast<uint32_t>(c));
+        }
+    }
+    return gr4pm_costas_loop_process_ragged(h->costas, h->symall.p, out_stride, h->produced.data(), out_symbols,
+                                            h->all_tags.data(), h->all_channel.data(), h->all_tags.size());
 }
 
 } // extern "C"

@@ -782,6 +782,7 @@ struct gr4pm_rotator {
         DevBuf<unsigned> seg_counter0;
         unsigned n_segs = 0;
         size_t n_in = 0;
+        std::vector<unsigned> seg_first; // [n_channels + 1]: the segments of channel c are [seg_first[c], seg_first[c + 1])
     } plans[GR4PM_CFC_PLANS];
     int plan_cur = 0;
     std::vector<float> next_freq;     // per channel, coarse_frequency_correction.hpp:44
@@ -919,6 +920,9 @@ static gr4pm_status rotator_plan(gr4pm_rotator* h, size_t n, const gr4pm_tag* ta
     auto& pl = h->plans[h->plan_cur];
     pl.n_segs = n_segs;
     pl.n_in = n;
+    pl.seg_first.assign(h->n_channels + 1, n_segs); // segments were generated channel by channel
+    for (unsigned i = n_segs; i-- > 0;) pl.seg_first[segs[i].channel] = i;
+    for (size_t c = h->n_channels; c-- > 0;) pl.seg_first[c] = std::min(pl.seg_first[c], pl.seg_first[c + 1]);
     GR4PM_TRY(upload_vec(pl.segs, segs, s));
     if (pl.ck.n < ck) GR4PM_TRY(pl.ck.alloc(static_cast<size_t>(ck) * 2));
     if (pl.seg_incr.n < n_segs) {
@@ -1070,18 +1074,23 @@ gr4pm_status gr4pm_costas_loop_set(gr4pm_costas_loop* h, double loop_bandwidth, 
     return GR4PM_OK;
 }
 
-gr4pm_status gr4pm_costas_loop_process(gr4pm_costas_loop* h, const gr4pm_c64* in, size_t stride, size_t n,
-                                       gr4pm_c64* out, const gr4pm_tag* tags, const uint32_t* tag_channel,
-                                       size_t n_tags)
+// n_of(c): items of channel c in this call (channels with 0 items keep their state)
+extern "C++" {
+template <typename NOf>
+static gr4pm_status costas_process_impl(gr4pm_costas_loop* h, const gr4pm_c64* in, size_t stride, NOf n_of,
+                                        gr4pm_c64* out, const gr4pm_tag* tags, const uint32_t* tag_channel,
+                                        size_t n_tags)
 {
-    if (!h) return GR4PM_ERR_INVALID;
-    if (n == 0) return GR4PM_OK;
-    if (!in || !out) {
-        set_error("null sample pointer");
-        return GR4PM_ERR_INVALID;
-    }
     std::vector<CostasSeg> segs;
     for (size_t c = 0; c < h->n_channels; ++c) {
+        const size_t n = n_of(c);
+        if (n == 0) { // a piece of length 0 that only hands the carried state on to the other slot
+            CostasSeg g{};
+            g.channel = static_cast<unsigned>(c);
+            g.last = 1;
+            segs.push_back(g);
+            continue;
+        }
         size_t pos = 0;
         int mode = 0;
         float phase0 = 0.0f;
@@ -1129,6 +1138,33 @@ gr4pm_status gr4pm_costas_loop_process(gr4pm_costas_loop* h, const gr4pm_c64* in
     GR4PM_HIP_TRY(hipGetLastError());
     GR4PM_HIP_TRY(final_sync(s));
     return GR4PM_OK;
+}
+} // extern "C++"
+
+gr4pm_status gr4pm_costas_loop_process(gr4pm_costas_loop* h, const gr4pm_c64* in, size_t stride, size_t n,
+                                       gr4pm_c64* out, const gr4pm_tag* tags, const uint32_t* tag_channel,
+                                       size_t n_tags)
+{
+    if (!h) return GR4PM_ERR_INVALID;
+    if (n == 0) return GR4PM_OK;
+    if (!in || !out) {
+        set_error("null sample pointer");
+        return GR4PM_ERR_INVALID;
+    }
+    return costas_process_impl(h, in, stride, [n](size_t) { return n; }, out, tags, tag_channel, n_tags);
+}
+
+gr4pm_status gr4pm_costas_loop_process_ragged(gr4pm_costas_loop* h, const gr4pm_c64* in, size_t stride,
+                                              const size_t* n_per_channel, gr4pm_c64* out, const gr4pm_tag* tags,
+                                              const uint32_t* tag_channel, size_t n_tags)
+{
+    if (!h || !n_per_channel) return GR4PM_ERR_INVALID;
+    if (!in || !out) {
+        set_error("null sample pointer");
+        return GR4PM_ERR_INVALID;
+    }
+    return costas_process_impl(h, in, stride, [n_per_channel](size_t c) { return n_per_channel[c]; }, out, tags,
+                               tag_channel, n_tags);
 }
 
 gr4pm_status gr4pm_costas_loop_process_packets(gr4pm_costas_loop* h, const gr4pm_c64* in, size_t n,
@@ -1899,27 +1935,51 @@ gr4pm_status gr4pm_symbol_filter_process(gr4pm_symbol_filter* h, const void* in,
                               consumed, produced, nullptr);
 }
 
-gr4pm_status gr4pm_cfc_symbol_filter_plan(gr4pm_rotator* cfc, size_t n_in, const gr4pm_tag* tags_in,
-                                          size_t n_tags_in, int* plan)
+gr4pm_status gr4pm_cfc_symbol_filter_plan_channels(gr4pm_rotator* cfc, size_t n_in, const gr4pm_tag* tags_in,
+                                                   const uint32_t* tag_channel, size_t n_tags_in, int* plan)
 {
     if (!cfc || !plan) return GR4PM_ERR_INVALID;
     *plan = -1;
-    if (cfc->mode != 1 || cfc->n_channels != 1) {
-        set_error("fused call needs a single-channel CoarseFrequencyCorrection");
+    if (cfc->mode != 1) {
+        set_error("fused call needs a CoarseFrequencyCorrection handle");
+        return GR4PM_ERR_INVALID;
+    }
+    if (!tag_channel && cfc->n_channels != 1 && n_tags_in) {
+        set_error("tag_channel is required with more than one channel");
         return GR4PM_ERR_INVALID;
     }
     if (n_in == 0) return GR4PM_OK;
     std::vector<RotSeg> segs;
-    GR4PM_TRY(rotator_plan(cfc, n_in, tags_in, nullptr, n_tags_in, segs)); // checkpoints on the CFC's stream
+    GR4PM_TRY(rotator_plan(cfc, n_in, tags_in, tag_channel, n_tags_in, segs)); // checkpoints on the CFC's stream
     *plan = cfc->plan_cur;
     GR4PM_HIP_TRY(final_sync(cfc->stream));
     return GR4PM_OK;
+}
+
+gr4pm_status gr4pm_cfc_symbol_filter_plan(gr4pm_rotator* cfc, size_t n_in, const gr4pm_tag* tags_in,
+                                          size_t n_tags_in, int* plan)
+{
+    if (cfc && cfc->n_channels != 1) {
+        set_error("fused call needs a single-channel CoarseFrequencyCorrection (or ..._plan_channels)");
+        return GR4PM_ERR_INVALID;
+    }
+    return gr4pm_cfc_symbol_filter_plan_channels(cfc, n_in, tags_in, nullptr, n_tags_in, plan);
 }
 
 gr4pm_status gr4pm_cfc_symbol_filter_run(gr4pm_rotator* cfc, int plan, gr4pm_symbol_filter* sf,
                                          const gr4pm_c64* in, size_t n_in, gr4pm_c64* out, size_t out_cap,
                                          const gr4pm_tag* tags_in, size_t n_tags_in, gr4pm_tag* tags_out,
                                          size_t tags_cap, size_t* n_tags_out, size_t* consumed, size_t* produced)
+{
+    return gr4pm_cfc_symbol_filter_run_channel(cfc, plan, 0, sf, in, n_in, out, out_cap, tags_in, n_tags_in, tags_out,
+                                               tags_cap, n_tags_out, consumed, produced);
+}
+
+gr4pm_status gr4pm_cfc_symbol_filter_run_channel(gr4pm_rotator* cfc, int plan, size_t channel, gr4pm_symbol_filter* sf,
+                                                 const gr4pm_c64* in, size_t n_in, gr4pm_c64* out, size_t out_cap,
+                                                 const gr4pm_tag* tags_in, size_t n_tags_in, gr4pm_tag* tags_out,
+                                                 size_t tags_cap, size_t* n_tags_out, size_t* consumed,
+                                                 size_t* produced)
 {
     if (!cfc || !sf || !consumed || !produced) return GR4PM_ERR_INVALID;
     *consumed = *produced = 0;
@@ -1943,12 +2003,18 @@ gr4pm_status gr4pm_cfc_symbol_filter_run(gr4pm_rotator* cfc, int plan, gr4pm_sym
         return GR4PM_INSUFFICIENT_OUTPUT_ITEMS;
     }
     const auto& pl = cfc->plans[plan];
+    if (channel >= cfc->n_channels || pl.seg_first.size() != cfc->n_channels + 1) {
+        set_error("channel %zu outside the rotation plan", channel);
+        return GR4PM_ERR_INVALID;
+    }
+    // the channel's own segments (they tile its [0, n_in)); checkpoint slots are plan-wide
+    const unsigned first = pl.seg_first[channel];
     CfcDev f;
-    f.segs = pl.segs.p;
+    f.segs = pl.segs.p + first;
     f.ck = pl.ck.p;
-    f.seg_incr = pl.seg_incr.p;
-    f.seg_counter0 = pl.seg_counter0.p;
-    f.n_segs = pl.n_segs;
+    f.seg_incr = pl.seg_incr.p + first;
+    f.seg_counter0 = pl.seg_counter0.p + first;
+    f.n_segs = pl.seg_first[channel + 1] - first;
     const gr4pm_status st = symbol_filter_impl(sf, in, n_in, out, out_cap, tags_in, n_tags_in, tags_out, tags_cap,
                                                n_tags_out, consumed, produced, &f);
     if (st == GR4PM_OK && *consumed != n_in) {

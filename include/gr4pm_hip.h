@@ -235,6 +235,11 @@ gr4pm_status gr4pm_costas_loop_set(gr4pm_costas_loop* h, double loop_bandwidth,
 gr4pm_status gr4pm_costas_loop_process(gr4pm_costas_loop* h, const gr4pm_c64* in, size_t stride,
                                        size_t n, gr4pm_c64* out, const gr4pm_tag* tags,
                                        const uint32_t* tag_channel, size_t n_tags);
+/* the same with a different item count per channel (n_per_channel: host [n_channels]) */
+gr4pm_status gr4pm_costas_loop_process_ragged(gr4pm_costas_loop* h, const gr4pm_c64* in, size_t stride,
+                                              const size_t* n_per_channel, gr4pm_c64* out,
+                                              const gr4pm_tag* tags, const uint32_t* tag_channel,
+                                              size_t n_tags);
 
 /* ------------------------------------------------------------------------------------
  * SyncwordWipeoff<c64,float> -- syncword_wipeoff.hpp:12-91
@@ -319,6 +324,17 @@ gr4pm_status gr4pm_cfc_symbol_filter_process(gr4pm_rotator* cfc, gr4pm_symbol_fi
 #define GR4PM_CFC_PLANS 8
 gr4pm_status gr4pm_cfc_symbol_filter_plan(gr4pm_rotator* cfc, size_t n_in, const gr4pm_tag* tags_in,
                                           size_t n_tags_in, int* plan);
+/* many channels: ONE CoarseFrequencyCorrection handle with n_channels channels plans all of them
+ * in one launch (tags of all channels, tag_channel[i] = channel of tags_in[i], indices relative
+ * to the channel's first item); every channel's own SymbolFilter then runs with
+ * _run_channel(plan, channel, ...), `in` pointing at that channel's items */
+gr4pm_status gr4pm_cfc_symbol_filter_plan_channels(gr4pm_rotator* cfc, size_t n_in, const gr4pm_tag* tags_in,
+                                                   const uint32_t* tag_channel, size_t n_tags_in, int* plan);
+gr4pm_status gr4pm_cfc_symbol_filter_run_channel(gr4pm_rotator* cfc, int plan, size_t channel,
+                                                 gr4pm_symbol_filter* sf, const gr4pm_c64* in, size_t n_in,
+                                                 gr4pm_c64* out, size_t out_cap, const gr4pm_tag* tags_in,
+                                                 size_t n_tags_in, gr4pm_tag* tags_out, size_t tags_cap,
+                                                 size_t* n_tags_out, size_t* consumed, size_t* produced);
 gr4pm_status gr4pm_cfc_symbol_filter_run(gr4pm_rotator* cfc, int plan, gr4pm_symbol_filter* sf,
                                          const gr4pm_c64* in, size_t n_in, gr4pm_c64* out,
                                          size_t out_cap, const gr4pm_tag* tags_in, size_t n_tags_in,
