@@ -11,7 +11,10 @@
 // channel by channel: same constants, same results (tests compare with one receiver per
 // channel, bit for bit).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <condition_variable>
 #include <cstring>
 #include <memory>
@@ -251,6 +254,10 @@ gr4pm_status gr4pm_multichannel_receiver_process(gr4pm_multichannel_receiver* h,
     if (!h || !in || !out_symbols || !consumed || !n_symbols) return GR4PM_ERR_INVALID;
     *consumed = 0;
     for (size_t c = 0; c < h->p.n_channels; ++c) n_symbols[c] = 0;
+    static const bool timing = getenv("GR4PM_MC_TIMING") != nullptr; // wall time of the four phases, to stderr
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    const auto t0 = now();
     size_t n_done = 0;
     const gr4pm_status st = gr4pm_syncword_detection_process(h->sd, in, in_stride, n_in, h->y.p, h->y_stride, &n_done,
                                                              h->det_tags.data(), h->p.tags_cap, h->n_det.data());
@@ -259,6 +266,7 @@ gr4pm_status gr4pm_multichannel_receiver_process(gr4pm_multichannel_receiver* h,
     if (detector_tags) std::memcpy(detector_tags, h->det_tags.data(), h->det_tags.size() * sizeof(gr4pm_tag));
     if (n_detector_tags)
         for (size_t c = 0; c < h->p.n_channels; ++c) n_detector_tags[c] = h->n_det[c];
+    const auto t1 = now();
     h->job.consumed = n_done;
     h->job.base = gr4pm_syncword_detection_items_consumed(h->sd) - n_done;
     h->job.packet_length = packet_length;
@@ -298,6 +306,7 @@ gr4pm_status gr4pm_multichannel_receiver_process(gr4pm_multichannel_receiver* h,
     // CoarseFrequencyCorrection of all channels: one plan, one launch of the serial checkpoints
     GR4PM_TRY(gr4pm_cfc_symbol_filter_plan_channels(h->cfc, n_done, h->all_tags.data(), h->all_channel.data(),
                                                     h->all_tags.size(), &h->plan));
+    const auto t2 = now();
     // every channel's SymbolFilter + SyncwordWipeoff on the workers
     {
         std::unique_lock<std::mutex> l(h->m);
@@ -311,6 +320,7 @@ gr4pm_status gr4pm_multichannel_receiver_process(gr4pm_multichannel_receiver* h,
             return h->status;
         }
     }
+    const auto t3 = now();
     // CostasLoop of all channels: one launch
     h->all_tags.clear();
     h->all_channel.clear();
@@ -325,8 +335,13 @@ gr4pm_status gr4pm_multichannel_receiver_process(gr4pm_multichannel_receiver* h,
             h->all_channel.push_back(static_cast<uint32_t>(c));
         }
     }
-    return gr4pm_costas_loop_process_ragged(h->costas, h->symall.p, out_stride, h->produced.data(), out_symbols,
-                                            h->all_tags.data(), h->all_channel.data(), h->all_tags.size());
+    const gr4pm_status cst = gr4pm_costas_loop_process_ragged(h->costas, h->symall.p, out_stride, h->produced.data(),
+                                                              out_symbols, h->all_tags.data(), h->all_channel.data(),
+                                                              h->all_tags.size());
+    if (timing)
+        fprintf(stderr, "[gr4pm multichannel] detector %.0f us, gate + CFC plan %.0f us, symbol filters %.0f us, Costas %.0f us\n",
+                us(t0, t1), us(t1, t2), us(t2, t3), us(t3, now()));
+    return cst;
 }
 
 } // extern "C"
