@@ -1725,6 +1725,59 @@ def test_native_packet_receiver_many_batches_pipelined_equals_sequential(pkg, so
                 assert a["llr"].cpu().numpy().tobytes() == b["llr"].cpu().numpy().tobytes()
 
 
+def test_native_packet_receiver_decode_many_batches_pipelined_equals_sequential(pkg):
+    """the same for the complete receiver (decode_headers: pass A, gate, symbol filter, control
+    blocks, header loop and payload tail are six stages on six threads): forty batches whose cuts
+    land inside headers and payloads; header messages, packet bytes and CRC verdicts are those of
+    the batch-by-batch run, and every transmitted packet comes back"""
+    rng = np.random.default_rng(41)
+    payloads = [rng.integers(0, 256, int(n)).astype(np.uint8).tobytes() for n in rng.integers(20, 600, 260)]
+    gaps = rng.integers(800, 3000, len(payloads))
+    x = pkg.BurstGenerator().stream(payloads, gaps, freq_error=-0.008, esn0_db=20.0, seed=42)
+    n_total = x.numel()
+    chunks, pos = [], 0
+    while pos + 40000 <= n_total:
+        take = min(int(rng.integers(30000, 90000)), n_total - pos)
+        chunks.append(x[pos:pos + take])
+        pos += ((take - 2048) // 1752 + 1) * 1752
+    assert len(chunks) >= 30
+
+    def run(pipelined):
+        rx = pkg.NativePacketReceiver(max_items=90000, tags_cap=1024, pipelined=pipelined, decode_headers=True)
+        out, announced = [], 0
+        for k, c in enumerate(chunks):
+            while pipelined and announced < min(k + 2, len(chunks) - 1):
+                announced += 1
+                rx.announce(chunks[announced])
+            r = rx.process_bulk(c)
+            if r is not None:
+                out.append(r)
+        return out + rx.flush()
+
+    def packets(results):
+        got = []
+        for r in results:
+            data, p = r["packets"].cpu().numpy(), 0
+            for ln in r["packet_lengths"]:
+                if ln > 0:
+                    got.append(data[p:p + int(ln)].tobytes())
+                    p += int(ln)
+        return got
+
+    want = run(False)
+    assert sum(r["header_mismatches"] for r in want) == 0
+    sent = [p for p in payloads][: len(packets(want))]
+    assert len(sent) >= len(payloads) - 3 and packets(want) == sent
+    for _ in range(3):
+        got = run(True)
+        assert len(got) == len(want)
+        for a, b in zip(want, got):
+            assert a["consumed"] == b["consumed"] and b["header_mismatches"] == 0
+            assert np.array_equal(a["header_messages"], b["header_messages"])
+            assert np.array_equal(a["packet_lengths"], b["packet_lengths"])
+            assert np.array_equal(a["packets"].cpu().numpy(), b["packets"].cpu().numpy())
+
+
 @pytest.mark.parametrize("mode", ["one_call", "three_calls", "pipelined"])
 def test_native_packet_receiver_decodes_headers_and_packets(pkg, mode):
     """gr4pm_packet_receiver with decode_headers: the whole receiver inside the C++ library, IQ samples
