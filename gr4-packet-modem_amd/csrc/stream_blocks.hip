@@ -475,7 +475,11 @@ struct SymRun {
     unsigned wg0;   // first workgroup of the run (workgroups never straddle runs)
     unsigned pad;
 };
-// One workgroup = up to 256 consecutive output symbols of ONE run.  The inputs of those symbols
+#ifndef GR4PM_SYM_PER_WG
+#define GR4PM_SYM_PER_WG 256
+#endif
+constexpr unsigned kSymPerWg = GR4PM_SYM_PER_WG; // output symbols (= threads) per workgroup
+// One workgroup = up to kSymPerWg consecutive output symbols of ONE run.  The inputs of those symbols
 // are one contiguous span (255*sps + arm_size items): it is staged into LDS with coalesced
 // loads and every thread then reads its arm_size items from LDS (the MAC order of the
 // reference, std::inner_product, m ascending, is kept: bit-exact).
@@ -546,10 +550,10 @@ __global__ void k_symf_wg_plan(const SymRun* __restrict__ runs, unsigned n_runs,
         else hi = mid - 1;
     }
     const SymRun r = runs[lo];
-    const unsigned first = (w - r.wg0) * 256u;
+    const unsigned first = (w - r.wg0) * kSymPerWg;
     SymWg p;
     p.o0 = r.out0 + first;
-    p.count = min(256u, r.count - first);
+    p.count = min(kSymPerWg, r.count - first);
     p.lo_item = r.in0 + static_cast<long long>(first) * sps - (arm_size - 1);
     p.arm = r.arm;
     p.scale = r.scale;
@@ -565,7 +569,7 @@ __device__ __forceinline__ unsigned raw_slot(unsigned i) { return i + i / kRotCh
 // SPS > 0: samples_per_symbol known at compile time (divisions become shifts / constants);
 // SPS == 0: run-time value.
 template <typename T, int SPS, bool CFC>
-__global__ __launch_bounds__(256) void k_symbol_filter(const T* __restrict__ in, const T* __restrict__ carry,
+__global__ __launch_bounds__(kSymPerWg) void k_symbol_filter(const T* __restrict__ in, const T* __restrict__ carry,
                                                        unsigned cap, const float* __restrict__ taps,
                                                        unsigned arm_size, unsigned sps_rt,
                                                        const SymWg* __restrict__ plan, T* __restrict__ out,
@@ -578,14 +582,14 @@ __global__ __launch_bounds__(256) void k_symbol_filter(const T* __restrict__ in,
     const unsigned span = (p.count - 1) * sps + arm_size;
     // tile is stored phase-major: item i lives at (i % sps) * pitch + i / sps, so that for a
     // fixed tap m the 64 lanes (items sps apart) read consecutive LDS words
-    const unsigned pitch = (256 * sps + arm_size) / sps + 2;
+    const unsigned pitch = (kSymPerWg * sps + arm_size) / sps + 2;
     // the arm is the same for the whole workgroup: its taps go to LDS (broadcast reads)
     float* s_arm = reinterpret_cast<float*>(tile + pitch * sps);
-    for (unsigned m = threadIdx.x; m < arm_size; m += 256) s_arm[m] = taps[static_cast<size_t>(p.arm) * arm_size + m];
+    for (unsigned m = threadIdx.x; m < arm_size; m += kSymPerWg) s_arm[m] = taps[static_cast<size_t>(p.arm) * arm_size + m];
     if constexpr (CFC) {
         // 1. raw items, coalesced, into LDS (history items are stored rotated: straight to the tile)
         cf* raw = reinterpret_cast<cf*>(s_arm + ((arm_size + 1) & ~1u));
-        for (unsigned i = threadIdx.x; i < span; i += 256) {
+        for (unsigned i = threadIdx.x; i < span; i += kSymPerWg) {
             const long long idx = p.lo_item + i;
             if (idx < 0) tile[(i % sps) * pitch + i / sps] = carry[static_cast<long long>(cap) + idx];
             else raw[raw_slot(i)] = in[idx];
@@ -605,7 +609,7 @@ __global__ __launch_bounds__(256) void k_symbol_filter(const T* __restrict__ in,
                 const unsigned long long c_first = static_cast<unsigned long long>(a - g.start) / kRotChunk;
                 const unsigned n_chunks =
                     static_cast<unsigned>(static_cast<unsigned long long>(b - 1 - g.start) / kRotChunk - c_first) + 1;
-                for (unsigned ch = threadIdx.x; ch < n_chunks; ch += 256) {
+                for (unsigned ch = threadIdx.x; ch < n_chunks; ch += kSymPerWg) {
                     const unsigned long long c = c_first + ch;
                     cf e = cfc.ck[g.ck0 + c];
                     unsigned counter = c0 + static_cast<unsigned>(c * kRotChunk);
@@ -637,7 +641,7 @@ __global__ __launch_bounds__(256) void k_symbol_filter(const T* __restrict__ in,
             if (static_cast<long long>(g.start + g.len) >= hi) break;
         }
     } else {
-        for (unsigned i = threadIdx.x; i < span; i += 256)
+        for (unsigned i = threadIdx.x; i < span; i += kSymPerWg)
             tile[(i % sps) * pitch + i / sps] = item_at(in, carry, cap, p.lo_item + i);
     }
     __syncthreads();
@@ -658,7 +662,7 @@ static void launch_symbol_filter(hipStream_t s, unsigned n_wg, size_t smem, unsi
                                  const T* carry, unsigned cap, const float* taps, unsigned arm_size,
                                  const SymRun* runs, unsigned n_runs, SymWg* plan, T* out, CfcDev cfc)
 {
-    const dim3 grid(n_wg), block(256);
+    const dim3 grid(n_wg), block(kSymPerWg);
     hipLaunchKernelGGL(k_symf_wg_plan, dim3((n_wg + 255) / 256), dim3(256), 0, s, runs, n_runs, n_wg, sps, arm_size,
                        cfc, plan);
     if (sps == 4)
@@ -1869,12 +1873,12 @@ static gr4pm_status symbol_filter_impl(gr4pm_symbol_filter* h, const void* in, s
         for (auto& r : runs) { // workgroups never straddle runs
             r.wg0 = n_wg;
             r.pad = 0;
-            n_wg += (r.count + 255u) / 256u;
+            n_wg += (r.count + kSymPerWg - 1u) / kSymPerWg;
         }
         GR4PM_TRY(upload_vec(h->runs, runs, s));
-        const size_t pitch = (256 * sps + h->arm_size) / sps + 2;
+        const size_t pitch = (kSymPerWg * sps + h->arm_size) / sps + 2;
         if (h->wg_plan.n < n_wg) GR4PM_TRY(h->wg_plan.alloc(static_cast<size_t>(n_wg) * 2));
-        const size_t span_max = 255 * sps + h->arm_size;
+        const size_t span_max = (kSymPerWg - 1) * sps + h->arm_size;
         const size_t arm_bytes = ((h->arm_size + 1) & ~size_t{ 1 }) * sizeof(float);
         const unsigned n_runs = static_cast<unsigned>(runs.size());
         if (fuse)
