@@ -1078,8 +1078,10 @@ def test_multichannel_packet_receiver_equals_single_channel_receivers(pkg):
     singles = [pkg.PacketReceiver(max_items=n) for _ in range(C)]
     xd = dev(xs)
     total_tags = 0
+    parts = [xd[:, part * n:(part + 1) * n].contiguous() for part in range(2)]
+    native.announce(parts[1])  # the detector's look-ahead: the second call's front runs behind the first call
     for part in range(2):
-        w = xd[:, part * n:(part + 1) * n].contiguous()
+        w = parts[part]
         got = multi.process_bulk(w, 300, tags_cap=256)
         got_native = native.process_bulk(w, 300)
         for c in range(C):
