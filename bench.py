@@ -421,7 +421,7 @@ def main():
                     "alg_bytes_per_sample": 8,
                     "fp32_tflops": round(flops / (ms * 1e-3) / 1e12, 2),
                     "fp32_frac": round(flops / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg runs at N = 1 only (rank 0)
             cpu = cpu_baseline((x[0] if args.channels > 1 else x)[: min(n_items, 1 << 27)].cpu().numpy(), rrc)
     if rank == 0:
         line = {
