@@ -261,7 +261,7 @@ def main():
     if native:
         rx = pkg.NativePacketReceiver(SPS, BINS, 9.5, "QPSK", max_items=n_items, tags_cap=max(64, 2 * n_pkt + 64),
                                       pipelined=not args.no_pipeline, soft_bits=args.soft_bits,
-                                      decode_headers=args.decode_headers)
+                                      decode_headers=args.decode_headers, output_ring=True)
         sd = None
     else:
         rx = pkg.PacketReceiver(SPS, BINS, 9.5, "QPSK", max_items=n_items, pipelined=not args.no_pipeline,

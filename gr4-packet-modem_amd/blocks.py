@@ -1498,8 +1498,9 @@ class NativePacketReceiver:
 
     def __init__(self, samples_per_symbol=4, syncword_freq_bins=4, syncword_threshold=9.5,
                  costas_constellation="QPSK", max_items=1 << 22, tags_cap=4096, pipelined=False, soft_bits=False,
-                 decode_headers=False):
+                 decode_headers=False, output_ring=False):
         soft_bits = soft_bits or decode_headers
+        self.output_ring = output_ring
         self.samples_per_symbol, self.pipelined, self.soft_bits = samples_per_symbol, pipelined, soft_bits
         self.decode_headers = decode_headers
         self.time_threshold = 768
@@ -1518,13 +1519,35 @@ class NativePacketReceiver:
         x = _dev_c64(x)
         check(lib().gr4pm_packet_receiver_announce(self._h, x.data_ptr(), x.numel()), "PacketReceiver.announce")
 
-    def submit(self, x, packet_length=None, history=None, next_x=None):
+    # output buffers.  output_ring=True (streaming callers, bench.py): a ring of _OUT_RING sets (more
+    # than the batches the library keeps in flight), allocated at the first submit and whenever a
+    # bigger batch arrives -- not once per call: a device allocation in the middle of a stream stalls
+    # every stage.  A result's "symbols" / "llr" / "packets" then stay valid until _OUT_RING - 1
+    # further batches have been submitted.
+    _OUT_RING = 8
+
+    def _outputs(self, n, device):
         torch = _torch()
+        if not self.output_ring:  # fresh buffers for every batch: results stay valid as long as they are referenced
+            n_sym = n // self.samples_per_symbol + 4160
+            return (torch.empty(n_sym, dtype=torch.complex64, device=device),
+                    torch.empty(2 * n_sym if self.soft_bits else 1, dtype=torch.float32, device=device),
+                    torch.empty(n // 16 + 65536 if self.decode_headers else 1, dtype=torch.uint8, device=device))
+        if getattr(self, "_out_n", -1) < n:
+            n_sym = n // self.samples_per_symbol + 4160
+            self._out_ring = [(torch.empty(n_sym, dtype=torch.complex64, device=device),
+                               torch.empty(2 * n_sym if self.soft_bits else 1, dtype=torch.float32, device=device),
+                               torch.empty(n // 16 + 65536 if self.decode_headers else 1, dtype=torch.uint8,
+                                           device=device)) for _ in range(self._OUT_RING)]
+            self._out_n, self._out_next = n, 0
+        out = self._out_ring[self._out_next]
+        self._out_next = (self._out_next + 1) % self._OUT_RING
+        return out
+
+    def submit(self, x, packet_length=None, history=None, next_x=None):
         x = _dev_c64(x)
         n = x.numel()
-        sym = torch.empty(n // self.samples_per_symbol + 4160, dtype=torch.complex64, device=x.device)
-        llr = torch.empty(2 * sym.numel() if self.soft_bits else 1, dtype=torch.float32, device=x.device)
-        pk = torch.empty(n // 16 + 65536 if self.decode_headers else 1, dtype=torch.uint8, device=x.device)
+        sym, llr, pk = self._outputs(n, x.device)
         delayed = None
         if history is not None:
             d = 2 * self.time_threshold + 1

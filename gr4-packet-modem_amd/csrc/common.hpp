@@ -80,22 +80,27 @@ struct DevBuf {
     }
     // per-call tables: through the pinned staging area, truly asynchronous.  The caller
     // synchronises the stream before the next upload_staged() of this buffer.
+    // makes room for uploads of up to `count` items ahead of time (buffer rings: first use of every set)
+    gr4pm_status reserve_stage(size_t count)
+    {
+        if (stage_n >= count) return GR4PM_OK;
+        if (stage) (void)hipHostFree(stage);
+        stage = nullptr;
+        stage_n = 0;
+        const size_t want = count * 2;
+        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&stage), want * sizeof(T), hipHostMallocDefault);
+        if (e != hipSuccess) {
+            stage = nullptr;
+            set_error("hipHostMalloc(%zu bytes) failed: %s", want * sizeof(T), hipGetErrorString(e));
+            return GR4PM_ERR_NOMEM;
+        }
+        stage_n = want;
+        return GR4PM_OK;
+    }
     gr4pm_status upload_staged(const T* host, size_t count, hipStream_t s)
     {
         if (count == 0) return GR4PM_OK;
-        if (stage_n < count) {
-            if (stage) (void)hipHostFree(stage);
-            stage = nullptr;
-            stage_n = 0;
-            const size_t want = count * 2;
-            hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&stage), want * sizeof(T), hipHostMallocDefault);
-            if (e != hipSuccess) {
-                stage = nullptr;
-                set_error("hipHostMalloc(%zu bytes) failed: %s", want * sizeof(T), hipGetErrorString(e));
-                return GR4PM_ERR_NOMEM;
-            }
-            stage_n = want;
-        }
+        GR4PM_TRY(reserve_stage(count));
         memcpy(stage, host, count * sizeof(T));
         GR4PM_HIP_TRY(hipMemcpyAsync(p, stage, count * sizeof(T), hipMemcpyHostToDevice, s));
         return GR4PM_OK;

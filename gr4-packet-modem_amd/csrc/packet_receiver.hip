@@ -895,10 +895,20 @@ gr4pm_status gr4pm_packet_receiver_create(const gr4pm_packet_receiver_params* p,
         if (hipStreamSynchronize(s1) != hipSuccess) return bail(GR4PM_ERR_HIP);
     }
     const size_t tags_cap = std::max<size_t>(p->tags_cap, 64);
+    // every slot's buffers at the size of a full batch, now: a slot is first used by one of the first
+    // kSlots batches, and a device allocation in the middle of a stream stalls all stages
+    const size_t sym_cap = p->max_items / sps + tags_cap + 2;
     for (int i = 0; i < kSlots; ++i) {
-        h->slots[i].det_tags.resize(tags_cap);
-        h->slots[i].tags.resize(tags_cap);
-        h->slots[i].sym_tags.resize(tags_cap + 64);
+        auto& sl = h->slots[i];
+        sl.det_tags.resize(tags_cap);
+        sl.tags.resize(tags_cap);
+        sl.sym_tags.resize(tags_cap + 64);
+        if ((st = sl.sym.alloc(sym_cap)) != GR4PM_OK) return bail(st);
+        if (p->soft_bits) {
+            if ((st = sl.pm.alloc(sym_cap + 1)) != GR4PM_OK) return bail(st);
+            if ((st = sl.data.alloc(sym_cap + 1)) != GR4PM_OK) return bail(st);
+            if (!p->decode_headers && (st = sl.z.alloc(sym_cap + 1)) != GR4PM_OK) return bail(st);
+        }
         h->free_slots.push(i);
     }
     if (p->pipelined) {

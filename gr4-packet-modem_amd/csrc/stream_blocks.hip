@@ -789,6 +789,7 @@ struct gr4pm_rotator {
         std::vector<unsigned> seg_first; // [n_channels + 1]: the segments of channel c are [seg_first[c], seg_first[c + 1])
     } plans[GR4PM_CFC_PLANS];
     int plan_cur = 0;
+    bool ring_sized = false;
     std::vector<float> next_freq;     // per channel, coarse_frequency_correction.hpp:44
     std::vector<long> next_freq_delay; // :45
 };
@@ -849,8 +850,12 @@ gr4pm_status gr4pm_rotator_reset(gr4pm_rotator* h) { return h ? rotator_reset_im
 
 // host replay of the tag-driven control flow + the serial phasor checkpoints; leaves the segment
 // table, checkpoints, increments and counters of this call on the device (h->plans[h->plan_cur])
+// ring: the plan goes to the next set of the ring (callers that keep several plans alive:
+// gr4pm_cfc_symbol_filter_plan*); otherwise the current set is reused.  When the ring is used for
+// the first time every set gets the capacity of the first plan, so that no later call of a
+// steady stream has to allocate.
 static gr4pm_status rotator_plan(gr4pm_rotator* h, size_t n, const gr4pm_tag* tags, const uint32_t* tag_channel,
-                                 size_t n_tags, std::vector<RotSeg>& segs)
+                                 size_t n_tags, std::vector<RotSeg>& segs, bool ring = false)
 {
     unsigned ck = 0;
     for (size_t c = 0; c < h->n_channels; ++c) {
@@ -920,7 +925,21 @@ static gr4pm_status rotator_plan(gr4pm_rotator* h, size_t n, const gr4pm_tag* ta
     const unsigned n_segs = static_cast<unsigned>(segs.size());
     unsigned ck_total = 0;
     for (const auto& g : segs) ck_total = std::max<unsigned>(ck_total, g.ck0 + static_cast<unsigned>((g.len + kRotChunk - 1) / kRotChunk));
-    h->plan_cur = (h->plan_cur + 1) % GR4PM_CFC_PLANS;
+    if (ring) {
+        h->plan_cur = (h->plan_cur + 1) % GR4PM_CFC_PLANS;
+        if (!h->ring_sized) {
+            h->ring_sized = true;
+            for (auto& q : h->plans) {
+                if (q.ck.n < ck) GR4PM_TRY(q.ck.alloc(static_cast<size_t>(ck) * 2));
+                if (q.seg_incr.n < n_segs) {
+                    GR4PM_TRY(q.seg_incr.alloc(n_segs * 2));
+                    GR4PM_TRY(q.seg_counter0.alloc(n_segs * 2));
+                }
+                if (q.segs.n < n_segs) GR4PM_TRY(q.segs.alloc(n_segs * 2));
+                GR4PM_TRY(q.segs.reserve_stage(n_segs));
+            }
+        }
+    }
     auto& pl = h->plans[h->plan_cur];
     pl.n_segs = n_segs;
     pl.n_in = n;
@@ -1939,8 +1958,8 @@ gr4pm_status gr4pm_symbol_filter_process(gr4pm_symbol_filter* h, const void* in,
                               consumed, produced, nullptr);
 }
 
-gr4pm_status gr4pm_cfc_symbol_filter_plan_channels(gr4pm_rotator* cfc, size_t n_in, const gr4pm_tag* tags_in,
-                                                   const uint32_t* tag_channel, size_t n_tags_in, int* plan)
+static gr4pm_status cfc_plan_impl(gr4pm_rotator* cfc, size_t n_in, const gr4pm_tag* tags_in,
+                                  const uint32_t* tag_channel, size_t n_tags_in, int* plan, bool ring)
 {
     if (!cfc || !plan) return GR4PM_ERR_INVALID;
     *plan = -1;
@@ -1954,10 +1973,16 @@ gr4pm_status gr4pm_cfc_symbol_filter_plan_channels(gr4pm_rotator* cfc, size_t n_
     }
     if (n_in == 0) return GR4PM_OK;
     std::vector<RotSeg> segs;
-    GR4PM_TRY(rotator_plan(cfc, n_in, tags_in, tag_channel, n_tags_in, segs)); // checkpoints on the CFC's stream
+    GR4PM_TRY(rotator_plan(cfc, n_in, tags_in, tag_channel, n_tags_in, segs, ring)); // checkpoints on the CFC's stream
     *plan = cfc->plan_cur;
     GR4PM_HIP_TRY(final_sync(cfc->stream));
     return GR4PM_OK;
+}
+
+gr4pm_status gr4pm_cfc_symbol_filter_plan_channels(gr4pm_rotator* cfc, size_t n_in, const gr4pm_tag* tags_in,
+                                                   const uint32_t* tag_channel, size_t n_tags_in, int* plan)
+{
+    return cfc_plan_impl(cfc, n_in, tags_in, tag_channel, n_tags_in, plan, true);
 }
 
 gr4pm_status gr4pm_cfc_symbol_filter_plan(gr4pm_rotator* cfc, size_t n_in, const gr4pm_tag* tags_in,
@@ -2053,7 +2078,12 @@ gr4pm_status gr4pm_cfc_symbol_filter_process(gr4pm_rotator* cfc, gr4pm_symbol_fi
     int plan = -1;
     const bool was = deferred_sync();
     gr4pm_set_deferred_sync(1); // same stream: the filter queues up behind the checkpoints
-    const gr4pm_status st = gr4pm_cfc_symbol_filter_plan(cfc, n_in, tags_in, n_tags_in, &plan);
+    // (one stream, nothing in between: the current plan set is reused, no ring)
+    if (cfc->n_channels != 1) {
+        set_error("fused call needs a single-channel CoarseFrequencyCorrection");
+        return GR4PM_ERR_INVALID;
+    }
+    const gr4pm_status st = cfc_plan_impl(cfc, n_in, tags_in, nullptr, n_tags_in, &plan, false);
     gr4pm_set_deferred_sync(was ? 1 : 0);
     if (st != GR4PM_OK) return st;
     return gr4pm_cfc_symbol_filter_run(cfc, plan, sf, in, n_in, out, out_cap, tags_in, n_tags_in, tags_out,
