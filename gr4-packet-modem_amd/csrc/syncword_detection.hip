@@ -1617,6 +1617,7 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
     if (s == GR4PM_OK) s = h->twp.upload(twp.data(), twp.size(), h->stream);
     if (s == GR4PM_OK && hipStreamSynchronize(h->stream) != hipSuccess) s = GR4PM_ERR_HIP;
     if (s == GR4PM_OK) s = sd_reset(h);
+    if (s == GR4PM_OK) s = ensure_ahead_streams(h); // now, not at the first announcement in the middle of a stream
     if (s != GR4PM_OK) {
         delete h;
         return s;
