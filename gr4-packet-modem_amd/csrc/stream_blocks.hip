@@ -269,12 +269,17 @@ __device__ __forceinline__ cf costas_step(cf x, float& phase, float& freq, float
 // The PLL over `len` items starting at item `base` (one lane).  Lanes walk different
 // segments, so every load instruction touches 64 different cache lines: whole 128-byte
 // lines are loaded with 16-byte instructions, one chunk (16 symbols) ahead of the PLL.
-template <int CONSTELLATION>
+// KV: float4 per prefetched chunk.  8 = whole 128-byte lines, the fastest loop by itself; 2 keeps
+// the kernel under 48 VGPRs, which is what a SIMD has left beside two correlator waves: k_costas
+// alone then takes 1.06 instead of 0.63 ms per 2^26 samples, but the pipelined front end gains
+// 2.7 % (the stage has the time, the correlator gets its slots back).  k_costas_chains keeps 8:
+// its stages are the slowest ones of the decode_headers pipeline.
+template <int CONSTELLATION, int KV = 8>
 __device__ __forceinline__ void costas_run(const cf* __restrict__ in, cf* __restrict__ out, size_t base,
                                            unsigned len, float& phase, float& freq, float k1, float k2)
 {
     auto step = [&](cf x) -> cf { return costas_step<CONSTELLATION>(x, phase, freq, k1, k2); };
-    constexpr int kV = 8;            // float4 per chunk
+    constexpr int kV = KV;           // float4 per chunk
     constexpr unsigned kC = 2 * kV;  // symbols per chunk
     unsigned j = 0;
     if (((base + j) & 1) && j < len) { // align to 16 bytes
@@ -340,7 +345,7 @@ __global__ void k_costas(const CostasSeg* __restrict__ segs, unsigned n_segs,
         phase = g.phase0;
         freq = 0.0f;
     }
-    costas_run<CONSTELLATION>(in, out, static_cast<size_t>(g.channel) * stride + g.start, g.len, phase, freq, k1,
+    costas_run<CONSTELLATION, 2>(in, out, static_cast<size_t>(g.channel) * stride + g.start, g.len, phase, freq, k1,
                               k2);
     if (g.last) { // ping-pong: another lane may still have to read `state`
         state_next[g.channel].phase = phase;
