@@ -188,8 +188,10 @@ def main():
                     help="materialise SyncwordDetection's delayed output instead of reading the ring in place")
     ap.add_argument("--no-scatter", action="store_true",
                     help="N > 1: let every rank generate its own channel instead of the RCCL scatter from rank 0")
-    ap.add_argument("--lookahead-depth", type=int, default=2,
-                    help="how many calls ahead the detector's front part (correlator, candidates, tables) is launched (max 2)")
+    ap.add_argument("--lookahead-depth", type=int, default=None,
+                    help="how many calls ahead the detector's front part (correlator, candidates, tables) is launched "
+                         "(max 2; default 2, and 1 with --channels: the multi-channel receiver is synchronous, a second "
+                         "front in flight only slows the phases of the current call)")
     ap.add_argument("--no-lookahead", action="store_true",
                     help="do not announce the next window to SyncwordDetection (no correlator look-ahead)")
     ap.add_argument("--soft-bits", action="store_true",
@@ -204,6 +206,8 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the two halves of the chain back to back on one stream")
     args = ap.parse_args()
+    if args.lookahead_depth is None:
+        args.lookahead_depth = 1 if args.channels > 1 else 2
     # three host threads drive the three pipeline stages and spend most of their time inside the
     # C library (GIL released); when one comes back it should not wait 5 ms (the default switch
     # interval) for whichever thread is running Python glue at that moment

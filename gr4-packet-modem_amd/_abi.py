@@ -196,7 +196,7 @@ EXPORTS = [
     "gr4pm_symbol_filter_create", "gr4pm_symbol_filter_destroy", "gr4pm_symbol_filter_reset",
     "gr4pm_symbol_filter_process", "gr4pm_cfc_symbol_filter_process",
     "gr4pm_cfc_symbol_filter_plan", "gr4pm_cfc_symbol_filter_run",
-    "gr4pm_cfc_symbol_filter_plan_channels", "gr4pm_cfc_symbol_filter_run_channel", "gr4pm_costas_loop_process_ragged",
+    "gr4pm_cfc_symbol_filter_plan_channels", "gr4pm_cfc_symbol_filter_run_channel", "gr4pm_costas_loop_process_ragged", "gr4pm_costas_loop_set_small_footprint",
     "gr4pm_pfb_arb_resampler_create", "gr4pm_pfb_arb_resampler_destroy", "gr4pm_pfb_arb_resampler_reset",
     "gr4pm_pfb_arb_resampler_process",
     "gr4pm_firdes_root_raised_cosine",

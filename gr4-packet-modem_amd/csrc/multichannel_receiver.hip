@@ -338,9 +338,13 @@ gr4pm_status gr4pm_multichannel_receiver_process(gr4pm_multichannel_receiver* h,
     const gr4pm_status cst = gr4pm_costas_loop_process_ragged(h->costas, h->symall.p, out_stride, h->produced.data(),
                                                               out_symbols, h->all_tags.data(), h->all_channel.data(),
                                                               h->all_tags.size());
-    if (timing)
-        fprintf(stderr, "[gr4pm multichannel] detector %.0f us, gate + CFC plan %.0f us, symbol filters %.0f us, Costas %.0f us\n",
-                us(t0, t1), us(t1, t2), us(t2, t3), us(t3, now()));
+    if (timing) {
+        static auto last_return = t0;
+        const auto t4 = now();
+        fprintf(stderr, "[gr4pm multichannel] caller %.0f us | detector %.0f us, gate + CFC plan %.0f us, symbol filters %.0f us, Costas %.0f us\n",
+                us(last_return, t0), us(t0, t1), us(t1, t2), us(t2, t3), us(t3, t4));
+        last_return = t4;
+    }
     return cst;
 }
 

@@ -270,10 +270,10 @@ __device__ __forceinline__ cf costas_step(cf x, float& phase, float& freq, float
 // segments, so every load instruction touches 64 different cache lines: whole 128-byte
 // lines are loaded with 16-byte instructions, one chunk (16 symbols) ahead of the PLL.
 // KV: float4 per prefetched chunk.  8 = whole 128-byte lines, the fastest loop by itself; 2 keeps
-// the kernel under 48 VGPRs, which is what a SIMD has left beside two correlator waves: k_costas
-// alone then takes 1.06 instead of 0.63 ms per 2^26 samples, but the pipelined front end gains
-// 2.7 % (the stage has the time, the correlator gets its slots back).  k_costas_chains keeps 8:
-// its stages are the slowest ones of the decode_headers pipeline.
+// k_costas under 48 VGPRs, which is what a SIMD has left beside two correlator waves
+// (gr4pm_costas_loop_set_small_footprint; the pipelined receiver asks for it): the kernel alone then
+// takes 1.06 instead of 0.63 ms per 2^26 samples, but the pipelined front end gains 2.7 % (the
+// stage has the time, the correlator gets its slots back).
 template <int CONSTELLATION, int KV = 8>
 __device__ __forceinline__ void costas_run(const cf* __restrict__ in, cf* __restrict__ out, size_t base,
                                            unsigned len, float& phase, float& freq, float k1, float k2)
@@ -327,7 +327,7 @@ __device__ __forceinline__ void costas_run(const cf* __restrict__ in, cf* __rest
 }
 
 // One lane per segment (the PLL is serial inside a segment).
-template <int CONSTELLATION>
+template <int CONSTELLATION, int KV = 8>
 __global__ void k_costas(const CostasSeg* __restrict__ segs, unsigned n_segs,
                          const CostasState* __restrict__ state, CostasState* __restrict__ state_next,
                          float k1, float k2,
@@ -345,7 +345,7 @@ __global__ void k_costas(const CostasSeg* __restrict__ segs, unsigned n_segs,
         phase = g.phase0;
         freq = 0.0f;
     }
-    costas_run<CONSTELLATION, 2>(in, out, static_cast<size_t>(g.channel) * stride + g.start, g.len, phase, freq, k1,
+    costas_run<CONSTELLATION, KV>(in, out, static_cast<size_t>(g.channel) * stride + g.start, g.len, phase, freq, k1,
                               k2);
     if (g.last) { // ping-pong: another lane may still have to read `state`
         state_next[g.channel].phase = phase;
@@ -1018,6 +1018,7 @@ struct gr4pm_costas_loop {
     unsigned memo_next = 0;
     DevBuf<CostasState> state; // [2][n_channels], st_cur selects the current half
     int st_cur = 0;
+    bool small_footprint = false; // k_costas with 32-byte prefetch pieces (46 VGPRs)
     DevBuf<CostasSeg> segs;
     DevBuf<CostasChain> chains;
     DevBuf<CostasPiece> pieces;
@@ -1154,20 +1155,31 @@ static gr4pm_status costas_process_impl(gr4pm_costas_loop* h, const gr4pm_c64* i
     const CostasState* st_in = h->state.p + h->st_cur * h->n_channels;
     CostasState* st_out = h->state.p + (h->st_cur ^ 1) * h->n_channels;
     h->st_cur ^= 1;
-    if (h->constellation == 0)
-        hipLaunchKernelGGL(k_costas<0>, grid, block, 0, s, h->segs.p, n_segs, st_in, st_out, h->k1, h->k2,
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, grid, block, 0, s, h->segs.p, n_segs, st_in, st_out, h->k1, h->k2,
                            reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(out), stride);
-    else if (h->constellation == 1)
-        hipLaunchKernelGGL(k_costas<1>, grid, block, 0, s, h->segs.p, n_segs, st_in, st_out, h->k1, h->k2,
-                           reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(out), stride);
-    else
-        hipLaunchKernelGGL(k_costas<2>, grid, block, 0, s, h->segs.p, n_segs, st_in, st_out, h->k1, h->k2,
-                           reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(out), stride);
+    };
+    if (h->small_footprint) {
+        if (h->constellation == 0) launch(k_costas<0, 2>);
+        else if (h->constellation == 1) launch(k_costas<1, 2>);
+        else launch(k_costas<2, 2>);
+    } else {
+        if (h->constellation == 0) launch(k_costas<0, 8>);
+        else if (h->constellation == 1) launch(k_costas<1, 8>);
+        else launch(k_costas<2, 8>);
+    }
     GR4PM_HIP_TRY(hipGetLastError());
     GR4PM_HIP_TRY(final_sync(s));
     return GR4PM_OK;
 }
 } // extern "C++"
+
+gr4pm_status gr4pm_costas_loop_set_small_footprint(gr4pm_costas_loop* h, int on)
+{
+    if (!h) return GR4PM_ERR_INVALID;
+    h->small_footprint = on != 0;
+    return GR4PM_OK;
+}
 
 gr4pm_status gr4pm_costas_loop_process(gr4pm_costas_loop* h, const gr4pm_c64* in, size_t stride, size_t n,
                                        gr4pm_c64* out, const gr4pm_tag* tags, const uint32_t* tag_channel,

@@ -1409,11 +1409,13 @@ gr4pm_status ensure_ahead_streams(gr4pm_syncword_detection* h)
     // and a priority of its own also gives the stream a hardware queue of its own (streams of one
     // priority share GPU_MAX_HW_QUEUES = 4 queues; a shared queue serialises its kernels)
     GR4PM_HIP_TRY(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, least));
-    // the candidate / table kernels behind it are short and latency-bound and a later call waits
-    // for them: highest priority (measured: the correlator's lowest priority too is as good; the
-    // default priority, which the receiver's other stage streams have, costs 20 %, and so does
-    // any higher priority for the correlator)
-    GR4PM_HIP_TRY(hipStreamCreateWithPriority(&h->stream3, hipStreamNonBlocking, greatest));
+    // the candidate / table kernels behind it: the lowest priority as well.  Their stream starts every
+    // front with a wait for the correlator; at the caller's (usually highest) priority it can end up
+    // in the caller's hardware queue, and the caller's scan / tag kernels then sit behind that wait
+    // for a whole correlator launch (measured with 64 channels: 7 instead of 2 ms per call).  The
+    // default priority, which the receiver's stage streams have, costs 20 % for the same reason.
+    GR4PM_HIP_TRY(hipStreamCreateWithPriority(&h->stream3, hipStreamNonBlocking, least));
+    (void)greatest;
     GR4PM_HIP_TRY(hipEventCreateWithFlags(&h->ev_zcarry, hipEventDisableTiming));
     for (int i = 0; i < kSets; ++i) {
         GR4PM_HIP_TRY(hipEventCreateWithFlags(&h->ev_mid[i], hipEventDisableTiming));

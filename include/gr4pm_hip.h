@@ -232,6 +232,10 @@ void gr4pm_costas_loop_coeffs(const gr4pm_costas_loop* h, float* k1, float* k2);
 /* settingsChanged() (:52-88): new constellation / loop bandwidth from tags or messages */
 gr4pm_status gr4pm_costas_loop_set(gr4pm_costas_loop* h, double loop_bandwidth,
                                    int constellation);
+/* same results either way; on: the kernel of _process / _process_ragged keeps under 48 VGPRs (what a
+ * SIMD has left beside two waves of the syncword correlator) at the price of being slower by
+ * itself -- for callers that run it next to a SyncwordDetection, as gr4pm_packet_receiver does */
+gr4pm_status gr4pm_costas_loop_set_small_footprint(gr4pm_costas_loop* h, int on);
 gr4pm_status gr4pm_costas_loop_process(gr4pm_costas_loop* h, const gr4pm_c64* in, size_t stride,
                                        size_t n, gr4pm_c64* out, const gr4pm_tag* tags,
                                        const uint32_t* tag_channel, size_t n_tags);
