@@ -1225,6 +1225,7 @@ struct gr4pm_syncword_detection {
     // call's scan, tag kernels and read-back are in flight
     hipStream_t stream2 = nullptr, stream3 = nullptr;
     hipEvent_t ev_zcarry = nullptr, ev_mid[kSets] = {}, ev_front[kSets] = {};
+    bool front_recorded[kSets] = {}; // ev_front[i] has been recorded at least once (never wait for a fresh event)
     struct Ahead {
         const gr4pm_c64* in;
         size_t stride, n;
@@ -1381,7 +1382,10 @@ gr4pm_status launch_front(gr4pm_syncword_detection* h, hipStream_t stream, int w
     const uint64_t A0 = E0 > T ? E0 - T : 0, A1 = E1 > T ? E1 - T : 0;
     const uint32_t cnt = static_cast<uint32_t>(A1 - A0);
     if (cnt == 0) {
-        if (ahead) GR4PM_HIP_TRY(hipEventRecord(h->ev_front[which], stream));
+        if (ahead) {
+            GR4PM_HIP_TRY(hipEventRecord(h->ev_front[which], stream));
+            h->front_recorded[which] = true;
+        }
         return GR4PM_OK;
     }
     const float* zloc = zw + h->zc - static_cast<ptrdiff_t>(E0 - A0);
@@ -1396,7 +1400,10 @@ gr4pm_status launch_front(gr4pm_syncword_detection* h, hipStream_t stream, int w
     hipLaunchKernelGGL(k_group_tables, dim3((T + 1 + 127) / 128, n_groups, nch), dim3(128), 0, stream, cnt, T,
                        n_tiles, h->table[which].p, h->table_stride, h->gtable[which].p, h->gtable_stride);
     GR4PM_HIP_TRY(hipGetLastError());
-    if (ahead) GR4PM_HIP_TRY(hipEventRecord(h->ev_front[which], stream));
+    if (ahead) {
+        GR4PM_HIP_TRY(hipEventRecord(h->ev_front[which], stream));
+        h->front_recorded[which] = true;
+    }
     return GR4PM_OK;
 }
 
@@ -1805,7 +1812,8 @@ gr4pm_status gr4pm_syncword_detection_process(gr4pm_syncword_detection* h, const
             // this front's correlator overwrites the z buffer whose tail the z carry of the front two
             // calls before it reads on the other look-ahead stream (set + 1): long done in practice
             // (a whole correlator launch lies in between), ordered by its event all the same
-            GR4PM_HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_front[(set + 1) % kSets], 0));
+            if (h->front_recorded[(set + 1) % kSets])
+                GR4PM_HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_front[(set + 1) % kSets], 0));
             GR4PM_TRY(launch_front(h, h->stream2, set, c, a.in, a.stride, a.n, e0, j_prev));
             h->launched.push_back(a);
             const size_t nb = (a.n - h->fft_size) / h->S + 1;
