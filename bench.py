@@ -119,38 +119,142 @@ def burst_stream(pkg, n_items, rrc, seed, device, header=None):
     return (x + noise).to(torch.complex64).contiguous(), n_pkt
 
 
-def cpu_baseline(x_host, rrc, seconds_target=12.0):
-    """the CPU oracle (one thread) on a bounded sample of the same workload: the stream prefix is
-    fed repeatedly (state carried, like a longer stream) until ~seconds_target of CPU work"""
+def _cpu_detector_rate(piece, rrc, seconds, threads=1):
+    """oracle SyncwordDetection on `threads` host threads, each with its own detector state over
+    the same samples (one independent channel per thread: the path shards by channel)"""
+    import threading
     import _oracle as orc
     bpsk = np.array([1, -1], dtype=np.complex64)
-    sd = orc.SyncwordDetection(rrc, SYNCWORD, bpsk, -BINS, BINS, power_threshold=9.5)
-    piece = x_host[: min(x_host.size, 1 << 25)]
-    done, n_tags, passes = 0, 0, 0
+    dets = [orc.SyncwordDetection(rrc, SYNCWORD, bpsk, -BINS, BINS, power_threshold=9.5) for _ in range(threads)]
+    done = [0] * threads
+    tags = [0] * threads
     t0 = time.perf_counter()
-    while True:
-        _, out, tags = sd.process(piece)
-        done += out.size
-        n_tags += tags.size
-        passes += 1
-        if time.perf_counter() - t0 >= seconds_target:
-            break
+
+    def run(i):
+        while True:  # ctypes releases the GIL inside the oracle
+            _, out, tg = dets[i].process(piece)
+            done[i] += out.size
+            tags[i] += tg.size
+            if time.perf_counter() - t0 >= seconds:
+                return
+
+    if threads == 1:
+        run(0)
+    else:
+        th = [threading.Thread(target=run, args=(i,)) for i in range(threads)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
     dt = time.perf_counter() - t0
-    return {"value": round(done / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
-            "sample": f"{passes} passes over the first {piece.size} samples of the same burst stream "
-                      f"({done} samples, {n_tags} tags, {dt:.1f} s), CPU oracle oracle/gr4pm_oracle.cpp "
-                      f"SyncwordDetection, 1 thread"}
+    return sum(done) / dt / 1e6, sum(done), sum(tags), dt
+
+
+def _cpu_front_end_rate(piece, rrc, seconds, threads=1):
+    """the whole front end on the CPU oracle, block after block like the reference flowgraph
+    (packet_receiver.hpp:76-127): SyncwordDetection -> CoarseFrequencyCorrection (delay 26) ->
+    SymbolFilter (32 x 44 PFB) -> SyncwordWipeoff -> CostasLoop; the tag gate is a pure copy that
+    accepts every tag of this stream and is left out"""
+    import threading
+    import _oracle as orc
+    bpsk = np.array([1, -1], dtype=np.complex64)
+    pfb = orc.rrc_taps(32.0 / float(orc.unit_norm_rrc(SPS)[1]), 32.0 * SPS, 1.0, 0.35, 32 * SPS * 11)[:-1]
+    bipolar = np.where(SYNCWORD == 1, -1.0, 1.0).astype(np.float32)
+    done = [0] * threads
+    t0 = time.perf_counter()
+
+    def run(i):
+        while True:
+            sd = orc.SyncwordDetection(rrc, SYNCWORD, bpsk, -BINS, BINS, power_threshold=9.5)
+            _, out, tg = sd.process(piece, tags_cap=1 << 16)
+            z = orc.coarse_frequency_correction(out, tg["index"], tg["freq"], delay=26)
+            sym, sym_tags, _ = orc.symbol_filter(z, pfb, 32, SPS, 44, tags=tg.astype(orc.TAG_DTYPE))
+            w = orc.syncword_wipeoff(sym, bipolar, sym_tags["index"])
+            orc.costas_loop(w, "QPSK", 0.01, sym_tags["index"], sym_tags["phase"])
+            done[i] += out.size
+            if time.perf_counter() - t0 >= seconds:
+                return
+
+    th = [threading.Thread(target=run, args=(i,)) for i in range(threads)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    return sum(done) / dt / 1e6, sum(done), dt
+
+
+def cpu_baseline(x_host, rrc, seconds_target=24.0):
+    """the CPU oracle (kind "port": the reference cannot be built on the GPU box) on a bounded
+    sample of the same workload, ~seconds_target of wall time split over five legs:
+    value = the full front end on ALL host cores (one channel per thread, `cores` threads);
+    beside it the same on one core, the detector alone on one core and on all cores, and the
+    detector on the reference benchmark's all-zeros input (benchmark_syncword_detection.cpp:31)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    piece = x_host[: min(x_host.size, 1 << 24)]
+    leg = seconds_target / 5.0
+    fe_all, fe_all_n, fe_all_dt = _cpu_front_end_rate(piece, rrc, leg, cores)
+    fe_one, fe_one_n, _ = _cpu_front_end_rate(piece, rrc, leg, 1)
+    det_one, det_n, det_tags, det_dt = _cpu_detector_rate(piece, rrc, leg, 1)
+    det_all, _, _, _ = _cpu_detector_rate(piece, rrc, leg, cores)
+    det_zero, _, _, _ = _cpu_detector_rate(np.zeros(1 << 22, dtype=np.complex64), rrc, leg, 1)
+    return {"value": round(fe_all, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": f"full front end (detector 9 bins + CFC + SymbolFilter + wipe-off + Costas), CPU oracle "
+                      f"oracle/gr4pm_oracle.cpp, {cores} threads x the first {piece.size} samples of the same burst "
+                      f"stream ({fe_all_n} samples in {fe_all_dt:.1f} s); other legs ~{leg:.0f} s each",
+            "front_end_one_core": round(fe_one, 3),
+            "detector_one_core": round(det_one, 3),
+            "detector_all_cores": round(det_all, 3),
+            "detector_zeros_input_one_core": round(det_zero, 3),
+            "reference_published": "13 Msps detector / 6-8 Msps receiver at 9 bins on a Ryzen 7 5800X "
+                                   "(benchmarks/results.md:41,51)"}
+
+
+def pmc_traffic(samples):
+    """roofline.traffic: HBM bytes per launch from the PMC passes committed under profiles/ (read at
+    run time; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note + WRITE_SIZE, per sample of
+    the profiled launch, scaled to this launch).  null when the file is missing."""
+    path = os.path.join(ROOT, "profiles", "r2_k_correlate_hbm_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        return {"traffic": round(float(t["traffic_bytes_per_sample"]) * samples),
+                "traffic_source": f"profiles/{os.path.basename(path)}: {t['traffic_bytes_per_sample']:.3f} B/sample "
+                                  f"(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, kernel {t.get('kernel', '?')})"}
+    except (OSError, KeyError, ValueError):
+        return {"traffic": None, "traffic_source": "profiles/r2_k_correlate_hbm_traffic.json missing"}
+
+
+def channel_bank(x, n_channels):
+    """configs[2]/[3]: C channels from one burst stream: channel c is the stream rotated by 997 c
+    samples with a carrier offset of -0.04 + 0.08 c / (C - 1) rad/sample on top"""
+    n = x.numel()
+    k = torch.arange(n, device=x.device, dtype=torch.float32)
+    xs = torch.empty((n_channels, n), dtype=torch.complex64, device=x.device)
+    for c in range(n_channels):
+        f = -0.04 + 0.08 * c / max(n_channels - 1, 1)
+        xs[c] = x.roll(997 * c) * torch.polar(torch.ones_like(k), (f * k) % (2 * np.pi))
+    return xs
+
+
+def host_sample_ring(world, shape):
+    """configs[3]: rank 0's host sample ring [world, channels, n] (pinned when the host allows it)"""
+    try:
+        return torch.empty((world,) + tuple(shape), dtype=torch.complex64, pin_memory=True), "pinned"
+    except RuntimeError:
+        return torch.empty((world,) + tuple(shape), dtype=torch.complex64), "pageable"
 
 
 def scatter_channels(dist, make_all, n_items, device, rank, world):
     """the only collective of this workload is the initial sample scatter -- rank 0
     holds every channel's samples ([world, n_items] complex64) and sends one channel to each
     rank (RCCL send/recv over xGMI on the GPUs; any torch.distributed backend works)."""
-    mine = torch.empty(n_items, dtype=torch.complex64, device=device)
+    shape = (n_items,) if isinstance(n_items, int) else tuple(n_items)  # per-rank shape: [n] or [channels, n]
+    mine = torch.empty(shape, dtype=torch.complex64, device=device)
     mine_f = torch.view_as_real(mine)  # interleaved float32 pairs: every backend moves floats
     if rank == 0:
         allx = make_all()
-        assert allx.shape == (world, n_items)
+        assert tuple(allx.shape) == (world,) + shape
         dist.scatter(mine_f, [torch.view_as_real(allx[r].contiguous()) for r in range(world)], src=0)
     else:
         dist.scatter(mine_f, None, src=0)
@@ -168,6 +272,124 @@ def aggregate(dist, dt, consumed, device):
     csum = torch.tensor([consumed], dtype=torch.float64, device=device)
     dist.all_reduce(csum, op=dist.ReduceOp.SUM)
     return tmax.item(), csum.item()
+
+
+def launch_ranks(n):
+    """one worker process per GPU, rendezvous on 127.0.0.1 (what torch.distributed.run would set
+    up); the parent only waits -- it never initialises the GPU -- and returns the worst exit code"""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rcs = [p.wait() for p in procs]
+    return max(abs(rc) for rc in rcs)
+
+
+def dry_run(args):
+    """--dry-run: the N > 1 plumbing (rendezvous, MAX / SUM aggregation, rank 0 prints) on gloo"""
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    dt, total = aggregate(dist if world > 1 else None, 1.0 + rank, 1000.0 * (rank + 1), torch.device("cpu"))
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run", "value": total / dt, "n_gpus": world, "gpus_requested": args.gpus,
+                          "steps": args.steps, "warmup": args.warmup}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def config5(args):
+    """--config 5 = BASELINE configs[4], the stress shape: 1 channel, fft_size 4096, RRC 1024 requested ->
+    1025 taps -> syncword of 63 * 4 + 1025 = 1277 samples, stride 2820 (SURVEY.md 8(d) config 5), 9 bins;
+    SyncwordDetection over a resident noise + burst stream, and beside it the 1025-tap shaping /
+    matched-filter leg (InterpolatingFirFilter x4, interpolating_fir_filter.hpp:76-102).  One rank."""
+    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(device)
+    pkg = ge.load_package()
+    n, nfft = args.items, 4096
+    rrc = pkg.root_raised_cosine(1.0, float(SPS), 1.0, 0.35, 1024)
+    rrc = (rrc / np.sqrt(np.sum(rrc.astype(np.float64) ** 2))).astype(np.float32)
+    L = 63 * SPS + rrc.size
+    S = nfft - L + 1
+    g = torch.Generator(device=device)
+    g.manual_seed(5)
+    # bursts: syncword + random BPSK symbols shaped with the 1025-tap RRC, every 16384 symbols, in AWGN
+    n_sym = n // SPS
+    bits = torch.randint(0, 2, (n_sym,), generator=g, device=device)
+    sw = torch.from_numpy(SYNCWORD.astype(np.int64)).to(device)
+    starts = torch.arange(2000, n_sym - 64, 16384, device=device)
+    for k in range(64):
+        bits[starts + k] = sw[k]
+    sym = torch.complex((1 - 2 * bits).float(), torch.zeros(n_sym, device=device))
+    fir = pkg.InterpolatingFirFilter(SPS, rrc)
+    x = fir.process_bulk(sym.contiguous())[:n]
+    x = (x + torch.view_as_complex(0.05 * torch.randn((n, 2), device=device, generator=g))).contiguous()
+    bpsk = np.array([1, -1], dtype=np.complex64)
+    sd = pkg.SyncwordDetection(rrc, SYNCWORD, bpsk, -BINS, BINS, fft_size=nfft, power_threshold=9.5, max_items=n)
+    cap = 1 << 16
+
+    def step():
+        st, _, tags, nd = sd.process_bulk(x, want_output=False, tags_cap=cap)
+        return nd, tags.size
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    done = n_tags = 0
+    for _ in range(args.steps):
+        nd, nt = step()
+        done += nd
+        n_tags += nt
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # the 1025-tap filter leg, timed beside it (symbols in, 4 samples per symbol out)
+    for _ in range(2):
+        fir.process_bulk(sym)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(5):
+        y = fir.process_bulk(sym)
+    torch.cuda.synchronize()
+    fir_rate = 5 * y.numel() / (time.perf_counter() - t1) / 1e6
+    # roofline of the correlator kernel for this size
+    reps = 5
+    sd.correlate_only(x)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        sd.correlate_only(x)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    samples = ((n - nfft) // S + 1) * S
+    flops = 950.0 * samples  # SURVEY.md 8(d): N = 4096, B = 9
+    achieved = 8.0 * samples / (ms * 1e-3) / 1e9
+    line = {"metric": "RX Msamples/s (syncword-detect + RRC chain)", "value": round(done / dt / 1e6, 2),
+            "unit": "Msamples/s", "n_gpus": 1, "gpus_requested": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[4]: 1 channel, SyncwordDetection with fft_size 4096, 1025-tap RRC "
+                                   f"(syncword {L} samples, stride {S}), 9 bins, resident burst + AWGN stream",
+                       "items_per_step_per_gpu": n, "freq_bins": 2 * BINS + 1, "tags_per_step": n_tags // max(args.steps, 1),
+                       "fir_1025_taps_x4_msps_out": round(fir_rate, 1)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": "correlator, N = 4096",
+                         "launch_ms": round(ms, 4), "samples_per_launch": samples, "alg_bytes_per_sample": 8,
+                         "fp32_tflops": round(flops / (ms * 1e-3) / 1e12, 2),
+                         "fp32_frac": round(flops / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)},
+            "cpu_baseline": None}
+    print(json.dumps(line))
 
 
 def main():
@@ -205,7 +427,25 @@ def main():
                          "native composition gr4pm_packet_receiver (identical results)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the two halves of the chain back to back on one stream")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 5],
+                    help="2 (default): BASELINE configs[1], the headline workload; 5: BASELINE configs[4], the stress "
+                         "shape (N = 4096 overlap-save blocks, 1025-tap RRC, SyncwordDetection + the 1025-tap filter leg)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / aggregation check without a GPU: every rank joins a gloo group, aggregates "
+                         "fixed numbers and rank 0 prints the line (tests/test_distributed_cpu.py)")
     args = ap.parse_args()
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves, as fresh child processes,
+        # BEFORE this process makes any GPU call (a process that has touched the GPU is never re-executed)
+        sys.exit(launch_ranks(args.gpus))
+    if int(world_env or 1) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_env or 1}: refusing to print a line "
+                         f"for a different GPU count")
+    if args.dry_run:
+        return dry_run(args)
+    if args.config == 5:
+        return config5(args)
     if args.lookahead_depth is None:
         args.lookahead_depth = 1 if args.channels > 1 else 2
     # three host threads drive the three pipeline stages and spend most of their time inside the
@@ -236,16 +476,32 @@ def main():
         return burst_stream(pkg, n_items, rrc, seed=seed, device=device, header=hdr_syms)
 
     x, n_pkt = make_stream(1 + rank)
+    xs_bank = None
     if dist and not args.no_scatter:
         # multi-channel receive: rank 0 owns the sample ring of all channels and scatters it
         try:
-            def make_all():
-                chans = [x] + [make_stream(1 + r)[0] for r in range(1, world)]
-                return torch.stack(chans)
-            x = scatter_channels(dist, make_all, n_items, device, rank, world)
-            input_mode = "rank 0 -> all ranks, torch.distributed scatter (RCCL)"
+            if args.channels > 1:
+                # configs[3]: `channels` per GPU; rank 0 fills its host sample ring [world, C, n] (D2H), uploads
+                # it and scatters one [C, n] slab per rank: the workload's only collective
+                ring_kind = ["?"]
+
+                def make_all():
+                    host, ring_kind[0] = host_sample_ring(world, (args.channels, n_items))
+                    for r in range(world):
+                        host[r].copy_(channel_bank(x if r == 0 else make_stream(1 + r)[0], args.channels))
+                    return host.to(device, non_blocking=False)
+                xs_bank = scatter_channels(dist, make_all, (args.channels, n_items), device, rank, world)
+                input_mode = (f"rank 0 host sample ring [{world}, {args.channels}, {n_items}] -> all ranks, "
+                              f"torch.distributed scatter (RCCL)")
+            else:
+                def make_all():
+                    chans = [x] + [make_stream(1 + r)[0] for r in range(1, world)]
+                    return torch.stack(chans)
+                x = scatter_channels(dist, make_all, n_items, device, rank, world)
+                input_mode = "rank 0 -> all ranks, torch.distributed scatter (RCCL)"
         except Exception as e:  # keep the benchmark alive: fall back to local generation
             input_mode = f"generated on each GPU (scatter failed: {type(e).__name__})"
+            xs_bank = None
     # the stream lives in a device ring [.. | window A | window B]: two different stretches of the
     # burst stream that the steps present alternately, each preceded in memory by the 2T+1 items
     # "before" it (for A: a copy of B's tail, for B: A's tail itself).  While one window is being
@@ -278,11 +534,7 @@ def main():
         full_chain = not args.detector_only
         args.detector_only = True
         C = args.channels
-        k = torch.arange(n_items, device=device, dtype=torch.float32)
-        xs = torch.empty((C, n_items), dtype=torch.complex64, device=device)
-        for c in range(C):
-            f = -0.04 + 0.08 * c / max(C - 1, 1)
-            xs[c] = x.roll(997 * c) * torch.polar(torch.ones_like(k), (f * k) % (2 * np.pi))
+        xs = xs_bank if xs_bank is not None else channel_bank(x, C)
         x = xs
         windows = [(xs, None), (xs, None)]
         if full_chain:
@@ -418,14 +670,12 @@ def main():
         flops = 710.0 * samples  # (1+B) 5N log2 N + 6BN + 1.5N + 4BS per stride, B = 9
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5),
-                    # HBM bytes per launch from the PMC passes of profiles/r1_k_correlate_hbm_traffic.json
-                    # (2 x FETCH_SIZE + WRITE_SIZE = 12.57 B/sample), scaled to this launch
-                    "traffic": round(12.569 * samples),
+                    **pmc_traffic(samples),
                     "kernel": "k_correlate", "launch_ms": round(ms, 4), "samples_per_launch": samples,
                     "alg_bytes_per_sample": 8,
                     "fp32_tflops": round(flops / (ms * 1e-3) / 1e12, 2),
                     "fp32_frac": round(flops / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)}
-        if not args.no_cpu_baseline and world == 1:  # the CPU leg runs at N = 1 only (rank 0)
+        if not args.no_cpu_baseline:  # rank 0, after the timed region (the other ranks are idle by then)
             cpu = cpu_baseline((x[0] if args.channels > 1 else x)[: min(n_items, 1 << 27)].cpu().numpy(), rrc)
     if rank == 0:
         line = {
@@ -433,6 +683,7 @@ def main():
             "value": round(total / dt / 1e6, 2),
             "unit": "Msamples/s",
             "n_gpus": world,
+            "gpus_requested": args.gpus,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),

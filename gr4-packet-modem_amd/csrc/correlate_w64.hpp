@@ -1,0 +1,380 @@
+// correlate_w64.hpp -- k_correlate_w64: the overlap-save correlator on the one-exchange wave FFT
+// of fft2048_w64.hpp (device code, included by syncword_detection.hip).
+// Replaces syncword_detection.hpp:238-252,300-313 (forward FFT of the block, x B templates, FFT,
+// |.|^2, best bin per lag).
+//
+// One 512-thread workgroup per CU, eight PERSISTENT waves: every wave walks its own sequence of
+// overlap-save blocks (item = channel * n_blocks + block), so the waves of a CU drift apart and
+// one wave's HBM prologue / LDS exchange is covered by the arithmetic of the others.
+//
+// LDS (151.5 KiB of 160): [0, 16 KiB) the mid-stage twiddle table T (shared by the 8 waves) |
+// eight private 16.5 KiB exchange buffers.  There is no room for a shared template buffer and
+// none is needed: between the last mid-stage read of a transform and the first exchange store
+// of the next one a wave's exchange buffer is idle, and during exactly that window the wave
+// has the NEXT template copied global -> LDS into it by the LDS-DMA path (global_load_lds, no
+// VGPRs).  So no wave ever waits for another one: the kernel has no barrier after its
+// prologue, no spin loop and no hand-off words.
+//
+// Per transform and wave the LDS pipe now sees 64 ds_write_addtid_b32 (128 cycles) + 32 + 16 + 16
+// ds_read_b128 (exchange rows, T, template: 256 cycles) where k_correlate needed ~800 cycles
+// (two exchanges through ds_write2_b64 at 79 B/clk).
+#pragma once
+#include "fft2048_w64.hpp"
+
+namespace gr4pm {
+namespace {
+
+constexpr int kW64Waves = 8, kW64Threads = kW64Waves * 64;
+constexpr int kW64BufF4 = kW64BufDwords / 4;                         // 1056 float4 per wave
+constexpr int kW64LdsF4 = kW64TwFloat4 + kW64Waves * kW64BufF4;      // 9472 float4 = 151552 B
+static_assert(kW64LdsF4 * 16 <= 160 * 1024, "LDS budget of one workgroup per CU");
+
+// exchange store: lane l writes r[k1] to row k1, column l (re plane, im plane 256 B further)
+// with ds_write_addtid_b32: LDS address = M0 + offset + 4 * lane.  M0 is written ONCE, in front of the
+// 64 stores (one wait state before the first DS use): rewriting it per group of stores made every
+// group wait for the previous group's stores to leave the LDS queue (0.19 ms of 0.79 per 2^26 samples).
+// hipcc itself never touches M0 in this kernel (no LDS-DMA builtin, no GWS / sendmsg / movrel): the
+// only other writer is w64_dma_template, which sets it for itself.
+#define GR4PM_ADDTID4(k)                                                                                              \
+    asm volatile("ds_write_addtid_b32 %0 offset:%c8\n\tds_write_addtid_b32 %1 offset:%c9\n\t"                        \
+                 "ds_write_addtid_b32 %2 offset:%c10\n\tds_write_addtid_b32 %3 offset:%c11\n\t"                      \
+                 "ds_write_addtid_b32 %4 offset:%c12\n\tds_write_addtid_b32 %5 offset:%c13\n\t"                      \
+                 "ds_write_addtid_b32 %6 offset:%c14\n\tds_write_addtid_b32 %7 offset:%c15"                          \
+                 :                                                                                                    \
+                 : "v"(r[(k)].x), "v"(r[(k)].y), "v"(r[(k) + 1].x), "v"(r[(k) + 1].y), "v"(r[(k) + 2].x),           \
+                   "v"(r[(k) + 2].y), "v"(r[(k) + 3].x), "v"(r[(k) + 3].y), "i"((k) * kW64Row * 4),                  \
+                   "i"((k) * kW64Row * 4 + 256), "i"(((k) + 1) * kW64Row * 4), "i"(((k) + 1) * kW64Row * 4 + 256),   \
+                   "i"(((k) + 2) * kW64Row * 4), "i"(((k) + 2) * kW64Row * 4 + 256), "i"(((k) + 3) * kW64Row * 4),   \
+                   "i"(((k) + 3) * kW64Row * 4 + 256)                                                                 \
+                 : "memory")
+
+__device__ __forceinline__ void w64_store(const cf* r, uint32_t base)
+{
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(base) : "memory");
+    GR4PM_ADDTID4(0);
+    GR4PM_ADDTID4(4);
+    GR4PM_ADDTID4(8);
+    GR4PM_ADDTID4(12);
+    GR4PM_ADDTID4(16);
+    GR4PM_ADDTID4(20);
+    GR4PM_ADDTID4(24);
+    GR4PM_ADDTID4(28);
+}
+#undef GR4PM_ADDTID4
+
+// rows k and k + 16 of the exchange, issued from inside the last stage of pass A (M0 already holds the
+// buffer address: w64_store_begin)
+__device__ __forceinline__ void w64_store_begin(uint32_t base)
+{
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(base) : "memory");
+}
+template <int K>
+__device__ __forceinline__ void w64_store_pair(const cf* r)
+{
+    asm volatile("ds_write_addtid_b32 %0 offset:%c4\n\tds_write_addtid_b32 %1 offset:%c5\n\t"
+                 "ds_write_addtid_b32 %2 offset:%c6\n\tds_write_addtid_b32 %3 offset:%c7"
+                 :
+                 : "v"(r[K].x), "v"(r[K].y), "v"(r[K + 16].x), "v"(r[K + 16].y), "i"(K * kW64Row * 4),
+                   "i"(K * kW64Row * 4 + 256), "i"((K + 16) * kW64Row * 4), "i"((K + 16) * kW64Row * 4 + 256)
+                 : "memory");
+}
+struct W64StoreHook {
+    const cf* r;
+    __device__ __forceinline__ void operator()(int k) const
+    {
+        switch (k) { // k is a compile-time constant after unrolling
+        case 0: w64_store_pair<0>(r); break;
+        case 1: w64_store_pair<1>(r); break;
+        case 2: w64_store_pair<2>(r); break;
+        case 3: w64_store_pair<3>(r); break;
+        case 4: w64_store_pair<4>(r); break;
+        case 5: w64_store_pair<5>(r); break;
+        case 6: w64_store_pair<6>(r); break;
+        case 7: w64_store_pair<7>(r); break;
+        case 8: w64_store_pair<8>(r); break;
+        case 9: w64_store_pair<9>(r); break;
+        case 10: w64_store_pair<10>(r); break;
+        case 11: w64_store_pair<11>(r); break;
+        case 12: w64_store_pair<12>(r); break;
+        case 13: w64_store_pair<13>(r); break;
+        case 14: w64_store_pair<14>(r); break;
+        default: w64_store_pair<15>(r); break;
+        }
+    }
+};
+
+// 16 KiB template, global -> this wave's exchange buffer, linear ([u][lane] float4), by the
+// LDS-DMA path: 16 pieces of 1 KiB, LDS address of a piece = M0 + 16 * lane.  All LDS reads of
+// the wave have returned before the first piece is issued (s_waitcnt lgkmcnt(0)): the DMA is
+// not ordered against them by the LDS queue.
+__device__ __forceinline__ void w64_dma_template(const float4* tg, uint32_t base, uint32_t voff)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // opaque copies: otherwise the 16 offsets / 16 LDS addresses are hoisted out of the block loop
+    // and live (or spill) across the whole kernel
+    asm volatile("" : "+v"(voff), "+s"(base));
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        // global address = tg (SGPR pair) + per-lane byte offset (lane * 16 + u * 1024)
+        const uint32_t vo = voff + u * 1024u;
+        const uint32_t b0 = base + u * 1024u;
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(vo), "s"(tg), "s"(b0) : "memory");
+    }
+}
+
+// Issue order: the reads of group g + 1, then the arithmetic of group g, and nothing further ahead.
+// A "memory" barrier alone is not enough -- hipcc keeps the reads in order but sinks all the
+// arithmetic below them (48 x 16 bytes in flight = 192 VGPRs, spills): the barrier also takes the
+// group's results as operands, so they exist before the next reads are issued.
+__device__ __forceinline__ void w64_pin4(cf* b)
+{
+    asm volatile("" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])::"memory");
+}
+// the same arithmetic on two consecutive m at a time with packed FP32 (the planar reads put re[m], re[m+1]
+// in one register pair): 8 packed instructions per pair + 2 v_pk_mov_b32 to interleave (re, im) for pass B,
+// instead of 16 scalar ones -- fewer issue slots per wave (a lone wave issues one VALU op per 4 cycles,
+// packed or not)
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void w64_mid_pair(f2 a0r, f2 a1r, f2 a0i, f2 a1i, f2 tr, f2 ti, cf c, cf* b)
+{
+    f2 ur, ui, br, bi, t;
+    // ur = a0r + c.x a1r - c.y a1i ; ui = a0i + c.x a1i + c.y a1r   (c.x / c.y broadcast with op_sel)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(t) : "v"(a1r), "v"(c), "v"(a0r));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0] neg_hi:[0,1,0]"
+        : "=v"(ur)
+        : "v"(a1i), "v"(c), "v"(t));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(t) : "v"(a1i), "v"(c), "v"(a0i));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(ui) : "v"(a1r), "v"(c), "v"(t));
+    // br = tr ur - ti ui ; bi = tr ui + ti ur
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(t) : "v"(tr), "v"(ur));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(br) : "v"(ti), "v"(ui), "v"(t));
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(t) : "v"(tr), "v"(ui));
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(bi) : "v"(ti), "v"(ur), "v"(t));
+    // (br.lo, bi.lo), (br.hi, bi.hi)
+    asm("v_pk_mov_b32 %0, %1, %2 op_sel:[0,0]" : "=v"(b[0]) : "v"(br), "v"(bi));
+    asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,1]" : "=v"(b[1]) : "v"(br), "v"(bi));
+}
+
+template <int DEPTH, bool PACKED, bool FAKE = false>
+__device__ __forceinline__ void w64_mid_dev(int lane, const float4* row, const float4* tT, cf c, cf* b)
+{
+    if (FAKE) { // timing-only ablation: no LDS reads, same arithmetic on register values
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            float4 s0 = make_float4(c.x, c.y, c.x + g, c.y), s1 = make_float4(c.y, c.x, g, c.y);
+            asm volatile("" : "+v"(s0.x), "+v"(s0.y), "+v"(s0.z), "+v"(s0.w), "+v"(s1.x), "+v"(s1.y), "+v"(s1.z), "+v"(s1.w));
+            w64_mid_group(s0, s1, s1, s0, s0, s1, c, b + 4 * g);
+            w64_pin4(b + 4 * g);
+        }
+        return;
+    }
+    // q[g % (DEPTH + 1)] holds group g's six reads; groups g + 1 .. g + DEPTH are in flight while g is consumed
+    float4 q[DEPTH + 1][6];
+    auto issue = [&](int g) {
+        float4* d = q[g % (DEPTH + 1)];
+        d[0] = row[g], d[1] = row[8 + g], d[2] = row[16 + g], d[3] = row[24 + g];
+        d[4] = tT[(g * 2 + 0) * 64 + lane], d[5] = tT[(g * 2 + 1) * 64 + lane];
+    };
+#pragma unroll
+    for (int g = 0; g < DEPTH; ++g) issue(g);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        if (g + DEPTH < 8) issue(g + DEPTH);
+        const float4* s = q[g % (DEPTH + 1)];
+        if (PACKED) {
+            w64_mid_pair(f2{ s[0].x, s[0].y }, f2{ s[1].x, s[1].y }, f2{ s[2].x, s[2].y }, f2{ s[3].x, s[3].y },
+                         f2{ s[4].x, s[4].y }, f2{ s[5].x, s[5].y }, c, b + 4 * g);
+            w64_mid_pair(f2{ s[0].z, s[0].w }, f2{ s[1].z, s[1].w }, f2{ s[2].z, s[2].w }, f2{ s[3].z, s[3].w },
+                         f2{ s[4].z, s[4].w }, f2{ s[5].z, s[5].w }, c, b + 4 * g + 2);
+        } else {
+            w64_mid_group(s[0], s[1], s[2], s[3], s[4], s[5], c, b + 4 * g);
+        }
+        w64_pin4(b + 4 * g);
+    }
+}
+
+// ---- interleaved layout (VAR bit 8 = 256): ds_write_b64 stores, cmul-based mid stage
+__device__ __forceinline__ void w64c_store(const cf* r, cf* xbc, int lane)
+{
+#pragma unroll
+    for (int k1 = 0; k1 < 32; ++k1) xbc[k1 * (kW64Row / 2) + lane] = r[k1];
+    asm volatile("" ::: "memory");
+}
+// u = a0 + c a1 (two packed FMAs), b = T u (cmul)
+__device__ __forceinline__ cf w64c_mid1_dev(cf a0, cf a1, cf t, cf c)
+{
+    cf s, u;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(s) : "v"(a1), "v"(c), "v"(a0));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(u) : "v"(a1), "v"(c), "v"(s));
+    return cmul(u, t);
+}
+template <int DEPTH>
+__device__ __forceinline__ void w64c_mid_dev(int lane, const float4* row, const float4* tC, cf c, cf* b)
+{
+    float4 q[DEPTH + 1][3];
+    auto issue = [&](int i) {
+        float4* d = q[i % (DEPTH + 1)];
+        d[0] = row[i], d[1] = row[16 + i], d[2] = tC[i * 64 + lane];
+    };
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i) issue(i);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (i + DEPTH < 16) issue(i + DEPTH);
+        const float4* s = q[i % (DEPTH + 1)];
+        b[2 * i] = w64c_mid1_dev(mk(s[0].x, s[0].y), mk(s[1].x, s[1].y), mk(s[2].x, s[2].y), c);
+        b[2 * i + 1] = w64c_mid1_dev(mk(s[0].z, s[0].w), mk(s[1].z, s[1].w), mk(s[2].z, s[2].w), c);
+        if (i & 1) w64_pin4(b + 2 * i - 2);
+    }
+}
+
+// tmpl: [bin][u = 16][lane = 64] float4 = (T[lane + 128 u], T[lane + 128 u + 64]) (conjugated
+// template spectra, hpp:166-189); tT / cc: build_w64_tables.  total = n_channels * n_blocks items.
+// VAR: tuning / ablation variants selected at run time (GR4PM_W64_VARIANT): bit 0 = mid-stage reads three
+// groups ahead instead of two, bit 1 = all sixteen template reads issued up front, bit 2 = waves 4-7 start
+// half a transform late, bit 4 (16) = packed mid stage; 8 = timing-only ablation without the template DMA (wrong results)
+template <int VAR>
+__global__ __launch_bounds__(kW64Threads, 2) void k_correlate_w64(const cf* __restrict__ in, size_t in_stride,
+                                                                  uint32_t n_blocks, uint32_t total,
+                                                                  uint32_t stride_s, int n_bins,
+                                                                  const float4* __restrict__ tmpl,
+                                                                  const float4* __restrict__ tT,
+                                                                  const cf* __restrict__ cc,
+                                                                  float* __restrict__ zpow, size_t z_stride)
+{
+    __shared__ float4 lds4[kW64LdsF4];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < kW64TwFloat4; i += kW64Threads) lds4[i] = tT[i];
+    __syncthreads(); // the only workgroup-wide synchronisation of the kernel
+    float4* xb4 = lds4 + kW64TwFloat4 + wave * kW64BufF4;
+    // LDS byte address of the buffer (what DS instructions and M0 take)
+    const uint32_t base = __builtin_amdgcn_readfirstlane(
+        static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)xb4)));
+    const float4* row = xb4 + (lane & 31) * (kW64Row / 4);
+    cf* xbc = reinterpret_cast<cf*>(xb4);
+    constexpr bool kC = (VAR & 256) != 0; // interleaved exchange layout (tT then holds build_w64_tables_c's table)
+    const float4* ldsT = lds4;
+    const cf c = cc[lane];
+    const uint32_t voff = static_cast<uint32_t>(lane) * 16u;
+    const uint32_t n_waves = gridDim.x * kW64Waves;
+    uint32_t item = blockIdx.x * kW64Waves + wave;
+    if (item >= total) return;
+    constexpr int kMidDepth = (VAR & 1) ? 2 : 1;
+    if ((VAR & 4) && wave >= 4) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) __builtin_amdgcn_s_sleep(8); // ~2500 cycles: half a transform
+    }
+
+    cf X[32];
+    {
+        const uint32_t ch = item / n_blocks, b = item - ch * n_blocks;
+        const cf* x = in + static_cast<size_t>(ch) * in_stride + static_cast<size_t>(b) * stride_s + lane;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) X[j] = x[64 * j];
+    }
+    for (;;) {
+        const uint32_t ch = item / n_blocks, blk = item - ch * n_blocks;
+        float* zo = zpow + static_cast<size_t>(ch) * z_stride + static_cast<size_t>(blk) * stride_s;
+        const uint32_t next = item + n_waves;
+        const bool has_next = next < total;
+        // ---- forward transform of the block (hpp:239-241)
+        {
+            cf bq[32];
+            dft32(X);
+            if (kC) {
+                w64c_store(X, xbc, lane);
+                w64c_mid_dev<2 * kMidDepth>(lane, row, ldsT, c, bq);
+            } else {
+                if (!(VAR & 32)) w64_store(X, base);
+                w64_mid_dev<kMidDepth, (VAR & 16) != 0, (VAR & 64) != 0>(lane, row, ldsT, c, bq);
+            }
+            if (!(VAR & 8)) w64_dma_template(tmpl, base, voff); // template 0 while pass B runs
+            dft32(bq);
+#pragma unroll
+            for (int j = 0; j < 32; ++j) X[j] = bq[j];
+        }
+        float zmax[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) zmax[j] = -1.0f; // hpp:303
+        for (int bin = 0; bin < n_bins; ++bin) {
+            cf p[32], bq[32];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the template has landed in the exchange buffer
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { // hpp:247-249
+                float4 t;
+                if (VAR & 128) {
+                    t = make_float4(c.x, c.y, c.y, c.x);
+                    asm volatile("" : "+v"(t.x), "+v"(t.y), "+v"(t.z), "+v"(t.w));
+                } else {
+                    t = xb4[u * 64 + lane];
+                }
+                p[2 * u] = cmul(X[2 * u], mk(t.x, t.y));
+                p[2 * u + 1] = cmul(X[2 * u + 1], mk(t.z, t.w));
+                if (!(VAR & 2) && (u & 1) == 1 && u >= 3) w64_pin4(p + 2 * u - 6); // at most four template reads ahead of their use
+            }
+#if !defined(GR4PM_W64_NOPREFETCH)
+            if (bin == n_bins - 1 && has_next) {
+                // the spectrum is dead: its registers take the samples of this wave's next block,
+                // which arrive while the last transform of this one runs
+                const uint32_t nch = next / n_blocks, nb = next - nch * n_blocks;
+                int ln = lane;
+                asm volatile("" : "+v"(ln)); // addresses are formed here, not hoisted out of the block loop
+                const cf* x = in + static_cast<size_t>(nch) * in_stride + static_cast<size_t>(nb) * stride_s + ln;
+#pragma unroll
+                for (int j = 0; j < 32; ++j) X[j] = x[64 * j];
+            }
+#endif
+            if (VAR & 512) { // stores issued from inside the last stage of the transform
+                w64_store_begin(base);
+                dft32(p, W64StoreHook{ p });
+            } else {
+                dft32(p); // hpp:250-251
+            }
+            if (kC) {
+                w64c_store(p, xbc, lane);
+                w64c_mid_dev<2 * kMidDepth>(lane, row, ldsT, c, bq);
+            } else {
+                if (!(VAR & (32 | 512))) w64_store(p, base);
+                if (VAR & 32) { // timing-only ablation: no exchange stores, but pass A stays alive
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) asm volatile("" ::"v"(p[j]));
+                }
+                w64_mid_dev<kMidDepth, (VAR & 16) != 0, (VAR & 64) != 0>(lane, row, ldsT, c, bq);
+            }
+            if (!(VAR & 8) && bin + 1 < n_bins) w64_dma_template(tmpl + static_cast<size_t>(bin + 1) * 1024, base, voff);
+            dft32(bq);
+            if (VAR & 1024) { // timing-only ablation: no power / maximum
+#pragma unroll
+                for (int j = 0; j < 32; ++j) asm volatile("" ::"v"(bq[j]));
+            } else
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                // hpp:307-308: the best bin's power (max() == the strict-> scan for the VALUE)
+                const float pw = fmaf(bq[j].y, bq[j].y, bq[j].x * bq[j].x);
+                asm("v_max_f32 %0, %1, %2" : "=v"(zmax[j]) : "v"(zmax[j]), "v"(pw));
+            }
+        }
+        // lag k <-> correlation index (N - k) mod N (hpp:300); register j of lane l holds index l + 64 j
+        {
+            int ln = lane;
+            asm volatile("" : "+v"(ln)); // as above: no 32 hoisted lag registers
+            float* zl = zo + (kFftN - ln); // lag of register j: 2048 - lane - 64 j (j = 0, lane = 0: lag 0)
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const uint32_t lag = static_cast<uint32_t>((kFftN - (ln + 64 * j)) & (kFftN - 1));
+                if (j == 0) {
+                    if (lag < stride_s) zo[lag] = zmax[0];
+                } else if (lag < stride_s) {
+                    zl[-64 * j] = zmax[j];
+                }
+            }
+        }
+        if (!has_next) break;
+        item = next;
+    }
+}
+
+} // namespace
+} // namespace gr4pm

@@ -34,6 +34,7 @@
 #include "common.hpp"
 #include "fft2048_wave.hpp"
 #include "fft2048_pair.hpp"
+#include "fft2048_w64.hpp"
 
 #ifndef GR4PM_ABL
 #define GR4PM_ABL 0
@@ -468,6 +469,12 @@ __global__ __launch_bounds__(kPairThreads, 3) void k_correlate_pair(
         if (lag < stride_s) zo[lag] = zmax[j];
     }
 }
+
+} // namespace
+} // namespace gr4pm
+#include "correlate_w64.hpp"
+namespace gr4pm {
+namespace {
 
 // ------------------------------------------------------------------ k_candidates
 // B(p) = zpow[p] >= max(zpow[p+1 .. p+T]) for local positions [0, cnt) of a channel; z points
@@ -1192,6 +1199,13 @@ struct gr4pm_syncword_detection {
     // device
     DevBuf<float4> tmpl;
     DevBuf<cf> tw; // tw1a ++ tw1b ++ twA ++ twB (fft2048_wave.hpp)
+    // the one-exchange correlator (fft2048_w64.hpp, k_correlate_w64): templates in its lane order
+    // ([bin][16][64] float4), mid-stage twiddle table, lane constants
+    int corr_kind = 0; // 0: k_correlate_w64 (default), 1: k_correlate (two exchanges), 2: k_correlate_pair
+    DevBuf<float4> tmpl64, tT64, tC64;
+    DevBuf<cf> cc64;
+    int n_cus = 256;
+    int w64_variant = 0;
     // the two-waves-per-block correlator (fft2048_pair.hpp): templates in its lane order,
     // tw1p ++ twAp ++ twB
     bool use_pair = false;
@@ -1334,6 +1348,38 @@ gr4pm_status launch_correlate(gr4pm_syncword_detection* h, hipStream_t stream, c
                            in_stride, n_blocks, static_cast<uint32_t>(h->S), h->n_bins, h->tmplp.p, h->twp.p,
                            h->tw.p + kTw1aItems, reinterpret_cast<const float4*>(h->twp.p + kTw1pItems), zout,
                            h->z_stride);
+        GR4PM_HIP_TRY(hipGetLastError());
+        return GR4PM_OK;
+    }
+    if (h->corr_kind == 0) {
+        // persistent waves: one 8-wave workgroup per CU, every wave walks items wave, wave + W, ...
+        const uint32_t total = n_blocks * static_cast<uint32_t>(h->n_channels);
+        const uint32_t wgs = std::min<uint32_t>(static_cast<uint32_t>(h->n_cus), (total + kW64Waves - 1) / kW64Waves);
+#define GR4PM_W64_LAUNCH(V)                                                                                         \
+    hipLaunchKernelGGL(k_correlate_w64<V>, dim3(wgs), dim3(kW64Threads), 0, stream, reinterpret_cast<const cf*>(in), \
+                       in_stride, n_blocks, total, static_cast<uint32_t>(h->S), h->n_bins, h->tmpl64.p,             \
+                       ((V) & 256) ? h->tC64.p : h->tT64.p,                                                         \
+                       h->cc64.p, zout, h->z_stride)
+        switch (h->w64_variant) {
+        case 1: GR4PM_W64_LAUNCH(1); break;
+        case 2: GR4PM_W64_LAUNCH(2); break;
+        case 3: GR4PM_W64_LAUNCH(3); break;
+        case 4: GR4PM_W64_LAUNCH(4); break;
+        case 7: GR4PM_W64_LAUNCH(7); break;
+        case 8: GR4PM_W64_LAUNCH(8); break;
+        case 16: GR4PM_W64_LAUNCH(16); break;
+        case 32: GR4PM_W64_LAUNCH(32); break;
+        case 64: GR4PM_W64_LAUNCH(64); break;
+        case 128: GR4PM_W64_LAUNCH(128); break;
+        case 232: GR4PM_W64_LAUNCH(232); break;
+        case 256: GR4PM_W64_LAUNCH(256); break;
+        case 257: GR4PM_W64_LAUNCH(257); break;
+        case 512: GR4PM_W64_LAUNCH(512); break;
+        case 248: GR4PM_W64_LAUNCH(248); break;
+        case 1256: GR4PM_W64_LAUNCH(1256); break;
+        default: GR4PM_W64_LAUNCH(0); break;
+        }
+#undef GR4PM_W64_LAUNCH
         GR4PM_HIP_TRY(hipGetLastError());
         return GR4PM_OK;
     }
@@ -1505,7 +1551,7 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
     for (auto x : sw) self_corr += x.real() * x.real() + x.imag() * x.imag(); // hpp:161-164
     h->self_corr = self_corr;
     std::vector<float4> tmpl(h->generic ? 1 : static_cast<size_t>(n_bins) * 1024);
-    std::vector<float4> tmplp(tmpl.size());
+    std::vector<float4> tmplp(tmpl.size()), tmpl64(tmpl.size());
     std::vector<cf> g_tmpl(h->generic ? static_cast<size_t>(n_bins) * p->fft_size : 0);
     for (int b = 0; b < n_bins; ++b) {
         const int freq_bin = p->min_freq_bin + b;
@@ -1539,6 +1585,14 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
                     make_float4(static_cast<float>(t0.real()), static_cast<float>(t0.imag()),
                                 static_cast<float>(t1.real()), static_cast<float>(t1.imag()));
             }
+        for (int lane = 0; lane < 64; ++lane) // and in the one-exchange schedule's: index lane + 64 j
+            for (int u = 0; u < 16; ++u) {
+                const auto t0 = std::conj(a[w64_index(lane, 2 * u)]);
+                const auto t1 = std::conj(a[w64_index(lane, 2 * u + 1)]);
+                tmpl64[static_cast<size_t>(b) * 1024 + u * 64 + lane] =
+                    make_float4(static_cast<float>(t0.real()), static_cast<float>(t0.imag()),
+                                static_cast<float>(t1.real()), static_cast<float>(t1.imag()));
+            }
         for (int L = 0; L < 128; ++L) // the same values in the pair schedule's lane order
             for (int jp = 0; jp < 8; ++jp) {
                 const auto t0 = std::conj(a[fft1p_out_index(L, 2 * jp)]);
@@ -1564,9 +1618,37 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
         },
         twp.data(), twp.data() + kTw1pItems);
     for (int i = 0; i < kTwBItems; ++i) twp[kTw1pItems + kTwApItems + i] = tw[kTw1aItems + kTw1bItems + kTwAItems + i];
+    std::vector<float4> tT64(kW64TwFloat4);
+    std::vector<cf> cc64(64);
+    build_w64_tables(
+        [](int k) {
+            const double ang = -2.0 * M_PI * k / kFftN;
+            return mk(static_cast<float>(std::cos(ang)), static_cast<float>(std::sin(ang)));
+        },
+        tT64.data(), cc64.data());
+    std::vector<float4> tC64(kW64TwFloat4);
+    build_w64_tables_c(
+        [](int k) {
+            const double ang = -2.0 * M_PI * k / kFftN;
+            return mk(static_cast<float>(std::cos(ang)), static_cast<float>(std::sin(ang)));
+        },
+        tC64.data());
     {
-        const char* e = getenv("GR4PM_CORRELATOR"); // "pair" / "wave": which of the two bit-identical kernels runs
-        h->use_pair = !h->generic && e && std::string(e) == "pair";
+        // which correlator kernel runs: "w64" (default: one LDS exchange per transform), "wave" (round 1: two
+        // exchanges; bit-identical to "pair", two waves per block)
+        const char* e = getenv("GR4PM_CORRELATOR");
+        const std::string k = e ? e : "w64";
+        h->use_pair = !h->generic && k == "pair";
+        h->corr_kind = k == "pair" ? 2 : k == "wave" ? 1 : 0;
+        const char* v = getenv("GR4PM_W64_VARIANT");
+        h->w64_variant = v ? atoi(v) : 16; // 16: packed mid stage (the fastest measured, tools/w64_variants.py)
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            h->n_cus = prop.multiProcessorCount;
+        // GR4PM_W64_CUS: persistent workgroups of the correlator (default: one per CU); fewer leave whole CUs
+        // to the kernels of the other pipeline stages
+        if (const char* c = getenv("GR4PM_W64_CUS")) h->n_cus = std::max(1, std::min(h->n_cus, atoi(c)));
     }
 
     h->xc = static_cast<uint32_t>(round_up(h->hist + h->S + 2, 64));
@@ -1585,6 +1667,10 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
     ok(h->tmpl.alloc(tmpl.size()));
     ok(h->tw.alloc(tw.size()));
     ok(h->tmplp.alloc(tmplp.size()));
+    ok(h->tmpl64.alloc(tmpl64.size()));
+    ok(h->tT64.alloc(tT64.size()));
+    ok(h->tC64.alloc(tC64.size()));
+    ok(h->cc64.alloc(cc64.size()));
     ok(h->twp.alloc(twp.size()));
     std::vector<cf> g_tw(h->generic ? p->fft_size / 2 : 0);
     for (size_t k = 0; k < g_tw.size(); ++k) {
@@ -1623,6 +1709,10 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
     if (s == GR4PM_OK) s = h->tmpl.upload(tmpl.data(), tmpl.size(), h->stream);
     if (s == GR4PM_OK) s = h->tw.upload(tw.data(), tw.size(), h->stream);
     if (s == GR4PM_OK) s = h->tmplp.upload(tmplp.data(), tmplp.size(), h->stream);
+    if (s == GR4PM_OK && !h->generic) s = h->tmpl64.upload(tmpl64.data(), tmpl64.size(), h->stream);
+    if (s == GR4PM_OK) s = h->tT64.upload(tT64.data(), tT64.size(), h->stream);
+    if (s == GR4PM_OK) s = h->tC64.upload(tC64.data(), tC64.size(), h->stream);
+    if (s == GR4PM_OK) s = h->cc64.upload(cc64.data(), cc64.size(), h->stream);
     if (s == GR4PM_OK) s = h->twp.upload(twp.data(), twp.size(), h->stream);
     if (s == GR4PM_OK && hipStreamSynchronize(h->stream) != hipSuccess) s = GR4PM_ERR_HIP;
     if (s == GR4PM_OK) s = sd_reset(h);

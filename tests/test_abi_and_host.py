@@ -71,3 +71,14 @@ def test_one_wave_fft_schedules_host_emulation(tmp_path):
         assert float(err) < 5e-7 and int(bad) == 0
     # the pair schedules do the same arithmetic in another distribution: identical bits
     assert re.search(r"pair_vs_wave_differing_values 0\b", out)
+
+
+def test_one_exchange_wave_fft_host_emulation(tmp_path):
+    """fft2048_w64.hpp (the correlator's 32 x 64 schedule, one LDS exchange per transform): the 64 lanes run
+    phase by phase on the CPU, both exchange layouts, against a double DFT"""
+    exe = tmp_path / "fft_w64_emu"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ge.PKG_DIR, "csrc"), "-o", str(exe),
+                           os.path.join(ROOT, "tests", "fft_w64_emu.cpp")])
+    out = subprocess.check_output([str(exe)]).decode()
+    errs = [float(e) for e in re.findall(r"max_rel_err ([0-9.e+-]+)", out)]
+    assert len(errs) == 5 and max(errs) < 5e-7, out

@@ -29,7 +29,17 @@ def _worker(rank, world, port, out):
     def make_all():
         return torch.stack([torch.full((n,), complex(r + 1, -r), dtype=torch.complex64) for r in range(world)])
     mine = bench.scatter_channels(dist, make_all, n, torch.device("cpu"), rank, world)
-    out[rank] = (dt, total, complex(mine[0].item()), bool((mine == mine[0]).all()))
+    # configs[3]: one [channels, n] slab per rank from rank 0's host sample ring
+    C = 3
+    def make_bank():
+        host, _ = bench.host_sample_ring(world, (C, n))
+        for r in range(world):
+            for c in range(C):
+                host[r, c] = complex(10 * r + c, 0)
+        return host
+    slab = bench.scatter_channels(dist, make_bank, (C, n), torch.device("cpu"), rank, world)
+    slab_ok = slab.shape == (C, n) and all(bool((slab[c] == complex(10 * rank + c, 0)).all()) for c in range(C))
+    out[rank] = (dt, total, complex(mine[0].item()), bool((mine == mine[0]).all()) and slab_ok)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -50,3 +60,31 @@ def test_two_rank_aggregation_gloo():
 def test_single_rank_aggregation_is_identity():
     import bench
     assert bench.aggregate(None, 1.5, 42.0, torch.device("cpu")) == (1.5, 42.0)
+
+
+def test_bench_launcher_starts_one_process_per_gpu():
+    """`python bench.py --gpus 2` without a torch.distributed launcher starts two fresh ranks itself
+    (gloo rendezvous on 127.0.0.1 in --dry-run), rank 0 prints ONE line with n_gpus == --gpus"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["gpus_requested"] == 2
+    assert line["value"] == 3000.0 / 2.0   # SUM of items / MAX of times
+
+
+def test_bench_refuses_a_world_size_that_differs_from_gpus():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--dry-run"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "refusing" in r.stderr

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""k_correlate (one wave per block) against k_correlate_pair (two waves per block): same powers?
-how fast?  tools/compare_correlators.py [items] [reps] [bins]"""
+"""two correlator kernels (GR4PM_CORRELATOR = w64 / wave / pair) on the same input: same powers? how fast?
+tools/compare_correlators.py [items] [reps] [bins] [kindA,kindB]"""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,7 +15,7 @@ rrc = bench.unit_norm_rrc(pkg)
 x, _ = bench.burst_stream(pkg, n, rrc, 1, torch.device("cuda"))
 bpsk = np.array([1, -1], dtype=np.complex64)
 z = {}
-for kind in ("wave", "pair"):
+for kind in (sys.argv[4].split(",") if len(sys.argv) > 4 else ("wave", "w64")):
     os.environ["GR4PM_CORRELATOR"] = kind
     sd = pkg.SyncwordDetection(rrc, bench.SYNCWORD, bpsk, -bins, bins, power_threshold=9.5, max_items=n)
     st, out, tags, nd = sd.process_bulk(x, want_output=False, tags_cap=1 << 16)
@@ -29,7 +29,9 @@ for kind in ("wave", "pair"):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     print(f"{kind}: {dt * 1e3:.4f} ms/launch  {n / dt / 1e6:.1f} Msps  tags {tags.size}")
-a, b = z["wave"], z["pair"]
+kinds = list(z)
+a, b = z[kinds[0]], z[kinds[1]]
+print("full scale", float(a.max()), " max abs difference / full scale:", float(np.max(np.abs(a - b)) / a.max()))
 same = np.array_equal(a.view(np.uint32), b.view(np.uint32))
 rel = np.max(np.abs(a - b) / np.maximum(np.abs(a), 1e-30))
 print("identical bits:", same, " max relative difference:", rel, " differing:", int(np.sum(a != b)), "of", a.size)
