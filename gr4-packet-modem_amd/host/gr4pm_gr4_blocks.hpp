@@ -1,28 +1,45 @@
 // gr4pm_gr4_blocks.hpp -- GNU Radio 4.0 block wrappers over the C ABI (include/gr4pm_hip.h).
 //
-// Same namespace-level names, ports, settings and tag keys as the reference blocks, so a
-// flowgraph written against
+// Same class templates (parameter lists and defaults), ports, settings and tag keys as the
+// reference blocks, so that a flowgraph written against
 //   <gnuradio-4.0/packet-modem/syncword_detection.hpp> etc.
-// links against these instead by switching the include.  The classes live
-// in gr::packet_modem::hip to be able to coexist with the CPU blocks in one binary; add
-// `namespace gr::packet_modem { using hip::SyncwordDetection; }` for a pure drop-in.
+// compiles against these instead: put gr4-packet-modem_amd/host in front of the reference's
+// blocks/include on the include path -- host/gnuradio-4.0/packet-modem/*.hpp carry the reference's
+// header names and pull the classes below into gr::packet_modem.  The classes
+// themselves live in gr::packet_modem::hip so that they can coexist with the CPU blocks.
 //
-// gnuradio4 is NOT part of this repository's image (the reference's submodule is empty), so
-// this header is compile-checked only where gnuradio4 is installed.  It touches exactly the
-// GR4 surface the reference blocks touch: gr::Block<D>, PortIn/PortOut,
-// ConsumableSpan/PublishableSpan (size, begin, consume, publish), input_tags_present(),
-// mergedInputTag(), publishTag(), gr::exception, ENABLE_REFLECTION.
+// Supported instantiations are the ones the reference's receiver and benchmarks use
+// (packet_receiver.hpp:84-125, apps/packet_transceiver.cpp:71-73, python/bindings/register_*.cpp):
+// complex<float> items, float taps / phases; everything else is a static_assert, not a silent CPU path.
 //
-// Staging: GR4 port buffers are host memory; each wrapper owns a device input and output
-// buffer and copies through the handle's stream.  Chains that should stay in HBM use the
-// C ABI directly with device rings (bench.py does).
+// gnuradio4 is not in this repository's image.  The header is compiled by __graft_entry__.build()
+// and driven by tests/gr4_blocks_driver.cpp against tests/gr4_stub/ (a test-only stand-in for the
+// GR4 surface used here: gr::Block<D>, PortIn/PortOut, ConsumableSpan/PublishableSpan (size, begin,
+// consume, publish), input_tags_present(), mergedInputTag(), publishTag(), gr::exception,
+// ENABLE_REFLECTION) -- SURVEY.md 8(b).
+//
+// Staging.  GR4 port buffers are host memory; the kernels work on device memory.  A wrapped block
+// uploads its input span and downloads its output span -- unless the span it is handed was written
+// by another wrapped block: every block leaves its device-side output registered in a process-wide
+// arena keyed by the HOST address of the span it published (detail::Arena), and a consumer whose
+// input span lies inside such a registration reads the device copy (no H2D).  With the setting
+// `host_output = false` a block also skips its D2H copy; if a consumer that is not a wrapped block
+// (or a partial consumer) shows up later, the unconsumed remainder is written back to the host ring
+// before the device buffer is reused.  So a chain of wrapped blocks stages once at its entry and
+// once at its exit.  Every HIP call is checked.
 #pragma once
 #include <gnuradio-4.0/Block.hpp>
 #include <gnuradio-4.0/reflection.hpp>
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cctype>
+#include <cstdio>
 #include <complex>
+#include <cstdlib>
+#include <fstream>
+#include <mutex>
+#include <sstream>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -36,23 +53,163 @@ inline void check(gr4pm_status s, const char* what)
 {
     if (s < 0) throw gr::exception(std::string(what) + ": " + gr4pm_last_error());
 }
+inline void check_hip(hipError_t e, const char* what)
+{
+    if (e != hipSuccess) throw gr::exception(std::string(what) + ": " + hipGetErrorString(e));
+}
+// largest chunk a wrapper hands to the library in one call (the handles are created for it)
+inline size_t max_items()
+{
+    static const size_t n = [] {
+        const char* e = std::getenv("GR4PM_GR4_MAX_ITEMS");
+        const size_t v = e ? static_cast<size_t>(std::strtoull(e, nullptr, 10)) : (size_t{ 1 } << 22);
+        return std::max<size_t>(v, 4096);
+    }();
+    return n;
+}
+
+// Device-side shadows of published output spans, keyed by host address.
+class Arena
+{
+public:
+    struct Seg {
+        const void* owner;
+        const char* host;
+        char* dev;
+        size_t bytes, consumed;
+        bool on_host; // the host span already holds the data
+    };
+    static Arena& instance()
+    {
+        static Arena a;
+        return a;
+    }
+    // consumer side: device address of [host, host + bytes) if a producer left it here
+    const void* find(const void* host, size_t bytes)
+    {
+        std::lock_guard<std::mutex> g(_m);
+        const char* h = static_cast<const char*>(host);
+        for (auto& s : _segs)
+            if (h >= s.host && h + bytes <= s.host + s.bytes) return s.dev + (h - s.host);
+        return nullptr;
+    }
+    void consumed(const void* host, size_t bytes)
+    {
+        std::lock_guard<std::mutex> g(_m);
+        const char* h = static_cast<const char*>(host);
+        for (auto& s : _segs)
+            if (h >= s.host && h + bytes <= s.host + s.bytes) s.consumed = std::max(s.consumed, static_cast<size_t>(h - s.host) + bytes);
+    }
+    // write back what the host does not hold yet of every registration that overlaps [host, host + bytes)
+    void flush(const void* host, size_t bytes)
+    {
+        std::lock_guard<std::mutex> g(_m);
+        const char* h = static_cast<const char*>(host);
+        for (auto& s : _segs)
+            if (!s.on_host && h < s.host + s.bytes && s.host < h + bytes) {
+                check_hip(hipMemcpy(const_cast<char*>(s.host), s.dev, s.bytes, hipMemcpyDeviceToHost), "arena flush");
+                s.on_host = true;
+            }
+    }
+    // producer side: forget this producer's previous span; what nobody consumed and the host does not hold
+    // yet is written back first (the device buffer is about to be reused)
+    void retire(const void* owner)
+    {
+        std::lock_guard<std::mutex> g(_m);
+        for (size_t i = 0; i < _segs.size();) {
+            if (_segs[i].owner == owner) {
+                const Seg s = _segs[i];
+                if (!s.on_host && s.consumed < s.bytes)
+                    check_hip(hipMemcpy(const_cast<char*>(s.host) + s.consumed, s.dev + s.consumed,
+                                        s.bytes - s.consumed, hipMemcpyDeviceToHost),
+                              "arena write-back");
+                _segs.erase(_segs.begin() + static_cast<ptrdiff_t>(i));
+            } else {
+                ++i;
+            }
+        }
+    }
+    void publish(const void* owner, const void* host, void* dev, size_t bytes, bool on_host)
+    {
+        if (bytes == 0) return;
+        std::lock_guard<std::mutex> g(_m);
+        const char* h = static_cast<const char*>(host);
+        // a new span over the same host memory supersedes whatever was registered there
+        for (size_t i = 0; i < _segs.size();)
+            if (h < _segs[i].host + _segs[i].bytes && _segs[i].host < h + bytes)
+                _segs.erase(_segs.begin() + static_cast<ptrdiff_t>(i));
+            else
+                ++i;
+        _segs.push_back({ owner, h, static_cast<char*>(dev), bytes, 0, on_host });
+    }
+
+private:
+    std::mutex _m;
+    std::vector<Seg> _segs;
+};
+
 // device staging buffer that grows on demand
 template <typename T>
 struct DeviceStage {
     T* p = nullptr;
     size_t n = 0;
-    ~DeviceStage() { if (p) (void)hipFree(p); }
+    DeviceStage() = default;
+    DeviceStage(const DeviceStage&) = delete;
+    DeviceStage& operator=(const DeviceStage&) = delete;
+    ~DeviceStage()
+    {
+        try {
+            Arena::instance().retire(this);
+        } catch (...) {
+        }
+        if (p) (void)hipFree(p);
+    }
     T* get(size_t count)
     {
         if (count > n) {
-            if (p) (void)hipFree(p);
-            if (hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)) != hipSuccess)
-                throw gr::exception("hipMalloc failed");
+            Arena::instance().retire(this);
+            if (p) check_hip(hipFree(p), "hipFree");
+            p = nullptr;
+            check_hip(hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T)), "hipMalloc");
             n = count;
         }
         return p;
     }
+    // input of a block: the producer's device copy if the span was published by a wrapped block, else H2D
+    template <typename H>
+    const T* in(const H* host, size_t count)
+    {
+        static_assert(sizeof(H) == sizeof(T));
+        if (count == 0) return get(1);
+        if (const void* d = Arena::instance().find(host, count * sizeof(T))) {
+            if (std::getenv("GR4PM_GR4_DEBUG")) std::fprintf(stderr, "arena hit  %p %zu\n", static_cast<const void*>(host), count);
+            return static_cast<const T*>(d);
+        }
+        if (std::getenv("GR4PM_GR4_DEBUG")) std::fprintf(stderr, "arena miss %p %zu\n", static_cast<const void*>(host), count);
+        // a span that only partly lies in a device-only registration: bring the host copy up to date first
+        Arena::instance().flush(host, count * sizeof(T));
+        T* d = get(count);
+        check_hip(hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice), "hipMemcpy H2D");
+        return d;
+    }
+    // buffer for `count` output items (the previous output span is retired first)
+    T* out(size_t count)
+    {
+        Arena::instance().retire(this);
+        return get(count);
+    }
+    // `count` items of the output buffer become the host span [host, host + count)
+    template <typename H>
+    void publish(H* host, size_t count, bool host_output)
+    {
+        static_assert(sizeof(H) == sizeof(T));
+        if (count == 0) return;
+        if (host_output) check_hip(hipMemcpy(host, p, count * sizeof(T), hipMemcpyDeviceToHost), "hipMemcpy D2H");
+        Arena::instance().publish(this, host, p, count * sizeof(T), host_output);
+    }
 };
+inline void consumed(const void* host, size_t bytes) { Arena::instance().consumed(host, bytes); }
+
 inline gr::property_map to_map(const gr4pm_tag& t)
 {
     // syncword_detection.hpp:106-114
@@ -76,16 +233,29 @@ inline gr4pm_tag from_map(const gr::property_map& m, uint64_t index)
         if (!k.starts_with("syncword_")) t.flags |= GR4PM_TAG_OTHER;
     return t;
 }
+inline int constellation_id(const std::string& s)
+{
+    std::string u;
+    for (char c : s) u.push_back(static_cast<char>(std::toupper(static_cast<unsigned char>(c))));
+    if (u == "PILOT") return 0;
+    if (u == "BPSK") return 1;
+    if (u == "QPSK") return 2;
+    throw gr::exception("unknown constellation " + s); // enum_cast(...).value() throws, costas_loop.hpp:59-61
+}
+template <typename T>
+inline constexpr bool is_c64 = std::is_same_v<T, std::complex<float>>;
 } // namespace detail
+
+using c64 = std::complex<float>;
 
 // ---------------------------------------------------------------- SyncwordDetection
 // replaces gr::packet_modem::SyncwordDetection (syncword_detection.hpp:32-357)
 class SyncwordDetection : public gr::Block<SyncwordDetection>
 {
-    using c64 = std::complex<float>;
     gr4pm_syncword_detection* _h = nullptr;
     detail::DeviceStage<gr4pm_c64> _din, _dout;
     std::vector<gr4pm_tag> _tags;
+    size_t _max_items = 0;
 
 public:
     size_t _syncword_samples_size = 0; // read by tests/apps (qa_syncword_detection.cpp:133)
@@ -100,7 +270,10 @@ public:
     int max_freq_bin = 0;
     uint64_t time_threshold = 768;
     float power_threshold = 9.5;
+    bool host_output = true; // false: downstream is a wrapped block, keep the samples on the device
 
+    SyncwordDetection() = default;
+    SyncwordDetection(const SyncwordDetection&) = delete;
     ~SyncwordDetection() { gr4pm_syncword_detection_destroy(_h); }
 
     void start()
@@ -121,12 +294,13 @@ public:
         p.time_threshold = time_threshold;
         p.power_threshold = power_threshold;
         p.n_channels = 1;
-        p.max_items = size_t{ 1 } << 22;
-        detail::check(gr4pm_syncword_detection_create(&p, &_h), "SyncwordDetection::start");
+        _max_items = std::max(detail::max_items(), 2 * fft_size);
+        p.max_items = _max_items;
+        detail::check(gr4pm_syncword_detection_create(&p, &_h), "SyncwordDetection::start"); // :146,151 throw
         _syncword_samples_size = gr4pm_syncword_detection_syncword_samples_size(_h);
         in.min_samples = fft_size; // syncword_detection.hpp:200-201
         out.min_samples = fft_size;
-        _tags.resize(4096);
+        _tags.resize(_max_items / (time_threshold + 1) + 16);
     }
 
     gr::work::Status processBulk(const gr::ConsumableSpan auto& inSpan, gr::PublishableSpan auto& outSpan)
@@ -136,17 +310,16 @@ public:
             outSpan.publish(0);
             return gr::work::Status::INSUFFICIENT_INPUT_ITEMS;
         }
-        const size_t n = std::min<size_t>(inSpan.size(), size_t{ 1 } << 22);
-        gr4pm_c64* din = _din.get(n);
-        gr4pm_c64* dout = _dout.get(n);
-        if (hipMemcpy(din, &*inSpan.begin(), n * sizeof(c64), hipMemcpyHostToDevice) != hipSuccess)
-            throw gr::exception("hipMemcpy H2D failed");
+        const size_t n = std::min({ inSpan.size(), outSpan.size(), _max_items });
+        const c64* hin = std::to_address(inSpan.begin());
+        const gr4pm_c64* din = _din.in(hin, n);
+        gr4pm_c64* dout = _dout.out(n);
         size_t n_done = 0, n_tags = 0;
-        detail::check(gr4pm_syncword_detection_process(_h, din, n, n, dout, n, &n_done, _tags.data(),
-                                                       _tags.size(), &n_tags),
+        detail::check(gr4pm_syncword_detection_process(_h, din, n, n, dout, n, &n_done, _tags.data(), _tags.size(),
+                                                       &n_tags),
                       "SyncwordDetection::processBulk");
-        if (hipMemcpy(&*outSpan.begin(), dout, n_done * sizeof(c64), hipMemcpyDeviceToHost) != hipSuccess)
-            throw gr::exception("hipMemcpy D2H failed");
+        _dout.publish(std::to_address(outSpan.begin()), n_done, host_output);
+        detail::consumed(hin, n_done * sizeof(c64));
         for (size_t i = 0; i < n_tags; ++i)
             out.publishTag(detail::to_map(_tags[i]), static_cast<ssize_t>(_tags[i].index)); // :321-324
         if (!inSpan.consume(n_done)) throw gr::exception("consume failed"); // :346-348
@@ -156,74 +329,89 @@ public:
 };
 
 // ---------------------------------------------------------------- rotators
-// replaces gr::packet_modem::Rotator<float> (rotator.hpp:20-65)
-class Rotator : public gr::Block<Rotator>
+// replaces gr::packet_modem::Rotator<T = float> (rotator.hpp:20-65)
+template <typename T = float>
+class Rotator : public gr::Block<Rotator<T>>
 {
-    using c64 = std::complex<float>;
+    static_assert(std::is_same_v<T, float>, "gr4pm: Rotator is built for T = float (complex<float> items)");
     gr4pm_rotator* _h = nullptr;
     detail::DeviceStage<gr4pm_c64> _din, _dout;
 
 public:
-    gr::PortIn<c64> in;
-    gr::PortOut<c64> out;
-    float phase_incr = 0;
+    gr::PortIn<std::complex<T>> in;
+    gr::PortOut<std::complex<T>> out;
+    T phase_incr = 0;
+    bool host_output = true;
+    Rotator() = default;
+    Rotator(const Rotator&) = delete;
     ~Rotator() { gr4pm_rotator_destroy(_h); }
-    void settingsChanged(const gr::property_map&, const gr::property_map&) { start(); }
-    void start()
+    void settingsChanged(const gr::property_map&, const gr::property_map&) { start(); } // :44-48
+    void start()                                                                         // :50-54
     {
         gr4pm_rotator_destroy(_h);
+        _h = nullptr;
         gr4pm_rotator_params p{ 0, phase_incr, 0, 1, nullptr };
         detail::check(gr4pm_rotator_create(&p, &_h), "Rotator::start");
     }
     gr::work::Status processBulk(const gr::ConsumableSpan auto& inSpan, gr::PublishableSpan auto& outSpan)
     {
-        const size_t n = std::min(inSpan.size(), outSpan.size());
-        gr4pm_c64* din = _din.get(n);
-        gr4pm_c64* dout = _dout.get(n);
-        (void)hipMemcpy(din, &*inSpan.begin(), n * sizeof(c64), hipMemcpyHostToDevice);
+        if (!_h) start();
+        const size_t n = std::min({ inSpan.size(), outSpan.size(), detail::max_items() });
+        const c64* hin = std::to_address(inSpan.begin());
+        const gr4pm_c64* din = _din.in(hin, n);
+        gr4pm_c64* dout = _dout.out(n);
         detail::check(gr4pm_rotator_process(_h, din, n, n, dout, nullptr, nullptr, 0), "Rotator");
-        (void)hipMemcpy(&*outSpan.begin(), dout, n * sizeof(c64), hipMemcpyDeviceToHost);
+        _dout.publish(std::to_address(outSpan.begin()), n, host_output);
+        detail::consumed(hin, n * sizeof(c64));
         if (!inSpan.consume(n)) throw gr::exception("consume failed");
         outSpan.publish(n);
         return gr::work::Status::OK;
     }
 };
 
-// replaces gr::packet_modem::CoarseFrequencyCorrection<float> (coarse_frequency_correction.hpp:20-99)
-class CoarseFrequencyCorrection : public gr::Block<CoarseFrequencyCorrection>
+// replaces gr::packet_modem::CoarseFrequencyCorrection<T = float> (coarse_frequency_correction.hpp:20-99)
+template <typename T = float>
+class CoarseFrequencyCorrection : public gr::Block<CoarseFrequencyCorrection<T>>
 {
-    using c64 = std::complex<float>;
+    static_assert(std::is_same_v<T, float>, "gr4pm: CoarseFrequencyCorrection is built for T = float");
     gr4pm_rotator* _h = nullptr;
     detail::DeviceStage<gr4pm_c64> _din, _dout;
 
 public:
-    gr::PortIn<c64> in;
-    gr::PortOut<c64> out;
+    gr::PortIn<std::complex<T>> in;
+    gr::PortOut<std::complex<T>> out;
     size_t delay = 0;
+    bool host_output = true;
+    CoarseFrequencyCorrection() = default;
+    CoarseFrequencyCorrection(const CoarseFrequencyCorrection&) = delete;
     ~CoarseFrequencyCorrection() { gr4pm_rotator_destroy(_h); }
-    void start()
+    void start() // :61-65
     {
         gr4pm_rotator_destroy(_h);
+        _h = nullptr;
         gr4pm_rotator_params p{ 1, 0.0f, delay, 1, nullptr };
         detail::check(gr4pm_rotator_create(&p, &_h), "CoarseFrequencyCorrection::start");
     }
     gr::work::Status processBulk(const gr::ConsumableSpan auto& inSpan, gr::PublishableSpan auto& outSpan)
     {
+        if (!_h) start();
         gr4pm_tag tag{};
         size_t n_tags = 0;
         if (this->input_tags_present()) { // :76-82: the tag refers to inSpan[0]
             tag = detail::from_map(this->mergedInputTag().map, 0);
             if (this->mergedInputTag().map.contains("syncword_freq")) {
                 tag.flags |= GR4PM_TAG_SYNCWORD;
+                tag.freq = pmtv::cast<double>(this->mergedInputTag().map.at("syncword_freq"));
                 n_tags = 1;
             }
         }
-        const size_t n = std::min(inSpan.size(), outSpan.size());
-        gr4pm_c64* din = _din.get(n);
-        gr4pm_c64* dout = _dout.get(n);
-        (void)hipMemcpy(din, &*inSpan.begin(), n * sizeof(c64), hipMemcpyHostToDevice);
+        const size_t n = std::min({ inSpan.size(), outSpan.size(), detail::max_items() });
+        const c64* hin = std::to_address(inSpan.begin());
+        const gr4pm_c64* din = _din.in(hin, n);
+        gr4pm_c64* dout = _dout.out(n);
         detail::check(gr4pm_rotator_process(_h, din, n, n, dout, &tag, nullptr, n_tags), "CoarseFrequencyCorrection");
-        (void)hipMemcpy(&*outSpan.begin(), dout, n * sizeof(c64), hipMemcpyDeviceToHost);
+        _dout.publish(std::to_address(outSpan.begin()), n, host_output);
+        detail::consumed(hin, n * sizeof(c64));
         if (!inSpan.consume(n)) throw gr::exception("consume failed");
         outSpan.publish(n);
         return gr::work::Status::OK;
@@ -231,27 +419,32 @@ public:
 };
 
 // ---------------------------------------------------------------- SyncwordDetectionFilter
-// replaces gr::packet_modem::SyncwordDetectionFilter<c64> (syncword_detection_filter.hpp:10-211)
-class SyncwordDetectionFilter : public gr::Block<SyncwordDetectionFilter>
+// replaces gr::packet_modem::SyncwordDetectionFilter<T = complex<float>> (syncword_detection_filter.hpp:10-211)
+template <typename T = std::complex<float>>
+class SyncwordDetectionFilter : public gr::Block<SyncwordDetectionFilter<T>>
 {
-    using c64 = std::complex<float>;
+    static_assert(detail::is_c64<T>, "gr4pm: SyncwordDetectionFilter is built for complex<float> items");
     gr4pm_syncword_detection_filter* _h = nullptr;
     detail::DeviceStage<gr4pm_c64> _din, _dout;
 
 public:
     gr::PortIn<gr::Message, gr::Async> parsed_header;
     gr::PortIn<gr::Message, gr::Async> ignored_syncword;
-    gr::PortIn<c64> in;
-    gr::PortOut<c64> out;
+    gr::PortIn<T> in;
+    gr::PortOut<T> out;
     size_t samples_per_symbol = 4;
     size_t syncword_size = 64;
     size_t header_size = 128;
+    bool host_output = true;
     constexpr static gr::TagPropagationPolicy tag_policy = gr::TagPropagationPolicy::TPP_CUSTOM;
 
+    SyncwordDetectionFilter() = default;
+    SyncwordDetectionFilter(const SyncwordDetectionFilter&) = delete;
     ~SyncwordDetectionFilter() { gr4pm_syncword_detection_filter_destroy(_h); }
     void start()
     {
         gr4pm_syncword_detection_filter_destroy(_h);
+        _h = nullptr;
         gr4pm_syncword_detection_filter_params p{ samples_per_symbol, syncword_size, header_size, nullptr };
         detail::check(gr4pm_syncword_detection_filter_create(&p, &_h), "SyncwordDetectionFilter::start");
     }
@@ -259,6 +452,7 @@ public:
                                  const gr::ConsumableSpan auto& ignoredSpan,
                                  const gr::ConsumableSpan auto& inSpan, gr::PublishableSpan auto& outSpan)
     {
+        if (!_h) start();
         int head_flags = 0;
         gr::property_map syncword_keys, other_keys;
         if (this->input_tags_present()) { // :75-93
@@ -280,17 +474,18 @@ public:
             if (!m.invalid_header) m.packet_length = pmtv::cast<uint64_t>(meta.at("packet_length"));
             msgs.push_back(m);
         }
-        const size_t n = std::min(inSpan.size(), outSpan.size());
-        gr4pm_c64* din = _din.get(n);
-        gr4pm_c64* dout = _dout.get(n);
-        (void)hipMemcpy(din, &*inSpan.begin(), n * sizeof(c64), hipMemcpyHostToDevice);
+        const size_t n = std::min({ inSpan.size(), outSpan.size(), detail::max_items() });
+        const c64* hin = std::to_address(inSpan.begin());
+        const gr4pm_c64* din = _din.in(hin, n);
+        gr4pm_c64* dout = _dout.out(n);
         size_t consumed = 0, hc = 0, ic = 0;
         int out_flags = 0;
         detail::check(gr4pm_syncword_detection_filter_process(_h, din, n, dout, n, head_flags, msgs.data(),
                                                               msgs.size(), ignoredSpan.size(), &consumed, &hc,
                                                               &ic, &out_flags),
                       "SyncwordDetectionFilter::processBulk");
-        (void)hipMemcpy(&*outSpan.begin(), dout, consumed * sizeof(c64), hipMemcpyDeviceToHost);
+        _dout.publish(std::to_address(outSpan.begin()), consumed, host_output);
+        detail::consumed(hin, consumed * sizeof(c64));
         gr::property_map output_tags; // :82-104
         if (out_flags & GR4PM_TAG_SYNCWORD) output_tags.insert(syncword_keys.begin(), syncword_keys.end());
         if (out_flags & GR4PM_TAG_OTHER) output_tags.insert(other_keys.begin(), other_keys.end());
@@ -305,24 +500,29 @@ public:
 };
 
 // ---------------------------------------------------------------- SymbolFilter
-// replaces gr::packet_modem::SymbolFilter<c64, c64, float> (symbol_filter.hpp:13-253)
-class SymbolFilter : public gr::Block<SymbolFilter, gr::Resampling<>>
+// replaces gr::packet_modem::SymbolFilter<TIn, TOut = TIn, TTaps = TIn> (symbol_filter.hpp:13-253)
+template <typename TIn, typename TOut = TIn, typename TTaps = TIn>
+class SymbolFilter : public gr::Block<SymbolFilter<TIn, TOut, TTaps>, gr::Resampling<>>
 {
-    using c64 = std::complex<float>;
+    static_assert(detail::is_c64<TIn> && detail::is_c64<TOut> && std::is_same_v<TTaps, float>,
+                  "gr4pm: SymbolFilter is built for <complex<float>, complex<float>, float> (packet_receiver.hpp:111)");
     gr4pm_symbol_filter* _h = nullptr;
     detail::DeviceStage<gr4pm_c64> _din, _dout;
     std::vector<gr::property_map> _held; // full maps of queued tags (opaque keys travel with them)
     std::vector<gr4pm_tag> _tags_out;
 
 public:
-    gr::PortIn<c64> in;
-    gr::PortOut<c64> out;
+    gr::PortIn<TIn> in;
+    gr::PortOut<TOut> out;
     size_t samples_per_symbol = 4;
-    std::vector<float> taps;
+    std::vector<TTaps> taps;
     size_t num_arms = 32;
     size_t delay = 0;
+    bool host_output = true;
     constexpr static gr::TagPropagationPolicy tag_policy = gr::TagPropagationPolicy::TPP_CUSTOM;
 
+    SymbolFilter() = default;
+    SymbolFilter(const SymbolFilter&) = delete;
     ~SymbolFilter() { gr4pm_symbol_filter_destroy(_h); }
     void settingsChanged(const gr::property_map&, const gr::property_map&)
     {
@@ -330,11 +530,19 @@ public:
         _h = nullptr;
         gr4pm_symbol_filter_params p{ samples_per_symbol, taps.data(), taps.size(), num_arms, delay, 0, nullptr };
         detail::check(gr4pm_symbol_filter_create(&p, &_h), "SymbolFilter::settingsChanged"); // :67-73 throw
+        this->input_chunk_size = samples_per_symbol; // :75-76
+        this->output_chunk_size = 1;
         _tags_out.resize(64);
+        _held.clear();
     }
-    void start() { detail::check(gr4pm_symbol_filter_reset(_h), "SymbolFilter::start"); }
+    void start()
+    {
+        if (!_h) settingsChanged({}, {});
+        detail::check(gr4pm_symbol_filter_reset(_h), "SymbolFilter::start");
+    }
     gr::work::Status processBulk(const gr::ConsumableSpan auto& inSpan, gr::PublishableSpan auto& outSpan)
     {
+        if (!_h) settingsChanged({}, {});
         gr4pm_tag tag{};
         size_t n_tags = 0;
         if (this->input_tags_present()) { // :127-206: the tag refers to inSpan[0]
@@ -343,15 +551,17 @@ public:
             _held.push_back(this->mergedInputTag().map);
             n_tags = 1;
         }
-        const size_t n = inSpan.size();
-        gr4pm_c64* din = _din.get(n);
-        gr4pm_c64* dout = _dout.get(outSpan.size());
-        (void)hipMemcpy(din, &*inSpan.begin(), n * sizeof(c64), hipMemcpyHostToDevice);
+        const size_t n = std::min(inSpan.size(), detail::max_items());
+        const size_t cap = std::min(outSpan.size(), detail::max_items());
+        const c64* hin = std::to_address(inSpan.begin());
+        const gr4pm_c64* din = _din.in(hin, n);
+        gr4pm_c64* dout = _dout.out(cap);
         size_t n_out_tags = 0, consumed = 0, produced = 0;
-        detail::check(gr4pm_symbol_filter_process(_h, din, n, dout, outSpan.size(), &tag, n_tags, _tags_out.data(),
+        detail::check(gr4pm_symbol_filter_process(_h, din, n, dout, cap, &tag, n_tags, _tags_out.data(),
                                                   _tags_out.size(), &n_out_tags, &consumed, &produced),
                       "SymbolFilter::processBulk");
-        (void)hipMemcpy(&*outSpan.begin(), dout, produced * sizeof(c64), hipMemcpyDeviceToHost);
+        _dout.publish(std::to_address(outSpan.begin()), produced, host_output);
+        detail::consumed(hin, consumed * sizeof(c64));
         for (size_t i = 0; i < n_out_tags; ++i) { // :218-228 re-timed tags, :152-155 adjusted phase
             auto map = _held.at(static_cast<size_t>(_tags_out[i].freq_bin));
             if (_tags_out[i].flags & GR4PM_TAG_SYNCWORD) map["syncword_phase"] = _tags_out[i].phase;
@@ -364,54 +574,67 @@ public:
 };
 
 // ---------------------------------------------------------------- CostasLoop
-// replaces gr::packet_modem::CostasLoop<float, float> (costas_loop.hpp:15-149)
-class CostasLoop : public gr::Block<CostasLoop>
+// replaces gr::packet_modem::CostasLoop<T = float, TPhase = float> (costas_loop.hpp:15-149)
+template <typename T = float, typename TPhase = float>
+class CostasLoop : public gr::Block<CostasLoop<T, TPhase>>
 {
-    using c64 = std::complex<float>;
+    static_assert(std::is_same_v<T, float> && std::is_same_v<TPhase, float>, "gr4pm: CostasLoop is built for <float, float>");
     gr4pm_costas_loop* _h = nullptr;
     detail::DeviceStage<gr4pm_c64> _din, _dout;
-    static int constellation_id(const std::string& s)
-    {
-        std::string u;
-        for (char c : s) u.push_back(static_cast<char>(std::toupper(c)));
-        if (u == "PILOT") return 0;
-        if (u == "BPSK") return 1;
-        if (u == "QPSK") return 2;
-        throw gr::exception("unknown constellation " + s); // enum_cast(...).value() throws, :59-61
-    }
 
 public:
-    gr::PortIn<c64> in;
-    gr::PortOut<c64> out;
+    gr::PortIn<std::complex<T>> in;
+    gr::PortOut<std::complex<T>> out;
     double loop_bandwidth = 0.01;
     std::string constellation = "BPSK";
+    bool host_output = true;
 
+    CostasLoop() = default;
+    CostasLoop(const CostasLoop&) = delete;
     ~CostasLoop() { gr4pm_costas_loop_destroy(_h); }
     void settingsChanged(const gr::property_map&, const gr::property_map&) // :52-88 (also driven by tags)
     {
         if (!_h) {
-            gr4pm_costas_loop_params p{ loop_bandwidth, constellation_id(constellation), 1, nullptr };
+            gr4pm_costas_loop_params p{ loop_bandwidth, detail::constellation_id(constellation), 1, nullptr };
             detail::check(gr4pm_costas_loop_create(&p, &_h), "CostasLoop::settingsChanged");
         } else {
-            detail::check(gr4pm_costas_loop_set(_h, loop_bandwidth, constellation_id(constellation)), "CostasLoop::set");
+            detail::check(gr4pm_costas_loop_set(_h, loop_bandwidth, detail::constellation_id(constellation)),
+                          "CostasLoop::set");
         }
     }
     gr::work::Status processBulk(const gr::ConsumableSpan auto& inSpan, gr::PublishableSpan auto& outSpan)
     {
+        if (!_h) settingsChanged({}, {});
         gr4pm_tag tag{};
         size_t n_tags = 0;
-        if (this->input_tags_present() && this->mergedInputTag().map.contains("syncword_phase")) { // :101-106
-            tag.index = 0;
-            tag.flags = GR4PM_TAG_SYNCWORD;
-            tag.phase = pmtv::cast<float>(this->mergedInputTag().map.at("syncword_phase"));
-            n_tags = 1;
+        if (this->input_tags_present()) {
+            const auto& map = this->mergedInputTag().map;
+            // the runtime applies tag keys that name a setting before the call (costas_loop.hpp:52-88 via
+            // settings auto-update): "constellation" / "loop_bandwidth" from PayloadMetadataInsert
+            bool changed = false;
+            if (map.contains("constellation")) {
+                constellation = pmtv::cast<std::string>(map.at("constellation"));
+                changed = true;
+            }
+            if (map.contains("loop_bandwidth")) {
+                loop_bandwidth = pmtv::cast<double>(map.at("loop_bandwidth"));
+                changed = true;
+            }
+            if (changed) settingsChanged({}, {});
+            if (map.contains("syncword_phase")) { // :101-106
+                tag.index = 0;
+                tag.flags = GR4PM_TAG_SYNCWORD;
+                tag.phase = pmtv::cast<float>(map.at("syncword_phase"));
+                n_tags = 1;
+            }
         }
-        const size_t n = std::min(inSpan.size(), outSpan.size());
-        gr4pm_c64* din = _din.get(n);
-        gr4pm_c64* dout = _dout.get(n);
-        (void)hipMemcpy(din, &*inSpan.begin(), n * sizeof(c64), hipMemcpyHostToDevice);
+        const size_t n = std::min({ inSpan.size(), outSpan.size(), detail::max_items() });
+        const c64* hin = std::to_address(inSpan.begin());
+        const gr4pm_c64* din = _din.in(hin, n);
+        gr4pm_c64* dout = _dout.out(n);
         detail::check(gr4pm_costas_loop_process(_h, din, n, n, dout, &tag, nullptr, n_tags), "CostasLoop::processBulk");
-        (void)hipMemcpy(&*outSpan.begin(), dout, n * sizeof(c64), hipMemcpyDeviceToHost);
+        _dout.publish(std::to_address(outSpan.begin()), n, host_output);
+        detail::consumed(hin, n * sizeof(c64));
         if (!inSpan.consume(n)) throw gr::exception("consume failed");
         outSpan.publish(n);
         return gr::work::Status::OK;
@@ -419,27 +642,33 @@ public:
 };
 
 // ---------------------------------------------------------------- SyncwordWipeoff
-// replaces gr::packet_modem::SyncwordWipeoff<c64, float> (syncword_wipeoff.hpp:12-91)
-class SyncwordWipeoff : public gr::Block<SyncwordWipeoff>
+// replaces gr::packet_modem::SyncwordWipeoff<T = complex<float>, TSyncword = float> (syncword_wipeoff.hpp:12-91)
+template <typename T = std::complex<float>, typename TSyncword = float>
+class SyncwordWipeoff : public gr::Block<SyncwordWipeoff<T, TSyncword>>
 {
-    using c64 = std::complex<float>;
+    static_assert(detail::is_c64<T> && std::is_same_v<TSyncword, float>, "gr4pm: SyncwordWipeoff is built for <complex<float>, float>");
     gr4pm_syncword_wipeoff* _h = nullptr;
     detail::DeviceStage<gr4pm_c64> _din, _dout;
 
 public:
-    gr::PortIn<c64> in;
-    gr::PortOut<c64> out;
-    std::vector<float> syncword;
+    gr::PortIn<T> in;
+    gr::PortOut<T> out;
+    std::vector<TSyncword> syncword;
+    bool host_output = true;
 
+    SyncwordWipeoff() = default;
+    SyncwordWipeoff(const SyncwordWipeoff&) = delete;
     ~SyncwordWipeoff() { gr4pm_syncword_wipeoff_destroy(_h); }
     void start()
     {
         gr4pm_syncword_wipeoff_destroy(_h);
+        _h = nullptr;
         gr4pm_syncword_wipeoff_params p{ syncword.data(), syncword.size(), nullptr };
         detail::check(gr4pm_syncword_wipeoff_create(&p, &_h), "SyncwordWipeoff::start");
     }
     gr::work::Status processBulk(const gr::ConsumableSpan auto& inSpan, gr::PublishableSpan auto& outSpan)
     {
+        if (!_h) start();
         gr4pm_tag tag{};
         size_t n_tags = 0;
         if (this->input_tags_present() && this->mergedInputTag().map.contains("syncword_amplitude")) { // :53-62
@@ -447,12 +676,13 @@ public:
             tag.flags = GR4PM_TAG_SYNCWORD;
             n_tags = 1;
         }
-        const size_t n = std::min(inSpan.size(), outSpan.size());
-        gr4pm_c64* din = _din.get(n);
-        gr4pm_c64* dout = _dout.get(n);
-        (void)hipMemcpy(din, &*inSpan.begin(), n * sizeof(c64), hipMemcpyHostToDevice);
+        const size_t n = std::min({ inSpan.size(), outSpan.size(), detail::max_items() });
+        const c64* hin = std::to_address(inSpan.begin());
+        const gr4pm_c64* din = _din.in(hin, n);
+        gr4pm_c64* dout = _dout.out(n);
         detail::check(gr4pm_syncword_wipeoff_process(_h, din, n, dout, &tag, n_tags), "SyncwordWipeoff::processBulk");
-        (void)hipMemcpy(&*outSpan.begin(), dout, n * sizeof(c64), hipMemcpyDeviceToHost);
+        _dout.publish(std::to_address(outSpan.begin()), n, host_output);
+        detail::consumed(hin, n * sizeof(c64));
         if (!inSpan.consume(n)) throw gr::exception("consume failed");
         outSpan.publish(n);
         return gr::work::Status::OK;
@@ -460,19 +690,24 @@ public:
 };
 
 // ---------------------------------------------------------------- InterpolatingFirFilter
-// replaces gr::packet_modem::InterpolatingFirFilter<c64, c64, float> (interpolating_fir_filter.hpp:14-103)
-class InterpolatingFirFilter : public gr::Block<InterpolatingFirFilter, gr::Resampling<>>
+// replaces gr::packet_modem::InterpolatingFirFilter<TIn, TOut = TIn, TTaps = TIn> (interpolating_fir_filter.hpp:14-103)
+template <typename TIn, typename TOut = TIn, typename TTaps = TIn>
+class InterpolatingFirFilter : public gr::Block<InterpolatingFirFilter<TIn, TOut, TTaps>, gr::Resampling<>>
 {
-    using c64 = std::complex<float>;
+    static_assert(detail::is_c64<TIn> && detail::is_c64<TOut> && std::is_same_v<TTaps, float>,
+                  "gr4pm: InterpolatingFirFilter is built for <complex<float>, complex<float>, float>");
     gr4pm_interp_fir* _h = nullptr;
     detail::DeviceStage<gr4pm_c64> _din, _dout;
 
 public:
-    gr::PortIn<c64> in;
-    gr::PortOut<c64> out;
+    gr::PortIn<TIn> in;
+    gr::PortOut<TOut> out;
     size_t interpolation = 1;
-    std::vector<float> taps;
+    std::vector<TTaps> taps;
+    bool host_output = true;
 
+    InterpolatingFirFilter() = default;
+    InterpolatingFirFilter(const InterpolatingFirFilter&) = delete;
     ~InterpolatingFirFilter() { gr4pm_interp_fir_destroy(_h); }
     void settingsChanged(const gr::property_map&, const gr::property_map&)
     {
@@ -485,12 +720,14 @@ public:
     }
     gr::work::Status processBulk(const gr::ConsumableSpan auto& inSpan, gr::PublishableSpan auto& outSpan)
     {
-        const size_t n = std::min(inSpan.size(), outSpan.size() / interpolation); // :91
-        gr4pm_c64* din = _din.get(n);
-        gr4pm_c64* dout = _dout.get(n * interpolation);
-        (void)hipMemcpy(din, &*inSpan.begin(), n * sizeof(c64), hipMemcpyHostToDevice);
+        if (!_h) settingsChanged({}, {});
+        const size_t n = std::min({ inSpan.size(), outSpan.size() / interpolation, detail::max_items() / interpolation }); // :91
+        const c64* hin = std::to_address(inSpan.begin());
+        const gr4pm_c64* din = _din.in(hin, n);
+        gr4pm_c64* dout = _dout.out(n * interpolation);
         detail::check(gr4pm_interp_fir_process(_h, din, n, dout), "InterpolatingFirFilter::processBulk");
-        (void)hipMemcpy(&*outSpan.begin(), dout, n * interpolation * sizeof(c64), hipMemcpyDeviceToHost);
+        _dout.publish(std::to_address(outSpan.begin()), n * interpolation, host_output);
+        detail::consumed(hin, n * sizeof(c64));
         if (!inSpan.consume(n)) throw gr::exception("consume failed");
         outSpan.publish(n * interpolation);
         return gr::work::Status::OK;
@@ -498,21 +735,26 @@ public:
 };
 
 // ---------------------------------------------------------------- PfbArbResampler
-// replaces gr::packet_modem::PfbArbResampler<c64, c64, float, TRate> (pfb_arb_resampler.hpp:23-183)
-template <typename TRate = float>
-class PfbArbResampler : public gr::Block<PfbArbResampler<TRate>>
+// replaces gr::packet_modem::PfbArbResampler<TIn, TOut = TIn, TTaps = TIn, TRate = float> (pfb_arb_resampler.hpp:23-183)
+template <typename TIn, typename TOut = TIn, typename TTaps = TIn, typename TRate = float>
+class PfbArbResampler : public gr::Block<PfbArbResampler<TIn, TOut, TTaps, TRate>>
 {
-    using c64 = std::complex<float>;
+    static_assert(detail::is_c64<TIn> && detail::is_c64<TOut> && std::is_same_v<TTaps, float> &&
+                      (std::is_same_v<TRate, float> || std::is_same_v<TRate, double>),
+                  "gr4pm: PfbArbResampler is built for <complex<float>, complex<float>, float, float | double>");
     gr4pm_pfb_arb_resampler* _h = nullptr;
     detail::DeviceStage<gr4pm_c64> _din, _dout;
 
 public:
-    gr::PortIn<c64, gr::Async> in;   // :59-62: no rational resampling ratio
-    gr::PortOut<c64, gr::Async> out;
+    gr::PortIn<TIn, gr::Async> in; // :59-62: no rational resampling ratio
+    gr::PortOut<TOut, gr::Async> out;
     TRate rate{ 1.0 };
-    std::vector<float> taps; // the reference's default (pfb_arb_taps.hpp) ships as data/pfb_arb_taps.f32
+    std::vector<TTaps> taps; // the reference's default (pfb_arb_taps.hpp) ships as data/pfb_arb_taps.f32
     size_t filter_size = 32;
+    bool host_output = true;
 
+    PfbArbResampler() = default;
+    PfbArbResampler(const PfbArbResampler&) = delete;
     ~PfbArbResampler() { gr4pm_pfb_arb_resampler_destroy(_h); }
     void settingsChanged(const gr::property_map&, const gr::property_map&)
     {
@@ -524,14 +766,17 @@ public:
     }
     gr::work::Status processBulk(const gr::ConsumableSpan auto& inSpan, gr::PublishableSpan auto& outSpan)
     {
-        const size_t n = inSpan.size();
-        gr4pm_c64* din = _din.get(n);
-        gr4pm_c64* dout = _dout.get(outSpan.size());
-        (void)hipMemcpy(din, &*inSpan.begin(), n * sizeof(c64), hipMemcpyHostToDevice);
+        if (!_h) settingsChanged({}, {});
+        const size_t n = std::min(inSpan.size(), detail::max_items());
+        const size_t cap = std::min(outSpan.size(), detail::max_items());
+        const c64* hin = std::to_address(inSpan.begin());
+        const gr4pm_c64* din = _din.in(hin, n);
+        gr4pm_c64* dout = _dout.out(cap);
         size_t consumed = 0, produced = 0;
-        detail::check(gr4pm_pfb_arb_resampler_process(_h, din, n, dout, outSpan.size(), &consumed, &produced),
+        detail::check(gr4pm_pfb_arb_resampler_process(_h, din, n, dout, cap, &consumed, &produced),
                       "PfbArbResampler::processBulk");
-        (void)hipMemcpy(&*outSpan.begin(), dout, produced * sizeof(c64), hipMemcpyDeviceToHost);
+        _dout.publish(std::to_address(outSpan.begin()), produced, host_output);
+        detail::consumed(hin, consumed * sizeof(c64));
         if (!inSpan.consume(consumed)) throw gr::exception("consume failed"); // :169-172
         outSpan.publish(produced);
         return gr::work::Status::OK;
@@ -539,10 +784,11 @@ public:
 };
 
 // ---------------------------------------------------------------- PayloadMetadataInsert
-// replaces gr::packet_modem::PayloadMetadataInsert<c64> (payload_metadata_insert.hpp:12-324)
-class PayloadMetadataInsert : public gr::Block<PayloadMetadataInsert>
+// replaces gr::packet_modem::PayloadMetadataInsert<T = complex<float>> (payload_metadata_insert.hpp:12-324)
+template <typename T = std::complex<float>>
+class PayloadMetadataInsert : public gr::Block<PayloadMetadataInsert<T>>
 {
-    using c64 = std::complex<float>;
+    static_assert(detail::is_c64<T>, "gr4pm: PayloadMetadataInsert is built for complex<float> items");
     gr4pm_payload_metadata_insert* _h = nullptr;
     detail::DeviceStage<gr4pm_c64> _din, _dout;
     std::vector<gr4pm_packet_tag> _tags;
@@ -551,8 +797,8 @@ class PayloadMetadataInsert : public gr::Block<PayloadMetadataInsert>
 
 public:
     gr::PortIn<gr::Message, gr::Async> parsed_header;
-    gr::PortIn<c64> in;
-    gr::PortOut<c64> out;
+    gr::PortIn<T> in;
+    gr::PortOut<T> out;
     gr::PortOut<gr::Message, gr::Async> ignored_syncword;
     size_t syncword_size = 64;
     size_t header_size = 128;
@@ -560,12 +806,16 @@ public:
     double header_costas_loop_bandwidth = 0.01;
     double payload_costas_loop_bandwidth = 0.005;
     bool log = false;
+    bool host_output = true;
     constexpr static gr::TagPropagationPolicy tag_policy = gr::TagPropagationPolicy::TPP_CUSTOM;
 
+    PayloadMetadataInsert() = default;
+    PayloadMetadataInsert(const PayloadMetadataInsert&) = delete;
     ~PayloadMetadataInsert() { gr4pm_payload_metadata_insert_destroy(_h); }
     void start() // :71-75
     {
         gr4pm_payload_metadata_insert_destroy(_h);
+        _h = nullptr;
         gr4pm_payload_metadata_insert_params p{ syncword_size, header_size, syncword_costas_loop_bandwidth,
                                                 header_costas_loop_bandwidth, payload_costas_loop_bandwidth, nullptr };
         detail::check(gr4pm_payload_metadata_insert_create(&p, &_h), "PayloadMetadataInsert::start");
@@ -573,6 +823,7 @@ public:
     gr::work::Status processBulk(const gr::ConsumableSpan auto& headerSpan, const gr::ConsumableSpan auto& inSpan,
                                  gr::PublishableSpan auto& outSpan, gr::PublishableSpan auto& ignoredSpan)
     {
+        if (!_h) start();
         gr4pm_tag tag{};
         size_t n_tags = 0;
         if (this->input_tags_present()) {
@@ -590,28 +841,29 @@ public:
             msgs.push_back(hm);
             metas.push_back(meta);
         }
-        const size_t n = inSpan.size(), cap = outSpan.size();
-        gr4pm_c64* din = _din.get(n);
-        gr4pm_c64* dout = _dout.get(cap);
-        (void)hipMemcpy(din, &*inSpan.begin(), n * sizeof(c64), hipMemcpyHostToDevice);
+        const size_t n = std::min(inSpan.size(), detail::max_items()), cap = std::min(outSpan.size(), detail::max_items());
+        const c64* hin = std::to_address(inSpan.begin());
+        const gr4pm_c64* din = _din.in(hin, n);
+        gr4pm_c64* dout = _dout.out(cap);
         _tags.resize(8);
         size_t n_out_tags = 0, consumed = 0, produced = 0, used = 0, ignored = 0;
         detail::check(gr4pm_payload_metadata_insert_process(_h, din, n, dout, cap, &tag, n_tags, msgs.data(),
                                                             msgs.size(), 0, _tags.data(), _tags.size(), &n_out_tags,
                                                             &consumed, &produced, &used, &ignored),
                       "PayloadMetadataInsert::processBulk");
-        (void)hipMemcpy(&*outSpan.begin(), dout, produced * sizeof(c64), hipMemcpyDeviceToHost);
+        _dout.publish(std::to_address(outSpan.begin()), produced, host_output);
+        detail::consumed(hin, consumed * sizeof(c64));
         size_t hdr = 0;
         for (size_t i = 0; i < n_out_tags; ++i) {
             const auto& t = _tags[i];
             gr::property_map m;
-            if (t.kind == GR4PM_PKT_SYNCWORD) m = _syncword_map;                    // :104-112
+            if (t.kind == GR4PM_PKT_SYNCWORD) m = _syncword_map;                        // :104-112
             if (t.kind == GR4PM_PKT_HEADER_START) m["header_start"] = pmtv::pmt_null(); // :186-194
-            if (t.kind == GR4PM_PKT_PAYLOAD) {                                       // :222-234
+            if (t.kind == GR4PM_PKT_PAYLOAD) {                                          // :222-234
                 while (hdr < used && metas[hdr].contains("invalid_header")) ++hdr;
                 m = metas[hdr++];
-                m["payload_symbols"] = pmtv::pmt(t.payload_symbols);
-                m["payload_bits"] = pmtv::pmt(t.payload_bits);
+                m["payload_symbols"] = pmtv::pmt(static_cast<uint64_t>(t.payload_symbols));
+                m["payload_bits"] = pmtv::pmt(static_cast<uint64_t>(t.payload_bits));
             }
             if (t.constellation >= 0) m["constellation"] = std::string(constellation_name(t.constellation));
             if (t.loop_bandwidth >= 0) m["loop_bandwidth"] = t.loop_bandwidth;
@@ -632,28 +884,34 @@ public:
 };
 
 // ---------------------------------------------------------------- SyncwordRemove
-// replaces gr::packet_modem::SyncwordRemove<c64> (syncword_remove.hpp:11-112)
-class SyncwordRemove : public gr::Block<SyncwordRemove>
+// replaces gr::packet_modem::SyncwordRemove<T = complex<float>> (syncword_remove.hpp:11-112)
+template <typename T = std::complex<float>>
+class SyncwordRemove : public gr::Block<SyncwordRemove<T>>
 {
-    using c64 = std::complex<float>;
+    static_assert(detail::is_c64<T>, "gr4pm: SyncwordRemove is built for complex<float> items");
     gr4pm_syncword_remove* _h = nullptr;
     detail::DeviceStage<gr4pm_c64> _din, _dout;
 
 public:
-    gr::PortIn<c64> in;
-    gr::PortOut<c64> out;
+    gr::PortIn<T> in;
+    gr::PortOut<T> out;
     size_t syncword_size = 64;
+    bool host_output = true;
     constexpr static gr::TagPropagationPolicy tag_policy = gr::TagPropagationPolicy::TPP_CUSTOM;
 
+    SyncwordRemove() = default;
+    SyncwordRemove(const SyncwordRemove&) = delete;
     ~SyncwordRemove() { gr4pm_syncword_remove_destroy(_h); }
     void start()
     {
         gr4pm_syncword_remove_destroy(_h);
+        _h = nullptr;
         gr4pm_syncword_remove_params p{ syncword_size, nullptr };
         detail::check(gr4pm_syncword_remove_create(&p, &_h), "SyncwordRemove::start");
     }
     gr::work::Status processBulk(const gr::ConsumableSpan auto& inSpan, gr::PublishableSpan auto& outSpan)
     {
+        if (!_h) start();
         gr4pm_packet_tag tag{}, tout[2];
         size_t n_tags = 0;
         if (this->input_tags_present()) { // :51-64
@@ -664,14 +922,15 @@ public:
             tag.loop_bandwidth = -1.0;
             n_tags = 1;
         }
-        const size_t n = std::min(inSpan.size(), outSpan.size());
-        gr4pm_c64* din = _din.get(n);
-        gr4pm_c64* dout = _dout.get(n);
-        (void)hipMemcpy(din, &*inSpan.begin(), n * sizeof(c64), hipMemcpyHostToDevice);
+        const size_t n = std::min({ inSpan.size(), outSpan.size(), detail::max_items() });
+        const c64* hin = std::to_address(inSpan.begin());
+        const gr4pm_c64* din = _din.in(hin, n);
+        gr4pm_c64* dout = _dout.out(n);
         size_t n_out_tags = 0, produced = 0;
         detail::check(gr4pm_syncword_remove_process(_h, din, n, dout, &tag, n_tags, tout, 2, &n_out_tags, &produced),
                       "SyncwordRemove::processBulk");
-        (void)hipMemcpy(&*outSpan.begin(), dout, produced * sizeof(c64), hipMemcpyDeviceToHost);
+        _dout.publish(std::to_address(outSpan.begin()), produced, host_output);
+        detail::consumed(hin, n * sizeof(c64));
         if (n_out_tags) out.publishTag(this->mergedInputTag().map, static_cast<ssize_t>(tout[0].index)); // :59-62
         if (!inSpan.consume(n)) throw gr::exception("consume failed");
         outSpan.publish(produced);
@@ -681,27 +940,29 @@ public:
 };
 
 // ---------------------------------------------------------------- ConstellationLLRDecoder
-// replaces gr::packet_modem::ConstellationLLRDecoder<float> (constellation_llr_decoder.hpp:13-142)
-class ConstellationLLRDecoder : public gr::Block<ConstellationLLRDecoder, gr::Resampling<>>
+// replaces gr::packet_modem::ConstellationLLRDecoder<T = float> (constellation_llr_decoder.hpp:13-142)
+template <typename T = float>
+class ConstellationLLRDecoder : public gr::Block<ConstellationLLRDecoder<T>, gr::Resampling<>>
 {
-    using c64 = std::complex<float>;
+    static_assert(std::is_same_v<T, float>, "gr4pm: ConstellationLLRDecoder is built for T = float");
     gr4pm_constellation_llr_decoder* _h = nullptr;
     detail::DeviceStage<gr4pm_c64> _din;
     detail::DeviceStage<float> _dout;
 
 public:
-    gr::PortIn<c64> in;
-    gr::PortOut<float> out;
-    float noise_sigma = 1.0f;
+    gr::PortIn<std::complex<T>> in;
+    gr::PortOut<T> out;
+    T noise_sigma = 1.0f;
     std::string constellation = "BPSK";
+    bool host_output = true;
     constexpr static gr::TagPropagationPolicy tag_policy = gr::TagPropagationPolicy::TPP_CUSTOM;
 
+    ConstellationLLRDecoder() = default;
+    ConstellationLLRDecoder(const ConstellationLLRDecoder&) = delete;
     ~ConstellationLLRDecoder() { gr4pm_constellation_llr_decoder_destroy(_h); }
     void settingsChanged(const gr::property_map&, const gr::property_map&) // :55-78 (also driven by tags)
     {
-        std::string u;
-        for (char c : constellation) u.push_back(static_cast<char>(std::toupper(c)));
-        const int id = u == "BPSK" ? 1 : u == "QPSK" ? 2 : 0;
+        const int id = detail::constellation_id(constellation);
         if (id == 0) throw gr::exception("constellation " + constellation + " not supported"); // :72-74
         this->input_chunk_size = 1;
         this->output_chunk_size = static_cast<size_t>(id); // :64-71
@@ -712,16 +973,25 @@ public:
     }
     gr::work::Status processBulk(const gr::ConsumableSpan auto& inSpan, gr::PublishableSpan auto& outSpan)
     {
-        if (this->input_tags_present()) out.publishTag(this->mergedInputTag().map, 0); // :93-99
-        const size_t n = std::min(inSpan.size(), outSpan.size() / this->output_chunk_size);
-        gr4pm_c64* din = _din.get(n);
-        float* dout = _dout.get(2 * n);
-        (void)hipMemcpy(din, &*inSpan.begin(), n * sizeof(c64), hipMemcpyHostToDevice);
+        if (!_h) settingsChanged({}, {});
+        if (this->input_tags_present()) {
+            const auto& map = this->mergedInputTag().map;
+            if (map.contains("constellation")) { // the runtime's tag -> settings update
+                constellation = pmtv::cast<std::string>(map.at("constellation"));
+                settingsChanged({}, {});
+            }
+            out.publishTag(map, 0); // :93-99
+        }
+        const size_t n = std::min({ inSpan.size(), outSpan.size() / this->output_chunk_size, detail::max_items() });
+        const c64* hin = std::to_address(inSpan.begin());
+        const gr4pm_c64* din = _din.in(hin, n);
+        float* dout = _dout.out(2 * n);
         size_t produced = 0;
         detail::check(gr4pm_constellation_llr_decoder_process(_h, din, n, dout, 2 * n, nullptr, 0, nullptr, 0, nullptr,
                                                               &produced),
                       "ConstellationLLRDecoder::processBulk");
-        (void)hipMemcpy(&*outSpan.begin(), dout, produced * sizeof(float), hipMemcpyDeviceToHost);
+        _dout.publish(std::to_address(outSpan.begin()), produced, host_output);
+        detail::consumed(hin, n * sizeof(c64));
         if (!inSpan.consume(n)) throw gr::exception("consume failed");
         outSpan.publish(produced);
         return gr::work::Status::OK;
@@ -733,7 +1003,7 @@ public:
 template <typename T>
 class AdditiveScrambler : public gr::Block<AdditiveScrambler<T>>
 {
-    static_assert(std::is_same_v<T, float> || std::is_same_v<T, uint8_t>);
+    static_assert(std::is_same_v<T, float> || std::is_same_v<T, uint8_t>, "gr4pm: AdditiveScrambler is built for float and uint8_t");
     gr4pm_additive_scrambler* _h = nullptr;
     detail::DeviceStage<T> _din, _dout;
 
@@ -742,26 +1012,32 @@ public:
     gr::PortOut<T> out;
     uint64_t mask = 0x8a, seed = 0x7f, length = 7, count = 0; // :61-64
     std::string reset_tag_key = "";
+    bool host_output = true;
 
+    AdditiveScrambler() = default;
+    AdditiveScrambler(const AdditiveScrambler&) = delete;
     ~AdditiveScrambler() { gr4pm_additive_scrambler_destroy(_h); }
     void start() // :68
     {
         gr4pm_additive_scrambler_destroy(_h);
+        _h = nullptr;
         gr4pm_additive_scrambler_params p{ mask, seed, length, count, std::is_same_v<T, float> ? 1 : 2, nullptr };
         detail::check(gr4pm_additive_scrambler_create(&p, &_h), "AdditiveScrambler::start");
     }
     gr::work::Status processBulk(const gr::ConsumableSpan auto& inSpan, gr::PublishableSpan auto& outSpan)
     {
+        if (!_h) start();
         const uint64_t zero = 0;
         const bool reset = !reset_tag_key.empty() && this->input_tags_present() &&
                            this->mergedInputTag().map.contains(reset_tag_key); // :78-80
-        const size_t n = std::min(inSpan.size(), outSpan.size());
-        T* din = _din.get(n);
-        T* dout = _dout.get(n);
-        (void)hipMemcpy(din, &*inSpan.begin(), n * sizeof(T), hipMemcpyHostToDevice);
+        const size_t n = std::min({ inSpan.size(), outSpan.size(), detail::max_items() });
+        const T* hin = std::to_address(inSpan.begin());
+        const T* din = _din.in(hin, n);
+        T* dout = _dout.out(n);
         detail::check(gr4pm_additive_scrambler_process(_h, din, n, dout, &zero, reset ? 1 : 0),
                       "AdditiveScrambler::processBulk");
-        (void)hipMemcpy(&*outSpan.begin(), dout, n * sizeof(T), hipMemcpyDeviceToHost);
+        _dout.publish(std::to_address(outSpan.begin()), n, host_output);
+        detail::consumed(hin, n * sizeof(T));
         if (!inSpan.consume(n)) throw gr::exception("consume failed");
         outSpan.publish(n);
         return gr::work::Status::OK;
@@ -769,31 +1045,38 @@ public:
 };
 
 // ---------------------------------------------------------------- HeaderPayloadSplit
-// replaces gr::packet_modem::HeaderPayloadSplit<float> (header_payload_split.hpp:9-147)
-class HeaderPayloadSplit : public gr::Block<HeaderPayloadSplit>
+// replaces gr::packet_modem::HeaderPayloadSplit<T = float> (header_payload_split.hpp:9-147)
+template <typename T = float>
+class HeaderPayloadSplit : public gr::Block<HeaderPayloadSplit<T>>
 {
+    static_assert(std::is_same_v<T, float>, "gr4pm: HeaderPayloadSplit is built for T = float");
     gr4pm_header_payload_split* _h = nullptr;
     detail::DeviceStage<float> _din, _dhdr, _dpay;
 
 public:
-    gr::PortIn<float> in;
-    gr::PortOut<float> header;
-    gr::PortOut<float> payload;
+    gr::PortIn<T> in;
+    gr::PortOut<T> header;
+    gr::PortOut<T> payload;
     size_t header_size = 256;
     std::string packet_len_tag_key = "packet_len";
     std::string payload_length_key = "payload_bits";
+    bool host_output = true;
     constexpr static gr::TagPropagationPolicy tag_policy = gr::TagPropagationPolicy::TPP_CUSTOM;
 
+    HeaderPayloadSplit() = default;
+    HeaderPayloadSplit(const HeaderPayloadSplit&) = delete;
     ~HeaderPayloadSplit() { gr4pm_header_payload_split_destroy(_h); }
     void start() // :41-45
     {
         gr4pm_header_payload_split_destroy(_h);
+        _h = nullptr;
         gr4pm_header_payload_split_params p{ header_size, nullptr };
         detail::check(gr4pm_header_payload_split_create(&p, &_h), "HeaderPayloadSplit::start");
     }
     gr::work::Status processBulk(const gr::ConsumableSpan auto& inSpan, gr::PublishableSpan auto& headerSpan,
                                  gr::PublishableSpan auto& payloadSpan)
     {
+        if (!_h) start();
         gr4pm_packet_tag tag{}, ht[2], pt[2];
         size_t n_tags = 0;
         gr::property_map map;
@@ -805,21 +1088,22 @@ public:
             if (map.contains(payload_length_key)) {
                 tag.kind = GR4PM_PKT_PAYLOAD;
                 tag.payload_bits = pmtv::cast<uint64_t>(map.at(payload_length_key));
-                map[packet_len_tag_key] = pmtv::pmt(tag.payload_bits); // :81
+                map[packet_len_tag_key] = pmtv::pmt(static_cast<uint64_t>(tag.payload_bits)); // :81
             }
             n_tags = 1;
         }
         // one output per call, like the reference (:97-123)
-        const size_t n = std::min({ inSpan.size(), headerSpan.size(), payloadSpan.size() });
-        float* din = _din.get(n);
-        float* dh = _dhdr.get(n);
-        float* dp = _dpay.get(n);
-        (void)hipMemcpy(din, &*inSpan.begin(), n * sizeof(float), hipMemcpyHostToDevice);
+        const size_t n = std::min({ inSpan.size(), headerSpan.size(), payloadSpan.size(), detail::max_items() });
+        const float* hin = std::to_address(inSpan.begin());
+        const float* din = _din.in(hin, n);
+        float* dh = _dhdr.out(n);
+        float* dp = _dpay.out(n);
         size_t nh = 0, np = 0, nht = 0, npt = 0;
         detail::check(gr4pm_header_payload_split_process(_h, din, n, dh, &nh, dp, &np, &tag, n_tags, ht, &nht, pt, &npt, 2),
                       "HeaderPayloadSplit::processBulk"); // the unexpected-tag exception of :75-78 included
-        (void)hipMemcpy(&*headerSpan.begin(), dh, nh * sizeof(float), hipMemcpyDeviceToHost);
-        (void)hipMemcpy(&*payloadSpan.begin(), dp, np * sizeof(float), hipMemcpyDeviceToHost);
+        _dhdr.publish(std::to_address(headerSpan.begin()), nh, host_output);
+        _dpay.publish(std::to_address(payloadSpan.begin()), np, host_output);
+        detail::consumed(hin, n * sizeof(float));
         if (nht) header.publishTag(map, 0);
         if (npt) payload.publishTag(map, 0);
         if (!inSpan.consume(n)) throw gr::exception("consume failed");
@@ -842,13 +1126,30 @@ class HeaderFecDecoder : public gr::Block<HeaderFecDecoder, gr::Resampling<1U, 6
 public:
     gr::PortIn<float> in;
     gr::PortOut<uint8_t> out;
-    std::string alist; // the text of header_fec_decoder.hpp:31-258 (data/header_ldpc_128_32.alist)
+    // the reference embeds the alist text (header_fec_decoder.hpp:31-258); here it is data: this string, or,
+    // when empty, the file header_ldpc_128_32.alist under $GR4PM_DATA_DIR (default: the package's data/)
+    std::string alist;
 
+    HeaderFecDecoder() = default;
+    HeaderFecDecoder(const HeaderFecDecoder&) = delete;
     ~HeaderFecDecoder() { gr4pm_header_fec_decoder_destroy(_h); }
     void start() // :268-280
     {
         if (_h) throw gr::exception("an LDPC decoder already exists");
-        gr4pm_header_fec_decoder_params p{ alist.c_str(), 25, nullptr };
+        std::string text = alist;
+        if (text.empty()) {
+            const char* dir = std::getenv("GR4PM_DATA_DIR");
+#if defined(GR4PM_DATA_DIR_DEFAULT)
+            if (!dir) dir = GR4PM_DATA_DIR_DEFAULT;
+#endif
+            if (!dir) throw gr::exception("HeaderFecDecoder: set `alist` or GR4PM_DATA_DIR");
+            std::ifstream f(std::string(dir) + "/header_ldpc_128_32.alist");
+            if (!f) throw gr::exception("HeaderFecDecoder: cannot read header_ldpc_128_32.alist");
+            std::stringstream ss;
+            ss << f.rdbuf();
+            text = ss.str();
+        }
+        gr4pm_header_fec_decoder_params p{ text.c_str(), 25, nullptr };
         detail::check(gr4pm_header_fec_decoder_create(&p, &_h), "HeaderFecDecoder::start");
     }
     void stop() // :282-288
@@ -865,12 +1166,13 @@ public:
             return inSpan.size() < 256 ? gr::work::Status::INSUFFICIENT_INPUT_ITEMS
                                        : gr::work::Status::INSUFFICIENT_OUTPUT_ITEMS;
         }
-        float* din = _din.get(codewords * 256);
-        (void)hipMemcpy(din, &*inSpan.begin(), codewords * 256 * sizeof(float), hipMemcpyHostToDevice);
+        const float* hin = std::to_address(inSpan.begin());
+        const float* din = _din.in(hin, codewords * 256);
         _bytes.resize(codewords * 4);
         _invalid.resize(codewords);
         detail::check(gr4pm_header_fec_decoder_process(_h, din, codewords, _bytes.data(), _invalid.data()),
                       "HeaderFecDecoder::processBulk");
+        detail::consumed(hin, codewords * 256 * sizeof(float));
         std::copy(_bytes.begin(), _bytes.end(), outSpan.begin());
         for (size_t c = 0; c < codewords; ++c)
             if (_invalid[c]) out.publishTag({ { "invalid_header", pmtv::pmt_null() } }, static_cast<ssize_t>(4 * c)); // :322-326
@@ -880,26 +1182,40 @@ public:
     }
 };
 
+// firdes::root_raised_cosine<T> (firdes.hpp:29-76): same signature, the library's design routine
+namespace firdes {
+template <typename T = float>
+std::vector<T> root_raised_cosine(double gain, double sampling_freq, double symbol_rate, double alpha, size_t ntaps)
+{
+    static_assert(std::is_same_v<T, float>, "gr4pm: firdes::root_raised_cosine is built for float");
+    std::vector<float> taps(ntaps | 1);
+    const size_t n = gr4pm_firdes_root_raised_cosine(gain, sampling_freq, symbol_rate, alpha, ntaps, taps.data());
+    if (n == 0) throw gr::exception(std::string("root_raised_cosine: ") + gr4pm_last_error());
+    taps.resize(n);
+    return taps;
+}
+} // namespace firdes
+
 } // namespace gr::packet_modem::hip
 
 ENABLE_REFLECTION(gr::packet_modem::hip::SyncwordDetection, in, out, fft_size, samples_per_symbol, rrc_taps,
                   syncword, constellation, min_freq_bin, max_freq_bin, time_threshold, power_threshold);
-ENABLE_REFLECTION(gr::packet_modem::hip::Rotator, in, out, phase_incr);
-ENABLE_REFLECTION(gr::packet_modem::hip::CoarseFrequencyCorrection, in, out, delay);
-ENABLE_REFLECTION(gr::packet_modem::hip::SyncwordDetectionFilter, parsed_header, ignored_syncword, in, out,
-                  samples_per_symbol, syncword_size, header_size);
-ENABLE_REFLECTION(gr::packet_modem::hip::SymbolFilter, in, out, samples_per_symbol, taps, num_arms, delay);
-ENABLE_REFLECTION(gr::packet_modem::hip::CostasLoop, in, out, loop_bandwidth, constellation);
-ENABLE_REFLECTION(gr::packet_modem::hip::SyncwordWipeoff, in, out, syncword);
-ENABLE_REFLECTION(gr::packet_modem::hip::InterpolatingFirFilter, in, out, interpolation, taps);
+ENABLE_REFLECTION_FOR_TEMPLATE(gr::packet_modem::hip::Rotator, in, out, phase_incr);
+ENABLE_REFLECTION_FOR_TEMPLATE(gr::packet_modem::hip::CoarseFrequencyCorrection, in, out, delay);
+ENABLE_REFLECTION_FOR_TEMPLATE(gr::packet_modem::hip::SyncwordDetectionFilter, parsed_header, ignored_syncword, in,
+                               out, samples_per_symbol, syncword_size, header_size);
+ENABLE_REFLECTION_FOR_TEMPLATE(gr::packet_modem::hip::SymbolFilter, in, out, samples_per_symbol, taps, num_arms, delay);
+ENABLE_REFLECTION_FOR_TEMPLATE(gr::packet_modem::hip::CostasLoop, in, out, loop_bandwidth, constellation);
+ENABLE_REFLECTION_FOR_TEMPLATE(gr::packet_modem::hip::SyncwordWipeoff, in, out, syncword);
+ENABLE_REFLECTION_FOR_TEMPLATE(gr::packet_modem::hip::InterpolatingFirFilter, in, out, interpolation, taps);
 ENABLE_REFLECTION_FOR_TEMPLATE(gr::packet_modem::hip::PfbArbResampler, in, out, rate, taps, filter_size);
-ENABLE_REFLECTION(gr::packet_modem::hip::PayloadMetadataInsert, parsed_header, in, out, ignored_syncword,
-                  syncword_size, header_size, syncword_costas_loop_bandwidth, header_costas_loop_bandwidth,
-                  payload_costas_loop_bandwidth, log);
-ENABLE_REFLECTION(gr::packet_modem::hip::SyncwordRemove, in, out, syncword_size);
-ENABLE_REFLECTION(gr::packet_modem::hip::ConstellationLLRDecoder, in, out, noise_sigma, constellation);
+ENABLE_REFLECTION_FOR_TEMPLATE(gr::packet_modem::hip::PayloadMetadataInsert, parsed_header, in, out, ignored_syncword,
+                               syncword_size, header_size, syncword_costas_loop_bandwidth,
+                               header_costas_loop_bandwidth, payload_costas_loop_bandwidth, log);
+ENABLE_REFLECTION_FOR_TEMPLATE(gr::packet_modem::hip::SyncwordRemove, in, out, syncword_size);
+ENABLE_REFLECTION_FOR_TEMPLATE(gr::packet_modem::hip::ConstellationLLRDecoder, in, out, noise_sigma, constellation);
 ENABLE_REFLECTION_FOR_TEMPLATE(gr::packet_modem::hip::AdditiveScrambler, in, out, mask, seed, length, count,
                                reset_tag_key);
-ENABLE_REFLECTION(gr::packet_modem::hip::HeaderPayloadSplit, in, header, payload, header_size, packet_len_tag_key,
-                  payload_length_key);
-ENABLE_REFLECTION(gr::packet_modem::hip::HeaderFecDecoder, in, out, alist);
+ENABLE_REFLECTION_FOR_TEMPLATE(gr::packet_modem::hip::HeaderPayloadSplit, in, header, payload, header_size,
+                               packet_len_tag_key, payload_length_key);
+ENABLE_REFLECTION(gr::packet_modem::hip::HeaderFecDecoder, in, out);
