@@ -79,6 +79,15 @@ def _np_ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def sincosf(x):
+    """sinf / cosf as the CostasLoop kernels evaluate them (glibc's algorithm on the device), for the parity suite"""
+    torch = _torch()
+    xd = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32)).cuda()
+    s, c = torch.empty_like(xd), torch.empty_like(xd)
+    check(lib().gr4pm_sincosf(xd.data_ptr(), xd.numel(), s.data_ptr(), c.data_ptr()), "sincosf")
+    return s.cpu().numpy(), c.cpu().numpy()
+
+
 def root_raised_cosine(gain, sampling_freq, symbol_rate, alpha, ntaps):
     """firdes::root_raised_cosine<float>, firdes.hpp:29-76"""
     out = np.zeros(ntaps | 1, dtype=np.float32)

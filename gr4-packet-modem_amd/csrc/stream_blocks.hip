@@ -210,28 +210,45 @@ struct CostasSeg {
     float pad;
 };
 
-// cos/sin of the loop phase.  The reference calls glibc cosf/sinf (< 1 ULP).  |phase| <= pi
-// here, so one Cody-Waite quadrant reduction plus the classic single-precision minimax
-// polynomials on [-pi/4, pi/4] (< 1 ULP each) are enough; the PLL is contractive, so last-bit
-// differences against glibc stay at the 1e-7 level in the output (tests allow 1e-5).
-__device__ __forceinline__ void sincos_pi(float x, float* s_out, float* c_out)
+// cos/sin of the loop phase, BIT-EXACT with glibc's cosf / sinf / sincosf (what the reference's
+// std::cos(float) / std::sin(float) call, costas_loop.hpp:113-115).  glibc >= 2.28 evaluates them in
+// double (sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, s_sincosf.h: Szabolcs Nagy's routines): the
+// quadrant n from x * (2/pi * 2^24) by an integer shift, x - n * (pi/2 as a double), one sine and one
+// cosine polynomial in x^2, ONE rounding to float.  MI355X has the FP64 rate to do the same, so the
+// loop's local oscillator carries the reference's bits instead of "< 1 ULP" ones.  Pinned against the
+// host libm for every float of |x| <= 3.2 (tests/sincosf_glibc_check.c: 0 mismatches, with and
+// without FMA contraction) and on the device by test_device_sincosf_is_glibc_bit_exact.
+// Valid for |x| < 120 (glibc's reduce_fast range; the loop phase is wrapped to [-pi, pi)).
+__device__ __forceinline__ void sincosf_glibc(float y, float* s_out, float* c_out)
 {
-    const float kf = rintf(x * 0.63661977236758134308f);
-    const int k = static_cast<int>(kf);
-    // pi/2 = 1.5707962512969971 + 7.5497894158615964e-08 (+ 5.39e-15): |k| <= 2
-    float r = fmaf(-kf, 1.5707962512969971f, x);
-    r = fmaf(-kf, 7.5497894158615964e-08f, r);
-    const float r2 = r * r;
-    float sp = -1.9515295891e-4f;
-    sp = fmaf(sp, r2, 8.3321608736e-3f);
-    sp = fmaf(sp, r2, -1.6666654611e-1f);
-    const float sn = fmaf(sp * r2, r, r);
-    float cp = 2.443315711809948e-5f;
-    cp = fmaf(cp, r2, -1.388731625493765e-3f);
-    cp = fmaf(cp, r2, 4.166664568298827e-2f);
-    const float cs = fmaf(cp * r2, r2, fmaf(-0.5f, r2, 1.0f));
-    // quadrant fix-up without branches: odd k swaps sin/cos, the signs follow k and k+1
-    const unsigned ku = static_cast<unsigned>(k);
+    const double hpi_inv = 0x1.45F306DC9C883p+23, hpi = 0x1.921FB54442D18p0; // 2/pi * 2^24, pi/2
+    const double C0 = 0x1p0, C1 = -0x1.ffffffd0c621cp-2, C2 = 0x1.55553e1068f19p-5, C3 = -0x1.6c087e89a359dp-10,
+                 C4 = 0x1.99343027bf8c3p-16, S1 = -0x1.555545995a603p-3, S2 = 0x1.1107605230bc4p-7,
+                 S3 = -0x1.994eb3774cf24p-13;
+    const double x0 = static_cast<double>(y);
+    // reduce_fast (for |y| < pi/4 this yields n = 0 and x = x0: the same as glibc's short path)
+    const int n = (static_cast<int>(x0 * hpi_inv) + 0x800000) >> 24;
+    const double x = fma(-static_cast<double>(n), hpi, x0);
+    const double x2 = x * x;
+    // sinf_poly, even n
+    const double x3 = x * x2;
+    const double s1 = fma(x2, S3, S2);
+    const double x7 = x3 * x2;
+    const double sp = fma(x7, s1, fma(x3, S1, x));
+    // sinf_poly, odd n
+    const double x4 = x2 * x2;
+    const double c2 = fma(x2, C4, C3);
+    const double c1 = fma(x2, C1, C0);
+    const double x6 = x4 * x2;
+    const double cp = fma(x6, c2, fma(x4, C2, c1));
+    float sn = static_cast<float>(sp), cs = static_cast<float>(cp);
+    // tiny arguments: glibc returns y and 1.0f (top 12 bits below those of 2^-12)
+    const bool tiny = ((__float_as_uint(y) >> 20) & 0x7ffu) < ((0x39800000u >> 20) & 0x7ffu);
+    sn = tiny ? y : sn;
+    cs = tiny ? 1.0f : cs;
+    // quadrant: sign[n & 3] on the sine argument (an odd polynomial: exact negation), second table =
+    // cosine polynomial negated when n & 2; odd n swaps the two
+    const unsigned ku = static_cast<unsigned>(n);
     const bool swap = (ku & 1u) != 0;
     const float s0 = swap ? cs : sn;
     const float c0 = swap ? sn : cs;
@@ -251,7 +268,7 @@ __device__ __forceinline__ cf costas_step(cf x, float& phase, float& freq, float
     sn = __sinf(phase);
     cs = __cosf(phase);
 #else
-    sincos_pi(phase, &sn, &cs);
+    sincosf_glibc(phase, &sn, &cs);
 #endif
     const cf lo = { cs, -sn }; // :114-115
     const cf z = cmul(x, lo);
@@ -413,6 +430,12 @@ __global__ void k_wipe(const WipeSpan* __restrict__ spans, const float* __restri
     const WipeSpan w = spans[blockIdx.x];
     for (unsigned i = threadIdx.x; i < w.len; i += blockDim.x)
         out[w.start + i] = fmulc(syncword[w.first + i], in[w.start + i]);
+}
+
+__global__ void k_sincosf(const float* __restrict__ x, size_t n, float* __restrict__ sn, float* __restrict__ cs)
+{
+    const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) sincosf_glibc(x[i], sn + i, cs + i);
 }
 
 template <typename T>
@@ -1328,6 +1351,18 @@ gr4pm_status gr4pm_syncword_wipeoff_reset(gr4pm_syncword_wipeoff* h)
     if (!h) return GR4PM_ERR_INVALID;
     h->in_syncword = false;
     h->position = 0;
+    return GR4PM_OK;
+}
+
+gr4pm_status gr4pm_sincosf(const float* x, size_t n, float* sin_out, float* cos_out)
+{
+    if (!x || !sin_out || !cos_out) return GR4PM_ERR_INVALID;
+    GR4PM_TRY(require_device());
+    if (n == 0) return GR4PM_OK;
+    hipLaunchKernelGGL(k_sincosf, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, nullptr, x, n, sin_out,
+                       cos_out);
+    GR4PM_HIP_TRY(hipGetLastError());
+    GR4PM_HIP_TRY(hipStreamSynchronize(nullptr));
     return GR4PM_OK;
 }
 

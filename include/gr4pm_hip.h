@@ -720,6 +720,11 @@ gr4pm_status gr4pm_burst_shaper_process(const void* in, size_t n, void* out, int
                                         const uint64_t* packet_offset, const uint64_t* packet_len,
                                         size_t n_packets, void* stream);
 
+/* The library's cosf / sinf on device arrays: the local oscillator of CostasLoop (costas_loop.hpp:113-115 calls
+ * std::cos(float) / std::sin(float), i.e. glibc's cosf / sinf; the kernels restate glibc's double-precision
+ * algorithm and are bit-exact with it for |x| < 120).  Exposed so that the parity suite can pin it directly. */
+gr4pm_status gr4pm_sincosf(const float* x, size_t n, float* sin_out, float* cos_out);
+
 /* firdes::root_raised_cosine<float> -- firdes.hpp:29-76 (host helper; out: ntaps|1 floats) */
 size_t gr4pm_firdes_root_raised_cosine(double gain, double sampling_freq, double symbol_rate,
                                        double alpha, size_t ntaps, float* out);

@@ -658,6 +658,14 @@ orc_costas* orc_costas_create(double loop_bandwidth, int constellation)
     return c;
 }
 void orc_costas_destroy(orc_costas* c) { delete c; }
+/* the host libm's sinf / cosf, what std::cos(float) / std::sin(float) of costas_loop.hpp:113-115 call */
+void orc_sincosf(const float* x, size_t n, float* s, float* c)
+{
+    for (size_t i = 0; i < n; ++i) {
+        s[i] = sinf(x[i]);
+        c[i] = cosf(x[i]);
+    }
+}
 void orc_costas_coeffs(const orc_costas* c, float* k1, float* k2)
 {
     *k1 = c->k1;

@@ -107,6 +107,7 @@ void orc_rot_process(orc_rot*, const orc_c64* in, size_t n, orc_c64* out);
 typedef struct orc_costas orc_costas;
 orc_costas* orc_costas_create(double loop_bandwidth, int constellation);
 void orc_costas_destroy(orc_costas*);
+void orc_sincosf(const float* x, size_t n, float* s, float* c);
 void orc_costas_coeffs(const orc_costas*, float* k1, float* k2);
 void orc_costas_process(orc_costas*, const orc_c64* in, size_t n, orc_c64* out,
                         const uint64_t* tag_index, const float* tag_phase, size_t n_tags);

@@ -124,6 +124,7 @@ def lib():
         L.orc_costas_create.restype = vp
         L.orc_costas_create.argtypes = [C.c_double, C.c_int]
         L.orc_costas_destroy.argtypes = [vp]
+        L.orc_sincosf.argtypes = [vp, sz, vp, vp]
         L.orc_costas_coeffs.argtypes = [vp, f32p, f32p]
         L.orc_costas_process.argtypes = [vp, vp, sz, vp, vp, vp, sz]
         L.orc_wipe_create.restype = vp
@@ -319,6 +320,14 @@ def rotator(x, phase_incr):
 
 
 CONSTELLATIONS = {"PILOT": 0, "BPSK": 1, "QPSK": 2}
+
+
+def sincosf(x):
+    """the host libm's sinf / cosf (what the reference's CostasLoop calls)"""
+    x = _f32(x)
+    s, c = np.empty_like(x), np.empty_like(x)
+    lib().orc_sincosf(_p(x), x.size, _p(s), _p(c))
+    return s, c
 
 
 def costas_coeffs(loop_bandwidth, constellation):

@@ -82,3 +82,15 @@ def test_one_exchange_wave_fft_host_emulation(tmp_path):
     out = subprocess.check_output([str(exe)]).decode()
     errs = [float(e) for e in re.findall(r"max_rel_err ([0-9.e+-]+)", out)]
     assert len(errs) == 5 and max(errs) < 5e-7, out
+
+
+def test_glibc_sinf_cosf_restatement_matches_the_host_libm(tmp_path):
+    """tests/sincosf_glibc_check.c: the double-precision sinf / cosf algorithm the Costas kernels use
+    (csrc/stream_blocks.hip: sincosf_glibc) against the host libm the reference calls, for EVERY float of
+    |x| <= 3.2 (the loop phase lives in [-pi, pi)), with and without FMA contraction"""
+    for fma in (1, 0):
+        exe = tmp_path / f"sc{fma}"
+        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", f"-DFMA={fma}"] + (["-march=native"] if fma else []) +
+                              ["-o", str(exe), os.path.join(ROOT, "tests", "sincosf_glibc_check.c"), "-lm", "-lpthread"])
+        out = subprocess.check_output([str(exe)]).decode()
+        assert re.search(r"sin mismatches 0, cos mismatches 0", out), out
