@@ -9,6 +9,7 @@ namespace gr4pm {
 static thread_local char g_error[512] = "";
 static thread_local bool g_deferred_sync = false;
 bool deferred_sync() { return g_deferred_sync; }
+void set_deferred_sync(bool on) { g_deferred_sync = on; }
 
 void set_error(const char* fmt, ...)
 {

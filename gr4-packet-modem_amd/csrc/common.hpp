@@ -140,6 +140,17 @@ inline size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
 // several handles on ONE stream and reads nothing back in between (csrc/packet_receiver.hip) turns
 // that wait off for its thread (gr4pm_set_deferred_sync) and synchronises once per stage.
 bool deferred_sync();
+void set_deferred_sync(bool on);
+// switches the calling thread to deferred synchronisation for a scope and restores the previous state on
+// EVERY exit path (an early error return used to leave it on: later calls of that thread then returned
+// before their kernels had finished)
+struct DeferredSyncScope {
+    bool was;
+    DeferredSyncScope() : was(deferred_sync()) { set_deferred_sync(true); }
+    ~DeferredSyncScope() { set_deferred_sync(was); }
+    DeferredSyncScope(const DeferredSyncScope&) = delete;
+    DeferredSyncScope& operator=(const DeferredSyncScope&) = delete;
+};
 inline hipError_t final_sync(hipStream_t s) { return deferred_sync() ? hipSuccess : hipStreamSynchronize(s); }
 
 } // namespace gr4pm

@@ -258,6 +258,12 @@ gr4pm_status gr4pm_multichannel_receiver_process(gr4pm_multichannel_receiver* h,
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
     const auto t0 = now();
+    // checked BEFORE the detector consumes the batch: an error here must not lose items (the detector
+    // consumes at most n_in items per channel)
+    if (out_stride < n_in / h->p.samples_per_symbol + h->p.tags_cap + 2) {
+        set_error("out_stride %zu too small for %zu items per channel", out_stride, n_in);
+        return GR4PM_INSUFFICIENT_OUTPUT_ITEMS;
+    }
     size_t n_done = 0;
     const gr4pm_status st = gr4pm_syncword_detection_process(h->sd, in, in_stride, n_in, h->y.p, h->y_stride, &n_done,
                                                              h->det_tags.data(), h->p.tags_cap, h->n_det.data());
@@ -276,10 +282,6 @@ gr4pm_status gr4pm_multichannel_receiver_process(gr4pm_multichannel_receiver* h,
     h->job.tags = tags;
     h->job.n_tags = n_tags;
     const size_t C = h->p.n_channels;
-    if (out_stride < n_done / h->p.samples_per_symbol + h->p.tags_cap + 2) {
-        set_error("out_stride %zu too small for %zu items per channel", out_stride, n_done);
-        return GR4PM_INSUFFICIENT_OUTPUT_ITEMS;
-    }
     if (h->symall.n < C * out_stride) GR4PM_TRY(h->symall.alloc(C * out_stride));
     // SyncwordDetectionFilter of every channel (host only): the samples pass unchanged, the tags are gated
     h->all_tags.clear();

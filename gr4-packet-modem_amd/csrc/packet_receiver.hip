@@ -1057,14 +1057,14 @@ gr4pm_status gr4pm_packet_receiver_submit(gr4pm_packet_receiver* h, const gr4pm_
         if (h->p.decode_headers) h->to_stageA.push(i);
         else h->to_stage1.push(i);
     } else {
-        const bool was = deferred_sync();
-        gr4pm_set_deferred_sync(1);
-        h->stageA(s);
-        h->stage1(s);
-        h->stage1b(s);
-        h->stage2(s);
-        h->stage3(s);
-        gr4pm_set_deferred_sync(was ? 1 : 0);
+        {
+            DeferredSyncScope defer;
+            h->stageA(s);
+            h->stage1(s);
+            h->stage1b(s);
+            h->stage2(s);
+            h->stage3(s);
+        }
         h->done.push(i);
     }
     return GR4PM_OK;

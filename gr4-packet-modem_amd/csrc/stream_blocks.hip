@@ -2127,16 +2127,18 @@ gr4pm_status gr4pm_cfc_symbol_filter_process(gr4pm_rotator* cfc, gr4pm_symbol_fi
         set_error("out_cap too small for a fused call");
         return GR4PM_INSUFFICIENT_OUTPUT_ITEMS;
     }
-    int plan = -1;
-    const bool was = deferred_sync();
-    gr4pm_set_deferred_sync(1); // same stream: the filter queues up behind the checkpoints
-    // (one stream, nothing in between: the current plan set is reused, no ring)
-    if (cfc->n_channels != 1) {
+    if (cfc->n_channels != 1) { // validated before any state is touched
         set_error("fused call needs a single-channel CoarseFrequencyCorrection");
         return GR4PM_ERR_INVALID;
     }
-    const gr4pm_status st = cfc_plan_impl(cfc, n_in, tags_in, nullptr, n_tags_in, &plan, false);
-    gr4pm_set_deferred_sync(was ? 1 : 0);
+    int plan = -1;
+    gr4pm_status st;
+    {
+        // same stream: the filter queues up behind the checkpoints
+        // (one stream, nothing in between: the current plan set is reused, no ring)
+        DeferredSyncScope defer;
+        st = cfc_plan_impl(cfc, n_in, tags_in, nullptr, n_tags_in, &plan, false);
+    }
     if (st != GR4PM_OK) return st;
     return gr4pm_cfc_symbol_filter_run(cfc, plan, sf, in, n_in, out, out_cap, tags_in, n_tags_in, tags_out,
                                        tags_cap, n_tags_out, consumed, produced);

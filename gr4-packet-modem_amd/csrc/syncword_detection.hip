@@ -170,7 +170,8 @@ __global__ __launch_bounds__(kCorrThreads, 2) void k_correlate(const cf* __restr
                                                                const cf* __restrict__ tw1a,
                                                                const cf* __restrict__ tw1b,
                                                                const float4* __restrict__ twAB,
-                                                               float* __restrict__ zpow, size_t z_stride)
+                                                               float* __restrict__ zpow, size_t z_stride,
+                                                               unsigned* __restrict__ fault, int spin_limit)
 {
     __shared__ float4 lds4[kLdsTotal];
     const int tid = threadIdx.x;
@@ -229,7 +230,9 @@ __global__ __launch_bounds__(kCorrThreads, 2) void k_correlate(const cf* __restr
     // Wave 0 copies template bin+1 global -> LDS with the DMA path (global_load_lds: no VGPRs,
     // no ds_write) in the middle of its own transform, once consumed == 4 (bin + 1); everybody
     // waits for ready >= bin before reading.  LDS operations of a wave execute in order, so
-    // the ds_add of a wave is performed after its template reads.  All spins are bounded.
+    // the ds_add of a wave is performed after its template reads.  All spins are bounded, and a spin
+    // that runs out does NOT carry on silently with a stale template: it raises the handle's fault word
+    // (pinned host memory), which process() turns into GR4PM_ERR_HIP after its stream synchronisation.
     unsigned* ctl = reinterpret_cast<unsigned*>(lds4 + kLdsCtl);
     if (tid == 0) {
         ctl[0] = 0; // consumed
@@ -237,10 +240,11 @@ __global__ __launch_bounds__(kCorrThreads, 2) void k_correlate(const cf* __restr
     }
     __syncthreads();
     auto wait_ge = [&](int word, unsigned v) {
-        for (int guard = 0; guard < (1 << 20); ++guard) {
+        for (int guard = 0; guard < spin_limit; ++guard) {
             if (__hip_atomic_load(ctl + word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= v) return;
             __builtin_amdgcn_s_sleep(2);
         }
+        if (lane == 0) __hip_atomic_fetch_or(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     };
     for (int bin = 0; bin < n_bins; ++bin) {
         const bool more = bin + 1 < n_bins;
@@ -332,17 +336,24 @@ __device__ __forceinline__ void mul_template_pair(int L, const cf* X, cf* r, con
 struct PairSync {
     unsigned* mine;
     const unsigned* other;
+    unsigned* fault;
+    int spin_limit;
     unsigned step = 0;
     __device__ __forceinline__ void operator()(int lane)
     {
         ++step;
         asm volatile("" ::: "memory");
         if (lane == 0) __hip_atomic_store(mine, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        for (int guard = 0; guard < (1 << 22); ++guard) {
+        bool met = false;
+        for (int guard = 0; guard < 4 * spin_limit; ++guard) {
             const unsigned v = __hip_atomic_load(other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (__builtin_amdgcn_readfirstlane(v) >= step) break;
+            if (__builtin_amdgcn_readfirstlane(v) >= step) {
+                met = true;
+                break;
+            }
             __builtin_amdgcn_s_sleep(1);
         }
+        if (!met && lane == 0) __hip_atomic_fetch_or(fault, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         asm volatile("" ::: "memory");
     }
 };
@@ -350,7 +361,8 @@ struct PairSync {
 __global__ __launch_bounds__(kPairThreads, 3) void k_correlate_pair(
     const cf* __restrict__ in, size_t in_stride, uint32_t n_blocks, uint32_t stride_s, int n_bins,
     const float4* __restrict__ tmplp, const cf* __restrict__ tw1p, const cf* __restrict__ tw1b,
-    const float4* __restrict__ twABp, float* __restrict__ zpow, size_t z_stride)
+    const float4* __restrict__ twABp, float* __restrict__ zpow, size_t z_stride, unsigned* __restrict__ fault,
+    int spin_limit)
 {
     __shared__ float4 lds4[kPLdsTotal + 2];
     const int tid = threadIdx.x;
@@ -381,15 +393,16 @@ __global__ __launch_bounds__(kPairThreads, 3) void k_correlate_pair(
 #if defined(GR4PM_PAIR_NOSYNC) /* timing-only ablation: wrong results */
     auto sync = [&](int) { wave_lds_sync(); };
 #elif defined(GR4PM_PAIR_FLAGS) /* measured: 1.27 ms per 2^26 samples against 1.18 with the workgroup barrier */
-    PairSync sync{ ctl + 4 + 2 * pair + wv, ctl + 4 + 2 * pair + (wv ^ 1) };
+    PairSync sync{ ctl + 4 + 2 * pair + wv, ctl + 4 + 2 * pair + (wv ^ 1), fault, spin_limit };
 #else
     auto sync = [&](int) { pair_sync(); };
 #endif
     auto wait_ge = [&](int word, unsigned v) {
-        for (int guard = 0; guard < (1 << 20); ++guard) {
+        for (int guard = 0; guard < spin_limit; ++guard) {
             if (__hip_atomic_load(ctl + word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= v) return;
             __builtin_amdgcn_s_sleep(2);
         }
+        if (lane == 0) __hip_atomic_fetch_or(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     };
     // ---- FFT-1
     fft1p_pass1(L, r, tw1p);
@@ -1206,6 +1219,10 @@ struct gr4pm_syncword_detection {
     DevBuf<cf> cc64;
     int n_cus = 256;
     int w64_variant = 0;
+    // raised by a correlator kernel whose bounded hand-off spin ran out ("wave" / "pair" kernels; k_correlate_w64
+    // has no spins); checked after the stream synchronisation of process()
+    PinnedBuf<unsigned> fault;
+    int spin_limit = 1 << 20;
     // the two-waves-per-block correlator (fft2048_pair.hpp): templates in its lane order,
     // tw1p ++ twAp ++ twB
     bool use_pair = false;
@@ -1245,7 +1262,12 @@ struct gr4pm_syncword_detection {
         size_t stride, n;
         uint64_t E0; // first item of that call
         int set;     // buffer set its front writes
+        int ev;      // index into ev_announce: recorded on the handle's stream when the input was announced
     };
+    // an announced buffer is only read by the look-ahead streams after everything that was queued on the
+    // handle's stream at announcement time (the producer of that buffer, in stream-ordered code) has run
+    hipEvent_t ev_announce[kAhead + 2] = {};
+    int ev_next = 0;
     std::deque<Ahead> launched;  // fronts in flight or done, oldest first
     std::deque<Ahead> announced; // inputs announced but not launched yet
     ~gr4pm_syncword_detection()
@@ -1259,6 +1281,8 @@ struct gr4pm_syncword_detection {
             (void)hipStreamDestroy(stream3);
         }
         for (auto e : ev_mid)
+            if (e) (void)hipEventDestroy(e);
+        for (auto e : ev_announce)
             if (e) (void)hipEventDestroy(e);
         for (auto e : ev_front)
             if (e) (void)hipEventDestroy(e);
@@ -1347,7 +1371,7 @@ gr4pm_status launch_correlate(gr4pm_syncword_detection* h, hipStream_t stream, c
         hipLaunchKernelGGL(k_correlate_pair, gridp, dim3(kPairThreads), 0, stream, reinterpret_cast<const cf*>(in),
                            in_stride, n_blocks, static_cast<uint32_t>(h->S), h->n_bins, h->tmplp.p, h->twp.p,
                            h->tw.p + kTw1aItems, reinterpret_cast<const float4*>(h->twp.p + kTw1pItems), zout,
-                           h->z_stride);
+                           h->z_stride, h->fault.p, h->spin_limit);
         GR4PM_HIP_TRY(hipGetLastError());
         return GR4PM_OK;
     }
@@ -1389,7 +1413,7 @@ gr4pm_status launch_correlate(gr4pm_syncword_detection* h, hipStream_t stream, c
     const cf* twA = tw1b + kTw1bItems;
     hipLaunchKernelGGL(k_correlate, grid, dim3(kCorrThreads), 0, stream, reinterpret_cast<const cf*>(in),
                        in_stride, n_blocks, static_cast<uint32_t>(h->S), h->n_bins, h->tmpl.p, tw1a, tw1b,
-                       reinterpret_cast<const float4*>(twA), zout, h->z_stride);
+                       reinterpret_cast<const float4*>(twA), zout, h->z_stride, h->fault.p, h->spin_limit);
     GR4PM_HIP_TRY(hipGetLastError());
     return GR4PM_OK;
 }
@@ -1667,6 +1691,9 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
     ok(h->tmpl.alloc(tmpl.size()));
     ok(h->tw.alloc(tw.size()));
     ok(h->tmplp.alloc(tmplp.size()));
+    ok(h->fault.alloc(1));
+    if (h->fault.p) *h->fault.p = 0;
+    if (const char* e = getenv("GR4PM_TEST_SPIN_LIMIT")) h->spin_limit = atoi(e); // tests force a timeout with 0
     ok(h->tmpl64.alloc(tmpl64.size()));
     ok(h->tT64.alloc(tT64.size()));
     ok(h->tC64.alloc(tC64.size()));
@@ -1762,8 +1789,13 @@ gr4pm_status gr4pm_syncword_detection_announce(gr4pm_syncword_detection* h, cons
     if (!h || !in) return GR4PM_ERR_INVALID;
     GR4PM_TRY(ensure_ahead_streams(h));
     // one launched front is consumed by the next call before a new one is launched
-    if (h->launched.size() + h->announced.size() < static_cast<size_t>(kAhead) + 1)
-        h->announced.push_back({ in, in_stride, n_in, 0, 0 });
+    if (h->launched.size() + h->announced.size() < static_cast<size_t>(kAhead) + 1) {
+        const int e = h->ev_next;
+        h->ev_next = (h->ev_next + 1) % (kAhead + 2);
+        if (!h->ev_announce[e]) GR4PM_HIP_TRY(hipEventCreateWithFlags(&h->ev_announce[e], hipEventDisableTiming));
+        GR4PM_HIP_TRY(hipEventRecord(h->ev_announce[e], h->stream));
+        h->announced.push_back({ in, in_stride, n_in, 0, 0, e });
+    }
     return GR4PM_OK;
 }
 
@@ -1904,6 +1936,7 @@ gr4pm_status gr4pm_syncword_detection_process(gr4pm_syncword_detection* h, const
             // (a whole correlator launch lies in between), ordered by its event all the same
             if (h->front_recorded[(set + 1) % kSets])
                 GR4PM_HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_front[(set + 1) % kSets], 0));
+            GR4PM_HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_announce[a.ev], 0)); // the producer of a.in has run
             GR4PM_TRY(launch_front(h, h->stream2, set, c, a.in, a.stride, a.n, e0, j_prev));
             h->launched.push_back(a);
             const size_t nb = (a.n - h->fft_size) / h->S + 1;
@@ -1918,6 +1951,12 @@ gr4pm_status gr4pm_syncword_detection_process(gr4pm_syncword_detection* h, const
 #ifdef GR4PM_TIMING
     const auto tp2 = std::chrono::steady_clock::now();
 #endif
+    if (*h->fault.p != 0) {
+        set_error("correlator template hand-off timed out (fault word %u): the correlation powers of this call are "
+                  "not valid", *h->fault.p);
+        *h->fault.p = 0;
+        return GR4PM_ERR_HIP;
+    }
 
     // the raw records were written by k_tags straight into pinned host memory (a handful of
     // 48-byte records per call: no second copy, no second synchronisation); the tag arithmetic

@@ -126,7 +126,9 @@ gr4pm_status gr4pm_syncword_detection_process(gr4pm_syncword_detection* h, const
  * correlator, candidate bitmap, tile / group tables), where it overlaps this call's scan, tag
  * kernels and read-back; the later process(in, in_stride, n_in) with exactly the announced
  * arguments finds that work done.  The items must not change between the announcement and
- * their call.  A call with other arguments drops the look-ahead and recomputes; results are
+ * their call, and whatever produces them must have been queued on the handle's stream (or have
+ * finished) when they are announced: the look-ahead streams wait for an event recorded on the
+ * handle's stream at announcement time before they read an announced buffer.  A call with other arguments drops the look-ahead and recomputes; results are
  * identical either way.  _hint_next is the one-call form: it replaces every announcement not
  * yet launched (in_next == NULL: just clears them). */
 #define GR4PM_SD_LOOKAHEAD 2

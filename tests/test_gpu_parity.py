@@ -243,6 +243,23 @@ def test_two_waves_per_block_correlator_is_bit_identical(pkg, monkeypatch):
         assert a.size >= 2 and same_tags(a, b)
 
 
+@pytest.mark.parametrize("kind", ["wave", "pair"])
+def test_correlator_spin_timeout_is_reported(pkg, monkeypatch, kind):
+    """the round-1 correlator kernels hand templates over through bounded spins: a spin that runs out raises the
+    handle's fault word and process() fails with GR4PM_ERR_HIP instead of returning powers computed from a
+    stale template (GR4PM_TEST_SPIN_LIMIT=0 forces every wait to time out); the default kernel has no spins"""
+    x, rrc = sig.qa_syncword_stream(20000, [100, 1000, 5000], 0.0, seed=3)
+    monkeypatch.setenv("GR4PM_CORRELATOR", kind)
+    monkeypatch.setenv("GR4PM_TEST_SPIN_LIMIT", "0")
+    sd = pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, power_threshold=20.0, max_items=x.size)
+    with pytest.raises(pkg.Gr4pmError, match="hand-off timed out"):
+        sd.process_bulk(dev(x))
+    monkeypatch.delenv("GR4PM_TEST_SPIN_LIMIT")
+    sd = pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, power_threshold=20.0, max_items=x.size)
+    st, out, tags, n = sd.process_bulk(dev(x))
+    assert st == 0 and tags.size == 3
+
+
 def test_syncword_detection_awgn_threshold_and_noise_only(pkg):
     """default threshold 9.5, bursts in AWGN: same detections (incl. none on noise) as the oracle"""
     rng = np.random.default_rng(77)
