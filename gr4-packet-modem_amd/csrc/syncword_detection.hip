@@ -643,17 +643,76 @@ __device__ __forceinline__ uint32_t next_candidate_wave(const unsigned long long
     }
     return hi;
 }
-__device__ __forceinline__ uint32_t walk_from_candidate_wave(const unsigned long long* bm, uint32_t c, uint32_t hi,
-                                                             uint32_t T, int lane)
-{
-    uint32_t r = c + T + 1;
-    while (r < hi) {
-        const uint32_t p = next_candidate_wave(bm, r, hi, lane);
-        if (p >= hi) return 0;
-        r = p + T + 1;
+// The whole bitmap of one tile (kTileW / 64 words) in the registers of one wave, lane l holding words
+// l, l + 64, ...: the walks of k_tile_tables / k_tile_visit then cost a ballot and a shuffle per step instead of
+// a global-memory round trip (they were the whole cost of those kernels: 150 + 175 us per 2^26 items).
+constexpr int kTileChunks = static_cast<int>(kTileW / 4096);
+static_assert(kTileW % 4096 == 0 && kTileChunks >= 1 && kTileChunks <= 16, "tile = whole 4096-item chunks");
+struct TileBits {
+    unsigned long long w[kTileChunks];
+    uint32_t lo;
+    __device__ __forceinline__ void load(const unsigned long long* bm, uint32_t lo_, uint32_t hi, int lane)
+    {
+        lo = __builtin_amdgcn_readfirstlane(lo_);
+        const uint32_t w0 = lo >> 6, wlast = (hi - 1) >> 6;
+#pragma unroll
+        for (int k = 0; k < kTileChunks; ++k) {
+            const uint32_t wi = w0 + 64u * k + lane;
+            unsigned long long v = wi <= wlast ? bm[wi] : 0ull;
+            if (wi == wlast && (hi & 63u)) v &= (1ull << (hi & 63u)) - 1ull; // nothing at or beyond hi
+            w[k] = v;
+        }
     }
-    return r - hi;
-}
+    // word number j (0-based inside the tile), wave-uniform j
+    __device__ __forceinline__ unsigned long long word(uint32_t j) const
+    {
+        unsigned long long v = 0;
+#pragma unroll
+        for (int k = 0; k < kTileChunks; ++k)
+            if (static_cast<uint32_t>(k) == (j >> 6)) v = w[k];
+        const unsigned long long x = __shfl(v, static_cast<int>(j & 63));
+        // wave-uniform by construction: tell the compiler (scalar registers, scalar branches)
+        const uint32_t lo32 = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(x));
+        const uint32_t hi32 = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(x >> 32));
+        return (static_cast<unsigned long long>(hi32) << 32) | lo32;
+    }
+    // first set bit at local position >= r and < hi, or hi if none (r wave-uniform, lo <= r)
+    __device__ __forceinline__ uint32_t next(uint32_t r_, uint32_t hi_, int lane) const
+    {
+        // r and hi are wave-uniform; without the hint every chunk below runs under an exec mask, every step
+        // executes all of them, and a step costs ~2000 cycles instead of ~100
+        const uint32_t r = __builtin_amdgcn_readfirstlane(r_), hi = __builtin_amdgcn_readfirstlane(hi_);
+        if (r >= hi) return hi;
+        const uint32_t j0 = (r - lo) >> 6; // word of r inside the tile
+#pragma unroll
+        for (int k = 0; k < kTileChunks; ++k) {
+            if (static_cast<uint32_t>(k) < (j0 >> 6)) continue;
+            unsigned long long wd = w[k];
+            const uint32_t j = 64u * k + lane;
+            if (j < j0) wd = 0ull;
+            else if (j == j0) wd &= ~0ull << (r & 63);
+            const unsigned long long any = __ballot(wd != 0ull);
+            if (any) {
+                const int src = __ffsll(static_cast<long long>(any)) - 1;
+                const unsigned long long hit = __shfl(wd, src);
+                const uint32_t p = __builtin_amdgcn_readfirstlane(
+                    lo + ((64u * k + src) << 6) + static_cast<uint32_t>(__ffsll(static_cast<long long>(hit)) - 1));
+                return p < hi ? p : hi;
+            }
+        }
+        return hi;
+    }
+    __device__ __forceinline__ uint32_t walk(uint32_t c, uint32_t hi, uint32_t T, int lane) const
+    {
+        uint32_t r = c + T + 1;
+        while (r < hi) {
+            const uint32_t p = next(r, hi, lane);
+            if (p >= hi) return 0;
+            r = p + T + 1;
+        }
+        return r - hi;
+    }
+};
 __device__ __forceinline__ uint32_t walk_from_candidate(const unsigned long long* bm, uint32_t c, uint32_t hi,
                                                         uint32_t T)
 {
@@ -665,25 +724,14 @@ __device__ __forceinline__ uint32_t walk_from_candidate(const unsigned long long
     }
     return r - hi;
 }
-__global__ __launch_bounds__(64) void k_tile_tables(const unsigned long long* __restrict__ bitmap,
-                                                    size_t bm_stride, uint32_t cnt, uint32_t T, uint32_t n_tiles,
-                                                    uint32_t* __restrict__ table, size_t table_stride)
+// the walking form (one walk per candidate of the entry window): kept for tiles with more candidates than the
+// list form below holds (all-zero input: every item is a candidate)
+__device__ __forceinline__ void tile_tables_walks(const TileBits& tb, const unsigned long long* bm, uint32_t* tab,
+                                                  uint32_t lo, uint32_t hi, uint32_t wend, uint32_t T, int lane)
 {
-#ifndef GR4PM_NO_SETPRIO
-    __builtin_amdgcn_s_setprio(3); // latency-bound, few waves: win the issue arbitration against throughput kernels
-#endif
-    const uint32_t tile = blockIdx.x;
-    const int lane = threadIdx.x;
-    const unsigned long long* bm = bitmap + static_cast<size_t>(blockIdx.y) * bm_stride;
-    uint32_t* tab = table + static_cast<size_t>(blockIdx.y) * table_stride + static_cast<size_t>(tile) * (T + 1);
-    const uint32_t lo = tile * kTileW;
-    const uint32_t hi = min(lo + kTileW, cnt);
-    const uint32_t wend = min(lo + T + 1, hi); // entry window [lo, wend)
-    // entries that start at or beyond hi keep their position: table = (lo + e) - hi
-    for (uint32_t e = (hi - lo) + lane; e <= T; e += 64) tab[e] = lo + e - hi;
     uint32_t prev = lo; // first entry position not yet filled
     for (uint32_t w0 = lo; w0 < wend; w0 += 64) { // kTileW is a multiple of 64: words are aligned
-        unsigned long long word = bm[w0 >> 6];
+        unsigned long long word = tb.word((w0 - lo) >> 6);
         if (wend - w0 < 64) word &= (1ull << (wend - w0)) - 1ull;
         if (!word) continue;
         const bool mine = (word >> lane) & 1ull;
@@ -695,24 +743,140 @@ __global__ __launch_bounds__(64) void k_tile_tables(const unsigned long long* __
             while (rest) {
                 const int bit = __ffsll(static_cast<long long>(rest)) - 1;
                 rest &= rest - 1;
-                const uint32_t rr = walk_from_candidate_wave(bm, w0 + bit, hi, T, lane);
+                const uint32_t rr = tb.walk(w0 + bit, hi, T, lane);
                 if (lane == bit) res = rr;
             }
         } else if (mine) { // dense candidates (e.g. all-zero input): every step hits at once
             res = walk_from_candidate(bm, w0 + lane, hi, T);
         }
-        // lane's entry range: (previous candidate, this candidate]
-        const unsigned long long below = word & ((1ull << lane) - 1ull);
-        const uint32_t first = below ? w0 + (63 - __clzll(below)) + 1 : prev;
-        if (mine)
-            for (uint32_t p = first; p <= w0 + lane; ++p) tab[p - lo] = res;
+        // entries (previous candidate, candidate] share the candidate's result.  Filled by the whole wave with
+        // coalesced stores (one lane per entry), not by every candidate's lane walking its own range: the
+        // per-lane loops were ~T scattered 4-byte stores per tile and the whole cost of this kernel.
+        const int topbit = 63 - __clzll(word), firstbit = __ffsll(static_cast<long long>(word)) - 1;
+        // (a) the gap since the last candidate of an earlier word, up to this word's first candidate's word start
+        const uint32_t res_first = __shfl(res, firstbit);
+        for (uint32_t p = prev + lane; p < w0; p += 64) tab[p - lo] = res_first;
+        // (b) inside this word: lane l's entry belongs to the first candidate at or above l
+        if (lane <= topbit) {
+            const unsigned long long at_or_above = word >> lane; // non-zero: topbit >= lane
+            const int nb = lane + __ffsll(static_cast<long long>(at_or_above)) - 1;
+            const uint32_t v = __shfl(res, nb);
+            if (w0 + lane >= prev) tab[w0 + lane - lo] = v;
+        } else {
+            (void)__shfl(res, lane); // keep the shuffle convergent
+        }
         prev = w0 + (63 - __clzll(word)) + 1;
     }
     if (prev < wend) { // entries behind the last candidate of the window share the next candidate
         uint32_t res = 0;
-        const uint32_t c = next_candidate_wave(bm, prev, hi, lane);
-        if (c < hi) res = walk_from_candidate_wave(bm, c, hi, T, lane);
+        const uint32_t c = tb.next(prev, hi, lane);
+        if (c < hi) res = tb.walk(c, hi, T, lane);
         for (uint32_t p = prev + lane; p < wend; p += 64) tab[p - lo] = res;
+    }
+}
+
+
+// table[tile][e], e in [0, T]: entering the tile at local lo + e, the scan leaves it wanting to resume at
+// hi + table (>= hi).  LIST FORM: the tile's candidates (a few dozen on noise) are compacted into LDS in position
+// order; every candidate learns the candidate the scan meets next (binary search for pos + T + 1), the chain is
+// closed by pointer jumping (log2 rounds, all candidates at once), and an entry's value is the value of the first
+// candidate at or behind it.  No serial walk: the walking form cost ~1 us per step and 150 us per 2^26 items.
+constexpr uint32_t kListCap = 512, kListEnd = 0xffffffffu;
+__global__ __launch_bounds__(64) void k_tile_tables(const unsigned long long* __restrict__ bitmap,
+                                                    size_t bm_stride, uint32_t cnt, uint32_t T, uint32_t n_tiles,
+                                                    uint32_t* __restrict__ table, size_t table_stride)
+{
+#ifndef GR4PM_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3); // latency-bound, few waves: win the issue arbitration against throughput kernels
+#endif
+    __shared__ uint32_t cpos[kListCap], jmp[kListCap], val[kListCap];
+    const uint32_t tile = blockIdx.x;
+    const int lane = threadIdx.x;
+    const unsigned long long* bm = bitmap + static_cast<size_t>(blockIdx.y) * bm_stride;
+    uint32_t* tab = table + static_cast<size_t>(blockIdx.y) * table_stride + static_cast<size_t>(tile) * (T + 1);
+    const uint32_t lo = tile * kTileW;
+    const uint32_t hi = min(lo + kTileW, cnt);
+    const uint32_t wend = min(lo + T + 1, hi); // entry window [lo, wend)
+    // entries that start at or beyond hi keep their position: table = (lo + e) - hi
+    for (uint32_t e = (hi - lo) + lane; e <= T; e += 64) tab[e] = lo + e - hi;
+    TileBits tb;
+    tb.load(bm, lo, hi, lane);
+    // ---- candidates in position order: chunk k, then lane, then bit
+    uint32_t n = 0; // wave-uniform running count
+    bool dense = false;
+#pragma unroll
+    for (int k = 0; k < kTileChunks; ++k) {
+        unsigned long long wd = tb.w[k];
+        const uint32_t mine = static_cast<uint32_t>(__popcll(wd));
+        uint32_t incl = mine; // inclusive prefix sum over the lanes
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        const uint32_t total = __builtin_amdgcn_readfirstlane(__shfl(incl, 63));
+        if (n + total > kListCap) {
+            dense = true;
+            break;
+        }
+        uint32_t at = n + incl - mine;
+        const uint32_t base = lo + ((64u * k + lane) << 6);
+        while (wd) {
+            const uint32_t pos = base + static_cast<uint32_t>(__ffsll(static_cast<long long>(wd)) - 1);
+            wd &= wd - 1;
+            cpos[at++] = pos; // positions at or beyond hi cannot occur: the bitmap ends at cnt
+        }
+        n += total;
+    }
+    if (dense) {
+        tile_tables_walks(tb, bm, tab, lo, hi, wend, T, lane);
+        return;
+    }
+    wave_lds_sync();
+    auto lower_bound = [&](uint32_t q) { // first list index with cpos >= q, n if none
+        uint32_t a = 0, b = n;
+        while (a < b) {
+            const uint32_t m = (a + b) >> 1;
+            if (cpos[m] < q) a = m + 1;
+            else b = m;
+        }
+        return a;
+    };
+    for (uint32_t i = lane; i < n; i += 64) {
+        const uint32_t target = cpos[i] + T + 1;
+        uint32_t jv = kListEnd, v = 0;
+        if (target >= hi) {
+            v = target - hi;
+        } else {
+            const uint32_t nx = lower_bound(target);
+            if (nx < n) jv = nx; // else: the scan position ends at hi (value 0)
+        }
+        jmp[i] = jv;
+        val[i] = v;
+    }
+    wave_lds_sync();
+    for (int round = 0; round < 32; ++round) { // chain length <= n <= 512: at most 10 doubling rounds
+        bool changed = false;
+        for (uint32_t i = lane; i < n; i += 64) {
+            const uint32_t jv = jmp[i];
+            if (jv != kListEnd) {
+                const uint32_t jj = jmp[jv];
+                if (jj == kListEnd) {
+                    val[i] = val[jv];
+                    jmp[i] = kListEnd;
+                } else {
+                    jmp[i] = jj;
+                }
+                changed = true;
+            }
+        }
+        wave_lds_sync();
+        if (!__any(changed)) break;
+    }
+    // ---- entries: the value of the first candidate at or behind the entry position, 0 if there is none
+    for (uint32_t q = lo + lane; q < wend; q += 64) {
+        const uint32_t nx = lower_bound(q);
+        tab[q - lo] = nx < n ? val[nx] : 0u;
     }
     (void)n_tiles;
 }
@@ -722,7 +886,7 @@ struct ChanState {
     unsigned int det_cnt;        // pending detections
     unsigned int rec_cnt;        // raw tag records written by the current call
     unsigned int overflow;
-    unsigned int pad;
+    unsigned int vis_cnt;        // candidates visited by the scan in the current call (k_tile_visit)
 };
 
 // The scan position after tile t is r_{t+1} = f_t(r_t) with f_t given by table row t; walking
@@ -806,17 +970,18 @@ __global__ __launch_bounds__(256) void k_scan_entries(ChanState* __restrict__ st
     }
 }
 
-// one wave per (tile, channel): redo the scan from the known entry and run the median test
-// of hpp:273-295 on every visited candidate.  zloc points at local position 0 of the
-// channel (and is readable T items before it).
-__global__ __launch_bounds__(64) void k_tile_detect(const unsigned long long* __restrict__ bitmap,
-                                                    size_t bm_stride, const float* __restrict__ zloc,
-                                                    size_t z_stride, unsigned long long A0,
-                                                    uint32_t cnt, uint32_t T, float power_threshold,
-                                                    uint32_t n_tiles, const int32_t* __restrict__ entry,
-                                                    ChanState* __restrict__ st,
-                                                    unsigned long long* __restrict__ det,
-                                                    uint32_t det_cap)
+// Two steps instead of one wave per tile doing scan + median tests serially (175 us per 2^26 items: every test
+// waited for the one before it):
+//   k_tile_visit    one wave per (tile, channel): redo the scan from the known entry on the bitmap alone and
+//                   append every visited candidate (the items whose history the reference tests, hpp:268-272)
+//                   to the channel's visit list
+//   k_median_tests  the tests of hpp:273-295 for all visited candidates of a call in parallel, one wave each:
+//                   2T + 1 powers read with all loads in flight, bandwidth- instead of latency-bound
+// zloc points at local position 0 of the channel (and is readable T items before it).
+__global__ __launch_bounds__(64) void k_tile_visit(const unsigned long long* __restrict__ bitmap, size_t bm_stride,
+                                                   uint32_t cnt, uint32_t T, uint32_t n_tiles,
+                                                   const int32_t* __restrict__ entry, ChanState* __restrict__ st,
+                                                   uint32_t* __restrict__ visit, uint32_t visit_cap)
 {
 #ifndef GR4PM_NO_SETPRIO
     __builtin_amdgcn_s_setprio(3); // latency-bound, few waves: win the issue arbitration against throughput kernels
@@ -826,19 +991,60 @@ __global__ __launch_bounds__(64) void k_tile_detect(const unsigned long long* __
     if (e < 0) return;
     const int lane = threadIdx.x;
     const unsigned long long* bm = bitmap + static_cast<size_t>(ch) * bm_stride;
-    const float* z = zloc + static_cast<size_t>(ch) * z_stride;
     const uint32_t lo = tile * kTileW;
     const uint32_t hi = min(lo + kTileW, cnt);
     uint32_t r = lo + static_cast<uint32_t>(e);
-    const uint32_t hist = 2 * T + 1;
+    TileBits tb;
+    tb.load(bm, lo, hi, lane);
+    // lane i keeps the i-th candidate of the current batch of 64; ONE atomic per batch reserves the slots
+    // (one returning atomic per candidate on the channel's single counter cost 0.5 ms per 2^26 items)
+    uint32_t mine = 0, have = 0;
+    auto flush = [&]() {
+        if (have == 0) return;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&st[ch].vis_cnt, have);
+        base = __shfl(base, 0);
+        if (static_cast<uint32_t>(lane) < have) {
+            if (base + lane < visit_cap) visit[static_cast<size_t>(ch) * visit_cap + base + lane] = mine;
+            else st[ch].overflow = 1;
+        }
+        have = 0;
+    };
     while (r < hi) {
-        const uint32_t p = next_candidate_wave(bm, r, hi, lane);
+        const uint32_t p = tb.next(r, hi, lane);
         if (p >= hi) break;
+        if (static_cast<uint32_t>(lane) == have) mine = p;
+        if (++have == 64) flush();
+        r = p + T + 1;
+    }
+    flush();
+}
+__global__ __launch_bounds__(64) void k_median_tests(const float* __restrict__ zloc, size_t z_stride,
+                                                     unsigned long long A0, uint32_t T, float power_threshold,
+                                                     ChanState* __restrict__ st, const uint32_t* __restrict__ visit,
+                                                     uint32_t visit_cap, unsigned long long* __restrict__ det,
+                                                     uint32_t det_cap)
+{
+    const uint32_t ch = blockIdx.y;
+    const int lane = threadIdx.x;
+    const float* z = zloc + static_cast<size_t>(ch) * z_stride;
+    const uint32_t n = min(st[ch].vis_cnt, visit_cap);
+    const uint32_t hist = 2 * T + 1;
+    for (uint32_t idx = blockIdx.x; idx < n; idx += gridDim.x) {
+        const uint32_t p = visit[static_cast<size_t>(ch) * visit_cap + idx];
         const float best = z[p];
         const float thr = best / power_threshold; // hpp:275
-        uint32_t below = 0;
         const long long base = static_cast<long long>(p) - static_cast<long long>(T);
-        for (uint32_t u = lane; u < hist; u += 64) below += z[base + u] < thr ? 1u : 0u;
+        uint32_t below = 0;
+        uint32_t u = lane;
+        for (; u + 7 * 64 < hist; u += 8 * 64) { // eight independent loads in flight per lane
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = z[base + u + 64 * k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) below += v[k] < thr ? 1u : 0u;
+        }
+        for (; u < hist; u += 64) below += z[base + u] < thr ? 1u : 0u;
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) below += __shfl_xor(below, d);
         if (2 * below >= hist && lane == 0) { // hpp:279
@@ -846,7 +1052,6 @@ __global__ __launch_bounds__(64) void k_tile_detect(const unsigned long long* __
             if (slot < det_cap) det[static_cast<size_t>(ch) * det_cap + slot] = A0 + p;
             else st[ch].overflow = 1;
         }
-        r = p + T + 1;
     }
 }
 
@@ -865,7 +1070,7 @@ __global__ __launch_bounds__(64) void k_tags(const cf* __restrict__ in, size_t i
                                              uint32_t hist, uint32_t stride_s, int n_bins,
                                              const float4* __restrict__ tmpl, const cf* __restrict__ tw1a,
                                              const cf* __restrict__ tw1b, const cf* __restrict__ twA,
-                                             const cf* __restrict__ twB,
+                                             const cf* __restrict__ twB, const cf* __restrict__ td, uint32_t td_len,
                                              const float* __restrict__ zcur, size_t z_stride,
                                              ChanState* __restrict__ st,
                                              const unsigned long long* __restrict__ det, uint32_t det_cap,
@@ -877,13 +1082,15 @@ __global__ __launch_bounds__(64) void k_tags(const cf* __restrict__ in, size_t i
     __shared__ cf lds[kExchangeItems];
     __shared__ cf zbin[kMaxBins];
     const uint32_t ch = blockIdx.y;
-    const uint32_t idx = blockIdx.x;
     const uint32_t n_det = min(st[ch].det_cnt, det_cap);
-    if (idx >= n_det) return;
+    const int lane = threadIdx.x;
+    // the grid strides over the pending detections (a launch of det_cap mostly empty workgroups cost more than
+    // the records themselves)
+    for (uint32_t idx = blockIdx.x; idx < n_det; idx += gridDim.x) {
     const unsigned long long pos = det[static_cast<size_t>(ch) * det_cap + idx];
     const unsigned long long c = pos + hist;
-    if (c < E0 || c >= E1) return;
-    const int lane = threadIdx.x;
+    if (c < E0 || c >= E1) continue;
+    wave_lds_sync();
     const unsigned long long blk = pos / stride_s;
     const uint32_t lag = static_cast<uint32_t>(pos - blk * stride_s);
     const long long o = static_cast<long long>(blk * stride_s) - static_cast<long long>(E0);
@@ -909,18 +1116,29 @@ __global__ __launch_bounds__(64) void k_tags(const cf* __restrict__ in, size_t i
     for (int d = 32; d > 0; d >>= 1) noise += __shfl_xor(noise, d);
     noise /= static_cast<float>(kFftN / 2) * static_cast<float>(kFftN);
 
-    const int kt = static_cast<int>((kFftN - lag) & (kFftN - 1)); // hpp:300
-    const int lane_t = kt & 63, j_t = ((kt >> 6) & 1) * 16 + (kt >> 7);
+    // The correlation at the ONE lag of the detection, for every bin, straight from its definition instead of
+    // n_bins more transforms: the value the reference reads at z_idx = (N - lag) mod N of FFT(X .* conj(FFT(s_b)))
+    // (hpp:246-252,300) is N * sum_n x[pos + n] conj(s_b[n]) over the L = (64 - 1) sps + ntaps template samples
+    // (no wrap: lag < S).  297 complex MACs per bin against 112 kFLOP per transform; accumulated in double
+    // (closer to the exact sum than either float FFT).  td: [bin][L] conj(s_b[n]), the float template of hpp:166-182.
+    (void)tmpl;
+    (void)twA;
+    (void)twB;
     for (int bin = 0; bin < n_bins; ++bin) {
-        wave_lds_sync();
-        cf c[32];
-        mul_template(lane, X, r, tmpl + static_cast<size_t>(bin) * 1024);
-        fft2_wave(lane, r, c, lds, twA, twB);
-        cf sel = mk(0.f, 0.f);
+        const cf* tb = td + static_cast<size_t>(bin) * td_len;
+        double ax = 0.0, ay = 0.0;
+        for (uint32_t n = lane; n < td_len; n += 64) {
+            const cf x = sample_at(cur, car, xc, o + static_cast<long long>(lag) + n);
+            const cf t = tb[n];
+            ax += static_cast<double>(x.x) * t.x - static_cast<double>(x.y) * t.y;
+            ay += static_cast<double>(x.x) * t.y + static_cast<double>(x.y) * t.x;
+        }
 #pragma unroll
-        for (int j = 0; j < 32; ++j)
-            if (j == j_t) sel = c[j];
-        if (lane == lane_t) zbin[bin] = sel;
+        for (int d = 32; d > 0; d >>= 1) {
+            ax += __shfl_xor(ax, d);
+            ay += __shfl_xor(ay, d);
+        }
+        if (lane == 0) zbin[bin] = mk(static_cast<float>(ax * kFftN), static_cast<float>(ay * kFftN));
     }
     wave_lds_sync();
     if (lane == 0) {
@@ -953,6 +1171,7 @@ __global__ __launch_bounds__(64) void k_tags(const cf* __restrict__ in, size_t i
         if (slot < rec_cap) rec[static_cast<size_t>(ch) * rec_cap + slot] = t;
         else st[ch].overflow = 1;
     }
+    } // detections of this workgroup
 }
 
 // =====================================================================================
@@ -1126,6 +1345,7 @@ __global__ __launch_bounds__(64) void k_compact_pending(ChanState* __restrict__ 
     if (lane == 0) {
         st[ch].det_cnt = w;
         st[ch].rec_cnt = 0; // the host copy of ChanState was written above
+        st[ch].vis_cnt = 0;
     }
 }
 
@@ -1216,6 +1436,7 @@ struct gr4pm_syncword_detection {
     // ([bin][16][64] float4), mid-stage twiddle table, lane constants
     int corr_kind = 0; // 0: k_correlate_w64 (default), 1: k_correlate (two exchanges), 2: k_correlate_pair
     DevBuf<float4> tmpl64, tT64, tC64;
+    DevBuf<cf> td; // [bin][L] conj of the float time-domain templates (hpp:166-182): k_tags' direct correlation
     DevBuf<cf> cc64;
     int n_cus = 256;
     int w64_variant = 0;
@@ -1244,6 +1465,8 @@ struct gr4pm_syncword_detection {
     DevBuf<int32_t> entry;
     DevBuf<ChanState> st;
     DevBuf<unsigned long long> det;
+    DevBuf<uint32_t> visit; // candidates visited by the scan of the current call, per channel
+    uint32_t visit_cap = 0;
     PinnedBuf<ChanState> st_host;
     PinnedBuf<RawTag> rec_host; // written by k_tags through the device-visible mapping
     // stream position
@@ -1577,6 +1800,7 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
     std::vector<float4> tmpl(h->generic ? 1 : static_cast<size_t>(n_bins) * 1024);
     std::vector<float4> tmplp(tmpl.size()), tmpl64(tmpl.size());
     std::vector<cf> g_tmpl(h->generic ? static_cast<size_t>(n_bins) * p->fft_size : 0);
+    std::vector<cf> td(static_cast<size_t>(n_bins) * L);
     for (int b = 0; b < n_bins; ++b) {
         const int freq_bin = p->min_freq_bin + b;
         double phase = 0.0;
@@ -1586,6 +1810,7 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
             const float c = static_cast<float>(std::cos(phase)), s = static_cast<float>(std::sin(phase));
             const float xr = sw[i].real(), xi = sw[i].imag();
             a[i] = { static_cast<double>(xr * c - xi * s), static_cast<double>(xr * s + xi * c) };
+            td[static_cast<size_t>(b) * L + i] = mk(xr * c - xi * s, -(xr * s + xi * c));
             phase += phase_incr;
             if (phase >= M_PI) { // hpp:177-181, including the `< pi` quirk
                 phase -= 2.0 * M_PI;
@@ -1696,6 +1921,7 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
     if (const char* e = getenv("GR4PM_TEST_SPIN_LIMIT")) h->spin_limit = atoi(e); // tests force a timeout with 0
     ok(h->tmpl64.alloc(tmpl64.size()));
     ok(h->tT64.alloc(tT64.size()));
+    ok(h->td.alloc(td.size()));
     ok(h->tC64.alloc(tC64.size()));
     ok(h->cc64.alloc(cc64.size()));
     ok(h->twp.alloc(twp.size()));
@@ -1729,6 +1955,8 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
     ok(h->gentry.alloc(static_cast<size_t>(h->max_groups) * h->n_channels));
     ok(h->st.alloc(h->n_channels));
     ok(h->det.alloc(static_cast<size_t>(h->det_cap) * h->n_channels));
+    h->visit_cap = static_cast<uint32_t>((h->max_items + h->T) / (h->T + 1) + h->max_tiles + 16);
+    ok(h->visit.alloc(static_cast<size_t>(h->visit_cap) * h->n_channels));
     ok(h->st_host.alloc(h->n_channels));
     ok(h->rec_host.alloc(static_cast<size_t>(h->rec_cap) * h->n_channels));
     if (s == GR4PM_OK && h->generic) s = h->g_tmpl.upload(g_tmpl.data(), g_tmpl.size(), h->stream);
@@ -1738,6 +1966,7 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
     if (s == GR4PM_OK) s = h->tmplp.upload(tmplp.data(), tmplp.size(), h->stream);
     if (s == GR4PM_OK && !h->generic) s = h->tmpl64.upload(tmpl64.data(), tmpl64.size(), h->stream);
     if (s == GR4PM_OK) s = h->tT64.upload(tT64.data(), tT64.size(), h->stream);
+    if (s == GR4PM_OK) s = h->td.upload(td.data(), td.size(), h->stream);
     if (s == GR4PM_OK) s = h->tC64.upload(tC64.data(), tC64.size(), h->stream);
     if (s == GR4PM_OK) s = h->cc64.upload(cc64.data(), cc64.size(), h->stream);
     if (s == GR4PM_OK) s = h->twp.upload(twp.data(), twp.size(), h->stream);
@@ -1869,9 +2098,13 @@ gr4pm_status gr4pm_syncword_detection_process(gr4pm_syncword_detection* h, const
         hipLaunchKernelGGL(k_scan_entries, dim3(nch), dim3(256), 0, s, h->st.p, static_cast<unsigned long long>(A0),
                            cnt, T, n_tiles, h->table[cur].p, h->table_stride, h->gtable[cur].p, h->gtable_stride,
                            h->gentry.p, n_groups, h->entry.p);
-        hipLaunchKernelGGL(k_tile_detect, dim3(n_tiles, nch), dim3(64), 0, s, h->bitmap[cur].p, h->bm_stride,
-                           zloc, h->z_stride, static_cast<unsigned long long>(A0), cnt, T,
-                           h->power_threshold, n_tiles, h->entry.p, h->st.p, h->det.p, h->det_cap);
+        hipLaunchKernelGGL(k_tile_visit, dim3(n_tiles, nch), dim3(64), 0, s, h->bitmap[cur].p, h->bm_stride, cnt, T,
+                           n_tiles, h->entry.p, h->st.p, h->visit.p, h->visit_cap);
+        // at most one visited candidate per T + 1 items (+ one per tile): the grid strides over the real count
+        const uint32_t n_med = std::min<uint32_t>(cnt / (T + 1) + n_tiles + 1, 16384u);
+        hipLaunchKernelGGL(k_median_tests, dim3(n_med, nch), dim3(64), 0, s, zloc, h->z_stride,
+                           static_cast<unsigned long long>(A0), T, h->power_threshold, h->st.p, h->visit.p,
+                           h->visit_cap, h->det.p, h->det_cap);
     }
     // tags leaving in this call
     if (h->generic) {
@@ -1884,14 +2117,14 @@ gr4pm_status gr4pm_syncword_detection_process(gr4pm_syncword_detection* h, const
                            h->g_tmpl.p, h->g_tw.p, zcur + h->zc, h->z_stride, h->st.p, h->det.p, h->det_cap,
                            h->rec_host.p, h->rec_cap);
     } else
-    hipLaunchKernelGGL(k_tags, dim3(h->det_cap, nch), dim3(64), 0, s,
+    hipLaunchKernelGGL(k_tags, dim3(std::min<uint32_t>(h->det_cap, 4096u), nch), dim3(64), 0, s,
                        reinterpret_cast<const cf*>(in),
                        in_stride, carry, static_cast<size_t>(h->xc), h->xc,
                        static_cast<unsigned long long>(E0), static_cast<unsigned long long>(E1),
                        static_cast<uint32_t>(h->hist), static_cast<uint32_t>(h->S), h->n_bins, h->tmpl.p,
                        h->tw.p, h->tw.p + kTw1aItems, h->tw.p + kTw1aItems + kTw1bItems,
-                       h->tw.p + kTw1aItems + kTw1bItems + kTwAItems, zcur + h->zc, h->z_stride, h->st.p,
-                       h->det.p, h->det_cap, h->rec_host.p, h->rec_cap);
+                       h->tw.p + kTw1aItems + kTw1bItems + kTwAItems, h->td.p, static_cast<uint32_t>(h->L),
+                       zcur + h->zc, h->z_stride, h->st.p, h->det.p, h->det_cap, h->rec_host.p, h->rec_cap);
     hipLaunchKernelGGL(k_compact_pending, dim3(nch), dim3(64), 0, s, h->st.p, h->st_host.p, h->det.p,
                        h->det_cap, static_cast<unsigned long long>(E1), static_cast<uint32_t>(h->hist),
                        static_cast<int>(nch));
