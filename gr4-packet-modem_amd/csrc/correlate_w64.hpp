@@ -62,47 +62,6 @@ __device__ __forceinline__ void w64_store(const cf* r, uint32_t base)
 }
 #undef GR4PM_ADDTID4
 
-// rows k and k + 16 of the exchange, issued from inside the last stage of pass A (M0 already holds the
-// buffer address: w64_store_begin)
-__device__ __forceinline__ void w64_store_begin(uint32_t base)
-{
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(base) : "memory");
-}
-template <int K>
-__device__ __forceinline__ void w64_store_pair(const cf* r)
-{
-    asm volatile("ds_write_addtid_b32 %0 offset:%c4\n\tds_write_addtid_b32 %1 offset:%c5\n\t"
-                 "ds_write_addtid_b32 %2 offset:%c6\n\tds_write_addtid_b32 %3 offset:%c7"
-                 :
-                 : "v"(r[K].x), "v"(r[K].y), "v"(r[K + 16].x), "v"(r[K + 16].y), "i"(K * kW64Row * 4),
-                   "i"(K * kW64Row * 4 + 256), "i"((K + 16) * kW64Row * 4), "i"((K + 16) * kW64Row * 4 + 256)
-                 : "memory");
-}
-struct W64StoreHook {
-    const cf* r;
-    __device__ __forceinline__ void operator()(int k) const
-    {
-        switch (k) { // k is a compile-time constant after unrolling
-        case 0: w64_store_pair<0>(r); break;
-        case 1: w64_store_pair<1>(r); break;
-        case 2: w64_store_pair<2>(r); break;
-        case 3: w64_store_pair<3>(r); break;
-        case 4: w64_store_pair<4>(r); break;
-        case 5: w64_store_pair<5>(r); break;
-        case 6: w64_store_pair<6>(r); break;
-        case 7: w64_store_pair<7>(r); break;
-        case 8: w64_store_pair<8>(r); break;
-        case 9: w64_store_pair<9>(r); break;
-        case 10: w64_store_pair<10>(r); break;
-        case 11: w64_store_pair<11>(r); break;
-        case 12: w64_store_pair<12>(r); break;
-        case 13: w64_store_pair<13>(r); break;
-        case 14: w64_store_pair<14>(r); break;
-        default: w64_store_pair<15>(r); break;
-        }
-    }
-};
-
 // 16 KiB template, global -> this wave's exchange buffer, linear ([u][lane] float4), by the
 // LDS-DMA path: 16 pieces of 1 KiB, LDS address of a piece = M0 + 16 * lane.  All LDS reads of
 // the wave have returned before the first piece is issued (s_waitcnt lgkmcnt(0)): the DMA is
@@ -193,46 +152,19 @@ __device__ __forceinline__ void w64_mid_dev(int lane, const float4* row, const f
     }
 }
 
-// ---- interleaved layout (VAR bit 8 = 256): ds_write_b64 stores, cmul-based mid stage
-__device__ __forceinline__ void w64c_store(const cf* r, cf* xbc, int lane)
-{
-#pragma unroll
-    for (int k1 = 0; k1 < 32; ++k1) xbc[k1 * (kW64Row / 2) + lane] = r[k1];
-    asm volatile("" ::: "memory");
-}
-// u = a0 + c a1 (two packed FMAs), b = T u (cmul)
-__device__ __forceinline__ cf w64c_mid1_dev(cf a0, cf a1, cf t, cf c)
-{
-    cf s, u;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(s) : "v"(a1), "v"(c), "v"(a0));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(u) : "v"(a1), "v"(c), "v"(s));
-    return cmul(u, t);
-}
-template <int DEPTH>
-__device__ __forceinline__ void w64c_mid_dev(int lane, const float4* row, const float4* tC, cf c, cf* b)
-{
-    float4 q[DEPTH + 1][3];
-    auto issue = [&](int i) {
-        float4* d = q[i % (DEPTH + 1)];
-        d[0] = row[i], d[1] = row[16 + i], d[2] = tC[i * 64 + lane];
-    };
-#pragma unroll
-    for (int i = 0; i < DEPTH; ++i) issue(i);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        if (i + DEPTH < 16) issue(i + DEPTH);
-        const float4* s = q[i % (DEPTH + 1)];
-        b[2 * i] = w64c_mid1_dev(mk(s[0].x, s[0].y), mk(s[1].x, s[1].y), mk(s[2].x, s[2].y), c);
-        b[2 * i + 1] = w64c_mid1_dev(mk(s[0].z, s[0].w), mk(s[1].z, s[1].w), mk(s[2].z, s[2].w), c);
-        if (i & 1) w64_pin4(b + 2 * i - 2);
-    }
-}
-
 // tmpl: [bin][u = 16][lane = 64] float4 = (T[lane + 128 u], T[lane + 128 u + 64]) (conjugated
 // template spectra, hpp:166-189); tT / cc: build_w64_tables.  total = n_channels * n_blocks items.
-// VAR: tuning / ablation variants selected at run time (GR4PM_W64_VARIANT): bit 0 = mid-stage reads three
-// groups ahead instead of two, bit 1 = all sixteen template reads issued up front, bit 2 = waves 4-7 start
-// half a transform late, bit 4 (16) = packed mid stage; 8 = timing-only ablation without the template DMA (wrong results)
+//
+// Measured, not adopted (tools/w64_variants.py, MI355X, 2^26 samples): the samples of the next block requested a
+// whole block ahead into a register set of their own when n_bins == 1 (0.232 against 0.227 ms: a block's fixed
+// cost is its two transforms, not HBM latency -- without any sample load or power store the one-bin launch still
+// takes 0.176 ms); waves started at 8 .. 64 different offsets so that they do not ask HBM for their next block at
+// the same moment (0.846 .. 0.884 against 0.831 ms at nine bins: they are not in step to begin with); exchange stores
+// issued from inside the last stage of pass A (no change); (re, im) interleaved exchange rows written with
+// ds_write_b64 (0.82 against 0.78 ms); mid-stage and template reads further ahead (no change).
+// Timing-only ablations (wrong results; tools/w64_variants.py): 8 no template DMA, 32 no
+// exchange stores, 64 no exchange / twiddle reads, 128 no template reads, 1024 no power / maximum, 2048 no power
+// stores, 4096 no sample loads after the first block.
 template <int VAR>
 __global__ __launch_bounds__(kW64Threads, 2) void k_correlate_w64(const cf* __restrict__ in, size_t in_stride,
                                                                   uint32_t n_blocks, uint32_t total,
@@ -253,27 +185,32 @@ __global__ __launch_bounds__(kW64Threads, 2) void k_correlate_w64(const cf* __re
     const uint32_t base = __builtin_amdgcn_readfirstlane(
         static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)xb4)));
     const float4* row = xb4 + (lane & 31) * (kW64Row / 4);
-    cf* xbc = reinterpret_cast<cf*>(xb4);
-    constexpr bool kC = (VAR & 256) != 0; // interleaved exchange layout (tT then holds build_w64_tables_c's table)
     const float4* ldsT = lds4;
     const cf c = cc[lane];
     const uint32_t voff = static_cast<uint32_t>(lane) * 16u;
     const uint32_t n_waves = gridDim.x * kW64Waves;
     uint32_t item = blockIdx.x * kW64Waves + wave;
     if (item >= total) return;
-    constexpr int kMidDepth = (VAR & 1) ? 2 : 1;
-    if ((VAR & 4) && wave >= 4) {
+
+    auto load_block = [&](cf* dst, uint32_t it) {
+        const uint32_t ch = it / n_blocks, b = it - ch * n_blocks;
+        int ln = lane;
+        asm volatile("" : "+v"(ln)); // addresses are formed here, not hoisted out of the block loop
+        const cf* x = in + static_cast<size_t>(ch) * in_stride + static_cast<size_t>(b) * stride_s + ln;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) __builtin_amdgcn_s_sleep(8); // ~2500 cycles: half a transform
-    }
+        for (int j = 0; j < 32; ++j) dst[j] = x[64 * j];
+    };
+    auto exchange = [&](const cf* r, cf* bq) { // pass-A output -> pass-B input
+        if (!(VAR & 32)) w64_store(r, base);
+        if (VAR & 32) { // ablation: the stores are gone, pass A stays alive
+#pragma unroll
+            for (int j = 0; j < 32; ++j) asm volatile("" ::"v"(r[j]));
+        }
+        w64_mid_dev<1, true, (VAR & 64) != 0>(lane, row, ldsT, c, bq);
+    };
 
     cf X[32];
-    {
-        const uint32_t ch = item / n_blocks, b = item - ch * n_blocks;
-        const cf* x = in + static_cast<size_t>(ch) * in_stride + static_cast<size_t>(b) * stride_s + lane;
-#pragma unroll
-        for (int j = 0; j < 32; ++j) X[j] = x[64 * j];
-    }
+    load_block(X, item);
     for (;;) {
         const uint32_t ch = item / n_blocks, blk = item - ch * n_blocks;
         float* zo = zpow + static_cast<size_t>(ch) * z_stride + static_cast<size_t>(blk) * stride_s;
@@ -283,13 +220,7 @@ __global__ __launch_bounds__(kW64Threads, 2) void k_correlate_w64(const cf* __re
         {
             cf bq[32];
             dft32(X);
-            if (kC) {
-                w64c_store(X, xbc, lane);
-                w64c_mid_dev<2 * kMidDepth>(lane, row, ldsT, c, bq);
-            } else {
-                if (!(VAR & 32)) w64_store(X, base);
-                w64_mid_dev<kMidDepth, (VAR & 16) != 0, (VAR & 64) != 0>(lane, row, ldsT, c, bq);
-            }
+            exchange(X, bq);
             if (!(VAR & 8)) w64_dma_template(tmpl, base, voff); // template 0 while pass B runs
             dft32(bq);
 #pragma unroll
@@ -312,54 +243,36 @@ __global__ __launch_bounds__(kW64Threads, 2) void k_correlate_w64(const cf* __re
                 }
                 p[2 * u] = cmul(X[2 * u], mk(t.x, t.y));
                 p[2 * u + 1] = cmul(X[2 * u + 1], mk(t.z, t.w));
-                if (!(VAR & 2) && (u & 1) == 1 && u >= 3) w64_pin4(p + 2 * u - 6); // at most four template reads ahead of their use
+                if ((u & 1) == 1 && u >= 3) w64_pin4(p + 2 * u - 6); // at most four template reads ahead of their use
             }
-#if !defined(GR4PM_W64_NOPREFETCH)
-            if (bin == n_bins - 1 && has_next) {
+            if (!(VAR & 4096) && bin == n_bins - 1 && has_next) {
                 // the spectrum is dead: its registers take the samples of this wave's next block,
                 // which arrive while the last transform of this one runs
-                const uint32_t nch = next / n_blocks, nb = next - nch * n_blocks;
-                int ln = lane;
-                asm volatile("" : "+v"(ln)); // addresses are formed here, not hoisted out of the block loop
-                const cf* x = in + static_cast<size_t>(nch) * in_stride + static_cast<size_t>(nb) * stride_s + ln;
-#pragma unroll
-                for (int j = 0; j < 32; ++j) X[j] = x[64 * j];
+                load_block(X, next);
             }
-#endif
-            if (VAR & 512) { // stores issued from inside the last stage of the transform
-                w64_store_begin(base);
-                dft32(p, W64StoreHook{ p });
-            } else {
-                dft32(p); // hpp:250-251
-            }
-            if (kC) {
-                w64c_store(p, xbc, lane);
-                w64c_mid_dev<2 * kMidDepth>(lane, row, ldsT, c, bq);
-            } else {
-                if (!(VAR & (32 | 512))) w64_store(p, base);
-                if (VAR & 32) { // timing-only ablation: no exchange stores, but pass A stays alive
-#pragma unroll
-                    for (int j = 0; j < 32; ++j) asm volatile("" ::"v"(p[j]));
-                }
-                w64_mid_dev<kMidDepth, (VAR & 16) != 0, (VAR & 64) != 0>(lane, row, ldsT, c, bq);
-            }
+            dft32(p); // hpp:250-251
+            exchange(p, bq);
             if (!(VAR & 8) && bin + 1 < n_bins) w64_dma_template(tmpl + static_cast<size_t>(bin + 1) * 1024, base, voff);
             dft32(bq);
-            if (VAR & 1024) { // timing-only ablation: no power / maximum
+            if (VAR & 1024) { // ablation: no power / maximum
 #pragma unroll
                 for (int j = 0; j < 32; ++j) asm volatile("" ::"v"(bq[j]));
-            } else
+            } else {
 #pragma unroll
-            for (int j = 0; j < 32; ++j) {
-                // hpp:307-308: the best bin's power (max() == the strict-> scan for the VALUE)
-                const float pw = fmaf(bq[j].y, bq[j].y, bq[j].x * bq[j].x);
-                asm("v_max_f32 %0, %1, %2" : "=v"(zmax[j]) : "v"(zmax[j]), "v"(pw));
+                for (int j = 0; j < 32; ++j) {
+                    // hpp:307-308: the best bin's power (max() == the strict-> scan for the VALUE)
+                    const float pw = fmaf(bq[j].y, bq[j].y, bq[j].x * bq[j].x);
+                    asm("v_max_f32 %0, %1, %2" : "=v"(zmax[j]) : "v"(zmax[j]), "v"(pw));
+                }
             }
         }
         // lag k <-> correlation index (N - k) mod N (hpp:300); register j of lane l holds index l + 64 j
-        {
+        if (VAR & 2048) { // ablation: no power stores
+#pragma unroll
+            for (int j = 0; j < 32; ++j) asm volatile("" ::"v"(zmax[j]));
+        } else {
             int ln = lane;
-            asm volatile("" : "+v"(ln)); // as above: no 32 hoisted lag registers
+            asm volatile("" : "+v"(ln)); // no 32 hoisted lag registers
             float* zl = zo + (kFftN - ln); // lag of register j: 2048 - lane - 64 j (j = 0, lane = 0: lag 0)
 #pragma unroll
             for (int j = 0; j < 32; ++j) {

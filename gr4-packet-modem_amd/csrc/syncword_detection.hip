@@ -1435,11 +1435,11 @@ struct gr4pm_syncword_detection {
     // the one-exchange correlator (fft2048_w64.hpp, k_correlate_w64): templates in its lane order
     // ([bin][16][64] float4), mid-stage twiddle table, lane constants
     int corr_kind = 0; // 0: k_correlate_w64 (default), 1: k_correlate (two exchanges), 2: k_correlate_pair
-    DevBuf<float4> tmpl64, tT64, tC64;
+    DevBuf<float4> tmpl64, tT64;
     DevBuf<cf> td; // [bin][L] conj of the float time-domain templates (hpp:166-182): k_tags' direct correlation
     DevBuf<cf> cc64;
     int n_cus = 256;
-    int w64_variant = 0;
+    int w64_variant = -1;
     // raised by a correlator kernel whose bounded hand-off spin ran out ("wave" / "pair" kernels; k_correlate_w64
     // has no spins); checked after the stream synchronisation of process()
     PinnedBuf<unsigned> fault;
@@ -1604,26 +1604,17 @@ gr4pm_status launch_correlate(gr4pm_syncword_detection* h, hipStream_t stream, c
         const uint32_t wgs = std::min<uint32_t>(static_cast<uint32_t>(h->n_cus), (total + kW64Waves - 1) / kW64Waves);
 #define GR4PM_W64_LAUNCH(V)                                                                                         \
     hipLaunchKernelGGL(k_correlate_w64<V>, dim3(wgs), dim3(kW64Threads), 0, stream, reinterpret_cast<const cf*>(in), \
-                       in_stride, n_blocks, total, static_cast<uint32_t>(h->S), h->n_bins, h->tmpl64.p,             \
-                       ((V) & 256) ? h->tC64.p : h->tT64.p,                                                         \
+                       in_stride, n_blocks, total, static_cast<uint32_t>(h->S), h->n_bins, h->tmpl64.p, h->tT64.p,  \
                        h->cc64.p, zout, h->z_stride)
+        // GR4PM_W64_VARIANT: the timing-only ablations of tools/w64_variants.py
         switch (h->w64_variant) {
-        case 1: GR4PM_W64_LAUNCH(1); break;
-        case 2: GR4PM_W64_LAUNCH(2); break;
-        case 3: GR4PM_W64_LAUNCH(3); break;
-        case 4: GR4PM_W64_LAUNCH(4); break;
-        case 7: GR4PM_W64_LAUNCH(7); break;
         case 8: GR4PM_W64_LAUNCH(8); break;
-        case 16: GR4PM_W64_LAUNCH(16); break;
         case 32: GR4PM_W64_LAUNCH(32); break;
-        case 64: GR4PM_W64_LAUNCH(64); break;
-        case 128: GR4PM_W64_LAUNCH(128); break;
         case 232: GR4PM_W64_LAUNCH(232); break;
-        case 256: GR4PM_W64_LAUNCH(256); break;
-        case 257: GR4PM_W64_LAUNCH(257); break;
-        case 512: GR4PM_W64_LAUNCH(512); break;
-        case 248: GR4PM_W64_LAUNCH(248); break;
         case 1256: GR4PM_W64_LAUNCH(1256); break;
+        case 2048: GR4PM_W64_LAUNCH(2048); break;
+        case 4096: GR4PM_W64_LAUNCH(4096); break;
+        case 6144: GR4PM_W64_LAUNCH(6144); break;
         default: GR4PM_W64_LAUNCH(0); break;
         }
 #undef GR4PM_W64_LAUNCH
@@ -1875,13 +1866,6 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
             return mk(static_cast<float>(std::cos(ang)), static_cast<float>(std::sin(ang)));
         },
         tT64.data(), cc64.data());
-    std::vector<float4> tC64(kW64TwFloat4);
-    build_w64_tables_c(
-        [](int k) {
-            const double ang = -2.0 * M_PI * k / kFftN;
-            return mk(static_cast<float>(std::cos(ang)), static_cast<float>(std::sin(ang)));
-        },
-        tC64.data());
     {
         // which correlator kernel runs: "w64" (default: one LDS exchange per transform), "wave" (round 1: two
         // exchanges; bit-identical to "pair", two waves per block)
@@ -1890,7 +1874,7 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
         h->use_pair = !h->generic && k == "pair";
         h->corr_kind = k == "pair" ? 2 : k == "wave" ? 1 : 0;
         const char* v = getenv("GR4PM_W64_VARIANT");
-        h->w64_variant = v ? atoi(v) : 16; // 16: packed mid stage (the fastest measured, tools/w64_variants.py)
+        h->w64_variant = v ? atoi(v) : -1;
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
@@ -1922,7 +1906,6 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
     ok(h->tmpl64.alloc(tmpl64.size()));
     ok(h->tT64.alloc(tT64.size()));
     ok(h->td.alloc(td.size()));
-    ok(h->tC64.alloc(tC64.size()));
     ok(h->cc64.alloc(cc64.size()));
     ok(h->twp.alloc(twp.size()));
     std::vector<cf> g_tw(h->generic ? p->fft_size / 2 : 0);
@@ -1967,7 +1950,6 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
     if (s == GR4PM_OK && !h->generic) s = h->tmpl64.upload(tmpl64.data(), tmpl64.size(), h->stream);
     if (s == GR4PM_OK) s = h->tT64.upload(tT64.data(), tT64.size(), h->stream);
     if (s == GR4PM_OK) s = h->td.upload(td.data(), td.size(), h->stream);
-    if (s == GR4PM_OK) s = h->tC64.upload(tC64.data(), tC64.size(), h->stream);
     if (s == GR4PM_OK) s = h->cc64.upload(cc64.data(), cc64.size(), h->stream);
     if (s == GR4PM_OK) s = h->twp.upload(twp.data(), twp.size(), h->stream);
     if (s == GR4PM_OK && hipStreamSynchronize(h->stream) != hipSuccess) s = GR4PM_ERR_HIP;

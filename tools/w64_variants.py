@@ -11,7 +11,7 @@ pkg = ge.load_package()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 26
 bins = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 5
-variants = sys.argv[4].split(",") if len(sys.argv) > 4 else ["wave", "0", "1", "2", "3", "4", "7", "8"]
+variants = sys.argv[4].split(",") if len(sys.argv) > 4 else ["wave", "0", "8", "32", "232", "1256", "2048", "4096", "6144"]
 rrc = bench.unit_norm_rrc(pkg)
 x, _ = bench.burst_stream(pkg, n, rrc, 1, torch.device("cuda"))
 bpsk = np.array([1, -1], dtype=np.complex64)
