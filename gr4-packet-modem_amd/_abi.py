@@ -218,7 +218,8 @@ EXPORTS = [
     "gr4pm_mapper_process", "gr4pm_burst_shaper_process",
     "gr4pm_packet_receiver_create", "gr4pm_packet_receiver_destroy", "gr4pm_packet_receiver_submit", "gr4pm_packet_receiver_announce",
     "gr4pm_multichannel_receiver_create", "gr4pm_multichannel_receiver_destroy", "gr4pm_multichannel_receiver_announce",
-    "gr4pm_multichannel_receiver_process",
+    "gr4pm_multichannel_receiver_process", "gr4pm_multichannel_receiver_submit", "gr4pm_multichannel_receiver_collect",
+    "gr4pm_multichannel_receiver_in_flight",
     "gr4pm_packet_receiver_collect", "gr4pm_packet_receiver_inflight",
 ]
 
@@ -363,6 +364,9 @@ def lib():
     L.gr4pm_multichannel_receiver_destroy.restype = None
     L.gr4pm_multichannel_receiver_announce.argtypes = [vp, vp, sz, sz]
     L.gr4pm_multichannel_receiver_process.argtypes = [vp, vp, sz, sz, C.c_uint64, vp, sz, szp, szp, vp, szp, vp, szp]
+    L.gr4pm_multichannel_receiver_submit.argtypes = [vp, vp, sz, sz, C.c_uint64, vp, sz, szp]
+    L.gr4pm_multichannel_receiver_collect.argtypes = [vp, szp, szp, vp, szp, vp, szp]
+    L.gr4pm_multichannel_receiver_in_flight.argtypes = [vp]
     L.gr4pm_packet_receiver_collect.argtypes = [vp, C.POINTER(PacketReceiverResult)]
     L.gr4pm_packet_receiver_inflight.argtypes = [vp]
     L.gr4pm_packet_receiver_inflight.restype = sz

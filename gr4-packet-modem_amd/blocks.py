@@ -1463,6 +1463,7 @@ class NativeMultiChannelReceiver:
                                             {"PILOT": 0, "BPSK": 1, "QPSK": 2}[costas_constellation], max_items,
                                             self.tags_cap, workers)
         self._h = C.c_void_p()
+        self._pending = []
         check(lib().gr4pm_multichannel_receiver_create(C.byref(p), C.byref(self._h)), "MultiChannelReceiver")
 
     def announce(self, x):
@@ -1470,6 +1471,37 @@ class NativeMultiChannelReceiver:
         assert x.dim() == 2 and x.shape[0] == self.n_channels
         check(lib().gr4pm_multichannel_receiver_announce(self._h, x.data_ptr(), x.stride(0), x.shape[1]),
               "MultiChannelReceiver.announce")
+
+    def submit(self, x, packet_length=None):
+        """pipelined form: returns the items consumed per channel as soon as the detector has taken the batch;
+        the stages behind it keep working on up to four batches.  Results come from collect(), in order."""
+        torch = _torch()
+        x = _dev_c64(x)
+        assert x.dim() == 2 and x.shape[0] == self.n_channels
+        Cn, n = self.n_channels, x.shape[1]
+        stride = n // self.samples_per_symbol + self.tags_cap + 64
+        sym = torch.empty((Cn, stride), dtype=torch.complex64, device=x.device)
+        consumed = C.c_size_t(0)
+        check(lib().gr4pm_multichannel_receiver_submit(
+            self._h, x.data_ptr(), x.stride(0), n, 0 if packet_length is None else int(packet_length),
+            sym.data_ptr(), stride, C.byref(consumed)), "MultiChannelReceiver.submit")
+        self._pending.append((sym, x))  # keep the buffers alive until collected
+        return consumed.value
+
+    def in_flight(self):
+        return int(lib().gr4pm_multichannel_receiver_in_flight(self._h))
+
+    def collect(self):
+        Cn = self.n_channels
+        sym, _x = self._pending.pop(0)
+        consumed = C.c_size_t(0)
+        n_sym, n_tags, n_det = (C.c_size_t * Cn)(), (C.c_size_t * Cn)(), (C.c_size_t * Cn)()
+        tags = np.zeros((Cn, self.tags_cap), dtype=TAG_DTYPE)
+        det = np.zeros((Cn, self.tags_cap), dtype=TAG_DTYPE)
+        check(lib().gr4pm_multichannel_receiver_collect(self._h, C.byref(consumed), n_sym, _np_ptr(tags), n_tags,
+                                                        _np_ptr(det), n_det), "MultiChannelReceiver.collect")
+        return [{"status": 0, "consumed": consumed.value, "symbols": sym[c, : n_sym[c]],
+                 "tags": tags[c, : n_tags[c]].copy(), "detector_tags": det[c, : n_det[c]].copy()} for c in range(Cn)]
 
     def process_bulk(self, x, packet_length=None):
         torch = _torch()

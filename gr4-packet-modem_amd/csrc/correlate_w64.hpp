@@ -172,7 +172,8 @@ __global__ __launch_bounds__(kW64Threads, 2) void k_correlate_w64(const cf* __re
                                                                   const float4* __restrict__ tmpl,
                                                                   const float4* __restrict__ tT,
                                                                   const cf* __restrict__ cc,
-                                                                  float* __restrict__ zpow, size_t z_stride)
+                                                                  float* __restrict__ zpow, size_t z_stride,
+                                                                  uint32_t blocks_per_wave)
 {
     __shared__ float4 lds4[kW64LdsF4];
     const int tid = threadIdx.x;
@@ -188,9 +189,14 @@ __global__ __launch_bounds__(kW64Threads, 2) void k_correlate_w64(const cf* __re
     const float4* ldsT = lds4;
     const cf c = cc[lane];
     const uint32_t voff = static_cast<uint32_t>(lane) * 16u;
-    const uint32_t n_waves = gridDim.x * kW64Waves;
-    uint32_t item = blockIdx.x * kW64Waves + wave;
-    if (item >= total) return;
+    // blocks_per_wave == 0: persistent waves, wave w of the grid walks items w, w + W, w + 2W, ... (a stand-alone
+    // launch).  blocks_per_wave == K: a workgroup owns 8 K consecutive items and retires after them, so that the
+    // dispatcher can place the workgroups of other streams' kernels on the CU in between (a pipelined receiver:
+    // a persistent launch keeps every CU's LDS for its whole duration and everything else waits for it).
+    const uint32_t n_waves = blocks_per_wave ? kW64Waves : gridDim.x * kW64Waves;
+    uint32_t item = blocks_per_wave ? blockIdx.x * kW64Waves * blocks_per_wave + wave : blockIdx.x * kW64Waves + wave;
+    const uint32_t item_end = blocks_per_wave ? min(total, (blockIdx.x + 1) * kW64Waves * blocks_per_wave) : total;
+    if (item >= item_end) return;
 
     auto load_block = [&](cf* dst, uint32_t it) {
         const uint32_t ch = it / n_blocks, b = it - ch * n_blocks;
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(kW64Threads, 2) void k_correlate_w64(const cf* __re
         const uint32_t ch = item / n_blocks, blk = item - ch * n_blocks;
         float* zo = zpow + static_cast<size_t>(ch) * z_stride + static_cast<size_t>(blk) * stride_s;
         const uint32_t next = item + n_waves;
-        const bool has_next = next < total;
+        const bool has_next = next < item_end;
         // ---- forward transform of the block (hpp:239-241)
         {
             cf bq[32];

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -26,70 +27,118 @@
 
 using namespace gr4pm;
 
+// Batches in flight: the detector of batch n + 2 (caller's thread), the tag gates + CFC plan of batch n + 1
+// (stage 1), the symbol filters of batch n + 1 / n (stage 2 and its workers) and the Costas loop of batch n
+// (stage 3) run at the same time; the two serial kernels (phasor checkpoints, PLL), whose time is that of the
+// longest segment of the batch, overlap the correlator of the next batches.
+constexpr int kMcSlots = 4;
+
 struct gr4pm_multichannel_receiver {
     gr4pm_multichannel_receiver_params p{};
     gr4pm_syncword_detection* sd = nullptr;
     hipStream_t sd_stream = nullptr;
-    struct Chain {
+    struct Chain { // per-channel blocks (their state carries from batch to batch)
         gr4pm_syncword_detection_filter* sdf = nullptr;
         gr4pm_symbol_filter* symf = nullptr;
         gr4pm_syncword_wipeoff* wipe = nullptr;
-        std::vector<gr4pm_tag> tags, sym_tags;
-        size_t n_acc = 0, n_sym_tags = 0, produced = 0;
         std::vector<uint64_t> idx;
         std::vector<gr4pm_header_msg> msgs;
         std::vector<uint8_t> accepted;
     };
     std::unique_ptr<Chain[]> chains; // [n_channels] (DevBuf members: neither copied nor moved)
-    gr4pm_rotator* cfc = nullptr;      // n_channels channels
+    gr4pm_rotator* cfc = nullptr;        // n_channels channels
     gr4pm_costas_loop* costas = nullptr; // n_channels channels
-    hipStream_t batch_stream = nullptr;  // the two batched handles
-    int plan = -1;
-    DevBuf<gr4pm_c64> symall;            // symbol filter outputs, [n_channels][out_stride]
-    std::vector<gr4pm_tag> all_tags;     // accepted tags / symbol tags of all channels, concatenated
-    std::vector<uint32_t> all_channel;
-    std::vector<size_t> produced;
+    hipStream_t batch_stream = nullptr, costas_stream = nullptr;
     std::vector<hipStream_t> streams; // one per worker
-    DevBuf<gr4pm_c64> y;              // SyncwordDetection's delayed output, [n_channels][y_stride]
     size_t y_stride = 0;
-    std::vector<gr4pm_tag> det_tags;  // [n_channels][tags_cap]
-    std::vector<size_t> n_det;
-    // one job = one process() call, fanned out to the workers
-    struct Job {
-        size_t consumed = 0;
+    struct ChanBatch { // what one batch holds per channel
+        std::vector<gr4pm_tag> tags, sym_tags; // accepted detector tags, re-timed symbol tags
+        size_t n_acc = 0, n_sym_tags = 0, produced = 0;
+    };
+    struct Slot { // one batch
+        DevBuf<gr4pm_c64> y;      // SyncwordDetection's delayed output, [n_channels][y_stride]
+        DevBuf<gr4pm_c64> symall; // symbol filter outputs, [n_channels][out_stride]
+        std::vector<gr4pm_tag> det_tags; // [n_channels][tags_cap]
+        std::vector<size_t> n_det;
+        std::vector<ChanBatch> ch;
+        std::vector<gr4pm_tag> all_tags;
+        std::vector<uint32_t> all_channel;
+        std::vector<size_t> produced;
+        int plan = -1;
+        size_t consumed = 0, out_stride = 0;
         uint64_t base = 0, packet_length = 0;
         gr4pm_c64* out_symbols = nullptr;
-        size_t out_stride = 0;
-        size_t* n_symbols = nullptr;
-        gr4pm_tag* tags = nullptr;
-        size_t* n_tags = nullptr;
-    } job;
+        gr4pm_status status = GR4PM_OK;
+        char error[256] = { 0 };
+        std::chrono::steady_clock::time_point t_submit, t_done;
+    } slots[kMcSlots];
+    // slot indices travel through the stages in submission order
+    struct Queue {
+        std::mutex m;
+        std::condition_variable cv;
+        std::deque<int> q;
+        bool quit = false;
+        void push(int v)
+        {
+            {
+                std::lock_guard<std::mutex> l(m);
+                q.push_back(v);
+            }
+            cv.notify_all();
+        }
+        int pop() // -1 on shutdown
+        {
+            std::unique_lock<std::mutex> l(m);
+            cv.wait(l, [&] { return quit || !q.empty(); });
+            if (q.empty()) return -1;
+            const int v = q.front();
+            q.pop_front();
+            return v;
+        }
+        void stop()
+        {
+            {
+                std::lock_guard<std::mutex> l(m);
+                quit = true;
+            }
+            cv.notify_all();
+        }
+    } to_stage1, to_stage2, to_stage3, done;
+    std::thread t_stage1, t_stage2, t_stage3;
+    int next_slot = 0, inflight = 0;
+    // stage 2 fans a batch out to the workers
+    Slot* cur = nullptr;
     std::vector<std::thread> workers;
     std::mutex m;
     std::condition_variable cv_go, cv_done;
     uint64_t generation = 0;
     unsigned pending = 0;
     bool quit = false;
-    gr4pm_status status = GR4PM_OK;
-    char error[256] = { 0 };
+    gr4pm_status wstatus = GR4PM_OK;
+    char werror[256] = { 0 };
 
-    gr4pm_status run_channel(size_t c);
+    gr4pm_status run_channel(Slot& s, size_t c);
     void worker(unsigned w);
+    gr4pm_status stage1(Slot& s);
+    gr4pm_status stage2(Slot& s);
+    gr4pm_status stage3(Slot& s);
+    void stage_loop(int which);
 };
 
-gr4pm_status gr4pm_multichannel_receiver::run_channel(size_t c)
+gr4pm_status gr4pm_multichannel_receiver::run_channel(Slot& s, size_t c)
 {
     Chain& ch = chains[c];
-    const size_t cap = job.out_stride;
+    ChanBatch& cb = s.ch[c];
+    const size_t cap = s.out_stride;
     size_t n_out_tags = 0, consumed = 0, produced_c = 0;
-    GR4PM_TRY(gr4pm_cfc_symbol_filter_run_channel(cfc, plan, c, ch.symf, y.p + c * y_stride, job.consumed,
-                                                  symall.p + c * job.out_stride, cap, ch.tags.data(), ch.n_acc,
-                                                  ch.sym_tags.data(), ch.sym_tags.size(), &n_out_tags, &consumed,
+    GR4PM_TRY(gr4pm_cfc_symbol_filter_run_channel(cfc, s.plan, c, ch.symf, s.y.p + c * y_stride, s.consumed,
+                                                  s.symall.p + c * s.out_stride, cap, cb.tags.data(), cb.n_acc,
+                                                  cb.sym_tags.data(), cb.sym_tags.size(), &n_out_tags, &consumed,
                                                   &produced_c));
-    GR4PM_TRY(gr4pm_syncword_wipeoff_process(ch.wipe, symall.p + c * job.out_stride, produced_c,
-                                             symall.p + c * job.out_stride, ch.sym_tags.data(), n_out_tags));
-    ch.n_sym_tags = n_out_tags;
-    ch.produced = produced_c;
+    GR4PM_TRY(gr4pm_syncword_wipeoff_process(ch.wipe, s.symall.p + c * s.out_stride, produced_c,
+                                             s.symall.p + c * s.out_stride, cb.sym_tags.data(), n_out_tags));
+    cb.n_sym_tags = n_out_tags;
+    cb.produced = produced_c;
     return GR4PM_OK;
 }
 
@@ -98,23 +147,116 @@ void gr4pm_multichannel_receiver::worker(unsigned w)
     gr4pm_set_deferred_sync(1);
     uint64_t seen = 0;
     for (;;) {
+        Slot* s = nullptr;
         {
             std::unique_lock<std::mutex> l(m);
             cv_go.wait(l, [&] { return quit || generation != seen; });
             if (quit) return;
             seen = generation;
+            s = cur;
         }
         gr4pm_status st = GR4PM_OK;
-        for (size_t c = w; c < p.n_channels && st == GR4PM_OK; c += streams.size()) st = run_channel(c);
+        for (size_t c = w; c < p.n_channels && st == GR4PM_OK; c += streams.size()) st = run_channel(*s, c);
         if (hipStreamSynchronize(streams[w]) != hipSuccess && st == GR4PM_OK) st = GR4PM_ERR_HIP;
         {
             std::lock_guard<std::mutex> l(m);
-            if (st != GR4PM_OK && status == GR4PM_OK) {
-                status = st;
-                std::strncpy(error, gr4pm_last_error(), sizeof(error) - 1);
+            if (st != GR4PM_OK && wstatus == GR4PM_OK) {
+                wstatus = st;
+                std::strncpy(werror, gr4pm_last_error(), sizeof(werror) - 1);
             }
             if (--pending == 0) cv_done.notify_all();
         }
+    }
+}
+
+// stage 1: SyncwordDetectionFilter of every channel (host only: the samples pass unchanged, the tags are gated),
+// then the CoarseFrequencyCorrection plan of all channels: one launch of the serial phasor checkpoints
+gr4pm_status gr4pm_multichannel_receiver::stage1(Slot& s)
+{
+    const size_t C = p.n_channels;
+    s.all_tags.clear();
+    s.all_channel.clear();
+    for (size_t c = 0; c < C; ++c) {
+        auto& ch = chains[c];
+        auto& cb = s.ch[c];
+        const gr4pm_tag* dt = s.det_tags.data() + c * p.tags_cap;
+        const size_t nd = s.n_det[c];
+        ch.idx.resize(nd);
+        ch.msgs.assign(std::max<size_t>(nd, 1), gr4pm_header_msg{ s.packet_length, s.packet_length == 0 ? 1 : 0 });
+        for (size_t i = 0; i < nd; ++i) ch.idx[i] = s.base + dt[i].index;
+        ch.accepted.assign(std::max<size_t>(nd, 1), 0);
+        size_t used = 0;
+        GR4PM_TRY(gr4pm_syncword_detection_filter_gate(ch.sdf, ch.idx.data(), nd, ch.msgs.data(), nd, 1,
+                                                       ch.accepted.data(), &used));
+        cb.n_acc = 0;
+        for (size_t i = 0; i < nd; ++i)
+            if (ch.accepted[i]) {
+                cb.tags[cb.n_acc++] = dt[i];
+                s.all_tags.push_back(dt[i]);
+                s.all_channel.push_back(static_cast<uint32_t>(c));
+            }
+    }
+    return gr4pm_cfc_symbol_filter_plan_channels(cfc, s.consumed, s.all_tags.data(), s.all_channel.data(),
+                                                 s.all_tags.size(), &s.plan);
+}
+
+// stage 2: every channel's SymbolFilter (fused with its share of the CFC plan) + SyncwordWipeoff on the workers
+gr4pm_status gr4pm_multichannel_receiver::stage2(Slot& s)
+{
+    std::unique_lock<std::mutex> l(m);
+    wstatus = GR4PM_OK;
+    cur = &s;
+    pending = static_cast<unsigned>(workers.size());
+    ++generation;
+    cv_go.notify_all();
+    cv_done.wait(l, [&] { return pending == 0; });
+    if (wstatus != GR4PM_OK) {
+        set_error("%s", werror);
+        return wstatus;
+    }
+    return GR4PM_OK;
+}
+
+// stage 3: CostasLoop of all channels: one launch
+gr4pm_status gr4pm_multichannel_receiver::stage3(Slot& s)
+{
+    const size_t C = p.n_channels;
+    s.all_tags.clear();
+    s.all_channel.clear();
+    for (size_t c = 0; c < C; ++c) {
+        auto& cb = s.ch[c];
+        s.produced[c] = cb.produced;
+        for (size_t i = 0; i < cb.n_sym_tags; ++i) {
+            s.all_tags.push_back(cb.sym_tags[i]);
+            s.all_channel.push_back(static_cast<uint32_t>(c));
+        }
+    }
+    return gr4pm_costas_loop_process_ragged(costas, s.symall.p, s.out_stride, s.produced.data(), s.out_symbols,
+                                            s.all_tags.data(), s.all_channel.data(), s.all_tags.size());
+}
+
+void gr4pm_multichannel_receiver::stage_loop(int which)
+{
+    Queue& in = which == 1 ? to_stage1 : which == 2 ? to_stage2 : to_stage3;
+    Queue& out = which == 1 ? to_stage2 : which == 2 ? to_stage3 : done;
+    for (;;) {
+        const int i = in.pop();
+        if (i < 0) return;
+        Slot& s = slots[i];
+        if (s.status == GR4PM_OK) { // a failed batch just travels on to collect()
+            static const bool timing = getenv("GR4PM_MC_TIMING") != nullptr;
+            const auto ta = std::chrono::steady_clock::now();
+            const gr4pm_status st = which == 1 ? stage1(s) : which == 2 ? stage2(s) : stage3(s);
+            if (timing)
+                fprintf(stderr, "[gr4pm multichannel] stage %d: %.0f us\n", which,
+                        std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ta).count());
+            if (st != GR4PM_OK) {
+                s.status = st;
+                std::strncpy(s.error, gr4pm_last_error(), sizeof(s.error) - 1);
+            }
+        }
+        if (which == 3) s.t_done = std::chrono::steady_clock::now();
+        out.push(i);
     }
 }
 
@@ -188,7 +330,8 @@ gr4pm_status gr4pm_multichannel_receiver_create(const gr4pm_multichannel_receive
     if (hipStreamCreateWithPriority(&h->batch_stream, hipStreamNonBlocking, greatest) != hipSuccess) return bail(GR4PM_ERR_HIP);
     gr4pm_rotator_params rp{ 1, 0.0f, (rrc.size() - 1) / 2 + sps, p->n_channels, h->batch_stream };
     if ((st = gr4pm_rotator_create(&rp, &h->cfc)) != GR4PM_OK) return bail(st);
-    gr4pm_costas_loop_params cp{ 0.01, p->costas_constellation, p->n_channels, h->batch_stream };
+    if (hipStreamCreateWithPriority(&h->costas_stream, hipStreamNonBlocking, least) != hipSuccess) return bail(GR4PM_ERR_HIP);
+    gr4pm_costas_loop_params cp{ 0.01, p->costas_constellation, p->n_channels, h->costas_stream };
     if ((st = gr4pm_costas_loop_create(&cp, &h->costas)) != GR4PM_OK) return bail(st);
     for (size_t c = 0; c < p->n_channels; ++c) {
         auto& ch = h->chains[c];
@@ -199,15 +342,23 @@ gr4pm_status gr4pm_multichannel_receiver_create(const gr4pm_multichannel_receive
         if ((st = gr4pm_symbol_filter_create(&fsp, &ch.symf)) != GR4PM_OK) return bail(st);
         gr4pm_syncword_wipeoff_params wp{ bipolar, 64, s };
         if ((st = gr4pm_syncword_wipeoff_create(&wp, &ch.wipe)) != GR4PM_OK) return bail(st);
-        ch.tags.resize(h->p.tags_cap);
-        ch.sym_tags.resize(h->p.tags_cap + 64);
     }
-    h->produced.assign(p->n_channels, 0);
     h->y_stride = (p->max_items + 63) & ~size_t{ 63 };
-    if ((st = h->y.alloc(h->y_stride * p->n_channels)) != GR4PM_OK) return bail(st);
-    h->det_tags.resize(p->n_channels * h->p.tags_cap);
-    h->n_det.assign(p->n_channels, 0);
+    for (auto& sl : h->slots) {
+        if ((st = sl.y.alloc(h->y_stride * p->n_channels)) != GR4PM_OK) return bail(st);
+        sl.det_tags.resize(p->n_channels * h->p.tags_cap);
+        sl.n_det.assign(p->n_channels, 0);
+        sl.produced.assign(p->n_channels, 0);
+        sl.ch.resize(p->n_channels);
+        for (auto& cb : sl.ch) {
+            cb.tags.resize(h->p.tags_cap);
+            cb.sym_tags.resize(h->p.tags_cap + 64);
+        }
+    }
     for (unsigned w = 0; w < n_workers; ++w) h->workers.emplace_back([h, w] { h->worker(w); });
+    h->t_stage1 = std::thread([h] { h->stage_loop(1); });
+    h->t_stage2 = std::thread([h] { h->stage_loop(2); });
+    h->t_stage3 = std::thread([h] { h->stage_loop(3); });
     *out = h;
     return GR4PM_OK;
 }
@@ -220,6 +371,12 @@ void gr4pm_multichannel_receiver_destroy(gr4pm_multichannel_receiver* h)
         h->quit = true;
     }
     h->cv_go.notify_all();
+    h->to_stage1.stop();
+    h->to_stage2.stop();
+    h->to_stage3.stop();
+    h->done.stop();
+    for (std::thread* t : { &h->t_stage1, &h->t_stage2, &h->t_stage3 })
+        if (t->joinable()) t->join();
     for (auto& t : h->workers)
         if (t.joinable()) t.join();
     gr4pm_syncword_detection_destroy(h->sd);
@@ -232,6 +389,7 @@ void gr4pm_multichannel_receiver_destroy(gr4pm_multichannel_receiver* h)
     gr4pm_rotator_destroy(h->cfc);
     gr4pm_costas_loop_destroy(h->costas);
     if (h->batch_stream) (void)hipStreamDestroy(h->batch_stream);
+    if (h->costas_stream) (void)hipStreamDestroy(h->costas_stream);
     for (auto s : h->streams)
         if (s) (void)hipStreamDestroy(s);
     if (h->sd_stream) (void)hipStreamDestroy(h->sd_stream);
@@ -245,6 +403,86 @@ gr4pm_status gr4pm_multichannel_receiver_announce(gr4pm_multichannel_receiver* h
     return gr4pm_syncword_detection_announce(h->sd, in, in_stride, n_in);
 }
 
+gr4pm_status gr4pm_multichannel_receiver_submit(gr4pm_multichannel_receiver* h, const gr4pm_c64* in,
+                                                size_t in_stride, size_t n_in, uint64_t packet_length,
+                                                gr4pm_c64* out_symbols, size_t out_stride, size_t* consumed)
+{
+    if (!h || !in || !out_symbols || !consumed) return GR4PM_ERR_INVALID;
+    *consumed = 0;
+    // checked BEFORE the detector consumes the batch: an error here must not lose items (the detector
+    // consumes at most n_in items per channel)
+    if (out_stride < n_in / h->p.samples_per_symbol + h->p.tags_cap + 2) {
+        set_error("out_stride %zu too small for %zu items per channel", out_stride, n_in);
+        return GR4PM_INSUFFICIENT_OUTPUT_ITEMS;
+    }
+    if (h->inflight >= kMcSlots) {
+        set_error("%d batches in flight: collect one first", h->inflight);
+        return GR4PM_ERR_INVALID;
+    }
+    auto& s = h->slots[h->next_slot];
+    const size_t C = h->p.n_channels;
+    if (s.symall.n < C * out_stride) GR4PM_TRY(s.symall.alloc(C * out_stride));
+    s.t_submit = std::chrono::steady_clock::now();
+    size_t n_done = 0;
+    // stage 0, in the caller's thread: the batched detector (its look-ahead runs the correlator of the announced
+    // batches behind this call's own kernels)
+    const gr4pm_status st = gr4pm_syncword_detection_process(h->sd, in, in_stride, n_in, s.y.p, h->y_stride, &n_done,
+                                                             s.det_tags.data(), h->p.tags_cap, s.n_det.data());
+    if (st != GR4PM_OK) return st;
+    if (getenv("GR4PM_MC_TIMING"))
+        fprintf(stderr, "[gr4pm multichannel] stage 0: %.0f us\n",
+                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - s.t_submit).count());
+    *consumed = n_done;
+    s.consumed = n_done;
+    s.base = gr4pm_syncword_detection_items_consumed(h->sd) - n_done;
+    s.packet_length = packet_length;
+    s.out_symbols = out_symbols;
+    s.out_stride = out_stride;
+    s.status = GR4PM_OK;
+    const int i = h->next_slot;
+    h->next_slot = (h->next_slot + 1) % kMcSlots;
+    ++h->inflight;
+    h->to_stage1.push(i);
+    return GR4PM_OK;
+}
+
+gr4pm_status gr4pm_multichannel_receiver_collect(gr4pm_multichannel_receiver* h, size_t* consumed, size_t* n_symbols,
+                                                 gr4pm_tag* tags, size_t* n_tags, gr4pm_tag* detector_tags,
+                                                 size_t* n_detector_tags)
+{
+    if (!h || !n_symbols) return GR4PM_ERR_INVALID;
+    if (h->inflight == 0) {
+        set_error("nothing in flight");
+        return GR4PM_ERR_INVALID;
+    }
+    const int i = h->done.pop();
+    if (i < 0) return GR4PM_ERR_INVALID;
+    --h->inflight;
+    auto& s = h->slots[i];
+    const size_t C = h->p.n_channels;
+    if (consumed) *consumed = s.consumed;
+    if (s.status != GR4PM_OK) {
+        for (size_t c = 0; c < C; ++c) n_symbols[c] = 0;
+        set_error("%s", s.error);
+        return s.status;
+    }
+    for (size_t c = 0; c < C; ++c) {
+        const auto& cb = s.ch[c];
+        n_symbols[c] = cb.produced;
+        if (n_tags) n_tags[c] = cb.n_sym_tags;
+        if (tags) std::memcpy(tags + c * h->p.tags_cap, cb.sym_tags.data(), std::min(cb.n_sym_tags, h->p.tags_cap) * sizeof(gr4pm_tag));
+        if (n_detector_tags) n_detector_tags[c] = s.n_det[c];
+    }
+    if (detector_tags) std::memcpy(detector_tags, s.det_tags.data(), s.det_tags.size() * sizeof(gr4pm_tag));
+    static const bool timing = getenv("GR4PM_MC_TIMING") != nullptr;
+    if (timing)
+        fprintf(stderr, "[gr4pm multichannel] batch latency %.0f us\n",
+                std::chrono::duration<double, std::micro>(s.t_done - s.t_submit).count());
+    return GR4PM_OK;
+}
+
+int gr4pm_multichannel_receiver_in_flight(const gr4pm_multichannel_receiver* h) { return h ? h->inflight : 0; }
+
 gr4pm_status gr4pm_multichannel_receiver_process(gr4pm_multichannel_receiver* h, const gr4pm_c64* in,
                                                  size_t in_stride, size_t n_in, uint64_t packet_length,
                                                  gr4pm_c64* out_symbols, size_t out_stride, size_t* consumed,
@@ -252,102 +490,13 @@ gr4pm_status gr4pm_multichannel_receiver_process(gr4pm_multichannel_receiver* h,
                                                  gr4pm_tag* detector_tags, size_t* n_detector_tags)
 {
     if (!h || !in || !out_symbols || !consumed || !n_symbols) return GR4PM_ERR_INVALID;
-    *consumed = 0;
+    if (h->inflight != 0) {
+        set_error("process() with batches in flight: collect them first");
+        return GR4PM_ERR_INVALID;
+    }
     for (size_t c = 0; c < h->p.n_channels; ++c) n_symbols[c] = 0;
-    static const bool timing = getenv("GR4PM_MC_TIMING") != nullptr; // wall time of the four phases, to stderr
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-    const auto t0 = now();
-    // checked BEFORE the detector consumes the batch: an error here must not lose items (the detector
-    // consumes at most n_in items per channel)
-    if (out_stride < n_in / h->p.samples_per_symbol + h->p.tags_cap + 2) {
-        set_error("out_stride %zu too small for %zu items per channel", out_stride, n_in);
-        return GR4PM_INSUFFICIENT_OUTPUT_ITEMS;
-    }
-    size_t n_done = 0;
-    const gr4pm_status st = gr4pm_syncword_detection_process(h->sd, in, in_stride, n_in, h->y.p, h->y_stride, &n_done,
-                                                             h->det_tags.data(), h->p.tags_cap, h->n_det.data());
-    if (st != GR4PM_OK) return st;
-    *consumed = n_done;
-    if (detector_tags) std::memcpy(detector_tags, h->det_tags.data(), h->det_tags.size() * sizeof(gr4pm_tag));
-    if (n_detector_tags)
-        for (size_t c = 0; c < h->p.n_channels; ++c) n_detector_tags[c] = h->n_det[c];
-    const auto t1 = now();
-    h->job.consumed = n_done;
-    h->job.base = gr4pm_syncword_detection_items_consumed(h->sd) - n_done;
-    h->job.packet_length = packet_length;
-    h->job.out_symbols = out_symbols;
-    h->job.out_stride = out_stride;
-    h->job.n_symbols = n_symbols;
-    h->job.tags = tags;
-    h->job.n_tags = n_tags;
-    const size_t C = h->p.n_channels;
-    if (h->symall.n < C * out_stride) GR4PM_TRY(h->symall.alloc(C * out_stride));
-    // SyncwordDetectionFilter of every channel (host only): the samples pass unchanged, the tags are gated
-    h->all_tags.clear();
-    h->all_channel.clear();
-    for (size_t c = 0; c < C; ++c) {
-        auto& ch = h->chains[c];
-        const gr4pm_tag* dt = h->det_tags.data() + c * h->p.tags_cap;
-        const size_t nd = h->n_det[c];
-        ch.idx.resize(nd);
-        ch.msgs.assign(std::max<size_t>(nd, 1), gr4pm_header_msg{ packet_length, packet_length == 0 ? 1 : 0 });
-        for (size_t i = 0; i < nd; ++i) ch.idx[i] = h->job.base + dt[i].index;
-        ch.accepted.assign(std::max<size_t>(nd, 1), 0);
-        size_t used = 0;
-        GR4PM_TRY(gr4pm_syncword_detection_filter_gate(ch.sdf, ch.idx.data(), nd, ch.msgs.data(), nd, 1,
-                                                       ch.accepted.data(), &used));
-        ch.n_acc = 0;
-        for (size_t i = 0; i < nd; ++i)
-            if (ch.accepted[i]) {
-                ch.tags[ch.n_acc++] = dt[i];
-                h->all_tags.push_back(dt[i]);
-                h->all_channel.push_back(static_cast<uint32_t>(c));
-            }
-    }
-    // CoarseFrequencyCorrection of all channels: one plan, one launch of the serial checkpoints
-    GR4PM_TRY(gr4pm_cfc_symbol_filter_plan_channels(h->cfc, n_done, h->all_tags.data(), h->all_channel.data(),
-                                                    h->all_tags.size(), &h->plan));
-    const auto t2 = now();
-    // every channel's SymbolFilter + SyncwordWipeoff on the workers
-    {
-        std::unique_lock<std::mutex> l(h->m);
-        h->status = GR4PM_OK;
-        h->pending = static_cast<unsigned>(h->workers.size());
-        ++h->generation;
-        h->cv_go.notify_all();
-        h->cv_done.wait(l, [&] { return h->pending == 0; });
-        if (h->status != GR4PM_OK) {
-            set_error("%s", h->error);
-            return h->status;
-        }
-    }
-    const auto t3 = now();
-    // CostasLoop of all channels: one launch
-    h->all_tags.clear();
-    h->all_channel.clear();
-    for (size_t c = 0; c < C; ++c) {
-        auto& ch = h->chains[c];
-        h->produced[c] = ch.produced;
-        n_symbols[c] = ch.produced;
-        if (n_tags) n_tags[c] = ch.n_sym_tags;
-        if (tags) std::memcpy(tags + c * h->p.tags_cap, ch.sym_tags.data(), std::min(ch.n_sym_tags, h->p.tags_cap) * sizeof(gr4pm_tag));
-        for (size_t i = 0; i < ch.n_sym_tags; ++i) {
-            h->all_tags.push_back(ch.sym_tags[i]);
-            h->all_channel.push_back(static_cast<uint32_t>(c));
-        }
-    }
-    const gr4pm_status cst = gr4pm_costas_loop_process_ragged(h->costas, h->symall.p, out_stride, h->produced.data(),
-                                                              out_symbols, h->all_tags.data(), h->all_channel.data(),
-                                                              h->all_tags.size());
-    if (timing) {
-        static auto last_return = t0;
-        const auto t4 = now();
-        fprintf(stderr, "[gr4pm multichannel] caller %.0f us | detector %.0f us, gate + CFC plan %.0f us, symbol filters %.0f us, Costas %.0f us\n",
-                us(last_return, t0), us(t0, t1), us(t1, t2), us(t2, t3), us(t3, t4));
-        last_return = t4;
-    }
-    return cst;
+    GR4PM_TRY(gr4pm_multichannel_receiver_submit(h, in, in_stride, n_in, packet_length, out_symbols, out_stride, consumed));
+    return gr4pm_multichannel_receiver_collect(h, nullptr, n_symbols, tags, n_tags, detector_tags, n_detector_tags);
 }
 
 } // extern "C"

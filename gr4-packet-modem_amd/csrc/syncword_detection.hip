@@ -486,6 +486,7 @@ __global__ __launch_bounds__(kPairThreads, 3) void k_correlate_pair(
 } // namespace
 } // namespace gr4pm
 #include "correlate_w64.hpp"
+#include "correlate_4096.hpp"
 namespace gr4pm {
 namespace {
 
@@ -1440,6 +1441,7 @@ struct gr4pm_syncword_detection {
     DevBuf<cf> cc64;
     int n_cus = 256;
     int w64_variant = -1;
+    uint32_t w64_blocks_per_wave = 4; // blocks per wave and workgroup; 0: persistent waves (GR4PM_W64_BLOCKS_PER_WAVE)
     // raised by a correlator kernel whose bounded hand-off spin ran out ("wave" / "pair" kernels; k_correlate_w64
     // has no spins); checked after the stream synchronisation of process()
     PinnedBuf<unsigned> fault;
@@ -1453,6 +1455,8 @@ struct gr4pm_syncword_detection {
     bool generic = false;
     int log2n = 0;
     DevBuf<cf> g_tmpl, g_tw;
+    DevBuf<cf> tw4k;          // fft_size 4096: tw1 ++ tw2 of fft4096_wg.hpp
+    bool force_radix2 = false; // GR4PM_CORRELATOR=radix2: the generic kernel also for 4096 (tests compare the two)
     DevBuf<cf> carry[kCarry]; // sample carry before this call, before the calls ahead, and the one being written
     DevBuf<float> z[kSets];
     // candidate bitmap, tile tables and group tables exist kSets times like z[]: the look-ahead of
@@ -1580,6 +1584,13 @@ void finish_tag(const gr4pm_syncword_detection* h, const RawTag& t, uint64_t out
 gr4pm_status launch_correlate(gr4pm_syncword_detection* h, hipStream_t stream, const gr4pm_c64* in,
                               size_t in_stride, uint32_t n_blocks, float* zout)
 {
+    if (h->generic && h->fft_size == static_cast<size_t>(kN4k) && !h->force_radix2) {
+        hipLaunchKernelGGL(k_correlate_4096, dim3(n_blocks, static_cast<unsigned>(h->n_channels)), dim3(kT4k), 0, stream,
+                           reinterpret_cast<const cf*>(in), in_stride, n_blocks, static_cast<uint32_t>(h->S), h->n_bins,
+                           h->g_tmpl.p, h->tw4k.p, h->tw4k.p + 16 * 256, zout, h->z_stride);
+        GR4PM_HIP_TRY(hipGetLastError());
+        return GR4PM_OK;
+    }
     if (h->generic) {
         const uint32_t N = static_cast<uint32_t>(h->fft_size);
         hipLaunchKernelGGL(k_correlate_generic, dim3(n_blocks, static_cast<unsigned>(h->n_channels)), dim3(256),
@@ -1601,11 +1612,13 @@ gr4pm_status launch_correlate(gr4pm_syncword_detection* h, hipStream_t stream, c
     if (h->corr_kind == 0) {
         // persistent waves: one 8-wave workgroup per CU, every wave walks items wave, wave + W, ...
         const uint32_t total = n_blocks * static_cast<uint32_t>(h->n_channels);
-        const uint32_t wgs = std::min<uint32_t>(static_cast<uint32_t>(h->n_cus), (total + kW64Waves - 1) / kW64Waves);
+        const uint32_t bpw = h->w64_blocks_per_wave;
+        const uint32_t wgs = bpw ? (total + kW64Waves * bpw - 1) / (kW64Waves * bpw)
+                                 : std::min<uint32_t>(static_cast<uint32_t>(h->n_cus), (total + kW64Waves - 1) / kW64Waves);
 #define GR4PM_W64_LAUNCH(V)                                                                                         \
     hipLaunchKernelGGL(k_correlate_w64<V>, dim3(wgs), dim3(kW64Threads), 0, stream, reinterpret_cast<const cf*>(in), \
                        in_stride, n_blocks, total, static_cast<uint32_t>(h->S), h->n_bins, h->tmpl64.p, h->tT64.p,  \
-                       h->cc64.p, zout, h->z_stride)
+                       h->cc64.p, zout, h->z_stride, bpw)
         // GR4PM_W64_VARIANT: the timing-only ablations of tools/w64_variants.py
         switch (h->w64_variant) {
         case 8: GR4PM_W64_LAUNCH(8); break;
@@ -1875,6 +1888,7 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
         h->corr_kind = k == "pair" ? 2 : k == "wave" ? 1 : 0;
         const char* v = getenv("GR4PM_W64_VARIANT");
         h->w64_variant = v ? atoi(v) : -1;
+        if (const char* b = getenv("GR4PM_W64_BLOCKS_PER_WAVE")) h->w64_blocks_per_wave = static_cast<uint32_t>(std::max(0, atoi(b)));
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
@@ -1913,6 +1927,18 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
         const double ang = -2.0 * M_PI * static_cast<double>(k) / static_cast<double>(p->fft_size);
         g_tw[k] = mk(static_cast<float>(std::cos(ang)), static_cast<float>(std::sin(ang)));
     }
+    std::vector<cf> tw4k(16 * 256 + 256);
+    if (h->generic && p->fft_size == static_cast<size_t>(kN4k)) {
+        build_4096_tables(
+            [](int k) {
+                const double ang = -2.0 * M_PI * k / kN4k;
+                return mk(static_cast<float>(std::cos(ang)), static_cast<float>(std::sin(ang)));
+            },
+            tw4k.data(), tw4k.data() + 16 * 256);
+        ok(h->tw4k.alloc(tw4k.size()));
+        const char* e = getenv("GR4PM_CORRELATOR");
+        h->force_radix2 = e && std::string(e) == "radix2";
+    }
     if (h->generic) {
         ok(h->g_tmpl.alloc(g_tmpl.size()));
         ok(h->g_tw.alloc(g_tw.size()));
@@ -1944,6 +1970,7 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
     ok(h->rec_host.alloc(static_cast<size_t>(h->rec_cap) * h->n_channels));
     if (s == GR4PM_OK && h->generic) s = h->g_tmpl.upload(g_tmpl.data(), g_tmpl.size(), h->stream);
     if (s == GR4PM_OK && h->generic) s = h->g_tw.upload(g_tw.data(), g_tw.size(), h->stream);
+    if (s == GR4PM_OK && h->tw4k.p) s = h->tw4k.upload(tw4k.data(), tw4k.size(), h->stream);
     if (s == GR4PM_OK) s = h->tmpl.upload(tmpl.data(), tmpl.size(), h->stream);
     if (s == GR4PM_OK) s = h->tw.upload(tw.data(), tw.size(), h->stream);
     if (s == GR4PM_OK) s = h->tmplp.upload(tmplp.data(), tmplp.size(), h->stream);

@@ -675,7 +675,11 @@ size_t gr4pm_packet_receiver_inflight(const gr4pm_packet_receiver* h);
  * GPU (front-end mode of gr4pm_packet_receiver, channel by channel).  One batched
  * SyncwordDetection handle for all channels, then every channel's own SyncwordDetectionFilter /
  * CoarseFrequencyCorrection / SymbolFilter / SyncwordWipeoff / CostasLoop, spread over `workers`
- * threads with a stream each.  process() is synchronous. */
+ * threads with a stream each.  process() is synchronous; submit() / collect() run the same chain as a
+ * pipeline: submit returns when the detector has consumed the batch, the stages behind it (tag gates + CFC
+ * plan | symbol filters + wipe-off | Costas loop) work on up to GR4PM_MC_SLOTS batches at a time in their own
+ * threads, collect() waits for the oldest one (results in submission order, bit-identical to process()). */
+#define GR4PM_MC_SLOTS 4
 typedef struct gr4pm_multichannel_receiver gr4pm_multichannel_receiver;
 typedef struct {
     size_t n_channels;
@@ -702,6 +706,15 @@ gr4pm_status gr4pm_multichannel_receiver_process(gr4pm_multichannel_receiver* h,
                                                  gr4pm_c64* out_symbols, size_t out_stride, size_t* consumed,
                                                  size_t* n_symbols, gr4pm_tag* tags, size_t* n_tags,
                                                  gr4pm_tag* detector_tags, size_t* n_detector_tags);
+
+/* the pipelined form: out_symbols must stay valid until the batch has been collected */
+gr4pm_status gr4pm_multichannel_receiver_submit(gr4pm_multichannel_receiver* h, const gr4pm_c64* in,
+                                                size_t in_stride, size_t n_in, uint64_t packet_length,
+                                                gr4pm_c64* out_symbols, size_t out_stride, size_t* consumed);
+gr4pm_status gr4pm_multichannel_receiver_collect(gr4pm_multichannel_receiver* h, size_t* consumed, size_t* n_symbols,
+                                                 gr4pm_tag* tags, size_t* n_tags, gr4pm_tag* detector_tags,
+                                                 size_t* n_detector_tags);
+int gr4pm_multichannel_receiver_in_flight(const gr4pm_multichannel_receiver* h);
 
 /* ====================================================================================
  * Burst generator pieces (packet_transmitter_pdu.hpp:131-337): with

@@ -94,3 +94,13 @@ def test_glibc_sinf_cosf_restatement_matches_the_host_libm(tmp_path):
                               ["-o", str(exe), os.path.join(ROOT, "tests", "sincosf_glibc_check.c"), "-lm", "-lpthread"])
         out = subprocess.check_output([str(exe)]).decode()
         assert re.search(r"sin mismatches 0, cos mismatches 0", out), out
+
+
+def test_fft4096_workgroup_schedule_host_emulation(tmp_path):
+    """fft4096_wg.hpp (configs[4]: 16 x 16 x 16, 256 threads): the threads run phase by phase on the CPU"""
+    exe = tmp_path / "fft4096_emu"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ge.PKG_DIR, "csrc"), "-o", str(exe),
+                           os.path.join(ROOT, "tests", "fft4096_emu.cpp")])
+    out = subprocess.check_output([str(exe)]).decode()
+    errs = [float(e) for e in re.findall(r"max_rel_err ([0-9.e+-]+)", out)]
+    assert len(errs) == 2 and max(errs) < 5e-7, out

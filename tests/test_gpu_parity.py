@@ -872,6 +872,30 @@ def test_syncword_detection_other_fft_sizes(pkg, fft_size, ntaps_req):
     assert d1 + d2 == n and np.array_equal(np.concatenate([t1, t2])["index"], tags["index"])
 
 
+def test_fft4096_workgroup_correlator_against_the_radix2_kernel(pkg, monkeypatch):
+    """fft_size 4096 runs k_correlate_4096 (16 x 16 x 16, three in-register passes); GR4PM_CORRELATOR=radix2 keeps
+    the generic radix-2 kernel for it: same powers within float rounding, identical tags"""
+    sps = 4
+    rrc = orc.rrc_taps(1.0, float(sps), 1.0, 0.35, 1024)
+    rrc = (rrc / np.sqrt(np.sum(rrc.astype(np.float64) ** 2))).astype(np.float32)
+    rng = np.random.default_rng(4)
+    symbols = rng.integers(0, 2, 60000).astype(np.uint8)
+    for loc in (700, 9000, 21000, 40000, 52000):
+        symbols[loc:loc + 64] = sig.SYNCWORD
+    x = orc.interpolating_fir(sig.BPSK[symbols], sps, rrc)
+    x = (orc.rotator(x, np.float32(-0.003)) + sig.awgn(x.size, 0.05, 8)).astype(np.complex64)
+    res = {}
+    for kind in ("w64", "radix2"):
+        monkeypatch.setenv("GR4PM_CORRELATOR", kind)
+        sd = pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, fft_size=4096, power_threshold=30.0, max_items=x.size)
+        st, out, tags, n = sd.process_bulk(dev(x))
+        res[kind] = (tags, host(sd.last_zpow(n))[0])
+    (ta, za), (tb, zb) = res["w64"], res["radix2"]
+    assert np.array_equal(ta["index"], tb["index"]) and np.array_equal(ta["freq_bin"], tb["freq_bin"])
+    assert set(1537 + 4 * np.array([700, 9000, 21000, 40000, 52000])) <= set(ta["index"].tolist())  # (+ a start-up transient)
+    assert np.max(np.abs(za - zb)) / np.max(zb) < 2e-6
+
+
 def test_syncword_detection_unsupported_fft_size_is_reported(pkg):
     rrc, _ = orc.unit_norm_rrc(4)
     with pytest.raises(pkg.Gr4pmError, match="not built"):
@@ -1096,6 +1120,48 @@ def test_syncword_wipeoff_in_place(pkg):
         yb = b.process_bulk(xb, t, in_place=True)
         assert yb.data_ptr() == xb.data_ptr()
         assert np.array_equal(bits(ya), bits(host(yb)))
+
+
+def test_multichannel_receiver_64_channels_pipelined_equals_synchronous(pkg):
+    """BASELINE configs[2] at its channel count: 64 channels with the per-channel CFO sweep of SURVEY 8(d) config 3
+    (-0.04 .. +0.04 rad/sample), six batches.  submit() / collect() with up to four batches in flight (stages in
+    their own threads) == process() batch by batch, bit for bit: symbols, re-timed tags, detector tags; and channel 0
+    / 31 / 63 against one single-channel PacketReceiver each"""
+    C, n, n_batches = 64, 1 << 15, 6
+    rng = np.random.default_rng(77)
+    total = n * n_batches
+    base, _ = sig.qa_syncword_stream(total // 4, sorted(rng.choice(np.arange(500, total // 4 - 2500, 1700), size=24, replace=False).tolist()), 0.0, seed=5)
+    base = (0.7 * base[:total] + sig.awgn(total, 0.05, 6)).astype(np.complex64)
+    k = np.arange(total, dtype=np.float64)
+    xs = np.stack([np.roll(base, 997 * c) * np.exp(1j * ((-0.04 + 0.08 * c / (C - 1)) * k)) for c in range(C)]).astype(np.complex64)
+    xd = dev(xs)
+    parts = [xd[:, b * n:(b + 1) * n].contiguous() for b in range(n_batches)]
+    sync = pkg.NativeMultiChannelReceiver(C, max_items=n, tags_cap=128, workers=8)
+    pipe = pkg.NativeMultiChannelReceiver(C, max_items=n, tags_cap=128, workers=8)
+    want = [sync.process_bulk(w, 200) for w in parts]
+    got = []
+    for b, w in enumerate(parts):
+        if pipe.in_flight() == 4:
+            got.append(pipe.collect())
+        pipe.submit(w, 200)
+    while pipe.in_flight():
+        got.append(pipe.collect())
+    assert len(got) == n_batches
+    n_tags = 0
+    for b in range(n_batches):
+        for c in range(C):
+            g, w_ = got[b][c], want[b][c]
+            assert g["consumed"] == w_["consumed"]
+            assert np.array_equal(bits(host(g["symbols"])), bits(host(w_["symbols"]))), (b, c)
+            assert same_tags(g["tags"], w_["tags"]) and same_tags(g["detector_tags"], w_["detector_tags"])
+            n_tags += g["tags"].size
+    assert n_tags > 15 * C  # most packets are found on most channels (the edge channels miss some)
+    for c in (0, 31, 63):
+        single = pkg.PacketReceiver(max_items=n)
+        for b in range(n_batches):
+            ref = single.process_bulk(parts[b][c], 200, tags_cap=128)
+            assert np.array_equal(bits(host(got[b][c]["symbols"])), bits(host(ref["symbols"]))), (b, c)
+            assert same_tags(got[b][c]["tags"], ref["tags"])
 
 
 def test_multichannel_packet_receiver_equals_single_channel_receivers(pkg):
