@@ -88,6 +88,21 @@ def sincosf(x):
     return s.cpu().numpy(), c.cpu().numpy()
 
 
+def packet_transmitter_rrc_taps(samples_per_symbol):
+    """packet_transmitter_rrc_taps.hpp:8-28: the transmitter's RRC (root_raised_cosine(1, sps, 1, 0.35, 11 sps))
+    scaled so that the largest polyphase |tap| sum is 0.9 (DAC head-room), in the reference's float32 arithmetic
+    and summation order"""
+    sps = int(samples_per_symbol)
+    taps = root_raised_cosine(1.0, float(sps), 1.0, 0.35, sps * 11)
+    worst = np.float32(0.0)
+    for j in range(sps):
+        acc = np.float32(0.0)
+        for k in range(j, taps.size, sps):
+            acc = np.float32(acc + np.abs(taps[k]))
+        worst = max(worst, acc)
+    return (taps * np.float32(np.float32(0.9) / worst)).astype(np.float32)
+
+
 def root_raised_cosine(gain, sampling_freq, symbol_rate, alpha, ntaps):
     """firdes::root_raised_cosine<float>, firdes.hpp:29-76"""
     out = np.zeros(ntaps | 1, dtype=np.float32)
@@ -1293,8 +1308,7 @@ class BurstGenerator:
         here = os.path.dirname(os.path.abspath(__file__))
         self.generator = np.fromfile(os.path.join(here, "data", "header_ldpc_generator.u32"), dtype="<u4") \
             if generator is None else np.ascontiguousarray(generator, dtype=np.uint32)
-        taps = np.fromfile(os.path.join(here, "data", "tx_rrc_taps_4.f32"), dtype="<f4")
-        assert samples_per_symbol == 4, "the shipped transmit RRC is the 4 samples/symbol one"
+        taps = packet_transmitter_rrc_taps(samples_per_symbol)  # computed here, not shipped as data
         self.rrc_taps = taps
         self.fir = InterpolatingFirFilter(samples_per_symbol, taps)
         self.scrambler = AdditiveScrambler(0x4001, 0x18E38, 16, dtype="uint8")   # :118-122
@@ -1349,9 +1363,14 @@ class BurstGenerator:
         lens = n_syms * np.uint64(self.sps)
         return burst_shaper(x, self.leading, self.trailing, lens), lens                         # :314-316
 
-    def stream(self, payloads, gaps, freq_error=0.0, esn0_db=None, seed=1, tail=4000, packet_types=None):
-        """bursts separated by `gaps` (samples of silence before each burst), rotated by freq_error
-        rad/sample and with AWGN for the given Es/N0 (apps/packet_transceiver.cpp:48-52: tx power 0.32)"""
+    def stream(self, payloads, gaps, freq_error=0.0, esn0_db=None, seed=1, tail=4000, packet_types=None,
+               sfo_ppm=None, carrier="rotator"):
+        """bursts separated by `gaps` (samples of silence before each burst) through the channel model of
+        apps/packet_transceiver.cpp:48-78: PfbArbResampler<c64, c64, float> at rate 1 + 1e-6 sfo_ppm (sampling
+        frequency offset; sfo_ppm=None leaves the block out), Rotator at freq_error rad/sample, AWGN for the
+        given Es/N0 (tx power 0.32).  carrier="rotator" is the reference's Rotator (phasor recurrence, one serial
+        lane for an untagged stream: 50 Msamples/s); carrier="closed_form" multiplies by exp(j freq_error n) from
+        a double-precision phase instead -- a generator-only mode, not the reference's rounding, at HBM speed."""
         torch = _torch()
         x, lens = self.bursts(payloads, packet_types)
         total = int(np.sum(lens)) + int(np.sum(gaps)) + tail
@@ -1362,7 +1381,15 @@ class BurstGenerator:
             out[dst:dst + int(n)] = x[src:src + int(n)]
             src += int(n)
             dst += int(n)
-        if freq_error:
+        if sfo_ppm is not None:                                                                  # :69-71
+            rate = float(np.float32(1.0) + np.float32(1e-6) * np.float32(sfo_ppm))
+            out, _ = PfbArbResampler(rate, rate_dtype="float32").process_bulk(out)
+            total = out.numel()
+        if freq_error and carrier == "closed_form":
+            k = torch.arange(total, device="cuda", dtype=torch.float64)
+            ph = torch.remainder(k * float(np.float32(freq_error)), 2.0 * np.pi)
+            out = (out * torch.polar(torch.ones_like(ph), ph).to(torch.complex64)).contiguous()
+        elif freq_error:
             out = Rotator(np.float32(freq_error)).process_bulk(out)                              # :72-73
         if esn0_db is not None:
             n0 = 0.32 * self.sps * 10.0 ** (-0.1 * esn0_db)                                      # :48-52

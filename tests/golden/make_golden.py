@@ -63,7 +63,7 @@ def header_code():
     np.array(gen, dtype="<u4").tofile(os.path.join(data_dir, "header_ldpc_generator.u32"))  # BurstGenerator
     tx = orc.ref_taps_dump("txrrc", 4)  # packet_transmitter_rrc_taps(4), from the reference's own header
     assert tx is not None, "build oracle/_ref first (make -C oracle)"
-    tx.astype("<f4").tofile(os.path.join(data_dir, "tx_rrc_taps_4.f32"))
+    np.save(os.path.join(HERE, "ref_txrrc_4.npy"), tx.astype("<f4"))  # fixture only: the product computes these taps itself
     src = open(os.path.join(REF, "test", "qa_header_fec_decoder.cpp")).read()
     vecs = []
     pos = 0

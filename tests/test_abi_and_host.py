@@ -104,3 +104,11 @@ def test_fft4096_workgroup_schedule_host_emulation(tmp_path):
     out = subprocess.check_output([str(exe)]).decode()
     errs = [float(e) for e in re.findall(r"max_rel_err ([0-9.e+-]+)", out)]
     assert len(errs) == 2 and max(errs) < 5e-7, out
+
+
+def test_packet_transmitter_rrc_taps_computed_in_product(pkg):
+    """packet_transmitter_rrc_taps.hpp:8-28 restated over the library's own firdes: bit-exact against the taps
+    the reference's header produced (tests/golden/ref_txrrc_4.npy, built by oracle/_ref)"""
+    got = pkg.packet_transmitter_rrc_taps(4)
+    ref = np.load(os.path.join(ROOT, "tests", "golden", "ref_txrrc_4.npy"))
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))

@@ -1987,6 +1987,30 @@ def test_mapper_and_burst_shaper_reference_qa(pkg):
     assert np.array_equal(bits(got), bits(np.concatenate(want)))
 
 
+def test_burst_generator_sfo_and_closed_form_carrier(pkg):
+    """the channel model's remaining leg (apps/packet_transceiver.cpp:69-73): PfbArbResampler at 1 + 20 ppm in
+    front of the carrier offset; and the generator-only closed-form carrier.  All packets come back through the
+    native receiver, CRC-checked, either way."""
+    rng = np.random.default_rng(31)
+    gen = pkg.BurstGenerator()
+    payloads = [rng.integers(0, 256, int(n), dtype=np.uint8).tobytes() for n in rng.integers(40, 300, 12)]
+    gaps = rng.integers(3000, 6000, len(payloads))
+    for kw in (dict(sfo_ppm=20.0), dict(carrier="closed_form"), dict(sfo_ppm=-15.0, carrier="closed_form")):
+        x = gen.stream(payloads, gaps, freq_error=0.008, esn0_db=22.0, seed=7, **kw)
+        rx = pkg.NativePacketReceiver(max_items=x.numel(), tags_cap=256, decode_headers=True)
+        res = rx.process_bulk(x)
+        lens, data = res["packet_lengths"], res["packets"].cpu().numpy()
+        got, pos = [], 0
+        for n in lens[lens > 0]:
+            got.append(data[pos:pos + int(n)].tobytes())
+            pos += int(n)
+        assert got == payloads, kw
+    # the closed-form carrier is the reference Rotator's signal up to rounding
+    y = gen.stream(payloads[:2], gaps[:2], freq_error=0.008, seed=7)
+    z = gen.stream(payloads[:2], gaps[:2], freq_error=0.008, seed=7, carrier="closed_form")
+    assert float((y - z).abs().max()) < 2e-4
+
+
 def test_burst_generator_loopback(pkg):
     """packet_transmitter_pdu.hpp's burst path and packet_transceiver.cpp's channel on the device, received
     by the native receiver: every packet comes back byte for byte at Es/N0 = 20 dB with carrier offset"""
