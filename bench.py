@@ -119,89 +119,47 @@ def burst_stream(pkg, n_items, rrc, seed, device, header=None):
     return (x + noise).to(torch.complex64).contiguous(), n_pkt
 
 
-def _cpu_detector_rate(piece, rrc, seconds, threads=1):
-    """oracle SyncwordDetection on `threads` host threads, each with its own detector state over
-    the same samples (one independent channel per thread: the path shards by channel)"""
-    import threading
-    import _oracle as orc
-    bpsk = np.array([1, -1], dtype=np.complex64)
-    dets = [orc.SyncwordDetection(rrc, SYNCWORD, bpsk, -BINS, BINS, power_threshold=9.5) for _ in range(threads)]
-    done = [0] * threads
-    tags = [0] * threads
-    t0 = time.perf_counter()
-
-    def run(i):
-        while True:  # ctypes releases the GIL inside the oracle
-            _, out, tg = dets[i].process(piece)
-            done[i] += out.size
-            tags[i] += tg.size
-            if time.perf_counter() - t0 >= seconds:
-                return
-
-    if threads == 1:
-        run(0)
-    else:
-        th = [threading.Thread(target=run, args=(i,)) for i in range(threads)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-    dt = time.perf_counter() - t0
-    return sum(done) / dt / 1e6, sum(done), sum(tags), dt
-
-
-def _cpu_front_end_rate(piece, rrc, seconds, threads=1):
-    """the whole front end on the CPU oracle, block after block like the reference flowgraph
-    (packet_receiver.hpp:76-127): SyncwordDetection -> CoarseFrequencyCorrection (delay 26) ->
-    SymbolFilter (32 x 44 PFB) -> SyncwordWipeoff -> CostasLoop; the tag gate is a pure copy that
-    accepts every tag of this stream and is left out"""
-    import threading
-    import _oracle as orc
-    bpsk = np.array([1, -1], dtype=np.complex64)
-    pfb = orc.rrc_taps(32.0 / float(orc.unit_norm_rrc(SPS)[1]), 32.0 * SPS, 1.0, 0.35, 32 * SPS * 11)[:-1]
-    bipolar = np.where(SYNCWORD == 1, -1.0, 1.0).astype(np.float32)
-    done = [0] * threads
-    t0 = time.perf_counter()
-
-    def run(i):
-        while True:
-            sd = orc.SyncwordDetection(rrc, SYNCWORD, bpsk, -BINS, BINS, power_threshold=9.5)
-            _, out, tg = sd.process(piece, tags_cap=1 << 16)
-            z = orc.coarse_frequency_correction(out, tg["index"], tg["freq"], delay=26)
-            sym, sym_tags, _ = orc.symbol_filter(z, pfb, 32, SPS, 44, tags=tg.astype(orc.TAG_DTYPE))
-            w = orc.syncword_wipeoff(sym, bipolar, sym_tags["index"])
-            orc.costas_loop(w, "QPSK", 0.01, sym_tags["index"], sym_tags["phase"])
-            done[i] += out.size
-            if time.perf_counter() - t0 >= seconds:
-                return
-
-    th = [threading.Thread(target=run, args=(i,)) for i in range(threads)]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    dt = time.perf_counter() - t0
-    return sum(done) / dt / 1e6, sum(done), dt
+def _cpu_leg(piece_path, leg, seconds, workers):
+    """`workers` processes (tools/cpu_baseline_worker.py: numpy + the oracle library, no torch, no GPU), each with
+    its own detector / chain state over the same samples -- one independent channel per process, the way the path
+    shards; rate = samples of all workers / the longest worker time"""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "cpu_baseline_worker.py"), piece_path, leg, str(seconds)]
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env) for _ in range(workers)]
+    done, tmax = 0, 0.0
+    for p in procs:
+        out = p.communicate()[0].split()
+        if p.returncode == 0 and len(out) == 2:
+            done += int(out[0])
+            tmax = max(tmax, float(out[1]))
+    return (done / tmax / 1e6 if tmax > 0 else 0.0), done, tmax
 
 
 def cpu_baseline(x_host, rrc, seconds_target=24.0):
-    """the CPU oracle (kind "port": the reference cannot be built on the GPU box) on a bounded
-    sample of the same workload, ~seconds_target of wall time split over five legs:
-    value = the full front end on ALL host cores (one channel per thread, `cores` threads);
-    beside it the same on one core, the detector alone on one core and on all cores, and the
-    detector on the reference benchmark's all-zeros input (benchmark_syncword_detection.cpp:31)."""
+    """the CPU oracle (kind "port": the reference cannot be built on the GPU box) on a bounded sample of the same
+    workload, ~seconds_target of wall time over five legs: value = the full front end on ALL host cores (one
+    channel per process, `cores` processes); beside it the same on one core, the detector alone on one core and on
+    all cores, and the detector on the reference benchmark's all-zeros input (benchmark_syncword_detection.cpp:31)."""
+    import tempfile
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    piece = x_host[: min(x_host.size, 1 << 24)]
-    leg = seconds_target / 5.0
-    fe_all, fe_all_n, fe_all_dt = _cpu_front_end_rate(piece, rrc, leg, cores)
-    fe_one, fe_one_n, _ = _cpu_front_end_rate(piece, rrc, leg, 1)
-    det_one, det_n, det_tags, det_dt = _cpu_detector_rate(piece, rrc, leg, 1)
-    det_all, _, _, _ = _cpu_detector_rate(piece, rrc, leg, cores)
-    det_zero, _, _, _ = _cpu_detector_rate(np.zeros(1 << 22, dtype=np.complex64), rrc, leg, 1)
+    leg = seconds_target / 6.0
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    with tempfile.TemporaryDirectory(dir=shm) as d:
+        big, small, zeros = os.path.join(d, "big.npy"), os.path.join(d, "small.npy"), os.path.join(d, "zeros.npy")
+        np.save(big, x_host[: min(x_host.size, 1 << 24)])     # one-core legs: passes of 2^24 samples
+        np.save(small, x_host[: min(x_host.size, 1 << 21)])   # all-core legs: short passes, every worker gets several
+        np.save(zeros, np.zeros(1 << 22, dtype=np.complex64))
+        fe_all, fe_all_n, fe_all_dt = _cpu_leg(small, "front_end", leg, cores)
+        fe_one, _, _ = _cpu_leg(big, "front_end", leg, 1)
+        det_one, _, _ = _cpu_leg(big, "detector", leg, 1)
+        det_all, _, _ = _cpu_leg(small, "detector", leg, cores)
+        det_zero, _, _ = _cpu_leg(zeros, "detector", leg, 1)
     return {"value": round(fe_all, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
             "sample": f"full front end (detector 9 bins + CFC + SymbolFilter + wipe-off + Costas), CPU oracle "
-                      f"oracle/gr4pm_oracle.cpp, {cores} threads x the first {piece.size} samples of the same burst "
-                      f"stream ({fe_all_n} samples in {fe_all_dt:.1f} s); other legs ~{leg:.0f} s each",
+                      f"oracle/gr4pm_oracle.cpp, {cores} processes x passes over the first {min(x_host.size, 1 << 21)} "
+                      f"samples of the same burst stream ({fe_all_n} samples in {fe_all_dt:.1f} s); four more legs of "
+                      f"~{leg:.0f} s each",
             "front_end_one_core": round(fe_one, 3),
             "detector_one_core": round(det_one, 3),
             "detector_all_cores": round(det_all, 3),
