@@ -96,22 +96,21 @@ __device__ __forceinline__ void w64_pin4(cf* b)
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void w64_mid_pair(f2 a0r, f2 a1r, f2 a0i, f2 a1i, f2 tr, f2 ti, cf c, cf* b)
 {
-    f2 ur, ui, br, bi, t;
-    // ur = a0r + c.x a1r - c.y a1i ; ui = a0i + c.x a1i + c.y a1r   (c.x / c.y broadcast with op_sel)
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(t) : "v"(a1r), "v"(c), "v"(a0r));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0] neg_hi:[0,1,0]"
-        : "=v"(ur)
-        : "v"(a1i), "v"(c), "v"(t));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(t) : "v"(a1i), "v"(c), "v"(a0i));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(ui) : "v"(a1r), "v"(c), "v"(t));
-    // br = tr ur - ti ui ; bi = tr ui + ti ur
-    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(t) : "v"(tr), "v"(ur));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(br) : "v"(ti), "v"(ui), "v"(t));
-    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(t) : "v"(tr), "v"(ui));
-    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(bi) : "v"(ti), "v"(ur), "v"(t));
-    // (br.lo, bi.lo), (br.hi, bi.hi)
-    asm("v_pk_mov_b32 %0, %1, %2 op_sel:[0,0]" : "=v"(b[0]) : "v"(br), "v"(bi));
-    asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,1]" : "=v"(b[1]) : "v"(br), "v"(bi));
+    f2 ur, ui, br, bi, t0, t1;
+    // one statement (see cmul): ur = a0r + c.x a1r - c.y a1i ; ui = a0i + c.x a1i + c.y a1r (c.x / c.y broadcast with
+    // op_sel) ; br = tr ur - ti ui ; bi = tr ui + ti ur ; then (br.lo, bi.lo), (br.hi, bi.hi)
+    asm("v_pk_fma_f32 %4, %9, %14, %8 op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %5, %11, %14, %10 op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %0, %11, %14, %4 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %1, %9, %14, %5 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_mul_f32 %4, %12, %0\n\t"
+        "v_pk_mul_f32 %5, %12, %1\n\t"
+        "v_pk_fma_f32 %2, %13, %1, %4 neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 %3, %13, %0, %5\n\t"
+        "v_pk_mov_b32 %6, %2, %3 op_sel:[0,0]\n\t"
+        "v_pk_mov_b32 %7, %2, %3 op_sel:[1,1]"
+        : "=&v"(ur), "=&v"(ui), "=&v"(br), "=&v"(bi), "=&v"(t0), "=&v"(t1), "=&v"(b[0]), "=&v"(b[1])
+        : "v"(a0r), "v"(a1r), "v"(a0i), "v"(a1i), "v"(tr), "v"(ti), "v"(c));
 }
 
 template <int DEPTH, bool PACKED, bool FAKE = false>
@@ -265,10 +264,17 @@ __global__ __launch_bounds__(kW64Threads, 2) void k_correlate_w64(const cf* __re
                 for (int j = 0; j < 32; ++j) asm volatile("" ::"v"(bq[j]));
             } else {
 #pragma unroll
-                for (int j = 0; j < 32; ++j) {
-                    // hpp:307-308: the best bin's power (max() == the strict-> scan for the VALUE)
-                    const float pw = fmaf(bq[j].y, bq[j].y, bq[j].x * bq[j].x);
-                    asm("v_max_f32 %0, %1, %2" : "=v"(zmax[j]) : "v"(zmax[j]), "v"(pw));
+                for (int j0 = 0; j0 < 32; j0 += 8) {
+                    // hpp:307-308: the best bin's power (max() == the strict-> scan for the VALUE).  v_max_f32 in asm
+                    // (fmaxf adds a canonicalising second one), eight per statement (one boundary pad, not eight)
+                    float pw[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) pw[u] = fmaf(bq[j0 + u].y, bq[j0 + u].y, bq[j0 + u].x * bq[j0 + u].x);
+                    asm("v_max_f32 %0, %0, %8\n\tv_max_f32 %1, %1, %9\n\tv_max_f32 %2, %2, %10\n\tv_max_f32 %3, %3, %11\n\t"
+                        "v_max_f32 %4, %4, %12\n\tv_max_f32 %5, %5, %13\n\tv_max_f32 %6, %6, %14\n\tv_max_f32 %7, %7, %15"
+                        : "+v"(zmax[j0]), "+v"(zmax[j0 + 1]), "+v"(zmax[j0 + 2]), "+v"(zmax[j0 + 3]), "+v"(zmax[j0 + 4]),
+                          "+v"(zmax[j0 + 5]), "+v"(zmax[j0 + 6]), "+v"(zmax[j0 + 7])
+                        : "v"(pw[0]), "v"(pw[1]), "v"(pw[2]), "v"(pw[3]), "v"(pw[4]), "v"(pw[5]), "v"(pw[6]), "v"(pw[7]));
                 }
             }
         }

@@ -73,11 +73,14 @@ __device__ __forceinline__ cf sub_mj(cf b, cf a)
 // a * w = (a.x w.x - a.y w.y, a.x w.y + a.y w.x) for a run-time twiddle w
 __device__ __forceinline__ cf cmul(cf a, cf w)
 {
+    // ONE statement for the dependent pair: between two separate asm statements hipcc pads the dependency with
+    // an s_nop (it does not model what is inside an asm), and an s_nop costs a whole issue slot -- 80 of them per
+    // transform of the correlator; the hardware interlocks a VALU result by itself
     cf t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
-        : "=v"(r)
-        : "v"(a), "v"(w), "v"(t));
+    asm("v_pk_mul_f32 %1, %2, %3 op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+        : "=&v"(r), "=&v"(t)
+        : "v"(a), "v"(w));
     return r;
 }
 #else
