@@ -22,6 +22,14 @@
  *    out-of-place) is restated here as a Stockham radix-4 float32 FFT; raw FFT bits are
  *    NOT pinned by any reference test, so FFT-derived float values are compared with a
  *    tolerance while indices / freq_bin / pass-through are compared exactly.
+ *  - pinned by the restated tolerance bands of the reference's tests plus a reading of the reference code only
+ *    (no reference test or reference-built binary pins them more tightly): the bits of the FFT and of the
+ *    template spectra (the product computes its templates with a double-precision FFT rounded once: nothing
+ *    pins template bits), SymbolFilter WITH tags (arm selection, clock-phase special cases, tag re-timing:
+ *    symbol_filter.hpp:160-228), CoarseFrequencyCorrection with delay > 0, the float VALUES of the detector's
+ *    tags beyond the bands of qa_syncword_detection.cpp:121-147, PfbArbResampler with a float rate.
+ *  - CostasLoop's cosf / sinf are the host libm's: the product restates glibc's algorithm on the device and is
+ *    pinned against this libm for every float of the loop's phase range (tests/sincosf_glibc_check.c).
  *  - the gr::Block runtime (gnuradio4) is absent, so the reference blocks themselves
  *    cannot be built here without writing stand-ins: no reference block executable exists.
  */
