@@ -117,6 +117,14 @@ struct gr4pm_multichannel_receiver {
     gr4pm_status wstatus = GR4PM_OK;
     char werror[256] = { 0 };
 
+    // stage 2 as one launch per kernel: argument vectors of the ..._channels calls
+    bool per_channel_launches = false;
+    std::vector<gr4pm_symbol_filter*> v_symf;
+    std::vector<gr4pm_syncword_wipeoff*> v_wipe;
+    std::vector<const gr4pm_tag*> v_tags_in;
+    std::vector<gr4pm_tag*> v_tags_out;
+    std::vector<size_t> v_n_tags_in, v_n_tags_out, v_produced;
+
     gr4pm_status run_channel(Slot& s, size_t c);
     void worker(unsigned w);
     gr4pm_status stage1(Slot& s);
@@ -200,9 +208,33 @@ gr4pm_status gr4pm_multichannel_receiver::stage1(Slot& s)
                                                  s.all_tags.size(), &s.plan);
 }
 
-// stage 2: every channel's SymbolFilter (fused with its share of the CFC plan) + SyncwordWipeoff on the workers
+// stage 2: every channel's SymbolFilter (fused with its share of the CFC plan) + SyncwordWipeoff: ONE launch of
+// each kernel for all channels (per_channel_launches: on the workers, channel by channel -- GR4PM_MC_PER_CHANNEL=1,
+// kept for comparison: 64 channels of 2^22 items are 64 x 4 small kernels and 64 x 2 table uploads that way)
 gr4pm_status gr4pm_multichannel_receiver::stage2(Slot& s)
 {
+    if (!per_channel_launches) {
+        const size_t C = p.n_channels;
+        for (size_t c = 0; c < C; ++c) {
+            v_tags_in[c] = s.ch[c].tags.data();
+            v_n_tags_in[c] = s.ch[c].n_acc;
+            v_tags_out[c] = s.ch[c].sym_tags.data();
+        }
+        DeferredSyncScope defer;
+        GR4PM_TRY(gr4pm_cfc_symbol_filter_run_channels(cfc, s.plan, v_symf.data(), C, s.y.p, y_stride, s.consumed,
+                                                       s.symall.p, s.out_stride, v_tags_in.data(), v_n_tags_in.data(),
+                                                       v_tags_out.data(), s.ch[0].sym_tags.size(), v_n_tags_out.data(),
+                                                       v_produced.data()));
+        for (size_t c = 0; c < C; ++c) {
+            s.ch[c].n_sym_tags = v_n_tags_out[c];
+            s.ch[c].produced = v_produced[c];
+            v_tags_in[c] = s.ch[c].sym_tags.data();
+        }
+        GR4PM_TRY(gr4pm_syncword_wipeoff_process_channels(v_wipe.data(), C, s.symall.p, s.out_stride, v_produced.data(),
+                                                          v_tags_in.data(), v_n_tags_out.data()));
+        GR4PM_HIP_TRY(hipStreamSynchronize(streams[0]));
+        return GR4PM_OK;
+    }
     std::unique_lock<std::mutex> l(m);
     wstatus = GR4PM_OK;
     cur = &s;
@@ -342,6 +374,22 @@ gr4pm_status gr4pm_multichannel_receiver_create(const gr4pm_multichannel_receive
         if ((st = gr4pm_symbol_filter_create(&fsp, &ch.symf)) != GR4PM_OK) return bail(st);
         gr4pm_syncword_wipeoff_params wp{ bipolar, 64, s };
         if ((st = gr4pm_syncword_wipeoff_create(&wp, &ch.wipe)) != GR4PM_OK) return bail(st);
+    }
+    {
+        const char* e = getenv("GR4PM_MC_PER_CHANNEL");
+        h->per_channel_launches = e && e[0] == '1';
+        const size_t C = p->n_channels;
+        h->v_symf.resize(C);
+        h->v_wipe.resize(C);
+        for (size_t c = 0; c < C; ++c) {
+            h->v_symf[c] = h->chains[c].symf;
+            h->v_wipe[c] = h->chains[c].wipe;
+        }
+        h->v_tags_in.assign(C, nullptr);
+        h->v_tags_out.assign(C, nullptr);
+        h->v_n_tags_in.assign(C, 0);
+        h->v_n_tags_out.assign(C, 0);
+        h->v_produced.assign(C, 0);
     }
     h->y_stride = (p->max_items + 63) & ~size_t{ 63 };
     for (auto& sl : h->slots) {

@@ -854,7 +854,11 @@ gr4pm_status gr4pm_packet_receiver_create(const gr4pm_packet_receiver_params* p,
     if ((st = gr4pm_syncword_wipeoff_create(&wp, &h->wipe)) != GR4PM_OK) return bail(st);
     gr4pm_costas_loop_params cp{ 0.01, p->soft_bits ? 1 : p->costas_constellation, 1, h->streams[2] }; // :125
     if ((st = gr4pm_costas_loop_create(&cp, &h->costas)) != GR4PM_OK) return bail(st);
-    if (p->pipelined) (void)gr4pm_costas_loop_set_small_footprint(h->costas, 1); // it shares the GPU with the correlator
+    // Beside the round-1 correlator (2 x 232 VGPRs per SIMD) the 46-VGPR form of k_costas paid off; beside
+    // k_correlate_w64 (2 x 210) it does not: the Costas stage is the slowest stage of the pipeline, and its 40 waves
+    // cost the correlator 4 % of its SIMD slots at most.  GR4PM_COSTAS_SMALL=1 brings the small form back.
+    if (p->pipelined && getenv("GR4PM_COSTAS_SMALL") != nullptr)
+        (void)gr4pm_costas_loop_set_small_footprint(h->costas, 1);
     if (p->soft_bits) {
         gr4pm_payload_metadata_insert_params pp{ 64, 128, 0.02, 0.01, 0.005, h->streams[2] }; // :123-124
         if ((st = gr4pm_payload_metadata_insert_create(&pp, &h->pmi)) != GR4PM_OK) return bail(st);

@@ -501,8 +501,11 @@ struct SymRun {
     unsigned arm;
     float scale;
     unsigned wg0;   // first workgroup of the run (workgroups never straddle runs)
-    unsigned pad;
+    unsigned chan;  // channel of the run (launches that span channels: SymChan table)
 };
+#ifndef GR4PM_SYMF_ABL
+#define GR4PM_SYMF_ABL 0 // timing-only ablations of k_symbol_filter (wrong results): 1 no MACs, 2 no rotation, 3 no item loads
+#endif
 #ifndef GR4PM_SYM_PER_WG
 #define GR4PM_SYM_PER_WG 256
 #endif
@@ -520,7 +523,7 @@ struct SymWg {
     unsigned arm;
     float scale;
     unsigned seg;      // fused CFC: segment of max(lo_item, 0)
-    unsigned pad;
+    unsigned chan;     // index into the SymChan table (launches that span channels)
 };
 // Fused CoarseFrequencyCorrection: when the symbol filter is fed by a CFC block, the rotation
 // is applied while the filter stages its input (the rotated stream is never written to HBM).
@@ -531,6 +534,30 @@ struct CfcDev {
     const unsigned* seg_counter0;
     unsigned n_segs;
 };
+// One launch for every channel of a batch (gr4pm_cfc_symbol_filter_run_channels): what the single-channel launch
+// passes as kernel arguments comes from a table, indexed by the channel of the workgroup's run.
+struct SymChan {
+    const cf* in;
+    const cf* carry; // history of the channel's SymbolFilter (rotated items)
+    cf* carry_next;
+    cf* out;
+    const RotSeg* segs; // the channel's share of the CFC plan
+    const cf* seg_incr;
+    const unsigned* seg_counter0;
+    unsigned n_segs;
+    unsigned pad;
+    unsigned long long n; // items consumed by the channel in this call (history update)
+};
+__device__ __forceinline__ CfcDev chan_cfc(const SymChan& c, const cf* ck)
+{
+    CfcDev f;
+    f.segs = c.segs;
+    f.ck = ck;
+    f.seg_incr = c.seg_incr;
+    f.seg_counter0 = c.seg_counter0;
+    f.n_segs = c.n_segs;
+    return f;
+}
 __device__ __forceinline__ unsigned cfc_find_seg(const CfcDev& f, long long idx)
 {
     unsigned lo = 0, hi = f.n_segs - 1;
@@ -566,8 +593,21 @@ __global__ void k_update_hist_cfc(const cf* __restrict__ in, const cf* __restric
                             : cfc_item(f, in, idx, cfc_find_seg(f, idx));
 }
 
+// the same for every channel of a batched launch (blockIdx.y = channel)
+__global__ void k_update_hist_cfc_channels(const SymChan* __restrict__ chans, const cf* __restrict__ ck, unsigned cap)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap) return;
+    const SymChan c = chans[blockIdx.y];
+    if (c.n == 0) return;
+    const long long idx = static_cast<long long>(c.n) - cap + i;
+    const CfcDev f = chan_cfc(c, ck);
+    c.carry_next[i] = idx < 0 ? c.carry[static_cast<long long>(cap) + idx] : cfc_item(f, c.in, idx, cfc_find_seg(f, idx));
+}
+
 __global__ void k_symf_wg_plan(const SymRun* __restrict__ runs, unsigned n_runs, unsigned n_wg, unsigned sps,
-                               unsigned arm_size, CfcDev cfc, SymWg* __restrict__ plan)
+                               unsigned arm_size, CfcDev cfc, SymWg* __restrict__ plan,
+                               const SymChan* __restrict__ chans)
 {
     const unsigned w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= n_wg) return;
@@ -585,14 +625,11 @@ __global__ void k_symf_wg_plan(const SymRun* __restrict__ runs, unsigned n_runs,
     p.lo_item = r.in0 + static_cast<long long>(first) * sps - (arm_size - 1);
     p.arm = r.arm;
     p.scale = r.scale;
+    if (chans) cfc = chan_cfc(chans[r.chan], cfc.ck);
     p.seg = cfc.n_segs ? cfc_find_seg(cfc, p.lo_item) : 0u;
-    p.pad = 0;
+    p.chan = r.chan;
     plan[w] = p;
 }
-
-// LDS slot of raw (unrotated) item i of the span: one pad item per kRotChunk, so that lanes
-// reading one chunk each (stride 9 items = 18 words) do not collide
-__device__ __forceinline__ unsigned raw_slot(unsigned i) { return i + i / kRotChunk; }
 
 // SPS > 0: samples_per_symbol known at compile time (divisions become shifts / constants);
 // SPS == 0: run-time value.
@@ -601,12 +638,25 @@ __global__ __launch_bounds__(kSymPerWg) void k_symbol_filter(const T* __restrict
                                                        unsigned cap, const float* __restrict__ taps,
                                                        unsigned arm_size, unsigned sps_rt,
                                                        const SymWg* __restrict__ plan, T* __restrict__ out,
-                                                       CfcDev cfc)
+                                                       CfcDev cfc, const SymChan* __restrict__ chans)
 {
     extern __shared__ unsigned char s_raw[];
     T* tile = reinterpret_cast<T*>(s_raw);
     const unsigned sps = SPS > 0 ? static_cast<unsigned>(SPS) : sps_rt;
     const SymWg p = plan[blockIdx.x];
+#if GR4PM_SYMF_ABL == 4
+    if (threadIdx.x < p.count) out[p.o0 + threadIdx.x] = zero_item(T{});
+    return;
+#endif
+    if constexpr (CFC) {
+        if (chans) { // a launch that spans channels: the workgroup's channel supplies the pointers
+            const SymChan c = chans[p.chan];
+            in = c.in;
+            carry = c.carry;
+            out = c.out;
+            cfc = chan_cfc(c, cfc.ck);
+        }
+    }
     const unsigned span = (p.count - 1) * sps + arm_size;
     // tile is stored phase-major: item i lives at (i % sps) * pitch + i / sps, so that for a
     // fixed tap m the 64 lanes (items sps apart) read consecutive LDS words
@@ -615,16 +665,15 @@ __global__ __launch_bounds__(kSymPerWg) void k_symbol_filter(const T* __restrict
     float* s_arm = reinterpret_cast<float*>(tile + pitch * sps);
     for (unsigned m = threadIdx.x; m < arm_size; m += kSymPerWg) s_arm[m] = taps[static_cast<size_t>(p.arm) * arm_size + m];
     if constexpr (CFC) {
-        // 1. raw items, coalesced, into LDS (history items are stored rotated: straight to the tile)
-        cf* raw = reinterpret_cast<cf*>(s_arm + ((arm_size + 1) & ~1u));
-        for (unsigned i = threadIdx.x; i < span; i += kSymPerWg) {
-            const long long idx = p.lo_item + i;
-            if (idx < 0) tile[(i % sps) * pitch + i / sps] = carry[static_cast<long long>(cap) + idx];
-            else raw[raw_slot(i)] = in[idx];
-        }
-        __syncthreads();
-        // 2. one lane per checkpoint chunk: the phasor recurrence of the chunk is replayed once
-        //    (kRotChunk-1 steps for kRotChunk items), segment by segment (usually one)
+        // 1. history items are stored rotated: straight to the tile
+        if (p.lo_item < 0)
+            for (unsigned i = threadIdx.x; i < span && p.lo_item + i < 0; i += kSymPerWg)
+                tile[(i % sps) * pitch + i / sps] = carry[static_cast<long long>(cap) + p.lo_item + i];
+        // 2. one lane per checkpoint chunk: the lane reads its kRotChunk raw items (64 contiguous bytes) straight
+        //    from global memory, replays the phasor recurrence of the chunk once (kRotChunk-1 steps for kRotChunk
+        //    items) and writes the rotated items to the tile; segment by segment (usually one).  No staging of the
+        //    raw items in LDS: half the LDS footprint, one barrier and one global-memory latency less per workgroup
+        //    (the checkpoint load used to wait behind the staged items' barrier).
         const long long lo = p.lo_item < 0 ? 0 : p.lo_item;
         const long long hi = p.lo_item + span;
         for (unsigned sg = p.seg; sg < cfc.n_segs; ++sg) {
@@ -647,11 +696,22 @@ __global__ __launch_bounds__(kSymPerWg) void k_symbol_filter(const T* __restrict
                         // whole chunk inside the span and no renormalisation among its 7 steps (the
                         // usual case): straight-line packed arithmetic, same operations as below
                         const unsigned i0 = static_cast<unsigned>(idx0 - p.lo_item);
+                        cf x[kRotChunk];
+#pragma unroll
+#if GR4PM_SYMF_ABL == 3
+                        for (unsigned t = 0; t < kRotChunk; ++t) x[t] = e;
+#else
+                        for (unsigned t = 0; t < kRotChunk; ++t) x[t] = in[idx0 + t];
+#endif
 #pragma unroll
                         for (unsigned t = 0; t < kRotChunk; ++t) {
                             const unsigned i = i0 + t;
-                            tile[(i % sps) * pitch + i / sps] = cmul_pk(raw[raw_slot(i)], e); // hpp:87
+#if GR4PM_SYMF_ABL == 2
+                            tile[(i % sps) * pitch + i / sps] = x[t];
+#else
+                            tile[(i % sps) * pitch + i / sps] = cmul_pk(x[t], e); // hpp:87
                             if (t + 1 < kRotChunk) e = cmul_pk(e, inc);
+#endif
                         }
                         continue;
                     }
@@ -660,7 +720,7 @@ __global__ __launch_bounds__(kSymPerWg) void k_symbol_filter(const T* __restrict
                         const long long idx = idx0 + t;
                         if (idx >= a && idx < b) {
                             const unsigned i = static_cast<unsigned>(idx - p.lo_item);
-                            tile[(i % sps) * pitch + i / sps] = cmul(raw[raw_slot(i)], e); // hpp:87
+                            tile[(i % sps) * pitch + i / sps] = cmul(in[idx], e); // hpp:87
                         }
                         if (t + 1 < kRotChunk) rot_step(e, inc, counter);
                     }
@@ -677,10 +737,14 @@ __global__ __launch_bounds__(kSymPerWg) void k_symbol_filter(const T* __restrict
         // tile index of tap m of this symbol: tid * sps + j with j = arm_size - 1 - m;
         // j % sps and j / sps are the same for every thread
         T acc = zero_item(T{});
+#if GR4PM_SYMF_ABL == 1
+        acc = tile[threadIdx.x];
+#else
         for (unsigned m = 0; m < arm_size; ++m) {
             const unsigned j = arm_size - 1 - m;
             acc = mac(acc, s_arm[m], tile[(j % sps) * pitch + j / sps + threadIdx.x]);
         }
+#endif
         out[p.o0 + threadIdx.x] = scale_item(p.scale, acc);
     }
 }
@@ -688,23 +752,24 @@ __global__ __launch_bounds__(kSymPerWg) void k_symbol_filter(const T* __restrict
 template <typename T, bool CFC>
 static void launch_symbol_filter(hipStream_t s, unsigned n_wg, size_t smem, unsigned sps, const T* in,
                                  const T* carry, unsigned cap, const float* taps, unsigned arm_size,
-                                 const SymRun* runs, unsigned n_runs, SymWg* plan, T* out, CfcDev cfc)
+                                 const SymRun* runs, unsigned n_runs, SymWg* plan, T* out, CfcDev cfc,
+                                 const SymChan* chans = nullptr)
 {
     const dim3 grid(n_wg), block(kSymPerWg);
     hipLaunchKernelGGL(k_symf_wg_plan, dim3((n_wg + 255) / 256), dim3(256), 0, s, runs, n_runs, n_wg, sps, arm_size,
-                       cfc, plan);
+                       cfc, plan, chans);
     if (sps == 4)
         hipLaunchKernelGGL((k_symbol_filter<T, 4, CFC>), grid, block, smem, s, in, carry, cap, taps, arm_size, sps,
-                           plan, out, cfc);
+                           plan, out, cfc, chans);
     else if (sps == 2)
         hipLaunchKernelGGL((k_symbol_filter<T, 2, CFC>), grid, block, smem, s, in, carry, cap, taps, arm_size, sps,
-                           plan, out, cfc);
+                           plan, out, cfc, chans);
     else if (sps == 8)
         hipLaunchKernelGGL((k_symbol_filter<T, 8, CFC>), grid, block, smem, s, in, carry, cap, taps, arm_size, sps,
-                           plan, out, cfc);
+                           plan, out, cfc, chans);
     else
         hipLaunchKernelGGL((k_symbol_filter<T, 0, CFC>), grid, block, smem, s, in, carry, cap, taps, arm_size, sps,
-                           plan, out, cfc);
+                           plan, out, cfc, chans);
 }
 
 // PfbArbResampler (pfb_arb_resampler.hpp:134-167).  The accumulator recurrence decides which
@@ -818,6 +883,10 @@ struct gr4pm_rotator {
     } plans[GR4PM_CFC_PLANS];
     int plan_cur = 0;
     bool ring_sized = false;
+    // gr4pm_cfc_symbol_filter_run_channels: channel table + runs of all channels (one upload), workgroup plan
+    DevBuf<unsigned long long> mc_tab;
+    DevBuf<SymWg> mc_wg;
+    std::vector<unsigned long long> mc_host;
     std::vector<float> next_freq;     // per channel, coarse_frequency_correction.hpp:44
     std::vector<long> next_freq_delay; // :45
 };
@@ -1354,6 +1423,41 @@ gr4pm_status gr4pm_syncword_wipeoff_reset(gr4pm_syncword_wipeoff* h)
     return GR4PM_OK;
 }
 
+} // extern "C"
+
+// replay of syncword_wipeoff.hpp:53-75 over the tag list of one call: the spans of the syncword inside it
+// (base: offset of the channel's item 0 in the buffer the kernel indexes)
+static void wipe_replay(gr4pm_syncword_wipeoff* h, size_t n, const gr4pm_tag* tags, size_t n_tags, size_t base,
+                        std::vector<WipeSpan>& spans)
+{
+    size_t pos = 0, t = 0;
+    const size_t L = h->syncword.size();
+    while (pos < n) {
+        while (t < n_tags && tags[t].index < pos) ++t;
+        const bool has_tag = t < n_tags && tags[t].index == pos && (tags[t].flags & GR4PM_TAG_SYNCWORD);
+        if (!h->in_syncword && has_tag) {
+            h->in_syncword = true;
+            h->position = 0;
+        }
+        size_t end = n;
+        for (size_t u = t; u < n_tags; ++u)
+            if (tags[u].index > pos) {
+                end = std::min<size_t>(end, tags[u].index);
+                break;
+            }
+        if (h->in_syncword) {
+            const size_t m = std::min(end - pos, L - h->position);
+            spans.push_back({ base + pos, static_cast<unsigned>(h->position), static_cast<unsigned>(m) });
+            h->position += m;
+            if (h->position == L) h->in_syncword = false;
+        }
+        pos = end;
+        if (t < n_tags && tags[t].index < pos) ++t;
+    }
+}
+
+extern "C" {
+
 gr4pm_status gr4pm_sincosf(const float* x, size_t n, float* sin_out, float* cos_out)
 {
     if (!x || !sin_out || !cos_out) return GR4PM_ERR_INVALID;
@@ -1375,32 +1479,8 @@ gr4pm_status gr4pm_syncword_wipeoff_process(gr4pm_syncword_wipeoff* h, const gr4
         set_error("null sample pointer");
         return GR4PM_ERR_INVALID;
     }
-    // replay syncword_wipeoff.hpp:53-75 over the tag list
     std::vector<WipeSpan> spans;
-    size_t pos = 0, t = 0;
-    const size_t L = h->syncword.size();
-    while (pos < n) {
-        while (t < n_tags && tags[t].index < pos) ++t;
-        const bool has_tag = t < n_tags && tags[t].index == pos && (tags[t].flags & GR4PM_TAG_SYNCWORD);
-        if (!h->in_syncword && has_tag) {
-            h->in_syncword = true;
-            h->position = 0;
-        }
-        size_t end = n;
-        for (size_t u = t; u < n_tags; ++u)
-            if (tags[u].index > pos) {
-                end = std::min<size_t>(end, tags[u].index);
-                break;
-            }
-        if (h->in_syncword) {
-            const size_t m = std::min(end - pos, L - h->position);
-            spans.push_back({ pos, static_cast<unsigned>(h->position), static_cast<unsigned>(m) });
-            h->position += m;
-            if (h->position == L) h->in_syncword = false;
-        }
-        pos = end;
-        if (t < n_tags && tags[t].index < pos) ++t;
-    }
+    wipe_replay(h, n, tags, n_tags, 0, spans);
     hipStream_t s = h->stream;
     if (in != out) // in place: only the syncword spans are touched
         hipLaunchKernelGGL(k_copy<cf>, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s,
@@ -1409,6 +1489,34 @@ gr4pm_status gr4pm_syncword_wipeoff_process(gr4pm_syncword_wipeoff* h, const gr4
         GR4PM_TRY(upload_vec(h->spans, spans, s));
         hipLaunchKernelGGL(k_wipe, dim3(static_cast<unsigned>(spans.size())), dim3(64), 0, s, h->spans.p,
                            h->d_syncword.p, reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(out));
+    }
+    GR4PM_HIP_TRY(hipGetLastError());
+    GR4PM_HIP_TRY(final_sync(s));
+    return GR4PM_OK;
+}
+
+gr4pm_status gr4pm_syncword_wipeoff_process_channels(gr4pm_syncword_wipeoff* const* h, size_t n_channels,
+                                                     gr4pm_c64* buf, size_t stride, const size_t* n,
+                                                     const gr4pm_tag* const* tags, const size_t* n_tags)
+{
+    if (!h || n_channels == 0 || !n || !tags || !n_tags) return GR4PM_ERR_INVALID;
+    if (!buf) {
+        set_error("null sample pointer");
+        return GR4PM_ERR_INVALID;
+    }
+    std::vector<WipeSpan> spans;
+    for (size_t c = 0; c < n_channels; ++c) {
+        if (!h[c] || h[c]->syncword != h[0]->syncword || n[c] > stride) {
+            set_error("a launch that spans channels needs wipe-off blocks of one syncword and n <= stride");
+            return GR4PM_ERR_INVALID;
+        }
+        wipe_replay(h[c], n[c], tags[c], n_tags[c], c * stride, spans);
+    }
+    hipStream_t s = h[0]->stream;
+    if (!spans.empty()) {
+        GR4PM_TRY(upload_vec(h[0]->spans, spans, s));
+        hipLaunchKernelGGL(k_wipe, dim3(static_cast<unsigned>(spans.size())), dim3(64), 0, s, h[0]->spans.p,
+                           h[0]->d_syncword.p, reinterpret_cast<const cf*>(buf), reinterpret_cast<cf*>(buf));
     }
     GR4PM_HIP_TRY(hipGetLastError());
     GR4PM_HIP_TRY(final_sync(s));
@@ -1811,25 +1919,23 @@ gr4pm_status gr4pm_symbol_filter_reset(gr4pm_symbol_filter* h)
 
 } // extern "C"
 
-// fuse == nullptr: plain SymbolFilter.  Otherwise the input is rotated by the CFC plan on the fly.
-static gr4pm_status symbol_filter_impl(gr4pm_symbol_filter* h, const void* in, size_t n_in, void* out,
-                                       size_t out_cap, const gr4pm_tag* tags_in, size_t n_tags_in,
-                                       gr4pm_tag* tags_out, size_t tags_cap, size_t* n_tags_out,
-                                       size_t* consumed_, size_t* produced_, const CfcDev* fuse)
-{
-    if (!h || !consumed_ || !produced_) return GR4PM_ERR_INVALID;
-    *consumed_ = *produced_ = 0;
-    if (n_tags_out) *n_tags_out = 0;
-    if (n_in == 0) return GR4PM_OK; // nothing consumed, nothing produced, queued tags keep waiting
-    if (!in || !out) {
-        set_error("null sample pointer");
-        return GR4PM_ERR_INVALID;
-    }
-    const size_t sps = h->sps;
-    const long half = static_cast<long>(sps / 2);
+// Host replay of the tag-driven state machine of symbol_filter.hpp:130-238 over one call: which outputs exist, from
+// which input, with which arm and scale (runs), and where the tags leave.
+struct SymReplay {
     std::vector<SymRun> runs;
     size_t pos = 0, produced = 0, n_pub = 0;
     bool tag_overflow = false;
+};
+static void symf_replay(gr4pm_symbol_filter* h, size_t n_in, size_t out_cap, const gr4pm_tag* tags_in,
+                        size_t n_tags_in, gr4pm_tag* tags_out, size_t tags_cap, SymReplay& rp)
+{
+    const size_t sps = h->sps;
+    const long half = static_cast<long>(sps / 2);
+    std::vector<SymRun>& runs = rp.runs;
+    size_t& pos = rp.pos;
+    size_t& produced = rp.produced;
+    size_t& n_pub = rp.n_pub;
+    bool& tag_overflow = rp.tag_overflow;
     auto publish = [&](const gr4pm_tag& t, size_t out_index) {
         if (tags_out && n_pub < tags_cap) {
             tags_out[n_pub] = t;
@@ -1938,23 +2044,44 @@ static gr4pm_status symbol_filter_impl(gr4pm_symbol_filter* h, const void* in, s
         }
         if (produced >= out_cap && pos < n_in) full = true;
     }
+}
+
+// fuse == nullptr: plain SymbolFilter.  Otherwise the input is rotated by the CFC plan on the fly.
+static gr4pm_status symbol_filter_impl(gr4pm_symbol_filter* h, const void* in, size_t n_in, void* out,
+                                       size_t out_cap, const gr4pm_tag* tags_in, size_t n_tags_in,
+                                       gr4pm_tag* tags_out, size_t tags_cap, size_t* n_tags_out,
+                                       size_t* consumed_, size_t* produced_, const CfcDev* fuse)
+{
+    if (!h || !consumed_ || !produced_) return GR4PM_ERR_INVALID;
+    *consumed_ = *produced_ = 0;
+    if (n_tags_out) *n_tags_out = 0;
+    if (n_in == 0) return GR4PM_OK; // nothing consumed, nothing produced, queued tags keep waiting
+    if (!in || !out) {
+        set_error("null sample pointer");
+        return GR4PM_ERR_INVALID;
+    }
+    const size_t sps = h->sps;
+    SymReplay rp;
+    symf_replay(h, n_in, out_cap, tags_in, n_tags_in, tags_out, tags_cap, rp);
+    std::vector<SymRun>& runs = rp.runs;
+    const size_t pos = rp.pos, produced = rp.produced, n_pub = rp.n_pub;
+    const bool tag_overflow = rp.tag_overflow;
     hipStream_t s = h->stream;
     if (!runs.empty()) {
         unsigned n_wg = 0;
         for (auto& r : runs) { // workgroups never straddle runs
             r.wg0 = n_wg;
-            r.pad = 0;
+            r.chan = 0;
             n_wg += (r.count + kSymPerWg - 1u) / kSymPerWg;
         }
         GR4PM_TRY(upload_vec(h->runs, runs, s));
         const size_t pitch = (kSymPerWg * sps + h->arm_size) / sps + 2;
         if (h->wg_plan.n < n_wg) GR4PM_TRY(h->wg_plan.alloc(static_cast<size_t>(n_wg) * 2));
-        const size_t span_max = (kSymPerWg - 1) * sps + h->arm_size;
         const size_t arm_bytes = ((h->arm_size + 1) & ~size_t{ 1 }) * sizeof(float);
         const unsigned n_runs = static_cast<unsigned>(runs.size());
         if (fuse)
             launch_symbol_filter<cf, true>(
-                s, n_wg, pitch * sps * sizeof(cf) + arm_bytes + (span_max + span_max / kRotChunk + 2) * sizeof(cf),
+                s, n_wg, pitch * sps * sizeof(cf) + arm_bytes,
                 static_cast<unsigned>(sps), static_cast<const cf*>(in),
                 reinterpret_cast<const cf*>(h->carry[h->cur].p), h->cap, h->taps.p,
                 static_cast<unsigned>(h->arm_size), h->runs.p, n_runs, h->wg_plan.p, static_cast<cf*>(out), *fuse);
@@ -2103,6 +2230,115 @@ gr4pm_status gr4pm_cfc_symbol_filter_run_channel(gr4pm_rotator* cfc, int plan, s
         return GR4PM_ERR_INVALID;
     }
     return st;
+}
+
+gr4pm_status gr4pm_cfc_symbol_filter_run_channels(gr4pm_rotator* cfc, int plan, gr4pm_symbol_filter* const* sf,
+                                                  size_t n_channels, const gr4pm_c64* in, size_t in_stride, size_t n_in,
+                                                  gr4pm_c64* out, size_t out_stride, const gr4pm_tag* const* tags_in,
+                                                  const size_t* n_tags_in, gr4pm_tag* const* tags_out, size_t tags_cap,
+                                                  size_t* n_tags_out, size_t* produced)
+{
+    if (!cfc || !sf || !n_tags_in || !tags_in || !tags_out || !n_tags_out || !produced || n_channels == 0)
+        return GR4PM_ERR_INVALID;
+    for (size_t c = 0; c < n_channels; ++c) n_tags_out[c] = produced[c] = 0;
+    if (n_in == 0) return GR4PM_OK;
+    if (plan < 0 || plan >= GR4PM_CFC_PLANS || cfc->plans[plan].n_in != n_in) {
+        set_error("no rotation plan for this call");
+        return GR4PM_ERR_INVALID;
+    }
+    const auto& pl = cfc->plans[plan];
+    if (n_channels != cfc->n_channels || pl.seg_first.size() != cfc->n_channels + 1) {
+        set_error("the rotation plan has %zu channels, the call %zu", cfc->n_channels, n_channels);
+        return GR4PM_ERR_INVALID;
+    }
+    if (!in || !out || in_stride < n_in) {
+        set_error("null sample pointer or in_stride < n_in");
+        return GR4PM_ERR_INVALID;
+    }
+    gr4pm_symbol_filter* h0 = sf[0];
+    size_t max_tags = 0;
+    for (size_t c = 0; c < n_channels; ++c) {
+        const gr4pm_symbol_filter* h = sf[c];
+        if (!h || h->item_kind != 0 || h->sps != h0->sps || h->arm_size != h0->arm_size || h->cap != h0->cap ||
+            h->num_arms != h0->num_arms) {
+            set_error("a launch that spans channels needs complex SymbolFilters of one design");
+            return GR4PM_ERR_INVALID;
+        }
+        max_tags = std::max(max_tags, n_tags_in[c]);
+    }
+    // the rotation plan covers all n_in items, so every filter must be able to consume them all
+    if (out_stride < n_in / h0->sps + max_tags + 2) {
+        set_error("out_stride too small for a fused call");
+        return GR4PM_INSUFFICIENT_OUTPUT_ITEMS;
+    }
+    // host replay per channel; the runs of all channels in one table
+    static_assert(sizeof(SymChan) % 8 == 0 && sizeof(SymRun) % 8 == 0, "table layout");
+    std::vector<SymChan> chans(n_channels);
+    std::vector<SymRun> runs;
+    unsigned n_wg = 0;
+    bool overflow = false;
+    for (size_t c = 0; c < n_channels; ++c) {
+        gr4pm_symbol_filter* h = sf[c];
+        SymReplay rp;
+        symf_replay(h, n_in, out_stride, tags_in[c], n_tags_in[c], tags_out[c], tags_cap, rp);
+        if (rp.pos != n_in) {
+            set_error("fused call consumed %zu of %zu items (channel %zu)", rp.pos, n_in, c);
+            return GR4PM_ERR_INVALID;
+        }
+        overflow |= rp.tag_overflow;
+        for (auto& r : rp.runs) { // workgroups never straddle runs
+            r.wg0 = n_wg;
+            r.chan = static_cast<unsigned>(c);
+            n_wg += (r.count + kSymPerWg - 1u) / kSymPerWg;
+            runs.push_back(r);
+        }
+        const unsigned first = pl.seg_first[c];
+        SymChan& d = chans[c];
+        d.in = reinterpret_cast<const cf*>(in) + c * in_stride;
+        d.carry = reinterpret_cast<const cf*>(h->carry[h->cur].p);
+        d.carry_next = reinterpret_cast<cf*>(h->carry[h->cur ^ 1].p);
+        d.out = reinterpret_cast<cf*>(out) + c * out_stride;
+        d.segs = pl.segs.p + first;
+        d.seg_incr = pl.seg_incr.p + first;
+        d.seg_counter0 = pl.seg_counter0.p + first;
+        d.n_segs = pl.seg_first[c + 1] - first;
+        d.pad = 0;
+        d.n = rp.pos;
+        h->cur ^= 1;
+        produced[c] = rp.produced;
+        n_tags_out[c] = rp.n_pub;
+    }
+    hipStream_t s = h0->stream;
+    const size_t chan_words = n_channels * sizeof(SymChan) / 8, run_words = runs.size() * sizeof(SymRun) / 8;
+    cfc->mc_host.resize(chan_words + run_words);
+    std::memcpy(cfc->mc_host.data(), chans.data(), chan_words * 8);
+    if (run_words) std::memcpy(cfc->mc_host.data() + chan_words, runs.data(), run_words * 8);
+    GR4PM_TRY(upload_vec(cfc->mc_tab, cfc->mc_host, s));
+    const SymChan* d_chans = reinterpret_cast<const SymChan*>(cfc->mc_tab.p);
+    const SymRun* d_runs = reinterpret_cast<const SymRun*>(cfc->mc_tab.p + chan_words);
+    CfcDev f{};
+    f.ck = pl.ck.p;
+    f.n_segs = 1; // per channel from the table
+    if (n_wg) {
+        if (cfc->mc_wg.n < n_wg) GR4PM_TRY(cfc->mc_wg.alloc(static_cast<size_t>(n_wg) * 2));
+        const size_t sps = h0->sps;
+        const size_t pitch = (kSymPerWg * sps + h0->arm_size) / sps + 2;
+        const size_t arm_bytes = ((h0->arm_size + 1) & ~size_t{ 1 }) * sizeof(float);
+        launch_symbol_filter<cf, true>(
+            s, n_wg, pitch * sps * sizeof(cf) + arm_bytes,
+            static_cast<unsigned>(sps), static_cast<const cf*>(nullptr), static_cast<const cf*>(nullptr), h0->cap,
+            h0->taps.p, static_cast<unsigned>(h0->arm_size), d_runs, static_cast<unsigned>(runs.size()), cfc->mc_wg.p,
+            static_cast<cf*>(nullptr), f, d_chans);
+    }
+    hipLaunchKernelGGL(k_update_hist_cfc_channels, dim3((h0->cap + 63) / 64, static_cast<unsigned>(n_channels)),
+                       dim3(64), 0, s, d_chans, pl.ck.p, h0->cap);
+    GR4PM_HIP_TRY(hipGetLastError());
+    GR4PM_HIP_TRY(final_sync(s));
+    if (overflow) {
+        set_error("tags_cap too small");
+        return GR4PM_ERR_OVERFLOW;
+    }
+    return GR4PM_OK;
 }
 
 gr4pm_status gr4pm_cfc_symbol_filter_process(gr4pm_rotator* cfc, gr4pm_symbol_filter* sf, const gr4pm_c64* in,

@@ -604,6 +604,87 @@ __global__ __launch_bounds__(256) void k_candidates(const float* __restrict__ zb
     }
 }
 
+// The same flags WITHOUT LDS, for T = 64 TQ (the default 768 = 12 x 64): k_candidates wants 20 KiB of LDS per
+// workgroup and therefore only gets a CU between two correlator workgroups (151 KiB each) -- behind the
+// look-ahead it ran 4x slower than alone and stretched the correlator with it.  Here one wave walks `chain`
+// consecutive T-item blocks with everything in registers (van Herk / Gil-Werman with block size T):
+//     max(z[p+1 .. p+T]) = max( suffix maximum of p's block from p+1,  prefix maximum of the next block up to p+T )
+// and p+T has the same offset in the next block as p in its own, i.e. the same lane and register.
+// Item i of a block <-> register i / 64, lane 63 - i % 64 (lanes reversed, so that the suffix inside a row is a
+// DPP prefix over lanes and "the item after mine" is wave_shr:1); rows are coalesced 256-byte loads.
+// Per block and wave: TQ loads, 2 TQ DPP scans, 2 TQ ds_bpermute (crossbar only, no LDS allocation), TQ ballots.
+template <int TQ>
+__global__ __launch_bounds__(64) void k_candidates_wave(const float* __restrict__ zbase, size_t z_stride, uint32_t cnt,
+                                                        uint32_t n_words, uint32_t chain,
+                                                        unsigned long long* __restrict__ bitmap, size_t bm_stride)
+{
+    constexpr uint32_t T = TQ * 64;
+    const int lane = threadIdx.x, rl = 63 - lane;
+    const float* z = zbase + static_cast<size_t>(blockIdx.y) * z_stride;
+    unsigned long long* bmp = bitmap + static_cast<size_t>(blockIdx.y) * bm_stride;
+    const uint32_t avail = cnt + T; // readable items
+    const uint32_t n_blk = (n_words + TQ - 1) / TQ;
+    const uint32_t b0 = blockIdx.x * chain;
+    if (b0 >= n_blk) return;
+    const uint32_t b1 = min(b0 + chain, n_blk);
+    auto load = [&](uint32_t b, float* v) {
+#pragma unroll
+        for (int r = 0; r < TQ; ++r) {
+            const uint32_t g = b * T + 64u * r + rl;
+            v[r] = g < avail ? z[g] : -INFINITY;
+        }
+    };
+    // per block: rs[r] = suffix maximum inside row r (inclusive, reversed lanes), after[r] = maximum of the rows
+    // behind r (uniform), pr[r] = prefix maximum of the block up to the lane's item (inclusive, reversed lanes)
+    auto scans = [&](const float* v, float* rs, float* after, float* pr) {
+        float rowmax[TQ];
+#pragma unroll
+        for (int r = 0; r < TQ; ++r) {
+            rs[r] = wave_prefix_max(v[r]);
+            rowmax[r] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rs[r]), 63));
+        }
+        float a = -INFINITY;
+#pragma unroll
+        for (int r = TQ - 1; r >= 0; --r) {
+            after[r] = a;
+            a = fmaxf(a, rowmax[r]);
+        }
+        float carry = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < TQ; ++r) {
+            const float fwd = __shfl(v[r], rl);                 // row in item order
+            const float pn = fmaxf(wave_prefix_max(fwd), carry); // prefix of the block, item order
+            pr[r] = __shfl(pn, rl);
+            carry = fmaxf(carry, rowmax[r]);
+        }
+    };
+    float cur[TQ], rs[TQ], after[TQ], pr[TQ], nxt[TQ];
+    load(b0, cur);
+    scans(cur, rs, after, pr);
+    for (uint32_t b = b0; b < b1; ++b) {
+        load(b + 1, nxt);
+        float nrs[TQ], nafter[TQ], npr[TQ];
+        scans(nxt, nrs, nafter, npr);
+        unsigned long long mine = 0;
+#pragma unroll
+        for (int r = 0; r < TQ; ++r) {
+            const float m = fmaxf(fmaxf(wave_prev(rs[r]), after[r]), npr[r]);
+            const uint32_t pos = b * T + 64u * r + rl;
+            const unsigned long long word = __brevll(__ballot(pos < cnt && cur[r] >= m)); // back to item order
+            if (lane == r) mine = word;
+        }
+        const uint32_t w = b * TQ + lane;
+        if (lane < TQ && w < n_words) bmp[w] = mine;
+#pragma unroll
+        for (int r = 0; r < TQ; ++r) {
+            cur[r] = nxt[r];
+            rs[r] = nrs[r];
+            after[r] = nafter[r];
+        }
+    }
+}
+
+
 // first set bit at local position >= r and < hi, or hi if none
 __device__ __forceinline__ uint32_t next_candidate(const unsigned long long* bm, uint32_t r, uint32_t hi)
 {
@@ -1435,6 +1516,7 @@ struct gr4pm_syncword_detection {
     DevBuf<cf> tw; // tw1a ++ tw1b ++ twA ++ twB (fft2048_wave.hpp)
     // the one-exchange correlator (fft2048_w64.hpp, k_correlate_w64): templates in its lane order
     // ([bin][16][64] float4), mid-stage twiddle table, lane constants
+    bool lds_candidates = false; // GR4PM_CANDIDATES_LDS at creation: k_candidates also for T = 768
     int corr_kind = 0; // 0: k_correlate_w64 (default), 1: k_correlate (two exchanges), 2: k_correlate_pair
     DevBuf<float4> tmpl64, tT64;
     DevBuf<cf> td; // [bin][L] conj of the float time-domain templates (hpp:166-182): k_tags' direct correlation
@@ -1663,7 +1745,8 @@ gr4pm_status launch_front(gr4pm_syncword_detection* h, hipStream_t stream, int w
     // and the candidate / table kernels
     GR4PM_TRY(launch_correlate(h, stream, in, in_stride, n_blocks, zw + h->zc));
     const bool ahead = stream != h->stream;
-    if (ahead) {
+    static const bool one_front_stream = getenv("GR4PM_SD_FRONT_ONE_STREAM") != nullptr;
+    if (ahead && !one_front_stream) {
         GR4PM_HIP_TRY(hipEventRecord(h->ev_mid[which], stream));
         stream = h->stream3;
         GR4PM_HIP_TRY(hipStreamWaitEvent(stream, h->ev_mid[which], 0));
@@ -1688,8 +1771,15 @@ gr4pm_status launch_front(gr4pm_syncword_detection* h, hipStream_t stream, int w
     const float* zloc = zw + h->zc - static_cast<ptrdiff_t>(E0 - A0);
     const uint32_t n_wg = (cnt + kCandTile - 1) / kCandTile;
     const size_t smem = (static_cast<size_t>(kCandBlocks + (T >> 6) + 2) * 65 + kCandBlocks) * sizeof(float);
-    hipLaunchKernelGGL(k_candidates, dim3(n_wg, nch), dim3(256), smem, stream, zloc, h->z_stride, cnt, T,
-                       h->bitmap[which].p, h->bm_stride);
+    if (T == 768 && !h->lds_candidates) { // the LDS-free form: runs beside the correlator's workgroups
+        constexpr uint32_t kChain = 8;
+        const uint32_t n_words = n_wg * (kCandTile / 64), n_blk = (n_words + 11) / 12;
+        hipLaunchKernelGGL(k_candidates_wave<12>, dim3((n_blk + kChain - 1) / kChain, nch), dim3(64), 0, stream, zloc,
+                           h->z_stride, cnt, n_words, kChain, h->bitmap[which].p, h->bm_stride);
+    } else {
+        hipLaunchKernelGGL(k_candidates, dim3(n_wg, nch), dim3(256), smem, stream, zloc, h->z_stride, cnt, T,
+                           h->bitmap[which].p, h->bm_stride);
+    }
     const uint32_t n_tiles = (cnt + kTileW - 1) / kTileW;
     hipLaunchKernelGGL(k_tile_tables, dim3(n_tiles, nch), dim3(64), 0, stream, h->bitmap[which].p, h->bm_stride,
                        cnt, T, n_tiles, h->table[which].p, h->table_stride);
@@ -1917,6 +2007,7 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
     ok(h->fault.alloc(1));
     if (h->fault.p) *h->fault.p = 0;
     if (const char* e = getenv("GR4PM_TEST_SPIN_LIMIT")) h->spin_limit = atoi(e); // tests force a timeout with 0
+    h->lds_candidates = getenv("GR4PM_CANDIDATES_LDS") != nullptr;
     ok(h->tmpl64.alloc(tmpl64.size()));
     ok(h->tT64.alloc(tT64.size()));
     ok(h->td.alloc(td.size()));

@@ -264,6 +264,11 @@ gr4pm_status gr4pm_syncword_wipeoff_reset(gr4pm_syncword_wipeoff* h);
 gr4pm_status gr4pm_syncword_wipeoff_process(gr4pm_syncword_wipeoff* h, const gr4pm_c64* in,
                                             size_t n, gr4pm_c64* out, const gr4pm_tag* tags,
                                             size_t n_tags);
+/* many channels, in place, one launch: h[c] is channel c's block (one syncword for all), its items are
+ * buf[c * stride .. c * stride + n[c]), its tags tags[c][0 .. n_tags[c]).  Runs on h[0]'s stream. */
+gr4pm_status gr4pm_syncword_wipeoff_process_channels(gr4pm_syncword_wipeoff* const* h, size_t n_channels,
+                                                     gr4pm_c64* buf, size_t stride, const size_t* n,
+                                                     const gr4pm_tag* const* tags, const size_t* n_tags);
 
 /* ------------------------------------------------------------------------------------
  * InterpolatingFirFilter<TIn,TOut,float> -- interpolating_fir_filter.hpp:14-103
@@ -341,6 +346,17 @@ gr4pm_status gr4pm_cfc_symbol_filter_run_channel(gr4pm_rotator* cfc, int plan, s
                                                  gr4pm_c64* out, size_t out_cap, const gr4pm_tag* tags_in,
                                                  size_t n_tags_in, gr4pm_tag* tags_out, size_t tags_cap,
                                                  size_t* n_tags_out, size_t* consumed, size_t* produced);
+/* ... or ALL channels in ONE launch of the filter kernel (64 channels of 2^22 items are 64 small launches
+ * otherwise): sf[c] is channel c's SymbolFilter (one design for all; its tag-driven state is replayed on the
+ * host exactly as by _run_channel), in: [n_channels][in_stride], out: [n_channels][out_stride] (out_stride >=
+ * n_in / samples_per_symbol + tags + 2), tags_in[c] / n_tags_in[c] and tags_out[c] (tags_cap each) /
+ * n_tags_out[c] / produced[c] per channel.  Runs on sf[0]'s stream. */
+gr4pm_status gr4pm_cfc_symbol_filter_run_channels(gr4pm_rotator* cfc, int plan, gr4pm_symbol_filter* const* sf,
+                                                  size_t n_channels, const gr4pm_c64* in, size_t in_stride,
+                                                  size_t n_in, gr4pm_c64* out, size_t out_stride,
+                                                  const gr4pm_tag* const* tags_in, const size_t* n_tags_in,
+                                                  gr4pm_tag* const* tags_out, size_t tags_cap, size_t* n_tags_out,
+                                                  size_t* produced);
 gr4pm_status gr4pm_cfc_symbol_filter_run(gr4pm_rotator* cfc, int plan, gr4pm_symbol_filter* sf,
                                          const gr4pm_c64* in, size_t n_in, gr4pm_c64* out,
                                          size_t out_cap, const gr4pm_tag* tags_in, size_t n_tags_in,

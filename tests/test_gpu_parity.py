@@ -260,6 +260,38 @@ def test_correlator_spin_timeout_is_reported(pkg, monkeypatch, kind):
     assert st == 0 and tags.size == 3
 
 
+def test_candidate_kernels_agree(pkg, monkeypatch):
+    """the LDS-free candidate kernel (one wave walks T-item blocks in registers; default at T = 768) and the LDS one
+    (GR4PM_CANDIDATES_LDS) flag the same items: identical tags on bursts + noise + a constant stretch (ties), in one
+    call and in ragged chunks, two channels"""
+    rng = np.random.default_rng(5)
+    n = 300000
+    x, rrc = sig.qa_syncword_stream(n // 4, [700, 9000, 31000, 52000, 70001], 0.01, seed=12)
+    x = (0.6 * x[:n] + sig.awgn(n, 0.2, 13)).astype(np.complex64)
+    x[120000:150000] = 0.25  # constant input: equal powers, every tie counts
+    x[200000:200700] = 0
+    xs = np.stack([x, np.roll(x, 12345)]).astype(np.complex64)
+    res = {}
+    for kind in ("wave", "lds"):
+        if kind == "lds":
+            monkeypatch.setenv("GR4PM_CANDIDATES_LDS", "1")
+        sd = pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, power_threshold=9.5, max_items=n, n_channels=2)
+        one = sd.process_bulk(dev(xs))
+        sd2 = pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, power_threshold=9.5, max_items=n, n_channels=2)
+        chunks, pos = [], 0
+        for m in (70000, 4096, 100001, 125903):
+            chunks.append(sd2.process_bulk(dev(np.ascontiguousarray(xs[:, pos:pos + m]))))
+            pos += m
+        res[kind] = (one, chunks)
+    monkeypatch.delenv("GR4PM_CANDIDATES_LDS")
+    (one_w, ch_w), (one_l, ch_l) = res["wave"], res["lds"]
+    assert sum(t.size for t in one_w[2]) >= 8
+    for c in range(2):
+        assert same_tags(one_w[2][c], one_l[2][c])
+        for a, b in zip(ch_w, ch_l):
+            assert same_tags(a[2][c], b[2][c])
+
+
 def test_syncword_detection_awgn_threshold_and_noise_only(pkg):
     """default threshold 9.5, bursts in AWGN: same detections (incl. none on noise) as the oracle"""
     rng = np.random.default_rng(77)
@@ -1122,11 +1154,12 @@ def test_syncword_wipeoff_in_place(pkg):
         assert np.array_equal(bits(ya), bits(host(yb)))
 
 
-def test_multichannel_receiver_64_channels_pipelined_equals_synchronous(pkg):
+def test_multichannel_receiver_64_channels_pipelined_equals_synchronous(pkg, monkeypatch):
     """BASELINE configs[2] at its channel count: 64 channels with the per-channel CFO sweep of SURVEY 8(d) config 3
     (-0.04 .. +0.04 rad/sample), six batches.  submit() / collect() with up to four batches in flight (stages in
-    their own threads) == process() batch by batch, bit for bit: symbols, re-timed tags, detector tags; and channel 0
-    / 31 / 63 against one single-channel PacketReceiver each"""
+    their own threads, the symbol filters and wipe-offs of all channels in ONE launch each) == process() batch by
+    batch with one launch per channel (GR4PM_MC_PER_CHANNEL=1), bit for bit: symbols, re-timed tags, detector tags;
+    and channel 0 / 31 / 63 against one single-channel PacketReceiver each"""
     C, n, n_batches = 64, 1 << 15, 6
     rng = np.random.default_rng(77)
     total = n * n_batches
@@ -1136,7 +1169,9 @@ def test_multichannel_receiver_64_channels_pipelined_equals_synchronous(pkg):
     xs = np.stack([np.roll(base, 997 * c) * np.exp(1j * ((-0.04 + 0.08 * c / (C - 1)) * k)) for c in range(C)]).astype(np.complex64)
     xd = dev(xs)
     parts = [xd[:, b * n:(b + 1) * n].contiguous() for b in range(n_batches)]
+    monkeypatch.setenv("GR4PM_MC_PER_CHANNEL", "1")
     sync = pkg.NativeMultiChannelReceiver(C, max_items=n, tags_cap=128, workers=8)
+    monkeypatch.delenv("GR4PM_MC_PER_CHANNEL")
     pipe = pkg.NativeMultiChannelReceiver(C, max_items=n, tags_cap=128, workers=8)
     want = [sync.process_bulk(w, 200) for w in parts]
     got = []
