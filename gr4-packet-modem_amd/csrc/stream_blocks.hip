@@ -503,9 +503,6 @@ struct SymRun {
     unsigned wg0;   // first workgroup of the run (workgroups never straddle runs)
     unsigned chan;  // channel of the run (launches that span channels: SymChan table)
 };
-#ifndef GR4PM_SYMF_ABL
-#define GR4PM_SYMF_ABL 0 // timing-only ablations of k_symbol_filter (wrong results): 1 no MACs, 2 no rotation, 3 no item loads
-#endif
 #ifndef GR4PM_SYM_PER_WG
 #define GR4PM_SYM_PER_WG 256
 #endif
@@ -607,7 +604,7 @@ __global__ void k_update_hist_cfc_channels(const SymChan* __restrict__ chans, co
 
 __global__ void k_symf_wg_plan(const SymRun* __restrict__ runs, unsigned n_runs, unsigned n_wg, unsigned sps,
                                unsigned arm_size, CfcDev cfc, SymWg* __restrict__ plan,
-                               const SymChan* __restrict__ chans)
+                               const SymChan* __restrict__ chans, unsigned sym_per_wg)
 {
     const unsigned w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= n_wg) return;
@@ -618,10 +615,10 @@ __global__ void k_symf_wg_plan(const SymRun* __restrict__ runs, unsigned n_runs,
         else hi = mid - 1;
     }
     const SymRun r = runs[lo];
-    const unsigned first = (w - r.wg0) * kSymPerWg;
+    const unsigned first = (w - r.wg0) * sym_per_wg;
     SymWg p;
     p.o0 = r.out0 + first;
-    p.count = min(kSymPerWg, r.count - first);
+    p.count = min(sym_per_wg, r.count - first);
     p.lo_item = r.in0 + static_cast<long long>(first) * sps - (arm_size - 1);
     p.arm = r.arm;
     p.scale = r.scale;
@@ -629,6 +626,69 @@ __global__ void k_symf_wg_plan(const SymRun* __restrict__ runs, unsigned n_runs,
     p.seg = cfc.n_segs ? cfc_find_seg(cfc, p.lo_item) : 0u;
     p.chan = r.chan;
     plan[w] = p;
+}
+
+// Fused CFC: fills the workgroup's tile (phase-major: item i at (i % sps) * pitch + i / sps) with the ROTATED items of
+// the span [p.lo_item, p.lo_item + span).
+//  1. history items are stored rotated: straight to the tile
+//  2. one lane per checkpoint chunk: the lane reads its kRotChunk raw items (64 contiguous bytes) straight from global
+//     memory, replays the phasor recurrence of the chunk once (kRotChunk-1 steps for kRotChunk items) and writes the
+//     rotated items to the tile; segment by segment (usually one).  The raw items are not staged in LDS (round 1 did):
+//     half the LDS footprint, one barrier and one global-memory latency less per workgroup.
+template <unsigned THREADS>
+__device__ __forceinline__ void cfc_fill_tile(const SymWg& p, unsigned span, unsigned sps, unsigned pitch, cf* tile,
+                                              const cf* __restrict__ in, const cf* __restrict__ carry, unsigned cap,
+                                              const CfcDev& cfc)
+{
+    if (p.lo_item < 0)
+        for (unsigned i = threadIdx.x; i < span && p.lo_item + i < 0; i += THREADS)
+            tile[(i % sps) * pitch + i / sps] = carry[static_cast<long long>(cap) + p.lo_item + i];
+    const long long lo = p.lo_item < 0 ? 0 : p.lo_item;
+    const long long hi = p.lo_item + span;
+    for (unsigned sg = p.seg; sg < cfc.n_segs; ++sg) {
+        const RotSeg g = cfc.segs[sg];
+        const long long a = max(static_cast<long long>(g.start), lo);
+        const long long b = min(static_cast<long long>(g.start + g.len), hi);
+        if (a < b) {
+            const cf inc = cfc.seg_incr[sg];
+            const unsigned c0 = cfc.seg_counter0[sg];
+            const unsigned long long c_first = static_cast<unsigned long long>(a - g.start) / kRotChunk;
+            const unsigned n_chunks =
+                static_cast<unsigned>(static_cast<unsigned long long>(b - 1 - g.start) / kRotChunk - c_first) + 1;
+            for (unsigned ch = threadIdx.x; ch < n_chunks; ch += THREADS) {
+                const unsigned long long c = c_first + ch;
+                cf e = cfc.ck[g.ck0 + c];
+                unsigned counter = c0 + static_cast<unsigned>(c * kRotChunk);
+                const long long idx0 = static_cast<long long>(g.start + c * kRotChunk);
+                if (idx0 >= a && idx0 + static_cast<long long>(kRotChunk) <= b &&
+                    (counter & 511u) <= 512u - kRotChunk) {
+                    // whole chunk inside the span and no renormalisation among its 7 steps (the
+                    // usual case): straight-line packed arithmetic, same operations as below
+                    const unsigned i0 = static_cast<unsigned>(idx0 - p.lo_item);
+                    cf x[kRotChunk];
+#pragma unroll
+                    for (unsigned t = 0; t < kRotChunk; ++t) x[t] = in[idx0 + t];
+#pragma unroll
+                    for (unsigned t = 0; t < kRotChunk; ++t) {
+                        const unsigned i = i0 + t;
+                        tile[(i % sps) * pitch + i / sps] = cmul_pk(x[t], e); // hpp:87
+                        if (t + 1 < kRotChunk) e = cmul_pk(e, inc);
+                    }
+                    continue;
+                }
+#pragma unroll
+                for (unsigned t = 0; t < kRotChunk; ++t) {
+                    const long long idx = idx0 + t;
+                    if (idx >= a && idx < b) {
+                        const unsigned i = static_cast<unsigned>(idx - p.lo_item);
+                        tile[(i % sps) * pitch + i / sps] = cmul(in[idx], e); // hpp:87
+                    }
+                    if (t + 1 < kRotChunk) rot_step(e, inc, counter);
+                }
+            }
+        }
+        if (static_cast<long long>(g.start + g.len) >= hi) break;
+    }
 }
 
 // SPS > 0: samples_per_symbol known at compile time (divisions become shifts / constants);
@@ -644,10 +704,6 @@ __global__ __launch_bounds__(kSymPerWg) void k_symbol_filter(const T* __restrict
     T* tile = reinterpret_cast<T*>(s_raw);
     const unsigned sps = SPS > 0 ? static_cast<unsigned>(SPS) : sps_rt;
     const SymWg p = plan[blockIdx.x];
-#if GR4PM_SYMF_ABL == 4
-    if (threadIdx.x < p.count) out[p.o0 + threadIdx.x] = zero_item(T{});
-    return;
-#endif
     if constexpr (CFC) {
         if (chans) { // a launch that spans channels: the workgroup's channel supplies the pointers
             const SymChan c = chans[p.chan];
@@ -665,69 +721,7 @@ __global__ __launch_bounds__(kSymPerWg) void k_symbol_filter(const T* __restrict
     float* s_arm = reinterpret_cast<float*>(tile + pitch * sps);
     for (unsigned m = threadIdx.x; m < arm_size; m += kSymPerWg) s_arm[m] = taps[static_cast<size_t>(p.arm) * arm_size + m];
     if constexpr (CFC) {
-        // 1. history items are stored rotated: straight to the tile
-        if (p.lo_item < 0)
-            for (unsigned i = threadIdx.x; i < span && p.lo_item + i < 0; i += kSymPerWg)
-                tile[(i % sps) * pitch + i / sps] = carry[static_cast<long long>(cap) + p.lo_item + i];
-        // 2. one lane per checkpoint chunk: the lane reads its kRotChunk raw items (64 contiguous bytes) straight
-        //    from global memory, replays the phasor recurrence of the chunk once (kRotChunk-1 steps for kRotChunk
-        //    items) and writes the rotated items to the tile; segment by segment (usually one).  No staging of the
-        //    raw items in LDS: half the LDS footprint, one barrier and one global-memory latency less per workgroup
-        //    (the checkpoint load used to wait behind the staged items' barrier).
-        const long long lo = p.lo_item < 0 ? 0 : p.lo_item;
-        const long long hi = p.lo_item + span;
-        for (unsigned sg = p.seg; sg < cfc.n_segs; ++sg) {
-            const RotSeg g = cfc.segs[sg];
-            const long long a = max(static_cast<long long>(g.start), lo);
-            const long long b = min(static_cast<long long>(g.start + g.len), hi);
-            if (a < b) {
-                const cf inc = cfc.seg_incr[sg];
-                const unsigned c0 = cfc.seg_counter0[sg];
-                const unsigned long long c_first = static_cast<unsigned long long>(a - g.start) / kRotChunk;
-                const unsigned n_chunks =
-                    static_cast<unsigned>(static_cast<unsigned long long>(b - 1 - g.start) / kRotChunk - c_first) + 1;
-                for (unsigned ch = threadIdx.x; ch < n_chunks; ch += kSymPerWg) {
-                    const unsigned long long c = c_first + ch;
-                    cf e = cfc.ck[g.ck0 + c];
-                    unsigned counter = c0 + static_cast<unsigned>(c * kRotChunk);
-                    const long long idx0 = static_cast<long long>(g.start + c * kRotChunk);
-                    if (idx0 >= a && idx0 + static_cast<long long>(kRotChunk) <= b &&
-                        (counter & 511u) <= 512u - kRotChunk) {
-                        // whole chunk inside the span and no renormalisation among its 7 steps (the
-                        // usual case): straight-line packed arithmetic, same operations as below
-                        const unsigned i0 = static_cast<unsigned>(idx0 - p.lo_item);
-                        cf x[kRotChunk];
-#pragma unroll
-#if GR4PM_SYMF_ABL == 3
-                        for (unsigned t = 0; t < kRotChunk; ++t) x[t] = e;
-#else
-                        for (unsigned t = 0; t < kRotChunk; ++t) x[t] = in[idx0 + t];
-#endif
-#pragma unroll
-                        for (unsigned t = 0; t < kRotChunk; ++t) {
-                            const unsigned i = i0 + t;
-#if GR4PM_SYMF_ABL == 2
-                            tile[(i % sps) * pitch + i / sps] = x[t];
-#else
-                            tile[(i % sps) * pitch + i / sps] = cmul_pk(x[t], e); // hpp:87
-                            if (t + 1 < kRotChunk) e = cmul_pk(e, inc);
-#endif
-                        }
-                        continue;
-                    }
-#pragma unroll
-                    for (unsigned t = 0; t < kRotChunk; ++t) {
-                        const long long idx = idx0 + t;
-                        if (idx >= a && idx < b) {
-                            const unsigned i = static_cast<unsigned>(idx - p.lo_item);
-                            tile[(i % sps) * pitch + i / sps] = cmul(in[idx], e); // hpp:87
-                        }
-                        if (t + 1 < kRotChunk) rot_step(e, inc, counter);
-                    }
-                }
-            }
-            if (static_cast<long long>(g.start + g.len) >= hi) break;
-        }
+        cfc_fill_tile<kSymPerWg>(p, span, sps, pitch, tile, in, carry, cap, cfc);
     } else {
         for (unsigned i = threadIdx.x; i < span; i += kSymPerWg)
             tile[(i % sps) * pitch + i / sps] = item_at(in, carry, cap, p.lo_item + i);
@@ -737,16 +731,99 @@ __global__ __launch_bounds__(kSymPerWg) void k_symbol_filter(const T* __restrict
         // tile index of tap m of this symbol: tid * sps + j with j = arm_size - 1 - m;
         // j % sps and j / sps are the same for every thread
         T acc = zero_item(T{});
-#if GR4PM_SYMF_ABL == 1
-        acc = tile[threadIdx.x];
-#else
         for (unsigned m = 0; m < arm_size; ++m) {
             const unsigned j = arm_size - 1 - m;
             acc = mac(acc, s_arm[m], tile[(j % sps) * pitch + j / sps + threadIdx.x]);
         }
-#endif
         out[p.o0 + threadIdx.x] = scale_item(p.scale, acc);
     }
+}
+
+// The receiver's design (4 samples per symbol, 44-tap arms, fused CFC) as its own kernel.  Measured on the kernel above
+// (343 us per 2^26 samples): no MACs -76 us, no rotation -31, no item loads -63, empty workgroups 26 -- VALU (~0.10 ms),
+// the LDS pipe (~0.15 ms: 44 8-byte tile reads and 44 tap reads per symbol) and HBM (0.13 ms) add up instead of
+// overlapping.  Here the LDS traffic of the MACs is 45 % of that:
+//   * a lane computes TWO neighbouring symbols; they share 40 of their 44 items, and one 16-byte read delivers the two
+//     tile entries (phase row, items 2l + 2k and 2l + 2k + 1) that the pair needs at one tap position: 24 ds_read_b128
+//     per two symbols instead of 88 ds_read_b64
+//   * the 44 taps of the workgroup's arm are uniform: scalar loads into SGPRs, no LDS copy, no tap reads
+//   * 240 symbols per workgroup of 128 threads: the span is 1000 items = at most 126 checkpoint chunks, one pass of the
+//     rotation phase with 98 % of the lanes busy (256 symbols: 134 chunks on 256 lanes)
+// MAC order as in the reference (std::inner_product, tap index ascending), every product and sum rounded once: bit-exact.
+constexpr unsigned kFastSym = 240, kFastThreads = 128, kFastArm = 44, kFastSps = 4;
+constexpr unsigned kFastPitch = ((kFastSym - 1) * kFastSps + kFastArm) / kFastSps + 2; // entries per phase row (even)
+static_assert(kFastPitch % 2 == 0, "16-byte reads need even rows");
+__global__ __launch_bounds__(kFastThreads) void k_symbol_filter_fast(const cf* __restrict__ in, const cf* __restrict__ carry,
+                                                                     unsigned cap, const float* __restrict__ taps,
+                                                                     const SymWg* __restrict__ plan, cf* __restrict__ out,
+                                                                     CfcDev cfc, const SymChan* __restrict__ chans)
+{
+    __shared__ __attribute__((aligned(16))) cf tile[kFastSps * kFastPitch];
+    const SymWg p = plan[blockIdx.x];
+    if (chans) { // a launch that spans channels: the workgroup's channel supplies the pointers
+        const SymChan c = chans[p.chan];
+        in = c.in;
+        carry = c.carry;
+        out = c.out;
+        cfc = chan_cfc(c, cfc.ck);
+    }
+    const unsigned span = (p.count - 1) * kFastSps + kFastArm;
+    cfc_fill_tile<kFastThreads>(p, span, kFastSps, kFastPitch, tile, in, carry, cap, cfc);
+    const float* __restrict__ tp = taps + static_cast<size_t>(p.arm) * kFastArm; // uniform: scalar loads
+    float tap[kFastArm];
+#pragma unroll
+    for (unsigned m = 0; m < kFastArm; ++m) tap[m] = tp[m];
+    __syncthreads();
+    const unsigned l = threadIdx.x;
+    if (2 * l >= p.count) return;
+    // pair(ph, k) = tile entries (ph, 2l + 2k) and (ph, 2l + 2k + 1); symbol A = 2l uses entry 2l + q at tap position
+    // q = j / 4 of phase ph = j % 4 (j = 43 - m), symbol B = 2l + 1 uses entry 2l + 1 + q
+    const float4* rows = reinterpret_cast<const float4*>(tile) + l;
+    constexpr unsigned kRow4 = kFastPitch / 2; // float4 per phase row
+    cf accA = { 0.f, 0.f }, accB = { 0.f, 0.f };
+    float4 hi[kFastSps], lo[kFastSps];
+#pragma unroll
+    for (unsigned ph = 0; ph < kFastSps; ++ph) hi[ph] = rows[ph * kRow4 + 5];
+#pragma unroll
+    for (int k = 5; k >= 0; --k) {
+        if (k > 0) {
+#pragma unroll
+            for (unsigned ph = 0; ph < kFastSps; ++ph) lo[ph] = rows[ph * kRow4 + (k - 1)];
+        }
+        asm volatile("" ::: "memory"); // the reads of the next pair stay here, ahead of the MACs that hide them
+#pragma unroll
+        for (int ph = kFastSps - 1; ph >= 0; --ph) { // q = 2k: A <- pair.lo, B <- pair.hi
+            const float t = tap[kFastArm - 1 - (4 * (2 * k) + ph)];
+            accA = mac(accA, t, cf{ hi[ph].x, hi[ph].y });
+            accB = mac(accB, t, cf{ hi[ph].z, hi[ph].w });
+        }
+        // both chains advance together (hipcc otherwise runs A's 44 MACs first and keeps all 24 pairs live: 102 VGPRs)
+        asm volatile("" : "+v"(accA.x), "+v"(accA.y), "+v"(accB.x), "+v"(accB.y));
+        if (k > 0) {
+#pragma unroll
+            for (int ph = kFastSps - 1; ph >= 0; --ph) { // q = 2k - 1: A <- pair(k - 1).hi, B <- pair(k).lo
+                const float t = tap[kFastArm - 1 - (4 * (2 * k - 1) + ph)];
+                accA = mac(accA, t, cf{ lo[ph].z, lo[ph].w });
+                accB = mac(accB, t, cf{ hi[ph].x, hi[ph].y });
+            }
+            asm volatile("" : "+v"(accA.x), "+v"(accA.y), "+v"(accB.x), "+v"(accB.y));
+#pragma unroll
+            for (unsigned ph = 0; ph < kFastSps; ++ph) hi[ph] = lo[ph];
+        }
+    }
+    out[p.o0 + 2 * l] = scale_item(p.scale, accA);
+    if (2 * l + 1 < p.count) out[p.o0 + 2 * l + 1] = scale_item(p.scale, accB);
+}
+
+// symbols per workgroup of the kernel that a (fused, sps, arm size) combination runs
+static bool symf_fast(bool fused, size_t sps, size_t arm_size)
+{
+    static const bool off = getenv("GR4PM_SYMF_GENERIC") != nullptr; // A/B switch: the generic kernel for every design
+    return fused && sps == kFastSps && arm_size == kFastArm && !off;
+}
+static unsigned symf_per_wg(bool fused, size_t sps, size_t arm_size)
+{
+    return symf_fast(fused, sps, arm_size) ? kFastSym : kSymPerWg;
 }
 
 template <typename T, bool CFC>
@@ -757,7 +834,14 @@ static void launch_symbol_filter(hipStream_t s, unsigned n_wg, size_t smem, unsi
 {
     const dim3 grid(n_wg), block(kSymPerWg);
     hipLaunchKernelGGL(k_symf_wg_plan, dim3((n_wg + 255) / 256), dim3(256), 0, s, runs, n_runs, n_wg, sps, arm_size,
-                       cfc, plan, chans);
+                       cfc, plan, chans, symf_per_wg(CFC, sps, arm_size));
+    if constexpr (CFC) {
+        if (symf_fast(true, sps, arm_size)) {
+            hipLaunchKernelGGL(k_symbol_filter_fast, grid, dim3(kFastThreads), 0, s, in, carry, cap, taps, plan, out, cfc,
+                               chans);
+            return;
+        }
+    }
     if (sps == 4)
         hipLaunchKernelGGL((k_symbol_filter<T, 4, CFC>), grid, block, smem, s, in, carry, cap, taps, arm_size, sps,
                            plan, out, cfc, chans);
@@ -2069,10 +2153,11 @@ static gr4pm_status symbol_filter_impl(gr4pm_symbol_filter* h, const void* in, s
     hipStream_t s = h->stream;
     if (!runs.empty()) {
         unsigned n_wg = 0;
+        const unsigned per_wg = symf_per_wg(fuse != nullptr, sps, h->arm_size);
         for (auto& r : runs) { // workgroups never straddle runs
             r.wg0 = n_wg;
             r.chan = 0;
-            n_wg += (r.count + kSymPerWg - 1u) / kSymPerWg;
+            n_wg += (r.count + per_wg - 1u) / per_wg;
         }
         GR4PM_TRY(upload_vec(h->runs, runs, s));
         const size_t pitch = (kSymPerWg * sps + h->arm_size) / sps + 2;
@@ -2276,6 +2361,7 @@ gr4pm_status gr4pm_cfc_symbol_filter_run_channels(gr4pm_rotator* cfc, int plan, 
     std::vector<SymChan> chans(n_channels);
     std::vector<SymRun> runs;
     unsigned n_wg = 0;
+    const unsigned per_wg = symf_per_wg(true, h0->sps, h0->arm_size);
     bool overflow = false;
     for (size_t c = 0; c < n_channels; ++c) {
         gr4pm_symbol_filter* h = sf[c];
@@ -2289,7 +2375,7 @@ gr4pm_status gr4pm_cfc_symbol_filter_run_channels(gr4pm_rotator* cfc, int plan, 
         for (auto& r : rp.runs) { // workgroups never straddle runs
             r.wg0 = n_wg;
             r.chan = static_cast<unsigned>(c);
-            n_wg += (r.count + kSymPerWg - 1u) / kSymPerWg;
+            n_wg += (r.count + per_wg - 1u) / per_wg;
             runs.push_back(r);
         }
         const unsigned first = pl.seg_first[c];
