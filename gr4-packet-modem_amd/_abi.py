@@ -197,7 +197,8 @@ EXPORTS = [
     "gr4pm_symbol_filter_process", "gr4pm_cfc_symbol_filter_process",
     "gr4pm_cfc_symbol_filter_plan", "gr4pm_cfc_symbol_filter_run",
     "gr4pm_cfc_symbol_filter_plan_channels", "gr4pm_cfc_symbol_filter_run_channel",
-    "gr4pm_cfc_symbol_filter_run_channels", "gr4pm_syncword_wipeoff_process_channels", "gr4pm_costas_loop_process_ragged", "gr4pm_costas_loop_set_small_footprint",
+    "gr4pm_cfc_symbol_filter_run_channels", "gr4pm_syncword_wipeoff_process_channels",
+    "gr4pm_multichannel_receiver_set_input_in_place", "gr4pm_costas_loop_process_ragged", "gr4pm_costas_loop_set_small_footprint",
     "gr4pm_pfb_arb_resampler_create", "gr4pm_pfb_arb_resampler_destroy", "gr4pm_pfb_arb_resampler_reset",
     "gr4pm_pfb_arb_resampler_process",
     "gr4pm_firdes_root_raised_cosine",
@@ -293,7 +294,8 @@ def lib():
     L.gr4pm_syncword_wipeoff_reset.argtypes = [vp]
     L.gr4pm_syncword_wipeoff_process.argtypes = [vp, vp, sz, vp, vp, sz]
     L.gr4pm_syncword_wipeoff_process_channels.argtypes = [vp, sz, vp, sz, vp, vp, vp]
-    L.gr4pm_cfc_symbol_filter_run_channels.argtypes = [vp, C.c_int, vp, sz, vp, sz, sz, vp, sz, vp, vp, vp, sz, vp, vp]
+    L.gr4pm_cfc_symbol_filter_run_channels.argtypes = [vp, C.c_int, vp, sz, vp, sz, sz, vp, sz, vp, vp, vp, sz, vp, vp, vp, sz, sz]
+    L.gr4pm_multichannel_receiver_set_input_in_place.argtypes = [vp, C.c_int]
     L.gr4pm_interp_fir_create.argtypes = [C.POINTER(InterpFirParams), C.POINTER(vp)]
     L.gr4pm_interp_fir_destroy.argtypes = [vp]
     L.gr4pm_interp_fir_destroy.restype = None

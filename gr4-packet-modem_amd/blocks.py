@@ -1518,6 +1518,12 @@ class NativeMultiChannelReceiver:
     def in_flight(self):
         return int(lib().gr4pm_multichannel_receiver_in_flight(self._h))
 
+    def set_input_in_place(self, on=True):
+        """the caller keeps every submitted input unchanged until it has been collected (a device ring): the receiver
+        reads the detector's delayed stream in place instead of writing a delayed copy per batch.  Same results."""
+        check(lib().gr4pm_multichannel_receiver_set_input_in_place(self._h, 1 if on else 0),
+              "MultiChannelReceiver.set_input_in_place")
+
     def collect(self):
         Cn = self.n_channels
         sym, _x = self._pending.pop(0)

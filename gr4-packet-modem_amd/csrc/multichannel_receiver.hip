@@ -65,6 +65,9 @@ struct gr4pm_multichannel_receiver {
         std::vector<uint32_t> all_channel;
         std::vector<size_t> produced;
         int plan = -1;
+        const gr4pm_c64* in = nullptr; // in place: the batch's own input and the tail of the batch before
+        size_t in_stride = 0;
+        const gr4pm_c64* head = nullptr;
         size_t consumed = 0, out_stride = 0;
         uint64_t base = 0, packet_length = 0;
         gr4pm_c64* out_symbols = nullptr;
@@ -117,6 +120,12 @@ struct gr4pm_multichannel_receiver {
     gr4pm_status wstatus = GR4PM_OK;
     char werror[256] = { 0 };
 
+    // input in place (gr4pm_multichannel_receiver_set_input_in_place): no delayed copy; the last `hist` items of every
+    // batch's input are kept (tails: one more than batches in flight) for the batch after it
+    bool in_place = false;
+    size_t hist = 0;
+    DevBuf<gr4pm_c64> tails[kMcSlots + 1]; // [n_channels][hist]
+    int tail_next = 0;                     // where the NEXT submitted batch saves its tail
     // stage 2 as one launch per kernel: argument vectors of the ..._channels calls
     bool per_channel_launches = false;
     std::vector<gr4pm_symbol_filter*> v_symf;
@@ -221,10 +230,18 @@ gr4pm_status gr4pm_multichannel_receiver::stage2(Slot& s)
             v_tags_out[c] = s.ch[c].sym_tags.data();
         }
         DeferredSyncScope defer;
-        GR4PM_TRY(gr4pm_cfc_symbol_filter_run_channels(cfc, s.plan, v_symf.data(), C, s.y.p, y_stride, s.consumed,
-                                                       s.symall.p, s.out_stride, v_tags_in.data(), v_n_tags_in.data(),
-                                                       v_tags_out.data(), s.ch[0].sym_tags.size(), v_n_tags_out.data(),
-                                                       v_produced.data()));
+        if (s.in)
+            GR4PM_TRY(gr4pm_cfc_symbol_filter_run_channels(cfc, s.plan, v_symf.data(), C, s.in, s.in_stride, s.consumed,
+                                                           s.symall.p, s.out_stride, v_tags_in.data(),
+                                                           v_n_tags_in.data(), v_tags_out.data(),
+                                                           s.ch[0].sym_tags.size(), v_n_tags_out.data(),
+                                                           v_produced.data(), s.head, hist, hist));
+        else
+            GR4PM_TRY(gr4pm_cfc_symbol_filter_run_channels(cfc, s.plan, v_symf.data(), C, s.y.p, y_stride, s.consumed,
+                                                           s.symall.p, s.out_stride, v_tags_in.data(),
+                                                           v_n_tags_in.data(), v_tags_out.data(),
+                                                           s.ch[0].sym_tags.size(), v_n_tags_out.data(),
+                                                           v_produced.data(), nullptr, 0, 0));
         for (size_t c = 0; c < C; ++c) {
             s.ch[c].n_sym_tags = v_n_tags_out[c];
             s.ch[c].produced = v_produced[c];
@@ -391,6 +408,12 @@ gr4pm_status gr4pm_multichannel_receiver_create(const gr4pm_multichannel_receive
         h->v_n_tags_out.assign(C, 0);
         h->v_produced.assign(C, 0);
     }
+    h->hist = 2 * 768 + 1; // SyncwordDetection's delay: 2 * time_threshold + 1 (syncword_detection.hpp:318-319)
+    for (auto& t : h->tails) {
+        if ((st = t.alloc(h->hist * p->n_channels)) != GR4PM_OK) return bail(st);
+        if ((st = t.zero(h->sd_stream)) != GR4PM_OK) return bail(st);
+    }
+    if (hipStreamSynchronize(h->sd_stream) != hipSuccess) return bail(GR4PM_ERR_HIP);
     h->y_stride = (p->max_items + 63) & ~size_t{ 63 };
     for (auto& sl : h->slots) {
         if ((st = sl.y.alloc(h->y_stride * p->n_channels)) != GR4PM_OK) return bail(st);
@@ -451,6 +474,17 @@ gr4pm_status gr4pm_multichannel_receiver_announce(gr4pm_multichannel_receiver* h
     return gr4pm_syncword_detection_announce(h->sd, in, in_stride, n_in);
 }
 
+gr4pm_status gr4pm_multichannel_receiver_set_input_in_place(gr4pm_multichannel_receiver* h, int on)
+{
+    if (!h) return GR4PM_ERR_INVALID;
+    if (h->inflight != 0 || gr4pm_syncword_detection_items_consumed(h->sd) != 0) {
+        set_error("set_input_in_place: before the first batch");
+        return GR4PM_ERR_INVALID;
+    }
+    h->in_place = on != 0;
+    return GR4PM_OK;
+}
+
 gr4pm_status gr4pm_multichannel_receiver_submit(gr4pm_multichannel_receiver* h, const gr4pm_c64* in,
                                                 size_t in_stride, size_t n_in, uint64_t packet_length,
                                                 gr4pm_c64* out_symbols, size_t out_stride, size_t* consumed)
@@ -474,9 +508,30 @@ gr4pm_status gr4pm_multichannel_receiver_submit(gr4pm_multichannel_receiver* h, 
     size_t n_done = 0;
     // stage 0, in the caller's thread: the batched detector (its look-ahead runs the correlator of the announced
     // batches behind this call's own kernels)
-    const gr4pm_status st = gr4pm_syncword_detection_process(h->sd, in, in_stride, n_in, s.y.p, h->y_stride, &n_done,
-                                                             s.det_tags.data(), h->p.tags_cap, s.n_det.data());
+    const bool in_place = h->in_place && !h->per_channel_launches;
+    const gr4pm_status st = gr4pm_syncword_detection_process(h->sd, in, in_stride, n_in, in_place ? nullptr : s.y.p,
+                                                             h->y_stride, &n_done, s.det_tags.data(), h->p.tags_cap,
+                                                             s.n_det.data());
     if (st != GR4PM_OK) return st;
+    s.in = nullptr;
+    if (in_place) {
+        // this batch reads the tail the batch before it saved; its own tail (the last hist items it consumed) goes
+        // to the next buffer of the ring, for the batch after it
+        constexpr int kTails = kMcSlots + 1;
+        s.in = in;
+        s.in_stride = in_stride;
+        s.head = h->tails[(h->tail_next + kTails - 1) % kTails].p;
+        if (n_done >= h->hist) {
+            GR4PM_HIP_TRY(hipMemcpy2DAsync(h->tails[h->tail_next].p, h->hist * sizeof(gr4pm_c64),
+                                           in + (n_done - h->hist), in_stride * sizeof(gr4pm_c64),
+                                           h->hist * sizeof(gr4pm_c64), C, hipMemcpyDeviceToDevice, h->sd_stream));
+            GR4PM_HIP_TRY(hipStreamSynchronize(h->sd_stream));
+            h->tail_next = (h->tail_next + 1) % kTails;
+        } else if (n_done != 0) {
+            set_error("in-place input needs batches of at least %zu consumed items", h->hist);
+            return GR4PM_ERR_INVALID;
+        }
+    }
     if (getenv("GR4PM_MC_TIMING"))
         fprintf(stderr, "[gr4pm multichannel] stage 0: %.0f us\n",
                 std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - s.t_submit).count());

@@ -544,6 +544,10 @@ struct SymChan {
     unsigned n_segs;
     unsigned pad;
     unsigned long long n; // items consumed by the channel in this call (history update)
+    // two-piece input: items [0, n_head) of the call live at head[], item i >= n_head at in[i - n_head] (the
+    // detector's delayed stream read in place: the tail of the batch before + this batch's input)
+    const cf* head;
+    unsigned long long n_head;
 };
 __device__ __forceinline__ CfcDev chan_cfc(const SymChan& c, const cf* ck)
 {
@@ -568,7 +572,7 @@ __device__ __forceinline__ unsigned cfc_find_seg(const CfcDev& f, long long idx)
 }
 // rotated item idx (>= 0) of the current call: the lane replays at most kRotChunk-1 steps of
 // the recurrence from its chunk's checkpoint
-__device__ __forceinline__ cf cfc_item(const CfcDev& f, const cf* in, long long idx, unsigned seg)
+__device__ __forceinline__ cf cfc_phasor(const CfcDev& f, long long idx, unsigned seg)
 {
     const unsigned long long j = static_cast<unsigned long long>(idx) - f.segs[seg].start;
     const unsigned long long c = j / kRotChunk;
@@ -577,7 +581,11 @@ __device__ __forceinline__ cf cfc_item(const CfcDev& f, const cf* in, long long 
     unsigned counter = f.seg_counter0[seg] + static_cast<unsigned>(c * kRotChunk);
     const unsigned steps = static_cast<unsigned>(j - c * kRotChunk);
     for (unsigned t = 0; t < steps; ++t) rot_step(e, inc, counter);
-    return cmul(in[idx], e); // coarse_frequency_correction.hpp:87
+    return e;
+}
+__device__ __forceinline__ cf cfc_item(const CfcDev& f, const cf* in, long long idx, unsigned seg)
+{
+    return cmul(in[idx], cfc_phasor(f, idx, seg)); // coarse_frequency_correction.hpp:87
 }
 // history after a fused call: last cap ROTATED items
 __global__ void k_update_hist_cfc(const cf* __restrict__ in, const cf* __restrict__ carry, cf* __restrict__ carry_next,
@@ -599,7 +607,12 @@ __global__ void k_update_hist_cfc_channels(const SymChan* __restrict__ chans, co
     if (c.n == 0) return;
     const long long idx = static_cast<long long>(c.n) - cap + i;
     const CfcDev f = chan_cfc(c, ck);
-    c.carry_next[i] = idx < 0 ? c.carry[static_cast<long long>(cap) + idx] : cfc_item(f, c.in, idx, cfc_find_seg(f, idx));
+    if (idx < 0) {
+        c.carry_next[i] = c.carry[static_cast<long long>(cap) + idx];
+        return;
+    }
+    const cf x = static_cast<unsigned long long>(idx) < c.n_head ? c.head[idx] : c.in[idx - static_cast<long long>(c.n_head)];
+    c.carry_next[i] = cmul(x, cfc_phasor(f, idx, cfc_find_seg(f, idx)));
 }
 
 __global__ void k_symf_wg_plan(const SymRun* __restrict__ runs, unsigned n_runs, unsigned n_wg, unsigned sps,
@@ -638,7 +651,8 @@ __global__ void k_symf_wg_plan(const SymRun* __restrict__ runs, unsigned n_runs,
 template <unsigned THREADS>
 __device__ __forceinline__ void cfc_fill_tile(const SymWg& p, unsigned span, unsigned sps, unsigned pitch, cf* tile,
                                               const cf* __restrict__ in, const cf* __restrict__ carry, unsigned cap,
-                                              const CfcDev& cfc)
+                                              const CfcDev& cfc, const cf* __restrict__ head = nullptr,
+                                              long long n_head = 0)
 {
     if (p.lo_item < 0)
         for (unsigned i = threadIdx.x; i < span && p.lo_item + i < 0; i += THREADS)
@@ -661,13 +675,15 @@ __device__ __forceinline__ void cfc_fill_tile(const SymWg& p, unsigned span, uns
                 unsigned counter = c0 + static_cast<unsigned>(c * kRotChunk);
                 const long long idx0 = static_cast<long long>(g.start + c * kRotChunk);
                 if (idx0 >= a && idx0 + static_cast<long long>(kRotChunk) <= b &&
-                    (counter & 511u) <= 512u - kRotChunk) {
-                    // whole chunk inside the span and no renormalisation among its 7 steps (the
-                    // usual case): straight-line packed arithmetic, same operations as below
+                    (counter & 511u) <= 512u - kRotChunk &&
+                    (idx0 >= n_head || idx0 + static_cast<long long>(kRotChunk) <= n_head)) {
+                    // whole chunk inside the span (and on one side of a two-piece input) and no renormalisation
+                    // among its 7 steps (the usual case): straight-line packed arithmetic, same operations as below
                     const unsigned i0 = static_cast<unsigned>(idx0 - p.lo_item);
+                    const cf* __restrict__ src = idx0 >= n_head ? in + (idx0 - n_head) : head + idx0;
                     cf x[kRotChunk];
 #pragma unroll
-                    for (unsigned t = 0; t < kRotChunk; ++t) x[t] = in[idx0 + t];
+                    for (unsigned t = 0; t < kRotChunk; ++t) x[t] = src[t];
 #pragma unroll
                     for (unsigned t = 0; t < kRotChunk; ++t) {
                         const unsigned i = i0 + t;
@@ -681,7 +697,8 @@ __device__ __forceinline__ void cfc_fill_tile(const SymWg& p, unsigned span, uns
                     const long long idx = idx0 + t;
                     if (idx >= a && idx < b) {
                         const unsigned i = static_cast<unsigned>(idx - p.lo_item);
-                        tile[(i % sps) * pitch + i / sps] = cmul(in[idx], e); // hpp:87
+                        const cf x = idx < n_head ? head[idx] : in[idx - n_head];
+                        tile[(i % sps) * pitch + i / sps] = cmul(x, e); // hpp:87
                     }
                     if (t + 1 < kRotChunk) rot_step(e, inc, counter);
                 }
@@ -704,6 +721,8 @@ __global__ __launch_bounds__(kSymPerWg) void k_symbol_filter(const T* __restrict
     T* tile = reinterpret_cast<T*>(s_raw);
     const unsigned sps = SPS > 0 ? static_cast<unsigned>(SPS) : sps_rt;
     const SymWg p = plan[blockIdx.x];
+    const cf* head = nullptr;
+    long long n_head = 0;
     if constexpr (CFC) {
         if (chans) { // a launch that spans channels: the workgroup's channel supplies the pointers
             const SymChan c = chans[p.chan];
@@ -711,6 +730,8 @@ __global__ __launch_bounds__(kSymPerWg) void k_symbol_filter(const T* __restrict
             carry = c.carry;
             out = c.out;
             cfc = chan_cfc(c, cfc.ck);
+            head = c.head;
+            n_head = static_cast<long long>(c.n_head);
         }
     }
     const unsigned span = (p.count - 1) * sps + arm_size;
@@ -721,7 +742,7 @@ __global__ __launch_bounds__(kSymPerWg) void k_symbol_filter(const T* __restrict
     float* s_arm = reinterpret_cast<float*>(tile + pitch * sps);
     for (unsigned m = threadIdx.x; m < arm_size; m += kSymPerWg) s_arm[m] = taps[static_cast<size_t>(p.arm) * arm_size + m];
     if constexpr (CFC) {
-        cfc_fill_tile<kSymPerWg>(p, span, sps, pitch, tile, in, carry, cap, cfc);
+        cfc_fill_tile<kSymPerWg>(p, span, sps, pitch, tile, in, carry, cap, cfc, head, n_head);
     } else {
         for (unsigned i = threadIdx.x; i < span; i += kSymPerWg)
             tile[(i % sps) * pitch + i / sps] = item_at(in, carry, cap, p.lo_item + i);
@@ -760,15 +781,19 @@ __global__ __launch_bounds__(kFastThreads) void k_symbol_filter_fast(const cf* _
 {
     __shared__ __attribute__((aligned(16))) cf tile[kFastSps * kFastPitch];
     const SymWg p = plan[blockIdx.x];
+    const cf* head = nullptr;
+    long long n_head = 0;
     if (chans) { // a launch that spans channels: the workgroup's channel supplies the pointers
         const SymChan c = chans[p.chan];
         in = c.in;
         carry = c.carry;
         out = c.out;
         cfc = chan_cfc(c, cfc.ck);
+        head = c.head;
+        n_head = static_cast<long long>(c.n_head);
     }
     const unsigned span = (p.count - 1) * kFastSps + kFastArm;
-    cfc_fill_tile<kFastThreads>(p, span, kFastSps, kFastPitch, tile, in, carry, cap, cfc);
+    cfc_fill_tile<kFastThreads>(p, span, kFastSps, kFastPitch, tile, in, carry, cap, cfc, head, n_head);
     const float* __restrict__ tp = taps + static_cast<size_t>(p.arm) * kFastArm; // uniform: scalar loads
     float tap[kFastArm];
 #pragma unroll
@@ -2321,7 +2346,8 @@ gr4pm_status gr4pm_cfc_symbol_filter_run_channels(gr4pm_rotator* cfc, int plan, 
                                                   size_t n_channels, const gr4pm_c64* in, size_t in_stride, size_t n_in,
                                                   gr4pm_c64* out, size_t out_stride, const gr4pm_tag* const* tags_in,
                                                   const size_t* n_tags_in, gr4pm_tag* const* tags_out, size_t tags_cap,
-                                                  size_t* n_tags_out, size_t* produced)
+                                                  size_t* n_tags_out, size_t* produced, const gr4pm_c64* head,
+                                                  size_t head_stride, size_t n_head)
 {
     if (!cfc || !sf || !n_tags_in || !tags_in || !tags_out || !n_tags_out || !produced || n_channels == 0)
         return GR4PM_ERR_INVALID;
@@ -2336,8 +2362,8 @@ gr4pm_status gr4pm_cfc_symbol_filter_run_channels(gr4pm_rotator* cfc, int plan, 
         set_error("the rotation plan has %zu channels, the call %zu", cfc->n_channels, n_channels);
         return GR4PM_ERR_INVALID;
     }
-    if (!in || !out || in_stride < n_in) {
-        set_error("null sample pointer or in_stride < n_in");
+    if (!in || !out || in_stride + n_head < n_in || (n_head && (!head || head_stride < n_head || n_head > n_in))) {
+        set_error("null sample pointer, in_stride + n_head < n_in or a bad head");
         return GR4PM_ERR_INVALID;
     }
     gr4pm_symbol_filter* h0 = sf[0];
@@ -2390,6 +2416,8 @@ gr4pm_status gr4pm_cfc_symbol_filter_run_channels(gr4pm_rotator* cfc, int plan, 
         d.n_segs = pl.seg_first[c + 1] - first;
         d.pad = 0;
         d.n = rp.pos;
+        d.head = n_head ? reinterpret_cast<const cf*>(head) + c * head_stride : nullptr;
+        d.n_head = n_head;
         h->cur ^= 1;
         produced[c] = rp.produced;
         n_tags_out[c] = rp.n_pub;

@@ -350,13 +350,17 @@ gr4pm_status gr4pm_cfc_symbol_filter_run_channel(gr4pm_rotator* cfc, int plan, s
  * otherwise): sf[c] is channel c's SymbolFilter (one design for all; its tag-driven state is replayed on the
  * host exactly as by _run_channel), in: [n_channels][in_stride], out: [n_channels][out_stride] (out_stride >=
  * n_in / samples_per_symbol + tags + 2), tags_in[c] / n_tags_in[c] and tags_out[c] (tags_cap each) /
- * n_tags_out[c] / produced[c] per channel.  Runs on sf[0]'s stream. */
+ * n_tags_out[c] / produced[c] per channel.  Runs on sf[0]'s stream.
+ * Two-piece input (n_head > 0): the first n_head items of channel c's call are head[c * head_stride + i], item
+ * i >= n_head is in[c * in_stride + i - n_head] -- SyncwordDetection's delayed stream read in place: the last
+ * 2 * time_threshold + 1 items of the batch before, then this batch's own input (no delayed copy, 16 B/sample). */
 gr4pm_status gr4pm_cfc_symbol_filter_run_channels(gr4pm_rotator* cfc, int plan, gr4pm_symbol_filter* const* sf,
                                                   size_t n_channels, const gr4pm_c64* in, size_t in_stride,
                                                   size_t n_in, gr4pm_c64* out, size_t out_stride,
                                                   const gr4pm_tag* const* tags_in, const size_t* n_tags_in,
                                                   gr4pm_tag* const* tags_out, size_t tags_cap, size_t* n_tags_out,
-                                                  size_t* produced);
+                                                  size_t* produced, const gr4pm_c64* head, size_t head_stride,
+                                                  size_t n_head);
 gr4pm_status gr4pm_cfc_symbol_filter_run(gr4pm_rotator* cfc, int plan, gr4pm_symbol_filter* sf,
                                          const gr4pm_c64* in, size_t n_in, gr4pm_c64* out,
                                          size_t out_cap, const gr4pm_tag* tags_in, size_t n_tags_in,
@@ -731,6 +735,11 @@ gr4pm_status gr4pm_multichannel_receiver_collect(gr4pm_multichannel_receiver* h,
                                                  gr4pm_tag* tags, size_t* n_tags, gr4pm_tag* detector_tags,
                                                  size_t* n_detector_tags);
 int gr4pm_multichannel_receiver_in_flight(const gr4pm_multichannel_receiver* h);
+/* on: the caller keeps every submitted input valid and unchanged until its batch has been collected (a device
+ * ring).  The receiver then reads SyncwordDetection's delayed stream in place (the tail of the batch before, kept
+ * by the receiver, + the batch's own input) instead of writing a delayed copy of every batch (16 B/sample).
+ * Same results.  Call it before the first batch. */
+gr4pm_status gr4pm_multichannel_receiver_set_input_in_place(gr4pm_multichannel_receiver* h, int on);
 
 /* ====================================================================================
  * Burst generator pieces (packet_transmitter_pdu.hpp:131-337): with

@@ -1157,7 +1157,8 @@ def test_syncword_wipeoff_in_place(pkg):
 def test_multichannel_receiver_64_channels_pipelined_equals_synchronous(pkg, monkeypatch):
     """BASELINE configs[2] at its channel count: 64 channels with the per-channel CFO sweep of SURVEY 8(d) config 3
     (-0.04 .. +0.04 rad/sample), six batches.  submit() / collect() with up to four batches in flight (stages in
-    their own threads, the symbol filters and wipe-offs of all channels in ONE launch each) == process() batch by
+    their own threads, the symbol filters and wipe-offs of all channels in ONE launch each, the detector's delayed
+    stream read in place) == process() batch by
     batch with one launch per channel (GR4PM_MC_PER_CHANNEL=1), bit for bit: symbols, re-timed tags, detector tags;
     and channel 0 / 31 / 63 against one single-channel PacketReceiver each"""
     C, n, n_batches = 64, 1 << 15, 6
@@ -1173,6 +1174,7 @@ def test_multichannel_receiver_64_channels_pipelined_equals_synchronous(pkg, mon
     sync = pkg.NativeMultiChannelReceiver(C, max_items=n, tags_cap=128, workers=8)
     monkeypatch.delenv("GR4PM_MC_PER_CHANNEL")
     pipe = pkg.NativeMultiChannelReceiver(C, max_items=n, tags_cap=128, workers=8)
+    pipe.set_input_in_place(True)  # `parts` stay alive: the delayed stream is read in place, no copy per batch
     want = [sync.process_bulk(w, 200) for w in parts]
     got = []
     for b, w in enumerate(parts):
