@@ -463,6 +463,20 @@ gr4pm_status gr4pm_packet_receiver::stage3_soft(Slot& s)
 // pass A (see blocks.py PacketReceiver._predecode, which this mirrors): the header of every detection
 gr4pm_status gr4pm_packet_receiver::predecode(Slot& s, const gr4pm_c64* y)
 {
+#ifdef GR4PM_TIMING
+    static double lap_sum[12] = { 0 };
+    static int lap_n = 0;
+    int lap_i = 0;
+    auto lap_t = std::chrono::steady_clock::now();
+#define A_LAP()                                                                                              \
+    do {                                                                                                     \
+        const auto now_ = std::chrono::steady_clock::now();                                                  \
+        lap_sum[lap_i++] += std::chrono::duration<double, std::micro>(now_ - lap_t).count();                \
+        lap_t = now_;                                                                                        \
+    } while (0)
+#else
+#define A_LAP() do { } while (0)
+#endif
     hipStream_t st1 = streams[5];
     s.newly_known.clear();
     const long long n = static_cast<long long>(s.consumed);
@@ -499,6 +513,7 @@ gr4pm_status gr4pm_packet_receiver::predecode(Slot& s, const gr4pm_c64* y)
         hipLaunchKernelGGL(k_gather_windows, dim3(static_cast<unsigned>(k)), dim3(256), 0, st1, y, a_head.p,
                            static_cast<long long>(tail_len), a_starts.p, kW, a_compact.p);
         GR4PM_HIP_TRY(hipGetLastError());
+        A_LAP(); // 0 gather
         for (size_t j = 0; j < k; ++j) tags[j].index = j * kW + kPre;
         const size_t n_items = k * kW, cap = n_items / p.samples_per_symbol + k + 2;
         if (a_sym.n < cap) {
@@ -512,7 +527,9 @@ gr4pm_status gr4pm_packet_receiver::predecode(Slot& s, const gr4pm_c64* y)
         size_t n_st = 0, consumed = 0, produced = 0;
         GR4PM_TRY(gr4pm_cfc_symbol_filter_process(a_cfc, a_symf, a_compact.p, n_items, a_sym.p, cap, tags.data(), k,
                                                   sym_tags.data(), sym_tags.size(), &n_st, &consumed, &produced));
+        A_LAP(); // 1 cfc + symbol filter
         GR4PM_TRY(gr4pm_syncword_wipeoff_process(a_wipe, a_sym.p, produced, a_sym.p, sym_tags.data(), n_st));
+        A_LAP(); // 2 wipe-off
         a_fifo += k; // one "invalid_header" per detection: only syncword + header pass
         std::vector<gr4pm_header_msg> inv(std::max<size_t>(n_st, 1), gr4pm_header_msg{ 0, 1 });
         a_fifo -= std::min(a_fifo, n_st);
@@ -521,15 +538,19 @@ gr4pm_status gr4pm_packet_receiver::predecode(Slot& s, const gr4pm_c64* y)
         GR4PM_TRY(gr4pm_payload_metadata_insert_process(a_pmi, a_sym.p, produced, a_pm.p, cap, sym_tags.data(), n_st,
                                                         inv.data(), n_st, 1, ptags.data(), ptags.size(), &n_pt, &c2,
                                                         &n_pm, &used, &ignored));
+        A_LAP(); // 3 pmi
         GR4PM_TRY(gr4pm_costas_loop_process_packets(a_costas, a_pm.p, n_pm, a_z.p, ptags.data(), n_pt));
+        A_LAP(); // 4 costas
         size_t n_dt = 0, n_data = 0, n_lt = 0, n_llr = 0;
         GR4PM_TRY(gr4pm_syncword_remove_process(a_remove, a_z.p, n_pm, a_data.p, ptags.data(), n_pt, dtags.data(),
                                                 dtags.size(), &n_dt, &n_data));
         GR4PM_TRY(gr4pm_constellation_llr_decoder_process(a_llr, a_data.p, n_data, a_llrbuf.p, a_llrbuf.n, dtags.data(),
                                                           n_dt, ltags.data(), ltags.size(), &n_lt, &n_llr));
+        A_LAP(); // 5 remove + llr
         std::vector<gr4pm_header_msg> done;
         std::vector<int32_t> ptype;
         GR4PM_TRY(a_loop.run(a_llrbuf.p, n_llr, ltags.data(), n_lt, done, ptype));
+        A_LAP(); // 6 header loop
         for (uint64_t o : order) a_order.push_back(o);
         for (const auto& m : done) {
             if (a_order.empty()) break;
@@ -553,7 +574,19 @@ gr4pm_status gr4pm_packet_receiver::predecode(Slot& s, const gr4pm_c64* y)
     if (n >= static_cast<long long>(tail_len))
         GR4PM_HIP_TRY(hipMemcpyAsync(a_tail.p, y + (n - tail_len), tail_len * sizeof(gr4pm_c64), hipMemcpyDeviceToDevice,
                                      st1));
+    A_LAP(); // 7 bookkeeping
     GR4PM_HIP_TRY(hipStreamSynchronize(st1));
+    A_LAP(); // 8 final wait
+#ifdef GR4PM_TIMING
+    if (++lap_n % 8 == 0) {
+        fprintf(stderr, "[gr4pm timing] pass A laps (us, mean of 8): gather %.0f cfc+symf %.0f wipe %.0f pmi %.0f costas %.0f "
+                        "remove+llr %.0f header_loop %.0f bookkeeping %.0f final_wait %.0f\n",
+                lap_sum[0] / 8, lap_sum[1] / 8, lap_sum[2] / 8, lap_sum[3] / 8, lap_sum[4] / 8, lap_sum[5] / 8,
+                lap_sum[6] / 8, lap_sum[7] / 8, lap_sum[8] / 8);
+        for (double& v : lap_sum) v = 0;
+    }
+#endif
+#undef A_LAP
     return GR4PM_OK;
 }
 
@@ -801,9 +834,16 @@ gr4pm_status gr4pm_packet_receiver_create(const gr4pm_packet_receiver_params* p,
     // look-ahead stream)
     int least = 0, greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return bail(GR4PM_ERR_HIP);
-    for (int i = 0; i < 6; ++i)
-        if (hipStreamCreateWithPriority(&h->streams[i], hipStreamNonBlocking, i == 0 ? greatest : 0) != hipSuccess)
+    for (int i = 0; i < 6; ++i) {
+        // pass A of the header loop (streams[5]) is a chain of fifteen small dependent kernels: on a chip that the
+        // correlator and the filters keep full, each of them waits for a free slot -- at the highest priority it is
+        // dispatched first
+        // (GR4PM_HIGH_STREAMS: the digits of the stage streams that get the highest priority, default "05")
+        static const char* high = getenv("GR4PM_HIGH_STREAMS") ? getenv("GR4PM_HIGH_STREAMS") : "05";
+        const int prio = strchr(high, '0' + i) != nullptr ? greatest : 0;
+        if (hipStreamCreateWithPriority(&h->streams[i], hipStreamNonBlocking, prio) != hipSuccess)
             return bail(GR4PM_ERR_HIP);
+    }
     const size_t sps = p->samples_per_symbol;
     // packet_receiver.hpp:60-74: RRC taps normalised to unit RMS norm (float accumulation)
     std::vector<float> rrc(((sps * 11) | 1));

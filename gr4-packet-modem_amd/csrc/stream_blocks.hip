@@ -15,6 +15,7 @@
 // whose float rounding makes them order dependent (rotator phasor, Costas PLL, resampler
 // phase accumulator) run serially per independent segment (one lane each).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <deque>
@@ -2781,6 +2782,9 @@ gr4pm_status gr4pm_payload_metadata_insert_process(
         set_error("null sample pointer");
         return GR4PM_ERR_INVALID;
     }
+#ifdef GR4PM_TIMING
+    const auto t_pmi0 = std::chrono::steady_clock::now();
+#endif
     std::vector<CopySpan> spans;
     size_t n_pub = 0, hdr = 0, ignored = 0;
     bool tag_overflow = false;
@@ -2891,8 +2895,25 @@ gr4pm_status gr4pm_payload_metadata_insert_process(
     // spans of length 0 come from the min() above when a stage has nothing to move
     spans.erase(std::remove_if(spans.begin(), spans.end(), [](const CopySpan& c) { return c.len == 0; }),
                 spans.end());
+#ifdef GR4PM_TIMING
+    const auto t_pmi1 = std::chrono::steady_clock::now();
+#endif
     GR4PM_TRY(launch_gather(h->stream, h->spans, spans, reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(out)));
     GR4PM_HIP_TRY(final_sync(h->stream));
+#ifdef GR4PM_TIMING
+    {
+        static double a = 0, b = 0;
+        static int n = 0;
+        const auto t_pmi2 = std::chrono::steady_clock::now();
+        a += std::chrono::duration<double, std::micro>(t_pmi1 - t_pmi0).count();
+        b += std::chrono::duration<double, std::micro>(t_pmi2 - t_pmi1).count();
+        if (++n % 64 == 0) {
+            fprintf(stderr, "[gr4pm timing] PayloadMetadataInsert: replay %.0f us, upload + launch %.0f us, %zu spans (mean of 64)\n",
+                    a / 64, b / 64, spans.size());
+            a = b = 0;
+        }
+    }
+#endif
     *n_tags_out = n_pub;
     *consumed = ipos;
     *produced = opos;
