@@ -45,6 +45,15 @@ def _dev_c64(x, what="in"):
     return x
 
 
+def _dev_c64_rows(x, what="in"):
+    """[channels, n] with contiguous rows; the row stride is free (a window of a wider ring)"""
+    torch = _torch()
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.complex64 and x.dim() == 2 and
+            (x.shape[1] <= 1 or x.stride(1) == 1) and x.stride(0) >= x.shape[1]):
+        raise TypeError(f"{what} must be a [channels, n] complex64 CUDA tensor with contiguous rows")
+    return x
+
+
 def _tags_array(tags):
     if tags is None:
         return np.zeros(0, dtype=TAG_DTYPE)
@@ -1494,7 +1503,7 @@ class NativeMultiChannelReceiver:
         check(lib().gr4pm_multichannel_receiver_create(C.byref(p), C.byref(self._h)), "MultiChannelReceiver")
 
     def announce(self, x):
-        x = _dev_c64(x)
+        x = _dev_c64_rows(x)
         assert x.dim() == 2 and x.shape[0] == self.n_channels
         check(lib().gr4pm_multichannel_receiver_announce(self._h, x.data_ptr(), x.stride(0), x.shape[1]),
               "MultiChannelReceiver.announce")
@@ -1503,7 +1512,7 @@ class NativeMultiChannelReceiver:
         """pipelined form: returns the items consumed per channel as soon as the detector has taken the batch;
         the stages behind it keep working on up to four batches.  Results come from collect(), in order."""
         torch = _torch()
-        x = _dev_c64(x)
+        x = _dev_c64_rows(x)
         assert x.dim() == 2 and x.shape[0] == self.n_channels
         Cn, n = self.n_channels, x.shape[1]
         stride = n // self.samples_per_symbol + self.tags_cap + 64
@@ -1538,7 +1547,7 @@ class NativeMultiChannelReceiver:
 
     def process_bulk(self, x, packet_length=None):
         torch = _torch()
-        x = _dev_c64(x)
+        x = _dev_c64_rows(x)
         assert x.dim() == 2 and x.shape[0] == self.n_channels
         Cn, n = self.n_channels, x.shape[1]
         stride = n // self.samples_per_symbol + self.tags_cap + 64

@@ -849,6 +849,46 @@ def test_packet_receiver_full_size_round_trip(pkg):
     assert len(got) >= complete and got == payloads[: len(got)]
 
 
+def test_multichannel_receiver_full_size_config2(pkg):
+    """BASELINE configs[2] at its full size: 64 channels x 2^22 samples per batch (the bench's burst stream with the
+    per-channel CFO sweep), three batches in flight with the streaming stride.  Size-independent properties: the
+    pipelined receiver (one launch for all channels, input read in place) returns, bit for bit, what a second
+    receiver returns that processes batch by batch with a delayed copy; channels 0, 21, 42 and 63 equal one
+    single-channel PacketReceiver each; the centre channels find (almost) every packet"""
+    import bench
+    C, n = 64, 1 << 22
+    device = torch.device("cuda")
+    rrc = bench.unit_norm_rrc(pkg)
+    x, n_pkt = bench.burst_stream(pkg, 3 * n, rrc, seed=5, device=device)
+    xs = bench.channel_bank(x, C)
+    stride = ((n - 2048) // 1752 + 1) * 1752  # a streaming caller presents the unconsumed tail again (hpp:238)
+    parts = [xs[:, b * stride:b * stride + n] for b in range(3) if b * stride + n <= xs.shape[1]]
+    assert len(parts) == 3
+    cap = 2 * (n_pkt // 3) + 64
+    pipe = pkg.NativeMultiChannelReceiver(C, max_items=n, tags_cap=cap, workers=8)
+    pipe.set_input_in_place(True)
+    sync = pkg.NativeMultiChannelReceiver(C, max_items=n, tags_cap=cap, workers=8)
+    for w in parts:
+        assert pipe.submit(w, 1500) == stride
+    got = [pipe.collect() for _ in parts]
+    want = [sync.process_bulk(w, 1500) for w in parts]
+    singles = {c: pkg.PacketReceiver(max_items=n) for c in (0, 21, 42, 63)}
+    found = np.zeros(C, dtype=np.int64)
+    for b in range(3):
+        for c in range(C):
+            g, w_ = got[b][c], want[b][c]
+            assert g["consumed"] == w_["consumed"] == stride
+            assert torch.equal(g["symbols"].view(torch.int64), w_["symbols"].view(torch.int64)), (b, c)
+            assert same_tags(g["tags"], w_["tags"]) and same_tags(g["detector_tags"], w_["detector_tags"])
+            found[c] += g["detector_tags"].size
+        for c, rx in singles.items():
+            ref = rx.process_bulk(parts[b][c], 1500, tags_cap=cap)
+            assert torch.equal(got[b][c]["symbols"].view(torch.int64), ref["symbols"].view(torch.int64)), (b, c)
+            assert same_tags(got[b][c]["tags"], ref["tags"])
+    expect = 3 * stride // ((64 + 128 + 1504 * 4 + 500) * 4)
+    assert found[24:40].min() >= expect - 2 and found.max() <= expect + 4  # the edge channels miss up to a fifth
+
+
 def test_c_abi_from_cpp(pkg, tmp_path):
     """the boundary is usable from plain C++ (what a gr::Block wrapper does): build
     tests/cabi_smoke.cpp against include/gr4pm_hip.h + libgr4pm_hip.so and run it"""
