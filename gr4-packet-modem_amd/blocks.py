@@ -1041,7 +1041,10 @@ class PacketReceiver:
         self._inflight = []
         if pipelined:
             import concurrent.futures
-            self._workers = [concurrent.futures.ThreadPoolExecutor(max_workers=1) for _ in range(2)]
+            # the current device is a per-thread setting (torch and HIP alike): the workers take the creator's
+            dev = _torch().cuda.current_device()
+            self._workers = [concurrent.futures.ThreadPoolExecutor(max_workers=1, initializer=_torch().cuda.set_device,
+                                                                   initargs=(dev,)) for _ in range(2)]
 
     # ---- the three stages
     def _stage0(self, x, tags_cap, history, next_x=None):
@@ -1450,7 +1453,8 @@ class MultiChannelPacketReceiver:
             self.chains[0].rrc_taps, SYNCWORD, bpsk, -syncword_freq_bins, syncword_freq_bins,
             samples_per_symbol=samples_per_symbol, power_threshold=syncword_threshold, n_channels=n_channels,
             max_items=max_items)
-        self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=workers)
+        self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=workers, initializer=torch.cuda.set_device,
+                                                           initargs=(torch.cuda.current_device(),))
 
     def announce(self, x):
         self.syncword_detection.announce(x)

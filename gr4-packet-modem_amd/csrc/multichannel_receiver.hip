@@ -35,6 +35,7 @@ constexpr int kMcSlots = 4;
 
 struct gr4pm_multichannel_receiver {
     gr4pm_multichannel_receiver_params p{};
+    int device = 0; // the device the handle was created on: its threads select it (hipSetDevice is per thread)
     gr4pm_syncword_detection* sd = nullptr;
     hipStream_t sd_stream = nullptr;
     struct Chain { // per-channel blocks (their state carries from batch to batch)
@@ -161,6 +162,7 @@ gr4pm_status gr4pm_multichannel_receiver::run_channel(Slot& s, size_t c)
 
 void gr4pm_multichannel_receiver::worker(unsigned w)
 {
+    (void)hipSetDevice(device);
     gr4pm_set_deferred_sync(1);
     uint64_t seen = 0;
     for (;;) {
@@ -286,6 +288,7 @@ gr4pm_status gr4pm_multichannel_receiver::stage3(Slot& s)
 
 void gr4pm_multichannel_receiver::stage_loop(int which)
 {
+    (void)hipSetDevice(device);
     Queue& in = which == 1 ? to_stage1 : which == 2 ? to_stage2 : to_stage3;
     Queue& out = which == 1 ? to_stage2 : which == 2 ? to_stage3 : done;
     for (;;) {
@@ -426,6 +429,8 @@ gr4pm_status gr4pm_multichannel_receiver_create(const gr4pm_multichannel_receive
             cb.sym_tags.resize(h->p.tags_cap + 64);
         }
     }
+    // HIP's current device is per thread and starts at 0: every thread of the handle works on the creator's device
+    if (hipGetDevice(&h->device) != hipSuccess) return bail(GR4PM_ERR_HIP);
     for (unsigned w = 0; w < n_workers; ++w) h->workers.emplace_back([h, w] { h->worker(w); });
     h->t_stage1 = std::thread([h] { h->stage_loop(1); });
     h->t_stage2 = std::thread([h] { h->stage_loop(2); });

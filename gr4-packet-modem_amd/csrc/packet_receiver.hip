@@ -956,8 +956,13 @@ gr4pm_status gr4pm_packet_receiver_create(const gr4pm_packet_receiver_params* p,
         }
         h->free_slots.push(i);
     }
+    // HIP's current device is a per-thread setting that starts at device 0: the stage threads work on the device the
+    // handle was created on (one process per GPU under torch.distributed: rank k creates it on device k)
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return bail(GR4PM_ERR_HIP);
     if (p->pipelined) {
-        h->workers[4] = std::thread([h] {
+        h->workers[4] = std::thread([h, device] {
+            (void)hipSetDevice(device);
             gr4pm_set_deferred_sync(getenv("GR4PM_NO_DEFER") ? 0 : 1);
             for (;;) {
                 const int i = h->to_stageA.pop();
@@ -969,7 +974,8 @@ gr4pm_status gr4pm_packet_receiver_create(const gr4pm_packet_receiver_params* p,
             }
             h->to_stage1.push(-1);
         });
-        h->workers[0] = std::thread([h] {
+        h->workers[0] = std::thread([h, device] {
+            (void)hipSetDevice(device);
             gr4pm_set_deferred_sync(getenv("GR4PM_NO_DEFER") ? 0 : 1);
             for (;;) {
                 const int i = h->to_stage1.pop();
@@ -981,7 +987,8 @@ gr4pm_status gr4pm_packet_receiver_create(const gr4pm_packet_receiver_params* p,
             }
             h->to_stage1b.push(-1);
         });
-        h->workers[3] = std::thread([h] {
+        h->workers[3] = std::thread([h, device] {
+            (void)hipSetDevice(device);
             gr4pm_set_deferred_sync(getenv("GR4PM_NO_DEFER") ? 0 : 1);
             for (;;) {
                 const int i = h->to_stage1b.pop();
@@ -993,7 +1000,8 @@ gr4pm_status gr4pm_packet_receiver_create(const gr4pm_packet_receiver_params* p,
             }
             h->to_stage2.push(-1);
         });
-        h->workers[1] = std::thread([h] {
+        h->workers[1] = std::thread([h, device] {
+            (void)hipSetDevice(device);
             gr4pm_set_deferred_sync(getenv("GR4PM_NO_DEFER") ? 0 : 1);
             for (;;) {
                 const int i = h->to_stage2.pop();
@@ -1005,7 +1013,8 @@ gr4pm_status gr4pm_packet_receiver_create(const gr4pm_packet_receiver_params* p,
             }
             h->to_stage3.push(-1);
         });
-        h->workers[2] = std::thread([h] {
+        h->workers[2] = std::thread([h, device] {
+            (void)hipSetDevice(device);
             gr4pm_set_deferred_sync(getenv("GR4PM_NO_DEFER") ? 0 : 1);
             for (;;) {
                 const int i = h->to_stage3.pop();
