@@ -706,25 +706,6 @@ __device__ __forceinline__ uint32_t next_candidate(const unsigned long long* bm,
 // resume at hi + table (>= hi).  All entries that meet the same first candidate share one walk,
 // so one wave handles a tile: every candidate inside the entry window [lo, lo+T] gets a lane
 // that walks from it, plus one walk for the entries behind the window's last candidate.
-// wave-cooperative version for wave-uniform r: 64 bitmap words (4096 positions) per load
-__device__ __forceinline__ uint32_t next_candidate_wave(const unsigned long long* bm, uint32_t r, uint32_t hi,
-                                                        int lane)
-{
-    if (r >= hi) return hi;
-    const uint32_t wlast = (hi - 1) >> 6;
-    for (uint32_t w = r >> 6; w <= wlast; w += 64) {
-        unsigned long long word = (w + lane <= wlast) ? bm[w + lane] : 0ull;
-        if (w == (r >> 6) && lane == 0) word &= ~0ull << (r & 63);
-        const unsigned long long any = __ballot(word != 0ull);
-        if (any) {
-            const int src = __ffsll(static_cast<long long>(any)) - 1;
-            const unsigned long long hit = __shfl(word, src);
-            const uint32_t p = ((w + src) << 6) + static_cast<uint32_t>(__ffsll(static_cast<long long>(hit)) - 1);
-            return p < hi ? p : hi;
-        }
-    }
-    return hi;
-}
 // The whole bitmap of one tile (kTileW / 64 words) in the registers of one wave, lane l holding words
 // l, l + 64, ...: the walks of k_tile_tables / k_tile_visit then cost a ballot and a shuffle per step instead of
 // a global-memory round trip (they were the whole cost of those kernels: 150 + 175 us per 2^26 items).
