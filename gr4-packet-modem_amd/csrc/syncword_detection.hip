@@ -499,22 +499,25 @@ namespace {
 // the prefix maxima of the last block are only computed for the rare survivors.
 // inclusive prefix maximum over the 64 lanes with DPP row shifts / row broadcasts (no LDS
 // round trips, unlike __shfl_*): lane l ends with max(v[0..l]); lane 63 holds the wave maximum
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_max_step(float v)
-{
-    const float ninf = -INFINITY;
-    const int t = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, ninf), __builtin_bit_cast(int, v), CTRL,
-                                              ROW_MASK, 0xf, false);
-    return fmaxf(v, __builtin_bit_cast(float, t));
-}
 __device__ __forceinline__ float wave_prefix_max(float v)
 {
-    v = dpp_max_step<0x111, 0xf>(v); // row_shr:1
-    v = dpp_max_step<0x112, 0xf>(v); // row_shr:2
-    v = dpp_max_step<0x114, 0xf>(v); // row_shr:4
-    v = dpp_max_step<0x118, 0xf>(v); // row_shr:8
-    v = dpp_max_step<0x142, 0xa>(v); // row_bcast:15 -> rows 1, 3
-    v = dpp_max_step<0x143, 0xc>(v); // row_bcast:31 -> rows 2, 3
+    // v_max_f32 with a DPP source: a lane whose source lane does not exist (or whose row is masked out) keeps its
+    // value, which is what an inclusive scan step wants -- ONE instruction a step (the builtin form above costs a
+    // v_mov of -inf, a v_mov_dpp and two v_max: fmaxf canonicalises).  s_nop 1: the two wait states between a VALU
+    // write of a VGPR and its use as a DPP source.
+    asm volatile("s_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+                 : "+v"(v));
     return v;
 }
 // value of lane l-1 (lane 0 gets -inf): wave_shr:1
