@@ -1190,21 +1190,49 @@ __global__ __launch_bounds__(64) void k_tags(const cf* __restrict__ in, size_t i
     (void)tmpl;
     (void)twA;
     (void)twB;
-    for (int bin = 0; bin < n_bins; ++bin) {
-        const cf* tb = td + static_cast<size_t>(bin) * td_len;
-        double ax = 0.0, ay = 0.0;
-        for (uint32_t n = lane; n < td_len; n += 64) {
-            const cf x = sample_at(cur, car, xc, o + static_cast<long long>(lag) + n);
-            const cf t = tb[n];
-            ax += static_cast<double>(x.x) * t.x - static_cast<double>(x.y) * t.y;
-            ay += static_cast<double>(x.x) * t.y + static_cast<double>(x.y) * t.x;
+    // All loads of a group of bins are in flight before the first product (one lane-sample per 64 template samples,
+    // the same for every bin; bin by bin every pass of the loop waited for its own two loads: 45 dependent round
+    // trips per tag), and the bins' lane sums are reduced side by side.
+    constexpr int kU = 5, kBinGroup = 9; // 320 template samples and 9 bins per round: one round for the defaults
+    for (int bin0 = 0; bin0 < n_bins; bin0 += kBinGroup) {
+        double ax[kBinGroup], ay[kBinGroup];
+#pragma unroll
+        for (int b = 0; b < kBinGroup; ++b) ax[b] = ay[b] = 0.0;
+        for (uint32_t n0 = 0; n0 < td_len; n0 += 64 * kU) {
+            cf x[kU], t[kBinGroup][kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const uint32_t n = n0 + 64 * u + lane;
+                x[u] = n < td_len ? sample_at(cur, car, xc, o + static_cast<long long>(lag) + n) : mk(0.f, 0.f);
+            }
+#pragma unroll
+            for (int b = 0; b < kBinGroup; ++b) {
+                const cf* tb = td + static_cast<size_t>(min(bin0 + b, n_bins - 1)) * td_len;
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    const uint32_t n = n0 + 64 * u + lane;
+                    t[b][u] = n < td_len ? tb[n] : mk(0.f, 0.f);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < kBinGroup; ++b)
+#pragma unroll
+                for (int u = 0; u < kU; ++u) { // same order of accumulation per lane as the loop it replaces
+                    ax[b] += static_cast<double>(x[u].x) * t[b][u].x - static_cast<double>(x[u].y) * t[b][u].y;
+                    ay[b] += static_cast<double>(x[u].x) * t[b][u].y + static_cast<double>(x[u].y) * t[b][u].x;
+                }
         }
 #pragma unroll
-        for (int d = 32; d > 0; d >>= 1) {
-            ax += __shfl_xor(ax, d);
-            ay += __shfl_xor(ay, d);
-        }
-        if (lane == 0) zbin[bin] = mk(static_cast<float>(ax * kFftN), static_cast<float>(ay * kFftN));
+        for (int d = 32; d > 0; d >>= 1)
+#pragma unroll
+            for (int b = 0; b < kBinGroup; ++b) {
+                ax[b] += __shfl_xor(ax[b], d);
+                ay[b] += __shfl_xor(ay[b], d);
+            }
+#pragma unroll
+        for (int b = 0; b < kBinGroup; ++b)
+            if (lane == 0 && bin0 + b < n_bins)
+                zbin[bin0 + b] = mk(static_cast<float>(ax[b] * kFftN), static_cast<float>(ay[b] * kFftN));
     }
     wave_lds_sync();
     if (lane == 0) {
