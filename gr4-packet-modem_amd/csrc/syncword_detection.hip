@@ -4,18 +4,22 @@
 // Data flow of one process() call (all kernels on the handle's stream, nothing leaves HBM
 // except the sparse tag records):
 //
-//   k_correlate      overlap-save correlator: one 64-lane wave per 2048-sample block; FFT,
+//   k_correlate_w64  overlap-save correlator (correlate_w64.hpp): one 64-lane wave per 2048-sample block; FFT,
 //                    x B templates, FFT, |.|^2, max over bins, all in registers/LDS; reads
 //                    8 B/sample, writes the 4 B/sample correlation power `zpow`
-//                    (hpp:238-252,300-313)
-//   k_candidates     B(p) = zpow[p] >= max(zpow[p+1..p+T]) as a bitmap (sliding max)
+//                    (hpp:238-252,300-313).  k_correlate / k_correlate_pair (round 1, below),
+//                    k_correlate_4096 (fft_size 4096), k_correlate_generic (other sizes)
+//   k_candidates_wave  B(p) = zpow[p] >= max(zpow[p+1..p+T]) as a bitmap (sliding max in registers, T = 768;
+//                    k_candidates with LDS for other T)
 //   k_tile_tables    for every tile and every possible entry point, where the greedy peak
 //   k_group_tables   scan of hpp:267-298,314-317 leaves the tile (then a group of tiles); then
-//   k_scan_entries   the entry point of each tile; then the scan itself per tile + the median
-//   k_tile_detect    test (hpp:273-295)
-//   k_tags           recomputes the FFT block of every detection that is emitted in this call
-//                    and writes a raw record (correlation, neighbour bins, noise power)
-//   k_delay_copy     out[i] = in[i - (2T+1)] (hpp:318-319,342)
+//   k_scan_entries   the entry point of each tile; then the candidates the scan visits per tile
+//   k_tile_visit     and, for all of them in parallel, the median test (hpp:273-295)
+//   k_median_tests
+//   k_tags           for every detection that is emitted in this call: noise power from the transform of its
+//                    block, the correlation at its lag for every bin from its definition; writes a raw record
+//   k_compact_pending  drops the emitted detections, channel state to pinned host memory
+//   k_delay_copy     out[i] = in[i - (2T+1)] (hpp:318-319,342); skipped when the caller reads the input in place
 //
 // Why the detector can be parallel although the reference is a sequential greedy scan:
 // with r the item after the last reset (hpp:296-297), the next item whose history is tested
