@@ -168,14 +168,22 @@ def cpu_baseline(x_host, rrc, seconds_target=24.0):
                                    "(benchmarks/results.md:41,51)"}
 
 
-def pmc_traffic(samples):
+def correlator_kernel():
+    """name of the correlator kernel a default-size detector runs (GR4PM_CORRELATOR selects the round-1 ones)"""
+    return {"wave": "k_correlate", "pair": "k_correlate_pair"}.get(os.environ.get("GR4PM_CORRELATOR", ""), "k_correlate_w64")
+
+
+def pmc_traffic(samples, kernel="k_correlate_w64"):
     """roofline.traffic: HBM bytes per launch from the PMC passes committed under profiles/ (read at
     run time; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note + WRITE_SIZE, per sample of
-    the profiled launch, scaled to this launch).  null when the file is missing."""
+    the profiled launch, scaled to this launch).  null when the file is missing or describes another kernel."""
     path = os.path.join(ROOT, "profiles", "r2_k_correlate_hbm_traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
+        if not str(t.get("kernel", "")).startswith(kernel + " "):
+            return {"traffic": None, "traffic_source": f"profiles/{os.path.basename(path)} describes {t.get('kernel', '?')}, "
+                                                       f"this run launched {kernel}"}
         return {"traffic": round(float(t["traffic_bytes_per_sample"]) * samples),
                 "traffic_source": f"profiles/{os.path.basename(path)}: {t['traffic_bytes_per_sample']:.3f} B/sample "
                                   f"(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, kernel {t.get('kernel', '?')})"}
@@ -363,7 +371,7 @@ def config5(args):
                        "fir_1025_taps_x4_msps_out": round(fir_rate, 1),
                        "symbol_filter_32x1025_taps_msps_in": round(symf_rate, 1) if isinstance(symf_rate, float) else symf_rate},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": "correlator, N = 4096",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": "k_correlate_4096",
                          "launch_ms": round(ms, 4), "samples_per_launch": samples, "alg_bytes_per_sample": 8,
                          "fp32_tflops": round(flops / (ms * 1e-3) / 1e12, 2),
                          "fp32_frac": round(flops / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)},
@@ -666,8 +674,9 @@ def main():
         flops = 710.0 * samples  # (1+B) 5N log2 N + 6BN + 1.5N + 4BS per stride, B = 9
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5),
-                    **pmc_traffic(samples),
-                    "kernel": "k_correlate", "launch_ms": round(ms, 4), "samples_per_launch": samples,
+                    **pmc_traffic(samples, correlator_kernel()),
+                    "kernel": correlator_kernel(),
+                    "launch_ms": round(ms, 4), "samples_per_launch": samples,
                     "alg_bytes_per_sample": 8,
                     "fp32_tflops": round(flops / (ms * 1e-3) / 1e12, 2),
                     "fp32_frac": round(flops / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)}
@@ -699,7 +708,11 @@ def main():
                        "items_per_step_per_gpu": n_items * args.channels, "channels_per_gpu": args.channels, "freq_bins": 2 * BINS + 1, "tags_per_step": n_tags // max(args.steps, 1),
                        "parallelism": f"channel-per-gpu x{world}", "input": input_mode,
                        "pipelined_streams": 1 if (args.no_pipeline or args.detector_only) else (3 if args.python_pipeline else 4),
-                       "pipeline_driver": "native (gr4pm_packet_receiver)" if native else "python threads",
+                       "pipeline_driver": ("native (gr4pm_multichannel_receiver: submit / collect, 4 batches in flight, "
+                                           + ("delayed copy per batch" if args.copy_delay else "input read in place") + ")"
+                                           if (multi is not None and not args.python_pipeline and not args.no_pipeline) else
+                                           "native (gr4pm_multichannel_receiver, synchronous)" if (multi is not None and not args.python_pipeline) else
+                                           "native (gr4pm_packet_receiver)" if native else "python threads"),
                        "windows": 2, "correlator_lookahead": 0 if args.no_lookahead else args.lookahead_depth,
                        **({"headers": hdr_stats} if args.decode_headers else {})},
             "roofline": roofline,
