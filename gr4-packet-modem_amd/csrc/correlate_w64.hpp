@@ -172,7 +172,7 @@ __global__ __launch_bounds__(kW64Threads, 2) void k_correlate_w64(const cf* __re
                                                                   const float4* __restrict__ tT,
                                                                   const cf* __restrict__ cc,
                                                                   float* __restrict__ zpow, size_t z_stride,
-                                                                  uint32_t blocks_per_wave)
+                                                                  uint32_t blocks_per_wave, uint32_t noise_rel)
 {
     __shared__ float4 lds4[kW64LdsF4];
     const int tid = threadIdx.x;
@@ -230,6 +230,30 @@ __global__ __launch_bounds__(kW64Threads, 2) void k_correlate_w64(const cf* __re
             dft32(bq);
 #pragma unroll
             for (int j = 0; j < 32; ++j) X[j] = bq[j];
+        }
+        if (noise_rel) {
+            // hpp:257-265: the block's noise power is the energy of the spectrum's middle half, bins N/4 .. 3N/4 - 1 =
+            // registers 8 .. 23 of every lane.  One float per block, behind the channel's powers (k_tags reads it for
+            // the few blocks that hold a detection instead of transforming them again).  Unnormalised.
+            float e = 0.0f;
+#pragma unroll
+            for (int j = 8; j < 24; ++j) e = fmaf(X[j].y, X[j].y, fmaf(X[j].x, X[j].x, e));
+            // wave sum into lane 63 with DPP adds (an inclusive scan; no lane-index registers that LICM would keep
+            // alive across the bin loop, unlike __shfl_xor: 218 instead of 210 VGPRs)
+            asm volatile("s_nop 1\n\t"
+                         "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 1\n\t"
+                         "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 1\n\t"
+                         "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 1\n\t"
+                         "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 1\n\t"
+                         "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                         "s_nop 1\n\t"
+                         "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+                         : "+v"(e));
+            if (lane == 63) zpow[static_cast<size_t>(ch) * z_stride + noise_rel + 1 + blk] = e;
         }
         float zmax[32];
 #pragma unroll

@@ -1133,7 +1133,10 @@ __device__ __forceinline__ cf sample_at(const cf* cur, const cf* carry, uint32_t
 
 // ------------------------------------------------------------------ k_tags
 // one wave per pending detection; emits a raw record when the tag leaves in this call, i.e.
-// pos + hist in [E0, E1).  Same arithmetic as k_correlate for the block containing pos.
+// pos + hist in [E0, E1).  FFT_NOISE: the noise power comes from a forward transform of the block containing pos (same
+// arithmetic as k_correlate); otherwise k_correlate_w64 has left it behind the channel's powers (noise_rel) and the
+// kernel needs neither the transform's LDS nor its registers.
+template <bool FFT_NOISE>
 __global__ __launch_bounds__(64) void k_tags(const cf* __restrict__ in, size_t in_stride,
                                              const cf* __restrict__ carry, size_t carry_stride,
                                              uint32_t xc, unsigned long long E0, unsigned long long E1,
@@ -1144,12 +1147,12 @@ __global__ __launch_bounds__(64) void k_tags(const cf* __restrict__ in, size_t i
                                              const float* __restrict__ zcur, size_t z_stride,
                                              ChanState* __restrict__ st,
                                              const unsigned long long* __restrict__ det, uint32_t det_cap,
-                                             RawTag* __restrict__ rec, uint32_t rec_cap)
+                                             RawTag* __restrict__ rec, uint32_t rec_cap, uint32_t noise_rel)
 {
 #ifndef GR4PM_NO_SETPRIO
     __builtin_amdgcn_s_setprio(3); // latency-bound, few waves: win the issue arbitration against throughput kernels
 #endif
-    __shared__ cf lds[kExchangeItems];
+    __shared__ cf lds[FFT_NOISE ? kExchangeItems : 1];
     __shared__ cf zbin[kMaxBins];
     const uint32_t ch = blockIdx.y;
     const uint32_t n_det = min(st[ch].det_cnt, det_cap);
@@ -1166,24 +1169,30 @@ __global__ __launch_bounds__(64) void k_tags(const cf* __restrict__ in, size_t i
     const long long o = static_cast<long long>(blk * stride_s) - static_cast<long long>(E0);
     const cf* cur = in + static_cast<size_t>(ch) * in_stride;
     const cf* car = carry + static_cast<size_t>(ch) * carry_stride;
-    cf r[32];
-#pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) {
-        r[2 * n1] = sample_at(cur, car, xc, o + 2 * lane + 128 * n1);
-        r[2 * n1 + 1] = sample_at(cur, car, xc, o + 2 * lane + 1 + 128 * n1);
-    }
-    fft1_wave(lane, r, lds, tw1a, tw1b);
-    cf X[32];
-#pragma unroll
-    for (int j = 0; j < 32; ++j) X[j] = r[j];
-    // noise power: bins N/4 .. 3N/4-1 == k3 in {2,3,4,5} (hpp:257-265)
     float noise = 0.0f;
+    if constexpr (FFT_NOISE) {
+        cf r[32];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+        for (int n1 = 0; n1 < 16; ++n1) {
+            r[2 * n1] = sample_at(cur, car, xc, o + 2 * lane + 128 * n1);
+            r[2 * n1 + 1] = sample_at(cur, car, xc, o + 2 * lane + 1 + 128 * n1);
+        }
+        fft1_wave(lane, r, lds, tw1a, tw1b);
+        // noise power: bins N/4 .. 3N/4-1 == k3 in {2,3,4,5} (hpp:257-265)
 #pragma unroll
-        for (int k3 = 2; k3 < 6; ++k3) noise += cnorm(X[8 * q + k3]);
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) noise += __shfl_xor(noise, d);
+            for (int k3 = 2; k3 < 6; ++k3) noise += cnorm(r[8 * q + k3]);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) noise += __shfl_xor(noise, d);
+    } else {
+        (void)tw1a;
+        (void)tw1b;
+        (void)lds;
+        // block b of this call, or the last block of the call before (b = -1): the carried value at [0]
+        const long long b = static_cast<long long>(blk) - static_cast<long long>(E0 / stride_s);
+        noise = zcur[static_cast<size_t>(ch) * z_stride + noise_rel + 1 + b];
+    }
     noise /= static_cast<float>(kFftN / 2) * static_cast<float>(kFftN);
 
     // The correlation at the ONE lag of the detection, for every bin, straight from its definition instead of
@@ -1476,11 +1485,13 @@ __global__ void k_update_carry(const cf* __restrict__ in, size_t in_stride, cons
 
 // zcur head (zc items before item E0) = tail of the previous call's z buffer
 __global__ void k_update_zcarry(const float* __restrict__ zprev, float* __restrict__ zcur, size_t z_stride,
-                                uint32_t zc, size_t n_prev)
+                                uint32_t zc, size_t n_prev, uint32_t noise_off, uint32_t n_prev_blocks)
 {
     const float* p = zprev + static_cast<size_t>(blockIdx.y) * z_stride;
     float* c = zcur + static_cast<size_t>(blockIdx.y) * z_stride;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    // the noise power of the last block of the call before: a detection in its last 2T + 1 items is emitted by this call
+    if (i == 0) c[noise_off] = n_prev_blocks ? p[noise_off + n_prev_blocks] : 0.0f;
     if (i >= zc) return;
     c[i] = p[n_prev + i]; // prev layout: [zc carry][n_prev items]; take its last zc entries
 }
@@ -1526,6 +1537,8 @@ struct gr4pm_syncword_detection {
     // geometry of carried state
     uint32_t xc, zc;
     size_t z_stride, bm_stride, table_stride;
+    uint32_t noise_off = 0; // per channel row of a z set: [zc carried powers][items][...] and, from here, one noise power
+                            // per block: [0] the last block of the call before, [1 + b] block b (k_correlate_w64 writes them)
     uint32_t max_tiles, det_cap, rec_cap;
     // device
     DevBuf<float4> tmpl;
@@ -1716,7 +1729,7 @@ gr4pm_status launch_correlate(gr4pm_syncword_detection* h, hipStream_t stream, c
 #define GR4PM_W64_LAUNCH(V)                                                                                         \
     hipLaunchKernelGGL(k_correlate_w64<V>, dim3(wgs), dim3(kW64Threads), 0, stream, reinterpret_cast<const cf*>(in), \
                        in_stride, n_blocks, total, static_cast<uint32_t>(h->S), h->n_bins, h->tmpl64.p, h->tT64.p,  \
-                       h->cc64.p, zout, h->z_stride, bpw)
+                       h->cc64.p, zout, h->z_stride, bpw, h->noise_off - h->zc)
         // GR4PM_W64_VARIANT: the timing-only ablations of tools/w64_variants.py
         switch (h->w64_variant) {
         case 8: GR4PM_W64_LAUNCH(8); break;
@@ -1771,7 +1784,8 @@ gr4pm_status launch_front(gr4pm_syncword_detection* h, hipStream_t stream, int w
     // correlator -- behind that call's on its stream -- is); sample carry for the call after this
     // one: the last xc items up to E1
     hipLaunchKernelGGL(k_update_zcarry, dim3((h->zc + 255) / 256, nch), dim3(256), 0, stream,
-                       h->z[(which + kSets - 1) % kSets].p, zw, h->z_stride, h->zc, n_prev);
+                       h->z[(which + kSets - 1) % kSets].p, zw, h->z_stride, h->zc, n_prev, h->noise_off,
+                       static_cast<uint32_t>(n_prev / h->S));
     hipLaunchKernelGGL(k_update_carry, dim3((h->xc + 255) / 256, nch), dim3(256), 0, stream,
                        reinterpret_cast<const cf*>(in), in_stride, h->carry[ci].p, h->carry[(ci + 1) % kCarry].p,
                        static_cast<size_t>(h->xc), h->xc, J);
@@ -2006,7 +2020,8 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
 
     h->xc = static_cast<uint32_t>(round_up(h->hist + h->S + 2, 64));
     h->zc = static_cast<uint32_t>(round_up(2 * h->T + 2, 64));
-    h->z_stride = h->zc + round_up(h->max_items, 64) + 64;
+    h->noise_off = static_cast<uint32_t>(h->zc + round_up(h->max_items, 64) + 64);
+    h->z_stride = h->noise_off + round_up(h->max_items / h->S + 4, 64);
     const size_t max_cnt = h->max_items + h->T;
     h->bm_stride = round_up(max_cnt, kCandTile) / 64 + 16;
     h->max_tiles = static_cast<uint32_t>((max_cnt + kTileW - 1) / kTileW);
@@ -2232,15 +2247,21 @@ gr4pm_status gr4pm_syncword_detection_process(gr4pm_syncword_detection* h, const
                            static_cast<uint32_t>(h->hist), static_cast<uint32_t>(h->S), N, h->log2n, h->n_bins,
                            h->g_tmpl.p, h->g_tw.p, zcur + h->zc, h->z_stride, h->st.p, h->det.p, h->det_cap,
                            h->rec_host.p, h->rec_cap);
-    } else
-    hipLaunchKernelGGL(k_tags, dim3(std::min<uint32_t>(h->det_cap, 4096u), nch), dim3(64), 0, s,
-                       reinterpret_cast<const cf*>(in),
-                       in_stride, carry, static_cast<size_t>(h->xc), h->xc,
-                       static_cast<unsigned long long>(E0), static_cast<unsigned long long>(E1),
-                       static_cast<uint32_t>(h->hist), static_cast<uint32_t>(h->S), h->n_bins, h->tmpl.p,
-                       h->tw.p, h->tw.p + kTw1aItems, h->tw.p + kTw1aItems + kTw1bItems,
-                       h->tw.p + kTw1aItems + kTw1bItems + kTwAItems, h->td.p, static_cast<uint32_t>(h->L),
-                       zcur + h->zc, h->z_stride, h->st.p, h->det.p, h->det_cap, h->rec_host.p, h->rec_cap);
+    } else {
+        auto launch_tags = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3(std::min<uint32_t>(h->det_cap, 4096u), nch), dim3(64), 0, s,
+                               reinterpret_cast<const cf*>(in), in_stride, carry, static_cast<size_t>(h->xc), h->xc,
+                               static_cast<unsigned long long>(E0), static_cast<unsigned long long>(E1),
+                               static_cast<uint32_t>(h->hist), static_cast<uint32_t>(h->S), h->n_bins, h->tmpl.p, h->tw.p,
+                               h->tw.p + kTw1aItems, h->tw.p + kTw1aItems + kTw1bItems,
+                               h->tw.p + kTw1aItems + kTw1bItems + kTwAItems, h->td.p, static_cast<uint32_t>(h->L),
+                               zcur + h->zc, h->z_stride, h->st.p, h->det.p, h->det_cap, h->rec_host.p, h->rec_cap,
+                               h->noise_off - h->zc);
+        };
+        // k_correlate_w64 leaves every block's noise power behind the powers; the round-1 correlators do not
+        if (h->corr_kind == 0 && !h->use_pair) launch_tags(k_tags<false>);
+        else launch_tags(k_tags<true>);
+    }
     hipLaunchKernelGGL(k_compact_pending, dim3(nch), dim3(64), 0, s, h->st.p, h->st_host.p, h->det.p,
                        h->det_cap, static_cast<unsigned long long>(E1), static_cast<uint32_t>(h->hist),
                        static_cast<int>(nch));
