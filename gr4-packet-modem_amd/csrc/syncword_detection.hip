@@ -641,21 +641,15 @@ __global__ __launch_bounds__(64) void k_candidates_wave(const float* __restrict_
             v[r] = g < avail ? z[g] : -INFINITY;
         }
     };
-    // per block: rs[r] = suffix maximum inside row r (inclusive, reversed lanes), after[r] = maximum of the rows
-    // behind r (uniform), pr[r] = prefix maximum of the block up to the lane's item (inclusive, reversed lanes)
-    auto scans = [&](const float* v, float* rs, float* after, float* pr) {
-        float rowmax[TQ];
+    // per block: rs[r] = suffix maximum inside row r (inclusive, reversed lanes), rowmax[r] = maximum of row r (uniform:
+    // readlane, i.e. an SGPR), pr[r] = prefix maximum of the block up to the lane's item (inclusive, reversed lanes)
+    auto scans = [&](const float* v, float* rs, float* rowmax, float* pr) {
 #pragma unroll
         for (int r = 0; r < TQ; ++r) {
             rs[r] = wave_prefix_max(v[r]);
             rowmax[r] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rs[r]), 63));
         }
-        float a = -INFINITY;
-#pragma unroll
-        for (int r = TQ - 1; r >= 0; --r) {
-            after[r] = a;
-            a = fmaxf(a, rowmax[r]);
-        }
+        if (!pr) return;
         float carry = -INFINITY;
 #pragma unroll
         for (int r = 0; r < TQ; ++r) {
@@ -665,20 +659,22 @@ __global__ __launch_bounds__(64) void k_candidates_wave(const float* __restrict_
             carry = fmaxf(carry, rowmax[r]);
         }
     };
-    float cur[TQ], rs[TQ], after[TQ], pr[TQ], nxt[TQ];
+    float cur[TQ], rs[TQ], rowmax[TQ], nxt[TQ];
     load(b0, cur);
-    scans(cur, rs, after, pr);
+    scans(cur, rs, rowmax, nullptr);
     for (uint32_t b = b0; b < b1; ++b) {
         load(b + 1, nxt);
-        float nrs[TQ], nafter[TQ], npr[TQ];
-        scans(nxt, nrs, nafter, npr);
+        float nrs[TQ], nrowmax[TQ], npr[TQ];
+        scans(nxt, nrs, nrowmax, npr);
         unsigned long long mine = 0;
+        float after = -INFINITY; // maximum of the rows behind r (uniform): built while r walks down
 #pragma unroll
-        for (int r = 0; r < TQ; ++r) {
-            const float m = fmaxf(fmaxf(wave_prev(rs[r]), after[r]), npr[r]);
+        for (int r = TQ - 1; r >= 0; --r) {
+            const float m = fmaxf(fmaxf(wave_prev(rs[r]), after), npr[r]);
             const uint32_t pos = b * T + 64u * r + rl;
             const unsigned long long word = __brevll(__ballot(pos < cnt && cur[r] >= m)); // back to item order
             if (lane == r) mine = word;
+            after = fmaxf(after, rowmax[r]);
         }
         const uint32_t w = b * TQ + lane;
         if (lane < TQ && w < n_words) bmp[w] = mine;
@@ -686,7 +682,7 @@ __global__ __launch_bounds__(64) void k_candidates_wave(const float* __restrict_
         for (int r = 0; r < TQ; ++r) {
             cur[r] = nxt[r];
             rs[r] = nrs[r];
-            after[r] = nafter[r];
+            rowmax[r] = nrowmax[r];
         }
     }
 }
