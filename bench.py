@@ -532,7 +532,8 @@ def main():
                 sd = multi.syncword_detection
             else:
                 multi = pkg.NativeMultiChannelReceiver(C, SPS, BINS, 9.5, "QPSK", max_items=n_items,
-                                                       tags_cap=max(64, 2 * n_pkt + 64), workers=args.channel_workers)
+                                                       tags_cap=max(64, 2 * n_pkt + 64), workers=args.channel_workers,
+                                                       output_ring=True)
                 if not args.copy_delay:  # the ring's windows stay valid and unchanged: no delayed copy per batch
                     multi.set_input_in_place(True)
                 sd = multi  # announce() goes to the library's detector

@@ -1495,8 +1495,13 @@ class NativeMultiChannelReceiver:
     process_bulk(x[n_channels, n], packet_length) -> one dict per channel."""
 
     def __init__(self, n_channels, samples_per_symbol=4, syncword_freq_bins=4, syncword_threshold=9.5,
-                 costas_constellation="QPSK", max_items=1 << 22, tags_cap=4096, workers=12):
+                 costas_constellation="QPSK", max_items=1 << 22, tags_cap=4096, workers=12, output_ring=False):
         self.n_channels = n_channels
+        # output_ring (streaming callers, bench.py): submit() takes its symbol buffer from a ring of 6 (more than the
+        # batches in flight) instead of allocating one per batch -- a device allocation in the middle of a stream stalls
+        # every stage; a result's "symbols" then stay valid until five further batches have been submitted
+        self.output_ring = output_ring
+        self._ring, self._ring_next = [], 0
         self.samples_per_symbol = samples_per_symbol
         self.tags_cap = max(int(tags_cap), 64)
         p = _abi.MultiChannelReceiverParams(n_channels, samples_per_symbol, syncword_freq_bins, syncword_threshold,
@@ -1520,7 +1525,14 @@ class NativeMultiChannelReceiver:
         assert x.dim() == 2 and x.shape[0] == self.n_channels
         Cn, n = self.n_channels, x.shape[1]
         stride = n // self.samples_per_symbol + self.tags_cap + 64
-        sym = torch.empty((Cn, stride), dtype=torch.complex64, device=x.device)
+        if self.output_ring:
+            if not self._ring or self._ring[0].shape[1] < stride:
+                self._ring = [torch.empty((Cn, stride), dtype=torch.complex64, device=x.device) for _ in range(6)]
+            sym = self._ring[self._ring_next][:, :stride]
+            stride = self._ring[self._ring_next].stride(0)
+            self._ring_next = (self._ring_next + 1) % 6
+        else:
+            sym = torch.empty((Cn, stride), dtype=torch.complex64, device=x.device)
         consumed = C.c_size_t(0)
         check(lib().gr4pm_multichannel_receiver_submit(
             self._h, x.data_ptr(), x.stride(0), n, 0 if packet_length is None else int(packet_length),
