@@ -384,7 +384,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=8)  # covers the first use of every buffer ring
-    ap.add_argument("--items", type=int, default=1 << 26, help="samples per step per GPU")
+    ap.add_argument("--items", type=int, default=None,
+                    help="samples per step per GPU (per channel with --channels).  Default: 2^28 (SURVEY.md 8(d) config 2: "
+                         "2^28 samples resident in HBM per pass), 2^22 per channel with --channels (config 3), 2^26 with "
+                         "--config 5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--detector-only", action="store_true", help="time SyncwordDetection alone")
     ap.add_argument("--channels", type=int, default=1,
@@ -421,6 +424,8 @@ def main():
                     help="launcher / aggregation check without a GPU: every rank joins a gloo group, aggregates "
                          "fixed numbers and rank 0 prints the line (tests/test_distributed_cpu.py)")
     args = ap.parse_args()
+    if args.items is None:
+        args.items = 1 << 26 if args.config == 5 else (1 << 22 if args.channels > 1 else 1 << 28)
     world_env = os.environ.get("WORLD_SIZE")
     if world_env is None and args.gpus > 1:
         # plain `python bench.py --gpus N`: start the N ranks ourselves, as fresh child processes,

@@ -19,9 +19,9 @@ run python_pipeline --python-pipeline
 run soft_bits --soft-bits
 run decode_headers --decode-headers
 run detector_only --detector-only
-run channels64 --channels 64 --items 4194304 --steps 40 --warmup 6
-run channels64_sync --channels 64 --items 4194304 --steps 40 --warmup 6 --no-pipeline
-run channels64_detector --channels 64 --items 4194304 --steps 40 --warmup 6 --detector-only
+run channels64 --channels 64 --steps 40 --warmup 6
+run channels64_sync --channels 64 --steps 40 --warmup 6 --no-pipeline
+run channels64_detector --channels 64 --steps 40 --warmup 6 --detector-only
 run config5 --config 5 --steps 10 --warmup 3
 GR4PM_CORRELATOR=wave run default_round1_correlator
 python3 tools/benchmark_syncword_detection.py 4 9.5 2>/dev/null | tail -2
