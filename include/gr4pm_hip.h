@@ -264,7 +264,8 @@ gr4pm_status gr4pm_syncword_wipeoff_reset(gr4pm_syncword_wipeoff* h);
 gr4pm_status gr4pm_syncword_wipeoff_process(gr4pm_syncword_wipeoff* h, const gr4pm_c64* in,
                                             size_t n, gr4pm_c64* out, const gr4pm_tag* tags,
                                             size_t n_tags);
-/* many channels, in place, one launch: h[c] is channel c's block (one syncword for all), its items are
+/* many channels, in place, one launch (per channel SyncwordWipeoff::processBulk, syncword_wipeoff.hpp:38-90):
+ * h[c] is channel c's block (one syncword for all), its items are
  * buf[c * stride .. c * stride + n[c]), its tags tags[c][0 .. n_tags[c]).  Runs on h[0]'s stream. */
 gr4pm_status gr4pm_syncword_wipeoff_process_channels(gr4pm_syncword_wipeoff* const* h, size_t n_channels,
                                                      gr4pm_c64* buf, size_t stride, const size_t* n,
@@ -347,7 +348,8 @@ gr4pm_status gr4pm_cfc_symbol_filter_run_channel(gr4pm_rotator* cfc, int plan, s
                                                  size_t n_tags_in, gr4pm_tag* tags_out, size_t tags_cap,
                                                  size_t* n_tags_out, size_t* consumed, size_t* produced);
 /* ... or ALL channels in ONE launch of the filter kernel (64 channels of 2^22 items are 64 small launches
- * otherwise): sf[c] is channel c's SymbolFilter (one design for all; its tag-driven state is replayed on the
+ * otherwise; per channel it is SymbolFilter::processBulk, symbol_filter.hpp:112-252, fed by
+ * CoarseFrequencyCorrection::processBulk, coarse_frequency_correction.hpp:67-98): sf[c] is channel c's SymbolFilter (one design for all; its tag-driven state is replayed on the
  * host exactly as by _run_channel), in: [n_channels][in_stride], out: [n_channels][out_stride] (out_stride >=
  * n_in / samples_per_symbol + tags + 2), tags_in[c] / n_tags_in[c] and tags_out[c] (tags_cap each) /
  * n_tags_out[c] / produced[c] per channel.  Runs on sf[0]'s stream.
@@ -736,7 +738,8 @@ gr4pm_status gr4pm_multichannel_receiver_collect(gr4pm_multichannel_receiver* h,
                                                  size_t* n_detector_tags);
 int gr4pm_multichannel_receiver_in_flight(const gr4pm_multichannel_receiver* h);
 /* on: the caller keeps every submitted input valid and unchanged until its batch has been collected (a device
- * ring).  The receiver then reads SyncwordDetection's delayed stream in place (the tail of the batch before, kept
+ * ring).  SyncwordDetection's output is its input delayed by 2 * time_threshold + 1 items
+ * (syncword_detection.hpp:318-319,342).  The receiver then reads SyncwordDetection's delayed stream in place (the tail of the batch before, kept
  * by the receiver, + the batch's own input) instead of writing a delayed copy of every batch (16 B/sample).
  * Same results.  Call it before the first batch. */
 gr4pm_status gr4pm_multichannel_receiver_set_input_in_place(gr4pm_multichannel_receiver* h, int on);
