@@ -112,3 +112,19 @@ def test_packet_transmitter_rrc_taps_computed_in_product(pkg):
     got = pkg.packet_transmitter_rrc_taps(4)
     ref = np.load(os.path.join(ROOT, "tests", "golden", "ref_txrrc_4.npy"))
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_bench_roofline_traffic_comes_from_the_committed_counters(monkeypatch):
+    """roofline.traffic is read from profiles/ at run time (never a constant in bench.py) and only for the kernel the
+    counters were taken on: another correlator kernel gets null and a reason"""
+    import bench
+    samples = 67106856
+    t = bench.pmc_traffic(samples, "k_correlate_w64")
+    assert t["traffic"] is not None and 11.5 * samples < t["traffic"] < 13.5 * samples
+    assert "r2_k_correlate_hbm_traffic.json" in t["traffic_source"]
+    other = bench.pmc_traffic(samples, "k_correlate")
+    assert other["traffic"] is None and "describes" in other["traffic_source"]
+    monkeypatch.setenv("GR4PM_CORRELATOR", "wave")
+    assert bench.correlator_kernel() == "k_correlate"
+    monkeypatch.delenv("GR4PM_CORRELATOR")
+    assert bench.correlator_kernel() == "k_correlate_w64"
