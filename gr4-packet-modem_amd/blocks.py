@@ -45,6 +45,13 @@ def _dev_c64(x, what="in"):
     return x
 
 
+def _inputs_ready(x):
+    """The receivers inside the library run on streams of their own (non-blocking: they do not order themselves against
+    torch's streams).  An input that a torch kernel is still writing on the caller's current stream would be read too
+    early: wait for that stream (a few microseconds when it is idle)."""
+    _torch().cuda.current_stream(x.device).synchronize()
+
+
 def _dev_c64_rows(x, what="in"):
     """[channels, n] with contiguous rows; the row stride is free (a window of a wider ring)"""
     torch = _torch()
@@ -1514,6 +1521,7 @@ class NativeMultiChannelReceiver:
     def announce(self, x):
         x = _dev_c64_rows(x)
         assert x.dim() == 2 and x.shape[0] == self.n_channels
+        _inputs_ready(x)
         check(lib().gr4pm_multichannel_receiver_announce(self._h, x.data_ptr(), x.stride(0), x.shape[1]),
               "MultiChannelReceiver.announce")
 
@@ -1523,6 +1531,7 @@ class NativeMultiChannelReceiver:
         torch = _torch()
         x = _dev_c64_rows(x)
         assert x.dim() == 2 and x.shape[0] == self.n_channels
+        _inputs_ready(x)
         Cn, n = self.n_channels, x.shape[1]
         stride = n // self.samples_per_symbol + self.tags_cap + 64
         if self.output_ring:
@@ -1565,6 +1574,7 @@ class NativeMultiChannelReceiver:
         torch = _torch()
         x = _dev_c64_rows(x)
         assert x.dim() == 2 and x.shape[0] == self.n_channels
+        _inputs_ready(x)
         Cn, n = self.n_channels, x.shape[1]
         stride = n // self.samples_per_symbol + self.tags_cap + 64
         sym = torch.empty((Cn, stride), dtype=torch.complex64, device=x.device)
@@ -1616,6 +1626,7 @@ class NativePacketReceiver:
         """names the input of a later submit (after the ones already announced): the detector's
         look-ahead, up to two batches ahead.  The caller keeps x alive and unchanged until then."""
         x = _dev_c64(x)
+        _inputs_ready(x)
         check(lib().gr4pm_packet_receiver_announce(self._h, x.data_ptr(), x.numel()), "PacketReceiver.announce")
 
     # output buffers.  output_ring=True (streaming callers, bench.py): a ring of _OUT_RING sets (more
@@ -1645,6 +1656,7 @@ class NativePacketReceiver:
 
     def submit(self, x, packet_length=None, history=None, next_x=None):
         x = _dev_c64(x)
+        _inputs_ready(x)
         n = x.numel()
         sym, llr, pk = self._outputs(n, x.device)
         delayed = None
