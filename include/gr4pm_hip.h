@@ -679,7 +679,9 @@ void gr4pm_packet_receiver_destroy(gr4pm_packet_receiver* h);
  * delayed stream in place).  next_in/next_n: the following batch (look-ahead) or NULL.
  * out_symbols (device, out_cap >= n_in / samples_per_symbol + tags + 2) and out_llr (device,
  * soft_bits, 2 floats per symbol) and out_packets (device, decode_headers, n_in / 16 bytes is
- * always enough) stay the caller's; the result points at them. */
+ * always enough) stay the caller's; the result points at them.  The receiver works on streams of its
+ * own, which are not ordered against the caller's: `in` (and `next_in`, and what announce names) must be
+ * complete when the call is made. */
 gr4pm_status gr4pm_packet_receiver_submit(gr4pm_packet_receiver* h, const gr4pm_c64* in, size_t n_in,
                                           const gr4pm_c64* delayed, const gr4pm_c64* next_in,
                                           size_t next_n, uint64_t packet_length, gr4pm_c64* out_symbols,
@@ -729,7 +731,9 @@ gr4pm_status gr4pm_multichannel_receiver_process(gr4pm_multichannel_receiver* h,
                                                  size_t* n_symbols, gr4pm_tag* tags, size_t* n_tags,
                                                  gr4pm_tag* detector_tags, size_t* n_detector_tags);
 
-/* the pipelined form: out_symbols must stay valid until the batch has been collected */
+/* the pipelined form: out_symbols must stay valid until the batch has been collected.  The receiver works on
+ * streams of its own, which are not ordered against the caller's: `in` must be complete (its producer finished,
+ * or waited for) when submit / announce is called. */
 gr4pm_status gr4pm_multichannel_receiver_submit(gr4pm_multichannel_receiver* h, const gr4pm_c64* in,
                                                 size_t in_stride, size_t n_in, uint64_t packet_length,
                                                 gr4pm_c64* out_symbols, size_t out_stride, size_t* consumed);
