@@ -294,6 +294,15 @@ __global__ __launch_bounds__(kW64Threads, 2) void k_correlate_w64(const cf* __re
                     float pw[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) pw[u] = fmaf(bq[j0 + u].y, bq[j0 + u].y, bq[j0 + u].x * bq[j0 + u].x);
+                    if ((VAR & 16384) && j0 == 0) {
+                        // lags of registers 1 .. 3 are 2048 - 64 j - lane >= 1793: never stored when stride_s <= 1793
+                        // (the launch checks it), so neither their powers nor the last additions of pass B for them exist
+                        asm("v_max_f32 %0, %0, %5\n\tv_max_f32 %1, %1, %6\n\tv_max_f32 %2, %2, %7\n\tv_max_f32 %3, %3, %8\n\t"
+                            "v_max_f32 %4, %4, %9"
+                            : "+v"(zmax[0]), "+v"(zmax[4]), "+v"(zmax[5]), "+v"(zmax[6]), "+v"(zmax[7])
+                            : "v"(pw[0]), "v"(pw[4]), "v"(pw[5]), "v"(pw[6]), "v"(pw[7]));
+                        continue;
+                    }
                     asm("v_max_f32 %0, %0, %8\n\tv_max_f32 %1, %1, %9\n\tv_max_f32 %2, %2, %10\n\tv_max_f32 %3, %3, %11\n\t"
                         "v_max_f32 %4, %4, %12\n\tv_max_f32 %5, %5, %13\n\tv_max_f32 %6, %6, %14\n\tv_max_f32 %7, %7, %15"
                         : "+v"(zmax[j0]), "+v"(zmax[j0 + 1]), "+v"(zmax[j0 + 2]), "+v"(zmax[j0 + 3]), "+v"(zmax[j0 + 4]),
@@ -312,6 +321,7 @@ __global__ __launch_bounds__(kW64Threads, 2) void k_correlate_w64(const cf* __re
             float* zl = zo + (kFftN - ln); // lag of register j: 2048 - lane - 64 j (j = 0, lane = 0: lag 0)
 #pragma unroll
             for (int j = 0; j < 32; ++j) {
+                if ((VAR & 16384) && j >= 1 && j <= 3) continue; // lags >= 1793 > stride_s
                 const uint32_t lag = static_cast<uint32_t>((kFftN - (ln + 64 * j)) & (kFftN - 1));
                 if (j == 0) {
                     if (lag < stride_s) zo[lag] = zmax[0];

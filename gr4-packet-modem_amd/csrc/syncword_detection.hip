@@ -1542,6 +1542,7 @@ struct gr4pm_syncword_detection {
     // the one-exchange correlator (fft2048_w64.hpp, k_correlate_w64): templates in its lane order
     // ([bin][16][64] float4), mid-stage twiddle table, lane constants
     bool lds_candidates = false; // GR4PM_CANDIDATES_LDS at creation: k_candidates also for T = 768
+    bool w64_no_prune = false;   // GR4PM_W64_NO_PRUNE at creation: the correlator variant that computes all 32 registers
     int corr_kind = 0; // 0: k_correlate_w64 (default), 1: k_correlate (two exchanges), 2: k_correlate_pair
     DevBuf<float4> tmpl64, tT64;
     DevBuf<cf> td; // [bin][L] conj of the float time-domain templates (hpp:166-182): k_tags' direct correlation
@@ -1735,7 +1736,12 @@ gr4pm_status launch_correlate(gr4pm_syncword_detection* h, hipStream_t stream, c
         case 2048: GR4PM_W64_LAUNCH(2048); break;
         case 4096: GR4PM_W64_LAUNCH(4096); break;
         case 6144: GR4PM_W64_LAUNCH(6144); break;
-        default: GR4PM_W64_LAUNCH(0); break;
+        default:
+            // registers 1 .. 3 of the output hold lags >= 1793: with a stride of at most that (the default: 1752) the
+            // kernel variant that never computes their powers runs
+            if (h->S <= 1793 && !h->w64_no_prune) GR4PM_W64_LAUNCH(16384);
+            else GR4PM_W64_LAUNCH(0);
+            break;
         }
 #undef GR4PM_W64_LAUNCH
         GR4PM_HIP_TRY(hipGetLastError());
@@ -2035,6 +2041,7 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
     if (h->fault.p) *h->fault.p = 0;
     if (const char* e = getenv("GR4PM_TEST_SPIN_LIMIT")) h->spin_limit = atoi(e); // tests force a timeout with 0
     h->lds_candidates = getenv("GR4PM_CANDIDATES_LDS") != nullptr;
+    h->w64_no_prune = getenv("GR4PM_W64_NO_PRUNE") != nullptr;
     ok(h->tmpl64.alloc(tmpl64.size()));
     ok(h->tT64.alloc(tT64.size()));
     ok(h->td.alloc(td.size()));

@@ -308,6 +308,38 @@ def test_syncword_detection_awgn_threshold_and_noise_only(pkg):
     assert tags.size >= 3
 
 
+def test_syncword_detection_two_samples_per_symbol_long_stride(pkg):
+    """samples_per_symbol = 2: the template is 63 * 2 + 23 = 149 samples, the overlap-save stride 2048 - 149 + 1 = 1900.
+    Above a stride of 1793 the lags held by output registers 1 .. 3 of the correlator are stored, i.e. the kernel
+    variant that computes all 32 registers runs (the default stride, 1752, takes the one that leaves them out):
+    powers, pass-through samples and tags against the oracle, in one call and in chunks"""
+    locations = [300, 4100, 9000, 15000, 22222]
+    x, rrc = sig.qa_syncword_stream(30000, locations, 0.01, seed=21, sps=2)
+    x = (0.6 * x + sig.awgn(x.size, 0.15, 22)).astype(np.complex64)
+    kw = dict(samples_per_symbol=2, power_threshold=9.5)
+    ref = orc.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, **kw)
+    _, ref_out, ref_tags, ref_zpow, _ = ref.process(x, debug=True)
+    sd = pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, max_items=x.size, **kw)
+    st, out, tags, n = sd.process_bulk(dev(x))
+    assert n == ref_out.size and n % 1900 == 0 and np.array_equal(bits(host(out)), bits(ref_out))
+    assert_tags_match(tags, ref_tags, rtol=2e-4)
+    assert tags.size >= 4
+    zpow = host(sd.last_zpow(n))[0]
+    assert np.max(np.abs(zpow - ref_zpow)) / np.max(ref_zpow) < 2e-6  # every lag of every block, incl. 1793 .. 1899
+    sd2 = pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, max_items=x.size, **kw)
+    pos, all_tags = 0, []
+    for m in (20000, 7000, x.size):
+        st, out2, t2, n2 = sd2.process_bulk(dev(x[pos:min(pos + m, x.size)]))
+        t2 = t2.copy()
+        t2["index"] += pos
+        all_tags.append(t2)
+        pos += n2
+        if pos + 2048 > x.size:
+            break
+    got = np.concatenate(all_tags)
+    assert same_tags(got[: tags.size], tags[: got.size])
+
+
 def test_syncword_detection_zero_input_and_short_input(pkg):
     """benchmark_syncword_detection.cpp feeds zeros: no tags, zeros out; < fft_size -> INSUFFICIENT"""
     rrc, _ = orc.unit_norm_rrc(4)
