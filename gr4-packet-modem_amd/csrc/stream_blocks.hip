@@ -474,23 +474,66 @@ __global__ void k_update_hist(const T* __restrict__ in, const T* __restrict__ ca
 
 // InterpolatingFirFilter::processBulk (interpolating_fir_filter.hpp:93-99): taps laid out
 // [arm][arm_stride]; out[n*L + j] = sum_m arm_j[m] * x[n - m], m ascending, acc from 0.
+// One thread per INPUT item: a workgroup stages its 256 items and the arm_stride - 1 before them in LDS once
+// (coalesced), every thread then forms its L outputs from LDS (neighbouring lanes read neighbouring items, the taps
+// are broadcast reads) and writes them as one contiguous run of L items.  Round 1 had one thread per OUTPUT: every
+// item was fetched L * arm length times through L1 and every output paid two 64-bit divisions (542 us per 2^24
+// symbols in, 2^26 samples out; this form: see DESIGN.md section 5).
+constexpr unsigned kFirItems = 256;
 template <typename T>
-__global__ void k_interp_fir(const T* __restrict__ in, const T* __restrict__ carry, unsigned cap,
-                             const float* __restrict__ taps, const unsigned* __restrict__ arm_len,
-                             unsigned arm_stride, unsigned L, size_t n_out, T* __restrict__ out)
+__global__ __launch_bounds__(kFirItems) void k_interp_fir(const T* __restrict__ in, const T* __restrict__ carry,
+                                                          unsigned cap, const float* __restrict__ taps,
+                                                          const unsigned* __restrict__ arm_len, unsigned arm_stride,
+                                                          unsigned L, size_t n_in, T* __restrict__ out)
 {
     extern __shared__ float s_taps[];
-    for (unsigned i = threadIdx.x; i < L * arm_stride; i += blockDim.x) s_taps[i] = taps[i];
-    __syncthreads();
-    for (size_t o = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; o < n_out;
-         o += static_cast<size_t>(gridDim.x) * blockDim.x) {
-        const long long n = static_cast<long long>(o / L);
-        const unsigned j = static_cast<unsigned>(o % L);
-        const float* arm = s_taps + j * arm_stride;
-        const unsigned len = arm_len[j];
-        T acc = zero_item(T{});
-        for (unsigned m = 0; m < len; ++m) acc = mac(acc, arm[m], item_at(in, carry, cap, n - m));
-        out[o] = acc;
+    unsigned* s_len = reinterpret_cast<unsigned*>(s_taps + L * arm_stride);
+    T* tile = reinterpret_cast<T*>(s_len + ((L + 3u) & ~3u)); // tile[i] = x[n0 - (arm_stride - 1) + i]
+    for (unsigned i = threadIdx.x; i < L * arm_stride; i += kFirItems) s_taps[i] = taps[i];
+    for (unsigned i = threadIdx.x; i < L; i += kFirItems) s_len[i] = arm_len[i];
+    const unsigned hist = arm_stride - 1;
+    for (size_t n0 = static_cast<size_t>(blockIdx.x) * kFirItems; n0 < n_in; n0 += static_cast<size_t>(gridDim.x) * kFirItems) {
+        __syncthreads(); // taps staged / the tile of the round before is no longer read
+        const unsigned count = static_cast<unsigned>(min(static_cast<size_t>(kFirItems), n_in - n0));
+        for (unsigned i = threadIdx.x; i < count + hist; i += kFirItems)
+            tile[i] = item_at(in, carry, cap, static_cast<long long>(n0) + i - hist);
+        __syncthreads();
+        if (threadIdx.x < count && L == 4) {
+            // the usual interpolation: every item is read from LDS once for the four arms, the four outputs leave as
+            // one 32-byte (complex) or 16-byte (float) run.  Per arm the sum still runs over m ascending.
+            const T* x = tile + hist + threadIdx.x;
+            const unsigned l0 = s_len[0], l1 = s_len[1], l2 = s_len[2], l3 = s_len[3];
+            T a0 = zero_item(T{}), a1 = a0, a2 = a0, a3 = a0;
+            for (unsigned m = 0; m < arm_stride; ++m) {
+                const T v = *(x - m);
+                if (m < l0) a0 = mac(a0, s_taps[m], v);
+                if (m < l1) a1 = mac(a1, s_taps[arm_stride + m], v);
+                if (m < l2) a2 = mac(a2, s_taps[2 * arm_stride + m], v);
+                if (m < l3) a3 = mac(a3, s_taps[3 * arm_stride + m], v);
+            }
+            T* o = out + (n0 + threadIdx.x) * 4;
+            if constexpr (sizeof(T) == sizeof(cf)) {
+                if ((reinterpret_cast<uintptr_t>(out) & 15u) == 0) { // two 16-byte stores per lane
+                    float4* o4 = reinterpret_cast<float4*>(o);
+                    o4[0] = make_float4(a0.x, a0.y, a1.x, a1.y);
+                    o4[1] = make_float4(a2.x, a2.y, a3.x, a3.y);
+                } else {
+                    o[0] = a0, o[1] = a1, o[2] = a2, o[3] = a3;
+                }
+            } else {
+                o[0] = a0, o[1] = a1, o[2] = a2, o[3] = a3;
+            }
+        } else if (threadIdx.x < count) {
+            const T* x = tile + hist + threadIdx.x; // x[-m] = item n - m
+            T* o = out + (n0 + threadIdx.x) * L;
+            for (unsigned j = 0; j < L; ++j) {
+                const float* arm = s_taps + j * arm_stride;
+                const unsigned len = s_len[j];
+                T acc = zero_item(T{});
+                for (unsigned m = 0; m < len; ++m) acc = mac(acc, arm[m], *(x - m));
+                o[j] = acc;
+            }
+        }
     }
 }
 
@@ -1866,10 +1909,12 @@ static gr4pm_status interp_fir_run(gr4pm_interp_fir* h, const void* in, size_t n
     const size_t n_out = n_in * h->L;
     const T* carry = reinterpret_cast<const T*>(h->carry[h->cur].p);
     T* carry_next = reinterpret_cast<T*>(h->carry[h->cur ^ 1].p);
-    hipLaunchKernelGGL(k_interp_fir<T>, dim3(grid_for(n_out, 256, 16384)), dim3(256),
-                       h->L * h->arm_stride * sizeof(float), s, static_cast<const T*>(in), carry, h->cap,
-                       h->taps.p, h->arm_len.p, h->arm_stride, static_cast<unsigned>(h->L), n_out,
-                       static_cast<T*>(out));
+    (void)n_out;
+    const size_t smem = h->L * h->arm_stride * sizeof(float) + ((h->L + 3) & ~size_t{ 3 }) * sizeof(unsigned) +
+                        (kFirItems + h->arm_stride) * sizeof(T);
+    hipLaunchKernelGGL(k_interp_fir<T>, dim3(grid_for(n_in, kFirItems, 65536)), dim3(kFirItems), smem, s,
+                       static_cast<const T*>(in), carry, h->cap, h->taps.p, h->arm_len.p, h->arm_stride,
+                       static_cast<unsigned>(h->L), n_in, static_cast<T*>(out));
     hipLaunchKernelGGL(k_update_hist<T>, dim3((h->cap + 63) / 64), dim3(64), 0, s, static_cast<const T*>(in),
                        carry, carry_next, h->cap, n_in);
     GR4PM_HIP_TRY(hipGetLastError());
