@@ -935,33 +935,105 @@ struct ArbState {
     unsigned produced;
     unsigned long long consumed;
 };
+// The serial lane keeps to the recurrence itself and leaves a checkpoint of its state every kArbChunk outputs (round 1
+// wrote three plan arrays entry by entry from that one lane: 147 ns per output, 6.8 Msamples/s); the filter kernel's
+// lanes replay at most kArbChunk - 1 steps from their chunk's checkpoint -- the same operations in the same order, so
+// the same (input index, arm, phase) as the serial walk -- and go on to their two inner products.
+constexpr unsigned kArbChunk = 64;
 template <typename TRate>
-__global__ void k_arb_plan(ArbState* __restrict__ st, unsigned long long n_in, unsigned out_cap,
-                           unsigned filter_size, unsigned long long decim_rate, TRate filt_rate,
-                           int* __restrict__ plan_idx, unsigned* __restrict__ plan_arm,
-                           float* __restrict__ plan_pa)
+struct ArbCk {
+    unsigned ii;          // inputs consumed when output k * kArbChunk is formed
+    unsigned last_filter; // < filter_size there
+    TRate phase_acc;
+    unsigned pad[sizeof(TRate) == 8 ? 2 : 3];
+};
+// One pass of the reference loop between two outputs that both exist: the update of pfb_arb_resampler.hpp:161-166, then
+// the input items of :135-138.  With last_filter < filter_size before, decim_rate = q0 filter_size + r0 and wrap <= 1
+// the walk "while (last_filter >= filter_size) { ++ii; last_filter -= filter_size; }" takes q0 or q0 + 1 items:
+// no loop, no division, 32-bit integers -- the same values as the walk.
+template <typename TRate>
+__device__ __forceinline__ void arb_step(unsigned& ii, unsigned& last_filter, TRate& phase_acc, unsigned filter_size,
+                                         unsigned q0, unsigned r0, TRate filt_rate)
+{
+    phase_acc += filt_rate;
+    const bool wrap = phase_acc > TRate{ 1 };
+    phase_acc = wrap ? phase_acc - TRate{ 1 } : phase_acc;
+    const unsigned t = last_filter + r0 + (wrap ? 1u : 0u);
+    const bool c = t >= filter_size;
+    ii += q0 + (c ? 1u : 0u);
+    last_filter = c ? t - filter_size : t;
+}
+template <typename TRate>
+__global__ void k_arb_plan(ArbState* __restrict__ st, unsigned n_in, unsigned out_cap, unsigned filter_size,
+                           unsigned long long decim_rate, unsigned q0, unsigned r0, TRate filt_rate,
+                           ArbCk<TRate>* __restrict__ ck)
 {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     unsigned long long last_filter = st->last_filter;
     TRate phase_acc = sizeof(TRate) == 8 ? static_cast<TRate>(st->phase_acc_d)
                                          : static_cast<TRate>(st->phase_acc_f);
-    unsigned long long ii = 0;
-    unsigned oi = 0;
-    while (ii < n_in && oi < out_cap) {
-        while (last_filter >= filter_size && ii < n_in) {
-            ++ii;
-            last_filter -= filter_size;
-        }
-        if (last_filter >= filter_size) break;
-        plan_idx[oi] = static_cast<int>(static_cast<long long>(ii) - 1);
-        plan_arm[oi] = static_cast<unsigned>(last_filter);
-        plan_pa[oi] = static_cast<float>(phase_acc);
-        ++oi;
-        phase_acc += filt_rate;
-        last_filter += decim_rate;
-        if (phase_acc > TRate{ 1 }) {
-            phase_acc -= TRate{ 1 };
-            ++last_filter;
+    unsigned ii = 0, oi = 0;
+    // first pass of the reference loop (n_in > 0 and out_cap > 0: checked by the caller): the carried last_filter may
+    // ask for any number of items
+    while (last_filter >= filter_size && ii < n_in) {
+        ++ii;
+        last_filter -= filter_size;
+    }
+    if (last_filter < filter_size) {
+        unsigned lf = static_cast<unsigned>(last_filter);
+        for (;;) { // state: output oi is about to be formed from (ii, lf, phase_acc)
+            // whole chunks while neither the input nor the output can end inside one: a checkpoint, then kArbChunk
+            // steps of straight-line code (every pass of the reference loop in between finds its loop condition true
+            // and its items there); the chain of phase_acc is then all that a step costs
+            while ((oi & (kArbChunk - 1)) == 0 && oi + kArbChunk < out_cap &&
+                   static_cast<unsigned long long>(ii) + static_cast<unsigned long long>(kArbChunk) * (q0 + 1u) < n_in) {
+                ArbCk<TRate> c{};
+                c.ii = ii, c.last_filter = lf, c.phase_acc = phase_acc;
+                ck[oi / kArbChunk] = c;
+                // inside a chunk only phase_acc is a chain: the kArbChunk conditional subtractions of filter_size add up
+                // to a division of lf + kArbChunk r0 + (number of wraps) by filter_size (every partial sum stays below
+                // 2 filter_size, so the walk subtracts exactly when the running sum passes a multiple)
+                unsigned wraps = 0;
+#pragma unroll
+                for (unsigned k = 0; k < kArbChunk; ++k) {
+                    phase_acc += filt_rate;
+                    const bool wrap = phase_acc > TRate{ 1 };
+                    phase_acc = wrap ? phase_acc - TRate{ 1 } : phase_acc;
+                    wraps += wrap ? 1u : 0u;
+                }
+                const unsigned long long sum = static_cast<unsigned long long>(lf) + static_cast<unsigned long long>(kArbChunk) * r0 + wraps;
+                const unsigned long long sub = sum / filter_size;
+                lf = static_cast<unsigned>(sum - sub * filter_size);
+                ii += kArbChunk * q0 + static_cast<unsigned>(sub);
+                oi += kArbChunk;
+            }
+            if ((oi & (kArbChunk - 1)) == 0) {
+                ArbCk<TRate> c{};
+                c.ii = ii, c.last_filter = lf, c.phase_acc = phase_acc;
+                ck[oi / kArbChunk] = c;
+            }
+            ++oi;
+            if (ii < n_in && oi < out_cap) { // the reference's loop condition for the next pass
+                const unsigned need = q0 + ((lf + r0 + 1u >= filter_size) ? 1u : 0u); // at most this many items
+                if (ii + need <= n_in) {
+                    arb_step(ii, lf, phase_acc, filter_size, q0, r0, filt_rate);
+                    continue;
+                }
+            }
+            // last pass: the update, then -- if the loop goes on at all -- the walk over what is left of the input
+            phase_acc += filt_rate;
+            last_filter = static_cast<unsigned long long>(lf) + decim_rate;
+            if (phase_acc > TRate{ 1 }) {
+                phase_acc -= TRate{ 1 };
+                ++last_filter;
+            }
+            if (!(ii < n_in && oi < out_cap)) break;
+            while (last_filter >= filter_size && ii < n_in) {
+                ++ii;
+                last_filter -= filter_size;
+            }
+            if (last_filter >= filter_size) break;
+            lf = static_cast<unsigned>(last_filter); // the items sufficed after all (need was the upper bound)
         }
     }
     st->last_filter = last_filter;
@@ -970,21 +1042,25 @@ __global__ void k_arb_plan(ArbState* __restrict__ st, unsigned long long n_in, u
     st->produced = oi;
     st->consumed = ii;
 }
+template <typename TRate>
 __global__ void k_arb_filter(const cf* __restrict__ in, const cf* __restrict__ carry, unsigned cap,
                              const float* __restrict__ taps, const float* __restrict__ diff_taps,
-                             unsigned arm_size, const ArbState* __restrict__ st,
-                             const int* __restrict__ plan_idx, const unsigned* __restrict__ plan_arm,
-                             const float* __restrict__ plan_pa, cf* __restrict__ out)
+                             unsigned arm_size, const ArbState* __restrict__ st, const ArbCk<TRate>* __restrict__ ck,
+                             unsigned filter_size, unsigned q0, unsigned r0, TRate filt_rate, cf* __restrict__ out)
 {
     const unsigned n_out = st->produced;
     for (unsigned o = blockIdx.x * blockDim.x + threadIdx.x; o < n_out; o += gridDim.x * blockDim.x) {
-        const long long idx = plan_idx[o];
-        const float* arm = taps + static_cast<size_t>(plan_arm[o]) * arm_size;
-        const float* darm = diff_taps + static_cast<size_t>(plan_arm[o]) * arm_size;
+        const ArbCk<TRate> c = ck[o / kArbChunk];
+        unsigned ii = c.ii, last_filter = c.last_filter;
+        TRate phase_acc = c.phase_acc;
+        for (unsigned r = o % kArbChunk; r > 0; --r) arb_step(ii, last_filter, phase_acc, filter_size, q0, r0, filt_rate);
+        const long long idx = static_cast<long long>(ii) - 1;
+        const float* arm = taps + static_cast<size_t>(last_filter) * arm_size;
+        const float* darm = diff_taps + static_cast<size_t>(last_filter) * arm_size;
         cf filt = { 0.f, 0.f }, diff = { 0.f, 0.f };
         for (unsigned m = 0; m < arm_size; ++m) filt = mac(filt, arm[m], item_at(in, carry, cap, idx - m));
         for (unsigned m = 0; m < arm_size; ++m) diff = mac(diff, darm[m], item_at(in, carry, cap, idx - m));
-        out[o] = cadd(filt, fmulc(plan_pa[o], diff)); // :153-160
+        out[o] = cadd(filt, fmulc(static_cast<float>(phase_acc), diff)); // :153-160
     }
 }
 // history after the call: last cap items of (carry ++ in[0..consumed))
@@ -2554,9 +2630,7 @@ struct gr4pm_pfb_arb_resampler {
     DevBuf<float> taps, diff_taps;
     DevBuf<cf> carry[2];
     DevBuf<ArbState> st;
-    DevBuf<int> plan_idx;
-    DevBuf<unsigned> plan_arm;
-    DevBuf<float> plan_pa;
+    DevBuf<char> plan_ck; // ArbCk<TRate> per kArbChunk outputs
     PinnedBuf<ArbState> st_host;
     int cur = 0;
 };
@@ -2656,27 +2730,31 @@ gr4pm_status gr4pm_pfb_arb_resampler_process(gr4pm_pfb_arb_resampler* h, const g
     }
     if (out_cap > 0xffffffffull || n_in > 0x7fffffffull) return GR4PM_ERR_INVALID;
     hipStream_t s = h->stream;
-    if (h->plan_cap < out_cap) {
-        GR4PM_TRY(h->plan_idx.alloc(out_cap));
-        GR4PM_TRY(h->plan_arm.alloc(out_cap));
-        GR4PM_TRY(h->plan_pa.alloc(out_cap));
-        h->plan_cap = static_cast<unsigned>(out_cap);
+    const size_t n_ck = out_cap / kArbChunk + 2;
+    if (h->plan_cap < n_ck) {
+        GR4PM_TRY(h->plan_ck.alloc(n_ck * 24)); // ArbCk<float> / ArbCk<double>: 24 bytes each
+        h->plan_cap = static_cast<unsigned>(n_ck);
     }
-    if (h->rate_is_double)
-        hipLaunchKernelGGL(k_arb_plan<double>, dim3(1), dim3(64), 0, s, h->st.p,
-                           static_cast<unsigned long long>(n_in), static_cast<unsigned>(out_cap),
-                           static_cast<unsigned>(h->filter_size), h->decim_rate, h->filt_rate_d, h->plan_idx.p,
-                           h->plan_arm.p, h->plan_pa.p);
-    else
-        hipLaunchKernelGGL(k_arb_plan<float>, dim3(1), dim3(64), 0, s, h->st.p,
-                           static_cast<unsigned long long>(n_in), static_cast<unsigned>(out_cap),
-                           static_cast<unsigned>(h->filter_size), h->decim_rate, h->filt_rate_f, h->plan_idx.p,
-                           h->plan_arm.p, h->plan_pa.p);
+    static_assert(sizeof(ArbCk<float>) == 24 && sizeof(ArbCk<double>) == 24, "checkpoint layout");
     const cf* carry = h->carry[h->cur].p;
-    hipLaunchKernelGGL(k_arb_filter, dim3(grid_for(out_cap, 256, 8192)), dim3(256), 0, s,
-                       reinterpret_cast<const cf*>(in), carry, h->cap, h->taps.p, h->diff_taps.p,
-                       static_cast<unsigned>(h->arm_size), h->st.p, h->plan_idx.p, h->plan_arm.p, h->plan_pa.p,
-                       reinterpret_cast<cf*>(out));
+    const unsigned grid = grid_for(out_cap, 256, 16384);
+    const unsigned fs = static_cast<unsigned>(h->filter_size);
+    const unsigned q0 = static_cast<unsigned>(h->decim_rate / fs), r0 = static_cast<unsigned>(h->decim_rate % fs);
+    if (h->rate_is_double) {
+        auto* ck = reinterpret_cast<ArbCk<double>*>(h->plan_ck.p);
+        hipLaunchKernelGGL(k_arb_plan<double>, dim3(1), dim3(64), 0, s, h->st.p, static_cast<unsigned>(n_in),
+                           static_cast<unsigned>(out_cap), fs, h->decim_rate, q0, r0, h->filt_rate_d, ck);
+        hipLaunchKernelGGL(k_arb_filter<double>, dim3(grid), dim3(256), 0, s, reinterpret_cast<const cf*>(in), carry,
+                           h->cap, h->taps.p, h->diff_taps.p, static_cast<unsigned>(h->arm_size), h->st.p, ck, fs, q0, r0,
+                           h->filt_rate_d, reinterpret_cast<cf*>(out));
+    } else {
+        auto* ck = reinterpret_cast<ArbCk<float>*>(h->plan_ck.p);
+        hipLaunchKernelGGL(k_arb_plan<float>, dim3(1), dim3(64), 0, s, h->st.p, static_cast<unsigned>(n_in),
+                           static_cast<unsigned>(out_cap), fs, h->decim_rate, q0, r0, h->filt_rate_f, ck);
+        hipLaunchKernelGGL(k_arb_filter<float>, dim3(grid), dim3(256), 0, s, reinterpret_cast<const cf*>(in), carry,
+                           h->cap, h->taps.p, h->diff_taps.p, static_cast<unsigned>(h->arm_size), h->st.p, ck, fs, q0, r0,
+                           h->filt_rate_f, reinterpret_cast<cf*>(out));
+    }
     hipLaunchKernelGGL(k_arb_update_hist, dim3((h->cap + 63) / 64), dim3(64), 0, s,
                        reinterpret_cast<const cf*>(in), carry, h->carry[h->cur ^ 1].p, h->cap, h->st.p);
     GR4PM_HIP_TRY(hipMemcpyAsync(h->st_host.p, h->st.p, sizeof(ArbState), hipMemcpyDeviceToHost, s));
