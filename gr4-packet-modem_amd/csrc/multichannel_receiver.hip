@@ -125,6 +125,7 @@ struct gr4pm_multichannel_receiver {
     // batch's input are kept (tails: one more than batches in flight) for the batch after it
     bool in_place = false;
     size_t hist = 0;
+    size_t sd_fft = 0, sd_stride = 0;      // the detector's block size and overlap-save stride (syncword_detection.hpp:236-238)
     DevBuf<gr4pm_c64> tails[kMcSlots + 1]; // [n_channels][hist]
     int tail_next = 0;                     // where the NEXT submitted batch saves its tail
     // stage 2 as one launch per kernel: argument vectors of the ..._channels calls
@@ -412,6 +413,8 @@ gr4pm_status gr4pm_multichannel_receiver_create(const gr4pm_multichannel_receive
         h->v_produced.assign(C, 0);
     }
     h->hist = 2 * 768 + 1; // SyncwordDetection's delay: 2 * time_threshold + 1 (syncword_detection.hpp:318-319)
+    h->sd_fft = sp.fft_size;
+    h->sd_stride = sp.fft_size - (63 * sps + rrc.size()) + 1;
     for (auto& t : h->tails) {
         if ((st = t.alloc(h->hist * p->n_channels)) != GR4PM_OK) return bail(st);
         if ((st = t.zero(h->sd_stream)) != GR4PM_OK) return bail(st);
@@ -506,6 +509,16 @@ gr4pm_status gr4pm_multichannel_receiver_submit(gr4pm_multichannel_receiver* h, 
         set_error("%d batches in flight: collect one first", h->inflight);
         return GR4PM_ERR_INVALID;
     }
+    const bool in_place = h->in_place && !h->per_channel_launches;
+    if (in_place && n_in >= h->sd_fft) {
+        // what the detector will consume is known up front (hpp:238): a batch too short to leave a whole tail is
+        // refused HERE, while the detector's state has not moved
+        const size_t will_consume = ((n_in - h->sd_fft) / h->sd_stride + 1) * h->sd_stride;
+        if (will_consume < h->hist) {
+            set_error("in-place input needs batches of at least %zu consumed items (this one: %zu)", h->hist, will_consume);
+            return GR4PM_ERR_INVALID;
+        }
+    }
     auto& s = h->slots[h->next_slot];
     const size_t C = h->p.n_channels;
     if (s.symall.n < C * out_stride) GR4PM_TRY(s.symall.alloc(C * out_stride));
@@ -513,7 +526,6 @@ gr4pm_status gr4pm_multichannel_receiver_submit(gr4pm_multichannel_receiver* h, 
     size_t n_done = 0;
     // stage 0, in the caller's thread: the batched detector (its look-ahead runs the correlator of the announced
     // batches behind this call's own kernels)
-    const bool in_place = h->in_place && !h->per_channel_launches;
     const gr4pm_status st = gr4pm_syncword_detection_process(h->sd, in, in_stride, n_in, in_place ? nullptr : s.y.p,
                                                              h->y_stride, &n_done, s.det_tags.data(), h->p.tags_cap,
                                                              s.n_det.data());

@@ -480,15 +480,23 @@ __global__ void k_update_hist(const T* __restrict__ in, const T* __restrict__ ca
 // item was fetched L * arm length times through L1 and every output paid two 64-bit divisions (542 us per 2^24
 // symbols in, 2^26 samples out; this form: see DESIGN.md section 5).
 constexpr unsigned kFirItems = 256;
+constexpr size_t kFirMaxSmem = 160 * 1024;
+inline size_t interp_fir_smem(size_t L, size_t arm_stride, size_t item_size)
+{
+    return ((kFirItems + arm_stride) * item_size + 15) / 16 * 16 + L * arm_stride * sizeof(float) + L * sizeof(unsigned);
+}
 template <typename T>
 __global__ __launch_bounds__(kFirItems) void k_interp_fir(const T* __restrict__ in, const T* __restrict__ carry,
                                                           unsigned cap, const float* __restrict__ taps,
                                                           const unsigned* __restrict__ arm_len, unsigned arm_stride,
                                                           unsigned L, size_t n_in, T* __restrict__ out)
 {
-    extern __shared__ float s_taps[];
+    // LDS: the item tile first (16-byte aligned whatever L * arm_stride is: complex items are read and written as
+    // 64-bit words), then the taps, then the arm lengths; interp_fir_smem() is the host's copy of this layout
+    extern __shared__ float4 s_fir[];
+    T* tile = reinterpret_cast<T*>(s_fir); // tile[i] = x[n0 - (arm_stride - 1) + i]
+    float* s_taps = reinterpret_cast<float*>(s_fir + ((kFirItems + arm_stride) * sizeof(T) + 15u) / 16u);
     unsigned* s_len = reinterpret_cast<unsigned*>(s_taps + L * arm_stride);
-    T* tile = reinterpret_cast<T*>(s_len + ((L + 3u) & ~3u)); // tile[i] = x[n0 - (arm_stride - 1) + i]
     for (unsigned i = threadIdx.x; i < L * arm_stride; i += kFirItems) s_taps[i] = taps[i];
     for (unsigned i = threadIdx.x; i < L; i += kFirItems) s_len[i] = arm_len[i];
     const unsigned hist = arm_stride - 1;
@@ -1986,8 +1994,15 @@ static gr4pm_status interp_fir_run(gr4pm_interp_fir* h, const void* in, size_t n
     const T* carry = reinterpret_cast<const T*>(h->carry[h->cur].p);
     T* carry_next = reinterpret_cast<T*>(h->carry[h->cur ^ 1].p);
     (void)n_out;
-    const size_t smem = h->L * h->arm_stride * sizeof(float) + ((h->L + 3) & ~size_t{ 3 }) * sizeof(unsigned) +
-                        (kFirItems + h->arm_stride) * sizeof(T);
+    const size_t smem = interp_fir_smem(h->L, h->arm_stride, sizeof(T));
+    if (smem > kFirMaxSmem) {
+        set_error("InterpolatingFirFilter: %zu taps x %zu arms need %zu bytes of LDS per workgroup (limit %zu)",
+                  static_cast<size_t>(h->arm_stride), static_cast<size_t>(h->L), smem, kFirMaxSmem);
+        return GR4PM_ERR_INVALID;
+    }
+    if (smem > 48 * 1024) // beyond the default dynamic-LDS window
+        GR4PM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_interp_fir<T>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem)));
     hipLaunchKernelGGL(k_interp_fir<T>, dim3(grid_for(n_in, kFirItems, 65536)), dim3(kFirItems), smem, s,
                        static_cast<const T*>(in), carry, h->cap, h->taps.p, h->arm_len.p, h->arm_stride,
                        static_cast<unsigned>(h->L), n_in, static_cast<T*>(out));
@@ -2739,6 +2754,13 @@ gr4pm_status gr4pm_pfb_arb_resampler_process(gr4pm_pfb_arb_resampler* h, const g
     const cf* carry = h->carry[h->cur].p;
     const unsigned grid = grid_for(out_cap, 256, 16384);
     const unsigned fs = static_cast<unsigned>(h->filter_size);
+    if (h->decim_rate / fs >= (1ull << 30)) {
+        // the plan kernels walk the input with 32-bit item counts (q0 items per output, q0 + 1 after a wrap): a rate this
+        // small would wrap them where the reference's 64-bit walk (pfb_arb_resampler.hpp:135-138) does not
+        set_error("PfbArbResampler: rate too small for the device path (decim_rate / filter_size = %llu >= 2^30)",
+                  static_cast<unsigned long long>(h->decim_rate / fs));
+        return GR4PM_ERR_INVALID;
+    }
     const unsigned q0 = static_cast<unsigned>(h->decim_rate / fs), r0 = static_cast<unsigned>(h->decim_rate % fs);
     if (h->rate_is_double) {
         auto* ck = reinterpret_cast<ArbCk<double>*>(h->plan_ck.p);

@@ -2261,8 +2261,12 @@ gr4pm_status gr4pm_syncword_detection_process(gr4pm_syncword_detection* h, const
                                zcur + h->zc, h->z_stride, h->st.p, h->det.p, h->det_cap, h->rec_host.p, h->rec_cap,
                                h->noise_off - h->zc);
         };
-        // k_correlate_w64 leaves every block's noise power behind the powers; the round-1 correlators do not
-        if (h->corr_kind == 0 && !h->use_pair) launch_tags(k_tags<false>);
+        // k_correlate_w64 leaves every block's noise power behind the powers; the round-1 correlators do not.  Only ONE
+        // block of the call before is carried (k_update_zcarry): enough while a detection that leaves in this call
+        // cannot lie more than one block before E0, i.e. hist = 2T + 1 <= S.  A longer history (T > 875 at the
+        // default S = 1752) puts detections two or more blocks back; their block is then transformed again from the
+        // sample carry (xc >= hist + S + 2 covers it).
+        if (h->corr_kind == 0 && !h->use_pair && h->hist <= h->S) launch_tags(k_tags<false>);
         else launch_tags(k_tags<true>);
     }
     hipLaunchKernelGGL(k_compact_pending, dim3(nch), dim3(64), 0, s, h->st.p, h->st_host.p, h->det.p,

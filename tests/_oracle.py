@@ -640,6 +640,52 @@ def pfb_arb_resampler(x, rate, taps, filter_size=32, rate_is_double=True, out_ca
     return out[:n], consumed.value
 
 
+class PfbArbResampler:
+    """the same restatement with its state kept across calls (pfb_arb_resampler.hpp:122-182): call-by-call
+    comparisons with the device block under identical input / output span sizes"""
+
+    def __init__(self, rate, taps, filter_size=32, rate_is_double=True):
+        taps = _f32(taps)
+        self._h = lib().orc_arb_create(rate, 1 if rate_is_double else 0, _p(taps), taps.size, filter_size)
+
+    def process(self, x, out_cap):
+        x = _c64(x)
+        out = np.zeros(max(out_cap, 1), dtype=np.complex64)
+        consumed = C.c_size_t(0)
+        n = lib().orc_arb_process(self._h, _p(x), x.size, _p(out), out_cap, C.byref(consumed))
+        return out[:n], consumed.value
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_arb_destroy(self._h)
+            self._h = None
+
+
+class InterpolatingFir:
+    """interpolating_fir_filter.hpp:76-102 with the history kept across calls"""
+
+    def __init__(self, interpolation, taps):
+        taps = _f32(taps)
+        self.interpolation = interpolation
+        self._h = lib().orc_ifir_create(interpolation, _p(taps), taps.size)
+
+    def process(self, x):
+        if np.iscomplexobj(x):
+            x = _c64(x)
+            out = np.empty(x.size * self.interpolation, dtype=np.complex64)
+            lib().orc_ifir_process_c64(self._h, _p(x), x.size, _p(out))
+        else:
+            x = _f32(x)
+            out = np.empty(x.size * self.interpolation, dtype=np.float32)
+            lib().orc_ifir_process_f32(self._h, _p(x), x.size, _p(out))
+        return out
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_ifir_destroy(self._h)
+            self._h = None
+
+
 # ---------------------------------------------------------------- reference-built taps
 def ref_taps_dump(*args):
     """runs oracle/_ref/ref_taps_dump (built from the reference's own headers) if present"""

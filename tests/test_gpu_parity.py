@@ -552,6 +552,88 @@ def test_interpolating_fir_filter(pkg):
     assert np.array_equal(bits(y), bits(orc.interpolating_fir(x, 4, rrc)))
 
 
+@pytest.mark.parametrize("interp,ntaps,dtype", [
+    (4, 1025, "complex64"),   # configs[4]'s shaping filter: arms of 257 / 256 taps, longer than one 256-item tile's reach
+    (4, 2049, "complex64"),   # arms of 513 taps: two tiles of history
+    (5, 23, "complex64"),     # L * arm_stride = 25: odd, the item tile must still be 8-byte aligned in LDS
+    (3, 9, "complex64"),      # L * arm_stride = 9
+    (7, 100, "float32"),      # ragged arms (15, 15, 14, ...), not the L == 4 path
+    (4, 1025, "float32"),
+])
+def test_interpolating_fir_filter_long_arms_and_odd_layouts(pkg, interp, ntaps, dtype):
+    """interpolating_fir_filter.hpp:76-102 at the sizes k_interp_fir was rewritten for: every output against the
+    oracle bit for bit, history carried over calls of 1 .. several thousand items (shorter than an arm, shorter than
+    a tile, several tiles)"""
+    rng = np.random.default_rng(ntaps * 10 + interp)
+    taps = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+    n = 9000
+    if dtype == "complex64":
+        x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    else:
+        x = rng.standard_normal(n).astype(np.float32)
+    want = orc.interpolating_fir(x, interp, taps)
+    f = pkg.InterpolatingFirFilter(interp, taps, dtype)
+    cuts = [0, 1, 3, 200, 255, 256, 257, 700, 2500, 2501, 6000, n]
+    got = np.concatenate([host(f.process_bulk(dev(x[a:b]))) for a, b in zip(cuts[:-1], cuts[1:])])
+    assert got.size == want.size
+    if dtype == "complex64":
+        assert np.array_equal(bits(got), bits(want))
+    else:
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # the same through the oracle call by call (its history is carried the same way)
+    o = orc.InterpolatingFir(interp, taps)
+    assert np.array_equal(np.concatenate([o.process(x[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]), want)
+
+
+def test_interpolating_fir_filter_lds_limit_is_reported(pkg):
+    """the tile + taps of one workgroup must fit the CU's LDS: a filter that cannot is refused, not mis-launched"""
+    taps = np.ones(64 * 1024, dtype=np.float32)
+    f = pkg.InterpolatingFirFilter(4, taps)
+    with pytest.raises(pkg.Gr4pmError, match="LDS"):
+        f.process_bulk(dev(np.ones(1000, dtype=np.complex64)))
+
+
+def test_symbol_filter_32x1025_taps_with_tags(pkg):
+    """configs[4]'s receiving filter (bench.py --config 5): SymbolFilter with 32 arms x 1025 taps, delay 1025,
+    c64 items, tag-driven clock phase (symbol_filter.hpp:112-252) -- the generic kernel (k_symbol_filter), not the
+    receiver's 44-tap fast path; outputs and re-timed tags bit for bit against the oracle, one call and split calls"""
+    pfb = orc.rrc_taps(32.0, 128.0, 1.0, 0.35, 32 * 1024)   # 32769 taps: arms of 1025 (arm 0) and 1024 taps
+    assert pfb.size == 32 * 1024 + 1
+    rng = np.random.default_rng(1025)
+    n = 40000
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    idx = [0, 3001, 6002, 6500, 12000, 12003, 20444, 25557, 31000, 31001, 39998]
+    tags = np.zeros(len(idx), dtype=pkg.TAG_DTYPE)
+    tags["index"] = idx
+    tags["amplitude"] = rng.uniform(0.5, 2.0, len(idx))
+    tags["time_est"] = [0.1, -0.2, 0.49, -0.5, 0.0, -0.01, 0.3, -0.3, 0.5, 0.2, -0.45]
+    tags["phase"] = rng.uniform(-3, 3, len(idx))
+    tags["freq"] = rng.uniform(-0.03, 0.03, len(idx))
+    tags["flags"] = pkg.TAG_SYNCWORD
+    tags["flags"][4] = pkg.TAG_OTHER
+    want, want_tags, want_cons = orc.symbol_filter(x, pfb, 32, 4, 1025, tags=tags.astype(orc.TAG_DTYPE))
+    for cuts in ([0, n], [0, 2500, 2501, 13000, 31001, n]):
+        f = pkg.SymbolFilter(pfb, 32, 4, 1025)
+        ys, ts, cons, produced = [], [], 0, 0
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            t = tags[(tags["index"] >= a) & (tags["index"] < b)].copy()
+            t["index"] -= a
+            y, to, c = f.process_bulk(dev(x[a:b]), t)
+            assert c == b - a
+            to = to.copy()
+            to["index"] += produced
+            produced += y.numel()
+            ys.append(host(y))
+            ts.append(to)
+            cons += c
+        y, t = np.concatenate(ys), np.concatenate(ts)
+        assert cons == want_cons == n and y.size == want.size
+        assert np.array_equal(bits(y), bits(want))
+        assert t.size == want_tags.size
+        for k in ("index", "amplitude", "phase", "freq", "time_est", "flags"):
+            assert np.array_equal(t[k], want_tags[k]), k
+
+
 def test_symbol_filter_free_running_reference_qa(pkg):
     """test/qa_symbol_filter.cpp:17-63 (float items, no tags) + bit-exact vs oracle"""
     num_symbols = 200000
@@ -632,6 +714,59 @@ def test_pfb_arb_resampler(pkg):
     want, _ = orc.pfb_arb_resampler(x, 1.0 + 1.2e-6, taps, 32, rate_is_double=False)
     got = np.concatenate([host(y1), host(y2)])
     assert np.array_equal(bits(got), bits(want[: got.size])) and abs(got.size - want.size) <= 1
+
+
+@pytest.mark.parametrize("rate_dtype", ["float64", "float32"])
+@pytest.mark.parametrize("rate", [0.37, 0.7, 1.0 - 50e-6, 1.0 + 50e-6, 1.1234, 3.3, 40.5, 0.011])
+def test_pfb_arb_resampler_random_calls(pkg, rate, rate_dtype):
+    """pfb_arb_resampler.hpp:122-182 call by call against the oracle with ITS state carried the same way: random
+    input span sizes (1 item .. thousands), random output span sizes (full, cut inside a 64-output chunk of the
+    device plan, one item), rates below and above 1 (decim_rate from 0 to 2900 = 90 filter_size): consumed, produced
+    and every output bit for bit in every call.  The serial plan lane takes q0 or q0 + 1 items per output and one
+    division per 64 outputs (k_arb_plan); its first pass and the passes near either span's end run the loop as
+    written -- all of them are crossed here."""
+    taps = pkg.default_pfb_arb_taps()
+    is_double = rate_dtype == "float64"
+    rng = np.random.default_rng(int(rate * 1000) + (7 if is_double else 0))
+    n = 60000 if rate < 5 else 8000
+    f = 0.02
+    x = (np.exp(1j * f * np.arange(n)) + 0.1 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64)
+    r = pkg.PfbArbResampler(rate, taps, 32, rate_dtype)
+    o = orc.PfbArbResampler(rate, taps, 32, rate_is_double=is_double)
+    pos, calls, produced = 0, 0, 0
+    while pos < n and calls < 60:
+        kind = calls % 6
+        n_in = int(rng.integers(1, 6)) if kind == 5 else int(rng.integers(1, 4000 if rate < 5 else 300))
+        n_in = min(n_in, n - pos)
+        full = int(n_in * rate) + 64
+        if kind == 0:
+            out_cap = full
+        elif kind == 1:
+            out_cap = max(1, int(full * rng.uniform(0.2, 0.9)))        # the output span runs out first
+        elif kind == 2:
+            out_cap = 64 * int(rng.integers(1, 8)) + int(rng.integers(1, 63))  # ends inside a 64-output chunk
+        elif kind == 3:
+            out_cap = 1
+        else:
+            out_cap = full
+        want, wcons = o.process(x[pos:pos + n_in], out_cap)
+        y, cons = r.process_bulk(dev(x[pos:pos + n_in]), out_cap=out_cap)
+        y = host(y)
+        assert cons == wcons and y.size == want.size, (calls, kind, n_in, out_cap, cons, wcons, y.size, want.size)
+        assert np.array_equal(bits(y), bits(want)), (calls, kind, n_in, out_cap)
+        pos += cons
+        produced += y.size
+        calls += 1
+        if cons == 0 and y.size == 0:
+            break
+    assert calls >= 20 and produced > 500
+
+
+def test_pfb_arb_resampler_tiny_rate_is_refused(pkg):
+    """decim_rate / filter_size >= 2^30 would wrap the plan's 32-bit item counts: reported, not mis-computed"""
+    r = pkg.PfbArbResampler(1e-10, None, 32, "float64")
+    with pytest.raises(pkg.Gr4pmError, match="rate too small"):
+        r.process_bulk(dev(np.ones(100, dtype=np.complex64)), out_cap=8)
 
 
 # ------------------------------------------------------------------ SDF gate + receiver chain
@@ -976,6 +1111,49 @@ def test_syncword_detection_other_fft_sizes(pkg, fft_size, ntaps_req):
     assert d1 + d2 == n and np.array_equal(np.concatenate([t1, t2])["index"], tags["index"])
 
 
+def test_syncword_detection_config4_nine_bins_vs_oracle(pkg):
+    """BASELINE configs[4] as bench.py --config 5 runs it: fft_size 4096, 1025-tap RRC (L = 1277, stride 2820),
+    NINE frequency bins, power_threshold 30 -- k_correlate_4096 and the detector against the oracle: correlation
+    powers within 5e-6 of full scale, tag indices and freq_bin exact, tag floats within tolerance; one call and two"""
+    sps = 4
+    rrc = orc.rrc_taps(1.0, float(sps), 1.0, 0.35, 1024)
+    rrc = (rrc / np.sqrt(np.sum(rrc.astype(np.float64) ** 2))).astype(np.float32)
+    assert rrc.size == 1025
+    rng = np.random.default_rng(4096)
+    nsym = 60000
+    symbols = rng.integers(0, 2, nsym).astype(np.uint8)
+    locs = [700, 9000, 21000, 40000, 52000]
+    for loc in locs:
+        symbols[loc:loc + 64] = sig.SYNCWORD
+    x = orc.interpolating_fir(sig.BPSK[symbols], sps, rrc)
+    # carrier offsets that put detections in different bins (bin spacing pi / L rad/sample, hpp:166-182)
+    L = 63 * sps + rrc.size
+    seg = x.size // 5
+    for k, b in enumerate((-3.6, -1.2, 0.3, 2.1, 3.9)):
+        x[k * seg:(k + 1) * seg] = orc.rotator(x[k * seg:(k + 1) * seg], np.float32(b * np.pi / L))
+    x = (x + sig.awgn(x.size, 0.05, 9)).astype(np.complex64)
+    kw = dict(fft_size=4096, power_threshold=30.0)
+    ref = orc.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, **kw)
+    st0, ref_out, ref_tags, ref_zpow, _ = ref.process(x, debug=True)
+    sd = pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, max_items=x.size, **kw)
+    st, out, tags, n = sd.process_bulk(dev(x))
+    assert st == st0 == 0 and n == ref_out.size
+    assert np.array_equal(bits(host(out)), bits(ref_out))
+    assert set(1537 + 4 * np.array(locs)) <= set(ref_tags["index"].tolist())
+    assert len(set(ref_tags["freq_bin"].tolist())) >= 4
+    assert_tags_match(tags, ref_tags, rtol=3e-4)
+    zpow = host(sd.last_zpow(n))[0]
+    assert np.max(np.abs(zpow - ref_zpow)) / np.max(ref_zpow) < 5e-6
+    sd2 = pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, max_items=x.size, **kw)
+    cut = 4096 + 17 * 2820
+    _, _, t1, d1 = sd2.process_bulk(dev(x[:cut]), want_output=False)
+    _, _, t2, d2 = sd2.process_bulk(dev(x[d1:]), want_output=False)
+    t2 = t2.copy()
+    t2["index"] += d1
+    assert d1 + d2 == n
+    assert_tags_match(np.concatenate([t1, t2]), ref_tags, rtol=3e-4)
+
+
 def test_fft4096_workgroup_correlator_against_the_radix2_kernel(pkg, monkeypatch):
     """fft_size 4096 runs k_correlate_4096 (16 x 16 x 16, three in-register passes); GR4PM_CORRELATOR=radix2 keeps
     the generic radix-2 kernel for it: same powers within float rounding, identical tags"""
@@ -1079,6 +1257,45 @@ def test_syncword_detection_settings_matrix(pkg, sps, ntaps_req, tthr, bins, thr
         pos += d
     got = np.concatenate(got)
     assert np.array_equal(got["index"], tags["index"][: got.size]) and got.size >= tags.size - 1
+
+
+def test_syncword_detection_history_longer_than_stride_small_calls(pkg):
+    """hist = 2T + 1 = 2001 > S = 1752 (T = 1000): a detection that leaves in a call can lie two or more blocks
+    before the call's first item, and with 2048-item calls (one block each) more than one CALL back -- its block's
+    noise power is then not among the values k_correlate_w64 left behind.  Every float of every tag against the
+    oracle (syncword_detection.hpp:56-115,257-265), not only the indices."""
+    rrc = orc.rrc_taps(1.0, 4.0, 1.0, 0.35, 44)
+    rrc = (rrc / np.sqrt(np.sum(rrc.astype(np.float64) ** 2))).astype(np.float32)
+    rng = np.random.default_rng(1000)
+    nsym = 30000
+    symbols = rng.integers(0, 2, nsym).astype(np.uint8)
+    locs = [1200, 4050, 9031, 15002, 20990, 26011]
+    for loc in locs:
+        symbols[loc:loc + 64] = sig.SYNCWORD
+    x = orc.rotator(orc.interpolating_fir(sig.BPSK[symbols], 4, rrc), np.float32(0.003))
+    # noise level that changes from packet to packet: a neighbouring block's noise power is visibly wrong
+    sigma = np.repeat(rng.uniform(0.02, 0.3, x.size // 5000 + 1), 5000)[: x.size].astype(np.float32)
+    x = (x + sigma * sig.awgn(x.size, 1.0, 7)).astype(np.complex64)
+    kw = dict(time_threshold=1000, power_threshold=9.5)
+    ref = orc.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -2, 2, **kw)
+    _, _, ref_tags = ref.process(x)
+    assert ref_tags.size >= 5
+    for sizes in ([2048], [2048, 2048 + 1752, 2048, 2048 + 2 * 1752, 6000]):
+        sd = pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -2, 2, max_items=1 << 14, **kw)
+        xd = dev(x)
+        pos, got, i = 0, [], 0
+        while pos + 2048 <= x.size:
+            size = sizes[i % len(sizes)]
+            i += 1
+            st, _, t, d = sd.process_bulk(xd[pos:pos + size].contiguous(), want_output=False)
+            assert st == 0 and d > 0
+            t = t.copy()
+            t["index"] += pos
+            got.append(t)
+            pos += d
+        got = np.concatenate(got)
+        assert got.size >= ref_tags.size - 1
+        assert_tags_match(got, ref_tags[: got.size], rtol=3e-4)
 
 
 def test_rotator_and_costas_multichannel(pkg):
