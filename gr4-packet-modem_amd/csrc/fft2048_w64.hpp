@@ -62,6 +62,82 @@ inline void build_w64_tables(W w, f4* tT, cf* cc)
     for (int lane = 0; lane < 64; ++lane) cc[lane] = w((32 * lane) % kFftN);
 }
 
+// ---- twiddled radix-2 butterflies in three packed instructions -------------------------------------------------
+// (u, v) = (a + w b, a - w b) with the twiddle written as  w = g rho (1 + j t),  g in {1, -j},  |t| <= 1:
+//     c = b + t (j b)        = (b.x - t b.y, b.y + t b.x)          one v_pk_fma_f32 (swizzled b, one half negated)
+//     g = 1 :  u = a + rho c,            v = a - rho c             two v_pk_fma_f32
+//     g = -j:  u = a + rho (c.y, -c.x),  v = a - rho (c.y, -c.x)   two v_pk_fma_f32 (swizzled c)
+// i.e. the complex multiply (two packed instructions) and the two additions (two more) fold into three
+// multiply-adds (Linzer / Feig's form of the butterfly): the in-lane DFT-32 needs 194 packed instructions
+// instead of 214.  K = (rho, |t|) lives in an SGPR pair; the sign of t is a source modifier (TNEG).  g = -1 is
+// the g = 1 form with u and v exchanged, so every W32^k, k = 1 .. 15, is one of these with
+// (rho, |t|) in {(cos, tan)(pi/16), (cos, tan)(pi/8), (cos, tan)(3 pi/16), (sqrt(1/2), 1)}.
+#if defined(__clang__)
+GR4PM_HD cf vfma(cf a, cf b, cf c) { return __builtin_elementwise_fma(a, b, c); } // one v_pk_fma_f32, never split
+#else
+GR4PM_HD cf vfma(cf a, cf b, cf c) { return mk(a.x * b.x + c.x, a.y * b.y + c.y); }
+#endif
+template <bool MJ, bool TNEG>
+GR4PM_HD void bf_tw(cf a, cf b, cf K, cf& u, cf& v)
+{
+    // plain vector arithmetic: every per-half sign sits in a compile-time constant (an SGPR pair), the swizzles
+    // become op_sel, and hipcc schedules real instructions -- between inline-asm statements it pads every register
+    // overlap with an s_nop (gfx940's dst-forwarding hazard is assumed for anything an asm defines).  Explicit
+    // fma: a * b + c forms would be re-associated into one shared product and two additions (four instructions).
+    const float t = TNEG ? -K.y : K.y;
+    const cf c = vfma(swap_xy(b), mk(-t, t), b);
+    if (MJ) {
+        const cf d = swap_xy(c);
+        u = vfma(d, mk(K.x, -K.x), a);
+        v = vfma(d, mk(-K.x, K.x), a);
+    } else {
+        u = vfma(c, mk(K.x, K.x), a);
+        v = vfma(c, mk(-K.x, -K.x), a);
+    }
+}
+// (rho, |t|) of the four twiddle magnitudes
+#define GR4PM_K1 mk(0.98078528040323044913f, 0.19891236737965800691f) /* pi/16 */
+#define GR4PM_K2 mk(0.92387953251128675613f, 0.41421356237309504880f) /* pi/8 */
+#define GR4PM_K3 mk(0.83146961230254523708f, 0.66817863791929891999f) /* 3 pi/16 */
+#define GR4PM_K4 mk(0.70710678118654752440f, 1.0f)                    /* pi/4 */
+
+// W = exp(-j theta): theta in (0, pi/4]: g = 1, t = -tan(theta); around pi/2: g = -j, t = -tan(theta - pi/2);
+// theta in [3 pi/4, pi): g = -1 (u, v exchanged), t = -tan(theta - pi)
+GR4PM_HD void dft8f(cf* v)
+{
+    dft4(v[0], v[2], v[4], v[6]);
+    dft4(v[1], v[3], v[5], v[7]);
+    const cf e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+    const cf o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+    v[0] = e0 + o0;
+    v[4] = e0 - o0;
+    bf_tw<false, true>(e1, o1, GR4PM_K4, v[1], v[5]);  // W8^1: theta = pi/4
+    v[2] = add_mj(e2, o2);                             // W8^2 = -j
+    v[6] = sub_mj(e2, o2);
+    bf_tw<false, false>(e3, o3, GR4PM_K4, v[7], v[3]); // W8^3: theta = 3 pi/4 -> g = -1, t = +1
+}
+GR4PM_HD void dft16f(cf* v)
+{
+    cf e[8], o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        e[i] = v[2 * i];
+        o[i] = v[2 * i + 1];
+    }
+    dft8f(e);
+    dft8f(o);
+    v[0] = e[0] + o[0];
+    v[8] = e[0] - o[0];
+    bf_tw<false, true>(e[1], o[1], GR4PM_K2, v[1], v[9]);    // theta = pi/8
+    bf_tw<false, true>(e[2], o[2], GR4PM_K4, v[2], v[10]);   // pi/4
+    bf_tw<true, false>(e[3], o[3], GR4PM_K2, v[3], v[11]);   // 3 pi/8 = pi/2 - pi/8: g = -j, t = +tan(pi/8)
+    v[4] = add_mj(e[4], o[4]);                               // -j
+    v[12] = sub_mj(e[4], o[4]);
+    bf_tw<true, true>(e[5], o[5], GR4PM_K2, v[5], v[13]);    // 5 pi/8 = pi/2 + pi/8: g = -j, t = -tan(pi/8)
+    bf_tw<false, false>(e[6], o[6], GR4PM_K4, v[14], v[6]);  // 3 pi/4: g = -1, t = +1
+    bf_tw<false, false>(e[7], o[7], GR4PM_K2, v[15], v[7]);  // 7 pi/8 = pi - pi/8: g = -1, t = +tan(pi/8)
+}
+
 // in-lane 32-point DFT, forward sign, natural order in and out; `done(k)` is called as soon as v[k] and
 // v[k + 16] are final (the correlator issues their exchange stores there, between the butterflies of the
 // last stage, instead of 64 stores in one burst)
@@ -71,46 +147,49 @@ struct NoDone {
 template <typename Done = NoDone>
 GR4PM_HD void dft32(cf* v, Done done = Done{})
 {
-    constexpr float c8 = 0.70710678118654752440f;
-    // cos / sin of pi k / 16
-    constexpr float c1 = 0.98078528040323044913f, s1 = 0.19509032201612826785f;
-    constexpr float c2 = 0.92387953251128675613f, s2 = 0.38268343236508977173f;
-    constexpr float c3 = 0.83146961230254523708f, s3 = 0.55557023301960222474f;
     cf e[16], o[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         e[i] = v[2 * i];
         o[i] = v[2 * i + 1];
     }
-    dft16(e);
-    dft16(o);
-    // o[k] *= W32^k = cos(pi k/16) - j sin(pi k/16)
-    o[1] = cmulc(o[1], mk(c1, -s1));
-    o[2] = cmulc(o[2], mk(c2, -s2));
-    o[3] = cmulc(o[3], mk(c3, -s3));
-    o[4] = c8 * add_mj(o[4], o[4]);
-    o[5] = cmulc(o[5], mk(s3, -c3));
-    o[6] = cmulc(o[6], mk(s2, -c2));
-    o[7] = cmulc(o[7], mk(s1, -c1));
-    // o[8] * (-j) is folded into the combination below
-    o[9] = cmulc(o[9], mk(-s1, -c1));
-    o[10] = cmulc(o[10], mk(-s2, -c2));
-    o[11] = cmulc(o[11], mk(-s3, -c3));
-    o[12] = (-c8) * sub_mj(o[12], o[12]);
-    o[13] = cmulc(o[13], mk(-c3, -s3));
-    o[14] = cmulc(o[14], mk(-c2, -s2));
-    o[15] = cmulc(o[15], mk(-c1, -s1));
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        if (k == 8) {
-            v[8] = add_mj(e[8], o[8]);
-            v[24] = sub_mj(e[8], o[8]);
-        } else {
-            v[k] = e[k] + o[k];
-            v[k + 16] = e[k] - o[k];
-        }
-        done(k);
-    }
+    dft16f(e);
+    dft16f(o);
+    // v[k], v[k + 16] = e[k] +- W32^k o[k], theta = pi k / 16
+    v[0] = e[0] + o[0];
+    v[16] = e[0] - o[0];
+    done(0);
+    bf_tw<false, true>(e[1], o[1], GR4PM_K1, v[1], v[17]);
+    done(1);
+    bf_tw<false, true>(e[2], o[2], GR4PM_K2, v[2], v[18]);
+    done(2);
+    bf_tw<false, true>(e[3], o[3], GR4PM_K3, v[3], v[19]);
+    done(3);
+    bf_tw<false, true>(e[4], o[4], GR4PM_K4, v[4], v[20]);
+    done(4);
+    bf_tw<true, false>(e[5], o[5], GR4PM_K3, v[5], v[21]);   // pi/2 - 3 pi/16
+    done(5);
+    bf_tw<true, false>(e[6], o[6], GR4PM_K2, v[6], v[22]);   // pi/2 - pi/8
+    done(6);
+    bf_tw<true, false>(e[7], o[7], GR4PM_K1, v[7], v[23]);   // pi/2 - pi/16
+    done(7);
+    v[8] = add_mj(e[8], o[8]);
+    v[24] = sub_mj(e[8], o[8]);
+    done(8);
+    bf_tw<true, true>(e[9], o[9], GR4PM_K1, v[9], v[25]);     // pi/2 + pi/16
+    done(9);
+    bf_tw<true, true>(e[10], o[10], GR4PM_K2, v[10], v[26]);
+    done(10);
+    bf_tw<true, true>(e[11], o[11], GR4PM_K3, v[11], v[27]);
+    done(11);
+    bf_tw<false, false>(e[12], o[12], GR4PM_K4, v[28], v[12]); // 3 pi/4: g = -1
+    done(12);
+    bf_tw<false, false>(e[13], o[13], GR4PM_K3, v[29], v[13]); // pi - 3 pi/16
+    done(13);
+    bf_tw<false, false>(e[14], o[14], GR4PM_K2, v[30], v[14]);
+    done(14);
+    bf_tw<false, false>(e[15], o[15], GR4PM_K1, v[31], v[15]);
+    done(15);
 }
 
 // exchange image of one wave (host emulation / reference of what the addtid stores do)

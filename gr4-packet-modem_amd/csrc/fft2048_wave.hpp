@@ -56,20 +56,11 @@ GR4PM_HD cf mul_mj(cf a) { return neg_y(swap_xy(a)); } // a * (-j) = (a.y, -a.x)
 // The swizzle (op_sel) and per-half sign (neg_lo / neg_hi) source modifiers of the packed
 // FP32 instructions make "b +- (-j) a" one instruction and a full complex multiply two; hipcc
 // does not fold a per-half negation by itself (it emits v_xor), hence the explicit forms.
-// b + (-j) a = (b.x + a.y, b.y - a.x)
-__device__ __forceinline__ cf add_mj(cf b, cf a)
-{
-    cf r;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(b), "v"(a));
-    return r;
-}
+// b + (-j) a = (b.x + a.y, b.y - a.x): one v_pk_fma_f32 whose per-half sign is a constant operand (a real
+// instruction, not an asm: hipcc pads an s_nop between an asm statement and whatever reads its result)
+__device__ __forceinline__ cf add_mj(cf b, cf a) { return __builtin_elementwise_fma(a.yx, cf{ 1.0f, -1.0f }, b); }
 // b - (-j) a = (b.x - a.y, b.y + a.x)
-__device__ __forceinline__ cf sub_mj(cf b, cf a)
-{
-    cf r;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(b), "v"(a));
-    return r;
-}
+__device__ __forceinline__ cf sub_mj(cf b, cf a) { return __builtin_elementwise_fma(a.yx, cf{ -1.0f, 1.0f }, b); }
 // a * w = (a.x w.x - a.y w.y, a.x w.y + a.y w.x) for a run-time twiddle w
 __device__ __forceinline__ cf cmul(cf a, cf w)
 {

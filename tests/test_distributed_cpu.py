@@ -78,6 +78,29 @@ def test_bench_launcher_starts_one_process_per_gpu():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["gpus_requested"] == 2
     assert line["value"] == 3000.0 / 2.0   # SUM of items / MAX of times
+    assert line["scatter_ok"] is True
+    job = line["job"]
+    assert job["backend"] == "gloo" and job["world"] == 2 and [r["rank"] for r in job["ranks"]] == [0, 1]
+    assert len({r["pci_bus_id"] for r in job["ranks"]}) == 2   # two different processes took part
+
+
+@pytest.mark.parametrize("fail_rank", [0, 1])
+def test_bench_launcher_fails_when_a_rank_dies_before_the_scatter(fail_rank):
+    """a rank that dies while the others are about to enter the scatter: the launcher stops the survivors (they
+    would wait for ever) and returns non-zero, and no JSON line is printed"""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["GR4PM_BENCH_TEST_FAIL_RANK"] = str(fail_rank)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert time.time() - t0 < 120
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "stopping the other ranks" in r.stderr
 
 
 def test_bench_refuses_a_world_size_that_differs_from_gpus():
