@@ -94,6 +94,7 @@ __device__ __forceinline__ void w64_pin4(cf* b)
 // instead of 16 scalar ones -- fewer issue slots per wave (a lone wave issues one VALU op per 4 cycles,
 // packed or not)
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void w64_mid_pair(f2 a0r, f2 a1r, f2 a0i, f2 a1i, f2 tr, f2 ti, cf c, cf* b)
 {
     f2 ur, ui, br, bi, t0, t1;
@@ -148,6 +149,52 @@ __device__ __forceinline__ void w64_mid_dev(int lane, const float4* row, const f
             w64_mid_group(s[0], s[1], s[2], s[3], s[4], s[5], c, b + 4 * g);
         }
         w64_pin4(b + 4 * g);
+    }
+}
+
+// the planar form of the mid stage (fft2048_w64.hpp: pc): same reads, same prefetch distance, outputs
+// b[2g], b[2g + 1] = items (4g, 4g + 1), (4g + 2, 4g + 3) as (re, re) / (im, im) pairs: eight packed instructions
+// per pair and no v_pk_mov_b32.  One asm statement per pair: hipcc pads every pair of ADJACENT DEPENDENT packed
+// instructions of its own with an s_nop (it takes op_sel_hi of a VOP3P source for a dst_sel: "forwarding hazard";
+// the hardware interlocks by itself, the interleaved kernel has run such pairs inside asm statements since round 1),
+// and between two asm statements it pads every register overlap -- so the statement has no scratch outputs: u is
+// formed in the registers of the row reads it consumes (dead afterwards).
+__device__ __forceinline__ pc w64_mid_pair_asm(f2 a0r, f2 a1r, f2 a0i, f2 a1i, f2 tr, f2 ti, cf c)
+{
+    pc b;
+    asm("v_pk_fma_f32 %2, %4, %8, %2 op_sel_hi:[1,0,1]\n\t"                                       // ur  = a0r + c.x a1r
+        "v_pk_fma_f32 %3, %5, %8, %3 op_sel_hi:[1,0,1]\n\t"                                       // ui  = a0i + c.x a1i
+        "v_pk_fma_f32 %2, %5, %8, %2 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t" // ur -= c.y a1i
+        "v_pk_fma_f32 %3, %4, %8, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"                        // ui += c.y a1r
+        "v_pk_mul_f32 %0, %6, %2\n\t"                                                             // br  = tr ur
+        "v_pk_mul_f32 %1, %6, %3\n\t"                                                             // bi  = tr ui
+        "v_pk_fma_f32 %0, %7, %3, %0 neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"                           // br -= ti ui
+        "v_pk_fma_f32 %1, %7, %2, %1"                                                              // bi += ti ur
+        : "=&v"(b.r), "=&v"(b.i), "+v"(a0r), "+v"(a0i)
+        : "v"(a1r), "v"(a1i), "v"(tr), "v"(ti), "v"(c));
+    return b;
+}
+template <int DEPTH>
+__device__ __forceinline__ void w64_mid_dev_p(int lane, const float4* row, const float4* tT, cf c, pc* b)
+{
+    float4 q[DEPTH + 1][6];
+    auto issue = [&](int g) {
+        float4* d = q[g % (DEPTH + 1)];
+        d[0] = row[g], d[1] = row[8 + g], d[2] = row[16 + g], d[3] = row[24 + g];
+        d[4] = tT[(g * 2 + 0) * 64 + lane], d[5] = tT[(g * 2 + 1) * 64 + lane];
+    };
+#pragma unroll
+    for (int g = 0; g < DEPTH; ++g) issue(g);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        if (g + DEPTH < 8) issue(g + DEPTH);
+        const float4* s = q[g % (DEPTH + 1)];
+        b[2 * g] = w64_mid_pair_asm(f2{ s[0].x, s[0].y }, f2{ s[1].x, s[1].y }, f2{ s[2].x, s[2].y }, f2{ s[3].x, s[3].y },
+                                    f2{ s[4].x, s[4].y }, f2{ s[5].x, s[5].y }, c);
+        b[2 * g + 1] = w64_mid_pair_asm(f2{ s[0].z, s[0].w }, f2{ s[1].z, s[1].w }, f2{ s[2].z, s[2].w },
+                                        f2{ s[3].z, s[3].w }, f2{ s[4].z, s[4].w }, f2{ s[5].z, s[5].w }, c);
+        // issue order: the reads of group g + 1, then the arithmetic of group g, and nothing further ahead (w64_pin4)
+        asm volatile("" : "+v"(b[2 * g].r), "+v"(b[2 * g].i), "+v"(b[2 * g + 1].r), "+v"(b[2 * g + 1].i)::"memory");
     }
 }
 
@@ -214,6 +261,32 @@ __global__ __launch_bounds__(kW64Threads, 2) void k_correlate_w64(const cf* __re
         w64_mid_dev<1, true, (VAR & 64) != 0>(lane, row, ldsT, c, bq);
     };
 
+    // VAR & 32768 (with the planar bin loop): the templates come straight from global memory (L2: B x 16 KiB, shared
+    // by every wave of the chip) into registers, two halves of eight global_load_dwordx4: half A of the next bin is
+    // requested when the mid stage's row reads have left their registers, a whole pass B ahead of its use; half B when
+    // pass B's registers have died, in front of the product, which starts on half A.  No LDS-DMA (sixteen M0 writes and
+    // their wait states per bin, issue behind the wave's last exchange read), no s_waitcnt vmcnt(0) per bin.
+    constexpr bool TG = (VAR & 32768) != 0;
+    f4v tqa[TG ? 8 : 1], tqb[TG ? 8 : 1];
+    // eight global_load_dwordx4 in the saddr form: uniform base (SGPR pair, 4 KiB into the half so that the eight
+    // 1-KiB steps fit the 13-bit immediate) + the lane's byte offset in ONE VGPR.  Written as asm: from C++ hipcc forms
+    // 64-bit per-lane addresses for them (38 more vector instructions per bin).  The compiler does not know these are
+    // loads, so the waits are explicit (tq_wait): s_waitcnt vmcnt(n) with n = the requests issued after the ones wanted.
+    auto load_template_half = [&](f4v* dst, int bin, int half) {
+        const float4* tb = tmpl + static_cast<size_t>(bin) * 1024 + half * 512 + 256;
+        asm volatile("global_load_dwordx4 %0, %8, %9 offset:-4096\n\t"
+                     "global_load_dwordx4 %1, %8, %9 offset:-3072\n\t"
+                     "global_load_dwordx4 %2, %8, %9 offset:-2048\n\t"
+                     "global_load_dwordx4 %3, %8, %9 offset:-1024\n\t"
+                     "global_load_dwordx4 %4, %8, %9\n\t"
+                     "global_load_dwordx4 %5, %8, %9 offset:1024\n\t"
+                     "global_load_dwordx4 %6, %8, %9 offset:2048\n\t"
+                     "global_load_dwordx4 %7, %8, %9 offset:3072"
+                     : "=&v"(dst[0]), "=&v"(dst[1]), "=&v"(dst[2]), "=&v"(dst[3]), "=&v"(dst[4]), "=&v"(dst[5]),
+                       "=&v"(dst[6]), "=&v"(dst[7])
+                     : "v"(voff), "s"(tb)
+                     : "memory");
+    };
     cf X[32];
     load_block(X, item);
     for (;;) {
@@ -226,7 +299,8 @@ __global__ __launch_bounds__(kW64Threads, 2) void k_correlate_w64(const cf* __re
             cf bq[32];
             dft32(X);
             exchange(X, bq);
-            if (!(VAR & 8)) w64_dma_template(tmpl, base, voff); // template 0 while pass B runs
+            if (TG) load_template_half(tqa, 0, 0);
+            else if (!(VAR & 8)) w64_dma_template(tmpl, base, voff); // template 0 while pass B runs
             dft32(bq);
 #pragma unroll
             for (int j = 0; j < 32; ++j) X[j] = bq[j];
@@ -260,11 +334,25 @@ __global__ __launch_bounds__(kW64Threads, 2) void k_correlate_w64(const cf* __re
         for (int j = 0; j < 32; ++j) zmax[j] = -1.0f; // hpp:303
         for (int bin = 0; bin < n_bins; ++bin) {
             cf p[32], bq[32];
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the template has landed in the exchange buffer
+            if (!TG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the template has landed in the exchange buffer
+            if (TG) {
+                load_template_half(tqb, bin, 1);
+                // half A (requested a pass B ago) has landed once only the eight requests just made are outstanding
+                asm volatile("s_waitcnt vmcnt(8)"
+                             : "+v"(tqa[0]), "+v"(tqa[1]), "+v"(tqa[2]), "+v"(tqa[3]), "+v"(tqa[4]), "+v"(tqa[5]),
+                               "+v"(tqa[6]), "+v"(tqa[7])::"memory");
+            }
 #pragma unroll
             for (int u = 0; u < 16; ++u) { // hpp:247-249
                 float4 t;
-                if (VAR & 128) {
+                if (TG) {
+                    if (u == 8)
+                        asm volatile("s_waitcnt vmcnt(0)"
+                                     : "+v"(tqb[0]), "+v"(tqb[1]), "+v"(tqb[2]), "+v"(tqb[3]), "+v"(tqb[4]), "+v"(tqb[5]),
+                                       "+v"(tqb[6]), "+v"(tqb[7])::"memory");
+                    const f4v tv = u < 8 ? tqa[u] : tqb[u - 8];
+                    t = make_float4(tv.x, tv.y, tv.z, tv.w);
+                } else if (VAR & 128) {
                     t = make_float4(c.x, c.y, c.y, c.x);
                     asm volatile("" : "+v"(t.x), "+v"(t.y), "+v"(t.z), "+v"(t.w));
                 } else {
@@ -280,6 +368,39 @@ __global__ __launch_bounds__(kW64Threads, 2) void k_correlate_w64(const cf* __re
                 load_block(X, next);
             }
             dft32(p); // hpp:250-251
+            if (VAR & 65536) {
+                // planar second half: exchange stores as before, mid stage and pass B on (re, re) / (im, im) pairs
+                pc bp[16];
+                w64_store(p, base);
+                w64_mid_dev_p<1>(lane, row, ldsT, c, bp);
+                if (TG) {
+                    if (bin + 1 < n_bins) load_template_half(tqa, bin + 1, 0);
+                } else if (!(VAR & 8) && bin + 1 < n_bins) {
+                    w64_dma_template(tmpl + static_cast<size_t>(bin + 1) * 1024, base, voff);
+                }
+                dft32p(bp);
+#pragma unroll
+                for (int k0 = 0; k0 < 16; k0 += 4) {
+                    // hpp:307-308: powers of outputs k (lo) and k + 16 (hi) in two packed instructions
+                    cf pw[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) pw[u] = vfma(bp[k0 + u].i, bp[k0 + u].i, bp[k0 + u].r * bp[k0 + u].r);
+                    if ((VAR & 16384) && k0 == 0) { // registers 1 .. 3 are never stored
+                        asm("v_max_f32 %0, %0, %5\n\tv_max_f32 %1, %1, %6\n\tv_max_f32 %2, %2, %7\n\tv_max_f32 %3, %3, %8\n\t"
+                            "v_max_f32 %4, %4, %9"
+                            : "+v"(zmax[0]), "+v"(zmax[16]), "+v"(zmax[17]), "+v"(zmax[18]), "+v"(zmax[19])
+                            : "v"(pw[0].x), "v"(pw[0].y), "v"(pw[1].y), "v"(pw[2].y), "v"(pw[3].y));
+                        continue;
+                    }
+                    asm("v_max_f32 %0, %0, %8\n\tv_max_f32 %1, %1, %9\n\tv_max_f32 %2, %2, %10\n\tv_max_f32 %3, %3, %11\n\t"
+                        "v_max_f32 %4, %4, %12\n\tv_max_f32 %5, %5, %13\n\tv_max_f32 %6, %6, %14\n\tv_max_f32 %7, %7, %15"
+                        : "+v"(zmax[k0]), "+v"(zmax[k0 + 1]), "+v"(zmax[k0 + 2]), "+v"(zmax[k0 + 3]), "+v"(zmax[k0 + 16]),
+                          "+v"(zmax[k0 + 17]), "+v"(zmax[k0 + 18]), "+v"(zmax[k0 + 19])
+                        : "v"(pw[0].x), "v"(pw[1].x), "v"(pw[2].x), "v"(pw[3].x), "v"(pw[0].y), "v"(pw[1].y), "v"(pw[2].y),
+                          "v"(pw[3].y));
+                }
+                continue;
+            }
             exchange(p, bq);
             if (!(VAR & 8) && bin + 1 < n_bins) w64_dma_template(tmpl + static_cast<size_t>(bin + 1) * 1024, base, voff);
             dft32(bq);

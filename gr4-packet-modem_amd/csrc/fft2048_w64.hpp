@@ -101,14 +101,53 @@ GR4PM_HD void bf_tw(cf a, cf b, cf K, cf& u, cf& v)
 #define GR4PM_K3 mk(0.83146961230254523708f, 0.66817863791929891999f) /* 3 pi/16 */
 #define GR4PM_K4 mk(0.70710678118654752440f, 1.0f)                    /* pi/4 */
 
+// ---- two complex numbers side by side, planar: r = (re0, re1), i = (im0, im1) -----------------------------------
+// What the mid stage's ds_read_b128 deliver is planar (four consecutive re, four consecutive im): with this type the
+// per-bin pass B works on (re[m], re[m + 1]) pairs as they come -- no v_pk_mov_b32 to re-pair them into (re, im) --,
+// a multiplication by -j is a renaming, every sign is a whole-vector negation or sits in a constant, and the power
+// of two outputs is one v_pk_mul_f32 + one v_pk_fma_f32.  The two halves run the SAME small DFT on two different
+// sequences (even and odd items); only the last radix-2 stage combines the halves of one register.
+struct pc {
+    cf r, i;
+};
+GR4PM_HD pc operator+(pc a, pc b) { return pc{ a.r + b.r, a.i + b.i }; }
+GR4PM_HD pc operator-(pc a, pc b) { return pc{ a.r - b.r, a.i - b.i }; }
+GR4PM_HD pc add_mj(pc b, pc a) { return pc{ b.r + a.i, b.i - a.r }; } // b + (-j) a
+GR4PM_HD pc sub_mj(pc b, pc a) { return pc{ b.r - a.i, b.i + a.r }; } // b - (-j) a
+template <bool MJ, bool TNEG>
+GR4PM_HD void bf_tw(pc a, pc b, cf K, pc& u, pc& v)
+{
+    const float t = TNEG ? -K.y : K.y, rho = K.x;
+    const cf cr = vfma(b.i, mk(-t, -t), b.r), ci = vfma(b.r, mk(t, t), b.i); // c = b + t (j b)
+    if (MJ) { // w b = rho (c.i, -c.r)
+        u = pc{ vfma(ci, mk(rho, rho), a.r), vfma(cr, mk(-rho, -rho), a.i) };
+        v = pc{ vfma(ci, mk(-rho, -rho), a.r), vfma(cr, mk(rho, rho), a.i) };
+    } else {
+        u = pc{ vfma(cr, mk(rho, rho), a.r), vfma(ci, mk(rho, rho), a.i) };
+        v = pc{ vfma(cr, mk(-rho, -rho), a.r), vfma(ci, mk(-rho, -rho), a.i) };
+    }
+}
+// last radix-2 stage of the planar DFT-32: x = (E, O) side by side; out = (E + w O, E - w O) side by side, i.e.
+// outputs k (lo) and k + 16 (hi); w = g rho (1 + j t), g = 1 / -j (MJ) / -1 (NEG)
+template <bool MJ, bool TNEG, bool NEG>
+GR4PM_HD pc bf_last(pc x, cf K)
+{
+    const float t = TNEG ? -K.y : K.y, rho = NEG ? -K.x : K.x;
+    const cf cr = vfma(x.i, mk(-t, -t), x.r), ci = vfma(x.r, mk(t, t), x.i); // hi halves: c = O + t (j O)
+    const cf er = dup_x(x.r), ei = dup_x(x.i);
+    if (MJ) return pc{ vfma(dup_y(ci), mk(rho, -rho), er), vfma(dup_y(cr), mk(-rho, rho), ei) };
+    return pc{ vfma(dup_y(cr), mk(rho, -rho), er), vfma(dup_y(ci), mk(rho, -rho), ei) };
+}
+
 // W = exp(-j theta): theta in (0, pi/4]: g = 1, t = -tan(theta); around pi/2: g = -j, t = -tan(theta - pi/2);
 // theta in [3 pi/4, pi): g = -1 (u, v exchanged), t = -tan(theta - pi)
-GR4PM_HD void dft8f(cf* v)
+template <typename T>
+GR4PM_HD void dft8f(T* v)
 {
     dft4(v[0], v[2], v[4], v[6]);
     dft4(v[1], v[3], v[5], v[7]);
-    const cf e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
-    const cf o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+    const T e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+    const T o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
     v[0] = e0 + o0;
     v[4] = e0 - o0;
     bf_tw<false, true>(e1, o1, GR4PM_K4, v[1], v[5]);  // W8^1: theta = pi/4
@@ -116,9 +155,10 @@ GR4PM_HD void dft8f(cf* v)
     v[6] = sub_mj(e2, o2);
     bf_tw<false, false>(e3, o3, GR4PM_K4, v[7], v[3]); // W8^3: theta = 3 pi/4 -> g = -1, t = +1
 }
-GR4PM_HD void dft16f(cf* v)
+template <typename T>
+GR4PM_HD void dft16f(T* v)
 {
-    cf e[8], o[8];
+    T e[8], o[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         e[i] = v[2 * i];
@@ -190,6 +230,62 @@ GR4PM_HD void dft32(cf* v, Done done = Done{})
     done(14);
     bf_tw<false, false>(e[15], o[15], GR4PM_K1, v[31], v[15]);
     done(15);
+}
+
+// planar in-lane DFT-32: b[i] = (v[2i], v[2i + 1]) on entry, b[k] = (V[k], V[k + 16]) on exit.  148 + 60 packed
+// instructions (the interleaved form: 194) -- the 14 extra ones buy the mid stage without its 32 v_pk_mov_b32 and a
+// power tail of 2 instead of 3 instructions per output.
+GR4PM_HD void dft32p(pc* b)
+{
+    dft16f(b); // lo halves: DFT-16 of the even items, hi halves: DFT-16 of the odd items
+    const cf one_m = mk(1.0f, -1.0f);
+    {   // k = 0: (E + O, E - O)
+        const pc x = b[0];
+        b[0] = pc{ vfma(dup_y(x.r), one_m, dup_x(x.r)), vfma(dup_y(x.i), one_m, dup_x(x.i)) };
+    }
+    b[1] = bf_last<false, true, false>(b[1], GR4PM_K1);
+    b[2] = bf_last<false, true, false>(b[2], GR4PM_K2);
+    b[3] = bf_last<false, true, false>(b[3], GR4PM_K3);
+    b[4] = bf_last<false, true, false>(b[4], GR4PM_K4);
+    b[5] = bf_last<true, false, false>(b[5], GR4PM_K3);
+    b[6] = bf_last<true, false, false>(b[6], GR4PM_K2);
+    b[7] = bf_last<true, false, false>(b[7], GR4PM_K1);
+    {   // k = 8: w = -j: (E_r + O_i, E_r - O_i), (E_i - O_r, E_i + O_r)
+        const pc x = b[8];
+        b[8] = pc{ vfma(dup_y(x.i), one_m, dup_x(x.r)), vfma(dup_y(x.r), -one_m, dup_x(x.i)) };
+    }
+    b[9] = bf_last<true, true, false>(b[9], GR4PM_K1);
+    b[10] = bf_last<true, true, false>(b[10], GR4PM_K2);
+    b[11] = bf_last<true, true, false>(b[11], GR4PM_K3);
+    b[12] = bf_last<false, false, true>(b[12], GR4PM_K4);
+    b[13] = bf_last<false, false, true>(b[13], GR4PM_K3);
+    b[14] = bf_last<false, false, true>(b[14], GR4PM_K2);
+    b[15] = bf_last<false, false, true>(b[15], GR4PM_K1);
+}
+
+// mid stage, planar out: the pair (m, m + 1) from the row reads as they are.  ur = a0r + c.x a1r - c.y a1i ;
+// ui = a0i + c.x a1i + c.y a1r ; b = T u
+GR4PM_HD pc w64_mid_pair_p(cf a0r, cf a1r, cf a0i, cf a1i, cf tr, cf ti, cf c)
+{
+    const cf cx = dup_x(c), cy = dup_y(c);
+    const cf ur = vfma(a1i, -cy, vfma(a1r, cx, a0r));
+    const cf ui = vfma(a1r, cy, vfma(a1i, cx, a0i));
+    return pc{ vfma(ti, -ui, tr * ur), vfma(ti, ur, tr * ui) };
+}
+GR4PM_HD void w64_mid_group_p(const f4& r0, const f4& r1, const f4& i0, const f4& i1, const f4& tr, const f4& ti, cf c,
+                              pc* b)
+{
+    b[0] = w64_mid_pair_p(mk(r0.x, r0.y), mk(r1.x, r1.y), mk(i0.x, i0.y), mk(i1.x, i1.y), mk(tr.x, tr.y), mk(ti.x, ti.y), c);
+    b[1] = w64_mid_pair_p(mk(r0.z, r0.w), mk(r1.z, r1.w), mk(i0.z, i0.w), mk(i1.z, i1.w), mk(tr.z, tr.w), mk(ti.z, ti.w), c);
+}
+// host reference of the planar mid stage (the device version keeps its reads two groups ahead: correlate_w64.hpp)
+GR4PM_HD void w64_mid_p(int lane, const float* xb, const f4* tT, cf c, pc* b)
+{
+    const f4* row = reinterpret_cast<const f4*>(xb + (lane & 31) * kW64Row);
+#pragma unroll
+    for (int g = 0; g < 8; ++g)
+        w64_mid_group_p(row[g], row[8 + g], row[16 + g], row[24 + g], tT[(g * 2 + 0) * 64 + lane],
+                        tT[(g * 2 + 1) * 64 + lane], c, b + 2 * g);
 }
 
 // exchange image of one wave (host emulation / reference of what the addtid stores do)

@@ -43,6 +43,7 @@ GR4PM_HD cf operator+(cf a, cf b) { return { a.x + b.x, a.y + b.y }; }
 GR4PM_HD cf operator-(cf a, cf b) { return { a.x - b.x, a.y - b.y }; }
 GR4PM_HD cf operator*(cf a, cf b) { return { a.x * b.x, a.y * b.y }; }
 GR4PM_HD cf operator*(float a, cf b) { return { a * b.x, a * b.y }; }
+GR4PM_HD cf operator-(cf a) { return { -a.x, -a.y }; }
 GR4PM_HD cf swap_xy(cf a) { return { a.y, a.x }; }
 GR4PM_HD cf dup_x(cf a) { return { a.x, a.x }; }
 GR4PM_HD cf dup_y(cf a) { return { a.y, a.y }; }
@@ -67,10 +68,13 @@ __device__ __forceinline__ cf cmul(cf a, cf w)
     // ONE statement for the dependent pair: between two separate asm statements hipcc pads the dependency with
     // an s_nop (it does not model what is inside an asm), and an s_nop costs a whole issue slot -- 80 of them per
     // transform of the correlator; the hardware interlocks a VALU result by itself
-    cf t, r;
-    asm("v_pk_mul_f32 %1, %2, %3 op_sel_hi:[0,1]\n\t"
-        "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
-        : "=&v"(r), "=&v"(t)
+    // the product of the first instruction sits in the result register itself: a scratch output would be given the
+    // same physical register in consecutive statements, and hipcc pads every register overlap between two asm
+    // statements with an s_nop (gfx940 dst-forwarding hazard, assumed for whatever an asm defines)
+    cf r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+        : "=&v"(r)
         : "v"(a), "v"(w));
     return r;
 }
@@ -124,9 +128,10 @@ inline void build_twiddle_tables(W w, cf* tw1a, cf* tw1b, cf* twA, cf* twB)
 }
 
 // ---- small DFTs, forward sign, natural-order output, everything in registers ----
-GR4PM_HD void dft4(cf& a0, cf& a1, cf& a2, cf& a3)
+template <typename T>
+GR4PM_HD void dft4(T& a0, T& a1, T& a2, T& a3)
 {
-    const cf t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, d = a1 - a3;
+    const T t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, d = a1 - a3;
     a0 = t0 + t2;
     a1 = add_mj(t1, d); // t1 + (-j) d
     a2 = t0 - t2;

@@ -1728,6 +1728,9 @@ gr4pm_status launch_correlate(gr4pm_syncword_detection* h, hipStream_t stream, c
                        in_stride, n_blocks, total, static_cast<uint32_t>(h->S), h->n_bins, h->tmpl64.p, h->tT64.p,  \
                        h->cc64.p, zout, h->z_stride, bpw, h->noise_off - h->zc)
         // GR4PM_W64_VARIANT: the timing-only ablations of tools/w64_variants.py
+        // registers 1 .. 3 of the output hold lags >= 1793: with a stride of at most that (the default: 1752) the
+        // kernel variant that never computes their powers runs (bit 16384)
+        const bool prune = h->S <= 1793 && !h->w64_no_prune;
         switch (h->w64_variant) {
         case 8: GR4PM_W64_LAUNCH(8); break;
         case 32: GR4PM_W64_LAUNCH(32); break;
@@ -1736,11 +1739,16 @@ gr4pm_status launch_correlate(gr4pm_syncword_detection* h, hipStream_t stream, c
         case 2048: GR4PM_W64_LAUNCH(2048); break;
         case 4096: GR4PM_W64_LAUNCH(4096); break;
         case 6144: GR4PM_W64_LAUNCH(6144); break;
-        default:
-            // registers 1 .. 3 of the output hold lags >= 1793: with a stride of at most that (the default: 1752) the
-            // kernel variant that never computes their powers runs
-            if (h->S <= 1793 && !h->w64_no_prune) GR4PM_W64_LAUNCH(16384);
+        case 0: // round 2's bin loop: everything (re, im) interleaved, templates by LDS-DMA into the exchange buffer
+            if (prune) GR4PM_W64_LAUNCH(16384);
             else GR4PM_W64_LAUNCH(0);
+            break;
+        case 65536: GR4PM_W64_LAUNCH(65536 + 16384); break; // planar second half, templates still by LDS-DMA
+        default:
+            // planar mid stage / pass B / powers in the bin loop (65536), templates from global memory straight
+            // into registers (32768)
+            if (prune) GR4PM_W64_LAUNCH(98304 + 16384);
+            else GR4PM_W64_LAUNCH(98304);
             break;
         }
 #undef GR4PM_W64_LAUNCH

@@ -2,6 +2,7 @@
 // 64 lanes phase by phase on the CPU and prints the max error (relative to the largest output) of
 // X = FFT(x) and of FFT(X .* t) against a double-precision DFT.  Built and run by
 // tests/test_abi_and_host.py (no GPU needed).
+#include <algorithm>
 #include <cmath>
 #include <complex>
 #include <cstdio>
@@ -47,6 +48,34 @@ static void fft_w64(std::vector<std::vector<cf>>& r)
     for (int l = 0; l < 64; ++l) dft32(r[l].data());
 }
 
+// the per-bin transform as the correlator runs it: pass A interleaved, mid stage and pass B planar; returns the
+// largest difference to the all-interleaved schedule relative to the largest output
+static double planar_vs_interleaved(const std::vector<cf>& x)
+{
+    std::vector<std::vector<cf>> r(64, std::vector<cf>(32)), ref;
+    for (int l = 0; l < 64; ++l)
+        for (int j = 0; j < 32; ++j) r[l][j] = x[w64_index(l, j)];
+    ref = r;
+    interleaved = false;
+    fft_w64(ref);
+    std::vector<float> xb(kW64BufDwords, 0.f);
+    for (int l = 0; l < 64; ++l) dft32(r[l].data());
+    for (int l = 0; l < 64; ++l) w64_store_ref(l, r[l].data(), xb.data());
+    double e = 0, m = 0;
+    for (int l = 0; l < 64; ++l) {
+        pc b[16];
+        w64_mid_p(l, xb.data(), tT.data(), cc[l], b);
+        dft32p(b);
+        for (int k = 0; k < 16; ++k) {
+            const cf lo = mk(b[k].r.x, b[k].i.x), hi = mk(b[k].r.y, b[k].i.y);
+            const cf a = ref[l][k], c = ref[l][k + 16];
+            e = std::max({ e, (double)std::hypot(lo.x - a.x, lo.y - a.y), (double)std::hypot(hi.x - c.x, hi.y - c.y) });
+            m = std::max({ m, (double)std::hypot(a.x, a.y), (double)std::hypot(c.x, c.y) });
+        }
+    }
+    return e / m;
+}
+
 int main()
 {
     build_w64_tables(
@@ -85,6 +114,11 @@ int main()
         std::printf("dft32 max_rel_err %.3e\n", e / m);
     }
     int rc = 0;
+    {
+        const double e = planar_vs_interleaved(x);
+        std::printf("planar pass B vs interleaved max_rel_err %.3e\n", e);
+        if (!(e < 5e-7)) rc = 1;
+    }
     for (int layout = 0; layout < 2; ++layout) {
     interleaved = layout == 1;
     std::vector<std::vector<cf>> r(64, std::vector<cf>(32));

@@ -81,7 +81,7 @@ def test_one_exchange_wave_fft_host_emulation(tmp_path):
                            os.path.join(ROOT, "tests", "fft_w64_emu.cpp")])
     out = subprocess.check_output([str(exe)]).decode()
     errs = [float(e) for e in re.findall(r"max_rel_err ([0-9.e+-]+)", out)]
-    assert len(errs) == 5 and max(errs) < 5e-7, out
+    assert len(errs) == 6 and max(errs) < 5e-7, out   # incl. the planar pass B of the per-bin transforms
 
 
 def test_glibc_sinf_cosf_restatement_matches_the_host_libm(tmp_path):
