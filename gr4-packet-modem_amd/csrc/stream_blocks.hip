@@ -1286,7 +1286,8 @@ static gr4pm_status rotator_plan(gr4pm_rotator* h, size_t n, const gr4pm_tag* ta
         GR4PM_TRY(pl.seg_incr.alloc(n_segs * 2));
         GR4PM_TRY(pl.seg_counter0.alloc(n_segs * 2));
     }
-    hipLaunchKernelGGL(k_rot_checkpoints, dim3(grid_for(n_segs, 64)), dim3(64), 0, s, pl.segs.p, n_segs,
+    static const unsigned wg = getenv("GR4PM_SERIAL_WG") ? static_cast<unsigned>(atoi(getenv("GR4PM_SERIAL_WG"))) : 64u;
+    hipLaunchKernelGGL(k_rot_checkpoints, dim3(grid_for(n_segs, wg)), dim3(wg), 0, s, pl.segs.p, n_segs,
                        h->state.p + static_cast<size_t>(h->st_cur) * h->n_channels,
                        h->state.p + static_cast<size_t>(h->st_cur ^ 1) * h->n_channels,
                        pl.ck.p, pl.seg_incr.p, pl.seg_counter0.p);
@@ -1479,7 +1480,8 @@ static gr4pm_status costas_process_impl(gr4pm_costas_loop* h, const gr4pm_c64* i
     }
     hipStream_t s = h->stream;
     GR4PM_TRY(upload_vec(h->segs, segs, s));
-    const dim3 grid(grid_for(segs.size(), 64)), block(64);
+    static const unsigned wg = getenv("GR4PM_SERIAL_WG") ? static_cast<unsigned>(atoi(getenv("GR4PM_SERIAL_WG"))) : 64u;
+    const dim3 grid(grid_for(segs.size(), wg)), block(wg);
     const unsigned n_segs = static_cast<unsigned>(segs.size());
     const CostasState* st_in = h->state.p + h->st_cur * h->n_channels;
     CostasState* st_out = h->state.p + (h->st_cur ^ 1) * h->n_channels;

@@ -1744,6 +1744,9 @@ gr4pm_status launch_correlate(gr4pm_syncword_detection* h, hipStream_t stream, c
             else GR4PM_W64_LAUNCH(0);
             break;
         case 65536: GR4PM_W64_LAUNCH(65536 + 16384); break; // planar second half, templates still by LDS-DMA
+        case 100352: GR4PM_W64_LAUNCH(98304 + 16384 + 2048); break; // timing only: the default kernel without power stores
+        case 102400: GR4PM_W64_LAUNCH(98304 + 16384 + 4096); break; // ... without sample loads after the first block
+        case 104448: GR4PM_W64_LAUNCH(98304 + 16384 + 6144); break; // ... without either
         default:
             // planar mid stage / pass B / powers in the bin loop (65536), templates from global memory straight
             // into registers (32768)

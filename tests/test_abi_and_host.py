@@ -5,6 +5,7 @@ include/gr4pm_hip.h declares, the one-wave FFT index algebra is right (host emul
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -128,3 +129,20 @@ def test_bench_roofline_traffic_comes_from_the_committed_counters(monkeypatch):
     assert bench.correlator_kernel() == "k_correlate"
     monkeypatch.delenv("GR4PM_CORRELATOR")
     assert bench.correlator_kernel() == "k_correlate_w64"
+
+
+def test_m0_guard_catches_a_compiler_written_m0(tmp_path):
+    """tools/check_m0.py (run by build()): a write of m0 outside the kernel's own asm blocks inside k_correlate_w64
+    fails the check; the asm sites themselves pass"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_m0
+    good = tmp_path / "good.s"
+    good.write_text("_ZN5gr4pm15k_correlate_w64ILi0EEEvv:\n\t;;#ASMSTART\n\ts_mov_b32 m0, s12\n\ts_nop 0\n\t;;#ASMEND\n"
+                    "\tv_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7]\n.Lfunc_end0:\n"
+                    "_ZN5gr4pm7k_otherEv:\n\ts_movk_i32 m0, 0x400\n.Lfunc_end1:\n")
+    assert check_m0.check(str(good)) == (1, 1, [])
+    bad = tmp_path / "bad.s"
+    bad.write_text("_ZN5gr4pm15k_correlate_w64ILi0EEEvv:\n\ts_mov_b32 m0, s3\n\t;;#ASMSTART\n\ts_mov_b32 m0, s12\n\t;;#ASMEND\n"
+                   ".Lfunc_end0:\n")
+    seen, sites, problems = check_m0.check(str(bad))
+    assert seen == 1 and len(problems) == 1 and "compiler-generated" in problems[0]

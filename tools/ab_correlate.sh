@@ -5,6 +5,6 @@ A=$1; B=$2; N=${3:-67108864}; BINS=${4:-4}; R=${5:-3}
 for r in $(seq 1 $R); do
   for L in "$A" "$B"; do
     echo -n "$(basename $L): "
-    GR4PM_LIB=$L python3 tools/w64_variants.py $N $BINS 5 0 2>&1 | grep "median"
+    GR4PM_LIB=$L python3 tools/w64_variants.py $N $BINS 7 -1 2>&1 | grep "median"
   done
 done
