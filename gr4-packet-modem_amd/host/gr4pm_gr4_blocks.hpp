@@ -530,8 +530,9 @@ public:
         _h = nullptr;
         gr4pm_symbol_filter_params p{ samples_per_symbol, taps.data(), taps.size(), num_arms, delay, 0, nullptr };
         detail::check(gr4pm_symbol_filter_create(&p, &_h), "SymbolFilter::settingsChanged"); // :67-73 throw
-        this->input_chunk_size = samples_per_symbol; // :75-76
-        this->output_chunk_size = 1;
+        // input_chunk_size / output_chunk_size stay 1 : 1 like the reference's (symbol_filter.hpp:74-81 has the
+        // samples_per_symbol : 1 ratio commented out: input tags are not aligned to samples_per_symbol blocks, and a
+        // scheduler that sizes spans in that ratio would never offer the items in front of such a tag)
         _tags_out.resize(64);
         _held.clear();
     }

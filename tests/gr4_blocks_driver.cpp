@@ -22,125 +22,9 @@
 #include <gnuradio-4.0/packet-modem/syncword_detection_filter.hpp>
 #include <gnuradio-4.0/packet-modem/syncword_wipeoff.hpp>
 
-#include <cmath>
-#include <cstdio>
-#include <cstring>
-#include <deque>
-#include <numeric>
+#include "gr4_mini_scheduler.hpp"
 
-using c64 = std::complex<float>;
 using namespace gr::packet_modem;
-
-// one stream edge: the "ring" (never reallocated: downstream spans alias it, like GR4's buffers) + its tags
-template <typename T>
-struct Edge {
-    std::vector<T> data;
-    size_t size = 0, rd = 0;
-    std::vector<gr::Tag> tags; // absolute item index
-    explicit Edge(size_t cap) : data(cap) {}
-    const gr::Tag* tag_at(size_t idx) const
-    {
-        for (const auto& t : tags)
-            if (static_cast<size_t>(t.index) == idx) return &t;
-        return nullptr;
-    }
-    size_t next_tag_after(size_t idx) const
-    {
-        size_t best = static_cast<size_t>(-1);
-        for (const auto& t : tags)
-            if (static_cast<size_t>(t.index) > idx) best = std::min(best, static_cast<size_t>(t.index));
-        return best;
-    }
-};
-
-struct TagRecord { // what the Python side reads back
-    uint64_t index;
-    float amplitude, phase;
-    double freq;
-    int32_t freq_bin;
-    float noise_power, esn0_db, time_est;
-    int32_t has_syncword;
-};
-static TagRecord record(const gr::Tag& t)
-{
-    TagRecord r{};
-    r.index = static_cast<uint64_t>(t.index);
-    const auto& m = t.map;
-    r.has_syncword = m.contains("syncword_amplitude") ? 1 : 0;
-    if (r.has_syncword) {
-        r.amplitude = pmtv::cast<float>(m.at("syncword_amplitude"));
-        r.phase = pmtv::cast<float>(m.at("syncword_phase"));
-        r.freq = pmtv::cast<double>(m.at("syncword_freq"));
-        r.freq_bin = pmtv::cast<int32_t>(m.at("syncword_freq_bin"));
-        r.noise_power = pmtv::cast<float>(m.at("syncword_noise_power"));
-        r.esn0_db = pmtv::cast<float>(m.at("syncword_esn0_db"));
-        r.time_est = pmtv::cast<float>(m.at("syncword_time_est"));
-    }
-    return r;
-}
-template <typename T>
-static void dump(const std::string& path, const T* p, size_t n)
-{
-    FILE* f = std::fopen(path.c_str(), "wb");
-    if (!f || std::fwrite(p, sizeof(T), n, f) != n) throw std::runtime_error("cannot write " + path);
-    std::fclose(f);
-}
-static void dump_tags(const std::string& path, const std::vector<gr::Tag>& tags)
-{
-    std::vector<TagRecord> r;
-    for (const auto& t : tags) r.push_back(record(t));
-    dump(path, r.data(), r.size());
-}
-
-// runs `blk` over everything `in` holds; `call(inSpan, outSpan)` forwards to processBulk (extra message
-// spans are bound by the caller).  Returns when the block makes no more progress.
-// one processBulk() call; returns whether the block made progress
-template <typename Blk, typename TI, typename TO, typename Call>
-static bool step(Blk& blk, Edge<TI>& in, Edge<TO>& out, size_t max_chunk, Call call)
-{
-    {
-        const size_t start = in.rd;
-        if (start >= in.size) return false;
-        const size_t end = std::min({ in.size, start + max_chunk, in.next_tag_after(start) });
-        blk._mergedInputTag = {};
-        if (const gr::Tag* t = in.tag_at(start)) blk._mergedInputTag = { 0, t->map };
-        gr::InSpan<TI> is(in.data.data() + start, end - start);
-        gr::OutSpan<TO> os(out.data.data() + out.size, out.data.size() - out.size);
-        blk.out.published_tags.clear();
-        const auto st = call(is, os);
-        if (!is.consume_called || !os.publish_called) throw std::runtime_error("processBulk did not consume / publish");
-        // blocks without a custom policy get their input tag forwarded by the runtime (the default
-        // TagPropagationPolicy: CoarseFrequencyCorrection, SyncwordWipeoff, CostasLoop rely on it)
-        constexpr bool custom = requires { Blk::tag_policy; };
-        if constexpr (!custom)
-            if (blk.input_tags_present() && (is.consumed > 0 || os.published > 0))
-                out.tags.push_back({ static_cast<ssize_t>(out.size), blk._mergedInputTag.map });
-        for (const auto& t : blk.out.published_tags)
-            out.tags.push_back({ static_cast<ssize_t>(out.size) + t.index, t.map });
-        in.rd += is.consumed;
-        out.size += os.published;
-        return st == gr::work::Status::OK && (is.consumed != 0 || os.published != 0);
-    }
-}
-template <typename Blk, typename TI, typename TO, typename Call>
-static void run(Blk& blk, Edge<TI>& in, Edge<TO>& out, size_t max_chunk, Call call)
-{
-    for (int guard = 0; guard < 1000000; ++guard)
-        if (!step(blk, in, out, max_chunk, call)) break;
-}
-
-static std::vector<c64> read_c64(const char* path)
-{
-    FILE* f = std::fopen(path, "rb");
-    if (!f) throw std::runtime_error(std::string("cannot read ") + path);
-    std::fseek(f, 0, SEEK_END);
-    const size_t n = static_cast<size_t>(std::ftell(f)) / sizeof(c64);
-    std::fseek(f, 0, SEEK_SET);
-    std::vector<c64> x(n);
-    if (std::fread(x.data(), sizeof(c64), n, f) != n) throw std::runtime_error("short read");
-    std::fclose(f);
-    return x;
-}
 
 static int chain(int argc, char** argv)
 {
@@ -162,29 +46,48 @@ static int chain(int argc, char** argv)
     norm = std::sqrt(norm);
     for (auto& t : rrc) t /= norm;
 
-    SyncwordDetection syncword_detection;
-    syncword_detection.rrc_taps = rrc;
-    syncword_detection.syncword = syncword;
-    syncword_detection.constellation = { { 1.0f, 0.0f }, { -1.0f, 0.0f } };
-    syncword_detection.min_freq_bin = -4;
-    syncword_detection.max_freq_bin = 4;
-    syncword_detection.power_threshold = 9.5f;
-    SyncwordDetectionFilter<> syncword_filter;
-    CoarseFrequencyCorrection<> freq_correction;
-    freq_correction.delay = (rrc.size() - 1) / 2 + sps;
-    const size_t pfb_arms = 32;
-    auto pfb = firdes::root_raised_cosine(static_cast<double>(pfb_arms) / norm, static_cast<double>(pfb_arms * sps), 1.0,
-                                          0.35, pfb_arms * sps * 11);
-    pfb.pop_back(); // packet_receiver.hpp:104-108
-    SymbolFilter<c64, c64, float> symbol_filter;
-    symbol_filter.taps = pfb;
-    symbol_filter.num_arms = pfb_arms;
-    symbol_filter.samples_per_symbol = sps;
-    symbol_filter.delay = pfb.size() / pfb_arms; // :112-114
-    SyncwordWipeoff<> syncword_wipeoff;
-    for (uint8_t b : syncword) syncword_wipeoff.syncword.push_back(b ? -1.0f : 1.0f);
-    CostasLoop<> costas_loop;
-    costas_loop.constellation = "QPSK"; // the front-end test feeds no constellation tags
+    // every block is created and configured as PacketReceiver's constructor does it: fg.emplaceBlock<T>(property_map)
+    // with the literal keys and value expressions of packet_receiver.hpp:76-127 (benchmark_syncword_detection.cpp:64-70
+    // uses the same six keys for the detector).  The stand-in's Graph assigns the settings BY NAME through the member
+    // lists the wrappers register with ENABLE_REFLECTION, and throws for a key a block does not have.
+    gr::stub::Graph fg;
+    const auto& rrc_taps = rrc;
+    const size_t samples_per_symbol = sps;
+    const int syncword_freq_bins = 4;
+    const float syncword_threshold = 9.5f;
+    const std::vector<c64> bpsk_constellation = { { 1.0f, 0.0f }, { -1.0f, 0.0f } };
+    auto& syncword_detection = fg.emplaceBlock<SyncwordDetection>({ { "rrc_taps", rrc_taps },
+                                                                     { "syncword", syncword },
+                                                                     { "constellation", bpsk_constellation },
+                                                                     { "min_freq_bin", -syncword_freq_bins },
+                                                                     { "max_freq_bin", syncword_freq_bins },
+                                                                     { "power_threshold", syncword_threshold } });
+    auto& syncword_filter = fg.emplaceBlock<SyncwordDetectionFilter<>>({ { "samples_per_symbol", samples_per_symbol } });
+    auto& freq_correction =
+        fg.emplaceBlock<CoarseFrequencyCorrection<>>({ { "delay", (rrc_taps.size() - 1) / 2 + samples_per_symbol } });
+    const size_t symbol_filter_pfb_arms = 32;
+    auto rrc_taps_pfb = firdes::root_raised_cosine(static_cast<double>(symbol_filter_pfb_arms) / static_cast<double>(norm),
+                                                   static_cast<double>(symbol_filter_pfb_arms * samples_per_symbol), 1.0,
+                                                   0.35, symbol_filter_pfb_arms * samples_per_symbol * 11U);
+    rrc_taps_pfb.pop_back(); // packet_receiver.hpp:104-108
+    auto& symbol_filter = fg.emplaceBlock<SymbolFilter<c64, c64, float>>({ { "taps", rrc_taps_pfb },
+                                                                           { "num_arms", symbol_filter_pfb_arms },
+                                                                           { "samples_per_symbol", samples_per_symbol },
+                                                                           { "delay", rrc_taps.size() - 1 } });
+    std::vector<float> syncword_bipolar;
+    for (auto b : syncword) syncword_bipolar.push_back(b ? -1.0f : 1.0f);
+    auto& syncword_wipeoff = fg.emplaceBlock<SyncwordWipeoff<>>({ { "syncword", syncword_bipolar } });
+    // the front-end test feeds no constellation tags: the loop runs the payload's constellation throughout
+    auto& costas_loop = fg.emplaceBlock<CostasLoop<>>({ { "constellation", "QPSK" } });
+    {   // a key the block does not have is an error, as in the runtime
+        bool thrown = false;
+        try {
+            fg.emplaceBlock<CoarseFrequencyCorrection<>>({ { "no_such_setting", 1 } });
+        } catch (const gr::exception&) {
+            thrown = true;
+        }
+        if (!thrown) throw std::runtime_error("emplaceBlock accepted an unknown setting");
+    }
     for (bool* ho : { &syncword_detection.host_output, &syncword_filter.host_output, &freq_correction.host_output,
                       &symbol_filter.host_output, &syncword_wipeoff.host_output })
         *ho = host_output; // internal edges; the last block always writes the host span
@@ -193,10 +96,8 @@ static int chain(int argc, char** argv)
     syncword_detection.start();
     syncword_filter.start();
     freq_correction.start();
-    symbol_filter.settingsChanged({}, {});
     symbol_filter.start();
     syncword_wipeoff.start();
-    costas_loop.settingsChanged({}, {});
 
     Edge<c64> e_in(x.size()), e_sd(x.size()), e_sdf(x.size()), e_cfc(x.size()), e_sym(x.size() / sps + 64),
         e_wipe(x.size() / sps + 64), e_out(x.size() / sps + 64);
@@ -254,25 +155,22 @@ static int blocks(int argc, char** argv)
     Edge<c64> e_in(x.size()), e_rot(x.size()), e_fir(4 * x.size() + 64), e_arb(8 * x.size() + 64);
     std::copy(x.begin(), x.end(), e_in.data.begin());
     e_in.size = x.size();
-    Rotator<> rot;
-    rot.phase_incr = 0.1f; // qa_rotator.cpp:20
+    gr::stub::Graph fg;
+    auto& rot = fg.emplaceBlock<Rotator<>>({ { "phase_incr", 0.1f } }); // qa_rotator.cpp:20
     rot.start();
     run(rot, e_in, e_rot, 5000, [&](auto& is, auto& os) { return rot.processBulk(is, os); });
-    InterpolatingFirFilter<c64, c64, float> fir;
-    fir.interpolation = 4;
-    fir.taps = firdes::root_raised_cosine(1.0, 4.0, 1.0, 0.35, 44);
-    fir.settingsChanged({}, {});
+    auto& fir = fg.emplaceBlock<InterpolatingFirFilter<c64, c64, float>>(
+        { { "interpolation", size_t{ 4 } }, { "taps", firdes::root_raised_cosine(1.0, 4.0, 1.0, 0.35, 44) } });
     run(fir, e_rot, e_fir, 3001, [&](auto& is, auto& os) { return fir.processBulk(is, os); });
-    PfbArbResampler<c64, c64, float, double> arb; // qa_pfb_arb_resampler.cpp:28-31
-    arb.rate = 1.1234;
+    std::vector<float> arb_taps(1280);
     {
         FILE* f = std::fopen(argv[4], "rb"); // the default taps (data/pfb_arb_taps.f32)
         if (!f) throw std::runtime_error("cannot read taps");
-        arb.taps.resize(1280);
-        if (std::fread(arb.taps.data(), 4, 1280, f) != 1280) throw std::runtime_error("short taps");
+        if (std::fread(arb_taps.data(), 4, 1280, f) != 1280) throw std::runtime_error("short taps");
         std::fclose(f);
     }
-    arb.settingsChanged({}, {});
+    auto& arb = fg.emplaceBlock<PfbArbResampler<c64, c64, float, double>>( // qa_pfb_arb_resampler.cpp:28-31
+        { { "rate", 1.1234 }, { "taps", arb_taps } });
     run(arb, e_fir, e_arb, 7001, [&](auto& is, auto& os) { return arb.processBulk(is, os); });
     dump(prefix + ".rot.c64", e_rot.data.data(), e_rot.size);
     dump(prefix + ".fir.c64", e_fir.data.data(), e_fir.size);

@@ -4,10 +4,25 @@
 // gnuradio4 is not installed.  It is NOT an oracle and NOT part of the product: it checks OUR header.
 // Written from the API surface the reference blocks use (syncword_detection.hpp:4-7,143-356;
 // symbol_filter.hpp:112-252; costas_loop.hpp:92-148), not from gnuradio4 sources.
+//
+// Checked in both directions (tests/test_gr4_blocks.py): the wrappers compile and run against it, and -- in the
+// build container, where /root/reference exists -- so do the reference's OWN block headers (rotator,
+// coarse_frequency_correction, symbol_filter, costas_loop, interpolating_fir_filter, pfb_arb_resampler,
+// syncword_wipeoff; tests/ref_headers_check.cpp), i.e. the surface declared here is the one the reference uses.
+// Settings by name: ENABLE_REFLECTION records the member list, gr::stub::Graph::emplaceBlock<T>(property_map)
+// initialises a block from a property_map exactly as the reference's flowgraphs do (packet_receiver.hpp:76-127).
 #pragma once
 #include <sys/types.h>
 
+#include <algorithm>
+#include <bit>
+#include <cassert>
+#include <cmath>
 #include <complex>
+#include <memory>
+#include <numbers>
+#include <numeric>
+#include <ranges>
 #include <concepts>
 #include <cstdint>
 #include <map>
@@ -37,7 +52,32 @@ T cast(const pmt& p)
 }
 } // namespace pmtv
 
+// std::views::repeat (C++23) is not in this image's libstdc++: the reference fills its history buffers with it
+// (symbol_filter.hpp:97, interpolating_fir_filter.hpp:67, pfb_arb_resampler.hpp:108)
+#if !defined(__cpp_lib_ranges_repeat)
+namespace std::ranges::views {
+struct gr4_stub_repeat_fn {
+    template <typename T>
+    std::vector<T> operator()(const T& v, size_t n) const
+    {
+        return std::vector<T>(n, v);
+    }
+};
+inline constexpr gr4_stub_repeat_fn repeat{};
+} // namespace std::ranges::views
+#endif
+
 namespace gr {
+namespace meta {
+template <size_t N>
+struct fixed_string {
+    char data[N]{};
+    constexpr fixed_string(const char (&s)[N]) { std::copy_n(s, N, data); }
+};
+} // namespace meta
+// `using Description = Doc<R""(...)"">;` inside every block
+template <meta::fixed_string>
+struct Doc {};
 
 struct exception : std::runtime_error {
     using std::runtime_error::runtime_error;
@@ -100,11 +140,13 @@ concept PublishableSpan = requires(S& s) {
 template <typename T, typename... Attr>
 struct PortIn {
     using value_type = T;
+    static constexpr bool is_async = (std::is_same_v<Attr, Async> || ... || false);
     size_t min_samples = 1, max_samples = static_cast<size_t>(-1);
 };
 template <typename T, typename... Attr>
 struct PortOut {
     using value_type = T;
+    static constexpr bool is_async = (std::is_same_v<Attr, Async> || ... || false);
     size_t min_samples = 1, max_samples = static_cast<size_t>(-1);
     // what the block published during the current processBulk(): offsets are relative to the out span
     std::vector<Tag> published_tags;
@@ -124,6 +166,116 @@ struct Block {
 
 } // namespace gr
 
-#define ENABLE_REFLECTION(...) static_assert(true)
-#define ENABLE_REFLECTION_FOR_TEMPLATE(...) static_assert(true)
+// ---- settings by name ------------------------------------------------------------------------------------------
+namespace gr::stub {
+template <typename M>
+concept PortLike = requires { typename M::value_type; } && requires(M m) { m.min_samples; };
+template <typename T>
+struct is_vector : std::false_type {};
+template <typename T, typename A>
+struct is_vector<std::vector<T, A>> : std::true_type {};
+
+// property_map value -> setting member, with the conversions pmtv allows (arithmetic <-> arithmetic, same vectors)
+template <typename M>
+void assign(M& member, const pmtv::pmt& v, const char* name)
+{
+    if constexpr (PortLike<M>) {
+        throw exception(std::string("'") + name + "' is a port, not a setting");
+    } else if constexpr (std::is_arithmetic_v<M>) {
+        member = pmtv::cast<M>(v);
+    } else if constexpr (std::is_same_v<M, std::string>) {
+        if (!std::holds_alternative<std::string>(v)) throw exception(std::string("setting '") + name + "' wants a string");
+        member = std::get<std::string>(v);
+    } else if constexpr (is_vector<M>::value) {
+        std::visit(
+            [&](const auto& src) {
+                using S = std::decay_t<decltype(src)>;
+                if constexpr (std::is_same_v<S, M>) {
+                    member = src;
+                } else if constexpr (is_vector<S>::value) {
+                    if constexpr (std::is_convertible_v<typename S::value_type, typename M::value_type> &&
+                                  std::is_arithmetic_v<typename S::value_type>)
+                        member.assign(src.begin(), src.end());
+                    else
+                        throw exception(std::string("setting '") + name + "': vector of another item type");
+                } else {
+                    throw exception(std::string("setting '") + name + "' wants a vector");
+                }
+            },
+            v);
+    } else {
+        throw exception(std::string("setting '") + name + "': type not supported by the test stand-in");
+    }
+}
+template <typename T>
+struct Reflect; // specialised by ENABLE_REFLECTION*: size_t apply(T&, const property_map&) -> settings assigned
+
+// what `fg.emplaceBlock<T>({ { "key", value }, ... })` does with the initial settings
+struct Graph {
+    std::vector<std::shared_ptr<void>> blocks;
+    template <typename T>
+    T& emplaceBlock(property_map settings = {})
+    {
+        auto p = std::make_shared<T>();
+        const size_t n = Reflect<T>::apply(*p, settings);
+        if (n != settings.size()) {
+            std::string unknown;
+            for (const auto& kv : settings) {
+                property_map one{ kv };
+                T probe;
+                if (Reflect<T>::apply(probe, one) == 0) unknown += " " + kv.first;
+            }
+            throw exception("emplaceBlock: no such setting:" + unknown);
+        }
+        if constexpr (requires { p->settingsChanged(settings, settings); }) p->settingsChanged({}, settings);
+        blocks.push_back(p);
+        return *p;
+    }
+};
+} // namespace gr::stub
+
+#define GR4_STUB_EXPAND(x) x
+#define GR4_STUB_FE_1(F, a) F(a)
+#define GR4_STUB_FE_2(F, a, ...) F(a) GR4_STUB_EXPAND(GR4_STUB_FE_1(F, __VA_ARGS__))
+#define GR4_STUB_FE_3(F, a, ...) F(a) GR4_STUB_EXPAND(GR4_STUB_FE_2(F, __VA_ARGS__))
+#define GR4_STUB_FE_4(F, a, ...) F(a) GR4_STUB_EXPAND(GR4_STUB_FE_3(F, __VA_ARGS__))
+#define GR4_STUB_FE_5(F, a, ...) F(a) GR4_STUB_EXPAND(GR4_STUB_FE_4(F, __VA_ARGS__))
+#define GR4_STUB_FE_6(F, a, ...) F(a) GR4_STUB_EXPAND(GR4_STUB_FE_5(F, __VA_ARGS__))
+#define GR4_STUB_FE_7(F, a, ...) F(a) GR4_STUB_EXPAND(GR4_STUB_FE_6(F, __VA_ARGS__))
+#define GR4_STUB_FE_8(F, a, ...) F(a) GR4_STUB_EXPAND(GR4_STUB_FE_7(F, __VA_ARGS__))
+#define GR4_STUB_FE_9(F, a, ...) F(a) GR4_STUB_EXPAND(GR4_STUB_FE_8(F, __VA_ARGS__))
+#define GR4_STUB_FE_10(F, a, ...) F(a) GR4_STUB_EXPAND(GR4_STUB_FE_9(F, __VA_ARGS__))
+#define GR4_STUB_FE_11(F, a, ...) F(a) GR4_STUB_EXPAND(GR4_STUB_FE_10(F, __VA_ARGS__))
+#define GR4_STUB_FE_12(F, a, ...) F(a) GR4_STUB_EXPAND(GR4_STUB_FE_11(F, __VA_ARGS__))
+#define GR4_STUB_FE_13(F, a, ...) F(a) GR4_STUB_EXPAND(GR4_STUB_FE_12(F, __VA_ARGS__))
+#define GR4_STUB_FE_14(F, a, ...) F(a) GR4_STUB_EXPAND(GR4_STUB_FE_13(F, __VA_ARGS__))
+#define GR4_STUB_FE_15(F, a, ...) F(a) GR4_STUB_EXPAND(GR4_STUB_FE_14(F, __VA_ARGS__))
+#define GR4_STUB_FE_16(F, a, ...) F(a) GR4_STUB_EXPAND(GR4_STUB_FE_15(F, __VA_ARGS__))
+#define GR4_STUB_PICK(_1, _2, _3, _4, _5, _6, _7, _8, _9, _10, _11, _12, _13, _14, _15, _16, N, ...) N
+#define GR4_STUB_FOR_EACH(F, ...)                                                                                    \
+    GR4_STUB_EXPAND(GR4_STUB_PICK(__VA_ARGS__, GR4_STUB_FE_16, GR4_STUB_FE_15, GR4_STUB_FE_14, GR4_STUB_FE_13,        \
+                                  GR4_STUB_FE_12, GR4_STUB_FE_11, GR4_STUB_FE_10, GR4_STUB_FE_9, GR4_STUB_FE_8,       \
+                                  GR4_STUB_FE_7, GR4_STUB_FE_6, GR4_STUB_FE_5, GR4_STUB_FE_4, GR4_STUB_FE_3,          \
+                                  GR4_STUB_FE_2, GR4_STUB_FE_1)(F, __VA_ARGS__))
+#define GR4_STUB_APPLY_ONE(member)                                                                                   \
+    if (auto it_ = m_.find(#member); it_ != m_.end()) {                                                              \
+        ::gr::stub::assign(b_.member, it_->second, #member);                                                         \
+        ++n_;                                                                                                        \
+    }
+#define GR4_STUB_REFLECT_BODY(...)                                                                                   \
+    {                                                                                                                \
+        size_t n_ = 0;                                                                                               \
+        GR4_STUB_FOR_EACH(GR4_STUB_APPLY_ONE, __VA_ARGS__)                                                           \
+        return n_;                                                                                                   \
+    }
+#define ENABLE_REFLECTION(Type, ...)                                                                                 \
+    template <>                                                                                                      \
+    struct gr::stub::Reflect<Type> {                                                                                 \
+        static size_t apply(Type& b_, const ::gr::property_map& m_) GR4_STUB_REFLECT_BODY(__VA_ARGS__)                \
+    }
+#define ENABLE_REFLECTION_FOR_TEMPLATE(Tmpl, ...)                                                                    \
+    template <typename... Ts_>                                                                                       \
+    struct gr::stub::Reflect<Tmpl<Ts_...>> {                                                                         \
+        static size_t apply(Tmpl<Ts_...>& b_, const ::gr::property_map& m_) GR4_STUB_REFLECT_BODY(__VA_ARGS__)        \
+    }
 #define ENABLE_REFLECTION_FOR_TEMPLATE_FULL(...) static_assert(true)

@@ -144,3 +144,107 @@ def test_rotator_fir_resampler_wrappers(tmp_path):
     ref_arb, _ = orc.pfb_arb_resampler(ref_fir, 1.1234, np.fromfile(taps_file, dtype=np.float32), 32, True)
     n = min(arb.size, ref_arb.size)
     assert abs(arb.size - ref_arb.size) <= 2 and np.array_equal(arb[:n].view(np.uint64), ref_arb[:n].view(np.uint64))
+
+
+# ------------------------------------------------------------------ the stand-in checked in the other direction
+REFERENCE_INCLUDE = "/root/reference/blocks/include"
+
+
+@pytest.fixture(scope="module")
+def ref_check(tmp_path_factory):
+    """tests/ref_headers_check.cpp: the reference's OWN block headers compiled against tests/gr4_stub (only where
+    /root/reference exists: the build container).  That it compiles is the first half of the check: the stand-in
+    declares the API surface the reference uses."""
+    if not os.path.isdir(REFERENCE_INCLUDE):
+        pytest.skip("the reference tree is not on this machine")
+    exe = tmp_path_factory.mktemp("refcheck") / "ref_headers_check"
+    subprocess.check_call(["g++", "-std=c++23", "-O2", "-ffp-contract=off", "-I", os.path.join(ROOT, "tests", "gr4_stub"),
+                           "-I", REFERENCE_INCLUDE, "-I", os.path.join(ROOT, "tests"), "-o", str(exe),
+                           os.path.join(ROOT, "tests", "ref_headers_check.cpp")])
+    return str(exe)
+
+
+def _run_ref(exe, tmp_path, case, x, tags=None, chunk=4000):
+    xin = tmp_path / f"{case}.in.c64"
+    np.ascontiguousarray(x, dtype=np.complex64).tofile(xin)
+    tpath = "-"
+    if tags is not None:
+        tpath = str(tmp_path / f"{case}.tags.bin")
+        np.ascontiguousarray(tags, dtype=orc.TAG_DTYPE).tofile(tpath)
+    prefix = str(tmp_path / case)
+    subprocess.check_call([exe, case, str(xin), tpath, prefix, str(chunk)], stdout=subprocess.DEVNULL)
+    out = np.fromfile(prefix + ".out.c64", dtype=np.complex64)
+    consumed, produced = np.fromfile(prefix + ".counts.bin", dtype=np.uint64)
+    return out, np.fromfile(prefix + ".out_tags.bin", dtype=REC), int(consumed), int(produced)
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint64)
+
+
+def _detection_tags(idx, seed):
+    rng = np.random.default_rng(seed)
+    tags = np.zeros(len(idx), dtype=orc.TAG_DTYPE)
+    tags["index"] = idx
+    tags["amplitude"] = rng.uniform(0.5, 2.0, len(idx))
+    tags["phase"] = rng.uniform(-3, 3, len(idx))
+    tags["freq"] = rng.uniform(-0.03, 0.03, len(idx)).astype(np.float32)
+    tags["time_est"] = rng.uniform(-0.5, 0.5, len(idx))
+    tags["flags"] = 1
+    return tags
+
+
+def test_reference_headers_on_the_stub_agree_with_the_oracle(ref_check, tmp_path):
+    """The reference's rotator / coarse_frequency_correction / symbol_filter / costas_loop / interpolating_fir_filter /
+    pfb_arb_resampler / syncword_wipeoff headers, driven through processBulk() on the stand-in, against the oracle's
+    restatement of the same blocks, bit for bit -- on the paths the reference's own qa_*.cpp do not cover (tags into
+    SymbolFilter, CFC with delay = 26, a float-rate resampler, phase tags into the Costas loop).  Earns no parity
+    credit (the API under the blocks is a stand-in); it catches restatement slips."""
+    rng = np.random.default_rng(77)
+    n = 30000
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    for chunk in (4000, 997):
+        # Rotator (processOne)
+        y, _, c, p = _run_ref(ref_check, tmp_path, "rotator", x, chunk=chunk)
+        assert c == p == n and np.array_equal(_bits(y), _bits(orc.rotator(x, np.float32(0.1))))
+        # CoarseFrequencyCorrection, delay 26, several set_freq tags incl. two closer than the delay
+        tags = _detection_tags([0, 5000, 5010, 12000, 20001, 29990], 1)
+        y, t, c, p = _run_ref(ref_check, tmp_path, "cfc", x, tags, chunk)
+        want = orc.coarse_frequency_correction(x, tags["index"], tags["freq"], delay=26)
+        assert c == p == n and np.array_equal(_bits(y), _bits(want))
+        assert np.array_equal(t["index"], tags["index"])                    # forwarded by the default policy
+        # SymbolFilter with tags: every clock-phase case of symbol_filter.hpp:130-206
+        idx = [0, 1001, 2002, 2500, 3000, 3003, 4444, 5557, 7000, 7001, 9998, 20000]
+        tags = _detection_tags(idx, 2)
+        tags["time_est"] = [0.1, -0.2, 0.49, -0.5, 0.0, -0.01, 0.3, -0.3, 0.5, 0.2, -0.45, 0.25]
+        tags["flags"][4] = 2                                                # not a detection: only re-timed
+        rrc, norm = orc.unit_norm_rrc(4)
+        pfb = orc.rrc_taps(32.0 / float(norm), 128.0, 1.0, 0.35, 32 * 4 * 11)[:-1]
+        y, t, c, p = _run_ref(ref_check, tmp_path, "symbol_filter", x, tags, chunk)
+        want, want_tags, want_cons = orc.symbol_filter(x, pfb, 32, 4, 44, tags=tags)
+        assert c == want_cons and p == want.size and np.array_equal(_bits(y), _bits(want))
+        assert np.array_equal(t["index"], want_tags["index"])
+        det = want_tags["flags"] == 1
+        for k in ("amplitude", "phase", "time_est"):
+            assert np.array_equal(t[k][det], want_tags[k][det]), k
+        assert np.array_equal(t["freq"][det], want_tags["freq"][det])
+        # CostasLoop, QPSK, phase tags
+        tags = _detection_tags([0, 3000, 3001, 17000], 3)
+        y, _, c, p = _run_ref(ref_check, tmp_path, "costas", x, tags, chunk)
+        want = orc.costas_loop(x, "QPSK", 0.01, tags["index"], tags["phase"])
+        assert c == p == n and np.array_equal(_bits(y), _bits(want))
+        # InterpolatingFirFilter x4 with the 45-tap RRC
+        y, _, c, p = _run_ref(ref_check, tmp_path, "interp_fir", x[:8000], chunk=chunk)
+        want = orc.interpolating_fir(x[:8000], 4, orc.rrc_taps(1.0, 4.0, 1.0, 0.35, 44))
+        assert c == 8000 and np.array_equal(_bits(y), _bits(want))
+        # PfbArbResampler: float rate 1 + 1.2e-6 (TRate = float) and 1.1234 (TRate = double)
+        pkg_taps = np.fromfile(os.path.join(ROOT, "gr4-packet-modem_amd", "data", "pfb_arb_taps.f32"), dtype=np.float32)
+        for case, rate, dbl in (("arb_float", float(np.float32(1.0) + np.float32(1.2e-6)), False), ("arb_double", 1.1234, True)):
+            y, _, c, p = _run_ref(ref_check, tmp_path, case, x, chunk=chunk)
+            want, wcons = orc.pfb_arb_resampler(x, rate, pkg_taps, 32, rate_is_double=dbl, out_cap=8 * n + 4096)
+            assert c == wcons and p == want.size and np.array_equal(_bits(y), _bits(want)), case
+        # SyncwordWipeoff
+        sw = np.array([(-1.0 if (i * 7 % 3) else 1.0) for i in range(64)], dtype=np.float32)
+        tags = _detection_tags([10, 500, 6000, 29000], 4)
+        y, _, c, p = _run_ref(ref_check, tmp_path, "wipeoff", x, tags, chunk)
+        assert c == p == n and np.array_equal(_bits(y), _bits(orc.syncword_wipeoff(x, sw, tags["index"])))
