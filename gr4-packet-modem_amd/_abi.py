@@ -165,7 +165,14 @@ class PacketReceiverResult(C.Structure):
                 ("header_messages", C.c_void_p), ("packet_type", C.c_void_p), ("n_header_messages", C.c_size_t),
                 ("header_mismatches", C.c_size_t), ("payload_llr", C.c_void_p), ("n_payload_llr", C.c_size_t),
                 ("payload_tags", C.c_void_p), ("n_payload_tags", C.c_size_t), ("packets", C.c_void_p),
-                ("n_packet_bytes", C.c_size_t), ("packet_lengths", C.c_void_p), ("n_packets", C.c_size_t)]
+                ("n_packet_bytes", C.c_size_t), ("packet_lengths", C.c_void_p), ("n_packets", C.c_size_t),
+                ("pdu_symbols", C.c_void_p), ("n_pdu_symbols", C.c_size_t), ("symbol_pdus", C.c_void_p),
+                ("n_symbol_pdus", C.c_size_t)]
+
+
+SYMBOL_PDU_DTYPE = np.dtype([("offset", "<u8"), ("length", "<u8"), ("kind", "<i4"), ("first", "<i4"), ("last", "<i4"),
+                             ("pad", "<i4")])
+SYMBOL_PDU_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t)
 
 
 class PfbArbParams(C.Structure):
@@ -176,6 +183,7 @@ class PfbArbParams(C.Structure):
 # every symbol include/gr4pm_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
     "gr4pm_last_error", "gr4pm_version", "gr4pm_device_count", "gr4pm_set_deferred_sync", "gr4pm_sincosf",
+    "gr4pm_packet_receiver_set_symbol_pdu_callback",
     "gr4pm_syncword_detection_create", "gr4pm_syncword_detection_destroy",
     "gr4pm_syncword_detection_reset", "gr4pm_syncword_detection_syncword_samples_size",
     "gr4pm_syncword_detection_self_corr", "gr4pm_syncword_detection_items_consumed",
@@ -374,6 +382,7 @@ def lib():
     L.gr4pm_multichannel_receiver_in_flight.argtypes = [vp]
     L.gr4pm_packet_receiver_collect.argtypes = [vp, C.POINTER(PacketReceiverResult)]
     L.gr4pm_packet_receiver_inflight.argtypes = [vp]
+    L.gr4pm_packet_receiver_set_symbol_pdu_callback.argtypes = [vp, vp, vp]
     L.gr4pm_packet_receiver_inflight.restype = sz
     L.gr4pm_sincosf.argtypes = [vp, sz, vp, vp]
     L.gr4pm_firdes_root_raised_cosine.argtypes = [C.c_double] * 4 + [sz, vp]

@@ -1690,6 +1690,11 @@ class NativePacketReceiver:
                "detector_tags": records(r.detector_tags, r.n_detector_tags, TAG_DTYPE),
                "accepted": records(r.accepted, r.n_detector_tags, np.dtype(np.uint8)).astype(bool)}
         if self.soft_bits:
+            torch = _torch()
+            pdu_sym = torch.empty(r.n_pdu_symbols, dtype=torch.complex64, device=sym.device)
+            if r.n_pdu_symbols:  # the library's buffer is recycled: take a copy
+                check(_hip_memcpy_d2d(pdu_sym.data_ptr(), r.pdu_symbols, 8 * r.n_pdu_symbols), "pdu_symbols")
+            res.update(pdu_symbols=pdu_sym, symbol_pdus=records(r.symbol_pdus, r.n_symbol_pdus, _abi.SYMBOL_PDU_DTYPE))
             res.update(llr=llr[: r.n_llr], llr_tags=records(r.llr_tags, r.n_llr_tags, PACKET_TAG_DTYPE),
                        packet_tags=records(r.packet_tags, r.n_packet_tags, PACKET_TAG_DTYPE),
                        ignored_syncwords=r.ignored_syncwords)
@@ -1706,6 +1711,20 @@ class NativePacketReceiver:
                        packet_lengths=records(r.packet_lengths, r.n_packets, np.dtype(np.uint64)))
             res["crc_ok"] = res["packet_lengths"] > 0
         return res
+
+    def set_symbol_pdu_callback(self, fn):
+        """the symbol PDU tap (packet_receiver.hpp:159-189): fn(kind, symbols) is called from collect() once per
+        complete header (kind 0, 128 symbols) / payload (kind 1) PDU with a numpy copy of its symbols; None removes it"""
+        if fn is None:
+            self._pdu_cb = None
+            check(lib().gr4pm_packet_receiver_set_symbol_pdu_callback(self._h, None, None), "set_symbol_pdu_callback")
+            return
+
+        def tramp(user, kind, ptr, n):
+            buf = (C.c_char * (8 * n)).from_address(ptr)
+            fn(int(kind), np.frombuffer(buf, dtype=np.complex64, count=n).copy())
+        self._pdu_cb = _abi.SYMBOL_PDU_FN(tramp)  # keep the trampoline alive
+        check(lib().gr4pm_packet_receiver_set_symbol_pdu_callback(self._h, self._pdu_cb, None), "set_symbol_pdu_callback")
 
     def process_bulk(self, x, header_fn=None, tags_cap=None, history=None, next_x=None):
         """same calling convention as PacketReceiver.process_bulk (header_fn: None or a constant

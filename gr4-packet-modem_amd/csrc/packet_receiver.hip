@@ -69,6 +69,9 @@ struct Slot {
     size_t n_payload_llr = 0;
     std::vector<gr4pm_packet_tag> payload_tags;
     size_t n_payload_tags = 0;
+    // symbol PDU tap (soft_bits): SyncwordRemove's output is s.data[0 .. n_data), cut into header / payload pieces
+    size_t n_data = 0;
+    std::vector<gr4pm_symbol_pdu> pdus;
 };
 
 template <typename T>
@@ -238,6 +241,15 @@ struct gr4pm_packet_receiver {
     gr4pm_payload_metadata_insert* pmi = nullptr;
     gr4pm_syncword_remove* remove = nullptr;
     gr4pm_constellation_llr_decoder* llr = nullptr;
+    // HeaderPayloadSplit<c64> of the symbol tap (header_payload_split.hpp:30-45): state carried across batches
+    struct {
+        bool in_payload = false;
+        uint64_t position = 0, payload_items = 0;
+    } tap;
+    gr4pm_symbol_pdu_fn pdu_fn = nullptr;
+    void* pdu_user = nullptr;
+    std::vector<gr4pm_c64> pdu_host, pdu_acc[2];
+    gr4pm_status split_symbol_pdus(Slot& s, size_t n_data, size_t n_dt);
     uint64_t hist = 0;
     std::deque<gr4pm_header_msg> hdr_fifo; // gate -> PayloadMetadataInsert (stage 1 -> 2, in the slot)
     // ---- decode_headers: pass A (stage 1 thread) ----
@@ -446,6 +458,59 @@ void gr4pm_packet_receiver::stage2(Slot& s)
     s.n_symbols = produced; // SyncwordRemove and the LLR decoder follow in stage 3
 }
 
+// The symbol tap's HeaderPayloadSplit<c64> (packet_receiver.hpp:159-162; header_payload_split.hpp:46-135, header_size
+// 128, payload_length_key "payload_symbols"), replayed over the tags of SyncwordRemove's output: the runtime presents a
+// tag at the head of a chunk, so the stream is walked chunk by chunk between tags.  No items move: the PDUs are spans of
+// s.data (TaggedStreamToPdu, :163-164, collects exactly those spans).
+gr4pm_status gr4pm_packet_receiver::split_symbol_pdus(Slot& s, size_t n_data, size_t n_dt)
+{
+    constexpr uint64_t header_size = 128;
+    s.n_data = n_data;
+    s.pdus.clear();
+    size_t ti = 0;
+    uint64_t pos = 0;
+    while (pos < n_data) {
+        while (ti < n_dt && s.data_tags[ti].index < pos) ++ti; // (tags are ascending)
+        while (ti < n_dt && s.data_tags[ti].index == pos) {
+            const gr4pm_packet_tag& t = s.data_tags[ti++];
+            if (t.kind == GR4PM_PKT_PAYLOAD) { // :70-82
+                if (tap.in_payload || tap.position != header_size) {
+                    set_error("symbol tap: unexpected payload_symbols tag at symbol %llu", static_cast<unsigned long long>(pos));
+                    return GR4PM_ERR_INVALID;
+                }
+                tap.in_payload = true;
+                tap.position = 0;
+                tap.payload_items = t.payload_symbols;
+            }
+        }
+        const uint64_t chunk_end = ti < n_dt ? std::min<uint64_t>(s.data_tags[ti].index, n_data) : n_data;
+        if (!tap.in_payload && tap.position == header_size) tap.position = 0; // :90-95: the header did not decode
+        const uint64_t want = tap.in_payload ? tap.payload_items - tap.position : header_size - tap.position;
+        const uint64_t m = std::min(chunk_end - pos, want);
+        gr4pm_symbol_pdu pc{};
+        pc.offset = pos;
+        pc.length = m;
+        pc.kind = tap.in_payload ? 1 : 0;
+        pc.first = tap.position == 0;
+        tap.position += m;
+        pc.last = tap.position >= (tap.in_payload ? tap.payload_items : header_size);
+        if (!s.pdus.empty() && s.pdus.back().kind == pc.kind && !s.pdus.back().last && !pc.first &&
+            s.pdus.back().offset + s.pdus.back().length == pc.offset) {
+            s.pdus.back().length += m; // pieces of one PDU separated only by a tag
+            s.pdus.back().last = pc.last;
+        } else if (m > 0 || pc.last) {
+            s.pdus.push_back(pc);
+        }
+        pos += m;
+        if (tap.in_payload && tap.position >= tap.payload_items) { // :123-126
+            tap.in_payload = false;
+            tap.position = 0;
+        }
+        if (m == 0 && chunk_end == pos && ti >= n_dt) break;
+    }
+    return GR4PM_OK;
+}
+
 // soft_bits without decode_headers: SyncwordRemove + ConstellationLLRDecoder as stage 3 (stage 2,
 // the tag-driven Costas loop behind PayloadMetadataInsert, is the slowest one of this mode)
 gr4pm_status gr4pm_packet_receiver::stage3_soft(Slot& s)
@@ -457,7 +522,7 @@ gr4pm_status gr4pm_packet_receiver::stage3_soft(Slot& s)
                                                       n_dt, s.llr_tags.data(), s.llr_tags.size(), &n_lt, &n_llr));
     s.n_llr_tags = n_lt;
     s.n_llr = n_llr;
-    return GR4PM_OK;
+    return split_symbol_pdus(s, n_data, n_dt);
 }
 
 // pass A (see blocks.py PacketReceiver._predecode, which this mirrors): the header of every detection
@@ -720,6 +785,7 @@ gr4pm_status gr4pm_packet_receiver::stage2_decode(Slot& s)
     T2_MARK("llr");
     s.n_llr_tags = n_lt;
     s.n_llr = n_llr;
+    GR4PM_TRY(split_symbol_pdus(s, n_data, n_dt));
     s.opened.clear();
     for (size_t i = 0, j = 0; i < n_pt; ++i)
         if (s.packet_tags[i].kind == GR4PM_PKT_SYNCWORD) { // a packet PayloadMetadataInsert opened: both lists ascend
@@ -1102,6 +1168,8 @@ gr4pm_status gr4pm_packet_receiver_submit(gr4pm_packet_receiver* h, const gr4pm_
     s.status = GR4PM_OK;
     s.error[0] = 0;
     s.consumed = s.n_symbols = s.n_llr = s.n_det = s.n_tags = s.n_sym_tags = s.n_packet_tags = s.n_llr_tags = 0;
+    s.n_data = 0;
+    s.pdus.clear();
     CLK_GOT(h->clk[0]);
     h->stage0(s, next_in, next_n);
     CLK_DONE(h->clk[0]);
@@ -1172,8 +1240,39 @@ gr4pm_status gr4pm_packet_receiver_collect(gr4pm_packet_receiver* h, gr4pm_packe
     r->n_packet_bytes = s.n_packet_bytes;
     r->packet_lengths = s.packet_lengths.data();
     r->n_packets = s.packet_lengths.size();
+    r->pdu_symbols = s.data.p;
+    r->n_pdu_symbols = s.n_data;
+    r->symbol_pdus = s.pdus.data();
+    r->n_symbol_pdus = s.pdus.size();
     if (s.status != GR4PM_OK) set_error("%s", s.error);
+    if (s.status == GR4PM_OK && h->pdu_fn && s.n_data) {
+        // the tap's sink side: one copy of the batch's symbols to the host, then one call per complete PDU
+        h->pdu_host.resize(s.n_data);
+        GR4PM_HIP_TRY(hipMemcpy(h->pdu_host.data(), s.data.p, s.n_data * sizeof(gr4pm_c64), hipMemcpyDeviceToHost));
+        for (const auto& pc : s.pdus) {
+            auto& acc = h->pdu_acc[pc.kind];
+            if (pc.first) acc.clear();
+            acc.insert(acc.end(), h->pdu_host.begin() + static_cast<ptrdiff_t>(pc.offset),
+                       h->pdu_host.begin() + static_cast<ptrdiff_t>(pc.offset + pc.length));
+            if (pc.last) {
+                h->pdu_fn(h->pdu_user, pc.kind, acc.data(), acc.size());
+                acc.clear();
+            }
+        }
+    }
     return s.status;
+}
+
+gr4pm_status gr4pm_packet_receiver_set_symbol_pdu_callback(gr4pm_packet_receiver* h, gr4pm_symbol_pdu_fn fn, void* user)
+{
+    if (!h) return GR4PM_ERR_INVALID;
+    if (fn && !h->p.soft_bits) {
+        set_error("the symbol PDU tap hangs off SyncwordRemove: soft_bits receivers only");
+        return GR4PM_ERR_INVALID;
+    }
+    h->pdu_fn = fn;
+    h->pdu_user = user;
+    return GR4PM_OK;
 }
 
 } // extern "C"

@@ -624,6 +624,23 @@ gr4pm_status gr4pm_crc_check_process(gr4pm_crc_check* h, const uint8_t* in, cons
  * The parsed_header feedback is a constant packet_length per submit (0 = every header invalid),
  * or with decode_headers the header decode loop on the device.
  * ================================================================================== */
+/* The symbol PDU tap of packet_receiver.hpp:159-189 (`zmq_output`): SyncwordRemove's output ->
+ * HeaderPayloadSplit<c64>{ header_size 128, payload_length_key "payload_symbols" } -> TaggedStreamToPdu ->
+ * ZmqPduPubSink on tcp://*:5000 (headers) / :5001 (payloads).  The split (header_payload_split.hpp:46-135) is done by
+ * the receiver: every batch's post-SyncwordRemove symbols are cut into header PDUs (128 symbols) and payload PDUs
+ * ("payload_symbols" symbols behind a parsed header); a PDU that crosses a batch boundary appears as a piece with
+ * `last == 0` and continues in the next batch with `first == 0`.  With a callback registered, collect() copies the
+ * batch's symbols to the host once and calls it once per COMPLETE PDU, in stream order, from the collecting thread:
+ * the place where a caller publishes them (INTEGRATION.md shows the ZeroMQ binding; libzmq is not in this image). */
+typedef struct {
+    uint64_t offset;  /* first symbol of the piece inside pdu_symbols */
+    uint64_t length;  /* symbols of the piece in this batch */
+    int32_t kind;     /* 0 header, 1 payload */
+    int32_t first;    /* the PDU starts with this piece */
+    int32_t last;     /* the PDU ends with this piece */
+    int32_t pad;
+} gr4pm_symbol_pdu;
+typedef void (*gr4pm_symbol_pdu_fn)(void* user, int kind, const gr4pm_c64* symbols_host, size_t n_symbols);
 typedef struct gr4pm_packet_receiver gr4pm_packet_receiver;
 typedef struct {
     size_t samples_per_symbol; /* packet_receiver.hpp:49 */
@@ -670,6 +687,11 @@ typedef struct {
     size_t n_packet_bytes;
     const uint64_t* packet_lengths;     /* per finished packet: bytes delivered, 0 = CRC failure */
     size_t n_packets;
+    /* soft_bits: the symbol PDU tap (below) */
+    const gr4pm_c64* pdu_symbols;       /* device: SyncwordRemove's output of this batch (header + payload symbols) */
+    size_t n_pdu_symbols;
+    const gr4pm_symbol_pdu* symbol_pdus; /* host: the pieces of header / payload PDUs inside pdu_symbols, in order */
+    size_t n_symbol_pdus;
 } gr4pm_packet_receiver_result;
 gr4pm_status gr4pm_packet_receiver_create(const gr4pm_packet_receiver_params* params,
                                           gr4pm_packet_receiver** out);
@@ -694,6 +716,8 @@ gr4pm_status gr4pm_packet_receiver_announce(gr4pm_packet_receiver* h, const gr4p
 /* waits for the oldest batch; returns its status (the error text of a failed stage included) */
 gr4pm_status gr4pm_packet_receiver_collect(gr4pm_packet_receiver* h, gr4pm_packet_receiver_result* result);
 size_t gr4pm_packet_receiver_inflight(const gr4pm_packet_receiver* h);
+/* soft_bits receivers: fn == NULL removes the callback */
+gr4pm_status gr4pm_packet_receiver_set_symbol_pdu_callback(gr4pm_packet_receiver* h, gr4pm_symbol_pdu_fn fn, void* user);
 
 /* gr4pm_multichannel_receiver: BASELINE configs[2] -- n_channels independent receive chains on one
  * GPU (front-end mode of gr4pm_packet_receiver, channel by channel).  One batched

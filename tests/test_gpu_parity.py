@@ -2112,6 +2112,91 @@ def test_native_packet_receiver_equals_python_composition(pkg, pipelined, soft_b
     assert np.array_equal(pkg.SYNCWORD, np.unpackbits(np.frombuffer(bytes.fromhex("034776C7272895B0"), dtype=np.uint8)))
 
 
+def test_native_packet_receiver_symbol_pdu_tap(pkg):
+    """packet_receiver.hpp:159-189 (zmq_output): SyncwordRemove's symbols -> HeaderPayloadSplit<c64>{128,
+    "payload_symbols"} -> TaggedStreamToPdu -> PUB sinks.  The receiver lists the PDUs of every batch and, with a
+    callback, delivers each complete one on the host.  Checked three ways: (1) against header_payload_split.hpp:46-135
+    restated here over the packet tags (state carried across batches), (2) against the LLRs of the same symbols
+    (constellation_llr_decoder.hpp: QPSK LLR pair = scale * (re, im)), (3) callback deliveries = the listed PDUs,
+    PDUs that cross a batch boundary included."""
+    H, n = 1537, 40000
+    payload_len = 120
+    x, _, _ = _tx_packets(np.random.default_rng(5), [payload_len] * 9, [300, 500, 420, 610, 350, 800, 333, 450, 700])
+    x = np.concatenate([x, np.zeros(3 * n, np.complex64)])[: 3 * n]
+    x = (x + sig.awgn(x.size, 0.05, 9)).astype(np.complex64)
+    ring = torch.zeros(2 + H + 3 * n, dtype=torch.complex64, device="cuda")
+    ring[2 + H:] = dev(x)
+    nat = pkg.NativePacketReceiver(max_items=n, pipelined=True, soft_bits=True)
+    delivered = []
+    nat.set_symbol_pdu_callback(lambda kind, sym: delivered.append((kind, sym)))
+    got = []
+    for k in range(3):
+        lo = 2 + H + k * n
+        r = nat.process_bulk(ring[lo:lo + n], payload_len, history=ring[lo - H:lo])
+        if r is not None:
+            got.append(r)
+    got += nat.flush()
+    assert len(got) == 3
+    # (1) the split restated: position counting, payload tag exactly at the end of a header
+    in_payload, position, payload_items = False, 0, 0
+    listed = []  # (kind, symbols) of complete PDUs, assembled from the per-batch pieces
+    acc = {0: [], 1: []}
+    n_hdr = n_pay = 0
+    for r in got:
+        sym = host(r["pdu_symbols"])
+        llr = r["llr"].cpu().numpy()
+        assert llr.size == 2 * sym.size
+        scale = llr[0] / sym[0].real if sym.size else 1.0
+        assert np.allclose(llr[0::2], scale * sym.real, rtol=1e-6) and np.allclose(llr[1::2], scale * sym.imag, rtol=1e-6)  # (2)
+        tags = r["llr_tags"]  # same tags, at 2 LLRs per symbol
+        pay_at = {int(t["index"]) // 2: int(t["payload_symbols"]) for t in tags if t["kind"] == 3}
+        pieces, pos = [], 0
+        while pos < sym.size:
+            if pos in pay_at:
+                assert not in_payload and position == 128
+                in_payload, position, payload_items = True, 0, pay_at[pos]
+            nxt = min([q for q in pay_at if q > pos] + [sym.size])
+            if not in_payload and position == 128:
+                position = 0
+            want = (payload_items if in_payload else 128) - position
+            m = min(nxt - pos, want)
+            first = position == 0
+            position += m
+            last = position >= (payload_items if in_payload else 128)
+            pieces.append((pos, m, 1 if in_payload else 0, first, last))
+            pos += m
+            if in_payload and position >= payload_items:
+                in_payload, position = False, 0
+        merged = []
+        for pc in pieces:  # pieces of one PDU separated only by a tag
+            if merged and merged[-1][2] == pc[2] and not merged[-1][4] and not pc[3] and merged[-1][0] + merged[-1][1] == pc[0]:
+                merged[-1] = (merged[-1][0], merged[-1][1] + pc[1], pc[2], merged[-1][3], pc[4])
+            else:
+                merged.append(pc)
+        pd = r["symbol_pdus"]
+        assert [(int(p["offset"]), int(p["length"]), int(p["kind"]), bool(p["first"]), bool(p["last"])) for p in pd] == \
+            [(a, b, c, bool(d), bool(e)) for a, b, c, d, e in merged]
+        for p in pd:
+            k = int(p["kind"])
+            if p["first"]:
+                acc[k] = []
+            acc[k].append(sym[int(p["offset"]):int(p["offset"] + p["length"])])
+            if p["last"]:
+                listed.append((k, np.concatenate(acc[k])))
+                n_hdr += k == 0
+                n_pay += k == 1
+    assert n_hdr >= 8 and n_pay >= 8
+    assert all(s.size == 128 for k, s in listed if k == 0)
+    assert all(s.size == (payload_len + 4) * 4 for k, s in listed if k == 1)   # payload + CRC-32, QPSK: 4 symbols per byte
+    # (3) the callback saw exactly the complete PDUs, in order
+    assert len(delivered) == len(listed)
+    for (k1, s1), (k2, s2) in zip(delivered, listed):
+        assert k1 == k2 and np.array_equal(bits(s1), bits(s2))
+    nat.set_symbol_pdu_callback(None)
+    with pytest.raises(pkg.Gr4pmError, match="soft_bits"):
+        pkg.NativePacketReceiver(max_items=n).set_symbol_pdu_callback(lambda k, s: None)
+
+
 @pytest.mark.parametrize("soft_bits", [False, True])
 def test_native_packet_receiver_many_batches_pipelined_equals_sequential(pkg, soft_bits):
     """every stage of the pipelined receiver works on another batch at any moment (up to six in
