@@ -24,6 +24,13 @@
 #include "common.hpp"
 
 namespace gr4pm {
+// GR4PM_TIMING_SKIP=name[,name]: timing experiments only -- the named kernels are not launched (their outputs are
+// garbage); tells what a kernel costs the pipelined chain, which its duration alone does not
+static inline bool timing_skip(const char* name)
+{
+    static const char* e = getenv("GR4PM_TIMING_SKIP");
+    return e && strstr(e, name) != nullptr;
+}
 namespace {
 
 struct cf {
@@ -96,9 +103,10 @@ __device__ __forceinline__ cf cmul_pk(cf a, cf b)
 // kRotChunk steps e *= inc without renormalisation, three packed instructions a step:
 //   a = (e.x * inc.x, e.x * inc.y)   b = (e.y * inc.y, e.y * inc.x)   e = (a.x - b.x, a.y + b.y)
 // which are exactly the four products and two sums of cmul(), each rounded once (the sign of
-// b.x is an input modifier).  The s_nop are the wait state gfx950 needs between a packed
-// result and its packed consumer; hipcc spends seven instructions and four dependent levels a
-// step on the same arithmetic (it builds both a + b and a - b and moves halves around).
+// b.x is an input modifier).  No s_nop between a packed result and its packed consumer: the hardware
+// interlocks (hipcc pads such pairs because it takes op_sel_hi of a VOP3P source for a dst_sel; the
+// correlator's cmul has run them unpadded, bit-exact, since round 1).  hipcc itself spends seven instructions
+// and four dependent levels a step on the same arithmetic (it builds both a + b and a - b and moves halves around).
 __device__ __forceinline__ cf rot_chunk_pk(cf e, cf inc)
 {
     static_assert(kRotChunk == 8, "eight unrolled steps below");
@@ -106,9 +114,7 @@ __device__ __forceinline__ cf rot_chunk_pk(cf e, cf inc)
 #define GR4PM_ROT_STEP                                                  \
     "v_pk_mul_f32 %[a], %[e], %[i] op_sel_hi:[0,1]\n"                   \
     "v_pk_mul_f32 %[b], %[e], %[i] op_sel:[1,1] op_sel_hi:[1,0]\n"      \
-    "s_nop 0\n"                                                         \
-    "v_pk_add_f32 %[e], %[a], %[b] neg_lo:[0,1] neg_hi:[0,0]\n"         \
-    "s_nop 0\n"
+    "v_pk_add_f32 %[e], %[a], %[b] neg_lo:[0,1] neg_hi:[0,0]\n"
     asm volatile(GR4PM_ROT_STEP GR4PM_ROT_STEP GR4PM_ROT_STEP GR4PM_ROT_STEP GR4PM_ROT_STEP GR4PM_ROT_STEP
                      GR4PM_ROT_STEP GR4PM_ROT_STEP
                  : [e] "+v"(e), [a] "=&v"(a), [b] "=&v"(b)
@@ -117,6 +123,10 @@ __device__ __forceinline__ cf rot_chunk_pk(cf e, cf inc)
     return e;
 }
 
+// Measured, not adopted (round 3): four chains per lane, interleaved (k_rot_checkpoints4: a quarter of the waves).
+// A chain's step is NOT latency-bound on this chip: the four-chain kernel took 3.7 x the time of the one-chain kernel
+// (1.49 against 0.40 ms for 10 004 packet segments, with or without the checkpoint stores) -- each packed instruction
+// costs the same ~5 ns whether its neighbours depend on it or not, and the pipelined receiver lost 6 % (stage latency).
 // serial: one lane per segment, phasor checkpoints every kRotChunk samples.  The chain of
 // dependent complex multiplies is the whole cost, so the loop body is kept to exactly that.
 __global__ void k_rot_checkpoints(const RotSeg* __restrict__ segs, unsigned n_segs,
@@ -914,6 +924,7 @@ static void launch_symbol_filter(hipStream_t s, unsigned n_wg, size_t smem, unsi
                        cfc, plan, chans, symf_per_wg(CFC, sps, arm_size));
     if constexpr (CFC) {
         if (symf_fast(true, sps, arm_size)) {
+            if (!timing_skip("symf"))
             hipLaunchKernelGGL(k_symbol_filter_fast, grid, dim3(kFastThreads), 0, s, in, carry, cap, taps, plan, out, cfc,
                                chans);
             return;
@@ -1287,10 +1298,11 @@ static gr4pm_status rotator_plan(gr4pm_rotator* h, size_t n, const gr4pm_tag* ta
         GR4PM_TRY(pl.seg_counter0.alloc(n_segs * 2));
     }
     static const unsigned wg = getenv("GR4PM_SERIAL_WG") ? static_cast<unsigned>(atoi(getenv("GR4PM_SERIAL_WG"))) : 64u;
-    hipLaunchKernelGGL(k_rot_checkpoints, dim3(grid_for(n_segs, wg)), dim3(wg), 0, s, pl.segs.p, n_segs,
-                       h->state.p + static_cast<size_t>(h->st_cur) * h->n_channels,
-                       h->state.p + static_cast<size_t>(h->st_cur ^ 1) * h->n_channels,
-                       pl.ck.p, pl.seg_incr.p, pl.seg_counter0.p);
+    if (!timing_skip("rot")) // GR4PM_TIMING_SKIP: what a kernel costs the pipeline (results are garbage)
+        hipLaunchKernelGGL(k_rot_checkpoints, dim3(grid_for(n_segs, wg)), dim3(wg), 0, s, pl.segs.p, n_segs,
+                           h->state.p + static_cast<size_t>(h->st_cur) * h->n_channels,
+                           h->state.p + static_cast<size_t>(h->st_cur ^ 1) * h->n_channels,
+                           pl.ck.p, pl.seg_incr.p, pl.seg_counter0.p);
     GR4PM_HIP_TRY(hipGetLastError());
     h->st_cur ^= 1;
     return GR4PM_OK;
@@ -1487,6 +1499,7 @@ static gr4pm_status costas_process_impl(gr4pm_costas_loop* h, const gr4pm_c64* i
     CostasState* st_out = h->state.p + (h->st_cur ^ 1) * h->n_channels;
     h->st_cur ^= 1;
     auto launch = [&](auto kernel) {
+        if (timing_skip("costas")) return;
         hipLaunchKernelGGL(kernel, grid, block, 0, s, h->segs.p, n_segs, st_in, st_out, h->k1, h->k2,
                            reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(out), stride);
     };

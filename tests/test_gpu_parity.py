@@ -431,6 +431,33 @@ def test_coarse_frequency_correction_pending_delay_across_calls(pkg):
     assert np.array_equal(bits(np.concatenate(outs)), bits(want))
 
 
+@pytest.mark.parametrize("delay", [0, 26])
+def test_coarse_frequency_correction_many_ragged_segments(pkg, delay):
+    """hundreds of set_freq tags at ragged distances (shorter than a checkpoint chunk, longer than the 512-sample
+    renormalisation period, one carried over a call boundary): the checkpoint kernel and the parallel apply
+    against the oracle bit for bit, in one call and split in three"""
+    rng = np.random.default_rng(400 + delay)
+    n = 400000
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    gaps = np.concatenate([rng.integers(1, 40, 150), rng.integers(40, 3000, 350), rng.integers(400, 700, 100)])
+    rng.shuffle(gaps)
+    idx = np.cumsum(gaps)
+    idx = idx[idx < n - 10].astype(np.uint64)
+    fr = rng.uniform(-0.04, 0.04, idx.size)
+    want = orc.coarse_frequency_correction(x, idx, fr, delay=delay)
+    tags = np.zeros(idx.size, dtype=pkg.TAG_DTYPE)
+    tags["index"], tags["freq"], tags["flags"] = idx, fr, pkg.TAG_SYNCWORD
+    y = host(pkg.CoarseFrequencyCorrection(delay).process_bulk(dev(x), tags))
+    assert np.array_equal(bits(y), bits(want))
+    cfc = pkg.CoarseFrequencyCorrection(delay)
+    outs = []
+    for a, b in [(0, 100003), (100003, 250000), (250000, n)]:
+        t = tags[(tags["index"] >= a) & (tags["index"] < b)].copy()
+        t["index"] -= a
+        outs.append(host(cfc.process_bulk(dev(x[a:b]), t)))
+    assert np.array_equal(bits(np.concatenate(outs)), bits(want))
+
+
 @pytest.mark.gpu
 def test_device_sincosf_is_glibc_bit_exact(pkg):
     """the Costas loop's local oscillator: sinf / cosf on the device against the host libm the reference calls
