@@ -1297,7 +1297,7 @@ static gr4pm_status rotator_plan(gr4pm_rotator* h, size_t n, const gr4pm_tag* ta
         GR4PM_TRY(pl.seg_incr.alloc(n_segs * 2));
         GR4PM_TRY(pl.seg_counter0.alloc(n_segs * 2));
     }
-    static const unsigned wg = getenv("GR4PM_SERIAL_WG") ? static_cast<unsigned>(atoi(getenv("GR4PM_SERIAL_WG"))) : 64u;
+    static const unsigned wg = getenv("GR4PM_ROT_WG") ? static_cast<unsigned>(atoi(getenv("GR4PM_ROT_WG"))) : 64u;
     if (!timing_skip("rot")) // GR4PM_TIMING_SKIP: what a kernel costs the pipeline (results are garbage)
         hipLaunchKernelGGL(k_rot_checkpoints, dim3(grid_for(n_segs, wg)), dim3(wg), 0, s, pl.segs.p, n_segs,
                            h->state.p + static_cast<size_t>(h->st_cur) * h->n_channels,
@@ -1492,7 +1492,7 @@ static gr4pm_status costas_process_impl(gr4pm_costas_loop* h, const gr4pm_c64* i
     }
     hipStream_t s = h->stream;
     GR4PM_TRY(upload_vec(h->segs, segs, s));
-    static const unsigned wg = getenv("GR4PM_SERIAL_WG") ? static_cast<unsigned>(atoi(getenv("GR4PM_SERIAL_WG"))) : 64u;
+    static const unsigned wg = getenv("GR4PM_COSTAS_WG") ? static_cast<unsigned>(atoi(getenv("GR4PM_COSTAS_WG"))) : 64u;
     const dim3 grid(grid_for(segs.size(), wg)), block(wg);
     const unsigned n_segs = static_cast<unsigned>(segs.size());
     const CostasState* st_in = h->state.p + h->st_cur * h->n_channels;
