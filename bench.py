@@ -197,7 +197,7 @@ def pmc_traffic(samples, kernel="k_correlate_w64"):
     """roofline.traffic: HBM bytes per launch from the PMC passes committed under profiles/ (read at
     run time; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note + WRITE_SIZE, per sample of
     the profiled launch, scaled to this launch).  null when the file is missing or describes another kernel."""
-    path = os.path.join(ROOT, "profiles", "r2_k_correlate_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r3_k_correlate_hbm_traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
@@ -208,7 +208,7 @@ def pmc_traffic(samples, kernel="k_correlate_w64"):
                 "traffic_source": f"profiles/{os.path.basename(path)}: {t['traffic_bytes_per_sample']:.3f} B/sample "
                                   f"(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, kernel {t.get('kernel', '?')})"}
     except (OSError, KeyError, ValueError):
-        return {"traffic": None, "traffic_source": "profiles/r2_k_correlate_hbm_traffic.json missing"}
+        return {"traffic": None, "traffic_source": f"profiles/{os.path.basename(path)} missing"}
 
 
 def channel_bank(x, n_channels):

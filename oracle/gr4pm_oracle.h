@@ -32,6 +32,12 @@
  *    pinned against this libm for every float of the loop's phase range (tests/sincosf_glibc_check.c).
  *  - the gr::Block runtime (gnuradio4) is absent, so the reference blocks themselves
  *    cannot be built here without writing stand-ins: no reference block executable exists.
+ *  - cross-check that pins NOTHING (the API under the blocks is a stand-in) but catches restatement slips: in
+ *    the build container tests/test_gr4_blocks.py compiles the reference's own rotator / coarse_frequency_
+ *    correction / symbol_filter / costas_loop / interpolating_fir_filter / pfb_arb_resampler / syncword_wipeoff
+ *    headers against the test stand-in tests/gr4_stub/ and compares their outputs with this oracle on exactly
+ *    the paths listed above as pinned by code reading only (tags into SymbolFilter, CFC delay 26, float-rate
+ *    resampler, phase tags into the Costas loop): bit-identical.
  */
 #ifndef GR4PM_ORACLE_H
 #define GR4PM_ORACLE_H

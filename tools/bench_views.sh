@@ -1,8 +1,8 @@
 #!/bin/bash
-# every view of bench.py on one box, back to back (profiles/r2_bench_views.txt); run on the GPU box
-OUT=${1:-gpurun_out/r2_views}
+# every view of bench.py on one box, back to back (profiles/r<N>_bench_views.txt); run on the GPU box
+OUT=${1:-gpurun_out/r3_views}
 mkdir -p $OUT
-run() { name=$1; shift; timeout 600 python bench.py --no-cpu-baseline "$@" 2>/dev/null | tail -1 > $OUT/$name.json; python3 - $OUT/$name.json "$name" <<'PY'
+run() { name=$1; shift; timeout 600 python bench.py --no-cpu-baseline --no-channels-leg --repeats 3 "$@" 2>/dev/null | tail -1 > $OUT/$name.json; python3 - $OUT/$name.json "$name" <<'PY'
 import json,sys
 try:
     d=json.load(open(sys.argv[1])); r=d.get("roofline") or {}
@@ -23,7 +23,9 @@ run channels64 --channels 64 --steps 40 --warmup 6
 run channels64_sync --channels 64 --steps 40 --warmup 6 --no-pipeline
 run channels64_detector --channels 64 --steps 40 --warmup 6 --detector-only
 run config5 --config 5 --steps 10 --warmup 3
+GR4PM_W64_VARIANT=0 run default_round2_correlator
 GR4PM_CORRELATOR=wave run default_round1_correlator
+for sk in costas rot symf costas,rot costas,rot,symf; do GR4PM_TIMING_SKIP=$sk run timing_only_without_$sk; done
 python3 tools/benchmark_syncword_detection.py 4 9.5 2>/dev/null | tail -2
 python3 tools/benchmark_syncword_detection.py 0 9.5 2>/dev/null | tail -2
 python3 tools/bench_correlate.py 67108864 10 4 2>/dev/null | tail -1
