@@ -129,53 +129,57 @@ __device__ __forceinline__ cf rot_chunk_pk(cf e, cf inc)
 // costs the same ~5 ns whether its neighbours depend on it or not, and the pipelined receiver lost 6 % (stage latency).
 // serial: one lane per segment, phasor checkpoints every kRotChunk samples.  The chain of
 // dependent complex multiplies is the whole cost, so the loop body is kept to exactly that.
-__global__ void k_rot_checkpoints(const RotSeg* __restrict__ segs, unsigned n_segs,
-                                  const RotState* __restrict__ state, RotState* __restrict__ state_next,
-                                  cf* __restrict__ ck,
-                                  cf* __restrict__ seg_incr, unsigned* __restrict__ seg_counter0)
+// Register budget: at most 32 VGPRs, on purpose.  These waves live for half a millisecond; a SIMD that runs two
+// correlator waves (2 x 240 registers) has exactly 32 left, so a wave of this kernel fits BESIDE them instead of keeping
+// the next correlator workgroup off its CU.  Hence: segment fields are re-read where they are
+// needed instead of kept, chunk counts are 32 bit (a segment is shorter than 2^35 items), one running pointer.
+__global__ __launch_bounds__(64) void k_rot_checkpoints(const RotSeg* __restrict__ segs, unsigned n_segs,
+                                                        const RotState* __restrict__ state,
+                                                        RotState* __restrict__ state_next, cf* __restrict__ ck,
+                                                        cf* __restrict__ seg_incr, unsigned* __restrict__ seg_counter0)
 {
     __builtin_amdgcn_s_setprio(3); // latency-bound, few waves
     const unsigned s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_segs) return;
-    const RotSeg g = segs[s];
+    const RotSeg* gp = segs + s;
     cf e, inc;
     unsigned counter;
-    if (g.mode == 0) {
-        const RotState st = state[g.channel];
-        e = st.exp;
-        inc = st.incr;
-        counter = st.counter;
+    if (gp->mode == 0) {
+        const RotState* st = state + gp->channel;
+        e = st->exp;
+        inc = st->incr;
+        counter = st->counter;
     } else {
-        e = g.exp0;
-        inc = g.incr;
+        e = gp->exp0;
+        inc = gp->incr;
         counter = 0;
     }
     seg_incr[s] = inc;
     seg_counter0[s] = counter;
-    const unsigned long long n_full = g.len / kRotChunk;
-    cf* ckp = ck + g.ck0;
-    for (unsigned long long c = 0; c < n_full; ++c) {
-        ckp[c] = e;
+    cf* ckp = ck + gp->ck0;
+    for (unsigned left = static_cast<unsigned>(gp->len / kRotChunk); left != 0; --left, ++ckp) {
+        *ckp = e;
         if ((counter & 511u) < 512u - kRotChunk) { // no renormalisation inside this chunk
             e = rot_chunk_pk(e, inc);
             counter += kRotChunk;
-        } else {
-#pragma unroll
+        } else { // one chunk in 64: rolled, ONE instance of the renormalisation's double-precision square root
+#pragma unroll 1
             for (unsigned j = 0; j < kRotChunk; ++j) rot_step(e, inc, counter);
         }
     }
-    const unsigned rem = static_cast<unsigned>(g.len - n_full * kRotChunk);
+    gp = segs + s; // (recomputed: one register kept across the loop instead of two)
+    const unsigned rem = static_cast<unsigned>(gp->len) & (kRotChunk - 1);
     if (rem) {
-        ckp[n_full] = e;
+        *ckp = e;
         for (unsigned j = 0; j < rem; ++j) rot_step(e, inc, counter);
     }
-    if (g.last) {
+    if (gp->last) {
         RotState st;
         st.exp = e;
         st.incr = inc;
         st.counter = counter;
         st.pad = 0;
-        state_next[g.channel] = st; // ping-pong: another lane may still have to read `state`
+        state_next[gp->channel] = st; // ping-pong: another lane may still have to read `state`
     }
 }
 

@@ -1097,22 +1097,30 @@ __global__ __launch_bounds__(64) void k_median_tests(const float* __restrict__ z
     const uint32_t n = min(st[ch].vis_cnt, visit_cap);
     const uint32_t hist = 2 * T + 1;
     for (uint32_t idx = blockIdx.x; idx < n; idx += gridDim.x) {
-        const uint32_t p = visit[static_cast<size_t>(ch) * visit_cap + idx];
-        const float best = z[p];
+        // the candidate is the same for the whole wave: a uniform window pointer (SGPR pair) + the lane's 32-bit offset,
+        // i.e. one address register per lane instead of a 64-bit address per load.  With that the kernel needs at most
+        // 32 VGPRs, which is what a SIMD has left beside two correlator waves: its waves run
+        // beside them on the memory bandwidth the correlator leaves idle instead of waiting for a free CU.
+        const uint32_t p = __builtin_amdgcn_readfirstlane(visit[static_cast<size_t>(ch) * visit_cap + idx]);
+        const float* zw = z + (static_cast<long long>(p) - static_cast<long long>(T)); // window [p - T, p + T]
+        const float best = zw[T];
         const float thr = best / power_threshold; // hpp:275
-        const long long base = static_cast<long long>(p) - static_cast<long long>(T);
+        // counted per wave, not per lane: ballot + population count (scalar unit; no per-lane counter, no shuffles)
         uint32_t below = 0;
-        uint32_t u = lane;
-        for (; u + 7 * 64 < hist; u += 8 * 64) { // eight independent loads in flight per lane
+        const char* zb = reinterpret_cast<const char*>(zw);
+        const uint32_t off = static_cast<uint32_t>(lane) * 4u; // byte offset of the lane's item inside a row of 64
+        const uint32_t end = hist * 4u;
+        // the row loop is UNIFORM (every lane takes every pass; a lane beyond the window reads its last item again and
+        // does not count), so that the wave-wide count is the same in every lane
+#pragma unroll 1
+        for (uint32_t row = 0; row < end; row += 8u * 256u) { // eight independent loads in flight per lane
             float v[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = z[base + u + 64 * k];
+            for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float*>(zb + min(row + off + 256u * k, end - 4u));
 #pragma unroll
-            for (int k = 0; k < 8; ++k) below += v[k] < thr ? 1u : 0u;
+            for (int k = 0; k < 8; ++k)
+                below += static_cast<uint32_t>(__popcll(__ballot(row + off + 256u * k < end && v[k] < thr)));
         }
-        for (; u < hist; u += 64) below += z[base + u] < thr ? 1u : 0u;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) below += __shfl_xor(below, d);
         if (2 * below >= hist && lane == 0) { // hpp:279
             const unsigned int slot = atomicAdd(&st[ch].det_cnt, 1u);
             if (slot < det_cap) det[static_cast<size_t>(ch) * det_cap + slot] = A0 + p;
