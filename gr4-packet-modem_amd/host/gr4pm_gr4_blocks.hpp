@@ -69,45 +69,69 @@ inline size_t max_items()
 }
 
 // Device-side shadows of published output spans, keyed by host address.
+//
+// Double-mapped buffers.  gnuradio4's CircularBuffer maps its storage twice, back to back: the items a producer wrote
+// through a span that ran past the end of the first mapping are seen by the consumer, after the wrap, at addresses one
+// ring size LOWER.  A raw address comparison would miss them (and with host_output = false there is no host copy to
+// fall back to).  An integrator that runs wrapped blocks with host_output = false over such buffers registers every
+// buffer once with add_mirrored_ring(base, bytes); addresses inside [base, base + 2 bytes) are then compared modulo the
+// ring.  Without a registration addresses are compared as they are (single-mapped buffers, the test stand-in).
+// Threads: lookups are serialised by a mutex, but a consumer USES the producer's device buffer after the lookup; the
+// producer's next processBulk() may reuse that buffer.  host_output = false therefore assumes that producer and
+// consumer of one edge do not run concurrently (a single-threaded scheduler, or one worker for the wrapped chain).
 class Arena
 {
 public:
     struct Seg {
         const void* owner;
-        const char* host;
+        const char* host; // canonical (first-mapping) address of the first byte
         char* dev;
         size_t bytes, consumed;
-        bool on_host; // the host span already holds the data
+        bool on_host;     // the host span already holds the data
+        size_t ring;      // size of the mirrored ring the span lives in, 0: none
+        const char* raw;  // address as the producer saw it (write-back goes there)
     };
     static Arena& instance()
     {
         static Arena a;
         return a;
     }
+    void add_mirrored_ring(const void* base, size_t bytes)
+    {
+        std::lock_guard<std::mutex> g(_m);
+        _rings.push_back({ static_cast<const char*>(base), bytes });
+    }
     // consumer side: device address of [host, host + bytes) if a producer left it here
     const void* find(const void* host, size_t bytes)
     {
         std::lock_guard<std::mutex> g(_m);
-        const char* h = static_cast<const char*>(host);
-        for (auto& s : _segs)
-            if (h >= s.host && h + bytes <= s.host + s.bytes) return s.dev + (h - s.host);
+        size_t ring = 0;
+        const char* h = canonical(static_cast<const char*>(host), &ring);
+        for (auto& s : _segs) {
+            const ptrdiff_t off = offset_in(s, h, bytes, ring);
+            if (off >= 0) return s.dev + off;
+        }
         return nullptr;
     }
     void consumed(const void* host, size_t bytes)
     {
         std::lock_guard<std::mutex> g(_m);
-        const char* h = static_cast<const char*>(host);
-        for (auto& s : _segs)
-            if (h >= s.host && h + bytes <= s.host + s.bytes) s.consumed = std::max(s.consumed, static_cast<size_t>(h - s.host) + bytes);
+        size_t ring = 0;
+        const char* h = canonical(static_cast<const char*>(host), &ring);
+        for (auto& s : _segs) {
+            const ptrdiff_t off = offset_in(s, h, bytes, ring);
+            if (off >= 0) s.consumed = std::max(s.consumed, static_cast<size_t>(off) + bytes);
+        }
     }
     // write back what the host does not hold yet of every registration that overlaps [host, host + bytes)
     void flush(const void* host, size_t bytes)
     {
         std::lock_guard<std::mutex> g(_m);
-        const char* h = static_cast<const char*>(host);
+        size_t ring = 0;
+        const char* h = canonical(static_cast<const char*>(host), &ring);
         for (auto& s : _segs)
-            if (!s.on_host && h < s.host + s.bytes && s.host < h + bytes) {
-                check_hip(hipMemcpy(const_cast<char*>(s.host), s.dev, s.bytes, hipMemcpyDeviceToHost), "arena flush");
+            if (!s.on_host && overlaps(s, h, bytes, ring)) {
+                check_hip(hipMemcpy(const_cast<char*>(s.raw), s.dev, s.bytes, hipMemcpyDeviceToHost), "arena flush");
                 s.on_host = true;
             }
     }
@@ -120,7 +144,7 @@ public:
             if (_segs[i].owner == owner) {
                 const Seg s = _segs[i];
                 if (!s.on_host && s.consumed < s.bytes)
-                    check_hip(hipMemcpy(const_cast<char*>(s.host) + s.consumed, s.dev + s.consumed,
+                    check_hip(hipMemcpy(const_cast<char*>(s.raw) + s.consumed, s.dev + s.consumed,
                                         s.bytes - s.consumed, hipMemcpyDeviceToHost),
                               "arena write-back");
                 _segs.erase(_segs.begin() + static_cast<ptrdiff_t>(i));
@@ -133,19 +157,54 @@ public:
     {
         if (bytes == 0) return;
         std::lock_guard<std::mutex> g(_m);
-        const char* h = static_cast<const char*>(host);
+        size_t ring = 0;
+        const char* raw = static_cast<const char*>(host);
+        const char* h = canonical(raw, &ring);
         // a new span over the same host memory supersedes whatever was registered there
         for (size_t i = 0; i < _segs.size();)
-            if (h < _segs[i].host + _segs[i].bytes && _segs[i].host < h + bytes)
+            if (overlaps(_segs[i], h, bytes, ring))
                 _segs.erase(_segs.begin() + static_cast<ptrdiff_t>(i));
             else
                 ++i;
-        _segs.push_back({ owner, h, static_cast<char*>(dev), bytes, 0, on_host });
+        _segs.push_back({ owner, h, static_cast<char*>(dev), bytes, 0, on_host, ring, raw });
     }
 
 private:
+    struct Ring {
+        const char* base;
+        size_t bytes;
+    };
+    // first-mapping address of h and the size of its ring (0: not inside a registered ring)
+    const char* canonical(const char* h, size_t* ring) const
+    {
+        for (const auto& r : _rings)
+            if (h >= r.base && h < r.base + 2 * r.bytes) {
+                *ring = r.bytes;
+                return r.base + static_cast<size_t>(h - r.base) % r.bytes;
+            }
+        *ring = 0;
+        return h;
+    }
+    // byte offset of [h, h + bytes) inside the registration, -1 if it is not wholly inside.  In a ring a registration
+    // may run past the end of the first mapping: a span that begins after the wrap is then one ring size further on.
+    static ptrdiff_t offset_in(const Seg& s, const char* h, size_t bytes, size_t ring)
+    {
+        if (h >= s.host && h + bytes <= s.host + s.bytes) return h - s.host;
+        if (ring != 0 && ring == s.ring && h + ring >= s.host && h + ring + bytes <= s.host + s.bytes) return h + ring - s.host;
+        return -1;
+    }
+    static bool overlaps(const Seg& s, const char* h, size_t bytes, size_t ring)
+    {
+        if (h < s.host + s.bytes && s.host < h + bytes) return true;
+        if (ring != 0 && ring == s.ring) {
+            if (h + ring < s.host + s.bytes && s.host < h + ring + bytes) return true; // query after the wrap
+            if (h < s.host + ring + s.bytes && s.host + ring < h + bytes) return true; // registration after the wrap
+        }
+        return false;
+    }
     std::mutex _m;
     std::vector<Seg> _segs;
+    std::vector<Ring> _rings;
 };
 
 // device staging buffer that grows on demand

@@ -179,12 +179,71 @@ static int blocks(int argc, char** argv)
     return 0;
 }
 
+// A double-mapped ring between two wrapped blocks with host_output = false (gnuradio4's CircularBuffer maps its storage
+// twice, back to back): the producer's spans run past the end of the first mapping, the consumer -- reading in smaller
+// chunks -- sees the items behind the wrap at addresses one ring size lower.  The host memory of the ring is never
+// written here (host_output = false) and is filled with NaNs: the consumer gets correct data only from the device
+// arena, i.e. only if the arena compares addresses modulo the registered ring.
+static int mirror(int argc, char** argv)
+{
+    if (argc < 4) return 2;
+    const auto x = read_c64(argv[2]);
+    const std::string prefix = argv[3];
+    const size_t R = 4096; // ring size in items
+    std::vector<c64> ring(2 * R, c64{ std::nanf(""), std::nanf("") });
+    gr::packet_modem::hip::detail::Arena::instance().add_mirrored_ring(ring.data(), R * sizeof(c64));
+    gr::stub::Graph fg;
+    auto& a = fg.emplaceBlock<Rotator<>>({ { "phase_incr", 0.1f } });
+    auto& b = fg.emplaceBlock<Rotator<>>({ { "phase_incr", -0.03f } });
+    a.host_output = false;
+    b.host_output = true;
+    a.start();
+    b.start();
+    std::vector<c64> out(x.size());
+    size_t in_pos = 0, w = 0, r = 0, o = 0; // items read from x, written to / read from the ring, written to out
+    const size_t prod_chunk[3] = { 1500, 2900, 777 }, cons_chunk[2] = { 640, 1111 };
+    std::vector<std::pair<size_t, size_t>> spans; // producer spans [begin, end) in item counts, for the consumer to stay inside
+    size_t pi = 0, ci = 0, hits_needed = 0;
+    while (o < x.size()) {
+        // producer: as much as fits (never more than R items ahead of the reader)
+        const size_t room = R - (w - r);
+        size_t np = std::min({ prod_chunk[pi % 3], x.size() - in_pos, room });
+        if (np > 0) {
+            gr::InSpan<c64> is(x.data() + in_pos, np);
+            gr::OutSpan<c64> os(ring.data() + (w % R), np); // may run into the second mapping
+            if (a.processBulk(is, os) != gr::work::Status::OK) throw std::runtime_error("producer");
+            in_pos += is.consumed;
+            spans.push_back({ w, w + os.published });
+            w += os.published;
+            ++pi;
+        }
+        // consumer: chunks that stay inside one producer span
+        while (r < w) {
+            size_t end = w;
+            for (const auto& sp : spans)
+                if (r >= sp.first && r < sp.second) end = sp.second;
+            const size_t nc = std::min(cons_chunk[ci % 2], end - r);
+            gr::InSpan<c64> is(ring.data() + (r % R), nc); // after the wrap: one ring size below the producer's address
+            gr::OutSpan<c64> os(out.data() + o, nc);
+            if (b.processBulk(is, os) != gr::work::Status::OK) throw std::runtime_error("consumer");
+            if ((r % R) + nc <= R && (r / R) != ((spans.back().first) / R)) ++hits_needed;
+            r += is.consumed;
+            o += os.published;
+            ++ci;
+        }
+    }
+    dump(prefix + ".mirror.c64", out.data(), out.size());
+    std::printf("mirror: %zu items through a %zu-item double-mapped ring, %zu consumer spans behind a wrap\n", o, R, hits_needed);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     try {
         if (argc >= 2 && std::strcmp(argv[1], "chain") == 0) return chain(argc, argv);
         if (argc >= 2 && std::strcmp(argv[1], "blocks") == 0) return blocks(argc, argv);
-        std::fprintf(stderr, "usage: %s chain|blocks ...\n", argv[0]);
+        if (argc >= 2 && std::strcmp(argv[1], "mirror") == 0) return mirror(argc, argv);
+        std::fprintf(stderr, "usage: %s chain|blocks|mirror ...\n", argv[0]);
         return 2;
     } catch (const std::exception& e) {
         std::fprintf(stderr, "gr4_blocks_driver: %s\n", e.what());

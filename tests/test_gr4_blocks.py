@@ -146,6 +146,27 @@ def test_rotator_fir_resampler_wrappers(tmp_path):
     assert abs(arb.size - ref_arb.size) <= 2 and np.array_equal(arb[:n].view(np.uint64), ref_arb[:n].view(np.uint64))
 
 
+@pytest.mark.gpu
+def test_device_arena_over_a_double_mapped_ring(tmp_path):
+    """gnuradio4's CircularBuffer is mapped twice back to back: a producer span runs past the end of the first mapping
+    and the consumer sees the items behind the wrap one ring size lower.  Two wrapped Rotators with host_output = false
+    between them over such a ring (registered with Arena::add_mirrored_ring; its host memory holds NaNs throughout):
+    the output equals the oracle's two rotators only if the arena compares addresses modulo the ring"""
+    ge.build_gr4_driver()
+    rng = np.random.default_rng(8)
+    n = 40000
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    xin = tmp_path / "x.c64"
+    x.tofile(xin)
+    r = subprocess.run([DRIVER, "mirror", str(xin), str(tmp_path / "m")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert int(r.stdout.split("ring,")[1].split()[0]) > 5, r.stdout      # the aliased case really occurred
+    got = np.fromfile(str(tmp_path / "m.mirror.c64"), dtype=np.complex64)
+    want = orc.rotator(orc.rotator(x, np.float32(0.1)), np.float32(-0.03))
+    assert not np.isnan(got.view(np.float32)).any()
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+
+
 # ------------------------------------------------------------------ the stand-in checked in the other direction
 REFERENCE_INCLUDE = "/root/reference/blocks/include"
 
