@@ -244,8 +244,9 @@ __global__ __launch_bounds__(kW64Threads, 2) void k_correlate_w64(const cf* __re
     const uint32_t item_end = blocks_per_wave ? min(total, (blockIdx.x + 1) * kW64Waves * blocks_per_wave) : total;
     if (item >= item_end) return;
 
+    const bool one_channel = total <= n_blocks; // no division per block (two 32-bit divisions: ~50 instructions)
     auto load_block = [&](cf* dst, uint32_t it) {
-        const uint32_t ch = it / n_blocks, b = it - ch * n_blocks;
+        const uint32_t ch = one_channel ? 0u : it / n_blocks, b = it - ch * n_blocks;
         int ln = lane;
         asm volatile("" : "+v"(ln)); // addresses are formed here, not hoisted out of the block loop
         const cf* x = in + static_cast<size_t>(ch) * in_stride + static_cast<size_t>(b) * stride_s + ln;
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(kW64Threads, 2) void k_correlate_w64(const cf* __re
     cf X[32];
     load_block(X, item);
     for (;;) {
-        const uint32_t ch = item / n_blocks, blk = item - ch * n_blocks;
+        const uint32_t ch = one_channel ? 0u : item / n_blocks, blk = item - ch * n_blocks;
         float* zo = zpow + static_cast<size_t>(ch) * z_stride + static_cast<size_t>(blk) * stride_s;
         const uint32_t next = item + n_waves;
         const bool has_next = next < item_end;
