@@ -157,8 +157,26 @@ __global__ __launch_bounds__(64) void k_rot_checkpoints(const RotSeg* __restrict
     seg_incr[s] = inc;
     seg_counter0[s] = counter;
     cf* ckp = ck + gp->ck0;
-    for (unsigned left = static_cast<unsigned>(gp->len / kRotChunk); left != 0; --left, ++ckp) {
-        *ckp = e;
+    unsigned left = static_cast<unsigned>(gp->len / kRotChunk);
+    while (left != 0) {
+        if (left >= 4 && (counter & 511u) < 512u - 4 * kRotChunk) {
+            // four chunks per pass while no renormalisation falls into them: the chain itself (3 instructions a step)
+            // with one counter test and one branch per 32 steps instead of per 8
+            ckp[0] = e;
+            e = rot_chunk_pk(e, inc);
+            ckp[1] = e;
+            e = rot_chunk_pk(e, inc);
+            ckp[2] = e;
+            e = rot_chunk_pk(e, inc);
+            ckp[3] = e;
+            e = rot_chunk_pk(e, inc);
+            counter += 4 * kRotChunk;
+            ckp += 4;
+            left -= 4;
+            continue;
+        }
+        *ckp++ = e;
+        --left;
         if ((counter & 511u) < 512u - kRotChunk) { // no renormalisation inside this chunk
             e = rot_chunk_pk(e, inc);
             counter += kRotChunk;
