@@ -9,6 +9,7 @@ numpy records (TAG_DTYPE) with explicit indices instead of the runtime's chunk-h
 The C++ gr::Block wrappers in host/ are the drop-in for the reference's flowgraphs; this
 module is what the parity tests and bench.py drive."""
 import ctypes as C
+import os
 
 import numpy as np
 

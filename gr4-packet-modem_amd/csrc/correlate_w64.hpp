@@ -223,6 +223,9 @@ __global__ __launch_bounds__(kW64Threads, 2) void k_correlate_w64(const cf* __re
 {
     __shared__ float4 lds4[kW64LdsF4];
     const int tid = threadIdx.x;
+#ifdef GR4PM_W64_PRIO
+    __builtin_amdgcn_s_setprio(GR4PM_W64_PRIO); // A/B: make ABL=-DGR4PM_W64_PRIO=2
+#endif
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < kW64TwFloat4; i += kW64Threads) lds4[i] = tT[i];

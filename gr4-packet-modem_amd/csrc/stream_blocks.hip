@@ -26,6 +26,9 @@
 namespace gr4pm {
 // GR4PM_TIMING_SKIP=name[,name]: timing experiments only -- the named kernels are not launched (their outputs are
 // garbage); tells what a kernel costs the pipelined chain, which its duration alone does not
+#ifndef GR4PM_SERIAL_PRIO
+#define GR4PM_SERIAL_PRIO 3 // s_setprio of the one-lane-per-packet kernels (A/B: make EXTRA=-DGR4PM_SERIAL_PRIO=0)
+#endif
 static inline bool timing_skip(const char* name)
 {
     static const char* e = getenv("GR4PM_TIMING_SKIP");
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(64) void k_rot_checkpoints(const RotSeg* __restrict
                                                         RotState* __restrict__ state_next, cf* __restrict__ ck,
                                                         cf* __restrict__ seg_incr, unsigned* __restrict__ seg_counter0)
 {
-    __builtin_amdgcn_s_setprio(3); // latency-bound, few waves
+    __builtin_amdgcn_s_setprio(GR4PM_SERIAL_PRIO); // latency-bound, few waves
     const unsigned s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_segs) return;
     const RotSeg* gp = segs + s;
@@ -385,7 +388,7 @@ __global__ void k_costas(const CostasSeg* __restrict__ segs, unsigned n_segs,
 {
     const unsigned s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_segs) return;
-    __builtin_amdgcn_s_setprio(3); // a few latency-bound waves among throughput kernels
+    __builtin_amdgcn_s_setprio(GR4PM_SERIAL_PRIO); // a few latency-bound waves among throughput kernels
     const CostasSeg g = segs[s];
     float phase, freq;
     if (g.mode == 0) {
@@ -427,7 +430,7 @@ __global__ void k_costas_chains(const CostasChain* __restrict__ chains, unsigned
 {
     const unsigned s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_chains) return;
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(GR4PM_SERIAL_PRIO);
     const CostasChain ch = chains[s];
     float phase, freq;
     if (ch.mode == 0) {
@@ -889,7 +892,37 @@ __global__ __launch_bounds__(kFastThreads) void k_symbol_filter_fast(const cf* _
     // q = j / 4 of phase ph = j % 4 (j = 43 - m), symbol B = 2l + 1 uses entry 2l + 1 + q
     const float4* rows = reinterpret_cast<const float4*>(tile) + l;
     constexpr unsigned kRow4 = kFastPitch / 2; // float4 per phase row
-    cf accA = { 0.f, 0.f }, accB = { 0.f, 0.f };
+    // The MACs as packed FP32: v_pk_mul_f32 (re, im) x (tap, tap) -- the tap broadcast from one half of an SGPR pair by
+    // op_sel -- and v_pk_add_f32 onto the accumulator: every product and every sum still rounded once, in the
+    // reference's order, in 2 instead of 4 instructions per tap and symbol.  One statement per tap position (four
+    // phases, both symbols: 16 instructions; hipcc pads register overlaps BETWEEN asm statements with s_nop).
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 accA = { 0.f, 0.f }, accB = { 0.f, 0.f };
+    // a3 .. a0 / b3 .. b0: the entries of phases 3 .. 0 for symbol A / B at this tap position; t01, t23: the four taps
+    // (ascending index) that go with phases 3, 2, 1, 0
+    auto mac4 = [&](f2 a3, f2 b3, f2 a2, f2 b2, f2 a1, f2 b1, f2 a0, f2 b0, f2 t01, f2 t23) {
+        f2 pa, pb;
+        asm("v_pk_mul_f32 %2, %4, %12 op_sel_hi:[1,0]\n\t"
+            "v_pk_mul_f32 %3, %5, %12 op_sel_hi:[1,0]\n\t"
+            "v_pk_add_f32 %0, %0, %2\n\t"
+            "v_pk_add_f32 %1, %1, %3\n\t"
+            "v_pk_mul_f32 %2, %6, %12 op_sel:[0,1]\n\t"
+            "v_pk_mul_f32 %3, %7, %12 op_sel:[0,1]\n\t"
+            "v_pk_add_f32 %0, %0, %2\n\t"
+            "v_pk_add_f32 %1, %1, %3\n\t"
+            "v_pk_mul_f32 %2, %8, %13 op_sel_hi:[1,0]\n\t"
+            "v_pk_mul_f32 %3, %9, %13 op_sel_hi:[1,0]\n\t"
+            "v_pk_add_f32 %0, %0, %2\n\t"
+            "v_pk_add_f32 %1, %1, %3\n\t"
+            "v_pk_mul_f32 %2, %10, %13 op_sel:[0,1]\n\t"
+            "v_pk_mul_f32 %3, %11, %13 op_sel:[0,1]\n\t"
+            "v_pk_add_f32 %0, %0, %2\n\t"
+            "v_pk_add_f32 %1, %1, %3"
+            : "+v"(accA), "+v"(accB), "=&v"(pa), "=&v"(pb)
+            : "v"(a3), "v"(b3), "v"(a2), "v"(b2), "v"(a1), "v"(b1), "v"(a0), "v"(b0), "s"(t01), "s"(t23));
+    };
+    auto lo2 = [](const float4& v) { return f2{ v.x, v.y }; };
+    auto hi2 = [](const float4& v) { return f2{ v.z, v.w }; };
     float4 hi[kFastSps], lo[kFastSps];
 #pragma unroll
     for (unsigned ph = 0; ph < kFastSps; ++ph) hi[ph] = rows[ph * kRow4 + 5];
@@ -900,28 +933,45 @@ __global__ __launch_bounds__(kFastThreads) void k_symbol_filter_fast(const cf* _
             for (unsigned ph = 0; ph < kFastSps; ++ph) lo[ph] = rows[ph * kRow4 + (k - 1)];
         }
         asm volatile("" ::: "memory"); // the reads of the next pair stay here, ahead of the MACs that hide them
-#pragma unroll
-        for (int ph = kFastSps - 1; ph >= 0; --ph) { // q = 2k: A <- pair.lo, B <- pair.hi
-            const float t = tap[kFastArm - 1 - (4 * (2 * k) + ph)];
-            accA = mac(accA, t, cf{ hi[ph].x, hi[ph].y });
-            accB = mac(accB, t, cf{ hi[ph].z, hi[ph].w });
+        {   // q = 2k: A <- pair.lo, B <- pair.hi; taps 40 - 8k .. 43 - 8k
+            const int m0 = static_cast<int>(kFastArm) - 4 - 4 * (2 * k);
+            mac4(lo2(hi[3]), hi2(hi[3]), lo2(hi[2]), hi2(hi[2]), lo2(hi[1]), hi2(hi[1]), lo2(hi[0]), hi2(hi[0]),
+                 f2{ tap[m0], tap[m0 + 1] }, f2{ tap[m0 + 2], tap[m0 + 3] });
         }
-        // both chains advance together (hipcc otherwise runs A's 44 MACs first and keeps all 24 pairs live: 102 VGPRs)
-        asm volatile("" : "+v"(accA.x), "+v"(accA.y), "+v"(accB.x), "+v"(accB.y));
-        if (k > 0) {
-#pragma unroll
-            for (int ph = kFastSps - 1; ph >= 0; --ph) { // q = 2k - 1: A <- pair(k - 1).hi, B <- pair(k).lo
-                const float t = tap[kFastArm - 1 - (4 * (2 * k - 1) + ph)];
-                accA = mac(accA, t, cf{ lo[ph].z, lo[ph].w });
-                accB = mac(accB, t, cf{ hi[ph].x, hi[ph].y });
-            }
-            asm volatile("" : "+v"(accA.x), "+v"(accA.y), "+v"(accB.x), "+v"(accB.y));
+        if (k > 0) { // q = 2k - 1: A <- pair(k - 1).hi, B <- pair(k).lo
+            const int m0 = static_cast<int>(kFastArm) - 4 - 4 * (2 * k - 1);
+            mac4(hi2(lo[3]), lo2(hi[3]), hi2(lo[2]), lo2(hi[2]), hi2(lo[1]), lo2(hi[1]), hi2(lo[0]), lo2(hi[0]),
+                 f2{ tap[m0], tap[m0 + 1] }, f2{ tap[m0 + 2], tap[m0 + 3] });
 #pragma unroll
             for (unsigned ph = 0; ph < kFastSps; ++ph) hi[ph] = lo[ph];
         }
     }
-    out[p.o0 + 2 * l] = scale_item(p.scale, accA);
-    if (2 * l + 1 < p.count) out[p.o0 + 2 * l + 1] = scale_item(p.scale, accB);
+    out[p.o0 + 2 * l] = scale_item(p.scale, cf{ accA.x, accA.y });
+    if (2 * l + 1 < p.count) out[p.o0 + 2 * l + 1] = scale_item(p.scale, cf{ accB.x, accB.y });
+}
+
+// GR4PM_TIMING_SKIP=symf_fake / costas_fake: timing experiments only.  Stand-ins with the memory traffic (symbol
+// filter) or the life time (Costas) of the kernel they replace and at most 32 VGPRs, no LDS: what would the chain
+// gain if the real kernel fitted beside two 240-VGPR correlator waves of every SIMD?
+__global__ __launch_bounds__(kFastThreads) void k_symf_fake(const cf* __restrict__ in, const SymWg* __restrict__ plan,
+                                                           cf* __restrict__ out)
+{
+    const SymWg p = plan[blockIdx.x];
+    const float4* ip = reinterpret_cast<const float4*>(in + (p.lo_item > 0 ? (p.lo_item & ~1ll) : 0));
+    float4 a = ip[threadIdx.x], b = ip[threadIdx.x + 128], c = ip[threadIdx.x + 256];
+    float4 d = threadIdx.x < 96 ? ip[threadIdx.x + 384] : a;
+    a.x += b.x + c.x + d.x, a.y += b.y + c.y + d.y, a.z += b.z + c.z + d.z, a.w += b.w + c.w + d.w;
+    if (threadIdx.x < 120) reinterpret_cast<float4*>(out + (p.o0 & ~1u))[threadIdx.x] = a;
+}
+__global__ __launch_bounds__(64) void k_serial_fake(unsigned ticks, float* sink)
+{
+    const unsigned long long t0 = wall_clock64();
+    float x = threadIdx.x;
+    while (wall_clock64() - t0 < ticks) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) x = __builtin_fmaf(x, 1.0001f, 0.5f);
+    }
+    if (x == 12345.0f) *sink = x;
 }
 
 // symbols per workgroup of the kernel that a (fused, sps, arm size) combination runs
@@ -946,7 +996,9 @@ static void launch_symbol_filter(hipStream_t s, unsigned n_wg, size_t smem, unsi
                        cfc, plan, chans, symf_per_wg(CFC, sps, arm_size));
     if constexpr (CFC) {
         if (symf_fast(true, sps, arm_size)) {
-            if (!timing_skip("symf"))
+            if (timing_skip("symf_fake"))
+                hipLaunchKernelGGL(k_symf_fake, grid, dim3(kFastThreads), 0, s, in, plan, out);
+            else if (!timing_skip("symf"))
             hipLaunchKernelGGL(k_symbol_filter_fast, grid, dim3(kFastThreads), 0, s, in, carry, cap, taps, plan, out, cfc,
                                chans);
             return;
@@ -1521,6 +1573,15 @@ static gr4pm_status costas_process_impl(gr4pm_costas_loop* h, const gr4pm_c64* i
     CostasState* st_out = h->state.p + (h->st_cur ^ 1) * h->n_channels;
     h->st_cur ^= 1;
     auto launch = [&](auto kernel) {
+        if (timing_skip("costas_fake")) { // GR4PM_FAKE=workgroups,ticks(10 ns),bytes of LDS
+            unsigned wgs = grid.x, ticks = 83000u, lds = 0u;
+            if (const char* e = getenv("GR4PM_FAKE")) sscanf(e, "%u,%u,%u", &wgs, &ticks, &lds);
+            if (lds > 48 * 1024)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_serial_fake),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+            hipLaunchKernelGGL(k_serial_fake, dim3(wgs), block, lds, s, ticks, reinterpret_cast<float*>(st_out));
+            return;
+        }
         if (timing_skip("costas")) return;
         hipLaunchKernelGGL(kernel, grid, block, 0, s, h->segs.p, n_segs, st_in, st_out, h->k1, h->k2,
                            reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(out), stride);

@@ -626,7 +626,7 @@ gr4pm_status gr4pm_crc_check_process(gr4pm_crc_check* h, const uint8_t* in, cons
  * ================================================================================== */
 /* The symbol PDU tap of packet_receiver.hpp:159-189 (`zmq_output`): SyncwordRemove's output ->
  * HeaderPayloadSplit<c64>{ header_size 128, payload_length_key "payload_symbols" } -> TaggedStreamToPdu ->
- * ZmqPduPubSink on tcp://*:5000 (headers) / :5001 (payloads).  The split (header_payload_split.hpp:46-135) is done by
+ * ZmqPduPubSink on TCP port 5000 (headers) / :5001 (payloads).  The split (header_payload_split.hpp:46-135) is done by
  * the receiver: every batch's post-SyncwordRemove symbols are cut into header PDUs (128 symbols) and payload PDUs
  * ("payload_symbols" symbols behind a parsed header); a PDU that crosses a batch boundary appears as a piece with
  * `last == 0` and continues in the next batch with `first == 0`.  With a callback registered, collect() copies the
