@@ -490,6 +490,7 @@ __global__ __launch_bounds__(kPairThreads, 3) void k_correlate_pair(
 } // namespace
 } // namespace gr4pm
 #include "correlate_w64.hpp"
+#include "correlate_w64_one.hpp"
 #include "correlate_4096.hpp"
 namespace gr4pm {
 namespace {
@@ -1557,6 +1558,7 @@ struct gr4pm_syncword_detection {
     DevBuf<cf> cc64;
     int n_cus = 256;
     int w64_variant = -1;
+    int w64_one = 0; // GR4PM_W64_ONE at creation
     uint32_t w64_blocks_per_wave = 4; // blocks per wave and workgroup; 0: persistent waves (GR4PM_W64_BLOCKS_PER_WAVE)
     // raised by a correlator kernel whose bounded hand-off spin ran out ("wave" / "pair" kernels; k_correlate_w64
     // has no spins); checked after the stream synchronisation of process()
@@ -1739,6 +1741,24 @@ gr4pm_status launch_correlate(gr4pm_syncword_detection* h, hipStream_t stream, c
         // registers 1 .. 3 of the output hold lags >= 1793: with a stride of at most that (the default: 1752) the
         // kernel variant that never computes their powers runs (bit 16384)
         const bool prune = h->S <= 1793 && !h->w64_no_prune;
+        // one frequency bin: GR4PM_W64_ONE=1 runs the three-waves-per-SIMD kernel of correlate_w64_one.hpp instead of the
+        // general one (bit-identical powers, the same launch time: DESIGN.md section 3a; 2, 3: its timing-only ablations)
+        const int one_mode = h->w64_one;
+        const bool one_off = one_mode == 0;
+        if (h->n_bins == 1 && prune && h->w64_variant < 0 && !one_off) {
+            const uint32_t wgs1 = bpw ? (total + kW1Waves * bpw - 1) / (kW1Waves * bpw)
+                                      : std::min<uint32_t>(static_cast<uint32_t>(h->n_cus), (total + kW1Waves - 1) / kW1Waves);
+#define GR4PM_W1_LAUNCH(A)                                                                                           \
+    hipLaunchKernelGGL(k_correlate_w64_one<A>, dim3(wgs1), dim3(kW1Threads), 0, stream, reinterpret_cast<const cf*>(in), \
+                       in_stride, n_blocks, total, static_cast<uint32_t>(h->S), h->tmpl64.p, h->tT64.p, h->cc64.p, zout, \
+                       h->z_stride, bpw, h->noise_off - h->zc)
+            if (one_mode == 2) GR4PM_W1_LAUNCH(1);
+            else if (one_mode == 3) GR4PM_W1_LAUNCH(2);
+            else GR4PM_W1_LAUNCH(0);
+#undef GR4PM_W1_LAUNCH
+            GR4PM_HIP_TRY(hipGetLastError());
+            return GR4PM_OK;
+        }
         switch (h->w64_variant) {
         case 8: GR4PM_W64_LAUNCH(8); break;
         case 32: GR4PM_W64_LAUNCH(32); break;
@@ -2029,6 +2049,7 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
         h->corr_kind = k == "pair" ? 2 : k == "wave" ? 1 : 0;
         const char* v = getenv("GR4PM_W64_VARIANT");
         h->w64_variant = v ? atoi(v) : -1;
+        h->w64_one = getenv("GR4PM_W64_ONE") ? atoi(getenv("GR4PM_W64_ONE")) : 0;
         if (const char* b = getenv("GR4PM_W64_BLOCKS_PER_WAVE")) h->w64_blocks_per_wave = static_cast<uint32_t>(std::max(0, atoi(b)));
         int dev = 0;
         hipDeviceProp_t prop;

@@ -243,6 +243,32 @@ def test_two_waves_per_block_correlator_is_bit_identical(pkg, monkeypatch):
         assert a.size >= 2 and same_tags(a, b)
 
 
+def test_one_bin_correlator_three_waves_per_simd_is_bit_identical(pkg, monkeypatch):
+    """correlate_w64_one.hpp (GR4PM_W64_ONE=1 when the handle is created: one frequency bin, twelve waves per CU, the
+    exchange through a half-size buffer in two passes) against the general kernel: the same powers bit for bit, the
+    same output and tags, over two calls with odd block counts and over two channels"""
+    locations = [100, 1000, 1250, 10000, 13721, 43124, 58000 - 64]
+    x, rrc = sig.qa_syncword_stream(60000, locations, 0.0, seed=21)
+    x = (x + sig.awgn(x.size, 0.2, 22)).astype(np.complex64)
+    xd = dev(x)
+    res = {}
+    for one in ("0", "1"):
+        monkeypatch.setenv("GR4PM_W64_ONE", one)
+        sd = pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, 0, 0, power_threshold=9.5, max_items=1 << 18)
+        outs, tags, z = [], [], []
+        for lo, hi in ((0, 100000), (100000 - 1600, x.size)):
+            st, o, t, n = sd.process_bulk(xd[lo:hi])
+            assert st == 0 and n > 0
+            outs.append(host(o)); tags.append(t); z.append(host(sd.last_zpow(n)))
+        res[one] = (outs, tags, z)
+    for a, b in zip(res["0"][2], res["1"][2]):
+        assert a.size > 50000 and np.array_equal(bits(a), bits(b))
+    for a, b in zip(res["0"][0], res["1"][0]):
+        assert np.array_equal(bits(a), bits(b))
+    for a, b in zip(res["0"][1], res["1"][1]):
+        assert a.size >= 2 and same_tags(a, b)
+
+
 @pytest.mark.parametrize("kind", ["wave", "pair"])
 def test_correlator_spin_timeout_is_reported(pkg, monkeypatch, kind):
     """the round-1 correlator kernels hand templates over through bounded spins: a spin that runs out raises the
