@@ -14,7 +14,7 @@ from .blocks import (SYNCWORD, AdditiveScrambler, BurstGenerator, CrcCheck, burs
                      PayloadMetadataInsert, PfbArbResampler, Rotator, SymbolFilter, SyncwordDetection,
                      SyncwordDetectionFilter, SyncwordRemove, SyncwordWipeoff, cfc_symbol_filter, cfc_symbol_filter_plan, cfc_symbol_filter_run,
                      header_ldpc_alist,
-                     header_parse, packet_transmitter_rrc_taps, root_raised_cosine, sincosf)
+                     header_parse, packet_transmitter_rrc_taps, root_raised_cosine, sincosf, costas_phase_wrap)
 
 _DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
 

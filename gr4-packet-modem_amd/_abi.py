@@ -182,7 +182,7 @@ class PfbArbParams(C.Structure):
 
 # every symbol include/gr4pm_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
-    "gr4pm_last_error", "gr4pm_version", "gr4pm_device_count", "gr4pm_set_deferred_sync", "gr4pm_sincosf",
+    "gr4pm_last_error", "gr4pm_version", "gr4pm_device_count", "gr4pm_set_deferred_sync", "gr4pm_sincosf", "gr4pm_costas_phase_wrap",
     "gr4pm_packet_receiver_set_symbol_pdu_callback",
     "gr4pm_syncword_detection_create", "gr4pm_syncword_detection_destroy",
     "gr4pm_syncword_detection_reset", "gr4pm_syncword_detection_syncword_samples_size",
@@ -385,6 +385,7 @@ def lib():
     L.gr4pm_packet_receiver_set_symbol_pdu_callback.argtypes = [vp, vp, vp]
     L.gr4pm_packet_receiver_inflight.restype = sz
     L.gr4pm_sincosf.argtypes = [vp, sz, vp, vp]
+    L.gr4pm_costas_phase_wrap.argtypes = [vp, sz, vp]
     L.gr4pm_firdes_root_raised_cosine.argtypes = [C.c_double] * 4 + [sz, vp]
     L.gr4pm_firdes_root_raised_cosine.restype = sz
     _lib = L

@@ -105,6 +105,15 @@ def sincosf(x):
     return s.cpu().numpy(), c.cpu().numpy()
 
 
+def costas_phase_wrap(x):
+    """the phase wrap of a CostasLoop iteration (costas_loop.hpp:141-145) as the kernels evaluate it, for the parity suite"""
+    torch = _torch()
+    xd = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32)).cuda()
+    out = torch.empty_like(xd)
+    check(lib().gr4pm_costas_phase_wrap(xd.data_ptr(), xd.numel(), out.data_ptr()), "costas_phase_wrap")
+    return out.cpu().numpy()
+
+
 def packet_transmitter_rrc_taps(samples_per_symbol):
     """packet_transmitter_rrc_taps.hpp:8-28: the transmitter's RRC (root_raised_cosine(1, sps, 1, 0.35, 11 sps))
     scaled so that the largest polyphase |tap| sum is 0.9 (DAC head-room), in the reference's float32 arithmetic

@@ -278,18 +278,46 @@ __device__ __forceinline__ void sincosf_glibc(float y, float* s_out, float* c_ou
     const double x6 = x4 * x2;
     const double cp = fma(x6, c2, fma(x4, C2, c1));
     float sn = static_cast<float>(sp), cs = static_cast<float>(cp);
-    // tiny arguments: glibc returns y and 1.0f (top 12 bits below those of 2^-12)
-    const bool tiny = ((__float_as_uint(y) >> 20) & 0x7ffu) < ((0x39800000u >> 20) & 0x7ffu);
-    sn = tiny ? y : sn;
-    cs = tiny ? 1.0f : cs;
+    // Tiny arguments (|y| < 2^-12): glibc returns y and 1.0f without evaluating anything.  The polynomials give the same
+    // bits by themselves -- cos: x^2 |C1| < 2^-25, so cp > 1 - 2^-25 rounds to 1.0f; sin: sp = x (1 - d) with d < 2^-26
+    // rounds back to y -- except for y = -0.0f, where the odd polynomial's sums produce +0.0.  The sign of the sine
+    // polynomial IS the sign of the reduced argument whenever the result is not zero, so copying x's sign bit into sn
+    // (one v_bfi_b32, no compare, no select) leaves every other value alone and restores the signed zero
+    // (tests/sincosf_glibc_check.c and test_device_sincosf_is_glibc_bit_exact sweep it).
+    // v_bitop3_b32 (gfx950): any function of three words in one instruction; 0xca = (a & b) | (~a & c), 0x78 = a ^ (b & c)
+    const unsigned sb = __builtin_amdgcn_bitop3_b32(0x7fffffffu, __float_as_uint(sn), static_cast<unsigned>(__double2hiint(x)), 0xca);
+    const unsigned cb = __float_as_uint(cs);
     // quadrant: sign[n & 3] on the sine argument (an odd polynomial: exact negation), second table =
-    // cosine polynomial negated when n & 2; odd n swaps the two
-    const unsigned ku = static_cast<unsigned>(n);
-    const bool swap = (ku & 1u) != 0;
-    const float s0 = swap ? cs : sn;
-    const float c0 = swap ? sn : cs;
-    *s_out = __uint_as_float(__float_as_uint(s0) ^ ((ku & 2u) << 30));
-    *c_out = __uint_as_float(__float_as_uint(c0) ^ (((ku + 1u) & 2u) << 30));
+    // cosine polynomial negated when n & 2; odd n swaps the two.  Bit arithmetic on a 0 / ~0 mask instead of
+    // compare + select: a v_cmp result needs wait states before the v_cndmask that reads it, and this chain has
+    // nothing to fill them with.  Eight instructions for tiny / swap / signs together (round 2: fifteen + 4 s_nop).
+    const unsigned swap = static_cast<unsigned>(__builtin_amdgcn_sbfe(n, 0, 1)); // 0 or ~0
+    const unsigned s0 = __builtin_amdgcn_bitop3_b32(swap, cb, sb, 0xca);
+    const unsigned c0 = __builtin_amdgcn_bitop3_b32(swap, sb, cb, 0xca);
+    const unsigned q = static_cast<unsigned>(n) << 30; // bit 31 = n & 2, bit 30 = n & 1
+    *s_out = __uint_as_float(__builtin_amdgcn_bitop3_b32(s0, q, 0x80000000u, 0x78));
+    *c_out = __uint_as_float(__builtin_amdgcn_bitop3_b32(c0, q + 0x40000000u, 0x80000000u, 0x78));
+}
+
+// costas_loop.hpp:141-145: phase >= pi ? phase - 2 pi : (phase < -pi ? phase + 2 pi : phase), without compares:
+//   up   = clamp(phase * K - below(pi) * K)   1.0f for phase > below(pi) <=> phase >= pi (below = the next float down),
+//   down = clamp(-phase * K - pi * K)         1.0f for phase < -pi, else 0.0f (K = 2^100: the smallest positive
+//                                             difference, one ulp of pi = 2^-22, still scales past 1)
+//   phase = fma(up - down, -2 pi, phase)
+// up - down is 1, -1 or +0 (at most one of the two is 1): fma(+-1, -2 pi, phase) is the reference's single rounding
+// of phase -+ 2 pi, and fma(+0, -2 pi, phase) = -0 + phase is phase bit for bit, the signed zeros included (a product
+// of +0 with a POSITIVE constant would turn a phase of -0.0 into +0.0).  Four instructions, no VCC round trip (was
+// six + wait states).
+__device__ __forceinline__ float costas_wrap(float phase, float pi_f)
+{
+    const float K = 0x1p100f, two_pi = 2.0f * pi_f;
+    const float pi_below = __uint_as_float(__float_as_uint(pi_f) - 1u);
+    float up, down;
+    asm("v_fma_f32 %0, %2, %3, -%4 clamp\n\t"
+        "v_fma_f32 %1, -%2, %3, -%5 clamp"
+        : "=&v"(up), "=&v"(down)
+        : "v"(phase), "v"(K), "v"(pi_below * K), "v"(pi_f * K));
+    return __builtin_fmaf(up - down, -two_pi, phase);
 }
 
 // one PLL iteration, costas_loop.hpp:112-146.  Everything is straight-line code (selects, no
@@ -314,8 +342,7 @@ __device__ __forceinline__ cf costas_step(cf x, float& phase, float& freq, float
     else error = (z.x > 0 ? z.y : -z.y) + (z.y > 0 ? -z.x : z.x);
     freq += k2 * error;
     phase += k1 * error + freq;
-    const float down = phase - 2.0f * pi_f, up = phase + 2.0f * pi_f;
-    phase = phase >= pi_f ? down : (phase < -pi_f ? up : phase);
+    phase = costas_wrap(phase, pi_f);
     return z;
 }
 
@@ -472,6 +499,12 @@ __global__ void k_sincosf(const float* __restrict__ x, size_t n, float* __restri
 {
     const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i < n) sincosf_glibc(x[i], sn + i, cs + i);
+}
+
+__global__ void k_costas_wrap(const float* __restrict__ x, size_t n, float* __restrict__ out)
+{
+    const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = costas_wrap(x[i], 3.14159265358979323846f);
 }
 
 template <typename T>
@@ -1842,6 +1875,17 @@ gr4pm_status gr4pm_sincosf(const float* x, size_t n, float* sin_out, float* cos_
     if (n == 0) return GR4PM_OK;
     hipLaunchKernelGGL(k_sincosf, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, nullptr, x, n, sin_out,
                        cos_out);
+    GR4PM_HIP_TRY(hipGetLastError());
+    GR4PM_HIP_TRY(hipStreamSynchronize(nullptr));
+    return GR4PM_OK;
+}
+
+gr4pm_status gr4pm_costas_phase_wrap(const float* x, size_t n, float* out)
+{
+    if (!x || !out) return GR4PM_ERR_INVALID;
+    GR4PM_TRY(require_device());
+    if (n == 0) return GR4PM_OK;
+    hipLaunchKernelGGL(k_costas_wrap, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, nullptr, x, n, out);
     GR4PM_HIP_TRY(hipGetLastError());
     GR4PM_HIP_TRY(hipStreamSynchronize(nullptr));
     return GR4PM_OK;

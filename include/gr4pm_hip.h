@@ -796,6 +796,12 @@ gr4pm_status gr4pm_burst_shaper_process(const void* in, size_t n, void* out, int
  * algorithm and are bit-exact with it for |x| < 120).  Exposed so that the parity suite can pin it directly. */
 gr4pm_status gr4pm_sincosf(const float* x, size_t n, float* sin_out, float* cos_out);
 
+/* The phase wrap at the end of a CostasLoop iteration on device arrays -- costas_loop.hpp:141-145
+ * (`if (phase >= pi) phase -= 2 pi; else if (phase < -pi) phase += 2 pi`, float).  The kernels evaluate it without
+ * compares (two fused multiply-adds with the clamp modifier); exposed so that the parity suite can pin it on the
+ * boundary values a signal rarely produces. */
+gr4pm_status gr4pm_costas_phase_wrap(const float* x, size_t n, float* out);
+
 /* firdes::root_raised_cosine<float> -- firdes.hpp:29-76 (host helper; out: ntaps|1 floats) */
 size_t gr4pm_firdes_root_raised_cosine(double gain, double sampling_freq, double symbol_rate,
                                        double alpha, size_t ntaps, float* out);

@@ -503,6 +503,26 @@ def test_device_sincosf_is_glibc_bit_exact(pkg):
     assert ds == 0 and dc == 0
 
 
+def test_device_costas_phase_wrap_is_exact(pkg):
+    """costas_loop.hpp:141-145 (phase >= pi: - 2 pi, phase < -pi: + 2 pi, in float) as the kernels evaluate it -- two
+    fused multiply-adds with the clamp modifier instead of compares -- on every float within 4096 ulps of +-pi, of
+    +-2 pi and of +-3 pi, the signed zeros, tiny values and 2^22 random phases"""
+    pi = np.float32(3.14159265358979323846)
+    two_pi = np.float32(2.0) * pi
+    rng = np.random.default_rng(2)
+    parts = [rng.uniform(-10.0, 10.0, 1 << 22).astype(np.float32),
+             np.float32([0.0, -0.0, 1e-30, -1e-30, pi, -pi, two_pi, -two_pi, 3.0, -3.0, 9.5, -9.5])]
+    for c in (pi, two_pi, np.float32(3.0) * pi):
+        near = np.float32(c).view(np.uint32) + np.arange(-4096, 4097, dtype=np.int64)
+        parts += [near.astype(np.uint32).view(np.float32), -near.astype(np.uint32).view(np.float32)]
+    x = np.concatenate(parts).astype(np.float32)
+    want = np.where(x >= pi, x - two_pi, np.where(x < -pi, x + two_pi, x)).astype(np.float32)
+    got = pkg.costas_phase_wrap(x)
+    bad = int(np.sum(got.view(np.uint32) != want.view(np.uint32)))
+    print("phase wrap: differing", bad, "of", x.size)
+    assert bad == 0
+
+
 # ------------------------------------------------------------------ Costas
 @pytest.mark.parametrize("constellation", ["PILOT", "BPSK", "QPSK"])
 def test_costas_loop(pkg, constellation):
