@@ -37,7 +37,9 @@
  *    correction / symbol_filter / costas_loop / interpolating_fir_filter / pfb_arb_resampler / syncword_wipeoff
  *    headers against the test stand-in tests/gr4_stub/ and compares their outputs with this oracle on exactly
  *    the paths listed above as pinned by code reading only (tags into SymbolFilter, CFC delay 26, float-rate
- *    resampler, phase tags into the Costas loop): bit-identical.
+ *    resampler, phase tags into the Costas loop): bit-identical.  syncword_detection.hpp itself is driven the same
+ *    way on orc_fft (below) as its gr::algorithm::FFTw: its items, tag positions and tag values equal orc_sd_process's
+ *    bit for bit, i.e. the detector scan (:267-298) and output_tag (:56-115) are restated without a slip.
  */
 #ifndef GR4PM_ORACLE_H
 #define GR4PM_ORACLE_H

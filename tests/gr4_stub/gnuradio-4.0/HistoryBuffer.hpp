@@ -1,7 +1,8 @@
 // TEST-ONLY stand-in (see Block.hpp) for gr::HistoryBuffer as the reference's FIR blocks use it
 // (symbol_filter.hpp:43,95-103,211-214; interpolating_fir_filter.hpp:34,65-72,94-99; pfb_arb_resampler.hpp:105-113,
 // 136-152): capacity a power of two, push_back() puts the newest item at index 0, cbegin() is a CONTIGUOUS
-// newest -> oldest range (std::inner_product walks it), push_back_bulk(range), size(), operator[], copyable.
+// newest -> oldest range (std::inner_product walks it), push_back_bulk(range), size(), operator[] (mutable for
+// syncword_detection.hpp:294), copyable.
 #pragma once
 #include <cstddef>
 #include <vector>
@@ -33,6 +34,10 @@ public:
     const T* cend() const { return cbegin() + _size; }
     const T* begin() const { return cbegin(); }
     const T* end() const { return cend(); }
-    const T& operator[](size_t i) const { return _buf[(_w % _cap) + i]; }
+    // indexed access goes to ONE of the two copies, the same one for reading and writing: syncword_detection.hpp:294
+    // sets `_history[i].detection = true` and reads the flag back hundreds of items later (a mirrored copy that is
+    // read on one side and written on the other loses detections)
+    const T& operator[](size_t i) const { return _buf[(_w + i) % _cap]; }
+    T& operator[](size_t i) { return _buf[(_w + i) % _cap]; }
 };
 } // namespace gr

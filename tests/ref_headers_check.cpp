@@ -14,6 +14,7 @@
 #include <gnuradio-4.0/packet-modem/pfb_arb_taps.hpp>
 #include <gnuradio-4.0/packet-modem/rotator.hpp>
 #include <gnuradio-4.0/packet-modem/symbol_filter.hpp>
+#include <gnuradio-4.0/packet-modem/syncword_detection.hpp>
 #include <gnuradio-4.0/packet-modem/syncword_wipeoff.hpp>
 #include <gnuradio-4.0/packet-modem/firdes.hpp>
 
@@ -115,6 +116,24 @@ int main(int argc, char** argv)
                     { { "rate", 1.1234 }, { "taps", pfb_arb_taps } });
                 run(b, in, out, chunk, [&](auto& is, auto& os) { return b.processBulk(is, os); });
             }
+        } else if (what == "syncword_detection" || what == "syncword_detection_1bin") {
+            // the reference's detector (start(): templates; processBulk(): overlap-save correlation, the best-bin / median
+            // scan over its mutable history, output_tag) on the oracle's FFT (gnuradio-4.0/algorithm/fourier/fftw.hpp)
+            const std::vector<uint8_t> sw = { 0, 0, 0, 0, 0, 0, 1, 1, 0, 1, 0, 0, 0, 1, 1, 1, 0, 1, 1, 1, 0, 1,
+                                              1, 0, 1, 1, 0, 0, 0, 1, 1, 1, 0, 0, 1, 0, 0, 1, 1, 1, 0, 0, 1, 0,
+                                              1, 0, 0, 0, 1, 0, 0, 1, 0, 1, 0, 1, 1, 0, 1, 1, 0, 0, 0, 0 }; // tests/_signals.py SYNCWORD
+            auto rrc = firdes::root_raised_cosine(1.0, 4.0, 1.0, 0.35, 44);
+            float norm = 0.0f;
+            for (float t : rrc) norm += t * t;
+            norm = std::sqrt(norm);
+            for (float& t : rrc) t /= norm;
+            const int edge = what == "syncword_detection" ? 4 : 0;
+            auto& b = fg.emplaceBlock<SyncwordDetection>(
+                { { "rrc_taps", rrc }, { "syncword", sw },
+                  { "constellation", std::vector<std::complex<float>>{ { 1.0f, 0.0f }, { -1.0f, 0.0f } } },
+                  { "min_freq_bin", -edge }, { "max_freq_bin", edge } });
+            b.start();
+            run(b, in, out, chunk, [&](auto& is, auto& os) { return b.processBulk(is, os); });
         } else if (what == "wipeoff") {
             std::vector<float> sw(64);
             for (size_t i = 0; i < 64; ++i) sw[i] = (i * 7 % 3) ? -1.0f : 1.0f;

@@ -146,6 +146,32 @@ def test_rotator_fir_resampler_wrappers(tmp_path):
     assert abs(arb.size - ref_arb.size) <= 2 and np.array_equal(arb[:n].view(np.uint64), ref_arb[:n].view(np.uint64))
 
 
+def test_reference_syncword_detection_header_on_the_stub_agrees_with_the_oracle(ref_check, tmp_path):
+    """syncword_detection.hpp itself -- start() (templates), the overlap-save correlation, the sequential best-bin /
+    median scan over its mutable history (:267-298), output_tag (:56-115) -- compiled against the stand-in with the
+    ORACLE's FFT underneath (gr4_stub/gnuradio-4.0/algorithm/fourier/fftw.hpp -> orc_fft), against the oracle's
+    restatement: the same items, the same tag positions and the same tag values bit for bit, at nine bins and at one,
+    over two chunkings.  Earns no parity credit (the API and the FFT under the block are stand-ins); it catches slips in
+    the restatement of the detector, whose float compare chain no reference test pins beyond tag positions."""
+    locations = [100, 1000, 1250, 10000, 13721, 43124, 58000 - 64]
+    x, rrc = sig.qa_syncword_stream(60000, locations, 0.007, seed=31)
+    x = (x + sig.awgn(x.size, 0.3, 32)).astype(np.complex64)
+    for case, edge in (("syncword_detection", 4), ("syncword_detection_1bin", 0)):
+        sd = orc.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -edge, edge)
+        st, want, want_tags = sd.process(x)
+        assert st == 0 and want_tags.size >= len(locations) - 1
+        for chunk in (1 << 20, 9000):
+            y, t, c, p = _run_ref(ref_check, tmp_path, case, x, chunk=chunk)
+            # with a 9000-item chunk the block takes 4 strides + one FFT length per call, the oracle everything at once:
+            # the tail the reference leaves unconsumed may be longer, what it did produce must agree
+            assert c == p and p <= want.size and want.size - p < 9000 + 2048
+            assert np.array_equal(_bits(y), _bits(want[:p]))
+            k = int(np.sum(want_tags["index"] < p))
+            assert t.size == k and np.array_equal(t["index"], want_tags["index"][:k])
+            for f in ("amplitude", "phase", "freq", "freq_bin", "noise_power", "esn0_db", "time_est"):
+                assert np.array_equal(t[f], want_tags[f][:k]), (case, chunk, f)
+
+
 @pytest.mark.gpu
 def test_device_arena_over_a_double_mapped_ring(tmp_path):
     """gnuradio4's CircularBuffer is mapped twice back to back: a producer span runs past the end of the first mapping
@@ -181,7 +207,9 @@ def ref_check(tmp_path_factory):
     exe = tmp_path_factory.mktemp("refcheck") / "ref_headers_check"
     subprocess.check_call(["g++", "-std=c++23", "-O2", "-ffp-contract=off", "-I", os.path.join(ROOT, "tests", "gr4_stub"),
                            "-I", REFERENCE_INCLUDE, "-I", os.path.join(ROOT, "tests"), "-o", str(exe),
-                           os.path.join(ROOT, "tests", "ref_headers_check.cpp")])
+                           os.path.join(ROOT, "tests", "ref_headers_check.cpp"),
+                           # the FFT under the reference's SyncwordDetection is the oracle's (gr4_stub/.../fftw.hpp)
+                           "-L", os.path.join(ROOT, "oracle"), "-lgr4pm_oracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle")])
     return str(exe)
 
 
