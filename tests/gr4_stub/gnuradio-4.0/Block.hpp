@@ -30,8 +30,28 @@
 #include <span>
 #include <stdexcept>
 #include <string>
+#include <string_view>
 #include <variant>
 #include <vector>
+
+// {fmt} comes with gnuradio4's Block.hpp; the reference uses fmt::format for exception texts and fmt::println under
+// #ifdef TRACE (syncword_detection_filter.hpp:117, payload_metadata_insert.hpp:115, ...).  The stand-in keeps the format
+// string and drops the arguments (libstdc++ 11 has no <format>).
+namespace fmt {
+template <typename... A>
+std::string format(std::string_view f, const A&...)
+{
+    return std::string(f);
+}
+template <typename... A>
+void println(std::string_view, const A&...)
+{
+}
+template <typename... A>
+void print(std::string_view, const A&...)
+{
+}
+} // namespace fmt
 
 namespace pmtv {
 using pmt = std::variant<std::monostate, bool, int32_t, int64_t, uint64_t, float, double, std::string,

@@ -146,6 +146,18 @@ def test_rotator_fir_resampler_wrappers(tmp_path):
     assert abs(arb.size - ref_arb.size) <= 2 and np.array_equal(arb[:n].view(np.uint64), ref_arb[:n].view(np.uint64))
 
 
+def test_remaining_reference_receive_headers_compile_on_the_stub(tmp_path):
+    """syncword_detection_filter / payload_metadata_insert / syncword_remove / constellation_llr_decoder /
+    additive_scrambler / header_payload_split of the reference, with processBulk() / processOne() instantiated on the
+    stand-in's span and message types: the stand-in declares the API surface these blocks use (nothing is run; their
+    arithmetic is pinned by the restated qa_*.cpp in test_oracle_reference_qa.py)"""
+    if not os.path.isdir(REFERENCE_INCLUDE):
+        pytest.skip("the reference tree is not on this machine")
+    subprocess.check_call(["g++", "-std=c++23", "-O1", "-I", os.path.join(ROOT, "tests", "gr4_stub"), "-I", REFERENCE_INCLUDE,
+                           "-o", str(tmp_path / "compile_only"), os.path.join(ROOT, "tests", "ref_headers_compile_only.cpp")])
+    assert subprocess.call([str(tmp_path / "compile_only")]) == 0
+
+
 def test_reference_syncword_detection_header_on_the_stub_agrees_with_the_oracle(ref_check, tmp_path):
     """syncword_detection.hpp itself -- start() (templates), the overlap-save correlation, the sequential best-bin /
     median scan over its mutable history (:267-298), output_tag (:56-115) -- compiled against the stand-in with the
