@@ -139,11 +139,16 @@ __device__ __forceinline__ cf rot_chunk_pk(cf e, cf inc)
 __global__ __launch_bounds__(64) void k_rot_checkpoints(const RotSeg* __restrict__ segs, unsigned n_segs,
                                                         const RotState* __restrict__ state,
                                                         RotState* __restrict__ state_next, cf* __restrict__ ck,
-                                                        cf* __restrict__ seg_incr, unsigned* __restrict__ seg_counter0)
+                                                        cf* __restrict__ seg_incr, unsigned* __restrict__ seg_counter0,
+                                                        const unsigned* __restrict__ order)
 {
     __builtin_amdgcn_s_setprio(GR4PM_SERIAL_PRIO); // latency-bound, few waves
-    const unsigned s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_segs) return;
+    const unsigned lane_seg = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane_seg >= n_segs) return;
+    // order[]: the segments by descending length, so that the long ones (a stream with missed detections) share
+    // waves -- a wave lives as long as its longest lane (see costas_process_impl); the array itself stays sorted by
+    // position (k_rot_apply and the fused symbol filter search it)
+    const unsigned s = order[lane_seg];
     const RotSeg* gp = segs + s;
     cf e, inc;
     unsigned counter;
@@ -1273,7 +1278,7 @@ struct gr4pm_rotator {
     struct Plan {
         DevBuf<RotSeg> segs;
         DevBuf<cf> ck, seg_incr;
-        DevBuf<unsigned> seg_counter0;
+        DevBuf<unsigned> seg_counter0, order;
         unsigned n_segs = 0;
         size_t n_in = 0;
         std::vector<unsigned> seg_first; // [n_channels + 1]: the segments of channel c are [seg_first[c], seg_first[c + 1])
@@ -1431,6 +1436,8 @@ static gr4pm_status rotator_plan(gr4pm_rotator* h, size_t n, const gr4pm_tag* ta
                 }
                 if (q.segs.n < n_segs) GR4PM_TRY(q.segs.alloc(n_segs * 2));
                 GR4PM_TRY(q.segs.reserve_stage(n_segs));
+                if (q.order.n < n_segs) GR4PM_TRY(q.order.alloc(n_segs * 2));
+                GR4PM_TRY(q.order.reserve_stage(n_segs));
             }
         }
     }
@@ -1446,12 +1453,20 @@ static gr4pm_status rotator_plan(gr4pm_rotator* h, size_t n, const gr4pm_tag* ta
         GR4PM_TRY(pl.seg_incr.alloc(n_segs * 2));
         GR4PM_TRY(pl.seg_counter0.alloc(n_segs * 2));
     }
+    {
+        static thread_local std::vector<unsigned> order;
+        order.resize(n_segs);
+        for (unsigned i = 0; i < n_segs; ++i) order[i] = i;
+        if (!getenv("GR4PM_ROT_NO_SORT"))
+            std::stable_sort(order.begin(), order.end(), [&](unsigned a, unsigned b) { return segs[a].len > segs[b].len; });
+        GR4PM_TRY(upload_vec(pl.order, order, s));
+    }
     static const unsigned wg = getenv("GR4PM_ROT_WG") ? static_cast<unsigned>(atoi(getenv("GR4PM_ROT_WG"))) : 64u;
     if (!timing_skip("rot")) // GR4PM_TIMING_SKIP: what a kernel costs the pipeline (results are garbage)
         hipLaunchKernelGGL(k_rot_checkpoints, dim3(grid_for(n_segs, wg)), dim3(wg), 0, s, pl.segs.p, n_segs,
                            h->state.p + static_cast<size_t>(h->st_cur) * h->n_channels,
                            h->state.p + static_cast<size_t>(h->st_cur ^ 1) * h->n_channels,
-                           pl.ck.p, pl.seg_incr.p, pl.seg_counter0.p);
+                           pl.ck.p, pl.seg_incr.p, pl.seg_counter0.p, pl.order.p);
     GR4PM_HIP_TRY(hipGetLastError());
     h->st_cur ^= 1;
     return GR4PM_OK;
@@ -1640,7 +1655,18 @@ static gr4pm_status costas_process_impl(gr4pm_costas_loop* h, const gr4pm_c64* i
         if (!segs.empty() && segs.back().channel == c) segs.back().last = 1;
     }
     hipStream_t s = h->stream;
+    // A wave lives as long as its longest lane.  Segments are independent of one another (carried state travels through
+    // the ping-pong state array, not through their order), so the longest ones are put together: a stream with missed
+    // detections (segments that run through several packets: 64 channels of configs[2] hold ~80 of five packets'
+    // length among 9700) then keeps two waves alive for the long tail instead of eighty.
+    if (!getenv("GR4PM_COSTAS_NO_SORT"))
+        std::stable_sort(segs.begin(), segs.end(), [](const CostasSeg& a, const CostasSeg& b) { return a.len > b.len; });
     GR4PM_TRY(upload_vec(h->segs, segs, s));
+    if (timing_skip("seg_stats")) { // GR4PM_TIMING_SKIP=seg_stats: what the serial kernel is given
+        size_t longest = 0, total = 0;
+        for (const auto& g : segs) longest = std::max<size_t>(longest, g.len), total += g.len;
+        fprintf(stderr, "[gr4pm costas] %zu segments, %zu items, longest %zu\n", segs.size(), total, longest);
+    }
     static const unsigned wg = getenv("GR4PM_COSTAS_WG") ? static_cast<unsigned>(atoi(getenv("GR4PM_COSTAS_WG"))) : 64u;
     const dim3 grid(grid_for(segs.size(), wg)), block(wg);
     const unsigned n_segs = static_cast<unsigned>(segs.size());
