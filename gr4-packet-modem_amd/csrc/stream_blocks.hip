@@ -325,9 +325,9 @@ __device__ __forceinline__ float costas_wrap(float phase, float pi_f)
     return __builtin_fmaf(up - down, -two_pi, phase);
 }
 
-// one PLL iteration, costas_loop.hpp:112-146.  Everything is straight-line code (selects, no
-// exec-mask branches): the chain of dependent float operations of one iteration is the whole
-// cost of the block.
+// one PLL iteration, costas_loop.hpp:112-146.  Everything is straight-line code without exec-mask branches; the phase
+// wrap and sincosf's quadrant logic also without compares (round 3; the QPSK error term keeps its two selects): the
+// chain of dependent operations of one iteration is the whole cost of the block.
 template <int CONSTELLATION>
 __device__ __forceinline__ cf costas_step(cf x, float& phase, float& freq, float k1, float k2)
 {
