@@ -96,10 +96,11 @@ def packet_stream(pkg, n_items, seed, device):
     return x[:n_items].contiguous(), n_pkt
 
 
-def burst_stream(pkg, n_items, rrc, seed, device, header=None):
+def burst_stream(pkg, n_items, rrc, seed, device, header=None, cfo=None):
     """synthetic 3.2 Msps-shaped bursts, generated on the GPU:
     packets of 64 (BPSK syncword) + 128 (header) + 1504*4 (payload) QPSK symbols, gaps of 500
-    zero symbols, CFO uniform in +-0.03 rad/sample per packet, AWGN at Es/N0 = 10 dB."""
+    zero symbols, CFO uniform in +-0.03 rad/sample per packet (cfo = f: the constant carrier offset f of the whole
+    stream instead, config 3's channels), AWGN at Es/N0 = 10 dB."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     pkt_syms, gap = 64 + 128 + 1504 * 4, 500
@@ -119,9 +120,13 @@ def burst_stream(pkg, n_items, rrc, seed, device, header=None):
     # pulse shaping with this package's own InterpolatingFirFilter kernel (the TX-side block the
     # reference uses to make its test signals, interpolating_fir_filter.hpp)
     x = pkg.InterpolatingFirFilter(SPS, rrc).process_bulk(sym.to(torch.complex64).contiguous())[:n_items]
-    cfo = (torch.rand(n_pkt, generator=g, device=device) * 0.06 - 0.03).repeat_interleave(period * SPS)[:n_items]
-    k = torch.arange(n_items, device=device) % (period * SPS)
-    x = x * torch.polar(torch.ones_like(cfo), cfo * k)
+    per_packet = (torch.rand(n_pkt, generator=g, device=device) * 0.06 - 0.03).repeat_interleave(period * SPS)[:n_items]
+    if cfo is None:
+        k = torch.arange(n_items, device=device) % (period * SPS)
+        x = x * torch.polar(torch.ones_like(per_packet), per_packet * k)
+    else:  # (the draw above keeps the generator's sequence, i.e. the noise, independent of the choice)
+        ph = (torch.arange(n_items, device=device, dtype=torch.float64) * float(cfo)) % (2.0 * np.pi)
+        x = x * torch.polar(torch.ones(n_items, device=device), ph.to(torch.float32))
     sigma = np.float32(np.sqrt(0.1 / 2.0))  # Es = 1 per symbol -> N0 = 0.1
     noise = torch.complex(torch.randn(n_items, generator=g, device=device) * sigma,
                           torch.randn(n_items, generator=g, device=device) * sigma)
@@ -220,6 +225,20 @@ def channel_bank(x, n_channels):
     for c in range(n_channels):
         f = -0.04 + 0.08 * c / max(n_channels - 1, 1)
         xs[c] = x.roll(997 * c) * torch.polar(torch.ones_like(k), (f * k) % (2 * np.pi))
+    return xs
+
+
+def channel_bank_config3(pkg, n_items, rrc, n_channels, device, seed0=0):
+    """configs[2] / [3] as SURVEY.md 8(d) config 3 defines the channels: channel c is its own burst stream (seed
+    seed0 + c) with a carrier offset of -0.04 + 0.08 c / (C - 1) rad/sample -- inside the +-4-bin search range
+    (+-0.0423), so every channel's packets can be found.  (channel_bank() puts that sweep ON TOP of a stream whose
+    packets already carry +-0.03: its edge channels lie outside the range and lose detections, which the parity test of
+    the multi-channel receiver wants; as a throughput workload it measured missed detections -- serial segments five
+    packets long -- rather than the configuration.)"""
+    xs = torch.empty((n_channels, n_items), dtype=torch.complex64, device=device)
+    for c in range(n_channels):
+        f = -0.04 + 0.08 * c / max(n_channels - 1, 1)
+        xs[c] = burst_stream(pkg, n_items, rrc, seed=seed0 + c, device=device, cfo=f)[0]
     return xs
 
 
@@ -484,20 +503,18 @@ def channels64_leg(pkg, dist, device, rank, world, rrc, steps, warmup, repeats, 
     sample ring [N, 64, 2^22] and scatters one [64, 2^22] slab per rank (the job's backend: RCCL on the GPUs); every
     rank then runs its 64 channels through gr4pm_multichannel_receiver (one batched detector + every channel's own
     chain, submit / collect with four batches in flight, input read in place).  Timed like the headline region."""
-    x, n_pkt = burst_stream(pkg, n_items, rrc, seed=77 + rank, device=device)
+    n_pkt = (n_items // SPS + 64) // (64 + 128 + 1504 * 4 + 500) + 1  # packets per channel and batch (burst_stream)
     if dist:
         def make_all():
             host, _ = host_sample_ring(world, (channels, n_items))
             for r in range(world):
-                xr = x if r == 0 else burst_stream(pkg, n_items, rrc, seed=77 + r, device=device)[0]
-                host[r].copy_(channel_bank(xr, channels))
+                host[r].copy_(channel_bank_config3(pkg, n_items, rrc, channels, device, seed0=1000 * (r + 1)))
             return host.to(device, non_blocking=False)
         xs = scatter_channels(dist, make_all, (channels, n_items), device, rank, world)
         input_mode = f"rank 0 host sample ring [{world}, {channels}, {n_items}] -> all ranks, scatter ({dist.get_backend()})"
     else:
-        xs = channel_bank(x, channels)
+        xs = channel_bank_config3(pkg, n_items, rrc, channels, device, seed0=1000 * (rank + 1))
         input_mode = "generated on the GPU"
-    del x
     multi = pkg.NativeMultiChannelReceiver(channels, SPS, BINS, 9.5, "QPSK", max_items=n_items,
                                            tags_cap=max(64, 2 * n_pkt + 64), workers=12, output_ring=True)
     multi.set_input_in_place(True)
@@ -655,7 +672,7 @@ def main():
             def make_all():
                 host, _ = host_sample_ring(world, (args.channels, n_items))
                 for r in range(world):
-                    host[r].copy_(channel_bank(x if r == 0 else make_stream(1 + r)[0], args.channels))
+                    host[r].copy_(channel_bank_config3(pkg, n_items, rrc, args.channels, device, seed0=1000 * (r + 1)))
                 return host.to(device, non_blocking=False)
             xs_bank = scatter_channels(dist, make_all, (args.channels, n_items), device, rank, world)
             input_mode = (f"rank 0 host sample ring [{world}, {args.channels}, {n_items}] -> all ranks, "
@@ -694,11 +711,11 @@ def main():
     out_keep = None
     multi = None
     if args.channels > 1:
-        # config 3: per-channel CFO sweep -0.04 .. +0.04 rad/sample on top of the burst stream
+        # config 3: every channel its own burst stream (seed) with a carrier offset of -0.04 .. +0.04 rad/sample
         full_chain = not args.detector_only
         args.detector_only = True
         C = args.channels
-        xs = xs_bank if xs_bank is not None else channel_bank(x, C)
+        xs = xs_bank if xs_bank is not None else channel_bank_config3(pkg, n_items, rrc, C, device, seed0=1000 * (rank + 1))
         x = xs
         windows = [(xs, None), (xs, None)]
         if full_chain:
