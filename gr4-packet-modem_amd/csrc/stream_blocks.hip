@@ -805,10 +805,14 @@ __device__ __forceinline__ void cfc_fill_tile(const SymWg& p, unsigned span, uns
                     // whole chunk inside the span (and on one side of a two-piece input) and no renormalisation
                     // among its 7 steps (the usual case): straight-line packed arithmetic, same operations as below
                     const unsigned i0 = static_cast<unsigned>(idx0 - p.lo_item);
-                    const cf* __restrict__ src = idx0 >= n_head ? in + (idx0 - n_head) : head + idx0;
+                    // (explicitly a global-memory pointer: in the multi-channel launch `in` / `head` are loaded from the
+                    // channel table, which makes them generic pointers and these loads flat_load -- both address paths,
+                    // both wait counters -- instead of global_load)
+                    typedef const float __attribute__((address_space(1))) * gflt;
+                    const gflt src = (gflt)(idx0 >= n_head ? in + (idx0 - n_head) : head + idx0);
                     cf x[kRotChunk];
 #pragma unroll
-                    for (unsigned t = 0; t < kRotChunk; ++t) x[t] = src[t];
+                    for (unsigned t = 0; t < kRotChunk; ++t) x[t] = cf{ src[2 * t], src[2 * t + 1] };
 #pragma unroll
                     for (unsigned t = 0; t < kRotChunk; ++t) {
                         const unsigned i = i0 + t;
