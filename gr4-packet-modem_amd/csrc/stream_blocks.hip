@@ -646,7 +646,14 @@ struct SymWg {
     float scale;
     unsigned seg;      // fused CFC: segment of max(lo_item, 0)
     unsigned chan;     // index into the SymChan table (launches that span channels)
+    // what the fused CFC needs of segment `seg` (RotSeg start / len / ck0, the increment and the counter that
+    // k_rot_checkpoints left for it): one scalar load of this entry instead of three dependent ones in front of every
+    // workgroup's first vector load.  Spans that run into further segments read those from the tables.
+    unsigned long long seg_start, seg_len;
+    unsigned seg_ck0, seg_counter0;
+    cf seg_incr;
 };
+static_assert(sizeof(SymWg) == 64, "one 64-byte scalar load per workgroup");
 // Fused CoarseFrequencyCorrection: when the symbol filter is fed by a CFC block, the rotation
 // is applied while the filter stages its input (the rotated stream is never written to HBM).
 struct CfcDev {
@@ -763,6 +770,15 @@ __global__ void k_symf_wg_plan(const SymRun* __restrict__ runs, unsigned n_runs,
     if (chans) cfc = chan_cfc(chans[r.chan], cfc.ck);
     p.seg = cfc.n_segs ? cfc_find_seg(cfc, p.lo_item) : 0u;
     p.chan = r.chan;
+    p.seg_start = p.seg_len = 0;
+    p.seg_ck0 = p.seg_counter0 = 0;
+    p.seg_incr = cf{ 0.f, 0.f };
+    if (cfc.n_segs) {
+        const RotSeg g = cfc.segs[p.seg];
+        p.seg_start = g.start, p.seg_len = g.len, p.seg_ck0 = g.ck0;
+        p.seg_incr = cfc.seg_incr[p.seg];
+        p.seg_counter0 = cfc.seg_counter0[p.seg];
+    }
     plan[w] = p;
 }
 
@@ -785,12 +801,19 @@ __device__ __forceinline__ void cfc_fill_tile(const SymWg& p, unsigned span, uns
     const long long lo = p.lo_item < 0 ? 0 : p.lo_item;
     const long long hi = p.lo_item + span;
     for (unsigned sg = p.seg; sg < cfc.n_segs; ++sg) {
-        const RotSeg g = cfc.segs[sg];
+        RotSeg g;
+        cf inc;
+        unsigned c0;
+        if (sg == p.seg) { // (uniform) the usual case, and the only segment of most spans: everything is in the plan entry
+            g.start = p.seg_start, g.len = p.seg_len, g.ck0 = p.seg_ck0;
+            inc = p.seg_incr, c0 = p.seg_counter0;
+        } else {
+            g = cfc.segs[sg];
+            inc = cfc.seg_incr[sg], c0 = cfc.seg_counter0[sg];
+        }
         const long long a = max(static_cast<long long>(g.start), lo);
         const long long b = min(static_cast<long long>(g.start + g.len), hi);
         if (a < b) {
-            const cf inc = cfc.seg_incr[sg];
-            const unsigned c0 = cfc.seg_counter0[sg];
             const unsigned long long c_first = static_cast<unsigned long long>(a - g.start) / kRotChunk;
             const unsigned n_chunks =
                 static_cast<unsigned>(static_cast<unsigned long long>(b - 1 - g.start) / kRotChunk - c_first) + 1;
@@ -903,13 +926,28 @@ __global__ __launch_bounds__(kSymPerWg) void k_symbol_filter(const T* __restrict
 constexpr unsigned kFastSym = 240, kFastThreads = 128, kFastArm = 44, kFastSps = 4;
 constexpr unsigned kFastPitch = ((kFastSym - 1) * kFastSps + kFastArm) / kFastSps + 2; // entries per phase row (even)
 static_assert(kFastPitch % 2 == 0, "16-byte reads need even rows");
-__global__ __launch_bounds__(kFastThreads) void k_symbol_filter_fast(const cf* __restrict__ in, const cf* __restrict__ carry,
+// ABL (timing only, wrong results; GR4PM_SYMF_ABL): 1 = no MAC phase, 2 = no tile fill (no item loads, no rotation)
+template <int ABL>
+__global__ __launch_bounds__(kFastThreads) void k_symbol_filter_fast(const cf* __restrict__ in0, const cf* __restrict__ carry0,
                                                                      unsigned cap, const float* __restrict__ taps,
-                                                                     const SymWg* __restrict__ plan, cf* __restrict__ out,
-                                                                     CfcDev cfc, const SymChan* __restrict__ chans)
+                                                                     const SymWg* __restrict__ plan, cf* __restrict__ out0,
+                                                                     CfcDev cfc0, const SymChan* __restrict__ chans,
+                                                                     unsigned n_wg, unsigned tiles)
 {
     __shared__ __attribute__((aligned(16))) cf tile[kFastSps * kFastPitch];
-    const SymWg p = plan[blockIdx.x];
+    // `tiles` consecutive plan entries per workgroup: the entry of the NEXT tile is requested (one 64-byte scalar load)
+    // before this tile's work starts, so that from the second tile on the vector loads of the fill go out at once --
+    // alone the kernel is bound by (workgroups a CU holds) / (life time of one), and two thirds of that life time
+    // were round trips in front of the first vector load: plan entry -> segment -> increment / counter
+    unsigned w = blockIdx.x * tiles;
+    const unsigned w_end = min(w + tiles, n_wg);
+    SymWg p = plan[w];
+    for (; w < w_end; ++w) {
+    const SymWg p_next = plan[min(w + 1, n_wg - 1)];
+    const cf* in = in0;
+    const cf* carry = carry0;
+    cf* out = out0;
+    CfcDev cfc = cfc0;
     const cf* head = nullptr;
     long long n_head = 0;
     if (chans) { // a launch that spans channels: the workgroup's channel supplies the pointers
@@ -922,14 +960,18 @@ __global__ __launch_bounds__(kFastThreads) void k_symbol_filter_fast(const cf* _
         n_head = static_cast<long long>(c.n_head);
     }
     const unsigned span = (p.count - 1) * kFastSps + kFastArm;
-    cfc_fill_tile<kFastThreads>(p, span, kFastSps, kFastPitch, tile, in, carry, cap, cfc, head, n_head);
+    if (!(ABL & 2)) cfc_fill_tile<kFastThreads>(p, span, kFastSps, kFastPitch, tile, in, carry, cap, cfc, head, n_head);
     const float* __restrict__ tp = taps + static_cast<size_t>(p.arm) * kFastArm; // uniform: scalar loads
     float tap[kFastArm];
 #pragma unroll
     for (unsigned m = 0; m < kFastArm; ++m) tap[m] = tp[m];
     __syncthreads();
     const unsigned l = threadIdx.x;
-    if (2 * l >= p.count) return;
+    if (2 * l < p.count) {
+    if (ABL & 1) {
+        out[p.o0 + 2 * l] = cf{ tap[0], tap[1] };
+        if (2 * l + 1 < p.count) out[p.o0 + 2 * l + 1] = cf{ tap[2], tap[3] };
+    } else {
     // pair(ph, k) = tile entries (ph, 2l + 2k) and (ph, 2l + 2k + 1); symbol A = 2l uses entry 2l + q at tap position
     // q = j / 4 of phase ph = j % 4 (j = 43 - m), symbol B = 2l + 1 uses entry 2l + 1 + q
     const float4* rows = reinterpret_cast<const float4*>(tile) + l;
@@ -990,6 +1032,11 @@ __global__ __launch_bounds__(kFastThreads) void k_symbol_filter_fast(const cf* _
     }
     out[p.o0 + 2 * l] = scale_item(p.scale, cf{ accA.x, accA.y });
     if (2 * l + 1 < p.count) out[p.o0 + 2 * l + 1] = scale_item(p.scale, cf{ accB.x, accB.y });
+    }
+    }
+    if (w + 1 < w_end) __syncthreads(); // the tile is free for the next fill
+    p = p_next;
+    }
 }
 
 // GR4PM_TIMING_SKIP=symf_fake / costas_fake: timing experiments only.  Stand-ins with the memory traffic (symbol
@@ -1040,9 +1087,20 @@ static void launch_symbol_filter(hipStream_t s, unsigned n_wg, size_t smem, unsi
         if (symf_fast(true, sps, arm_size)) {
             if (timing_skip("symf_fake"))
                 hipLaunchKernelGGL(k_symf_fake, grid, dim3(kFastThreads), 0, s, in, plan, out);
-            else if (!timing_skip("symf"))
-            hipLaunchKernelGGL(k_symbol_filter_fast, grid, dim3(kFastThreads), 0, s, in, carry, cap, taps, plan, out, cfc,
-                               chans);
+            else if (!timing_skip("symf")) {
+                static const int abl = getenv("GR4PM_SYMF_ABL") ? atoi(getenv("GR4PM_SYMF_ABL")) : 0;
+                static const unsigned pad = getenv("GR4PM_SYMF_PAD") ? static_cast<unsigned>(atoi(getenv("GR4PM_SYMF_PAD"))) : 0u;
+                static const unsigned tiles = getenv("GR4PM_SYMF_TILES") ? static_cast<unsigned>(std::max(1, atoi(getenv("GR4PM_SYMF_TILES")))) : 4u;
+                const dim3 gridf((n_wg + tiles - 1) / tiles);
+#define GR4PM_SYMF_LAUNCH(A)                                                                                         \
+    hipLaunchKernelGGL(k_symbol_filter_fast<A>, gridf, dim3(kFastThreads), pad, s, in, carry, cap, taps, plan, out, cfc, \
+                       chans, n_wg, tiles)
+                if (abl == 1) GR4PM_SYMF_LAUNCH(1);
+                else if (abl == 2) GR4PM_SYMF_LAUNCH(2);
+                else if (abl == 3) GR4PM_SYMF_LAUNCH(3);
+                else GR4PM_SYMF_LAUNCH(0);
+#undef GR4PM_SYMF_LAUNCH
+            }
             return;
         }
     }
