@@ -1090,7 +1090,7 @@ static void launch_symbol_filter(hipStream_t s, unsigned n_wg, size_t smem, unsi
             else if (!timing_skip("symf")) {
                 static const int abl = getenv("GR4PM_SYMF_ABL") ? atoi(getenv("GR4PM_SYMF_ABL")) : 0;
                 static const unsigned pad = getenv("GR4PM_SYMF_PAD") ? static_cast<unsigned>(atoi(getenv("GR4PM_SYMF_PAD"))) : 0u;
-                static const unsigned tiles = getenv("GR4PM_SYMF_TILES") ? static_cast<unsigned>(std::max(1, atoi(getenv("GR4PM_SYMF_TILES")))) : 4u;
+                static const unsigned tiles = getenv("GR4PM_SYMF_TILES") ? static_cast<unsigned>(std::max(1, atoi(getenv("GR4PM_SYMF_TILES")))) : 2u;
                 const dim3 gridf((n_wg + tiles - 1) / tiles);
 #define GR4PM_SYMF_LAUNCH(A)                                                                                         \
     hipLaunchKernelGGL(k_symbol_filter_fast<A>, gridf, dim3(kFastThreads), pad, s, in, carry, cap, taps, plan, out, cfc, \
