@@ -927,8 +927,10 @@ constexpr unsigned kFastSym = 240, kFastThreads = 128, kFastArm = 44, kFastSps =
 constexpr unsigned kFastPitch = ((kFastSym - 1) * kFastSps + kFastArm) / kFastSps + 2; // entries per phase row (even)
 static_assert(kFastPitch % 2 == 0, "16-byte reads need even rows");
 // ABL (timing only, wrong results; GR4PM_SYMF_ABL): 1 = no MAC phase, 2 = no tile fill (no item loads, no rotation)
+// (second launch bound: eight waves per SIMD, i.e. at most 64 VGPRs -- hipcc takes 80 when left alone, and the kernel is
+// bound by the workgroups a CU holds: 16 instead of 12)
 template <int ABL>
-__global__ __launch_bounds__(kFastThreads) void k_symbol_filter_fast(const cf* __restrict__ in0, const cf* __restrict__ carry0,
+__global__ __launch_bounds__(kFastThreads, 8) void k_symbol_filter_fast(const cf* __restrict__ in0, const cf* __restrict__ carry0,
                                                                      unsigned cap, const float* __restrict__ taps,
                                                                      const SymWg* __restrict__ plan, cf* __restrict__ out0,
                                                                      CfcDev cfc0, const SymChan* __restrict__ chans,
