@@ -1089,6 +1089,27 @@ def test_packet_receiver_full_size_round_trip(pkg):
     assert len(got) >= complete and got == payloads[: len(got)]
 
 
+def test_config3_channel_bank_every_packet_is_found(pkg):
+    """the channels bench.py builds for configs[2] / [3] (channel c = its own burst stream, seed
+    c, carrier offset -0.04 + 0.08 c / (C - 1) rad/sample) lie inside the +-4-bin search range: the detector finds every
+    packet of every channel, so no serial segment of the chain is longer than one packet period"""
+    import bench
+    C, n = 8, 1 << 20
+    device = torch.device("cuda")
+    rrc = bench.unit_norm_rrc(pkg)
+    xs = bench.channel_bank_config3(pkg, n, rrc, C, device, seed0=3)
+    period = (64 + 128 + 1504 * 4 + 500) * 4
+    sd = pkg.SyncwordDetection(rrc, bench.SYNCWORD, np.array([1, -1], dtype=np.complex64), -4, 4, power_threshold=9.5,
+                               n_channels=C, max_items=n)
+    st, out, tags, nd = sd.process_bulk(xs, want_output=False, tags_cap=256)
+    assert st == 0
+    expected = (nd - 1537 - 300) // period  # whole packets inside the produced range
+    for c in range(C):
+        idx = np.sort(tags[c]["index"].astype(np.int64))
+        assert idx.size >= expected, (c, idx.size, expected)
+        assert np.all(np.diff(idx) < 1.5 * period), c   # no gap of two packets between detections
+
+
 def test_multichannel_receiver_full_size_config2(pkg):
     """BASELINE configs[2] at its full size: 64 channels x 2^22 samples per batch (the bench's burst stream with the
     per-channel CFO sweep), three batches in flight with the streaming stride.  Size-independent properties: the
