@@ -789,7 +789,13 @@ __global__ void k_symf_wg_plan(const SymRun* __restrict__ runs, unsigned n_runs,
 //     memory, replays the phasor recurrence of the chunk once (kRotChunk-1 steps for kRotChunk items) and writes the
 //     rotated items to the tile; segment by segment (usually one).  The raw items are not staged in LDS (round 1 did):
 //     half the LDS footprint, one barrier and one global-memory latency less per workgroup.
-template <unsigned THREADS>
+// ORIGIN (a multiple of sps and of kRotChunk): item i of the span lives at tile index i + ORIGIN, and a chunk that
+// only PARTLY overlaps the span is written whole, its other items into the ORIGIN entries in front of the span or the
+// kRotChunk behind it -- as long as the whole chunk lies inside its segment (then its raw items exist).  With
+// ORIGIN = 0 a partly overlapping chunk goes item by item through the path at the bottom (about 220 instructions for
+// its whole wave): the first and the last chunk of almost every span, i.e. both waves of every workgroup of the
+// receiver's filter.
+template <unsigned THREADS, unsigned ORIGIN = 0>
 __device__ __forceinline__ void cfc_fill_tile(const SymWg& p, unsigned span, unsigned sps, unsigned pitch, cf* tile,
                                               const cf* __restrict__ in, const cf* __restrict__ carry, unsigned cap,
                                               const CfcDev& cfc, const cf* __restrict__ head = nullptr,
@@ -797,7 +803,7 @@ __device__ __forceinline__ void cfc_fill_tile(const SymWg& p, unsigned span, uns
 {
     if (p.lo_item < 0)
         for (unsigned i = threadIdx.x; i < span && p.lo_item + i < 0; i += THREADS)
-            tile[(i % sps) * pitch + i / sps] = carry[static_cast<long long>(cap) + p.lo_item + i];
+            tile[((i + ORIGIN) % sps) * pitch + (i + ORIGIN) / sps] = carry[static_cast<long long>(cap) + p.lo_item + i];
     const long long lo = p.lo_item < 0 ? 0 : p.lo_item;
     const long long hi = p.lo_item + span;
     for (unsigned sg = p.seg; sg < cfc.n_segs; ++sg) {
@@ -822,12 +828,14 @@ __device__ __forceinline__ void cfc_fill_tile(const SymWg& p, unsigned span, uns
                 cf e = cfc.ck[g.ck0 + c];
                 unsigned counter = c0 + static_cast<unsigned>(c * kRotChunk);
                 const long long idx0 = static_cast<long long>(g.start + c * kRotChunk);
-                if (idx0 >= a && idx0 + static_cast<long long>(kRotChunk) <= b &&
-                    (counter & 511u) <= 512u - kRotChunk &&
+                const bool whole = ORIGIN ? idx0 + static_cast<long long>(kRotChunk) <= static_cast<long long>(g.start + g.len)
+                                          : idx0 >= a && idx0 + static_cast<long long>(kRotChunk) <= b;
+                if (whole && (counter & 511u) <= 512u - kRotChunk &&
                     (idx0 >= n_head || idx0 + static_cast<long long>(kRotChunk) <= n_head)) {
-                    // whole chunk inside the span (and on one side of a two-piece input) and no renormalisation
-                    // among its 7 steps (the usual case): straight-line packed arithmetic, same operations as below
-                    const unsigned i0 = static_cast<unsigned>(idx0 - p.lo_item);
+                    // whole chunk inside the span or (ORIGIN) at least inside the segment, on one side of a two-piece
+                    // input, and no renormalisation among its 7 steps (the usual case): straight-line packed arithmetic,
+                    // same operations as below.  (With ORIGIN the index can start up to kRotChunk - 1 in front of the span.)
+                    const unsigned i0 = static_cast<unsigned>(idx0 - p.lo_item + static_cast<long long>(ORIGIN));
                     // (explicitly a global-memory pointer: in the multi-channel launch `in` / `head` are loaded from the
                     // channel table, which makes them generic pointers and these loads flat_load -- both address paths,
                     // both wait counters -- instead of global_load)
@@ -848,7 +856,7 @@ __device__ __forceinline__ void cfc_fill_tile(const SymWg& p, unsigned span, uns
                 for (unsigned t = 0; t < kRotChunk; ++t) {
                     const long long idx = idx0 + t;
                     if (idx >= a && idx < b) {
-                        const unsigned i = static_cast<unsigned>(idx - p.lo_item);
+                        const unsigned i = static_cast<unsigned>(idx - p.lo_item) + ORIGIN;
                         const cf x = idx < n_head ? head[idx] : in[idx - n_head];
                         tile[(i % sps) * pitch + i / sps] = cmul(x, e); // hpp:87
                     }
@@ -924,8 +932,11 @@ __global__ __launch_bounds__(kSymPerWg) void k_symbol_filter(const T* __restrict
 //     rotation phase with 98 % of the lanes busy (256 symbols: 134 chunks on 256 lanes)
 // MAC order as in the reference (std::inner_product, tap index ascending), every product and sum rounded once: bit-exact.
 constexpr unsigned kFastSym = 240, kFastThreads = 128, kFastArm = 44, kFastSps = 4;
-constexpr unsigned kFastPitch = ((kFastSym - 1) * kFastSps + kFastArm) / kFastSps + 2; // entries per phase row (even)
-static_assert(kFastPitch % 2 == 0, "16-byte reads need even rows");
+constexpr unsigned kFastOrigin = 8; // tile index of the span's first item: room for a chunk that starts in front of it
+constexpr unsigned kFastPitch = 256; // entries per phase row: (8 + 1000 + 7) / 4 = 254 used, 8 KiB per tile
+static_assert(kFastPitch % 2 == 0 && kFastPitch * kFastSps >= kFastOrigin + (kFastSym - 1) * kFastSps + kFastArm + kRotChunk - 1 &&
+                  kFastOrigin % 8 == 0,
+              "16-byte reads need even rows; the margins of partly overlapping chunks need room");
 // ABL (timing only, wrong results; GR4PM_SYMF_ABL): 1 = no MAC phase, 2 = no tile fill (no item loads, no rotation)
 // (second launch bound: eight waves per SIMD, i.e. at most 64 VGPRs -- hipcc takes 80 when left alone, and the kernel is
 // bound by the workgroups a CU holds: 16 instead of 12)
@@ -962,7 +973,7 @@ __global__ __launch_bounds__(kFastThreads, 8) void k_symbol_filter_fast(const cf
         n_head = static_cast<long long>(c.n_head);
     }
     const unsigned span = (p.count - 1) * kFastSps + kFastArm;
-    if (!(ABL & 2)) cfc_fill_tile<kFastThreads>(p, span, kFastSps, kFastPitch, tile, in, carry, cap, cfc, head, n_head);
+    if (!(ABL & 2)) cfc_fill_tile<kFastThreads, kFastOrigin>(p, span, kFastSps, kFastPitch, tile, in, carry, cap, cfc, head, n_head);
     const float* __restrict__ tp = taps + static_cast<size_t>(p.arm) * kFastArm; // uniform: scalar loads
     float tap[kFastArm];
 #pragma unroll
@@ -976,7 +987,7 @@ __global__ __launch_bounds__(kFastThreads, 8) void k_symbol_filter_fast(const cf
     } else {
     // pair(ph, k) = tile entries (ph, 2l + 2k) and (ph, 2l + 2k + 1); symbol A = 2l uses entry 2l + q at tap position
     // q = j / 4 of phase ph = j % 4 (j = 43 - m), symbol B = 2l + 1 uses entry 2l + 1 + q
-    const float4* rows = reinterpret_cast<const float4*>(tile) + l;
+    const float4* rows = reinterpret_cast<const float4*>(tile) + l + kFastOrigin / (2 * kFastSps); // two entries per float4
     constexpr unsigned kRow4 = kFastPitch / 2; // float4 per phase row
     // The MACs as packed FP32: v_pk_mul_f32 (re, im) x (tap, tap) -- the tap broadcast from one half of an SGPR pair by
     // op_sel -- and v_pk_add_f32 onto the accumulator: every product and every sum still rounded once, in the
