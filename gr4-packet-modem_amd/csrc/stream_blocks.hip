@@ -234,6 +234,30 @@ __global__ __launch_bounds__(256) void k_rot_apply(const RotSeg* __restrict__ se
     (void)n_segs;
 }
 
+// x[t] *= e_t for the eight items of a checkpoint chunk, e_(t+1) = e_t * inc in between (coarse_frequency_correction.hpp:
+// 87, rotator.hpp:58-59): cmul_pk's three packed instructions per product, all 45 in ONE statement -- between separate
+// asm statements hipcc pads every dependent packed pair with an s_nop (21 of them in this chain).
+__device__ __forceinline__ void rot8_pk(cf (&x)[kRotChunk], cf e, cf inc)
+{
+    static_assert(kRotChunk == 8, "eight items below");
+    cf a, b;
+#define GR4PM_X(n)                                                          \
+    "v_pk_mul_f32 %[a], %[x" #n "], %[e] op_sel_hi:[0,1]\n"                 \
+    "v_pk_mul_f32 %[b], %[x" #n "], %[e] op_sel:[1,1] op_sel_hi:[1,0]\n"    \
+    "v_pk_add_f32 %[x" #n "], %[a], %[b] neg_lo:[0,1] neg_hi:[0,0]\n"
+#define GR4PM_E                                                             \
+    "v_pk_mul_f32 %[a], %[e], %[i] op_sel_hi:[0,1]\n"                       \
+    "v_pk_mul_f32 %[b], %[e], %[i] op_sel:[1,1] op_sel_hi:[1,0]\n"          \
+    "v_pk_add_f32 %[e], %[a], %[b] neg_lo:[0,1] neg_hi:[0,0]\n"
+    asm(GR4PM_X(0) GR4PM_E GR4PM_X(1) GR4PM_E GR4PM_X(2) GR4PM_E GR4PM_X(3) GR4PM_E GR4PM_X(4) GR4PM_E GR4PM_X(5) GR4PM_E
+            GR4PM_X(6) GR4PM_E GR4PM_X(7)
+        : [x0] "+v"(x[0]), [x1] "+v"(x[1]), [x2] "+v"(x[2]), [x3] "+v"(x[3]), [x4] "+v"(x[4]), [x5] "+v"(x[5]),
+          [x6] "+v"(x[6]), [x7] "+v"(x[7]), [e] "+v"(e), [a] "=&v"(a), [b] "=&v"(b)
+        : [i] "v"(inc));
+#undef GR4PM_X
+#undef GR4PM_E
+}
+
 // =====================================================================================
 // CostasLoop (costas_loop.hpp:92-148): serial per segment (state fully reset by a
 // syncword_phase tag, :35-42), one lane per segment.
@@ -844,11 +868,21 @@ __device__ __forceinline__ void cfc_fill_tile(const SymWg& p, unsigned span, uns
                     cf x[kRotChunk];
 #pragma unroll
                     for (unsigned t = 0; t < kRotChunk; ++t) x[t] = cf{ src[2 * t], src[2 * t + 1] };
+                    rot8_pk(x, e, inc); // hpp:87
+                    if (sps == 4) { // items t and t + 4 share their phase row and sit side by side: four addresses, not eight
 #pragma unroll
-                    for (unsigned t = 0; t < kRotChunk; ++t) {
-                        const unsigned i = i0 + t;
-                        tile[(i % sps) * pitch + i / sps] = cmul_pk(x[t], e); // hpp:87
-                        if (t + 1 < kRotChunk) e = cmul_pk(e, inc);
+                        for (unsigned t = 0; t < 4; ++t) {
+                            const unsigned i = i0 + t;
+                            cf* q = tile + (i % 4) * pitch + i / 4;
+                            q[0] = x[t];
+                            q[1] = x[t + 4];
+                        }
+                    } else {
+#pragma unroll
+                        for (unsigned t = 0; t < kRotChunk; ++t) {
+                            const unsigned i = i0 + t;
+                            tile[(i % sps) * pitch + i / sps] = x[t];
+                        }
                     }
                     continue;
                 }
