@@ -1,6 +1,7 @@
-import importlib, sys, time
+"""PfbArbResampler alone: Msamples/s in at three rates (the serial phase chain of k_arb_plan).  tools/arb_time.py"""
+import importlib, os, sys, time
 import numpy as np, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 pkg = importlib.import_module("gr4-packet-modem_amd")
 n = 1 << 22
 x = (torch.randn(n, device="cuda") + 1j * torch.randn(n, device="cuda")).to(torch.complex64)
