@@ -27,7 +27,10 @@ namespace gr4pm {
 // GR4PM_TIMING_SKIP=name[,name]: timing experiments only -- the named kernels are not launched (their outputs are
 // garbage); tells what a kernel costs the pipelined chain, which its duration alone does not
 #ifndef GR4PM_SERIAL_PRIO
-#define GR4PM_SERIAL_PRIO 3 // s_setprio of the one-lane-per-packet kernels (A/B: make EXTRA=-DGR4PM_SERIAL_PRIO=0)
+#define GR4PM_SERIAL_PRIO 3 // s_setprio of the Costas kernels (A/B: make EXTRA=-DGR4PM_SERIAL_PRIO=0)
+#endif
+#ifndef GR4PM_ROT_PRIO
+#define GR4PM_ROT_PRIO GR4PM_SERIAL_PRIO // ... of k_rot_checkpoints, the one serial kernel that runs BESIDE correlator waves
 #endif
 static inline bool timing_skip(const char* name)
 {
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(64) void k_rot_checkpoints(const RotSeg* __restrict
                                                         cf* __restrict__ seg_incr, unsigned* __restrict__ seg_counter0,
                                                         const unsigned* __restrict__ order)
 {
-    __builtin_amdgcn_s_setprio(GR4PM_SERIAL_PRIO); // latency-bound, few waves
+    __builtin_amdgcn_s_setprio(GR4PM_ROT_PRIO); // latency-bound, few waves
     const unsigned lane_seg = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane_seg >= n_segs) return;
     // order[]: the segments by descending length, so that the long ones (a stream with missed detections) share
