@@ -2536,3 +2536,17 @@ def test_burst_generator_loopback(pkg):
         got.append(data[pos:pos + int(n)].tobytes())
         pos += int(n)
     assert got == payloads
+
+
+@pytest.mark.parametrize("tool,cases", [("fuzz_detector.py", 8), ("fuzz_cfc_symf.py", 6), ("fuzz_costas.py", 9)])
+def test_randomised_differential_tools(tool, cases):
+    """a few cases of every randomised differential test under tools/ (random settings, tags, chunkings against the
+    oracle; the long runs are quoted in DESIGN.md section 2)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", tool), str(cases), "12345"], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert f"{cases} of {cases} cases agree" in r.stdout
+
