@@ -1,5 +1,9 @@
 // common.hip -- error text, device probing and the host-only firdes helper of libgr4pm_hip.so
+#include <atomic>
 #include <cmath>
+#include <cstdlib>
+#include <exception>
+#include <system_error>
 #include <vector>
 
 #include "common.hpp"
@@ -31,9 +35,84 @@ gr4pm_status require_device()
     return GR4PM_OK;
 }
 
+gr4pm_status exception_status(const char* where) noexcept
+{
+    try {
+        throw;
+    } catch (const std::bad_alloc&) {
+        set_error("%s: out of host memory (std::bad_alloc)", where);
+        return GR4PM_ERR_NOMEM;
+    } catch (const std::system_error& e) {
+        set_error("%s: %s (std::system_error %d)", where, e.what(), e.code().value());
+        return GR4PM_ERR_INTERNAL;
+    } catch (const std::exception& e) {
+        set_error("%s: unexpected C++ exception: %s", where, e.what());
+        return GR4PM_ERR_INTERNAL;
+    } catch (...) {
+        set_error("%s: unexpected non-standard exception", where);
+        return GR4PM_ERR_INTERNAL;
+    }
+}
+
+// Test-only allocator hook (gr4pm_test_fail_allocations): the library's own operator new -- local to the library (csrc/exports.map), so it
+// serves exactly the allocations made by this library's code and nothing else in the process -- counts down and throws
+// std::bad_alloc for `count` allocations after letting `after` pass, then disarms itself.  One relaxed atomic load per
+// allocation when not armed.
+static std::atomic<bool> g_alloc_armed{ false };
+static std::atomic<long> g_alloc_pass_left{ 0 }, g_alloc_fail_left{ 0 };
+static std::atomic<unsigned long long> g_alloc_calls{ 0 };
+#if !defined(__HIP_DEVICE_COMPILE__)
+static inline void* hooked_alloc(std::size_t n)
+{
+    g_alloc_calls.fetch_add(1, std::memory_order_relaxed);
+    if (g_alloc_armed.load(std::memory_order_relaxed) && g_alloc_pass_left.fetch_sub(1, std::memory_order_relaxed) <= 0) {
+        const long f = g_alloc_fail_left.fetch_sub(1, std::memory_order_relaxed);
+        if (f <= 1) g_alloc_armed.store(false, std::memory_order_relaxed);
+        if (f > 0) return nullptr;
+    }
+    return std::malloc(n ? n : 1);
+}
+#endif
+
 } // namespace gr4pm
 
+#if !defined(__HIP_DEVICE_COMPILE__)
+// (kept out of the dynamic symbol table by csrc/exports.map: the link makes everything but gr4pm_* local)
+#define GR4PM_HIDDEN
+GR4PM_HIDDEN void* operator new(std::size_t n)
+{
+    void* p = gr4pm::hooked_alloc(n);
+    if (!p) throw std::bad_alloc();
+    return p;
+}
+GR4PM_HIDDEN void* operator new[](std::size_t n)
+{
+    void* p = gr4pm::hooked_alloc(n);
+    if (!p) throw std::bad_alloc();
+    return p;
+}
+GR4PM_HIDDEN void* operator new(std::size_t n, const std::nothrow_t&) noexcept { return gr4pm::hooked_alloc(n); }
+GR4PM_HIDDEN void* operator new[](std::size_t n, const std::nothrow_t&) noexcept { return gr4pm::hooked_alloc(n); }
+GR4PM_HIDDEN void operator delete(void* p) noexcept { std::free(p); }
+GR4PM_HIDDEN void operator delete[](void* p) noexcept { std::free(p); }
+GR4PM_HIDDEN void operator delete(void* p, std::size_t) noexcept { std::free(p); }
+GR4PM_HIDDEN void operator delete[](void* p, std::size_t) noexcept { std::free(p); }
+GR4PM_HIDDEN void operator delete(void* p, const std::nothrow_t&) noexcept { std::free(p); }
+GR4PM_HIDDEN void operator delete[](void* p, const std::nothrow_t&) noexcept { std::free(p); }
+#endif
+
 extern "C" {
+
+void gr4pm_test_fail_allocations(long after, long count)
+try {
+    gr4pm::g_alloc_armed.store(false);
+    if (after < 0) return; // disarm
+    gr4pm::g_alloc_fail_left.store(count > 0 ? count : 1);
+    gr4pm::g_alloc_pass_left.store(after);
+    gr4pm::g_alloc_armed.store(true);
+}
+GR4PM_ABI_CATCH_VOID
+unsigned long long gr4pm_test_allocation_count(void) { return gr4pm::g_alloc_calls.load(std::memory_order_relaxed); }
 
 const char* gr4pm_last_error(void) { return gr4pm::g_error; }
 
@@ -42,16 +121,17 @@ void gr4pm_set_deferred_sync(int on) { gr4pm::g_deferred_sync = on != 0; }
 const char* gr4pm_version(void) { return "gr4pm-hip 0.1 (gfx950, one-wave FFT-2048 correlator)"; }
 
 int gr4pm_device_count(void)
-{
+try {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
 }
+GR4PM_ABI_CATCH_RET(0)
 
 // firdes.hpp:29-76 -- the GR3-equivalent RRC design, evaluated in double and cast
 size_t gr4pm_firdes_root_raised_cosine(double gain, double sampling_freq, double symbol_rate,
                                        double alpha, size_t ntaps, float* out)
-{
+try {
     ntaps |= 1;
     const double pi = 3.14159265358979323846;
     const double spb = sampling_freq / symbol_rate;
@@ -84,5 +164,6 @@ size_t gr4pm_firdes_root_raised_cosine(double gain, double sampling_freq, double
     for (size_t i = 0; i < ntaps; ++i) out[i] = static_cast<float>(taps[i] * gain / scale);
     return ntaps;
 }
+GR4PM_ABI_CATCH_RET(0)
 
 } // extern "C"

@@ -33,6 +33,30 @@ void set_error(const char* fmt, ...);
 // the product has no CPU fallback: every create() goes through this first
 gr4pm_status require_device();
 
+// "No exceptions cross the ABI" (include/gr4pm_hip.h): every extern "C" entry is a function-try-block whose handler is
+// GR4PM_ABI_CATCH, and every thread a handle starts runs its body under guarded().  The library allocates through
+// std::vector / std::deque / std::thread, so std::bad_alloc and std::system_error are possible anywhere; they become
+// GR4PM_ERR_NOMEM / GR4PM_ERR_INTERNAL plus gr4pm_last_error() text instead of unwinding into C (or std::terminate in
+// a worker).  tools/check_abi_guards.py (run by build()) verifies that no entry point lacks the handler.
+gr4pm_status exception_status(const char* where) noexcept; // call inside a catch (...) handler
+#define GR4PM_ABI_CATCH                                                                      \
+    catch (...) { return ::gr4pm::exception_status(__func__); }
+#define GR4PM_ABI_CATCH_RET(value)                                                           \
+    catch (...) { (void)::gr4pm::exception_status(__func__); return value; }
+#define GR4PM_ABI_CATCH_VOID                                                                 \
+    catch (...) { (void)::gr4pm::exception_status(__func__); }
+// runs fn() (a stage body); an exception becomes a status, never leaves the thread
+template <typename F>
+inline gr4pm_status guarded(const char* where, F&& fn) noexcept
+{
+    try {
+        fn();
+        return GR4PM_OK;
+    } catch (...) {
+        return exception_status(where);
+    }
+}
+
 template <typename T>
 struct DevBuf {
     T* p = nullptr;

@@ -405,7 +405,7 @@ extern "C" {
 
 gr4pm_status gr4pm_additive_scrambler_create(const gr4pm_additive_scrambler_params* p,
                                              gr4pm_additive_scrambler** out)
-{
+try {
     if (!p || !out || (p->item_kind != 1 && p->item_kind != 2) || p->length > 63) return GR4PM_ERR_INVALID;
     *out = nullptr;
     GR4PM_TRY(require_device());
@@ -473,21 +473,24 @@ gr4pm_status gr4pm_additive_scrambler_create(const gr4pm_additive_scrambler_para
     *out = h;
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 void gr4pm_additive_scrambler_destroy(gr4pm_additive_scrambler* h)
-{
+try {
     if (!h) return;
     (void)hipStreamSynchronize(h->stream);
     delete h;
 }
+GR4PM_ABI_CATCH_VOID
 gr4pm_status gr4pm_additive_scrambler_reset(gr4pm_additive_scrambler* h)
-{
+try {
     if (!h) return GR4PM_ERR_INVALID;
     h->position = 0;
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 gr4pm_status gr4pm_additive_scrambler_process(gr4pm_additive_scrambler* h, const void* in, size_t n, void* out,
                                               const uint64_t* reset_index, size_t n_resets)
-{
+try {
     if (!h) return GR4PM_ERR_INVALID;
     if (n == 0) return GR4PM_OK;
     if (!in || !out) {
@@ -538,10 +541,11 @@ gr4pm_status gr4pm_additive_scrambler_process(gr4pm_additive_scrambler* h, const
     GR4PM_HIP_TRY(final_sync(h->stream));
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 
 gr4pm_status gr4pm_header_payload_split_create(const gr4pm_header_payload_split_params* p,
                                                gr4pm_header_payload_split** out)
-{
+try {
     if (!p || !out || p->header_size == 0) return GR4PM_ERR_INVALID;
     *out = nullptr;
     GR4PM_TRY(require_device());
@@ -552,26 +556,29 @@ gr4pm_status gr4pm_header_payload_split_create(const gr4pm_header_payload_split_
     *out = h;
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 void gr4pm_header_payload_split_destroy(gr4pm_header_payload_split* h)
-{
+try {
     if (!h) return;
     (void)hipStreamSynchronize(h->stream);
     delete h;
 }
+GR4PM_ABI_CATCH_VOID
 gr4pm_status gr4pm_header_payload_split_reset(gr4pm_header_payload_split* h)
-{
+try {
     if (!h) return GR4PM_ERR_INVALID;
     h->in_payload = false; // start(), :41-45
     h->position = 0;
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 gr4pm_status gr4pm_header_payload_split_process(gr4pm_header_payload_split* h, const float* in, size_t n,
                                                 float* header, size_t* n_header, float* payload,
                                                 size_t* n_payload, const gr4pm_packet_tag* tags_in,
                                                 size_t n_tags_in, gr4pm_packet_tag* header_tags,
                                                 size_t* n_header_tags, gr4pm_packet_tag* payload_tags,
                                                 size_t* n_payload_tags, size_t tags_cap)
-{
+try {
     if (!h || !n_header || !n_payload) return GR4PM_ERR_INVALID;
     *n_header = *n_payload = 0;
     if (n_header_tags) *n_header_tags = 0;
@@ -664,9 +671,10 @@ gr4pm_status gr4pm_header_payload_split_process(gr4pm_header_payload_split* h, c
     }
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 
 gr4pm_status gr4pm_header_fec_decoder_create(const gr4pm_header_fec_decoder_params* p, gr4pm_header_fec_decoder** out)
-{
+try {
     if (!p || !out || !p->alist) return GR4PM_ERR_INVALID;
     *out = nullptr;
     GR4PM_TRY(require_device());
@@ -783,15 +791,17 @@ gr4pm_status gr4pm_header_fec_decoder_create(const gr4pm_header_fec_decoder_para
     *out = h;
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 void gr4pm_header_fec_decoder_destroy(gr4pm_header_fec_decoder* h)
-{
+try {
     if (!h) return;
     (void)hipStreamSynchronize(h->stream);
     delete h;
 }
+GR4PM_ABI_CATCH_VOID
 gr4pm_status gr4pm_header_fec_decoder_process(gr4pm_header_fec_decoder* h, const float* llrs, size_t n_codewords,
                                               uint8_t* headers, uint8_t* invalid)
-{
+try {
     if (!h) return GR4PM_ERR_INVALID;
     if (n_codewords == 0) return GR4PM_OK;
     if (!llrs || !headers || !invalid) {
@@ -814,10 +824,11 @@ gr4pm_status gr4pm_header_fec_decoder_process(gr4pm_header_fec_decoder* h, const
     std::copy_n(h->h_out.p + n_codewords * hb, n_codewords, invalid);
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 
 void gr4pm_header_parse(const uint8_t* headers, const uint8_t* invalid, size_t n, gr4pm_header_msg* msgs,
                         int32_t* packet_type)
-{
+try {
     for (size_t i = 0; i < n; ++i) { // header_parser.hpp:56-85
         const uint8_t* hd = headers + 4 * i;
         bool valid = !(invalid && invalid[i]);
@@ -829,11 +840,12 @@ void gr4pm_header_parse(const uint8_t* headers, const uint8_t* invalid, size_t n
         if (packet_type) packet_type[i] = valid ? hd[2] : -1;
     }
 }
+GR4PM_ABI_CATCH_VOID
 
 static unsigned grid1d(size_t n) { return static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>((n + 255) / 256, 65535 * 4))); }
 
 gr4pm_status gr4pm_binary_slicer_process(const float* in, size_t n, uint8_t* out, int invert, void* stream)
-{
+try {
     if (n == 0) return GR4PM_OK;
     if (!in || !out) return GR4PM_ERR_INVALID;
     GR4PM_TRY(require_device());
@@ -843,9 +855,10 @@ gr4pm_status gr4pm_binary_slicer_process(const float* in, size_t n, uint8_t* out
     GR4PM_HIP_TRY(final_sync(s));
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 gr4pm_status gr4pm_pack_bits_process(const uint8_t* in, size_t n_out, uint8_t* out, size_t inputs_per_output,
                                      unsigned bits_per_input, int msb_first, void* stream)
-{
+try {
     if (inputs_per_output == 0 || bits_per_input == 0 || inputs_per_output * bits_per_input > 8) {
         set_error("inputs_per_output %zu x bits_per_input %u does not fit a byte", inputs_per_output, bits_per_input);
         return GR4PM_ERR_INVALID;
@@ -860,8 +873,9 @@ gr4pm_status gr4pm_pack_bits_process(const uint8_t* in, size_t n_out, uint8_t* o
     GR4PM_HIP_TRY(final_sync(s));
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 gr4pm_status gr4pm_slice_pack_process(const float* in, size_t n_out, uint8_t* out, void* stream)
-{
+try {
     if (n_out == 0) return GR4PM_OK;
     if (!in || !out) return GR4PM_ERR_INVALID;
     GR4PM_TRY(require_device());
@@ -871,9 +885,10 @@ gr4pm_status gr4pm_slice_pack_process(const float* in, size_t n_out, uint8_t* ou
     GR4PM_HIP_TRY(final_sync(s));
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 
 gr4pm_status gr4pm_crc_check_create(const gr4pm_crc_check_params* p, gr4pm_crc_check** out)
-{
+try {
     if (!p || !out) return GR4PM_ERR_INVALID;
     *out = nullptr;
     if (p->num_bits < 8 || p->num_bits > 64 || p->num_bits % 8 != 0) {
@@ -918,14 +933,16 @@ gr4pm_status gr4pm_crc_check_create(const gr4pm_crc_check_params* p, gr4pm_crc_c
     *out = h;
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 void gr4pm_crc_check_destroy(gr4pm_crc_check* h)
-{
+try {
     if (!h) return;
     (void)hipStreamSynchronize(static_cast<hipStream_t>(h->p.stream));
     delete h;
 }
+GR4PM_ABI_CATCH_VOID
 uint64_t gr4pm_crc_check_compute(const gr4pm_crc_check* h, const uint8_t* data, size_t n)
-{
+try {
     unsigned long long rem = h->p.initial_value & h->mask; // crc.hpp:119-156
     if (h->p.input_reflected) {
         for (size_t k = 0; k < n; ++k) rem = h->table[(rem ^ data[k]) & 0xff] ^ (rem >> 8);
@@ -936,10 +953,11 @@ uint64_t gr4pm_crc_check_compute(const gr4pm_crc_check* h, const uint8_t* data, 
     if ((h->p.input_reflected != 0) != (h->p.result_reflected != 0)) rem = h->reflect(rem);
     return rem ^ (h->p.final_xor & h->mask);
 }
+GR4PM_ABI_CATCH_RET(0)
 gr4pm_status gr4pm_crc_check_process(gr4pm_crc_check* h, const uint8_t* in, const uint64_t* packet_offset,
                                      const uint64_t* packet_len, size_t n_packets, uint8_t* out,
                                      uint64_t* out_len, size_t* n_out_bytes)
-{
+try {
     if (!h || !n_out_bytes) return GR4PM_ERR_INVALID;
     *n_out_bytes = 0;
     if (n_packets == 0) return GR4PM_OK;
@@ -996,10 +1014,11 @@ gr4pm_status gr4pm_crc_check_process(gr4pm_crc_check* h, const uint8_t* in, cons
     *n_out_bytes = opos;
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 
 gr4pm_status gr4pm_mapper_process(const uint8_t* in, size_t n, void* out, const void* map_host, size_t map_size,
                                   int item_kind, void* stream)
-{
+try {
     if (map_size == 0 || (map_size & (map_size - 1)) || map_size > 256) {
         set_error("the map size must be a power of 2 (got %zu)", map_size); // mapper.hpp:37-41
         return GR4PM_ERR_INVALID;
@@ -1024,12 +1043,13 @@ gr4pm_status gr4pm_mapper_process(const uint8_t* in, size_t n, void* out, const 
     GR4PM_HIP_TRY(hipStreamSynchronize(s));
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 
 gr4pm_status gr4pm_burst_shaper_process(const void* in, size_t n, void* out, int item_kind, const float* leading_host,
                                         size_t leading_n, const float* trailing_host, size_t trailing_n,
                                         const uint64_t* packet_offset, const uint64_t* packet_len, size_t n_packets,
                                         void* stream)
-{
+try {
     if (n == 0) return GR4PM_OK;
     if (!in || !out || (item_kind != 0 && item_kind != 1)) return GR4PM_ERR_INVALID;
     GR4PM_TRY(require_device());
@@ -1073,5 +1093,6 @@ gr4pm_status gr4pm_burst_shaper_process(const void* in, size_t n, void* out, int
     }
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 
 } // extern "C"

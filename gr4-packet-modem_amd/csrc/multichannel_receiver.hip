@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "hostlogic/slot_queue.hpp"
 
 using namespace gr4pm;
 
@@ -77,37 +78,8 @@ struct gr4pm_multichannel_receiver {
         std::chrono::steady_clock::time_point t_submit, t_done;
     } slots[kMcSlots];
     // slot indices travel through the stages in submission order
-    struct Queue {
-        std::mutex m;
-        std::condition_variable cv;
-        std::deque<int> q;
-        bool quit = false;
-        void push(int v)
-        {
-            {
-                std::lock_guard<std::mutex> l(m);
-                q.push_back(v);
-            }
-            cv.notify_all();
-        }
-        int pop() // -1 on shutdown
-        {
-            std::unique_lock<std::mutex> l(m);
-            cv.wait(l, [&] { return quit || !q.empty(); });
-            if (q.empty()) return -1;
-            const int v = q.front();
-            q.pop_front();
-            return v;
-        }
-        void stop()
-        {
-            {
-                std::lock_guard<std::mutex> l(m);
-                quit = true;
-            }
-            cv.notify_all();
-        }
-    } to_stage1, to_stage2, to_stage3, done;
+    using Queue = hostlogic::SlotQueue<16>; // fixed ring, push() cannot throw (hostlogic/slot_queue.hpp)
+    Queue to_stage1, to_stage2, to_stage3, done;
     std::thread t_stage1, t_stage2, t_stage3;
     int next_slot = 0, inflight = 0;
     // stage 2 fans a batch out to the workers
@@ -176,7 +148,10 @@ void gr4pm_multichannel_receiver::worker(unsigned w)
             s = cur;
         }
         gr4pm_status st = GR4PM_OK;
-        for (size_t c = w; c < p.n_channels && st == GR4PM_OK; c += streams.size()) st = run_channel(*s, c);
+        const gr4pm_status gs = guarded("multichannel receiver, channel worker", [&] {
+            for (size_t c = w; c < p.n_channels && st == GR4PM_OK; c += streams.size()) st = run_channel(*s, c);
+        });
+        if (gs != GR4PM_OK) st = gs;
         if (hipStreamSynchronize(streams[w]) != hipSuccess && st == GR4PM_OK) st = GR4PM_ERR_HIP;
         {
             std::lock_guard<std::mutex> l(m);
@@ -292,32 +267,40 @@ void gr4pm_multichannel_receiver::stage_loop(int which)
     (void)hipSetDevice(device);
     Queue& in = which == 1 ? to_stage1 : which == 2 ? to_stage2 : to_stage3;
     Queue& out = which == 1 ? to_stage2 : which == 2 ? to_stage3 : done;
-    for (;;) {
-        const int i = in.pop();
-        if (i < 0) return;
-        Slot& s = slots[i];
-        if (s.status == GR4PM_OK) { // a failed batch just travels on to collect()
-            static const bool timing = getenv("GR4PM_MC_TIMING") != nullptr;
-            const auto ta = std::chrono::steady_clock::now();
-            const gr4pm_status st = which == 1 ? stage1(s) : which == 2 ? stage2(s) : stage3(s);
-            if (timing)
-                fprintf(stderr, "[gr4pm multichannel] stage %d: %.0f us\n", which,
-                        std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ta).count());
-            if (st != GR4PM_OK) {
-                s.status = st;
-                std::strncpy(s.error, gr4pm_last_error(), sizeof(s.error) - 1);
+    // hostlogic::run_stage: an exception inside a stage body fails that batch (collect() returns its status); the
+    // end of the input is NOT forwarded -- destroy() stops every queue itself
+    hostlogic::run_stage(
+        in, &out, /*forward_quit=*/false,
+        [&](int i) {
+            Slot& s = slots[i];
+            if (s.status == GR4PM_OK) { // a failed batch just travels on to collect()
+                static const bool timing = getenv("GR4PM_MC_TIMING") != nullptr;
+                const auto ta = std::chrono::steady_clock::now();
+                const gr4pm_status st = which == 1 ? stage1(s) : which == 2 ? stage2(s) : stage3(s);
+                if (timing)
+                    fprintf(stderr, "[gr4pm multichannel] stage %d: %.0f us\n", which,
+                            std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ta).count());
+                if (st != GR4PM_OK) {
+                    s.status = st;
+                    std::strncpy(s.error, gr4pm_last_error(), sizeof(s.error) - 1);
+                }
             }
-        }
-        if (which == 3) s.t_done = std::chrono::steady_clock::now();
-        out.push(i);
-    }
+            if (which == 3) s.t_done = std::chrono::steady_clock::now();
+        },
+        [&](int i) {
+            Slot& s = slots[i];
+            s.status = exception_status(which == 1 ? "multichannel receiver, stage 1"
+                                                   : which == 2 ? "multichannel receiver, stage 2" : "multichannel receiver, stage 3");
+            std::strncpy(s.error, gr4pm_last_error(), sizeof(s.error) - 1);
+            if (which == 3) s.t_done = std::chrono::steady_clock::now();
+        });
 }
 
 extern "C" {
 
 gr4pm_status gr4pm_multichannel_receiver_create(const gr4pm_multichannel_receiver_params* p,
                                                 gr4pm_multichannel_receiver** out)
-{
+try {
     if (!p || !out || p->n_channels == 0 || p->samples_per_symbol == 0 || p->max_items < 2048) return GR4PM_ERR_INVALID;
     *out = nullptr;
     GR4PM_TRY(require_device());
@@ -434,16 +417,22 @@ gr4pm_status gr4pm_multichannel_receiver_create(const gr4pm_multichannel_receive
     }
     // HIP's current device is per thread and starts at 0: every thread of the handle works on the creator's device
     if (hipGetDevice(&h->device) != hipSuccess) return bail(GR4PM_ERR_HIP);
-    for (unsigned w = 0; w < n_workers; ++w) h->workers.emplace_back([h, w] { h->worker(w); });
-    h->t_stage1 = std::thread([h] { h->stage_loop(1); });
-    h->t_stage2 = std::thread([h] { h->stage_loop(2); });
-    h->t_stage3 = std::thread([h] { h->stage_loop(3); });
+    try {
+        h->workers.reserve(n_workers);
+        for (unsigned w = 0; w < n_workers; ++w) h->workers.emplace_back([h, w] { h->worker(w); });
+        h->t_stage1 = std::thread([h] { h->stage_loop(1); });
+        h->t_stage2 = std::thread([h] { h->stage_loop(2); });
+        h->t_stage3 = std::thread([h] { h->stage_loop(3); });
+    } catch (...) { // a thread could not start: wind down the ones that did
+        return bail(exception_status("gr4pm_multichannel_receiver_create (threads)"));
+    }
     *out = h;
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 
 void gr4pm_multichannel_receiver_destroy(gr4pm_multichannel_receiver* h)
-{
+try {
     if (!h) return;
     {
         std::lock_guard<std::mutex> l(h->m);
@@ -474,16 +463,18 @@ void gr4pm_multichannel_receiver_destroy(gr4pm_multichannel_receiver* h)
     if (h->sd_stream) (void)hipStreamDestroy(h->sd_stream);
     delete h;
 }
+GR4PM_ABI_CATCH_VOID
 
 gr4pm_status gr4pm_multichannel_receiver_announce(gr4pm_multichannel_receiver* h, const gr4pm_c64* in,
                                                   size_t in_stride, size_t n_in)
-{
+try {
     if (!h || !in) return GR4PM_ERR_INVALID;
     return gr4pm_syncword_detection_announce(h->sd, in, in_stride, n_in);
 }
+GR4PM_ABI_CATCH
 
 gr4pm_status gr4pm_multichannel_receiver_set_input_in_place(gr4pm_multichannel_receiver* h, int on)
-{
+try {
     if (!h) return GR4PM_ERR_INVALID;
     if (h->inflight != 0 || gr4pm_syncword_detection_items_consumed(h->sd) != 0) {
         set_error("set_input_in_place: before the first batch");
@@ -492,11 +483,12 @@ gr4pm_status gr4pm_multichannel_receiver_set_input_in_place(gr4pm_multichannel_r
     h->in_place = on != 0;
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 
 gr4pm_status gr4pm_multichannel_receiver_submit(gr4pm_multichannel_receiver* h, const gr4pm_c64* in,
                                                 size_t in_stride, size_t n_in, uint64_t packet_length,
                                                 gr4pm_c64* out_symbols, size_t out_stride, size_t* consumed)
-{
+try {
     if (!h || !in || !out_symbols || !consumed) return GR4PM_ERR_INVALID;
     *consumed = 0;
     // checked BEFORE the detector consumes the batch: an error here must not lose items (the detector
@@ -565,11 +557,12 @@ gr4pm_status gr4pm_multichannel_receiver_submit(gr4pm_multichannel_receiver* h, 
     h->to_stage1.push(i);
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 
 gr4pm_status gr4pm_multichannel_receiver_collect(gr4pm_multichannel_receiver* h, size_t* consumed, size_t* n_symbols,
                                                  gr4pm_tag* tags, size_t* n_tags, gr4pm_tag* detector_tags,
                                                  size_t* n_detector_tags)
-{
+try {
     if (!h || !n_symbols) return GR4PM_ERR_INVALID;
     if (h->inflight == 0) {
         set_error("nothing in flight");
@@ -600,6 +593,7 @@ gr4pm_status gr4pm_multichannel_receiver_collect(gr4pm_multichannel_receiver* h,
                 std::chrono::duration<double, std::micro>(s.t_done - s.t_submit).count());
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 
 int gr4pm_multichannel_receiver_in_flight(const gr4pm_multichannel_receiver* h) { return h ? h->inflight : 0; }
 
@@ -608,7 +602,7 @@ gr4pm_status gr4pm_multichannel_receiver_process(gr4pm_multichannel_receiver* h,
                                                  gr4pm_c64* out_symbols, size_t out_stride, size_t* consumed,
                                                  size_t* n_symbols, gr4pm_tag* tags, size_t* n_tags,
                                                  gr4pm_tag* detector_tags, size_t* n_detector_tags)
-{
+try {
     if (!h || !in || !out_symbols || !consumed || !n_symbols) return GR4PM_ERR_INVALID;
     if (h->inflight != 0) {
         set_error("process() with batches in flight: collect them first");
@@ -618,5 +612,6 @@ gr4pm_status gr4pm_multichannel_receiver_process(gr4pm_multichannel_receiver* h,
     GR4PM_TRY(gr4pm_multichannel_receiver_submit(h, in, in_stride, n_in, packet_length, out_symbols, out_stride, consumed));
     return gr4pm_multichannel_receiver_collect(h, nullptr, n_symbols, tags, n_tags, detector_tags, n_detector_tags);
 }
+GR4PM_ABI_CATCH
 
 } // extern "C"

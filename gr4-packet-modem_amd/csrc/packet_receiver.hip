@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "hostlogic/slot_queue.hpp"
 
 using namespace gr4pm;
 
@@ -74,35 +75,8 @@ struct Slot {
     std::vector<gr4pm_symbol_pdu> pdus;
 };
 
-template <typename T>
-class Channel { // blocking FIFO between two threads
-    std::deque<T> q_;
-    std::mutex m_;
-    std::condition_variable cv_;
-
-public:
-    void push(T v)
-    {
-        {
-            std::lock_guard<std::mutex> l(m_);
-            q_.push_back(v);
-        }
-        cv_.notify_one();
-    }
-    T pop()
-    {
-        std::unique_lock<std::mutex> l(m_);
-        cv_.wait(l, [&] { return !q_.empty(); });
-        T v = q_.front();
-        q_.pop_front();
-        return v;
-    }
-    size_t size()
-    {
-        std::lock_guard<std::mutex> l(m_);
-        return q_.size();
-    }
-};
+// slot indices between the stage threads: hostlogic/slot_queue.hpp (fixed ring, push() cannot throw)
+using SlotRing = hostlogic::SlotQueue<16>;
 
 // pass A of the header loop: one window of W items per detection, gathered into a compact stream.
 // starts[j] is relative to y[0]; negative starts read the saved tail of the previous batch, which
@@ -281,7 +255,7 @@ struct gr4pm_packet_receiver {
     std::deque<uint64_t> payload_bits;      // their lengths
     DevBuf<uint8_t> packed;
     Slot slots[kSlots];
-    Channel<int> free_slots, to_stageA, to_stage1, to_stage1b, to_stage2, to_stage3, done;
+    SlotRing free_slots, to_stageA, to_stage1, to_stage1b, to_stage2, to_stage3, done;
     std::thread workers[5];
     int held = -1; // slot whose result the caller is looking at
     size_t inflight = 0;
@@ -884,7 +858,7 @@ gr4pm_status gr4pm_packet_receiver::stage3_decode(Slot& s)
 extern "C" {
 
 gr4pm_status gr4pm_packet_receiver_create(const gr4pm_packet_receiver_params* p, gr4pm_packet_receiver** out)
-{
+try {
     if (!p || !out || p->samples_per_symbol == 0 || p->max_items < 2048) return GR4PM_ERR_INVALID;
     *out = nullptr;
     GR4PM_TRY(require_device());
@@ -1027,86 +1001,54 @@ gr4pm_status gr4pm_packet_receiver_create(const gr4pm_packet_receiver_params* p,
     int device = 0;
     if (hipGetDevice(&device) != hipSuccess) return bail(GR4PM_ERR_HIP);
     if (p->pipelined) {
-        h->workers[4] = std::thread([h, device] {
-            (void)hipSetDevice(device);
-            gr4pm_set_deferred_sync(getenv("GR4PM_NO_DEFER") ? 0 : 1);
-            for (;;) {
-                const int i = h->to_stageA.pop();
-                if (i < 0) break;
-                CLK_GOT(h->clk[5]);
-                h->stageA(h->slots[i]);
-                CLK_DONE(h->clk[5]);
-                h->to_stage1.push(i);
-            }
-            h->to_stage1.push(-1);
-        });
-        h->workers[0] = std::thread([h, device] {
-            (void)hipSetDevice(device);
-            gr4pm_set_deferred_sync(getenv("GR4PM_NO_DEFER") ? 0 : 1);
-            for (;;) {
-                const int i = h->to_stage1.pop();
-                if (i < 0) break;
-                CLK_GOT(h->clk[1]);
-                h->stage1(h->slots[i]);
-                CLK_DONE(h->clk[1]);
-                h->to_stage1b.push(i);
-            }
-            h->to_stage1b.push(-1);
-        });
-        h->workers[3] = std::thread([h, device] {
-            (void)hipSetDevice(device);
-            gr4pm_set_deferred_sync(getenv("GR4PM_NO_DEFER") ? 0 : 1);
-            for (;;) {
-                const int i = h->to_stage1b.pop();
-                if (i < 0) break;
-                CLK_GOT(h->clk[4]);
-                h->stage1b(h->slots[i]);
-                CLK_DONE(h->clk[4]);
-                h->to_stage2.push(i);
-            }
-            h->to_stage2.push(-1);
-        });
-        h->workers[1] = std::thread([h, device] {
-            (void)hipSetDevice(device);
-            gr4pm_set_deferred_sync(getenv("GR4PM_NO_DEFER") ? 0 : 1);
-            for (;;) {
-                const int i = h->to_stage2.pop();
-                if (i < 0) break;
-                CLK_GOT(h->clk[2]);
-                h->stage2(h->slots[i]);
-                CLK_DONE(h->clk[2]);
-                h->to_stage3.push(i);
-            }
-            h->to_stage3.push(-1);
-        });
-        h->workers[2] = std::thread([h, device] {
-            (void)hipSetDevice(device);
-            gr4pm_set_deferred_sync(getenv("GR4PM_NO_DEFER") ? 0 : 1);
-            for (;;) {
-                const int i = h->to_stage3.pop();
-                if (i < 0) break;
-                CLK_GOT(h->clk[3]);
-                h->stage3(h->slots[i]);
-                CLK_DONE(h->clk[3]);
-                h->done.push(i);
-            }
-        });
+        // one thread per stage (hostlogic::run_stage): a C++ exception inside a stage body (std::bad_alloc from a table
+        // that grows, std::system_error) fails that batch -- collect() returns its status -- and the thread lives on
+        struct StageDef {
+            int worker, clk;
+            SlotRing *from, *to;
+            void (gr4pm_packet_receiver::*body)(Slot&);
+            const char* name;
+        };
+        const StageDef stages[5] = {
+            { 4, 5, &h->to_stageA, &h->to_stage1, &gr4pm_packet_receiver::stageA, "packet receiver, stage A" },
+            { 0, 1, &h->to_stage1, &h->to_stage1b, &gr4pm_packet_receiver::stage1, "packet receiver, stage 1" },
+            { 3, 4, &h->to_stage1b, &h->to_stage2, &gr4pm_packet_receiver::stage1b, "packet receiver, stage 1b" },
+            { 1, 2, &h->to_stage2, &h->to_stage3, &gr4pm_packet_receiver::stage2, "packet receiver, stage 2" },
+            { 2, 3, &h->to_stage3, &h->done, &gr4pm_packet_receiver::stage3, "packet receiver, stage 3" },
+        };
+        try {
+            for (const StageDef& sd : stages)
+                h->workers[sd.worker] = std::thread([h, device, sd] {
+                    (void)hipSetDevice(device);
+                    gr4pm_set_deferred_sync(getenv("GR4PM_NO_DEFER") ? 0 : 1);
+                    hostlogic::run_stage(
+                        *sd.from, sd.to, /*forward_quit=*/sd.to != &h->done,
+                        [&](int i) {
+                            CLK_GOT(h->clk[sd.clk]);
+                            (h->*sd.body)(h->slots[i]);
+                            CLK_DONE(h->clk[sd.clk]);
+                        },
+                        [&](int i) { h->fail(h->slots[i], exception_status(sd.name)); });
+                });
+        } catch (...) { // std::thread could not start: wind down the ones that did
+            const gr4pm_status ts = exception_status("gr4pm_packet_receiver_create (stage threads)");
+            gr4pm_packet_receiver_destroy(h);
+            return ts;
+        }
     }
     *out = h;
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 
 void gr4pm_packet_receiver_destroy(gr4pm_packet_receiver* h)
-{
+try {
     if (!h) return;
-    if (h->workers[0].joinable()) {
-        h->to_stageA.push(-1);
-        h->workers[4].join();
-        h->workers[0].join();
-        h->workers[1].join();
-        h->workers[2].join();
-        h->workers[3].join();
-    }
+    // every queue is told to stop (a stage whose predecessor never started would not see a forwarded end);
+    // batches still queued are delivered first, so the stages drain in order
+    for (SlotRing* q : { &h->to_stageA, &h->to_stage1, &h->to_stage1b, &h->to_stage2, &h->to_stage3 }) q->stop();
+    for (int w : { 4, 0, 3, 1, 2 })
+        if (h->workers[w].joinable()) h->workers[w].join();
     gr4pm_syncword_detection_destroy(h->sd);
     gr4pm_syncword_detection_filter_destroy(h->sdf);
     gr4pm_rotator_destroy(h->cfc);
@@ -1130,6 +1072,7 @@ void gr4pm_packet_receiver_destroy(gr4pm_packet_receiver* h)
         if (s) (void)hipStreamDestroy(s);
     delete h;
 }
+GR4PM_ABI_CATCH_VOID
 
 size_t gr4pm_packet_receiver_inflight(const gr4pm_packet_receiver* h) { return h ? h->inflight : 0; }
 
@@ -1137,7 +1080,7 @@ gr4pm_status gr4pm_packet_receiver_submit(gr4pm_packet_receiver* h, const gr4pm_
                                           const gr4pm_c64* delayed, const gr4pm_c64* next_in, size_t next_n,
                                           uint64_t packet_length, gr4pm_c64* out_symbols, size_t out_cap,
                                           float* out_llr, size_t llr_cap, uint8_t* out_packets, size_t packets_cap)
-{
+try {
     if (!h || !in || !out_symbols || (h->p.soft_bits && !out_llr) || (h->p.decode_headers && !out_packets))
         return GR4PM_ERR_INVALID;
     if (h->p.decode_headers && n_in < gr4pm_packet_receiver::kW + gr4pm_packet_receiver::kPre + 2048) {
@@ -1150,6 +1093,16 @@ gr4pm_status gr4pm_packet_receiver_submit(gr4pm_packet_receiver* h, const gr4pm_
         return GR4PM_ERR_INVALID;
     }
     const int i = h->free_slots.pop();
+    // until the batch counts as in flight, an exception (stage 0 runs in this thread) hands the slot back
+    struct SlotReturn {
+        SlotRing& q;
+        int slot;
+        bool armed = true;
+        ~SlotReturn()
+        {
+            if (armed) (void)q.push(slot);
+        }
+    } slot_return{ h->free_slots, i };
     Slot& s = h->slots[i];
     s.in = in;
     s.n_in = n_in;
@@ -1174,31 +1127,35 @@ gr4pm_status gr4pm_packet_receiver_submit(gr4pm_packet_receiver* h, const gr4pm_
     h->stage0(s, next_in, next_n);
     CLK_DONE(h->clk[0]);
     ++h->inflight;
+    slot_return.armed = false;
     if (h->p.pipelined) {
-        if (h->p.decode_headers) h->to_stageA.push(i);
-        else h->to_stage1.push(i);
+        if (h->p.decode_headers) (void)h->to_stageA.push(i);
+        else (void)h->to_stage1.push(i);
     } else {
-        {
+        const gr4pm_status gs = guarded("packet receiver, stages in the caller's thread", [&] {
             DeferredSyncScope defer;
             h->stageA(s);
             h->stage1(s);
             h->stage1b(s);
             h->stage2(s);
             h->stage3(s);
-        }
-        h->done.push(i);
+        });
+        if (gs != GR4PM_OK) h->fail(s, gs);
+        (void)h->done.push(i);
     }
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 
 gr4pm_status gr4pm_packet_receiver_announce(gr4pm_packet_receiver* h, const gr4pm_c64* in, size_t n_in)
-{
+try {
     if (!h || !in) return GR4PM_ERR_INVALID;
     return gr4pm_syncword_detection_announce(h->sd, in, n_in, n_in);
 }
+GR4PM_ABI_CATCH
 
 gr4pm_status gr4pm_packet_receiver_collect(gr4pm_packet_receiver* h, gr4pm_packet_receiver_result* r)
-{
+try {
     if (!h || !r) return GR4PM_ERR_INVALID;
     if (h->held >= 0) { // the previous result is handed back now
         h->free_slots.push(h->held);
@@ -1262,9 +1219,10 @@ gr4pm_status gr4pm_packet_receiver_collect(gr4pm_packet_receiver* h, gr4pm_packe
     }
     return s.status;
 }
+GR4PM_ABI_CATCH
 
 gr4pm_status gr4pm_packet_receiver_set_symbol_pdu_callback(gr4pm_packet_receiver* h, gr4pm_symbol_pdu_fn fn, void* user)
-{
+try {
     if (!h) return GR4PM_ERR_INVALID;
     if (fn && !h->p.soft_bits) {
         set_error("the symbol PDU tap hangs off SyncwordRemove: soft_bits receivers only");
@@ -1274,5 +1232,6 @@ gr4pm_status gr4pm_packet_receiver_set_symbol_pdu_callback(gr4pm_packet_receiver
     h->pdu_user = user;
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 
 } // extern "C"

@@ -1429,7 +1429,7 @@ static gr4pm_status rotator_reset_impl(gr4pm_rotator* h)
 extern "C" {
 
 gr4pm_status gr4pm_rotator_create(const gr4pm_rotator_params* p, gr4pm_rotator** out)
-{
+try {
     if (!p || !out || p->n_channels == 0 || (p->mode != 0 && p->mode != 1)) return GR4PM_ERR_INVALID;
     *out = nullptr;
     GR4PM_TRY(require_device());
@@ -1449,13 +1449,19 @@ gr4pm_status gr4pm_rotator_create(const gr4pm_rotator_params* p, gr4pm_rotator**
     *out = h;
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 void gr4pm_rotator_destroy(gr4pm_rotator* h)
-{
+try {
     if (!h) return;
     (void)hipStreamSynchronize(h->stream);
     delete h;
 }
-gr4pm_status gr4pm_rotator_reset(gr4pm_rotator* h) { return h ? rotator_reset_impl(h) : GR4PM_ERR_INVALID; }
+GR4PM_ABI_CATCH_VOID
+gr4pm_status gr4pm_rotator_reset(gr4pm_rotator* h)
+try {
+    return h ? rotator_reset_impl(h) : GR4PM_ERR_INVALID;
+}
+GR4PM_ABI_CATCH
 
 } // extern "C"
 
@@ -1589,7 +1595,7 @@ extern "C" {
 gr4pm_status gr4pm_rotator_process(gr4pm_rotator* h, const gr4pm_c64* in, size_t stride, size_t n,
                                    gr4pm_c64* out, const gr4pm_tag* tags, const uint32_t* tag_channel,
                                    size_t n_tags)
-{
+try {
     if (!h) return GR4PM_ERR_INVALID;
     if (n == 0) return GR4PM_OK; // an empty chunk is legal (and may come with null pointers)
     if (!in || !out) {
@@ -1617,6 +1623,7 @@ gr4pm_status gr4pm_rotator_process(gr4pm_rotator* h, const gr4pm_c64* in, size_t
     GR4PM_HIP_TRY(hipStreamSynchronize(s));
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 
 } // extern "C"
 
@@ -1671,7 +1678,7 @@ static void costas_coeffs(gr4pm_costas_loop* h)
 extern "C" {
 
 gr4pm_status gr4pm_costas_loop_create(const gr4pm_costas_loop_params* p, gr4pm_costas_loop** out)
-{
+try {
     if (!p || !out || p->n_channels == 0 || p->constellation < 0 || p->constellation > 2)
         return GR4PM_ERR_INVALID;
     *out = nullptr;
@@ -1693,33 +1700,38 @@ gr4pm_status gr4pm_costas_loop_create(const gr4pm_costas_loop_params* p, gr4pm_c
     *out = h;
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 void gr4pm_costas_loop_destroy(gr4pm_costas_loop* h)
-{
+try {
     if (!h) return;
     (void)hipStreamSynchronize(h->stream);
     delete h;
 }
+GR4PM_ABI_CATCH_VOID
 gr4pm_status gr4pm_costas_loop_reset(gr4pm_costas_loop* h)
-{
+try {
     if (!h) return GR4PM_ERR_INVALID;
     GR4PM_TRY(h->state.zero(h->stream));
     GR4PM_HIP_TRY(hipStreamSynchronize(h->stream));
     h->st_cur = 0;
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 void gr4pm_costas_loop_coeffs(const gr4pm_costas_loop* h, float* k1, float* k2)
-{
+try {
     *k1 = h->k1;
     *k2 = h->k2;
 }
+GR4PM_ABI_CATCH_VOID
 gr4pm_status gr4pm_costas_loop_set(gr4pm_costas_loop* h, double loop_bandwidth, int constellation)
-{
+try {
     if (!h || constellation < 0 || constellation > 2) return GR4PM_ERR_INVALID;
     h->loop_bandwidth = loop_bandwidth;
     h->constellation = constellation;
     costas_coeffs(h);
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 
 // n_of(c): items of channel c in this call (channels with 0 items keep their state)
 extern "C++" {
@@ -1815,16 +1827,17 @@ static gr4pm_status costas_process_impl(gr4pm_costas_loop* h, const gr4pm_c64* i
 } // extern "C++"
 
 gr4pm_status gr4pm_costas_loop_set_small_footprint(gr4pm_costas_loop* h, int on)
-{
+try {
     if (!h) return GR4PM_ERR_INVALID;
     h->small_footprint = on != 0;
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 
 gr4pm_status gr4pm_costas_loop_process(gr4pm_costas_loop* h, const gr4pm_c64* in, size_t stride, size_t n,
                                        gr4pm_c64* out, const gr4pm_tag* tags, const uint32_t* tag_channel,
                                        size_t n_tags)
-{
+try {
     if (!h) return GR4PM_ERR_INVALID;
     if (n == 0) return GR4PM_OK;
     if (!in || !out) {
@@ -1833,11 +1846,12 @@ gr4pm_status gr4pm_costas_loop_process(gr4pm_costas_loop* h, const gr4pm_c64* in
     }
     return costas_process_impl(h, in, stride, [n](size_t) { return n; }, out, tags, tag_channel, n_tags);
 }
+GR4PM_ABI_CATCH
 
 gr4pm_status gr4pm_costas_loop_process_ragged(gr4pm_costas_loop* h, const gr4pm_c64* in, size_t stride,
                                               const size_t* n_per_channel, gr4pm_c64* out, const gr4pm_tag* tags,
                                               const uint32_t* tag_channel, size_t n_tags)
-{
+try {
     if (!h || !n_per_channel) return GR4PM_ERR_INVALID;
     if (!in || !out) {
         set_error("null sample pointer");
@@ -1846,10 +1860,11 @@ gr4pm_status gr4pm_costas_loop_process_ragged(gr4pm_costas_loop* h, const gr4pm_
     return costas_process_impl(h, in, stride, [n_per_channel](size_t c) { return n_per_channel[c]; }, out, tags,
                                tag_channel, n_tags);
 }
+GR4PM_ABI_CATCH
 
 gr4pm_status gr4pm_costas_loop_process_packets(gr4pm_costas_loop* h, const gr4pm_c64* in, size_t n,
                                                gr4pm_c64* out, const gr4pm_packet_tag* tags, size_t n_tags)
-{
+try {
     if (!h) return GR4PM_ERR_INVALID;
     if (h->n_channels != 1) {
         set_error("process_packets needs a single-channel CostasLoop");
@@ -1922,6 +1937,7 @@ gr4pm_status gr4pm_costas_loop_process_packets(gr4pm_costas_loop* h, const gr4pm
     GR4PM_HIP_TRY(final_sync(s));
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 
 } // extern "C"
 
@@ -1939,7 +1955,7 @@ extern "C" {
 
 gr4pm_status gr4pm_syncword_wipeoff_create(const gr4pm_syncword_wipeoff_params* p,
                                            gr4pm_syncword_wipeoff** out)
-{
+try {
     if (!p || !out || !p->syncword || p->n_syncword == 0) return GR4PM_ERR_INVALID;
     *out = nullptr;
     GR4PM_TRY(require_device());
@@ -1957,19 +1973,22 @@ gr4pm_status gr4pm_syncword_wipeoff_create(const gr4pm_syncword_wipeoff_params* 
     *out = h;
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 void gr4pm_syncword_wipeoff_destroy(gr4pm_syncword_wipeoff* h)
-{
+try {
     if (!h) return;
     (void)hipStreamSynchronize(h->stream);
     delete h;
 }
+GR4PM_ABI_CATCH_VOID
 gr4pm_status gr4pm_syncword_wipeoff_reset(gr4pm_syncword_wipeoff* h)
-{
+try {
     if (!h) return GR4PM_ERR_INVALID;
     h->in_syncword = false;
     h->position = 0;
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 
 } // extern "C"
 
@@ -2007,7 +2026,7 @@ static void wipe_replay(gr4pm_syncword_wipeoff* h, size_t n, const gr4pm_tag* ta
 extern "C" {
 
 gr4pm_status gr4pm_sincosf(const float* x, size_t n, float* sin_out, float* cos_out)
-{
+try {
     if (!x || !sin_out || !cos_out) return GR4PM_ERR_INVALID;
     GR4PM_TRY(require_device());
     if (n == 0) return GR4PM_OK;
@@ -2017,9 +2036,10 @@ gr4pm_status gr4pm_sincosf(const float* x, size_t n, float* sin_out, float* cos_
     GR4PM_HIP_TRY(hipStreamSynchronize(nullptr));
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 
 gr4pm_status gr4pm_costas_phase_wrap(const float* x, size_t n, float* out)
-{
+try {
     if (!x || !out) return GR4PM_ERR_INVALID;
     GR4PM_TRY(require_device());
     if (n == 0) return GR4PM_OK;
@@ -2028,10 +2048,11 @@ gr4pm_status gr4pm_costas_phase_wrap(const float* x, size_t n, float* out)
     GR4PM_HIP_TRY(hipStreamSynchronize(nullptr));
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 
 gr4pm_status gr4pm_syncword_wipeoff_process(gr4pm_syncword_wipeoff* h, const gr4pm_c64* in, size_t n,
                                             gr4pm_c64* out, const gr4pm_tag* tags, size_t n_tags)
-{
+try {
     if (!h) return GR4PM_ERR_INVALID;
     if (n == 0) return GR4PM_OK;
     if (!in || !out) {
@@ -2053,11 +2074,12 @@ gr4pm_status gr4pm_syncword_wipeoff_process(gr4pm_syncword_wipeoff* h, const gr4
     GR4PM_HIP_TRY(final_sync(s));
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 
 gr4pm_status gr4pm_syncword_wipeoff_process_channels(gr4pm_syncword_wipeoff* const* h, size_t n_channels,
                                                      gr4pm_c64* buf, size_t stride, const size_t* n,
                                                      const gr4pm_tag* const* tags, const size_t* n_tags)
-{
+try {
     if (!h || n_channels == 0 || !n || !tags || !n_tags) return GR4PM_ERR_INVALID;
     if (!buf) {
         set_error("null sample pointer");
@@ -2081,6 +2103,7 @@ gr4pm_status gr4pm_syncword_wipeoff_process_channels(gr4pm_syncword_wipeoff* con
     GR4PM_HIP_TRY(final_sync(s));
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 
 } // extern "C"
 
@@ -2101,7 +2124,7 @@ extern "C" {
 
 gr4pm_status gr4pm_syncword_detection_filter_create(const gr4pm_syncword_detection_filter_params* p,
                                                     gr4pm_syncword_detection_filter** out)
-{
+try {
     if (!p || !out) return GR4PM_ERR_INVALID;
     *out = nullptr;
     GR4PM_TRY(require_device());
@@ -2114,14 +2137,20 @@ gr4pm_status gr4pm_syncword_detection_filter_create(const gr4pm_syncword_detecti
     *out = h;
     return GR4PM_OK;
 }
-void gr4pm_syncword_detection_filter_destroy(gr4pm_syncword_detection_filter* h) { delete h; }
+GR4PM_ABI_CATCH
+void gr4pm_syncword_detection_filter_destroy(gr4pm_syncword_detection_filter* h)
+try {
+    delete h;
+}
+GR4PM_ABI_CATCH_VOID
 gr4pm_status gr4pm_syncword_detection_filter_reset(gr4pm_syncword_detection_filter* h)
-{
+try {
     if (!h) return GR4PM_ERR_INVALID;
     h->in_packet = false; // start(), :52
     h->gate_in_packet = false;
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 
 gr4pm_status gr4pm_syncword_detection_filter_process(gr4pm_syncword_detection_filter* h, const gr4pm_c64* in,
                                                      size_t n_in, gr4pm_c64* out, size_t out_cap,
@@ -2129,7 +2158,7 @@ gr4pm_status gr4pm_syncword_detection_filter_process(gr4pm_syncword_detection_fi
                                                      size_t n_headers, size_t n_ignored, size_t* consumed_,
                                                      size_t* headers_consumed, size_t* ignored_consumed,
                                                      int* tag_out_flags)
-{
+try {
     if (!h || !consumed_ || !headers_consumed || !ignored_consumed || !tag_out_flags) return GR4PM_ERR_INVALID;
     *consumed_ = *headers_consumed = *ignored_consumed = 0;
     *tag_out_flags = 0;
@@ -2197,6 +2226,7 @@ gr4pm_status gr4pm_syncword_detection_filter_process(gr4pm_syncword_detection_fi
     GR4PM_HIP_TRY(hipStreamSynchronize(h->stream));
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 
 } // extern "C"
 
@@ -2205,7 +2235,7 @@ extern "C" gr4pm_status gr4pm_syncword_detection_filter_gate(gr4pm_syncword_dete
                                                              const gr4pm_header_msg* headers, size_t n_headers,
                                                              int headers_per_tag, uint8_t* accepted,
                                                              size_t* headers_used)
-{
+try {
     if (!h || !accepted || !headers_used) return GR4PM_ERR_INVALID;
     if (headers_per_tag && n_headers != n_tags) return GR4PM_ERR_INVALID;
     *headers_used = 0;
@@ -2276,10 +2306,11 @@ extern "C" gr4pm_status gr4pm_syncword_detection_filter_gate(gr4pm_syncword_dete
     *headers_used = hu;
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 
 extern "C" gr4pm_status gr4pm_syncword_detection_filter_gate_resolve(gr4pm_syncword_detection_filter* h,
                                                                      const gr4pm_header_msg* msg)
-{
+try {
     if (!h || !msg) return GR4PM_ERR_INVALID;
     if (!h->gate_in_packet || h->gate_end_known) return GR4PM_OK; // nothing is waiting
     const uint64_t allowed = h->sps * (h->syncword_size + h->header_size + h->allowed_margin);
@@ -2295,6 +2326,7 @@ extern "C" gr4pm_status gr4pm_syncword_detection_filter_gate_resolve(gr4pm_syncw
     h->gate_end_known = true;
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 
 // ------------------------------------------------------------------ InterpolatingFirFilter
 struct gr4pm_interp_fir {
@@ -2339,7 +2371,7 @@ static gr4pm_status interp_fir_run(gr4pm_interp_fir* h, const void* in, size_t n
 extern "C" {
 
 gr4pm_status gr4pm_interp_fir_create(const gr4pm_interp_fir_params* p, gr4pm_interp_fir** out)
-{
+try {
     if (!p || !out || !p->taps) return GR4PM_ERR_INVALID;
     *out = nullptr;
     if (p->interpolation == 0) { // interpolating_fir_filter.hpp:45-47
@@ -2377,21 +2409,24 @@ gr4pm_status gr4pm_interp_fir_create(const gr4pm_interp_fir_params* p, gr4pm_int
     *out = h;
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 void gr4pm_interp_fir_destroy(gr4pm_interp_fir* h)
-{
+try {
     if (!h) return;
     (void)hipStreamSynchronize(h->stream);
     delete h;
 }
+GR4PM_ABI_CATCH_VOID
 gr4pm_status gr4pm_interp_fir_reset(gr4pm_interp_fir* h)
-{
+try {
     if (!h) return GR4PM_ERR_INVALID;
     for (int i = 0; i < 2; ++i) GR4PM_TRY(h->carry[i].zero(h->stream));
     GR4PM_HIP_TRY(hipStreamSynchronize(h->stream));
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 gr4pm_status gr4pm_interp_fir_process(gr4pm_interp_fir* h, const void* in, size_t n_in, void* out)
-{
+try {
     if (!h) return GR4PM_ERR_INVALID;
     if (n_in == 0) return GR4PM_OK;
     if (!in || !out) {
@@ -2400,6 +2435,7 @@ gr4pm_status gr4pm_interp_fir_process(gr4pm_interp_fir* h, const void* in, size_
     }
     return h->item_kind == 0 ? interp_fir_run<cf>(h, in, n_in, out) : interp_fir_run<float>(h, in, n_in, out);
 }
+GR4PM_ABI_CATCH
 
 } // extern "C"
 
@@ -2427,7 +2463,7 @@ struct gr4pm_symbol_filter {
 extern "C" {
 
 gr4pm_status gr4pm_symbol_filter_create(const gr4pm_symbol_filter_params* p, gr4pm_symbol_filter** out)
-{
+try {
     if (!p || !out || !p->taps) return GR4PM_ERR_INVALID;
     *out = nullptr;
     if (p->samples_per_symbol == 0) { // symbol_filter.hpp:67-69
@@ -2472,18 +2508,21 @@ gr4pm_status gr4pm_symbol_filter_create(const gr4pm_symbol_filter_params* p, gr4
     *out = h;
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 void gr4pm_symbol_filter_destroy(gr4pm_symbol_filter* h)
-{
+try {
     if (!h) return;
     (void)hipStreamSynchronize(h->stream);
     delete h;
 }
+GR4PM_ABI_CATCH_VOID
 gr4pm_status gr4pm_symbol_filter_reset(gr4pm_symbol_filter* h)
-{
+try {
     if (!h) return GR4PM_ERR_INVALID;
     h->clock_phase = 0; // start(), :110
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 
 } // extern "C"
 
@@ -2701,10 +2740,11 @@ gr4pm_status gr4pm_symbol_filter_process(gr4pm_symbol_filter* h, const void* in,
                                          size_t out_cap, const gr4pm_tag* tags_in, size_t n_tags_in,
                                          gr4pm_tag* tags_out, size_t tags_cap, size_t* n_tags_out,
                                          size_t* consumed, size_t* produced)
-{
+try {
     return symbol_filter_impl(h, in, n_in, out, out_cap, tags_in, n_tags_in, tags_out, tags_cap, n_tags_out,
                               consumed, produced, nullptr);
 }
+GR4PM_ABI_CATCH
 
 static gr4pm_status cfc_plan_impl(gr4pm_rotator* cfc, size_t n_in, const gr4pm_tag* tags_in,
                                   const uint32_t* tag_channel, size_t n_tags_in, int* plan, bool ring)
@@ -2729,35 +2769,38 @@ static gr4pm_status cfc_plan_impl(gr4pm_rotator* cfc, size_t n_in, const gr4pm_t
 
 gr4pm_status gr4pm_cfc_symbol_filter_plan_channels(gr4pm_rotator* cfc, size_t n_in, const gr4pm_tag* tags_in,
                                                    const uint32_t* tag_channel, size_t n_tags_in, int* plan)
-{
+try {
     return cfc_plan_impl(cfc, n_in, tags_in, tag_channel, n_tags_in, plan, true);
 }
+GR4PM_ABI_CATCH
 
 gr4pm_status gr4pm_cfc_symbol_filter_plan(gr4pm_rotator* cfc, size_t n_in, const gr4pm_tag* tags_in,
                                           size_t n_tags_in, int* plan)
-{
+try {
     if (cfc && cfc->n_channels != 1) {
         set_error("fused call needs a single-channel CoarseFrequencyCorrection (or ..._plan_channels)");
         return GR4PM_ERR_INVALID;
     }
     return gr4pm_cfc_symbol_filter_plan_channels(cfc, n_in, tags_in, nullptr, n_tags_in, plan);
 }
+GR4PM_ABI_CATCH
 
 gr4pm_status gr4pm_cfc_symbol_filter_run(gr4pm_rotator* cfc, int plan, gr4pm_symbol_filter* sf,
                                          const gr4pm_c64* in, size_t n_in, gr4pm_c64* out, size_t out_cap,
                                          const gr4pm_tag* tags_in, size_t n_tags_in, gr4pm_tag* tags_out,
                                          size_t tags_cap, size_t* n_tags_out, size_t* consumed, size_t* produced)
-{
+try {
     return gr4pm_cfc_symbol_filter_run_channel(cfc, plan, 0, sf, in, n_in, out, out_cap, tags_in, n_tags_in, tags_out,
                                                tags_cap, n_tags_out, consumed, produced);
 }
+GR4PM_ABI_CATCH
 
 gr4pm_status gr4pm_cfc_symbol_filter_run_channel(gr4pm_rotator* cfc, int plan, size_t channel, gr4pm_symbol_filter* sf,
                                                  const gr4pm_c64* in, size_t n_in, gr4pm_c64* out, size_t out_cap,
                                                  const gr4pm_tag* tags_in, size_t n_tags_in, gr4pm_tag* tags_out,
                                                  size_t tags_cap, size_t* n_tags_out, size_t* consumed,
                                                  size_t* produced)
-{
+try {
     if (!cfc || !sf || !consumed || !produced) return GR4PM_ERR_INVALID;
     *consumed = *produced = 0;
     if (n_tags_out) *n_tags_out = 0;
@@ -2800,6 +2843,7 @@ gr4pm_status gr4pm_cfc_symbol_filter_run_channel(gr4pm_rotator* cfc, int plan, s
     }
     return st;
 }
+GR4PM_ABI_CATCH
 
 gr4pm_status gr4pm_cfc_symbol_filter_run_channels(gr4pm_rotator* cfc, int plan, gr4pm_symbol_filter* const* sf,
                                                   size_t n_channels, const gr4pm_c64* in, size_t in_stride, size_t n_in,
@@ -2807,7 +2851,7 @@ gr4pm_status gr4pm_cfc_symbol_filter_run_channels(gr4pm_rotator* cfc, int plan, 
                                                   const size_t* n_tags_in, gr4pm_tag* const* tags_out, size_t tags_cap,
                                                   size_t* n_tags_out, size_t* produced, const gr4pm_c64* head,
                                                   size_t head_stride, size_t n_head)
-{
+try {
     if (!cfc || !sf || !n_tags_in || !tags_in || !tags_out || !n_tags_out || !produced || n_channels == 0)
         return GR4PM_ERR_INVALID;
     for (size_t c = 0; c < n_channels; ++c) n_tags_out[c] = produced[c] = 0;
@@ -2913,13 +2957,14 @@ gr4pm_status gr4pm_cfc_symbol_filter_run_channels(gr4pm_rotator* cfc, int plan, 
     }
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 
 gr4pm_status gr4pm_cfc_symbol_filter_process(gr4pm_rotator* cfc, gr4pm_symbol_filter* sf, const gr4pm_c64* in,
                                              size_t n_in, gr4pm_c64* out, size_t out_cap,
                                              const gr4pm_tag* tags_in, size_t n_tags_in, gr4pm_tag* tags_out,
                                              size_t tags_cap, size_t* n_tags_out, size_t* consumed,
                                              size_t* produced)
-{
+try {
     if (!cfc || !sf || !consumed || !produced) return GR4PM_ERR_INVALID;
     *consumed = *produced = 0;
     if (n_tags_out) *n_tags_out = 0;
@@ -2952,6 +2997,7 @@ gr4pm_status gr4pm_cfc_symbol_filter_process(gr4pm_rotator* cfc, gr4pm_symbol_fi
     return gr4pm_cfc_symbol_filter_run(cfc, plan, sf, in, n_in, out, out_cap, tags_in, n_tags_in, tags_out,
                                        tags_cap, n_tags_out, consumed, produced);
 }
+GR4PM_ABI_CATCH
 
 } // extern "C"
 
@@ -2989,7 +3035,7 @@ extern "C" {
 
 gr4pm_status gr4pm_pfb_arb_resampler_create(const gr4pm_pfb_arb_resampler_params* p,
                                             gr4pm_pfb_arb_resampler** out)
-{
+try {
     if (!p || !out) return GR4PM_ERR_INVALID;
     *out = nullptr;
     if (p->filter_size == 0) { // :70-72
@@ -3044,20 +3090,23 @@ gr4pm_status gr4pm_pfb_arb_resampler_create(const gr4pm_pfb_arb_resampler_params
     *out = h;
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 void gr4pm_pfb_arb_resampler_destroy(gr4pm_pfb_arb_resampler* h)
-{
+try {
     if (!h) return;
     (void)hipStreamSynchronize(h->stream);
     delete h;
 }
+GR4PM_ABI_CATCH_VOID
 gr4pm_status gr4pm_pfb_arb_resampler_reset(gr4pm_pfb_arb_resampler* h)
-{
+try {
     return h ? arb_reset_impl(h) : GR4PM_ERR_INVALID;
 }
+GR4PM_ABI_CATCH
 
 gr4pm_status gr4pm_pfb_arb_resampler_process(gr4pm_pfb_arb_resampler* h, const gr4pm_c64* in, size_t n_in,
                                              gr4pm_c64* out, size_t out_cap, size_t* consumed, size_t* produced)
-{
+try {
     if (!h || !consumed || !produced) return GR4PM_ERR_INVALID;
     *consumed = *produced = 0;
     if (n_in == 0 || out_cap == 0) return GR4PM_OK;
@@ -3109,6 +3158,7 @@ gr4pm_status gr4pm_pfb_arb_resampler_process(gr4pm_pfb_arb_resampler* h, const g
     *produced = h->st_host.p->produced;
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 
 } // extern "C"
 
@@ -3202,7 +3252,7 @@ extern "C" {
 
 gr4pm_status gr4pm_payload_metadata_insert_create(const gr4pm_payload_metadata_insert_params* p,
                                                   gr4pm_payload_metadata_insert** out)
-{
+try {
     if (!p || !out) return GR4PM_ERR_INVALID;
     *out = nullptr;
     GR4PM_TRY(require_device());
@@ -3217,27 +3267,30 @@ gr4pm_status gr4pm_payload_metadata_insert_create(const gr4pm_payload_metadata_i
     *out = h;
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 void gr4pm_payload_metadata_insert_destroy(gr4pm_payload_metadata_insert* h)
-{
+try {
     if (!h) return;
     (void)hipStreamSynchronize(h->stream);
     delete h;
 }
+GR4PM_ABI_CATCH_VOID
 gr4pm_status gr4pm_payload_metadata_insert_reset(gr4pm_payload_metadata_insert* h)
-{
+try {
     if (!h) return GR4PM_ERR_INVALID;
     h->in_packet = false; // start(), :71-75
     h->position = 0;
     h->has_held = false;
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 
 gr4pm_status gr4pm_payload_metadata_insert_process(
     gr4pm_payload_metadata_insert* h, const gr4pm_c64* in, size_t n_in, gr4pm_c64* out, size_t out_cap,
     const gr4pm_tag* tags_in, size_t n_tags_in, const gr4pm_header_msg* headers, size_t n_headers,
     int headers_per_tag, gr4pm_packet_tag* tags_out, size_t tags_cap, size_t* n_tags_out, size_t* consumed,
     size_t* produced, size_t* headers_used, size_t* ignored_syncwords)
-{
+try {
     if (!h || !n_tags_out || !consumed || !produced || !headers_used || !ignored_syncwords) return GR4PM_ERR_INVALID;
     *n_tags_out = *consumed = *produced = *headers_used = *ignored_syncwords = 0;
     if (headers_per_tag && n_headers != n_tags_in) {
@@ -3392,9 +3445,10 @@ gr4pm_status gr4pm_payload_metadata_insert_process(
     }
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 
 gr4pm_status gr4pm_payload_metadata_insert_resolve(gr4pm_payload_metadata_insert* h, const gr4pm_header_msg* msg)
-{
+try {
     if (!h || !msg) return GR4PM_ERR_INVALID;
     if (h->in_packet && !h->has_held) {
         h->held = *msg;
@@ -3402,9 +3456,10 @@ gr4pm_status gr4pm_payload_metadata_insert_resolve(gr4pm_payload_metadata_insert
     }
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 
 gr4pm_status gr4pm_syncword_remove_create(const gr4pm_syncword_remove_params* p, gr4pm_syncword_remove** out)
-{
+try {
     if (!p || !out) return GR4PM_ERR_INVALID;
     *out = nullptr;
     GR4PM_TRY(require_device());
@@ -3415,24 +3470,27 @@ gr4pm_status gr4pm_syncword_remove_create(const gr4pm_syncword_remove_params* p,
     *out = h;
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 void gr4pm_syncword_remove_destroy(gr4pm_syncword_remove* h)
-{
+try {
     if (!h) return;
     (void)hipStreamSynchronize(h->stream);
     delete h;
 }
+GR4PM_ABI_CATCH_VOID
 gr4pm_status gr4pm_syncword_remove_reset(gr4pm_syncword_remove* h)
-{
+try {
     if (!h) return GR4PM_ERR_INVALID;
     h->in_syncword = false;
     h->position = 0;
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 gr4pm_status gr4pm_syncword_remove_process(gr4pm_syncword_remove* h, const gr4pm_c64* in, size_t n, gr4pm_c64* out,
                                            const gr4pm_packet_tag* tags_in, size_t n_tags_in,
                                            gr4pm_packet_tag* tags_out, size_t tags_cap, size_t* n_tags_out,
                                            size_t* produced)
-{
+try {
     if (!h || !produced) return GR4PM_ERR_INVALID;
     *produced = 0;
     if (n_tags_out) *n_tags_out = 0;
@@ -3491,10 +3549,11 @@ gr4pm_status gr4pm_syncword_remove_process(gr4pm_syncword_remove* h, const gr4pm
     }
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 
 gr4pm_status gr4pm_constellation_llr_decoder_create(const gr4pm_constellation_llr_decoder_params* p,
                                                     gr4pm_constellation_llr_decoder** out)
-{
+try {
     if (!p || !out) return GR4PM_ERR_INVALID;
     *out = nullptr;
     if (p->constellation != 1 && p->constellation != 2) { // :72-74
@@ -3511,18 +3570,20 @@ gr4pm_status gr4pm_constellation_llr_decoder_create(const gr4pm_constellation_ll
     *out = h;
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 void gr4pm_constellation_llr_decoder_destroy(gr4pm_constellation_llr_decoder* h)
-{
+try {
     if (!h) return;
     (void)hipStreamSynchronize(h->stream);
     delete h;
 }
+GR4PM_ABI_CATCH_VOID
 gr4pm_status gr4pm_constellation_llr_decoder_process(gr4pm_constellation_llr_decoder* h, const gr4pm_c64* in,
                                                      size_t n, float* out, size_t out_cap,
                                                      const gr4pm_packet_tag* tags_in, size_t n_tags_in,
                                                      gr4pm_packet_tag* tags_out, size_t tags_cap,
                                                      size_t* n_tags_out, size_t* produced)
-{
+try {
     if (!h || !produced) return GR4PM_ERR_INVALID;
     *produced = 0;
     if (n_tags_out) *n_tags_out = 0;
@@ -3587,5 +3648,6 @@ gr4pm_status gr4pm_constellation_llr_decoder_process(gr4pm_constellation_llr_dec
     }
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 
 } // extern "C"

@@ -1895,7 +1895,7 @@ extern "C" {
 
 gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_params* p,
                                              gr4pm_syncword_detection** out)
-{
+try {
     if (!p || !out) return GR4PM_ERR_INVALID;
     *out = nullptr;
     if (p->min_freq_bin > p->max_freq_bin) { // hpp:145-147
@@ -2154,28 +2154,32 @@ gr4pm_status gr4pm_syncword_detection_create(const gr4pm_syncword_detection_para
     *out = h;
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 
 void gr4pm_syncword_detection_destroy(gr4pm_syncword_detection* h)
-{
+try {
     if (!h) return;
     (void)hipStreamSynchronize(h->stream);
     delete h;
 }
+GR4PM_ABI_CATCH_VOID
 
 gr4pm_status gr4pm_syncword_detection_reset(gr4pm_syncword_detection* h)
-{
+try {
     return h ? sd_reset(h) : GR4PM_ERR_INVALID;
 }
+GR4PM_ABI_CATCH
 size_t gr4pm_syncword_detection_syncword_samples_size(const gr4pm_syncword_detection* h) { return h->L; }
 float gr4pm_syncword_detection_self_corr(const gr4pm_syncword_detection* h) { return h->self_corr; }
 uint64_t gr4pm_syncword_detection_items_consumed(const gr4pm_syncword_detection* h)
-{
+try {
     return h->items_consumed;
 }
+GR4PM_ABI_CATCH_RET(0)
 
 gr4pm_status gr4pm_syncword_detection_correlate_only(gr4pm_syncword_detection* h, const gr4pm_c64* in,
                                                      size_t in_stride, size_t n_in)
-{
+try {
     if (!h || !in) return GR4PM_ERR_INVALID;
     if (n_in < h->fft_size) return GR4PM_INSUFFICIENT_INPUT_ITEMS;
     if (n_in > h->max_items) {
@@ -2185,10 +2189,11 @@ gr4pm_status gr4pm_syncword_detection_correlate_only(gr4pm_syncword_detection* h
     const uint32_t n_blocks = static_cast<uint32_t>((n_in - h->fft_size) / h->S + 1);
     return launch_correlate(h, h->stream, in, in_stride, n_blocks, h->z[h->cur].p + h->zc);
 }
+GR4PM_ABI_CATCH
 
 gr4pm_status gr4pm_syncword_detection_announce(gr4pm_syncword_detection* h, const gr4pm_c64* in,
                                                size_t in_stride, size_t n_in)
-{
+try {
     if (!h || !in) return GR4PM_ERR_INVALID;
     GR4PM_TRY(ensure_ahead_streams(h));
     // one launched front is consumed by the next call before a new one is launched
@@ -2201,21 +2206,23 @@ gr4pm_status gr4pm_syncword_detection_announce(gr4pm_syncword_detection* h, cons
     }
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 
 gr4pm_status gr4pm_syncword_detection_hint_next(gr4pm_syncword_detection* h, const gr4pm_c64* in_next,
                                                 size_t in_stride, size_t n_next)
-{
+try {
     if (!h) return GR4PM_ERR_INVALID;
     h->announced.clear();
     if (!in_next) return GR4PM_OK;
     return gr4pm_syncword_detection_announce(h, in_next, in_stride, n_next);
 }
+GR4PM_ABI_CATCH
 
 gr4pm_status gr4pm_syncword_detection_process(gr4pm_syncword_detection* h, const gr4pm_c64* in,
                                               size_t in_stride, size_t n_in, gr4pm_c64* out,
                                               size_t out_stride, size_t* n_done, gr4pm_tag* tags,
                                               size_t tags_cap, size_t* n_tags)
-{
+try {
     if (!h || !in || !n_done) return GR4PM_ERR_INVALID;
     *n_done = 0;
     if (n_tags)
@@ -2427,9 +2434,10 @@ gr4pm_status gr4pm_syncword_detection_process(gr4pm_syncword_detection* h, const
 #endif
     return ret;
 }
+GR4PM_ABI_CATCH
 
 gr4pm_status gr4pm_syncword_detection_last_zpow(gr4pm_syncword_detection* h, float* zpow, size_t stride)
-{
+try {
     if (!h || !zpow) return GR4PM_ERR_INVALID;
     for (size_t c = 0; c < h->n_channels; ++c) {
         GR4PM_HIP_TRY(hipMemcpyAsync(zpow + c * stride, h->z[h->cur].p + c * h->z_stride + h->zc,
@@ -2438,5 +2446,6 @@ gr4pm_status gr4pm_syncword_detection_last_zpow(gr4pm_syncword_detection* h, flo
     GR4PM_HIP_TRY(hipStreamSynchronize(h->stream));
     return GR4PM_OK;
 }
+GR4PM_ABI_CATCH
 
 } // extern "C"

@@ -38,6 +38,8 @@
 #include <complex>
 #include <cstdlib>
 #include <fstream>
+#include <limits>
+#include <map>
 #include <mutex>
 #include <sstream>
 #include <string>
@@ -567,7 +569,11 @@ class SymbolFilter : public gr::Block<SymbolFilter<TIn, TOut, TTaps>, gr::Resamp
                   "gr4pm: SymbolFilter is built for <complex<float>, complex<float>, float> (packet_receiver.hpp:111)");
     gr4pm_symbol_filter* _h = nullptr;
     detail::DeviceStage<gr4pm_c64> _din, _dout;
-    std::vector<gr::property_map> _held; // full maps of queued tags (opaque keys travel with them)
+    // full maps of the tags queued inside the filter (opaque keys travel with them), keyed by the handle the tag carries
+    // through the library in its freq_bin field; an entry leaves when its tag is published (it used to stay for the
+    // life of the block: one property_map leaked per packet)
+    std::map<int32_t, gr::property_map> _held;
+    int32_t _next_handle = 0;
     std::vector<gr4pm_tag> _tags_out;
 
 public:
@@ -579,6 +585,7 @@ public:
     size_t delay = 0;
     bool host_output = true;
     constexpr static gr::TagPropagationPolicy tag_policy = gr::TagPropagationPolicy::TPP_CUSTOM;
+    size_t held_tag_maps() const { return _held.size(); } // tests: stays at the number of tags inside the filter
 
     SymbolFilter() = default;
     SymbolFilter(const SymbolFilter&) = delete;
@@ -607,8 +614,9 @@ public:
         size_t n_tags = 0;
         if (this->input_tags_present()) { // :127-206: the tag refers to inSpan[0]
             tag = detail::from_map(this->mergedInputTag().map, 0);
-            tag.freq_bin = static_cast<int32_t>(_held.size()); // handle of the full map
-            _held.push_back(this->mergedInputTag().map);
+            tag.freq_bin = _next_handle; // handle of the full map
+            _held.emplace(_next_handle, this->mergedInputTag().map);
+            _next_handle = _next_handle == std::numeric_limits<int32_t>::max() ? 0 : _next_handle + 1;
             n_tags = 1;
         }
         const size_t n = std::min(inSpan.size(), detail::max_items());
@@ -623,7 +631,9 @@ public:
         _dout.publish(std::to_address(outSpan.begin()), produced, host_output);
         detail::consumed(hin, consumed * sizeof(c64));
         for (size_t i = 0; i < n_out_tags; ++i) { // :218-228 re-timed tags, :152-155 adjusted phase
-            auto map = _held.at(static_cast<size_t>(_tags_out[i].freq_bin));
+            auto node = _held.extract(_tags_out[i].freq_bin); // published once: the entry goes with it
+            if (node.empty()) throw gr::exception("SymbolFilter: a published tag has no queued map");
+            auto& map = node.mapped();
             if (_tags_out[i].flags & GR4PM_TAG_SYNCWORD) map["syncword_phase"] = _tags_out[i].phase;
             out.publishTag(map, static_cast<ssize_t>(_tags_out[i].index));
         }

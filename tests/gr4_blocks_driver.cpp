@@ -135,6 +135,10 @@ static int chain(int argc, char** argv)
         if (!progress) break;
     }
     const std::vector<gr::Tag> sd_tags = e_sd.tags;
+    // every tag that went into the symbol filter has come out again (the stream ends in zeros), so the wrapper holds no
+    // property_map any more (it used to keep one per tag for the life of the block)
+    if (symbol_filter.held_tag_maps() != 0)
+        throw std::runtime_error("SymbolFilter wrapper still holds " + std::to_string(symbol_filter.held_tag_maps()) + " tag maps");
 
     dump(prefix + ".symbols.c64", e_out.data.data(), e_out.size);
     dump_tags(prefix + ".sd_tags.bin", sd_tags);

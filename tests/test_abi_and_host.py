@@ -45,6 +45,37 @@ def test_no_cpu_fallback_without_gpu(pkg):
         pkg.Rotator(0.1)
 
 
+def test_every_abi_entry_point_has_an_exception_guard():
+    """include/gr4pm_hip.h: "No exceptions cross the ABI".  tools/check_abi_guards.py reads csrc/*.hip and fails when
+    an extern "C" definition is neither a function-try-block ending in GR4PM_ABI_CATCH* nor on its no-throw list."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_abi_guards.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_bad_alloc_inside_an_entry_point_comes_back_as_a_status(pkg):
+    """test-only allocator hook (gr4pm_test_fail_allocations): the std::vector inside the RRC design throws
+    std::bad_alloc; the entry point returns 0 taps and the error text instead of unwinding into the caller.  The hook
+    only sees the library's own allocations and disarms itself after the failure."""
+    L = pkg.lib()
+    before = L.gr4pm_test_allocation_count()
+    assert pkg.root_raised_cosine(1.0, 4.0, 1.0, 0.35, 65).size == 65
+    assert L.gr4pm_test_allocation_count() > before  # the library's operator new is the one in use
+    L.gr4pm_test_fail_allocations(0, 1)
+    assert pkg.root_raised_cosine(1.0, 4.0, 1.0, 0.35, 65).size == 0
+    assert b"bad_alloc" in L.gr4pm_last_error()
+    assert pkg.root_raised_cosine(1.0, 4.0, 1.0, 0.35, 65).size == 65  # disarmed again
+    np.zeros(1 << 20)  # allocations of the rest of the process never saw the hook
+    L.gr4pm_test_fail_allocations(-1, 0)
+
+
+def test_library_exports_only_the_c_abi(pkg):
+    """csrc/exports.map: nothing but gr4pm_* is in the dynamic symbol table -- in particular not the library's own
+    operator new / delete, which would otherwise interpose on every C++ allocation of the process"""
+    r = subprocess.run(["nm", "-D", "--defined-only", pkg.LIB_PATH], capture_output=True, text=True, check=True)
+    names = [l.split()[-1] for l in r.stdout.splitlines() if l.strip()]
+    assert names and all(n.startswith("gr4pm_") for n in names), [n for n in names if not n.startswith("gr4pm_")][:5]
+
+
 def test_firdes_matches_oracle_and_reference_vector(pkg):
     for args in [(1.0, 4.0, 1.0, 0.35, 44), (32.0, 128.0, 1.0, 0.35, 1408), (1.0, 4.0, 1.0, 0.35, 65)]:
         got = pkg.root_raised_cosine(*args)

@@ -2550,3 +2550,77 @@ def test_randomised_differential_tools(tool, cases):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert f"{cases} of {cases} cases agree" in r.stdout
 
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("mode", ["front_end", "decode_headers", "multichannel"])
+def test_receivers_survive_allocation_failures(pkg, mode):
+    """include/gr4pm_hip.h: "No exceptions cross the ABI".  The library's test-only allocator hook
+    (gr4pm_test_fail_allocations) makes the k-th allocation of a whole receiver life -- create, a few pipelined
+    batches, collect, destroy -- throw std::bad_alloc, for k swept over that life.  Whichever thread it strikes (the
+    caller inside an entry point, or one of the receiver's stage threads): no exception, no std::terminate, no hang --
+    the failure is an error status of the call or of the batch (Gr4pmError here), every batch in flight is still
+    collected, and a receiver created afterwards gives the undisturbed result bit for bit."""
+    L = pkg.lib()
+    n = 60000
+    x, _, _ = _tx_packets(np.random.default_rng(5), [200] * 12, list(np.random.default_rng(6).integers(300, 2000, 12)))
+    x = np.concatenate([x, np.zeros(4 * n, np.complex64)])[:4 * n]
+    x = (x + sig.awgn(x.size, 0.05, 7)).astype(np.complex64)
+    if mode == "multichannel":
+        xd = dev(np.stack([x, np.roll(x, 777)]))
+        chunks = [xd[:, k * 58000:k * 58000 + n].contiguous() for k in range(3)]
+    else:
+        xd = dev(x)
+        chunks = [xd[k * 58000:k * 58000 + n] for k in range(3)]
+
+    def life(fail_after):
+        errors, out = [], []
+        if fail_after is not None:
+            L.gr4pm_test_fail_allocations(fail_after, 1)
+        try:
+            if mode == "multichannel":
+                rx = pkg.NativeMultiChannelReceiver(2, max_items=n, tags_cap=256)
+            else:
+                rx = pkg.NativePacketReceiver(max_items=n, tags_cap=256, pipelined=True,
+                                              decode_headers=(mode == "decode_headers"))
+        except pkg.Gr4pmError as e:
+            L.gr4pm_test_fail_allocations(-1, 0)
+            return [str(e)], []
+        for c in chunks:
+            try:
+                if mode == "multichannel":
+                    rx.submit(c, 200)
+                else:
+                    r = rx.process_bulk(c, None if mode == "decode_headers" else 200)
+                    if r is not None:
+                        out.append(r)
+            except pkg.Gr4pmError as e:
+                errors.append(str(e))
+        while (rx.in_flight() if mode == "multichannel" else L.gr4pm_packet_receiver_inflight(rx._h)):
+            try:
+                out.append(rx.collect())
+            except pkg.Gr4pmError as e:
+                errors.append(str(e))
+        del rx
+        L.gr4pm_test_fail_allocations(-1, 0)
+        return errors, out
+
+    def key(results):
+        if mode == "multichannel":
+            return [tuple(host(d["symbols"]).tobytes() for d in r) for r in results]
+        return [(r["consumed"], host(r["symbols"]).tobytes()) for r in results]
+
+    c0 = L.gr4pm_test_allocation_count()
+    errors, want = life(None)
+    total = L.gr4pm_test_allocation_count() - c0
+    assert not errors and total > 50, (errors, total)
+    struck = 0
+    for k in sorted(set(np.linspace(0, total - 1, 48).astype(int).tolist())):
+        errors, _ = life(k)
+        if errors:
+            struck += 1
+            assert any(("memory" in e) or ("bad_alloc" in e) or ("NOMEM" in e) or ("-4" in e) for e in errors), errors
+    assert struck >= 24, struck  # most injected failures hit an allocation that matters and were reported
+    errors, again = life(None)
+    assert not errors and key(again) == key(want)
