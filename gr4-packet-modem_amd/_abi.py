@@ -167,7 +167,7 @@ class PacketReceiverResult(C.Structure):
                 ("payload_tags", C.c_void_p), ("n_payload_tags", C.c_size_t), ("packets", C.c_void_p),
                 ("n_packet_bytes", C.c_size_t), ("packet_lengths", C.c_void_p), ("n_packets", C.c_size_t),
                 ("pdu_symbols", C.c_void_p), ("n_pdu_symbols", C.c_size_t), ("symbol_pdus", C.c_void_p),
-                ("n_symbol_pdus", C.c_size_t)]
+                ("n_symbol_pdus", C.c_size_t), ("symbol_pdu_resyncs", C.c_size_t)]
 
 
 SYMBOL_PDU_DTYPE = np.dtype([("offset", "<u8"), ("length", "<u8"), ("kind", "<i4"), ("first", "<i4"), ("last", "<i4"),

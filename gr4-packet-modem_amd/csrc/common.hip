@@ -1,4 +1,5 @@
 // common.hip -- error text, device probing and the host-only firdes helper of libgr4pm_hip.so
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
@@ -33,6 +34,24 @@ gr4pm_status require_device()
         return GR4PM_ERR_NO_DEVICE;
     }
     return GR4PM_OK;
+}
+
+const char* experiment_env(const char* name, bool wrong_results)
+{
+    const char* e = getenv(name);
+    if (e && wrong_results)
+        fprintf(stderr, "[gr4pm] WARNING: %s=%s is set: a timing experiment that leaves kernels out or replaces them -- "
+                        "calls return GR4PM_OK with WRONG outputs\n", name, e);
+    return e;
+}
+unsigned experiment_env_wg(const char* name, unsigned fallback, unsigned lo, unsigned hi)
+{
+    const char* e = getenv(name);
+    if (!e) return fallback;
+    const long v = atol(e);
+    const unsigned c = static_cast<unsigned>(std::min<long>(std::max<long>(v, lo), hi));
+    if (static_cast<long>(c) != v) fprintf(stderr, "[gr4pm] %s=%ld is outside [%u, %u]: using %u\n", name, v, lo, hi, c);
+    return c;
 }
 
 gr4pm_status exception_status(const char* where) noexcept

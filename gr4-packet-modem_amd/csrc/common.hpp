@@ -160,6 +160,13 @@ struct PinnedBuf {
 
 inline size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
 
+// Environment switches of the A/B and timing experiments.  Every one is read ONCE per process
+// through these helpers; a switch that makes a call return GR4PM_OK with WRONG OUTPUTS (kernels left out or replaced
+// by stand-ins: GR4PM_TIMING_SKIP, GR4PM_SYMF_ABL, GR4PM_FAKE ...) says so on stderr the first time it is seen, so a
+// variable that leaked into a production environment cannot go unnoticed.
+const char* experiment_env(const char* name, bool wrong_results); // nullptr when unset
+unsigned experiment_env_wg(const char* name, unsigned fallback, unsigned lo, unsigned hi); // clamped to [lo, hi]
+
 // The last thing most process() calls do is wait for their stream.  A native caller that chains
 // several handles on ONE stream and reads nothing back in between (csrc/packet_receiver.hip) turns
 // that wait off for its thread (gr4pm_set_deferred_sync) and synchronises once per stage.

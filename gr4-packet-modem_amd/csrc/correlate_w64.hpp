@@ -223,6 +223,9 @@ __global__ __launch_bounds__(kW64Threads, 2) void k_correlate_w64(const cf* __re
 {
     __shared__ float4 lds4[kW64LdsF4];
     const int tid = threadIdx.x;
+    // at least one frequency bin (the create call checks min <= max): without this the compiler keeps a path around the
+    // bin loop on which the template loads requested during the forward transform are never awaited (tools/check_m0.py)
+    __builtin_assume(n_bins >= 1);
 #ifdef GR4PM_W64_PRIO
     __builtin_amdgcn_s_setprio(GR4PM_W64_PRIO); // A/B: make ABL=-DGR4PM_W64_PRIO=2
 #endif

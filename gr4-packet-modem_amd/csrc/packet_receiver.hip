@@ -73,6 +73,7 @@ struct Slot {
     // symbol PDU tap (soft_bits): SyncwordRemove's output is s.data[0 .. n_data), cut into header / payload pieces
     size_t n_data = 0;
     std::vector<gr4pm_symbol_pdu> pdus;
+    size_t pdu_resyncs = 0;
 };
 
 // slot indices between the stage threads: hostlogic/slot_queue.hpp (fixed ring, push() cannot throw)
@@ -223,6 +224,7 @@ struct gr4pm_packet_receiver {
     gr4pm_symbol_pdu_fn pdu_fn = nullptr;
     void* pdu_user = nullptr;
     std::vector<gr4pm_c64> pdu_host, pdu_acc[2];
+    bool pdu_open[2] = { false, false }; // the sink has seen the first piece of the PDU it is collecting
     gr4pm_status split_symbol_pdus(Slot& s, size_t n_data, size_t n_dt);
     uint64_t hist = 0;
     std::deque<gr4pm_header_msg> hdr_fifo; // gate -> PayloadMetadataInsert (stage 1 -> 2, in the slot)
@@ -441,6 +443,7 @@ gr4pm_status gr4pm_packet_receiver::split_symbol_pdus(Slot& s, size_t n_data, si
     constexpr uint64_t header_size = 128;
     s.n_data = n_data;
     s.pdus.clear();
+    s.pdu_resyncs = 0;
     size_t ti = 0;
     uint64_t pos = 0;
     while (pos < n_data) {
@@ -449,8 +452,11 @@ gr4pm_status gr4pm_packet_receiver::split_symbol_pdus(Slot& s, size_t n_data, si
             const gr4pm_packet_tag& t = s.data_tags[ti++];
             if (t.kind == GR4PM_PKT_PAYLOAD) { // :70-82
                 if (tap.in_payload || tap.position != header_size) {
-                    set_error("symbol tap: unexpected payload_symbols tag at symbol %llu", static_cast<unsigned long long>(pos));
-                    return GR4PM_ERR_INVALID;
+                    // header_payload_split.hpp:75-78 throws here.  The tap is the receiver's OPTIONAL side output
+                    // (zmq_output, packet_receiver.hpp:159): it must not fail the batch's LLRs and packets, and it
+                    // must not carry the broken state into the next batches.  The piece in progress is closed as it
+                    // is (never `last`, so no sink delivers it), the tap starts over at this tag, the result counts it.
+                    ++s.pdu_resyncs;
                 }
                 tap.in_payload = true;
                 tap.position = 0;
@@ -1201,19 +1207,33 @@ try {
     r->n_pdu_symbols = s.n_data;
     r->symbol_pdus = s.pdus.data();
     r->n_symbol_pdus = s.pdus.size();
+    r->symbol_pdu_resyncs = s.pdu_resyncs;
     if (s.status != GR4PM_OK) set_error("%s", s.error);
+    if (s.status != GR4PM_OK || !h->pdu_fn) {
+        // a failed batch, or nobody listening: whatever the sink had collected so far is not continued (a callback
+        // registered in the middle of a PDU must not get its tail as if it were a whole one)
+        for (int k = 0; k < 2; ++k) {
+            h->pdu_acc[k].clear();
+            h->pdu_open[k] = false;
+        }
+    }
     if (s.status == GR4PM_OK && h->pdu_fn && s.n_data) {
         // the tap's sink side: one copy of the batch's symbols to the host, then one call per complete PDU
         h->pdu_host.resize(s.n_data);
         GR4PM_HIP_TRY(hipMemcpy(h->pdu_host.data(), s.data.p, s.n_data * sizeof(gr4pm_c64), hipMemcpyDeviceToHost));
         for (const auto& pc : s.pdus) {
             auto& acc = h->pdu_acc[pc.kind];
-            if (pc.first) acc.clear();
+            if (pc.first) {
+                acc.clear();
+                h->pdu_open[pc.kind] = true;
+            }
+            if (!h->pdu_open[pc.kind]) continue; // the start of this PDU was never seen: not delivered
             acc.insert(acc.end(), h->pdu_host.begin() + static_cast<ptrdiff_t>(pc.offset),
                        h->pdu_host.begin() + static_cast<ptrdiff_t>(pc.offset + pc.length));
             if (pc.last) {
                 h->pdu_fn(h->pdu_user, pc.kind, acc.data(), acc.size());
                 acc.clear();
+                h->pdu_open[pc.kind] = false;
             }
         }
     }

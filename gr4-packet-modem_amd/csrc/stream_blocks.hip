@@ -34,8 +34,13 @@ namespace gr4pm {
 #endif
 static inline bool timing_skip(const char* name)
 {
-    static const char* e = getenv("GR4PM_TIMING_SKIP");
-    return e && strstr(e, name) != nullptr;
+    // comma-separated list, whole names ("symf" does not match "symf_fake"); read once, announced on stderr
+    static const char* e = gr4pm::experiment_env("GR4PM_TIMING_SKIP", true);
+    if (!e) return false;
+    const size_t n = strlen(name);
+    for (const char* p = e; (p = strstr(p, name)) != nullptr; p += n)
+        if ((p == e || p[-1] == ',') && (p[n] == 0 || p[n] == ',')) return true;
+    return false;
 }
 namespace {
 
@@ -1138,9 +1143,10 @@ static void launch_symbol_filter(hipStream_t s, unsigned n_wg, size_t smem, unsi
             if (timing_skip("symf_fake"))
                 hipLaunchKernelGGL(k_symf_fake, grid, dim3(kFastThreads), 0, s, in, plan, out);
             else if (!timing_skip("symf")) {
-                static const int abl = getenv("GR4PM_SYMF_ABL") ? atoi(getenv("GR4PM_SYMF_ABL")) : 0;
-                static const unsigned pad = getenv("GR4PM_SYMF_PAD") ? static_cast<unsigned>(atoi(getenv("GR4PM_SYMF_PAD"))) : 0u;
-                static const unsigned tiles = getenv("GR4PM_SYMF_TILES") ? static_cast<unsigned>(std::max(1, atoi(getenv("GR4PM_SYMF_TILES")))) : 2u;
+                static const char* abl_e = gr4pm::experiment_env("GR4PM_SYMF_ABL", true);
+                static const int abl = abl_e ? atoi(abl_e) : 0;
+                static const unsigned pad = gr4pm::experiment_env_wg("GR4PM_SYMF_PAD", 0u, 0u, 64u * 1024u);
+                static const unsigned tiles = gr4pm::experiment_env_wg("GR4PM_SYMF_TILES", 2u, 1u, 64u);
                 const dim3 gridf((n_wg + tiles - 1) / tiles);
 #define GR4PM_SYMF_LAUNCH(A)                                                                                         \
     hipLaunchKernelGGL(k_symbol_filter_fast<A>, gridf, dim3(kFastThreads), pad, s, in, carry, cap, taps, plan, out, cfc, \
@@ -1575,11 +1581,12 @@ static gr4pm_status rotator_plan(gr4pm_rotator* h, size_t n, const gr4pm_tag* ta
         static thread_local std::vector<unsigned> order;
         order.resize(n_segs);
         for (unsigned i = 0; i < n_segs; ++i) order[i] = i;
-        if (!getenv("GR4PM_ROT_NO_SORT"))
+        static const bool no_sort = gr4pm::experiment_env("GR4PM_ROT_NO_SORT", false) != nullptr;
+        if (!no_sort)
             std::stable_sort(order.begin(), order.end(), [&](unsigned a, unsigned b) { return segs[a].len > segs[b].len; });
         GR4PM_TRY(upload_vec(pl.order, order, s));
     }
-    static const unsigned wg = getenv("GR4PM_ROT_WG") ? static_cast<unsigned>(atoi(getenv("GR4PM_ROT_WG"))) : 64u;
+    static const unsigned wg = gr4pm::experiment_env_wg("GR4PM_ROT_WG", 64u, 1u, 64u); // __launch_bounds__(64)
     if (!timing_skip("rot")) // GR4PM_TIMING_SKIP: what a kernel costs the pipeline (results are garbage)
         hipLaunchKernelGGL(k_rot_checkpoints, dim3(grid_for(n_segs, wg)), dim3(wg), 0, s, pl.segs.p, n_segs,
                            h->state.p + static_cast<size_t>(h->st_cur) * h->n_channels,
@@ -1783,7 +1790,8 @@ static gr4pm_status costas_process_impl(gr4pm_costas_loop* h, const gr4pm_c64* i
     // the ping-pong state array, not through their order), so the longest ones are put together: a stream with missed
     // detections (segments that run through several packets: 64 channels of configs[2] hold ~80 of five packets'
     // length among 9700) then keeps two waves alive for the long tail instead of eighty.
-    if (!getenv("GR4PM_COSTAS_NO_SORT"))
+    static const bool costas_no_sort = gr4pm::experiment_env("GR4PM_COSTAS_NO_SORT", false) != nullptr;
+    if (!costas_no_sort)
         std::stable_sort(segs.begin(), segs.end(), [](const CostasSeg& a, const CostasSeg& b) { return a.len > b.len; });
     GR4PM_TRY(upload_vec(h->segs, segs, s));
     if (timing_skip("seg_stats")) { // GR4PM_TIMING_SKIP=seg_stats: what the serial kernel is given
@@ -1791,7 +1799,7 @@ static gr4pm_status costas_process_impl(gr4pm_costas_loop* h, const gr4pm_c64* i
         for (const auto& g : segs) longest = std::max<size_t>(longest, g.len), total += g.len;
         fprintf(stderr, "[gr4pm costas] %zu segments, %zu items, longest %zu\n", segs.size(), total, longest);
     }
-    static const unsigned wg = getenv("GR4PM_COSTAS_WG") ? static_cast<unsigned>(atoi(getenv("GR4PM_COSTAS_WG"))) : 64u;
+    static const unsigned wg = gr4pm::experiment_env_wg("GR4PM_COSTAS_WG", 64u, 1u, 1024u);
     const dim3 grid(grid_for(segs.size(), wg)), block(wg);
     const unsigned n_segs = static_cast<unsigned>(segs.size());
     const CostasState* st_in = h->state.p + h->st_cur * h->n_channels;
@@ -1800,7 +1808,9 @@ static gr4pm_status costas_process_impl(gr4pm_costas_loop* h, const gr4pm_c64* i
     auto launch = [&](auto kernel) {
         if (timing_skip("costas_fake")) { // GR4PM_FAKE=workgroups,ticks(10 ns),bytes of LDS
             unsigned wgs = grid.x, ticks = 83000u, lds = 0u;
-            if (const char* e = getenv("GR4PM_FAKE")) sscanf(e, "%u,%u,%u", &wgs, &ticks, &lds);
+            static const char* fake = gr4pm::experiment_env("GR4PM_FAKE", true);
+            if (fake) sscanf(fake, "%u,%u,%u", &wgs, &ticks, &lds);
+            wgs = std::max(wgs, 1u);
             if (lds > 48 * 1024)
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_serial_fake),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));

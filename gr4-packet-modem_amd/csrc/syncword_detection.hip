@@ -2047,9 +2047,14 @@ try {
         const std::string k = e ? e : "w64";
         h->use_pair = !h->generic && k == "pair";
         h->corr_kind = k == "pair" ? 2 : k == "wave" ? 1 : 0;
+        // the bit-identical variants (-1 default, 0 = round 2's bin loop, 65536 = planar loop with LDS-DMA templates,
+        // GR4PM_W64_ONE=1) select silently; every other value is a timing-only ablation with wrong powers and says so
         const char* v = getenv("GR4PM_W64_VARIANT");
         h->w64_variant = v ? atoi(v) : -1;
-        h->w64_one = getenv("GR4PM_W64_ONE") ? atoi(getenv("GR4PM_W64_ONE")) : 0;
+        if (v && h->w64_variant != -1 && h->w64_variant != 0 && h->w64_variant != 65536) (void)experiment_env("GR4PM_W64_VARIANT", true);
+        const char* one = getenv("GR4PM_W64_ONE");
+        h->w64_one = one ? atoi(one) : 0;
+        if (h->w64_one > 1) (void)experiment_env("GR4PM_W64_ONE", true);
         if (const char* b = getenv("GR4PM_W64_BLOCKS_PER_WAVE")) h->w64_blocks_per_wave = static_cast<uint32_t>(std::max(0, atoi(b)));
         int dev = 0;
         hipDeviceProp_t prop;

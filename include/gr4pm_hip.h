@@ -701,6 +701,10 @@ typedef struct {
     size_t n_pdu_symbols;
     const gr4pm_symbol_pdu* symbol_pdus; /* host: the pieces of header / payload PDUs inside pdu_symbols, in order */
     size_t n_symbol_pdus;
+    size_t symbol_pdu_resyncs;          /* "payload_symbols" tags that arrived where the tap's HeaderPayloadSplit did not
+                                           expect one (the reference block throws, header_payload_split.hpp:75-78; here
+                                           the tap starts over at the tag and the batch -- LLRs, packets -- is not failed
+                                           because of its optional side output) */
 } gr4pm_packet_receiver_result;
 gr4pm_status gr4pm_packet_receiver_create(const gr4pm_packet_receiver_params* params,
                                           gr4pm_packet_receiver** out);

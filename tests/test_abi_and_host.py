@@ -68,6 +68,31 @@ def test_bad_alloc_inside_an_entry_point_comes_back_as_a_status(pkg):
     L.gr4pm_test_fail_allocations(-1, 0)
 
 
+def test_isa_guard_catches_what_it_is_there_for(tmp_path):
+    """tools/check_m0.py on hand-made assembly: a register of an asm-issued template load touched before the
+    s_waitcnt that covers it, a compiler-generated m0 write (also in the v_readfirstlane form) and scratch use are
+    each reported; the same code with the wait in place passes"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_m0
+    head = ("_Z15k_correlate_w64ILi1EEvv:\n; %bb.0:\n\ts_mov_b32 s4, 0\n.LBB0_1:   ; in Loop: Header=BB0_1 Depth=1\n"
+            "\t;;#ASMSTART\n\tglobal_load_dwordx4 v[0:3], v9, s[2:3] offset:1024\n\t;;#ASMEND\n"
+            "\tglobal_store_dword v8, v7, s[4:5]\n")
+    tail = ("\tv_add_f32_e32 v5, v1, v6\n\ts_cbranch_scc1 .LBB0_1\n; %bb.2:\n\ts_endpgm\n.Lfunc_end0:\n"
+            "\t.amdhsa_kernel _Z15k_correlate_w64ILi1EEvv\n\t\t.amdhsa_private_segment_fixed_size {scr}\n\t.end_amdhsa_kernel\n")
+
+    def run(body, scr=0):
+        f = tmp_path / "k.s"
+        f.write_text(head + body + tail.format(scr=scr))
+        return check_m0.check(str(f))[-1]
+
+    assert run("\t;;#ASMSTART\n\ts_waitcnt vmcnt(1)\n\t;;#ASMEND\n") == []            # the store may stay in flight
+    bad = run("\t;;#ASMSTART\n\ts_waitcnt vmcnt(2)\n\t;;#ASMEND\n")                    # ... the load may not
+    assert len(bad) == 1 and "v1 is still being loaded" in bad[0]
+    assert any("still being loaded" in b for b in run(""))                                # no wait at all (loop path too)
+    assert any("write of m0" in b for b in run("\ts_waitcnt vmcnt(0)\n\tv_readfirstlane_b32 m0, v4\n"))
+    assert any("scratch" in b for b in run("\ts_waitcnt vmcnt(0)\n", scr=16))
+
+
 def test_library_exports_only_the_c_abi(pkg):
     """csrc/exports.map: nothing but gr4pm_* is in the dynamic symbol table -- in particular not the library's own
     operator new / delete, which would otherwise interpose on every C++ allocation of the process"""
@@ -171,9 +196,10 @@ def test_m0_guard_catches_a_compiler_written_m0(tmp_path):
     good.write_text("_ZN5gr4pm15k_correlate_w64ILi0EEEvv:\n\t;;#ASMSTART\n\ts_mov_b32 m0, s12\n\ts_nop 0\n\t;;#ASMEND\n"
                     "\tv_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7]\n.Lfunc_end0:\n"
                     "_ZN5gr4pm7k_otherEv:\n\ts_movk_i32 m0, 0x400\n.Lfunc_end1:\n")
-    assert check_m0.check(str(good)) == (1, 1, [])
+    seen, sites, _, _, problems = check_m0.check(str(good))
+    assert (seen, sites, problems) == (1, 1, [])
     bad = tmp_path / "bad.s"
     bad.write_text("_ZN5gr4pm15k_correlate_w64ILi0EEEvv:\n\ts_mov_b32 m0, s3\n\t;;#ASMSTART\n\ts_mov_b32 m0, s12\n\t;;#ASMEND\n"
                    ".Lfunc_end0:\n")
-    seen, sites, problems = check_m0.check(str(bad))
+    seen, sites, _, _, problems = check_m0.check(str(bad))
     assert seen == 1 and len(problems) == 1 and "compiler-generated" in problems[0]
