@@ -216,6 +216,20 @@ def pmc_traffic(samples, kernel="k_correlate_w64"):
         return {"traffic": None, "traffic_source": f"profiles/{os.path.basename(path)} missing"}
 
 
+def config2_reference():
+    """the configs[2] sub-record of the latest committed single-GPU bench line (profiles/r<N>_bench.json)"""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench.json"))):
+        try:
+            d = json.loads(open(path).read().strip().splitlines()[-1])
+            if d.get("n_gpus") == 1 and "config2" in d:
+                best = {"value": d["config2"]["value"], "source": os.path.relpath(path, ROOT)}
+        except (ValueError, OSError, IndexError, KeyError):
+            continue
+    return best
+
+
 def channel_bank(x, n_channels):
     """configs[2]/[3]: C channels from one burst stream: channel c is the stream rotated by 997 c
     samples with a carrier offset of -0.04 + 0.08 c / (C - 1) rad/sample on top"""
@@ -279,22 +293,39 @@ def aggregate(dist, dt, consumed, device):
     return tmax.item(), csum.item()
 
 
-def launch_ranks(n):
+def launch_ranks(n, selfcheck_first=True):
     """one worker process per GPU, rendezvous on 127.0.0.1 (what torch.distributed.run would set up); the parent
-    only waits -- it never initialises the GPU.  A rank that ends with an error ends the run: the ranks still
-    alive (blocked in a collective the failed rank never joins) are terminated -- the processes started here, by
-    handle -- and the launcher returns non-zero; no line can come out of a job that lost a rank."""
+    only waits -- it never initialises the GPU, and every rank is a FRESH child (a process that has touched the GPU
+    is never re-executed).  A rank that ends with an error ends the run: the ranks still alive (blocked in a
+    collective the failed rank never joins) are terminated -- the processes started here, by handle -- and the
+    launcher returns non-zero; no line can come out of a job that lost a rank.
+    First contact: before the real job the same ranks run `--selfcheck` (rendezvous with a 120-s timeout, identities,
+    a 2^22-item scatter, two steps of the receiver, no CPU legs: seconds); when that fails, the failing rank's stderr
+    is shown and the real job is not started."""
+    if selfcheck_first and "--selfcheck" not in sys.argv:
+        rc = _launch_once(n, sys.argv[1:] + ["--selfcheck"], capture=True)
+        if rc != 0:
+            print(f"bench.py: the {n}-rank self-check failed (exit {rc}); not starting the job", file=sys.stderr)
+            return rc
+    return _launch_once(n, sys.argv[1:], capture=False)
+
+
+def _launch_once(n, argv, capture):
     import socket
     import subprocess
+    import tempfile
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    procs = []
+    procs, logs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        log = tempfile.TemporaryFile(mode="w+") if capture else None
+        logs.append(log)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.DEVNULL if capture else None, stderr=log))
     worst = 0
     alive = list(procs)
     while alive:
@@ -307,6 +338,7 @@ def launch_ranks(n):
             if rc != 0:
                 worst = max(worst, abs(rc))
                 print(f"bench.py: rank {procs.index(p)} exited with {rc}; stopping the other ranks", file=sys.stderr)
+                failed_first = procs.index(p)
                 for q in alive:
                     q.terminate()
                 for q in alive:
@@ -315,6 +347,12 @@ def launch_ranks(n):
                     except subprocess.TimeoutExpired:
                         q.kill()
                 alive = []
+                if capture:  # the self-check's output is only shown when it fails: the failing rank's first
+                    for r in [failed_first] + [k for k in range(n) if k != failed_first]:
+                        logs[r].seek(0)
+                        text = logs[r].read()[-3000:]
+                        if text.strip():
+                            print(f"---- stderr of rank {r} ----\n{text}", file=sys.stderr)
                 break
     return worst
 
@@ -337,6 +375,80 @@ def rank_identities(dist, device, world):
     return {"backend": dist.get_backend(), "world": dist.get_world_size(), "ranks": everyone}
 
 
+def check_distinct_devices(job, world):
+    """every rank evaluates the gathered list (nobody is left waiting in a barrier for a rank that quit): N ranks must
+    sit on N different devices"""
+    ids = {(r["pci_bus_id"], r["uuid"]) for r in job["ranks"]}
+    if len(ids) != world:
+        raise SystemExit(f"bench.py: {world} ranks on {len(ids)} distinct devices: {job['ranks']}")
+
+
+def init_ranks(backend, local_rank=None):
+    """rendezvous with a bounded wait (a wedged rank costs two minutes, not the ten-minute default)"""
+    import datetime
+    import torch.distributed as dist
+    kw = {"timeout": datetime.timedelta(seconds=int(os.environ.get("GR4PM_DIST_TIMEOUT_S", "120")))}
+    if backend == "nccl":
+        kw["device_id"] = torch.device("cuda", local_rank)
+    dist.init_process_group(backend=backend, **kw)
+    return dist
+
+
+def scatter_budget(dist, rank, world, per_rank_bytes, device, host_ring):
+    """what rank 0 needs for a scatter, against what it has, BEFORE anything is allocated: `world` slabs on the device
+    (the ring uploaded for the scatter) + its own, and with host_ring the same bytes of (pinned) host memory.  Every
+    rank gets the verdict and leaves together when it does not fit."""
+    verdict = [None]
+    if rank == 0:
+        need_dev = per_rank_bytes * (world + 1)
+        free_dev = torch.cuda.mem_get_info(device)[0] if device.type == "cuda" else 1 << 62
+        need_host = per_rank_bytes * world if host_ring else 0
+        try:
+            import psutil
+            free_host = psutil.virtual_memory().available
+        except ImportError:
+            free_host = 1 << 62
+        msg = (f"scatter budget on rank 0: device {need_dev / 2**30:.1f} GiB needed / {free_dev / 2**30:.1f} GiB free, "
+               f"host {need_host / 2**30:.1f} GiB needed / {free_host / 2**30:.1f} GiB available")
+        print("bench.py:", msg, file=sys.stderr)
+        ok = need_dev < 0.9 * free_dev and need_host < 0.8 * free_host
+        verdict = [None if ok else msg]
+    dist.broadcast_object_list(verdict, src=0)
+    if verdict[0] is not None:
+        raise SystemExit(f"bench.py: rank 0 cannot hold the sample ring of {world} ranks: {verdict[0]}")
+
+
+def selfcheck(pkg, dist, device, rank, world, rrc):
+    """first contact of an N-rank job, seconds long: identities (N distinct devices), one scatter of 2^22-item channels
+    from rank 0, two batches through the native receiver on what arrived, detections counted on every rank (SUM > 0,
+    MIN > 0).  Any failure ends the rank with a message; the launcher ends the job."""
+    job = rank_identities(dist, device, world)
+    check_distinct_devices(job, world)
+    n = 1 << 22
+    def make_all():
+        return torch.stack([burst_stream(pkg, n, rrc, seed=77 + r, device=device)[0] for r in range(world)])
+    x = scatter_channels(dist, make_all, n, device, rank, world) if dist else burst_stream(pkg, n, rrc, seed=77, device=device)[0]
+    rx = pkg.NativePacketReceiver(SPS, BINS, 9.5, "QPSK", max_items=n, tags_cap=1024, pipelined=True)
+    tags = 0
+    for _ in range(2):
+        r = rx.process_bulk(x, 1500)
+        if r is not None:
+            tags += int(r["tags"].size)
+    for r in rx.flush():
+        tags += int(r["tags"].size)
+    del rx
+    t = torch.tensor([float(tags)], dtype=torch.float64, device=device)
+    if dist:
+        lo = t.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        if lo.item() <= 0:
+            raise SystemExit(f"bench.py self-check: a rank found no packet in its scattered channel (rank {rank}: {tags})")
+    elif tags <= 0:
+        raise SystemExit("bench.py self-check: no packet found")
+    return {"ranks": world, "tags": int(t.item()), "job": job}
+
+
 def dry_run(args):
     """--dry-run: the N > 1 plumbing (rendezvous, the channel scatter, MAX / SUM aggregation, rank identities,
     rank 0 prints) on gloo.  GR4PM_BENCH_TEST_FAIL_RANK=r makes rank r die just before the scatter
@@ -345,9 +457,19 @@ def dry_run(args):
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     device = torch.device("cpu")
     if world > 1:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        init_ranks("gloo")
+        # first thing after the rendezvous, evaluated on EVERY rank (GR4PM_BENCH_TEST_SAME_DEVICE: all ranks report
+        # one device -- the test of exactly that)
+        early = rank_identities(dist, device, world)
+        if os.environ.get("GR4PM_BENCH_TEST_SAME_DEVICE"):
+            for r in early["ranks"]:
+                r["pci_bus_id"] = "same"
+        check_distinct_devices(early, world)
     if os.environ.get("GR4PM_BENCH_TEST_FAIL_RANK") == str(rank):
-        os._exit(3)
+        # tests: die in the self-check pass (default) or, with GR4PM_BENCH_TEST_FAIL_IN_JOB, only in the job behind it
+        if bool(os.environ.get("GR4PM_BENCH_TEST_FAIL_IN_JOB")) != bool(args.selfcheck):
+            print(f"rank {rank}: forced failure (test)", file=sys.stderr, flush=True)
+            os._exit(3)
     scattered_ok = None
     if world > 1:
         mine = scatter_channels(dist, lambda: torch.stack([torch.full((64,), complex(r, 1), dtype=torch.complex64)
@@ -505,6 +627,8 @@ def channels64_leg(pkg, dist, device, rank, world, rrc, steps, warmup, repeats, 
     chain, submit / collect with four batches in flight, input read in place).  Timed like the headline region."""
     n_pkt = (n_items // SPS + 64) // (64 + 128 + 1504 * 4 + 500) + 1  # packets per channel and batch (burst_stream)
     if dist:
+        scatter_budget(dist, rank, world, 8 * n_items * channels, device, host_ring=True)
+
         def make_all():
             host, _ = host_sample_ring(world, (channels, n_items))
             for r in range(world):
@@ -614,6 +738,9 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=[2, 5],
                     help="2 (default): BASELINE configs[1], the headline workload; 5: BASELINE configs[4], the stress "
                          "shape (N = 4096 overlap-save blocks, 1025-tap RRC, SyncwordDetection + the 1025-tap filter leg)")
+    ap.add_argument("--selfcheck", action="store_true",
+                    help="N-rank first-contact check only (rendezvous, identities, a small scatter, two batches): what "
+                         "`bench.py --gpus N` runs by itself before the job")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / aggregation check without a GPU: every rank joins a gloo group, aggregates "
                          "fixed numbers and rank 0 prints the line (tests/test_distributed_cpu.py)")
@@ -643,14 +770,24 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist = init_ranks("nccl", local_rank)
+        # N distinct devices, checked right after the rendezvous and on every rank -- not after the timed regions
+        check_distinct_devices(rank_identities(dist, device, world), world)
     pkg = ge.load_package()
 
     rrc = unit_norm_rrc(pkg)
+    if args.selfcheck or world > 1:
+        sc = selfcheck(pkg, dist, device, rank, world, rrc)
+        if args.selfcheck:
+            if rank == 0:
+                print(json.dumps({"selfcheck": "ok", **sc}))
+            if dist:
+                dist.barrier()
+                dist.destroy_process_group()
+            return
     bpsk = np.array([1, -1], dtype=np.complex64)
     n_items = args.items
     input_mode = "generated on each GPU"
@@ -666,6 +803,7 @@ def main():
     if dist and not args.no_scatter:
         # multi-channel receive: rank 0 owns the sample ring of all channels and scatters it.  No fallback: a rank
         # that fails here ends with an error, and the launcher (torch.distributed.run or launch_ranks) ends the job.
+        scatter_budget(dist, rank, world, 8 * n_items * max(args.channels, 1), device, host_ring=args.channels > 1)
         if args.channels > 1:
             # configs[3]: `channels` per GPU; rank 0 fills its host sample ring [world, C, n] (D2H), uploads
             # it and scatters one [C, n] slab per rank: the workload's only collective
@@ -856,10 +994,7 @@ def main():
         channels_leg = channels64_leg(pkg, dist, device, rank, world, rrc, steps=max(args.steps, 8), warmup=6,
                                       repeats=min(args.repeats, 3))
     job = rank_identities(dist, device, world)
-    if dist and rank == 0:
-        ids = {(r["pci_bus_id"], r["uuid"]) for r in job["ranks"]}
-        if len(ids) != world:
-            raise SystemExit(f"bench.py: {world} ranks on {len(ids)} distinct devices: {job['ranks']}")
+    check_distinct_devices(job, world)
 
     # ---- roofline of the dominant kernel: HIP events on the stream the kernel runs on
     roofline = None
@@ -942,6 +1077,17 @@ def main():
             "job": job,
         }
         if channels_leg is not None:
+            if world > 1:
+                # 64 channels per GPU are the same work on every rank: the per-GPU rate of configs[3] should be the
+                # configs[2] rate of one GPU (the latest committed single-GPU line); flagged when it is not
+                ref = config2_reference()
+                channels_leg["per_gpu"] = round(channels_leg["value"] / world, 2)
+                channels_leg["config2_reference"] = ref
+                if ref:
+                    channels_leg["within_10pct_of_config2"] = bool(abs(channels_leg["per_gpu"] / ref["value"] - 1.0) <= 0.10)
+                    if not channels_leg["within_10pct_of_config2"]:
+                        print(f"bench.py: WARNING: config3 per GPU {channels_leg['per_gpu']} Msps vs config2 {ref['value']} "
+                              f"({ref['source']}): more than 10 % apart", file=sys.stderr)
             line["config2" if world == 1 else "config3"] = channels_leg
         print(json.dumps(line))
     if dist:

@@ -111,3 +111,56 @@ def test_bench_refuses_a_world_size_that_differs_from_gpus():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--dry-run"],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0 and "refusing" in r.stderr
+
+
+def _run_bench(argv, extra_env=None, timeout=600):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, capture_output=True, text=True, env=env,
+                          timeout=timeout)
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_bench_launcher_at_world_size_4_and_8(world):
+    """the launcher, the self-check pass in front of the job, the scatter shapes and the identities at the sizes the
+    driver's scaling run uses (gloo here): N fresh ranks, one line, N distinct participants, SUM / MAX aggregation"""
+    import json
+    r = _run_bench(["--gpus", str(world), "--dry-run", "--steps", "2"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1  # the self-check pass prints nothing
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == world and line["scatter_ok"] is True
+    assert line["value"] == 1000.0 * world * (world + 1) / 2 / world  # SUM of 1000 (r + 1) items / MAX of 1 + r seconds
+    job = line["job"]
+    assert job["world"] == world and [x["rank"] for x in job["ranks"]] == list(range(world))
+    assert len({x["pci_bus_id"] for x in job["ranks"]}) == world
+
+
+def test_bench_ranks_on_one_device_are_refused_by_every_rank():
+    """the distinct-device check runs right after the rendezvous and on every rank: all of them leave with the
+    message, nobody waits in a collective for a rank that quit"""
+    import time
+    t0 = time.time()
+    r = _run_bench(["--gpus", "2", "--dry-run"], {"GR4PM_BENCH_TEST_SAME_DEVICE": "1"})
+    assert r.returncode != 0 and time.time() - t0 < 120
+    assert r.stderr.count("2 ranks on 1 distinct devices") >= 2
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_selfcheck_failure_shows_the_failing_ranks_stderr_and_stops():
+    """first contact: the self-check pass fails -> its stderr is shown, the job itself is never started"""
+    r = _run_bench(["--gpus", "2", "--dry-run"], {"GR4PM_BENCH_TEST_FAIL_RANK": "1"})
+    assert r.returncode != 0
+    assert "---- stderr of rank 1 ----" in r.stderr and "forced failure (test)" in r.stderr
+    assert "self-check failed" in r.stderr and "not starting the job" in r.stderr
+
+
+def test_bench_rank_that_dies_inside_the_job_still_ends_it():
+    """the self-check passes, a rank dies later (before the job's scatter): same outcome as before the self-check existed"""
+    r = _run_bench(["--gpus", "2", "--dry-run"], {"GR4PM_BENCH_TEST_FAIL_RANK": "0", "GR4PM_BENCH_TEST_FAIL_IN_JOB": "1"})
+    assert r.returncode != 0 and "self-check failed" not in r.stderr and "stopping the other ranks" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
