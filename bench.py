@@ -738,6 +738,9 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=[2, 5],
                     help="2 (default): BASELINE configs[1], the headline workload; 5: BASELINE configs[4], the stress "
                          "shape (N = 4096 overlap-save blocks, 1025-tap RRC, SyncwordDetection + the 1025-tap filter leg)")
+    ap.add_argument("--no-per-bins", action="store_true",
+                    help="leave out the roofline.per_bins legs (profiling runs: the correlator's rocprof average is then "
+                         "the nine-bin launch alone)")
     ap.add_argument("--selfcheck", action="store_true",
                     help="N-rank first-contact check only (rendezvous, identities, a small scatter, two batches): what "
                          "`bench.py --gpus N` runs by itself before the job")
@@ -1032,7 +1035,7 @@ def main():
                     "alg_bytes_per_sample": 8,
                     "fp32_tflops": round(flops / (ms * 1e-3) / 1e12, 2),
                     "fp32_frac": round(flops / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)}
-        if args.channels == 1:
+        if args.channels == 1 and not args.no_per_bins:
             roofline["per_bins"] = per_bins_roofline(pkg, rrc, bpsk, x, n_items, roof_stream)
         # the CPU legs come after every GPU leg (256 busy host processes slow the GPU legs' launches), at N = 1 only
         if not args.no_cpu_baseline and world == 1:

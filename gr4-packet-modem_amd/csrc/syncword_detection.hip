@@ -621,6 +621,31 @@ __global__ __launch_bounds__(256) void k_candidates(const float* __restrict__ zb
 // Item i of a block <-> register i / 64, lane 63 - i % 64 (lanes reversed, so that the suffix inside a row is a
 // DPP prefix over lanes and "the item after mine" is wave_shr:1); rows are coalesced 256-byte loads.
 // Per block and wave: TQ loads, 2 TQ DPP scans, 2 TQ ds_bpermute (crossbar only, no LDS allocation), TQ ballots.
+// Round 4: (i) LAZY rows.  The window of an item of row r is: the rest of its own row, the rows behind it in its block
+// and the rows in front of it in the next block -- whole rows, whose maxima are wave-uniform (SGPRs) -- and the part of
+// row r of the next block up to the item's own offset.  U = the maximum over those whole rows costs scalar
+// instructions only; a row whose own maximum is below U cannot hold a candidate (strictly below: ties count, hpp:314),
+// and on noise that is 11 rows of 12.  Only the other rows pay for the item-order prefix of the next block's row (two
+// ds_bpermute + a scan), the shifted suffix, the compare and the ballot: 39 -> ~12 vector instructions per row on
+// average, identical flags (test_candidate_kernels_agree).  (ii) the suffix scans of four rows in ONE asm statement:
+// four independent chains fill each other's DPP wait states (was: an s_nop 1 in front of every step).
+// Uniform float maxima are kept as bit patterns and ordered through the usual monotone key (scalar ALU has no
+// float compare on gfx950): correct for every float, -inf (the fill behind the stream) and -1 included.
+__device__ __forceinline__ int fkey(int b) { return b ^ ((b >> 31) & 0x7fffffff); }
+__device__ __forceinline__ int smax_bits(int a, int b) { return fkey(a) >= fkey(b) ? a : b; }
+__device__ __forceinline__ void wave_prefix_max4(float& a, float& b, float& c, float& d)
+{
+#define GR4PM_STEP(ctl)                                    \
+    "v_max_f32_dpp %0, %0, %0 " ctl "\n\t"                 \
+    "v_max_f32_dpp %1, %1, %1 " ctl "\n\t"                 \
+    "v_max_f32_dpp %2, %2, %2 " ctl "\n\t"                 \
+    "v_max_f32_dpp %3, %3, %3 " ctl "\n\t"
+    asm volatile("s_nop 1\n\t" GR4PM_STEP("row_shr:1 row_mask:0xf bank_mask:0xf") GR4PM_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
+                     GR4PM_STEP("row_shr:4 row_mask:0xf bank_mask:0xf") GR4PM_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
+                         GR4PM_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf") GR4PM_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef GR4PM_STEP
+}
 template <int TQ>
 __global__ __launch_bounds__(64) void k_candidates_wave(const float* __restrict__ zbase, size_t z_stride, uint32_t cnt,
                                                         uint32_t n_words, uint32_t chain,
@@ -642,40 +667,49 @@ __global__ __launch_bounds__(64) void k_candidates_wave(const float* __restrict_
             v[r] = g < avail ? z[g] : -INFINITY;
         }
     };
-    // per block: rs[r] = suffix maximum inside row r (inclusive, reversed lanes), rowmax[r] = maximum of row r (uniform:
-    // readlane, i.e. an SGPR), pr[r] = prefix maximum of the block up to the lane's item (inclusive, reversed lanes)
-    auto scans = [&](const float* v, float* rs, float* rowmax, float* pr) {
+    // per block: rs[r] = suffix maximum inside row r (inclusive, reversed lanes), rowmax[r] = bits of the maximum of row r
+    // (uniform: readlane, i.e. an SGPR)
+    auto scans = [&](const float* v, float* rs, int* rowmax) {
 #pragma unroll
-        for (int r = 0; r < TQ; ++r) {
-            rs[r] = wave_prefix_max(v[r]);
-            rowmax[r] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rs[r]), 63));
-        }
-        if (!pr) return;
-        float carry = -INFINITY;
+        for (int r = 0; r < TQ; ++r) rs[r] = v[r];
+        if constexpr (TQ % 4 == 0) {
 #pragma unroll
-        for (int r = 0; r < TQ; ++r) {
-            const float fwd = __shfl(v[r], rl);                 // row in item order
-            const float pn = fmaxf(wave_prefix_max(fwd), carry); // prefix of the block, item order
-            pr[r] = __shfl(pn, rl);
-            carry = fmaxf(carry, rowmax[r]);
+            for (int r = 0; r < TQ; r += 4) wave_prefix_max4(rs[r], rs[r + 1], rs[r + 2], rs[r + 3]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < TQ; ++r) rs[r] = wave_prefix_max(rs[r]);
         }
+#pragma unroll
+        for (int r = 0; r < TQ; ++r) rowmax[r] = __builtin_amdgcn_readlane(__builtin_bit_cast(int, rs[r]), 63);
     };
-    float cur[TQ], rs[TQ], rowmax[TQ], nxt[TQ];
+    const int ninf = __builtin_bit_cast(int, -INFINITY);
+    float cur[TQ], rs[TQ], nxt[TQ];
+    int rowmax[TQ];
     load(b0, cur);
-    scans(cur, rs, rowmax, nullptr);
+    scans(cur, rs, rowmax);
     for (uint32_t b = b0; b < b1; ++b) {
         load(b + 1, nxt);
-        float nrs[TQ], nrowmax[TQ], npr[TQ];
-        scans(nxt, nrs, nrowmax, npr);
+        float nrs[TQ];
+        int nrowmax[TQ], before[TQ]; // before[r]: maximum of rows 0 .. r-1 of the next block
+        scans(nxt, nrs, nrowmax);
+        before[0] = ninf;
+#pragma unroll
+        for (int r = 1; r < TQ; ++r) before[r] = smax_bits(before[r - 1], nrowmax[r - 1]);
         unsigned long long mine = 0;
-        float after = -INFINITY; // maximum of the rows behind r (uniform): built while r walks down
+        int after = ninf; // maximum of the rows behind r in this block: built while r walks down
 #pragma unroll
         for (int r = TQ - 1; r >= 0; --r) {
-            const float m = fmaxf(fmaxf(wave_prev(rs[r]), after), npr[r]);
-            const uint32_t pos = b * T + 64u * r + rl;
-            const unsigned long long word = __brevll(__ballot(pos < cnt && cur[r] >= m)); // back to item order
+            const int U = smax_bits(after, before[r]);
+            unsigned long long word = 0;
+            if (fkey(rowmax[r]) >= fkey(U)) { // (uniform: a scalar branch)
+                const float fwd = __shfl(nxt[r], rl);              // the next block's row r in item order
+                const float pr = __shfl(wave_prefix_max(fwd), rl); // its prefix maximum up to the lane's own offset
+                const float m = fmaxf(fmaxf(wave_prev(rs[r]), __builtin_bit_cast(float, U)), pr);
+                const uint32_t pos = b * T + 64u * r + rl;
+                word = __brevll(__ballot(pos < cnt && cur[r] >= m)); // back to item order
+            }
             if (lane == r) mine = word;
-            after = fmaxf(after, rowmax[r]);
+            after = smax_bits(after, rowmax[r]);
         }
         const uint32_t w = b * TQ + lane;
         if (lane < TQ && w < n_words) bmp[w] = mine;
