@@ -422,6 +422,13 @@ def selfcheck(pkg, dist, device, rank, world, rrc):
     """first contact of an N-rank job, seconds long: identities (N distinct devices), one scatter of 2^22-item channels
     from rank 0, two batches through the native receiver on what arrived, detections counted on every rank (SUM > 0,
     MIN > 0).  Any failure ends the rank with a message; the launcher ends the job."""
+    # ---- BASELINE configs[4] (the 2-Gsps stress shape) as a sub-record of the default line, N = 1 only
+    config5_rec = None
+    if headline and not args.no_config5_leg and world == 1:
+        multi = None
+        torch.cuda.empty_cache()
+        config5_rec = config5_leg(pkg, device)
+        torch.cuda.empty_cache()
     job = rank_identities(dist, device, world)
     check_distinct_devices(job, world)
     n = 1 << 22
@@ -589,6 +596,131 @@ def config5(args):
     print(json.dumps(line))
 
 
+def config5_stream(pkg, n, device, seed=5, chunk=1 << 26):
+    """the configs[4] input: bursts (syncword + random BPSK, shaped with the 1025-tap RRC at 4 samples per symbol) every
+    16384 symbols in AWGN, n samples, generated on the GPU chunk by chunk (the noise is added in place)"""
+    rrc = pkg.root_raised_cosine(1.0, float(SPS), 1.0, 0.35, 1024)
+    rrc = (rrc / np.sqrt(np.sum(rrc.astype(np.float64) ** 2))).astype(np.float32)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    n_sym = n // SPS
+    bits = torch.randint(0, 2, (n_sym,), generator=g, device=device, dtype=torch.int8)
+    sw = torch.from_numpy(SYNCWORD.astype(np.int8)).to(device)
+    starts = torch.arange(2000, n_sym - 64, 16384, device=device)
+    for k in range(64):
+        bits[starts + k] = sw[k]
+    fir = pkg.InterpolatingFirFilter(SPS, rrc)
+    x = torch.empty(n, dtype=torch.complex64, device=device)
+    sym_chunk = chunk // SPS
+    for a in range(0, n_sym, sym_chunk):  # the filter carries its history from call to call: one continuous stream
+        b = min(a + sym_chunk, n_sym)
+        sym = torch.complex((1 - 2 * bits[a:b]).float(), torch.zeros(b - a, device=device))
+        y = fir.process_bulk(sym.contiguous())
+        y += torch.view_as_complex(0.05 * torch.randn((y.numel(), 2), device=device, generator=g))
+        x[a * SPS:a * SPS + y.numel()] = y
+    return x, rrc, fir
+
+
+def config5_leg(pkg, device, total=1 << 30, window=1 << 28, passes=2):
+    """BASELINE configs[4] as SURVEY.md 8(d) config 5 defines it, in the default run: 1 channel, fft_size 4096, 1025-tap
+    RRC (syncword 63 * 4 + 1025 = 1277 samples, stride 2820), B in {1, 9} bins, 2^30 samples STREAMED through a device
+    ring: SyncwordDetection takes them window by window (2^28 items offered, whole strides consumed, the next window
+    starts where the call stopped and is announced a call ahead: gr4pm_syncword_detection_hint_next), then the
+    receiving side of the same pulse, SymbolFilter with 32 arms x 1025 taps (symbol_filter.hpp:208-238), over the same
+    ring.  `value` = 2^30 samples / (detector at nine bins + symbol filter), one after the other."""
+    nfft = 4096
+    x, rrc, _fir = config5_stream(pkg, total, device)
+    del _fir
+    L = 63 * SPS + rrc.size
+    S = nfft - L + 1
+    bpsk = np.array([1, -1], dtype=np.complex64)
+
+    def windows():
+        pos, out = 0, []
+        while total - pos >= nfft:
+            take = min(window, total - pos)
+            out.append((pos, take))
+            pos += ((take - nfft) // S + 1) * S
+        return out
+    wins = windows()
+    per_bins = {}
+    for b in (0, BINS):
+        # power_threshold 30, not the receiver's 9.5: with a 1025-tap template the correlation power is smooth over
+        # hundreds of lags, a 1537-item history holds few independent values, and at 9.5 the detector (reference and
+        # oracle alike) fires on plain data
+        sd = pkg.SyncwordDetection(rrc, SYNCWORD, bpsk, -b, b, fft_size=nfft, power_threshold=30.0, max_items=window)
+
+        def one_pass():
+            done = tags = 0
+            for k, (pos, take) in enumerate(wins):
+                nxt = x[wins[k + 1][0]:wins[k + 1][0] + wins[k + 1][1]] if k + 1 < len(wins) else None
+                _, _, t, nd = sd.process_bulk(x[pos:pos + take], want_output=False, tags_cap=1 << 17, next_x=nxt)
+                assert nd == ((take - nfft) // S + 1) * S
+                done += nd
+                tags += t.size
+            return done, tags
+        one_pass()
+        sd.reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        done = tags = 0
+        for _ in range(passes):
+            d, t = one_pass()
+            sd.reset()  # the ring wraps: a new stream
+            done += d
+            tags += t
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        # the correlator alone on one window: HIP events on the launch stream
+        xs = x[:window]
+        sd.correlate_only(xs)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            sd.correlate_only(xs)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 3
+        samples = ((window - nfft) // S + 1) * S
+        fl = correlator_flops_per_sample(2 * b + 1, nfft, S) * samples / (ms * 1e-3) / 1e12
+        per_bins[str(2 * b + 1)] = {
+            "value": round(done / dt / 1e6, 2), "unit": "Msamples/s", "ms_per_2^30": round(dt / passes * 1e3, 3),
+            "tags_per_2^30": tags // passes,
+            "roofline": {"bound": "hbm", "kernel": "k_correlate_4096", "launch_ms": round(ms, 4), "samples_per_launch": samples,
+                         "achieved": round(8.0 * samples / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(8.0 * samples / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "alg_bytes_per_sample": 8,
+                         "traffic": None, "fp32_tflops": round(fl, 2), "fp32_frac": round(fl / FP32_PEAK_TFLOPS, 4)}}
+        del sd
+    pfb = pkg.root_raised_cosine(32.0, 32.0 * SPS, 1.0, 0.35, 32 * 1024)[: 32 * 1025]
+    sf = pkg.SymbolFilter(pfb, 32, SPS, delay=1025)
+
+    def symf_pass():
+        n = 0
+        for a in range(0, total, window):
+            _, _, c = sf.process_bulk(x[a:a + window])
+            n += c
+        return n
+    symf_pass()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n_sf = sum(symf_pass() for _ in range(passes))
+    torch.cuda.synchronize()
+    dt_sf = time.perf_counter() - t0
+    sf_rate = n_sf / dt_sf / 1e6
+    det9 = per_bins[str(2 * BINS + 1)]["value"]
+    both = 1.0 / (1.0 / det9 + 1.0 / sf_rate)
+    return {"workload": f"configs[4] (SURVEY.md 8(d) config 5): 1 channel, fft_size 4096, 1025-tap RRC (syncword {L} samples, "
+                        f"stride {S}), power_threshold 30, 2^30 samples streamed through a device ring in {len(wins)} windows of "
+                        "2^28 offered items (look-ahead one window ahead); SyncwordDetection at 1 and 9 bins, then "
+                        "SymbolFilter 32 arms x 1025 taps over the same ring",
+            "value": round(both, 2), "unit": "Msamples/s", "samples_per_pass": total, "passes": passes, "windows": len(wins),
+            "per_bins": per_bins,
+            "symbol_filter_32x1025": {"value": round(sf_rate, 2), "unit": "Msamples/s in",
+                                      "fp32_tflops": round(1025.0 * sf_rate * 1e6 / 1e12, 2),
+                                      "fp32_frac": round(1025.0 * sf_rate * 1e6 / 1e12 / FP32_PEAK_TFLOPS, 4)}}
+
+
 def correlator_flops_per_sample(n_bins, n_fft=N_FFT, stride=1752):
     """[(1 + B) 5 N log2 N + 6 B N + 1.5 N + 4 B S] / S"""
     return ((1 + n_bins) * 5.0 * n_fft * np.log2(n_fft) + 6.0 * n_bins * n_fft + 1.5 * n_fft + 4.0 * n_bins * stride) / stride
@@ -738,6 +870,8 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=[2, 5],
                     help="2 (default): BASELINE configs[1], the headline workload; 5: BASELINE configs[4], the stress "
                          "shape (N = 4096 overlap-save blocks, 1025-tap RRC, SyncwordDetection + the 1025-tap filter leg)")
+    ap.add_argument("--no-config5-leg", action="store_true",
+                    help="leave out the configs[4] sub-record (2^30 samples, fft_size 4096, 1025-tap RRC) of the default line")
     ap.add_argument("--no-per-bins", action="store_true",
                     help="leave out the roofline.per_bins legs (profiling runs: the correlator's rocprof average is then "
                          "the nine-bin launch alone)")
@@ -996,6 +1130,13 @@ def main():
         rx = None  # the headline receiver is done: its stage threads and streams go before the next leg starts
         channels_leg = channels64_leg(pkg, dist, device, rank, world, rrc, steps=max(args.steps, 8), warmup=6,
                                       repeats=min(args.repeats, 3))
+    # ---- BASELINE configs[4] (the 2-Gsps stress shape) as a sub-record of the default line, N = 1 only
+    config5_rec = None
+    if headline and not args.no_config5_leg and world == 1:
+        multi = None
+        torch.cuda.empty_cache()
+        config5_rec = config5_leg(pkg, device)
+        torch.cuda.empty_cache()
     job = rank_identities(dist, device, world)
     check_distinct_devices(job, world)
 
@@ -1079,6 +1220,8 @@ def main():
             "cpu_baseline": cpu,
             "job": job,
         }
+        if config5_rec is not None:
+            line["config5"] = config5_rec
         if channels_leg is not None:
             if world > 1:
                 # 64 channels per GPU are the same work on every rank: the per-GPU rate of configs[3] should be the

@@ -5,34 +5,68 @@
 // Replaces syncword_detection.hpp:238-252,300-313 for that size (the radix-2 LDS kernel k_correlate_generic keeps
 // every other power of two).
 #pragma once
+#include "fft2048_w64.hpp"
 #include "fft4096_wg.hpp"
 
 namespace gr4pm {
 namespace {
 
-__device__ __forceinline__ void f4k_fft(int t, cf* r, cf* lds, const cf* __restrict__ tw1, const cf* tw2)
+// VAR (GR4PM_C4096_VARIANT when the handle is created; 0 - 7 bit-identical; measured per 2^26 samples on one box, round 4,
+// tools/c4096_variants.py: 9 bins 1.221 / 1.014 / 1.468 / 1.112 / 1.455 / 1.273 / 1.387 / 1.217 ms for 0 .. 7, one bin
+// 0.307 / 0.249 / 0.463 / 0.314 / 0.418 / 0.374 / 0.424 / 0.384):
+//   1  (DEFAULT) the fifteen pass-1 twiddles W4096^(t k1) of the thread live in registers for the whole block (they
+//      are the same for the forward transform and for every bin) instead of fifteen L1 / L2 loads per transform; hipcc
+//      then needs 128 VGPRs instead of 158 (no per-transform address arithmetic): four waves per SIMD instead of three
+//   2  the next bin's sixteen template values are requested before the current bin's transform starts
+//   4  two exchange images (pass 1 -> 2 through A, pass 2 -> 3 through B): the two barriers that only protect an
+//      image against being overwritten while the transform before is still reading it go away (2 per transform, not 4)
+//      -- but 70 KiB of LDS per workgroup leave two workgroups per CU: slower
+//   9  variant 1 with the FMA-form DFT-16 of fft2048_w64.hpp: 314 instead of 326 packed instructions per bin, powers
+//      differ in the last bits; not adopted
+template <int VAR>
+__device__ __forceinline__ void f4k_fft(int t, cf* r, cf* lds, cf* ldsB, const cf* __restrict__ tw1, const cf* tw1r,
+                                        const cf* tw2)
 {
-    f4k_pass1(t, r, tw1);
-    __syncthreads(); // the previous transform's last reads of the image are done
+    if (VAR & 8) { // FMA-form butterflies (fft2048_w64.hpp: dft16f), the registers of variant 1; powers differ in the last bits
+        dft16f(r);
+#pragma unroll
+        for (int k1 = 1; k1 < 16; ++k1) r[k1] = cmul(r[k1], tw1r[k1]);
+    } else if (VAR & 1) {
+        dft16(r);
+#pragma unroll
+        for (int k1 = 1; k1 < 16; ++k1) r[k1] = cmul(r[k1], tw1r[k1]);
+    } else {
+        f4k_pass1(t, r, tw1);
+    }
+    if (!(VAR & 4)) __syncthreads(); // the previous transform's last reads of the image are done
     f4k_store1(t, r, lds);
     __syncthreads();
     f4k_load2(t, r, lds);
-    f4k_pass2(t, r, tw2);
+    if (VAR & 8) {
+        dft16f(r);
+#pragma unroll
+        for (int k2 = 1; k2 < 16; ++k2) r[k2] = cmul(r[k2], tw2[k2 * 16 + (t >> 4)]);
+    } else {
+        f4k_pass2(t, r, tw2);
+    }
+    if (!(VAR & 4)) __syncthreads();
+    f4k_store2(t, r, (VAR & 4) ? ldsB : lds);
     __syncthreads();
-    f4k_store2(t, r, lds);
-    __syncthreads();
-    f4k_load3(t, r, lds);
-    f4k_pass3(r);
+    f4k_load3(t, r, (VAR & 4) ? ldsB : lds);
+    if (VAR & 8) dft16f(r);
+    else f4k_pass3(r);
 }
 
 // grid (n_blocks, n_channels); tmpl: [bin][4096] conjugated template spectra, natural order
+template <int VAR>
 __global__ __launch_bounds__(kT4k) void k_correlate_4096(const cf* __restrict__ in, size_t in_stride, uint32_t n_blocks,
                                                          uint32_t stride_s, int n_bins, const cf* __restrict__ tmpl,
                                                          const cf* __restrict__ tw1, const cf* __restrict__ tw2g,
                                                          float* __restrict__ zpow, size_t z_stride)
 {
-    __shared__ cf lds[kX4kItems];
+    __shared__ cf lds[(VAR & 4) ? 2 * kX4kItems : kX4kItems];
     __shared__ cf tw2[256];
+    cf* ldsB = lds + ((VAR & 4) ? kX4kItems : 0);
     const int t = threadIdx.x;
     tw2[t] = tw2g[t];
     const uint32_t b = blockIdx.x;
@@ -41,19 +75,37 @@ __global__ __launch_bounds__(kT4k) void k_correlate_4096(const cf* __restrict__ 
     cf r[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) r[j] = x[256 * j];
+    cf tw1r[16];
+    if (VAR & 9) {
+#pragma unroll
+        for (int k1 = 1; k1 < 16; ++k1) tw1r[k1] = tw1[k1 * 256 + t];
+    }
     __syncthreads();
-    f4k_fft(t, r, lds, tw1, tw2); // hpp:239-241
+    f4k_fft<VAR>(t, r, lds, ldsB, tw1, tw1r, tw2); // hpp:239-241
     cf X[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) X[j] = r[j];
     float zmax[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) zmax[j] = -1.0f; // hpp:303
+    cf tn[16];
+    if (VAR & 2) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) tn[j] = tmpl[t + 256 * j];
+    }
     for (int bin = 0; bin < n_bins; ++bin) {
         const cf* tb = tmpl + static_cast<size_t>(bin) * kN4k + t;
+        if (VAR & 2) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) r[j] = cmul(X[j], tb[256 * j]); // hpp:247-249
-        f4k_fft(t, r, lds, tw1, tw2);                                  // hpp:250-251
+            for (int j = 0; j < 16; ++j) r[j] = cmul(X[j], tn[j]); // hpp:247-249
+            const cf* tnext = tmpl + static_cast<size_t>(min(bin + 1, n_bins - 1)) * kN4k + t;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) tn[j] = tnext[256 * j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) r[j] = cmul(X[j], tb[256 * j]); // hpp:247-249
+        }
+        f4k_fft<VAR>(t, r, lds, ldsB, tw1, tw1r, tw2); // hpp:250-251
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const float pw = fmaf(r[j].y, r[j].y, r[j].x * r[j].x); // hpp:307-308

@@ -1608,6 +1608,7 @@ struct gr4pm_syncword_detection {
     int log2n = 0;
     DevBuf<cf> g_tmpl, g_tw;
     DevBuf<cf> tw4k;          // fft_size 4096: tw1 ++ tw2 of fft4096_wg.hpp
+    int c4096_variant = 1;    // GR4PM_C4096_VARIANT: which form of k_correlate_4096 runs (1: pass-1 twiddles in registers)
     bool force_radix2 = false; // GR4PM_CORRELATOR=radix2: the generic kernel also for 4096 (tests compare the two)
     DevBuf<cf> carry[kCarry]; // sample carry before this call, before the calls ahead, and the one being written
     DevBuf<float> z[kSets];
@@ -1737,9 +1738,22 @@ gr4pm_status launch_correlate(gr4pm_syncword_detection* h, hipStream_t stream, c
                               size_t in_stride, uint32_t n_blocks, float* zout)
 {
     if (h->generic && h->fft_size == static_cast<size_t>(kN4k) && !h->force_radix2) {
-        hipLaunchKernelGGL(k_correlate_4096, dim3(n_blocks, static_cast<unsigned>(h->n_channels)), dim3(kT4k), 0, stream,
-                           reinterpret_cast<const cf*>(in), in_stride, n_blocks, static_cast<uint32_t>(h->S), h->n_bins,
-                           h->g_tmpl.p, h->tw4k.p, h->tw4k.p + 16 * 256, zout, h->z_stride);
+#define GR4PM_C4096(V)                                                                                                   \
+    hipLaunchKernelGGL(k_correlate_4096<V>, dim3(n_blocks, static_cast<unsigned>(h->n_channels)), dim3(kT4k), 0, stream,  \
+                       reinterpret_cast<const cf*>(in), in_stride, n_blocks, static_cast<uint32_t>(h->S), h->n_bins,      \
+                       h->g_tmpl.p, h->tw4k.p, h->tw4k.p + 16 * 256, zout, h->z_stride)
+        switch (h->c4096_variant) { // GR4PM_C4096_VARIANT (bit-identical forms, correlate_4096.hpp)
+        case 0: GR4PM_C4096(0); break;
+        case 1: GR4PM_C4096(1); break;
+        case 2: GR4PM_C4096(2); break;
+        case 3: GR4PM_C4096(3); break;
+        case 4: GR4PM_C4096(4); break;
+        case 5: GR4PM_C4096(5); break;
+        case 6: GR4PM_C4096(6); break;
+        case 7: GR4PM_C4096(7); break;
+        default: GR4PM_C4096(9); break; // (FMA-form butterflies: not bit-identical)
+        }
+#undef GR4PM_C4096
         GR4PM_HIP_TRY(hipGetLastError());
         return GR4PM_OK;
     }
@@ -2086,6 +2100,7 @@ try {
         const char* v = getenv("GR4PM_W64_VARIANT");
         h->w64_variant = v ? atoi(v) : -1;
         if (v && h->w64_variant != -1 && h->w64_variant != 0 && h->w64_variant != 65536) (void)experiment_env("GR4PM_W64_VARIANT", true);
+        if (const char* cv = getenv("GR4PM_C4096_VARIANT")) h->c4096_variant = atoi(cv) & 15;
         const char* one = getenv("GR4PM_W64_ONE");
         h->w64_one = one ? atoi(one) : 0;
         if (h->w64_one > 1) (void)experiment_env("GR4PM_W64_ONE", true);
