@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "hostlogic/packet_control.hpp"
 
 namespace gr4pm {
 namespace {
@@ -41,9 +42,7 @@ __global__ __launch_bounds__(256) void k_scramble(const ScrRun* __restrict__ run
 }
 
 // ------------------------------------------------------------------ span gather (float items)
-struct FSpan {
-    unsigned long long src, dst, len;
-};
+using FSpan = hostlogic::CopySpan; // hostlogic/base.hpp
 __global__ __launch_bounds__(256) void k_gather_f32(const FSpan* __restrict__ spans, const float* __restrict__ in,
                                                     float* __restrict__ out)
 {
@@ -383,13 +382,9 @@ struct gr4pm_additive_scrambler {
     DevBuf<uint8_t> seq;
     DevBuf<ScrRun> runs;
 };
-struct gr4pm_header_payload_split {
-    size_t header_size;
-    hipStream_t stream;
-    bool in_payload = false;    // header_payload_split.hpp:25
-    uint64_t position = 0;      // :26
-    uint64_t payload_items = 0; // :27
-    DevBuf<FSpan> hspans, pspans;
+struct gr4pm_header_payload_split : gr4pm::hostlogic::HpsState {
+    hipStream_t stream = nullptr;
+    DevBuf<gr4pm::hostlogic::CopySpan> hspans, pspans;
 };
 struct gr4pm_header_fec_decoder {
     unsigned n = 0, m = 0, n_steps = 0, max_iterations = 25;
@@ -588,76 +583,12 @@ try {
         set_error("null sample pointer");
         return GR4PM_ERR_INVALID;
     }
-    std::vector<FSpan> hs, ps;
-    size_t pos = 0, hp = 0, pp = 0, t = 0, nht = 0, npt = 0;
-    bool overflow = false;
-    while (pos < n) {
-        while (t < n_tags_in && tags_in[t].index < pos) ++t;
-        size_t t1 = t;
-        while (t1 < n_tags_in && tags_in[t1].index == pos) ++t1;
-        const size_t end = t1 < n_tags_in ? std::min<size_t>(n, tags_in[t1].index) : n;
-        for (size_t u = t; u < t1; ++u) // :68-82
-            if (tags_in[u].kind == GR4PM_PKT_PAYLOAD) {
-                if (h->in_payload || h->position != h->header_size) {
-                    set_error("received unexpected payload_bits tag"); // :75-78
-                    return GR4PM_ERR_INVALID;
-                }
-                h->in_payload = true;
-                h->position = 0;
-                h->payload_items = tags_in[u].payload_bits;
-            }
-        for (size_t u = t; u < t1; ++u) { // :83-87
-            gr4pm_packet_tag o = tags_in[u];
-            if (h->in_payload) {
-                o.index = pp;
-                if (payload_tags && npt < tags_cap) payload_tags[npt] = o;
-                else overflow = true;
-                ++npt;
-            } else {
-                o.index = hp;
-                if (header_tags && nht < tags_cap) header_tags[nht] = o;
-                else overflow = true;
-                ++nht;
-            }
-        }
-        t = t1;
-        size_t cur = pos;
-        while (cur < end) {
-            if (!h->in_payload && h->position == h->header_size) h->position = 0; // :90-95
-            if (!h->in_payload) { // :97-109
-                const size_t m = std::min<size_t>(end - cur, h->header_size - h->position);
-                hs.push_back({ cur, hp, m });
-                hp += m;
-                cur += m;
-                h->position += m;
-            } else { // :110-123
-                const size_t m = std::min<size_t>(end - cur, static_cast<size_t>(h->payload_items - h->position));
-                ps.push_back({ cur, pp, m });
-                pp += m;
-                cur += m;
-                h->position += m;
-                if (h->position >= h->payload_items) {
-                    h->in_payload = false;
-                    h->position = 0;
-                }
-            }
-        }
-        pos = end;
-    }
-    // neighbouring spans of one output are contiguous on both sides: merge them
-    auto merge = [](std::vector<FSpan>& v) {
-        std::vector<FSpan> o;
-        for (const auto& s : v) {
-            if (s.len == 0) continue;
-            if (!o.empty() && o.back().src + o.back().len == s.src && o.back().dst + o.back().len == s.dst)
-                o.back().len += s.len;
-            else
-                o.push_back(s);
-        }
-        v.swap(o);
-    };
-    merge(hs);
-    merge(ps);
+    gr4pm::hostlogic::HpsReplay rp; // the state machine: hostlogic/packet_control.hpp
+    GR4PM_TRY(gr4pm::hostlogic::hps_replay(*h, n, tags_in, n_tags_in, header_tags, payload_tags, tags_cap, rp));
+    const std::vector<FSpan>& hs = rp.header_spans;
+    const std::vector<FSpan>& ps = rp.payload_spans;
+    const size_t hp = rp.n_header, pp = rp.n_payload, nht = rp.n_header_tags, npt = rp.n_payload_tags;
+    const bool overflow = rp.tag_overflow;
     GR4PM_TRY(gather_f32(h->stream, h->hspans, hs, in, header));
     GR4PM_TRY(gather_f32(h->stream, h->pspans, ps, in, payload));
     GR4PM_HIP_TRY(final_sync(h->stream));

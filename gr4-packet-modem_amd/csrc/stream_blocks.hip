@@ -22,6 +22,9 @@
 #include <vector>
 
 #include "common.hpp"
+#include "hostlogic/sdf_gate.hpp"
+#include "hostlogic/symbol_filter_replay.hpp"
+#include "hostlogic/packet_control.hpp"
 
 namespace gr4pm {
 // GR4PM_TIMING_SKIP=name[,name]: timing experiments only -- the named kernels are not launched (their outputs are
@@ -651,15 +654,7 @@ __global__ __launch_bounds__(kFirItems) void k_interp_fir(const T* __restrict__ 
 }
 
 // SymbolFilter (symbol_filter.hpp:208-214): y = scale * sum_m arm[m] * x[idx - m]
-struct SymRun {
-    long long in0;  // input index of the newest sample of the run's first output
-    unsigned out0;  // first output index
-    unsigned count; // outputs, spaced samples_per_symbol apart
-    unsigned arm;
-    float scale;
-    unsigned wg0;   // first workgroup of the run (workgroups never straddle runs)
-    unsigned chan;  // channel of the run (launches that span channels: SymChan table)
-};
+using hostlogic::SymRun; // hostlogic/symbol_filter_replay.hpp
 #ifndef GR4PM_SYM_PER_WG
 #define GR4PM_SYM_PER_WG 256
 #endif
@@ -2118,16 +2113,9 @@ GR4PM_ABI_CATCH
 } // extern "C"
 
 // ------------------------------------------------------------------ SyncwordDetectionFilter
-struct gr4pm_syncword_detection_filter {
-    size_t sps, syncword_size, header_size, allowed_margin = 16; // :44-47
-    hipStream_t stream;
-    bool in_packet = false; // :35-37
-    size_t position = 0, block_until = 0;
-    // gate(): absolute item index where the current packet span ends (exclusive)
-    bool gate_in_packet = false;
-    uint64_t gate_start = 0, gate_end = 0;
-    bool gate_end_known = false;
-    size_t gate_hdr_idx = static_cast<size_t>(-1); // per-tag mode: header slot of the open packet
+// the state machine itself: hostlogic/sdf_gate.hpp (no HIP; also built with sanitizers by tests/hostlogic/)
+struct gr4pm_syncword_detection_filter : gr4pm::hostlogic::SdfState {
+    hipStream_t stream = nullptr;
 };
 
 extern "C" {
@@ -2170,69 +2158,14 @@ gr4pm_status gr4pm_syncword_detection_filter_process(gr4pm_syncword_detection_fi
                                                      int* tag_out_flags)
 try {
     if (!h || !consumed_ || !headers_consumed || !ignored_consumed || !tag_out_flags) return GR4PM_ERR_INVALID;
-    *consumed_ = *headers_consumed = *ignored_consumed = 0;
-    *tag_out_flags = 0;
-    auto copy = [&](size_t off, size_t n) -> gr4pm_status {
-        if (n == 0) return GR4PM_OK;
-        GR4PM_HIP_TRY(hipMemcpyAsync(out + off, in + off, n * sizeof(gr4pm_c64), hipMemcpyDeviceToDevice,
-                                     h->stream));
-        return GR4PM_OK;
-    };
-    if (head_tag_flags) { // :75-105
-        int of = 0;
-        bool new_in_packet = false;
-        if ((head_tag_flags & GR4PM_TAG_SYNCWORD) && !h->in_packet) {
-            new_in_packet = true;
-            of |= GR4PM_TAG_SYNCWORD;
-        }
-        if (head_tag_flags & GR4PM_TAG_OTHER) of |= GR4PM_TAG_OTHER;
-        if (new_in_packet) {
-            h->in_packet = true;
-            h->position = 0;
-            h->block_until = 0;
-        }
-        *tag_out_flags = of;
-    }
-    if (!h->in_packet) { // :107-130
-        const size_t n = std::min(n_in, out_cap);
-        GR4PM_TRY(copy(0, n));
-        *consumed_ = n;
-        GR4PM_HIP_TRY(hipStreamSynchronize(h->stream));
-        return GR4PM_OK;
-    }
-    if (h->block_until == 0 && n_headers > 0) { // :134-153
-        *headers_consumed = 1;
-        if (headers[0].invalid_header) {
-            h->block_until = 1;
-        } else {
-            if (headers[0].packet_length == 0) {
-                set_error("received packet_length = 0"); // :143-145
-                return GR4PM_ERR_INVALID;
-            }
-            const size_t payload_symbols = (headers[0].packet_length + 4) * 4;
-            h->block_until = h->sps * (h->header_size + h->syncword_size - h->allowed_margin + payload_symbols);
-        }
-    }
-    if (h->block_until == 0 && n_ignored > 0) { // :157-160
-        *ignored_consumed = 1;
-        h->block_until = 1;
-    }
-    size_t consumed = 0;
-    const size_t allowed = h->sps * (h->syncword_size + h->header_size + h->allowed_margin);
-    if (h->position < allowed) { // :166-172
-        const size_t n = std::min({ n_in, out_cap, allowed - h->position });
-        GR4PM_TRY(copy(0, n));
-        h->position += n;
-        consumed = n;
-    }
-    if (h->position >= allowed && h->block_until != 0) { // :174-185
-        const size_t n = std::min(n_in, out_cap) - consumed;
-        GR4PM_TRY(copy(consumed, n));
-        h->position += n;
-        consumed += n;
-        if (h->position >= h->block_until) h->in_packet = false;
-    }
-    *consumed_ = consumed;
+    gr4pm::hostlogic::CopySpan runs[2];
+    int n_runs = 0;
+    GR4PM_TRY(gr4pm::hostlogic::sdf_process_plan(*h, n_in, out_cap, head_tag_flags, headers, n_headers, n_ignored,
+                                                 consumed_, headers_consumed, ignored_consumed, tag_out_flags, runs,
+                                                 &n_runs));
+    for (int r = 0; r < n_runs; ++r)
+        GR4PM_HIP_TRY(hipMemcpyAsync(out + runs[r].dst, in + runs[r].src, runs[r].len * sizeof(gr4pm_c64),
+                                     hipMemcpyDeviceToDevice, h->stream));
     GR4PM_HIP_TRY(hipStreamSynchronize(h->stream));
     return GR4PM_OK;
 }
@@ -2247,74 +2180,7 @@ extern "C" gr4pm_status gr4pm_syncword_detection_filter_gate(gr4pm_syncword_dete
                                                              size_t* headers_used)
 try {
     if (!h || !accepted || !headers_used) return GR4PM_ERR_INVALID;
-    if (headers_per_tag && n_headers != n_tags) return GR4PM_ERR_INVALID;
-    *headers_used = 0;
-    const uint64_t allowed = h->sps * (h->syncword_size + h->header_size + h->allowed_margin); // :164-165
-    size_t hu = 0;
-    for (size_t i = 0; i < n_tags; ++i) {
-        const uint64_t at = tag_index[i];
-        if (h->gate_in_packet) {
-            // resolve the pending header before looking at this tag: the reference cannot get
-            // past `allowed` items of the packet without it (:166-185)
-            if (!h->gate_end_known &&
-                (headers_per_tag ? (h->gate_hdr_idx < n_headers && headers[h->gate_hdr_idx].invalid_header != 2)
-                                 : hu < n_headers)) {
-                const gr4pm_header_msg& m = headers_per_tag ? headers[h->gate_hdr_idx] : headers[hu];
-                ++hu;
-                uint64_t block_until = 1; // invalid header / ignored syncword, :139,:159
-                if (!m.invalid_header) {
-                    if (m.packet_length == 0) {
-                        set_error("received packet_length = 0");
-                        return GR4PM_ERR_INVALID;
-                    }
-                    block_until = h->sps * (h->header_size + h->syncword_size - h->allowed_margin +
-                                            (m.packet_length + 4) * 4); // :146-151
-                }
-                h->gate_end = h->gate_start + std::max<uint64_t>(allowed, block_until);
-                h->gate_end_known = true;
-            }
-            // inside the first `allowed` items the span is open whatever the header says
-            const uint64_t end = h->gate_end_known ? h->gate_end : h->gate_start + allowed;
-            if (at < end) {
-                accepted[i] = 0; // :83-88 dropped while _in_packet
-                continue;
-            }
-            if (!h->gate_end_known) {
-                // a tag beyond `allowed` with the header still unknown: the caller has not
-                // supplied the message the reference would be waiting for
-                set_error("parsed_header message missing for the packet at item %llu",
-                          static_cast<unsigned long long>(h->gate_start));
-                return GR4PM_INSUFFICIENT_INPUT_ITEMS;
-            }
-            h->gate_in_packet = false;
-        }
-        accepted[i] = 1; // :85-97
-        h->gate_in_packet = true;
-        h->gate_start = at;
-        h->gate_end_known = false;
-        h->gate_hdr_idx = i;
-    }
-    if (headers_per_tag && h->gate_in_packet && !h->gate_end_known && h->gate_hdr_idx < n_headers &&
-        headers[h->gate_hdr_idx].invalid_header != 2) {
-        // resolve the last accepted tag of this call now: its header will not be re-presented
-        // (a pending one, invalid_header == 2, is resolved later by ..._gate_resolve)
-        const gr4pm_header_msg& m = headers[h->gate_hdr_idx];
-        uint64_t block_until = 1;
-        if (!m.invalid_header) {
-            if (m.packet_length == 0) {
-                set_error("received packet_length = 0");
-                return GR4PM_ERR_INVALID;
-            }
-            block_until =
-                h->sps * (h->header_size + h->syncword_size - h->allowed_margin + (m.packet_length + 4) * 4);
-        }
-        h->gate_end = h->gate_start + std::max<uint64_t>(allowed, block_until);
-        h->gate_end_known = true;
-        ++hu;
-    }
-    h->gate_hdr_idx = static_cast<size_t>(-1);
-    *headers_used = hu;
-    return GR4PM_OK;
+    return gr4pm::hostlogic::sdf_gate(*h, tag_index, n_tags, headers, n_headers, headers_per_tag, accepted, headers_used);
 }
 GR4PM_ABI_CATCH
 
@@ -2322,19 +2188,7 @@ extern "C" gr4pm_status gr4pm_syncword_detection_filter_gate_resolve(gr4pm_syncw
                                                                      const gr4pm_header_msg* msg)
 try {
     if (!h || !msg) return GR4PM_ERR_INVALID;
-    if (!h->gate_in_packet || h->gate_end_known) return GR4PM_OK; // nothing is waiting
-    const uint64_t allowed = h->sps * (h->syncword_size + h->header_size + h->allowed_margin);
-    uint64_t block_until = 1;
-    if (!msg->invalid_header) {
-        if (msg->packet_length == 0) {
-            set_error("received packet_length = 0");
-            return GR4PM_ERR_INVALID;
-        }
-        block_until = h->sps * (h->header_size + h->syncword_size - h->allowed_margin + (msg->packet_length + 4) * 4);
-    }
-    h->gate_end = h->gate_start + std::max<uint64_t>(allowed, block_until);
-    h->gate_end_known = true;
-    return GR4PM_OK;
+    return gr4pm::hostlogic::sdf_gate_resolve(*h, *msg);
 }
 GR4PM_ABI_CATCH
 
@@ -2450,12 +2304,8 @@ GR4PM_ABI_CATCH
 } // extern "C"
 
 // ------------------------------------------------------------------ SymbolFilter
-struct SymQueued {
-    long value; // gr::Tag::index as counted down in symbol_filter.hpp:183-185,235-237
-    gr4pm_tag tag;
-};
-struct gr4pm_symbol_filter {
-    size_t sps, num_arms, delay, arm_size;
+struct gr4pm_symbol_filter : gr4pm::hostlogic::SymfHostState { // the tag-driven state: hostlogic/symbol_filter_replay.hpp
+    size_t arm_size;
     int item_kind;
     unsigned cap;
     hipStream_t stream;
@@ -2464,10 +2314,6 @@ struct gr4pm_symbol_filter {
     DevBuf<SymRun> runs;
     DevBuf<SymWg> wg_plan;
     int cur = 0;
-    // host replica of the tag-driven state (symbol_filter.hpp:44-50)
-    size_t clock_phase = 0, reset_clock_phase = 0, pfb_arm = 0;
-    float scale = 1.0f;
-    std::deque<SymQueued> queue;
 };
 
 extern "C" {
@@ -2536,132 +2382,8 @@ GR4PM_ABI_CATCH
 
 } // extern "C"
 
-// Host replay of the tag-driven state machine of symbol_filter.hpp:130-238 over one call: which outputs exist, from
-// which input, with which arm and scale (runs), and where the tags leave.
-struct SymReplay {
-    std::vector<SymRun> runs;
-    size_t pos = 0, produced = 0, n_pub = 0;
-    bool tag_overflow = false;
-};
-static void symf_replay(gr4pm_symbol_filter* h, size_t n_in, size_t out_cap, const gr4pm_tag* tags_in,
-                        size_t n_tags_in, gr4pm_tag* tags_out, size_t tags_cap, SymReplay& rp)
-{
-    const size_t sps = h->sps;
-    const long half = static_cast<long>(sps / 2);
-    std::vector<SymRun>& runs = rp.runs;
-    size_t& pos = rp.pos;
-    size_t& produced = rp.produced;
-    size_t& n_pub = rp.n_pub;
-    bool& tag_overflow = rp.tag_overflow;
-    auto publish = [&](const gr4pm_tag& t, size_t out_index) {
-        if (tags_out && n_pub < tags_cap) {
-            tags_out[n_pub] = t;
-            tags_out[n_pub].index = out_index;
-        } else {
-            tag_overflow = true;
-        }
-        ++n_pub;
-    };
-    // main loop of :208-238 over k items without tag events; returns items actually consumed
-    auto advance = [&](size_t k) -> size_t {
-        size_t done = 0;
-        while (done < k && produced < out_cap) {
-            if (h->clock_phase >= sps) { // only reachable through the sps <= 2 corner of :182,:194
-                ++h->clock_phase;
-                if (h->clock_phase >= sps) h->clock_phase = 0;
-                for (auto& q : h->queue) --q.value;
-                ++done;
-                ++pos;
-                continue;
-            }
-            const size_t span = k - done;
-            const size_t u0 = (sps - h->clock_phase) % sps; // offset of the first output
-            size_t count = u0 < span ? (span - u0 + sps - 1) / sps : 0;
-            size_t eff = span;
-            if (produced + count > out_cap) { // :208 stops once the output is full
-                count = out_cap - produced;
-                eff = u0 + (count - 1) * sps + 1;
-            }
-            if (count > 0) {
-                SymRun r;
-                r.in0 = static_cast<long long>(pos + u0);
-                r.out0 = static_cast<unsigned>(produced);
-                r.count = static_cast<unsigned>(count);
-                r.arm = static_cast<unsigned>(h->pfb_arm);
-                r.scale = h->scale;
-                runs.push_back(r);
-                // tags leave on the first output whose countdown is below sps/2 (:218-228)
-                while (!h->queue.empty()) {
-                    const long v = h->queue.front().value;
-                    const long umin = std::max<long>(0, v - half + 1);
-                    size_t tix = 0;
-                    if (static_cast<size_t>(umin) > u0) tix = (static_cast<size_t>(umin) - u0 + sps - 1) / sps;
-                    if (tix >= count) break;
-                    publish(h->queue.front().tag, produced + tix);
-                    h->queue.pop_front();
-                }
-            }
-            h->clock_phase = (h->clock_phase + eff) % sps;
-            for (auto& q : h->queue) q.value -= static_cast<long>(eff);
-            produced += count;
-            pos += eff;
-            done += eff;
-            if (eff < span) break; // output full
-        }
-        return done;
-    };
-    size_t t = 0;
-    bool full = false;
-    while (pos < n_in && !full) {
-        while (t < n_tags_in && tags_in[t].index < pos) ++t; // tags inside consumed specials
-        if (t < n_tags_in && tags_in[t].index == pos) {
-            gr4pm_tag tag = tags_in[t++];
-            long adjust = 0;
-            if (tag.flags & GR4PM_TAG_SYNCWORD) { // :130-203
-                size_t new_cp = h->reset_clock_phase;
-                h->scale = 1.0f / tag.amplitude;
-                float time_est = tag.time_est;
-                if (time_est < 0.0f) { // :148-156
-                    new_cp = (new_cp + 1) % sps;
-                    time_est += 1.0f;
-                    tag.phase = static_cast<float>(static_cast<double>(tag.phase) - tag.freq);
-                }
-                if (h->clock_phase == 0 && new_cp == 1) { // :160-189
-                    SymRun r;
-                    r.in0 = static_cast<long long>(pos);
-                    r.out0 = static_cast<unsigned>(produced);
-                    r.count = 1;
-                    r.arm = static_cast<unsigned>(h->pfb_arm); // arm not yet updated (:199)
-                    r.scale = h->scale;
-                    runs.push_back(r);
-                    while (!h->queue.empty() && h->queue.front().value < half) {
-                        publish(h->queue.front().tag, produced);
-                        h->queue.pop_front();
-                    }
-                    ++produced;
-                    ++new_cp;
-                    for (auto& q : h->queue) --q.value;
-                    adjust = -1;
-                    ++pos;
-                } else if (h->clock_phase == 1 && new_cp == 0) { // :192-195
-                    ++pos;
-                    ++new_cp;
-                }
-                h->clock_phase = new_cp;
-                const float a = std::round(static_cast<float>(h->num_arms) * time_est);
-                h->pfb_arm = std::min(static_cast<size_t>(a), h->num_arms - 1); // :199-202
-            }
-            h->queue.push_back({ static_cast<long>(h->delay) + adjust, tag }); // :204-205
-        }
-        size_t end = n_in;
-        if (t < n_tags_in && tags_in[t].index < end) end = std::max<size_t>(pos, tags_in[t].index);
-        if (end > pos) {
-            const size_t want = end - pos;
-            if (advance(want) < want) full = true;
-        }
-        if (produced >= out_cap && pos < n_in) full = true;
-    }
-}
+using hostlogic::SymReplay; // the host replay of symbol_filter.hpp:130-238: hostlogic/symbol_filter_replay.hpp
+using hostlogic::symf_replay;
 
 // fuse == nullptr: plain SymbolFilter.  Otherwise the input is rotated by the CFC plan on the fly.
 static gr4pm_status symbol_filter_impl(gr4pm_symbol_filter* h, const void* in, size_t n_in, void* out,
@@ -2679,7 +2401,7 @@ static gr4pm_status symbol_filter_impl(gr4pm_symbol_filter* h, const void* in, s
     }
     const size_t sps = h->sps;
     SymReplay rp;
-    symf_replay(h, n_in, out_cap, tags_in, n_tags_in, tags_out, tags_cap, rp);
+    symf_replay(*h, n_in, out_cap, tags_in, n_tags_in, tags_out, tags_cap, rp);
     std::vector<SymRun>& runs = rp.runs;
     const size_t pos = rp.pos, produced = rp.produced, n_pub = rp.n_pub;
     const bool tag_overflow = rp.tag_overflow;
@@ -2905,7 +2627,7 @@ try {
     for (size_t c = 0; c < n_channels; ++c) {
         gr4pm_symbol_filter* h = sf[c];
         SymReplay rp;
-        symf_replay(h, n_in, out_stride, tags_in[c], n_tags_in[c], tags_out[c], tags_cap, rp);
+        symf_replay(*h, n_in, out_stride, tags_in[c], n_tags_in[c], tags_out[c], tags_cap, rp);
         if (rp.pos != n_in) {
             set_error("fused call consumed %zu of %zu items (channel %zu)", rp.pos, n_in, c);
             return GR4PM_ERR_INVALID;
@@ -3180,9 +2902,7 @@ GR4PM_ABI_CATCH
 namespace gr4pm {
 namespace {
 
-struct CopySpan {
-    unsigned long long src, dst, len;
-};
+using hostlogic::CopySpan; // hostlogic/base.hpp
 // grid (x, n_spans): the blocks of a row walk their span with coalesced 8-byte accesses
 __global__ __launch_bounds__(256) void k_gather_spans(const CopySpan* __restrict__ spans, const cf* __restrict__ in,
                                                       cf* __restrict__ out)
@@ -3231,25 +2951,13 @@ __global__ __launch_bounds__(256) void k_llr(const LlrRun* __restrict__ runs, fl
 } // namespace
 } // namespace gr4pm
 
-struct gr4pm_payload_metadata_insert {
-    size_t syncword_size, header_size;
-    double syncword_bw, header_bw, payload_bw;
-    hipStream_t stream;
-    bool in_packet = false;     // payload_metadata_insert.hpp:37
-    uint64_t position = 0;      // :38
-    size_t payload_symbols = 0; // :39
-    uint64_t num_packet = 0;    // :40
-    // headers_per_tag mode: the message that answers the syncword which opened the packet
-    gr4pm_header_msg held{};
-    bool has_held = false;
-    DevBuf<CopySpan> spans;
+struct gr4pm_payload_metadata_insert : gr4pm::hostlogic::PmiState {
+    hipStream_t stream = nullptr;
+    DevBuf<gr4pm::hostlogic::CopySpan> spans;
 };
-struct gr4pm_syncword_remove {
-    size_t syncword_size;
-    hipStream_t stream;
-    bool in_syncword = false; // syncword_remove.hpp:25
-    size_t position = 0;      // :26
-    DevBuf<CopySpan> spans;
+struct gr4pm_syncword_remove : gr4pm::hostlogic::SrState {
+    hipStream_t stream = nullptr;
+    DevBuf<gr4pm::hostlogic::CopySpan> spans;
 };
 struct gr4pm_constellation_llr_decoder {
     float noise_sigma, scale;
@@ -3315,116 +3023,12 @@ try {
 #ifdef GR4PM_TIMING
     const auto t_pmi0 = std::chrono::steady_clock::now();
 #endif
-    std::vector<CopySpan> spans;
-    size_t n_pub = 0, hdr = 0, ignored = 0;
-    bool tag_overflow = false;
-    auto publish = [&](const gr4pm_packet_tag& t) {
-        if (tags_out && n_pub < tags_cap) tags_out[n_pub] = t;
-        else tag_overflow = true;
-        ++n_pub;
-    };
-    size_t ipos = 0, opos = 0; // items consumed / produced so far
-    auto pass = [&](size_t want) { // move up to `want` items from the input to the output
-        spans.push_back({ ipos, opos, want });
-        ipos += want;
-        opos += want;
-        h->position += want;
-    };
-    const size_t sw = h->syncword_size, hs = h->header_size;
-    size_t t = 0;
-    bool stop = false;
-    while (ipos < n_in && !stop) {
-        // one processBulk() call: the chunk [ipos, end) with at most one tag, at its head
-        while (t < n_tags_in && tags_in[t].index < ipos) ++t;
-        const bool head_tag = t < n_tags_in && tags_in[t].index == ipos;
-        const bool has_tag = head_tag && (tags_in[t].flags & GR4PM_TAG_SYNCWORD); // syncword_amplitude key
-        size_t end = n_in;
-        if (const size_t u = head_tag ? t + 1 : t; u < n_tags_in) end = std::min<size_t>(end, tags_in[u].index);
-        const size_t chunk0 = ipos;
-        if (has_tag) { // :96-149
-            if (!h->in_packet) {
-                h->in_packet = true;
-                h->position = 0;
-                ++h->num_packet;
-                gr4pm_packet_tag pt{};
-                pt.index = opos;
-                pt.kind = GR4PM_PKT_SYNCWORD;
-                pt.constellation = 0; // the syncword modulation has been wiped off: pure pilot
-                pt.loop_bandwidth = h->syncword_bw;
-                pt.syncword = tags_in[t];
-                publish(pt);
-                if (headers_per_tag) {
-                    h->held = headers[t];
-                    h->has_held = headers[t].invalid_header != 2; // 2 = pending, see ..._resolve
-                }
-            } else {
-                ++ignored;
-            }
-        }
-        if (!h->in_packet) { // :150-169
-            ipos = end;
-            if (head_tag) ++t;
-            continue;
-        }
-        while (opos < out_cap && ipos < end) { // :174
-            if (h->position < sw) pass(std::min({ end - ipos, out_cap - opos, static_cast<size_t>(sw - h->position) }));
-            if (h->position == sw) { // :186-194
-                gr4pm_packet_tag pt{};
-                pt.index = opos;
-                pt.kind = GR4PM_PKT_HEADER_START;
-                pt.constellation = 2;
-                pt.loop_bandwidth = h->header_bw;
-                publish(pt);
-            }
-            if (sw <= h->position && h->position < sw + hs)
-                pass(std::min({ end - ipos, out_cap - opos, static_cast<size_t>(sw + hs - h->position) }));
-            if (h->position == sw + hs && opos < out_cap && ipos < end) {
-                if (headers_per_tag ? h->has_held : hdr < n_headers) { // :207-242
-                    const gr4pm_header_msg msg = headers_per_tag ? h->held : headers[hdr];
-                    h->has_held = false;
-                    if (msg.invalid_header) {
-                        h->in_packet = false;
-                        ipos = end;
-                        ++hdr;
-                        break;
-                    }
-                    const uint64_t packet_length = msg.packet_length;
-                    if (packet_length == 0) {
-                        set_error("received packet_length = 0"); // :224-226
-                        return GR4PM_ERR_INVALID;
-                    }
-                    h->payload_symbols = static_cast<size_t>((packet_length + 4) * 4); // + CRC-32, QPSK
-                    gr4pm_packet_tag pt{};
-                    pt.index = opos;
-                    pt.kind = GR4PM_PKT_PAYLOAD;
-                    pt.constellation = -1;
-                    pt.loop_bandwidth = h->payload_bw;
-                    pt.packet_length = packet_length;
-                    pt.payload_symbols = h->payload_symbols;
-                    pt.payload_bits = 2 * static_cast<uint64_t>(h->payload_symbols);
-                    publish(pt);
-                    pass(std::min({ end - ipos, out_cap - opos, h->payload_symbols }));
-                    ++hdr;
-                } else { // :243-247: return and wait for the header
-                    stop = true;
-                    break;
-                }
-            }
-            if (sw + hs < h->position && h->position < sw + hs + h->payload_symbols)
-                pass(std::min({ end - ipos, out_cap - opos,
-                                static_cast<size_t>(sw + hs + h->payload_symbols - h->position) }));
-            if (h->position >= sw + hs + h->payload_symbols) { // :263-267
-                h->in_packet = false;
-                ipos = end;
-            }
-        }
-        if (head_tag && ipos > chunk0) ++t;
-        if (ipos == chunk0) stop = true; // no progress: waiting for a header or output full
-        else if (opos >= out_cap && ipos < end) stop = true;
-    }
-    // spans of length 0 come from the min() above when a stage has nothing to move
-    spans.erase(std::remove_if(spans.begin(), spans.end(), [](const CopySpan& c) { return c.len == 0; }),
-                spans.end());
+    gr4pm::hostlogic::PmiReplay rp; // the state machine: hostlogic/packet_control.hpp
+    GR4PM_TRY(gr4pm::hostlogic::pmi_replay(*h, n_in, out_cap, tags_in, n_tags_in, headers, n_headers, headers_per_tag,
+                                           tags_out, tags_cap, rp));
+    const std::vector<CopySpan>& spans = rp.spans;
+    const size_t n_pub = rp.n_pub, hdr = rp.headers_used, ignored = rp.ignored, ipos = rp.consumed, opos = rp.produced;
+    const bool tag_overflow = rp.tag_overflow;
 #ifdef GR4PM_TIMING
     const auto t_pmi1 = std::chrono::steady_clock::now();
 #endif
@@ -3509,46 +3113,11 @@ try {
         set_error("null sample pointer");
         return GR4PM_ERR_INVALID;
     }
-    std::vector<CopySpan> spans;
-    size_t pos = 0, opos = 0, t = 0, n_pub = 0;
-    bool tag_overflow = false;
-    while (pos < n) {
-        while (t < n_tags_in && tags_in[t].index < pos) ++t;
-        // the tags sitting on the chunk's first item (one merged map in the reference)
-        size_t t1 = t;
-        bool syncword = false;
-        while (t1 < n_tags_in && tags_in[t1].index == pos) syncword |= tags_in[t1++].kind == GR4PM_PKT_SYNCWORD;
-        const size_t end = t1 < n_tags_in ? std::min<size_t>(n, tags_in[t1].index) : n;
-        if (!h->in_syncword && t1 > t) { // :51-64
-            if (syncword) {
-                h->in_syncword = true;
-                h->position = 0;
-            } else {
-                for (size_t u = t; u < t1; ++u) {
-                    if (tags_out && n_pub < tags_cap) {
-                        tags_out[n_pub] = tags_in[u];
-                        tags_out[n_pub].index = opos;
-                    } else {
-                        tag_overflow = true;
-                    }
-                    ++n_pub;
-                }
-            }
-        }
-        size_t from = pos;
-        if (h->in_syncword) { // :67-74
-            const size_t m = std::min(end - pos, h->syncword_size - h->position);
-            from += m;
-            h->position += m;
-            if (h->position >= h->syncword_size) h->in_syncword = false;
-        }
-        if (!h->in_syncword && end > from) { // :76-81
-            spans.push_back({ from, opos, end - from });
-            opos += end - from;
-        }
-        t = t1;
-        pos = end;
-    }
+    gr4pm::hostlogic::SrReplay rp; // the state machine: hostlogic/packet_control.hpp
+    gr4pm::hostlogic::sr_replay(*h, n, tags_in, n_tags_in, tags_out, tags_cap, rp);
+    const std::vector<CopySpan>& spans = rp.spans;
+    const size_t opos = rp.produced, n_pub = rp.n_pub;
+    const bool tag_overflow = rp.tag_overflow;
     GR4PM_TRY(launch_gather(h->stream, h->spans, spans, reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(out)));
     GR4PM_HIP_TRY(final_sync(h->stream));
     *produced = opos;

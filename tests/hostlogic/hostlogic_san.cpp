@@ -1,0 +1,434 @@
+// tests/hostlogic/hostlogic_san.cpp -- the library's HIP-free host logic (csrc/hostlogic/*.hpp: the very code the .hip
+// files include) under AddressSanitizer / UndefinedBehaviorSanitizer / ThreadSanitizer, checked against the CPU oracle
+// on randomised streams in the style of tools/fuzz_*.py (tags at ragged distances, random messages, random call
+// boundaries).  What a run table or a span table means is applied here with plain loops -- the kernels' job on the GPU
+// -- so that items and tags can be compared with the oracle's bit for bit.
+//   hostlogic_san.<san>.bin [cases] [seed]
+#include <atomic>
+#include <cassert>
+#include <chrono>
+#include <cmath>
+#include <complex>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "gr4pm_oracle.h"
+#include "hostlogic/packet_control.hpp"
+#include "hostlogic/sdf_gate.hpp"
+#include "hostlogic/slot_queue.hpp"
+#include "hostlogic/symbol_filter_replay.hpp"
+
+namespace gr4pm {
+static thread_local char g_error[512];
+void set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+}
+} // namespace gr4pm
+using namespace gr4pm::hostlogic;
+
+static_assert(sizeof(orc_tag) == sizeof(gr4pm_tag) && sizeof(orc_ptag) == sizeof(gr4pm_packet_tag) &&
+                  sizeof(orc_c64) == sizeof(gr4pm_c64),
+              "the oracle's records and the ABI's have one layout");
+using c64 = orc_c64;
+static int g_failures = 0;
+#define CHECK(cond, ...)                                                   \
+    do {                                                                   \
+        if (!(cond)) {                                                     \
+            ++g_failures;                                                  \
+            fprintf(stderr, "FAIL %s:%d: %s -- ", __FILE__, __LINE__, #cond); \
+            fprintf(stderr, __VA_ARGS__);                                  \
+            fprintf(stderr, "\n");                                         \
+        }                                                                  \
+    } while (0)
+
+static bool same_bits(const c64* a, const c64* b, size_t n) { return n == 0 || std::memcmp(a, b, n * sizeof(c64)) == 0; }
+// field by field (the records have tail padding, which nobody defines)
+template <typename T>
+static bool bits_eq(const T& a, const T& b) { return std::memcmp(&a, &b, sizeof(T)) == 0; }
+static bool same_tag(const gr4pm_tag& a, const gr4pm_tag& b)
+{
+    return a.index == b.index && bits_eq(a.amplitude, b.amplitude) && bits_eq(a.phase, b.phase) && bits_eq(a.freq, b.freq) &&
+           a.freq_bin == b.freq_bin && bits_eq(a.noise_power, b.noise_power) && bits_eq(a.esn0_db, b.esn0_db) &&
+           bits_eq(a.time_est, b.time_est) && a.flags == b.flags;
+}
+static bool same_tags(const gr4pm_tag* a, const gr4pm_tag* b, size_t n)
+{
+    for (size_t i = 0; i < n; ++i)
+        if (!same_tag(a[i], b[i])) return false;
+    return true;
+}
+static bool same_ptags(const gr4pm_packet_tag* a, const gr4pm_packet_tag* b, size_t n)
+{
+    for (size_t i = 0; i < n; ++i)
+        if (!(a[i].index == b[i].index && a[i].kind == b[i].kind && a[i].constellation == b[i].constellation &&
+              bits_eq(a[i].loop_bandwidth, b[i].loop_bandwidth) && a[i].packet_length == b[i].packet_length &&
+              a[i].payload_symbols == b[i].payload_symbols && a[i].payload_bits == b[i].payload_bits &&
+              (a[i].kind != GR4PM_PKT_SYNCWORD || same_tag(a[i].syncword, b[i].syncword))))
+            return false;
+    return true;
+}
+static std::vector<c64> noise(std::mt19937_64& rng, size_t n)
+{
+    std::normal_distribution<float> g(0.f, 1.f);
+    std::vector<c64> x(n);
+    for (auto& v : x) v = { g(rng), g(rng) };
+    return x;
+}
+static void apply(const std::vector<CopySpan>& spans, const c64* in, c64* out)
+{
+    for (const auto& s : spans) std::memcpy(out + s.dst, in + s.src, s.len * sizeof(c64));
+}
+
+// ---------------------------------------------------------------- SyncwordDetectionFilter, call by call
+static void sdf_calls(std::mt19937_64& rng)
+{
+    SdfState h;
+    orc_sdf* ref = orc_sdf_create(h.sps, h.syncword_size, h.header_size);
+    const auto x = noise(rng, 40000);
+    size_t pos = 0;
+    std::vector<gr4pm_header_msg> hdrs;
+    size_t n_ignored = 0;
+    while (pos < x.size()) {
+        const size_t n = std::min<size_t>(x.size() - pos, 1 + rng() % (rng() % 2 ? 3000 : 90)), cap = 1 + rng() % 4000;
+        const int flags = (rng() % 3 == 0) ? static_cast<int>(1 + rng() % 3) : 0;
+        if (rng() % 4 == 0) hdrs.push_back({ rng() % 5 == 0 ? 0u : 1 + rng() % 300, rng() % 4 == 0 ? 1 : 0 });
+        if (rng() % 9 == 0) ++n_ignored;
+        if (!hdrs.empty() && hdrs[0].packet_length == 0 && !hdrs[0].invalid_header) hdrs[0].packet_length = 7; // (the error path is tested below)
+        std::vector<c64> got(cap, c64{ -1, -1 }), want(cap, c64{ -1, -1 });
+        CopySpan runs[2];
+        int n_runs = 0, of = 0, rof = 0;
+        size_t c = 0, hc = 0, ic = 0, rc = 0, rhc = 0, ric = 0;
+        const gr4pm_status st = sdf_process_plan(h, n, cap, flags, hdrs.data(), hdrs.size(), n_ignored, &c, &hc, &ic, &of, runs, &n_runs);
+        for (int r = 0; r < n_runs; ++r) std::memcpy(got.data() + runs[r].dst, x.data() + pos + runs[r].src, runs[r].len * sizeof(c64));
+        std::vector<uint64_t> pl;
+        std::vector<uint8_t> inv;
+        for (auto& m : hdrs) pl.push_back(m.packet_length), inv.push_back(static_cast<uint8_t>(m.invalid_header));
+        const int rst = orc_sdf_process(ref, x.data() + pos, n, want.data(), cap, flags, hdrs.size(), pl.data(), inv.data(), n_ignored,
+                                        &rc, &rhc, &ric, &rof);
+        CHECK(st == rst && c == rc && hc == rhc && ic == ric && of == rof, "sdf call at %zu: status %d/%d consumed %zu/%zu", pos, st, rst, c, rc);
+        CHECK(same_bits(got.data(), want.data(), cap), "sdf call at %zu: items differ", pos);
+        hdrs.erase(hdrs.begin(), hdrs.begin() + static_cast<long>(hc));
+        n_ignored -= ic;
+        pos += c;
+        if (c == 0 && hdrs.empty()) hdrs.push_back({ 1 + rng() % 100, 0 }); // blocked on a header: supply one
+    }
+    // packet_length = 0 is the reference's exception (:143-145)
+    SdfState e;
+    gr4pm_header_msg zero{ 0, 0 };
+    CopySpan runs[2];
+    int n_runs, of;
+    size_t c, hc, ic;
+    sdf_process_plan(e, 10, 10, GR4PM_TAG_SYNCWORD, nullptr, 0, 0, &c, &hc, &ic, &of, runs, &n_runs);
+    CHECK(sdf_process_plan(e, 10, 10, 0, &zero, 1, 0, &c, &hc, &ic, &of, runs, &n_runs) == GR4PM_ERR_INVALID, "packet_length 0 accepted");
+    orc_sdf_destroy(ref);
+}
+
+// ---------------------------------------------------------------- the gate: same decisions as the block run item by item
+static void sdf_gate_vs_block(std::mt19937_64& rng)
+{
+    SdfState g;
+    orc_sdf* ref = orc_sdf_create(g.sps, g.syncword_size, g.header_size);
+    const size_t n = 200000;
+    const uint64_t packet_length = 1 + rng() % 400;
+    std::vector<uint64_t> tag_at;
+    for (uint64_t p = rng() % 2000; p < n; p += 1 + rng() % 9000) tag_at.push_back(p);
+    // reference: the stream chunk by chunk (chunks cut at the tags), every accepted syncword answered at once
+    std::vector<uint8_t> want(tag_at.size(), 0);
+    const auto x = noise(rng, n);
+    std::vector<c64> out(n);
+    size_t pos = 0, ti = 0, pending = 0;
+    while (pos < n) {
+        while (ti < tag_at.size() && tag_at[ti] < pos) ++ti;
+        const bool head = ti < tag_at.size() && tag_at[ti] == pos;
+        const size_t nxt = head ? ti + 1 : ti;
+        const size_t end = nxt < tag_at.size() ? static_cast<size_t>(tag_at[nxt]) : n;
+        size_t c = 0, hc = 0, ic = 0;
+        int of = 0;
+        const uint64_t pl[1] = { packet_length };
+        const uint8_t inv[1] = { 0 };
+        orc_sdf_process(ref, x.data() + pos, end - pos, out.data(), n, head ? GR4PM_TAG_SYNCWORD : 0, pending, pl, inv, 0, &c, &hc, &ic, &of);
+        if (of & GR4PM_TAG_SYNCWORD) {
+            want[ti] = 1;
+            ++pending;
+        }
+        pending -= hc;
+        if (c == 0 && !of) break; // (cannot happen: every packet has its header)
+        pos += c;
+        if (head && c > 0) ++ti;
+    }
+    // gate: the same tags in a few calls
+    std::vector<uint8_t> got(tag_at.size(), 7);
+    size_t done = 0;
+    while (done < tag_at.size()) {
+        const size_t k = std::min<size_t>(tag_at.size() - done, 1 + rng() % 12);
+        std::vector<gr4pm_header_msg> msgs(k, gr4pm_header_msg{ packet_length, 0 });
+        size_t used = 0;
+        CHECK(sdf_gate(g, tag_at.data() + done, k, msgs.data(), k, 1, got.data() + done, &used) == GR4PM_OK, "gate failed: %s", gr4pm::g_error);
+        done += k;
+    }
+    CHECK(got == want, "gate decisions differ from the block's (%zu tags)", tag_at.size());
+    orc_sdf_destroy(ref);
+}
+
+// ---------------------------------------------------------------- SymbolFilter: replay -> run table -> symbols
+static void symbol_filter(std::mt19937_64& rng)
+{
+    const size_t sps = 1 + rng() % 5, arms = 1 + rng() % 33, n_taps = arms * (1 + rng() % 12) - (rng() % arms), delay = rng() % 60;
+    std::vector<float> taps(std::max<size_t>(n_taps, 1));
+    std::normal_distribution<float> g(0.f, 1.f);
+    for (auto& t : taps) t = g(rng);
+    SymfHostState h;
+    h.sps = sps, h.num_arms = arms, h.delay = delay;
+    h.reset_clock_phase = (sps - (delay % sps)) % sps; // symbol_filter.hpp:106-107
+    orc_symf* ref = orc_symf_create(sps, taps.data(), taps.size(), arms, delay);
+    const size_t arm_size = (taps.size() + arms - 1) / arms;
+    const size_t n = 30000;
+    const auto x = noise(rng, n);
+    std::vector<gr4pm_tag> tags;
+    for (uint64_t p = rng() % 500; p < n; p += 1 + rng() % 1500) {
+        gr4pm_tag t{};
+        t.index = p;
+        t.amplitude = 0.5f + static_cast<float>(rng() % 1000) / 500.f;
+        t.phase = g(rng);
+        t.freq = 0.01 * g(rng);
+        t.time_est = static_cast<float>(static_cast<int>(rng() % 1001) - 500) / 1000.f;
+        t.flags = (rng() % 7 == 0) ? GR4PM_TAG_OTHER : GR4PM_TAG_SYNCWORD;
+        tags.push_back(t);
+    }
+    size_t pos = 0;
+    while (pos < n) {
+        const size_t m = std::min<size_t>(n - pos, 1 + rng() % 6000), cap = 1 + rng() % (m / sps + 8);
+        std::vector<gr4pm_tag> tin, tout(64), rtout(64);
+        for (auto t : tags)
+            if (t.index >= pos && t.index < pos + m) {
+                t.index -= pos;
+                tin.push_back(t);
+            }
+        SymReplay rp;
+        symf_replay(h, m, cap, tin.data(), tin.size(), tout.data(), tout.size(), rp);
+        // what the filter kernels do with the run table (symbol_filter.hpp:208-214: inner_product over the arm, m
+        // ascending, hist[0] newest, then the scale)
+        std::vector<c64> got(cap, c64{ -1, -1 }), want(cap, c64{ -1, -1 });
+        for (const auto& r : rp.runs)
+            for (unsigned k = 0; k < r.count; ++k) {
+                std::complex<float> acc(0.f, 0.f);
+                const long long newest = static_cast<long long>(pos) + r.in0 + static_cast<long long>(k) * static_cast<long long>(sps);
+                for (size_t j = 0; r.arm + arms * j < taps.size() && j < arm_size; ++j) {
+                    const long long i = newest - static_cast<long long>(j);
+                    const std::complex<float> v = i >= 0 ? std::complex<float>(x[static_cast<size_t>(i)].re, x[static_cast<size_t>(i)].im) : std::complex<float>(0.f, 0.f);
+                    acc += taps[r.arm + arms * j] * v;
+                }
+                acc = r.scale * acc;
+                got[r.out0 + k] = { acc.real(), acc.imag() };
+            }
+        size_t rn_tags = 0, rcons = 0;
+        const size_t rprod = orc_symf_process_c64(ref, x.data() + pos, m, want.data(), cap, reinterpret_cast<const orc_tag*>(tin.data()), tin.size(),
+                                                  reinterpret_cast<orc_tag*>(rtout.data()), rtout.size(), &rn_tags, &rcons);
+        CHECK(rp.pos == rcons && rp.produced == rprod && rp.n_pub == rn_tags, "symf call at %zu: consumed %zu/%zu produced %zu/%zu tags %zu/%zu (sps %zu arms %zu taps %zu delay %zu)",
+              pos, rp.pos, rcons, rp.produced, rprod, rp.n_pub, rn_tags, sps, arms, taps.size(), delay);
+        if (getenv("HOSTLOGIC_DEBUG") && !(rp.pos == rcons && rp.produced == rprod)) {
+            fprintf(stderr, "  call: m %zu cap %zu, tags:", m, cap);
+            for (auto& t : tin) fprintf(stderr, " [%llu te %.3f fl %d]", (unsigned long long)t.index, t.time_est, t.flags);
+            fprintf(stderr, "\n");
+        }
+        CHECK(same_bits(got.data(), want.data(), std::min(rp.produced, rprod)), "symf call at %zu: symbols differ (sps %zu arms %zu taps %zu)", pos, sps, arms, taps.size());
+        CHECK(rp.n_pub > tout.size() || same_tags(tout.data(), rtout.data(), std::min(rp.n_pub, rn_tags)), "symf call at %zu: tags differ", pos);
+        if (rcons == 0) break;
+        pos += rcons;
+    }
+    orc_symf_destroy(ref);
+}
+
+// ---------------------------------------------------------------- PayloadMetadataInsert -> SyncwordRemove -> HeaderPayloadSplit
+static void control_blocks(std::mt19937_64& rng)
+{
+    const size_t n = 60000;
+    const auto x = noise(rng, n);
+    std::vector<gr4pm_tag> tags;
+    std::vector<gr4pm_header_msg> msgs;
+    for (uint64_t p = rng() % 300; p < n; p += 150 + rng() % 2500) {
+        gr4pm_tag t{};
+        t.index = p;
+        t.amplitude = 1.f, t.phase = 0.25f, t.flags = GR4PM_TAG_SYNCWORD;
+        tags.push_back(t);
+        msgs.push_back({ 1 + rng() % 200, rng() % 5 == 0 ? 1 : 0 });
+    }
+    PmiState h;
+    h.syncword_bw = 0.02, h.header_bw = 0.01, h.payload_bw = 0.005;
+    orc_pmi* ref = orc_pmi_create(h.syncword_size, h.header_size, h.syncword_bw, h.header_bw, h.payload_bw);
+    std::vector<c64> pm(n, c64{ -1, -1 }), rpm(n, c64{ -1, -1 });
+    std::vector<gr4pm_packet_tag> pt(3 * tags.size() + 8), rpt(3 * tags.size() + 8);
+    PmiReplay rp;
+    const gr4pm_status st = pmi_replay(h, n, n, tags.data(), tags.size(), msgs.data(), msgs.size(), 0, pt.data(), pt.size(), rp);
+    apply(rp.spans, x.data(), pm.data());
+    std::vector<uint64_t> pl;
+    std::vector<uint8_t> inv;
+    for (auto& m : msgs) pl.push_back(m.packet_length), inv.push_back(static_cast<uint8_t>(m.invalid_header));
+    size_t rnt = 0, rc = 0, rprod = 0, rused = 0, rign = 0;
+    const int rst = orc_pmi_process(ref, x.data(), n, rpm.data(), n, reinterpret_cast<const orc_tag*>(tags.data()), tags.size(), pl.data(), inv.data(), msgs.size(),
+                                    reinterpret_cast<orc_ptag*>(rpt.data()), rpt.size(), &rnt, &rc, &rprod, &rused, &rign);
+    CHECK(st == rst && rp.consumed == rc && rp.produced == rprod && rp.headers_used == rused && rp.ignored == rign && rp.n_pub == rnt,
+          "pmi: status %d/%d consumed %zu/%zu produced %zu/%zu headers %zu/%zu ignored %zu/%zu tags %zu/%zu", st, rst, rp.consumed, rc, rp.produced, rprod,
+          rp.headers_used, rused, rp.ignored, rign, rp.n_pub, rnt);
+    CHECK(same_bits(pm.data(), rpm.data(), n), "pmi: items differ");
+    CHECK(same_ptags(pt.data(), reinterpret_cast<const gr4pm_packet_tag*>(rpt.data()), std::min(rp.n_pub, rnt)), "pmi: tags differ");
+    orc_pmi_destroy(ref);
+    // SyncwordRemove over PayloadMetadataInsert's output, in several calls
+    SrState sh;
+    orc_sr* sref = orc_sr_create(sh.syncword_size);
+    const size_t n2 = rp.produced;
+    std::vector<c64> data(n2 + 1, c64{ -1, -1 }), rdata(n2 + 1, c64{ -1, -1 });
+    std::vector<gr4pm_packet_tag> dt(pt.size()), rdt(pt.size());
+    size_t rndt = 0;
+    const size_t rn_data = orc_sr_process(sref, rpm.data(), n2, rdata.data(), reinterpret_cast<const orc_ptag*>(rpt.data()), rnt,
+                                          reinterpret_cast<orc_ptag*>(rdt.data()), rdt.size(), &rndt);
+    size_t pos = 0, opos = 0, ntags = 0;
+    while (pos < n2) {
+        const size_t m = std::min<size_t>(n2 - pos, 1 + rng() % 9000);
+        std::vector<gr4pm_packet_tag> tin, tout(pt.size());
+        for (size_t i = 0; i < rp.n_pub; ++i)
+            if (pt[i].index >= pos && pt[i].index < pos + m) {
+                tin.push_back(pt[i]);
+                tin.back().index -= pos;
+            }
+        SrReplay sr;
+        sr_replay(sh, m, tin.data(), tin.size(), tout.data(), tout.size(), sr);
+        apply(sr.spans, pm.data() + pos, data.data() + opos);
+        for (size_t i = 0; i < sr.n_pub; ++i) {
+            dt[ntags] = tout[i];
+            dt[ntags++].index += opos;
+        }
+        pos += m;
+        opos += sr.produced;
+    }
+    CHECK(opos == rn_data && ntags == rndt, "syncword remove: %zu/%zu items %zu/%zu tags", opos, rn_data, ntags, rndt);
+    CHECK(same_bits(data.data(), rdata.data(), std::min(opos, rn_data)), "syncword remove: items differ");
+    CHECK(same_ptags(dt.data(), rdt.data(), std::min(ntags, rndt)), "syncword remove: tags differ");
+    orc_sr_destroy(sref);
+    // HeaderPayloadSplit<float> over the soft symbols (here: the real parts twice, as the QPSK LLR decoder lays them out:
+    // two floats per symbol, tags at twice the index -- only positions matter to the state machine)
+    std::vector<float> llr(2 * opos);
+    for (size_t i = 0; i < opos; ++i) llr[2 * i] = data[i].re, llr[2 * i + 1] = data[i].im;
+    std::vector<gr4pm_packet_tag> lt(ntags);
+    for (size_t i = 0; i < ntags; ++i) {
+        lt[i] = dt[i];
+        lt[i].index *= 2;
+    }
+    HpsState hh;
+    orc_hps* href = orc_hps_create(hh.header_size);
+    std::vector<float> hd(llr.size() + 1), pd(llr.size() + 1), rhd(llr.size() + 1), rpd(llr.size() + 1);
+    std::vector<gr4pm_packet_tag> ht(ntags + 1), ptg(ntags + 1), rht(ntags + 1), rptg(ntags + 1);
+    size_t rnh = 0, rnp = 0, rnht = 0, rnpt = 0;
+    const int hrst = orc_hps_process(href, llr.data(), llr.size(), rhd.data(), &rnh, rpd.data(), &rnp, reinterpret_cast<const orc_ptag*>(lt.data()), ntags,
+                                     reinterpret_cast<orc_ptag*>(rht.data()), &rnht, reinterpret_cast<orc_ptag*>(rptg.data()), &rnpt, ntags + 1);
+    HpsReplay hr;
+    const gr4pm_status hst = hps_replay(hh, llr.size(), lt.data(), ntags, ht.data(), ptg.data(), ntags + 1, hr);
+    CHECK((hst == GR4PM_OK) == (hrst == 0), "header/payload split: status %d / %d", hst, hrst);
+    if (hst == GR4PM_OK && hrst == 0) {
+        for (const auto& s : hr.header_spans) std::memcpy(hd.data() + s.dst, llr.data() + s.src, s.len * sizeof(float));
+        for (const auto& s : hr.payload_spans) std::memcpy(pd.data() + s.dst, llr.data() + s.src, s.len * sizeof(float));
+        CHECK(hr.n_header == rnh && hr.n_payload == rnp && hr.n_header_tags == rnht && hr.n_payload_tags == rnpt, "header/payload split: counts differ");
+        CHECK(std::memcmp(hd.data(), rhd.data(), std::min(hr.n_header, rnh) * sizeof(float)) == 0 &&
+                  std::memcmp(pd.data(), rpd.data(), std::min(hr.n_payload, rnp) * sizeof(float)) == 0, "header/payload split: items differ");
+        CHECK(same_ptags(ht.data(), rht.data(), std::min(hr.n_header_tags, rnht)) &&
+                  same_ptags(ptg.data(), rptg.data(), std::min(hr.n_payload_tags, rnpt)), "header/payload split: tags differ");
+    }
+    orc_hps_destroy(href);
+}
+
+// ---------------------------------------------------------------- the receivers' slot rings and stage loop, mock stage bodies
+static void slot_pipeline(std::mt19937_64& rng)
+{
+    constexpr int kSlots = 7, kStages = 5, kBatches = 400;
+    using Q = SlotQueue<16>;
+    Q free_slots, q[kStages], done;
+    struct Slot {
+        long value = 0;
+        int trace = 0, failed_at = -1;
+        unsigned char scratch[256];
+    } slots[kSlots];
+    for (int i = 0; i < kSlots; ++i) CHECK(free_slots.push(i), "push");
+    const int throw_stage = static_cast<int>(rng() % kStages), throw_batch = static_cast<int>(rng() % kBatches);
+    std::atomic<int> in_stage[kStages];
+    for (auto& a : in_stage) a = 0;
+    std::vector<std::thread> threads;
+    for (int s = 0; s < kStages; ++s)
+        threads.emplace_back([&, s] {
+            run_stage(
+                q[s], s + 1 < kStages ? &q[s + 1] : &done, /*forward_quit=*/s + 1 < kStages,
+                [&](int i) {
+                    CHECK(in_stage[s].fetch_add(1) == 0, "two batches inside stage %d", s); // one at a time, in order
+                    Slot& sl = slots[i];
+                    if (sl.failed_at < 0) {
+                        if (s == throw_stage && sl.value / 1000 == throw_batch) {
+                            in_stage[s].fetch_sub(1);
+                            throw std::runtime_error("mock stage failure");
+                        }
+                        CHECK(sl.trace == s, "slot %d reached stage %d after %d stages", i, s, sl.trace);
+                        sl.trace = s + 1;
+                        sl.value += s + 1;
+                        std::memset(sl.scratch, s, sizeof(sl.scratch)); // (a second owner of the slot would race here)
+                    }
+                    if ((sl.value & 15) == 0) std::this_thread::sleep_for(std::chrono::microseconds(20));
+                    in_stage[s].fetch_sub(1);
+                },
+                [&](int i) { slots[i].failed_at = s; });
+        });
+    int submitted = 0, collected = 0, failures = 0;
+    long expect_next = 0;
+    while (collected < kBatches) {
+        while (submitted < kBatches && submitted - collected < kSlots - 1) {
+            const int i = free_slots.pop();
+            slots[i] = Slot{};
+            slots[i].value = 1000L * submitted;
+            ++submitted;
+            CHECK(q[0].push(i), "ring full with %d in flight", submitted - collected);
+        }
+        const int i = done.pop();
+        const Slot& sl = slots[i];
+        CHECK(sl.value / 1000 == expect_next, "batches out of order: %ld, expected %ld", sl.value / 1000, expect_next);
+        if (sl.failed_at >= 0) {
+            ++failures;
+            CHECK(sl.failed_at == throw_stage && sl.value / 1000 == throw_batch, "wrong batch failed");
+        } else {
+            CHECK(sl.trace == kStages && sl.value % 1000 == 15, "batch %ld incomplete: %d stages", sl.value / 1000, sl.trace);
+        }
+        ++expect_next;
+        ++collected;
+        CHECK(free_slots.push(i), "push");
+    }
+    CHECK(failures == 1, "%d failed batches (one injected)", failures);
+    q[0].stop();
+    for (auto& t : threads) t.join();
+    CHECK(done.size() == 0 && free_slots.size() == kSlots, "slots lost");
+    // a full ring refuses, it does not overwrite
+    SlotQueue<4> small;
+    for (int i = 0; i < 4; ++i) CHECK(small.push(i), "push");
+    CHECK(!small.push(99) && small.pop() == 0, "a full ring must refuse");
+}
+
+int main(int argc, char** argv)
+{
+    const int cases = argc > 1 ? atoi(argv[1]) : 20;
+    const unsigned long long seed = argc > 2 ? strtoull(argv[2], nullptr, 10) : 4;
+    std::mt19937_64 rng(seed);
+    for (int c = 0; c < cases; ++c) {
+        sdf_calls(rng);
+        sdf_gate_vs_block(rng);
+        symbol_filter(rng);
+        control_blocks(rng);
+    }
+    for (int c = 0; c < std::max(2, cases / 5); ++c) slot_pipeline(rng);
+    printf("hostlogic_san: %d cases, seed %llu: %d failures\n", cases, seed, g_failures);
+    return g_failures ? 1 : 0;
+}

@@ -2626,3 +2626,40 @@ def test_receivers_survive_allocation_failures(pkg, mode):
     assert struck >= 24, struck  # most injected failures hit an allocation that matters and were reported
     errors, again = life(None)
     assert not errors and key(again) == key(want)
+
+
+@pytest.mark.gpu
+def test_symbol_filter_output_span_runs_out(pkg):
+    """symbol_filter.hpp:208: the loop stops as soon as the output span is full.  Found by the CPU sanitizer /
+    differential build (tests/hostlogic): when the outputs of a call fitted the span EXACTLY the replay went on to
+    consume the items behind the last output, and with a full span it still handled the tag of the next chunk (whose
+    special cases :160-195 consume an item).  Symbols, re-timed tags and `consumed` against the oracle for every
+    capacity around the exact fit, with a tag right behind the last output's item."""
+    rrc, pfb = _receiver_pfb()
+    rng = np.random.default_rng(77)
+    n = 2003
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    for tag_at, te in [(None, 0.0), (1999, -0.3), (2000, 0.2), (2001, -0.4), (1997, 0.45)]:
+        tags = np.zeros(0 if tag_at is None else 2, dtype=pkg.TAG_DTYPE)
+        if tag_at is not None:
+            tags["index"] = [500, tag_at]
+            tags["amplitude"] = [1.5, 0.7]
+            tags["time_est"] = [0.2, te]
+            tags["flags"] = pkg.TAG_SYNCWORD
+        otags = tags.astype(orc.TAG_DTYPE)
+        full = orc.symbol_filter(x, pfb, 32, 4, 44, tags=otags)[0].size
+        for cap in (full - 2, full - 1, full, full + 1):
+            want, want_tags, want_cons = orc.symbol_filter(x, pfb, 32, 4, 44, tags=otags, out_cap=cap)
+            f = pkg.SymbolFilter(pfb, 32, 4, 44)
+            y, t, cons = f.process_bulk(dev(x), tags, out_cap=cap)
+            assert cons == want_cons and y.numel() == want.size, (tag_at, cap, cons, want_cons)
+            assert np.array_equal(bits(host(y)), bits(want))
+            assert np.array_equal(t["index"], want_tags["index"])
+            # the rest of the stream in a second call ends where one unlimited call ends
+            if cons < n:
+                rest = tags[tags["index"] >= cons].copy()
+                rest["index"] -= cons
+                y2, _, c2 = f.process_bulk(dev(x[cons:]), rest)
+                whole = orc.symbol_filter(x, pfb, 32, 4, 44, tags=otags)[0]
+                assert c2 == n - cons
+                assert np.array_equal(bits(np.concatenate([host(y), host(y2)])), bits(whole))
