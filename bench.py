@@ -755,7 +755,53 @@ def per_bins_roofline(pkg, rrc, bpsk, x, n_items, stream, reps=5):
     return out
 
 
-def channels64_leg(pkg, dist, device, rank, world, rrc, steps, warmup, repeats, channels=64, n_items=1 << 22):
+def config2_latency(pkg, xs, channels, n_pkt, sizes=(1 << 12, 1 << 13, 1 << 14, 1 << 16, 1 << 18, 1 << 20, 1 << 22), rate_sps=3.2e6):
+    """the real-time operating point of configs[2] (64 channels of 3.2 Msps each, README.md:46-49): for batches of b
+    samples per channel -- one arrives every b / 3.2e6 s -- the submit -> collect latency of ONE batch with nothing else
+    in flight (median of 9), and the sustained rate with four batches in flight; `sustains` = the receiver keeps up with
+    64 x 3.2 Msps at that batch size (rate above 204.8 Msps and latency below the batch period)."""
+    rows = {}
+    for b in sizes:
+        x = xs[:, :b]
+        multi = pkg.NativeMultiChannelReceiver(channels, SPS, BINS, 9.5, "QPSK", max_items=b, tags_cap=max(64, 2 * n_pkt + 64),
+                                               workers=12, output_ring=True)
+        multi.set_input_in_place(True)
+        for _ in range(3):
+            multi.submit(x, 1500)
+            multi.collect()
+        lat = []
+        for _ in range(9):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            multi.submit(x, 1500)
+            multi.collect()
+            lat.append(time.perf_counter() - t0)
+        steps = max(8, min(200, (1 << 24) // b))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        consumed = 0
+        for _ in range(steps):
+            if multi.in_flight() == 4:
+                consumed += sum(r["consumed"] for r in multi.collect())
+            multi.announce(x)
+            multi.submit(x, 1500)
+        while multi.in_flight():
+            consumed += sum(r["consumed"] for r in multi.collect())
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        period = b / rate_sps
+        lat_ms = sorted(lat)[len(lat) // 2] * 1e3
+        rows[str(b)] = {"batch_period_ms": round(period * 1e3, 3), "latency_ms": round(lat_ms, 3),
+                        "latency_min_ms": round(min(lat) * 1e3, 3), "msps": round(consumed / dt / 1e6, 1),
+                        "ms_per_batch_pipelined": round(dt / steps * 1e3, 3),
+                        "sustains": bool(consumed / dt > channels * rate_sps and lat_ms < period * 1e3)}
+        del multi
+    ok = [int(k) for k, v in rows.items() if v["sustains"]]
+    return {"channel_rate_sps": rate_sps, "channels": channels, "batches": rows,
+            "smallest_batch_that_sustains_realtime": min(ok) if ok else None}
+
+
+def channels64_leg(pkg, dist, device, rank, world, rrc, steps, warmup, repeats, channels=64, n_items=1 << 22, latency_block=True):
     """BASELINE configs[2] (N = 1) / configs[3] (N > 1: 64 channels per GPU, 64 N in all): rank 0 fills a host
     sample ring [N, 64, 2^22] and scatters one [64, 2^22] slab per rank (the job's backend: RCCL on the GPUs); every
     rank then runs its 64 channels through gr4pm_multichannel_receiver (one batched detector + every channel's own
@@ -819,11 +865,15 @@ def channels64_leg(pkg, dist, device, rank, world, rrc, steps, warmup, repeats, 
         times.append(dt)
     med = sorted(range(len(rates)), key=lambda i: rates[i])[len(rates) // 2]
     del multi
+    latency = None
+    if dist is None and latency_block:
+        latency = config2_latency(pkg, xs, channels, n_pkt)
     return {"workload": f"{channels} channels per GPU x {n_items} samples per batch, {channels * world} channels in all, "
                         "full RX front end per channel (gr4pm_multichannel_receiver), per-channel CFO sweep",
             "value": round(rates[med], 2), "unit": "Msamples/s", "steps": steps, "warmup": warmup,
             "ms_per_step": round(times[med] / steps * 1e3, 4), "repeats": len(rates),
-            "value_min": round(min(rates), 2), "value_max": round(max(rates), 2), "input": input_mode}
+            "value_min": round(min(rates), 2), "value_max": round(max(rates), 2), "input": input_mode,
+            **({"latency": latency} if latency else {})}
 
 
 def main():
