@@ -1089,6 +1089,142 @@ __global__ __launch_bounds__(kFastThreads, 8) void k_symbol_filter_fast(const cf
     }
 }
 
+// Long arms (BASELINE configs[4]: 32 arms x 1025 taps, 4 samples per symbol), plain SymbolFilter on complex items: the
+// generic kernel above reads one 8-byte item and one tap from LDS per multiply-add (12 bytes per tap and symbol: 15 Gsps
+// in, bound by the LDS pipe).  Here, as in k_symbol_filter_fast: a lane computes TWO neighbouring symbols, one
+// ds_read_b128 delivers the two tile entries the pair needs at one tap position of one phase (4 bytes per tap and
+// symbol), the arm's taps are uniform and stream through SGPRs (scalar loads, eight a time, the next eight requested
+// before the current ones are used), and the multiply-adds are v_pk_mul_f32 / v_pk_add_f32 with the tap broadcast from
+// an SGPR pair -- every product and every sum rounded once, tap index ascending (symbol_filter.hpp:208-214): bit-exact.
+// Tap m of symbol s sits on tile item 4 s + j, j = arm_size - 1 - m: phase j % 4, entry s + j / 4 of the phase row.
+// The arm starts with (arm_size - 1) % 4 + 1 "head" taps on the top tap position, then whole tap positions of four.
+__global__ __launch_bounds__(kFastThreads, 8) void k_symbol_filter_long(const cf* __restrict__ in, const cf* __restrict__ carry,
+                                                                      unsigned cap, const float* __restrict__ taps,
+                                                                      unsigned arm_size, unsigned pitch,
+                                                                      const SymWg* __restrict__ plan, cf* __restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_long_raw[];
+    cf* tile = reinterpret_cast<cf*>(s_long_raw);
+    const SymWg p = plan[blockIdx.x];
+    const unsigned span = (p.count - 1) * kFastSps + arm_size;
+    for (unsigned i = threadIdx.x; i < span; i += kFastThreads)
+        tile[(i % kFastSps) * pitch + i / kFastSps] = item_at(in, carry, cap, p.lo_item + i);
+    __syncthreads();
+    const unsigned l = threadIdx.x;
+    if (2 * l >= p.count) return;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const float* __restrict__ tp = taps + static_cast<size_t>(p.arm) * arm_size; // uniform: scalar loads
+    f2 accA = { 0.f, 0.f }, accB = { 0.f, 0.f };
+    const unsigned J = arm_size - 1, q_top = J / kFastSps, r = J % kFastSps;
+    // head taps m = 0 .. r: phases r .. 0 of tap position q_top
+    for (unsigned m = 0; m <= r; ++m) {
+        const unsigned ph = r - m;
+        const cf a = tile[ph * pitch + 2 * l + q_top], b = tile[ph * pitch + 2 * l + 1 + q_top];
+        const float t = tp[m];
+        accA = f2{ accA.x + t * a.x, accA.y + t * a.y };
+        accB = f2{ accB.x + t * b.x, accB.y + t * b.y };
+    }
+    // a3 .. a0 / b3 .. b0: the entries of phases 3 .. 0 for symbol A / B at one tap position; t01, t23: its four taps
+    auto mac4 = [&](f2 a3, f2 b3, f2 a2, f2 b2, f2 a1, f2 b1, f2 a0, f2 b0, f2 t01, f2 t23) {
+        f2 pa, pb;
+        asm("v_pk_mul_f32 %2, %4, %12 op_sel_hi:[1,0]\n\t"
+            "v_pk_mul_f32 %3, %5, %12 op_sel_hi:[1,0]\n\t"
+            "v_pk_add_f32 %0, %0, %2\n\t"
+            "v_pk_add_f32 %1, %1, %3\n\t"
+            "v_pk_mul_f32 %2, %6, %12 op_sel:[0,1]\n\t"
+            "v_pk_mul_f32 %3, %7, %12 op_sel:[0,1]\n\t"
+            "v_pk_add_f32 %0, %0, %2\n\t"
+            "v_pk_add_f32 %1, %1, %3\n\t"
+            "v_pk_mul_f32 %2, %8, %13 op_sel_hi:[1,0]\n\t"
+            "v_pk_mul_f32 %3, %9, %13 op_sel_hi:[1,0]\n\t"
+            "v_pk_add_f32 %0, %0, %2\n\t"
+            "v_pk_add_f32 %1, %1, %3\n\t"
+            "v_pk_mul_f32 %2, %10, %13 op_sel:[0,1]\n\t"
+            "v_pk_mul_f32 %3, %11, %13 op_sel:[0,1]\n\t"
+            "v_pk_add_f32 %0, %0, %2\n\t"
+            "v_pk_add_f32 %1, %1, %3"
+            : "+v"(accA), "+v"(accB), "=&v"(pa), "=&v"(pb)
+            : "v"(a3), "v"(b3), "v"(a2), "v"(b2), "v"(a1), "v"(b1), "v"(a0), "v"(b0), "s"(t01), "s"(t23));
+    };
+    auto lo2 = [](const float4& v) { return f2{ v.x, v.y }; };
+    auto hi2 = [](const float4& v) { return f2{ v.z, v.w }; };
+    // pair(ph, k) = tile entries (ph, 2l + 2k) and (ph, 2l + 2k + 1): symbol A uses entry 2l + q at tap position q,
+    // symbol B entry 2l + 1 + q, so q = 2k takes (pair k .lo, pair k .hi) and q = 2k + 1 takes (pair k .hi, pair k+1 .lo)
+    const float4* rows = reinterpret_cast<const float4*>(tile) + l;
+    const unsigned row4 = pitch / 2; // float4 per phase row
+    auto load_pair = [&](float4(&v)[kFastSps], unsigned k) {
+#pragma unroll
+        for (unsigned ph = 0; ph < kFastSps; ++ph) v[ph] = rows[ph * row4 + k];
+    };
+    auto even = [&](const float4(&P)[kFastSps], const float* t) { // q = 2k
+        mac4(lo2(P[3]), hi2(P[3]), lo2(P[2]), hi2(P[2]), lo2(P[1]), hi2(P[1]), lo2(P[0]), hi2(P[0]), f2{ t[0], t[1] }, f2{ t[2], t[3] });
+    };
+    auto odd = [&](const float4(&P)[kFastSps], const float4(&Pn)[kFastSps], const float* t) { // q = 2k + 1, Pn = pair k + 1
+        mac4(hi2(P[3]), lo2(Pn[3]), hi2(P[2]), lo2(Pn[2]), hi2(P[1]), lo2(Pn[1]), hi2(P[0]), lo2(Pn[0]), f2{ t[0], t[1] }, f2{ t[2], t[3] });
+    };
+    if (q_top > 0) {
+        // eight taps with ONE scalar load (s_load_dwordx8; the address only needs dword alignment)
+        typedef float f8 __attribute__((ext_vector_type(8), aligned(4)));
+        unsigned m = r + 1;     // next tap
+        unsigned Q = q_top - 1; // next tap position
+        float4 P0[kFastSps], P1[kFastSps];
+        unsigned k = Q / 2;
+        load_pair(P0, k);
+        if (Q & 1u) {
+            load_pair(P1, k + 1);
+            float t[4] = { tp[m], tp[m + 1], tp[m + 2], tp[m + 3] };
+            odd(P0, P1, t);
+            m += 4;
+        }
+        {
+            float t[4] = { tp[m], tp[m + 1], tp[m + 2], tp[m + 3] };
+            even(P0, t);
+            m += 4;
+        }
+        // From here on two tap positions (eight taps) per pass, two passes per iteration with the pair registers P0 / P1
+        // taking turns (no moves).  The pair of the NEXT pass is requested between the two halves of a pass -- its
+        // registers are free once odd() has used their .lo halves -- so sixteen packed instructions cover the LDS
+        // latency; the sixteen taps of the next iteration are requested before this iteration's are used.
+        if (k > 0) load_pair(P1, k - 1);
+        f8 ta = *reinterpret_cast<const f8*>(tp + m), tb = *reinterpret_cast<const f8*>(tp + min(m + 8, arm_size - 8));
+        while (k >= 2) {
+            const f8 ua = ta, ub = tb;
+            m += 16;
+            // (clamped: the last iterations request taps they do not use instead of branching)
+            ta = *reinterpret_cast<const f8*>(tp + min(m, arm_size - 8));
+            tb = *reinterpret_cast<const f8*>(tp + min(m + 8, arm_size - 8));
+            {
+                const float t[8] = { ua[0], ua[1], ua[2], ua[3], ua[4], ua[5], ua[6], ua[7] };
+                odd(P1, P0, t); // pass a: pair k - 1, tap positions 2k - 1 and 2k - 2
+                load_pair(P0, k - 2);
+                asm volatile("" ::: "memory"); // the request stays here, in front of the sixteen instructions that hide it
+                even(P1, t + 4);
+            }
+            {
+                const float t[8] = { ub[0], ub[1], ub[2], ub[3], ub[4], ub[5], ub[6], ub[7] };
+                odd(P0, P1, t); // pass b: pair k - 2
+                if (k >= 3) load_pair(P1, k - 3);
+                asm volatile("" ::: "memory");
+                even(P0, t + 4);
+            }
+            k -= 2;
+        }
+        if (k == 1) {
+            const float t[8] = { ta[0], ta[1], ta[2], ta[3], ta[4], ta[5], ta[6], ta[7] };
+            odd(P1, P0, t);
+            even(P1, t + 4);
+        }
+    }
+    out[p.o0 + 2 * l] = scale_item(p.scale, cf{ accA.x, accA.y });
+    if (2 * l + 1 < p.count) out[p.o0 + 2 * l + 1] = scale_item(p.scale, cf{ accB.x, accB.y });
+}
+// which (fused, item type, sps, arm size) combinations run it
+static bool symf_long(bool fused, bool cf_items, size_t sps, size_t arm_size)
+{
+    static const bool off = getenv("GR4PM_SYMF_GENERIC") != nullptr;
+    return !fused && cf_items && sps == kFastSps && arm_size >= 64 && !off;
+}
+
 // GR4PM_TIMING_SKIP=symf_fake / costas_fake: timing experiments only.  Stand-ins with the memory traffic (symbol
 // filter) or the life time (Costas) of the kernel they replace and at most 32 VGPRs, no LDS: what would the chain
 // gain if the real kernel fitted beside two 240-VGPR correlator waves of every SIMD?
@@ -1119,9 +1255,9 @@ static bool symf_fast(bool fused, size_t sps, size_t arm_size)
     static const bool off = getenv("GR4PM_SYMF_GENERIC") != nullptr; // A/B switch: the generic kernel for every design
     return fused && sps == kFastSps && arm_size == kFastArm && !off;
 }
-static unsigned symf_per_wg(bool fused, size_t sps, size_t arm_size)
+static unsigned symf_per_wg(bool fused, size_t sps, size_t arm_size, bool cf_items = true)
 {
-    return symf_fast(fused, sps, arm_size) ? kFastSym : kSymPerWg;
+    return (symf_fast(fused, sps, arm_size) || symf_long(fused, cf_items, sps, arm_size)) ? kFastSym : kSymPerWg;
 }
 
 template <typename T, bool CFC>
@@ -1132,7 +1268,20 @@ static void launch_symbol_filter(hipStream_t s, unsigned n_wg, size_t smem, unsi
 {
     const dim3 grid(n_wg), block(kSymPerWg);
     hipLaunchKernelGGL(k_symf_wg_plan, dim3((n_wg + 255) / 256), dim3(256), 0, s, runs, n_runs, n_wg, sps, arm_size,
-                       cfc, plan, chans, symf_per_wg(CFC, sps, arm_size));
+                       cfc, plan, chans, symf_per_wg(CFC, sps, arm_size, std::is_same<T, cf>::value));
+    if constexpr (!CFC && std::is_same<T, cf>::value) {
+        if (symf_long(false, true, sps, arm_size)) {
+            // entries per phase row: the last symbol's entry at the top tap position, + 1 for symbol B; even
+            const unsigned pitch = ((kFastSym + (arm_size - 1) / kFastSps + 2) + 1u) & ~1u;
+            const size_t lds = static_cast<size_t>(kFastSps) * pitch * sizeof(cf);
+            if (lds > 48 * 1024)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_symbol_filter_long),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+            hipLaunchKernelGGL(k_symbol_filter_long, grid, dim3(kFastThreads), lds, s, in, carry, cap, taps, arm_size, pitch,
+                               plan, out);
+            return;
+        }
+    }
     if constexpr (CFC) {
         if (symf_fast(true, sps, arm_size)) {
             if (timing_skip("symf_fake"))
@@ -2408,7 +2557,7 @@ static gr4pm_status symbol_filter_impl(gr4pm_symbol_filter* h, const void* in, s
     hipStream_t s = h->stream;
     if (!runs.empty()) {
         unsigned n_wg = 0;
-        const unsigned per_wg = symf_per_wg(fuse != nullptr, sps, h->arm_size);
+        const unsigned per_wg = symf_per_wg(fuse != nullptr, sps, h->arm_size, h->item_kind == 0);
         for (auto& r : runs) { // workgroups never straddle runs
             r.wg0 = n_wg;
             r.chan = 0;
