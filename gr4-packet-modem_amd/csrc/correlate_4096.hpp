@@ -62,10 +62,11 @@ template <int VAR>
 __global__ __launch_bounds__(kT4k) void k_correlate_4096(const cf* __restrict__ in, size_t in_stride, uint32_t n_blocks,
                                                          uint32_t stride_s, int n_bins, const cf* __restrict__ tmpl,
                                                          const cf* __restrict__ tw1, const cf* __restrict__ tw2g,
-                                                         float* __restrict__ zpow, size_t z_stride)
+                                                         float* __restrict__ zpow, size_t z_stride, uint32_t noise_rel)
 {
     __shared__ cf lds[(VAR & 4) ? 2 * kX4kItems : kX4kItems];
     __shared__ cf tw2[256];
+    __shared__ float noise_part[kT4k / 64];
     cf* ldsB = lds + ((VAR & 4) ? kX4kItems : 0);
     const int t = threadIdx.x;
     tw2[t] = tw2g[t];
@@ -85,6 +86,25 @@ __global__ __launch_bounds__(kT4k) void k_correlate_4096(const cf* __restrict__ 
     cf X[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) X[j] = r[j];
+    if (noise_rel) {
+        // hpp:257-265: the block's noise power is the energy of the spectrum's middle half, bins N/4 .. 3N/4 - 1 =
+        // registers 4 .. 11 of every thread.  One float per block behind the channel's powers, unnormalised, as
+        // k_correlate_w64 leaves it: k_tags reads it for the few blocks that hold a detection (k_tags_generic
+        // transformed every such block again, with all its bins: 1.9 of 8.3 ms per 2^28 samples at nine bins).
+        float e = 0.0f;
+#pragma unroll
+        for (int j = 4; j < 12; ++j) e = fmaf(X[j].y, X[j].y, fmaf(X[j].x, X[j].x, e));
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) e += __shfl_xor(e, d);
+        if ((t & 63) == 0) noise_part[t >> 6] = e;
+        __syncthreads();
+        if (t == 0) {
+            float sum = 0.0f;
+#pragma unroll
+            for (int w = 0; w < kT4k / 64; ++w) sum += noise_part[w];
+            zpow[static_cast<size_t>(blockIdx.y) * z_stride + noise_rel + 1 + b] = sum;
+        }
+    }
     float zmax[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) zmax[j] = -1.0f; // hpp:303

@@ -1186,7 +1186,8 @@ __global__ __launch_bounds__(64) void k_tags(const cf* __restrict__ in, size_t i
                                              const float* __restrict__ zcur, size_t z_stride,
                                              ChanState* __restrict__ st,
                                              const unsigned long long* __restrict__ det, uint32_t det_cap,
-                                             RawTag* __restrict__ rec, uint32_t rec_cap, uint32_t noise_rel)
+                                             RawTag* __restrict__ rec, uint32_t rec_cap, uint32_t noise_rel,
+                                             uint32_t fft_n)
 {
 #ifndef GR4PM_NO_SETPRIO
     __builtin_amdgcn_s_setprio(3); // latency-bound, few waves: win the issue arbitration against throughput kernels
@@ -1232,7 +1233,8 @@ __global__ __launch_bounds__(64) void k_tags(const cf* __restrict__ in, size_t i
         const long long b = static_cast<long long>(blk) - static_cast<long long>(E0 / stride_s);
         noise = zcur[static_cast<size_t>(ch) * z_stride + noise_rel + 1 + b];
     }
-    noise /= static_cast<float>(kFftN / 2) * static_cast<float>(kFftN);
+    // (fft_n: 2048, or 4096 behind k_correlate_4096, which leaves the block energies the same way; FFT_NOISE is 2048 only)
+    noise /= static_cast<float>(fft_n / 2) * static_cast<float>(fft_n);
 
     // The correlation at the ONE lag of the detection, for every bin, straight from its definition instead of
     // n_bins more transforms: the value the reference reads at z_idx = (N - lag) mod N of FFT(X .* conj(FFT(s_b)))
@@ -1284,7 +1286,7 @@ __global__ __launch_bounds__(64) void k_tags(const cf* __restrict__ in, size_t i
 #pragma unroll
         for (int b = 0; b < kBinGroup; ++b)
             if (lane == 0 && bin0 + b < n_bins)
-                zbin[bin0 + b] = mk(static_cast<float>(ax[b] * kFftN), static_cast<float>(ay[b] * kFftN));
+                zbin[bin0 + b] = mk(static_cast<float>(ax[b] * fft_n), static_cast<float>(ay[b] * fft_n));
     }
     wave_lds_sync();
     if (lane == 0) {
@@ -1741,7 +1743,7 @@ gr4pm_status launch_correlate(gr4pm_syncword_detection* h, hipStream_t stream, c
 #define GR4PM_C4096(V)                                                                                                   \
     hipLaunchKernelGGL(k_correlate_4096<V>, dim3(n_blocks, static_cast<unsigned>(h->n_channels)), dim3(kT4k), 0, stream,  \
                        reinterpret_cast<const cf*>(in), in_stride, n_blocks, static_cast<uint32_t>(h->S), h->n_bins,      \
-                       h->g_tmpl.p, h->tw4k.p, h->tw4k.p + 16 * 256, zout, h->z_stride)
+                       h->g_tmpl.p, h->tw4k.p, h->tw4k.p + 16 * 256, zout, h->z_stride, h->noise_off - h->zc)
         switch (h->c4096_variant) { // GR4PM_C4096_VARIANT (bit-identical forms, correlate_4096.hpp)
         case 0: GR4PM_C4096(0); break;
         case 1: GR4PM_C4096(1); break;
@@ -2342,7 +2344,17 @@ try {
                            h->visit_cap, h->det.p, h->det_cap);
     }
     // tags leaving in this call
-    if (h->generic) {
+    if (h->generic && h->fft_size == static_cast<size_t>(kN4k) && !h->force_radix2 && h->hist <= h->S) {
+        // k_correlate_4096 has left every block's noise power behind the powers: the tags come from k_tags<false>
+        // (correlation at the detection's lag from its definition), as behind k_correlate_w64
+        hipLaunchKernelGGL(k_tags<false>, dim3(std::min<uint32_t>(h->det_cap, 4096u), nch), dim3(64), 0, s,
+                           reinterpret_cast<const cf*>(in), in_stride, carry, static_cast<size_t>(h->xc), h->xc,
+                           static_cast<unsigned long long>(E0), static_cast<unsigned long long>(E1),
+                           static_cast<uint32_t>(h->hist), static_cast<uint32_t>(h->S), h->n_bins, h->tmpl.p, h->tw.p, h->tw.p,
+                           h->tw.p, h->tw.p, h->td.p, static_cast<uint32_t>(h->L), zcur + h->zc, h->z_stride, h->st.p,
+                           h->det.p, h->det_cap, h->rec_host.p, h->rec_cap, h->noise_off - h->zc,
+                           static_cast<uint32_t>(kN4k));
+    } else if (h->generic) {
         const uint32_t N = static_cast<uint32_t>(h->fft_size);
         hipLaunchKernelGGL(k_tags_generic, dim3(std::min<uint32_t>(h->det_cap, 1024u), nch), dim3(256),
                            2 * N * sizeof(cf), s,
@@ -2360,7 +2372,7 @@ try {
                                h->tw.p + kTw1aItems, h->tw.p + kTw1aItems + kTw1bItems,
                                h->tw.p + kTw1aItems + kTw1bItems + kTwAItems, h->td.p, static_cast<uint32_t>(h->L),
                                zcur + h->zc, h->z_stride, h->st.p, h->det.p, h->det_cap, h->rec_host.p, h->rec_cap,
-                               h->noise_off - h->zc);
+                               h->noise_off - h->zc, static_cast<uint32_t>(kFftN));
         };
         // k_correlate_w64 leaves every block's noise power behind the powers; the round-1 correlators do not.  Only ONE
         // block of the call before is carried (k_update_zcarry): enough while a detection that leaves in this call
