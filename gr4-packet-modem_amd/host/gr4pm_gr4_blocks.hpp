@@ -48,6 +48,21 @@
 
 #include "gr4pm_hip.h"
 
+// Trace prints on entry and exit of every processBulk(), like the reference's blocks (README.md:144-150,
+// e.g. syncword_detection.hpp:207-212,351-353): compiled in with -DTRACE (cmake -D CMAKE_CXX_FLAGS=-DTRACE ..), same
+// wording ("<name>::processBulk(inSpan.size() = .., outSpan.size = ..)", "<name> consumed = .., published = ..").
+#ifdef TRACE
+#define GR4PM_TRACE_ENTRY(in_size, out_size)                                                                       \
+    std::fprintf(stderr, "%s::processBulk(inSpan.size() = %zu, outSpan.size = %zu)\n", std::string(this->name).c_str(), \
+                 static_cast<size_t>(in_size), static_cast<size_t>(out_size))
+#define GR4PM_TRACE_EXIT(consumed, published)                                                                      \
+    std::fprintf(stderr, "%s consumed = %zu, published = %zu\n", std::string(this->name).c_str(),                  \
+                 static_cast<size_t>(consumed), static_cast<size_t>(published))
+#else
+#define GR4PM_TRACE_ENTRY(in_size, out_size) ((void)0)
+#define GR4PM_TRACE_EXIT(consumed, published) ((void)0)
+#endif
+
 namespace gr::packet_modem::hip {
 
 namespace detail {
@@ -366,6 +381,7 @@ public:
 
     gr::work::Status processBulk(const gr::ConsumableSpan auto& inSpan, gr::PublishableSpan auto& outSpan)
     {
+        GR4PM_TRACE_ENTRY(inSpan.size(), outSpan.size());
         if (inSpan.size() < fft_size) { // :215-227
             if (!inSpan.consume(0)) throw gr::exception("consume failed");
             outSpan.publish(0);
@@ -385,6 +401,7 @@ public:
             out.publishTag(detail::to_map(_tags[i]), static_cast<ssize_t>(_tags[i].index)); // :321-324
         if (!inSpan.consume(n_done)) throw gr::exception("consume failed"); // :346-348
         outSpan.publish(n_done);
+        GR4PM_TRACE_EXIT(n_done, n_done);
         return gr::work::Status::OK;
     }
 };
@@ -416,6 +433,7 @@ public:
     }
     gr::work::Status processBulk(const gr::ConsumableSpan auto& inSpan, gr::PublishableSpan auto& outSpan)
     {
+        GR4PM_TRACE_ENTRY(inSpan.size(), outSpan.size());
         if (!_h) start();
         const size_t n = std::min({ inSpan.size(), outSpan.size(), detail::max_items() });
         const c64* hin = std::to_address(inSpan.begin());
@@ -426,6 +444,7 @@ public:
         detail::consumed(hin, n * sizeof(c64));
         if (!inSpan.consume(n)) throw gr::exception("consume failed");
         outSpan.publish(n);
+        GR4PM_TRACE_EXIT(n, n);
         return gr::work::Status::OK;
     }
 };
@@ -455,6 +474,7 @@ public:
     }
     gr::work::Status processBulk(const gr::ConsumableSpan auto& inSpan, gr::PublishableSpan auto& outSpan)
     {
+        GR4PM_TRACE_ENTRY(inSpan.size(), outSpan.size());
         if (!_h) start();
         gr4pm_tag tag{};
         size_t n_tags = 0;
@@ -475,6 +495,7 @@ public:
         detail::consumed(hin, n * sizeof(c64));
         if (!inSpan.consume(n)) throw gr::exception("consume failed");
         outSpan.publish(n);
+        GR4PM_TRACE_EXIT(n, n);
         return gr::work::Status::OK;
     }
 };
@@ -513,6 +534,7 @@ public:
                                  const gr::ConsumableSpan auto& ignoredSpan,
                                  const gr::ConsumableSpan auto& inSpan, gr::PublishableSpan auto& outSpan)
     {
+        GR4PM_TRACE_ENTRY(inSpan.size(), outSpan.size());
         if (!_h) start();
         int head_flags = 0;
         gr::property_map syncword_keys, other_keys;
@@ -556,6 +578,7 @@ public:
         if (!ignoredSpan.consume(ic)) throw gr::exception("ignoredSpan.consume failed");
         outSpan.publish(consumed);
         this->_mergedInputTag.map.clear(); // :125,202
+        GR4PM_TRACE_EXIT(consumed, consumed);
         return gr::work::Status::OK;
     }
 };
@@ -609,6 +632,7 @@ public:
     }
     gr::work::Status processBulk(const gr::ConsumableSpan auto& inSpan, gr::PublishableSpan auto& outSpan)
     {
+        GR4PM_TRACE_ENTRY(inSpan.size(), outSpan.size());
         if (!_h) settingsChanged({}, {});
         gr4pm_tag tag{};
         size_t n_tags = 0;
@@ -639,6 +663,7 @@ public:
         }
         if (!inSpan.consume(consumed)) throw gr::exception("consume failed"); // :240-243
         outSpan.publish(produced);
+        GR4PM_TRACE_EXIT(consumed, produced);
         return gr::work::Status::OK;
     }
 };
@@ -674,6 +699,7 @@ public:
     }
     gr::work::Status processBulk(const gr::ConsumableSpan auto& inSpan, gr::PublishableSpan auto& outSpan)
     {
+        GR4PM_TRACE_ENTRY(inSpan.size(), outSpan.size());
         if (!_h) settingsChanged({}, {});
         gr4pm_tag tag{};
         size_t n_tags = 0;
@@ -707,6 +733,7 @@ public:
         detail::consumed(hin, n * sizeof(c64));
         if (!inSpan.consume(n)) throw gr::exception("consume failed");
         outSpan.publish(n);
+        GR4PM_TRACE_EXIT(n, n);
         return gr::work::Status::OK;
     }
 };
@@ -738,6 +765,7 @@ public:
     }
     gr::work::Status processBulk(const gr::ConsumableSpan auto& inSpan, gr::PublishableSpan auto& outSpan)
     {
+        GR4PM_TRACE_ENTRY(inSpan.size(), outSpan.size());
         if (!_h) start();
         gr4pm_tag tag{};
         size_t n_tags = 0;
@@ -755,6 +783,7 @@ public:
         detail::consumed(hin, n * sizeof(c64));
         if (!inSpan.consume(n)) throw gr::exception("consume failed");
         outSpan.publish(n);
+        GR4PM_TRACE_EXIT(n, n);
         return gr::work::Status::OK;
     }
 };
@@ -790,6 +819,7 @@ public:
     }
     gr::work::Status processBulk(const gr::ConsumableSpan auto& inSpan, gr::PublishableSpan auto& outSpan)
     {
+        GR4PM_TRACE_ENTRY(inSpan.size(), outSpan.size());
         if (!_h) settingsChanged({}, {});
         const size_t n = std::min({ inSpan.size(), outSpan.size() / interpolation, detail::max_items() / interpolation }); // :91
         const c64* hin = std::to_address(inSpan.begin());
@@ -800,6 +830,7 @@ public:
         detail::consumed(hin, n * sizeof(c64));
         if (!inSpan.consume(n)) throw gr::exception("consume failed");
         outSpan.publish(n * interpolation);
+        GR4PM_TRACE_EXIT(n, n * interpolation);
         return gr::work::Status::OK;
     }
 };
@@ -836,6 +867,7 @@ public:
     }
     gr::work::Status processBulk(const gr::ConsumableSpan auto& inSpan, gr::PublishableSpan auto& outSpan)
     {
+        GR4PM_TRACE_ENTRY(inSpan.size(), outSpan.size());
         if (!_h) settingsChanged({}, {});
         const size_t n = std::min(inSpan.size(), detail::max_items());
         const size_t cap = std::min(outSpan.size(), detail::max_items());
@@ -849,6 +881,7 @@ public:
         detail::consumed(hin, consumed * sizeof(c64));
         if (!inSpan.consume(consumed)) throw gr::exception("consume failed"); // :169-172
         outSpan.publish(produced);
+        GR4PM_TRACE_EXIT(consumed, produced);
         return gr::work::Status::OK;
     }
 };
@@ -893,6 +926,7 @@ public:
     gr::work::Status processBulk(const gr::ConsumableSpan auto& headerSpan, const gr::ConsumableSpan auto& inSpan,
                                  gr::PublishableSpan auto& outSpan, gr::PublishableSpan auto& ignoredSpan)
     {
+        GR4PM_TRACE_ENTRY(inSpan.size(), outSpan.size());
         if (!_h) start();
         gr4pm_tag tag{};
         size_t n_tags = 0;
@@ -949,6 +983,7 @@ public:
         ignoredSpan.publish(ignored_published);
         outSpan.publish(produced);
         if (consumed != 0) this->_mergedInputTag.map.clear(); // :288-295
+        GR4PM_TRACE_EXIT(consumed, produced);
         return gr::work::Status::OK;
     }
 };
@@ -981,6 +1016,7 @@ public:
     }
     gr::work::Status processBulk(const gr::ConsumableSpan auto& inSpan, gr::PublishableSpan auto& outSpan)
     {
+        GR4PM_TRACE_ENTRY(inSpan.size(), outSpan.size());
         if (!_h) start();
         gr4pm_packet_tag tag{}, tout[2];
         size_t n_tags = 0;
@@ -1005,6 +1041,7 @@ public:
         if (!inSpan.consume(n)) throw gr::exception("consume failed");
         outSpan.publish(produced);
         if (n != 0) this->_mergedInputTag.map.clear(); // :95-102
+        GR4PM_TRACE_EXIT(n, produced);
         return gr::work::Status::OK;
     }
 };
@@ -1043,6 +1080,7 @@ public:
     }
     gr::work::Status processBulk(const gr::ConsumableSpan auto& inSpan, gr::PublishableSpan auto& outSpan)
     {
+        GR4PM_TRACE_ENTRY(inSpan.size(), outSpan.size());
         if (!_h) settingsChanged({}, {});
         if (this->input_tags_present()) {
             const auto& map = this->mergedInputTag().map;
@@ -1064,6 +1102,7 @@ public:
         detail::consumed(hin, n * sizeof(c64));
         if (!inSpan.consume(n)) throw gr::exception("consume failed");
         outSpan.publish(produced);
+        GR4PM_TRACE_EXIT(n, produced);
         return gr::work::Status::OK;
     }
 };
@@ -1096,6 +1135,7 @@ public:
     }
     gr::work::Status processBulk(const gr::ConsumableSpan auto& inSpan, gr::PublishableSpan auto& outSpan)
     {
+        GR4PM_TRACE_ENTRY(inSpan.size(), outSpan.size());
         if (!_h) start();
         const uint64_t zero = 0;
         const bool reset = !reset_tag_key.empty() && this->input_tags_present() &&
@@ -1110,6 +1150,7 @@ public:
         detail::consumed(hin, n * sizeof(T));
         if (!inSpan.consume(n)) throw gr::exception("consume failed");
         outSpan.publish(n);
+        GR4PM_TRACE_EXIT(n, n);
         return gr::work::Status::OK;
     }
 };
@@ -1146,6 +1187,7 @@ public:
     gr::work::Status processBulk(const gr::ConsumableSpan auto& inSpan, gr::PublishableSpan auto& headerSpan,
                                  gr::PublishableSpan auto& payloadSpan)
     {
+        GR4PM_TRACE_ENTRY(inSpan.size(), headerSpan.size());
         if (!_h) start();
         gr4pm_packet_tag tag{}, ht[2], pt[2];
         size_t n_tags = 0;
@@ -1229,6 +1271,7 @@ public:
     }
     gr::work::Status processBulk(const gr::ConsumableSpan auto& inSpan, gr::PublishableSpan auto& outSpan)
     {
+        GR4PM_TRACE_ENTRY(inSpan.size(), outSpan.size());
         const size_t codewords = std::min(inSpan.size() / 256, outSpan.size() / 4); // :293-294
         if (codewords == 0) { // :296-304
             std::ignore = inSpan.consume(0);
@@ -1248,6 +1291,7 @@ public:
             if (_invalid[c]) out.publishTag({ { "invalid_header", pmtv::pmt_null() } }, static_cast<ssize_t>(4 * c)); // :322-326
         if (!inSpan.consume(codewords * 256)) throw gr::exception("consume failed");
         outSpan.publish(codewords * 4);
+        GR4PM_TRACE_EXIT(codewords * 256, codewords * 4);
         return gr::work::Status::OK;
     }
 };

@@ -25,6 +25,16 @@ def test_wrapper_header_compiles_against_the_api_stub():
     assert os.path.exists(DRIVER)
 
 
+def test_wrappers_compile_with_trace_prints(tmp_path):
+    """-DTRACE (README.md:144-150 of the reference: cmake -D CMAKE_CXX_FLAGS=-DTRACE) turns on the entry / exit prints of
+    every processBulk() in the wrappers; the build with it must compile (the prints name spans and counters)"""
+    cmd = ge.gr4_compile_command(os.path.join(ROOT, "tests", "gr4_blocks_driver.cpp"), str(tmp_path / "trace.bin"))
+    r = subprocess.run(cmd[:1] + ["-DTRACE"] + cmd[1:], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    hdr = open(os.path.join(ROOT, "gr4-packet-modem_amd", "host", "gr4pm_gr4_blocks.hpp")).read()
+    assert hdr.count("GR4PM_TRACE_ENTRY(") - 2 == hdr.count("gr::work::Status processBulk(")  # (two in the macro definition)
+
+
 def test_unsupported_instantiations_are_compile_errors(tmp_path):
     """the wrappers are built for the reference's receiver instantiations; anything else must not compile
     (no silent CPU path)"""
