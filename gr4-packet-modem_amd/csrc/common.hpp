@@ -160,7 +160,7 @@ struct PinnedBuf {
 
 inline size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
 
-// Environment switches of the A/B and timing experiments.  Every one is read ONCE per process
+// Environment switches of the A/B and timing experiments (HISTORY.md appendix).  Every one is read ONCE per process
 // through these helpers; a switch that makes a call return GR4PM_OK with WRONG OUTPUTS (kernels left out or replaced
 // by stand-ins: GR4PM_TIMING_SKIP, GR4PM_SYMF_ABL, GR4PM_FAKE ...) says so on stderr the first time it is seen, so a
 // variable that leaked into a production environment cannot go unnoticed.

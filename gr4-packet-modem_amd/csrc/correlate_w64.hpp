@@ -208,7 +208,7 @@ __device__ __forceinline__ void w64_mid_dev_p(int lane, const float4* row, const
 // the same moment (0.846 .. 0.884 against 0.831 ms at nine bins: they are not in step to begin with); exchange stores
 // issued from inside the last stage of pass A (no change); (re, im) interleaved exchange rows written with
 // ds_write_b64 (0.82 against 0.78 ms); mid-stage and template reads further ahead (no change).
-// Timing-only ablations (wrong results; tools/w64_variants.py): 8 no template DMA, 32 no
+// Timing-only ablations (wrong results; tools/w64_variants.py, HISTORY.md section 3): 8 no template DMA, 32 no
 // exchange stores, 64 no exchange / twiddle reads, 128 no template reads, 1024 no power / maximum, 2048 no power
 // stores, 4096 no sample loads after the first block.
 template <int VAR>

@@ -145,7 +145,7 @@ __device__ __forceinline__ cf rot_chunk_pk(cf e, cf inc)
 // dependent complex multiplies is the whole cost, so the loop body is kept to exactly that.
 // Register budget: at most 32 VGPRs, on purpose.  These waves live for half a millisecond; a SIMD that runs two
 // correlator waves (2 x 240 registers) has exactly 32 left, so a wave of this kernel fits BESIDE them instead of keeping
-// the next correlator workgroup off its CU.  Hence: segment fields are re-read where they are
+// the next correlator workgroup off its CU (HISTORY.md section 9).  Hence: segment fields are re-read where they are
 // needed instead of kept, chunk counts are 32 bit (a segment is shorter than 2^35 items), one running pointer.
 __global__ __launch_bounds__(64) void k_rot_checkpoints(const RotSeg* __restrict__ segs, unsigned n_segs,
                                                         const RotState* __restrict__ state,
@@ -586,7 +586,7 @@ __global__ void k_update_hist(const T* __restrict__ in, const T* __restrict__ ca
 // (coalesced), every thread then forms its L outputs from LDS (neighbouring lanes read neighbouring items, the taps
 // are broadcast reads) and writes them as one contiguous run of L items.  Round 1 had one thread per OUTPUT: every
 // item was fetched L * arm length times through L1 and every output paid two 64-bit divisions (542 us per 2^24
-// symbols in, 2^26 samples out; this form: see DESIGN.md section 5).
+// symbols in, 2^26 samples out; this form: see HISTORY.md section 5).
 constexpr unsigned kFirItems = 256;
 constexpr size_t kFirMaxSmem = 160 * 1024;
 inline size_t interp_fir_smem(size_t L, size_t arm_stride, size_t item_size)

@@ -24,7 +24,7 @@
 // Why the detector can be parallel although the reference is a sequential greedy scan:
 // with r the item after the last reset (hpp:296-297), the next item whose history is tested
 // is the FIRST p >= r with zpow[p] >= max(zpow[p+1..p+T]) ("candidate"), and the following
-// reset happens at p+T+1 (proof in DESIGN.md).  Candidates are a per-item predicate; the
+// reset happens at p+T+1 (proof in HISTORY.md section 4).  Candidates are a per-item predicate; the
 // scan is a monotone map r -> r' that composes tile by tile.
 #include <algorithm>
 #include <chrono>
@@ -1134,7 +1134,7 @@ __global__ __launch_bounds__(64) void k_median_tests(const float* __restrict__ z
     for (uint32_t idx = blockIdx.x; idx < n; idx += gridDim.x) {
         // the candidate is the same for the whole wave: a uniform window pointer (SGPR pair) + the lane's 32-bit offset,
         // i.e. one address register per lane instead of a 64-bit address per load.  With that the kernel needs at most
-        // 32 VGPRs, which is what a SIMD has left beside two correlator waves: its waves run
+        // 32 VGPRs, which is what a SIMD has left beside two correlator waves (HISTORY.md section 9): its waves run
         // beside them on the memory bandwidth the correlator leaves idle instead of waiting for a free CU.
         const uint32_t p = __builtin_amdgcn_readfirstlane(visit[static_cast<size_t>(ch) * visit_cap + idx]);
         const float* zw = z + (static_cast<long long>(p) - static_cast<long long>(T)); // window [p - T, p + T]
@@ -1792,7 +1792,7 @@ gr4pm_status launch_correlate(gr4pm_syncword_detection* h, hipStream_t stream, c
         // kernel variant that never computes their powers runs (bit 16384)
         const bool prune = h->S <= 1793 && !h->w64_no_prune;
         // one frequency bin: GR4PM_W64_ONE=1 runs the three-waves-per-SIMD kernel of correlate_w64_one.hpp instead of the
-        // general one (bit-identical powers, the same launch time: DESIGN.md section 3a; 2, 3: its timing-only ablations)
+        // general one (bit-identical powers, the same launch time: HISTORY.md section 3a; 2, 3: its timing-only ablations)
         const int one_mode = h->w64_one;
         const bool one_off = one_mode == 0;
         if (h->n_bins == 1 && prune && h->w64_variant < 0 && !one_off) {

@@ -664,7 +664,7 @@ typedef struct {
                                   payload tail: descrambler, HeaderPayloadSplit, HeaderFecDecoder, HeaderParser
                                   (:131-139) answer SyncwordDetectionFilter and PayloadMetadataInsert instead of
                                   packet_length; BinarySlicer, PackBits, CrcCheck (:140-147) deliver the packets.
-                                  Two passes per batch, see DESIGN.md 5c. */
+                                  Two passes per batch, see HISTORY.md 5c. */
     const char* header_alist;  /* decode_headers: the header code, header_fec_decoder.hpp:31-258 */
 } gr4pm_packet_receiver_params;
 typedef struct {

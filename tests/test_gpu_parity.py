@@ -2543,7 +2543,7 @@ def test_burst_generator_loopback(pkg):
 @pytest.mark.parametrize("tool,cases", [("fuzz_detector.py", 8), ("fuzz_cfc_symf.py", 6), ("fuzz_costas.py", 9)])
 def test_randomised_differential_tools(tool, cases):
     """a few cases of every randomised differential test under tools/ (random settings, tags, chunkings against the
-    oracle; the long runs are quoted in DESIGN.md section 2)"""
+    oracle; the long runs are quoted in HISTORY.md section 2)"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
