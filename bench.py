@@ -202,7 +202,11 @@ def pmc_traffic(samples, kernel="k_correlate_w64"):
     """roofline.traffic: HBM bytes per launch from the PMC passes committed under profiles/ (read at
     run time; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note + WRITE_SIZE, per sample of
     the profiled launch, scaled to this launch).  null when the file is missing or describes another kernel."""
-    path = os.path.join(ROOT, "profiles", "r3_k_correlate_hbm_traffic.json")
+    import glob
+    # the newest round's file (profiles/r<N>_k_correlate_hbm_traffic.json)
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_k_correlate_hbm_traffic.json")),
+                   key=lambda f: int(os.path.basename(f)[1:].split("_")[0]))
+    path = found[-1] if found else os.path.join(ROOT, "profiles", "r4_k_correlate_hbm_traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
