@@ -669,7 +669,8 @@ def test_interpolating_fir_filter_lds_limit_is_reported(pkg):
 def test_symbol_filter_32x1025_taps_with_tags(pkg):
     """configs[4]'s receiving filter (bench.py --config 5): SymbolFilter with 32 arms x 1025 taps, delay 1025,
     c64 items, tag-driven clock phase (symbol_filter.hpp:112-252) -- the generic kernel (k_symbol_filter), not the
-    receiver's 44-tap fast path; outputs and re-timed tags bit for bit against the oracle, one call and split calls"""
+    receiver's 44-tap fast path but, since round 4, k_symbol_filter_long; outputs and re-timed tags bit for bit against
+    the oracle, one call and split calls"""
     pfb = orc.rrc_taps(32.0, 128.0, 1.0, 0.35, 32 * 1024)   # 32769 taps: arms of 1025 (arm 0) and 1024 taps
     assert pfb.size == 32 * 1024 + 1
     rng = np.random.default_rng(1025)
@@ -705,6 +706,34 @@ def test_symbol_filter_32x1025_taps_with_tags(pkg):
         assert t.size == want_tags.size
         for k in ("index", "amplitude", "phase", "freq", "time_est", "flags"):
             assert np.array_equal(t[k], want_tags[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_taps,num_arms", [(64 * 8, 8), (64 * 8 + 1, 8), (64 * 8 + 2, 8), (64 * 8 + 3, 8), (65 * 8 + 5, 8), (129 * 4, 4),
+                                             (257 * 3 + 1, 3), (2049, 1)])
+def test_symbol_filter_long_arms_all_layouts(pkg, n_taps, num_arms):
+    """k_symbol_filter_long (plain SymbolFilter, complex items, 4 samples per symbol, arms of 64 taps and more): every
+    layout of its tap walk -- 1 .. 4 head taps on the top tap position ((arm_size - 1) % 4), an even and an odd number
+    of whole tap positions behind them, arms of different lengths inside one filter (n_taps not a multiple of
+    num_arms), one and two passes left over after the two-pass loop -- with tags that change arm, scale and clock
+    phase and a symbol count that leaves the last workgroup and the last lane half empty: bit for bit the oracle's"""
+    rng = np.random.default_rng(n_taps)
+    taps = rng.standard_normal(n_taps).astype(np.float32)
+    n = 4 * 1501 + 3
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    idx = [0, 777, 2500, 4001, 5998]
+    tags = np.zeros(len(idx), dtype=pkg.TAG_DTYPE)
+    tags["index"] = idx
+    tags["amplitude"] = rng.uniform(0.5, 2.0, len(idx))
+    tags["time_est"] = [0.3, -0.2, 0.49, -0.45, 0.05]
+    tags["flags"] = pkg.TAG_SYNCWORD
+    delay = 37
+    want, want_tags, want_cons = orc.symbol_filter(x, taps, num_arms, 4, delay, tags=tags.astype(orc.TAG_DTYPE))
+    f = pkg.SymbolFilter(taps, num_arms, 4, delay)
+    y, t, cons = f.process_bulk(dev(x), tags)
+    assert cons == want_cons and y.numel() == want.size
+    assert np.array_equal(bits(host(y)), bits(want))
+    assert np.array_equal(t["index"], want_tags["index"])
 
 
 def test_symbol_filter_free_running_reference_qa(pkg):
