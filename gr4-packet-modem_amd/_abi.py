@@ -261,9 +261,10 @@ def lib():
     L.gr4pm_last_error.restype = C.c_char_p
     L.gr4pm_version.restype = C.c_char_p
     L.gr4pm_device_count.restype = C.c_int
-    L.gr4pm_test_fail_allocations.argtypes = [C.c_long, C.c_long]
-    L.gr4pm_test_fail_allocations.restype = None
-    L.gr4pm_test_allocation_count.restype = C.c_ulonglong
+    if hasattr(L, "gr4pm_test_fail_allocations"):  # (absent from older builds loaded through GR4PM_LIB for A/B runs)
+        L.gr4pm_test_fail_allocations.argtypes = [C.c_long, C.c_long]
+        L.gr4pm_test_fail_allocations.restype = None
+        L.gr4pm_test_allocation_count.restype = C.c_ulonglong
     L.gr4pm_syncword_detection_create.argtypes = [C.POINTER(SyncwordDetectionParams), C.POINTER(vp)]
     L.gr4pm_syncword_detection_destroy.argtypes = [vp]
     L.gr4pm_syncword_detection_destroy.restype = None

@@ -2692,3 +2692,49 @@ def test_symbol_filter_output_span_runs_out(pkg):
                 whole = orc.symbol_filter(x, pfb, 32, 4, 44, tags=otags)[0]
                 assert c2 == n - cons
                 assert np.array_equal(bits(np.concatenate([host(y), host(y2)])), bits(whole))
+
+
+@pytest.mark.gpu
+def test_native_packet_receiver_decode_cut_just_behind_a_header(pkg):
+    """decode_headers: a batch that ends 816 .. 848 items behind a syncword.  The real chain has then produced the
+    packet's 192 syncword + header symbols, while pass A -- whose window needs 848 items behind the tag -- delivers the
+    header message only with the next batch: PayloadMetadataInsert waits at the payload's first symbol
+    (payload_metadata_insert.hpp:243-247) and the stage carries the symbols it could not take to the front of the next
+    batch.  Round 3 failed such a batch ("PayloadMetadataInsert stalled ...": about one random cut in 200; found by
+    tools/stress_receiver.py in round 4).  Every cut over a range that covers the band: the packets of the two-batch run
+    are those of one call."""
+    rng = np.random.default_rng(77)
+    payloads = [rng.integers(0, 256, int(n)).astype(np.uint8).tobytes() for n in (300, 257, 411, 120)]
+    x = pkg.BurstGenerator().stream(payloads, [3000, 2500, 2000, 2200], freq_error=0.006, esn0_db=20.0, seed=78)
+    x = torch.cat([x, torch.zeros(8000, dtype=x.dtype, device=x.device)])
+
+    def packets(results):
+        got = []
+        for r in results:
+            data, p = r["packets"].cpu().numpy(), 0
+            for ln in r["packet_lengths"]:
+                if ln > 0:
+                    got.append(data[p:p + int(ln)].tobytes())
+                    p += int(ln)
+        return got
+
+    one = pkg.NativePacketReceiver(max_items=x.numel(), tags_cap=256, decode_headers=True)
+    whole = one.process_bulk(x)
+    assert packets([whole]) == payloads
+    tag = int(whole["detector_tags"]["index"][1]) - 1537  # sample index of the second packet's syncword in the stream
+    # The detector consumes whole strides of 1752 items, so the place where the first batch ends relative to the tag is
+    # moved by shifting the STREAM: `behind` = items of the delayed stream (what the chain behind the detector sees)
+    # that the first batch holds past the tag; the shifts cover 700 .. 700 + 1752, the band 816 .. 848 included.
+    seen = []
+    for shift in range(0, 1752, 8):
+        xs = torch.cat([torch.zeros(shift, dtype=x.dtype, device=x.device), x])
+        n_strides = (tag + shift + 1537 + 700 + 1751) // 1752
+        first = 2048 + (n_strides - 1) * 1752
+        rx = pkg.NativePacketReceiver(max_items=xs.numel(), tags_cap=256, decode_headers=True)
+        a = rx.process_bulk(xs[:first])
+        assert a["consumed"] == n_strides * 1752
+        seen.append(a["consumed"] - (tag + shift + 1537))
+        b = rx.process_bulk(xs[a["consumed"]:])
+        assert packets([a, b]) == payloads, (shift, seen[-1])
+        assert a["header_mismatches"] == 0 and b["header_mismatches"] == 0
+    assert min(seen) <= 716 and max(seen) >= 2400 and any(816 <= v < 848 for v in seen)
