@@ -1209,15 +1209,42 @@ class PacketReceiver:
             if not self.soft_bits:
                 res["symbols"] = self.costas_loop.process_bulk(res["symbols"], res["tags"])
                 return res
+            early_mismatch = 0
             if res.get("resolve") is not None:
                 self.payload_metadata_insert.resolve(res["resolve"])
                 if self.decode_headers:
                     waiting = np.nonzero(self._used_msgs["invalid_header"] == 2)[0]
+                    early = getattr(self, "_early_hdrs", [])
                     if waiting.size:
                         self._used_msgs[waiting[0]] = res["resolve"]
-            pm = self.payload_metadata_insert.process_bulk(res["symbols"], res["tags"], res["headers"],
-                                                           per_tag=True)
-            assert pm["consumed"] == res["symbols"].numel()  # every packet's header is known up front
+                    elif early:  # the chain's own decode of that header came first: checked now
+                        got0, r = early.pop(0), res["resolve"]
+                        if not (r["invalid_header"] == got0["invalid_header"] and
+                                (got0["invalid_header"] == 1 or r["packet_length"] == got0["packet_length"])):
+                            early_mismatch = 1
+            sym_in, tags_in, hdrs_in = res["symbols"], res["tags"], res["headers"]
+            carry = getattr(self, "_pm_carry", None)
+            if carry is not None:  # symbols PayloadMetadataInsert could not take in the batch before (below)
+                csym, ctags, chdrs = carry
+                tags_in = tags_in.copy()
+                tags_in["index"] += csym.numel()
+                sym_in = torch.cat([csym, sym_in])
+                tags_in = np.concatenate([ctags, tags_in])
+                hdrs_in = np.concatenate([chdrs, hdrs_in])
+                self._pm_carry = None
+            pm = self.payload_metadata_insert.process_bulk(sym_in, tags_in, hdrs_in, per_tag=True)
+            if pm["consumed"] != sym_in.numel():
+                # the block waits for a header that pass A delivers with the next batch (a batch that ends 816 .. 848 items
+                # behind a syncword, payload_metadata_insert.hpp:243-247): the rest is carried, as in the native receiver
+                rest = sym_in.numel() - pm["consumed"]
+                if rest > 1024:
+                    raise Gr4pmError(f"PayloadMetadataInsert stalled at symbol {pm['consumed']} of {sym_in.numel()}: "
+                                     "a header message is missing")
+                keep = tags_in["index"] >= pm["consumed"]
+                ctags = tags_in[keep].copy()
+                ctags["index"] -= pm["consumed"]
+                self._pm_carry = (sym_in[pm["consumed"]:].clone(), ctags, hdrs_in[keep].copy())
+            res["tags"], res["headers"] = tags_in, hdrs_in  # (what the bookkeeping below refers to)
             z = self.costas_loop.process_packets(pm["out"], pm["tags"])
             data, data_tags = self.syncword_remove.process_bulk(z, pm["tags"])
             llr, llr_tags = self.constellation_decoder.process_bulk(data, data_tags)
@@ -1236,9 +1263,12 @@ class PacketReceiver:
                 got = hd["messages"]
                 same = (given["invalid_header"] == got["invalid_header"]) & \
                     ((given["packet_length"] == got["packet_length"]) | (got["invalid_header"] == 1))
+                pending = given["invalid_header"] == 2  # pass A's message not there yet: checked when it arrives
+                if pending.any():
+                    self._early_hdrs = getattr(self, "_early_hdrs", []) + [got[i] for i in np.nonzero(pending)[0]]
                 res.update(header_messages=got, header_bytes=hd["header_bytes"], packet_type=hd["packet_type"],
                            payload_llr=hd["payload_llr"], payload_tags=hd["payload_tags"],
-                           header_mismatches=int(np.sum(~same)))
+                           header_mismatches=int(np.sum(~same & ~pending)) + early_mismatch)
                 # payload tail, packet_receiver.hpp:140-147: BinarySlicer<true> -> PackBits -> CrcCheck
                 # (which needs whole packets: an unfinished one waits for the next batch)
                 soft = hd["payload_llr"] if self._payload_carry is None else torch.cat([self._payload_carry,

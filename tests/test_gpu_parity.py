@@ -2738,3 +2738,20 @@ def test_native_packet_receiver_decode_cut_just_behind_a_header(pkg):
         assert packets([a, b]) == payloads, (shift, seen[-1])
         assert a["header_mismatches"] == 0 and b["header_mismatches"] == 0
     assert min(seen) <= 716 and max(seen) >= 2400 and any(816 <= v < 848 for v in seen)
+    # the host-layer composition (blocks.py PacketReceiver) takes the same way through the band: bit for bit the native one
+    for shift in [sh for sh, v in zip(range(0, 1752, 8), seen) if 812 <= v < 852]:
+        xs = torch.cat([torch.zeros(shift, dtype=x.dtype, device=x.device), x])
+        first = 2048 + ((tag + shift + 1537 + 700 + 1751) // 1752 - 1) * 1752
+        nat = pkg.NativePacketReceiver(max_items=xs.numel(), tags_cap=256, decode_headers=True)
+        ref = pkg.PacketReceiver(max_items=xs.numel(), decode_headers=True)
+        pos = 0
+        for piece_end in (first, xs.numel()):
+            g = nat.process_bulk(xs[pos:piece_end])
+            w = ref.process_bulk(xs[pos:piece_end])
+            assert w["consumed"] == g["consumed"] and g["header_mismatches"] == 0 and w["header_mismatches"] == 0
+            assert np.array_equal(bits(host(w["symbols"])), bits(host(g["symbols"])))
+            assert w["llr"].cpu().numpy().tobytes() == g["llr"].cpu().numpy().tobytes()
+            assert w["header_messages"].tobytes() == g["header_messages"].tobytes()
+            assert np.array_equal(w["packet_lengths"], g["packet_lengths"])
+            assert np.array_equal(w["packets"].cpu().numpy(), g["packets"].cpu().numpy())
+            pos += g["consumed"]
