@@ -3,6 +3,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
+#include <execinfo.h>
 #include <exception>
 #include <system_error>
 #include <vector>
@@ -87,7 +88,15 @@ static inline void* hooked_alloc(std::size_t n)
     if (g_alloc_armed.load(std::memory_order_relaxed) && g_alloc_pass_left.fetch_sub(1, std::memory_order_relaxed) <= 0) {
         const long f = g_alloc_fail_left.fetch_sub(1, std::memory_order_relaxed);
         if (f <= 1) g_alloc_armed.store(false, std::memory_order_relaxed);
-        if (f > 0) return nullptr;
+        if (f > 0) {
+            if (getenv("GR4PM_TEST_ALLOC_TRACE")) { // where the injected failure struck (test debugging)
+                void* bt[24];
+                const int nb = backtrace(bt, 24);
+                fprintf(stderr, "[gr4pm] injected allocation failure (%zu bytes) at:\n", n);
+                backtrace_symbols_fd(bt, nb, 2);
+            }
+            return nullptr;
+        }
     }
     return std::malloc(n ? n : 1);
 }

@@ -326,6 +326,7 @@ try {
     // the constants of packet_receiver.hpp:37-122, as in gr4pm_packet_receiver_create
     std::vector<float> rrc(((sps * 11) | 1));
     const size_t n_rrc = gr4pm_firdes_root_raised_cosine(1.0, static_cast<double>(sps), 1.0, 0.35, sps * 11, rrc.data());
+    if (n_rrc == 0) return bail(GR4PM_ERR_NOMEM); // the design ran out of host memory (its entry point reports that as 0 taps)
     rrc.resize(n_rrc);
     float norm = 0.0f;
     for (float v : rrc) norm += v * v;
@@ -358,6 +359,7 @@ try {
     const size_t n_pfb = gr4pm_firdes_root_raised_cosine(static_cast<double>(arms) / static_cast<double>(norm),
                                                          static_cast<double>(arms * sps), 1.0, 0.35, arms * sps * 11,
                                                          pfb.data());
+    if (n_pfb == 0) return bail(GR4PM_ERR_NOMEM);
     pfb.resize(n_pfb - 1);
     float bipolar[64];
     for (int i = 0; i < 64; ++i) bipolar[i] = syncword[i] ? -1.0f : 1.0f;

@@ -250,6 +250,15 @@ struct gr4pm_packet_receiver {
     uint64_t pending_idx = 0;
     std::deque<gr4pm_header_msg> s1_fifo;   // accepted tags' messages on their way to stage 2
     std::mutex s1_fifo_mutex;               // stage 1 pushes and patches, stage 1b pops
+    // batches stage 1 has started / stage 1b has finished (or seen failed).  Stage 1 patches a pending message inside
+    // s1_fifo only after stage 1b is done with every EARLIER batch: whether the entry is still in the fifo then says
+    // whether its tag left the symbol filter in the batch before (resolve path) or leaves it later (patch) -- the same
+    // answer with and without the pipeline (without the wait it depended on which thread got there first: the two
+    // forms of the receiver then cut the symbol stream differently around a pending header; tools/stress_receiver.py)
+    uint64_t stage1_started = 0, stage1_earlier = 0;
+    uint64_t stage1b_done = 0;
+    std::mutex stage1b_mutex;
+    std::condition_variable stage1b_cv;
     // ---- decode_headers: stage 2 thread ----
     // symbols (and their tags / messages) that PayloadMetadataInsert could not take at the end of a batch because the
     // header of the packet they belong to arrives with the next batch (stage2_decode)
@@ -325,6 +334,7 @@ void gr4pm_packet_receiver::stageA(Slot& s)
 // between; every stage waits once, at its end, before the slot moves on.
 void gr4pm_packet_receiver::stage1(Slot& s)
 {
+    stage1_earlier = stage1_started++; // every batch counts, failed ones too (stage 1b counts them as well)
     if (s.status != GR4PM_OK) return;
     const gr4pm_c64* y = s.delayed ? s.delayed : s.y.p;
     struct SyncAtEnd {
@@ -381,6 +391,17 @@ gr4pm_status gr4pm_packet_receiver::filter_and_wipe(Slot& s)
 // checkpoints are a serial, latency-bound kernel; the filter is a whole-chip one)
 void gr4pm_packet_receiver::stage1b(Slot& s)
 {
+    struct Done { // also on the early return and on an exception: stage 1 may be waiting for this batch
+        gr4pm_packet_receiver* h;
+        ~Done()
+        {
+            {
+                std::lock_guard<std::mutex> lk(h->stage1b_mutex);
+                ++h->stage1b_done;
+            }
+            h->stage1b_cv.notify_all();
+        }
+    } done{ this };
     if (s.status != GR4PM_OK) return;
     const gr4pm_status st = filter_and_wipe(s);
     (void)hipStreamSynchronize(streams[4]);
@@ -652,10 +673,15 @@ gr4pm_status gr4pm_packet_receiver::stage1_decode(Slot& s, const gr4pm_c64* y)
         return it != s.newly_known.end() && it->first == idx ? &it->second : nullptr;
     };
     s.has_resolve = false;
+    const uint64_t earlier = stage1_earlier; // batches in front of this one (stage 1 is one thread, or the caller's)
     if (pending_real)
         if (const gr4pm_header_msg* m = lookup(pending_idx)) {
             GR4PM_TRY(gr4pm_syncword_detection_filter_gate_resolve(sdf, m));
             pending_real = false;
+            {   // (rare: a detection within the last ~850 items of the batch before) stage 1b is done with every earlier batch
+                std::unique_lock<std::mutex> w(stage1b_mutex);
+                stage1b_cv.wait(w, [&] { return stage1b_done >= earlier; });
+            }
             bool patched = false;
             std::lock_guard<std::mutex> lk(s1_fifo_mutex);
             for (auto& f : s1_fifo)
@@ -754,8 +780,11 @@ gr4pm_status gr4pm_packet_receiver::stage2_decode(Slot& s)
             tj.back().index += pm_carry_n;
             hj.push_back(s.hdrs[i]);
         }
-        s.sym_tags.swap(tj);
-        s.n_sym_tags = s.sym_tags.size();
+        // (copied in, never swapped: the slot's tag array keeps its capacity -- the symbol filter of a later batch is told
+        // sym_tags.size() as the room it has)
+        if (s.sym_tags.size() < tj.size()) s.sym_tags.resize(tj.size());
+        std::copy(tj.begin(), tj.end(), s.sym_tags.begin());
+        s.n_sym_tags = tj.size();
         hj.resize(std::max<size_t>(hj.size(), 1));
         s.hdrs.swap(hj);
         pmi_in = pm_join.p;
@@ -959,6 +988,7 @@ try {
     // packet_receiver.hpp:60-74: RRC taps normalised to unit RMS norm (float accumulation)
     std::vector<float> rrc(((sps * 11) | 1));
     const size_t n_rrc = gr4pm_firdes_root_raised_cosine(1.0, static_cast<double>(sps), 1.0, 0.35, sps * 11, rrc.data());
+    if (n_rrc == 0) return bail(GR4PM_ERR_NOMEM); // the design ran out of host memory (its entry point reports that as 0 taps)
     rrc.resize(n_rrc);
     float norm = 0.0f;
     for (float v : rrc) norm += v * v;
@@ -996,6 +1026,7 @@ try {
     const size_t n_pfb = gr4pm_firdes_root_raised_cosine(static_cast<double>(arms) / static_cast<double>(norm),
                                                          static_cast<double>(arms * sps), 1.0, 0.35, arms * sps * 11,
                                                          pfb.data());
+    if (n_pfb == 0) return bail(GR4PM_ERR_NOMEM);
     pfb.resize(n_pfb - 1); // the design is odd-length: drop the last tap (:108-110)
     gr4pm_symbol_filter_params fsp{ sps, pfb.data(), pfb.size(), arms, rrc.size() - 1, 0, h->streams[4] };
     if ((st = gr4pm_symbol_filter_create(&fsp, &h->symf)) != GR4PM_OK) return bail(st);
