@@ -426,13 +426,6 @@ def selfcheck(pkg, dist, device, rank, world, rrc):
     """first contact of an N-rank job, seconds long: identities (N distinct devices), one scatter of 2^22-item channels
     from rank 0, two batches through the native receiver on what arrived, detections counted on every rank (SUM > 0,
     MIN > 0).  Any failure ends the rank with a message; the launcher ends the job."""
-    # ---- BASELINE configs[4] (the 2-Gsps stress shape) as a sub-record of the default line, N = 1 only
-    config5_rec = None
-    if headline and not args.no_config5_leg and world == 1:
-        multi = None
-        torch.cuda.empty_cache()
-        config5_rec = config5_leg(pkg, device)
-        torch.cuda.empty_cache()
     job = rank_identities(dist, device, world)
     check_distinct_devices(job, world)
     n = 1 << 22
@@ -728,6 +721,71 @@ def config5_leg(pkg, device, total=1 << 30, window=1 << 28, passes=2):
                                       "fp32_frac": round(1025.0 * sf_rate * 1e6 / 1e12 / FP32_PEAK_TFLOPS, 4)}}
 
 
+def host_stream_leg(pkg, device, rrc, chunk=1 << 25, host_chunks=4, total=1 << 29):
+    """PCIe-inclusive rate (never `value`): the headline front end fed from HOST memory, the way a GR4 port buffer or an
+    SDR driver hands samples over.  A pinned host ring of `host_chunks` chunks holds a burst + AWGN stream; every chunk
+    travels to one of six device slots on a copy stream (hipMemcpyAsync, two chunks ahead of the receiver) while the
+    pipelined native receiver works on the chunks before it; `total` samples = the host ring several times over.
+    Reported beside it: the same copies with no receiver behind them (what the link gives), so that the line says how
+    much of the link the receiver keeps busy."""
+    n_slots = 6
+    x, n_pkt = burst_stream(pkg, chunk * host_chunks, rrc, seed=77, device=device)
+    host = torch.empty(chunk * host_chunks, dtype=torch.complex64).pin_memory()
+    host.copy_(x)
+    del x
+    slots = [torch.empty(chunk, dtype=torch.complex64, device=device) for _ in range(n_slots)]
+    copy_stream = torch.cuda.Stream()
+    events = [torch.cuda.Event() for _ in range(n_slots)]
+    n_chunks = total // chunk
+
+    def upload(i):
+        src = host[(i % host_chunks) * chunk:(i % host_chunks + 1) * chunk]
+        with torch.cuda.stream(copy_stream):
+            slots[i % n_slots].copy_(src, non_blocking=True)
+            events[i % n_slots].record(copy_stream)
+
+    # the link alone
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n_chunks):
+        upload(i)
+    torch.cuda.synchronize()
+    dt_link = time.perf_counter() - t0
+    rx = pkg.NativePacketReceiver(SPS, BINS, 9.5, "QPSK", max_items=chunk, tags_cap=max(64, 2 * n_pkt + 64),
+                                  pipelined=True, output_ring=True)
+
+    def run(n):
+        done = tags = 0
+        upload(0)
+        upload(1)
+        for i in range(n):
+            if i + 2 < n:
+                upload(i + 2)  # slot (i + 2) % 6 held batch i - 4, collected by the process_bulk call of chunk i - 1
+            events[i % n_slots].synchronize()
+            res = rx.process_bulk(slots[i % n_slots], 1500)
+            if res is not None:
+                done += res["consumed"]
+                tags += res["tags"].size
+        for res in rx.flush():
+            done += res["consumed"]
+            tags += res["tags"].size
+        return done, tags
+    run(n_slots)  # warm-up: every slot and every output ring entry has been used
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    done, tags = run(n_chunks)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    del rx
+    return {"workload": f"configs[1] front end fed from pinned host memory: {n_chunks} chunks of 2^{chunk.bit_length() - 1} samples, "
+                        f"hipMemcpyAsync two chunks ahead into {n_slots} device slots, pipelined native receiver behind them",
+            "value": round(done / dt / 1e6, 2), "unit": "Msamples/s", "samples": done, "tags": tags,
+            "h2d_gbs": round(8.0 * done / dt / 1e9, 2),
+            "link_only": {"value": round(n_chunks * chunk / dt_link / 1e6, 2), "unit": "Msamples/s",
+                          "h2d_gbs": round(8.0 * n_chunks * chunk / dt_link / 1e9, 2)},
+            "note": "PCIe-inclusive; not `value` (inputs of the headline are resident in HBM when the timed region starts)"}
+
+
 def correlator_flops_per_sample(n_bins, n_fft=N_FFT, stride=1752):
     """[(1 + B) 5 N log2 N + 6 B N + 1.5 N + 4 B S] / S"""
     return ((1 + n_bins) * 5.0 * n_fft * np.log2(n_fft) + 6.0 * n_bins * n_fft + 1.5 * n_fft + 4.0 * n_bins * stride) / stride
@@ -929,6 +987,8 @@ def main():
                          "shape (N = 4096 overlap-save blocks, 1025-tap RRC, SyncwordDetection + the 1025-tap filter leg)")
     ap.add_argument("--no-config5-leg", action="store_true",
                     help="leave out the configs[4] sub-record (2^30 samples, fft_size 4096, 1025-tap RRC) of the default line")
+    ap.add_argument("--no-host-stream-leg", action="store_true",
+                    help="skip the PCIe-inclusive sub-record (front end fed from pinned host memory)")
     ap.add_argument("--no-per-bins", action="store_true",
                     help="leave out the roofline.per_bins legs (profiling runs: the correlator's rocprof average is then "
                          "the nine-bin launch alone)")
@@ -1194,6 +1254,11 @@ def main():
         torch.cuda.empty_cache()
         config5_rec = config5_leg(pkg, device)
         torch.cuda.empty_cache()
+    # ---- PCIe-inclusive: the same front end fed from pinned host memory (N = 1 only; never `value`)
+    host_stream_rec = None
+    if headline and not args.no_host_stream_leg and world == 1:
+        host_stream_rec = host_stream_leg(pkg, device, rrc)
+        torch.cuda.empty_cache()
     job = rank_identities(dist, device, world)
     check_distinct_devices(job, world)
 
@@ -1279,6 +1344,8 @@ def main():
         }
         if config5_rec is not None:
             line["config5"] = config5_rec
+        if host_stream_rec is not None:
+            line["host_stream"] = host_stream_rec
         if channels_leg is not None:
             if world > 1:
                 # 64 channels per GPU are the same work on every rank: the per-GPU rate of configs[3] should be the

@@ -203,3 +203,36 @@ def test_m0_guard_catches_a_compiler_written_m0(tmp_path):
                    ".Lfunc_end0:\n")
     seen, sites, _, _, problems = check_m0.check(str(bad))
     assert seen == 1 and len(problems) == 1 and "compiler-generated" in problems[0]
+
+
+def test_python_sources_reference_no_undefined_names():
+    """Static check of every Python file of the repository: a name a function reads without binding it must exist at
+    module level or be a builtin.  (Round 4: a misplaced edit left `if headline and not args...` inside
+    bench.selfcheck(), which only runs at N > 1 or under --selfcheck -- nothing on the one-GPU path would have
+    noticed the NameError before the driver's scaling run.)"""
+    import builtins
+    import glob
+    import symtable
+
+    def undefined(path):
+        top = symtable.symtable(open(path).read(), path, "exec")
+        mod = {s.get_name() for s in top.get_symbols() if s.is_assigned() or s.is_imported() or s.is_namespace()}
+        mod |= {"__file__", "__name__", "__doc__"}
+        bad = []
+
+        def walk(t):
+            for c in t.get_children():
+                for s in c.get_symbols():
+                    if s.is_global() and s.is_referenced() and not s.is_assigned():
+                        if s.get_name() not in mod and not hasattr(builtins, s.get_name()):
+                            bad.append(f"{os.path.relpath(path, ROOT)}:{c.get_lineno()}: {c.get_name()}() reads {s.get_name()}")
+                walk(c)
+        walk(top)
+        return bad
+
+    files = [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]
+    for pat in ("tools/*.py", "apps/*.py", "gr4-packet-modem_amd/*.py", "tests/*.py", "tests/golden/*.py", "oracle/*.py"):
+        files += sorted(glob.glob(os.path.join(ROOT, pat)))
+    assert len(files) > 40
+    bad = [b for f in files for b in undefined(f)]
+    assert not bad, "\n".join(bad)

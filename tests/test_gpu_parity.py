@@ -2785,3 +2785,19 @@ def test_native_packet_receiver_decode_cut_just_behind_a_header(pkg):
             assert np.array_equal(w["packet_lengths"], g["packet_lengths"])
             assert np.array_equal(w["packets"].cpu().numpy(), g["packets"].cpu().numpy())
             pos += g["consumed"]
+
+
+@pytest.mark.gpu
+def test_bench_selfcheck_runs_on_one_gpu():
+    """`bench.py --selfcheck` (what the N-rank launcher runs first, and what every rank of a torch.distributed.run job
+    goes through before the timed regions): identities, the scatter shape, two batches through the native receiver,
+    detections counted -- on one GPU here, so that the code every multi-GPU job starts with has run on hardware."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--selfcheck"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec["selfcheck"] == "ok" and rec["ranks"] == 1 and rec["tags"] > 0 and len(rec["job"]["ranks"]) == 1

@@ -39,14 +39,15 @@ for case in range(cases):
     _, ref_out, ref_tags = ref.process(x)
     try:
         sd = pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, lo, hi, max_items=x.size, **kw)
-        st, out, tags, n = sd.process_bulk(tp.dev(x))
+        cap = max(1024, 2 * ref_tags.size + 64)  # T = 64 in noise at a low threshold: thousands of tags
+        st, out, tags, n = sd.process_bulk(tp.dev(x), tags_cap=cap)
         assert n == ref_out.size and np.array_equal(tp.bits(tp.host(out)), tp.bits(ref_out)), "items"
         tp.assert_tags_match(tags, ref_tags, rtol=3e-4)
         sd2 = pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, lo, hi, max_items=x.size, **kw)
         pos, got = 0, []
         while pos + 2048 <= x.size:
             size = int(rng.integers(2048, 30000))
-            _, _, t, d = sd2.process_bulk(tp.dev(x[pos:pos + size]), want_output=False)
+            _, _, t, d = sd2.process_bulk(tp.dev(x[pos:pos + size]), want_output=False, tags_cap=cap)
             t = t.copy()
             t["index"] += pos
             got.append(t)

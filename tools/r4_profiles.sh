@@ -9,7 +9,7 @@ O=$R/gpurun_out/r4_final
 mkdir -p $O
 cd $R && python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
 cd /tmp && export TMPDIR=/tmp
-COMMON="--no-cpu-baseline --no-channels-leg --no-config5-leg --no-per-bins --repeats 1"
+COMMON="--no-cpu-baseline --no-channels-leg --no-config5-leg --no-host-stream-leg --no-per-bins --repeats 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_pipe -- python3 $R/bench.py --steps 20 --warmup 5 $COMMON > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_one -- python3 $R/bench.py --steps 5 --warmup 2 $COMMON --no-pipeline --no-lookahead > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 3 --warmup 1 $COMMON --no-pipeline --no-lookahead > /dev/null 2>&1
