@@ -48,6 +48,7 @@ import __graft_entry__ as ge  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3
 N_FFT, SPS, BINS = 2048, 4, 4
+SHARED_DEVICE_TEST = os.environ.get("GR4PM_BENCH_SHARED_DEVICE_TEST") == "1"  # tests only, see main()
 SYNCWORD = np.array(
     [0, 0, 0, 0, 0, 0, 1, 1, 0, 1, 0, 0, 0, 1, 1, 1, 0, 1, 1, 1, 0, 1, 1, 0, 1, 1, 0, 0, 0, 1, 1, 1,
      0, 0, 1, 0, 0, 1, 1, 1, 0, 0, 1, 0, 1, 0, 0, 0, 1, 0, 0, 1, 0, 1, 0, 1, 1, 0, 1, 1, 0, 0, 0, 0],
@@ -275,12 +276,17 @@ def scatter_channels(dist, make_all, n_items, device, rank, world):
     shape = (n_items,) if isinstance(n_items, int) else tuple(n_items)  # per-rank shape: [n] or [channels, n]
     mine = torch.empty(shape, dtype=torch.complex64, device=device)
     mine_f = torch.view_as_real(mine)  # interleaved float32 pairs: every backend moves floats
+    via_host = dist.get_backend() == "gloo" and device.type == "cuda"  # the shared-device test: gloo scatters host tensors
+    recv = torch.empty(shape + (2,), dtype=torch.float32) if via_host else mine_f
     if rank == 0:
         allx = make_all()
         assert tuple(allx.shape) == (world,) + shape
-        dist.scatter(mine_f, [torch.view_as_real(allx[r].contiguous()) for r in range(world)], src=0)
+        parts = [torch.view_as_real(allx[r].contiguous()) for r in range(world)]
+        dist.scatter(recv, [p.cpu() for p in parts] if via_host else parts, src=0)
     else:
-        dist.scatter(mine_f, None, src=0)
+        dist.scatter(recv, None, src=0)
+    if via_host:
+        mine_f.copy_(recv)
     return mine
 
 
@@ -290,6 +296,8 @@ def aggregate(dist, dt, consumed, device):
     torch.distributed backend (RCCL on the GPUs, gloo in the CPU test)."""
     if dist is None:
         return dt, consumed
+    if dist.get_backend() == "gloo":
+        device = torch.device("cpu")
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     csum = torch.tensor([consumed], dtype=torch.float64, device=device)
@@ -383,6 +391,9 @@ def check_distinct_devices(job, world):
     """every rank evaluates the gathered list (nobody is left waiting in a barrier for a rank that quit): N ranks must
     sit on N different devices"""
     ids = {(r["pci_bus_id"], r["uuid"]) for r in job["ranks"]}
+    if SHARED_DEVICE_TEST and job["ranks"][0]["device"] != "cpu":
+        job["shared_device_test"] = True
+        return
     if len(ids) != world:
         raise SystemExit(f"bench.py: {world} ranks on {len(ids)} distinct devices: {job['ranks']}")
 
@@ -441,7 +452,7 @@ def selfcheck(pkg, dist, device, rank, world, rrc):
     for r in rx.flush():
         tags += int(r["tags"].size)
     del rx
-    t = torch.tensor([float(tags)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(tags)], dtype=torch.float64, device="cpu" if (dist and dist.get_backend() == "gloo") else device)
     if dist:
         lo = t.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
@@ -1024,10 +1035,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    # GR4PM_BENCH_SHARED_DEVICE_TEST=1 (tests only; the line says so and is not a measurement): every rank takes
+    # cuda:0 and the group runs on gloo, so that the N > 1 code of this file -- self-check, scatter, barriers and
+    # aggregation around the timed regions, the configs[3] leg -- can run on a box with ONE GPU.
+    shared = SHARED_DEVICE_TEST and world > 1
+    if shared:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist = init_ranks("nccl", local_rank)
+        dist = init_ranks("gloo" if shared else "nccl", local_rank)
         # N distinct devices, checked right after the rendezvous and on every rank -- not after the timed regions
         check_distinct_devices(rank_identities(dist, device, world), world)
     pkg = ge.load_package()
@@ -1342,6 +1359,8 @@ def main():
             "cpu_baseline": cpu,
             "job": job,
         }
+        if shared:
+            line["shared_device_test"] = f"{world} ranks on ONE GPU over gloo: a check of the N > 1 code path, not a measurement"
         if config5_rec is not None:
             line["config5"] = config5_rec
         if host_stream_rec is not None:

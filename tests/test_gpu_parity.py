@@ -2801,3 +2801,45 @@ def test_bench_selfcheck_runs_on_one_gpu():
     assert r.returncode == 0, r.stderr[-2000:]
     rec = json.loads(r.stdout.strip().splitlines()[-1])
     assert rec["selfcheck"] == "ok" and rec["ranks"] == 1 and rec["tags"] > 0 and len(rec["job"]["ranks"]) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("launcher", ["torch.distributed.run", "bench.py --gpus 2"])
+def test_bench_two_ranks_share_the_gpu_through_the_whole_n_gt_1_path(launcher):
+    """The N > 1 code of bench.py on hardware, as far as a one-GPU box allows: two ranks (started the way the driver
+    starts them, and by bench.py's own launcher) that both take cuda:0 and talk over gloo
+    (GR4PM_BENCH_SHARED_DEVICE_TEST=1) go through the self-check, the channel scatter, the barrier-bracketed timed
+    regions with MAX / SUM aggregation and the configs[3] leg (64 channels per rank from rank 0's host ring), and
+    rank 0 prints ONE line for two ranks.  RCCL itself is the one thing this cannot reach; the rates mean nothing
+    (two processes share a GPU) and the line says so."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = ["--gpus", "2", "--steps", "3", "--warmup", "2", "--repeats", "2", "--items", str(1 << 24), "--no-cpu-baseline"]
+    env = dict(os.environ, GR4PM_BENCH_SHARED_DEVICE_TEST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    if launcher == "torch.distributed.run":
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py")] + args
+    else:
+        cmd = [sys.executable, os.path.join(root, "bench.py")] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and "shared_device_test" in rec
+    assert rec["job"]["world"] == 2 and [x["rank"] for x in rec["job"]["ranks"]] == [0, 1] and rec["job"]["backend"] == "gloo"
+    # both ranks' samples are in the sum: 3 steps x 2 ranks x (whole strides of 2^24 items)
+    per_step = ((1 << 24) - 2048) // 1752 * 1752 + 1752
+    assert abs(rec["value"] * 1e6 * rec["ms_per_step"] * 1e-3 * 3 / (3 * 2 * per_step) - 1.0) < 0.01
+    assert "scatter" in rec["config"]["input"]
+    c3 = rec["config3"]
+    assert c3["value"] > 0 and "128 channels in all" in c3["workload"] and "per_gpu" in c3
