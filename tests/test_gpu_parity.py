@@ -2843,3 +2843,47 @@ def test_bench_two_ranks_share_the_gpu_through_the_whole_n_gt_1_path(launcher):
     assert "scatter" in rec["config"]["input"]
     c3 = rec["config3"]
     assert c3["value"] > 0 and "128 channels in all" in c3["workload"] and "per_gpu" in c3
+
+
+@pytest.mark.gpu
+def test_bench_collectives_over_rccl_with_one_rank():
+    """RCCL itself, as far as one GPU reaches: a one-rank "nccl" group (init_process_group with device_id and the
+    bounded timeout, as bench.init_ranks makes it) carries every collective bench.py uses -- all_gather_object for the
+    identities, broadcast_object_list for the scatter budget, scatter of float views of complex slabs [C, n],
+    all_reduce MAX / SUM / MIN, barrier -- with bench.py's own helpers."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    code = """
+import sys, torch
+sys.path.insert(0, %r)
+import bench
+device = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+dist = bench.init_ranks("nccl", 0)
+assert dist.get_backend() == "nccl"
+job = bench.rank_identities(dist, device, 1)
+bench.check_distinct_devices(job, 1)
+bench.scatter_budget(dist, 0, 1, 8 << 20, device, host_ring=True)
+g = torch.Generator(device=device); g.manual_seed(3)
+src = torch.view_as_complex(torch.randn((1, 4, 1 << 16, 2), device=device, generator=g))
+x = bench.scatter_channels(dist, lambda: src, (4, 1 << 16), device, 0, 1)
+assert torch.equal(torch.view_as_real(x), torch.view_as_real(src[0]))
+dt, total = bench.aggregate(dist, 1.5, 7.0, device)
+assert (dt, total) == (1.5, 7.0)
+t = torch.tensor([3.0], dtype=torch.float64, device=device)
+dist.all_reduce(t, op=dist.ReduceOp.MIN)
+dist.barrier()
+torch.cuda.synchronize()
+dist.destroy_process_group()
+print("rccl one-rank ok", job["backend"], job["ranks"][0]["name"])
+""" % root
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0 and "rccl one-rank ok nccl" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
