@@ -232,6 +232,12 @@ __global__ __launch_bounds__(kW64Threads, 2) void k_correlate_w64(const cf* __re
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < kW64TwFloat4; i += kW64Threads) lds4[i] = tT[i];
+    // the next item of this workgroup that no wave has taken yet (see `dynamic` below) lives in a pad word of the
+    // exchange rows (row 0 of wave 0; only the LDS-DMA template variants ever write there, and they keep fixed shares):
+    // one more byte of LDS would cost the kernels that run beside this one their place on the CU
+    uint32_t* const wg_next = reinterpret_cast<uint32_t*>(lds4 + kW64TwFloat4) + 128;
+    constexpr bool kDynamic = (VAR & 32768) != 0 && (VAR & 131072) == 0;
+    if (kDynamic && tid == 0) *wg_next = blockIdx.x * kW64Waves * blocks_per_wave + kW64Waves;
     __syncthreads(); // the only workgroup-wide synchronisation of the kernel
     float4* xb4 = lds4 + kW64TwFloat4 + wave * kW64BufF4;
     // LDS byte address of the buffer (what DS instructions and M0 take)
@@ -245,6 +251,12 @@ __global__ __launch_bounds__(kW64Threads, 2) void k_correlate_w64(const cf* __re
     // launch).  blocks_per_wave == K: a workgroup owns 8 K consecutive items and retires after them, so that the
     // dispatcher can place the workgroups of other streams' kernels on the CU in between (a pipelined receiver:
     // a persistent launch keeps every CU's LDS for its whole duration and everything else waits for it).
+    // The 8 K items are handed out through a counter in LDS, one at a time and one block ahead (the samples of the
+    // next block are requested during the last transform of the current one): a wave that shares its SIMD with a wave
+    // of another kernel -- the serial kernels of the receiver fit beside two correlator waves and then take most of
+    // that SIMD's issue slots for as long as they live -- takes fewer blocks instead of keeping the other six waves'
+    // CU waiting for its fixed share (VAR & 131072: the fixed shares of rounds 1 - 3, for A/B).
+    const bool dynamic = kDynamic && blocks_per_wave != 0;
     const uint32_t n_waves = blocks_per_wave ? kW64Waves : gridDim.x * kW64Waves;
     uint32_t item = blocks_per_wave ? blockIdx.x * kW64Waves * blocks_per_wave + wave : blockIdx.x * kW64Waves + wave;
     const uint32_t item_end = blocks_per_wave ? min(total, (blockIdx.x + 1) * kW64Waves * blocks_per_wave) : total;
@@ -299,8 +311,8 @@ __global__ __launch_bounds__(kW64Threads, 2) void k_correlate_w64(const cf* __re
     for (;;) {
         const uint32_t ch = one_channel ? 0u : item / n_blocks, blk = item - ch * n_blocks;
         float* zo = zpow + static_cast<size_t>(ch) * z_stride + static_cast<size_t>(blk) * stride_s;
-        const uint32_t next = item + n_waves;
-        const bool has_next = next < item_end;
+        uint32_t next = item + n_waves; // dynamic: taken from the workgroup's counter in front of the last transform
+        bool has_next = next < item_end;
         // ---- forward transform of the block (hpp:239-241)
         {
             cf bq[32];
@@ -368,6 +380,14 @@ __global__ __launch_bounds__(kW64Threads, 2) void k_correlate_w64(const cf* __re
                 p[2 * u] = cmul(X[2 * u], mk(t.x, t.y));
                 p[2 * u + 1] = cmul(X[2 * u + 1], mk(t.z, t.w));
                 if ((u & 1) == 1 && u >= 3) w64_pin4(p + 2 * u - 6); // at most four template reads ahead of their use
+            }
+            if (bin == n_bins - 1 && dynamic) {
+                // as late as the prefetch below allows: a wave that is being held up has committed itself to the block
+                // it is working on and to nothing else
+                uint32_t taken = 0;
+                if (lane == 0) taken = atomicAdd(wg_next, 1u);
+                next = __builtin_amdgcn_readfirstlane(taken);
+                has_next = next < item_end;
             }
             if (!(VAR & 4096) && bin == n_bins - 1 && has_next) {
                 // the spectrum is dead: its registers take the samples of this wave's next block,

@@ -371,6 +371,11 @@ try {
     if (hipStreamCreateWithPriority(&h->costas_stream, hipStreamNonBlocking, least) != hipSuccess) return bail(GR4PM_ERR_HIP);
     gr4pm_costas_loop_params cp{ 0.01, p->costas_constellation, p->n_channels, h->costas_stream };
     if ((st = gr4pm_costas_loop_create(&cp, &h->costas)) != GR4PM_OK) return bail(st);
+    {
+        // the PLL of every batch runs beside the correlator of a later one: its 32-VGPR form (see gr4pm_packet_receiver_create)
+        static const char* small = gr4pm::experiment_env("GR4PM_COSTAS_SMALL", false);
+        (void)gr4pm_costas_loop_set_small_footprint(h->costas, small ? atoi(small) : 2);
+    }
     for (size_t c = 0; c < p->n_channels; ++c) {
         auto& ch = h->chains[c];
         hipStream_t s = h->streams[c % n_workers];

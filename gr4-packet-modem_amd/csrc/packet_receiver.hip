@@ -1036,11 +1036,14 @@ try {
     if ((st = gr4pm_syncword_wipeoff_create(&wp, &h->wipe)) != GR4PM_OK) return bail(st);
     gr4pm_costas_loop_params cp{ 0.01, p->soft_bits ? 1 : p->costas_constellation, 1, h->streams[2] }; // :125
     if ((st = gr4pm_costas_loop_create(&cp, &h->costas)) != GR4PM_OK) return bail(st);
-    // Beside the round-1 correlator (2 x 232 VGPRs per SIMD) the 46-VGPR form of k_costas paid off; beside
-    // k_correlate_w64 (2 x 210) it does not: the Costas stage is the slowest stage of the pipeline, and its 40 waves
-    // cost the correlator 4 % of its SIMD slots at most.  GR4PM_COSTAS_SMALL=1 brings the small form back.
-    if (p->pipelined && getenv("GR4PM_COSTAS_SMALL") != nullptr)
-        (void)gr4pm_costas_loop_set_small_footprint(h->costas, 1);
+    // Pipelined, the PLL runs while the correlator of a later batch has the chip: the 32-VGPR form of k_costas fits
+    // beside two correlator waves (2 x 240 of a SIMD's 512 registers), so its waves -- one per 64 packets, alive for as
+    // long as a packet's chain takes -- no longer keep a correlator workgroup off their CU.  Round 4: +2.5 % for the
+    // receiver although the kernel alone is slower (GR4PM_COSTAS_SMALL = 0 / 1 / 2 for A/B: 112 / 62 / 32 VGPRs).
+    if (p->pipelined) {
+        static const char* small = experiment_env("GR4PM_COSTAS_SMALL", false);
+        (void)gr4pm_costas_loop_set_small_footprint(h->costas, small ? atoi(small) : 2);
+    }
     if (p->soft_bits) {
         gr4pm_payload_metadata_insert_params pp{ 64, 128, 0.02, 0.01, 0.005, h->streams[2] }; // :123-124
         if ((st = gr4pm_payload_metadata_insert_create(&pp, &h->pmi)) != GR4PM_OK) return bail(st);

@@ -473,6 +473,36 @@ __global__ void k_costas(const CostasSeg* __restrict__ segs, unsigned n_segs,
     }
 }
 
+// The same kernel held to 32 VGPRs (amdgpu_num_vgpr counts register PAIRS on gfx90a and later: 16 -> 32; hipcc spills
+// 26 - 30 dwords, six scratch accesses per four symbols in the loop), which is what a SIMD has left beside two 240-VGPR
+// correlator waves: its waves start beside a correlator workgroup instead of waiting for -- and then keeping -- a CU
+// of their own.  Slower by itself, +2.5 % for the pipelined receiver (gr4pm_costas_loop_set_small_footprint(h, 2)).
+template <int CONSTELLATION, int KV>
+__global__ __attribute__((amdgpu_num_vgpr(16))) void k_costas_cap(const CostasSeg* __restrict__ segs, unsigned n_segs,
+                                                               const CostasState* __restrict__ state,
+                                                               CostasState* __restrict__ state_next, float k1, float k2,
+                                                               const cf* __restrict__ in, cf* __restrict__ out,
+                                                               size_t stride)
+{
+    const unsigned s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_segs) return;
+    __builtin_amdgcn_s_setprio(GR4PM_SERIAL_PRIO);
+    const CostasSeg g = segs[s];
+    float phase, freq;
+    if (g.mode == 0) {
+        phase = state[g.channel].phase;
+        freq = state[g.channel].freq;
+    } else {
+        phase = g.phase0;
+        freq = 0.0f;
+    }
+    costas_run<CONSTELLATION, KV>(in, out, static_cast<size_t>(g.channel) * stride + g.start, g.len, phase, freq, k1, k2);
+    if (g.last) {
+        state_next[g.channel].phase = phase;
+        state_next[g.channel].freq = freq;
+    }
+}
+
 // Tag-driven settings (gr4pm_costas_loop_process_packets): a chain is the run of items between
 // two set_phase events; it consists of pieces with their own constellation and loop
 // coefficients (syncword: PILOT, header and payload: QPSK with different bandwidths); phase
@@ -1794,7 +1824,7 @@ struct gr4pm_costas_loop {
     unsigned memo_next = 0;
     DevBuf<CostasState> state; // [2][n_channels], st_cur selects the current half
     int st_cur = 0;
-    bool small_footprint = false; // k_costas with 32-byte prefetch pieces (46 VGPRs)
+    int small_footprint = 0; // 0: k_costas<C, 8> (112 VGPRs, fastest alone), 1: k_costas<C, 2> (62), 2: k_costas_cap<C, 2> (32)
     DevBuf<CostasSeg> segs;
     DevBuf<CostasChain> chains;
     DevBuf<CostasPiece> pieces;
@@ -1965,7 +1995,11 @@ static gr4pm_status costas_process_impl(gr4pm_costas_loop* h, const gr4pm_c64* i
         hipLaunchKernelGGL(kernel, grid, block, 0, s, h->segs.p, n_segs, st_in, st_out, h->k1, h->k2,
                            reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(out), stride);
     };
-    if (h->small_footprint) {
+    if (h->small_footprint >= 2) {
+        if (h->constellation == 0) launch(k_costas_cap<0, 2>);
+        else if (h->constellation == 1) launch(k_costas_cap<1, 2>);
+        else launch(k_costas_cap<2, 2>);
+    } else if (h->small_footprint) {
         if (h->constellation == 0) launch(k_costas<0, 2>);
         else if (h->constellation == 1) launch(k_costas<1, 2>);
         else launch(k_costas<2, 2>);
@@ -1983,7 +2017,7 @@ static gr4pm_status costas_process_impl(gr4pm_costas_loop* h, const gr4pm_c64* i
 gr4pm_status gr4pm_costas_loop_set_small_footprint(gr4pm_costas_loop* h, int on)
 try {
     if (!h) return GR4PM_ERR_INVALID;
-    h->small_footprint = on != 0;
+    h->small_footprint = on < 0 ? 0 : (on > 2 ? 2 : on);
     return GR4PM_OK;
 }
 GR4PM_ABI_CATCH

@@ -1595,7 +1595,7 @@ struct gr4pm_syncword_detection {
     int n_cus = 256;
     int w64_variant = -1;
     int w64_one = 0; // GR4PM_W64_ONE at creation
-    uint32_t w64_blocks_per_wave = 4; // blocks per wave and workgroup; 0: persistent waves (GR4PM_W64_BLOCKS_PER_WAVE)
+    uint32_t w64_blocks_per_wave = 6; // blocks per wave and workgroup (handed out dynamically); 0: persistent waves (GR4PM_W64_BLOCKS_PER_WAVE)
     // raised by a correlator kernel whose bounded hand-off spin ran out ("wave" / "pair" kernels; k_correlate_w64
     // has no spins); checked after the stream synchronisation of process()
     PinnedBuf<unsigned> fault;
@@ -1825,6 +1825,7 @@ gr4pm_status launch_correlate(gr4pm_syncword_detection* h, hipStream_t stream, c
         case 100352: GR4PM_W64_LAUNCH(98304 + 16384 + 2048); break; // timing only: the default kernel without power stores
         case 102400: GR4PM_W64_LAUNCH(98304 + 16384 + 4096); break; // ... without sample loads after the first block
         case 104448: GR4PM_W64_LAUNCH(98304 + 16384 + 6144); break; // ... without either
+        case 131072: GR4PM_W64_LAUNCH(98304 + 16384 + 131072); break; // A/B: fixed shares of blocks per wave (rounds 1 - 3), same results
         default:
             // planar mid stage / pass B / powers in the bin loop (65536), templates from global memory straight
             // into registers (32768)
@@ -2101,7 +2102,7 @@ try {
         // GR4PM_W64_ONE=1) select silently; every other value is a timing-only ablation with wrong powers and says so
         const char* v = getenv("GR4PM_W64_VARIANT");
         h->w64_variant = v ? atoi(v) : -1;
-        if (v && h->w64_variant != -1 && h->w64_variant != 0 && h->w64_variant != 65536) (void)experiment_env("GR4PM_W64_VARIANT", true);
+        if (v && h->w64_variant != -1 && h->w64_variant != 0 && h->w64_variant != 65536 && h->w64_variant != 131072) (void)experiment_env("GR4PM_W64_VARIANT", true);
         if (const char* cv = getenv("GR4PM_C4096_VARIANT")) h->c4096_variant = atoi(cv) & 15;
         const char* one = getenv("GR4PM_W64_ONE");
         h->w64_one = one ? atoi(one) : 0;

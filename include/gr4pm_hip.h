@@ -243,9 +243,10 @@ void gr4pm_costas_loop_coeffs(const gr4pm_costas_loop* h, float* k1, float* k2);
 /* settingsChanged() (:52-88): new constellation / loop bandwidth from tags or messages */
 gr4pm_status gr4pm_costas_loop_set(gr4pm_costas_loop* h, double loop_bandwidth,
                                    int constellation);
-/* same results either way; on: the kernel of _process / _process_ragged keeps under 48 VGPRs (what a
- * SIMD has left beside two waves of the syncword correlator) at the price of being slower by
- * itself -- for callers that run it next to a SyncwordDetection, as gr4pm_packet_receiver does */
+/* same results either way.  on = 1: the kernel of _process / _process_ragged keeps to 62 VGPRs, on = 2: to 32 VGPRs
+ * (what a SIMD has left beside two waves of the syncword correlator: the PLL's waves then run BESIDE a correlator
+ * workgroup instead of keeping a compute unit from it) at the price of being slower by itself -- for callers that run
+ * it next to a SyncwordDetection; gr4pm_packet_receiver and gr4pm_multichannel_receiver ask for 2 when pipelined */
 gr4pm_status gr4pm_costas_loop_set_small_footprint(gr4pm_costas_loop* h, int on);
 gr4pm_status gr4pm_costas_loop_process(gr4pm_costas_loop* h, const gr4pm_c64* in, size_t stride,
                                        size_t n, gr4pm_c64* out, const gr4pm_tag* tags,
