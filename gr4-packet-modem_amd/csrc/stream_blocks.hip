@@ -1878,6 +1878,9 @@ try {
         delete h;
         return s;
     }
+    // GR4PM_COSTAS_FORM = 0 .. 2: the kernel form every CostasLoop starts with (tests and A/B; same results)
+    static const char* form = gr4pm::experiment_env("GR4PM_COSTAS_FORM", false);
+    if (form) h->small_footprint = std::min(2, std::max(0, atoi(form)));
     *out = h;
     return GR4PM_OK;
 }
