@@ -899,7 +899,7 @@ def channels64_leg(pkg, dist, device, rank, world, rrc, steps, warmup, repeats, 
     state = {"step": 0, "announced": 0}
 
     def step(left):
-        target = state["step"] + min(left, 1)
+        target = state["step"] + min(left, 2)  # look-ahead two batches ahead, as the headline
         state["announced"] = max(state["announced"], state["step"])
         while state["announced"] < target:
             state["announced"] += 1
@@ -1262,7 +1262,7 @@ def main():
     headline = native and not (args.soft_bits or args.decode_headers or args.no_pipeline or args.no_lookahead or args.copy_delay)
     if headline and not args.no_channels_leg:
         rx = None  # the headline receiver is done: its stage threads and streams go before the next leg starts
-        channels_leg = channels64_leg(pkg, dist, device, rank, world, rrc, steps=max(args.steps, 8), warmup=6,
+        channels_leg = channels64_leg(pkg, dist, device, rank, world, rrc, steps=max(args.steps, 50), warmup=6,
                                       repeats=min(args.repeats, 3))
     # ---- BASELINE configs[4] (the 2-Gsps stress shape) as a sub-record of the default line, N = 1 only
     config5_rec = None

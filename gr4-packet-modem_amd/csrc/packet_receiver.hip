@@ -5,6 +5,7 @@
 // Costas loop (+ PayloadMetadataInsert / SyncwordRemove / LLR decoder) -- run on three HIP streams
 // driven by the caller's thread and two worker threads, several batches in flight.
 // Host code only: every kernel is reached through the gr4pm_* entry points.
+#include <atomic>
 #include <algorithm>
 #include <cmath>
 #include <chrono>
@@ -28,6 +29,7 @@ static_assert(7 <= GR4PM_CFC_PLANS, "a slot keeps its CFC plan from stage 1 to s
 constexpr int kSlots = 7; // detector | pass A (decode_headers) | stage 1 | stage 1b | stage 2 | stage 3 (decode_headers) | held by the caller
 
 struct Slot {
+    uint64_t seq = 0; // ordinal of the batch (1, 2, ...)
     // inputs of the batch
     const gr4pm_c64* in = nullptr;
     size_t n_in = 0;
@@ -278,6 +280,10 @@ struct gr4pm_packet_receiver {
     std::thread workers[5];
     int held = -1; // slot whose result the caller is looking at
     size_t inflight = 0;
+    // what the PLL stage needs to know: is a correlator launch of a LATER batch running (or about to) beside it?
+    std::atomic<uint64_t> n_submitted{ 0 };
+    std::atomic<int> n_ahead{ 0 }; // announced and not yet submitted
+    int costas_form = 0;            // the PLL's kernel form while that is the case (gr4pm_costas_loop_set_small_footprint)
 
     void fail(Slot& s, gr4pm_status st)
     {
@@ -425,6 +431,10 @@ void gr4pm_packet_receiver::stage2(Slot& s)
             set_error("out_cap %zu < %zu symbols", s.out_cap, s.n_symbols);
             return fail(s, GR4PM_INSUFFICIENT_OUTPUT_ITEMS);
         }
+        // the 32-VGPR form pays beside a correlator launch; with nothing behind this batch (the pipeline is draining)
+        // the chip is the PLL's own and the fast form finishes a millisecond earlier
+        const bool later_work = n_submitted.load(std::memory_order_relaxed) > s.seq || n_ahead.load(std::memory_order_relaxed) > 0;
+        (void)gr4pm_costas_loop_set_small_footprint(costas, later_work ? costas_form : 0);
         const gr4pm_status st = gr4pm_costas_loop_process(costas, s.sym.p, s.n_symbols, s.n_symbols, s.out_symbols,
                                                           s.sym_tags.data(), nullptr, s.n_sym_tags);
         if (st != GR4PM_OK) fail(s, st);
@@ -1042,7 +1052,8 @@ try {
     // receiver although the kernel alone is slower (GR4PM_COSTAS_SMALL = 0 / 1 / 2 for A/B: 112 / 62 / 32 VGPRs).
     if (p->pipelined) {
         static const char* small = experiment_env("GR4PM_COSTAS_SMALL", false);
-        (void)gr4pm_costas_loop_set_small_footprint(h->costas, small ? atoi(small) : 2);
+        h->costas_form = small ? atoi(small) : 2;
+        (void)gr4pm_costas_loop_set_small_footprint(h->costas, h->costas_form);
     }
     if (p->soft_bits) {
         gr4pm_payload_metadata_insert_params pp{ 64, 128, 0.02, 0.01, 0.005, h->streams[2] }; // :123-124
@@ -1231,6 +1242,9 @@ try {
     CLK_GOT(h->clk[0]);
     h->stage0(s, next_in, next_n);
     CLK_DONE(h->clk[0]);
+    if (h->n_ahead.load(std::memory_order_relaxed) > 0) h->n_ahead.fetch_sub(1, std::memory_order_relaxed);
+    if (next_in) h->n_ahead.store(1, std::memory_order_relaxed); // hint_next: the one batch named with this submit
+    s.seq = h->n_submitted.fetch_add(1, std::memory_order_relaxed) + 1;
     ++h->inflight;
     slot_return.armed = false;
     if (h->p.pipelined) {
@@ -1255,6 +1269,7 @@ GR4PM_ABI_CATCH
 gr4pm_status gr4pm_packet_receiver_announce(gr4pm_packet_receiver* h, const gr4pm_c64* in, size_t n_in)
 try {
     if (!h || !in) return GR4PM_ERR_INVALID;
+    h->n_ahead.fetch_add(1, std::memory_order_relaxed);
     return gr4pm_syncword_detection_announce(h->sd, in, n_in, n_in);
 }
 GR4PM_ABI_CATCH

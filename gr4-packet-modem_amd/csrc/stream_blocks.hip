@@ -1998,11 +1998,19 @@ static gr4pm_status costas_process_impl(gr4pm_costas_loop* h, const gr4pm_c64* i
         hipLaunchKernelGGL(kernel, grid, block, 0, s, h->segs.p, n_segs, st_in, st_out, h->k1, h->k2,
                            reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(out), stride);
     };
-    if (h->small_footprint >= 2) {
+    // Form 2 pays when the call is long enough for a correlator launch of the same size to keep the chip busy beside it:
+    // a PLL wave lives for one packet's chain however small the call is (0.75 ms in the 112-VGPR form, 1.77 ms in the
+    // 32-VGPR form), and with batches of 2^26 samples and less that life, not the correlator, is what the receiver waits
+    // for (64 channels x 2^20 samples per batch: 40.8 against 25.5 Gsps sustained).  Below 2^25 symbols: the fast form.
+    size_t call_symbols = 0;
+    for (const auto& g : segs) call_symbols += g.len;
+    static const char* cap_min = gr4pm::experiment_env("GR4PM_COSTAS_CAP_MIN_LOG2", false);
+    const size_t cap_from = size_t{ 1 } << (cap_min ? std::min(40, std::max(0, atoi(cap_min))) : 25);
+    if (h->small_footprint >= 2 && call_symbols >= cap_from) {
         if (h->constellation == 0) launch(k_costas_cap<0, 2>);
         else if (h->constellation == 1) launch(k_costas_cap<1, 2>);
         else launch(k_costas_cap<2, 2>);
-    } else if (h->small_footprint) {
+    } else if (h->small_footprint == 1) {
         if (h->constellation == 0) launch(k_costas<0, 2>);
         else if (h->constellation == 1) launch(k_costas<1, 2>);
         else launch(k_costas<2, 2>);

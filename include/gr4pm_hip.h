@@ -246,7 +246,9 @@ gr4pm_status gr4pm_costas_loop_set(gr4pm_costas_loop* h, double loop_bandwidth,
 /* same results either way.  on = 1: the kernel of _process / _process_ragged keeps to 62 VGPRs, on = 2: to 32 VGPRs
  * (what a SIMD has left beside two waves of the syncword correlator: the PLL's waves then run BESIDE a correlator
  * workgroup instead of keeping a compute unit from it) at the price of being slower by itself -- for callers that run
- * it next to a SyncwordDetection; gr4pm_packet_receiver and gr4pm_multichannel_receiver ask for 2 when pipelined */
+ * it next to a SyncwordDetection: the pipelined gr4pm_packet_receiver asks for 2.  Form 2 is only taken for calls of
+ * 2^25 symbols and more: a PLL wave lives for one packet's chain however small the call, so below that the receiver
+ * waits for the kernel's own speed (gr4pm_multichannel_receiver keeps form 0: measured) */
 gr4pm_status gr4pm_costas_loop_set_small_footprint(gr4pm_costas_loop* h, int on);
 gr4pm_status gr4pm_costas_loop_process(gr4pm_costas_loop* h, const gr4pm_c64* in, size_t stride,
                                        size_t n, gr4pm_c64* out, const gr4pm_tag* tags,

@@ -2574,15 +2574,18 @@ def test_burst_generator_loopback(pkg):
     assert got == payloads
 
 
-@pytest.mark.parametrize("tool,cases", [("fuzz_detector.py", 8), ("fuzz_cfc_symf.py", 6), ("fuzz_costas.py", 9)])
-def test_randomised_differential_tools(tool, cases):
+@pytest.mark.parametrize("tool,cases,env", [("fuzz_detector.py", 8, {}), ("fuzz_cfc_symf.py", 6, {}), ("fuzz_costas.py", 9, {}),
+                                            ("fuzz_costas.py", 9, {"GR4PM_COSTAS_FORM": "1"}),
+                                            ("fuzz_costas.py", 12, {"GR4PM_COSTAS_FORM": "2", "GR4PM_COSTAS_CAP_MIN_LOG2": "0"})])
+def test_randomised_differential_tools(tool, cases, env):
     """a few cases of every randomised differential test under tools/ (random settings, tags, chunkings against the
-    oracle; the long runs are quoted in HISTORY.md section 2)"""
+    oracle; the long runs are quoted in HISTORY.md section 2).  GR4PM_COSTAS_FORM: the PLL kernel's 62-VGPR form and the
+    32-VGPR form the pipelined receivers run -- the same bits."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", tool), str(cases), "12345"], capture_output=True,
-                       text=True, timeout=600)
+                       text=True, timeout=600, env=dict(os.environ, **env))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert f"{cases} of {cases} cases agree" in r.stdout
 
