@@ -34,12 +34,14 @@
 
 #include <algorithm>
 #include <cctype>
+#include <chrono>
 #include <cstdio>
 #include <complex>
 #include <cstdlib>
 #include <fstream>
 #include <limits>
 #include <map>
+#include <condition_variable>
 #include <mutex>
 #include <sstream>
 #include <string>
@@ -93,14 +95,23 @@ inline size_t max_items()
 // fall back to).  An integrator that runs wrapped blocks with host_output = false over such buffers registers every
 // buffer once with add_mirrored_ring(base, bytes); addresses inside [base, base + 2 bytes) are then compared modulo the
 // ring.  Without a registration addresses are compared as they are (single-mapped buffers, the test stand-in).
-// Threads: lookups are serialised by a mutex, but a consumer USES the producer's device buffer after the lookup; the
-// producer's next processBulk() may reuse that buffer.  host_output = false therefore assumes that producer and
-// consumer of one edge do not run concurrently (a single-threaded scheduler, or one worker for the wrapped chain).
+//
+// Threads (round 4).  The two ends of an edge may run concurrently (the reference's multi-threaded schedulers,
+// benchmarks/README.md:8-26): a producer's next processBulk() then starts while the consumer is still reading the
+// device copy of the span before.  Hence a producer owns a small POOL of device buffers, a consumer PINS the registration
+// it reads (find() ... release()), and a producer never overwrites a buffer that is pinned: it takes another buffer of
+// its pool (fully consumed or never published first, then a new one up to kMaxPool, then -- after a grace period for the
+// reader -- the oldest unpinned one, whose unconsumed rest is written back to the host span so that the consumer falls
+// back to H2D; only if every buffer is pinned it waits for a release).  Everything under one mutex; the copies of a write-back run inside it.
 class Arena
 {
 public:
+    static constexpr int kMaxPool = 16; // spans a producer can be ahead of its reader: port buffer size / smallest span
     struct Seg {
         const void* owner;
+        int buf;          // index in the owner's pool
+        uint64_t id;
+        int users;        // consumers reading dev right now
         const char* host; // canonical (first-mapping) address of the first byte
         char* dev;
         size_t bytes, consumed;
@@ -118,17 +129,41 @@ public:
         std::lock_guard<std::mutex> g(_m);
         _rings.push_back({ static_cast<const char*>(base), bytes });
     }
-    // consumer side: device address of [host, host + bytes) if a producer left it here
-    const void* find(const void* host, size_t bytes)
+    // consumer side: device address of [host, host + bytes) if a producer left it here; the registration stays pinned
+    // (its buffer is not reused) until release(*pin)
+    const void* find(const void* host, size_t bytes, uint64_t* pin)
     {
         std::lock_guard<std::mutex> g(_m);
         size_t ring = 0;
         const char* h = canonical(static_cast<const char*>(host), &ring);
         for (auto& s : _segs) {
             const ptrdiff_t off = offset_in(s, h, bytes, ring);
-            if (off >= 0) return s.dev + off;
+            if (off >= 0) {
+                ++s.users;
+                ++_hits;
+                *pin = s.id;
+                return s.dev + off;
+            }
         }
+        ++_misses;
+        *pin = 0;
         return nullptr;
+    }
+    void release(uint64_t pin)
+    {
+        if (pin == 0) return;
+        {
+            std::lock_guard<std::mutex> g(_m);
+            for (auto* list : { &_segs, &_zombies })
+                for (size_t i = 0; i < list->size(); ++i)
+                    if ((*list)[i].id == pin) {
+                        --(*list)[i].users;
+                        if (list == &_zombies && (*list)[i].users <= 0) list->erase(list->begin() + static_cast<ptrdiff_t>(i));
+                        goto done;
+                    }
+        }
+    done:
+        _cv.notify_all();
     }
     void consumed(const void* host, size_t bytes)
     {
@@ -139,6 +174,7 @@ public:
             const ptrdiff_t off = offset_in(s, h, bytes, ring);
             if (off >= 0) s.consumed = std::max(s.consumed, static_cast<size_t>(off) + bytes);
         }
+        _cv.notify_all();
     }
     // write back what the host does not hold yet of every registration that overlaps [host, host + bytes)
     void flush(const void* host, size_t bytes)
@@ -152,13 +188,96 @@ public:
                 s.on_host = true;
             }
     }
-    // producer side: forget this producer's previous span; what nobody consumed and the host does not hold
-    // yet is written back first (the device buffer is about to be reused)
-    void retire(const void* owner)
+    // producer side: which buffer of its pool (`n_bufs` of them so far, the last one used was `cur`) the owner may
+    // overwrite now; n_bufs = "add a buffer".  The registration of the chosen buffer is retired: what nobody consumed and
+    // the host does not hold yet is written back first.
+    int acquire(const void* owner, int n_bufs, int cur)
     {
+        std::unique_lock<std::mutex> g(_m);
+        bool waited = false;
+        for (;;) {
+            int oldest_unpinned = -1;
+            uint64_t oldest_id = ~uint64_t{ 0 };
+            for (int k = 1; k <= n_bufs; ++k) {
+                const int b = (cur + k) % n_bufs;
+                bool pinned = false, pending = false;
+                uint64_t id = 0;
+                for (const auto* list : { &_segs, &_zombies })
+                    for (const auto& s : *list)
+                        if (s.owner == owner && s.buf == b) {
+                            pinned = pinned || s.users > 0;
+                            pending = pending || (list == &_segs && !s.on_host && s.consumed < s.bytes);
+                            id = std::max(id, s.id);
+                        }
+                if (pinned) continue;
+                if (!pending) {
+                    retire_locked(owner, b);
+                    return b;
+                }
+                if (id < oldest_id) oldest_id = id, oldest_unpinned = b;
+            }
+            if (n_bufs < kMaxPool) return n_bufs;
+            // every buffer holds a span that has not been read to its end.  Evicting the oldest would take away exactly
+            // what the reader needs next, so give the reader a moment first (release() and consumed() wake this up); a
+            // reader that is not a wrapped block never reports anything: after the grace period the oldest span goes to
+            // the host
+            if (!waited && _cv.wait_for(g, std::chrono::milliseconds(2)) == std::cv_status::no_timeout) continue;
+            waited = true;
+            if (oldest_unpinned >= 0) {
+                retire_locked(owner, oldest_unpinned);
+                return oldest_unpinned;
+            }
+            _cv.wait(g); // every buffer is being read: until a consumer lets go
+        }
+    }
+    // the owner goes away (or frees a buffer): forget its registrations (unconsumed data is written back first)
+    void retire(const void* owner, int buf = -1)
+    {
+        std::unique_lock<std::mutex> g(_m);
+        // a buffer that is still being read is not freed under its reader
+        _cv.wait(g, [&] {
+            for (const auto* list : { &_segs, &_zombies })
+                for (const auto& s : *list)
+                    if (s.owner == owner && (buf < 0 || s.buf == buf) && s.users > 0) return false;
+            return true;
+        });
+        retire_locked(owner, buf);
+    }
+    void publish(const void* owner, int buf, const void* host, void* dev, size_t bytes, bool on_host)
+    {
+        if (bytes == 0) return;
         std::lock_guard<std::mutex> g(_m);
+        size_t ring = 0;
+        const char* raw = static_cast<const char*>(host);
+        const char* h = canonical(raw, &ring);
+        // a new span over the same host memory supersedes whatever was registered there (the port buffer hands a region
+        // out for writing only after its readers are through with it; a reader that is not keeps its buffer pinned)
+        // -- and the part of an older span that the new one does NOT cover may still be unread (a producer a whole ring
+        // ahead overwrites the head of a span whose tail the consumer has yet to see): it goes to the host span first
+        for (size_t i = 0; i < _segs.size();)
+            if (overlaps(_segs[i], h, bytes, ring)) {
+                const Seg o = _segs[i];
+                if (!o.on_host && o.consumed < o.bytes)
+                    check_hip(hipMemcpy(const_cast<char*>(o.raw) + o.consumed, o.dev + o.consumed, o.bytes - o.consumed,
+                                        hipMemcpyDeviceToHost),
+                              "arena write-back (superseded span)");
+                if (o.users > 0) _zombies.push_back(o);
+                _segs.erase(_segs.begin() + static_cast<ptrdiff_t>(i));
+            } else {
+                ++i;
+            }
+        _segs.push_back({ owner, buf, ++_next_id, 0, h, static_cast<char*>(dev), bytes, 0, on_host, ring, raw });
+    }
+
+private:
+    struct Ring {
+        const char* base;
+        size_t bytes;
+    };
+    void retire_locked(const void* owner, int buf)
+    {
         for (size_t i = 0; i < _segs.size();) {
-            if (_segs[i].owner == owner) {
+            if (_segs[i].owner == owner && (buf < 0 || _segs[i].buf == buf)) {
                 const Seg s = _segs[i];
                 if (!s.on_host && s.consumed < s.bytes)
                     check_hip(hipMemcpy(const_cast<char*>(s.raw) + s.consumed, s.dev + s.consumed,
@@ -170,27 +289,6 @@ public:
             }
         }
     }
-    void publish(const void* owner, const void* host, void* dev, size_t bytes, bool on_host)
-    {
-        if (bytes == 0) return;
-        std::lock_guard<std::mutex> g(_m);
-        size_t ring = 0;
-        const char* raw = static_cast<const char*>(host);
-        const char* h = canonical(raw, &ring);
-        // a new span over the same host memory supersedes whatever was registered there
-        for (size_t i = 0; i < _segs.size();)
-            if (overlaps(_segs[i], h, bytes, ring))
-                _segs.erase(_segs.begin() + static_cast<ptrdiff_t>(i));
-            else
-                ++i;
-        _segs.push_back({ owner, h, static_cast<char*>(dev), bytes, 0, on_host, ring, raw });
-    }
-
-private:
-    struct Ring {
-        const char* base;
-        size_t bytes;
-    };
     // first-mapping address of h and the size of its ring (0: not inside a registered ring)
     const char* canonical(const char* h, size_t* ring) const
     {
@@ -220,44 +318,66 @@ private:
         return false;
     }
     std::mutex _m;
-    std::vector<Seg> _segs;
+    std::condition_variable _cv;
+    std::vector<Seg> _segs, _zombies; // zombies: superseded while a consumer was still reading them
     std::vector<Ring> _rings;
+    uint64_t _next_id = 0;
+    size_t _hits = 0, _misses = 0;
+
+public:
+    // how many input spans were found on the device / had to be uploaded (tests, tuning)
+    std::pair<size_t, size_t> lookups()
+    {
+        std::lock_guard<std::mutex> g(_m);
+        return { _hits, _misses };
+    }
 };
 
-// device staging buffer that grows on demand
+// device staging: the input side uploads into one buffer that grows on demand (or reads a producer's device copy);
+// the output side rotates through a small pool so that a consumer in another thread can still read the span before
 template <typename T>
 struct DeviceStage {
-    T* p = nullptr;
-    size_t n = 0;
+    struct Buf {
+        T* p = nullptr;
+        size_t n = 0;
+    };
+    std::vector<Buf> bufs{ Buf{} };
+    int cur = 0;
+    uint64_t pin = 0; // the producer registration this stage is reading (input side)
     DeviceStage() = default;
     DeviceStage(const DeviceStage&) = delete;
     DeviceStage& operator=(const DeviceStage&) = delete;
     ~DeviceStage()
     {
         try {
+            Arena::instance().release(pin);
             Arena::instance().retire(this);
         } catch (...) {
         }
-        if (p) (void)hipFree(p);
+        for (auto& b : bufs)
+            if (b.p) (void)hipFree(b.p);
     }
-    T* get(size_t count)
+    T* get(size_t count) // the current buffer, at least `count` items (its registration has been retired)
     {
-        if (count > n) {
-            Arena::instance().retire(this);
-            if (p) check_hip(hipFree(p), "hipFree");
-            p = nullptr;
-            check_hip(hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T)), "hipMalloc");
-            n = count;
+        Buf& b = bufs[static_cast<size_t>(cur)];
+        if (count > b.n) {
+            if (b.p) check_hip(hipFree(b.p), "hipFree");
+            b.p = nullptr;
+            b.n = 0;
+            check_hip(hipMalloc(reinterpret_cast<void**>(&b.p), std::max<size_t>(count, 1) * sizeof(T)), "hipMalloc");
+            b.n = count;
         }
-        return p;
+        return b.p;
     }
     // input of a block: the producer's device copy if the span was published by a wrapped block, else H2D
     template <typename H>
     const T* in(const H* host, size_t count)
     {
         static_assert(sizeof(H) == sizeof(T));
+        Arena::instance().release(pin); // the span of the call before
+        pin = 0;
         if (count == 0) return get(1);
-        if (const void* d = Arena::instance().find(host, count * sizeof(T))) {
+        if (const void* d = Arena::instance().find(host, count * sizeof(T), &pin)) {
             if (std::getenv("GR4PM_GR4_DEBUG")) std::fprintf(stderr, "arena hit  %p %zu\n", static_cast<const void*>(host), count);
             return static_cast<const T*>(d);
         }
@@ -268,10 +388,12 @@ struct DeviceStage {
         check_hip(hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice), "hipMemcpy H2D");
         return d;
     }
-    // buffer for `count` output items (the previous output span is retired first)
+    // buffer for `count` output items: one of the pool that no consumer is reading
     T* out(size_t count)
     {
-        Arena::instance().retire(this);
+        const int b = Arena::instance().acquire(this, static_cast<int>(bufs.size()), cur);
+        if (b == static_cast<int>(bufs.size())) bufs.push_back(Buf{});
+        cur = b;
         return get(count);
     }
     // `count` items of the output buffer become the host span [host, host + count)
@@ -280,8 +402,15 @@ struct DeviceStage {
     {
         static_assert(sizeof(H) == sizeof(T));
         if (count == 0) return;
+        T* p = bufs[static_cast<size_t>(cur)].p;
         if (host_output) check_hip(hipMemcpy(host, p, count * sizeof(T), hipMemcpyDeviceToHost), "hipMemcpy D2H");
-        Arena::instance().publish(this, host, p, count * sizeof(T), host_output);
+        Arena::instance().publish(this, cur, host, p, count * sizeof(T), host_output);
+    }
+    // the input span of this call has been used (its device copy may go)
+    void done()
+    {
+        Arena::instance().release(pin);
+        pin = 0;
     }
 };
 inline void consumed(const void* host, size_t bytes) { Arena::instance().consumed(host, bytes); }
@@ -397,6 +526,7 @@ public:
                       "SyncwordDetection::processBulk");
         _dout.publish(std::to_address(outSpan.begin()), n_done, host_output);
         detail::consumed(hin, n_done * sizeof(c64));
+        _din.done();
         for (size_t i = 0; i < n_tags; ++i)
             out.publishTag(detail::to_map(_tags[i]), static_cast<ssize_t>(_tags[i].index)); // :321-324
         if (!inSpan.consume(n_done)) throw gr::exception("consume failed"); // :346-348
@@ -442,6 +572,7 @@ public:
         detail::check(gr4pm_rotator_process(_h, din, n, n, dout, nullptr, nullptr, 0), "Rotator");
         _dout.publish(std::to_address(outSpan.begin()), n, host_output);
         detail::consumed(hin, n * sizeof(c64));
+        _din.done();
         if (!inSpan.consume(n)) throw gr::exception("consume failed");
         outSpan.publish(n);
         GR4PM_TRACE_EXIT(n, n);
@@ -493,6 +624,7 @@ public:
         detail::check(gr4pm_rotator_process(_h, din, n, n, dout, &tag, nullptr, n_tags), "CoarseFrequencyCorrection");
         _dout.publish(std::to_address(outSpan.begin()), n, host_output);
         detail::consumed(hin, n * sizeof(c64));
+        _din.done();
         if (!inSpan.consume(n)) throw gr::exception("consume failed");
         outSpan.publish(n);
         GR4PM_TRACE_EXIT(n, n);
@@ -569,6 +701,7 @@ public:
                       "SyncwordDetectionFilter::processBulk");
         _dout.publish(std::to_address(outSpan.begin()), consumed, host_output);
         detail::consumed(hin, consumed * sizeof(c64));
+        _din.done();
         gr::property_map output_tags; // :82-104
         if (out_flags & GR4PM_TAG_SYNCWORD) output_tags.insert(syncword_keys.begin(), syncword_keys.end());
         if (out_flags & GR4PM_TAG_OTHER) output_tags.insert(other_keys.begin(), other_keys.end());
@@ -654,6 +787,7 @@ public:
                       "SymbolFilter::processBulk");
         _dout.publish(std::to_address(outSpan.begin()), produced, host_output);
         detail::consumed(hin, consumed * sizeof(c64));
+        _din.done();
         for (size_t i = 0; i < n_out_tags; ++i) { // :218-228 re-timed tags, :152-155 adjusted phase
             auto node = _held.extract(_tags_out[i].freq_bin); // published once: the entry goes with it
             if (node.empty()) throw gr::exception("SymbolFilter: a published tag has no queued map");
@@ -731,6 +865,7 @@ public:
         detail::check(gr4pm_costas_loop_process(_h, din, n, n, dout, &tag, nullptr, n_tags), "CostasLoop::processBulk");
         _dout.publish(std::to_address(outSpan.begin()), n, host_output);
         detail::consumed(hin, n * sizeof(c64));
+        _din.done();
         if (!inSpan.consume(n)) throw gr::exception("consume failed");
         outSpan.publish(n);
         GR4PM_TRACE_EXIT(n, n);
@@ -781,6 +916,7 @@ public:
         detail::check(gr4pm_syncword_wipeoff_process(_h, din, n, dout, &tag, n_tags), "SyncwordWipeoff::processBulk");
         _dout.publish(std::to_address(outSpan.begin()), n, host_output);
         detail::consumed(hin, n * sizeof(c64));
+        _din.done();
         if (!inSpan.consume(n)) throw gr::exception("consume failed");
         outSpan.publish(n);
         GR4PM_TRACE_EXIT(n, n);
@@ -828,6 +964,7 @@ public:
         detail::check(gr4pm_interp_fir_process(_h, din, n, dout), "InterpolatingFirFilter::processBulk");
         _dout.publish(std::to_address(outSpan.begin()), n * interpolation, host_output);
         detail::consumed(hin, n * sizeof(c64));
+        _din.done();
         if (!inSpan.consume(n)) throw gr::exception("consume failed");
         outSpan.publish(n * interpolation);
         GR4PM_TRACE_EXIT(n, n * interpolation);
@@ -879,6 +1016,7 @@ public:
                       "PfbArbResampler::processBulk");
         _dout.publish(std::to_address(outSpan.begin()), produced, host_output);
         detail::consumed(hin, consumed * sizeof(c64));
+        _din.done();
         if (!inSpan.consume(consumed)) throw gr::exception("consume failed"); // :169-172
         outSpan.publish(produced);
         GR4PM_TRACE_EXIT(consumed, produced);
@@ -957,6 +1095,7 @@ public:
                       "PayloadMetadataInsert::processBulk");
         _dout.publish(std::to_address(outSpan.begin()), produced, host_output);
         detail::consumed(hin, consumed * sizeof(c64));
+        _din.done();
         size_t hdr = 0;
         for (size_t i = 0; i < n_out_tags; ++i) {
             const auto& t = _tags[i];
@@ -1037,6 +1176,7 @@ public:
                       "SyncwordRemove::processBulk");
         _dout.publish(std::to_address(outSpan.begin()), produced, host_output);
         detail::consumed(hin, n * sizeof(c64));
+        _din.done();
         if (n_out_tags) out.publishTag(this->mergedInputTag().map, static_cast<ssize_t>(tout[0].index)); // :59-62
         if (!inSpan.consume(n)) throw gr::exception("consume failed");
         outSpan.publish(produced);
@@ -1100,6 +1240,7 @@ public:
                       "ConstellationLLRDecoder::processBulk");
         _dout.publish(std::to_address(outSpan.begin()), produced, host_output);
         detail::consumed(hin, n * sizeof(c64));
+        _din.done();
         if (!inSpan.consume(n)) throw gr::exception("consume failed");
         outSpan.publish(produced);
         GR4PM_TRACE_EXIT(n, produced);
@@ -1148,6 +1289,7 @@ public:
                       "AdditiveScrambler::processBulk");
         _dout.publish(std::to_address(outSpan.begin()), n, host_output);
         detail::consumed(hin, n * sizeof(T));
+        _din.done();
         if (!inSpan.consume(n)) throw gr::exception("consume failed");
         outSpan.publish(n);
         GR4PM_TRACE_EXIT(n, n);
@@ -1216,6 +1358,7 @@ public:
         _dhdr.publish(std::to_address(headerSpan.begin()), nh, host_output);
         _dpay.publish(std::to_address(payloadSpan.begin()), np, host_output);
         detail::consumed(hin, n * sizeof(float));
+        _din.done();
         if (nht) header.publishTag(map, 0);
         if (npt) payload.publishTag(map, 0);
         if (!inSpan.consume(n)) throw gr::exception("consume failed");
@@ -1286,6 +1429,7 @@ public:
         detail::check(gr4pm_header_fec_decoder_process(_h, din, codewords, _bytes.data(), _invalid.data()),
                       "HeaderFecDecoder::processBulk");
         detail::consumed(hin, codewords * 256 * sizeof(float));
+        _din.done();
         std::copy(_bytes.begin(), _bytes.end(), outSpan.begin());
         for (size_t c = 0; c < codewords; ++c)
             if (_invalid[c]) out.publishTag({ { "invalid_header", pmtv::pmt_null() } }, static_cast<ssize_t>(4 * c)); // :322-326

@@ -1,3 +1,8 @@
+#include <mutex>
+#include <sys/mman.h>
+#include <unistd.h>
+#include <thread>
+#include <atomic>
 // Drives the GR4 block wrappers (gr4-packet-modem_amd/host/gr4pm_gr4_blocks.hpp) through processBulk()
 // the way the gnuradio4 scheduler would, against the test-only API stand-in tests/gr4_stub/.
 //
@@ -241,13 +246,118 @@ static int mirror(int argc, char** argv)
     return 0;
 }
 
+// The same double-mapped ring with the two ends of the edge in TWO THREADS (the reference's multi-threaded schedulers,
+// benchmarks/README.md:8-26): the producer runs ahead as far as the ring allows while the consumer is still inside the
+// spans before.  host_output = false and NaNs in the host ring: every consumer span has to come from a device buffer
+// the producer has not reused in the meantime (the arena's pool and pins), or from the write-back of a retired one.
+static int threads(int argc, char** argv)
+{
+    if (argc < 4) return 2;
+    const auto x = read_c64(argv[2]);
+    const std::string prefix = argv[3];
+    const size_t R = 8192; // ring size in items (64 KiB: whole pages)
+    // a REAL double mapping, as gnuradio4's CircularBuffer makes it (one memfd mapped twice, back to back): when the
+    // arena writes the unconsumed rest of a retired span back through the producer's address, the consumer sees it
+    // through the other mapping
+    const int fd = memfd_create("gr4pm_ring", 0);
+    if (fd < 0 || ftruncate(fd, static_cast<off_t>(R * sizeof(c64))) != 0) throw std::runtime_error("memfd");
+    char* base = static_cast<char*>(mmap(nullptr, 2 * R * sizeof(c64), PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0));
+    if (base == MAP_FAILED) throw std::runtime_error("mmap reserve");
+    for (int k = 0; k < 2; ++k)
+        if (mmap(base + k * R * sizeof(c64), R * sizeof(c64), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_FIXED, fd, 0) == MAP_FAILED)
+            throw std::runtime_error("mmap ring");
+    c64* ring_p = reinterpret_cast<c64*>(base);
+    for (size_t i = 0; i < R; ++i) ring_p[i] = c64{ std::nanf(""), std::nanf("") };
+    struct RingView {
+        c64* p;
+        c64* data() const { return p; }
+    } ring{ ring_p };
+    gr::packet_modem::hip::detail::Arena::instance().add_mirrored_ring(ring.data(), R * sizeof(c64));
+    gr::stub::Graph fg;
+    auto& a = fg.emplaceBlock<Rotator<>>({ { "phase_incr", 0.1f } });
+    auto& b = fg.emplaceBlock<Rotator<>>({ { "phase_incr", -0.03f } });
+    a.host_output = false;
+    b.host_output = true;
+    a.start();
+    b.start();
+    std::vector<c64> out(x.size());
+    std::atomic<size_t> w{ 0 }, r{ 0 }; // items written to / read from the ring
+    std::mutex m;
+    std::vector<std::pair<size_t, size_t>> spans; // producer spans, for the consumer to stay inside one
+    std::atomic<bool> failed{ false };
+    size_t ahead_max = 0;
+    std::thread producer([&] {
+        try {
+            const size_t chunk[4] = { 1500, 2900, 777, 2048 };
+            size_t in_pos = 0, k = 0;
+            while (in_pos < x.size() && !failed) {
+                const size_t room = R - (w.load() - r.load(std::memory_order_acquire));
+                const size_t np = std::min({ chunk[k % 4], x.size() - in_pos, room });
+                if (np == 0) {
+                    std::this_thread::yield();
+                    continue;
+                }
+                gr::InSpan<c64> is(x.data() + in_pos, np);
+                gr::OutSpan<c64> os(ring.data() + (w.load() % R), np);
+                if (a.processBulk(is, os) != gr::work::Status::OK) throw std::runtime_error("producer");
+                in_pos += is.consumed;
+                {
+                    std::lock_guard<std::mutex> g(m);
+                    spans.push_back({ w.load(), w.load() + os.published });
+                }
+                w.store(w.load() + os.published, std::memory_order_release);
+                ++k;
+            }
+        } catch (const std::exception& e) {
+            std::fprintf(stderr, "producer: %s\n", e.what());
+            failed = true;
+        }
+    });
+    try {
+        const size_t chunk[3] = { 640, 1111, 333 };
+        size_t o = 0, k = 0;
+        while (o < x.size() && !failed) {
+            const size_t wr = w.load(std::memory_order_acquire), rd = r.load();
+            if (rd == wr) {
+                std::this_thread::yield();
+                continue;
+            }
+            ahead_max = std::max(ahead_max, wr - rd);
+            size_t end = wr;
+            {
+                std::lock_guard<std::mutex> g(m);
+                for (const auto& sp : spans)
+                    if (rd >= sp.first && rd < sp.second) end = sp.second;
+            }
+            const size_t nc = std::min(chunk[k % 3], end - rd);
+            gr::InSpan<c64> is(ring.data() + (rd % R), nc);
+            gr::OutSpan<c64> os(out.data() + o, nc);
+            if (b.processBulk(is, os) != gr::work::Status::OK) throw std::runtime_error("consumer");
+            r.store(rd + is.consumed, std::memory_order_release);
+            o += os.published;
+            ++k;
+        }
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "consumer: %s\n", e.what());
+        failed = true;
+    }
+    producer.join();
+    if (failed) return 1;
+    dump(prefix + ".threads.c64", out.data(), out.size());
+    const auto lk = gr::packet_modem::hip::detail::Arena::instance().lookups();
+    std::printf("threads: %zu items through a %zu-item double-mapped ring, producer up to %zu items ahead, device hits %zu "
+                "uploads %zu\n", out.size(), R, ahead_max, lk.first, lk.second);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     try {
         if (argc >= 2 && std::strcmp(argv[1], "chain") == 0) return chain(argc, argv);
         if (argc >= 2 && std::strcmp(argv[1], "blocks") == 0) return blocks(argc, argv);
         if (argc >= 2 && std::strcmp(argv[1], "mirror") == 0) return mirror(argc, argv);
-        std::fprintf(stderr, "usage: %s chain|blocks|mirror ...\n", argv[0]);
+        if (argc >= 2 && std::strcmp(argv[1], "threads") == 0) return threads(argc, argv);
+        std::fprintf(stderr, "usage: %s chain|blocks|mirror|threads ...\n", argv[0]);
         return 2;
     } catch (const std::exception& e) {
         std::fprintf(stderr, "gr4_blocks_driver: %s\n", e.what());

@@ -215,6 +215,35 @@ def test_device_arena_over_a_double_mapped_ring(tmp_path):
     assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
 
 
+@pytest.mark.gpu
+def test_device_arena_with_the_two_ends_of_an_edge_in_two_threads(tmp_path):
+    """The reference's multi-threaded schedulers (benchmarks/README.md:8-26) run producer and consumer of an edge
+    concurrently.  Two wrapped Rotators in two threads over a double-mapped ring, host_output = false between them and
+    NaNs in the ring's host memory: the producer runs up to a ring ahead while the consumer is still reading the spans
+    before, so every consumer span must come from a device buffer that has not been reused (the arena's buffer pool
+    and pins; round 3's single staging buffer was overwritten under the reader).  Ten runs, bit-identical each."""
+    ge.build_gr4_driver()
+    rng = np.random.default_rng(9)
+    n = 300000
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    xin = tmp_path / "x.c64"
+    x.tofile(xin)
+    want = orc.rotator(orc.rotator(x, np.float32(0.1)), np.float32(-0.03))
+    ahead = 0
+    for run in range(10):
+        r = subprocess.run([DRIVER, "threads", str(xin), str(tmp_path / "t")], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        ahead = max(ahead, int(r.stdout.split("up to")[1].split()[0]))
+        hits, uploads = int(r.stdout.split("device hits")[1].split()[0]), int(r.stdout.split("uploads")[1].split()[0])
+        # uploads: the producer's own input spans (plain host memory) + the consumer spans whose device copy had been
+        # retired; most consumer spans must have come from the device
+        assert hits > 200 and uploads < hits, r.stdout
+        got = np.fromfile(str(tmp_path / "t.threads.c64"), dtype=np.complex64)
+        assert not np.isnan(got.view(np.float32)).any(), run
+        assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), run
+    assert ahead > 2900  # the producer really was more than one of its spans ahead of the reader
+
+
 # ------------------------------------------------------------------ the stand-in checked in the other direction
 REFERENCE_INCLUDE = "/root/reference/blocks/include"
 
