@@ -16,7 +16,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch --
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 3 --warmup 1 $COMMON --no-pipeline --no-lookahead > /dev/null 2>&1
 cd $R
 python3 tools/pmc_other_kernels.py $O/pmc_fetch $O/pmc_write $O/kernels_hbm_traffic.json > /dev/null
-for m in pipe one; do cp $(find $O/stats_$m -name "*kernel_stats.csv" | head -1) $O/kernel_stats_$m.csv; done
+for m in pipe one; do cp $(ls -t $(find $O/stats_$m -name "*kernel_stats.csv") | head -1) $O/kernel_stats_$m.csv; done
 bash tools/pmc_correlate.sh r4_final/pmc_corr9 67108864 4 > $O/pmc_corr9.log 2>&1
 bash tools/pmc_correlate.sh r4_final/pmc_corr1 67108864 0 > $O/pmc_corr1.log 2>&1
 { python3 tools/benchmark_syncword_detection.py 4 9.5 | tail -1; python3 tools/benchmark_syncword_detection.py 0 9.5 | tail -1;
