@@ -141,6 +141,7 @@ public:
             if (off >= 0) {
                 ++s.users;
                 ++_hits;
+                if (std::find(_read_owners.begin(), _read_owners.end(), s.owner) == _read_owners.end()) _read_owners.push_back(s.owner);
                 *pin = s.id;
                 return s.dev + off;
             }
@@ -218,10 +219,12 @@ public:
             }
             if (n_bufs < kMaxPool) return n_bufs;
             // every buffer holds a span that has not been read to its end.  Evicting the oldest would take away exactly
-            // what the reader needs next, so give the reader a moment first (release() and consumed() wake this up); a
-            // reader that is not a wrapped block never reports anything: after the grace period the oldest span goes to
-            // the host
-            if (!waited && _cv.wait_for(g, std::chrono::milliseconds(2)) == std::cv_status::no_timeout) continue;
+            // what the reader needs next, so give the reader a moment first (release() and consumed() wake this up) --
+            // if this producer's spans have ever been read from the device at all: a reader that is not a wrapped block
+            // never reports anything, and its producer must not wait for it.  After the grace period the oldest span goes
+            // to the host
+            const bool has_reader = std::find(_read_owners.begin(), _read_owners.end(), owner) != _read_owners.end();
+            if (has_reader && !waited && _cv.wait_for(g, std::chrono::milliseconds(2)) == std::cv_status::no_timeout) continue;
             waited = true;
             if (oldest_unpinned >= 0) {
                 retire_locked(owner, oldest_unpinned);
@@ -242,6 +245,7 @@ public:
             return true;
         });
         retire_locked(owner, buf);
+        if (buf < 0) _read_owners.erase(std::remove(_read_owners.begin(), _read_owners.end(), owner), _read_owners.end());
     }
     void publish(const void* owner, int buf, const void* host, void* dev, size_t bytes, bool on_host)
     {
@@ -323,6 +327,7 @@ private:
     std::vector<Ring> _rings;
     uint64_t _next_id = 0;
     size_t _hits = 0, _misses = 0;
+    std::vector<const void*> _read_owners; // producers whose device copies a wrapped consumer has read
 
 public:
     // how many input spans were found on the device / had to be uploaded (tests, tuning)
