@@ -274,6 +274,44 @@ def test_one_bin_correlator_three_waves_per_simd_is_bit_identical(pkg, monkeypat
         assert a.size >= 2 and same_tags(a, b)
 
 
+def test_correlator_block_hand_out_does_not_change_a_bit(pkg, monkeypatch):
+    """k_correlate_w64 hands the blocks of a workgroup out through a counter in LDS (which wave computes which block
+    depends on timing): the powers are those of the fixed shares of rounds 1 - 3 (GR4PM_W64_VARIANT=131072), for 1, 3, 6
+    and 16 blocks per wave and workgroup and for persistent waves, nine bins and one, one channel and three, over two
+    calls with odd block counts -- bit for bit, tags included"""
+    locations = [100, 1000, 1250, 10000, 13721, 43124, 58000 - 64, 90011]
+    x, rrc = sig.qa_syncword_stream(100000, locations, 0.0, seed=31)
+    x = (x + sig.awgn(x.size, 0.2, 32)).astype(np.complex64)
+    for n_channels, bins in ((1, 4), (1, 0), (3, 4)):
+        xd = dev(np.stack([np.roll(x, 1000 * c) for c in range(n_channels)])) if n_channels > 1 else dev(x)
+        res = {}
+        for name, env in (("fixed", {"GR4PM_W64_VARIANT": "131072"}), ("1", {"GR4PM_W64_BLOCKS_PER_WAVE": "1"}),
+                          ("3", {"GR4PM_W64_BLOCKS_PER_WAVE": "3"}), ("default", {}),
+                          ("16", {"GR4PM_W64_BLOCKS_PER_WAVE": "16"}), ("persistent", {"GR4PM_W64_BLOCKS_PER_WAVE": "0"})):
+            for k in ("GR4PM_W64_VARIANT", "GR4PM_W64_BLOCKS_PER_WAVE"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            sd = pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -bins, bins, power_threshold=9.5, max_items=1 << 18,
+                                       n_channels=n_channels)
+            z, tags = [], []
+            for lo, hi in ((0, 160000), (160000 - 1600, 4 * 100000 - 3)):
+                piece = xd[..., lo:hi].contiguous()
+                st, o, t, n = sd.process_bulk(piece)
+                assert st == 0 and n > 0
+                z.append(host(sd.last_zpow(n)))
+                tags.append(t)
+            res[name] = (z, tags)
+        for name, (z, tags) in res.items():
+            for a, b in zip(res["fixed"][0], z):
+                assert a.size > 100000 and np.array_equal(bits(a), bits(b)), (n_channels, bins, name)
+            for a, b in zip(res["fixed"][1], tags):
+                if n_channels == 1:
+                    assert a.size >= 2 and same_tags(a, b), (bins, name)
+                else:
+                    assert all(same_tags(p, q) for p, q in zip(a, b)), (bins, name)
+
+
 @pytest.mark.parametrize("kind", ["wave", "pair"])
 def test_correlator_spin_timeout_is_reported(pkg, monkeypatch, kind):
     """the round-1 correlator kernels hand templates over through bounded spins: a spin that runs out raises the
