@@ -182,7 +182,7 @@ class PfbArbParams(C.Structure):
 
 # every symbol include/gr4pm_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
-    "gr4pm_last_error", "gr4pm_version", "gr4pm_device_count", "gr4pm_test_fail_allocations", "gr4pm_test_allocation_count", "gr4pm_set_deferred_sync", "gr4pm_sincosf", "gr4pm_costas_phase_wrap",
+    "gr4pm_last_error", "gr4pm_version", "gr4pm_device_count", "gr4pm_set_deferred_sync", "gr4pm_sincosf", "gr4pm_costas_phase_wrap",
     "gr4pm_packet_receiver_set_symbol_pdu_callback",
     "gr4pm_syncword_detection_create", "gr4pm_syncword_detection_destroy",
     "gr4pm_syncword_detection_reset", "gr4pm_syncword_detection_syncword_samples_size",
@@ -261,7 +261,7 @@ def lib():
     L.gr4pm_last_error.restype = C.c_char_p
     L.gr4pm_version.restype = C.c_char_p
     L.gr4pm_device_count.restype = C.c_int
-    if hasattr(L, "gr4pm_test_fail_allocations"):  # (absent from older builds loaded through GR4PM_LIB for A/B runs)
+    if hasattr(L, "gr4pm_test_fail_allocations"):  # (the test build only: libgr4pm_hip_test.so)
         L.gr4pm_test_fail_allocations.argtypes = [C.c_long, C.c_long]
         L.gr4pm_test_fail_allocations.restype = None
         L.gr4pm_test_allocation_count.restype = C.c_ulonglong

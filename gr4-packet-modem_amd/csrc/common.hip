@@ -40,10 +40,20 @@ gr4pm_status require_device()
 const char* experiment_env(const char* name, bool wrong_results)
 {
     const char* e = getenv(name);
+#ifdef GR4PM_EXPERIMENTS
     if (e && wrong_results)
         fprintf(stderr, "[gr4pm] WARNING: %s=%s is set: a timing experiment that leaves kernels out or replaces them -- "
                         "calls return GR4PM_OK with WRONG outputs\n", name, e);
     return e;
+#else
+    // the shipped library has no switch that changes results: the timing-only kernels and paths are compiled under
+    // -DGR4PM_EXPERIMENTS only (make EXPERIMENTS=1; tools/build_variant.sh)
+    if (e && wrong_results) {
+        fprintf(stderr, "[gr4pm] %s=%s ignored: timing experiments need a library built with EXPERIMENTS=1\n", name, e);
+        return nullptr;
+    }
+    return e;
+#endif
 }
 unsigned experiment_env_wg(const char* name, unsigned fallback, unsigned lo, unsigned hi)
 {
@@ -74,6 +84,10 @@ gr4pm_status exception_status(const char* where) noexcept
     }
 }
 
+#ifdef GR4PM_TEST_ALLOC_HOOK
+// Only in the TEST build of the library (libgr4pm_hip_test.so, `make test_lib`; tests/gr4pm_test_hooks.h): the
+// shipped library neither replaces operator new / delete nor exports these entry points, so it is indifferent to
+// the host application's allocator (a non-malloc operator new, an ASan host).
 // Test-only allocator hook (gr4pm_test_fail_allocations): the library's own operator new -- local to the library (csrc/exports.map), so it
 // serves exactly the allocations made by this library's code and nothing else in the process -- counts down and throws
 // std::bad_alloc for `count` allocations after letting `after` pass, then disarms itself.  One relaxed atomic load per
@@ -101,10 +115,11 @@ static inline void* hooked_alloc(std::size_t n)
     return std::malloc(n ? n : 1);
 }
 #endif
+#endif // GR4PM_TEST_ALLOC_HOOK
 
 } // namespace gr4pm
 
-#if !defined(__HIP_DEVICE_COMPILE__)
+#if defined(GR4PM_TEST_ALLOC_HOOK) && !defined(__HIP_DEVICE_COMPILE__)
 // (kept out of the dynamic symbol table by csrc/exports.map: the link makes everything but gr4pm_* local)
 #define GR4PM_HIDDEN
 GR4PM_HIDDEN void* operator new(std::size_t n)
@@ -131,6 +146,7 @@ GR4PM_HIDDEN void operator delete[](void* p, const std::nothrow_t&) noexcept { s
 
 extern "C" {
 
+#ifdef GR4PM_TEST_ALLOC_HOOK
 void gr4pm_test_fail_allocations(long after, long count)
 try {
     gr4pm::g_alloc_armed.store(false);
@@ -141,6 +157,7 @@ try {
 }
 GR4PM_ABI_CATCH_VOID
 unsigned long long gr4pm_test_allocation_count(void) { return gr4pm::g_alloc_calls.load(std::memory_order_relaxed); }
+#endif
 
 const char* gr4pm_last_error(void) { return gr4pm::g_error; }
 

@@ -235,7 +235,10 @@ __global__ __launch_bounds__(kW64Threads, 2) void k_correlate_w64(const cf* __re
     // the next item of this workgroup that no wave has taken yet (see `dynamic` below) lives in a pad word of the
     // exchange rows (row 0 of wave 0; only the LDS-DMA template variants ever write there, and they keep fixed shares):
     // one more byte of LDS would cost the kernels that run beside this one their place on the CU
-    uint32_t* const wg_next = reinterpret_cast<uint32_t*>(lds4 + kW64TwFloat4) + 128;
+    constexpr int kWgNextDword = 128;
+    static_assert(kWgNextDword >= 2 * 64 && kWgNextDword < kW64Row,
+                  "the hand-out counter must sit in the pad behind re[64] | im[64] of exchange row 0");
+    uint32_t* const wg_next = reinterpret_cast<uint32_t*>(lds4 + kW64TwFloat4) + kWgNextDword;
     constexpr bool kDynamic = (VAR & 32768) != 0 && (VAR & 131072) == 0;
     if (kDynamic && tid == 0) *wg_next = blockIdx.x * kW64Waves * blocks_per_wave + kW64Waves;
     __syncthreads(); // the only workgroup-wide synchronisation of the kernel

@@ -259,6 +259,7 @@ struct gr4pm_packet_receiver {
     // forms of the receiver then cut the symbol stream differently around a pending header; tools/stress_receiver.py)
     uint64_t stage1_started = 0, stage1_earlier = 0;
     uint64_t stage1b_done = 0;
+    bool stage1b_abort = false; // destroy(): nobody waits for stage 1b any more
     std::mutex stage1b_mutex;
     std::condition_variable stage1b_cv;
     // ---- decode_headers: stage 2 thread ----
@@ -690,7 +691,11 @@ gr4pm_status gr4pm_packet_receiver::stage1_decode(Slot& s, const gr4pm_c64* y)
             pending_real = false;
             {   // (rare: a detection within the last ~850 items of the batch before) stage 1b is done with every earlier batch
                 std::unique_lock<std::mutex> w(stage1b_mutex);
-                stage1b_cv.wait(w, [&] { return stage1b_done >= earlier; });
+                stage1b_cv.wait(w, [&] { return stage1b_done >= earlier || stage1b_abort; });
+                if (stage1b_done < earlier) {
+                    set_error("packet receiver: shut down while a pending header waited for the symbol filter stage");
+                    return GR4PM_ERR_INVALID;
+                }
             }
             bool patched = false;
             std::lock_guard<std::mutex> lk(s1_fifo_mutex);
@@ -1160,11 +1165,27 @@ GR4PM_ABI_CATCH
 void gr4pm_packet_receiver_destroy(gr4pm_packet_receiver* h)
 try {
     if (!h) return;
-    // every queue is told to stop (a stage whose predecessor never started would not see a forwarded end);
-    // batches still queued are delivered first, so the stages drain in order
-    for (SlotRing* q : { &h->to_stageA, &h->to_stage1, &h->to_stage1b, &h->to_stage2, &h->to_stage3 }) q->stop();
-    for (int w : { 4, 0, 3, 1, 2 })
-        if (h->workers[w].joinable()) h->workers[w].join();
+    // Only the head of the chain is told to stop: run_stage hands the end on behind the batches still queued, so every
+    // stage sees its predecessors' deliveries first (an idle stage 1b that stopped at once would leave stage 1 waiting
+    // for a batch stage 1b never counts).  A stage whose predecessor's thread never started (create failed half way)
+    // would not see a forwarded end: its queue is stopped here.
+    {
+        SlotRing* const queues[5] = { &h->to_stageA, &h->to_stage1, &h->to_stage1b, &h->to_stage2, &h->to_stage3 };
+        const int order[5] = { 4, 0, 3, 1, 2 }; // worker index of the stage reading queues[k]
+        for (int k = 0; k < 5; ++k)
+            if (k == 0 || !h->workers[order[k - 1]].joinable()) queues[k]->stop();
+        for (int k = 0; k < 5; ++k) {
+            if (!h->workers[order[k]].joinable()) continue;
+            h->workers[order[k]].join();
+            if (order[k] == 3) { // stage 1b is gone: release whoever might still wait for it (belt and braces)
+                {
+                    std::lock_guard<std::mutex> lk(h->stage1b_mutex);
+                    h->stage1b_abort = true;
+                }
+                h->stage1b_cv.notify_all();
+            }
+        }
+    }
     gr4pm_syncword_detection_destroy(h->sd);
     gr4pm_syncword_detection_filter_destroy(h->sdf);
     gr4pm_rotator_destroy(h->cfc);
@@ -1260,6 +1281,10 @@ try {
             h->stage3(s);
         });
         if (gs != GR4PM_OK) h->fail(s, gs);
+        {   // an exception between stage 1 and stage 1b must not leave the next pending-header batch waiting for it
+            std::lock_guard<std::mutex> lk(h->stage1b_mutex);
+            if (h->stage1b_done < h->stage1_started) h->stage1b_done = h->stage1_started;
+        }
         (void)h->done.push(i);
     }
     return GR4PM_OK;

@@ -35,6 +35,9 @@ namespace gr4pm {
 #ifndef GR4PM_ROT_PRIO
 #define GR4PM_ROT_PRIO GR4PM_SERIAL_PRIO // ... of k_rot_checkpoints, the one serial kernel that runs BESIDE correlator waves
 #endif
+#ifndef GR4PM_EXPERIMENTS
+static constexpr bool timing_skip(const char*) { return false; } // the shipped library leaves no kernel out
+#else
 static inline bool timing_skip(const char* name)
 {
     // comma-separated list, whole names ("symf" does not match "symf_fake"); read once, announced on stderr
@@ -45,6 +48,7 @@ static inline bool timing_skip(const char* name)
         if ((p == e || p[-1] == ',') && (p[n] == 0 || p[n] == ',')) return true;
     return false;
 }
+#endif
 namespace {
 
 struct cf {
@@ -1249,12 +1253,17 @@ __global__ __launch_bounds__(kFastThreads, 8) void k_symbol_filter_long(const cf
     if (2 * l + 1 < p.count) out[p.o0 + 2 * l + 1] = scale_item(p.scale, cf{ accB.x, accB.y });
 }
 // which (fused, item type, sps, arm size) combinations run it
+// (its tile: entries per phase row = the last symbol's entry at the top tap position, + 1 for symbol B; even)
+static unsigned symf_long_pitch(size_t arm_size) { return ((kFastSym + (static_cast<unsigned>(arm_size) - 1) / kFastSps + 2) + 1u) & ~1u; }
+static size_t symf_long_lds(size_t arm_size) { return static_cast<size_t>(kFastSps) * symf_long_pitch(arm_size) * sizeof(cf); }
 static bool symf_long(bool fused, bool cf_items, size_t sps, size_t arm_size)
 {
     static const bool off = getenv("GR4PM_SYMF_GENERIC") != nullptr;
-    return !fused && cf_items && sps == kFastSps && arm_size >= 64 && !off;
+    // arms whose tile does not fit the LDS (arm sizes beyond ~20 000) stay with the generic kernel
+    return !fused && cf_items && sps == kFastSps && arm_size >= 64 && symf_long_lds(arm_size) <= kFirMaxSmem && !off;
 }
 
+#ifdef GR4PM_EXPERIMENTS
 // GR4PM_TIMING_SKIP=symf_fake / costas_fake: timing experiments only.  Stand-ins with the memory traffic (symbol
 // filter) or the life time (Costas) of the kernel they replace and at most 32 VGPRs, no LDS: what would the chain
 // gain if the real kernel fitted beside two 240-VGPR correlator waves of every SIMD?
@@ -1278,6 +1287,7 @@ __global__ __launch_bounds__(64) void k_serial_fake(unsigned ticks, float* sink)
     }
     if (x == 12345.0f) *sink = x;
 }
+#endif
 
 // symbols per workgroup of the kernel that a (fused, sps, arm size) combination runs
 static bool symf_fast(bool fused, size_t sps, size_t arm_size)
@@ -1301,9 +1311,10 @@ static void launch_symbol_filter(hipStream_t s, unsigned n_wg, size_t smem, unsi
                        cfc, plan, chans, symf_per_wg(CFC, sps, arm_size, std::is_same<T, cf>::value));
     if constexpr (!CFC && std::is_same<T, cf>::value) {
         if (symf_long(false, true, sps, arm_size)) {
-            // entries per phase row: the last symbol's entry at the top tap position, + 1 for symbol B; even
-            const unsigned pitch = ((kFastSym + (arm_size - 1) / kFastSps + 2) + 1u) & ~1u;
-            const size_t lds = static_cast<size_t>(kFastSps) * pitch * sizeof(cf);
+            const unsigned pitch = symf_long_pitch(arm_size);
+            const size_t lds = symf_long_lds(arm_size);
+            // (a refusal stays in hipGetLastError(), which the caller reads behind its launches; the launch below is
+            // then refused too)
             if (lds > 48 * 1024)
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_symbol_filter_long),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
@@ -1314,9 +1325,12 @@ static void launch_symbol_filter(hipStream_t s, unsigned n_wg, size_t smem, unsi
     }
     if constexpr (CFC) {
         if (symf_fast(true, sps, arm_size)) {
+#ifdef GR4PM_EXPERIMENTS
             if (timing_skip("symf_fake"))
                 hipLaunchKernelGGL(k_symf_fake, grid, dim3(kFastThreads), 0, s, in, plan, out);
-            else if (!timing_skip("symf")) {
+            else
+#endif
+            if (!timing_skip("symf")) {
                 static const char* abl_e = gr4pm::experiment_env("GR4PM_SYMF_ABL", true);
                 static const int abl = abl_e ? atoi(abl_e) : 0;
                 static const unsigned pad = gr4pm::experiment_env_wg("GR4PM_SYMF_PAD", 0u, 0u, 64u * 1024u);
@@ -1983,6 +1997,7 @@ static gr4pm_status costas_process_impl(gr4pm_costas_loop* h, const gr4pm_c64* i
     CostasState* st_out = h->state.p + (h->st_cur ^ 1) * h->n_channels;
     h->st_cur ^= 1;
     auto launch = [&](auto kernel) {
+#ifdef GR4PM_EXPERIMENTS
         if (timing_skip("costas_fake")) { // GR4PM_FAKE=workgroups,ticks(10 ns),bytes of LDS
             unsigned wgs = grid.x, ticks = 83000u, lds = 0u;
             static const char* fake = gr4pm::experiment_env("GR4PM_FAKE", true);
@@ -1994,6 +2009,7 @@ static gr4pm_status costas_process_impl(gr4pm_costas_loop* h, const gr4pm_c64* i
             hipLaunchKernelGGL(k_serial_fake, dim3(wgs), block, lds, s, ticks, reinterpret_cast<float*>(st_out));
             return;
         }
+#endif
         if (timing_skip("costas")) return;
         hipLaunchKernelGGL(kernel, grid, block, 0, s, h->segs.p, n_segs, st_in, st_out, h->k1, h->k2,
                            reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(out), stride);

@@ -1770,7 +1770,10 @@ gr4pm_status launch_correlate(gr4pm_syncword_detection* h, hipStream_t stream, c
         case 5: GR4PM_C4096(5); break;
         case 6: GR4PM_C4096(6); break;
         case 7: GR4PM_C4096(7); break;
-        default: GR4PM_C4096(9); break; // (FMA-form butterflies: not bit-identical)
+#ifdef GR4PM_EXPERIMENTS
+        case 9: GR4PM_C4096(9); break; // (FMA-form butterflies: not bit-identical; announced at creation)
+#endif
+        default: GR4PM_C4096(1); break;
         }
 #undef GR4PM_C4096
         GR4PM_HIP_TRY(hipGetLastError());
@@ -1819,14 +1822,18 @@ gr4pm_status launch_correlate(gr4pm_syncword_detection* h, hipStream_t stream, c
     hipLaunchKernelGGL(k_correlate_w64_one<A>, dim3(wgs1), dim3(kW1Threads), 0, stream, reinterpret_cast<const cf*>(in), \
                        in_stride, n_blocks, total, static_cast<uint32_t>(h->S), h->tmpl64.p, h->tT64.p, h->cc64.p, zout, \
                        h->z_stride, bpw, h->noise_off - h->zc)
+#ifdef GR4PM_EXPERIMENTS
             if (one_mode == 2) GR4PM_W1_LAUNCH(1);
             else if (one_mode == 3) GR4PM_W1_LAUNCH(2);
-            else GR4PM_W1_LAUNCH(0);
+            else
+#endif
+                GR4PM_W1_LAUNCH(0);
 #undef GR4PM_W1_LAUNCH
             GR4PM_HIP_TRY(hipGetLastError());
             return GR4PM_OK;
         }
         switch (h->w64_variant) {
+#ifdef GR4PM_EXPERIMENTS // timing-only ablations (wrong powers): tools/build_variant.sh builds them, build() does not
         case 8: GR4PM_W64_LAUNCH(8); break;
         case 32: GR4PM_W64_LAUNCH(32); break;
         case 232: GR4PM_W64_LAUNCH(232); break;
@@ -1834,14 +1841,15 @@ gr4pm_status launch_correlate(gr4pm_syncword_detection* h, hipStream_t stream, c
         case 2048: GR4PM_W64_LAUNCH(2048); break;
         case 4096: GR4PM_W64_LAUNCH(4096); break;
         case 6144: GR4PM_W64_LAUNCH(6144); break;
+        case 100352: GR4PM_W64_LAUNCH(98304 + 16384 + 2048); break; // the default kernel without power stores
+        case 102400: GR4PM_W64_LAUNCH(98304 + 16384 + 4096); break; // ... without sample loads after the first block
+        case 104448: GR4PM_W64_LAUNCH(98304 + 16384 + 6144); break; // ... without either
+#endif
         case 0: // round 2's bin loop: everything (re, im) interleaved, templates by LDS-DMA into the exchange buffer
             if (prune) GR4PM_W64_LAUNCH(16384);
             else GR4PM_W64_LAUNCH(0);
             break;
         case 65536: GR4PM_W64_LAUNCH(65536 + 16384); break; // planar second half, templates still by LDS-DMA
-        case 100352: GR4PM_W64_LAUNCH(98304 + 16384 + 2048); break; // timing only: the default kernel without power stores
-        case 102400: GR4PM_W64_LAUNCH(98304 + 16384 + 4096); break; // ... without sample loads after the first block
-        case 104448: GR4PM_W64_LAUNCH(98304 + 16384 + 6144); break; // ... without either
         case 131072: GR4PM_W64_LAUNCH(98304 + 16384 + 131072); break; // A/B: fixed shares of blocks per wave (rounds 1 - 3), same results
         default:
             // planar mid stage / pass B / powers in the bin loop (65536), templates from global memory straight
@@ -2117,13 +2125,22 @@ try {
         h->corr_kind = k == "pair" ? 2 : k == "wave" ? 1 : 0;
         // the bit-identical variants (-1 default, 0 = round 2's bin loop, 65536 = planar loop with LDS-DMA templates,
         // GR4PM_W64_ONE=1) select silently; every other value is a timing-only ablation with wrong powers and says so
+        // (the library as build() makes it holds the bit-identical forms only: experiment_env(.., true) returns nullptr
+        // there and says that the switch was ignored; `make EXPERIMENTS=1` -- tools/build_variant.sh -- has the rest)
         const char* v = getenv("GR4PM_W64_VARIANT");
         h->w64_variant = v ? atoi(v) : -1;
-        if (v && h->w64_variant != -1 && h->w64_variant != 0 && h->w64_variant != 65536 && h->w64_variant != 131072) (void)experiment_env("GR4PM_W64_VARIANT", true);
-        if (const char* cv = getenv("GR4PM_C4096_VARIANT")) h->c4096_variant = atoi(cv) & 15;
+        if (v && h->w64_variant != -1 && h->w64_variant != 0 && h->w64_variant != 65536 && h->w64_variant != 131072 &&
+            !experiment_env("GR4PM_W64_VARIANT", true))
+            h->w64_variant = -1;
+        if (const char* cv = getenv("GR4PM_C4096_VARIANT")) {
+            const int c = atoi(cv);
+            if (c >= 0 && c <= 7) h->c4096_variant = c;
+            else if (c == 9 && experiment_env("GR4PM_C4096_VARIANT", true)) h->c4096_variant = 9;
+            else fprintf(stderr, "[gr4pm] GR4PM_C4096_VARIANT=%s is not one of 0 .. 7: using the default (1)\n", cv);
+        }
         const char* one = getenv("GR4PM_W64_ONE");
         h->w64_one = one ? atoi(one) : 0;
-        if (h->w64_one > 1) (void)experiment_env("GR4PM_W64_ONE", true);
+        if (h->w64_one > 1 && !experiment_env("GR4PM_W64_ONE", true)) h->w64_one = 1;
         if (const char* b = getenv("GR4PM_W64_BLOCKS_PER_WAVE")) h->w64_blocks_per_wave = static_cast<uint32_t>(std::max(0, atoi(b)));
         int dev = 0;
         hipDeviceProp_t prop;

@@ -198,6 +198,7 @@ public:
         bool waited = false;
         for (;;) {
             int oldest_unpinned = -1;
+            bool any_pinned = false;
             uint64_t oldest_id = ~uint64_t{ 0 };
             for (int k = 1; k <= n_bufs; ++k) {
                 const int b = (cur + k) % n_bufs;
@@ -210,6 +211,7 @@ public:
                             pending = pending || (list == &_segs && !s.on_host && s.consumed < s.bytes);
                             id = std::max(id, s.id);
                         }
+                any_pinned = any_pinned || pinned;
                 if (pinned) continue;
                 if (!pending) {
                     retire_locked(owner, b);
@@ -217,13 +219,17 @@ public:
                 }
                 if (id < oldest_id) oldest_id = id, oldest_unpinned = b;
             }
-            if (n_bufs < kMaxPool) return n_bufs;
+            // The pool grows only for a reader that reads from the device (a pinned buffer, or a wrapped block that has
+            // read this producer's spans before).  With a downstream that is not a wrapped block nothing is ever
+            // reported consumed: its producer keeps ONE buffer in turn and the oldest span goes to the host at once
+            // (sixteen device buffers per output and a write-back into already published port memory otherwise).
+            const bool has_reader = std::find(_read_owners.begin(), _read_owners.end(), owner) != _read_owners.end();
+            if (n_bufs == 0 || (n_bufs < kMaxPool && (any_pinned || has_reader))) return n_bufs;
             // every buffer holds a span that has not been read to its end.  Evicting the oldest would take away exactly
             // what the reader needs next, so give the reader a moment first (release() and consumed() wake this up) --
             // if this producer's spans have ever been read from the device at all: a reader that is not a wrapped block
             // never reports anything, and its producer must not wait for it.  After the grace period the oldest span goes
             // to the host
-            const bool has_reader = std::find(_read_owners.begin(), _read_owners.end(), owner) != _read_owners.end();
             if (has_reader && !waited && _cv.wait_for(g, std::chrono::milliseconds(2)) == std::cv_status::no_timeout) continue;
             waited = true;
             if (oldest_unpinned >= 0) {

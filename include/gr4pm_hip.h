@@ -51,13 +51,6 @@ const char* gr4pm_last_error(void);
 const char* gr4pm_version(void);
 /* Number of visible HIP devices (0 when none; does not create a context). */
 int gr4pm_device_count(void);
-/* Test-only fault injection (tests/test_abi_and_host.py, tests/test_gpu_parity.py): the library's own operator new
- * lets `after` allocations pass, fails the next `count` (std::bad_alloc) and disarms itself; after < 0 disarms.  Only
- * allocations made by this library's code are affected (the operator has hidden visibility).  What is being tested is
- * the first convention above: the failure must come back as GR4PM_ERR_NOMEM from the entry point -- or as the failed
- * batch's status when it strikes in one of a receiver's stage threads -- never as an exception or a std::terminate. */
-void gr4pm_test_fail_allocations(long after, long count);
-unsigned long long gr4pm_test_allocation_count(void);
 /* For native callers that chain several handles on ONE HIP stream without reading anything back in
  * between: while on (per calling thread), the process() calls that return nothing device-produced
  * to the host (symbol filter, wipe-off, Costas loop, PayloadMetadataInsert, SyncwordRemove, LLR

@@ -53,9 +53,15 @@ def test_every_abi_entry_point_has_an_exception_guard():
 
 
 def test_bad_alloc_inside_an_entry_point_comes_back_as_a_status(pkg):
-    """test-only allocator hook (gr4pm_test_fail_allocations): the std::vector inside the RRC design throws
-    std::bad_alloc; the entry point returns 0 taps and the error text instead of unwinding into the caller.  The hook
-    only sees the library's own allocations and disarms itself after the failure."""
+    """test-only allocator hook (gr4pm_test_fail_allocations, TEST build of the library only: tests/gr4pm_test_hooks.h):
+    the std::vector inside the RRC design throws std::bad_alloc; the entry point returns 0 taps and the error text
+    instead of unwinding into the caller.  The hook only sees the library's own allocations and disarms itself after
+    the failure.  The shipped library has neither the entry points nor an operator new of its own."""
+    shipped = subprocess.run(["nm", "-D", "--defined-only", pkg.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "gr4pm_test_" not in shipped and "_Znwm" not in shipped and not hasattr(pkg.lib(), "gr4pm_test_fail_allocations")
+    all_syms = subprocess.run(["nm", "--defined-only", pkg.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert " _Znwm" not in all_syms, "the shipped library must not replace operator new"
+    pkg = ge.load_test_build()
     L = pkg.lib()
     before = L.gr4pm_test_allocation_count()
     assert pkg.root_raised_cosine(1.0, 4.0, 1.0, 0.35, 65).size == 65

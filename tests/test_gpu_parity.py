@@ -2638,7 +2638,9 @@ def test_receivers_survive_allocation_failures(pkg, mode):
     batches, collect, destroy -- throw std::bad_alloc, for k swept over that life.  Whichever thread it strikes (the
     caller inside an entry point, or one of the receiver's stage threads): no exception, no std::terminate, no hang --
     the failure is an error status of the call or of the batch (Gr4pmError here), every batch in flight is still
-    collected, and a receiver created afterwards gives the undisturbed result bit for bit."""
+    collected, and a receiver created afterwards gives the undisturbed result bit for bit.
+    Runs on the TEST build of the library (libgr4pm_hip_test.so = the same objects + the hook)."""
+    pkg = ge.load_test_build()
     L = pkg.lib()
     n = 60000
     x, _, _ = _tx_packets(np.random.default_rng(5), [200] * 12, list(np.random.default_rng(6).integers(300, 2000, 12)))
@@ -2826,6 +2828,49 @@ def test_native_packet_receiver_decode_cut_just_behind_a_header(pkg):
             assert np.array_equal(w["packet_lengths"], g["packet_lengths"])
             assert np.array_equal(w["packets"].cpu().numpy(), g["packets"].cpu().numpy())
             pos += g["consumed"]
+
+
+_DESTROY_IN_FLIGHT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import __graft_entry__ as ge
+pkg = ge.load_package()
+rng = np.random.default_rng(77)
+payloads = [rng.integers(0, 256, int(n)).astype(np.uint8).tobytes() for n in (300, 257, 411, 120)]
+x = pkg.BurstGenerator().stream(payloads, [3000, 2500, 2000, 2200], freq_error=0.006, esn0_db=20.0, seed=78)
+x = torch.cat([x, torch.zeros(8000, dtype=x.dtype, device=x.device)])
+one = pkg.NativePacketReceiver(max_items=x.numel(), tags_cap=256, decode_headers=True)
+tag = int(one.process_bulk(x)["detector_tags"]["index"][1]) - 1537
+del one
+n = 0
+for pipelined in (True, False):
+    for shift in range(0, 1752, 24):
+        xs = torch.cat([torch.zeros(shift, dtype=x.dtype, device=x.device), x])
+        first = 2048 + ((tag + shift + 1537 + 700 + 1751) // 1752 - 1) * 1752
+        rx = pkg.NativePacketReceiver(max_items=xs.numel(), tags_cap=256, decode_headers=True, pipelined=pipelined)
+        rx.submit(xs[:first])
+        rx.submit(xs[first - 296:])       # (whole strides of the first call: 2048 + k 1752 -> consumed (k + 1) 1752)
+        if pipelined and shift % 48 == 0:
+            rx.submit(xs[first - 296:])   # a third batch queued behind them
+        del rx                             # destroy with everything in flight, nothing collected
+        n += 1
+print("destroyed", n)
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_native_packet_receiver_destroy_with_batches_in_flight():
+    """gr4pm_packet_receiver_destroy with batches queued between the stage threads, decode_headers, and a pending header
+    (a detection in the last ~850 items of the first batch: stage 1 of the second batch waits for stage 1b to be done
+    with the first).  Round 4's destroy() stopped every stage queue at once: an idle stage 1b left, stage 1 waited for
+    it for ever and join() never returned.  Now only the head of the chain is stopped and the end travels behind the
+    queued batches.  Every cut over a detector stride, pipelined and not, in a child process (a hang is a timeout)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _DESTROY_IN_FLIGHT, root], capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0 and "destroyed 146" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
 
 
 @pytest.mark.gpu

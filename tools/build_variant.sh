@@ -9,7 +9,7 @@ mkdir -p $T/gr4-packet-modem_amd $T/include
 cp -r $ROOT/gr4-packet-modem_amd/csrc $T/gr4-packet-modem_amd/csrc
 cp $ROOT/include/*.h $T/include/
 rm -f $T/gr4-packet-modem_amd/csrc/*.o
-make -C $T/gr4-packet-modem_amd/csrc -j8 "$@" > /dev/null 2>&1
+make -C $T/gr4-packet-modem_amd/csrc -j8 EXPERIMENTS=1 "$@" ../libgr4pm_hip.so > /dev/null 2>&1
 mkdir -p $ROOT/tools/ab
 cp $T/gr4-packet-modem_amd/libgr4pm_hip.so $ROOT/tools/ab/libgr4pm_$NAME.so
 rm -rf $T
