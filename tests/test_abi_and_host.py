@@ -74,6 +74,52 @@ def test_bad_alloc_inside_an_entry_point_comes_back_as_a_status(pkg):
     L.gr4pm_test_fail_allocations(-1, 0)
 
 
+def test_occupancy_guard_trips_on_a_widened_kernel(pkg, tmp_path):
+    """tools/check_occupancy.py (run by build()): the budgets the pipelined receiver's co-residency rests on -- the
+    correlator at <= 240 VGPRs, exactly 151 552 bytes of LDS and no scratch; the two serial kernels at <= 32 VGPRs --
+    are read back from the code objects in the built library.  The built library passes; one more __shared__ word in
+    the correlator, a 34-register PLL, a spilling correlator or a renamed kernel is reported.  And the reader itself,
+    on a freshly compiled kernel with known LDS and a forced register count."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_occupancy as oc
+    rows = oc.table(pkg.LIB_PATH)
+    assert len(rows) > 60 and oc.check(rows) == []
+    by = {r["kernel"]: r for r in rows}
+    corr = next(k for k in by if "k_correlate_w64ILi114688E" in k)
+    pll = next(k for k in by if "k_costas_capILi1ELi2E" in k)
+    rot = next(k for k in by if "k_rot_checkpoints" in k)
+    assert by[corr]["vgpr"] <= 240 and by[corr]["lds_bytes"] == 151552 and by[corr]["scratch_bytes"] == 0
+    assert by[pll]["vgpr"] <= 32 and by[rot]["vgpr"] <= 32
+
+    def widened(name, **change):
+        return [dict(r, **change) if r["kernel"] == name else r for r in rows]
+
+    assert any("LDS" in e for e in oc.check(widened(corr, lds_bytes=151552 + 4)))
+    assert any("VGPRs" in e for e in oc.check(widened(corr, vgpr=248)))
+    assert any("scratch" in e for e in oc.check(widened(corr, scratch_bytes=16)))
+    assert any("VGPRs" in e and "k_costas_cap" in e for e in oc.check(widened(pll, vgpr=34)))
+    assert any("VGPRs" in e and "k_rot_checkpoints" in e for e in oc.check(widened(rot, vgpr=40)))
+    assert any("no kernel matches" in e for e in oc.check([r for r in rows if r["kernel"] != rot]))
+    src = tmp_path / "wide.hip"
+    src.write_text("""#include <hip/hip_runtime.h>
+__global__ __launch_bounds__(64) void k_rot_checkpoints(float* p) {
+    __shared__ float pad[3 * 1024 + 1];   // 12 292 bytes: four more than what is free beside the correlator
+    float v[48];
+    for (int i = 0; i < 48; ++i) v[i] = p[threadIdx.x + 64 * i];
+    pad[threadIdx.x] = v[0]; __syncthreads();
+    float s = pad[63 - threadIdx.x];
+    for (int i = 0; i < 48; ++i) s = s * v[i] + v[47 - i];
+    p[threadIdx.x] = s;
+}
+""")
+    so = tmp_path / "wide.so"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(so), str(src)])
+    wide = oc.table(str(so))
+    assert len(wide) == 1 and wide[0]["lds_bytes"] == 12292 and wide[0]["vgpr"] > 32
+    errors = [e for e in oc.check(wide) if "k_rot_checkpoints" in e and "no kernel" not in e]
+    assert any("VGPRs" in e for e in errors) and any("LDS" in e for e in errors), errors
+
+
 def test_isa_guard_catches_what_it_is_there_for(tmp_path):
     """tools/check_m0.py on hand-made assembly: a register of an asm-issued template load touched before the
     s_waitcnt that covers it, a compiler-generated m0 write (also in the v_readfirstlane form) and scratch use are
