@@ -220,7 +220,7 @@ EXPORTS = [
     "gr4pm_additive_scrambler_create", "gr4pm_additive_scrambler_destroy", "gr4pm_additive_scrambler_reset",
     "gr4pm_additive_scrambler_process",
     "gr4pm_header_payload_split_create", "gr4pm_header_payload_split_destroy",
-    "gr4pm_header_payload_split_reset", "gr4pm_header_payload_split_process",
+    "gr4pm_header_payload_split_reset", "gr4pm_header_payload_split_process", "gr4pm_header_payload_split_process_c64",
     "gr4pm_header_fec_decoder_create", "gr4pm_header_fec_decoder_destroy", "gr4pm_header_fec_decoder_process",
     "gr4pm_header_parse",
     "gr4pm_binary_slicer_process", "gr4pm_pack_bits_process", "gr4pm_slice_pack_process",
@@ -354,6 +354,7 @@ def lib():
     L.gr4pm_header_payload_split_destroy.restype = None
     L.gr4pm_header_payload_split_reset.argtypes = [vp]
     L.gr4pm_header_payload_split_process.argtypes = [vp, vp, sz, vp, szp, vp, szp, vp, sz, vp, szp, vp, szp, sz]
+    L.gr4pm_header_payload_split_process_c64.argtypes = [vp, vp, sz, vp, szp, vp, szp, vp, sz, vp, szp, vp, szp, sz]
     L.gr4pm_header_fec_decoder_create.argtypes = [C.POINTER(HeaderFecDecoderParams), C.POINTER(vp)]
     L.gr4pm_header_fec_decoder_destroy.argtypes = [vp]
     L.gr4pm_header_fec_decoder_destroy.restype = None

@@ -598,7 +598,8 @@ class AdditiveScrambler:
 
 
 class HeaderPayloadSplit:
-    """header_payload_split.hpp:9-147 on float32 items"""
+    """header_payload_split.hpp:9-147 on float32 items (the header loop, packet_receiver.hpp:136-137) or complex64
+    items (the symbol tap of zmq_output, :159-162: header_size 128, the payload tags carry payload_symbols)"""
 
     def __init__(self, header_size=256):
         self.header_size = header_size
@@ -610,13 +611,15 @@ class HeaderPayloadSplit:
         """returns (header items, payload items, header tags, payload tags)"""
         torch = _torch()
         x = x.contiguous()
-        assert x.is_cuda and x.dtype == torch.float32
+        assert x.is_cuda and x.dtype in (torch.float32, torch.complex64)
         t = _ptags_array(tags)
         hdr, pay = torch.empty(max(x.numel(), 1), dtype=x.dtype, device=x.device), torch.empty(
             max(x.numel(), 1), dtype=x.dtype, device=x.device)
         ht, pt = np.empty(t.size + 1, dtype=PACKET_TAG_DTYPE), np.empty(t.size + 1, dtype=PACKET_TAG_DTYPE)
         v = [C.c_size_t(0) for _ in range(4)]
-        check(lib().gr4pm_header_payload_split_process(
+        fn = (lib().gr4pm_header_payload_split_process if x.dtype == torch.float32
+              else lib().gr4pm_header_payload_split_process_c64)
+        check(fn(
             self._h, x.data_ptr(), x.numel(), hdr.data_ptr(), C.byref(v[0]), pay.data_ptr(), C.byref(v[1]),
             _np_ptr(t), t.size, _np_ptr(ht), C.byref(v[2]), _np_ptr(pt), C.byref(v[3]), t.size + 1),
             "HeaderPayloadSplit.processBulk")

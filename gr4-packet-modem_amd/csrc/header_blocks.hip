@@ -41,18 +41,19 @@ __global__ __launch_bounds__(256) void k_scramble(const ScrRun* __restrict__ run
     }
 }
 
-// ------------------------------------------------------------------ span gather (float items)
+// ------------------------------------------------------------------ span gather (float / complex<float> items)
 using FSpan = hostlogic::CopySpan; // hostlogic/base.hpp
-__global__ __launch_bounds__(256) void k_gather_f32(const FSpan* __restrict__ spans, const float* __restrict__ in,
-                                                    float* __restrict__ out)
+template <typename T>
+__global__ __launch_bounds__(256) void k_gather_items(const FSpan* __restrict__ spans, const T* __restrict__ in,
+                                                      T* __restrict__ out)
 {
     const FSpan sp = spans[blockIdx.y];
     for (unsigned long long i = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < sp.len;
          i += static_cast<unsigned long long>(gridDim.x) * blockDim.x)
         out[sp.dst + i] = in[sp.src + i];
 }
-gr4pm_status gather_f32(hipStream_t s, DevBuf<FSpan>& buf, const std::vector<FSpan>& spans, const float* in,
-                        float* out)
+template <typename T>
+gr4pm_status gather_items(hipStream_t s, DevBuf<FSpan>& buf, const std::vector<FSpan>& spans, const T* in, T* out)
 {
     if (spans.empty()) return GR4PM_OK;
     if (buf.n < spans.size()) GR4PM_TRY(buf.alloc(spans.size() * 2));
@@ -63,10 +64,14 @@ gr4pm_status gather_f32(hipStream_t s, DevBuf<FSpan>& buf, const std::vector<FSp
         1, std::min<unsigned long long>((longest + 2047) / 2048, 1024)));
     for (size_t first = 0; first < spans.size(); first += 65535) {
         const unsigned rows = static_cast<unsigned>(std::min<size_t>(65535, spans.size() - first));
-        hipLaunchKernelGGL(k_gather_f32, dim3(gx, rows), dim3(256), 0, s, buf.p + first, in, out);
+        hipLaunchKernelGGL(k_gather_items<T>, dim3(gx, rows), dim3(256), 0, s, buf.p + first, in, out);
     }
     GR4PM_HIP_TRY(hipGetLastError());
     return GR4PM_OK;
+}
+gr4pm_status gather_f32(hipStream_t s, DevBuf<FSpan>& buf, const std::vector<FSpan>& spans, const float* in, float* out)
+{
+    return gather_items<float>(s, buf, spans, in, out);
 }
 
 // ------------------------------------------------------------------ header FEC decoder
@@ -567,13 +572,16 @@ try {
     return GR4PM_OK;
 }
 GR4PM_ABI_CATCH
-gr4pm_status gr4pm_header_payload_split_process(gr4pm_header_payload_split* h, const float* in, size_t n,
-                                                float* header, size_t* n_header, float* payload,
-                                                size_t* n_payload, const gr4pm_packet_tag* tags_in,
-                                                size_t n_tags_in, gr4pm_packet_tag* header_tags,
-                                                size_t* n_header_tags, gr4pm_packet_tag* payload_tags,
-                                                size_t* n_payload_tags, size_t tags_cap)
-try {
+} // extern "C"
+// HeaderPayloadSplit<T>::processBulk for T = float (the header loop, packet_receiver.hpp:136-137) and T = complex<float>
+// (the symbol tap of zmq_output, :159-162): one state machine over the tags, the items gathered span by span
+template <typename T>
+static gr4pm_status header_payload_split_impl(gr4pm_header_payload_split* h, const T* in, size_t n, T* header,
+                                              size_t* n_header, T* payload, size_t* n_payload,
+                                              const gr4pm_packet_tag* tags_in, size_t n_tags_in,
+                                              gr4pm_packet_tag* header_tags, size_t* n_header_tags,
+                                              gr4pm_packet_tag* payload_tags, size_t* n_payload_tags, size_t tags_cap)
+{
     if (!h || !n_header || !n_payload) return GR4PM_ERR_INVALID;
     *n_header = *n_payload = 0;
     if (n_header_tags) *n_header_tags = 0;
@@ -589,8 +597,8 @@ try {
     const std::vector<FSpan>& ps = rp.payload_spans;
     const size_t hp = rp.n_header, pp = rp.n_payload, nht = rp.n_header_tags, npt = rp.n_payload_tags;
     const bool overflow = rp.tag_overflow;
-    GR4PM_TRY(gather_f32(h->stream, h->hspans, hs, in, header));
-    GR4PM_TRY(gather_f32(h->stream, h->pspans, ps, in, payload));
+    GR4PM_TRY(gather_items<T>(h->stream, h->hspans, hs, in, header));
+    GR4PM_TRY(gather_items<T>(h->stream, h->pspans, ps, in, payload));
     GR4PM_HIP_TRY(final_sync(h->stream));
     *n_header = hp;
     *n_payload = pp;
@@ -601,6 +609,29 @@ try {
         return GR4PM_ERR_OVERFLOW;
     }
     return GR4PM_OK;
+}
+extern "C" {
+gr4pm_status gr4pm_header_payload_split_process(gr4pm_header_payload_split* h, const float* in, size_t n,
+                                                float* header, size_t* n_header, float* payload,
+                                                size_t* n_payload, const gr4pm_packet_tag* tags_in,
+                                                size_t n_tags_in, gr4pm_packet_tag* header_tags,
+                                                size_t* n_header_tags, gr4pm_packet_tag* payload_tags,
+                                                size_t* n_payload_tags, size_t tags_cap)
+try {
+    return header_payload_split_impl<float>(h, in, n, header, n_header, payload, n_payload, tags_in, n_tags_in,
+                                            header_tags, n_header_tags, payload_tags, n_payload_tags, tags_cap);
+}
+GR4PM_ABI_CATCH
+gr4pm_status gr4pm_header_payload_split_process_c64(gr4pm_header_payload_split* h, const gr4pm_c64* in, size_t n,
+                                                    gr4pm_c64* header, size_t* n_header, gr4pm_c64* payload,
+                                                    size_t* n_payload, const gr4pm_packet_tag* tags_in,
+                                                    size_t n_tags_in, gr4pm_packet_tag* header_tags,
+                                                    size_t* n_header_tags, gr4pm_packet_tag* payload_tags,
+                                                    size_t* n_payload_tags, size_t tags_cap)
+try {
+    return header_payload_split_impl<float2>(h, reinterpret_cast<const float2*>(in), n, reinterpret_cast<float2*>(header),
+                                             n_header, reinterpret_cast<float2*>(payload), n_payload, tags_in, n_tags_in,
+                                             header_tags, n_header_tags, payload_tags, n_payload_tags, tags_cap);
 }
 GR4PM_ABI_CATCH
 

@@ -1309,13 +1309,15 @@ public:
 };
 
 // ---------------------------------------------------------------- HeaderPayloadSplit
-// replaces gr::packet_modem::HeaderPayloadSplit<T = float> (header_payload_split.hpp:9-147)
+// replaces gr::packet_modem::HeaderPayloadSplit<T = float> (header_payload_split.hpp:9-147): T = float is the header
+// loop's split (packet_receiver.hpp:136-137), T = std::complex<float> the symbol tap's (zmq_output, :159-162)
 template <typename T = float>
 class HeaderPayloadSplit : public gr::Block<HeaderPayloadSplit<T>>
 {
-    static_assert(std::is_same_v<T, float>, "gr4pm: HeaderPayloadSplit is built for T = float");
+    static_assert(std::is_same_v<T, float> || std::is_same_v<T, std::complex<float>>,
+                  "gr4pm: HeaderPayloadSplit is built for T = float and T = std::complex<float>");
     gr4pm_header_payload_split* _h = nullptr;
-    detail::DeviceStage<float> _din, _dhdr, _dpay;
+    detail::DeviceStage<T> _din, _dhdr, _dpay;
 
 public:
     gr::PortIn<T> in;
@@ -1359,16 +1361,23 @@ public:
         }
         // one output per call, like the reference (:97-123)
         const size_t n = std::min({ inSpan.size(), headerSpan.size(), payloadSpan.size(), detail::max_items() });
-        const float* hin = std::to_address(inSpan.begin());
-        const float* din = _din.in(hin, n);
-        float* dh = _dhdr.out(n);
-        float* dp = _dpay.out(n);
+        const T* hin = std::to_address(inSpan.begin());
+        const T* din = _din.in(hin, n);
+        T* dh = _dhdr.out(n);
+        T* dp = _dpay.out(n);
         size_t nh = 0, np = 0, nht = 0, npt = 0;
-        detail::check(gr4pm_header_payload_split_process(_h, din, n, dh, &nh, dp, &np, &tag, n_tags, ht, &nht, pt, &npt, 2),
-                      "HeaderPayloadSplit::processBulk"); // the unexpected-tag exception of :75-78 included
+        gr4pm_status st;
+        if constexpr (std::is_same_v<T, float>)
+            st = gr4pm_header_payload_split_process(_h, din, n, dh, &nh, dp, &np, &tag, n_tags, ht, &nht, pt, &npt, 2);
+        else
+            st = gr4pm_header_payload_split_process_c64(_h, reinterpret_cast<const gr4pm_c64*>(din), n,
+                                                        reinterpret_cast<gr4pm_c64*>(dh), &nh,
+                                                        reinterpret_cast<gr4pm_c64*>(dp), &np, &tag, n_tags, ht, &nht, pt,
+                                                        &npt, 2);
+        detail::check(st, "HeaderPayloadSplit::processBulk"); // the unexpected-tag exception of :75-78 included
         _dhdr.publish(std::to_address(headerSpan.begin()), nh, host_output);
         _dpay.publish(std::to_address(payloadSpan.begin()), np, host_output);
-        detail::consumed(hin, n * sizeof(float));
+        detail::consumed(hin, n * sizeof(T));
         _din.done();
         if (nht) header.publishTag(map, 0);
         if (npt) payload.publishTag(map, 0);

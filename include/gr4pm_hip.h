@@ -549,6 +549,14 @@ gr4pm_status gr4pm_header_payload_split_process(gr4pm_header_payload_split* h, c
                                                 size_t n_tags_in, gr4pm_packet_tag* header_tags,
                                                 size_t* n_header_tags, gr4pm_packet_tag* payload_tags,
                                                 size_t* n_payload_tags, size_t tags_cap);
+/* HeaderPayloadSplit<std::complex<float>>: the split of the symbol tap, packet_receiver.hpp:159-162 (header_size 128,
+ * the GR4PM_PKT_PAYLOAD tags then carry "payload_symbols" in payload_bits).  Same state machine, complex items. */
+gr4pm_status gr4pm_header_payload_split_process_c64(gr4pm_header_payload_split* h, const gr4pm_c64* in, size_t n,
+                                                    gr4pm_c64* header, size_t* n_header, gr4pm_c64* payload,
+                                                    size_t* n_payload, const gr4pm_packet_tag* tags_in,
+                                                    size_t n_tags_in, gr4pm_packet_tag* header_tags,
+                                                    size_t* n_header_tags, gr4pm_packet_tag* payload_tags,
+                                                    size_t* n_payload_tags, size_t tags_cap);
 
 /* ------------------------------------------------------------------------------------
  * HeaderFecDecoder -- header_fec_decoder.hpp:13-359: 256 LLRs (rate-1/2 repetition of a

@@ -24,6 +24,10 @@
 #include <numeric>
 #include <ranges>
 #include <concepts>
+#include <cstdio>
+#include <cstdlib>
+#include <sstream>
+#include <functional>
 #include <cstdint>
 #include <map>
 #include <optional>
@@ -34,24 +38,120 @@
 #include <variant>
 #include <vector>
 
-// {fmt} comes with gnuradio4's Block.hpp; the reference uses fmt::format for exception texts and fmt::println under
-// #ifdef TRACE (syncword_detection_filter.hpp:117, payload_metadata_insert.hpp:115, ...).  The stand-in keeps the format
-// string and drops the arguments (libstdc++ 11 has no <format>).
+// {fmt} comes with gnuradio4's Block.hpp; the reference uses fmt::format for exception texts, fmt::println under
+// #ifdef TRACE (syncword_detection_filter.hpp:117, payload_metadata_insert.hpp:115, ...) and for the reports of its
+// apps (message_debug.hpp:39, benchmark_syncword_detection.cpp:18-22,92).  libstdc++ 11 has no <format>: a miniature
+// that substitutes "{}" / "{:spec}" (the spec is ignored) with the streamed argument.
 namespace fmt {
-template <typename... A>
-std::string format(std::string_view f, const A&...)
+namespace stub_detail {
+template <typename T>
+void put(std::ostream& os, const T& v);
+template <typename T>
+concept Streamable = requires(std::ostream& os, const T& v) { os << v; };
+template <typename T>
+concept MapLike = requires(const T& m) { m.begin()->first; m.begin()->second; };
+template <typename T>
+concept RangeLike = requires(const T& r) { r.begin(); r.end(); } && !Streamable<T> && !MapLike<T>;
+template <typename T>
+concept VariantLike = requires(const T& v) { v.index(); std::variant_size<T>::value; };
+template <typename T>
+concept OptionalLike = requires(const T& o) { o.has_value(); *o; } && !VariantLike<T>;
+template <typename T>
+void put(std::ostream& os, const T& v)
 {
-    return std::string(f);
+    if constexpr (std::is_same_v<T, std::monostate>) {
+        os << "null";
+    } else if constexpr (std::is_same_v<T, bool>) {
+        os << (v ? "true" : "false");
+    } else if constexpr (std::is_same_v<T, uint8_t> || std::is_same_v<T, int8_t>) {
+        os << static_cast<int>(v);
+    } else if constexpr (Streamable<T>) {
+        os << v;
+    } else if constexpr (MapLike<T>) {
+        os << "{";
+        bool first = true;
+        for (const auto& kv : v) {
+            os << (first ? "" : ", ");
+            put(os, kv.first);
+            os << ": ";
+            put(os, kv.second);
+            first = false;
+        }
+        os << "}";
+    } else if constexpr (VariantLike<T>) {
+        std::visit([&](const auto& x) { put(os, x); }, v);
+    } else if constexpr (OptionalLike<T>) {
+        if (v.has_value()) put(os, *v);
+        else os << "(none)";
+    } else if constexpr (RangeLike<T>) {
+        os << "[";
+        size_t n = 0;
+        for (const auto& x : v) {
+            if (n == 8) {
+                os << ", ...";
+                break;
+            }
+            os << (n++ ? ", " : "");
+            put(os, x);
+        }
+        os << "]";
+    } else {
+        os << "<?>";
+    }
+}
+inline void next_field(std::ostream& os, std::string_view& f)
+{
+    // copies up to the next replacement field and skips the field; "{{" / "}}" are literal braces
+    while (!f.empty()) {
+        if (f.size() >= 2 && (f.substr(0, 2) == "{{" || f.substr(0, 2) == "}}")) {
+            os << f[0];
+            f.remove_prefix(2);
+        } else if (f[0] == '{') {
+            const size_t e = f.find('}');
+            f.remove_prefix(e == std::string_view::npos ? f.size() : e + 1);
+            return;
+        } else {
+            os << f[0];
+            f.remove_prefix(1);
+        }
+    }
 }
 template <typename... A>
-void println(std::string_view, const A&...)
+std::string vformat(std::string_view f, const A&... a)
 {
+    std::ostringstream os;
+    ((next_field(os, f), put(os, a)), ...);
+    next_field(os, f);
+    os << f;
+    return os.str();
+}
+} // namespace stub_detail
+template <typename... A>
+std::string format(std::string_view f, const A&... a)
+{
+    return stub_detail::vformat(f, a...);
 }
 template <typename... A>
-void print(std::string_view, const A&...)
+void println(std::FILE* to, std::string_view f, const A&... a)
 {
+    const std::string s = stub_detail::vformat(f, a...) + "\n";
+    std::fwrite(s.data(), 1, s.size(), to);
+}
+template <typename... A>
+void println(std::string_view f, const A&... a)
+{
+    println(stdout, f, a...);
+}
+template <typename... A>
+void print(std::string_view f, const A&... a)
+{
+    const std::string s = stub_detail::vformat(f, a...);
+    std::fwrite(s.data(), 1, s.size(), stdout);
 }
 } // namespace fmt
+
+// (magic_enum reaches the reference's blocks through gnuradio4's Block.hpp: header_parser.hpp:89 uses it without an include)
+#include <magic_enum.hpp>
 
 namespace pmtv {
 using pmt = std::variant<std::monostate, bool, int32_t, int64_t, uint64_t, float, double, std::string,
@@ -107,9 +207,19 @@ struct Tag {
     ssize_t index = 0;
     property_map map;
 };
-struct Message {
-    std::optional<property_map> data;
+// Message::data is a std::expected<property_map, Error> in gnuradio4 (message_debug.hpp:37-41 reads .has_value() /
+// .value() / .error()); libstdc++ 11 has no <expected>: an optional with an error text
+struct MessageData : std::optional<property_map> {
+    using std::optional<property_map>::optional;
+    using std::optional<property_map>::operator=;
+    std::string error() const { return "no data"; }
 };
+struct Message {
+    MessageData data;
+};
+namespace message {
+enum class Command { Set, Get, Subscribe, Unsubscribe, Partial, Final, Ready, Disconnect, Heartbeat, Invalid };
+}
 struct Async {};
 template <auto...>
 struct Resampling {};
@@ -157,15 +267,26 @@ concept PublishableSpan = requires(S& s) {
     s.begin();
 };
 
+namespace stub {
+// what Graph::connect() records on the two ports of an edge (gnuradio-4.0/Graph.hpp of the stand-in)
+struct Link {
+    const void* block = nullptr; // the block at the other end
+    std::string port;            // its port name
+};
+} // namespace stub
 template <typename T, typename... Attr>
 struct PortIn {
     using value_type = T;
+    static constexpr bool is_input = true;
     static constexpr bool is_async = (std::is_same_v<Attr, Async> || ... || false);
     size_t min_samples = 1, max_samples = static_cast<size_t>(-1);
+    std::vector<stub::Link> links;
 };
 template <typename T, typename... Attr>
 struct PortOut {
     using value_type = T;
+    static constexpr bool is_input = false;
+    std::vector<stub::Link> links;
     static constexpr bool is_async = (std::is_same_v<Attr, Async> || ... || false);
     size_t min_samples = 1, max_samples = static_cast<size_t>(-1);
     // what the block published during the current processBulk(): offsets are relative to the out span
@@ -173,8 +294,36 @@ struct PortOut {
     void publishTag(const property_map& map, ssize_t offset) { published_tags.push_back({ offset, map }); }
 };
 
+// built-in message ports (probe_rate.hpp:97, message_debug.hpp:30-31): messages, no samples
+struct MsgPortOut {
+    using value_type = Message;
+    static constexpr bool is_input = false, is_async = true;
+    size_t min_samples = 0, max_samples = static_cast<size_t>(-1);
+    std::vector<stub::Link> links;
+    std::vector<Message> sent; // what sendMessage() left here
+};
+template <meta::fixed_string Name>
+struct MsgPortInNamed {
+    using value_type = Message;
+    static constexpr bool is_input = true, is_async = true;
+    size_t min_samples = 0, max_samples = static_cast<size_t>(-1);
+    std::vector<stub::Link> links;
+};
+using MsgPortIn = MsgPortInNamed<"msgIn">;
+template <message::Command>
+void sendMessage(MsgPortOut& port, std::string_view /*service*/, std::string_view /*endpoint*/, property_map data)
+{
+    Message m;
+    m.data = std::move(data);
+    port.sent.push_back(std::move(m));
+}
+
 template <typename Derived, typename... Attr>
 struct Block {
+    bool stop_requested = false;
+    std::vector<std::pair<std::string, std::string>> error_messages;
+    void requestStop() { stop_requested = true; }
+    void emitErrorMessage(std::string_view where, std::string_view what) { error_messages.emplace_back(where, what); }
     std::string name = "block";
     size_t input_chunk_size = 1, output_chunk_size = 1;
     Tag _mergedInputTag;
@@ -227,12 +376,25 @@ void assign(M& member, const pmtv::pmt& v, const char* name)
         throw exception(std::string("setting '") + name + "': type not supported by the test stand-in");
     }
 }
+template <size_t N>
+constexpr bool same_name(const meta::fixed_string<N>& a, const char* b)
+{
+    for (size_t i = 0; i < N; ++i) {
+        if (a.data[i] != b[i]) return false;
+        if (b[i] == 0) return true;
+    }
+    return false;
+}
+template <meta::fixed_string>
+inline constexpr bool no_such_member = false;
 template <typename T>
 struct Reflect; // specialised by ENABLE_REFLECTION*: size_t apply(T&, const property_map&) -> settings assigned
 
 // what `fg.emplaceBlock<T>({ { "key", value }, ... })` does with the initial settings
 struct Graph {
     std::vector<std::shared_ptr<void>> blocks;
+    std::vector<std::function<void()>> starters, stoppers; // start() / stop() of the blocks that have them
+    size_t needed_a_device = 0;                            // settingsChanged() calls that asked for the GPU (see below)
     template <typename T>
     T& emplaceBlock(property_map settings = {})
     {
@@ -247,7 +409,19 @@ struct Graph {
             }
             throw exception("emplaceBlock: no such setting:" + unknown);
         }
-        if constexpr (requires { p->settingsChanged(settings, settings); }) p->settingsChanged({}, settings);
+        if constexpr (requires { p->settingsChanged(settings, settings); }) {
+            try {
+                p->settingsChanged({}, settings);
+            } catch (const exception& e) {
+                // GR4_STUB_LIFECYCLE=0 (a machine without a GPU: the drop-in blocks have no CPU fallback and say so from
+                // the first call that needs the device): note it and go on building the graph
+                const char* lc = std::getenv("GR4_STUB_LIFECYCLE");
+                if (!(lc && lc[0] == '0') || std::string_view(e.what()).find("no HIP device") == std::string_view::npos) throw;
+                ++needed_a_device;
+            }
+        }
+        if constexpr (requires { p->start(); }) starters.push_back([q = p.get()] { q->start(); });
+        if constexpr (requires { p->stop(); }) stoppers.push_back([q = p.get()] { q->stop(); });
         blocks.push_back(p);
         return *p;
     }
@@ -288,14 +462,36 @@ struct Graph {
         GR4_STUB_FOR_EACH(GR4_STUB_APPLY_ONE, __VA_ARGS__)                                                           \
         return n_;                                                                                                   \
     }
+// member by compile-time name: fg.connect<"out">(a) (gnuradio-4.0/Graph.hpp of the stand-in)
+#define GR4_STUB_MEMBER_ONE(member)                                                                                  \
+    if constexpr (::gr::stub::same_name(N_, #member)) return (b_.member);                                            \
+    else
+#define GR4_STUB_MEMBER_BODY(...)                                                                                    \
+    {                                                                                                                \
+        GR4_STUB_FOR_EACH(GR4_STUB_MEMBER_ONE, __VA_ARGS__)                                                          \
+        static_assert(::gr::stub::no_such_member<N_>, "no reflected member of that name");                           \
+    }
+#define GR4_STUB_STRIP(...) __VA_ARGS__
 #define ENABLE_REFLECTION(Type, ...)                                                                                 \
     template <>                                                                                                      \
     struct gr::stub::Reflect<Type> {                                                                                 \
         static size_t apply(Type& b_, const ::gr::property_map& m_) GR4_STUB_REFLECT_BODY(__VA_ARGS__)                \
+        template <::gr::meta::fixed_string N_>                                                                       \
+        static decltype(auto) member(Type& b_) GR4_STUB_MEMBER_BODY(__VA_ARGS__)                                     \
     }
 #define ENABLE_REFLECTION_FOR_TEMPLATE(Tmpl, ...)                                                                    \
     template <typename... Ts_>                                                                                       \
     struct gr::stub::Reflect<Tmpl<Ts_...>> {                                                                         \
         static size_t apply(Tmpl<Ts_...>& b_, const ::gr::property_map& m_) GR4_STUB_REFLECT_BODY(__VA_ARGS__)        \
+        template <::gr::meta::fixed_string N_>                                                                       \
+        static decltype(auto) member(Tmpl<Ts_...>& b_) GR4_STUB_MEMBER_BODY(__VA_ARGS__)                             \
     }
-#define ENABLE_REFLECTION_FOR_TEMPLATE_FULL(...) static_assert(true)
+// ENABLE_REFLECTION_FOR_TEMPLATE_FULL((bool invert, typename TIn, typename TOut), (BinarySlicer<invert, TIn, TOut>), in, out)
+#define ENABLE_REFLECTION_FOR_TEMPLATE_FULL(TParams, Type, ...)                                                      \
+    template <GR4_STUB_STRIP TParams>                                                                                \
+    struct gr::stub::Reflect<GR4_STUB_STRIP Type> {                                                                  \
+        using Self_ = GR4_STUB_STRIP Type;                                                                           \
+        static size_t apply(Self_& b_, const ::gr::property_map& m_) GR4_STUB_REFLECT_BODY(__VA_ARGS__)               \
+        template <::gr::meta::fixed_string N_>                                                                       \
+        static decltype(auto) member(Self_& b_) GR4_STUB_MEMBER_BODY(__VA_ARGS__)                                    \
+    }

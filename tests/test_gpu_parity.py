@@ -1958,6 +1958,24 @@ def test_header_payload_split_stream_vs_oracle(pkg):
     bad["index"], bad["kind"], bad["payload_bits"] = 10, pkg.PKT_PAYLOAD, 5
     with pytest.raises(pkg.Gr4pmError):
         pkg.HeaderPayloadSplit(256).process_bulk(torch.zeros(100).cuda(), bad)
+    # HeaderPayloadSplit<std::complex<float>> (packet_receiver.hpp:159-162, the symbol tap: gr4pm_header_payload_split_
+    # process_c64, the instantiation the reference's packet_receiver.hpp needs from the drop-in header): the same state
+    # machine over complex items -- real and imaginary parts are each what the oracle's float block gives
+    xc = (x + 1j * rng.standard_normal(x.size)).astype(np.complex64)
+    gpu, ref_re, ref_im = pkg.HeaderPayloadSplit(256), orc.HeaderPayloadSplit(256), orc.HeaderPayloadSplit(256)
+    p0 = 0
+    while p0 < xc.size:
+        m = min(int(rng.integers(1, 20000)), xc.size - p0)
+        tt = tags[(tags["index"] >= p0) & (tags["index"] < p0 + m)].copy()
+        tt["index"] -= p0
+        h, p, ht, pt = gpu.process_bulk(torch.from_numpy(xc[p0:p0 + m]).cuda(), tt)
+        wh, wp, wht, wpt = ref_re.process(np.ascontiguousarray(xc[p0:p0 + m].real), tt)
+        ih, ip, _, _ = ref_im.process(np.ascontiguousarray(xc[p0:p0 + m].imag), tt)
+        h, p = h.cpu().numpy(), p.cpu().numpy()
+        assert h.dtype == np.complex64 and h.real.tobytes() == wh.tobytes() and h.imag.tobytes() == ih.tobytes()
+        assert p.real.tobytes() == wp.tobytes() and p.imag.tobytes() == ip.tobytes()
+        assert same_ptags(ht, wht) and same_ptags(pt, wpt)
+        p0 += m
 
 
 def test_header_fec_decoder_reference_qa(pkg):

@@ -156,6 +156,61 @@ def test_rotator_fir_resampler_wrappers(tmp_path):
     assert abs(arb.size - ref_arb.size) <= 2 and np.array_equal(arb[:n].view(np.uint64), ref_arb[:n].view(np.uint64))
 
 
+REFERENCE_ROOT = "/root/reference"
+FLOWGRAPHS = [  # (source under /root/reference, arguments, blocks, edges): the reference's own flowgraph sources
+    ("benchmarks/benchmark_syncword_detection.cpp", ["2", "7.5"], 4, 3),
+    ("benchmarks/benchmark_packet_receiver.cpp", [], 20, 22),
+    ("apps/packet_receiver_file.cpp", ["/dev/null", "3"], 25, 27),
+]
+
+
+@pytest.mark.parametrize("source,args,n_blocks,n_edges", FLOWGRAPHS)
+def test_reference_flowgraph_sources_compile_and_link_against_the_drop_in_headers(tmp_path, source, args, n_blocks, n_edges):
+    """north_star: "... so the existing apps/packet_receiver_* and benchmark_syncword_detection flowgraphs link against
+    them unchanged".  The reference's OWN translation units -- benchmarks/benchmark_syncword_detection.cpp,
+    benchmarks/benchmark_packet_receiver.cpp, apps/packet_receiver_file.cpp, and through them packet_receiver.hpp:34-265
+    -- are compiled unchanged, by path, with gr4-packet-modem_amd/host IN FRONT OF the reference's blocks/include (exactly
+    INTEGRATION.md's CMake switch) and linked against libgr4pm_hip.so.  Every fg.emplaceBlock<T>({...}) spelling,
+    property-map key, fg.connect<"port">(a).to<"port">(b) port name and item type, and pointer member
+    (packet_receiver.syncword_detection, .payload_crc_check) then resolves against the HIP classes or the build fails;
+    the blocks that have no drop-in (sources, sinks, CRC, parser ...) come from the reference's headers.  gnuradio4 is
+    absent: Graph.hpp / Scheduler.hpp are the test stand-in (tests/gr4_stub), whose connect() checks names and types at
+    compile time and whose runAndWait() executes nothing.  Here (no GPU, GR4_STUB_LIFECYCLE=0) the binary builds its
+    graph -- the three device-needing settingsChanged() calls of the receiver noted -- and reports it.  Build container
+    only: nothing of the reference, source or binary, travels to the GPU box."""
+    src = os.path.join(REFERENCE_ROOT, source)
+    if not os.path.exists(src):
+        pytest.skip("the reference tree is not on this machine")
+    ge.build() if not os.path.exists(os.path.join(ge.PKG_DIR, "libgr4pm_hip.so")) else None
+    exe = str(tmp_path / "flowgraph.bin")
+    subprocess.check_call(["g++", "-std=c++23", "-O1", "-D__HIP_PLATFORM_AMD__",
+                           "-I", os.path.join(ROOT, "tests", "gr4_stub"),       # gnuradio4 stand-in (test-only)
+                           "-I", os.path.join(ge.PKG_DIR, "host"),              # the drop-in headers, first
+                           "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                           "-I", REFERENCE_INCLUDE,                             # everything else: the reference's own
+                           "-o", exe, src, "-L" + ge.PKG_DIR, "-lgr4pm_hip", "-L/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath," + ge.PKG_DIR, "-Wl,-rpath,/opt/rocm/lib", "-pthread"])
+    syms = subprocess.run(["nm", "-C", exe], capture_output=True, text=True, check=True).stdout
+    assert "gr::packet_modem::hip::SyncwordDetection" in syms           # the HIP class is the one instantiated
+    assert " U gr4pm_syncword_detection_create" in syms                 # ... and it calls the C ABI of the library
+    assert "gr::packet_modem::SyncwordDetection::" not in syms          # the reference's detector is not in the binary
+    if "packet_receiver" in source:
+        for cls in ("SyncwordDetectionFilter", "CoarseFrequencyCorrection", "SymbolFilter", "SyncwordWipeoff",
+                    "PayloadMetadataInsert", "CostasLoop", "SyncwordRemove", "ConstellationLLRDecoder", "AdditiveScrambler",
+                    "HeaderPayloadSplit", "HeaderFecDecoder"):
+            assert f"gr::packet_modem::hip::{cls}" in syms, cls
+        assert "ldpc_toolbox" not in syms                               # header_fec_decoder.hpp:276: replaced, not linked
+        assert "gr::packet_modem::CrcCheck<" in syms and "gr::packet_modem::HeaderParser<" in syms  # the reference's own
+    r = subprocess.run([exe] + args, capture_output=True, text=True, env=dict(os.environ, GR4_STUB_LIFECYCLE="0"))
+    assert r.returncode == 1, r.stdout + r.stderr
+    deferred = 0 if "syncword_detection" in source else 3
+    assert (f"{n_blocks} blocks, {n_edges} edges, lifecycle skipped, {deferred} settings calls deferred" in r.stdout + r.stderr), \
+        r.stdout + r.stderr
+    if "packet_receiver" in source:  # without the switch: the first device-needing call says that there is no CPU path
+        r = subprocess.run([exe] + args, capture_output=True, text=True)
+        assert r.returncode != 0 and "no HIP device" in r.stderr and "no CPU fallback" in r.stderr
+
+
 def test_remaining_reference_receive_headers_compile_on_the_stub(tmp_path):
     """syncword_detection_filter / payload_metadata_insert / syncword_remove / constellation_llr_decoder /
     additive_scrambler / header_payload_split of the reference, with processBulk() / processOne() instantiated on the
