@@ -629,6 +629,17 @@ def config5_stream(pkg, n, device, seed=5, chunk=1 << 26):
     return x, rrc, fir
 
 
+def config5_windows(total, window, nfft, stride):
+    """the streamed calls over the configs[4] ring: (position, items offered) -- `window` items offered, whole strides
+    consumed (syncword_detection.hpp:238), the next window starts where the call stopped"""
+    pos, out = 0, []
+    while total - pos >= nfft:
+        take = min(window, total - pos)
+        out.append((pos, take))
+        pos += ((take - nfft) // stride + 1) * stride
+    return out
+
+
 def config5_leg(pkg, device, total=1 << 30, window=1 << 28, passes=2):
     """BASELINE configs[4] as SURVEY.md 8(d) config 5 defines it, in the default run: 1 channel, fft_size 4096, 1025-tap
     RRC (syncword 63 * 4 + 1025 = 1277 samples, stride 2820), B in {1, 9} bins, 2^30 samples STREAMED through a device
@@ -643,14 +654,7 @@ def config5_leg(pkg, device, total=1 << 30, window=1 << 28, passes=2):
     S = nfft - L + 1
     bpsk = np.array([1, -1], dtype=np.complex64)
 
-    def windows():
-        pos, out = 0, []
-        while total - pos >= nfft:
-            take = min(window, total - pos)
-            out.append((pos, take))
-            pos += ((take - nfft) // S + 1) * S
-        return out
-    wins = windows()
+    wins = config5_windows(total, window, nfft, S)
     per_bins = {}
     for b in (0, BINS):
         # power_threshold 30 (nine bins) / 60 (one), not the receiver's 9.5: with a 1025-tap template the correlation
@@ -788,6 +792,7 @@ def host_stream_leg(pkg, device, rrc, chunk=1 << 25, host_chunks=4, total=1 << 2
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     del rx
+    check_tag_count("host-stream leg", tags, n_chunks, chunk)
     return {"workload": f"configs[1] front end fed from pinned host memory: {n_chunks} chunks of 2^{chunk.bit_length() - 1} samples, "
                         f"hipMemcpyAsync two chunks ahead into {n_slots} device slots, pipelined native receiver behind them",
             "value": round(done / dt / 1e6, 2), "unit": "Msamples/s", "samples": done, "tags": tags,
@@ -795,6 +800,32 @@ def host_stream_leg(pkg, device, rrc, chunk=1 << 25, host_chunks=4, total=1 << 2
             "link_only": {"value": round(n_chunks * chunk / dt_link / 1e6, 2), "unit": "Msamples/s",
                           "h2d_gbs": round(8.0 * n_chunks * chunk / dt_link / 1e9, 2)},
             "note": "PCIe-inclusive; not `value` (inputs of the headline are resident in HBM when the timed region starts)"}
+
+
+def headline_ring(x, xb):
+    """the headline's device ring [.. | window A | window B]: two different stretches of the burst stream that the steps
+    present alternately, each preceded in memory by the 2T+1 items "before" it (for A: a copy of B's tail, for B: A's
+    tail itself) -> (ring, [(window, its history)] x 2).  tests/test_gpu_parity.py builds the same ring."""
+    hist, n_items = 2 * 768 + 1, x.numel()
+    ring = torch.empty(hist + 1 + 2 * n_items, dtype=torch.complex64, device=x.device)  # +1: keep A 16-byte aligned
+    ring[1:1 + hist] = xb[-hist:]
+    ring[1 + hist:1 + hist + n_items] = x
+    ring[1 + hist + n_items:] = xb
+    return ring, [(ring[1 + hist:1 + hist + n_items], ring[1:1 + hist]),
+                  (ring[1 + hist + n_items:], ring[1 + n_items:1 + hist + n_items])]
+
+
+# samples per packet period of burst_stream(): 64 + 128 + 1504 * 4 symbols + a gap of 500, 4 samples per symbol
+BURST_PERIOD = (64 + 128 + 1504 * 4 + 500) * SPS
+
+
+def check_tag_count(what, n_tags, n_windows, items_per_window, period=BURST_PERIOD):
+    """outside every timed region: the detector found the packets the generator put in -- one tag per packet period of
+    every window, give or take the packet cut by each window edge"""
+    want = n_windows * (items_per_window / period)
+    if abs(n_tags - want) > 2 * n_windows + 1:
+        raise SystemExit(f"bench.py: {what}: {n_tags} tags over {n_windows} windows of {items_per_window} items, "
+                         f"the generator's packet count is {want:.1f}: the measured path does not do the receiver's work")
 
 
 def correlator_flops_per_sample(n_bins, n_fft=N_FFT, stride=1752):
@@ -896,7 +927,7 @@ def channels64_leg(pkg, dist, device, rank, world, rrc, steps, warmup, repeats, 
     multi = pkg.NativeMultiChannelReceiver(channels, SPS, BINS, 9.5, "QPSK", max_items=n_items,
                                            tags_cap=max(64, 2 * n_pkt + 64), workers=12, output_ring=True)
     multi.set_input_in_place(True)
-    state = {"step": 0, "announced": 0}
+    state = {"step": 0, "announced": 0, "tags": 0}
 
     def step(left):
         target = state["step"] + min(left, 2)  # look-ahead two batches ahead, as the headline
@@ -907,12 +938,16 @@ def channels64_leg(pkg, dist, device, rank, world, rrc, steps, warmup, repeats, 
         state["step"] += 1
         res = multi.collect() if multi.in_flight() == 4 else None
         multi.submit(xs, 1500)
+        if res is not None:
+            state["tags"] += sum(r["tags"].size for r in res)
         return 0 if res is None else sum(r["consumed"] for r in res)
 
     def drain():
         n = 0
         while multi.in_flight():
-            n += sum(r["consumed"] for r in multi.collect())
+            res = multi.collect()
+            n += sum(r["consumed"] for r in res)
+            state["tags"] += sum(r["tags"].size for r in res)
         return n
 
     for i in range(warmup):
@@ -926,6 +961,7 @@ def channels64_leg(pkg, dist, device, rank, world, rrc, steps, warmup, repeats, 
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         consumed = 0
+        state["tags"] = 0
         for i in range(steps):
             consumed += step(steps - 1 - i)
         consumed += drain()
@@ -936,6 +972,8 @@ def channels64_leg(pkg, dist, device, rank, world, rrc, steps, warmup, repeats, 
         dt, total = aggregate(dist, time.perf_counter() - t0, float(consumed), device)
         rates.append(total / dt / 1e6)
         times.append(dt)
+        tags_per_step = state["tags"] // steps
+        check_tag_count(f"{channels}-channel leg", state["tags"], steps * channels, n_items)
     med = sorted(range(len(rates)), key=lambda i: rates[i])[len(rates) // 2]
     del multi
     latency = None
@@ -944,7 +982,7 @@ def channels64_leg(pkg, dist, device, rank, world, rrc, steps, warmup, repeats, 
     return {"workload": f"{channels} channels per GPU x {n_items} samples per batch, {channels * world} channels in all, "
                         "full RX front end per channel (gr4pm_multichannel_receiver), per-channel CFO sweep",
             "value": round(rates[med], 2), "unit": "Msamples/s", "steps": steps, "warmup": warmup,
-            "ms_per_step": round(times[med] / steps * 1e3, 4), "repeats": len(rates),
+            "ms_per_step": round(times[med] / steps * 1e3, 4), "repeats": len(rates), "tags_per_step": tags_per_step,
             "value_min": round(min(rates), 2), "value_max": round(max(rates), 2), "input": input_mode,
             **({"latency": latency} if latency else {})}
 
@@ -1096,16 +1134,10 @@ def main():
     # burst stream that the steps present alternately, each preceded in memory by the 2T+1 items
     # "before" it (for A: a copy of B's tail, for B: A's tail itself).  While one window is being
     # processed the detector is told which one comes next (look-ahead of the correlator).
-    HIST = 2 * 768 + 1
     xb, n_pkt_b = make_stream(1001 + rank)
-    ring = torch.empty(HIST + 1 + 2 * n_items, dtype=torch.complex64, device=device)  # +1: keep A 16-byte aligned
-    ring[1:1 + HIST] = xb[-HIST:]
-    ring[1 + HIST:1 + HIST + n_items] = x
-    ring[1 + HIST + n_items:] = xb
+    ring, windows = headline_ring(x, xb)
     del xb
-    x = ring[1 + HIST:1 + HIST + n_items]
-    windows = [(x, ring[1:1 + HIST]),
-               (ring[1 + HIST + n_items:], ring[1 + n_items:1 + HIST + n_items])]
+    x = windows[0][0]
     n_pkt = max(n_pkt, n_pkt_b)
     native = not (args.python_pipeline or args.detector_only or args.channels > 1)
     if native:
@@ -1252,6 +1284,9 @@ def main():
         return dt, total, n_tags
 
     regions = [timed_region() for _ in range(max(1, args.repeats))]
+    if not args.decode_headers:  # (packet_stream has its own period; its leg counts CRC-checked packets instead)
+        for _, _, nt in regions:
+            check_tag_count("headline region", nt, args.steps * max(args.channels, 1), n_items)
     by_rate = sorted(regions, key=lambda r: r[1] / r[0])
     dt, total, n_tags = by_rate[len(by_rate) // 2]  # the median region is the number of record
     region_rates = [round(r[1] / r[0] / 1e6, 2) for r in regions]

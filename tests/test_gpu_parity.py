@@ -1161,6 +1161,147 @@ def test_packet_receiver_full_size_round_trip(pkg):
     assert len(got) >= complete and got == payloads[: len(got)]
 
 
+def _same_tag_records(a, b):
+    return a.size == b.size and all(np.array_equal(a[k], b[k]) for k in a.dtype.names)
+
+
+@pytest.mark.timeout(900)
+def test_headline_configuration_at_its_size_pipelined_equals_sequential_and_oracle_prefix(pkg):
+    """The configuration BENCH's `value` is measured on, as a whole and at its size (bench.py main(): configs[1] at
+    SURVEY 8(d) config 2's size): three 2^28-sample calls of NativePacketReceiver(pipelined, output_ring) on the bench's
+    own burst ring (headline_ring: two windows presented alternately, each with its history in front), announced two
+    calls ahead.  That is the path with the dynamic block hand-out beside the 32-VGPR PLL (k_costas_cap: calls of
+    >= 2^25 symbols while a later batch is in flight, stream_blocks.hip) and the switch to the fast PLL form on the
+    last batch.  Checked against
+      (1) the one-stream sequential receiver (pipelined = False: no look-ahead, every stage in the caller's thread, the
+          112-VGPR PLL throughout): consumed, detector tags, gate decisions, re-timed tags and all 3 x 2^26 symbols bit
+          for bit (syncword_detection.hpp:204-356, costas_loop.hpp:92-148 at the size the number is quoted on);
+      (2) the CPU oracle on the first 2^22 samples: detector tags (indices exact, floats in bands) and, fed with the
+          GPU's accepted tags, CFC -> SymbolFilter -> wipe-off -> Costas bit for bit;
+      (3) the generator: one accepted tag per packet period."""
+    import bench
+    n, device = 1 << 28, torch.device("cuda")
+    rrc = bench.unit_norm_rrc(pkg)
+    x, n_pkt = bench.burst_stream(pkg, n, rrc, seed=1, device=device)
+    xb, n_pkt_b = bench.burst_stream(pkg, n, rrc, seed=1001, device=device)
+    ring, windows = bench.headline_ring(x, xb)
+    del x, xb
+    cap = max(64, 2 * max(n_pkt, n_pkt_b) + 64)
+    calls = 3
+
+    def run(pipelined):
+        rx = pkg.NativePacketReceiver(bench.SPS, bench.BINS, 9.5, "QPSK", max_items=n, tags_cap=cap, pipelined=pipelined,
+                                      output_ring=True)
+        results, announced = [], 0
+        for k in range(calls):
+            w, history = windows[k % 2]
+            if pipelined:  # bench.py's step(): the inputs of the next calls announced, at most two ahead
+                while announced < min(k + 2, calls - 1):
+                    announced += 1
+                    rx.announce(windows[announced % 2][0])
+            r = rx.process_bulk(w, 1500, tags_cap=cap, history=history)
+            if r is not None:
+                results.append(r)
+        results += rx.flush()
+        return results
+
+    piped = run(True)
+    assert len(piped) == calls
+    kept = [dict(r, symbols=r["symbols"].clone()) for r in piped]  # (the output ring is reused by the next receiver's)
+    del piped
+    torch.cuda.synchronize()
+    seq = run(False)
+    stride_items = ((n - 2048) // 1752 + 1) * 1752
+    for k, (a, b) in enumerate(zip(kept, seq)):
+        assert a["consumed"] == b["consumed"] == stride_items
+        assert _same_tag_records(a["detector_tags"], b["detector_tags"]), k
+        assert np.array_equal(a["accepted"], b["accepted"])
+        assert _same_tag_records(a["tags"], b["tags"]), k
+        assert a["symbols"].numel() == b["symbols"].numel() > (n // 4) - 2048
+        assert torch.equal(a["symbols"].view(torch.float32).view(torch.int64), b["symbols"].view(torch.float32).view(torch.int64)), k
+        # (3) the generator's packets: one accepted tag per period, at the period's spacing
+        bench.check_tag_count(f"call {k}", int(a["tags"].size), 1, n)
+        det = a["detector_tags"][a["accepted"]]["index"].astype(np.int64)
+        assert np.all(np.abs(np.diff(det) - bench.BURST_PERIOD) <= 2)
+    # calls 0 and 2 present the same window: identical detections apart from the state carried in from the call before
+    assert abs(int(kept[0]["tags"].size) - int(kept[2]["tags"].size)) <= 1
+    # (2) the oracle on the first 2^22 samples of call 0
+    m = (1 << 22) + 2048
+    first = kept[0]
+    xh = host(windows[0][0][:m])
+    ref = orc.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, power_threshold=9.5)
+    _, ref_out, ref_tags = ref.process(xh, tags_cap=1 << 12)
+    done = ref_out.size
+    det = first["detector_tags"]
+    inside = det["index"] < done - 2 * 768 - 1  # (the scan decides a detection up to time_threshold items later)
+    ref_inside = ref_tags["index"] < done - 2 * 768 - 1
+    assert_tags_match(det[inside], ref_tags[ref_inside], rtol=2e-4)
+    # the delayed stream the chain reads in place: the ring's history, then the window (the detector's own pass-through
+    # starts with 2T+1 zeros, syncword_detection.hpp:318-319; a streaming caller's ring holds the items before instead)
+    delayed = np.concatenate([host(windows[0][1]), xh])[:done]
+    acc = det[inside & first["accepted"]]
+    z = orc.coarse_frequency_correction(delayed, acc["index"], acc["freq"], delay=26)
+    pfb = orc.rrc_taps(32.0 / float(orc.unit_norm_rrc(4)[1]), 128.0, 1.0, 0.35, 32 * 4 * 11)[:-1]
+    sym, sym_tags, _ = orc.symbol_filter(z, pfb, 32, 4, 44, tags=acc.astype(orc.TAG_DTYPE))
+    w = orc.syncword_wipeoff(sym, np.where(sig.SYNCWORD == 1, -1.0, 1.0).astype(np.float32), sym_tags["index"])
+    c = orc.costas_loop(w, "QPSK", 0.01, sym_tags["index"], sym_tags["phase"])
+    k_sym = c.size - 1024  # (symbols behind the last tag the oracle saw may belong to a detection it has not made yet)
+    got = host(first["symbols"][:k_sym])
+    gt = first["tags"][first["tags"]["index"] < k_sym]
+    st = sym_tags[sym_tags["index"] < k_sym]
+    assert np.array_equal(gt["index"], st["index"]) and gt.size >= 150
+    assert np.array_equal(bits(got), bits(c[:k_sym]))
+
+
+@pytest.mark.timeout(900)
+def test_config5_streamed_ring_at_its_size(pkg):
+    """BENCH's `config5` sub-record at its size (BASELINE configs[4] as SURVEY 8(d) config 5 defines it): 2^30 samples
+    of the bench's configs[4] stream (fft_size 4096, 1025-tap RRC: syncword 1277 samples, stride 2820) through a device
+    ring in windows of 2^28 offered items with the look-ahead (next_x: k_correlate_4096 of the next window behind the
+    current call's scan), B = 1 and B = 9 with the bench's thresholds.  The streamed calls give the tags of plain,
+    non-announced calls record for record; every burst the generator placed is found; and the first window's first
+    2^21 samples agree with the CPU oracle at fft_size 4096 (indices, freq_bin exact; floats in bands)."""
+    import bench
+    device = torch.device("cuda")
+    total, window, nfft = 1 << 30, 1 << 28, 4096
+    x, rrc, fir = bench.config5_stream(pkg, total, device)
+    del fir
+    L = 63 * 4 + rrc.size
+    S = nfft - L + 1
+    assert (L, S) == (1277, 2820)
+    wins = bench.config5_windows(total, window, nfft, S)
+    assert len(wins) == 5
+    bursts = 1537 + 4 * np.arange(2000, total // 4 - 64, 16384)  # config5_stream: a syncword every 16384 symbols
+    for b, thr in ((0, 60.0), (4, 30.0)):
+        def run(lookahead):
+            sd = pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -b, b, fft_size=nfft, power_threshold=thr, max_items=window)
+            out, done = [], 0
+            for k, (pos, take) in enumerate(wins):
+                nxt = x[wins[k + 1][0]:wins[k + 1][0] + wins[k + 1][1]] if (lookahead and k + 1 < len(wins)) else None
+                _, _, t, nd = sd.process_bulk(x[pos:pos + take], want_output=False, tags_cap=1 << 17, next_x=nxt)
+                assert nd == ((take - nfft) // S + 1) * S and pos == done
+                t = t.copy()
+                t["index"] += pos
+                out.append(t)
+                done += nd
+            return np.concatenate(out), done
+        streamed, done = run(True)
+        plain, done2 = run(False)
+        assert done == done2 > total - window // 64
+        assert _same_tag_records(streamed, plain), (b, streamed.size, plain.size)
+        found = np.isin(bursts[bursts < done - 1537], streamed["index"])
+        assert found.all(), (b, int((~found).sum()))
+        extra = streamed.size - int(found.sum())
+        assert extra <= 0.02 * found.sum(), (b, extra)  # (detections on plain data: a 1025-tap template, see bench.py)
+        # the oracle on the first 2^21 samples
+        m = (1 << 21) + nfft
+        ref = orc.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -b, b, fft_size=nfft, power_threshold=thr)
+        _, ref_out, ref_tags = ref.process(host(x[:m]), tags_cap=1 << 12)
+        lim = ref_out.size - 2 * 768 - 1
+        assert_tags_match(streamed[streamed["index"] < lim], ref_tags[ref_tags["index"] < lim], rtol=3e-4)
+        assert int((ref_tags["index"] < lim).sum()) >= 30
+
+
 def test_config3_channel_bank_every_packet_is_found(pkg):
     """the channels bench.py builds for configs[2] / [3] (channel c = its own burst stream, seed
     c, carrier offset -0.04 + 0.08 c / (C - 1) rad/sample) lie inside the +-4-bin search range: the detector finds every
