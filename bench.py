@@ -665,16 +665,29 @@ def config5_leg(pkg, device, total=1 << 30, window=1 << 28, passes=2):
         thr = 30.0 if b else 60.0
         sd = pkg.SyncwordDetection(rrc, SYNCWORD, bpsk, -b, b, fft_size=nfft, power_threshold=thr, max_items=window)
 
-        def one_pass():
+        def one_pass(indices=None):
             done = tags = 0
             for k, (pos, take) in enumerate(wins):
                 nxt = x[wins[k + 1][0]:wins[k + 1][0] + wins[k + 1][1]] if k + 1 < len(wins) else None
                 _, _, t, nd = sd.process_bulk(x[pos:pos + take], want_output=False, tags_cap=1 << 17, next_x=nxt)
                 assert nd == ((take - nfft) // S + 1) * S
+                if indices is not None:
+                    indices.append(t["index"].astype(np.int64) + pos)
                 done += nd
                 tags += t.size
             return done, tags
-        one_pass()
+        # the warm-up pass, outside the timed region, is also the check that the measured path does the detector's work:
+        # every burst config5_stream placed (a syncword every 16384 symbols from symbol 2000) is found at 2T + 1 + 4 x
+        # its symbol index, and the detections beside them (plain data, see the threshold note above) stay under 2 %
+        idx = []
+        done0, _ = one_pass(idx)
+        idx = np.concatenate(idx)
+        bursts = 1537 + 4 * np.arange(2000, total // 4 - 64, 16384)
+        bursts = bursts[bursts < done0 - 1537]
+        found = int(np.isin(bursts, idx).sum())
+        if found != bursts.size or idx.size - found > 0.02 * bursts.size:
+            raise SystemExit(f"bench.py: config5 at {2 * b + 1} bins: {found} of {bursts.size} bursts found, "
+                             f"{idx.size - found} other detections: the measured path does not do the detector's work")
         sd.reset()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -701,7 +714,8 @@ def config5_leg(pkg, device, total=1 << 30, window=1 << 28, passes=2):
         fl = correlator_flops_per_sample(2 * b + 1, nfft, S) * samples / (ms * 1e-3) / 1e12
         per_bins[str(2 * b + 1)] = {
             "value": round(done / dt / 1e6, 2), "unit": "Msamples/s", "ms_per_2^30": round(dt / passes * 1e3, 3),
-            "tags_per_2^30": tags // passes, "power_threshold": thr,
+            "tags_per_2^30": tags // passes, "bursts_in_2^30": int(bursts.size), "bursts_found": found,
+            "power_threshold": thr, "reference_default_power_threshold": 9.5,
             "roofline": {"bound": "hbm", "kernel": "k_correlate_4096", "launch_ms": round(ms, 4), "samples_per_launch": samples,
                          "achieved": round(8.0 * samples / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(8.0 * samples / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "alg_bytes_per_sample": 8,

@@ -167,6 +167,20 @@ __global__ __launch_bounds__(64) void k_rot_checkpoints(const RotSeg* __restrict
     const RotSeg* gp = segs + s;
     cf e, inc;
     unsigned counter;
+    if (gp->mode == 2) {
+        // a fixed point of the recurrence (see gr4pm_rotator::fixed): no chain; k_rot_const_fill writes the checkpoints
+        seg_incr[s] = gp->incr;
+        seg_counter0[s] = 0;
+        if (gp->last) {
+            RotState st;
+            st.exp = gp->exp0;
+            st.incr = gp->incr;
+            st.counter = 0; // (irrelevant while the phasor is fixed; the next set_freq() resets it)
+            st.pad = 0;
+            state_next[gp->channel] = st;
+        }
+        return;
+    }
     if (gp->mode == 0) {
         const RotState* st = state + gp->channel;
         e = st->exp;
@@ -222,6 +236,19 @@ __global__ __launch_bounds__(64) void k_rot_checkpoints(const RotSeg* __restrict
         st.pad = 0;
         state_next[gp->channel] = st; // ping-pong: another lane may still have to read `state`
     }
+}
+
+// the checkpoints of the segments whose phasor is a fixed point of the recurrence (RotSeg::mode == 2): the constant
+__global__ __launch_bounds__(256) void k_rot_const_fill(const RotSeg* __restrict__ segs, const unsigned* __restrict__ list,
+                                                        cf* __restrict__ ck)
+{
+    const RotSeg* g = segs + list[blockIdx.y];
+    const unsigned long long n = (g->len + kRotChunk - 1) / kRotChunk;
+    const cf e = g->exp0;
+    cf* dst = ck + g->ck0;
+    for (unsigned long long i = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+         i += static_cast<unsigned long long>(gridDim.x) * blockDim.x)
+        dst[i] = e;
 }
 
 // parallel: one lane per SAMPLE (coalesced 8-byte accesses); the lane replays at most
@@ -1597,6 +1624,17 @@ struct gr4pm_rotator {
     std::vector<unsigned long long> mc_host;
     std::vector<float> next_freq;     // per channel, coarse_frequency_correction.hpp:44
     std::vector<long> next_freq_delay; // :45
+    // Per channel: the carried phasor is a fixed point of the recurrence -- exp = (1, -+0) with incr = (1, -+0): every
+    // product e * incr gives e again and the renormalisation divides by hypot(1, 0) = 1.  That is the state of a
+    // CoarseFrequencyCorrection from start() to its first syncword_freq tag (set_freq(0) on the first item,
+    // coarse_frequency_correction.hpp:44-45,84-86), after every tag whose frequency is exactly 0, and of a Rotator with
+    // phase_incr 0: the stream the reference publishes its receiver benchmark on (zeros: no tag, ever) and every
+    // stream until its first detection.  Such a segment needs no serial chain: its checkpoints are the constant
+    // (k_rot_const_fill, parallel), the consumers multiply by it as before -- the same bits (x * (1, -0) is not a
+    // copy: it turns -0 into +0 in places, as the reference's multiplication does).
+    std::vector<uint8_t> fixed;
+    std::vector<cf> fixed_exp, fixed_incr;
+    DevBuf<unsigned> const_list;
 };
 
 static gr4pm_status rotator_reset_impl(gr4pm_rotator* h)
@@ -1617,6 +1655,10 @@ static gr4pm_status rotator_reset_impl(gr4pm_rotator* h)
     h->st_cur = 0;
     h->next_freq.assign(h->n_channels, 0.0f);
     h->next_freq_delay.assign(h->n_channels, 0); // :45 -> set_freq(0) on the first item
+    // (a Rotator whose increment is (1, +-0) never leaves exp = (1, +0); a CFC starts with set_freq(0) on item 0)
+    h->fixed.assign(h->n_channels, h->mode == 0 && st[0].incr.x == 1.0f && st[0].incr.y == 0.0f ? 1 : 0);
+    h->fixed_exp.assign(h->n_channels, st[0].exp);
+    h->fixed_incr.assign(h->n_channels, st[0].incr);
     return GR4PM_OK;
 }
 
@@ -1669,6 +1711,7 @@ static gr4pm_status rotator_plan(gr4pm_rotator* h, size_t n, const gr4pm_tag* ta
                                  size_t n_tags, std::vector<RotSeg>& segs, bool ring = false)
 {
     unsigned ck = 0;
+    size_t n_const = 0;
     for (size_t c = 0; c < h->n_channels; ++c) {
         // set_freq events (item, freq) of this channel: coarse_frequency_correction.hpp:76-96
         struct Ev {
@@ -1706,6 +1749,7 @@ static gr4pm_status rotator_plan(gr4pm_rotator* h, size_t n, const gr4pm_tag* ta
         // pieces of this channel: [0, first event) continues the carried phasor; every event
         // starts a piece with a fresh phasor (set_freq resets _exp and _counter, :55-58)
         size_t pos = 0;
+        static const bool no_fixed = getenv("GR4PM_ROT_NO_FIXED_POINT") != nullptr; // A/B: every segment as a chain
         auto push = [&](size_t start, size_t end, int mode, float freq) {
             if (end <= start) return;
             RotSeg g{};
@@ -1719,6 +1763,16 @@ static gr4pm_status rotator_plan(gr4pm_rotator* h, size_t n, const gr4pm_tag* ta
                 const float d = static_cast<float>(h->delay);
                 g.exp0 = { std::cos(freq * d), -std::sin(freq * d) };
                 g.incr = { std::cos(freq), -std::sin(freq) };
+                // exp0 = (1, -+0), incr = (1, -+0) (freq = +-0): e * incr == e for ever
+                h->fixed[c] = g.exp0.x == 1.0f && g.exp0.y == 0.0f && g.incr.x == 1.0f && g.incr.y == 0.0f;
+                h->fixed_exp[c] = g.exp0;
+                h->fixed_incr[c] = g.incr;
+            }
+            if (h->fixed[c] && !no_fixed) { // (mode 0: the carried phasor is the fixed point)
+                g.mode = 2;
+                g.exp0 = h->fixed_exp[c];
+                g.incr = h->fixed_incr[c];
+                n_const += 1;
             }
             ck += static_cast<unsigned>((g.len + kRotChunk - 1) / kRotChunk);
             segs.push_back(g);
@@ -1780,6 +1834,22 @@ static gr4pm_status rotator_plan(gr4pm_rotator* h, size_t n, const gr4pm_tag* ta
                            h->state.p + static_cast<size_t>(h->st_cur) * h->n_channels,
                            h->state.p + static_cast<size_t>(h->st_cur ^ 1) * h->n_channels,
                            pl.ck.p, pl.seg_incr.p, pl.seg_counter0.p, pl.order.p);
+    if (n_const) {
+        static thread_local std::vector<unsigned> list;
+        list.clear();
+        unsigned long long longest = 0;
+        for (unsigned i = 0; i < n_segs; ++i)
+            if (segs[i].mode == 2) {
+                list.push_back(i);
+                longest = std::max(longest, segs[i].len);
+            }
+        GR4PM_TRY(upload_vec(h->const_list, list, s));
+        const unsigned gx = static_cast<unsigned>(std::min<unsigned long long>((longest / kRotChunk + 255) / 256 + 1, 2048));
+        for (size_t first = 0; first < list.size(); first += 65535) {
+            const unsigned rows = static_cast<unsigned>(std::min<size_t>(65535, list.size() - first));
+            hipLaunchKernelGGL(k_rot_const_fill, dim3(gx, rows), dim3(256), 0, s, pl.segs.p, h->const_list.p + first, pl.ck.p);
+        }
+    }
     GR4PM_HIP_TRY(hipGetLastError());
     h->st_cur ^= 1;
     return GR4PM_OK;

@@ -1694,6 +1694,70 @@ def test_fused_cfc_symbol_filter_equals_separate_blocks(pkg):
     assert np.array_equal(bits(yb), bits(want)) and np.array_equal(tb["index"], want_tags["index"])
 
 
+def test_cfc_fixed_point_before_the_first_tag_and_at_zero_frequency(pkg):
+    """coarse_frequency_correction.hpp:44-45,50-59,84-86: from start() to the first syncword_freq tag -- and after every
+    tag whose frequency is exactly 0 -- the phasor is (1, -+0) with increment (1, -+0): a fixed point of the recurrence.
+    Those segments get no serial chain (RotSeg mode 2: constant checkpoints by a parallel fill; on the stream the
+    reference publishes its receiver benchmark on, zeros without a tag, that is everything), and the consumers still
+    MULTIPLY by the constant, so the bits are the reference's: x * (1, -0) turns -0 into +0 in places and the test
+    stream is full of signed zeros.  Against the oracle: a stream whose first tag comes after 2^24 samples, then tags
+    with frequencies != 0, == +0 and == -0 at ragged distances, in one call and in calls cut inside fixed and chained
+    stretches; CoarseFrequencyCorrection alone (delay 0 and 26), the fused CFC + SymbolFilter call of the receiver,
+    and Rotator(0)."""
+    rrc, pfb = _receiver_pfb()
+    rng = np.random.default_rng(2024)
+    n = (1 << 24) + (1 << 18)
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    z = rng.integers(0, 16, n)
+    x.real[z == 0] = 0.0
+    x.real[z == 1] = -0.0
+    x.imag[z == 2] = 0.0
+    x.imag[z == 3] = -0.0
+    x[z == 4] = np.complex64(complex(-0.0, -0.0))
+    first = (1 << 24) + 777
+    idx = np.array([first, first + 9000, first + 9030, first + 40000, first + 90000, first + 90003, first + 150000,
+                    first + 200000], dtype=np.uint64)
+    fr = np.array([0.011, 0.0, -0.02, -0.0, 0.0, 0.03, 0.0, -0.0])
+    tags = np.zeros(idx.size, dtype=pkg.TAG_DTYPE)
+    tags["index"], tags["freq"], tags["flags"] = idx, fr, pkg.TAG_SYNCWORD
+    tags["amplitude"], tags["time_est"] = 1.0, rng.uniform(-0.5, 0.5, idx.size)
+    xd = dev(x)
+    cuts = [0, 1 << 23, first - 5, first + 9010, first + 100000, n]
+    for delay in (0, 26):
+        want = orc.coarse_frequency_correction(x, idx, fr, delay=delay)
+        assert not np.array_equal(bits(want[: 1 << 20]), bits(x[: 1 << 20]))  # (not a copy: the signed zeros)
+        assert np.array_equal(want[: 1 << 20], x[: 1 << 20])                  # (... but the same values)
+        y = host(pkg.CoarseFrequencyCorrection(delay).process_bulk(xd, tags))
+        assert np.array_equal(bits(y), bits(want)), delay
+        cfc, outs = pkg.CoarseFrequencyCorrection(delay), []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            t = tags[(tags["index"] >= a) & (tags["index"] < b)].copy()
+            t["index"] -= a
+            outs.append(host(cfc.process_bulk(xd[a:b], t)))
+        assert np.array_equal(bits(np.concatenate(outs)), bits(want)), delay
+    # the receiver's fused call (CFC delay 26 -> 32-arm SymbolFilter)
+    want, want_tags, _ = orc.symbol_filter(orc.coarse_frequency_correction(x, idx, fr, delay=26), pfb, 32, 4, 44,
+                                           tags=tags.astype(orc.TAG_DTYPE))
+    cfc, sf, ys, ts, off = pkg.CoarseFrequencyCorrection(26), pkg.SymbolFilter(pfb, 32, 4, 44), [], [], 0
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        t = tags[(tags["index"] >= a) & (tags["index"] < b)].copy()
+        t["index"] -= a
+        y, tt, c = pkg.cfc_symbol_filter(cfc, sf, xd[a:b], t)
+        assert c == b - a
+        tt = tt.copy()
+        tt["index"] += off
+        off += y.numel()
+        ys.append(host(y))
+        ts.append(tt)
+    assert np.array_equal(bits(np.concatenate(ys)), bits(want))
+    assert np.array_equal(np.concatenate(ts)["index"], want_tags["index"])
+    # Rotator with phase_incr 0 (rotator.hpp:44-65): exp stays (1, +0)
+    m = 1 << 20
+    r = pkg.Rotator(0.0)
+    got = np.concatenate([host(r.process_bulk(xd[:m // 3])), host(r.process_bulk(xd[m // 3:m]))])
+    assert np.array_equal(bits(got), bits(orc.rotator(x[:m], np.float32(0.0))))
+
+
 def test_cfc_symbol_filter_plan_then_run_equals_fused_call(pkg):
     """gr4pm_cfc_symbol_filter_plan + _run (the two pipeline stages of the native receiver) ==
     gr4pm_cfc_symbol_filter_process, bit for bit, also when the plan of the next call is made
