@@ -816,6 +816,100 @@ def host_stream_leg(pkg, device, rrc, chunk=1 << 25, host_chunks=4, total=1 << 2
             "note": "PCIe-inclusive; not `value` (inputs of the headline are resident in HBM when the timed region starts)"}
 
 
+def sparse_leg(pkg, device, rrc, n=1 << 28, passes=3):
+    """What packet density does to the rate (never `value`): the whole receiver in decode_headers mode -- the reference's
+    PacketReceiver wiring, IQ in, CRC-checked packets out; what benchmarks/benchmark_packet_receiver.cpp runs -- over 2^28
+    resident samples of (i) zeros (that benchmark's own input, benchmarks/README.md:49-53, results.md:45-51: 6-8 Msps
+    at nine templates on eight CPU cores), (ii) AWGN only, (iii) one 1500-byte packet per 2^20 samples in AWGN (Es/N0 20
+    dB).  The frequency correction's phasor and the Costas loop are recurrences that are replayed in the reference's
+    rounding: a stretch between two syncword tags is ONE serial chain.  (i) and (ii) never see a tag: the phasor sits at
+    its fixed point (1, -0) (no chain at all) and PayloadMetadataInsert passes no symbol on to the Costas loop.  (iii): 256
+    chains of 2^20 items side by side per pass.  `detector_alone` is SyncwordDetection on the same stream;
+    `behind_the_detector_share` = 1 - detector_alone time / receiver time, i.e. the share of the serial part."""
+    hist = 2 * 768 + 1
+    bpsk = np.array([1, -1], dtype=np.complex64)
+    rows = {}
+    g = torch.Generator(device=device)
+    g.manual_seed(99)
+
+    def make(kind):
+        if kind == "zeros":
+            return torch.zeros(n, dtype=torch.complex64, device=device), 0
+        sigma = np.float32(np.sqrt(0.1 / 2.0))  # the headline stream's noise floor (Es/N0 = 10 dB at Es = 1)
+        if kind == "awgn":
+            return torch.complex(torch.randn(n, generator=g, device=device) * sigma,
+                                 torch.randn(n, generator=g, device=device) * sigma).contiguous(), 0
+        gen = pkg.BurstGenerator()
+        period = 1 << 20
+        n_pkt = n // period
+        rng = np.random.default_rng(5)
+        payloads = [rng.integers(0, 256, 1500, dtype=np.uint8).tobytes() for _ in range(n_pkt)]
+        burst = (64 + 128 + 1504 * 4 + gen.RAMP_DOWN + gen.FLUSH) * SPS
+        x = gen.stream(payloads, np.full(n_pkt, period - burst), freq_error=0.01, esn0_db=20.0, seed=6, tail=0,
+                       carrier="closed_form")
+        return x[:n].contiguous(), n_pkt
+
+    for kind in ("zeros", "awgn", "one_packet_per_2^20"):
+        x, n_pkt = make(kind)
+        ring = torch.empty(hist + 1 + n, dtype=torch.complex64, device=device)
+        ring[1:1 + hist] = x[-hist:]
+        ring[1 + hist:] = x
+        w, history = ring[1 + hist:], ring[1:1 + hist]
+        del x
+        rx = pkg.NativePacketReceiver(SPS, BINS, 9.5, "QPSK", max_items=n, tags_cap=max(4096, 4 * n_pkt), pipelined=True,
+                                      decode_headers=True, output_ring=True)
+        stats = {"consumed": 0, "tags": 0, "packets_crc_ok": 0}
+
+        def note(r):
+            if r is not None:
+                stats["consumed"] += r["consumed"]
+                stats["tags"] += int(r["tags"].size)
+                stats["packets_crc_ok"] += int(np.sum(r["packet_lengths"] > 0))
+
+        def run(k):
+            for i in range(k):
+                if i + 1 < k:
+                    rx.announce(w)
+                note(rx.process_bulk(w, None, history=history))
+            for r in rx.flush():
+                note(r)
+        run(2)
+        stats = {"consumed": 0, "tags": 0, "packets_crc_ok": 0}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(passes)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        del rx
+        sd = pkg.SyncwordDetection(rrc, SYNCWORD, bpsk, -BINS, BINS, power_threshold=9.5, max_items=n)
+        for _ in range(2):
+            sd.process_bulk(w, want_output=False, tags_cap=max(4096, 4 * n_pkt))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        done = 0
+        for _ in range(passes):
+            done += sd.process_bulk(w, want_output=False, tags_cap=max(4096, 4 * n_pkt))[3]
+        torch.cuda.synchronize()
+        dt_sd = (time.perf_counter() - t1) * stats["consumed"] / max(done, 1)
+        del sd, ring, w, history
+        torch.cuda.empty_cache()
+        if kind != "one_packet_per_2^20" and (stats["tags"] or stats["packets_crc_ok"]):
+            raise SystemExit(f"bench.py: sparse leg {kind}: {stats['tags']} tags on a stream without a packet")
+        if kind == "one_packet_per_2^20" and stats["packets_crc_ok"] < passes * (n_pkt - 2):
+            raise SystemExit(f"bench.py: sparse leg: {stats['packets_crc_ok']} of {passes * n_pkt} packets came back")
+        rows[kind] = {"value": round(stats["consumed"] / dt / 1e6, 2), "unit": "Msamples/s",
+                      "ms_per_2^28": round(dt / passes * 1e3, 3), "tags_per_2^28": stats["tags"] // passes,
+                      "packets_crc_ok_per_2^28": stats["packets_crc_ok"] // passes,
+                      "detector_alone": round(stats["consumed"] / dt_sd / 1e6, 2),
+                      "behind_the_detector_share": round(max(0.0, 1.0 - dt_sd / dt), 3)}
+    return {"workload": "whole receiver (decode_headers: IQ in, CRC-checked packets out), 2^28 resident samples per pass, "
+                        "nine templates: zeros (the reference's benchmark_packet_receiver input) / AWGN only / one "
+                        "1500-byte packet per 2^20 samples",
+            "reference_benchmark_packet_receiver_msps_ryzen_5800x": "6-8 (nine templates) ... 28-32 (one)",
+            "streams": rows,
+            "note": "not `value`: the headline is the packet-dense stream of configs[1]"}
+
+
 def headline_ring(x, xb):
     """the headline's device ring [.. | window A | window B]: two different stretches of the burst stream that the steps
     present alternately, each preceded in memory by the 2T+1 items "before" it (for A: a copy of B's tail, for B: A's
@@ -1050,6 +1144,8 @@ def main():
                          "shape (N = 4096 overlap-save blocks, 1025-tap RRC, SyncwordDetection + the 1025-tap filter leg)")
     ap.add_argument("--no-config5-leg", action="store_true",
                     help="leave out the configs[4] sub-record (2^30 samples, fft_size 4096, 1025-tap RRC) of the default line")
+    ap.add_argument("--no-sparse-leg", action="store_true",
+                    help="skip the packet-density sub-record (whole receiver on zeros / AWGN only / one packet per 2^20 samples)")
     ap.add_argument("--no-host-stream-leg", action="store_true",
                     help="skip the PCIe-inclusive sub-record (front end fed from pinned host memory)")
     ap.add_argument("--no-per-bins", action="store_true",
@@ -1325,6 +1421,11 @@ def main():
     if headline and not args.no_host_stream_leg and world == 1:
         host_stream_rec = host_stream_leg(pkg, device, rrc)
         torch.cuda.empty_cache()
+    # ---- packet density: the whole receiver on zeros / AWGN / one packet per 2^20 samples (N = 1 only; never `value`)
+    sparse_rec = None
+    if headline and not args.no_sparse_leg and world == 1:
+        sparse_rec = sparse_leg(pkg, device, rrc)
+        torch.cuda.empty_cache()
     job = rank_identities(dist, device, world)
     check_distinct_devices(job, world)
 
@@ -1414,6 +1515,8 @@ def main():
             line["config5"] = config5_rec
         if host_stream_rec is not None:
             line["host_stream"] = host_stream_rec
+        if sparse_rec is not None:
+            line["sparse"] = sparse_rec
         if channels_leg is not None:
             if world > 1:
                 # 64 channels per GPU are the same work on every rank: the per-GPU rate of configs[3] should be the
