@@ -278,16 +278,32 @@ def scatter_channels(dist, make_all, n_items, device, rank, world):
     mine_f = torch.view_as_real(mine)  # interleaved float32 pairs: every backend moves floats
     via_host = dist.get_backend() == "gloo" and device.type == "cuda"  # the shared-device test: gloo scatters host tensors
     recv = torch.empty(shape + (2,), dtype=torch.float32) if via_host else mine_f
+    parts = None
     if rank == 0:
         allx = make_all()
         assert tuple(allx.shape) == (world,) + shape
         parts = [torch.view_as_real(allx[r].contiguous()) for r in range(world)]
-        dist.scatter(recv, [p.cpu() for p in parts] if via_host else parts, src=0)
-    else:
-        dist.scatter(recv, None, src=0)
+        if via_host:
+            parts = [p.cpu() for p in parts]
+    # the collective alone, between two barriers (filling rank 0's ring is not the scatter's time)
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    dist.scatter(recv, parts, src=0)
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
     if via_host:
         mine_f.copy_(recv)
+    nbytes = 8 * int(np.prod(shape)) * (world - 1)  # what leaves rank 0 (its own part stays)
+    LAST_SCATTER.update(seconds=round(dt, 4), bytes_from_rank0=nbytes, gbs=round(nbytes / dt / 1e9, 2),
+                        backend=dist.get_backend())
     return mine
+
+
+LAST_SCATTER = {}
 
 
 def aggregate(dist, dt, consumed, device):
@@ -303,6 +319,19 @@ def aggregate(dist, dt, consumed, device):
     csum = torch.tensor([consumed], dtype=torch.float64, device=device)
     dist.all_reduce(csum, op=dist.ReduceOp.SUM)
     return tmax.item(), csum.item()
+
+
+def per_rank(dist, value, device):
+    """every rank's own number (a region's time, ...) in rank order, on every rank: the line shows which GPU of a job was
+    the slow one instead of only the MAX"""
+    if dist is None:
+        return [float(value)]
+    if dist.get_backend() == "gloo":
+        device = torch.device("cpu")
+    mine = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    every = [torch.zeros(1, dtype=torch.float64, device=device) for _ in range(dist.get_world_size())]
+    dist.all_gather(every, mine)
+    return [float(t.item()) for t in every]
 
 
 def launch_ranks(n, selfcheck_first=True):
@@ -492,11 +521,13 @@ def dry_run(args):
         ok = torch.tensor([1.0 if bool((mine == complex(rank, 1)).all()) else 0.0], dtype=torch.float64)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         scattered_ok = bool(ok.item() == 1.0)
+    every = per_rank(dist if world > 1 else None, 1.0 + rank, device)
     dt, total = aggregate(dist if world > 1 else None, 1.0 + rank, 1000.0 * (rank + 1), device)
     ids = rank_identities(dist if world > 1 else None, device, world)
     if rank == 0:
         print(json.dumps({"metric": "dry-run", "value": total / dt, "n_gpus": world, "gpus_requested": args.gpus,
-                          "steps": args.steps, "warmup": args.warmup, "scatter_ok": scattered_ok, "job": ids}))
+                          "steps": args.steps, "warmup": args.warmup, "scatter_ok": scattered_ok,
+                          "ms_per_step_per_rank": every, "scatter": dict(LAST_SCATTER) or None, "job": ids}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -1019,6 +1050,7 @@ def channels64_leg(pkg, dist, device, rank, world, rrc, steps, warmup, repeats, 
     rank then runs its 64 channels through gr4pm_multichannel_receiver (one batched detector + every channel's own
     chain, submit / collect with four batches in flight, input read in place).  Timed like the headline region."""
     n_pkt = (n_items // SPS + 64) // (64 + 128 + 1504 * 4 + 500) + 1  # packets per channel and batch (burst_stream)
+    scatter_rec = None
     if dist:
         scatter_budget(dist, rank, world, 8 * n_items * channels, device, host_ring=True)
 
@@ -1028,6 +1060,7 @@ def channels64_leg(pkg, dist, device, rank, world, rrc, steps, warmup, repeats, 
                 host[r].copy_(channel_bank_config3(pkg, n_items, rrc, channels, device, seed0=1000 * (r + 1)))
             return host.to(device, non_blocking=False)
         xs = scatter_channels(dist, make_all, (channels, n_items), device, rank, world)
+        scatter_rec = dict(LAST_SCATTER)
         input_mode = f"rank 0 host sample ring [{world}, {channels}, {n_items}] -> all ranks, scatter ({dist.get_backend()})"
     else:
         xs = channel_bank_config3(pkg, n_items, rrc, channels, device, seed0=1000 * (rank + 1))
@@ -1061,7 +1094,7 @@ def channels64_leg(pkg, dist, device, rank, world, rrc, steps, warmup, repeats, 
     for i in range(warmup):
         step(warmup - 1 - i)
     drain()
-    rates, times = [], []
+    rates, times, rank_ms = [], [], []
     for _ in range(max(1, repeats)):
         torch.cuda.synchronize()
         if dist:
@@ -1077,7 +1110,9 @@ def channels64_leg(pkg, dist, device, rank, world, rrc, steps, warmup, repeats, 
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
-        dt, total = aggregate(dist, time.perf_counter() - t0, float(consumed), device)
+        own = time.perf_counter() - t0
+        rank_ms.append([round(v / steps * 1e3, 4) for v in per_rank(dist, own, device)])
+        dt, total = aggregate(dist, own, float(consumed), device)
         rates.append(total / dt / 1e6)
         times.append(dt)
         tags_per_step = state["tags"] // steps
@@ -1092,6 +1127,8 @@ def channels64_leg(pkg, dist, device, rank, world, rrc, steps, warmup, repeats, 
             "value": round(rates[med], 2), "unit": "Msamples/s", "steps": steps, "warmup": warmup,
             "ms_per_step": round(times[med] / steps * 1e3, 4), "repeats": len(rates), "tags_per_step": tags_per_step,
             "value_min": round(min(rates), 2), "value_max": round(max(rates), 2), "input": input_mode,
+            "ms_per_step_per_rank": rank_ms[med],
+            **({"scatter": scatter_rec} if scatter_rec else {}),
             **({"latency": latency} if latency else {})}
 
 
@@ -1121,7 +1158,10 @@ def main():
     ap.add_argument("--copy-delay", action="store_true",
                     help="materialise SyncwordDetection's delayed output instead of reading the ring in place")
     ap.add_argument("--no-scatter", action="store_true",
-                    help="N > 1: let every rank generate its own channel instead of the RCCL scatter from rank 0")
+                    help="N > 1, --channels: let every rank generate its own channels instead of the scatter from rank 0")
+    ap.add_argument("--scatter-headline", action="store_true",
+                    help="N > 1: rank 0 generates every rank's headline channel and scatters them (rounds 1-4); by "
+                         "default every rank generates its own and only the configs[3] host sample ring is scattered")
     ap.add_argument("--lookahead-depth", type=int, default=None,
                     help="how many calls ahead the detector's front part (correlator, candidates, tables) is launched "
                          "(max 2; default 2, and 1 with --channels: the multi-channel receiver is synchronous, a second "
@@ -1234,12 +1274,17 @@ def main():
             xs_bank = scatter_channels(dist, make_all, (args.channels, n_items), device, rank, world)
             input_mode = (f"rank 0 host sample ring [{world}, {args.channels}, {n_items}] -> all ranks, "
                           f"torch.distributed scatter ({dist.get_backend()})")
-        else:
+        elif args.scatter_headline:
             def make_all():
                 chans = [x] + [make_stream(1 + r)[0] for r in range(1, world)]
                 return torch.stack(chans)
             x = scatter_channels(dist, make_all, n_items, device, rank, world)
             input_mode = f"rank 0 -> all ranks, torch.distributed scatter ({dist.get_backend()})"
+        else:
+            # the headline's one channel per GPU is generated where it is used, seeded by the rank (rank 0 building
+            # N x 2 GiB one after the other while N - 1 ranks wait was serial start-up for nothing); the scatter of
+            # SURVEY 8(e) -- rank 0's HOST sample ring to every GPU -- is the configs[3] leg's (channels64_leg)
+            input_mode = "generated on each GPU (seed = 1 + rank); the host sample ring's scatter is the config3 leg's"
     # the stream lives in a device ring [.. | window A | window B]: two different stretches of the
     # burst stream that the steps present alternately, each preceded in memory by the 2T+1 items
     # "before" it (for A: a copy of B's tail, for B: A's tail itself).  While one window is being
@@ -1390,15 +1435,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        ranks_ms.append([round(v / args.steps * 1e3, 4) for v in per_rank(dist, dt, device)])
         dt, total = aggregate(dist, dt, float(consumed), device)
         return dt, total, n_tags
 
+    ranks_ms = []  # per region: every rank's own ms per step
     regions = [timed_region() for _ in range(max(1, args.repeats))]
     if not args.decode_headers:  # (packet_stream has its own period; its leg counts CRC-checked packets instead)
         for _, _, nt in regions:
             check_tag_count("headline region", nt, args.steps * max(args.channels, 1), n_items)
     by_rate = sorted(regions, key=lambda r: r[1] / r[0])
     dt, total, n_tags = by_rate[len(by_rate) // 2]  # the median region is the number of record
+    median_region = regions.index(by_rate[len(by_rate) // 2])
     region_rates = [round(r[1] / r[0] / 1e6, 2) for r in regions]
 
     # ---- 64 channels per GPU (configs[2] at N = 1, configs[3] = 64 x N channels at N > 1), after the headline
@@ -1482,6 +1530,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "repeats": len(regions), "value_min": min(region_rates), "value_max": max(region_rates),
             "values": region_rates,
+            "ms_per_step_per_rank": ranks_ms[median_region],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

@@ -164,6 +164,7 @@ inline size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
 // through these helpers; a switch that makes a call return GR4PM_OK with WRONG OUTPUTS (kernels left out or replaced
 // by stand-ins: GR4PM_TIMING_SKIP, GR4PM_SYMF_ABL, GR4PM_FAKE ...) says so on stderr the first time it is seen, so a
 // variable that leaked into a production environment cannot go unnoticed.
+void sd_set_coresident(struct ::gr4pm_syncword_detection* h, bool on); // syncword_detection.hip: see launch_correlate
 const char* experiment_env(const char* name, bool wrong_results); // nullptr when unset
 unsigned experiment_env_wg(const char* name, unsigned fallback, unsigned lo, unsigned hi); // clamped to [lo, hi]
 

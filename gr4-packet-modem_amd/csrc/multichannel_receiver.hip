@@ -354,6 +354,7 @@ try {
     sp.stream = h->sd_stream;
     gr4pm_status st = gr4pm_syncword_detection_create(&sp, &h->sd);
     if (st != GR4PM_OK) return bail(st);
+    gr4pm::sd_set_coresident(h->sd, true);
     const size_t arms = 32;
     std::vector<float> pfb(((arms * sps * 11) | 1));
     const size_t n_pfb = gr4pm_firdes_root_raised_cosine(static_cast<double>(arms) / static_cast<double>(norm),

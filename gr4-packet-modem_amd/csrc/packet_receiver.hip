@@ -1031,6 +1031,7 @@ try {
     sp.stream = h->streams[0];
     gr4pm_status st = gr4pm_syncword_detection_create(&sp, &h->sd); // :76-83
     if (st != GR4PM_OK) return bail(st);
+    gr4pm::sd_set_coresident(h->sd, true);
     h->hist = 2 * 768 + 1;
     gr4pm_syncword_detection_filter_params fp{ sps, 64, 128, h->streams[1] }; // :84-85
     if ((st = gr4pm_syncword_detection_filter_create(&fp, &h->sdf)) != GR4PM_OK) return bail(st);

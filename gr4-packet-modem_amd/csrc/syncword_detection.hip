@@ -1611,7 +1611,8 @@ struct gr4pm_syncword_detection {
     DevBuf<cf> cc64;
     int n_cus = 256;
     int w64_variant = -1;
-    int w64_one = 0; // GR4PM_W64_ONE at creation
+    int w64_one = -1; // GR4PM_W64_ONE at creation; -1 (unset): the one-bin kernel unless the handle shares its CUs
+    bool coresident = false; // set by the receivers: kernels of other pipeline stages run beside the correlator
     uint32_t w64_blocks_per_wave = 6; // blocks per wave and workgroup (handed out dynamically); 0: persistent waves (GR4PM_W64_BLOCKS_PER_WAVE)
     // raised by a correlator kernel whose bounded hand-off spin ran out ("wave" / "pair" kernels; k_correlate_w64
     // has no spins); checked after the stream synchronisation of process()
@@ -1753,6 +1754,15 @@ void finish_tag(const gr4pm_syncword_detection* h, const RawTag& t, uint64_t out
     o->flags = GR4PM_TAG_SYNCWORD;
 }
 
+} // namespace
+namespace gr4pm {
+// (library-internal, common.hpp) the receivers tell their detector that it shares the CUs with the rest of the chain
+void sd_set_coresident(gr4pm_syncword_detection* h, bool on)
+{
+    if (h) h->coresident = on;
+}
+} // namespace gr4pm
+namespace {
 gr4pm_status launch_correlate(gr4pm_syncword_detection* h, hipStream_t stream, const gr4pm_c64* in,
                               size_t in_stride, uint32_t n_blocks, float* zout)
 {
@@ -1813,8 +1823,11 @@ gr4pm_status launch_correlate(gr4pm_syncword_detection* h, hipStream_t stream, c
         const bool prune = h->S <= 1793 && !h->w64_no_prune;
         // one frequency bin: GR4PM_W64_ONE=1 runs the three-waves-per-SIMD kernel of correlate_w64_one.hpp instead of the
         // general one (bit-identical powers, the same launch time: HISTORY.md section 3a; 2, 3: its timing-only ablations)
+        // A stand-alone SyncwordDetection with min_freq_bin == max_freq_bin has the chip to itself: the dedicated kernel
+        // (12 waves per CU, 4 % faster alone, bit-identical) is the default.  Inside a receiver the general kernel
+        // stays: the one-bin kernel leaves 14 VGPRs per SIMD and nothing of the chain fits beside it.
         const int one_mode = h->w64_one;
-        const bool one_off = one_mode == 0;
+        const bool one_off = one_mode == 0 || (one_mode < 0 && h->coresident);
         if (h->n_bins == 1 && prune && h->w64_variant < 0 && !one_off) {
             const uint32_t wgs1 = bpw ? (total + kW1Waves * bpw - 1) / (kW1Waves * bpw)
                                       : std::min<uint32_t>(static_cast<uint32_t>(h->n_cus), (total + kW1Waves - 1) / kW1Waves);
@@ -2139,7 +2152,7 @@ try {
             else fprintf(stderr, "[gr4pm] GR4PM_C4096_VARIANT=%s is not one of 0 .. 7: using the default (1)\n", cv);
         }
         const char* one = getenv("GR4PM_W64_ONE");
-        h->w64_one = one ? atoi(one) : 0;
+        h->w64_one = one ? atoi(one) : -1;
         if (h->w64_one > 1 && !experiment_env("GR4PM_W64_ONE", true)) h->w64_one = 1;
         if (const char* b = getenv("GR4PM_W64_BLOCKS_PER_WAVE")) h->w64_blocks_per_wave = static_cast<uint32_t>(std::max(0, atoi(b)));
         int dev = 0;

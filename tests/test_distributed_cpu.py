@@ -78,7 +78,7 @@ def test_bench_launcher_starts_one_process_per_gpu():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["gpus_requested"] == 2
     assert line["value"] == 3000.0 / 2.0   # SUM of items / MAX of times
-    assert line["scatter_ok"] is True
+    assert line["scatter_ok"] is True and line["ms_per_step_per_rank"] == [1.0, 2.0]
     job = line["job"]
     assert job["backend"] == "gloo" and job["world"] == 2 and [r["rank"] for r in job["ranks"]] == [0, 1]
     assert len({r["pci_bus_id"] for r in job["ranks"]}) == 2   # two different processes took part
@@ -135,6 +135,10 @@ def test_bench_launcher_at_world_size_4_and_8(world):
     line = json.loads(lines[0])
     assert line["n_gpus"] == world and line["scatter_ok"] is True
     assert line["value"] == 1000.0 * world * (world + 1) / 2 / world  # SUM of 1000 (r + 1) items / MAX of 1 + r seconds
+    # round 5: every rank's own time in the line (which GPU was the slow one), and the scatter's own time and rate
+    assert line["ms_per_step_per_rank"] == [1.0 + r for r in range(world)]
+    sc = line["scatter"]
+    assert sc["backend"] == "gloo" and sc["bytes_from_rank0"] == 8 * 64 * (world - 1) and sc["seconds"] > 0 and sc["gbs"] >= 0
     job = line["job"]
     assert job["world"] == world and [x["rank"] for x in job["ranks"]] == list(range(world))
     assert len({x["pci_bus_id"] for x in job["ranks"]}) == world

@@ -3149,9 +3149,13 @@ def test_bench_two_ranks_share_the_gpu_through_the_whole_n_gt_1_path(launcher):
     # both ranks' samples are in the sum: 3 steps x 2 ranks x (whole strides of 2^24 items)
     per_step = ((1 << 24) - 2048) // 1752 * 1752 + 1752
     assert abs(rec["value"] * 1e6 * rec["ms_per_step"] * 1e-3 * 3 / (3 * 2 * per_step) - 1.0) < 0.01
-    assert "scatter" in rec["config"]["input"]
+    # round 5: every rank generates its own headline channel (seeded by the rank), the line carries every rank's own time
+    assert "generated on each GPU" in rec["config"]["input"]
+    assert len(rec["ms_per_step_per_rank"]) == 2 and max(rec["ms_per_step_per_rank"]) == pytest.approx(rec["ms_per_step"], rel=1e-3)
     c3 = rec["config3"]
     assert c3["value"] > 0 and "128 channels in all" in c3["workload"] and "per_gpu" in c3
+    # ... and the host sample ring's scatter (the workload's one collective) its own time and rate
+    assert c3["scatter"]["bytes_from_rank0"] == 8 * 64 * (1 << 22) and c3["scatter"]["gbs"] > 0 and len(c3["ms_per_step_per_rank"]) == 2
 
 
 @pytest.mark.gpu
