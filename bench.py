@@ -750,7 +750,8 @@ def config5_leg(pkg, device, total=1 << 30, window=1 << 28, passes=2):
             "roofline": {"bound": "hbm", "kernel": "k_correlate_4096", "launch_ms": round(ms, 4), "samples_per_launch": samples,
                          "achieved": round(8.0 * samples / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(8.0 * samples / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "alg_bytes_per_sample": 8,
-                         "traffic": None, "fp32_tflops": round(fl, 2), "fp32_frac": round(fl / FP32_PEAK_TFLOPS, 4)}}
+                         "traffic": None, "fp32_tflops": round(fl, 2), "fp32_frac": round(fl / FP32_PEAK_TFLOPS, 4),
+                         "ceiling": roofline_ceiling(2 * b + 1, nfft, S)["frac"]}}
         del sd
     pfb = pkg.root_raised_cosine(32.0, 32.0 * SPS, 1.0, 0.35, 32 * 1024)[: 32 * 1025]
     sf = pkg.SymbolFilter(pfb, 32, SPS, delay=1025)
@@ -972,6 +973,25 @@ def correlator_flops_per_sample(n_bins, n_fft=N_FFT, stride=1752):
     return ((1 + n_bins) * 5.0 * n_fft * np.log2(n_fft) + 6.0 * n_bins * n_fft + 1.5 * n_fft + 4.0 * n_bins * stride) / stride
 
 
+HBM_ACHIEVABLE_GBS = 6300.0  # MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured (float4 copy)
+
+
+def roofline_ceiling(n_bins, n_fft=N_FFT, stride=1752):
+    """What `frac` (8 algorithmic bytes per sample over the 8 TB/s HBM peak) can be at most for an exact-FP32 FFT
+    correlator with n_bins templates on this chip: the arithmetic alone at the FP32 vector peak (SURVEY.md 8(d)'s flop
+    count), the real traffic alone (8 B read + 4 B zpow write per sample) at the HBM rate a streaming kernel reaches;
+    the smaller one is the ceiling.  north_star's >= 0.6 is above it at every bin count."""
+    # (nine bins at N = 2048: SURVEY.md 8(d) quotes 710 flop/sample, the figure `fp32_frac` of the headline is computed
+    # from; its own formula gives 744 -- the quoted figure is used where it exists, so that frac / ceiling = fp32_frac)
+    fl = 710.0 if (n_bins, n_fft, stride) == (9, N_FFT, 1752) else float(correlator_flops_per_sample(n_bins, n_fft, stride))
+    fp32_bound = float(FP32_PEAK_TFLOPS * 1e12 / fl * 8.0 / (HBM_PEAK_GBS * 1e9))
+    traffic_bound = HBM_ACHIEVABLE_GBS / 12.0 * 8.0 / HBM_PEAK_GBS
+    return {"fp32_bound_frac": round(fp32_bound, 4), "traffic_bound_frac": round(traffic_bound, 4),
+            "frac": round(min(fp32_bound, traffic_bound), 4),
+            "assumes": f"{fl:.0f} flop/sample at {FP32_PEAK_TFLOPS} TFLOP/s FP32 vector; 12 B/sample of real traffic at "
+                       f"{HBM_ACHIEVABLE_GBS / 1e3:.1f} TB/s achievable HBM"}
+
+
 def per_bins_roofline(pkg, rrc, bpsk, x, n_items, stream, reps=5):
     """the correlator alone for 1 / 3 / 5 / 7 / 9 templates (the rows the reference publishes,
     benchmarks/results.md:37-41): mean launch time (HIP events on the launch stream), fraction of the HBM roofline
@@ -993,7 +1013,8 @@ def per_bins_roofline(pkg, rrc, bpsk, x, n_items, stream, reps=5):
             fl = correlator_flops_per_sample(2 * b + 1) * samples / (ms * 1e-3) / 1e12
             out[str(2 * b + 1)] = {"launch_ms": round(ms, 4), "gsps": round(samples / ms / 1e6, 2),
                                    "frac": round(8.0 * samples / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                                   "fp32_tflops": round(fl, 2), "fp32_frac": round(fl / FP32_PEAK_TFLOPS, 4)}
+                                   "fp32_tflops": round(fl, 2), "fp32_frac": round(fl / FP32_PEAK_TFLOPS, 4),
+                                   "ceiling": roofline_ceiling(2 * b + 1)["frac"]}
             del sd
     return out
 
@@ -1512,7 +1533,9 @@ def main():
                     "launch_ms": round(ms, 4), "samples_per_launch": samples,
                     "alg_bytes_per_sample": 8,
                     "fp32_tflops": round(flops / (ms * 1e-3) / 1e12, 2),
-                    "fp32_frac": round(flops / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)}
+                    "fp32_frac": round(flops / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
+                    "ceiling": roofline_ceiling(2 * BINS + 1)}
+        roofline["frac_of_ceiling"] = round(roofline["frac"] / roofline["ceiling"]["frac"], 4)
         if args.channels == 1 and not args.no_per_bins:
             roofline["per_bins"] = per_bins_roofline(pkg, rrc, bpsk, x, n_items, roof_stream)
         # the CPU legs come after every GPU leg (256 busy host processes slow the GPU legs' launches), at N = 1 only
