@@ -133,10 +133,22 @@ __global__ __launch_bounds__(kT4k) void k_correlate_4096(const cf* __restrict__ 
         }
     }
     // lag k <-> correlation index (N - k) mod N (hpp:300); register j of thread t holds index t + 256 j
+    // Round 5 (as in k_correlate_w64): register j >= 1 holds the lags 4096 - 256 j - t <= 4096 - 256 j, so every register
+    // from jw = (4096 - stride_s) / 256 + 1 on is stored by every thread (configs[4]: stride 2820, jw = 5), register
+    // jw - 1 by the threads whose lag is below the stride, register 0 by thread 0 (lag 0) and nothing in between: one
+    // uniform branch per block instead of a lane compare, an exec mask and a branch around each of the 16 stores.
+    const uint32_t jw = (static_cast<uint32_t>(kN4k) - stride_s) / 256u + 1u;
+    if (jw == 5u && !(VAR & 16)) { // (VAR & 16: round 4's stores, for A/B)
+        if (t == 0) zo[0] = zmax[0];
+        if (static_cast<uint32_t>(kN4k - 1024 - t) < stride_s) zo[kN4k - 1024 - t] = zmax[4];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const uint32_t lag = static_cast<uint32_t>((kN4k - (t + 256 * j)) & (kN4k - 1));
-        if (lag < stride_s) zo[lag] = zmax[j];
+        for (int j = 5; j < 16; ++j) zo[kN4k - (t + 256 * j)] = zmax[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t lag = static_cast<uint32_t>((kN4k - (t + 256 * j)) & (kN4k - 1));
+            if (lag < stride_s) zo[lag] = zmax[j];
+        }
     }
     (void)n_blocks;
 }

@@ -207,7 +207,9 @@ __device__ __forceinline__ void w64_mid_dev_p(int lane, const float4* row, const
 // takes 0.176 ms); waves started at 8 .. 64 different offsets so that they do not ask HBM for their next block at
 // the same moment (0.846 .. 0.884 against 0.831 ms at nine bins: they are not in step to begin with); exchange stores
 // issued from inside the last stage of pass A (no change); (re, im) interleaved exchange rows written with
-// ds_write_b64 (0.82 against 0.78 ms); mid-stage and template reads further ahead (no change).
+// ds_write_b64 (0.82 against 0.78 ms); mid-stage and template reads further ahead (no change); round 5: the samples of
+// the next block requested eight at a time between the last bin's products instead of 32 in a row behind them (2.756
+// against 2.750 ms per 2^28 at nine bins, same box).
 // Timing-only ablations (wrong results; tools/w64_variants.py, HISTORY.md section 3): 8 no template DMA, 32 no
 // exchange stores, 64 no exchange / twiddle reads, 128 no template reads, 1024 no power / maximum, 2048 no power
 // stores, 4096 no sample loads after the first block.
@@ -470,14 +472,26 @@ __global__ __launch_bounds__(kW64Threads, 2) void k_correlate_w64(const cf* __re
             int ln = lane;
             asm volatile("" : "+v"(ln)); // no 32 hoisted lag registers
             float* zl = zo + (kFftN - ln); // lag of register j: 2048 - lane - 64 j (j = 0, lane = 0: lag 0)
+            // Round 5.  Register j >= 1 holds the lags 2048 - 64 j - lane <= 2048 - 64 j: with 1728 < stride_s (the
+            // receiver's 1752; the pruned variants run for stride_s <= 1793 only) registers 5 .. 31 are stored by every
+            // lane, register 4 by the lanes whose lag is below the stride and register 0 by lane 0 (lag 0).  One uniform
+            // branch per block instead of a lane compare, an exec mask, a branch around the store and a 64-bit address
+            // adjustment for each of the 29 stores (230 instructions and 29 branches per block: a third of a bin).
+            if ((VAR & 16384) && !(VAR & 262144) && stride_s > static_cast<uint32_t>(kFftN - 64 * 5)) {
+                if (ln == 0) zo[0] = zmax[0];
+                if (static_cast<uint32_t>(kFftN - 256 - ln) < stride_s) zl[-256] = zmax[4];
 #pragma unroll
-            for (int j = 0; j < 32; ++j) {
-                if ((VAR & 16384) && j >= 1 && j <= 3) continue; // lags >= 1793 > stride_s
-                const uint32_t lag = static_cast<uint32_t>((kFftN - (ln + 64 * j)) & (kFftN - 1));
-                if (j == 0) {
-                    if (lag < stride_s) zo[lag] = zmax[0];
-                } else if (lag < stride_s) {
-                    zl[-64 * j] = zmax[j];
+                for (int j = 5; j < 32; ++j) zl[-64 * j] = zmax[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 32; ++j) {
+                    if ((VAR & 16384) && j >= 1 && j <= 3) continue; // lags >= 1793 > stride_s
+                    const uint32_t lag = static_cast<uint32_t>((kFftN - (ln + 64 * j)) & (kFftN - 1));
+                    if (j == 0) {
+                        if (lag < stride_s) zo[lag] = zmax[0];
+                    } else if (lag < stride_s) {
+                        zl[-64 * j] = zmax[j];
+                    }
                 }
             }
         }

@@ -233,12 +233,26 @@ __global__ __launch_bounds__(kW1Threads) void k_correlate_w64_one(const cf* __re
             int ln = lane;
             asm volatile("" : "+v"(ln)); // no hoisted lag registers
             float* zl = zo + (kFftN - ln); // lag of register j: 2048 - lane - 64 j (j = 0, lane = 0: lag 0)
+            // (round 5, as in k_correlate_w64) with 1728 < stride_s registers 5 .. 31 are stored by every lane: one uniform
+            // branch per block instead of a lane compare, an exec mask and a branch around each of the 29 stores
+            const bool whole_rows = stride_s > static_cast<uint32_t>(kFftN - 64 * 5);
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 // outputs k (lo) and k + 16 (hi) of the pair; registers 1 .. 3 hold lags >= 1793 > stride_s: never stored
                 const cf pw = vfma(bp[k].i, bp[k].i, bp[k].r * bp[k].r);
                 if (ABL == 2) {
                     asm volatile("" ::"v"(pw));
+                    continue;
+                }
+                if (whole_rows) {
+                    if (k == 0) {
+                        if (ln == 0) zo[0] = pw.x;
+                    } else if (k == 4) {
+                        if (static_cast<uint32_t>(kFftN - 256 - ln) < stride_s) zl[-256] = pw.x;
+                    } else if (k > 4) {
+                        zl[-64 * k] = pw.x;
+                    }
+                    zl[-64 * (k + 16)] = pw.y;
                     continue;
                 }
                 if (k == 0) {

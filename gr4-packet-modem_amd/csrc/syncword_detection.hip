@@ -1780,6 +1780,7 @@ gr4pm_status launch_correlate(gr4pm_syncword_detection* h, hipStream_t stream, c
         case 5: GR4PM_C4096(5); break;
         case 6: GR4PM_C4096(6); break;
         case 7: GR4PM_C4096(7); break;
+        case 17: GR4PM_C4096(17); break; // A/B: variant 1 with round 4's power stores, same results
 #ifdef GR4PM_EXPERIMENTS
         case 9: GR4PM_C4096(9); break; // (FMA-form butterflies: not bit-identical; announced at creation)
 #endif
@@ -1864,6 +1865,7 @@ gr4pm_status launch_correlate(gr4pm_syncword_detection* h, hipStream_t stream, c
             break;
         case 65536: GR4PM_W64_LAUNCH(65536 + 16384); break; // planar second half, templates still by LDS-DMA
         case 131072: GR4PM_W64_LAUNCH(98304 + 16384 + 131072); break; // A/B: fixed shares of blocks per wave (rounds 1 - 3), same results
+        case 262144: GR4PM_W64_LAUNCH(98304 + 16384 + 262144); break; // A/B: round 4's power stores (a lane compare and a branch per store), same results
         default:
             // planar mid stage / pass B / powers in the bin loop (65536), templates from global memory straight
             // into registers (32768)
@@ -2143,11 +2145,12 @@ try {
         const char* v = getenv("GR4PM_W64_VARIANT");
         h->w64_variant = v ? atoi(v) : -1;
         if (v && h->w64_variant != -1 && h->w64_variant != 0 && h->w64_variant != 65536 && h->w64_variant != 131072 &&
+            h->w64_variant != 262144 &&
             !experiment_env("GR4PM_W64_VARIANT", true))
             h->w64_variant = -1;
         if (const char* cv = getenv("GR4PM_C4096_VARIANT")) {
             const int c = atoi(cv);
-            if (c >= 0 && c <= 7) h->c4096_variant = c;
+            if ((c >= 0 && c <= 7) || c == 17) h->c4096_variant = c;
             else if (c == 9 && experiment_env("GR4PM_C4096_VARIANT", true)) h->c4096_variant = 9;
             else fprintf(stderr, "[gr4pm] GR4PM_C4096_VARIANT=%s is not one of 0 .. 7: using the default (1)\n", cv);
         }
