@@ -646,15 +646,24 @@ __device__ __forceinline__ void wave_prefix_max4(float& a, float& b, float& c, f
                  : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 #undef GR4PM_STEP
 }
-template <int TQ>
+// Round 5, MEDIAN: the wave also holds the T-item block BEFORE the current one, i.e. the whole history [p - T, p + T] of
+// every candidate p of the current block (the 2T + 1 powers the reference's test looks at, hpp:273-279, when the scan
+// reaches p) -- so the median test of a candidate costs ballots and population counts on registers, and its result goes
+// into a second bitmap (`passmap`: candidate AND 2 count(history < z[p] / power_threshold) >= 2T + 1).  The scan
+// (k_tile_visit) then only has to look its visited candidates up: the separate pass over the powers (k_median_tests:
+// 6 KB read per visited candidate, 1.2 GB and 205 us per 2^28 samples) and the visit list are gone.  Every candidate
+// is tested, visited or not: on noise there is about one per block, and about two in three are visited.
+template <int TQ, bool MEDIAN>
 __global__ __launch_bounds__(64) void k_candidates_wave(const float* __restrict__ zbase, size_t z_stride, uint32_t cnt,
                                                         uint32_t n_words, uint32_t chain,
-                                                        unsigned long long* __restrict__ bitmap, size_t bm_stride)
+                                                        unsigned long long* __restrict__ bitmap, size_t bm_stride,
+                                                        unsigned long long* __restrict__ passmap, float power_threshold)
 {
     constexpr uint32_t T = TQ * 64;
     const int lane = threadIdx.x, rl = 63 - lane;
     const float* z = zbase + static_cast<size_t>(blockIdx.y) * z_stride;
     unsigned long long* bmp = bitmap + static_cast<size_t>(blockIdx.y) * bm_stride;
+    unsigned long long* pmp = MEDIAN ? passmap + static_cast<size_t>(blockIdx.y) * bm_stride : nullptr;
     const uint32_t avail = cnt + T; // readable items
     const uint32_t n_blk = (n_words + TQ - 1) / TQ;
     const uint32_t b0 = blockIdx.x * chain;
@@ -683,9 +692,18 @@ __global__ __launch_bounds__(64) void k_candidates_wave(const float* __restrict_
         for (int r = 0; r < TQ; ++r) rowmax[r] = __builtin_amdgcn_readlane(__builtin_bit_cast(int, rs[r]), 63);
     };
     const int ninf = __builtin_bit_cast(int, -INFINITY);
-    float cur[TQ], rs[TQ], nxt[TQ];
+    float cur[TQ], rs[TQ], nxt[TQ], prv[MEDIAN ? TQ : 1];
     int rowmax[TQ];
     load(b0, cur);
+    if (MEDIAN) {
+        // the block before the chain's first one: positions (b0 - 1) T ..; for b0 == 0 that is the T items before local
+        // position 0, which the caller keeps readable (the powers' carry: what k_median_tests read there)
+#pragma unroll
+        for (int r = 0; r < TQ; ++r) {
+            const long long g = static_cast<long long>(b0) * T - static_cast<long long>(T) + 64 * r + rl;
+            prv[r] = g < static_cast<long long>(avail) ? z[g] : -INFINITY; // (behind the stream: in nobody's history)
+        }
+    }
     scans(cur, rs, rowmax);
     for (uint32_t b = b0; b < b1; ++b) {
         load(b + 1, nxt);
@@ -695,26 +713,57 @@ __global__ __launch_bounds__(64) void k_candidates_wave(const float* __restrict_
         before[0] = ninf;
 #pragma unroll
         for (int r = 1; r < TQ; ++r) before[r] = smax_bits(before[r - 1], nrowmax[r - 1]);
-        unsigned long long mine = 0;
+        unsigned long long mine = 0, mine_pass = 0;
         int after = ninf; // maximum of the rows behind r in this block: built while r walks down
 #pragma unroll
         for (int r = TQ - 1; r >= 0; --r) {
             const int U = smax_bits(after, before[r]);
-            unsigned long long word = 0;
+            unsigned long long word = 0, pword = 0;
             if (fkey(rowmax[r]) >= fkey(U)) { // (uniform: a scalar branch)
                 const float fwd = __shfl(nxt[r], rl);              // the next block's row r in item order
                 const float pr = __shfl(wave_prefix_max(fwd), rl); // its prefix maximum up to the lane's own offset
                 const float m = fmaxf(fmaxf(wave_prev(rs[r]), __builtin_bit_cast(float, U)), pr);
                 const uint32_t pos = b * T + 64u * r + rl;
-                word = __brevll(__ballot(pos < cnt && cur[r] >= m)); // back to item order
+                unsigned long long cand = __ballot(pos < cnt && cur[r] >= m); // one bit per lane (items reversed)
+                word = __brevll(cand); // back to item order
+                if (MEDIAN) {
+                    // hpp:273-279 for every candidate of the row, one after the other (uniform loop; usually one pass):
+                    // its history is the items at or behind its own offset in the block before, the whole current
+                    // block, and the items up to its own offset in the next block = 2T + 1 powers, all in registers
+                    unsigned long long passed = 0;
+                    while (cand) {
+                        const int lp = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(cand)) - 1);
+                        cand &= cand - 1;
+                        const float best = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur[r]), lp));
+                        const float thr = best / power_threshold; // hpp:275
+                        uint32_t below = 0;
+#pragma unroll
+                        for (int q = 0; q < TQ; ++q) {
+                            if (q > r) below += static_cast<uint32_t>(__popcll(__ballot(prv[q] < thr)));
+                            else if (q == r) below += static_cast<uint32_t>(__popcll(__ballot(lane <= lp && prv[q] < thr)));
+                            below += static_cast<uint32_t>(__popcll(__ballot(cur[q] < thr)));
+                            if (q < r) below += static_cast<uint32_t>(__popcll(__ballot(nxt[q] < thr)));
+                            else if (q == r) below += static_cast<uint32_t>(__popcll(__ballot(lane >= lp && nxt[q] < thr)));
+                        }
+                        if (2u * below >= 2u * T + 1u) passed |= 1ull << lp; // hpp:279
+                    }
+                    pword = __brevll(passed);
+                }
             }
-            if (lane == r) mine = word;
+            if (lane == r) {
+                mine = word;
+                mine_pass = pword;
+            }
             after = smax_bits(after, rowmax[r]);
         }
         const uint32_t w = b * TQ + lane;
-        if (lane < TQ && w < n_words) bmp[w] = mine;
+        if (lane < TQ && w < n_words) {
+            bmp[w] = mine;
+            if (MEDIAN) pmp[w] = mine_pass;
+        }
 #pragma unroll
         for (int r = 0; r < TQ; ++r) {
+            if (MEDIAN) prv[r] = cur[r];
             cur[r] = nxt[r];
             rs[r] = nrs[r];
             rowmax[r] = nrowmax[r];
@@ -1082,7 +1131,10 @@ __global__ __launch_bounds__(256) void k_scan_entries(ChanState* __restrict__ st
 __global__ __launch_bounds__(64) void k_tile_visit(const unsigned long long* __restrict__ bitmap, size_t bm_stride,
                                                    uint32_t cnt, uint32_t T, uint32_t n_tiles,
                                                    const int32_t* __restrict__ entry, ChanState* __restrict__ st,
-                                                   uint32_t* __restrict__ visit, uint32_t visit_cap)
+                                                   uint32_t* __restrict__ visit, uint32_t visit_cap,
+                                                   const unsigned long long* __restrict__ passmap,
+                                                   unsigned long long A0, unsigned long long* __restrict__ det,
+                                                   uint32_t det_cap)
 {
 #ifndef GR4PM_NO_SETPRIO
     __builtin_amdgcn_s_setprio(3); // latency-bound, few waves: win the issue arbitration against throughput kernels
@@ -1102,6 +1154,25 @@ __global__ __launch_bounds__(64) void k_tile_visit(const unsigned long long* __r
     uint32_t mine = 0, have = 0;
     auto flush = [&]() {
         if (have == 0) return;
+        if (passmap) {
+            // round 5: k_candidates_wave<12, true> has tested every candidate (passmap); the visited ones that passed are
+            // the detections (hpp:279-295) -- no visit list, no separate pass over the powers
+            const unsigned long long* pm = passmap + static_cast<size_t>(ch) * bm_stride;
+            const bool ok = static_cast<uint32_t>(lane) < have && ((pm[mine >> 6] >> (mine & 63u)) & 1ull);
+            const unsigned long long m = __ballot(ok);
+            if (m) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&st[ch].det_cnt, static_cast<uint32_t>(__popcll(m)));
+                base = __shfl(base, 0);
+                if (ok) {
+                    const uint32_t slot = base + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
+                    if (slot < det_cap) det[static_cast<size_t>(ch) * det_cap + slot] = A0 + mine;
+                    else st[ch].overflow = 1;
+                }
+            }
+            have = 0;
+            return;
+        }
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(&st[ch].vis_cnt, have);
         base = __shfl(base, 0);
@@ -1604,6 +1675,7 @@ struct gr4pm_syncword_detection {
     // the one-exchange correlator (fft2048_w64.hpp, k_correlate_w64): templates in its lane order
     // ([bin][16][64] float4), mid-stage twiddle table, lane constants
     bool lds_candidates = false; // GR4PM_CANDIDATES_LDS at creation: k_candidates also for T = 768
+    bool separate_median = false; // GR4PM_SD_SEPARATE_MEDIAN at creation: k_candidates_wave<12, false> + k_median_tests
     bool w64_no_prune = false;   // GR4PM_W64_NO_PRUNE at creation: the correlator variant that computes all 32 registers
     int corr_kind = 0; // 0: k_correlate_w64 (default), 1: k_correlate (two exchanges), 2: k_correlate_pair
     DevBuf<float4> tmpl64, tT64;
@@ -1635,6 +1707,8 @@ struct gr4pm_syncword_detection {
     // candidate bitmap, tile tables and group tables exist kSets times like z[]: the look-ahead of
     // the next calls fills the other sets while this call's scan still reads its own
     DevBuf<unsigned long long> bitmap[kSets];
+    DevBuf<unsigned long long> passmap[kSets]; // candidates that pass the median test (k_candidates_wave<12, true>)
+    bool fused_median[kSets] = {};             // ... and whether the set's front was made by that kernel
     DevBuf<uint32_t> table[kSets];
     DevBuf<unsigned long long> gtable[kSets], gentry;
     size_t gtable_stride = 0;
@@ -1933,11 +2007,21 @@ gr4pm_status launch_front(gr4pm_syncword_detection* h, hipStream_t stream, int w
     const float* zloc = zw + h->zc - static_cast<ptrdiff_t>(E0 - A0);
     const uint32_t n_wg = (cnt + kCandTile - 1) / kCandTile;
     const size_t smem = (static_cast<size_t>(kCandBlocks + (T >> 6) + 2) * 65 + kCandBlocks) * sizeof(float);
+    h->fused_median[which] = false;
     if (T == 768 && !h->lds_candidates) { // the LDS-free form: runs beside the correlator's workgroups
-        constexpr uint32_t kChain = 8;
         const uint32_t n_words = n_wg * (kCandTile / 64), n_blk = (n_words + 11) / 12;
-        hipLaunchKernelGGL(k_candidates_wave<12>, dim3((n_blk + kChain - 1) / kChain, nch), dim3(64), 0, stream, zloc,
-                           h->z_stride, cnt, n_words, kChain, h->bitmap[which].p, h->bm_stride);
+        if (!h->separate_median) { // (GR4PM_SD_SEPARATE_MEDIAN at creation: round 4's two passes over the powers, for A/B)
+            // (a chain also reads the block before its first one: twice the chain length for the same overlap)
+            constexpr uint32_t kChain = 16;
+            h->fused_median[which] = true;
+            hipLaunchKernelGGL((k_candidates_wave<12, true>), dim3((n_blk + kChain - 1) / kChain, nch), dim3(64), 0, stream,
+                               zloc, h->z_stride, cnt, n_words, kChain, h->bitmap[which].p, h->bm_stride,
+                               h->passmap[which].p, h->power_threshold);
+        } else {
+            constexpr uint32_t kChain = 8;
+            hipLaunchKernelGGL((k_candidates_wave<12, false>), dim3((n_blk + kChain - 1) / kChain, nch), dim3(64), 0, stream,
+                               zloc, h->z_stride, cnt, n_words, kChain, h->bitmap[which].p, h->bm_stride, nullptr, 0.0f);
+        }
     } else {
         hipLaunchKernelGGL(k_candidates, dim3(n_wg, nch), dim3(256), smem, stream, zloc, h->z_stride, cnt, T,
                            h->bitmap[which].p, h->bm_stride);
@@ -2188,6 +2272,7 @@ try {
     if (h->fault.p) *h->fault.p = 0;
     if (const char* e = getenv("GR4PM_TEST_SPIN_LIMIT")) h->spin_limit = atoi(e); // tests force a timeout with 0
     h->lds_candidates = getenv("GR4PM_CANDIDATES_LDS") != nullptr;
+    h->separate_median = getenv("GR4PM_SD_SEPARATE_MEDIAN") != nullptr;
     h->w64_no_prune = getenv("GR4PM_W64_NO_PRUNE") != nullptr;
     ok(h->tmpl64.alloc(tmpl64.size()));
     ok(h->tT64.alloc(tT64.size()));
@@ -2227,6 +2312,7 @@ try {
     for (int i = 0; i < kSets; ++i) ok(h->z[i].alloc(h->z_stride * h->n_channels));
     for (int i = 0; i < kSets; ++i) {
         ok(h->bitmap[i].alloc(h->bm_stride * h->n_channels));
+        ok(h->passmap[i].alloc(h->bm_stride * h->n_channels));
         ok(h->table[i].alloc(h->table_stride * h->n_channels));
     }
     ok(h->entry.alloc(static_cast<size_t>(h->max_tiles) * h->n_channels));
@@ -2386,13 +2472,17 @@ try {
         hipLaunchKernelGGL(k_scan_entries, dim3(nch), dim3(256), 0, s, h->st.p, static_cast<unsigned long long>(A0),
                            cnt, T, n_tiles, h->table[cur].p, h->table_stride, h->gtable[cur].p, h->gtable_stride,
                            h->gentry.p, n_groups, h->entry.p);
+        const bool fused = h->fused_median[cur]; // the front's candidate kernel has done the median tests
         hipLaunchKernelGGL(k_tile_visit, dim3(n_tiles, nch), dim3(64), 0, s, h->bitmap[cur].p, h->bm_stride, cnt, T,
-                           n_tiles, h->entry.p, h->st.p, h->visit.p, h->visit_cap);
-        // at most one visited candidate per T + 1 items (+ one per tile): the grid strides over the real count
-        const uint32_t n_med = std::min<uint32_t>(cnt / (T + 1) + n_tiles + 1, 16384u);
-        hipLaunchKernelGGL(k_median_tests, dim3(n_med, nch), dim3(64), 0, s, zloc, h->z_stride,
-                           static_cast<unsigned long long>(A0), T, h->power_threshold, h->st.p, h->visit.p,
-                           h->visit_cap, h->det.p, h->det_cap);
+                           n_tiles, h->entry.p, h->st.p, h->visit.p, h->visit_cap, fused ? h->passmap[cur].p : nullptr,
+                           static_cast<unsigned long long>(A0), h->det.p, h->det_cap);
+        if (!fused) {
+            // at most one visited candidate per T + 1 items (+ one per tile): the grid strides over the real count
+            const uint32_t n_med = std::min<uint32_t>(cnt / (T + 1) + n_tiles + 1, 16384u);
+            hipLaunchKernelGGL(k_median_tests, dim3(n_med, nch), dim3(64), 0, s, zloc, h->z_stride,
+                               static_cast<unsigned long long>(A0), T, h->power_threshold, h->st.p, h->visit.p,
+                               h->visit_cap, h->det.p, h->det_cap);
+        }
     }
     // tags leaving in this call
     if (h->generic && h->fft_size == static_cast<size_t>(kN4k) && !h->force_radix2 && h->hist <= h->S) {

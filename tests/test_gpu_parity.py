@@ -341,9 +341,15 @@ def test_candidate_kernels_agree(pkg, monkeypatch):
     x[200000:200700] = 0
     xs = np.stack([x, np.roll(x, 12345)]).astype(np.complex64)
     res = {}
-    for kind in ("wave", "lds"):
+    # "wave": round 5's default, k_candidates_wave<12, true> -- the median test of every candidate done on the registers
+    # that hold its history, k_tile_visit looks the visited ones up; "split": round 4's two passes over the powers
+    # (k_candidates_wave<12, false> + k_median_tests, GR4PM_SD_SEPARATE_MEDIAN); "lds": the LDS kernel + k_median_tests
+    for kind in ("wave", "split", "lds"):
+        monkeypatch.delenv("GR4PM_SD_SEPARATE_MEDIAN", raising=False)
         if kind == "lds":
             monkeypatch.setenv("GR4PM_CANDIDATES_LDS", "1")
+        if kind == "split":
+            monkeypatch.setenv("GR4PM_SD_SEPARATE_MEDIAN", "1")
         sd = pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, power_threshold=9.5, max_items=n, n_channels=2)
         one = sd.process_bulk(dev(xs))
         sd2 = pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, power_threshold=9.5, max_items=n, n_channels=2)
@@ -353,12 +359,35 @@ def test_candidate_kernels_agree(pkg, monkeypatch):
             pos += m
         res[kind] = (one, chunks)
     monkeypatch.delenv("GR4PM_CANDIDATES_LDS")
-    (one_w, ch_w), (one_l, ch_l) = res["wave"], res["lds"]
+    (one_w, ch_w), (one_l, ch_l), (one_s, ch_s) = res["wave"], res["lds"], res["split"]
     assert sum(t.size for t in one_w[2]) >= 8
     for c in range(2):
-        assert same_tags(one_w[2][c], one_l[2][c])
-        for a, b in zip(ch_w, ch_l):
-            assert same_tags(a[2][c], b[2][c])
+        assert same_tags(one_w[2][c], one_l[2][c]) and same_tags(one_w[2][c], one_s[2][c])
+        for a, b, d in zip(ch_w, ch_l, ch_s):
+            assert same_tags(a[2][c], b[2][c]) and same_tags(a[2][c], d[2][c])
+    # thresholds at which the median test REJECTS visited candidates (9.5 lets nearly every local maximum of this stream
+    # through, so a wrong count would go unnoticed): the three forms agree there too, and against the oracle
+    for thr in (1.5, 3.0, 60.0):
+        got = {}
+        for kind in ("wave", "split"):
+            monkeypatch.delenv("GR4PM_SD_SEPARATE_MEDIAN", raising=False)
+            if kind == "split":
+                monkeypatch.setenv("GR4PM_SD_SEPARATE_MEDIAN", "1")
+            sd = pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, power_threshold=thr, max_items=n)
+            pos, tags = 0, []
+            for m in (70000, 4096, 100001, 125903):
+                _, _, t, nd = sd.process_bulk(dev(np.ascontiguousarray(x[pos:pos + m])), want_output=False, tags_cap=4096)
+                t = t.copy()
+                t["index"] += pos
+                tags.append(t)
+                pos += nd
+            got[kind] = np.concatenate(tags)
+        monkeypatch.delenv("GR4PM_SD_SEPARATE_MEDIAN", raising=False)
+        assert same_tags(got["wave"], got["split"]), thr
+        ref = orc.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, power_threshold=thr)
+        _, ref_out, ref_tags = ref.process(x, tags_cap=4096)
+        lim = min(pos, ref_out.size) - 2 * 768 - 1
+        assert np.array_equal(got["wave"]["index"][got["wave"]["index"] < lim], ref_tags["index"][ref_tags["index"] < lim]), thr
 
 
 def test_syncword_detection_awgn_threshold_and_noise_only(pkg):
