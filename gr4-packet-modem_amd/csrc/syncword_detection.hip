@@ -736,15 +736,55 @@ __global__ __launch_bounds__(64) void k_candidates_wave(const float* __restrict_
                         cand &= cand - 1;
                         const float best = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur[r]), lp));
                         const float thr = best / power_threshold; // hpp:275
-                        uint32_t below = 0;
+                        // counted per lane (a compare and an add-with-carry per row: two vector instructions, nothing on
+                        // the scalar unit -- a ballot, a population count and a scalar add per row were three issue slots),
+                        // summed over the wave once per candidate
+                        uint32_t acc = 0;
+                        const bool at_or_before = lane <= lp, at_or_after = lane >= lp;
+                        // the 2 TQ - 1 rows that lie wholly inside the history, four at a time (a compare's mask is read
+                        // by its add three instructions later: no wait states to pad), then the two partial rows
+                        float full[2 * TQ - 1];
+                        {
+                            int n = 0;
 #pragma unroll
-                        for (int q = 0; q < TQ; ++q) {
-                            if (q > r) below += static_cast<uint32_t>(__popcll(__ballot(prv[q] < thr)));
-                            else if (q == r) below += static_cast<uint32_t>(__popcll(__ballot(lane <= lp && prv[q] < thr)));
-                            below += static_cast<uint32_t>(__popcll(__ballot(cur[q] < thr)));
-                            if (q < r) below += static_cast<uint32_t>(__popcll(__ballot(nxt[q] < thr)));
-                            else if (q == r) below += static_cast<uint32_t>(__popcll(__ballot(lane >= lp && nxt[q] < thr)));
+                            for (int q = 0; q < TQ; ++q) {
+                                if (q > r) full[n++] = prv[q];
+                                full[n++] = cur[q];
+                                if (q < r) full[n++] = nxt[q];
+                            }
                         }
+#pragma unroll
+                        for (int q = 0; q + 4 <= 2 * TQ - 1; q += 4) {
+                            unsigned long long m0, m1, m2, m3;
+                            asm("v_cmp_lt_f32_e64 %1, %5, %9\n\t"
+                                "v_cmp_lt_f32_e64 %2, %6, %9\n\t"
+                                "v_cmp_lt_f32_e64 %3, %7, %9\n\t"
+                                "v_cmp_lt_f32_e64 %4, %8, %9\n\t"
+                                "v_addc_co_u32_e64 %0, %1, %0, 0, %1\n\t"
+                                "v_addc_co_u32_e64 %0, %2, %0, 0, %2\n\t"
+                                "v_addc_co_u32_e64 %0, %3, %0, 0, %3\n\t"
+                                "v_addc_co_u32_e64 %0, %4, %0, 0, %4"
+                                : "+v"(acc), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
+                                : "v"(full[q]), "v"(full[q + 1]), "v"(full[q + 2]), "v"(full[q + 3]), "v"(thr));
+                        }
+#pragma unroll
+                        for (int q = (2 * TQ - 1) / 4 * 4; q < 2 * TQ - 1; ++q) acc += full[q] < thr ? 1u : 0u;
+                        acc += (at_or_before && prv[r] < thr) ? 1u : 0u;
+                        acc += (at_or_after && nxt[r] < thr) ? 1u : 0u;
+                        asm volatile("s_nop 1\n\t"
+                                     "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                                     "s_nop 1\n\t"
+                                     "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                                     "s_nop 1\n\t"
+                                     "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                                     "s_nop 1\n\t"
+                                     "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                                     "s_nop 1\n\t"
+                                     "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                                     "s_nop 1\n\t"
+                                     "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+                                     : "+v"(acc));
+                        const uint32_t below = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(acc), 63));
                         if (2u * below >= 2u * T + 1u) passed |= 1ull << lp; // hpp:279
                     }
                     pword = __brevll(passed);
@@ -2011,8 +2051,9 @@ gr4pm_status launch_front(gr4pm_syncword_detection* h, hipStream_t stream, int w
     if (T == 768 && !h->lds_candidates) { // the LDS-free form: runs beside the correlator's workgroups
         const uint32_t n_words = n_wg * (kCandTile / 64), n_blk = (n_words + 11) / 12;
         if (!h->separate_median) { // (GR4PM_SD_SEPARATE_MEDIAN at creation: round 4's two passes over the powers, for A/B)
-            // (a chain also reads the block before its first one: twice the chain length for the same overlap)
-            constexpr uint32_t kChain = 16;
+            // blocks per wave: a wave also reads (without scanning it) the block before its first one.  Fewer, longer
+            // waves cost less overlap and balance worse (21 845 waves of 16 blocks on 7168 wave slots are 3.05 rounds)
+            static const uint32_t kChain = experiment_env_wg("GR4PM_CAND_CHAIN", 8u, 1u, 64u);
             h->fused_median[which] = true;
             hipLaunchKernelGGL((k_candidates_wave<12, true>), dim3((n_blk + kChain - 1) / kChain, nch), dim3(64), 0, stream,
                                zloc, h->z_stride, cnt, n_words, kChain, h->bitmap[which].p, h->bm_stride,
