@@ -657,13 +657,21 @@ template <int TQ, bool MEDIAN>
 __global__ __launch_bounds__(64) void k_candidates_wave(const float* __restrict__ zbase, size_t z_stride, uint32_t cnt,
                                                         uint32_t n_words, uint32_t chain,
                                                         unsigned long long* __restrict__ bitmap, size_t bm_stride,
-                                                        unsigned long long* __restrict__ passmap, float power_threshold)
+                                                        unsigned long long* __restrict__ passmap,
+                                                        unsigned long long* __restrict__ defermap, float power_threshold)
 {
     constexpr uint32_t T = TQ * 64;
     const int lane = threadIdx.x, rl = 63 - lane;
     const float* z = zbase + static_cast<size_t>(blockIdx.y) * z_stride;
     unsigned long long* bmp = bitmap + static_cast<size_t>(blockIdx.y) * bm_stride;
-    unsigned long long* pmp = MEDIAN ? passmap + static_cast<size_t>(blockIdx.y) * bm_stride : nullptr;
+    unsigned long long* pmp = MEDIAN ? passmap + 2 * static_cast<size_t>(blockIdx.y) * bm_stride : nullptr;
+    (void)defermap;
+    // At most kTestsPerBlock candidates of a block are tested here; the others are DEFERRED (defermap): if the scan
+    // visits one of them, k_tile_visit puts it on the visit list and k_median_tests reads its history from memory as in
+    // round 4.  On noise and on packet streams a block has one to five candidates; on constant input (all-zero: the
+    // reference's own benchmark input, where every item ties with its window and is a candidate) it has 768, of which the
+    // scan visits one -- testing them all made that input seven times slower than round 4.
+    constexpr uint32_t kTestsPerBlock = 8;
     const uint32_t avail = cnt + T; // readable items
     const uint32_t n_blk = (n_words + TQ - 1) / TQ;
     const uint32_t b0 = blockIdx.x * chain;
@@ -713,12 +721,13 @@ __global__ __launch_bounds__(64) void k_candidates_wave(const float* __restrict_
         before[0] = ninf;
 #pragma unroll
         for (int r = 1; r < TQ; ++r) before[r] = smax_bits(before[r - 1], nrowmax[r - 1]);
-        unsigned long long mine = 0, mine_pass = 0;
+        unsigned long long mine = 0, mine_pass = 0, mine_defer = 0;
+        uint32_t tests_left = kTestsPerBlock;
         int after = ninf; // maximum of the rows behind r in this block: built while r walks down
 #pragma unroll
         for (int r = TQ - 1; r >= 0; --r) {
             const int U = smax_bits(after, before[r]);
-            unsigned long long word = 0, pword = 0;
+            unsigned long long word = 0, pword = 0, dword = 0;
             if (fkey(rowmax[r]) >= fkey(U)) { // (uniform: a scalar branch)
                 const float fwd = __shfl(nxt[r], rl);              // the next block's row r in item order
                 const float pr = __shfl(wave_prefix_max(fwd), rl); // its prefix maximum up to the lane's own offset
@@ -732,6 +741,11 @@ __global__ __launch_bounds__(64) void k_candidates_wave(const float* __restrict_
                     // block, and the items up to its own offset in the next block = 2T + 1 powers, all in registers
                     unsigned long long passed = 0;
                     while (cand) {
+                        if (tests_left == 0) { // the block's budget is spent: the rest of the row is deferred
+                            dword = __brevll(cand);
+                            break;
+                        }
+                        --tests_left;
                         const int lp = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(cand)) - 1);
                         cand &= cand - 1;
                         const float best = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur[r]), lp));
@@ -793,13 +807,15 @@ __global__ __launch_bounds__(64) void k_candidates_wave(const float* __restrict_
             if (lane == r) {
                 mine = word;
                 mine_pass = pword;
+                mine_defer = dword;
             }
             after = smax_bits(after, rowmax[r]);
         }
         const uint32_t w = b * TQ + lane;
         if (lane < TQ && w < n_words) {
             bmp[w] = mine;
-            if (MEDIAN) pmp[w] = mine_pass;
+            if (MEDIAN) // (pass word, defer word) side by side: k_tile_visit reads both with one 16-byte load
+                reinterpret_cast<ulonglong2*>(pmp)[w] = make_ulonglong2(mine_pass, mine_defer);
         }
 #pragma unroll
         for (int r = 0; r < TQ; ++r) {
@@ -1077,6 +1093,8 @@ struct ChanState {
     unsigned int rec_cnt;        // raw tag records written by the current call
     unsigned int overflow;
     unsigned int vis_cnt;        // candidates visited by the scan in the current call (k_tile_visit)
+    unsigned int def_cnt;        // ... of which k_resolve_visited found untested (deferred): k_median_tests<true>
+    unsigned int pad;
 };
 
 // The scan position after tile t is r_{t+1} = f_t(r_t) with f_t given by table row t; walking
@@ -1171,10 +1189,7 @@ __global__ __launch_bounds__(256) void k_scan_entries(ChanState* __restrict__ st
 __global__ __launch_bounds__(64) void k_tile_visit(const unsigned long long* __restrict__ bitmap, size_t bm_stride,
                                                    uint32_t cnt, uint32_t T, uint32_t n_tiles,
                                                    const int32_t* __restrict__ entry, ChanState* __restrict__ st,
-                                                   uint32_t* __restrict__ visit, uint32_t visit_cap,
-                                                   const unsigned long long* __restrict__ passmap,
-                                                   unsigned long long A0, unsigned long long* __restrict__ det,
-                                                   uint32_t det_cap)
+                                                   uint32_t* __restrict__ visit, uint32_t visit_cap)
 {
 #ifndef GR4PM_NO_SETPRIO
     __builtin_amdgcn_s_setprio(3); // latency-bound, few waves: win the issue arbitration against throughput kernels
@@ -1194,25 +1209,6 @@ __global__ __launch_bounds__(64) void k_tile_visit(const unsigned long long* __r
     uint32_t mine = 0, have = 0;
     auto flush = [&]() {
         if (have == 0) return;
-        if (passmap) {
-            // round 5: k_candidates_wave<12, true> has tested every candidate (passmap); the visited ones that passed are
-            // the detections (hpp:279-295) -- no visit list, no separate pass over the powers
-            const unsigned long long* pm = passmap + static_cast<size_t>(ch) * bm_stride;
-            const bool ok = static_cast<uint32_t>(lane) < have && ((pm[mine >> 6] >> (mine & 63u)) & 1ull);
-            const unsigned long long m = __ballot(ok);
-            if (m) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&st[ch].det_cnt, static_cast<uint32_t>(__popcll(m)));
-                base = __shfl(base, 0);
-                if (ok) {
-                    const uint32_t slot = base + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
-                    if (slot < det_cap) det[static_cast<size_t>(ch) * det_cap + slot] = A0 + mine;
-                    else st[ch].overflow = 1;
-                }
-            }
-            have = 0;
-            return;
-        }
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(&st[ch].vis_cnt, have);
         base = __shfl(base, 0);
@@ -1231,6 +1227,38 @@ __global__ __launch_bounds__(64) void k_tile_visit(const unsigned long long* __r
     }
     flush();
 }
+// hpp:273-279 for one candidate p (wave-uniform; local position), by the whole wave: is count(history < z[p] /
+// power_threshold) at least half of the 2T + 1 powers around p?  Uniform result.
+__device__ __forceinline__ bool median_test_passes(const float* z, uint32_t p, uint32_t T, float power_threshold, int lane)
+{
+    const uint32_t hist = 2 * T + 1;
+    // the candidate is the same for the whole wave: a uniform window pointer (SGPR pair) + the lane's 32-bit offset,
+    // i.e. one address register per lane instead of a 64-bit address per load.  With that the kernel needs at most
+    // 32 VGPRs, which is what a SIMD has left beside two correlator waves (HISTORY.md section 9): its waves run
+    // beside them on the memory bandwidth the correlator leaves idle instead of waiting for a free CU.
+    const float* zw = z + (static_cast<long long>(p) - static_cast<long long>(T)); // window [p - T, p + T]
+    const float best = zw[T];
+    const float thr = best / power_threshold; // hpp:275
+    // counted per wave, not per lane: ballot + population count (scalar unit; no per-lane counter, no shuffles)
+    uint32_t below = 0;
+    const char* zb = reinterpret_cast<const char*>(zw);
+    const uint32_t off = static_cast<uint32_t>(lane) * 4u; // byte offset of the lane's item inside a row of 64
+    const uint32_t end = hist * 4u;
+    // the row loop is UNIFORM (every lane takes every pass; a lane beyond the window reads its last item again and
+    // does not count), so that the wave-wide count is the same in every lane
+#pragma unroll 1
+    for (uint32_t row = 0; row < end; row += 8u * 256u) { // eight independent loads in flight per lane
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float*>(zb + min(row + off + 256u * k, end - 4u));
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            below += static_cast<uint32_t>(__popcll(__ballot(row + off + 256u * k < end && v[k] < thr)));
+    }
+    return 2 * below >= hist; // hpp:279
+}
+// DEFERRED: the list k_resolve_visited compacted (count def_cnt) instead of k_tile_visit's (vis_cnt)
+template <bool DEFERRED>
 __global__ __launch_bounds__(64) void k_median_tests(const float* __restrict__ zloc, size_t z_stride,
                                                      unsigned long long A0, uint32_t T, float power_threshold,
                                                      ChanState* __restrict__ st, const uint32_t* __restrict__ visit,
@@ -1240,37 +1268,81 @@ __global__ __launch_bounds__(64) void k_median_tests(const float* __restrict__ z
     const uint32_t ch = blockIdx.y;
     const int lane = threadIdx.x;
     const float* z = zloc + static_cast<size_t>(ch) * z_stride;
-    const uint32_t n = min(st[ch].vis_cnt, visit_cap);
-    const uint32_t hist = 2 * T + 1;
+    const uint32_t n = min(DEFERRED ? st[ch].def_cnt : st[ch].vis_cnt, visit_cap);
     for (uint32_t idx = blockIdx.x; idx < n; idx += gridDim.x) {
-        // the candidate is the same for the whole wave: a uniform window pointer (SGPR pair) + the lane's 32-bit offset,
-        // i.e. one address register per lane instead of a 64-bit address per load.  With that the kernel needs at most
-        // 32 VGPRs, which is what a SIMD has left beside two correlator waves (HISTORY.md section 9): its waves run
-        // beside them on the memory bandwidth the correlator leaves idle instead of waiting for a free CU.
         const uint32_t p = __builtin_amdgcn_readfirstlane(visit[static_cast<size_t>(ch) * visit_cap + idx]);
-        const float* zw = z + (static_cast<long long>(p) - static_cast<long long>(T)); // window [p - T, p + T]
-        const float best = zw[T];
-        const float thr = best / power_threshold; // hpp:275
-        // counted per wave, not per lane: ballot + population count (scalar unit; no per-lane counter, no shuffles)
-        uint32_t below = 0;
-        const char* zb = reinterpret_cast<const char*>(zw);
-        const uint32_t off = static_cast<uint32_t>(lane) * 4u; // byte offset of the lane's item inside a row of 64
-        const uint32_t end = hist * 4u;
-        // the row loop is UNIFORM (every lane takes every pass; a lane beyond the window reads its last item again and
-        // does not count), so that the wave-wide count is the same in every lane
-#pragma unroll 1
-        for (uint32_t row = 0; row < end; row += 8u * 256u) { // eight independent loads in flight per lane
-            float v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float*>(zb + min(row + off + 256u * k, end - 4u));
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                below += static_cast<uint32_t>(__popcll(__ballot(row + off + 256u * k < end && v[k] < thr)));
-        }
-        if (2 * below >= hist && lane == 0) { // hpp:279
+        if (median_test_passes(z, p, T, power_threshold, lane) && lane == 0) {
             const unsigned int slot = atomicAdd(&st[ch].det_cnt, 1u);
             if (slot < det_cap) det[static_cast<size_t>(ch) * det_cap + slot] = A0 + p;
             else st[ch].overflow = 1;
+        }
+    }
+}
+// Round 5, behind k_candidates_wave<12, true>: the visited candidates, 256 per wave.  A lane looks four candidates up
+// in the (pass, defer) pairs of their bitmap words: passed -> a detection; deferred (beyond the candidate kernel's budget
+// per block: constant input) -> onto a second list, which k_median_tests<true> tests from memory with a wave per
+// candidate; else nothing.  ONE atomic per wave and list: the channel's counters are single addresses, and an atomic
+// per 64 candidates (5 461 per 2^28 samples, one behind the other at the L2) was most of this kernel's first form.
+// (Inside k_tile_visit's walk the same lookup cost 56 us per 2^28 samples without ever running.)
+__global__ __launch_bounds__(64) void k_resolve_visited(unsigned long long A0, ChanState* __restrict__ st,
+                                                        const uint32_t* __restrict__ visit, uint32_t visit_cap,
+                                                        const unsigned long long* __restrict__ passmap, size_t bm_stride,
+                                                        unsigned long long* __restrict__ det, uint32_t det_cap,
+                                                        uint32_t* __restrict__ deferred)
+{
+    const uint32_t ch = blockIdx.y;
+    const int lane = threadIdx.x;
+    const ulonglong2* pm = reinterpret_cast<const ulonglong2*>(passmap) + static_cast<size_t>(ch) * bm_stride;
+    const uint32_t* vis = visit + static_cast<size_t>(ch) * visit_cap;
+    const uint32_t n = min(st[ch].vis_cnt, visit_cap);
+    const uint32_t base = blockIdx.x * 256u;
+    if (base >= n) return;
+    uint32_t p[4];
+    bool ok[4], later[4];
+    unsigned long long m[4], md[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { // (coalesced: group k is the 64 consecutive entries base + 64 k ..)
+        const uint32_t idx = base + 64u * k + lane;
+        p[k] = idx < n ? vis[idx] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const ulonglong2 pd = pm[p[k] >> 6]; // (pass word, defer word)
+        const bool valid = base + 64u * k + lane < n;
+        ok[k] = valid && ((pd.x >> (p[k] & 63u)) & 1ull);
+        later[k] = valid && ((pd.y >> (p[k] & 63u)) & 1ull);
+        m[k] = __ballot(ok[k]);
+        md[k] = __ballot(later[k]);
+    }
+    const uint32_t n_ok = static_cast<uint32_t>(__popcll(m[0]) + __popcll(m[1]) + __popcll(m[2]) + __popcll(m[3]));
+    const uint32_t n_def = static_cast<uint32_t>(__popcll(md[0]) + __popcll(md[1]) + __popcll(md[2]) + __popcll(md[3]));
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (n_ok) {
+        uint32_t slot = 0;
+        if (lane == 0) slot = atomicAdd(&st[ch].det_cnt, n_ok);
+        slot = __shfl(slot, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (ok[k]) {
+                const uint32_t at = slot + static_cast<uint32_t>(__popcll(m[k] & below));
+                if (at < det_cap) det[static_cast<size_t>(ch) * det_cap + at] = A0 + p[k];
+                else st[ch].overflow = 1;
+            }
+            slot += static_cast<uint32_t>(__popcll(m[k]));
+        }
+    }
+    if (n_def) {
+        uint32_t slot = 0;
+        if (lane == 0) slot = atomicAdd(&st[ch].def_cnt, n_def);
+        slot = __shfl(slot, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (later[k]) {
+                const uint32_t at = slot + static_cast<uint32_t>(__popcll(md[k] & below));
+                if (at < visit_cap) deferred[static_cast<size_t>(ch) * visit_cap + at] = p[k];
+                else st[ch].overflow = 1;
+            }
+            slot += static_cast<uint32_t>(__popcll(md[k]));
         }
     }
 }
@@ -1622,6 +1694,7 @@ __global__ __launch_bounds__(64) void k_compact_pending(ChanState* __restrict__ 
         st[ch].det_cnt = w;
         st[ch].rec_cnt = 0; // the host copy of ChanState was written above
         st[ch].vis_cnt = 0;
+        st[ch].def_cnt = 0;
     }
 }
 
@@ -1747,7 +1820,9 @@ struct gr4pm_syncword_detection {
     // candidate bitmap, tile tables and group tables exist kSets times like z[]: the look-ahead of
     // the next calls fills the other sets while this call's scan still reads its own
     DevBuf<unsigned long long> bitmap[kSets];
-    DevBuf<unsigned long long> passmap[kSets]; // candidates that pass the median test (k_candidates_wave<12, true>)
+    // per bitmap word a pair: candidates that pass the median test | candidates k_candidates_wave<12, true> left untested
+    // (beyond its budget per block: k_median_tests if the scan visits them)
+    DevBuf<unsigned long long> passmap[kSets];
     bool fused_median[kSets] = {};             // ... and whether the set's front was made by that kernel
     DevBuf<uint32_t> table[kSets];
     DevBuf<unsigned long long> gtable[kSets], gentry;
@@ -1757,6 +1832,7 @@ struct gr4pm_syncword_detection {
     DevBuf<ChanState> st;
     DevBuf<unsigned long long> det;
     DevBuf<uint32_t> visit; // candidates visited by the scan of the current call, per channel
+    DevBuf<uint32_t> deferred; // ... of which the fused candidate kernel left untested (k_resolve_visited), per channel
     uint32_t visit_cap = 0;
     PinnedBuf<ChanState> st_host;
     PinnedBuf<RawTag> rec_host; // written by k_tags through the device-visible mapping
@@ -2057,11 +2133,11 @@ gr4pm_status launch_front(gr4pm_syncword_detection* h, hipStream_t stream, int w
             h->fused_median[which] = true;
             hipLaunchKernelGGL((k_candidates_wave<12, true>), dim3((n_blk + kChain - 1) / kChain, nch), dim3(64), 0, stream,
                                zloc, h->z_stride, cnt, n_words, kChain, h->bitmap[which].p, h->bm_stride,
-                               h->passmap[which].p, h->power_threshold);
+                               h->passmap[which].p, nullptr, h->power_threshold);
         } else {
             constexpr uint32_t kChain = 8;
             hipLaunchKernelGGL((k_candidates_wave<12, false>), dim3((n_blk + kChain - 1) / kChain, nch), dim3(64), 0, stream,
-                               zloc, h->z_stride, cnt, n_words, kChain, h->bitmap[which].p, h->bm_stride, nullptr, 0.0f);
+                               zloc, h->z_stride, cnt, n_words, kChain, h->bitmap[which].p, h->bm_stride, nullptr, nullptr, 0.0f);
         }
     } else {
         hipLaunchKernelGGL(k_candidates, dim3(n_wg, nch), dim3(256), smem, stream, zloc, h->z_stride, cnt, T,
@@ -2353,7 +2429,7 @@ try {
     for (int i = 0; i < kSets; ++i) ok(h->z[i].alloc(h->z_stride * h->n_channels));
     for (int i = 0; i < kSets; ++i) {
         ok(h->bitmap[i].alloc(h->bm_stride * h->n_channels));
-        ok(h->passmap[i].alloc(h->bm_stride * h->n_channels));
+        ok(h->passmap[i].alloc(2 * h->bm_stride * h->n_channels)); // (pass word, defer word) pairs
         ok(h->table[i].alloc(h->table_stride * h->n_channels));
     }
     ok(h->entry.alloc(static_cast<size_t>(h->max_tiles) * h->n_channels));
@@ -2365,6 +2441,7 @@ try {
     ok(h->det.alloc(static_cast<size_t>(h->det_cap) * h->n_channels));
     h->visit_cap = static_cast<uint32_t>((h->max_items + h->T) / (h->T + 1) + h->max_tiles + 16);
     ok(h->visit.alloc(static_cast<size_t>(h->visit_cap) * h->n_channels));
+    ok(h->deferred.alloc(static_cast<size_t>(h->visit_cap) * h->n_channels));
     ok(h->st_host.alloc(h->n_channels));
     ok(h->rec_host.alloc(static_cast<size_t>(h->rec_cap) * h->n_channels));
     if (s == GR4PM_OK && h->generic) s = h->g_tmpl.upload(g_tmpl.data(), g_tmpl.size(), h->stream);
@@ -2513,15 +2590,23 @@ try {
         hipLaunchKernelGGL(k_scan_entries, dim3(nch), dim3(256), 0, s, h->st.p, static_cast<unsigned long long>(A0),
                            cnt, T, n_tiles, h->table[cur].p, h->table_stride, h->gtable[cur].p, h->gtable_stride,
                            h->gentry.p, n_groups, h->entry.p);
-        const bool fused = h->fused_median[cur]; // the front's candidate kernel has done the median tests
         hipLaunchKernelGGL(k_tile_visit, dim3(n_tiles, nch), dim3(64), 0, s, h->bitmap[cur].p, h->bm_stride, cnt, T,
-                           n_tiles, h->entry.p, h->st.p, h->visit.p, h->visit_cap, fused ? h->passmap[cur].p : nullptr,
-                           static_cast<unsigned long long>(A0), h->det.p, h->det_cap);
-        if (!fused) {
-            // at most one visited candidate per T + 1 items (+ one per tile): the grid strides over the real count
-            const uint32_t n_med = std::min<uint32_t>(cnt / (T + 1) + n_tiles + 1, 16384u);
-            hipLaunchKernelGGL(k_median_tests, dim3(n_med, nch), dim3(64), 0, s, zloc, h->z_stride,
-                               static_cast<unsigned long long>(A0), T, h->power_threshold, h->st.p, h->visit.p,
+                           n_tiles, h->entry.p, h->st.p, h->visit.p, h->visit_cap);
+        // at most one visited candidate per T + 1 items (+ one per tile): the grids stride over the real count
+        const uint32_t n_vis = cnt / (T + 1) + n_tiles + 1;
+        if (h->fused_median[cur]) {
+            // the front's candidate kernel has tested (nearly) every candidate: look the visited ones up; the untested ones
+            // (constant input) onto a second list and through the test from memory (the grid strides over their real
+            // count and leaves at once when there is none)
+            hipLaunchKernelGGL(k_resolve_visited, dim3((n_vis + 255) / 256, nch), dim3(64), 0, s,
+                               static_cast<unsigned long long>(A0), h->st.p, h->visit.p, h->visit_cap, h->passmap[cur].p,
+                               h->bm_stride, h->det.p, h->det_cap, h->deferred.p);
+            hipLaunchKernelGGL(k_median_tests<true>, dim3(std::min<uint32_t>(n_vis, 16384u), nch), dim3(64), 0, s, zloc,
+                               h->z_stride, static_cast<unsigned long long>(A0), T, h->power_threshold, h->st.p,
+                               h->deferred.p, h->visit_cap, h->det.p, h->det_cap);
+        } else {
+            hipLaunchKernelGGL(k_median_tests<false>, dim3(std::min<uint32_t>(n_vis, 16384u), nch), dim3(64), 0, s, zloc,
+                               h->z_stride, static_cast<unsigned long long>(A0), T, h->power_threshold, h->st.p, h->visit.p,
                                h->visit_cap, h->det.p, h->det_cap);
         }
     }
