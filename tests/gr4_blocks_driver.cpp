@@ -14,6 +14,11 @@
 // tag positions (a tag is only ever seen at the head of a chunk: coarse_frequency_correction.hpp:76-82).
 //
 // usage: gr4_blocks_driver chain <in.c64> <out_prefix> <host_output 0|1> <max_chunk> <packet_length>
+//        gr4_blocks_driver receiver ... (same arguments): the front end, then PacketReceiver's wiring behind it
+//            (packet_receiver.hpp:123-139,208-240): PayloadMetadataInsert<> -> CostasLoop<> (steered by its tags) ->
+//            SyncwordRemove<> -> ConstellationLLRDecoder<> -> AdditiveScrambler<float> -> HeaderPayloadSplit<> ->
+//            HeaderFecDecoder, and the symbol split of zmq_output (:159-162) HeaderPayloadSplit<c64>; writes
+//            .llr.f32 / .hdr_llr.f32 / .pay_llr.f32 / .hdr_bytes.u8 / .hdr_sym.c64 / .pay_sym.c64 / .tail_counts.bin
 //        gr4_blocks_driver blocks <in.c64> <out_prefix>      (Rotator, InterpolatingFirFilter, PfbArbResampler)
 // writes <out_prefix>.sd.c64 / .sd_tags.bin / .symbols.c64 / .sym_tags.bin (tests/test_gr4_blocks.py reads them)
 #include <gnuradio-4.0/packet-modem/coarse_frequency_correction.hpp>
@@ -26,12 +31,45 @@
 #include <gnuradio-4.0/packet-modem/syncword_detection.hpp>
 #include <gnuradio-4.0/packet-modem/syncword_detection_filter.hpp>
 #include <gnuradio-4.0/packet-modem/syncword_wipeoff.hpp>
+// the blocks behind the front end (packet_receiver.hpp:123-139,159-162), `receiver` mode
+#include <gnuradio-4.0/packet-modem/additive_scrambler.hpp>
+#include <gnuradio-4.0/packet-modem/constellation_llr_decoder.hpp>
+#include <gnuradio-4.0/packet-modem/header_fec_decoder.hpp>
+#include <gnuradio-4.0/packet-modem/header_payload_split.hpp>
+#include <gnuradio-4.0/packet-modem/payload_metadata_insert.hpp>
+#include <gnuradio-4.0/packet-modem/syncword_remove.hpp>
 
 #include "gr4_mini_scheduler.hpp"
 
 using namespace gr::packet_modem;
 
-static int chain(int argc, char** argv)
+// two outputs (HeaderPayloadSplit): one processBulk() with the chunk cut at the next tag; the block publishes its tags
+// on the ports `header` / `payload` (header_payload_split.hpp:83-87)
+template <typename Blk, typename T>
+static bool step_split(Blk& blk, Edge<T>& in, Edge<T>& hdr, Edge<T>& pay, size_t max_chunk)
+{
+    const size_t start = in.rd;
+    if (start >= in.size) return false;
+    const size_t end = std::min({ in.size, start + max_chunk, in.next_tag_after(start) });
+    blk._mergedInputTag = {};
+    if (const gr::Tag* t = in.tag_at(start)) blk._mergedInputTag = { 0, t->map };
+    const size_t n = std::min({ end - start, hdr.data.size() - hdr.size, pay.data.size() - pay.size });
+    if (n == 0) return false;
+    gr::InSpan<T> is(in.data.data() + start, n);
+    gr::OutSpan<T> hs(hdr.data.data() + hdr.size, n), ps(pay.data.data() + pay.size, n);
+    blk.header.published_tags.clear();
+    blk.payload.published_tags.clear();
+    const auto st = blk.processBulk(is, hs, ps);
+    if (!is.consume_called || !hs.publish_called || !ps.publish_called) throw std::runtime_error("HeaderPayloadSplit: consume / publish missing");
+    for (const auto& t : blk.header.published_tags) hdr.tags.push_back({ static_cast<ssize_t>(hdr.size) + t.index, t.map });
+    for (const auto& t : blk.payload.published_tags) pay.tags.push_back({ static_cast<ssize_t>(pay.size) + t.index, t.map });
+    in.rd += is.consumed;
+    hdr.size += hs.published;
+    pay.size += ps.published;
+    return st == gr::work::Status::OK && is.consumed != 0;
+}
+
+static int chain(int argc, char** argv, bool tail = false)
 {
     if (argc < 7) return 2;
     const auto x = read_c64(argv[2]);
@@ -97,12 +135,43 @@ static int chain(int argc, char** argv)
                       &symbol_filter.host_output, &syncword_wipeoff.host_output })
         *ho = host_output; // internal edges; the last block always writes the host span
     costas_loop.host_output = true;
+    if (tail) syncword_wipeoff.host_output = true; // (the tail's edges are dumped: every tail block writes its host span)
+    // ---- behind the front end, exactly as packet_receiver.hpp:123-139 creates them (the literal keys and values)
+    const std::string packet_len_tag_key = "packet_len";
+    const bool log = false;
+    auto& payload_metadata_insert = fg.emplaceBlock<PayloadMetadataInsert<>>({ { "log", log } });
+    auto& tail_costas_loop = fg.emplaceBlock<CostasLoop<>>();
+    auto& syncword_remove = fg.emplaceBlock<SyncwordRemove<>>();
+    auto& constellation_decoder =
+        fg.emplaceBlock<ConstellationLLRDecoder<>>({ { "noise_sigma", 0.7f }, { "constellation", "QPSK" } });
+    auto& descrambler = fg.emplaceBlock<AdditiveScrambler<float>>({ { "mask", uint64_t{ 0x4001U } },
+                                                                    { "seed", uint64_t{ 0x18E38U } },
+                                                                    { "length", uint64_t{ 16U } },
+                                                                    { "reset_tag_key", "header_start" } });
+    auto& header_payload_split = fg.emplaceBlock<HeaderPayloadSplit<>>({ { "packet_len_tag_key", packet_len_tag_key } });
+    auto& header_fec_decoder = fg.emplaceBlock<HeaderFecDecoder>();
+    auto& symbols_split = fg.emplaceBlock<HeaderPayloadSplit<c64>>( // :159-162 (zmq_output)
+        { { "header_size", size_t{ 128 } }, { "payload_length_key", "payload_symbols" } });
 
     syncword_detection.start();
     syncword_filter.start();
     freq_correction.start();
     symbol_filter.start();
     syncword_wipeoff.start();
+    if (tail) {
+        payload_metadata_insert.start();
+        syncword_remove.start();
+        descrambler.start();
+        header_payload_split.start();
+        header_fec_decoder.start();
+        symbols_split.start();
+    }
+    const size_t n_sym_cap = x.size() / sps + 64;
+    Edge<c64> e_pm(n_sym_cap), e_cl(n_sym_cap), e_sr(n_sym_cap), e_hsym(n_sym_cap), e_psym(n_sym_cap), e_sr2(n_sym_cap);
+    Edge<float> e_llr(2 * n_sym_cap), e_ds(2 * n_sym_cap), e_hdr(2 * n_sym_cap), e_pay(2 * n_sym_cap);
+    Edge<uint8_t> e_bytes(n_sym_cap);
+    std::deque<gr::Message> pm_headers;
+    size_t pm_seen_tags = 0, sr_copied = 0;
 
     Edge<c64> e_in(x.size()), e_sd(x.size()), e_sdf(x.size()), e_cfc(x.size()), e_sym(x.size() / sps + 64),
         e_wipe(x.size() / sps + 64), e_out(x.size() / sps + 64);
@@ -136,7 +205,37 @@ static int chain(int argc, char** argv)
         progress |= step(freq_correction, e_sdf, e_cfc, max_chunk, [&](auto& is, auto& os) { return freq_correction.processBulk(is, os); });
         progress |= step(symbol_filter, e_cfc, e_sym, max_chunk, [&](auto& is, auto& os) { return symbol_filter.processBulk(is, os); });
         progress |= step(syncword_wipeoff, e_sym, e_wipe, max_chunk, [&](auto& is, auto& os) { return syncword_wipeoff.processBulk(is, os); });
-        progress |= step(costas_loop, e_wipe, e_out, max_chunk, [&](auto& is, auto& os) { return costas_loop.processBulk(is, os); });
+        if (!tail)
+            progress |= step(costas_loop, e_wipe, e_out, max_chunk, [&](auto& is, auto& os) { return costas_loop.processBulk(is, os); });
+        if (tail) {
+            // every syncword that reaches PayloadMetadataInsert is answered with its parsed_header message, as the
+            // header parser does (packet_receiver.hpp:241-243)
+            for (; pm_seen_tags < e_wipe.tags.size(); ++pm_seen_tags)
+                if (e_wipe.tags[pm_seen_tags].map.contains("syncword_amplitude")) {
+                    pm_headers.push_back({ gr::property_map{ { "packet_length", packet_length } } });
+                    progress = true;
+                }
+            progress |= step(payload_metadata_insert, e_wipe, e_pm, max_chunk, [&](auto& is, auto& os) {
+                std::vector<gr::Message> hv(pm_headers.begin(), pm_headers.end()), ign(4);
+                gr::InSpan<gr::Message> hs(hv.data(), hv.size());
+                gr::OutSpan<gr::Message> igs(ign.data(), ign.size());
+                const auto st = payload_metadata_insert.processBulk(hs, is, os, igs);
+                for (size_t i = 0; i < hs.consumed; ++i) pm_headers.pop_front();
+                if (hs.consumed) progress = true;
+                return st;
+            });
+            progress |= step(tail_costas_loop, e_pm, e_cl, max_chunk, [&](auto& is, auto& os) { return tail_costas_loop.processBulk(is, os); });
+            progress |= step(syncword_remove, e_cl, e_sr, max_chunk, [&](auto& is, auto& os) { return syncword_remove.processBulk(is, os); });
+            // SyncwordRemove's output has two readers (:159-162,216-219): the second one reads a copy of the edge
+            for (; sr_copied < e_sr.size; ++sr_copied) e_sr2.data[sr_copied] = e_sr.data[sr_copied];
+            e_sr2.size = e_sr.size;
+            e_sr2.tags = e_sr.tags;
+            progress |= step(constellation_decoder, e_sr, e_llr, max_chunk, [&](auto& is, auto& os) { return constellation_decoder.processBulk(is, os); });
+            progress |= step(descrambler, e_llr, e_ds, max_chunk, [&](auto& is, auto& os) { return descrambler.processBulk(is, os); });
+            progress |= step_split(header_payload_split, e_ds, e_hdr, e_pay, max_chunk);
+            progress |= step(header_fec_decoder, e_hdr, e_bytes, max_chunk, [&](auto& is, auto& os) { return header_fec_decoder.processBulk(is, os); });
+            progress |= step_split(symbols_split, e_sr2, e_hsym, e_psym, max_chunk);
+        }
         if (!progress) break;
     }
     const std::vector<gr::Tag> sd_tags = e_sd.tags;
@@ -145,6 +244,27 @@ static int chain(int argc, char** argv)
     if (symbol_filter.held_tag_maps() != 0)
         throw std::runtime_error("SymbolFilter wrapper still holds " + std::to_string(symbol_filter.held_tag_maps()) + " tag maps");
 
+    if (tail) {
+        dump(prefix + ".pm.c64", e_pm.data.data(), e_pm.size);
+        dump(prefix + ".costas.c64", e_cl.data.data(), e_cl.size);
+        dump(prefix + ".data.c64", e_sr.data.data(), e_sr.size);
+        dump(prefix + ".llr.f32", e_llr.data.data(), e_llr.size);
+        dump(prefix + ".hdr_llr.f32", e_hdr.data.data(), e_hdr.size);
+        dump(prefix + ".pay_llr.f32", e_pay.data.data(), e_pay.size);
+        dump(prefix + ".hdr_bytes.u8", e_bytes.data.data(), e_bytes.size);
+        dump(prefix + ".hdr_sym.c64", e_hsym.data.data(), e_hsym.size);
+        dump(prefix + ".pay_sym.c64", e_psym.data.data(), e_psym.size);
+        std::vector<uint64_t> pay_tag_idx, hdr_invalid;
+        for (const auto& t : e_pay.tags) pay_tag_idx.push_back(static_cast<uint64_t>(t.index));
+        for (const auto& t : e_bytes.tags)
+            if (t.map.contains("invalid_header")) hdr_invalid.push_back(static_cast<uint64_t>(t.index));
+        dump(prefix + ".pay_tag_index.u64", pay_tag_idx.data(), pay_tag_idx.size());
+        const uint64_t tc[8] = { e_pm.size, e_cl.size, e_sr.size, e_llr.size, e_hdr.size, e_pay.size, e_bytes.size, hdr_invalid.size() };
+        dump(prefix + ".tail_counts.bin", tc, 8);
+        std::printf("receiver tail: pm %zu (tags %zu) data %zu llr %zu header llr %zu payload llr %zu header bytes %zu (invalid %zu) "
+                    "symbol split %zu + %zu\n", e_pm.size, e_pm.tags.size(), e_sr.size, e_llr.size, e_hdr.size, e_pay.size,
+                    e_bytes.size, hdr_invalid.size(), e_hsym.size, e_psym.size);
+    }
     dump(prefix + ".symbols.c64", e_out.data.data(), e_out.size);
     dump_tags(prefix + ".sd_tags.bin", sd_tags);
     dump_tags(prefix + ".sym_tags.bin", e_sym.tags);
@@ -354,10 +474,11 @@ int main(int argc, char** argv)
 {
     try {
         if (argc >= 2 && std::strcmp(argv[1], "chain") == 0) return chain(argc, argv);
+        if (argc >= 2 && std::strcmp(argv[1], "receiver") == 0) return chain(argc, argv, true);
         if (argc >= 2 && std::strcmp(argv[1], "blocks") == 0) return blocks(argc, argv);
         if (argc >= 2 && std::strcmp(argv[1], "mirror") == 0) return mirror(argc, argv);
         if (argc >= 2 && std::strcmp(argv[1], "threads") == 0) return threads(argc, argv);
-        std::fprintf(stderr, "usage: %s chain|blocks|mirror|threads ...\n", argv[0]);
+        std::fprintf(stderr, "usage: %s chain|receiver|blocks|mirror|threads ...\n", argv[0]);
         return 2;
     } catch (const std::exception& e) {
         std::fprintf(stderr, "gr4_blocks_driver: %s\n", e.what());

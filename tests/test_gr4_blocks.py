@@ -114,6 +114,60 @@ def test_receiver_front_end_through_processBulk(tmp_path, host_output, max_chunk
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("host_output,max_chunk", [(1, 1 << 20), (0, 30000)])
+def test_receiver_behind_the_front_end_through_processBulk(tmp_path, host_output, max_chunk):
+    """The drop-in classes BEHIND the front end -- PayloadMetadataInsert<>, CostasLoop<> steered by its `constellation` /
+    `loop_bandwidth` tags, SyncwordRemove<>, ConstellationLLRDecoder<>, AdditiveScrambler<float>, HeaderPayloadSplit<>,
+    HeaderFecDecoder, and the symbol split of zmq_output HeaderPayloadSplit<std::complex<float>> -- created with the
+    literal property maps of packet_receiver.hpp:123-139,159-162, wired like :208-240 and driven through processBulk()
+    chunk by chunk (tags at chunk heads, parsed_header messages, two-output split, the Resampling<1, 64> decoder):
+    their outputs are the ones of the Python composition over the same C ABI (blocks.PacketReceiver(soft_bits) and the
+    header-loop blocks, which tests/test_gpu_parity.py holds against the oracle) bit for bit.  Until round 5 the
+    processBulk() bodies of these six wrappers had never been instantiated by any compiler."""
+    import torch
+    ge.build_gr4_driver()
+    pkg = ge.load_package()
+    sps, payload_len = 4, 100
+    x, rrc, starts = _packets(8, payload_len, seed=9)
+    fin = tmp_path / "in.c64"
+    x.tofile(fin)
+    prefix = str(tmp_path / "out")
+    env = dict(os.environ, GR4PM_DATA_DIR=os.path.join(ge.PKG_DIR, "data"))
+    r = subprocess.run([DRIVER, "receiver", str(fin), prefix, str(host_output), str(max_chunk), str(payload_len)],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr + r.stdout
+    print(r.stdout)
+    rx = pkg.PacketReceiver(max_items=x.size, soft_bits=True)
+    res = rx.process_bulk(torch.from_numpy(x).cuda(), payload_len)
+    f = lambda name, dt: np.fromfile(prefix + name, dtype=dt)
+    costas, llr = f(".costas.c64", np.complex64), f(".llr.f32", np.float32)
+    want_costas, want_llr = res["symbols"].cpu().numpy(), res["llr"].cpu().numpy()
+    n_pkt = len(starts)
+    assert costas.size == want_costas.size == n_pkt * (64 + 128 + (payload_len + 4) * 4)
+    assert np.array_equal(costas.view(np.uint64), want_costas.view(np.uint64))      # PayloadMetadataInsert + tag-steered Costas
+    assert llr.size == want_llr.size == 2 * n_pkt * (128 + (payload_len + 4) * 4)
+    assert np.array_equal(llr.view(np.uint32), want_llr.view(np.uint32))            # SyncwordRemove + LLR decoder
+    # the header loop over those LLRs: descrambler -> split -> LDPC decoder
+    hd = pkg.HeaderDecoder().process_bulk(res["llr"], res["llr_tags"])
+    hdr_llr, pay_llr, hdr_bytes = f(".hdr_llr.f32", np.float32), f(".pay_llr.f32", np.float32), f(".hdr_bytes.u8", np.uint8)
+    assert hdr_llr.size == 256 * n_pkt and pay_llr.size == 8 * (payload_len + 4) * n_pkt
+    assert np.array_equal(pay_llr.view(np.uint32), hd["payload_llr"].cpu().numpy().view(np.uint32))
+    assert np.array_equal(f(".pay_tag_index.u64", np.uint64), hd["payload_tags"]["index"])
+    assert np.array_equal(hdr_bytes, np.asarray(hd["header_bytes"]).reshape(-1))
+    counts = f(".tail_counts.bin", np.uint64)
+    assert counts[7] == int(np.sum(hd["invalid"]))  # (random header symbols: the decoder reports what it finds)
+    # the symbol split of zmq_output: SyncwordRemove's symbols, 128 per header, payload_symbols per payload
+    data, data_tags = pkg.SyncwordRemove(64).process_bulk(res["symbols"], res["packet_tags"])
+    sym_tags = data_tags.copy()
+    sym_tags["payload_bits"] = sym_tags["payload_symbols"]  # payload_length_key = "payload_symbols" (:161)
+    hs, ps, _, _ = pkg.HeaderPayloadSplit(128).process_bulk(data, sym_tags)
+    assert np.array_equal(f(".data.c64", np.complex64).view(np.uint64), data.cpu().numpy().view(np.uint64))
+    assert np.array_equal(f(".hdr_sym.c64", np.complex64).view(np.uint64), hs.cpu().numpy().view(np.uint64))
+    assert np.array_equal(f(".pay_sym.c64", np.complex64).view(np.uint64), ps.cpu().numpy().view(np.uint64))
+    assert hs.numel() == 128 * n_pkt and ps.numel() == (payload_len + 4) * 4 * n_pkt
+
+
+@pytest.mark.gpu
 def test_device_arena_gives_identical_results(tmp_path):
     """host_output = 0 on the internal edges (samples stay on the device between wrapped blocks, one staging at
     the entry and one at the exit of the chain) == every block staging through the host, bit for bit"""
