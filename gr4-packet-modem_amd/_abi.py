@@ -186,7 +186,7 @@ EXPORTS = [
     "gr4pm_packet_receiver_set_symbol_pdu_callback",
     "gr4pm_syncword_detection_create", "gr4pm_syncword_detection_destroy",
     "gr4pm_syncword_detection_reset", "gr4pm_syncword_detection_syncword_samples_size",
-    "gr4pm_syncword_detection_self_corr", "gr4pm_syncword_detection_items_consumed",
+    "gr4pm_syncword_detection_self_corr", "gr4pm_syncword_detection_items_consumed", "gr4pm_syncword_detection_scan_counts",
     "gr4pm_syncword_detection_process", "gr4pm_syncword_detection_last_zpow",
     "gr4pm_syncword_detection_correlate_only",
     "gr4pm_syncword_detection_hint_next", "gr4pm_syncword_detection_announce",
@@ -275,6 +275,8 @@ def lib():
     L.gr4pm_syncword_detection_self_corr.restype = C.c_float
     L.gr4pm_syncword_detection_items_consumed.argtypes = [vp]
     L.gr4pm_syncword_detection_items_consumed.restype = C.c_uint64
+    L.gr4pm_syncword_detection_scan_counts.argtypes = [vp, sz, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.gr4pm_syncword_detection_scan_counts.restype = None
     L.gr4pm_syncword_detection_process.argtypes = [vp, vp, sz, sz, vp, sz, szp, vp, sz, vp]
     L.gr4pm_syncword_detection_last_zpow.argtypes = [vp, vp, sz]
     L.gr4pm_syncword_detection_correlate_only.argtypes = [vp, vp, sz, sz]

@@ -174,6 +174,12 @@ class SyncwordDetection:
     def _items_consumed(self):
         return lib().gr4pm_syncword_detection_items_consumed(self._h)
 
+    def scan_counts(self, channel=0):
+        """(candidates the scan visited, of which tested by the separate pass over the powers) in the last call"""
+        v, m = C.c_uint64(0), C.c_uint64(0)
+        lib().gr4pm_syncword_detection_scan_counts(self._h, channel, C.byref(v), C.byref(m))
+        return v.value, m.value
+
     def reset(self):
         """back to the state right after start() without rebuilding the templates"""
         check(lib().gr4pm_syncword_detection_reset(self._h), "SyncwordDetection.reset")

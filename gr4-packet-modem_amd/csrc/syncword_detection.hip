@@ -653,6 +653,78 @@ __device__ __forceinline__ void wave_prefix_max4(float& a, float& b, float& c, f
 // (k_tile_visit) then only has to look its visited candidates up: the separate pass over the powers (k_median_tests:
 // 6 KB read per visited candidate, 1.2 GB and 205 us per 2^28 samples) and the visit list are gone.  Every candidate
 // is tested, visited or not: on noise there is about one per block, and about two in three are visited.
+// hpp:273-279 for the candidate at row R (compile time), lane lp (uniform) of the current block, on registers: its history
+// is the items at or behind its own offset in the block before, the whole current block, and the items up to its own
+// offset in the next block = 2T + 1 powers.  Counted per lane (a compare and an add-with-carry per row: two vector
+// instructions, nothing on the scalar unit -- a ballot, a population count and a scalar add per row were three issue
+// slots), summed over the wave once.  Uniform result.
+template <int TQ, int R>
+__device__ __forceinline__ bool median_in_registers(const float* prv, const float* cur, const float* nxt, int lp, int lane,
+                                                    float power_threshold)
+{
+    constexpr uint32_t T = TQ * 64;
+    const float best = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur[R]), lp));
+    const float thr = best / power_threshold; // hpp:275
+    uint32_t acc = 0;
+    const bool at_or_before = lane <= lp, at_or_after = lane >= lp;
+    // the 2 TQ - 1 rows that lie wholly inside the history, four at a time (a compare's mask is read by its add three
+    // instructions later: no wait states to pad), then the two partial rows
+    float full[2 * TQ - 1];
+    {
+        int n = 0;
+#pragma unroll
+        for (int q = 0; q < TQ; ++q) {
+            if (q > R) full[n++] = prv[q];
+            full[n++] = cur[q];
+            if (q < R) full[n++] = nxt[q];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q + 4 <= 2 * TQ - 1; q += 4) {
+        unsigned long long m0, m1, m2, m3;
+        asm("v_cmp_lt_f32_e64 %1, %5, %9\n\t"
+            "v_cmp_lt_f32_e64 %2, %6, %9\n\t"
+            "v_cmp_lt_f32_e64 %3, %7, %9\n\t"
+            "v_cmp_lt_f32_e64 %4, %8, %9\n\t"
+            "v_addc_co_u32_e64 %0, %1, %0, 0, %1\n\t"
+            "v_addc_co_u32_e64 %0, %2, %0, 0, %2\n\t"
+            "v_addc_co_u32_e64 %0, %3, %0, 0, %3\n\t"
+            "v_addc_co_u32_e64 %0, %4, %0, 0, %4"
+            : "+v"(acc), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
+            : "v"(full[q]), "v"(full[q + 1]), "v"(full[q + 2]), "v"(full[q + 3]), "v"(thr));
+    }
+#pragma unroll
+    for (int q = (2 * TQ - 1) / 4 * 4; q < 2 * TQ - 1; ++q) acc += full[q] < thr ? 1u : 0u;
+    acc += (at_or_before && prv[R] < thr) ? 1u : 0u;
+    acc += (at_or_after && nxt[R] < thr) ? 1u : 0u;
+    asm volatile("s_nop 1\n\t"
+                 "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+                 : "+v"(acc));
+    const uint32_t below = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(acc), 63));
+    return 2u * below >= 2u * T + 1u; // hpp:279
+}
+template <int TQ, int R>
+__device__ __forceinline__ bool median_dispatch(int r, const float* prv, const float* cur, const float* nxt, int lp, int lane,
+                                                float power_threshold)
+{
+    if constexpr (R >= TQ) {
+        return false;
+    } else {
+        if (r == R) return median_in_registers<TQ, R>(prv, cur, nxt, lp, lane, power_threshold); // (uniform: a scalar branch)
+        return median_dispatch<TQ, R + 1>(r, prv, cur, nxt, lp, lane, power_threshold);
+    }
+}
+
 template <int TQ, bool MEDIAN>
 __global__ __launch_bounds__(64) void k_candidates_wave(const float* __restrict__ zbase, size_t z_stride, uint32_t cnt,
                                                         uint32_t n_words, uint32_t chain,
@@ -666,11 +738,17 @@ __global__ __launch_bounds__(64) void k_candidates_wave(const float* __restrict_
     unsigned long long* bmp = bitmap + static_cast<size_t>(blockIdx.y) * bm_stride;
     unsigned long long* pmp = MEDIAN ? passmap + 2 * static_cast<size_t>(blockIdx.y) * bm_stride : nullptr;
     (void)defermap;
-    // At most kTestsPerBlock candidates of a block are tested here; the others are DEFERRED (defermap): if the scan
-    // visits one of them, k_tile_visit puts it on the visit list and k_median_tests reads its history from memory as in
-    // round 4.  On noise and on packet streams a block has one to five candidates; on constant input (all-zero: the
-    // reference's own benchmark input, where every item ties with its window and is a candidate) it has 768, of which the
-    // scan visits one -- testing them all made that input seven times slower than round 4.
+    // Which candidates are tested here.  (1) Only candidates the scan CAN visit.  The scan visits p when a reset falls
+    // into (prev(p), p], prev(p) = the candidate before p; resets are v + T + 1 for visited candidates v: so some
+    // candidate must lie in [prev(p) - T, p - T - 1] -- for p and prev(p) in one block that is "a candidate of the block
+    // before at an offset in [offset(prev(p)), offset(p) - 1]", two bitmap look-ups.  A packet stream has about five
+    // candidates a block (the correlation's side lobes around every local maximum) and the scan visits one.  The first
+    // candidate of a block, and every candidate where the look-up needs flags this wave does not hold (the first block of
+    // its chain), counts as visitable.  (2) At most kTestsPerBlock per block (constant input -- the all-zero stream of the
+    // reference's own benchmarks -- makes every item a candidate: 768 a block, of which the scan visits one).
+    // Every candidate that is NOT tested is DEFERRED (second word of the pair): should the scan visit it after all,
+    // k_resolve_visited hands it to k_median_tests<true>, which reads its history from memory as in round 4.  The rules
+    // above therefore decide what a candidate costs, never what the detector finds.
     constexpr uint32_t kTestsPerBlock = 8;
     const uint32_t avail = cnt + T; // readable items
     const uint32_t n_blk = (n_words + TQ - 1) / TQ;
@@ -713,6 +791,7 @@ __global__ __launch_bounds__(64) void k_candidates_wave(const float* __restrict_
         }
     }
     scans(cur, rs, rowmax);
+    unsigned long long before_mine = 0; // the candidate words of the block before (lane r: row r), known from b0 + 1 on
     for (uint32_t b = b0; b < b1; ++b) {
         load(b + 1, nxt);
         float nrs[TQ];
@@ -721,100 +800,78 @@ __global__ __launch_bounds__(64) void k_candidates_wave(const float* __restrict_
         before[0] = ninf;
 #pragma unroll
         for (int r = 1; r < TQ; ++r) before[r] = smax_bits(before[r - 1], nrowmax[r - 1]);
-        unsigned long long mine = 0, mine_pass = 0, mine_defer = 0;
-        uint32_t tests_left = kTestsPerBlock;
+        unsigned long long mine = 0;
         int after = ninf; // maximum of the rows behind r in this block: built while r walks down
 #pragma unroll
         for (int r = TQ - 1; r >= 0; --r) {
             const int U = smax_bits(after, before[r]);
-            unsigned long long word = 0, pword = 0, dword = 0;
+            unsigned long long word = 0;
             if (fkey(rowmax[r]) >= fkey(U)) { // (uniform: a scalar branch)
                 const float fwd = __shfl(nxt[r], rl);              // the next block's row r in item order
                 const float pr = __shfl(wave_prefix_max(fwd), rl); // its prefix maximum up to the lane's own offset
                 const float m = fmaxf(fmaxf(wave_prev(rs[r]), __builtin_bit_cast(float, U)), pr);
                 const uint32_t pos = b * T + 64u * r + rl;
-                unsigned long long cand = __ballot(pos < cnt && cur[r] >= m); // one bit per lane (items reversed)
-                word = __brevll(cand); // back to item order
-                if (MEDIAN) {
-                    // hpp:273-279 for every candidate of the row, one after the other (uniform loop; usually one pass):
-                    // its history is the items at or behind its own offset in the block before, the whole current
-                    // block, and the items up to its own offset in the next block = 2T + 1 powers, all in registers
-                    unsigned long long passed = 0;
-                    while (cand) {
-                        if (tests_left == 0) { // the block's budget is spent: the rest of the row is deferred
-                            dword = __brevll(cand);
-                            break;
+                word = __brevll(__ballot(pos < cnt && cur[r] >= m)); // back to item order
+            }
+            if (lane == r) mine = word;
+            after = smax_bits(after, rowmax[r]);
+        }
+        unsigned long long mine_pass = 0, mine_defer = 0;
+        if (MEDIAN) {
+            // the block's candidates in position order (a uniform walk over the rows that have any: usually one or two)
+            unsigned long long rows = __ballot(mine != 0);
+            uint32_t tests_left = kTestsPerBlock;
+            int prev_pos = -1; // offset of the candidate before the current one inside this block
+            const bool have_before = b != b0;
+            while (rows) {
+                const int r = __ffsll(static_cast<long long>(rows)) - 1;
+                rows &= rows - 1;
+                const unsigned long long word =
+                    (static_cast<unsigned long long>(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mine >> 32), r))) << 32) |
+                    static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mine), r));
+                unsigned long long todo = word, passed = 0, deferred = 0;
+                if (tests_left == 0 || __popcll(word) > 8) {
+                    // a row full of candidates (ties: constant input), or the block's budget is spent: the whole row is
+                    // deferred without a look at its candidates one by one
+                    deferred = word;
+                    prev_pos = 64 * r + 63 - __clzll(static_cast<long long>(word));
+                    todo = 0;
+                }
+                while (todo) {
+                    const int bit = __ffsll(static_cast<long long>(todo)) - 1;
+                    todo &= todo - 1;
+                    const int o = 64 * r + bit;
+                    bool visitable = true;
+                    if (prev_pos >= 0) {
+                        // a candidate of the block before at an offset in [prev_pos, o - 1]?
+                        visitable = false;
+                        if (have_before) {
+                            const int lo = prev_pos, hi = o - 1, rlo = lo >> 6, rhi = hi >> 6;
+                            unsigned long long mask = ~0ull;
+                            if (lane == rlo) mask &= ~0ull << (lo & 63);
+                            if (lane == rhi) mask &= ~0ull >> (63 - (hi & 63));
+                            visitable = __ballot(lane >= rlo && lane <= rhi && (before_mine & mask) != 0) != 0;
                         }
-                        --tests_left;
-                        const int lp = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(cand)) - 1);
-                        cand &= cand - 1;
-                        const float best = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur[r]), lp));
-                        const float thr = best / power_threshold; // hpp:275
-                        // counted per lane (a compare and an add-with-carry per row: two vector instructions, nothing on
-                        // the scalar unit -- a ballot, a population count and a scalar add per row were three issue slots),
-                        // summed over the wave once per candidate
-                        uint32_t acc = 0;
-                        const bool at_or_before = lane <= lp, at_or_after = lane >= lp;
-                        // the 2 TQ - 1 rows that lie wholly inside the history, four at a time (a compare's mask is read
-                        // by its add three instructions later: no wait states to pad), then the two partial rows
-                        float full[2 * TQ - 1];
-                        {
-                            int n = 0;
-#pragma unroll
-                            for (int q = 0; q < TQ; ++q) {
-                                if (q > r) full[n++] = prv[q];
-                                full[n++] = cur[q];
-                                if (q < r) full[n++] = nxt[q];
-                            }
-                        }
-#pragma unroll
-                        for (int q = 0; q + 4 <= 2 * TQ - 1; q += 4) {
-                            unsigned long long m0, m1, m2, m3;
-                            asm("v_cmp_lt_f32_e64 %1, %5, %9\n\t"
-                                "v_cmp_lt_f32_e64 %2, %6, %9\n\t"
-                                "v_cmp_lt_f32_e64 %3, %7, %9\n\t"
-                                "v_cmp_lt_f32_e64 %4, %8, %9\n\t"
-                                "v_addc_co_u32_e64 %0, %1, %0, 0, %1\n\t"
-                                "v_addc_co_u32_e64 %0, %2, %0, 0, %2\n\t"
-                                "v_addc_co_u32_e64 %0, %3, %0, 0, %3\n\t"
-                                "v_addc_co_u32_e64 %0, %4, %0, 0, %4"
-                                : "+v"(acc), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
-                                : "v"(full[q]), "v"(full[q + 1]), "v"(full[q + 2]), "v"(full[q + 3]), "v"(thr));
-                        }
-#pragma unroll
-                        for (int q = (2 * TQ - 1) / 4 * 4; q < 2 * TQ - 1; ++q) acc += full[q] < thr ? 1u : 0u;
-                        acc += (at_or_before && prv[r] < thr) ? 1u : 0u;
-                        acc += (at_or_after && nxt[r] < thr) ? 1u : 0u;
-                        asm volatile("s_nop 1\n\t"
-                                     "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                                     "s_nop 1\n\t"
-                                     "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                                     "s_nop 1\n\t"
-                                     "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                                     "s_nop 1\n\t"
-                                     "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                                     "s_nop 1\n\t"
-                                     "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-                                     "s_nop 1\n\t"
-                                     "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
-                                     : "+v"(acc));
-                        const uint32_t below = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(acc), 63));
-                        if (2u * below >= 2u * T + 1u) passed |= 1ull << lp; // hpp:279
                     }
-                    pword = __brevll(passed);
+                    prev_pos = o;
+                    if (visitable && tests_left != 0) {
+                        --tests_left;
+                        if (median_dispatch<TQ, 0>(r, prv, cur, nxt, 63 - bit, lane, power_threshold)) passed |= 1ull << bit;
+                    } else {
+                        deferred |= 1ull << bit;
+                    }
+                }
+                if (lane == r) {
+                    mine_pass = passed;
+                    mine_defer = deferred;
                 }
             }
-            if (lane == r) {
-                mine = word;
-                mine_pass = pword;
-                mine_defer = dword;
-            }
-            after = smax_bits(after, rowmax[r]);
+            before_mine = mine;
         }
         const uint32_t w = b * TQ + lane;
         if (lane < TQ && w < n_words) {
             bmp[w] = mine;
-            if (MEDIAN) // (pass word, defer word) side by side: k_tile_visit reads both with one 16-byte load
+            if (MEDIAN) // (pass word, defer word) side by side: k_resolve_visited reads both with one 16-byte load
                 reinterpret_cast<ulonglong2*>(pmp)[w] = make_ulonglong2(mine_pass, mine_defer);
         }
 #pragma unroll
@@ -2487,6 +2544,16 @@ try {
     return h->items_consumed;
 }
 GR4PM_ABI_CATCH_RET(0)
+
+void gr4pm_syncword_detection_scan_counts(const gr4pm_syncword_detection* h, size_t channel, uint64_t* visited,
+                                          uint64_t* tested_from_memory)
+try {
+    // (the host copy of the channel's counters, written by the last process() call before they were reset)
+    if (!h || channel >= h->n_channels) return;
+    if (visited) *visited = h->st_host.p[channel].vis_cnt;
+    if (tested_from_memory) *tested_from_memory = h->fused_median[h->cur] ? h->st_host.p[channel].def_cnt : h->st_host.p[channel].vis_cnt;
+}
+GR4PM_ABI_CATCH_VOID
 
 gr4pm_status gr4pm_syncword_detection_correlate_only(gr4pm_syncword_detection* h, const gr4pm_c64* in,
                                                      size_t in_stride, size_t n_in)

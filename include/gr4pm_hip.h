@@ -109,6 +109,11 @@ gr4pm_status gr4pm_syncword_detection_reset(gr4pm_syncword_detection* h);
 size_t gr4pm_syncword_detection_syncword_samples_size(const gr4pm_syncword_detection* h);
 float gr4pm_syncword_detection_self_corr(const gr4pm_syncword_detection* h);
 uint64_t gr4pm_syncword_detection_items_consumed(const gr4pm_syncword_detection* h);
+/* Diagnostics of the last process() call (no reference counterpart): how many candidates the scan visited in the channel
+ * (the items whose history the reference tests, :268-279) and how many of those were tested by the separate pass over
+ * the powers instead of on the candidate kernel's registers (all of them for a time_threshold other than 768). */
+void gr4pm_syncword_detection_scan_counts(const gr4pm_syncword_detection* h, size_t channel, uint64_t* visited,
+                                          uint64_t* tested_from_memory);
 /* == processBulk().  in: [n_channels][in_stride] items, n_in valid per channel.
  * out: [n_channels][out_stride] or NULL (skip the delayed pass-through copy when the
  * consumer reads the input ring itself).  *n_done = items consumed == published per channel

@@ -360,6 +360,25 @@ def test_candidate_kernels_agree(pkg, monkeypatch):
         res[kind] = (one, chunks)
     monkeypatch.delenv("GR4PM_CANDIDATES_LDS")
     (one_w, ch_w), (one_l, ch_l), (one_s, ch_s) = res["wave"], res["lds"], res["split"]
+    # where the tests ran (gr4pm_syncword_detection_scan_counts): "split" tests every visited candidate from memory; the
+    # fused kernel leaves that to the candidates it deferred -- here the ties of the constant stretches (every item a
+    # candidate, eight tested per block) and little else: a candidate it rules out as unvisitable is never visited
+    counts = {}
+    for kind in ("wave", "split"):
+        monkeypatch.delenv("GR4PM_SD_SEPARATE_MEDIAN", raising=False)
+        if kind == "split":
+            monkeypatch.setenv("GR4PM_SD_SEPARATE_MEDIAN", "1")
+        for name, sig_x in (("stream", x), ("noise", sig.awgn(n, 0.2, 99)), ("zeros", np.zeros(n, np.complex64))):
+            sd1 = pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, power_threshold=9.5, max_items=n)
+            sd1.process_bulk(dev(sig_x.astype(np.complex64)), want_output=False, tags_cap=4096)
+            counts[kind, name] = sd1.scan_counts()
+    monkeypatch.delenv("GR4PM_SD_SEPARATE_MEDIAN", raising=False)
+    for name in ("stream", "noise", "zeros"):
+        visited, from_memory = counts["split", name]
+        assert visited == from_memory >= n // 2000 and counts["wave", name][0] == visited, (name, counts)
+    assert counts["wave", "noise"][1] <= counts["wave", "noise"][0] // 20, counts      # noise: (nearly) everything in registers
+    assert counts["wave", "zeros"][1] >= counts["wave", "zeros"][0] * 9 // 10, counts  # constant input: deferred, tested from memory
+    assert 0 < counts["wave", "stream"][1] < counts["wave", "stream"][0] // 3, counts
     assert sum(t.size for t in one_w[2]) >= 8
     for c in range(2):
         assert same_tags(one_w[2][c], one_l[2][c]) and same_tags(one_w[2][c], one_s[2][c])
