@@ -732,15 +732,16 @@ def config5_leg(pkg, device, total=1 << 30, window=1 << 28, passes=2):
         dt = time.perf_counter() - t0
         # the correlator alone on one window: HIP events on the launch stream
         xs = x[:window]
-        sd.correlate_only(xs)
+        for _ in range(ROOF_WARM // 3):
+            sd.correlate_only(xs)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(3):
+        for _ in range(5):
             sd.correlate_only(xs)
         e1.record()
         torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 3
+        ms = e0.elapsed_time(e1) / 5
         samples = ((window - nfft) // S + 1) * S
         fl = correlator_flops_per_sample(2 * b + 1, nfft, S) * samples / (ms * 1e-3) / 1e12
         per_bins[str(2 * b + 1)] = {
@@ -973,6 +974,7 @@ def correlator_flops_per_sample(n_bins, n_fft=N_FFT, stride=1752):
     return ((1 + n_bins) * 5.0 * n_fft * np.log2(n_fft) + 6.0 * n_bins * n_fft + 1.5 * n_fft + 4.0 * n_bins * stride) / stride
 
 
+ROOF_WARM = 30  # untimed launches in front of a kernel-alone timing (see the roofline leg in main())
 HBM_ACHIEVABLE_GBS = 6300.0  # MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured (float4 copy)
 
 
@@ -1001,7 +1003,8 @@ def per_bins_roofline(pkg, rrc, bpsk, x, n_items, stream, reps=5):
     with torch.cuda.stream(stream):
         for b in range(0, BINS + 1):
             sd = pkg.SyncwordDetection(rrc, SYNCWORD, bpsk, -b, b, power_threshold=9.5, max_items=n_items)
-            sd.correlate_only(x)
+            for _ in range(ROOF_WARM // 2):
+                sd.correlate_only(x)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -1512,7 +1515,11 @@ def main():
             if own_detector:
                 sd = pkg.SyncwordDetection(rrc, SYNCWORD, bpsk, -BINS, BINS, power_threshold=9.5, max_items=n_items,
                                            n_channels=args.channels)
-            sd.correlate_only(x)
+            # untimed launches first: the legs before this one end in host work, and the first launches after a few idle
+            # milliseconds run at the clocks the chip idles at (tools/r5_sustained.py: 2.99 ms for the first ten launches
+            # after 3 s of idling against 2.70 - 2.74 ms for every launch of 12 s back to back)
+            for _ in range(ROOF_WARM):
+                sd.correlate_only(x)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
