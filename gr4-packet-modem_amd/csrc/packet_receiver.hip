@@ -1175,6 +1175,13 @@ try {
         const int order[5] = { 4, 0, 3, 1, 2 }; // worker index of the stage reading queues[k]
         for (int k = 0; k < 5; ++k)
             if (k == 0 || !h->workers[order[k - 1]].joinable()) queues[k]->stop();
+        if (!h->workers[3].joinable()) { // stage 1b never started: nobody may wait for it
+            {
+                std::lock_guard<std::mutex> lk(h->stage1b_mutex);
+                h->stage1b_abort = true;
+            }
+            h->stage1b_cv.notify_all();
+        }
         for (int k = 0; k < 5; ++k) {
             if (!h->workers[order[k]].joinable()) continue;
             h->workers[order[k]].join();
