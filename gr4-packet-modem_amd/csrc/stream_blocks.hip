@@ -109,7 +109,7 @@ __device__ __forceinline__ void rot_step(cf& e, cf inc, unsigned& counter)
 
 // cmul(a, b) as three packed instructions: (a.x b.x, a.x b.y), (a.y b.y, a.y b.x), then
 // (t.x - u.x, t.y + u.y) -- the same four products and two sums, each rounded once
-__device__ __forceinline__ cf cmul_pk(cf a, cf b)
+__device__ __forceinline__ __attribute__((unused)) cf cmul_pk(cf a, cf b)
 {
     cf t, u, r;
     asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
@@ -1038,40 +1038,133 @@ static_assert(kFastPitch % 2 == 0 && kFastPitch * kFastSps >= kFastOrigin + (kFa
 // ABL (timing only, wrong results; GR4PM_SYMF_ABL): 1 = no MAC phase, 2 = no tile fill (no item loads, no rotation)
 // (second launch bound: eight waves per SIMD, i.e. at most 64 VGPRs -- hipcc takes 80 when left alone, and the kernel is
 // bound by the workgroups a CU holds: 16 instead of 12)
-template <int ABL>
-__global__ __launch_bounds__(kFastThreads, 8) void k_symbol_filter_fast(const cf* __restrict__ in0, const cf* __restrict__ carry0,
-                                                                     unsigned cap, const float* __restrict__ taps,
-                                                                     const SymWg* __restrict__ plan, cf* __restrict__ out0,
-                                                                     CfcDev cfc0, const SymChan* __restrict__ chans,
-                                                                     unsigned n_wg, unsigned tiles)
+// Everything uniform stays on the scalar unit (round 5: 218.5 M -> 166.5 M vector wave-instructions per 2^28 samples, 391 ->
+// 298 per wave and tile of which 176 are the multiply-adds; 558 -> 521 us alone = 5.2 TB/s of input + output):
+//   * the channel's pointers come from ONE table entry through scalar loads -- the single-channel launch passes its entry
+//     by value as the FIRST kernel argument and the kernel reads it where it lies in the kernarg segment, so both launch
+//     forms share one code path and nothing of it stays live across the multiply-adds (the 44 taps need 44 SGPRs there;
+//     with separate in / carry / out / CfcDev arguments hipcc spilled ~65 SGPRs per tile through v_writelane / v_readlane)
+//   * further segments of a span are read through constant-address-space pointers (s_load; hipcc reads them with
+//     flat_load when it cannot prove the tables unwritten, which made every index of the fill a 64-bit vector value)
+//   * per lane only ch * 8 varies: chunk c_first + ch of the segment; checkpoint, items and tile slots are a uniform
+//     base plus that, the four tile addresses of a chunk are (uniform phase row and column of item t) + 16 ch bytes
+// Bit-exact as before: same packed products and sums (rot8_pk), same item-by-item path for the chunks that overlap a
+// segment end, the head / input seam of a two-piece input, or a renormalisation.
+typedef const unsigned long long __attribute__((address_space(4)))* symf_cu64;
+typedef const unsigned __attribute__((address_space(4)))* symf_cu32;
+typedef const float __attribute__((address_space(4)))* symf_cf32;
+static_assert(sizeof(SymChan) == 88 && offsetof(SymChan, segs) == 32 && offsetof(SymChan, n_segs) == 56 &&
+                  offsetof(SymChan, head) == 72 && offsetof(SymChan, n_head) == 80 && sizeof(RotSeg) == 48 &&
+                  offsetof(RotSeg, ck0) == 20,
+              "k_symbol_filter_fast reads these tables word by word");
+template <int ABL, bool LOOP>
+__global__ __launch_bounds__(kFastThreads, 8) void k_symbol_filter_fast(SymChan one, const SymChan* __restrict__ chans,
+                                                                     const SymWg* __restrict__ plan,
+                                                                     const float* __restrict__ taps,
+                                                                     const cf* __restrict__ ck, unsigned cap, unsigned n_wg,
+                                                                     unsigned tiles)
 {
+    (void)one; // read in place: the first 88 bytes of the kernarg segment
     __shared__ __attribute__((aligned(16))) cf tile[kFastSps * kFastPitch];
-    // `tiles` consecutive plan entries per workgroup: the entry of the NEXT tile is requested (one 64-byte scalar load)
-    // before this tile's work starts, so that from the second tile on the vector loads of the fill go out at once --
-    // alone the kernel is bound by (workgroups a CU holds) / (life time of one), and two thirds of that life time
-    // were round trips in front of the first vector load: plan entry -> segment -> increment / counter
+    // LOOP (GR4PM_SYMF_TILES > 1; the default is one tile per workgroup since round 5): `tiles` consecutive plan entries
+    // per workgroup, the entry of the NEXT tile requested (one 64-byte scalar load) while this tile's results are stored.
+    // Round 3 ran two tiles per workgroup with the next entry requested in FRONT of the tile's work; its 16 SGPRs do
+    // not fit beside the 44 taps (80 SGPRs at eight waves per SIMD) and the loop-carried state cost ~50 v_writelane /
+    // v_readlane per tile.  Measured with this kernel: 521 us with one tile, 538 with two (184.3 M instructions).
     unsigned w = blockIdx.x * tiles;
-    const unsigned w_end = min(w + tiles, n_wg);
+    const unsigned w_end = LOOP ? min(w + tiles, n_wg) : w + 1; // (!LOOP: one tile, tiles == 1)
     SymWg p = plan[w];
     for (; w < w_end; ++w) {
-    const SymWg p_next = plan[min(w + 1, n_wg - 1)];
-    const cf* in = in0;
-    const cf* carry = carry0;
-    cf* out = out0;
-    CfcDev cfc = cfc0;
-    const cf* head = nullptr;
-    long long n_head = 0;
-    if (chans) { // a launch that spans channels: the workgroup's channel supplies the pointers
-        const SymChan c = chans[p.chan];
-        in = c.in;
-        carry = c.carry;
-        out = c.out;
-        cfc = chan_cfc(c, cfc.ck);
-        head = c.head;
-        n_head = static_cast<long long>(c.n_head);
-    }
     const unsigned span = (p.count - 1) * kFastSps + kFastArm;
-    if (!(ABL & 2)) cfc_fill_tile<kFastThreads, kFastOrigin>(p, span, kFastSps, kFastPitch, tile, in, carry, cap, cfc, head, n_head);
+    cf* out;
+    {
+    const symf_cu64 cw = chans ? (symf_cu64)(chans + p.chan) : (symf_cu64)__builtin_amdgcn_kernarg_segment_ptr();
+    out = reinterpret_cast<cf*>(cw[3]);
+    if (!(ABL & 2)) {
+    const cf* in = reinterpret_cast<const cf*>(cw[0]);
+    const cf* head = reinterpret_cast<const cf*>(cw[9]);
+    const long long n_head = static_cast<long long>(cw[10]);
+    const unsigned n_segs = static_cast<unsigned>(cw[7]);
+    if (p.lo_item < 0) { // the carried history is stored rotated: straight to the tile
+        const cf* carry = reinterpret_cast<const cf*>(cw[1]);
+        for (unsigned i = threadIdx.x; i < span && p.lo_item + i < 0; i += kFastThreads)
+            tile[((i + kFastOrigin) % kFastSps) * kFastPitch + (i + kFastOrigin) / kFastSps] =
+                carry[static_cast<long long>(cap) + p.lo_item + i];
+    }
+    const long long lo = p.lo_item < 0 ? 0 : p.lo_item;
+    const long long hi = p.lo_item + span;
+    for (unsigned sg = p.seg; sg < n_segs; ++sg) {
+        unsigned long long g_start, g_len;
+        unsigned g_ck0, c0;
+        cf inc;
+        if (sg == p.seg) { // the usual case, and the only segment of most spans: everything is in the plan entry
+            g_start = p.seg_start, g_len = p.seg_len, g_ck0 = p.seg_ck0;
+            inc = p.seg_incr, c0 = p.seg_counter0;
+        } else {
+            const symf_cu64 gw = (symf_cu64)(reinterpret_cast<const RotSeg*>(cw[4]) + sg);
+            g_start = gw[0], g_len = gw[1];
+            g_ck0 = ((symf_cu32)gw)[5];
+            const symf_cf32 iw = (symf_cf32)(reinterpret_cast<const cf*>(cw[5]) + sg);
+            inc = cf{ iw[0], iw[1] };
+            c0 = ((symf_cu32)cw[6])[sg];
+        }
+        const long long g_end = static_cast<long long>(g_start + g_len);
+        const long long a = max(static_cast<long long>(g_start), lo);
+        const long long b = min(g_end, hi);
+        if (a < b) {
+            const unsigned long long c_first = static_cast<unsigned long long>(a - g_start) / kRotChunk;
+            const unsigned n_chunks =
+                static_cast<unsigned>(static_cast<unsigned long long>(b - 1 - g_start) / kRotChunk - c_first) + 1;
+            // (uniform) chunk ch of this pass: items first + 8 ch ..., checkpoint ck_s[ch], counter counter_s + 8 ch,
+            // tile slots from i0_s + 8 ch on
+            const long long first = static_cast<long long>(g_start + c_first * kRotChunk);
+            const cf* ck_s = ck + (g_ck0 + c_first);
+            const unsigned counter_s = c0 + static_cast<unsigned>(c_first * kRotChunk);
+            const unsigned i0_s = static_cast<unsigned>(first - p.lo_item + static_cast<long long>(kFastOrigin));
+            // items of the segment from `first` on (whole chunks only on the straight path)
+            const unsigned room = static_cast<unsigned>(min(g_end - first, static_cast<long long>(0x7fffffff)));
+            // every chunk of the pass on one side of a two-piece input's seam?  (else: item by item)
+            const bool in_side = first >= n_head;
+            const bool one_side = in_side || first + static_cast<long long>(n_chunks * kRotChunk) <= n_head;
+            typedef const float __attribute__((address_space(1))) * gflt;
+            const gflt src_s = (gflt)(in_side ? in + (first - n_head) : head + first);
+            for (unsigned ch = threadIdx.x; ch < n_chunks; ch += kFastThreads) {
+                const unsigned t8 = ch * kRotChunk;
+                cf e = ck_s[ch];
+                unsigned counter = counter_s + t8;
+                if (one_side && t8 + kRotChunk <= room && (counter & 511u) <= 512u - kRotChunk) {
+                    const gflt src = src_s + 2 * t8;
+                    cf x[kRotChunk];
+#pragma unroll
+                    for (unsigned t = 0; t < kRotChunk; ++t) x[t] = cf{ src[2 * t], src[2 * t + 1] };
+                    rot8_pk(x, e, inc); // hpp:87
+                    // items t and t + 4 share their phase row and sit side by side: four addresses, not eight
+#pragma unroll
+                    for (unsigned t = 0; t < 4; ++t) {
+                        const unsigned it = i0_s + t; // (uniform)
+                        cf* q = tile + ((it % kFastSps) * kFastPitch + it / kFastSps) + 2 * ch;
+                        q[0] = x[t];
+                        q[1] = x[t + 4];
+                    }
+                    continue;
+                }
+                const long long idx0 = first + t8;
+#pragma unroll
+                for (unsigned t = 0; t < kRotChunk; ++t) {
+                    const long long idx = idx0 + t;
+                    if (idx >= a && idx < b) {
+                        const unsigned i = static_cast<unsigned>(idx - p.lo_item) + kFastOrigin;
+                        const cf x = idx < n_head ? head[idx] : in[idx - n_head];
+                        tile[(i % kFastSps) * kFastPitch + i / kFastSps] = cmul(x, e); // hpp:87
+                    }
+                    if (t + 1 < kRotChunk) rot_step(e, inc, counter);
+                }
+            }
+        }
+        if (g_end >= hi) break;
+    }
+    }
+    }
     const float* __restrict__ tp = taps + static_cast<size_t>(p.arm) * kFastArm; // uniform: scalar loads
     float tap[kFastArm];
 #pragma unroll
@@ -1145,8 +1238,10 @@ __global__ __launch_bounds__(kFastThreads, 8) void k_symbol_filter_fast(const cf
     if (2 * l + 1 < p.count) out[p.o0 + 2 * l + 1] = scale_item(p.scale, cf{ accB.x, accB.y });
     }
     }
-    if (w + 1 < w_end) __syncthreads(); // the tile is free for the next fill
-    p = p_next;
+    if (w + 1 < w_end) {
+        p = plan[w + 1]; // (requested here, behind the multiply-adds: in front of them its 16 SGPRs do not fit beside the taps)
+        __syncthreads(); // the tile is free for the next fill
+    }
     }
 }
 
@@ -1361,15 +1456,29 @@ static void launch_symbol_filter(hipStream_t s, unsigned n_wg, size_t smem, unsi
                 static const char* abl_e = gr4pm::experiment_env("GR4PM_SYMF_ABL", true);
                 static const int abl = abl_e ? atoi(abl_e) : 0;
                 static const unsigned pad = gr4pm::experiment_env_wg("GR4PM_SYMF_PAD", 0u, 0u, 64u * 1024u);
-                static const unsigned tiles = gr4pm::experiment_env_wg("GR4PM_SYMF_TILES", 2u, 1u, 64u);
+                static const unsigned tiles = gr4pm::experiment_env_wg("GR4PM_SYMF_TILES", 1u, 1u, 64u);
                 const dim3 gridf((n_wg + tiles - 1) / tiles);
+                SymChan one{}; // the single-channel launch's table entry (unused when `chans` is given)
+                one.in = in, one.carry = carry, one.out = out;
+                one.segs = cfc.segs, one.seg_incr = cfc.seg_incr, one.seg_counter0 = cfc.seg_counter0;
+                one.n_segs = cfc.n_segs;
 #define GR4PM_SYMF_LAUNCH(A)                                                                                         \
-    hipLaunchKernelGGL(k_symbol_filter_fast<A>, gridf, dim3(kFastThreads), pad, s, in, carry, cap, taps, plan, out, cfc, \
-                       chans, n_wg, tiles)
+    do {                                                                                                             \
+        if (tiles > 1)                                                                                               \
+            hipLaunchKernelGGL((k_symbol_filter_fast<A, true>), gridf, dim3(kFastThreads), pad, s, one, chans, plan, \
+                               taps, cfc.ck, cap, n_wg, tiles);                                                      \
+        else                                                                                                         \
+            hipLaunchKernelGGL((k_symbol_filter_fast<A, false>), gridf, dim3(kFastThreads), pad, s, one, chans, plan, \
+                               taps, cfc.ck, cap, n_wg, tiles);                                                      \
+    } while (0)
+#ifdef GR4PM_EXPERIMENTS
                 if (abl == 1) GR4PM_SYMF_LAUNCH(1);
                 else if (abl == 2) GR4PM_SYMF_LAUNCH(2);
                 else if (abl == 3) GR4PM_SYMF_LAUNCH(3);
-                else GR4PM_SYMF_LAUNCH(0);
+                else
+#endif
+                    GR4PM_SYMF_LAUNCH(0);
+                (void)abl;
 #undef GR4PM_SYMF_LAUNCH
             }
             return;

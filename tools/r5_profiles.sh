@@ -29,6 +29,8 @@ bash tools/pmc_correlate.sh r5_final/pmc_corr1 67108864 0 > $O/pmc_corr1.log 2>&
   python3 tools/w64_variants.py 268435456 4 7 -1,262144 | tail -3; python3 tools/w64_variants.py 268435456 0 7 -1,262144 | tail -3;
   echo "## A/B, same box (tools/ab_env.sh): candidates + median tests in one pass | round 4's two passes";
   BENCH_ARGS="--no-sparse-leg --steps 30 --warmup 6" bash tools/ab_env.sh 2 - GR4PM_SD_SEPARATE_MEDIAN=1;
+  echo "## A/B, same box (tools/ab_env.sh): symbol filter with one tile per workgroup | two (round 3 / 4)";
+  BENCH_ARGS="--no-sparse-leg --steps 30 --warmup 6" bash tools/ab_env.sh 2 - GR4PM_SYMF_TILES=2;
   echo "## A/B, same box: phasor fixed point | every segment a serial chain (zeros -> whole receiver, nine templates, 2^26 per batch)";
   python3 tools/benchmark_packet_receiver.py 4 9.5 67108864 2 | tail -1; GR4PM_ROT_NO_FIXED_POINT=1 python3 tools/benchmark_packet_receiver.py 4 9.5 67108864 2 | tail -1;
 } > $O/ab.txt 2>/dev/null
