@@ -629,10 +629,10 @@ __global__ __launch_bounds__(256) void k_candidates(const float* __restrict__ zb
 // ds_bpermute + a scan), the shifted suffix, the compare and the ballot: 39 -> ~12 vector instructions per row on
 // average, identical flags (test_candidate_kernels_agree).  (ii) the suffix scans of four rows in ONE asm statement:
 // four independent chains fill each other's DPP wait states (was: an s_nop 1 in front of every step).
-// Uniform float maxima are kept as bit patterns and ordered through the usual monotone key (scalar ALU has no
-// float compare on gfx950): correct for every float, -inf (the fill behind the stream) and -1 included.
+// Uniform float maxima are kept as the usual monotone integer key of their bit pattern (scalar ALU has no float compare
+// on gfx950; round 5: the key itself is kept, so a maximum is one s_max_i32): correct for every float, -inf (the fill
+// behind the stream) and -1 included.
 __device__ __forceinline__ int fkey(int b) { return b ^ ((b >> 31) & 0x7fffffff); }
-__device__ __forceinline__ int smax_bits(int a, int b) { return fkey(a) >= fkey(b) ? a : b; }
 __device__ __forceinline__ void wave_prefix_max4(float& a, float& b, float& c, float& d)
 {
 #define GR4PM_STEP(ctl)                                    \
@@ -756,29 +756,43 @@ __global__ __launch_bounds__(64) void k_candidates_wave(const float* __restrict_
     if (b0 >= n_blk) return;
     const uint32_t b1 = min(b0 + chain, n_blk);
     auto load = [&](uint32_t b, float* v) {
+        if ((b + 1) * T <= avail) {
+            // (uniform) the whole block is readable -- every block but the stream's last ones: a uniform base, the lane's
+            // offset and the row as the instruction's immediate offset, instead of an index, a compare, an exec mask, a
+            // branch and a 64-bit address per row (60 of the kernel's 374 vector instructions per block)
+            const char* zb = reinterpret_cast<const char*>(z + static_cast<size_t>(b) * T);
+            const uint32_t voff = 4u * static_cast<uint32_t>(rl);
+#pragma unroll
+            for (int r = 0; r < TQ; ++r)
+                v[r] = *reinterpret_cast<const float*>(zb + static_cast<size_t>(voff) + 256 * r);
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < TQ; ++r) {
             const uint32_t g = b * T + 64u * r + rl;
             v[r] = g < avail ? z[g] : -INFINITY;
         }
     };
-    // per block: rs[r] = suffix maximum inside row r (inclusive, reversed lanes), rowmax[r] = bits of the maximum of row r
-    // (uniform: readlane, i.e. an SGPR)
-    auto scans = [&](const float* v, float* rs, int* rowmax) {
+    // per block: rowmax[r] = the monotone integer key (fkey) of the maximum of row r (uniform: readlane, i.e. an SGPR); the
+    // uniform maxima below are integer maxima of keys.  The scans themselves (suffix maxima inside the rows) are NOT kept
+    // (round 5): only a row that can hold a candidate needs its own, one or two rows a block, and recomputing those costs
+    // six instructions where keeping all of them cost 24 registers (two blocks' worth) and twelve copies per block.
+    auto scans = [&](const float* v, int* rowmax) {
+        float t[TQ];
 #pragma unroll
-        for (int r = 0; r < TQ; ++r) rs[r] = v[r];
+        for (int r = 0; r < TQ; ++r) t[r] = v[r];
         if constexpr (TQ % 4 == 0) {
 #pragma unroll
-            for (int r = 0; r < TQ; r += 4) wave_prefix_max4(rs[r], rs[r + 1], rs[r + 2], rs[r + 3]);
+            for (int r = 0; r < TQ; r += 4) wave_prefix_max4(t[r], t[r + 1], t[r + 2], t[r + 3]);
         } else {
 #pragma unroll
-            for (int r = 0; r < TQ; ++r) rs[r] = wave_prefix_max(rs[r]);
+            for (int r = 0; r < TQ; ++r) t[r] = wave_prefix_max(t[r]);
         }
 #pragma unroll
-        for (int r = 0; r < TQ; ++r) rowmax[r] = __builtin_amdgcn_readlane(__builtin_bit_cast(int, rs[r]), 63);
+        for (int r = 0; r < TQ; ++r) rowmax[r] = fkey(__builtin_amdgcn_readlane(__builtin_bit_cast(int, t[r]), 63));
     };
-    const int ninf = __builtin_bit_cast(int, -INFINITY);
-    float cur[TQ], rs[TQ], nxt[TQ], prv[MEDIAN ? TQ : 1];
+    const int ninf = fkey(__builtin_bit_cast(int, -INFINITY));
+    float cur[TQ], nxt[TQ], prv[MEDIAN ? TQ : 1];
     int rowmax[TQ];
     load(b0, cur);
     if (MEDIAN) {
@@ -790,31 +804,31 @@ __global__ __launch_bounds__(64) void k_candidates_wave(const float* __restrict_
             prv[r] = g < static_cast<long long>(avail) ? z[g] : -INFINITY; // (behind the stream: in nobody's history)
         }
     }
-    scans(cur, rs, rowmax);
+    scans(cur, rowmax);
     unsigned long long before_mine = 0; // the candidate words of the block before (lane r: row r), known from b0 + 1 on
     for (uint32_t b = b0; b < b1; ++b) {
         load(b + 1, nxt);
-        float nrs[TQ];
         int nrowmax[TQ], before[TQ]; // before[r]: maximum of rows 0 .. r-1 of the next block
-        scans(nxt, nrs, nrowmax);
+        scans(nxt, nrowmax);
         before[0] = ninf;
 #pragma unroll
-        for (int r = 1; r < TQ; ++r) before[r] = smax_bits(before[r - 1], nrowmax[r - 1]);
+        for (int r = 1; r < TQ; ++r) before[r] = max(before[r - 1], nrowmax[r - 1]);
         unsigned long long mine = 0;
         int after = ninf; // maximum of the rows behind r in this block: built while r walks down
 #pragma unroll
         for (int r = TQ - 1; r >= 0; --r) {
-            const int U = smax_bits(after, before[r]);
+            const int U = max(after, before[r]);
             unsigned long long word = 0;
-            if (fkey(rowmax[r]) >= fkey(U)) { // (uniform: a scalar branch)
+            if (rowmax[r] >= U) { // (uniform: a scalar branch)
                 const float fwd = __shfl(nxt[r], rl);              // the next block's row r in item order
                 const float pr = __shfl(wave_prefix_max(fwd), rl); // its prefix maximum up to the lane's own offset
-                const float m = fmaxf(fmaxf(wave_prev(rs[r]), __builtin_bit_cast(float, U)), pr);
+                const float sfx = wave_prefix_max(cur[r]);         // suffix maximum inside the row (reversed lanes)
+                const float m = fmaxf(fmaxf(wave_prev(sfx), __builtin_bit_cast(float, fkey(U))), pr); // (fkey: an involution)
                 const uint32_t pos = b * T + 64u * r + rl;
                 word = __brevll(__ballot(pos < cnt && cur[r] >= m)); // back to item order
             }
             if (lane == r) mine = word;
-            after = smax_bits(after, rowmax[r]);
+            after = max(after, rowmax[r]);
         }
         unsigned long long mine_pass = 0, mine_defer = 0;
         if (MEDIAN) {
@@ -878,7 +892,6 @@ __global__ __launch_bounds__(64) void k_candidates_wave(const float* __restrict_
         for (int r = 0; r < TQ; ++r) {
             if (MEDIAN) prv[r] = cur[r];
             cur[r] = nxt[r];
-            rs[r] = nrs[r];
             rowmax[r] = nrowmax[r];
         }
     }
