@@ -196,17 +196,28 @@ __global__ __launch_bounds__(64) void k_rot_checkpoints(const RotSeg* __restrict
     cf* ckp = ck + gp->ck0;
     unsigned left = static_cast<unsigned>(gp->len / kRotChunk);
     while (left != 0) {
-        if (left >= 4 && (counter & 511u) < 512u - 4 * kRotChunk) {
+        if (left >= 4 && (counter & 511u) < 512u - 4 * kRotChunk && !(reinterpret_cast<size_t>(ckp) & 8)) {
             // four chunks per pass while no renormalisation falls into them: the chain itself (3 instructions a step)
-            // with one counter test and one branch per 32 steps instead of per 8
-            ckp[0] = e;
+            // with one counter test and one branch per 32 steps instead of per 8.  The four checkpoints leave as two
+            // 16-byte stores (round 5; hence the alignment test -- a single chunk below flips it): every lane writes to
+            // its own segment, i.e. every store instruction touches 64 cache lines, and those transactions queue in front
+            // of the memory operations of the correlator waves this kernel shares its compute units with (leave-outs:
+            // the kernel costs the chain 0.15 ms a step, 0.065 of them its stores).
+#ifdef GR4PM_ROT_NO_STORES // (timing experiment: EXTRA=-DGR4PM_ROT_NO_STORES, wrong results)
             e = rot_chunk_pk(e, inc);
-            ckp[1] = e;
             e = rot_chunk_pk(e, inc);
-            ckp[2] = e;
             e = rot_chunk_pk(e, inc);
-            ckp[3] = e;
             e = rot_chunk_pk(e, inc);
+            if (left == 0xffffffffu) ckp[0] = e;
+#else
+            cf e0 = e;
+            e = rot_chunk_pk(e, inc);
+            reinterpret_cast<float4*>(ckp)[0] = make_float4(e0.x, e0.y, e.x, e.y);
+            e0 = rot_chunk_pk(e, inc);
+            e = rot_chunk_pk(e0, inc);
+            reinterpret_cast<float4*>(ckp)[1] = make_float4(e0.x, e0.y, e.x, e.y);
+            e = rot_chunk_pk(e, inc);
+#endif
             counter += 4 * kRotChunk;
             ckp += 4;
             left -= 4;
