@@ -165,6 +165,8 @@ inline size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
 // by stand-ins: GR4PM_TIMING_SKIP, GR4PM_SYMF_ABL, GR4PM_FAKE ...) says so on stderr the first time it is seen, so a
 // variable that leaked into a production environment cannot go unnoticed.
 void sd_set_coresident(struct ::gr4pm_syncword_detection* h, bool on); // syncword_detection.hip: see launch_correlate
+// header_blocks.hip: BinarySlicer + PackBits over a stream in two pieces (the native receiver's payload tail)
+gr4pm_status slice_pack_two(const float* a, size_t na, const float* b, size_t n_out, uint8_t* out, hipStream_t s);
 const char* experiment_env(const char* name, bool wrong_results); // nullptr when unset
 unsigned experiment_env_wg(const char* name, unsigned fallback, unsigned lo, unsigned hi); // clamped to [lo, hi]
 

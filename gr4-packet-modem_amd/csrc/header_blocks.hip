@@ -69,10 +69,6 @@ gr4pm_status gather_items(hipStream_t s, DevBuf<FSpan>& buf, const std::vector<F
     GR4PM_HIP_TRY(hipGetLastError());
     return GR4PM_OK;
 }
-gr4pm_status gather_f32(hipStream_t s, DevBuf<FSpan>& buf, const std::vector<FSpan>& spans, const float* in, float* out)
-{
-    return gather_items<float>(s, buf, spans, in, out);
-}
 
 // ------------------------------------------------------------------ header FEC decoder
 // One wavefront per codeword.  Posteriors P[n] and check-to-variable messages R[m][kMaxDeg]
@@ -255,6 +251,22 @@ __global__ __launch_bounds__(256) void k_slice_pack(const float* __restrict__ in
 #pragma unroll
         for (int k = 0; k < 8; ++k) b = (b << 1) | (in[i * 8 + k] < 0.0f ? 1u : 0u);
         out[i] = static_cast<uint8_t>(b);
+    }
+}
+// the same over a stream that lies in two pieces (the native receiver's payload tail: the LLRs of the packet that the
+// batch before left unfinished, then this batch's): item j comes from a[j] for j < na, from b[j - na] behind that
+__global__ __launch_bounds__(256) void k_slice_pack_two(const float* __restrict__ a, size_t na, const float* __restrict__ b,
+                                                        size_t n_out, uint8_t* __restrict__ out)
+{
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n_out;
+         i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        unsigned v = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const size_t j = i * 8 + k;
+            v = (v << 1) | ((j < na ? a[j] : b[j - na]) < 0.0f ? 1u : 0u);
+        }
+        out[i] = static_cast<uint8_t>(v);
     }
 }
 // CrcCheck: one lane per packet (table-driven, byte by byte, crc.hpp:130-147); the table sits in
@@ -836,6 +848,19 @@ try {
     return GR4PM_OK;
 }
 GR4PM_ABI_CATCH
+} // extern "C"
+// (library-internal: csrc/packet_receiver.hip) BinarySlicer + PackBits over [a[0 .. na) | b[0 ..)], no synchronisation
+gr4pm_status gr4pm::slice_pack_two(const float* a, size_t na, const float* b, size_t n_out, uint8_t* out, hipStream_t s)
+{
+    if (n_out == 0) return GR4PM_OK;
+    if (na == 0)
+        hipLaunchKernelGGL(k_slice_pack, dim3(grid1d(n_out)), dim3(256), 0, s, b, n_out, out);
+    else
+        hipLaunchKernelGGL(k_slice_pack_two, dim3(grid1d(n_out)), dim3(256), 0, s, a, na, b, n_out, out);
+    GR4PM_HIP_TRY(hipGetLastError());
+    return GR4PM_OK;
+}
+extern "C" {
 gr4pm_status gr4pm_slice_pack_process(const float* in, size_t n_out, uint8_t* out, void* stream)
 try {
     if (n_out == 0) return GR4PM_OK;

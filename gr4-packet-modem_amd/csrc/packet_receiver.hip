@@ -124,9 +124,10 @@ struct HeaderLoop {
         gr4pm_header_payload_split_destroy(split);
         gr4pm_header_fec_decoder_destroy(fec);
     }
-    // llr + tags in; appends the parsed_header messages of the codewords finished by this batch
+    // llr + tags in; appends the parsed_header messages of the codewords finished by this batch.  pay_dst (room for
+    // n + 1 items): where the payload LLRs go instead of this loop's own buffer
     gr4pm_status run(const float* llr, size_t n, const gr4pm_packet_tag* tags, size_t n_tags,
-                     std::vector<gr4pm_header_msg>& msgs, std::vector<int32_t>& ptype)
+                     std::vector<gr4pm_header_msg>& msgs, std::vector<int32_t>& ptype, float* pay_dst = nullptr)
     {
         n_pay = n_pay_tags = 0;
         std::vector<uint64_t> resets;
@@ -134,12 +135,15 @@ struct HeaderLoop {
             if (tags[i].kind == GR4PM_PKT_HEADER_START) resets.push_back(tags[i].index);
         if (desc.n < n + 1) GR4PM_TRY(desc.alloc(n + 1));
         if (hdr.n < n + 1) GR4PM_TRY(hdr.alloc(n + 1));
-        if (pay.n < n + 1) GR4PM_TRY(pay.alloc(n + 1));
+        if (!pay_dst) {
+            if (pay.n < n + 1) GR4PM_TRY(pay.alloc(n + 1));
+            pay_dst = pay.p;
+        }
         GR4PM_TRY(gr4pm_additive_scrambler_process(scr, llr, n, desc.p, resets.data(), resets.size()));
         hdr_tags.resize(n_tags + 1);
         pay_tags.resize(n_tags + 1);
         size_t n_hdr = 0, nht = 0;
-        GR4PM_TRY(gr4pm_header_payload_split_process(split, desc.p, n, hdr.p, &n_hdr, pay.p, &n_pay, tags, n_tags,
+        GR4PM_TRY(gr4pm_header_payload_split_process(split, desc.p, n, hdr.p, &n_hdr, pay_dst, &n_pay, tags, n_tags,
                                                      hdr_tags.data(), &nht, pay_tags.data(), &n_pay_tags, n_tags + 1));
         if (acc.n < acc_n + n_hdr + 256) {
             DevBuf<float> bigger;
@@ -272,7 +276,7 @@ struct gr4pm_packet_receiver {
     std::vector<gr4pm_header_msg> pm_carry_hdrs;
     std::deque<gr4pm_header_msg> used_msgs; // given to PayloadMetadataInsert, not yet verified
     std::deque<gr4pm_header_msg> early_hdrs; // decoded by the chain before pass A's message for the packet arrived
-    DevBuf<float> soft, soft_tmp;           // payload soft bits of packets not finished yet
+    DevBuf<float> soft;                     // payload soft bits of packets not finished yet
     size_t soft_n = 0;
     std::deque<uint64_t> payload_bits;      // their lengths
     DevBuf<uint8_t> packed;
@@ -898,7 +902,11 @@ gr4pm_status gr4pm_packet_receiver::stage3_decode(Slot& s)
     for (const auto& m : s.opened) used_msgs.push_back(m);
     s.header_messages.clear();
     s.packet_type.clear();
-    GR4PM_TRY(b_loop.run(s.out_llr, n_llr, s.llr_tags.data(), n_lt, s.header_messages, s.packet_type));
+    // (the descrambled payload LLRs of this batch go straight to the slot's buffer, which the caller reads: round 5 --
+    // they used to be copied there, and once more behind the unfinished packet's, 1.9 GB of traffic a step on a
+    // packet-dense stream in the stage that sets the pace of the decode_headers pipeline)
+    if (s.payload_llr.n < n_llr + 1) GR4PM_TRY(s.payload_llr.alloc(n_llr + 1));
+    GR4PM_TRY(b_loop.run(s.out_llr, n_llr, s.llr_tags.data(), n_lt, s.header_messages, s.packet_type, s.payload_llr.p));
     T3_MARK("header_loop");
     for (const auto& got : s.header_messages) {
         if (used_msgs.empty()) break;
@@ -912,31 +920,18 @@ gr4pm_status gr4pm_packet_receiver::stage3_decode(Slot& s)
         }
         if (!same_header(given, got)) ++s.header_mismatches;
     }
-    // descrambled payload LLRs of this batch, kept for the caller
-    s.n_payload_llr = b_loop.n_pay;
-    if (s.payload_llr.n < b_loop.n_pay + 1) GR4PM_TRY(s.payload_llr.alloc(b_loop.n_pay + 1));
-    if (b_loop.n_pay)
-        GR4PM_HIP_TRY(hipMemcpyAsync(s.payload_llr.p, b_loop.pay.p, b_loop.n_pay * sizeof(float),
-                                     hipMemcpyDeviceToDevice, st2));
+    const size_t n_pay = b_loop.n_pay;
+    const float* pay = s.payload_llr.p;
+    s.n_payload_llr = n_pay;
     s.n_payload_tags = b_loop.n_pay_tags;
     s.payload_tags.assign(b_loop.pay_tags.begin(), b_loop.pay_tags.begin() + b_loop.n_pay_tags);
-    // payload tail, packet_receiver.hpp:140-147 (whole packets only; the rest waits)
-    if (soft.n < soft_n + b_loop.n_pay + 8) {
-        DevBuf<float> bigger;
-        GR4PM_TRY(bigger.alloc((soft_n + b_loop.n_pay + 8) * 2));
-        if (soft_n) GR4PM_HIP_TRY(hipMemcpyAsync(bigger.p, soft.p, soft_n * sizeof(float), hipMemcpyDeviceToDevice, st2));
-        GR4PM_HIP_TRY(hipStreamSynchronize(st2));
-        std::swap(soft.p, bigger.p);
-        std::swap(soft.n, bigger.n);
-    }
-    if (b_loop.n_pay)
-        GR4PM_HIP_TRY(hipMemcpyAsync(soft.p + soft_n, b_loop.pay.p, b_loop.n_pay * sizeof(float), hipMemcpyDeviceToDevice,
-                                     st2));
-    soft_n += b_loop.n_pay;
+    // payload tail, packet_receiver.hpp:140-147 (whole packets only; the rest waits): the stream is
+    // [soft[0 .. soft_n): the unfinished packet of the batches before | pay[0 .. n_pay)], sliced and packed in place
     for (size_t i = 0; i < b_loop.n_pay_tags; ++i) payload_bits.push_back(b_loop.pay_tags[i].payload_bits);
+    const size_t total = soft_n + n_pay;
     std::vector<uint64_t> lens, offs;
     size_t used_bits = 0;
-    while (!payload_bits.empty() && used_bits + payload_bits.front() <= soft_n) {
+    while (!payload_bits.empty() && used_bits + payload_bits.front() <= total) {
         offs.push_back(used_bits / 8);
         lens.push_back(payload_bits.front() / 8);
         used_bits += payload_bits.front();
@@ -946,7 +941,7 @@ gr4pm_status gr4pm_packet_receiver::stage3_decode(Slot& s)
     s.n_packet_bytes = 0;
     if (!lens.empty()) {
         if (packed.n < used_bits / 8 + 1) GR4PM_TRY(packed.alloc(used_bits / 8 * 2 + 1));
-        GR4PM_TRY(gr4pm_slice_pack_process(soft.p, used_bits / 8, packed.p, st2));
+        GR4PM_TRY(gr4pm::slice_pack_two(soft.p, soft_n, pay, used_bits / 8, packed.p, st2));
         if (s.packets_cap < used_bits / 8) {
             set_error("packets_cap %zu < %zu bytes", s.packets_cap, used_bits / 8);
             return GR4PM_INSUFFICIENT_OUTPUT_ITEMS;
@@ -954,16 +949,31 @@ gr4pm_status gr4pm_packet_receiver::stage3_decode(Slot& s)
         GR4PM_TRY(gr4pm_crc_check_process(crc, packed.p, offs.data(), lens.data(), lens.size(), s.out_packets,
                                           s.packet_lengths.data(), &s.n_packet_bytes));
     }
-    if (used_bits && used_bits < soft_n) { // keep the unfinished payload (through a bounce: the ranges may overlap)
-        // (a persistent buffer: hipMalloc / hipFree per batch would synchronise the whole device)
-        if (soft_tmp.n < soft_n - used_bits) GR4PM_TRY(soft_tmp.alloc((soft_n - used_bits) * 2));
-        GR4PM_HIP_TRY(hipMemcpyAsync(soft_tmp.p, soft.p + used_bits, (soft_n - used_bits) * sizeof(float),
-                                     hipMemcpyDeviceToDevice, st2));
-        GR4PM_HIP_TRY(hipMemcpyAsync(soft.p, soft_tmp.p, (soft_n - used_bits) * sizeof(float), hipMemcpyDeviceToDevice,
-                                     st2));
+    // what is left for the next batch
+    const size_t rest = total - used_bits;
+    auto soft_room = [&](size_t want, size_t keep) -> gr4pm_status { // (keep: items at the front that must survive)
+        if (soft.n >= want + 8) return GR4PM_OK;
+        DevBuf<float> bigger;
+        GR4PM_TRY(bigger.alloc((want + 8) * 2));
+        if (keep) GR4PM_HIP_TRY(hipMemcpyAsync(bigger.p, soft.p, keep * sizeof(float), hipMemcpyDeviceToDevice, st2));
         GR4PM_HIP_TRY(hipStreamSynchronize(st2));
+        std::swap(soft.p, bigger.p);
+        std::swap(soft.n, bigger.n);
+        return GR4PM_OK;
+    };
+    // (the carried LLRs belong to ONE unfinished packet -- every complete one was consumed by the batch that completed
+    // it -- so a packet that ends in this batch ends behind them: used_bits is 0 or > soft_n)
+    if (used_bits) { // the tail of this batch's LLRs: one short copy, in stream order behind the kernel that read soft
+        GR4PM_TRY(soft_room(rest, 0));
+        if (rest)
+            GR4PM_HIP_TRY(hipMemcpyAsync(soft.p, pay + (used_bits - soft_n), rest * sizeof(float), hipMemcpyDeviceToDevice,
+                                         st2));
+    } else { // no packet ended in this batch (a batch with little payload): its LLRs go behind the carried ones
+        GR4PM_TRY(soft_room(rest, soft_n));
+        if (n_pay)
+            GR4PM_HIP_TRY(hipMemcpyAsync(soft.p + soft_n, pay, n_pay * sizeof(float), hipMemcpyDeviceToDevice, st2));
     }
-    soft_n -= used_bits;
+    soft_n = rest;
     GR4PM_HIP_TRY(hipStreamSynchronize(st2));
     T3_MARK("payload_tail");
     T3_END();
