@@ -36,6 +36,8 @@ BUDGETS = [
     # what runs BESIDE two correlator waves of a SIMD and the correlator's LDS
     (r"k_costas_capILi\dELi2E", dict(vgpr=32, lds=CU_LDS - 151552)),
     (r"k_rot_checkpoints", dict(vgpr=32, lds=CU_LDS - 151552)),
+    # (the detector tail's streaming kernel: eight waves per SIMD since round 5)
+    (r"k_candidates_waveILi12ELb1E", dict(vgpr=64, scratch=0)),
     # time-sliced against the correlator a CU at a time: their own occupancy targets
     (r"k_symbol_filter_fast", dict(vgpr=64)),
     (r"k_correlate_w64_oneILi0E", dict(vgpr=168, scratch=0)),  # three waves per SIMD
