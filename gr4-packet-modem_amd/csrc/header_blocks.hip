@@ -354,6 +354,41 @@ __global__ __launch_bounds__(64) void k_burst_edges(const T* __restrict__ in, T*
 struct BSpan {
     unsigned long long src, dst, len;
 };
+// CrcCheck, "passing packets leave back to back" (crc_check.hpp:180-202) without a trip to the host: one workgroup turns
+// the verdicts into the copy spans of k_gather_u8 -- an exclusive sum of the passing packets' output lengths (a failing
+// packet gets a span of length 0).  1024 lanes walk the packets 1024 at a time with a running carry.
+__global__ __launch_bounds__(1024) void k_crc_spans(const CrcPacket* __restrict__ pk, const uint8_t* __restrict__ ok,
+                                                    unsigned n_packets, unsigned drop, BSpan* __restrict__ spans)
+{
+    __shared__ unsigned long long part[16];
+    __shared__ unsigned long long carry_s;
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (unsigned base = 0; base < n_packets; base += 1024) {
+        const unsigned i = base + threadIdx.x;
+        unsigned long long n = 0;
+        CrcPacket q{ 0, 0 };
+        if (i < n_packets) {
+            q = pk[i];
+            n = ok[i] ? q.len - drop : 0;
+        }
+        // inclusive sum inside the wave, then over the sixteen waves
+        unsigned long long v = n;
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long u = __shfl_up(v, d);
+            if (static_cast<int>(lane) >= d) v += u;
+        }
+        if (lane == 63) part[wave] = v;
+        __syncthreads();
+        unsigned long long before = carry_s;
+        for (unsigned w = 0; w < wave; ++w) before += part[w];
+        if (i < n_packets) spans[i] = BSpan{ q.offset, before + v - n, n };
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = before + v;
+        __syncthreads();
+    }
+}
 __global__ __launch_bounds__(256) void k_gather_u8(const BSpan* __restrict__ spans, const uint8_t* __restrict__ in,
                                                    uint8_t* __restrict__ out)
 {
@@ -970,33 +1005,30 @@ try {
                        h->p.initial_value & h->mask, h->p.final_xor & h->mask, h->p.input_reflected ? 1 : 0,
                        h->p.result_reflected ? 1 : 0, h->p.swap_endianness ? 1 : 0, h->p.skip_header_bytes, h->ok.p);
     GR4PM_HIP_TRY(hipGetLastError());
+    // passing packets leave back to back (:180-202): the spans are made on the device (round 5: the verdicts used to go
+    // to the host first -- one more wait for a busy chip in the stage that sets the pace of the decode_headers pipeline)
+    const size_t crc_bytes = h->p.num_bits / 8;
+    if (h->spans.n < n_packets) GR4PM_TRY(h->spans.alloc(n_packets * 2));
+    hipLaunchKernelGGL(k_crc_spans, dim3(1), dim3(1024), 0, s, h->pk.p, h->ok.p, static_cast<unsigned>(n_packets),
+                       h->p.discard_crc ? static_cast<unsigned>(crc_bytes) : 0u, h->spans.p);
+    unsigned long long longest = 0;
+    for (size_t i = 0; i < n_packets; ++i) longest = std::max<unsigned long long>(longest, packet_len[i]);
+    const unsigned gx = static_cast<unsigned>(std::max<unsigned long long>(
+        1, std::min<unsigned long long>((longest + 2047) / 2048, 1024)));
+    for (size_t first = 0; first < n_packets; first += 65535) {
+        const unsigned rows = static_cast<unsigned>(std::min<size_t>(65535, n_packets - first));
+        hipLaunchKernelGGL(k_gather_u8, dim3(gx, rows), dim3(256), 0, s, h->spans.p + first, in, out);
+    }
+    GR4PM_HIP_TRY(hipGetLastError());
     GR4PM_HIP_TRY(hipMemcpyAsync(h->ok_host.p, h->ok.p, n_packets, hipMemcpyDeviceToHost, s));
     GR4PM_HIP_TRY(hipStreamSynchronize(s));
-    // passing packets leave back to back (:180-202)
-    std::vector<BSpan> spans;
-    const size_t crc_bytes = h->p.num_bits / 8;
     size_t opos = 0;
-    unsigned long long longest = 0;
     for (size_t i = 0; i < n_packets; ++i) {
         out_len[i] = 0;
         if (!h->ok_host.p[i]) continue;
         const unsigned long long n = h->p.discard_crc ? packet_len[i] - crc_bytes : packet_len[i];
-        spans.push_back({ packet_offset[i], opos, n });
         out_len[i] = n;
         opos += n;
-        longest = std::max(longest, n);
-    }
-    if (!spans.empty()) {
-        if (h->spans.n < spans.size()) GR4PM_TRY(h->spans.alloc(spans.size() * 2));
-        GR4PM_TRY(h->spans.upload_staged(spans.data(), spans.size(), s));
-        const unsigned gx = static_cast<unsigned>(std::max<unsigned long long>(
-            1, std::min<unsigned long long>((longest + 2047) / 2048, 1024)));
-        for (size_t first = 0; first < spans.size(); first += 65535) {
-            const unsigned rows = static_cast<unsigned>(std::min<size_t>(65535, spans.size() - first));
-            hipLaunchKernelGGL(k_gather_u8, dim3(gx, rows), dim3(256), 0, s, h->spans.p + first, in, out);
-        }
-        GR4PM_HIP_TRY(hipGetLastError());
-        GR4PM_HIP_TRY(hipStreamSynchronize(s));
     }
     *n_out_bytes = opos;
     return GR4PM_OK;
