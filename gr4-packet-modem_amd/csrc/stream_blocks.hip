@@ -2334,6 +2334,7 @@ try {
     hipStream_t s = h->stream;
     GR4PM_TRY(upload_vec(h->chains, chains, s));
     GR4PM_TRY(upload_vec(h->pieces, pieces, s));
+    if (!timing_skip("costas_chains")) // (EXPERIMENTS builds: GR4PM_TIMING_SKIP=costas_chains, wrong results)
     hipLaunchKernelGGL(k_costas_chains, dim3(grid_for(chains.size(), 64)), dim3(64), 0, s, h->chains.p,
                        static_cast<unsigned>(chains.size()), h->pieces.p, h->state.p + h->st_cur,
                        h->state.p + (h->st_cur ^ 1), reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(out));
