@@ -2425,6 +2425,40 @@ def test_binary_slicer_pack_bits_crc(pkg):
     assert [int(v > 0) for v in want_len] == [1, 1, 0, 1, 1, 1, 0, 0, 0]
 
 
+@pytest.mark.gpu
+def test_crc_check_thousands_of_packets_leave_back_to_back(pkg):
+    """crc_check.hpp:180-202 with more packets than one pass of the device-side span builder handles (k_crc_spans: 1024 a
+    time with a running carry): random lengths, one packet in five corrupted, a few too short to hold a CRC -- the passing
+    ones back to back, their lengths, both discard_crc settings, against the oracle"""
+    import zlib
+    rng = np.random.default_rng(77)
+    n_pk = 3 * 1024 + 77
+    pk, lens = [], []
+    for k in range(n_pk):
+        n = int(rng.integers(1, 300)) if k % 97 else 1500
+        if k % 211 == 5:  # too short for a CRC-32
+            pk.append(rng.integers(0, 256, 3).astype(np.uint8))
+            lens.append(3)
+            continue
+        body = rng.integers(0, 256, n).astype(np.uint8)
+        crc = zlib.crc32(body.tobytes())
+        tail = np.array([(crc >> sh) & 0xFF for sh in (24, 16, 8, 0)], dtype=np.uint8)
+        if rng.random() < 0.2:
+            body = body.copy()
+            body[int(rng.integers(0, n))] ^= 1 << int(rng.integers(0, 8))
+        pk.append(np.concatenate([body, tail]))
+        lens.append(n + 4)
+    stream = np.concatenate(pk)
+    sd = torch.from_numpy(stream).cuda()
+    for discard in (False, True):
+        want, want_len = orc.crc_check(stream, lens, discard_crc=discard, **orc.CRC32)
+        got, got_len = pkg.CrcCheck(discard_crc=discard).process_bulk(sd, lens)
+        assert np.array_equal(got_len, want_len)
+        assert np.array_equal(got.cpu().numpy(), want)
+    passed = int(np.count_nonzero(np.asarray(want_len)))
+    assert 0.7 * n_pk < passed < 0.9 * n_pk  # (the mix the test is about)
+
+
 @pytest.mark.parametrize("mode", ["one_call", "three_calls"])
 def test_packet_receiver_iq_to_packets(pkg, mode):
     """the whole receive chain of packet_receiver.hpp on the device: IQ samples in, the bytes of every
