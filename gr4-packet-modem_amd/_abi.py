@@ -28,9 +28,11 @@ TAG_DTYPE = np.dtype(
         ("esn0_db", "<f4"),
         ("time_est", "<f4"),
         ("flags", "<i4"),
+        ("user", "<i4"),  # the caller's cookie (never read by the library, copied with re-emitted tags)
     ],
     align=True,
 )
+assert TAG_DTYPE.itemsize == 48
 
 
 # gr4pm_packet_tag: the control tags of the symbol-rate chain behind SyncwordWipeoff

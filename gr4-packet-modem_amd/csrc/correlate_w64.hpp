@@ -242,7 +242,13 @@ __global__ __launch_bounds__(kW64Threads, 2) void k_correlate_w64(const cf* __re
                   "the hand-out counter must sit in the pad behind re[64] | im[64] of exchange row 0");
     uint32_t* const wg_next = reinterpret_cast<uint32_t*>(lds4 + kW64TwFloat4) + kWgNextDword;
     constexpr bool kDynamic = (VAR & 32768) != 0 && (VAR & 131072) == 0;
-    if (kDynamic && tid == 0) *wg_next = blockIdx.x * kW64Waves * blocks_per_wave + kW64Waves;
+    // blocks_per_wave != 0: the workgroup's share of the items is [wg_begin, wg_end), an even split of `total` over the grid
+    // (round 6: the host makes the grid a multiple of the CU count, so that the last round of workgroups is as full
+    // as the others -- with shares of exactly 8 K items the 2^28-sample launch was 12.47 rounds of 256 workgroups, the
+    // last one half empty: tools/overlap_save_pattern.hip measures the same loss on the access pattern alone)
+    const uint32_t wg_begin = static_cast<uint32_t>(static_cast<uint64_t>(blockIdx.x) * total / gridDim.x);
+    const uint32_t wg_end = static_cast<uint32_t>(static_cast<uint64_t>(blockIdx.x + 1) * total / gridDim.x);
+    if (kDynamic && tid == 0) *wg_next = wg_begin + kW64Waves;
     __syncthreads(); // the only workgroup-wide synchronisation of the kernel
     float4* xb4 = lds4 + kW64TwFloat4 + wave * kW64BufF4;
     // LDS byte address of the buffer (what DS instructions and M0 take)
@@ -253,7 +259,7 @@ __global__ __launch_bounds__(kW64Threads, 2) void k_correlate_w64(const cf* __re
     const cf c = cc[lane];
     const uint32_t voff = static_cast<uint32_t>(lane) * 16u;
     // blocks_per_wave == 0: persistent waves, wave w of the grid walks items w, w + W, w + 2W, ... (a stand-alone
-    // launch).  blocks_per_wave == K: a workgroup owns 8 K consecutive items and retires after them, so that the
+    // launch).  blocks_per_wave == K: a workgroup owns about 8 K consecutive items (its even share of the grid's) and retires after them, so that the
     // dispatcher can place the workgroups of other streams' kernels on the CU in between (a pipelined receiver:
     // a persistent launch keeps every CU's LDS for its whole duration and everything else waits for it).
     // The 8 K items are handed out through a counter in LDS, one at a time and one block ahead (the samples of the
@@ -263,8 +269,8 @@ __global__ __launch_bounds__(kW64Threads, 2) void k_correlate_w64(const cf* __re
     // CU waiting for its fixed share (VAR & 131072: the fixed shares of rounds 1 - 3, for A/B).
     const bool dynamic = kDynamic && blocks_per_wave != 0;
     const uint32_t n_waves = blocks_per_wave ? kW64Waves : gridDim.x * kW64Waves;
-    uint32_t item = blocks_per_wave ? blockIdx.x * kW64Waves * blocks_per_wave + wave : blockIdx.x * kW64Waves + wave;
-    const uint32_t item_end = blocks_per_wave ? min(total, (blockIdx.x + 1) * kW64Waves * blocks_per_wave) : total;
+    uint32_t item = blocks_per_wave ? wg_begin + wave : blockIdx.x * kW64Waves + wave;
+    const uint32_t item_end = blocks_per_wave ? wg_end : total;
     if (item >= item_end) return;
 
     const bool one_channel = total <= n_blocks; // no division per block (two 32-bit divisions: ~50 instructions)

@@ -139,8 +139,11 @@ __global__ __launch_bounds__(kW1Threads) void k_correlate_w64_one(const cf* __re
     const float4* row = xb4 + (lane & 31) * (kW1Row / 4);
     const cf c = cc[lane];
     const uint32_t n_waves = blocks_per_wave ? kW1Waves : gridDim.x * kW1Waves;
-    uint32_t item = blocks_per_wave ? blockIdx.x * kW1Waves * blocks_per_wave + wave : blockIdx.x * kW1Waves + wave;
-    const uint32_t item_end = blocks_per_wave ? min(total, (blockIdx.x + 1) * kW1Waves * blocks_per_wave) : total;
+    // (blocks_per_wave != 0: an even split of the items over the grid, as in k_correlate_w64)
+    const uint32_t wg_begin = static_cast<uint32_t>(static_cast<uint64_t>(blockIdx.x) * total / gridDim.x);
+    const uint32_t wg_end = static_cast<uint32_t>(static_cast<uint64_t>(blockIdx.x + 1) * total / gridDim.x);
+    uint32_t item = blocks_per_wave ? wg_begin + wave : blockIdx.x * kW1Waves + wave;
+    const uint32_t item_end = blocks_per_wave ? wg_end : total;
     if (item >= item_end) return;
 
     const bool one_channel = total <= n_blocks;

@@ -309,9 +309,28 @@ struct gr4pm_packet_receiver {
     void stage3(Slot& s)
     {
         if (s.status != GR4PM_OK || !p.soft_bits) return;
-        const gr4pm_status st = p.decode_headers ? stage3_decode(s) : stage3_soft(s);
+        gr4pm_status st;
+        try {
+            st = p.decode_headers ? stage3_decode(s) : stage3_soft(s);
+        } catch (...) {
+            drop_unfinished_payload();
+            (void)hipStreamSynchronize(streams[3]);
+            throw; // hostlogic::run_stage fails the batch
+        }
         (void)hipStreamSynchronize(streams[3]);
-        if (st != GR4PM_OK) fail(s, st);
+        if (st != GR4PM_OK) {
+            drop_unfinished_payload();
+            fail(s, st);
+        }
+    }
+    // A batch that fails in stage3_decode has popped payload lengths without consuming their soft bits, or has not
+    // appended its own: `soft` / `soft_n` / `payload_bits` no longer describe one stream.  The stage lives on after a
+    // failed batch (run_stage), so the carried state starts empty again -- the packets in flight across the failed
+    // batch are lost with it; everything behind is sliced from consistent state.
+    void drop_unfinished_payload()
+    {
+        soft_n = 0;
+        payload_bits.clear();
     }
 };
 
@@ -963,6 +982,10 @@ gr4pm_status gr4pm_packet_receiver::stage3_decode(Slot& s)
     };
     // (the carried LLRs belong to ONE unfinished packet -- every complete one was consumed by the batch that completed
     // it -- so a packet that ends in this batch ends behind them: used_bits is 0 or > soft_n)
+    if (used_bits && used_bits <= soft_n) { // cannot happen while the state above is consistent: never index pay[] below 0
+        set_error("payload tail: %zu bits end inside the %zu carried ones", used_bits, soft_n);
+        return GR4PM_ERR_INTERNAL;
+    }
     if (used_bits) { // the tail of this batch's LLRs: one short copy, in stream order behind the kernel that read soft
         GR4PM_TRY(soft_room(rest, 0));
         if (rest)

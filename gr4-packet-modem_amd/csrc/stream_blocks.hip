@@ -1732,6 +1732,7 @@ struct gr4pm_rotator {
         DevBuf<RotSeg> segs;
         DevBuf<cf> ck, seg_incr;
         DevBuf<unsigned> seg_counter0, order;
+        DevBuf<unsigned> const_list; // the mode-2 segments of THIS plan (its own staging buffer: plans are issued ahead)
         unsigned n_segs = 0;
         size_t n_in = 0;
         std::vector<unsigned> seg_first; // [n_channels + 1]: the segments of channel c are [seg_first[c], seg_first[c + 1])
@@ -1754,7 +1755,6 @@ struct gr4pm_rotator {
     // copy: it turns -0 into +0 in places, as the reference's multiplication does).
     std::vector<uint8_t> fixed;
     std::vector<cf> fixed_exp, fixed_incr;
-    DevBuf<unsigned> const_list;
 };
 
 static gr4pm_status rotator_reset_impl(gr4pm_rotator* h)
@@ -1827,8 +1827,36 @@ GR4PM_ABI_CATCH
 // gr4pm_cfc_symbol_filter_plan*); otherwise the current set is reused.  When the ring is used for
 // the first time every set gets the capacity of the first plan, so that no later call of a
 // steady stream has to allocate.
+static gr4pm_status rotator_plan_impl(gr4pm_rotator* h, size_t n, const gr4pm_tag* tags, const uint32_t* tag_channel,
+                                      size_t n_tags, std::vector<RotSeg>& segs, bool ring);
+// The host half of the carried state (pending frequency, fixed-point flags) is advanced while the segments are formed,
+// before the allocations, uploads and launches that can still fail: a call that fails leaves it as it found it, in step
+// with the device's RotState (st_cur flips only on success).
 static gr4pm_status rotator_plan(gr4pm_rotator* h, size_t n, const gr4pm_tag* tags, const uint32_t* tag_channel,
                                  size_t n_tags, std::vector<RotSeg>& segs, bool ring = false)
+{
+    static thread_local std::vector<float> nf;
+    static thread_local std::vector<long> nd;
+    static thread_local std::vector<uint8_t> fx;
+    static thread_local std::vector<cf> fe, fi;
+    nf = h->next_freq, nd = h->next_freq_delay, fx = h->fixed, fe = h->fixed_exp, fi = h->fixed_incr;
+    const int plan_was = h->plan_cur;
+    gr4pm_status st;
+    try {
+        st = rotator_plan_impl(h, n, tags, tag_channel, n_tags, segs, ring);
+    } catch (...) {
+        h->next_freq.swap(nf), h->next_freq_delay.swap(nd), h->fixed.swap(fx), h->fixed_exp.swap(fe), h->fixed_incr.swap(fi);
+        h->plan_cur = plan_was;
+        throw;
+    }
+    if (st != GR4PM_OK) {
+        h->next_freq.swap(nf), h->next_freq_delay.swap(nd), h->fixed.swap(fx), h->fixed_exp.swap(fe), h->fixed_incr.swap(fi);
+        h->plan_cur = plan_was;
+    }
+    return st;
+}
+static gr4pm_status rotator_plan_impl(gr4pm_rotator* h, size_t n, const gr4pm_tag* tags, const uint32_t* tag_channel,
+                                      size_t n_tags, std::vector<RotSeg>& segs, bool ring)
 {
     unsigned ck = 0;
     size_t n_const = 0;
@@ -1924,6 +1952,8 @@ static gr4pm_status rotator_plan(gr4pm_rotator* h, size_t n, const gr4pm_tag* ta
                 GR4PM_TRY(q.segs.reserve_stage(n_segs));
                 if (q.order.n < n_segs) GR4PM_TRY(q.order.alloc(n_segs * 2));
                 GR4PM_TRY(q.order.reserve_stage(n_segs));
+                if (q.const_list.n < n_segs) GR4PM_TRY(q.const_list.alloc(n_segs * 2));
+                GR4PM_TRY(q.const_list.reserve_stage(n_segs));
             }
         }
     }
@@ -1963,11 +1993,11 @@ static gr4pm_status rotator_plan(gr4pm_rotator* h, size_t n, const gr4pm_tag* ta
                 list.push_back(i);
                 longest = std::max(longest, segs[i].len);
             }
-        GR4PM_TRY(upload_vec(h->const_list, list, s));
+        GR4PM_TRY(upload_vec(pl.const_list, list, s));
         const unsigned gx = static_cast<unsigned>(std::min<unsigned long long>((longest / kRotChunk + 255) / 256 + 1, 2048));
         for (size_t first = 0; first < list.size(); first += 65535) {
             const unsigned rows = static_cast<unsigned>(std::min<size_t>(65535, list.size() - first));
-            hipLaunchKernelGGL(k_rot_const_fill, dim3(gx, rows), dim3(256), 0, s, pl.segs.p, h->const_list.p + first, pl.ck.p);
+            hipLaunchKernelGGL(k_rot_const_fill, dim3(gx, rows), dim3(256), 0, s, pl.segs.p, pl.const_list.p + first, pl.ck.p);
         }
     }
     GR4PM_HIP_TRY(hipGetLastError());

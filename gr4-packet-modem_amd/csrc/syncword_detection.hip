@@ -1894,6 +1894,7 @@ struct gr4pm_syncword_detection {
     // (beyond its budget per block: k_median_tests if the scan visits them)
     DevBuf<unsigned long long> passmap[kSets];
     bool fused_median[kSets] = {};             // ... and whether the set's front was made by that kernel
+    bool last_fused = false;                   // ... of the set the last process() call scanned (scan_counts)
     DevBuf<uint32_t> table[kSets];
     DevBuf<unsigned long long> gtable[kSets], gentry;
     size_t gtable_stride = 0;
@@ -2012,6 +2013,7 @@ void finish_tag(const gr4pm_syncword_detection* h, const RawTag& t, uint64_t out
     o->esn0_db = esn0_db;
     o->time_est = time_est;
     o->flags = GR4PM_TAG_SYNCWORD;
+    o->user = 0;
 }
 
 } // namespace
@@ -2072,8 +2074,20 @@ gr4pm_status launch_correlate(gr4pm_syncword_detection* h, hipStream_t stream, c
         // persistent waves: one 8-wave workgroup per CU, every wave walks items wave, wave + W, ...
         const uint32_t total = n_blocks * static_cast<uint32_t>(h->n_channels);
         const uint32_t bpw = h->w64_blocks_per_wave;
-        const uint32_t wgs = bpw ? (total + kW64Waves * bpw - 1) / (kW64Waves * bpw)
-                                 : std::min<uint32_t>(static_cast<uint32_t>(h->n_cus), (total + kW64Waves - 1) / kW64Waves);
+        // The grid for workgroups of about `waves` x bpw items each: a whole number of rounds of one workgroup per CU
+        // (both kernels take a CU's LDS), so that no CU idles through most of a last, partly filled round -- the
+        // 2^28-sample launch was 12.47 rounds at nine bins and 8.31 at one; a launch of less than a round gets one item
+        // per wave on as many CUs as it can use.  GR4PM_W64_BALANCED=0: round 5's fixed shares of waves x bpw items.
+        static const bool balanced = !(getenv("GR4PM_W64_BALANCED") && getenv("GR4PM_W64_BALANCED")[0] == '0');
+        auto grid_for_items = [&](uint32_t waves) -> uint32_t {
+            const uint32_t cus = static_cast<uint32_t>(h->n_cus);
+            if (!bpw) return std::min<uint32_t>(cus, (total + waves - 1) / waves);
+            const uint32_t g0 = (total + waves * bpw - 1) / (waves * bpw);
+            if (!balanced) return g0;
+            if (g0 <= cus) return std::max<uint32_t>(g0, std::min<uint32_t>(cus, (total + waves - 1) / waves));
+            return cus * std::max<uint32_t>(1u, (g0 + cus / 2) / cus);
+        };
+        const uint32_t wgs = grid_for_items(kW64Waves);
 #define GR4PM_W64_LAUNCH(V)                                                                                         \
     hipLaunchKernelGGL(k_correlate_w64<V>, dim3(wgs), dim3(kW64Threads), 0, stream, reinterpret_cast<const cf*>(in), \
                        in_stride, n_blocks, total, static_cast<uint32_t>(h->S), h->n_bins, h->tmpl64.p, h->tT64.p,  \
@@ -2090,8 +2104,7 @@ gr4pm_status launch_correlate(gr4pm_syncword_detection* h, hipStream_t stream, c
         const int one_mode = h->w64_one;
         const bool one_off = one_mode == 0 || (one_mode < 0 && h->coresident);
         if (h->n_bins == 1 && prune && h->w64_variant < 0 && !one_off) {
-            const uint32_t wgs1 = bpw ? (total + kW1Waves * bpw - 1) / (kW1Waves * bpw)
-                                      : std::min<uint32_t>(static_cast<uint32_t>(h->n_cus), (total + kW1Waves - 1) / kW1Waves);
+            const uint32_t wgs1 = grid_for_items(kW1Waves);
 #define GR4PM_W1_LAUNCH(A)                                                                                           \
     hipLaunchKernelGGL(k_correlate_w64_one<A>, dim3(wgs1), dim3(kW1Threads), 0, stream, reinterpret_cast<const cf*>(in), \
                        in_stride, n_blocks, total, static_cast<uint32_t>(h->S), h->tmpl64.p, h->tT64.p, h->cc64.p, zout, \
@@ -2564,7 +2577,7 @@ try {
     // (the host copy of the channel's counters, written by the last process() call before they were reset)
     if (!h || channel >= h->n_channels) return;
     if (visited) *visited = h->st_host.p[channel].vis_cnt;
-    if (tested_from_memory) *tested_from_memory = h->fused_median[h->cur] ? h->st_host.p[channel].def_cnt : h->st_host.p[channel].vis_cnt;
+    if (tested_from_memory) *tested_from_memory = h->last_fused ? h->st_host.p[channel].def_cnt : h->st_host.p[channel].vis_cnt;
 }
 GR4PM_ABI_CATCH_VOID
 
@@ -2674,6 +2687,7 @@ try {
                            n_tiles, h->entry.p, h->st.p, h->visit.p, h->visit_cap);
         // at most one visited candidate per T + 1 items (+ one per tile): the grids stride over the real count
         const uint32_t n_vis = cnt / (T + 1) + n_tiles + 1;
+        h->last_fused = h->fused_median[cur];
         if (h->fused_median[cur]) {
             // the front's candidate kernel has tested (nearly) every candidate: look the visited ones up; the untested ones
             // (constant input) onto a second list and through the test from memory (the grid strides over their real

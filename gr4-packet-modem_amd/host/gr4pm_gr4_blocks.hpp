@@ -460,6 +460,13 @@ inline int constellation_id(const std::string& s)
 }
 template <typename T>
 inline constexpr bool is_c64 = std::is_same_v<T, std::complex<float>>;
+// gr::packet_modem::Pdu<T> (pdu.hpp:15-21) by shape: value_type, data = std::vector<value_type>, tags
+template <typename P>
+concept PduLike = requires(P p) {
+    typename P::value_type;
+    requires std::is_same_v<std::remove_cvref_t<decltype(p.data)>, std::vector<typename P::value_type>>;
+    p.tags.size();
+};
 } // namespace detail
 
 using c64 = std::complex<float>;
@@ -732,13 +739,16 @@ public:
 template <typename TIn, typename TOut = TIn, typename TTaps = TIn>
 class SymbolFilter : public gr::Block<SymbolFilter<TIn, TOut, TTaps>, gr::Resampling<>>
 {
-    static_assert(detail::is_c64<TIn> && detail::is_c64<TOut> && std::is_same_v<TTaps, float>,
-                  "gr4pm: SymbolFilter is built for <complex<float>, complex<float>, float> (packet_receiver.hpp:111)");
+    // <complex<float>, complex<float>, float> (packet_receiver.hpp:111) and <float, float, float>
+    // (test/qa_symbol_filter.cpp:17-63, python/bindings/register_symbol_filter.cpp:9-15): the ABI's item_kind 0 / 1
+    static_assert(std::is_same_v<TIn, TOut> && (detail::is_c64<TIn> || std::is_same_v<TIn, float>) && std::is_same_v<TTaps, float>,
+                  "gr4pm: SymbolFilter is built for <complex<float>, complex<float>, float> and <float, float, float>");
+    using Item = std::conditional_t<detail::is_c64<TIn>, gr4pm_c64, float>;
     gr4pm_symbol_filter* _h = nullptr;
-    detail::DeviceStage<gr4pm_c64> _din, _dout;
+    detail::DeviceStage<Item> _din, _dout;
     // full maps of the tags queued inside the filter (opaque keys travel with them), keyed by the handle the tag carries
-    // through the library in its freq_bin field; an entry leaves when its tag is published (it used to stay for the
-    // life of the block: one property_map leaked per packet)
+    // through the library in its `user` field (the caller's cookie; round 6: no longer freq_bin); an entry leaves when
+    // its tag is published (it used to stay for the life of the block: one property_map leaked per packet)
     std::map<int32_t, gr::property_map> _held;
     int32_t _next_handle = 0;
     std::vector<gr4pm_tag> _tags_out;
@@ -761,7 +771,7 @@ public:
     {
         gr4pm_symbol_filter_destroy(_h);
         _h = nullptr;
-        gr4pm_symbol_filter_params p{ samples_per_symbol, taps.data(), taps.size(), num_arms, delay, 0, nullptr };
+        gr4pm_symbol_filter_params p{ samples_per_symbol, taps.data(), taps.size(), num_arms, delay, detail::is_c64<TIn> ? 0 : 1, nullptr };
         detail::check(gr4pm_symbol_filter_create(&p, &_h), "SymbolFilter::settingsChanged"); // :67-73 throw
         // input_chunk_size / output_chunk_size stay 1 : 1 like the reference's (symbol_filter.hpp:74-81 has the
         // samples_per_symbol : 1 ratio commented out: input tags are not aligned to samples_per_symbol blocks, and a
@@ -782,25 +792,25 @@ public:
         size_t n_tags = 0;
         if (this->input_tags_present()) { // :127-206: the tag refers to inSpan[0]
             tag = detail::from_map(this->mergedInputTag().map, 0);
-            tag.freq_bin = _next_handle; // handle of the full map
+            tag.user = _next_handle; // handle of the full map
             _held.emplace(_next_handle, this->mergedInputTag().map);
             _next_handle = _next_handle == std::numeric_limits<int32_t>::max() ? 0 : _next_handle + 1;
             n_tags = 1;
         }
         const size_t n = std::min(inSpan.size(), detail::max_items());
         const size_t cap = std::min(outSpan.size(), detail::max_items());
-        const c64* hin = std::to_address(inSpan.begin());
-        const gr4pm_c64* din = _din.in(hin, n);
-        gr4pm_c64* dout = _dout.out(cap);
+        const TIn* hin = std::to_address(inSpan.begin());
+        const Item* din = _din.in(hin, n);
+        Item* dout = _dout.out(cap);
         size_t n_out_tags = 0, consumed = 0, produced = 0;
         detail::check(gr4pm_symbol_filter_process(_h, din, n, dout, cap, &tag, n_tags, _tags_out.data(),
                                                   _tags_out.size(), &n_out_tags, &consumed, &produced),
                       "SymbolFilter::processBulk");
         _dout.publish(std::to_address(outSpan.begin()), produced, host_output);
-        detail::consumed(hin, consumed * sizeof(c64));
+        detail::consumed(hin, consumed * sizeof(TIn));
         _din.done();
         for (size_t i = 0; i < n_out_tags; ++i) { // :218-228 re-timed tags, :152-155 adjusted phase
-            auto node = _held.extract(_tags_out[i].freq_bin); // published once: the entry goes with it
+            auto node = _held.extract(_tags_out[i].user); // published once: the entry goes with it
             if (node.empty()) throw gr::exception("SymbolFilter: a published tag has no queued map");
             auto& map = node.mapped();
             if (_tags_out[i].flags & GR4PM_TAG_SYNCWORD) map["syncword_phase"] = _tags_out[i].phase;
@@ -940,10 +950,14 @@ public:
 template <typename TIn, typename TOut = TIn, typename TTaps = TIn>
 class InterpolatingFirFilter : public gr::Block<InterpolatingFirFilter<TIn, TOut, TTaps>, gr::Resampling<>>
 {
-    static_assert(detail::is_c64<TIn> && detail::is_c64<TOut> && std::is_same_v<TTaps, float>,
-                  "gr4pm: InterpolatingFirFilter is built for <complex<float>, complex<float>, float>");
+    // <complex<float>, complex<float>, float> (packet_transmitter_pdu.hpp:343) and <float, float, float> (the ABI's
+    // item_kind 0 / 1); Pdu<complex<float>> items: the specialisation below
+    static_assert(std::is_same_v<TIn, TOut> && (detail::is_c64<TIn> || std::is_same_v<TIn, float>) && std::is_same_v<TTaps, float>,
+                  "gr4pm: InterpolatingFirFilter is built for <complex<float>, complex<float>, float>, <float, float, float> "
+                  "and their Pdu forms");
+    using Item = std::conditional_t<detail::is_c64<TIn>, gr4pm_c64, float>;
     gr4pm_interp_fir* _h = nullptr;
-    detail::DeviceStage<gr4pm_c64> _din, _dout;
+    detail::DeviceStage<Item> _din, _dout;
 
 public:
     gr::PortIn<TIn> in;
@@ -959,7 +973,7 @@ public:
     {
         gr4pm_interp_fir_destroy(_h);
         _h = nullptr;
-        gr4pm_interp_fir_params p{ interpolation, taps.data(), taps.size(), 0, nullptr };
+        gr4pm_interp_fir_params p{ interpolation, taps.data(), taps.size(), detail::is_c64<TIn> ? 0 : 1, nullptr };
         detail::check(gr4pm_interp_fir_create(&p, &_h), "InterpolatingFirFilter::settingsChanged"); // :45-47
         this->input_chunk_size = 1; // :50-51
         this->output_chunk_size = interpolation;
@@ -969,17 +983,72 @@ public:
         GR4PM_TRACE_ENTRY(inSpan.size(), outSpan.size());
         if (!_h) settingsChanged({}, {});
         const size_t n = std::min({ inSpan.size(), outSpan.size() / interpolation, detail::max_items() / interpolation }); // :91
-        const c64* hin = std::to_address(inSpan.begin());
-        const gr4pm_c64* din = _din.in(hin, n);
-        gr4pm_c64* dout = _dout.out(n * interpolation);
+        const TIn* hin = std::to_address(inSpan.begin());
+        const Item* din = _din.in(hin, n);
+        Item* dout = _dout.out(n * interpolation);
         detail::check(gr4pm_interp_fir_process(_h, din, n, dout), "InterpolatingFirFilter::processBulk");
         _dout.publish(std::to_address(outSpan.begin()), n * interpolation, host_output);
-        detail::consumed(hin, n * sizeof(c64));
+        detail::consumed(hin, n * sizeof(TIn));
         _din.done();
         if (!inSpan.consume(n)) throw gr::exception("consume failed");
         outSpan.publish(n * interpolation);
         GR4PM_TRACE_EXIT(n, n * interpolation);
         return gr::work::Status::OK;
+    }
+};
+
+// Pdu<TIn> -> Pdu<TOut> (interpolating_fir_filter.hpp:104-175; packet_transmitter_pdu.hpp:288): one PDU per
+// processOne(), the filter history runs on ACROSS PDUs (:155-165 never clears _history), tags re-indexed by the
+// interpolation (:167-171).  Any type with `value_type`, `data` (std::vector<value_type>) and `tags` is a PDU here, so
+// that this header needs nothing of the reference's pdu.hpp.
+template <detail::PduLike PIn, detail::PduLike POut, typename TTaps>
+class InterpolatingFirFilter<PIn, POut, TTaps> : public gr::Block<InterpolatingFirFilter<PIn, POut, TTaps>>
+{
+    using TIn = typename PIn::value_type;
+    using TOut = typename POut::value_type;
+    static_assert(std::is_same_v<TIn, TOut> && (detail::is_c64<TIn> || std::is_same_v<TIn, float>) && std::is_same_v<TTaps, float>,
+                  "gr4pm: InterpolatingFirFilter<Pdu> is built for Pdu<complex<float>> and Pdu<float> items, float taps");
+    using Item = std::conditional_t<detail::is_c64<TIn>, gr4pm_c64, float>;
+    gr4pm_interp_fir* _h = nullptr;
+    detail::DeviceStage<Item> _din, _dout;
+
+public:
+    gr::PortIn<PIn> in;
+    gr::PortOut<POut> out;
+    size_t interpolation = 1;
+    std::vector<TTaps> taps;
+
+    InterpolatingFirFilter() = default;
+    InterpolatingFirFilter(const InterpolatingFirFilter&) = delete;
+    ~InterpolatingFirFilter() { gr4pm_interp_fir_destroy(_h); }
+    void settingsChanged(const gr::property_map&, const gr::property_map&)
+    {
+        // (the reference moves the old history into the new filter, :138-146; settings change once, before the first PDU)
+        gr4pm_interp_fir_destroy(_h);
+        _h = nullptr;
+        gr4pm_interp_fir_params p{ interpolation, taps.data(), taps.size(), detail::is_c64<TIn> ? 0 : 1, nullptr };
+        detail::check(gr4pm_interp_fir_create(&p, &_h), "InterpolatingFirFilter<Pdu>::settingsChanged"); // :124-126
+    }
+    [[nodiscard]] POut processOne(const PIn& pdu)
+    {
+        if (!_h) settingsChanged({}, {});
+        POut pdu_out;
+        const size_t n = pdu.data.size();
+        pdu_out.data.resize(n * interpolation);
+        if (n) {
+            const Item* din = _din.in(pdu.data.data(), n);
+            Item* dout = _dout.out(n * interpolation);
+            detail::check(gr4pm_interp_fir_process(_h, din, n, dout), "InterpolatingFirFilter<Pdu>::processOne");
+            detail::check_hip(hipMemcpy(pdu_out.data.data(), dout, n * interpolation * sizeof(Item), hipMemcpyDeviceToHost),
+                              "hipMemcpy D2H");
+            _din.done();
+        }
+        pdu_out.tags.reserve(pdu.tags.size());
+        for (auto tag : pdu.tags) { // :167-171
+            tag.index *= static_cast<decltype(tag.index)>(interpolation);
+            pdu_out.tags.push_back(std::move(tag));
+        }
+        return pdu_out;
     }
 };
 
@@ -1305,6 +1374,49 @@ public:
         outSpan.publish(n);
         GR4PM_TRACE_EXIT(n, n);
         return gr::work::Status::OK;
+    }
+};
+
+// AdditiveScrambler<Pdu<T>> (additive_scrambler.hpp:102-159; packet_transmitter_pdu.hpp:119): the LFSR restarts at
+// the head of every PDU (:133-134) and after every `count` items (:137-139); tags travel unchanged (:135)
+template <detail::PduLike P>
+class AdditiveScrambler<P> : public gr::Block<AdditiveScrambler<P>>
+{
+    using T = typename P::value_type;
+    static_assert(std::is_same_v<T, float> || std::is_same_v<T, uint8_t>, "gr4pm: AdditiveScrambler<Pdu> is built for Pdu<float> and Pdu<uint8_t>");
+    gr4pm_additive_scrambler* _h = nullptr;
+    detail::DeviceStage<T> _din, _dout;
+
+public:
+    gr::PortIn<P> in;
+    gr::PortOut<P> out;
+    uint64_t mask = 0x8a, seed = 0x7f, length = 7, count = 0; // :115-118
+    std::string reset_tag_key = "";
+
+    AdditiveScrambler() = default;
+    AdditiveScrambler(const AdditiveScrambler&) = delete;
+    ~AdditiveScrambler() { gr4pm_additive_scrambler_destroy(_h); }
+    void start() // :123
+    {
+        gr4pm_additive_scrambler_destroy(_h);
+        _h = nullptr;
+        gr4pm_additive_scrambler_params p{ mask, seed, length, count, std::is_same_v<T, float> ? 1 : 2, nullptr };
+        detail::check(gr4pm_additive_scrambler_create(&p, &_h), "AdditiveScrambler<Pdu>::start");
+    }
+    [[nodiscard]] P processOne(const P& pdu)
+    {
+        if (!_h) start();
+        P pdu_out = pdu; // :135
+        const size_t n = pdu.data.size();
+        if (n) {
+            const uint64_t zero = 0; // the reset at the PDU's first item
+            const T* din = _din.in(pdu.data.data(), n);
+            T* dout = _dout.out(n);
+            detail::check(gr4pm_additive_scrambler_process(_h, din, n, dout, &zero, 1), "AdditiveScrambler<Pdu>::processOne");
+            detail::check_hip(hipMemcpy(pdu_out.data.data(), dout, n * sizeof(T), hipMemcpyDeviceToHost), "hipMemcpy D2H");
+            _din.done();
+        }
+        return pdu_out;
     }
 };
 

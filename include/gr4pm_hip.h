@@ -72,7 +72,14 @@ typedef struct {
     float esn0_db;     /* "syncword_esn0_db" */
     float time_est;    /* "syncword_time_est" */
     int32_t flags;     /* GR4PM_TAG_* */
+    int32_t user;      /* the caller's own cookie: never read by the library, copied with the tag by every block that
+                          re-emits it (SymbolFilter's re-timed tags, :218-228) -- a binding keeps the full property map
+                          of a tag under this handle; SyncwordDetection writes 0.  (Round 6: the GR4 wrapper used to
+                          carry its handle in freq_bin; the field takes the struct's former tail padding, size 48.) */
 } gr4pm_tag;
+#if defined(__cplusplus)
+static_assert(sizeof(gr4pm_tag) == 48, "gr4pm_tag is 48 bytes (tests and bindings mirror it)");
+#endif
 #define GR4PM_TAG_SYNCWORD 1 /* carries the syncword_* keys */
 #define GR4PM_TAG_OTHER 2    /* carries other (opaque, wrapper-held) keys */
 

@@ -35,6 +35,8 @@
 #include <stdexcept>
 #include <string>
 #include <string_view>
+#include <thread>
+#include <typeinfo>
 #include <variant>
 #include <vector>
 
@@ -155,7 +157,7 @@ void print(std::string_view f, const A&... a)
 
 namespace pmtv {
 using pmt = std::variant<std::monostate, bool, int32_t, int64_t, uint64_t, float, double, std::string,
-                         std::vector<float>, std::vector<uint8_t>, std::vector<std::complex<float>>>;
+                         std::vector<float>, std::vector<uint8_t>, std::vector<std::complex<float>>, std::vector<double>>;
 inline pmt pmt_null() { return pmt{}; }
 template <typename T>
 T cast(const pmt& p)
@@ -220,7 +222,13 @@ struct Message {
 namespace message {
 enum class Command { Set, Get, Subscribe, Unsubscribe, Partial, Final, Ready, Disconnect, Heartbeat, Invalid };
 }
+enum class ConnectionResult { SUCCESS, FAILED };
 struct Async {};
+template <bool>
+struct BlockingIO {}; // block attribute (tun_source.hpp:15)
+template <size_t, size_t, bool = false>
+struct RequiredSamples {}; // port attribute (tun_source.hpp:33)
+struct Optional {}; // port attribute: the port may stay unconnected (packet_to_stream.hpp:57,159, pdu_to_tagged_stream.hpp:36)
 template <auto...>
 struct Resampling {};
 enum class TagPropagationPolicy { TPP_DONT, TPP_ALL_TO_ALL, TPP_ONE_TO_ONE, TPP_CUSTOM };
@@ -279,8 +287,15 @@ struct PortIn {
     using value_type = T;
     static constexpr bool is_input = true;
     static constexpr bool is_async = (std::is_same_v<Attr, Async> || ... || false);
+    static constexpr bool is_optional = (std::is_same_v<Attr, Optional> || ... || false);
     size_t min_samples = 1, max_samples = static_cast<size_t>(-1);
     std::vector<stub::Link> links;
+    size_t buffer_size = 65536; // resizeBuffer(): packet_transmitter_pdu.hpp:53-220 sizes its PDU edges
+    ConnectionResult resizeBuffer(size_t n)
+    {
+        buffer_size = n;
+        return ConnectionResult::SUCCESS;
+    }
 };
 template <typename T, typename... Attr>
 struct PortOut {
@@ -288,7 +303,14 @@ struct PortOut {
     static constexpr bool is_input = false;
     std::vector<stub::Link> links;
     static constexpr bool is_async = (std::is_same_v<Attr, Async> || ... || false);
+    static constexpr bool is_optional = (std::is_same_v<Attr, Optional> || ... || false);
     size_t min_samples = 1, max_samples = static_cast<size_t>(-1);
+    size_t buffer_size = 65536;
+    ConnectionResult resizeBuffer(size_t n)
+    {
+        buffer_size = n;
+        return ConnectionResult::SUCCESS;
+    }
     // what the block published during the current processBulk(): offsets are relative to the out span
     std::vector<Tag> published_tags;
     void publishTag(const property_map& map, ssize_t offset) { published_tags.push_back({ offset, map }); }
@@ -387,6 +409,32 @@ constexpr bool same_name(const meta::fixed_string<N>& a, const char* b)
 }
 template <meta::fixed_string>
 inline constexpr bool no_such_member = false;
+// a port found by its RUN-TIME name -- fg.connect(a, "out"s, b, "in#2"s), packet_transmitter_pdu.hpp:273-401: "name" is a
+// port member, "name#k" element k of a std::vector of ports (packet_mux.hpp:35,212)
+struct PortRef {
+    const std::type_info* item = nullptr;
+    bool is_input = false;
+    std::vector<Link>* links = nullptr;
+};
+template <typename M>
+bool port_named(M& m, std::string_view member, std::string_view wanted, PortRef& ref)
+{
+    if constexpr (PortLike<M>) {
+        if (wanted != member) return false;
+        ref = { &typeid(typename M::value_type), M::is_input, &m.links };
+        return true;
+    } else if constexpr (requires { typename M::value_type; requires PortLike<typename M::value_type>; m.size(); }) {
+        if (wanted.size() < member.size() + 2 || wanted.substr(0, member.size()) != member || wanted[member.size()] != '#')
+            return false;
+        const size_t k = std::stoul(std::string(wanted.substr(member.size() + 1)));
+        if (k >= m.size()) return false;
+        using P = typename M::value_type;
+        ref = { &typeid(typename P::value_type), P::is_input, &m[k].links };
+        return true;
+    } else {
+        return false;
+    }
+}
 template <typename T>
 struct Reflect; // specialised by ENABLE_REFLECTION*: size_t apply(T&, const property_map&) -> settings assigned
 
@@ -471,6 +519,13 @@ struct Graph {
         GR4_STUB_FOR_EACH(GR4_STUB_MEMBER_ONE, __VA_ARGS__)                                                          \
         static_assert(::gr::stub::no_such_member<N_>, "no reflected member of that name");                           \
     }
+#define GR4_STUB_PORT_ONE(member)                                                                                    \
+    if (::gr::stub::port_named(b_.member, #member, name_, ref_)) return true;
+#define GR4_STUB_PORT_BODY(...)                                                                                      \
+    {                                                                                                                \
+        GR4_STUB_FOR_EACH(GR4_STUB_PORT_ONE, __VA_ARGS__)                                                            \
+        return false;                                                                                                \
+    }
 #define GR4_STUB_STRIP(...) __VA_ARGS__
 #define ENABLE_REFLECTION(Type, ...)                                                                                 \
     template <>                                                                                                      \
@@ -478,6 +533,7 @@ struct Graph {
         static size_t apply(Type& b_, const ::gr::property_map& m_) GR4_STUB_REFLECT_BODY(__VA_ARGS__)                \
         template <::gr::meta::fixed_string N_>                                                                       \
         static decltype(auto) member(Type& b_) GR4_STUB_MEMBER_BODY(__VA_ARGS__)                                     \
+        static bool port(Type& b_, std::string_view name_, ::gr::stub::PortRef& ref_) GR4_STUB_PORT_BODY(__VA_ARGS__)\
     }
 #define ENABLE_REFLECTION_FOR_TEMPLATE(Tmpl, ...)                                                                    \
     template <typename... Ts_>                                                                                       \
@@ -485,6 +541,7 @@ struct Graph {
         static size_t apply(Tmpl<Ts_...>& b_, const ::gr::property_map& m_) GR4_STUB_REFLECT_BODY(__VA_ARGS__)        \
         template <::gr::meta::fixed_string N_>                                                                       \
         static decltype(auto) member(Tmpl<Ts_...>& b_) GR4_STUB_MEMBER_BODY(__VA_ARGS__)                             \
+        static bool port(Tmpl<Ts_...>& b_, std::string_view name_, ::gr::stub::PortRef& ref_) GR4_STUB_PORT_BODY(__VA_ARGS__)\
     }
 // ENABLE_REFLECTION_FOR_TEMPLATE_FULL((bool invert, typename TIn, typename TOut), (BinarySlicer<invert, TIn, TOut>), in, out)
 #define ENABLE_REFLECTION_FOR_TEMPLATE_FULL(TParams, Type, ...)                                                      \
@@ -494,4 +551,5 @@ struct Graph {
         static size_t apply(Self_& b_, const ::gr::property_map& m_) GR4_STUB_REFLECT_BODY(__VA_ARGS__)               \
         template <::gr::meta::fixed_string N_>                                                                       \
         static decltype(auto) member(Self_& b_) GR4_STUB_MEMBER_BODY(__VA_ARGS__)                                    \
+        static bool port(Self_& b_, std::string_view name_, ::gr::stub::PortRef& ref_) GR4_STUB_PORT_BODY(__VA_ARGS__)\
     }

@@ -7,7 +7,7 @@
 #include <gnuradio-4.0/Block.hpp>
 
 namespace gr {
-enum class ConnectionResult { SUCCESS, FAILED };
+// (ConnectionResult: Block.hpp, where PortOut::resizeBuffer() returns it too)
 
 class Graph : public stub::Graph
 {
@@ -46,6 +46,21 @@ public:
     Connector<SrcName, Src> connect(Src& src)
     {
         return { *this, src };
+    }
+    // fg.connect(a, "out"s, b, "in#2"s) (packet_transmitter_pdu.hpp:273-401): ports by run-time name, elements of a
+    // std::vector of ports as "name#k"; the same checks as the compile-time form, made when the graph is built
+    template <typename Src, typename Dst>
+    [[nodiscard]] ConnectionResult connect(Src& src, const std::string& src_port, Dst& dst, const std::string& dst_port)
+    {
+        stub::PortRef out, in;
+        if (!stub::Reflect<Src>::port(src, src_port, out) || !stub::Reflect<Dst>::port(dst, dst_port, in))
+            return ConnectionResult::FAILED; // no such port
+        if (out.is_input || !in.is_input || *out.item != *in.item) return ConnectionResult::FAILED;
+        if (!owns(&src) || !owns(&dst) || !in.links->empty()) return ConnectionResult::FAILED;
+        out.links->push_back({ &dst, dst_port });
+        in.links->push_back({ &src, src_port });
+        edges.push_back({ &src, &dst, src_port, dst_port });
+        return ConnectionResult::SUCCESS;
     }
     bool owns(const void* b) const
     {

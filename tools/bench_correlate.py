@@ -22,7 +22,8 @@ g = torch.Generator(device="cuda")
 g.manual_seed(1)
 x = torch.complex(torch.randn(items, generator=g, device="cuda"), torch.randn(items, generator=g, device="cuda"))
 sd = pkg.SyncwordDetection(rrc, bench.SYNCWORD, np.array([1, -1], np.complex64), -bins, bins, max_items=items)
-sd.correlate_only(x)
+for _ in range(int(os.environ.get("WARM", "30"))):  # (clocks: the first launches after host work run slower)
+    sd.correlate_only(x)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()

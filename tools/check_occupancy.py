@@ -8,6 +8,9 @@ compiler that needs 34 registers for the PLL, returns the chain to 50 Gsps with 
 read back from the code objects inside the built library (the .hip_fatbin bundles -> the gfx950 ELF -> its
 NT_AMDGPU_METADATA note, msgpack) and the build fails when one is exceeded.
 
+Exit status: 0 = every budget kept, 1 = a budget exceeded (build() fails), 2 = the library could not be inspected
+(unknown bundle layout; build() prints a warning and goes on: that is not an occupancy finding).
+
 Usage: tools/check_occupancy.py [--lib path/to/lib.so] [--json out.json]
 `--json` writes the table of every kernel of the library (profiles/r5_occupancy.json is that file)."""
 import argparse
@@ -17,7 +20,70 @@ import re
 import struct
 import sys
 
-import msgpack
+try:  # not a declared dependency of anything else in the repository: a reader of its own stands in when it is absent
+    import msgpack
+    unpack_metadata = lambda desc: msgpack.unpackb(desc, raw=False, strict_map_key=False)
+except ImportError:
+    msgpack = None
+
+    def unpack_metadata(desc):
+        """the subset of MessagePack the AMDGPU metadata note uses (maps, arrays, strings, integers, booleans, nil, floats)"""
+        def rd(p):
+            b = desc[p]
+            if b <= 0x7F:
+                return b, p + 1
+            if b >= 0xE0:
+                return b - 256, p + 1
+            if 0x80 <= b <= 0x8F:
+                return rd_map(b & 15, p + 1)
+            if 0x90 <= b <= 0x9F:
+                return rd_arr(b & 15, p + 1)
+            if 0xA0 <= b <= 0xBF:
+                n = b & 31
+                return desc[p + 1:p + 1 + n].decode(), p + 1 + n
+            if b == 0xC0:
+                return None, p + 1
+            if b in (0xC2, 0xC3):
+                return b == 0xC3, p + 1
+            if b in (0xC4, 0xC5, 0xC6, 0xD9, 0xDA, 0xDB):
+                w = {0xC4: 1, 0xC5: 2, 0xC6: 4, 0xD9: 1, 0xDA: 2, 0xDB: 4}[b]
+                n = int.from_bytes(desc[p + 1:p + 1 + w], "big")
+                raw = desc[p + 1 + w:p + 1 + w + n]
+                return (raw.decode() if b >= 0xD9 else bytes(raw)), p + 1 + w + n
+            if b == 0xCA:
+                return struct.unpack_from(">f", desc, p + 1)[0], p + 5
+            if b == 0xCB:
+                return struct.unpack_from(">d", desc, p + 1)[0], p + 9
+            if 0xCC <= b <= 0xCF:
+                w = 1 << (b - 0xCC)
+                return int.from_bytes(desc[p + 1:p + 1 + w], "big"), p + 1 + w
+            if 0xD0 <= b <= 0xD3:
+                w = 1 << (b - 0xD0)
+                return int.from_bytes(desc[p + 1:p + 1 + w], "big", signed=True), p + 1 + w
+            if b in (0xDC, 0xDD):
+                w = 2 if b == 0xDC else 4
+                return rd_arr(int.from_bytes(desc[p + 1:p + 1 + w], "big"), p + 1 + w)
+            if b in (0xDE, 0xDF):
+                w = 2 if b == 0xDE else 4
+                return rd_map(int.from_bytes(desc[p + 1:p + 1 + w], "big"), p + 1 + w)
+            raise ValueError(f"MessagePack type byte {b:#x} not handled")
+
+        def rd_arr(n, p):
+            out = []
+            for _ in range(n):
+                v, p = rd(p)
+                out.append(v)
+            return out, p
+
+        def rd_map(n, p):
+            out = {}
+            for _ in range(n):
+                k, p = rd(p)
+                v, p = rd(p)
+                out[k] = v
+            return out, p
+
+        return rd(0)[0]
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "gr4-packet-modem_amd", "libgr4pm_hip.so")
@@ -85,7 +151,7 @@ def kernels_of(elf):
             desc = elf[p:p + descsz]
             p += (descsz + 3) & ~3
             if name == b"AMDGPU" and ntype == 32:  # NT_AMDGPU_METADATA
-                meta = msgpack.unpackb(desc, raw=False, strict_map_key=False)
+                meta = unpack_metadata(desc)
                 found.extend(meta.get("amdhsa.kernels", []))
     return found
 
@@ -137,10 +203,16 @@ def main():
     ap.add_argument("--lib", default=LIB)
     ap.add_argument("--json")
     a = ap.parse_args()
-    rows = table(a.lib)
+    try:
+        rows = table(a.lib)
+    except Exception as e:  # a layout this reader does not know: "could not inspect" is not "budget exceeded"
+        print(f"check_occupancy: WARNING: could not read the code objects of {a.lib}: {e!r}")
+        return 2
     if not rows:
-        print("check_occupancy: no code object found in", a.lib)
-        return 1
+        compressed = b"CCOB" in open(a.lib, "rb").read()
+        print("check_occupancy: WARNING: no code object found in", a.lib,
+              "(compressed offload bundles: link with --no-offload-compress)" if compressed else "")
+        return 2
     errors = check(rows)
     if a.json:
         with open(a.json, "w") as f:
