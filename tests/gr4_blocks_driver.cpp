@@ -20,6 +20,11 @@
 //            HeaderFecDecoder, and the symbol split of zmq_output (:159-162) HeaderPayloadSplit<c64>; writes
 //            .llr.f32 / .hdr_llr.f32 / .pay_llr.f32 / .hdr_bytes.u8 / .hdr_sym.c64 / .pay_sym.c64 / .tail_counts.bin
 //        gr4_blocks_driver blocks <in.c64> <out_prefix>      (Rotator, InterpolatingFirFilter, PfbArbResampler)
+//        gr4_blocks_driver floats <in.f32> <out_prefix>      (test/qa_symbol_filter.cpp:17-63: InterpolatingFirFilter<float,
+//            float, float> -> SymbolFilter<float, float, float>; writes .fir.f32 / .sym.f32)
+//        gr4_blocks_driver pdus <bits.u8> <symbols.c64> <out_prefix>   (the PDU forms of packet_transmitter_pdu.hpp:119,288:
+//            AdditiveScrambler<Pdu<uint8_t>> and InterpolatingFirFilter<Pdu<c64>, Pdu<c64>, float> through processOne()
+//            on PDUs of ragged sizes; writes .scr.u8 / .fir.c64 / .scr_sizes.u64 / .fir_sizes.u64 / .fir_tag_index.u64)
 // writes <out_prefix>.sd.c64 / .sd_tags.bin / .symbols.c64 / .sym_tags.bin (tests/test_gr4_blocks.py reads them)
 #include <gnuradio-4.0/packet-modem/coarse_frequency_correction.hpp>
 #include <gnuradio-4.0/packet-modem/costas_loop.hpp>
@@ -308,6 +313,118 @@ static int blocks(int argc, char** argv)
     return 0;
 }
 
+
+// test/qa_symbol_filter.cpp:17-63 on the wrappers: +-1 float symbols -> InterpolatingFirFilter<float, float, float> (4 x,
+// 44-tap RRC) -> SymbolFilter<float, float, float> (32 arms); ragged chunk sizes
+static std::vector<float> read_f32(const char* path)
+{
+    FILE* f = std::fopen(path, "rb");
+    if (!f) throw std::runtime_error(std::string("cannot read ") + path);
+    std::fseek(f, 0, SEEK_END);
+    const size_t n = static_cast<size_t>(std::ftell(f)) / sizeof(float);
+    std::fseek(f, 0, SEEK_SET);
+    std::vector<float> x(n);
+    if (n && std::fread(x.data(), sizeof(float), n, f) != n) throw std::runtime_error("short read");
+    std::fclose(f);
+    return x;
+}
+static int floats(int argc, char** argv)
+{
+    if (argc < 4) return 2;
+    const auto x = read_f32(argv[2]);
+    const std::string prefix = argv[3];
+    const size_t sps = 4, arms = 32;
+    Edge<float> e_in(x.size()), e_fir(sps * x.size() + 64), e_sym(x.size() + 64);
+    std::copy(x.begin(), x.end(), e_in.data.begin());
+    e_in.size = x.size();
+    gr::stub::Graph fg;
+    auto& fir = fg.emplaceBlock<InterpolatingFirFilter<float, float, float>>(
+        { { "interpolation", sps }, { "taps", firdes::root_raised_cosine(1.0, static_cast<double>(sps), 1.0, 0.35, sps * 11) } });
+    run(fir, e_in, e_fir, 2999, [&](auto& is, auto& os) { return fir.processBulk(is, os); });
+    auto& symf = fg.emplaceBlock<SymbolFilter<float, float, float>>(
+        { { "taps", firdes::root_raised_cosine(static_cast<double>(arms), static_cast<double>(arms * sps), 1.0, 0.35, arms * sps * 11) },
+          { "num_arms", arms },
+          { "samples_per_symbol", sps } });
+    symf.start();
+    run(symf, e_fir, e_sym, 10007, [&](auto& is, auto& os) { return symf.processBulk(is, os); });
+    dump(prefix + ".fir.f32", e_fir.data.data(), e_fir.size);
+    dump(prefix + ".sym.f32", e_sym.data.data(), e_sym.size);
+    std::printf("floats: fir %zu symbols %zu\n", e_fir.size, e_sym.size);
+    return 0;
+}
+
+// gr::packet_modem::Pdu<T> by shape (pdu.hpp:15-21; the reference's header is not on the GPU box)
+template <typename T>
+struct TestPdu {
+    using value_type = T;
+    std::vector<T> data{};
+    std::vector<gr::Tag> tags{};
+};
+static int pdus(int argc, char** argv)
+{
+    if (argc < 5) return 2;
+    std::vector<uint8_t> bits;
+    {
+        FILE* f = std::fopen(argv[2], "rb");
+        if (!f) throw std::runtime_error("cannot read bits");
+        std::fseek(f, 0, SEEK_END);
+        bits.resize(static_cast<size_t>(std::ftell(f)));
+        std::fseek(f, 0, SEEK_SET);
+        if (!bits.empty() && std::fread(bits.data(), 1, bits.size(), f) != bits.size()) throw std::runtime_error("short read");
+        std::fclose(f);
+    }
+    const auto sym = read_c64(argv[3]);
+    const std::string prefix = argv[4];
+    gr::stub::Graph fg;
+    // packet_transmitter_pdu.hpp:119-122: the CCSDS scrambler, restarted at the head of every PDU
+    auto& scr = fg.emplaceBlock<AdditiveScrambler<TestPdu<uint8_t>>>(
+        { { "mask", uint64_t{ 0x4001U } }, { "seed", uint64_t{ 0x18E38U } }, { "length", uint64_t{ 16U } } });
+    scr.start();
+    std::vector<uint8_t> scr_out;
+    std::vector<uint64_t> sizes, fir_sizes;
+    uint32_t lcg = 12345u;
+    auto next_size = [&](size_t left) {
+        lcg = lcg * 1664525u + 1013904223u;
+        const size_t want = (lcg >> 16) % 5 == 0 ? 0 : 1 + (lcg >> 8) % 4000; // every fifth PDU is empty
+        return std::min(want, left);
+    };
+    for (size_t pos = 0; pos < bits.size();) {
+        const size_t n = next_size(bits.size() - pos);
+        TestPdu<uint8_t> pdu;
+        pdu.data.assign(bits.begin() + static_cast<ssize_t>(pos), bits.begin() + static_cast<ssize_t>(pos + n));
+        pdu.tags.push_back({ 0, { { "packet_len", static_cast<uint64_t>(n) } } });
+        const auto out = scr.processOne(pdu);
+        if (out.data.size() != n || out.tags.size() != 1 || out.tags[0].index != 0) throw std::runtime_error("scrambler PDU shape");
+        scr_out.insert(scr_out.end(), out.data.begin(), out.data.end());
+        sizes.push_back(n);
+        pos += n;
+    }
+    // packet_transmitter_pdu.hpp:288-291: the RRC interpolator on symbol PDUs, history running on across PDUs
+    auto& fir = fg.emplaceBlock<InterpolatingFirFilter<TestPdu<c64>, TestPdu<c64>, float>>(
+        { { "interpolation", size_t{ 4 } }, { "taps", firdes::root_raised_cosine(1.0, 4.0, 1.0, 0.35, 44) } });
+    std::vector<c64> fir_out;
+    std::vector<uint64_t> tag_index;
+    for (size_t pos = 0; pos < sym.size();) {
+        const size_t n = next_size(sym.size() - pos);
+        TestPdu<c64> pdu;
+        pdu.data.assign(sym.begin() + static_cast<ssize_t>(pos), sym.begin() + static_cast<ssize_t>(pos + n));
+        if (n) pdu.tags.push_back({ static_cast<ssize_t>(n / 2), { { "mark", static_cast<uint64_t>(pos) } } });
+        const auto out = fir.processOne(pdu);
+        if (out.data.size() != 4 * n || out.tags.size() != pdu.tags.size()) throw std::runtime_error("FIR PDU shape");
+        for (const auto& t : out.tags) tag_index.push_back(fir_out.size() + static_cast<uint64_t>(t.index)); // :167-171
+        fir_out.insert(fir_out.end(), out.data.begin(), out.data.end());
+        fir_sizes.push_back(n);
+        pos += n;
+    }
+    dump(prefix + ".scr.u8", scr_out.data(), scr_out.size());
+    dump(prefix + ".fir.c64", fir_out.data(), fir_out.size());
+    dump(prefix + ".scr_sizes.u64", sizes.data(), sizes.size());
+    dump(prefix + ".fir_sizes.u64", fir_sizes.data(), fir_sizes.size());
+    dump(prefix + ".fir_tag_index.u64", tag_index.data(), tag_index.size());
+    std::printf("pdus: %zu + %zu PDUs, scrambled %zu, filtered %zu\n", sizes.size(), fir_sizes.size(), scr_out.size(), fir_out.size());
+    return 0;
+}
+
 // A double-mapped ring between two wrapped blocks with host_output = false (gnuradio4's CircularBuffer maps its storage
 // twice, back to back): the producer's spans run past the end of the first mapping, the consumer -- reading in smaller
 // chunks -- sees the items behind the wrap at addresses one ring size lower.  The host memory of the ring is never
@@ -476,6 +593,8 @@ int main(int argc, char** argv)
         if (argc >= 2 && std::strcmp(argv[1], "chain") == 0) return chain(argc, argv);
         if (argc >= 2 && std::strcmp(argv[1], "receiver") == 0) return chain(argc, argv, true);
         if (argc >= 2 && std::strcmp(argv[1], "blocks") == 0) return blocks(argc, argv);
+        if (argc >= 2 && std::strcmp(argv[1], "floats") == 0) return floats(argc, argv);
+        if (argc >= 2 && std::strcmp(argv[1], "pdus") == 0) return pdus(argc, argv);
         if (argc >= 2 && std::strcmp(argv[1], "mirror") == 0) return mirror(argc, argv);
         if (argc >= 2 && std::strcmp(argv[1], "threads") == 0) return threads(argc, argv);
         std::fprintf(stderr, "usage: %s chain|receiver|blocks|mirror|threads ...\n", argv[0]);

@@ -36,11 +36,11 @@ def test_wrappers_compile_with_trace_prints(tmp_path):
 
 
 def test_unsupported_instantiations_are_compile_errors(tmp_path):
-    """the wrappers are built for the reference's receiver instantiations; anything else must not compile
-    (no silent CPU path)"""
+    """the wrappers are built for the instantiations the reference uses, registers or tests (round 6: SymbolFilter<float,
+    float, float> is one of them, test/qa_symbol_filter.cpp:41); anything else must not compile (no silent CPU path)"""
     src = tmp_path / "bad.cpp"
     src.write_text('#include <gnuradio-4.0/packet-modem/symbol_filter.hpp>\n'
-                   'gr::packet_modem::SymbolFilter<float, float, float> f;\nint main() { return 0; }\n')
+                   'gr::packet_modem::SymbolFilter<double, double, double> f;\nint main() { return 0; }\n')
     r = subprocess.run(ge.gr4_compile_command(str(src), str(tmp_path / "bad")), capture_output=True, text=True)
     assert r.returncode != 0 and "gr4pm: SymbolFilter is built for" in r.stderr
 
@@ -210,20 +210,117 @@ def test_rotator_fir_resampler_wrappers(tmp_path):
     assert abs(arb.size - ref_arb.size) <= 2 and np.array_equal(arb[:n].view(np.uint64), ref_arb[:n].view(np.uint64))
 
 
+@pytest.mark.gpu
+def test_float_symbol_filter_and_fir_wrappers_reference_qa(tmp_path):
+    """test/qa_symbol_filter.cpp:17-63 on the wrappers (the instantiations the reference registers and tests,
+    python/bindings/register_symbol_filter.cpp:9-15): +-1 float symbols -> InterpolatingFirFilter<float, float, float>
+    (4 x, 44-tap RRC) -> SymbolFilter<float, float, float> (32 arms) through processBulk() in ragged chunks.  Bit for
+    bit against the oracle's float forms, and the reference's own assertion: one symbol out per symbol in, amplitude
+    0.24819523 +- 5e-3 behind the 11-symbol transient."""
+    ge.build_gr4_driver()
+    rng = np.random.default_rng(17)
+    n = 100000  # (the reference runs 10^6; the oracle's serial loops set the size here)
+    x = (1.0 - 2.0 * rng.integers(0, 2, n)).astype(np.float32)
+    fin = tmp_path / "in.f32"
+    x.tofile(fin)
+    prefix = str(tmp_path / "f")
+    r = subprocess.run([DRIVER, "floats", str(fin), prefix], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    fir = np.fromfile(prefix + ".fir.f32", dtype=np.float32)
+    sym = np.fromfile(prefix + ".sym.f32", dtype=np.float32)
+    ref_fir = orc.interpolating_fir(x, 4, orc.rrc_taps(1.0, 4.0, 1.0, 0.35, 44))
+    assert np.array_equal(fir.view(np.uint32), ref_fir.view(np.uint32))
+    ref_sym, _, consumed = orc.symbol_filter(ref_fir, orc.rrc_taps(32.0, 128.0, 1.0, 0.35, 32 * 4 * 11), 32, 4, 0)
+    assert consumed == ref_fir.size and sym.size == n == ref_sym.size                     # qa_symbol_filter.cpp:56
+    assert np.array_equal(sym.view(np.uint32), ref_sym.view(np.uint32))
+    assert np.all(np.abs(np.abs(sym[11:]) - 0.24819523) < 5e-3)                           # qa_symbol_filter.cpp:57-62
+
+
+@pytest.mark.gpu
+def test_pdu_forms_of_scrambler_and_fir_wrappers(tmp_path):
+    """AdditiveScrambler<Pdu<uint8_t>> (additive_scrambler.hpp:102-159: the LFSR restarts at the head of every PDU) and
+    InterpolatingFirFilter<Pdu<c64>, Pdu<c64>, float> (interpolating_fir_filter.hpp:104-175: the history runs on across
+    PDUs, tag indices times the interpolation) -- the forms the reference's transmitter uses
+    (packet_transmitter_pdu.hpp:119,288) -- through processOne() on PDUs of ragged sizes, empty ones among them,
+    against the oracle."""
+    ge.build_gr4_driver()
+    rng = np.random.default_rng(23)
+    bits = rng.integers(0, 2, 60000).astype(np.uint8)
+    sym = ((1 - 2 * rng.integers(0, 2, 30000)) + 1j * (1 - 2 * rng.integers(0, 2, 30000))).astype(np.complex64) * np.float32(0.70710677)
+    fb, fs = tmp_path / "bits.u8", tmp_path / "sym.c64"
+    bits.tofile(fb)
+    sym.tofile(fs)
+    prefix = str(tmp_path / "p")
+    r = subprocess.run([DRIVER, "pdus", str(fb), str(fs), prefix], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    sizes = np.fromfile(prefix + ".scr_sizes.u64", dtype=np.uint64).astype(np.int64)
+    fir_sizes = np.fromfile(prefix + ".fir_sizes.u64", dtype=np.uint64).astype(np.int64)
+    scr = np.fromfile(prefix + ".scr.u8", dtype=np.uint8)
+    fir = np.fromfile(prefix + ".fir.c64", dtype=np.complex64)
+    assert np.sum(sizes) == bits.size and np.sum(fir_sizes) == sym.size and np.any(sizes == 0) and np.any(fir_sizes == 0)
+    starts = np.concatenate(([0], np.cumsum(sizes)[:-1]))
+    want = orc.AdditiveScrambler(0x4001, 0x18E38, 16, 0).process(bits, reset_index=np.unique(starts[sizes > 0]))
+    assert np.array_equal(scr, want)
+    ref = orc.InterpolatingFir(4, orc.rrc_taps(1.0, 4.0, 1.0, 0.35, 44))  # one running filter over the concatenated PDUs
+    want_fir = ref.process(sym)
+    assert np.array_equal(fir.view(np.uint64), want_fir.view(np.uint64))
+    fir_starts = np.concatenate(([0], np.cumsum(fir_sizes)[:-1]))
+    want_tags = [4 * (s0 + k // 2) for s0, k in zip(fir_starts, fir_sizes) if k]
+    assert np.array_equal(np.fromfile(prefix + ".fir_tag_index.u64", dtype=np.uint64), np.asarray(want_tags, dtype=np.uint64))
+
+
 REFERENCE_ROOT = "/root/reference"
-FLOWGRAPHS = [  # (source under /root/reference, arguments, blocks, edges): the reference's own flowgraph sources
-    ("benchmarks/benchmark_syncword_detection.cpp", ["2", "7.5"], 4, 3),
-    ("benchmarks/benchmark_packet_receiver.cpp", [], 20, 22),
-    ("apps/packet_receiver_file.cpp", ["/dev/null", "3"], 25, 27),
+GXX, CLANGXX = "g++", "/opt/rocm/lib/llvm/bin/clang++"
+# (source under /root/reference, compiler, arguments, blocks, edges, settings calls that need the device): the reference's
+# own flowgraph sources.  The transmit side (packet_transmitter_pdu.hpp, through packet_transceiver.cpp and the
+# transceiver benchmark) uses C++23 constexpr std::vector (packet_transmitter_rrc_taps.hpp:9), which g++ 11 rejects and
+# ROCm's clang accepts against the same libstdc++ -- the compiler oracle/Makefile builds oracle/_ref with.
+FLOWGRAPHS = [
+    ("benchmarks/benchmark_syncword_detection.cpp", GXX, ["2", "7.5"], 4, 3, 0),
+    ("benchmarks/benchmark_packet_receiver.cpp", GXX, [], 20, 22, 3),
+    ("apps/packet_receiver_file.cpp", GXX, ["/dev/null", "3"], 25, 27, 3),
+    # round 6: the other link targets north_star names, and the flowgraphs that use the Rotator / PfbArbResampler /
+    # InterpolatingFirFilter drop-ins (apps/packet_transceiver.cpp:71-75, packet_transmitter_pdu.hpp:288,343)
+    ("apps/packet_receiver_soapy.cpp", GXX, ["100e6"], 25, 27, 3),
+    ("apps/packet_transceiver.cpp", CLANGXX, ["10", "0.01", "1", "0"], 52, 56, 6),
+    ("apps/packet_transceiver.cpp", CLANGXX, ["10", "0.01", "1", "1"], 47, 51, 6),      # stream_mode
+    ("benchmarks/benchmark_packet_transceiver.cpp", CLANGXX, ["0"], 41, 44, 4),
+    ("benchmarks/benchmark_packet_transceiver.cpp", CLANGXX, ["1", "2", "9.5", "1"], 34, 37, 4),
 ]
 
 
-@pytest.mark.parametrize("source,args,n_blocks,n_edges", FLOWGRAPHS)
-def test_reference_flowgraph_sources_compile_and_link_against_the_drop_in_headers(tmp_path, source, args, n_blocks, n_edges):
+_FLOWGRAPH_BINARIES = {}
+
+
+def _flowgraph_binary(source, cxx):
+    """one build per source (the transceivers take a minute each and are run in two modes)"""
+    if source in _FLOWGRAPH_BINARIES:
+        return _FLOWGRAPH_BINARIES[source]
+    if not os.path.exists(os.path.join(ge.PKG_DIR, "libgr4pm_hip.so")):
+        ge.build()
+    import tempfile
+    exe = os.path.join(tempfile.mkdtemp(prefix="gr4pm_flowgraph_"), "flowgraph.bin")
+    subprocess.check_call([cxx, "-std=c++23", "-O1", "-D__HIP_PLATFORM_AMD__",
+                           "-I", os.path.join(ROOT, "tests", "gr4_stub"),       # gnuradio4 stand-in (test-only)
+                           "-I", os.path.join(ge.PKG_DIR, "host"),              # the drop-in headers, first
+                           "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                           "-I", REFERENCE_INCLUDE,                             # everything else: the reference's own
+                           "-o", exe, os.path.join(REFERENCE_ROOT, source), "-L" + ge.PKG_DIR, "-lgr4pm_hip",
+                           "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + ge.PKG_DIR, "-Wl,-rpath,/opt/rocm/lib", "-pthread"])
+    _FLOWGRAPH_BINARIES[source] = exe
+    return exe
+
+
+@pytest.mark.parametrize("source,cxx,args,n_blocks,n_edges,deferred", FLOWGRAPHS)
+def test_reference_flowgraph_sources_compile_and_link_against_the_drop_in_headers(tmp_path, source, cxx, args, n_blocks, n_edges,
+                                                                                 deferred):
     """north_star: "... so the existing apps/packet_receiver_* and benchmark_syncword_detection flowgraphs link against
     them unchanged".  The reference's OWN translation units -- benchmarks/benchmark_syncword_detection.cpp,
-    benchmarks/benchmark_packet_receiver.cpp, apps/packet_receiver_file.cpp, and through them packet_receiver.hpp:34-265
-    -- are compiled unchanged, by path, with gr4-packet-modem_amd/host IN FRONT OF the reference's blocks/include (exactly
+    benchmarks/benchmark_packet_receiver.cpp, apps/packet_receiver_file.cpp, apps/packet_receiver_soapy.cpp (round 6:
+    gr::blocks::soapy::SoapyBlock<c64, 1> and its four settings from the stand-in), apps/packet_transceiver.cpp and
+    benchmarks/benchmark_packet_transceiver.cpp (round 6: the whole transmitter of packet_transmitter_pdu.hpp in front of
+    the receiver, with the PfbArbResampler / Rotator / InterpolatingFirFilter<c64> / InterpolatingFirFilter<Pdu<c64>> /
+    AdditiveScrambler<Pdu<uint8_t>> drop-ins), and through them packet_receiver.hpp:34-265 -- are compiled unchanged, by path, with gr4-packet-modem_amd/host IN FRONT OF the reference's blocks/include (exactly
     INTEGRATION.md's CMake switch) and linked against libgr4pm_hip.so.  Every fg.emplaceBlock<T>({...}) spelling,
     property-map key, fg.connect<"port">(a).to<"port">(b) port name and item type, and pointer member
     (packet_receiver.syncword_detection, .payload_crc_check) then resolves against the HIP classes or the build fails;
@@ -235,20 +332,21 @@ def test_reference_flowgraph_sources_compile_and_link_against_the_drop_in_header
     src = os.path.join(REFERENCE_ROOT, source)
     if not os.path.exists(src):
         pytest.skip("the reference tree is not on this machine")
-    ge.build() if not os.path.exists(os.path.join(ge.PKG_DIR, "libgr4pm_hip.so")) else None
-    exe = str(tmp_path / "flowgraph.bin")
-    subprocess.check_call(["g++", "-std=c++23", "-O1", "-D__HIP_PLATFORM_AMD__",
-                           "-I", os.path.join(ROOT, "tests", "gr4_stub"),       # gnuradio4 stand-in (test-only)
-                           "-I", os.path.join(ge.PKG_DIR, "host"),              # the drop-in headers, first
-                           "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
-                           "-I", REFERENCE_INCLUDE,                             # everything else: the reference's own
-                           "-o", exe, src, "-L" + ge.PKG_DIR, "-lgr4pm_hip", "-L/opt/rocm/lib", "-lamdhip64",
-                           "-Wl,-rpath," + ge.PKG_DIR, "-Wl,-rpath,/opt/rocm/lib", "-pthread"])
+    exe = _flowgraph_binary(source, cxx)
     syms = subprocess.run(["nm", "-C", exe], capture_output=True, text=True, check=True).stdout
     assert "gr::packet_modem::hip::SyncwordDetection" in syms           # the HIP class is the one instantiated
     assert " U gr4pm_syncword_detection_create" in syms                 # ... and it calls the C ABI of the library
     assert "gr::packet_modem::SyncwordDetection::" not in syms          # the reference's detector is not in the binary
-    if "packet_receiver" in source:
+    if "transceiver" in source:  # "nm shows hip::PfbArbResampler / hip::Rotator in the transceiver"
+        for cls in ("InterpolatingFirFilter<std::complex<float>, std::complex<float>, float>",
+                    "InterpolatingFirFilter<gr::packet_modem::Pdu<std::complex<float>", "AdditiveScrambler<gr::packet_modem::Pdu<unsigned char>"):
+            assert f"gr::packet_modem::hip::{cls}" in syms, cls
+        if "apps/" in source:
+            assert "gr::packet_modem::hip::PfbArbResampler<std::complex<float>, std::complex<float>, float, float>" in syms
+            assert "gr::packet_modem::hip::Rotator<float>" in syms
+        for ref_cls in ("InterpolatingFirFilter<", "AdditiveScrambler<", "PfbArbResampler<", "Rotator<"):
+            assert f"gr::packet_modem::{ref_cls}" not in syms, ref_cls  # none of the reference's own forms was instantiated
+    if "packet_receiver" in source or "transceiver" in source:
         for cls in ("SyncwordDetectionFilter", "CoarseFrequencyCorrection", "SymbolFilter", "SyncwordWipeoff",
                     "PayloadMetadataInsert", "CostasLoop", "SyncwordRemove", "ConstellationLLRDecoder", "AdditiveScrambler",
                     "HeaderPayloadSplit", "HeaderFecDecoder"):
@@ -257,10 +355,9 @@ def test_reference_flowgraph_sources_compile_and_link_against_the_drop_in_header
         assert "gr::packet_modem::CrcCheck<" in syms and "gr::packet_modem::HeaderParser<" in syms  # the reference's own
     r = subprocess.run([exe] + args, capture_output=True, text=True, env=dict(os.environ, GR4_STUB_LIFECYCLE="0"))
     assert r.returncode == 1, r.stdout + r.stderr
-    deferred = 0 if "syncword_detection" in source else 3
     assert (f"{n_blocks} blocks, {n_edges} edges, lifecycle skipped, {deferred} settings calls deferred" in r.stdout + r.stderr), \
         r.stdout + r.stderr
-    if "packet_receiver" in source:  # without the switch: the first device-needing call says that there is no CPU path
+    if "syncword_detection" not in source:  # without the switch: the first device-needing call says that there is no CPU path
         r = subprocess.run([exe] + args, capture_output=True, text=True)
         assert r.returncode != 0 and "no HIP device" in r.stderr and "no CPU fallback" in r.stderr
 
