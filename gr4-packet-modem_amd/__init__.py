@@ -9,7 +9,7 @@ import numpy as np
 
 from ._abi import (EXPORTS, LIB_PATH, PACKET_TAG_DTYPE, PKT_HEADER_START, PKT_PAYLOAD, PKT_SYNCWORD,  # noqa: F401
                    TAG_DTYPE, TAG_OTHER, TAG_SYNCWORD, Gr4pmError, lib)
-from .blocks import (SYNCWORD, AdditiveScrambler, BurstGenerator, CrcCheck, burst_shaper, mapper, binary_slicer, pack_bits, slice_pack, CoarseFrequencyCorrection, ConstellationLLRDecoder,  # noqa: F401
+from .blocks import (SYNCWORD, ZmqPduPubSink, AdditiveScrambler, BurstGenerator, CrcCheck, burst_shaper, mapper, binary_slicer, pack_bits, slice_pack, CoarseFrequencyCorrection, ConstellationLLRDecoder,  # noqa: F401
                      CostasLoop, HeaderDecoder, HeaderFecDecoder, HeaderPayloadSplit, InterpolatingFirFilter, MultiChannelPacketReceiver, NativeMultiChannelReceiver, NativePacketReceiver, PacketReceiver,
                      PayloadMetadataInsert, PfbArbResampler, Rotator, SymbolFilter, SyncwordDetection,
                      SyncwordDetectionFilter, SyncwordRemove, SyncwordWipeoff, cfc_symbol_filter, cfc_symbol_filter_plan, cfc_symbol_filter_run,

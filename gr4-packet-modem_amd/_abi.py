@@ -186,6 +186,13 @@ class PfbArbParams(C.Structure):
 EXPORTS = [
     "gr4pm_last_error", "gr4pm_version", "gr4pm_device_count", "gr4pm_set_deferred_sync", "gr4pm_sincosf", "gr4pm_costas_phase_wrap",
     "gr4pm_packet_receiver_set_symbol_pdu_callback",
+    "gr4pm_packet_receiver_publish_symbol_pdus",
+    "gr4pm_zmq_pub_create",
+    "gr4pm_zmq_pub_destroy",
+    "gr4pm_zmq_pub_send",
+    "gr4pm_zmq_pub_port",
+    "gr4pm_zmq_pub_subscribers",
+    "gr4pm_zmq_pub_dropped",
     "gr4pm_syncword_detection_create", "gr4pm_syncword_detection_destroy",
     "gr4pm_syncword_detection_reset", "gr4pm_syncword_detection_syncword_samples_size",
     "gr4pm_syncword_detection_self_corr", "gr4pm_syncword_detection_items_consumed", "gr4pm_syncword_detection_scan_counts",
@@ -392,6 +399,17 @@ def lib():
     L.gr4pm_packet_receiver_collect.argtypes = [vp, C.POINTER(PacketReceiverResult)]
     L.gr4pm_packet_receiver_inflight.argtypes = [vp]
     L.gr4pm_packet_receiver_set_symbol_pdu_callback.argtypes = [vp, vp, vp]
+    L.gr4pm_packet_receiver_publish_symbol_pdus.argtypes = [vp, C.c_char_p, C.c_char_p, vp]
+    L.gr4pm_zmq_pub_create.argtypes = [C.c_char_p, vp]
+    L.gr4pm_zmq_pub_destroy.argtypes = [vp]
+    L.gr4pm_zmq_pub_destroy.restype = None
+    L.gr4pm_zmq_pub_send.argtypes = [vp, vp, C.c_size_t]
+    L.gr4pm_zmq_pub_port.argtypes = [vp]
+    L.gr4pm_zmq_pub_port.restype = C.c_int
+    L.gr4pm_zmq_pub_subscribers.argtypes = [vp]
+    L.gr4pm_zmq_pub_subscribers.restype = C.c_size_t
+    L.gr4pm_zmq_pub_dropped.argtypes = [vp]
+    L.gr4pm_zmq_pub_dropped.restype = C.c_uint64
     L.gr4pm_packet_receiver_inflight.restype = sz
     L.gr4pm_sincosf.argtypes = [vp, sz, vp, vp]
     L.gr4pm_costas_phase_wrap.argtypes = [vp, sz, vp]

@@ -1775,6 +1775,18 @@ class NativePacketReceiver:
         self._pdu_cb = _abi.SYMBOL_PDU_FN(tramp)  # keep the trampoline alive
         check(lib().gr4pm_packet_receiver_set_symbol_pdu_callback(self._h, self._pdu_cb, None), "set_symbol_pdu_callback")
 
+    def publish_symbol_pdus(self, header_endpoint="tcp://*:5000", payload_endpoint="tcp://*:5001"):
+        """`zmq_output` of packet_receiver.hpp:159-189: collect() publishes every complete header PDU (128 symbols) on
+        header_endpoint and every payload PDU on payload_endpoint, one ZeroMQ message of raw complex64 each
+        (zmq_pdu_pub_sink.hpp:31-41; the library speaks ZMTP 3.0 itself).  Returns the two bound TCP ports;
+        (None, None) stops publishing."""
+        self._pdu_cb = None
+        ports = (C.c_int * 2)(0, 0)
+        enc = lambda e: None if e is None else e.encode()
+        check(lib().gr4pm_packet_receiver_publish_symbol_pdus(self._h, enc(header_endpoint), enc(payload_endpoint), ports),
+              "publish_symbol_pdus")
+        return int(ports[0]), int(ports[1])
+
     def process_bulk(self, x, header_fn=None, tags_cap=None, history=None, next_x=None):
         """same calling convention as PacketReceiver.process_bulk (header_fn: None or a constant
         packet_length); pipelined: returns the result of an earlier batch, None while filling"""
@@ -1795,5 +1807,43 @@ class NativePacketReceiver:
             if getattr(self, "_h", None):
                 _release("gr4pm_packet_receiver_destroy", self._h)
                 self._h = None
+        except Exception:  # interpreter shutdown
+            pass
+
+
+class ZmqPduPubSink:
+    """zmq_pdu_pub_sink.hpp:11-44: a ZeroMQ PUB socket bound to `endpoint`, one message per PDU holding its raw items
+    (gr4pm_zmq_pub_*: ZMTP 3.0 in the library, no libzmq; host only -- works without a GPU)"""
+
+    def __init__(self, endpoint="tcp://*:5555"):
+        h = C.c_void_p()
+        check(lib().gr4pm_zmq_pub_create(endpoint.encode(), C.byref(h)), "ZmqPduPubSink")
+        self._h = h
+
+    @property
+    def port(self):
+        return int(lib().gr4pm_zmq_pub_port(self._h))
+
+    @property
+    def subscribers(self):
+        return int(lib().gr4pm_zmq_pub_subscribers(self._h))
+
+    @property
+    def dropped(self):
+        return int(lib().gr4pm_zmq_pub_dropped(self._h))
+
+    def process_one(self, data):
+        """data: the PDU's items (any contiguous numpy array or bytes)"""
+        buf = np.ascontiguousarray(data) if not isinstance(data, (bytes, bytearray)) else np.frombuffer(bytes(data), dtype=np.uint8)
+        check(lib().gr4pm_zmq_pub_send(self._h, buf.ctypes.data_as(C.c_void_p), buf.nbytes), "ZmqPduPubSink.process_one")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().gr4pm_zmq_pub_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
         except Exception:  # interpreter shutdown
             pass

@@ -229,6 +229,7 @@ struct gr4pm_packet_receiver {
     } tap;
     gr4pm_symbol_pdu_fn pdu_fn = nullptr;
     void* pdu_user = nullptr;
+    gr4pm_zmq_pub* pdu_pub[2] = { nullptr, nullptr }; // gr4pm_packet_receiver_publish_symbol_pdus: headers, payloads
     std::vector<gr4pm_c64> pdu_host, pdu_acc[2];
     bool pdu_open[2] = { false, false }; // the sink has seen the first piece of the PDU it is collecting
     gr4pm_status split_symbol_pdus(Slot& s, size_t n_data, size_t n_dt);
@@ -1246,6 +1247,7 @@ try {
     h->a_loop.destroy();
     h->b_loop.destroy();
     gr4pm_crc_check_destroy(h->crc);
+    for (auto pub : h->pdu_pub) gr4pm_zmq_pub_destroy(pub);
     for (auto s : h->streams)
         if (s) (void)hipStreamDestroy(s);
     delete h;
@@ -1430,6 +1432,43 @@ try {
     }
     h->pdu_fn = fn;
     h->pdu_user = user;
+    for (auto& pub : h->pdu_pub) { // the library's own sink (below) gives way to the caller's
+        gr4pm_zmq_pub_destroy(pub);
+        pub = nullptr;
+    }
+    return GR4PM_OK;
+}
+GR4PM_ABI_CATCH
+
+// zmq_pdu_pub_sink.hpp:31-41 behind the tap: kind 0 -> the header endpoint, 1 -> the payload endpoint
+static void publish_symbol_pdu(void* user, int kind, const gr4pm_c64* symbols, size_t n)
+{
+    auto* h = static_cast<gr4pm_packet_receiver*>(user);
+    if (kind >= 0 && kind < 2 && h->pdu_pub[kind]) (void)gr4pm_zmq_pub_send(h->pdu_pub[kind], symbols, n * sizeof(gr4pm_c64));
+}
+
+gr4pm_status gr4pm_packet_receiver_publish_symbol_pdus(gr4pm_packet_receiver* h, const char* header_endpoint,
+                                                       const char* payload_endpoint, int ports[2])
+try {
+    if (!h || (header_endpoint == nullptr) != (payload_endpoint == nullptr)) return GR4PM_ERR_INVALID;
+    GR4PM_TRY(gr4pm_packet_receiver_set_symbol_pdu_callback(h, nullptr, nullptr)); // (closes endpoints bound before)
+    if (!header_endpoint) return GR4PM_OK;
+    if (!h->p.soft_bits) {
+        set_error("the symbol PDU tap hangs off SyncwordRemove: soft_bits receivers only");
+        return GR4PM_ERR_INVALID;
+    }
+    gr4pm_zmq_pub* pubs[2] = { nullptr, nullptr };
+    gr4pm_status st = gr4pm_zmq_pub_create(header_endpoint, &pubs[0]);
+    if (st == GR4PM_OK) st = gr4pm_zmq_pub_create(payload_endpoint, &pubs[1]);
+    if (st != GR4PM_OK) {
+        gr4pm_zmq_pub_destroy(pubs[0]);
+        gr4pm_zmq_pub_destroy(pubs[1]);
+        return st;
+    }
+    h->pdu_pub[0] = pubs[0], h->pdu_pub[1] = pubs[1];
+    h->pdu_fn = publish_symbol_pdu;
+    h->pdu_user = h;
+    if (ports) ports[0] = gr4pm_zmq_pub_port(pubs[0]), ports[1] = gr4pm_zmq_pub_port(pubs[1]);
     return GR4PM_OK;
 }
 GR4PM_ABI_CATCH

@@ -65,6 +65,13 @@
 #define GR4PM_TRACE_EXIT(consumed, published) ((void)0)
 #endif
 
+namespace gr::packet_modem {
+// pdu.hpp:15-21 (the reference's own header defines it; the drop-in of zmq_pdu_pub_sink.hpp includes that when it is on
+// the include path).  Only named here: ZmqPduPubSink<T>'s port carries Pdu<T>.
+template <typename T>
+struct Pdu;
+} // namespace gr::packet_modem
+
 namespace gr::packet_modem::hip {
 
 namespace detail {
@@ -1420,6 +1427,42 @@ public:
     }
 };
 
+// ---------------------------------------------------------------- ZmqPduPubSink
+// replaces gr::packet_modem::ZmqPduPubSink<T> (zmq_pdu_pub_sink.hpp:11-44), the sink of PacketReceiver's symbol tap
+// (packet_receiver.hpp:163-168: endpoints tcp://*:5000 / :5001).  The socket is the library's own ZMTP 3.0 PUB endpoint
+// (gr4pm_zmq_pub_*): no cppzmq, no libzmq; a zmq.SUB peer (scripts/plot_symbols.py) connects as to the reference's.
+template <typename T>
+class ZmqPduPubSink : public gr::Block<ZmqPduPubSink<T>>
+{
+    gr4pm_zmq_pub* _h = nullptr;
+
+public:
+    gr::PortIn<gr::packet_modem::Pdu<T>> in;
+    std::string endpoint = "tcp://*:5555"; // :26
+
+    ZmqPduPubSink() = default;
+    ZmqPduPubSink(const ZmqPduPubSink&) = delete;
+    ~ZmqPduPubSink() { gr4pm_zmq_pub_destroy(_h); }
+    void start() // :29 _socket.bind(endpoint)
+    {
+        gr4pm_zmq_pub_destroy(_h);
+        _h = nullptr;
+        detail::check(gr4pm_zmq_pub_create(endpoint.c_str(), &_h), "ZmqPduPubSink::start");
+    }
+    void stop()
+    {
+        gr4pm_zmq_pub_destroy(_h);
+        _h = nullptr;
+    }
+    int port() const { return gr4pm_zmq_pub_port(_h); }                 // the bound port (endpoint "tcp://...:*")
+    size_t subscribers() const { return gr4pm_zmq_pub_subscribers(_h); }
+    void processOne(const gr::packet_modem::Pdu<T>& a) // :31-41: one message, the PDU's raw items
+    {
+        if (!_h) start();
+        detail::check(gr4pm_zmq_pub_send(_h, a.data.data(), a.data.size() * sizeof(T)), "ZmqPduPubSink::processOne");
+    }
+};
+
 // ---------------------------------------------------------------- HeaderPayloadSplit
 // replaces gr::packet_modem::HeaderPayloadSplit<T = float> (header_payload_split.hpp:9-147): T = float is the header
 // loop's split (packet_receiver.hpp:136-137), T = std::complex<float> the symbol tap's (zmq_output, :159-162)
@@ -1609,3 +1652,4 @@ ENABLE_REFLECTION_FOR_TEMPLATE(gr::packet_modem::hip::AdditiveScrambler, in, out
 ENABLE_REFLECTION_FOR_TEMPLATE(gr::packet_modem::hip::HeaderPayloadSplit, in, header, payload, header_size,
                                packet_len_tag_key, payload_length_key);
 ENABLE_REFLECTION(gr::packet_modem::hip::HeaderFecDecoder, in, out);
+ENABLE_REFLECTION_FOR_TEMPLATE(gr::packet_modem::hip::ZmqPduPubSink, in, endpoint);

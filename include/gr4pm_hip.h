@@ -656,7 +656,7 @@ gr4pm_status gr4pm_crc_check_process(gr4pm_crc_check* h, const uint8_t* in, cons
  * ("payload_symbols" symbols behind a parsed header); a PDU that crosses a batch boundary appears as a piece with
  * `last == 0` and continues in the next batch with `first == 0`.  With a callback registered, collect() copies the
  * batch's symbols to the host once and calls it once per COMPLETE PDU, in stream order, from the collecting thread:
- * the place where a caller publishes them (INTEGRATION.md shows the ZeroMQ binding; libzmq is not in this image). */
+ * the place where a caller publishes them (gr4pm_packet_receiver_publish_symbol_pdus below does: ZMTP 3.0, no libzmq). */
 typedef struct {
     uint64_t offset;  /* first symbol of the piece inside pdu_symbols */
     uint64_t length;  /* symbols of the piece in this batch */
@@ -747,6 +747,31 @@ gr4pm_status gr4pm_packet_receiver_collect(gr4pm_packet_receiver* h, gr4pm_packe
 size_t gr4pm_packet_receiver_inflight(const gr4pm_packet_receiver* h);
 /* soft_bits receivers: fn == NULL removes the callback */
 gr4pm_status gr4pm_packet_receiver_set_symbol_pdu_callback(gr4pm_packet_receiver* h, gr4pm_symbol_pdu_fn fn, void* user);
+
+/* ------------------------------------------------------------------------------------
+ * ZmqPduPubSink<T> -- zmq_pdu_pub_sink.hpp:11-44: a ZeroMQ PUB socket, one message per PDU holding its raw items.
+ * The library speaks ZMTP 3.0 (NULL mechanism) itself -- greeting, READY, the subscriptions a SUB peer sends, one
+ * single-frame message per send, PUB drop semantics (no subscriber / a peer whose queue holds 1000 messages) -- so a
+ * zmq.SUB socket (scripts/plot_symbols.py:10-17) connects to it as to the reference's; libzmq is not needed.
+ * Host only: works without a HIP device.
+ * ---------------------------------------------------------------------------------- */
+typedef struct gr4pm_zmq_pub gr4pm_zmq_pub;
+/* endpoint (:26): tcp://HOST:PORT as ZeroMQ spells it -- HOST an IPv4 address or a star (every interface), PORT a
+ * number, or a star / 0 for an ephemeral port (gr4pm_zmq_pub_port); the reference's default is port 5555 on every interface.
+ * = start(): socket.bind(endpoint) (:29) */
+gr4pm_status gr4pm_zmq_pub_create(const char* endpoint, gr4pm_zmq_pub** out);
+void gr4pm_zmq_pub_destroy(gr4pm_zmq_pub* h); /* queued messages get 200 ms to leave */
+/* processOne() (:31-41): data = a PDU's items (host), one message; never blocks on a peer */
+gr4pm_status gr4pm_zmq_pub_send(gr4pm_zmq_pub* h, const void* data, size_t bytes);
+int gr4pm_zmq_pub_port(const gr4pm_zmq_pub* h);           /* the bound TCP port */
+size_t gr4pm_zmq_pub_subscribers(const gr4pm_zmq_pub* h); /* connected peers holding a subscription */
+uint64_t gr4pm_zmq_pub_dropped(const gr4pm_zmq_pub* h);   /* messages a subscribed peer did not get: its queue was full */
+/* packet_receiver.hpp:159-189 (`zmq_output`) in one call: header PDUs to header_endpoint (port 5000 on every interface, :166),
+ * payload PDUs to payload_endpoint (port 5001, :168), published by collect() (it takes the place of a callback set
+ * with gr4pm_packet_receiver_set_symbol_pdu_callback, and is removed by one).  NULL, NULL stops publishing.  `ports`
+ * (may be NULL): the two bound TCP ports. */
+gr4pm_status gr4pm_packet_receiver_publish_symbol_pdus(gr4pm_packet_receiver* h, const char* header_endpoint,
+                                                       const char* payload_endpoint, int ports[2]);
 
 /* gr4pm_multichannel_receiver: BASELINE configs[2] -- n_channels independent receive chains on one
  * GPU (front-end mode of gr4pm_packet_receiver, channel by channel).  One batched

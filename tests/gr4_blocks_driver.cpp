@@ -22,6 +22,9 @@
 //        gr4_blocks_driver blocks <in.c64> <out_prefix>      (Rotator, InterpolatingFirFilter, PfbArbResampler)
 //        gr4_blocks_driver floats <in.f32> <out_prefix>      (test/qa_symbol_filter.cpp:17-63: InterpolatingFirFilter<float,
 //            float, float> -> SymbolFilter<float, float, float>; writes .fir.f32 / .sym.f32)
+//        gr4_blocks_driver zmq <n_pdus>                      (ZmqPduPubSink<c64> on an ephemeral port, printed first; waits
+//            for a subscriber, then publishes n_pdus PDUs through processOne(): PDU k holds 128 (k % 3 == 0) or 100 + 37 k
+//            symbols (k, i))
 //        gr4_blocks_driver pdus <bits.u8> <symbols.c64> <out_prefix>   (the PDU forms of packet_transmitter_pdu.hpp:119,288:
 //            AdditiveScrambler<Pdu<uint8_t>> and InterpolatingFirFilter<Pdu<c64>, Pdu<c64>, float> through processOne()
 //            on PDUs of ragged sizes; writes .scr.u8 / .fir.c64 / .scr_sizes.u64 / .fir_sizes.u64 / .fir_tag_index.u64)
@@ -43,6 +46,18 @@
 #include <gnuradio-4.0/packet-modem/header_payload_split.hpp>
 #include <gnuradio-4.0/packet-modem/payload_metadata_insert.hpp>
 #include <gnuradio-4.0/packet-modem/syncword_remove.hpp>
+// the sink of the symbol tap (packet_receiver.hpp:163-168), `zmq` mode
+#include <gnuradio-4.0/packet-modem/zmq_pdu_pub_sink.hpp>
+#if !__has_include(<gnuradio-4.0/packet-modem/pdu.hpp>)
+namespace gr::packet_modem { // pdu.hpp:15-21 by shape (the reference's header is not on this include path)
+template <typename T>
+struct Pdu {
+    using value_type = T;
+    std::vector<T> data{};
+    std::vector<gr::Tag> tags{};
+};
+} // namespace gr::packet_modem
+#endif
 
 #include "gr4_mini_scheduler.hpp"
 
@@ -425,6 +440,29 @@ static int pdus(int argc, char** argv)
     return 0;
 }
 
+// ZmqPduPubSink<c64> as PacketReceiver wires it (packet_receiver.hpp:163-168), on an ephemeral port
+static int zmq_mode(int argc, char** argv)
+{
+    if (argc < 3) return 2;
+    const int n_pdus = std::atoi(argv[2]);
+    gr::stub::Graph fg;
+    auto& sink = fg.emplaceBlock<ZmqPduPubSink<c64>>({ { "endpoint", "tcp://127.0.0.1:*" } });
+    sink.start();
+    std::printf("port %d\n", sink.port());
+    std::fflush(stdout);
+    for (int i = 0; i < 5000 && sink.subscribers() == 0; ++i) std::this_thread::sleep_for(std::chrono::milliseconds(2));
+    if (sink.subscribers() == 0) throw std::runtime_error("no subscriber came");
+    for (int k = 0; k < n_pdus; ++k) {
+        gr::packet_modem::Pdu<c64> pdu;
+        pdu.data.resize(k % 3 == 0 ? 128 : 100 + 37 * static_cast<size_t>(k));
+        for (size_t i = 0; i < pdu.data.size(); ++i) pdu.data[i] = c64(static_cast<float>(k), static_cast<float>(i));
+        sink.processOne(pdu);
+    }
+    sink.stop(); // (what is queued gets its linger time)
+    std::printf("published %d\n", n_pdus);
+    return 0;
+}
+
 // A double-mapped ring between two wrapped blocks with host_output = false (gnuradio4's CircularBuffer maps its storage
 // twice, back to back): the producer's spans run past the end of the first mapping, the consumer -- reading in smaller
 // chunks -- sees the items behind the wrap at addresses one ring size lower.  The host memory of the ring is never
@@ -595,6 +633,7 @@ int main(int argc, char** argv)
         if (argc >= 2 && std::strcmp(argv[1], "blocks") == 0) return blocks(argc, argv);
         if (argc >= 2 && std::strcmp(argv[1], "floats") == 0) return floats(argc, argv);
         if (argc >= 2 && std::strcmp(argv[1], "pdus") == 0) return pdus(argc, argv);
+        if (argc >= 2 && std::strcmp(argv[1], "zmq") == 0) return zmq_mode(argc, argv);
         if (argc >= 2 && std::strcmp(argv[1], "mirror") == 0) return mirror(argc, argv);
         if (argc >= 2 && std::strcmp(argv[1], "threads") == 0) return threads(argc, argv);
         std::fprintf(stderr, "usage: %s chain|receiver|blocks|mirror|threads ...\n", argv[0]);

@@ -23,6 +23,7 @@
 #include "hostlogic/sdf_gate.hpp"
 #include "hostlogic/slot_queue.hpp"
 #include "hostlogic/symbol_filter_replay.hpp"
+#include "hostlogic/zmtp_pub.hpp"
 
 namespace gr4pm {
 static thread_local char g_error[512];
@@ -512,6 +513,121 @@ static void slot_pipeline(std::mt19937_64& rng)
     CHECK(!small.push(99) && small.pop() == 0, "a full ring must refuse");
 }
 
+// ---------------------------------------------------------------- the ZeroMQ PUB endpoint (hostlogic/zmtp_pub.hpp)
+// A hand-written SUB peer over a blocking socket: greeting, READY, one subscription, then frames
+struct RawSub {
+    int fd = -1;
+    bool open(int port)
+    {
+        fd = ::socket(AF_INET, SOCK_STREAM, 0);
+        sockaddr_in a{};
+        a.sin_family = AF_INET;
+        a.sin_port = htons(static_cast<uint16_t>(port));
+        a.sin_addr.s_addr = htonl(INADDR_LOOPBACK);
+        timeval tv{ 5, 0 };
+        (void)::setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+        return ::connect(fd, reinterpret_cast<sockaddr*>(&a), sizeof a) == 0;
+    }
+    bool rd(void* p, size_t n)
+    {
+        uint8_t* b = static_cast<uint8_t*>(p);
+        while (n) {
+            const ssize_t k = ::recv(fd, b, n, 0);
+            if (k <= 0) return false;
+            b += k, n -= static_cast<size_t>(k);
+        }
+        return true;
+    }
+    bool wr(const void* p, size_t n) { return ::send(fd, p, n, MSG_NOSIGNAL) == static_cast<ssize_t>(n); }
+    bool handshake(const std::vector<uint8_t>& topic)
+    {
+        uint8_t g[64] = { 0xFF, 0, 0, 0, 0, 0, 0, 0, 1, 0x7F, 3, 0, 'N', 'U', 'L', 'L' };
+        uint8_t peer[64], hdr[2], body[256];
+        static const char ready[] = "\x04\x19\x05READY\x0BSocket-Type\x00\x00\x00\x03SUB";
+        if (!wr(g, 64) || !rd(peer, 64) || !wr(ready, sizeof ready - 1) || !rd(hdr, 2) || !rd(body, hdr[1])) return false;
+        const auto want_g = ZmtpPub::greeting();
+        const auto want_r = ZmtpPub::ready();
+        CHECK(std::memcmp(peer, want_g.data(), 64) == 0, "greeting");
+        CHECK(hdr[0] == 4 && hdr[1] == want_r.size() - 2 && std::memcmp(body, want_r.data() + 2, hdr[1]) == 0, "READY");
+        std::vector<uint8_t> sub{ 0, static_cast<uint8_t>(1 + topic.size()), 1 };
+        sub.insert(sub.end(), topic.begin(), topic.end());
+        return wr(sub.data(), sub.size());
+    }
+    bool message(std::vector<uint8_t>& out)
+    {
+        uint8_t flags, l1;
+        if (!rd(&flags, 1)) return false;
+        uint64_t len = 0;
+        if (flags & 2) {
+            uint8_t l8[8];
+            if (!rd(l8, 8)) return false;
+            for (uint8_t b : l8) len = (len << 8) | b;
+        } else {
+            if (!rd(&l1, 1)) return false;
+            len = l1;
+        }
+        out.resize(len);
+        return len == 0 || rd(out.data(), len);
+    }
+    ~RawSub()
+    {
+        if (fd >= 0) ::close(fd);
+    }
+};
+static void zmtp_pub(std::mt19937_64& rng)
+{
+    ZmtpPub pub;
+    CHECK(pub.bind("udp://127.0.0.1:1") != GR4PM_OK && pub.bind("tcp://nowhere:1") != GR4PM_OK, "bad endpoints must be refused");
+    CHECK(pub.send("x", 1) != GR4PM_OK, "send before bind");
+    CHECK(pub.bind("tcp://127.0.0.1:*") == GR4PM_OK && pub.port() > 0, "bind");
+    CHECK(pub.send("nobody", 6) == GR4PM_OK && pub.dropped() == 0, "no subscriber: dropped silently, as a PUB socket does");
+    const int n_msgs = 300;
+    std::vector<std::vector<uint8_t>> msgs(n_msgs);
+    for (auto& m : msgs) {
+        m.resize(rng() % 3 ? rng() % 200 : 256 + rng() % 70000); // short and long frames
+        for (auto& b : m) b = static_cast<uint8_t>(rng());
+        if (!m.empty()) m[0] = static_cast<uint8_t>(rng() % 2 ? 'A' : 'B');
+    }
+    // three subscribers in threads of their own: everything / topic "A" / one that connects, subscribes and never reads
+    std::atomic<int> ready{ 0 };
+    auto reader = [&](std::vector<uint8_t> topic, std::vector<std::vector<uint8_t>>* got) {
+        RawSub s;
+        CHECK(s.open(pub.port()) && s.handshake(topic), "subscriber handshake");
+        ready.fetch_add(1);
+        if (!got) {
+            std::this_thread::sleep_for(std::chrono::milliseconds(300));
+            return;
+        }
+        std::vector<uint8_t> m;
+        while (s.message(m)) {
+            if (m.size() == 3 && std::memcmp(m.data(), "END", 3) == 0) break;
+            got->push_back(m);
+        }
+    };
+    std::vector<std::vector<uint8_t>> got_all, got_a;
+    std::thread t_all(reader, std::vector<uint8_t>{}, &got_all), t_a(reader, std::vector<uint8_t>{ 'A' }, &got_a),
+        t_mute(reader, std::vector<uint8_t>{}, nullptr);
+    { // a peer that is no ZMTP peer at all
+        RawSub junk;
+        CHECK(junk.open(pub.port()) && junk.wr("GET / HTTP/1.0\r\n\r\n", 18), "junk peer");
+    }
+    for (int i = 0; i < 500 && (ready.load() < 3 || pub.subscribers() < 3); ++i) std::this_thread::sleep_for(std::chrono::milliseconds(2));
+    CHECK(pub.subscribers() == 3, "%zu subscribers", pub.subscribers());
+    for (const auto& m : msgs) CHECK(pub.send(m.data(), m.size()) == GR4PM_OK, "send");
+    CHECK(pub.send("END", 3) == GR4PM_OK && pub.send("AEND", 4) == GR4PM_OK, "send");
+    t_all.join();
+    std::vector<std::vector<uint8_t>> want_a;
+    for (const auto& m : msgs)
+        if (!m.empty() && m[0] == 'A') want_a.push_back(m);
+    CHECK(got_all == msgs, "the subscriber of everything got %zu of %d messages", got_all.size(), n_msgs);
+    // (the topic-A subscriber never sees "END": its stream ends with "AEND", or with the endpoint closing)
+    t_mute.join();
+    pub.close(500);
+    t_a.join();
+    if (!got_a.empty() && got_a.back() == std::vector<uint8_t>{ 'A', 'E', 'N', 'D' }) got_a.pop_back();
+    CHECK(got_a == want_a, "the subscriber of topic A got %zu messages, expected %zu", got_a.size(), want_a.size());
+}
+
 int main(int argc, char** argv)
 {
     const int cases = argc > 1 ? atoi(argv[1]) : 20;
@@ -524,6 +640,7 @@ int main(int argc, char** argv)
         control_blocks(rng);
     }
     for (int c = 0; c < std::max(2, cases / 5); ++c) slot_pipeline(rng);
+    for (int c = 0; c < std::max(2, cases / 10); ++c) zmtp_pub(rng);
     printf("hostlogic_san: %d cases, seed %llu: %d failures\n", cases, seed, g_failures);
     return g_failures ? 1 : 0;
 }

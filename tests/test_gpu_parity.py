@@ -5,6 +5,7 @@ Bars: indices / freq_bin / pass-through / FIR outputs bit-exact; FFT-derived flo
 values within 1e-4 relative (FFTW's own bits are unpinned, see oracle/gr4pm_oracle.h);
 recurrences (rotator, CFC) bit-exact; Costas bit-exact too (the device restates glibc's sinf / cosf)."""
 import os
+import time
 
 import numpy as np
 import pytest
@@ -2668,6 +2669,58 @@ def test_native_packet_receiver_symbol_pdu_tap(pkg):
     nat.set_symbol_pdu_callback(None)
     with pytest.raises(pkg.Gr4pmError, match="soft_bits"):
         pkg.NativePacketReceiver(max_items=n).set_symbol_pdu_callback(lambda k, s: None)
+
+
+def test_native_packet_receiver_publishes_symbol_pdus_on_zmq_pub_sockets(pkg):
+    """SURVEY 8(f) rank 4, the wire format of the symbol tap: packet_receiver.hpp:163-168 binds two ZmqPduPubSink<c64>
+    (tcp port 5000: header PDUs, 5001: payload PDUs), scripts/plot_symbols.py:10-17 subscribes and reads every message
+    as complex64.  gr4pm_packet_receiver_publish_symbol_pdus does that on the library's own ZMTP 3.0 endpoints
+    (ephemeral ports here): two SUB peers written on plain sockets (tests/test_zmq_pub.py) receive header PDUs of 128
+    symbols and payload PDUs of `payload_symbols` symbols, bit for bit the PDUs the receiver lists in its result spans,
+    PDUs that cross a batch boundary included."""
+    from test_zmq_pub import RawSub, wait_for
+    H, n = 1537, 40000
+    payload_len = 120
+    x, _, _ = _tx_packets(np.random.default_rng(5), [payload_len] * 9, [300, 500, 420, 610, 350, 800, 333, 450, 700])
+    x = np.concatenate([x, np.zeros(3 * n, np.complex64)])[: 3 * n]
+    x = (x + sig.awgn(x.size, 0.05, 9)).astype(np.complex64)
+    ring = torch.zeros(2 + H + 3 * n, dtype=torch.complex64, device="cuda")
+    ring[2 + H:] = dev(x)
+    nat = pkg.NativePacketReceiver(max_items=n, pipelined=True, soft_bits=True)
+    hdr_port, pay_port = nat.publish_symbol_pdus("tcp://127.0.0.1:*", "tcp://127.0.0.1:*")
+    assert hdr_port > 0 and pay_port > 0 and hdr_port != pay_port
+    subs = [RawSub(hdr_port), RawSub(pay_port)]
+    time.sleep(0.2)  # (subscriptions are in before the first PDU: a PUB socket does not keep messages for late joiners)
+    got = []
+    for k in range(3):
+        lo = 2 + H + k * n
+        r = nat.process_bulk(ring[lo:lo + n], payload_len, history=ring[lo - H:lo])
+        if r is not None:
+            got.append(r)
+    got += nat.flush()
+    listed, acc = {0: [], 1: []}, {0: [], 1: []}
+    for r in got:
+        sym = host(r["pdu_symbols"])
+        for p in r["symbol_pdus"]:
+            k = int(p["kind"])
+            if p["first"]:
+                acc[k] = []
+            acc[k].append(sym[int(p["offset"]):int(p["offset"] + p["length"])])
+            if p["last"]:
+                listed[k].append(np.concatenate(acc[k]))
+    assert len(listed[0]) >= 8 and len(listed[1]) >= 8
+    for kind in (0, 1):
+        for want in listed[kind]:
+            z = np.frombuffer(subs[kind].message(), "complex64")  # plot_symbols.py:17
+            assert z.size == (128 if kind == 0 else (payload_len + 4) * 4)
+            assert np.array_equal(bits(z), bits(want))
+    nat.publish_symbol_pdus(None, None)  # the endpoints close: the peers see the end of their streams
+    for s in subs:
+        with pytest.raises((EOFError, ConnectionError)):
+            s.message()
+        s.close()
+    with pytest.raises(pkg.Gr4pmError, match="soft_bits"):
+        pkg.NativePacketReceiver(max_items=n).publish_symbol_pdus("tcp://127.0.0.1:*", "tcp://127.0.0.1:*")
 
 
 @pytest.mark.parametrize("soft_bits", [False, True])

@@ -352,6 +352,9 @@ def test_reference_flowgraph_sources_compile_and_link_against_the_drop_in_header
                     "HeaderPayloadSplit", "HeaderFecDecoder"):
             assert f"gr::packet_modem::hip::{cls}" in syms, cls
         assert "ldpc_toolbox" not in syms                               # header_fec_decoder.hpp:276: replaced, not linked
+        # packet_receiver.hpp:163-168 (zmq_output): the sink is the library's ZMTP endpoint, not cppzmq (round 6)
+        assert "gr::packet_modem::hip::ZmqPduPubSink<std::complex<float>" in syms and " U gr4pm_zmq_pub_create" in syms
+        assert "zmq::socket_t" not in syms
         assert "gr::packet_modem::CrcCheck<" in syms and "gr::packet_modem::HeaderParser<" in syms  # the reference's own
     r = subprocess.run([exe] + args, capture_output=True, text=True, env=dict(os.environ, GR4_STUB_LIFECYCLE="0"))
     assert r.returncode == 1, r.stdout + r.stderr
