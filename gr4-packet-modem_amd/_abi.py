@@ -135,7 +135,7 @@ class HeaderPayloadSplitParams(C.Structure):
 
 
 class HeaderFecDecoderParams(C.Structure):
-    _fields_ = [("alist", C.c_char_p), ("max_iterations", C.c_uint32), ("stream", C.c_void_p)]
+    _fields_ = [("alist", C.c_char_p), ("max_iterations", C.c_uint32), ("stream", C.c_void_p), ("arithmetic", C.c_int)]
 
 
 class CrcCheckParams(C.Structure):

@@ -651,9 +651,10 @@ def header_ldpc_alist():
 class HeaderFecDecoder:
     """header_fec_decoder.hpp:13-359: 256 LLRs -> 4 header bytes, or invalid"""
 
-    def __init__(self, alist=None, max_iterations=25):
+    def __init__(self, alist=None, max_iterations=25, arithmetic=0):
+        """arithmetic: 0 float32 messages (default), 1 8-bit messages (include/gr4pm_hip.h)"""
         self._alist = (alist or header_ldpc_alist()).encode()
-        p = _abi.HeaderFecDecoderParams(self._alist, max_iterations, _stream_handle())
+        p = _abi.HeaderFecDecoderParams(self._alist, max_iterations, _stream_handle(), arithmetic)
         self._h = C.c_void_p()
         check(lib().gr4pm_header_fec_decoder_create(C.byref(p), C.byref(self._h)), "HeaderFecDecoder.start")
 

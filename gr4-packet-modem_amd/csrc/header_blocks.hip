@@ -91,16 +91,28 @@ struct LdpcDev {
     const float* corr;      // [64]: ln(1 + e^-x), x = i / 8
     unsigned n, m, n_steps;
 };
+// Q8 (gr4pm_header_fec_decoder_params::arithmetic == 1): the same schedule and check-node rule with 8-bit messages, as the
+// name of the reference's decoder says it runs ("HLAminstari8", header_fec_decoder.hpp:276: horizontal-layered, A-Min*,
+// i8): every LLR is a whole number of eighths, the channel LLRs and every message saturate at +-127 (= +-15.875), the
+// correction table holds rounded eighths, posteriors keep 16 bits (a posterior cut to the message width with every
+// update loses 3 dB at the receiver's LLR scale, 2 / 0.7^2: measured).  Values are integers carried in floats (exact).
+// The crate's own rounding and saturation points are not visible here: this form measures what 8-bit messages change
+// (tests: frame-error rates of the two forms side by side), it is not a restatement of the crate.
+template <bool Q8>
 __device__ __forceinline__ float ldpc_corr(const float* corr, float x) // x >= 0
 {
+    if (Q8) return x >= 64.0f ? 0.0f : corr[static_cast<int>(x)];
     return x >= 8.0f ? 0.0f : corr[static_cast<int>(x * 8.0f)];
 }
+template <bool Q8>
 __device__ __forceinline__ float ldpc_boxplus(const float* corr, float a, float b) // magnitudes
 {
     const float mn = a < b ? a : b;
-    const float r = mn + ldpc_corr(corr, a + b) - ldpc_corr(corr, a < b ? b - a : a - b);
+    const float r = mn + ldpc_corr<Q8>(corr, a + b) - ldpc_corr<Q8>(corr, a < b ? b - a : a - b);
     return r > 0.0f ? r : 0.0f;
 }
+__device__ __forceinline__ float ldpc_sat(float x, float limit) { return fminf(fmaxf(x, -limit), limit); }
+template <bool Q8>
 __global__ __launch_bounds__(64) void k_header_fec(const float* __restrict__ llrs, unsigned n_codewords, LdpcDev d,
                                                    unsigned max_iterations, unsigned n_llrs_per_codeword,
                                                    uint8_t* __restrict__ headers, uint8_t* __restrict__ invalid)
@@ -121,7 +133,10 @@ __global__ __launch_bounds__(64) void k_header_fec(const float* __restrict__ llr
     for (unsigned e = lane; e < d.m; e += 64) s_deg[e] = d.row_deg[e];
     for (unsigned e = lane; e < d.n_steps * 64; e += 64) s_sched[e] = d.sched[e];
     // header_fec_decoder.hpp:308-312: accumulate the two copies of the repetition code
-    for (unsigned v = lane; v < d.n; v += 64) P[v] = x[v] + x[d.n + v];
+    for (unsigned v = lane; v < d.n; v += 64) {
+        const float acc = x[v] + x[d.n + v];
+        P[v] = Q8 ? ldpc_sat(rintf(8.0f * acc), 127.0f) : acc;
+    }
     for (unsigned e = lane; e < d.m * kMaxDeg; e += 64) R[e] = 0.0f;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     bool found = false;
@@ -163,6 +178,10 @@ __global__ __launch_bounds__(64) void k_header_fec(const float* __restrict__ llr
                         const unsigned v = j < kPackDeg ? static_cast<unsigned>(entry >> (8 * j)) & 0xFFu
                                                         : s_var[c * kMaxDeg + j];
                         Q[j] = P[v] - rr[j];
+                        if (Q8) {
+                            if (j == k) q_own = Q[j]; // the posterior keeps its 16 bits ...
+                            Q[j] = ldpc_sat(Q[j], 127.0f); // ... the check node sees 8-bit messages
+                        }
                         if (Q[j] < 0.0f) neg ^= 1u;
                     }
                 }
@@ -179,11 +198,11 @@ __global__ __launch_bounds__(64) void k_header_fec(const float* __restrict__ llr
                 for (unsigned j = 0; j < kMaxDeg; ++j) {
                     if (j < dc && j != imin) {
                         const float a = fabsf(Q[j]);
-                        others = others < 0.0f ? a : ldpc_boxplus(corr, others, a);
+                        others = others < 0.0f ? a : ldpc_boxplus<Q8>(corr, others, a);
                     }
                 }
                 if (others < 0.0f) others = 0.0f;
-                const float all = ldpc_boxplus(corr, others, minabs);
+                const float all = ldpc_boxplus<Q8>(corr, others, minabs);
                 float qk = 0.0f;
 #pragma unroll
                 for (unsigned j = 0; j < kMaxDeg; ++j)
@@ -191,7 +210,7 @@ __global__ __launch_bounds__(64) void k_header_fec(const float* __restrict__ llr
                 const float mag = k == imin ? others : all;
                 const unsigned sgn = neg ^ (qk < 0.0f ? 1u : 0u);
                 r_own = sgn ? -mag : mag;
-                q_own = qk;
+                if (!Q8) q_own = qk;
                 v_own = k < kPackDeg ? static_cast<unsigned>(entry >> (8 * k)) & 0xFFu : s_var[c * kMaxDeg + k];
                 slot = c * kMaxDeg + k;
             }
@@ -200,7 +219,7 @@ __global__ __launch_bounds__(64) void k_header_fec(const float* __restrict__ llr
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             if (active) {
                 R[slot] = r_own;
-                P[v_own] = q_own + r_own;
+                P[v_own] = Q8 ? ldpc_sat(q_own + r_own, 32767.0f) : q_own + r_own;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         }
@@ -440,6 +459,7 @@ struct gr4pm_header_payload_split : gr4pm::hostlogic::HpsState {
 };
 struct gr4pm_header_fec_decoder {
     unsigned n = 0, m = 0, n_steps = 0, max_iterations = 25;
+    int arithmetic = 0; // 0: float32 messages, 1: 8-bit messages (k_header_fec<true>)
     hipStream_t stream;
     DevBuf<uint8_t> row_var, row_deg;
     DevBuf<unsigned long long> sched;
@@ -771,10 +791,18 @@ try {
         set_error("alist: %zu schedule steps do not fit the kernel's table", sched.size() / 64);
         return GR4PM_ERR_INVALID;
     }
+    if (p->arithmetic != 0 && p->arithmetic != 1) {
+        set_error("HeaderFecDecoder: arithmetic %d (0: float32 messages, 1: 8-bit messages)", p->arithmetic);
+        return GR4PM_ERR_INVALID;
+    }
     std::vector<float> corr(64);
-    for (int k = 0; k < 64; ++k) corr[k] = static_cast<float>(std::log1p(std::exp(-k / 8.0)));
+    for (int k = 0; k < 64; ++k) {
+        corr[k] = static_cast<float>(std::log1p(std::exp(-k / 8.0)));
+        if (p->arithmetic == 1) corr[k] = static_cast<float>(std::nearbyint(8.0 * std::log1p(std::exp(-k / 8.0))));
+    }
     auto* h = new (std::nothrow) gr4pm_header_fec_decoder;
     if (!h) return GR4PM_ERR_NOMEM;
+    h->arithmetic = p->arithmetic;
     h->n = n;
     h->m = m;
     h->n_steps = static_cast<unsigned>(sched.size() / 64);
@@ -824,8 +852,12 @@ try {
     LdpcDev d{ h->row_var.p, h->row_deg.p, h->sched.p, h->corr.p, h->n, h->m, h->n_steps };
     uint8_t* d_headers = h->d_out.p;
     uint8_t* d_invalid = h->d_out.p + n_codewords * hb;
-    hipLaunchKernelGGL(k_header_fec, dim3(static_cast<unsigned>(n_codewords)), dim3(64), 0, h->stream, llrs,
-                       static_cast<unsigned>(n_codewords), d, h->max_iterations, 2 * h->n, d_headers, d_invalid);
+    if (h->arithmetic == 1)
+        hipLaunchKernelGGL(k_header_fec<true>, dim3(static_cast<unsigned>(n_codewords)), dim3(64), 0, h->stream, llrs,
+                           static_cast<unsigned>(n_codewords), d, h->max_iterations, 2 * h->n, d_headers, d_invalid);
+    else
+        hipLaunchKernelGGL(k_header_fec<false>, dim3(static_cast<unsigned>(n_codewords)), dim3(64), 0, h->stream, llrs,
+                           static_cast<unsigned>(n_codewords), d, h->max_iterations, 2 * h->n, d_headers, d_invalid);
     GR4PM_HIP_TRY(hipGetLastError());
     GR4PM_HIP_TRY(hipMemcpyAsync(h->h_out.p, h->d_out.p, bytes, hipMemcpyDeviceToHost, h->stream));
     GR4PM_HIP_TRY(hipStreamSynchronize(h->stream));

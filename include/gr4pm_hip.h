@@ -582,6 +582,12 @@ typedef struct {
     const char* alist;       /* parity-check matrix, alist text (:31-258) */
     uint32_t max_iterations; /* :314, 25 */
     void* stream;
+    int arithmetic;          /* message arithmetic of the horizontal-layered A-Min* decoder ("HLAminstari8": HL =
+                                horizontal-layered schedule, Aminstar = the A-Min* check-node rule, i8 = 8-bit messages):
+                                0 (default) float32 messages; 1 the same schedule and rule with 8-bit messages -- LLRs in
+                                eighths, channel LLRs and messages saturating at +-127.  The crate is not part of the
+                                reference tree, so neither form is pinned against it bit for bit; form 1 exists to show
+                                what 8-bit messages change (tests/test_gpu_parity.py: frame-error rates side by side). */
 } gr4pm_header_fec_decoder_params;
 gr4pm_status gr4pm_header_fec_decoder_create(const gr4pm_header_fec_decoder_params* params,
                                              gr4pm_header_fec_decoder** out);

@@ -276,6 +276,7 @@ static orc_tag sd_output_tag(const orc_sd* s, const HistoryItem& item, const His
     t.esn0_db = esn0_db;
     t.time_est = time_est;
     t.flags = 1;
+    t.user = 0;
     return t;
 }
 
@@ -1558,6 +1559,7 @@ struct orc_ldpc {
     std::vector<std::vector<unsigned>> rows; /* variable indices of every check */
     std::vector<unsigned> order;             /* the order the layered schedule visits the checks in */
     float corr[64];                          /* ln(1 + e^-x), x = i / 8 */
+    float corr_q8[64];                       /* the same in rounded eighths (8-bit message form) */
 };
 orc_ldpc* orc_ldpc_create(const char* alist)
 {
@@ -1597,6 +1599,7 @@ orc_ldpc* orc_ldpc_create(const char* alist)
         }
     }
     for (int k = 0; k < 64; ++k) d->corr[k] = static_cast<float>(std::log1p(std::exp(-k / 8.0)));
+    for (int k = 0; k < 64; ++k) d->corr_q8[k] = static_cast<float>(std::nearbyint(8.0 * std::log1p(std::exp(-k / 8.0))));
     /* layers: scan the checks not yet placed in index order, take every one that shares no
      * variable with those already taken in this pass (at most 64 edges per pass); the checks
      * are visited pass by pass.  (A parallel decoder can do a whole pass at once.) */
@@ -1620,21 +1623,28 @@ orc_ldpc* orc_ldpc_create(const char* alist)
     return d;
 }
 void orc_ldpc_destroy(orc_ldpc* d) { delete d; }
-static inline float ldpc_corr(const orc_ldpc* d, float x) /* x >= 0 */
+/* q8: the 8-bit message form of the product's decoder (include/gr4pm_hip.h, gr4pm_header_fec_decoder_params::arithmetic
+ * == 1) -- LLRs are whole eighths carried in floats, channel LLRs and messages saturate at +-127, posteriors at 16 bits.
+ * Not a restatement of the ldpc-toolbox crate (absent): the checker of the product's own second form. */
+static inline float ldpc_corr(const orc_ldpc* d, float x, bool q8) /* x >= 0 */
 {
+    if (q8) return x >= 64.0f ? 0.0f : d->corr_q8[static_cast<int>(x)];
     return x >= 8.0f ? 0.0f : d->corr[static_cast<int>(x * 8.0f)];
 }
 /* |a| [+] |b| in the magnitude domain */
-static inline float ldpc_boxplus(const orc_ldpc* d, float a, float b)
+static inline float ldpc_boxplus(const orc_ldpc* d, float a, float b, bool q8)
 {
     const float mn = a < b ? a : b;
-    const float r = mn + ldpc_corr(d, a + b) - ldpc_corr(d, a < b ? b - a : a - b);
+    const float r = mn + ldpc_corr(d, a + b, q8) - ldpc_corr(d, a < b ? b - a : a - b, q8);
     return r > 0.0f ? r : 0.0f;
 }
-int orc_ldpc_decode(orc_ldpc* d, const float* llrs, uint8_t* bits_k, unsigned max_iterations)
+static inline float ldpc_sat(float x, float limit) { return std::fmin(std::fmax(x, -limit), limit); }
+static int ldpc_decode_impl(orc_ldpc* d, const float* llrs, uint8_t* bits_k, unsigned max_iterations, bool q8)
 {
     const unsigned k = d->n - d->m;
     std::vector<float> P(llrs, llrs + d->n);
+    if (q8)
+        for (auto& p : P) p = ldpc_sat(std::nearbyint(8.0f * p), 127.0f);
     std::vector<std::vector<float>> R(d->m);
     for (unsigned c = 0; c < d->m; ++c) R[c].assign(d->rows[c].size(), 0.0f);
     auto is_codeword = [&]() {
@@ -1655,11 +1665,12 @@ int orc_ldpc_decode(orc_ldpc* d, const float* llrs, uint8_t* bits_k, unsigned ma
         for (unsigned c : d->order) { /* check by check, layer by layer */
             const auto& vs = d->rows[c];
             const size_t dc = vs.size();
-            float Q[16] = {};
+            float Q[16] = {}, Qwide[16] = {};
             unsigned neg = 0;
             size_t imin = 0;
             for (size_t e = 0; e < dc; ++e) {
-                Q[e] = P[vs[e]] - R[c][e];
+                Q[e] = Qwide[e] = P[vs[e]] - R[c][e];
+                if (q8) Q[e] = ldpc_sat(Q[e], 127.0f); /* what the check node sees; the posterior keeps its 16 bits */
                 if (Q[e] < 0.0f) neg ^= 1u;
                 if (std::fabs(Q[e]) < std::fabs(Q[imin])) imin = e;
             }
@@ -1667,29 +1678,46 @@ int orc_ldpc_decode(orc_ldpc* d, const float* llrs, uint8_t* bits_k, unsigned ma
             for (size_t e = 0; e < dc; ++e) {
                 if (e == imin) continue;
                 const float a = std::fabs(Q[e]);
-                others = others < 0.0f ? a : ldpc_boxplus(d, others, a);
+                others = others < 0.0f ? a : ldpc_boxplus(d, others, a, q8);
             }
             if (others < 0.0f) others = 0.0f; /* degree-1 check */
-            const float all = ldpc_boxplus(d, others, std::fabs(Q[imin]));
+            const float all = ldpc_boxplus(d, others, std::fabs(Q[imin]), q8);
             for (size_t e = 0; e < dc; ++e) {
                 const float mag = e == imin ? others : all;
                 const unsigned s = neg ^ (Q[e] < 0.0f ? 1u : 0u);
                 const float r = s ? -mag : mag;
                 R[c][e] = r;
-                P[vs[e]] = Q[e] + r;
+                P[vs[e]] = q8 ? ldpc_sat(Qwide[e] + r, 32767.0f) : Q[e] + r;
             }
         }
     }
     for (unsigned b = 0; b < k; ++b) bits_k[b] = P[b] < 0.0f ? 1 : 0;
     return used;
 }
+int orc_ldpc_decode(orc_ldpc* d, const float* llrs, uint8_t* bits_k, unsigned max_iterations)
+{
+    return ldpc_decode_impl(d, llrs, bits_k, max_iterations, false);
+}
+int orc_ldpc_decode_q8(orc_ldpc* d, const float* llrs, uint8_t* bits_k, unsigned max_iterations)
+{
+    return ldpc_decode_impl(d, llrs, bits_k, max_iterations, true);
+}
+static void header_fec_decode_impl(orc_ldpc* d, const float* llrs, size_t n_codewords, uint8_t* bytes, uint8_t* invalid, bool q8);
+void orc_header_fec_decode_q8(orc_ldpc* d, const float* llrs, size_t n_codewords, uint8_t* bytes, uint8_t* invalid)
+{
+    header_fec_decode_impl(d, llrs, n_codewords, bytes, invalid, true);
+}
 void orc_header_fec_decode(orc_ldpc* d, const float* llrs, size_t n_codewords, uint8_t* bytes, uint8_t* invalid)
+{
+    header_fec_decode_impl(d, llrs, n_codewords, bytes, invalid, false);
+}
+static void header_fec_decode_impl(orc_ldpc* d, const float* llrs, size_t n_codewords, uint8_t* bytes, uint8_t* invalid, bool q8)
 {
     for (size_t c = 0; c < n_codewords; ++c, llrs += 256) {
         float acc[128];
         for (int k = 0; k < 128; ++k) acc[k] = llrs[k] + llrs[128 + k]; /* :308-312 */
         uint8_t bits[32];
-        const int ret = orc_ldpc_decode(d, acc, bits, 25); /* :315-321 */
+        const int ret = ldpc_decode_impl(d, acc, bits, 25, q8); /* :315-321 */
         invalid[c] = ret < 0 ? 1 : 0;
         for (int k = 0; k < 4; ++k) { /* :329-335 */
             uint8_t byte = 0;

@@ -64,6 +64,7 @@ typedef struct {
     float esn0_db;         /* syncword_esn0_db */
     float time_est;        /* syncword_time_est */
     int32_t flags;         /* bit0: carries syncword_* keys; bit1: carries other keys */
+    int32_t user;          /* the caller's cookie of gr4pm_tag (include/gr4pm_hip.h): never read, copied with the tag */
 } orc_tag;
 
 /* firdes.hpp:29-76; returns number of taps written (ntaps|1) */
@@ -258,8 +259,11 @@ orc_ldpc* orc_ldpc_create(const char* alist);
 void orc_ldpc_destroy(orc_ldpc*);
 /* returns iterations used (0 = the input already was a codeword), -1 = no codeword found */
 int orc_ldpc_decode(orc_ldpc*, const float* llrs, uint8_t* bits_k, unsigned max_iterations);
+/* the product's second message arithmetic (8-bit messages; include/gr4pm_hip.h), same return values */
+int orc_ldpc_decode_q8(orc_ldpc*, const float* llrs, uint8_t* bits_k, unsigned max_iterations);
 void orc_header_fec_decode(orc_ldpc*, const float* llrs, size_t n_codewords, uint8_t* bytes,
                            uint8_t* invalid);
+void orc_header_fec_decode_q8(orc_ldpc*, const float* llrs, size_t n_codewords, uint8_t* bytes, uint8_t* invalid);
 
 /* ---- Crc<uint64_t> (crc.hpp:31-156) and CrcCheck (crc_check.hpp:75-216) ---- */
 typedef struct {

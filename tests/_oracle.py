@@ -25,6 +25,7 @@ class OrcTag(C.Structure):
         ("esn0_db", C.c_float),
         ("time_est", C.c_float),
         ("flags", C.c_int32),
+        ("user", C.c_int32),
     ]
 
 
@@ -48,10 +49,11 @@ TAG_DTYPE = np.dtype(
         ("esn0_db", "<f4"),
         ("time_est", "<f4"),
         ("flags", "<i4"),
+        ("user", "<i4"),
     ],
     align=True,
 )
-assert TAG_DTYPE.itemsize == C.sizeof(OrcTag)
+assert TAG_DTYPE.itemsize == C.sizeof(OrcTag) == 48
 
 # symbol-rate control tags (orc_ptag == gr4pm_packet_tag): kind 1 syncword / 2 header / 3 payload
 PTAG_DTYPE = np.dtype(
@@ -183,6 +185,8 @@ def lib():
         L.orc_ldpc_destroy.argtypes = [vp]
         L.orc_ldpc_decode.argtypes = [vp, vp, vp, C.c_uint]
         L.orc_header_fec_decode.argtypes = [vp, vp, sz, vp, vp]
+        L.orc_header_fec_decode_q8.argtypes = [vp, vp, sz, vp, vp]
+        L.orc_ldpc_decode_q8.argtypes = [vp, vp, vp, C.c_uint]
         L.orc_crc_compute.restype = C.c_uint64
         L.orc_crc_compute.argtypes = [C.POINTER(OrcCrcParams), vp, sz]
         L.orc_crc_check.restype = sz
@@ -514,12 +518,13 @@ class HeaderFecDecoder:
         self._h = lib().orc_ldpc_create(alist.encode())
         assert self._h
 
-    def process(self, llrs):
+    def process(self, llrs, arithmetic=0):
+        """arithmetic 1: the product's 8-bit message form (gr4pm_header_fec_decoder_params::arithmetic)"""
         x = _f32(llrs)
         n = x.size // 256
         out = np.empty((n, 4), dtype=np.uint8)
         inval = np.empty(n, dtype=np.uint8)
-        lib().orc_header_fec_decode(self._h, _p(x), n, _p(out), _p(inval))
+        (lib().orc_header_fec_decode_q8 if arithmetic else lib().orc_header_fec_decode)(self._h, _p(x), n, _p(out), _p(inval))
         return out, inval.astype(bool)
 
     def decode(self, llrs, max_iterations=25):
