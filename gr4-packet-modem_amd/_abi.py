@@ -149,7 +149,7 @@ class PacketReceiverParams(C.Structure):
     _fields_ = [("samples_per_symbol", C.c_size_t), ("syncword_freq_bins", C.c_int), ("syncword_threshold", C.c_float),
                 ("costas_constellation", C.c_int), ("max_items", C.c_size_t), ("tags_cap", C.c_size_t),
                 ("pipelined", C.c_int), ("soft_bits", C.c_int), ("decode_headers", C.c_int),
-                ("header_alist", C.c_char_p)]
+                ("header_alist", C.c_char_p), ("packets_only", C.c_int)]
 
 
 class MultiChannelReceiverParams(C.Structure):

@@ -1657,8 +1657,12 @@ class NativePacketReceiver:
 
     def __init__(self, samples_per_symbol=4, syncword_freq_bins=4, syncword_threshold=9.5,
                  costas_constellation="QPSK", max_items=1 << 22, tags_cap=4096, pipelined=False, soft_bits=False,
-                 decode_headers=False, output_ring=False):
+                 decode_headers=False, output_ring=False, packets_only=False):
+        """packets_only (a form of decode_headers; include/gr4pm_hip.h): IQ in, CRC-checked packets out, the stream between
+        the Costas loop and the packer never written to memory -- the same packets / header messages / tags; the result
+        has no "llr", "payload_llr" and "pdu_symbols" arrays (None)"""
         soft_bits = soft_bits or decode_headers
+        self.packets_only = bool(packets_only)
         self.output_ring = output_ring
         self.samples_per_symbol, self.pipelined, self.soft_bits = samples_per_symbol, pipelined, soft_bits
         self.decode_headers = decode_headers
@@ -1667,7 +1671,7 @@ class NativePacketReceiver:
         p = _abi.PacketReceiverParams(samples_per_symbol, syncword_freq_bins, syncword_threshold,
                                       CONSTELLATIONS[costas_constellation.upper()], max_items, tags_cap,
                                       1 if pipelined else 0, 1 if soft_bits else 0, 1 if decode_headers else 0,
-                                      self._alist)
+                                      self._alist, 1 if packets_only else 0)
         self._h = C.c_void_p()
         check(lib().gr4pm_packet_receiver_create(C.byref(p), C.byref(self._h)), "PacketReceiver")
         self._keep = []  # (input tensors, output tensors) of the batches in flight
@@ -1691,12 +1695,13 @@ class NativePacketReceiver:
         if not self.output_ring:  # fresh buffers for every batch: results stay valid as long as they are referenced
             n_sym = n // self.samples_per_symbol + 4160
             return (torch.empty(n_sym, dtype=torch.complex64, device=device),
-                    torch.empty(2 * n_sym if self.soft_bits else 1, dtype=torch.float32, device=device),
+                    torch.empty(2 * n_sym if self.soft_bits and not self.packets_only else 1, dtype=torch.float32, device=device),
                     torch.empty(n // 16 + 65536 if self.decode_headers else 1, dtype=torch.uint8, device=device))
         if getattr(self, "_out_n", -1) < n:
             n_sym = n // self.samples_per_symbol + 4160
             self._out_ring = [(torch.empty(n_sym, dtype=torch.complex64, device=device),
-                               torch.empty(2 * n_sym if self.soft_bits else 1, dtype=torch.float32, device=device),
+                               torch.empty(2 * n_sym if self.soft_bits and not self.packets_only else 1, dtype=torch.float32,
+                                           device=device),
                                torch.empty(n // 16 + 65536 if self.decode_headers else 1, dtype=torch.uint8,
                                            device=device)) for _ in range(self._OUT_RING)]
             self._out_n, self._out_next = n, 0
@@ -1719,7 +1724,7 @@ class NativePacketReceiver:
         check(lib().gr4pm_packet_receiver_submit(
             self._h, x.data_ptr(), n, delayed, None if nx is None else nx.data_ptr(), 0 if nx is None else nx.numel(),
             0 if packet_length is None else int(packet_length), sym.data_ptr(), sym.numel(),
-            llr.data_ptr() if self.soft_bits else None, llr.numel(),
+            llr.data_ptr() if self.soft_bits and not self.packets_only else None, llr.numel(),
             pk.data_ptr() if self.decode_headers else None, pk.numel()), "PacketReceiver.submit")
         self._keep.append((x, history, nx, sym, llr, pk))
 
@@ -1741,21 +1746,26 @@ class NativePacketReceiver:
                "accepted": records(r.accepted, r.n_detector_tags, np.dtype(np.uint8)).astype(bool)}
         if self.soft_bits:
             torch = _torch()
-            pdu_sym = torch.empty(r.n_pdu_symbols, dtype=torch.complex64, device=sym.device)
-            if r.n_pdu_symbols:  # the library's buffer is recycled: take a copy
-                check(_hip_memcpy_d2d(pdu_sym.data_ptr(), r.pdu_symbols, 8 * r.n_pdu_symbols), "pdu_symbols")
+            pdu_sym = None
+            if not self.packets_only:
+                pdu_sym = torch.empty(r.n_pdu_symbols, dtype=torch.complex64, device=sym.device)
+                if r.n_pdu_symbols:  # the library's buffer is recycled: take a copy
+                    check(_hip_memcpy_d2d(pdu_sym.data_ptr(), r.pdu_symbols, 8 * r.n_pdu_symbols), "pdu_symbols")
             res.update(pdu_symbols=pdu_sym, symbol_pdus=records(r.symbol_pdus, r.n_symbol_pdus, _abi.SYMBOL_PDU_DTYPE))
-            res.update(llr=llr[: r.n_llr], llr_tags=records(r.llr_tags, r.n_llr_tags, PACKET_TAG_DTYPE),
+            res.update(llr=None if self.packets_only else llr[: r.n_llr], n_llr=int(r.n_llr),
+                       llr_tags=records(r.llr_tags, r.n_llr_tags, PACKET_TAG_DTYPE),
                        packet_tags=records(r.packet_tags, r.n_packet_tags, PACKET_TAG_DTYPE),
                        ignored_syncwords=r.ignored_syncwords)
         if self.decode_headers:
             torch = _torch()
-            pay = torch.empty(r.n_payload_llr, dtype=torch.float32, device=llr.device)
-            if r.n_payload_llr:  # the library's buffer is recycled at the next collect(): take a copy
-                check(_hip_memcpy_d2d(pay.data_ptr(), r.payload_llr, 4 * r.n_payload_llr), "payload_llr")
+            pay = None
+            if not self.packets_only:
+                pay = torch.empty(r.n_payload_llr, dtype=torch.float32, device=llr.device)
+                if r.n_payload_llr:  # the library's buffer is recycled at the next collect(): take a copy
+                    check(_hip_memcpy_d2d(pay.data_ptr(), r.payload_llr, 4 * r.n_payload_llr), "payload_llr")
             res.update(header_messages=records(r.header_messages, r.n_header_messages, _abi.HEADER_MSG_DTYPE),
                        packet_type=records(r.packet_type, r.n_header_messages, np.dtype(np.int32)),
-                       header_mismatches=r.header_mismatches, payload_llr=pay,
+                       header_mismatches=r.header_mismatches, payload_llr=pay, n_payload_llr=int(r.n_payload_llr),
                        payload_tags=records(r.payload_tags, r.n_payload_tags, PACKET_TAG_DTYPE),
                        packets=pk[: r.n_packet_bytes],
                        packet_lengths=records(r.packet_lengths, r.n_packets, np.dtype(np.uint64)))

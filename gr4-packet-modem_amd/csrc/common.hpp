@@ -8,7 +8,15 @@
 #include <cstring>
 #include <new>
 
+#include <vector>
+
 #include "../../include/gr4pm_hip.h"
+#include "hostlogic/tail_plan.hpp"
+
+struct gr4pm_additive_scrambler;
+struct gr4pm_header_payload_split;
+struct gr4pm_syncword_remove;
+struct gr4pm_constellation_llr_decoder;
 
 namespace gr4pm {
 
@@ -167,6 +175,23 @@ inline size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
 void sd_set_coresident(struct ::gr4pm_syncword_detection* h, bool on); // syncword_detection.hip: see launch_correlate
 // header_blocks.hip: BinarySlicer + PackBits over a stream in two pieces (the native receiver's payload tail)
 gr4pm_status slice_pack_two(const float* a, size_t na, const float* b, size_t n_out, uint8_t* out, hipStream_t s);
+// round 6, the packets_only receiver: the host halves of the blocks behind the Costas loop (state advances, tags and span
+// tables as in their process() calls, no kernel) and the one kernel that does their work (header_blocks.hip, k_tail_fused)
+gr4pm_status syncword_remove_plan(::gr4pm_syncword_remove* h, size_t n, const gr4pm_packet_tag* tags_in, size_t n_tags_in,
+                                  gr4pm_packet_tag* tags_out, size_t tags_cap, size_t* n_tags_out, size_t* produced,
+                                  std::vector<hostlogic::CopySpan>& spans);
+// (all_qpsk: every run maps a symbol to two LLRs -- what the composition of hostlogic/tail_plan.hpp assumes)
+gr4pm_status llr_decoder_plan(::gr4pm_constellation_llr_decoder* h, size_t n, const gr4pm_packet_tag* tags_in, size_t n_tags_in,
+                              gr4pm_packet_tag* tags_out, size_t tags_cap, size_t* n_tags_out, size_t* produced, bool* all_qpsk,
+                              float* scale);
+gr4pm_status scrambler_plan(::gr4pm_additive_scrambler* h, size_t n, const uint64_t* reset_index, size_t n_resets,
+                            std::vector<hostlogic::ScrambleRun>& runs);
+gr4pm_status header_payload_split_plan(::gr4pm_header_payload_split* h, size_t n, const gr4pm_packet_tag* tags_in,
+                                       size_t n_tags_in, gr4pm_packet_tag* header_tags, gr4pm_packet_tag* payload_tags,
+                                       size_t tags_cap, hostlogic::HpsReplay& rp);
+gr4pm_status tail_fused(::gr4pm_additive_scrambler* scr, DevBuf<hostlogic::TailSpan>& table,
+                        const std::vector<hostlogic::TailSpan>& spans, const gr4pm_c64* symbols, float scale, float* header_llr,
+                        uint8_t* packed, hipStream_t s);
 const char* experiment_env(const char* name, bool wrong_results); // nullptr when unset
 unsigned experiment_env_wg(const char* name, unsigned fallback, unsigned lo, unsigned hi); // clamped to [lo, hi]
 

@@ -14,6 +14,7 @@
 
 #include "common.hpp"
 #include "hostlogic/packet_control.hpp"
+#include "hostlogic/tail_plan.hpp"
 
 namespace gr4pm {
 namespace {
@@ -21,9 +22,7 @@ namespace {
 // ------------------------------------------------------------------ AdditiveScrambler
 // The LFSR output depends only on the number of items since the last reset, so the sequence
 // is tabulated once: `prefix` items, then a cycle of `period` items.
-struct ScrRun {
-    unsigned long long start, len, phase; // items [start, start+len) use sequence index phase, phase+1, ...
-};
+using ScrRun = hostlogic::ScrambleRun; // items [start, start+len) use sequence index phase, phase+1, ... (hostlogic/tail_plan.hpp)
 template <typename T>
 __global__ __launch_bounds__(256) void k_scramble(const ScrRun* __restrict__ runs, const uint8_t* __restrict__ seq,
                                                   unsigned long long prefix, unsigned long long period,
@@ -288,6 +287,41 @@ __global__ __launch_bounds__(256) void k_slice_pack_two(const float* __restrict_
         out[i] = static_cast<uint8_t>(v);
     }
 }
+// ------------------------------------------------------------------ the tail behind the Costas loop in one pass (round 6)
+// SyncwordRemove -> ConstellationLLRDecoder (QPSK) -> AdditiveScrambler -> HeaderPayloadSplit -> { header LLRs |
+// BinarySlicer<true> -> PackBits<MSB> } over the table hostlogic/tail_plan.hpp composes from the blocks' own state
+// machines: every symbol of the Costas loop's output is read ONCE (8 bytes); a header symbol leaves as two descrambled
+// LLR floats -- scale * re, scale * im (constellation_llr_decoder.hpp:106-116), negated where the LFSR bit is 1
+// (additive_scrambler.hpp:92-93): the unfused chain's bits --, a payload symbol as two bits of a packed byte
+// (binary_slicer.hpp:28-33 with invert: llr < 0; pack_bits.hpp MSB first).  grid (x, span).
+using hostlogic::TailSpan;
+__global__ __launch_bounds__(256) void k_tail_fused(const TailSpan* __restrict__ spans, const float* __restrict__ sym,
+                                                    float scale, const uint8_t* __restrict__ seq,
+                                                    unsigned long long prefix, unsigned long long period,
+                                                    float* __restrict__ header_llr, uint8_t* packed)
+{
+    const TailSpan sp = spans[blockIdx.y];
+    const unsigned step = gridDim.x * blockDim.x;
+    if (sp.kind == 0) { // header: one lane per symbol
+        for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < sp.n_sym; i += step) {
+            const float2 x = *reinterpret_cast<const float2*>(sym + 2 * (sp.src + i));
+            float2 o;
+            hostlogic::tail_llr_pair(x.x, x.y, scale, seq, sp.phase + 2ull * i, prefix, period, o.x, o.y);
+            *reinterpret_cast<float2*>(header_llr + sp.dst + 2ull * i) = o; // (dst is even: 8-byte aligned)
+        }
+        return;
+    }
+    // payload: one lane per output byte = up to four symbols (hostlogic/tail_plan.hpp: tail_payload_byte)
+    const unsigned long long byte0 = sp.dst >> 3;
+    const unsigned n_bytes = static_cast<unsigned>(((sp.dst + 2ull * sp.n_sym + 7) >> 3) - byte0);
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n_bytes; i += step) {
+        const unsigned long long B = byte0 + i;
+        unsigned v, mask;
+        hostlogic::tail_payload_byte(sp, B, sym, scale, seq, prefix, period, v, mask);
+        packed[B] = mask == 0xFFu ? static_cast<uint8_t>(v) : static_cast<uint8_t>((packed[B] & ~mask) | v);
+    }
+}
+
 // CrcCheck: one lane per packet (table-driven, byte by byte, crc.hpp:130-147); the table sits in
 // LDS.  ok[i] = the CRC at the end of the packet matches.
 struct CrcPacket {
@@ -442,14 +476,10 @@ struct gr4pm_crc_check {
     }
 };
 
-struct gr4pm_additive_scrambler {
-    uint64_t mask, seed, length, count;
+struct gr4pm_additive_scrambler : gr4pm::hostlogic::ScrState { // (count, position, shape of the tabulated LFSR output)
+    uint64_t mask, seed, length;
     int item_kind;
     hipStream_t stream;
-    uint64_t prefix = 0, period = 1; // shape of the tabulated LFSR output
-    bool cyclic = true;              // false: no repeat found, the table just covers `table_len` items
-    uint64_t table_len = 0;
-    uint64_t position = 0;           // items since the last reset (_current_count, :49)
     DevBuf<uint8_t> seq;
     DevBuf<ScrRun> runs;
 };
@@ -564,30 +594,8 @@ try {
         set_error("null sample pointer");
         return GR4PM_ERR_INVALID;
     }
-    // runs of items between resets (tag resets :78-80, count resets :81)
     std::vector<ScrRun> runs;
-    size_t pos = 0, t = 0;
-    while (pos < n) {
-        while (t < n_resets && reset_index[t] < pos) ++t;
-        if (t < n_resets && reset_index[t] == pos) {
-            h->position = 0;
-            ++t;
-        }
-        if (h->count != 0 && h->position == h->count) h->position = 0;
-        size_t end = n;
-        if (t < n_resets) end = std::min<size_t>(end, reset_index[t]);
-        if (h->count != 0) end = std::min<size_t>(end, pos + static_cast<size_t>(h->count - h->position));
-        if (!h->cyclic && h->position + (end - pos) > h->table_len) {
-            set_error("LFSR output needed beyond the %llu tabulated items",
-                      static_cast<unsigned long long>(h->table_len));
-            return GR4PM_ERR_INVALID;
-        }
-        runs.push_back({ pos, end - pos, h->position });
-        h->position += end - pos;
-        pos = end;
-    }
-    if (h->cyclic && h->position >= h->prefix + h->period) // keep the counter small
-        h->position = h->prefix + (h->position - h->prefix) % h->period;
+    GR4PM_TRY(hostlogic::scramble_runs(*h, n, reset_index, n_resets, runs));
     if (h->runs.n < runs.size()) GR4PM_TRY(h->runs.alloc(runs.size() * 2));
     GR4PM_TRY(h->runs.upload_staged(runs.data(), runs.size(), h->stream));
     unsigned long long longest = 0;
@@ -924,6 +932,47 @@ gr4pm_status gr4pm::slice_pack_two(const float* a, size_t na, const float* b, si
         hipLaunchKernelGGL(k_slice_pack, dim3(grid1d(n_out)), dim3(256), 0, s, b, n_out, out);
     else
         hipLaunchKernelGGL(k_slice_pack_two, dim3(grid1d(n_out)), dim3(256), 0, s, a, na, b, n_out, out);
+    GR4PM_HIP_TRY(hipGetLastError());
+    return GR4PM_OK;
+}
+// (library-internal: csrc/packet_receiver.hip, the packets_only receiver) the host halves of the descrambler and of
+// HeaderPayloadSplit -- the blocks' state advances exactly as in their process() calls, nothing is launched -- and the
+// one kernel that does their work together with SyncwordRemove's, the LLR decoder's, the slicer's and the packer's
+gr4pm_status gr4pm::scrambler_plan(gr4pm_additive_scrambler* h, size_t n, const uint64_t* reset_index, size_t n_resets,
+                                   std::vector<hostlogic::ScrambleRun>& runs)
+{
+    if (!h || h->item_kind != 1) return GR4PM_ERR_INVALID;
+    runs.clear();
+    return hostlogic::scramble_runs(*h, n, reset_index, n_resets, runs);
+}
+gr4pm_status gr4pm::header_payload_split_plan(gr4pm_header_payload_split* h, size_t n, const gr4pm_packet_tag* tags_in,
+                                              size_t n_tags_in, gr4pm_packet_tag* header_tags, gr4pm_packet_tag* payload_tags,
+                                              size_t tags_cap, hostlogic::HpsReplay& rp)
+{
+    if (!h) return GR4PM_ERR_INVALID;
+    GR4PM_TRY(hostlogic::hps_replay(*h, n, tags_in, n_tags_in, header_tags, payload_tags, tags_cap, rp));
+    if (rp.tag_overflow) {
+        set_error("tags_cap too small");
+        return GR4PM_ERR_OVERFLOW;
+    }
+    return GR4PM_OK;
+}
+gr4pm_status gr4pm::tail_fused(gr4pm_additive_scrambler* scr, DevBuf<hostlogic::TailSpan>& table,
+                               const std::vector<hostlogic::TailSpan>& spans, const gr4pm_c64* symbols, float scale,
+                               float* header_llr, uint8_t* packed, hipStream_t s)
+{
+    if (spans.empty()) return GR4PM_OK;
+    if (table.n < spans.size()) GR4PM_TRY(table.alloc(spans.size() * 2));
+    GR4PM_TRY(table.upload_staged(spans.data(), spans.size(), s));
+    unsigned longest = 0; // lanes of the longest span: a symbol per lane (header), a byte = four symbols per lane (payload)
+    for (const auto& sp : spans) longest = std::max(longest, sp.kind ? sp.n_sym / 4 + 2 : sp.n_sym);
+    const unsigned gx = std::max(1u, std::min((longest + 255) / 256, 1024u));
+    for (size_t first = 0; first < spans.size(); first += 65535) {
+        const unsigned rows = static_cast<unsigned>(std::min<size_t>(65535, spans.size() - first));
+        hipLaunchKernelGGL(k_tail_fused, dim3(gx, rows), dim3(256), 0, s, table.p + first,
+                           reinterpret_cast<const float*>(symbols), scale, scr->seq.p, scr->prefix, scr->period, header_llr,
+                           packed);
+    }
     GR4PM_HIP_TRY(hipGetLastError());
     return GR4PM_OK;
 }

@@ -74,6 +74,9 @@ struct Slot {
     size_t n_payload_tags = 0;
     // symbol PDU tap (soft_bits): SyncwordRemove's output is s.data[0 .. n_data), cut into header / payload pieces
     size_t n_data = 0;
+    // packets_only: SyncwordRemove's spans of this batch (stage 2 -> stage 3) and the LLR decoder's scale
+    std::vector<hostlogic::CopySpan> sr_spans;
+    float llr_scale = 0.0f;
     std::vector<gr4pm_symbol_pdu> pdus;
     size_t pdu_resyncs = 0;
 };
@@ -145,15 +148,25 @@ struct HeaderLoop {
         size_t n_hdr = 0, nht = 0;
         GR4PM_TRY(gr4pm_header_payload_split_process(split, desc.p, n, hdr.p, &n_hdr, pay_dst, &n_pay, tags, n_tags,
                                                      hdr_tags.data(), &nht, pay_tags.data(), &n_pay_tags, n_tags + 1));
-        if (acc.n < acc_n + n_hdr + 256) {
-            DevBuf<float> bigger;
-            GR4PM_TRY(bigger.alloc((acc_n + n_hdr + 256) * 2));
-            if (acc_n) GR4PM_HIP_TRY(hipMemcpyAsync(bigger.p, acc.p, acc_n * sizeof(float), hipMemcpyDeviceToDevice, stream));
-            GR4PM_HIP_TRY(hipStreamSynchronize(stream));
-            std::swap(acc.p, bigger.p);
-            std::swap(acc.n, bigger.n);
-        }
+        GR4PM_TRY(reserve_acc(n_hdr));
         if (n_hdr) GR4PM_HIP_TRY(hipMemcpyAsync(acc.p + acc_n, hdr.p, n_hdr * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        return decode_acc(n_hdr, msgs, ptype);
+    }
+    // room for n_hdr more header LLRs behind the acc_n waiting ones
+    gr4pm_status reserve_acc(size_t n_hdr)
+    {
+        if (acc.n >= acc_n + n_hdr + 256) return GR4PM_OK;
+        DevBuf<float> bigger;
+        GR4PM_TRY(bigger.alloc((acc_n + n_hdr + 256) * 2));
+        if (acc_n) GR4PM_HIP_TRY(hipMemcpyAsync(bigger.p, acc.p, acc_n * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        GR4PM_HIP_TRY(hipStreamSynchronize(stream));
+        std::swap(acc.p, bigger.p);
+        std::swap(acc.n, bigger.n);
+        return GR4PM_OK;
+    }
+    // n_hdr header LLRs have been put behind the waiting ones (in stream order): decode every complete codeword
+    gr4pm_status decode_acc(size_t n_hdr, std::vector<gr4pm_header_msg>& msgs, std::vector<int32_t>& ptype)
+    {
         acc_n += n_hdr;
         const size_t cw = acc_n / 256;
         bytes.resize(std::max<size_t>(cw, 1) * 4);
@@ -170,6 +183,35 @@ struct HeaderLoop {
         ptype.resize(at + cw);
         gr4pm_header_parse(bytes.data(), invalid.data(), cw, msgs.data() + at, ptype.data() + at);
         return GR4PM_OK;
+    }
+    // packets_only (round 6): the same loop with the blocks' host halves alone and ONE kernel over the Costas loop's output
+    // (hostlogic/tail_plan.hpp, k_tail_fused): header LLRs go straight behind the waiting ones, payload bits straight into
+    // the packer's byte stream at bit `payload_bit0` of `packed`.  sr_spans: SyncwordRemove's spans of this batch.
+    std::vector<hostlogic::ScrambleRun> scr_runs;
+    std::vector<hostlogic::TailSpan> tail_spans;
+    DevBuf<hostlogic::TailSpan> tail_table;
+    gr4pm_status run_fused(const gr4pm_c64* costas_out, float llr_scale, const std::vector<hostlogic::CopySpan>& sr_spans,
+                           size_t n_llr, const gr4pm_packet_tag* tags, size_t n_tags, uint8_t* packed, size_t payload_bit0,
+                           std::vector<gr4pm_header_msg>& msgs, std::vector<int32_t>& ptype)
+    {
+        n_pay = n_pay_tags = 0;
+        std::vector<uint64_t> resets;
+        for (size_t i = 0; i < n_tags; ++i)
+            if (tags[i].kind == GR4PM_PKT_HEADER_START) resets.push_back(tags[i].index);
+        GR4PM_TRY(gr4pm::scrambler_plan(scr, n_llr, resets.data(), resets.size(), scr_runs));
+        hdr_tags.resize(n_tags + 1);
+        pay_tags.resize(n_tags + 1);
+        hostlogic::HpsReplay rp;
+        GR4PM_TRY(gr4pm::header_payload_split_plan(split, n_llr, tags, n_tags, hdr_tags.data(), pay_tags.data(), n_tags + 1, rp));
+        n_pay = rp.n_payload;
+        n_pay_tags = rp.n_payload_tags;
+        GR4PM_TRY(reserve_acc(rp.n_header));
+        if (!hostlogic::compose_tail(sr_spans, scr_runs, rp, acc_n, payload_bit0, tail_spans)) {
+            set_error("packets_only: the tag stream behind the Costas loop does not compose (a boundary inside a symbol)");
+            return GR4PM_ERR_INTERNAL;
+        }
+        GR4PM_TRY(gr4pm::tail_fused(scr, tail_table, tail_spans, costas_out, llr_scale, acc.p, packed, stream));
+        return decode_acc(rp.n_header, msgs, ptype);
     }
 };
 
@@ -281,6 +323,12 @@ struct gr4pm_packet_receiver {
     size_t soft_n = 0;
     std::deque<uint64_t> payload_bits;      // their lengths
     DevBuf<uint8_t> packed;
+    // packets_only: the packer's byte stream of a batch starts with the bits of the packet the batch before left
+    // unfinished -- carried as BYTES (two buffers in turn: the tail of one batch's stream is copied to the front of the next
+    // one's; the last byte may be half full, k_tail_fused completes it)
+    DevBuf<uint8_t> packed2[2];
+    int packed_cur = 0;
+    size_t carry_bits = 0;
     Slot slots[kSlots];
     SlotRing free_slots, to_stageA, to_stage1, to_stage1b, to_stage2, to_stage3, done;
     std::thread workers[5];
@@ -331,6 +379,7 @@ struct gr4pm_packet_receiver {
     void drop_unfinished_payload()
     {
         soft_n = 0;
+        carry_bits = 0;
         payload_bits.clear();
     }
 };
@@ -833,7 +882,7 @@ gr4pm_status gr4pm_packet_receiver::stage2_decode(Slot& s)
         pm_carry_hdrs.clear();
     }
     if (s.pm.n < n + 1) GR4PM_TRY(s.pm.alloc(n + 1));
-    if (s.data.n < n + 1) GR4PM_TRY(s.data.alloc(n + 1));
+    if (!p.packets_only && s.data.n < n + 1) GR4PM_TRY(s.data.alloc(n + 1));
     s.packet_tags.resize(3 * s.n_sym_tags + 8);
     s.data_tags.resize(s.packet_tags.size());
     s.llr_tags.resize(s.packet_tags.size());
@@ -875,6 +924,25 @@ gr4pm_status gr4pm_packet_receiver::stage2_decode(Slot& s)
     T2_MARK("costas");
     s.n_symbols = produced;
     size_t n_dt = 0, n_data = 0, n_lt = 0, n_llr = 0;
+    if (p.packets_only) {
+        // SyncwordRemove and the LLR decoder on the host alone (state, tags, span table): stage 3's one kernel reads the
+        // Costas loop's output through the composed table (hostlogic/tail_plan.hpp); neither `data` nor the LLR stream exists
+        GR4PM_TRY(gr4pm::syncword_remove_plan(remove, produced, s.packet_tags.data(), n_pt, s.data_tags.data(), s.data_tags.size(),
+                                              &n_dt, &n_data, s.sr_spans));
+        bool all_qpsk = true;
+        GR4PM_TRY(gr4pm::llr_decoder_plan(llr, n_data, s.data_tags.data(), n_dt, s.llr_tags.data(), s.llr_tags.size(), &n_lt,
+                                          &n_llr, &all_qpsk, &s.llr_scale));
+        if (!all_qpsk) { // (PayloadMetadataInsert names QPSK for the header and nothing for the payload: packet_receiver.hpp:127-130)
+            set_error("packets_only: a run behind SyncwordRemove is not QPSK");
+            return GR4PM_ERR_INVALID;
+        }
+        T2_MARK("remove+llr plans");
+        s.n_llr_tags = n_lt;
+        s.n_llr = n_llr;
+        s.n_data = 0;
+        s.pdus.clear();
+        s.pdu_resyncs = 0;
+    } else {
     GR4PM_TRY(gr4pm_syncword_remove_process(remove, s.out_symbols, produced, s.data.p, s.packet_tags.data(), n_pt,
                                             s.data_tags.data(), s.data_tags.size(), &n_dt, &n_data));
     T2_MARK("remove");
@@ -884,6 +952,7 @@ gr4pm_status gr4pm_packet_receiver::stage2_decode(Slot& s)
     s.n_llr_tags = n_lt;
     s.n_llr = n_llr;
     GR4PM_TRY(split_symbol_pdus(s, n_data, n_dt));
+    }
     s.opened.clear();
     for (size_t i = 0, j = 0; i < n_pt; ++i)
         if (s.packet_tags[i].kind == GR4PM_PKT_SYNCWORD) { // a packet PayloadMetadataInsert opened: both lists ascend
@@ -922,11 +991,32 @@ gr4pm_status gr4pm_packet_receiver::stage3_decode(Slot& s)
     for (const auto& m : s.opened) used_msgs.push_back(m);
     s.header_messages.clear();
     s.packet_type.clear();
+    const size_t lean_bit0 = carry_bits; // packets_only: this batch's payload bits go behind the carried ones
+    if (p.packets_only) {
+        uint8_t* stream_bytes = nullptr;
+        {   // the packer's byte stream of this batch: carried bits + at most one bit per LLR
+            const size_t want = (carry_bits + n_llr) / 8 + 16;
+            auto& pk = packed2[packed_cur];
+            if (pk.n < want) {
+                DevBuf<uint8_t> bigger;
+                GR4PM_TRY(bigger.alloc(want * 2));
+                if (carry_bits)
+                    GR4PM_HIP_TRY(hipMemcpyAsync(bigger.p, pk.p, (carry_bits + 7) / 8, hipMemcpyDeviceToDevice, st2));
+                GR4PM_HIP_TRY(hipStreamSynchronize(st2));
+                std::swap(pk.p, bigger.p);
+                std::swap(pk.n, bigger.n);
+            }
+            stream_bytes = pk.p;
+        }
+        GR4PM_TRY(b_loop.run_fused(s.out_symbols, s.llr_scale, s.sr_spans, n_llr, s.llr_tags.data(), n_lt, stream_bytes,
+                                   lean_bit0, s.header_messages, s.packet_type));
+    } else {
     // (the descrambled payload LLRs of this batch go straight to the slot's buffer, which the caller reads: round 5 --
     // they used to be copied there, and once more behind the unfinished packet's, 1.9 GB of traffic a step on a
     // packet-dense stream in the stage that sets the pace of the decode_headers pipeline)
     if (s.payload_llr.n < n_llr + 1) GR4PM_TRY(s.payload_llr.alloc(n_llr + 1));
     GR4PM_TRY(b_loop.run(s.out_llr, n_llr, s.llr_tags.data(), n_lt, s.header_messages, s.packet_type, s.payload_llr.p));
+    }
     T3_MARK("header_loop");
     for (const auto& got : s.header_messages) {
         if (used_msgs.empty()) break;
@@ -941,14 +1031,14 @@ gr4pm_status gr4pm_packet_receiver::stage3_decode(Slot& s)
         if (!same_header(given, got)) ++s.header_mismatches;
     }
     const size_t n_pay = b_loop.n_pay;
-    const float* pay = s.payload_llr.p;
+    const float* pay = p.packets_only ? nullptr : s.payload_llr.p;
     s.n_payload_llr = n_pay;
     s.n_payload_tags = b_loop.n_pay_tags;
     s.payload_tags.assign(b_loop.pay_tags.begin(), b_loop.pay_tags.begin() + b_loop.n_pay_tags);
     // payload tail, packet_receiver.hpp:140-147 (whole packets only; the rest waits): the stream is
     // [soft[0 .. soft_n): the unfinished packet of the batches before | pay[0 .. n_pay)], sliced and packed in place
     for (size_t i = 0; i < b_loop.n_pay_tags; ++i) payload_bits.push_back(b_loop.pay_tags[i].payload_bits);
-    const size_t total = soft_n + n_pay;
+    const size_t total = (p.packets_only ? carry_bits : soft_n) + n_pay;
     std::vector<uint64_t> lens, offs;
     size_t used_bits = 0;
     while (!payload_bits.empty() && used_bits + payload_bits.front() <= total) {
@@ -959,18 +1049,37 @@ gr4pm_status gr4pm_packet_receiver::stage3_decode(Slot& s)
     }
     s.packet_lengths.assign(lens.size(), 0);
     s.n_packet_bytes = 0;
+    const uint8_t* packed_bytes = p.packets_only ? packed2[packed_cur].p : nullptr;
     if (!lens.empty()) {
-        if (packed.n < used_bits / 8 + 1) GR4PM_TRY(packed.alloc(used_bits / 8 * 2 + 1));
-        GR4PM_TRY(gr4pm::slice_pack_two(soft.p, soft_n, pay, used_bits / 8, packed.p, st2));
+        if (!p.packets_only) {
+            if (packed.n < used_bits / 8 + 1) GR4PM_TRY(packed.alloc(used_bits / 8 * 2 + 1));
+            GR4PM_TRY(gr4pm::slice_pack_two(soft.p, soft_n, pay, used_bits / 8, packed.p, st2));
+            packed_bytes = packed.p;
+        }
         if (s.packets_cap < used_bits / 8) {
             set_error("packets_cap %zu < %zu bytes", s.packets_cap, used_bits / 8);
             return GR4PM_INSUFFICIENT_OUTPUT_ITEMS;
         }
-        GR4PM_TRY(gr4pm_crc_check_process(crc, packed.p, offs.data(), lens.data(), lens.size(), s.out_packets,
+        GR4PM_TRY(gr4pm_crc_check_process(crc, packed_bytes, offs.data(), lens.data(), lens.size(), s.out_packets,
                                           s.packet_lengths.data(), &s.n_packet_bytes));
     }
     // what is left for the next batch
     const size_t rest = total - used_bits;
+    if (p.packets_only) {
+        // the unfinished packet's bytes (the last one perhaps half full) move to the front of the other buffer: the next
+        // batch's kernel goes on writing behind bit `rest` there.  (used_bits is a whole number of bytes: packets are.)
+        auto& next = packed2[packed_cur ^ 1];
+        const size_t n_bytes = (rest + 7) / 8;
+        if (next.n < n_bytes + 16) GR4PM_TRY(next.alloc((n_bytes + 16) * 2));
+        if (n_bytes)
+            GR4PM_HIP_TRY(hipMemcpyAsync(next.p, packed2[packed_cur].p + used_bits / 8, n_bytes, hipMemcpyDeviceToDevice, st2));
+        packed_cur ^= 1;
+        carry_bits = rest;
+        GR4PM_HIP_TRY(hipStreamSynchronize(st2));
+        T3_MARK("payload_tail");
+        T3_END();
+        return GR4PM_OK;
+    }
     auto soft_room = [&](size_t want, size_t keep) -> gr4pm_status { // (keep: items at the front that must survive)
         if (soft.n >= want + 8) return GR4PM_OK;
         DevBuf<float> bigger;
@@ -1109,6 +1218,12 @@ try {
             set_error("decode_headers needs soft_bits and the header code's alist");
             return bail(GR4PM_ERR_INVALID);
         }
+    }
+    if (p->packets_only && !p->decode_headers) {
+        set_error("packets_only is a form of the decode_headers receiver");
+        return bail(GR4PM_ERR_INVALID);
+    }
+    if (p->decode_headers) {
         // pass A: the same blocks a second time, on a stream (and pipeline stage) of their own
         hipStream_t s1 = h->streams[5], s2 = h->streams[3];
         gr4pm_rotator_params rp2{ 1, 0.0f, (rrc.size() - 1) / 2 + sps, 1, s1 };
@@ -1147,7 +1262,7 @@ try {
         if ((st = sl.sym.alloc(sym_cap)) != GR4PM_OK) return bail(st);
         if (p->soft_bits) {
             if ((st = sl.pm.alloc(sym_cap + 1)) != GR4PM_OK) return bail(st);
-            if ((st = sl.data.alloc(sym_cap + 1)) != GR4PM_OK) return bail(st);
+            if (!p->packets_only && (st = sl.data.alloc(sym_cap + 1)) != GR4PM_OK) return bail(st);
             if (!p->decode_headers && (st = sl.z.alloc(sym_cap + 1)) != GR4PM_OK) return bail(st);
         }
         h->free_slots.push(i);
@@ -1261,7 +1376,7 @@ gr4pm_status gr4pm_packet_receiver_submit(gr4pm_packet_receiver* h, const gr4pm_
                                           uint64_t packet_length, gr4pm_c64* out_symbols, size_t out_cap,
                                           float* out_llr, size_t llr_cap, uint8_t* out_packets, size_t packets_cap)
 try {
-    if (!h || !in || !out_symbols || (h->p.soft_bits && !out_llr) || (h->p.decode_headers && !out_packets))
+    if (!h || !in || !out_symbols || (h->p.soft_bits && !h->p.packets_only && !out_llr) || (h->p.decode_headers && !out_packets))
         return GR4PM_ERR_INVALID;
     if (h->p.decode_headers && n_in < gr4pm_packet_receiver::kW + gr4pm_packet_receiver::kPre + 2048) {
         set_error("decode_headers needs batches of at least %u items",
@@ -1372,12 +1487,12 @@ try {
     r->n_llr_tags = s.n_llr_tags;
     r->ignored_syncwords = s.ignored;
     r->symbols = s.out_symbols;
-    r->llr = s.out_llr;
+    r->llr = h->p.packets_only ? nullptr : s.out_llr; // packets_only: the LLR stream is never materialised (n_llr: its length)
     r->header_messages = s.header_messages.data();
     r->packet_type = s.packet_type.data();
     r->n_header_messages = s.header_messages.size();
     r->header_mismatches = s.header_mismatches;
-    r->payload_llr = s.payload_llr.p;
+    r->payload_llr = h->p.packets_only ? nullptr : s.payload_llr.p;
     r->n_payload_llr = s.n_payload_llr;
     r->payload_tags = s.payload_tags.data();
     r->n_payload_tags = s.n_payload_tags;
@@ -1385,7 +1500,7 @@ try {
     r->n_packet_bytes = s.n_packet_bytes;
     r->packet_lengths = s.packet_lengths.data();
     r->n_packets = s.packet_lengths.size();
-    r->pdu_symbols = s.data.p;
+    r->pdu_symbols = h->p.packets_only ? nullptr : s.data.p;
     r->n_pdu_symbols = s.n_data;
     r->symbol_pdus = s.pdus.data();
     r->n_symbol_pdus = s.pdus.size();
@@ -1430,6 +1545,10 @@ try {
         set_error("the symbol PDU tap hangs off SyncwordRemove: soft_bits receivers only");
         return GR4PM_ERR_INVALID;
     }
+    if (fn && h->p.packets_only) {
+        set_error("the symbol PDU tap needs SyncwordRemove's output stream: not a packets_only receiver");
+        return GR4PM_ERR_INVALID;
+    }
     h->pdu_fn = fn;
     h->pdu_user = user;
     for (auto& pub : h->pdu_pub) { // the library's own sink (below) gives way to the caller's
@@ -1455,6 +1574,10 @@ try {
     if (!header_endpoint) return GR4PM_OK;
     if (!h->p.soft_bits) {
         set_error("the symbol PDU tap hangs off SyncwordRemove: soft_bits receivers only");
+        return GR4PM_ERR_INVALID;
+    }
+    if (h->p.packets_only) {
+        set_error("the symbol PDU tap needs SyncwordRemove's output stream: not a packets_only receiver");
         return GR4PM_ERR_INVALID;
     }
     gr4pm_zmq_pub* pubs[2] = { nullptr, nullptr };

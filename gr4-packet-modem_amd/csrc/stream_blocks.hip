@@ -3397,6 +3397,89 @@ struct gr4pm_constellation_llr_decoder {
     DevBuf<LlrRun> runs;
 };
 
+// the host half of ConstellationLLRDecoder::processBulk over one call (constellation_llr_decoder.hpp:84-130): runs of
+// symbols with one constellation, the tags re-indexed to LLR positions (:93-99); the block's constellation follows the tags
+static gr4pm_status llr_runs(gr4pm_constellation_llr_decoder* h, size_t n, size_t out_cap, const gr4pm_packet_tag* tags_in,
+                             size_t n_tags_in, gr4pm_packet_tag* tags_out, size_t tags_cap, size_t* n_tags_out, size_t* produced,
+                             std::vector<gr4pm::LlrRun>& runs)
+{
+    using gr4pm::LlrRun;
+    size_t pos = 0, opos = 0, n_pub = 0;
+    bool tag_overflow = false;
+    auto close_run = [&](size_t end) {
+        if (end <= pos) return;
+        LlrRun r{};
+        r.in0 = pos;
+        r.out0 = opos;
+        r.qpsk = h->constellation == 2;
+        r.n_out = (end - pos) * (r.qpsk ? 2 : 1);
+        runs.push_back(r);
+        opos += r.n_out;
+        pos = end;
+    };
+    for (size_t t = 0; t < n_tags_in; ++t) {
+        if (tags_in[t].index >= n) break;
+        close_run(static_cast<size_t>(tags_in[t].index));
+        if (tags_in[t].constellation >= 0) {
+            if (tags_in[t].constellation != 1 && tags_in[t].constellation != 2) {
+                gr4pm::set_error("constellation %d not supported", tags_in[t].constellation);
+                return GR4PM_ERR_INVALID;
+            }
+            h->constellation = tags_in[t].constellation;
+        }
+        if (tags_out && n_pub < tags_cap) { // :93-99
+            tags_out[n_pub] = tags_in[t];
+            tags_out[n_pub].index = opos;
+        } else {
+            tag_overflow = true;
+        }
+        ++n_pub;
+    }
+    close_run(n);
+    if (opos > out_cap) {
+        gr4pm::set_error("out_cap %zu < %zu LLRs", out_cap, opos);
+        return GR4PM_INSUFFICIENT_OUTPUT_ITEMS;
+    }
+    *produced = opos;
+    if (n_tags_out) *n_tags_out = n_pub;
+    if (tag_overflow) {
+        gr4pm::set_error("tags_cap too small");
+        return GR4PM_ERR_OVERFLOW;
+    }
+    return GR4PM_OK;
+}
+// (library-internal: csrc/packet_receiver.hip, the packets_only receiver) the host halves alone: state, tags, spans
+gr4pm_status gr4pm::syncword_remove_plan(gr4pm_syncword_remove* h, size_t n, const gr4pm_packet_tag* tags_in, size_t n_tags_in,
+                                         gr4pm_packet_tag* tags_out, size_t tags_cap, size_t* n_tags_out, size_t* produced,
+                                         std::vector<hostlogic::CopySpan>& spans)
+{
+    if (!h || !produced) return GR4PM_ERR_INVALID;
+    hostlogic::SrReplay rp; // the state machine: hostlogic/packet_control.hpp
+    hostlogic::sr_replay(*h, n, tags_in, n_tags_in, tags_out, tags_cap, rp);
+    spans.swap(rp.spans);
+    *produced = rp.produced;
+    if (n_tags_out) *n_tags_out = rp.n_pub;
+    if (rp.tag_overflow) {
+        set_error("tags_cap too small");
+        return GR4PM_ERR_OVERFLOW;
+    }
+    return GR4PM_OK;
+}
+gr4pm_status gr4pm::llr_decoder_plan(gr4pm_constellation_llr_decoder* h, size_t n, const gr4pm_packet_tag* tags_in,
+                                     size_t n_tags_in, gr4pm_packet_tag* tags_out, size_t tags_cap, size_t* n_tags_out,
+                                     size_t* produced, bool* all_qpsk, float* scale)
+{
+    if (!h || !produced || !all_qpsk || !scale) return GR4PM_ERR_INVALID;
+    std::vector<LlrRun> runs;
+    *produced = 0;
+    if (n_tags_out) *n_tags_out = 0;
+    const gr4pm_status st = llr_runs(h, n, static_cast<size_t>(-1), tags_in, n_tags_in, tags_out, tags_cap, n_tags_out, produced, runs);
+    *all_qpsk = true;
+    for (const auto& r : runs) *all_qpsk = *all_qpsk && r.qpsk;
+    *scale = h->scale;
+    return st;
+}
+
 extern "C" {
 
 gr4pm_status gr4pm_payload_metadata_insert_create(const gr4pm_payload_metadata_insert_params* p,
@@ -3544,20 +3627,12 @@ try {
         set_error("null sample pointer");
         return GR4PM_ERR_INVALID;
     }
-    gr4pm::hostlogic::SrReplay rp; // the state machine: hostlogic/packet_control.hpp
-    gr4pm::hostlogic::sr_replay(*h, n, tags_in, n_tags_in, tags_out, tags_cap, rp);
-    const std::vector<CopySpan>& spans = rp.spans;
-    const size_t opos = rp.produced, n_pub = rp.n_pub;
-    const bool tag_overflow = rp.tag_overflow;
+    std::vector<CopySpan> spans;
+    const gr4pm_status st = gr4pm::syncword_remove_plan(h, n, tags_in, n_tags_in, tags_out, tags_cap, n_tags_out, produced, spans);
+    if (st != GR4PM_OK && st != GR4PM_ERR_OVERFLOW) return st;
     GR4PM_TRY(launch_gather(h->stream, h->spans, spans, reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(out)));
     GR4PM_HIP_TRY(final_sync(h->stream));
-    *produced = opos;
-    if (n_tags_out) *n_tags_out = n_pub;
-    if (tag_overflow) {
-        set_error("tags_cap too small");
-        return GR4PM_ERR_OVERFLOW;
-    }
-    return GR4PM_OK;
+    return st;
 }
 GR4PM_ABI_CATCH
 
@@ -3603,42 +3678,8 @@ try {
         return GR4PM_ERR_INVALID;
     }
     std::vector<LlrRun> runs;
-    size_t pos = 0, opos = 0, n_pub = 0;
-    bool tag_overflow = false;
-    auto close_run = [&](size_t end) {
-        if (end <= pos) return;
-        LlrRun r{};
-        r.in0 = pos;
-        r.out0 = opos;
-        r.qpsk = h->constellation == 2;
-        r.n_out = (end - pos) * (r.qpsk ? 2 : 1);
-        runs.push_back(r);
-        opos += r.n_out;
-        pos = end;
-    };
-    for (size_t t = 0; t < n_tags_in; ++t) {
-        if (tags_in[t].index >= n) break;
-        close_run(static_cast<size_t>(tags_in[t].index));
-        if (tags_in[t].constellation >= 0) {
-            if (tags_in[t].constellation != 1 && tags_in[t].constellation != 2) {
-                set_error("constellation %d not supported", tags_in[t].constellation);
-                return GR4PM_ERR_INVALID;
-            }
-            h->constellation = tags_in[t].constellation;
-        }
-        if (tags_out && n_pub < tags_cap) { // :93-99
-            tags_out[n_pub] = tags_in[t];
-            tags_out[n_pub].index = opos;
-        } else {
-            tag_overflow = true;
-        }
-        ++n_pub;
-    }
-    close_run(n);
-    if (opos > out_cap) {
-        set_error("out_cap %zu < %zu LLRs", out_cap, opos);
-        return GR4PM_INSUFFICIENT_OUTPUT_ITEMS;
-    }
+    const gr4pm_status st = llr_runs(h, n, out_cap, tags_in, n_tags_in, tags_out, tags_cap, n_tags_out, produced, runs);
+    if (st != GR4PM_OK && st != GR4PM_ERR_OVERFLOW) return st;
     GR4PM_TRY(upload_vec(h->runs, runs, h->stream));
     unsigned long long longest = 0;
     for (const auto& r : runs) longest = std::max(longest, r.n_out);
@@ -3650,13 +3691,7 @@ try {
     }
     GR4PM_HIP_TRY(hipGetLastError());
     GR4PM_HIP_TRY(final_sync(h->stream));
-    *produced = opos;
-    if (n_tags_out) *n_tags_out = n_pub;
-    if (tag_overflow) {
-        set_error("tags_cap too small");
-        return GR4PM_ERR_OVERFLOW;
-    }
-    return GR4PM_OK;
+    return st;
 }
 GR4PM_ABI_CATCH
 

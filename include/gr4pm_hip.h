@@ -688,6 +688,14 @@ typedef struct {
                                   packet_length; BinarySlicer, PackBits, CrcCheck (:140-147) deliver the packets.
                                   Two passes per batch, see HISTORY.md 5c. */
     const char* header_alist;  /* decode_headers: the header code, header_fec_decoder.hpp:31-258 */
+    int packets_only;          /* (decode_headers) round 6: what benchmarks/benchmark_packet_receiver.cpp measures -- IQ in,
+                                  CRC-checked packets out -- with the stream between the Costas loop and the packer never
+                                  written to memory: SyncwordRemove, the LLR decoder, the descrambler, HeaderPayloadSplit,
+                                  the slicer and the packer advance their state on the host as always, and ONE kernel
+                                  (k_tail_fused) reads every Costas-loop output symbol once, writes header LLRs for the
+                                  header decoder and packed payload bytes for CrcCheck.  The same packets, header messages
+                                  and tags as the full form, bit for bit; result.llr, .payload_llr and .pdu_symbols are NULL
+                                  (their counts and tags are still reported), out_llr may be NULL, no symbol PDU tap. */
 } gr4pm_packet_receiver_params;
 typedef struct {
     size_t consumed;                    /* items of the batch SyncwordDetection consumed */

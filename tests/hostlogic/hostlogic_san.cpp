@@ -23,6 +23,7 @@
 #include "hostlogic/sdf_gate.hpp"
 #include "hostlogic/slot_queue.hpp"
 #include "hostlogic/symbol_filter_replay.hpp"
+#include "hostlogic/tail_plan.hpp"
 #include "hostlogic/zmtp_pub.hpp"
 
 namespace gr4pm {
@@ -628,6 +629,148 @@ static void zmtp_pub(std::mt19937_64& rng)
     CHECK(got_a == want_a, "the subscriber of topic A got %zu messages, expected %zu", got_a.size(), want_a.size());
 }
 
+// ---------------------------------------------------------------- the composed tail table (hostlogic/tail_plan.hpp)
+// A PayloadMetadataInsert-shaped tag stream (syncword | header | payload of (len + 4) * 4 symbols, headers that did not
+// decode among them) cut into calls at random symbols.  Reference: the blocks one by one with plain loops -- SyncwordRemove's
+// gather, the QPSK LLRs, the descrambler over its runs, HeaderPayloadSplit's two gathers, then slicer + packer over the
+// whole payload stream.  Under test: the same host state machines + compose_tail + the kernel's own per-symbol / per-byte
+// functions (tail_llr_pair, tail_payload_byte), writing header LLRs and payload BITS in place, partial bytes at every cut.
+static void tail_compose(std::mt19937_64& rng)
+{
+    // the stream and its tags (absolute symbol positions)
+    std::vector<gr4pm_packet_tag> all;
+    uint64_t pos = 0;
+    const int n_packets = 40 + static_cast<int>(rng() % 40);
+    for (int k = 0; k < n_packets; ++k) {
+        gr4pm_packet_tag t{};
+        t.index = pos;
+        t.kind = GR4PM_PKT_SYNCWORD;
+        t.constellation = 0;
+        all.push_back(t);
+        t = gr4pm_packet_tag{};
+        t.index = pos + 64;
+        t.kind = GR4PM_PKT_HEADER_START;
+        t.constellation = 2;
+        all.push_back(t);
+        pos += 64 + 128;
+        if (rng() % 6) { // the header decoded: a payload follows
+            const uint64_t len = 1 + rng() % (rng() % 4 ? 40 : 700);
+            t = gr4pm_packet_tag{};
+            t.index = pos;
+            t.kind = GR4PM_PKT_PAYLOAD;
+            t.constellation = -1;
+            t.packet_length = len;
+            t.payload_symbols = (len + 4) * 4;
+            t.payload_bits = 2 * t.payload_symbols;
+            all.push_back(t);
+            pos += t.payload_symbols;
+        }
+    }
+    const uint64_t n_total = pos;
+    std::vector<float> sym(2 * n_total);
+    for (auto& v : sym) v = static_cast<float>(static_cast<double>(static_cast<int64_t>(rng() % 2001) - 1000) / 640.0); // zeros among them
+    const float scale = 2.0f / (0.7f * 0.7f);
+    ScrState scr_ref, scr_new;
+    scr_ref.prefix = scr_new.prefix = 5;
+    scr_ref.period = scr_new.period = 997;
+    scr_ref.table_len = scr_new.table_len = 1002;
+    std::vector<uint8_t> seq(1002);
+    for (auto& b : seq) b = static_cast<uint8_t>(rng() & 1);
+    SrState sr_ref, sr_new;
+    HpsState hps_ref, hps_new;
+    hps_ref.header_size = hps_new.header_size = 256;
+    std::vector<float> hdr_ref, pay_ref, hdr_new;
+    std::vector<uint8_t> packed_new;
+    uint64_t pay_bits_new = 0;
+    for (uint64_t start = 0; start < n_total;) {
+        const uint64_t n = std::min<uint64_t>(n_total - start, 1 + rng() % (rng() % 3 ? 3000 : 90));
+        std::vector<gr4pm_packet_tag> tags;
+        for (auto t : all)
+            if (t.index >= start && t.index < start + n) {
+                t.index -= start;
+                tags.push_back(t);
+            }
+        const float* x = sym.data() + 2 * start;
+        std::vector<gr4pm_packet_tag> dt(tags.size() + 4), lt, ht(tags.size() + 4), pt(tags.size() + 4);
+        // ---- the blocks one by one
+        {
+            SrReplay sr;
+            sr_replay(sr_ref, n, tags.data(), tags.size(), dt.data(), dt.size(), sr);
+            std::vector<float> data(2 * sr.produced), llr, desc;
+            for (const auto& sp : sr.spans) std::memcpy(data.data() + 2 * sp.dst, x + 2 * sp.src, 8 * sp.len);
+            llr.resize(data.size());
+            for (size_t i = 0; i < data.size(); ++i) llr[i] = scale * data[i];
+            lt.assign(dt.begin(), dt.begin() + static_cast<ptrdiff_t>(sr.n_pub));
+            std::vector<uint64_t> resets;
+            for (auto& t : lt) {
+                t.index *= 2;
+                if (t.kind == GR4PM_PKT_HEADER_START) resets.push_back(t.index);
+            }
+            std::vector<ScrambleRun> runs;
+            CHECK(scramble_runs(scr_ref, llr.size(), resets.data(), resets.size(), runs) == GR4PM_OK, "runs");
+            desc.resize(llr.size());
+            for (const auto& r : runs)
+                for (uint64_t i = 0; i < r.len; ++i) {
+                    const float a = llr[r.start + i];
+                    desc[r.start + i] = seq[scr_index(r.phase + i, scr_ref.prefix, scr_ref.period)] ? -a : a;
+                }
+            HpsReplay hp;
+            CHECK(hps_replay(hps_ref, desc.size(), lt.data(), lt.size(), ht.data(), pt.data(), ht.size(), hp) == GR4PM_OK, "hps");
+            const size_t h0 = hdr_ref.size(), p0 = pay_ref.size();
+            hdr_ref.resize(h0 + hp.n_header);
+            pay_ref.resize(p0 + hp.n_payload);
+            for (const auto& sp : hp.header_spans) std::memcpy(hdr_ref.data() + h0 + sp.dst, desc.data() + sp.src, 4 * sp.len);
+            for (const auto& sp : hp.payload_spans) std::memcpy(pay_ref.data() + p0 + sp.dst, desc.data() + sp.src, 4 * sp.len);
+        }
+        // ---- the host halves + the composed table + the kernel's functions
+        {
+            SrReplay sr;
+            sr_replay(sr_new, n, tags.data(), tags.size(), dt.data(), dt.size(), sr);
+            std::vector<gr4pm_packet_tag> lt2(dt.begin(), dt.begin() + static_cast<ptrdiff_t>(sr.n_pub));
+            std::vector<uint64_t> resets;
+            for (auto& t : lt2) {
+                t.index *= 2;
+                if (t.kind == GR4PM_PKT_HEADER_START) resets.push_back(t.index);
+            }
+            std::vector<ScrambleRun> runs;
+            CHECK(scramble_runs(scr_new, 2 * sr.produced, resets.data(), resets.size(), runs) == GR4PM_OK, "runs");
+            HpsReplay hp;
+            CHECK(hps_replay(hps_new, 2 * sr.produced, lt2.data(), lt2.size(), ht.data(), pt.data(), ht.size(), hp) == GR4PM_OK, "hps");
+            std::vector<TailSpan> spans;
+            const bool ok = compose_tail(sr.spans, runs, hp, hdr_new.size(), pay_bits_new, spans);
+            CHECK(ok, "compose_tail refused a regular tag stream");
+            hdr_new.resize(hdr_new.size() + hp.n_header);
+            packed_new.resize((pay_bits_new + hp.n_payload + 7) / 8 + 1, 0xAA); // (stale contents behind the stream's end)
+            for (const auto& sp : spans) {
+                if (sp.kind == 0) {
+                    for (unsigned i = 0; i < sp.n_sym; ++i)
+                        tail_llr_pair(x[2 * (sp.src + i)], x[2 * (sp.src + i) + 1], scale, seq.data(), sp.phase + 2ull * i,
+                                      scr_new.prefix, scr_new.period, hdr_new[sp.dst + 2ull * i], hdr_new[sp.dst + 2ull * i + 1]);
+                } else {
+                    for (uint64_t B = sp.dst >> 3; B < (sp.dst + 2ull * sp.n_sym + 7) >> 3; ++B) {
+                        unsigned v, mask;
+                        tail_payload_byte(sp, B, x, scale, seq.data(), scr_new.prefix, scr_new.period, v, mask);
+                        packed_new[B] = mask == 0xFFu ? static_cast<uint8_t>(v) : static_cast<uint8_t>((packed_new[B] & ~mask) | v);
+                    }
+                }
+            }
+            pay_bits_new += hp.n_payload;
+        }
+        start += n;
+    }
+    CHECK(hdr_ref.size() == hdr_new.size() && (hdr_ref.empty() || std::memcmp(hdr_ref.data(), hdr_new.data(), 4 * hdr_ref.size()) == 0),
+          "header LLRs differ (%zu / %zu)", hdr_ref.size(), hdr_new.size());
+    CHECK(pay_bits_new == pay_ref.size() && pay_ref.size() % 8 == 0, "payload stream %llu bits, reference %zu",
+          static_cast<unsigned long long>(pay_bits_new), pay_ref.size());
+    size_t wrong = 0;
+    for (size_t B = 0; B < pay_ref.size() / 8; ++B) {
+        unsigned v = 0;
+        for (int k = 0; k < 8; ++k) v = (v << 1) | (pay_ref[8 * B + static_cast<size_t>(k)] < 0.0f ? 1u : 0u); // k_slice_pack
+        wrong += packed_new[B] != v;
+    }
+    CHECK(wrong == 0, "%zu of %zu packed bytes differ", wrong, pay_ref.size() / 8);
+}
+
 int main(int argc, char** argv)
 {
     const int cases = argc > 1 ? atoi(argv[1]) : 20;
@@ -638,6 +781,7 @@ int main(int argc, char** argv)
         sdf_gate_vs_block(rng);
         symbol_filter(rng);
         control_blocks(rng);
+        tail_compose(rng);
     }
     for (int c = 0; c < std::max(2, cases / 5); ++c) slot_pipeline(rng);
     for (int c = 0; c < std::max(2, cases / 10); ++c) zmtp_pub(rng);

@@ -2891,6 +2891,76 @@ def test_native_packet_receiver_decode_many_batches_pipelined_equals_sequential(
             assert np.array_equal(a["packets"].cpu().numpy(), b["packets"].cpu().numpy())
 
 
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_native_packet_receiver_packets_only_equals_the_full_form(pkg, pipelined):
+    """round 6: gr4pm_packet_receiver_params::packets_only -- SyncwordRemove, the LLR decoder, the descrambler,
+    HeaderPayloadSplit, the slicer and the packer as host state machines + ONE kernel over the Costas loop's output
+    (hostlogic/tail_plan.hpp, k_tail_fused) -- against the full form, which runs the blocks one by one and materialises
+    every stream between them: 300 packets of 1 .. 1500 bytes (their payloads end at every phase of the packer's bytes
+    and of the four-symbol groups), damaged headers and damaged CRCs among them, cut into batches of ragged sizes so that
+    headers and payloads cross batch boundaries at every symbol phase.  Batch by batch: consumed items, every tag list,
+    header messages, packet types, the counts of the streams that are no longer written, packet lengths and packet bytes
+    are identical; every undamaged packet comes back."""
+    rng = np.random.default_rng(61)
+    lengths = [int(v) for v in rng.integers(1, 700, 290)] + [1500, 1499, 1, 2, 3, 4, 5, 6, 7, 8]
+    payloads = [rng.integers(0, 256, n).astype(np.uint8).tobytes() for n in lengths]
+    gaps = rng.integers(300, 2500, len(payloads))
+    x = pkg.BurstGenerator().stream(payloads, gaps, freq_error=0.006, esn0_db=18.0, seed=62)
+    # damage: a burst of strong noise over some headers (invalid_header) and inside some payloads (CRC failure)
+    n_total = x.numel()
+    hit = torch.zeros(n_total, dtype=torch.complex64, device="cuda")
+    g = torch.Generator(device="cuda")
+    g.manual_seed(63)
+    for _ in range(25):
+        at = int(rng.integers(0, n_total - 400))
+        hit[at:at + 300] = torch.complex(torch.randn(300, generator=g, device="cuda"), torch.randn(300, generator=g, device="cuda")) * 2.0
+    x = (x + hit).contiguous()
+    chunks, pos = [], 0
+    while pos + 12000 <= n_total:
+        take = min(int(rng.integers(9000, 70000)), n_total - pos)
+        chunks.append(x[pos:pos + take])
+        pos += ((take - 2048) // 1752 + 1) * 1752
+    assert len(chunks) >= 40
+
+    def run(packets_only):
+        rx = pkg.NativePacketReceiver(max_items=70000, tags_cap=1024, pipelined=pipelined, decode_headers=True,
+                                      packets_only=packets_only)
+        out, announced = [], 0
+        for k, c in enumerate(chunks):
+            while pipelined and announced < min(k + 2, len(chunks) - 1):
+                announced += 1
+                rx.announce(chunks[announced])
+            r = rx.process_bulk(c)
+            if r is not None:
+                out.append(r)
+        return out + rx.flush()
+
+    full, lean = run(False), run(True)
+    assert len(full) == len(lean) == len(chunks)
+    n_ok = n_bad_hdr = n_bad_crc = 0
+    for a, b in zip(full, lean):
+        assert a["consumed"] == b["consumed"] and a["header_mismatches"] == b["header_mismatches"]
+        assert np.array_equal(bits(host(a["symbols"])), bits(host(b["symbols"])))
+        for key in ("tags", "detector_tags", "packet_tags", "llr_tags", "payload_tags"):
+            assert _same_records(a[key], b[key]), key
+        assert _same_records(a["header_messages"], b["header_messages"]) and np.array_equal(a["packet_type"], b["packet_type"])
+        assert a["llr"].numel() == b["n_llr"] and a["payload_llr"].numel() == b["n_payload_llr"]
+        assert b["llr"] is None and b["payload_llr"] is None and b["pdu_symbols"] is None and b["symbol_pdus"].size == 0
+        assert np.array_equal(a["packet_lengths"], b["packet_lengths"])
+        assert np.array_equal(a["packets"].cpu().numpy(), b["packets"].cpu().numpy())
+        n_ok += int(np.sum(b["packet_lengths"] > 0))
+        n_bad_crc += int(np.sum(b["packet_lengths"] == 0))
+        n_bad_hdr += int(np.sum(b["header_messages"]["invalid_header"] != 0))
+    assert n_ok >= len(payloads) - 40 and n_bad_crc >= 3 and n_bad_hdr >= 1, (n_ok, n_bad_crc, n_bad_hdr)
+    got = b"".join(r["packets"].cpu().numpy().tobytes() for r in lean)
+    sent_ok = [p for p in payloads if p in got]
+    assert len(sent_ok) >= n_ok - 5  # (one-byte payloads can also match by accident; the bit-for-bit check is above)
+    with pytest.raises(pkg.Gr4pmError, match="packets_only"):
+        pkg.NativePacketReceiver(max_items=70000, soft_bits=True, packets_only=True)
+    with pytest.raises(pkg.Gr4pmError, match="packets_only"):
+        pkg.NativePacketReceiver(max_items=70000, decode_headers=True, packets_only=True).set_symbol_pdu_callback(lambda k, s: None)
+
+
 @pytest.mark.parametrize("mode", ["one_call", "three_calls", "pipelined"])
 def test_native_packet_receiver_decodes_headers_and_packets(pkg, mode):
     """gr4pm_packet_receiver with decode_headers: the whole receiver inside the C++ library, IQ samples

@@ -6,6 +6,7 @@ O=$R/gpurun_out/${1:-r6_dense}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/tools/r6_dense_kstats.py 12 > $O/plain.txt 2>&1; tail -1 $O/plain.txt
+if [ -n "$R6_LEAN" ]; then echo "(packets_only receiver)"; fi
 rm -rf $O/prof
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/tools/r6_dense_kstats.py 8 > $O/prof_run.txt 2>&1
 tail -1 $O/prof_run.txt
