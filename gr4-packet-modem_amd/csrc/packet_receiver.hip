@@ -920,6 +920,10 @@ gr4pm_status gr4pm_packet_receiver::stage2_decode(Slot& s)
         set_error("out_cap %zu < %zu symbols", s.out_cap, produced);
         return GR4PM_INSUFFICIENT_OUTPUT_ITEMS;
     }
+    {   // the 32-VGPR form of the PLL pays beside a correlator launch of a later batch (see stage2)
+        const bool later_work = n_submitted.load(std::memory_order_relaxed) > s.seq || n_ahead.load(std::memory_order_relaxed) > 0;
+        (void)gr4pm_costas_loop_set_small_footprint(costas, later_work ? costas_form : 0);
+    }
     GR4PM_TRY(gr4pm_costas_loop_process_packets(costas, s.pm.p, produced, s.out_symbols, s.packet_tags.data(), n_pt));
     T2_MARK("costas");
     s.n_symbols = produced;

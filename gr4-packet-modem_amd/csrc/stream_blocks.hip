@@ -562,10 +562,12 @@ struct CostasChain {
     float phase0;
     unsigned pad;
 };
-__global__ void k_costas_chains(const CostasChain* __restrict__ chains, unsigned n_chains,
-                                const CostasPiece* __restrict__ pieces, const CostasState* __restrict__ state,
-                                CostasState* __restrict__ state_next, const cf* __restrict__ in,
-                                cf* __restrict__ out)
+template <int KV>
+__device__ __forceinline__ void costas_chains_body(const CostasChain* __restrict__ chains, unsigned n_chains,
+                                                   const CostasPiece* __restrict__ pieces,
+                                                   const CostasState* __restrict__ state,
+                                                   CostasState* __restrict__ state_next, const cf* __restrict__ in,
+                                                   cf* __restrict__ out)
 {
     const unsigned s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_chains) return;
@@ -581,14 +583,34 @@ __global__ void k_costas_chains(const CostasChain* __restrict__ chains, unsigned
     }
     for (unsigned q = 0; q < ch.n_pieces; ++q) {
         const CostasPiece pc = pieces[ch.piece0 + q];
-        if (pc.constellation == 0) costas_run<0>(in, out, pc.start, pc.len, phase, freq, pc.k1, pc.k2);
-        else if (pc.constellation == 1) costas_run<1>(in, out, pc.start, pc.len, phase, freq, pc.k1, pc.k2);
-        else costas_run<2>(in, out, pc.start, pc.len, phase, freq, pc.k1, pc.k2);
+        if (pc.constellation == 0) costas_run<0, KV>(in, out, pc.start, pc.len, phase, freq, pc.k1, pc.k2);
+        else if (pc.constellation == 1) costas_run<1, KV>(in, out, pc.start, pc.len, phase, freq, pc.k1, pc.k2);
+        else costas_run<2, KV>(in, out, pc.start, pc.len, phase, freq, pc.k1, pc.k2);
     }
     if (ch.last) {
         state_next[0].phase = phase;
         state_next[0].freq = freq;
     }
+}
+template <int KV>
+__global__ void k_costas_chains(const CostasChain* __restrict__ chains, unsigned n_chains,
+                                const CostasPiece* __restrict__ pieces, const CostasState* __restrict__ state,
+                                CostasState* __restrict__ state_next, const cf* __restrict__ in,
+                                cf* __restrict__ out)
+{
+    costas_chains_body<KV>(chains, n_chains, pieces, state, state_next, in, out);
+}
+// The same chains held to 32 VGPRs, as k_costas_cap is (round 6): the decode_headers / soft_bits receivers' PLL -- 121
+// VGPRs in the form above -- could not start beside a correlator workgroup (2 x 240 of a SIMD's 512 registers): each of
+// its one-wave workgroups (one per 64 packets) waited for a compute unit and then kept a correlator workgroup off it for
+// as long as a packet's chain takes.
+__global__ __attribute__((amdgpu_num_vgpr(16))) void k_costas_chains_cap(const CostasChain* __restrict__ chains, unsigned n_chains,
+                                                                      const CostasPiece* __restrict__ pieces,
+                                                                      const CostasState* __restrict__ state,
+                                                                      CostasState* __restrict__ state_next,
+                                                                      const cf* __restrict__ in, cf* __restrict__ out)
+{
+    costas_chains_body<2>(chains, n_chains, pieces, state, state_next, in, out);
 }
 
 // =====================================================================================
@@ -2364,10 +2386,19 @@ try {
     hipStream_t s = h->stream;
     GR4PM_TRY(upload_vec(h->chains, chains, s));
     GR4PM_TRY(upload_vec(h->pieces, pieces, s));
-    if (!timing_skip("costas_chains")) // (EXPERIMENTS builds: GR4PM_TIMING_SKIP=costas_chains, wrong results)
-    hipLaunchKernelGGL(k_costas_chains, dim3(grid_for(chains.size(), 64)), dim3(64), 0, s, h->chains.p,
-                       static_cast<unsigned>(chains.size()), h->pieces.p, h->state.p + h->st_cur,
-                       h->state.p + (h->st_cur ^ 1), reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(out));
+    if (!timing_skip("costas_chains")) { // (EXPERIMENTS builds: GR4PM_TIMING_SKIP=costas_chains, wrong results)
+        // the kernel form as in gr4pm_costas_loop_process: 32 VGPRs beside a correlator launch where the call is long enough
+        static const char* cap_min = gr4pm::experiment_env("GR4PM_COSTAS_CAP_MIN_LOG2", false);
+        const size_t cap_from = size_t{ 1 } << (cap_min ? std::min(40, std::max(0, atoi(cap_min))) : 25);
+        auto launch = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3(grid_for(chains.size(), 64)), dim3(64), 0, s, h->chains.p,
+                               static_cast<unsigned>(chains.size()), h->pieces.p, h->state.p + h->st_cur,
+                               h->state.p + (h->st_cur ^ 1), reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(out));
+        };
+        if (h->small_footprint >= 2 && n >= cap_from) launch(k_costas_chains_cap);
+        else if (h->small_footprint == 1) launch(k_costas_chains<2>);
+        else launch(k_costas_chains<8>);
+    }
     h->st_cur ^= 1;
     GR4PM_HIP_TRY(hipGetLastError());
     GR4PM_HIP_TRY(final_sync(s));

@@ -3112,6 +3112,23 @@ def test_burst_generator_loopback(pkg):
     assert got == payloads
 
 
+def test_tag_driven_costas_chains_in_the_32_register_form():
+    """round 6: k_costas_chains_cap -- the PLL of the soft_bits / decode_headers receivers (tag-driven constellation and
+    loop bandwidth, costas_loop.hpp:52-106) held to 32 VGPRs so that it starts beside a correlator workgroup -- gives the
+    bits of the 121-register form: the chain test against the ORACLE (test_symbol_rate_chain_to_llrs: max |gpu - oracle|
+    = 0) and the receivers' own comparisons, re-run in a process where every CostasLoop takes that form at every size
+    (GR4PM_COSTAS_FORM=2, GR4PM_COSTAS_CAP_MIN_LOG2=0), then once more in the 71-register form"""
+    import subprocess
+    import sys
+    for form in ("2", "1"):
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                            "test_symbol_rate_chain_to_llrs or test_packet_receiver_iq_to_packets or "
+                            "test_native_packet_receiver_packets_only or test_native_packet_receiver_decodes_headers_and_packets"],
+                           capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, GR4PM_COSTAS_FORM=form, GR4PM_COSTAS_CAP_MIN_LOG2="0"))
+        assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("tool,cases,env", [("fuzz_detector.py", 8, {}), ("fuzz_cfc_symf.py", 6, {}), ("fuzz_costas.py", 9, {}),
                                             ("fuzz_costas.py", 9, {"GR4PM_COSTAS_FORM": "1"}),
                                             ("fuzz_costas.py", 12, {"GR4PM_COSTAS_FORM": "2", "GR4PM_COSTAS_CAP_MIN_LOG2": "0"})])
