@@ -17,6 +17,8 @@ struct gr4pm_additive_scrambler;
 struct gr4pm_header_payload_split;
 struct gr4pm_syncword_remove;
 struct gr4pm_constellation_llr_decoder;
+struct gr4pm_costas_loop;
+struct gr4pm_payload_metadata_insert;
 
 namespace gr4pm {
 
@@ -177,6 +179,15 @@ void sd_set_coresident(struct ::gr4pm_syncword_detection* h, bool on); // syncwo
 gr4pm_status slice_pack_two(const float* a, size_t na, const float* b, size_t n_out, uint8_t* out, hipStream_t s);
 // round 6, the packets_only receiver: the host halves of the blocks behind the Costas loop (state advances, tags and span
 // tables as in their process() calls, no kernel) and the one kernel that does their work (header_blocks.hip, k_tail_fused)
+// PayloadMetadataInsert's host half (state, tags, span table; nothing is moved) and the Costas loop reading its input stream
+// through that table: the block's gather folded into the loop's loads
+gr4pm_status payload_metadata_insert_plan(::gr4pm_payload_metadata_insert* h, size_t n_in, size_t out_cap, const gr4pm_tag* tags_in,
+                                          size_t n_tags_in, const gr4pm_header_msg* headers, size_t n_headers, int headers_per_tag,
+                                          gr4pm_packet_tag* tags_out, size_t tags_cap, size_t* n_tags_out, size_t* consumed,
+                                          size_t* produced, size_t* headers_used, size_t* ignored_syncwords,
+                                          std::vector<hostlogic::CopySpan>& spans);
+gr4pm_status costas_loop_process_packets_from(::gr4pm_costas_loop* h, const gr4pm_c64* in, const hostlogic::CopySpan* spans,
+                                              size_t n_spans, size_t n, gr4pm_c64* out, const gr4pm_packet_tag* tags, size_t n_tags);
 gr4pm_status syncword_remove_plan(::gr4pm_syncword_remove* h, size_t n, const gr4pm_packet_tag* tags_in, size_t n_tags_in,
                                   gr4pm_packet_tag* tags_out, size_t tags_cap, size_t* n_tags_out, size_t* produced,
                                   std::vector<hostlogic::CopySpan>& spans);

@@ -77,6 +77,7 @@ struct Slot {
     // packets_only: SyncwordRemove's spans of this batch (stage 2 -> stage 3) and the LLR decoder's scale
     std::vector<hostlogic::CopySpan> sr_spans;
     float llr_scale = 0.0f;
+    std::vector<hostlogic::CopySpan> pm_spans; // decode_headers: PayloadMetadataInsert's spans (the PLL reads through them)
     std::vector<gr4pm_symbol_pdu> pdus;
     size_t pdu_resyncs = 0;
 };
@@ -881,15 +882,16 @@ gr4pm_status gr4pm_packet_receiver::stage2_decode(Slot& s)
         pm_carry_tags.clear();
         pm_carry_hdrs.clear();
     }
-    if (s.pm.n < n + 1) GR4PM_TRY(s.pm.alloc(n + 1));
     if (!p.packets_only && s.data.n < n + 1) GR4PM_TRY(s.data.alloc(n + 1));
     s.packet_tags.resize(3 * s.n_sym_tags + 8);
     s.data_tags.resize(s.packet_tags.size());
     s.llr_tags.resize(s.packet_tags.size());
     size_t n_pt = 0, consumed = 0, produced = 0, used = 0, ignored = 0;
-    GR4PM_TRY(gr4pm_payload_metadata_insert_process(pmi, pmi_in, n, s.pm.p, n + 1, s.sym_tags.data(), s.n_sym_tags,
-                                                    s.hdrs.data(), s.n_sym_tags, 1, s.packet_tags.data(),
-                                                    s.packet_tags.size(), &n_pt, &consumed, &produced, &used, &ignored));
+    // (round 6) PayloadMetadataInsert on the host alone: its output stream is never written -- the Costas loop below reads
+    // the block's INPUT through the span table (one read and one write of the symbol stream less per batch)
+    GR4PM_TRY(gr4pm::payload_metadata_insert_plan(pmi, n, n + 1, s.sym_tags.data(), s.n_sym_tags, s.hdrs.data(), s.n_sym_tags, 1,
+                                                  s.packet_tags.data(), s.packet_tags.size(), &n_pt, &consumed, &produced, &used,
+                                                  &ignored, s.pm_spans));
     if (consumed != n) {
         // PayloadMetadataInsert has reached the payload of a packet whose header is still pending: pass A decodes a
         // header from a 912-item window, and a detection within the last ~848 items of a batch gets its message with
@@ -920,11 +922,15 @@ gr4pm_status gr4pm_packet_receiver::stage2_decode(Slot& s)
         set_error("out_cap %zu < %zu symbols", s.out_cap, produced);
         return GR4PM_INSUFFICIENT_OUTPUT_ITEMS;
     }
-    {   // the 32-VGPR form of the PLL pays beside a correlator launch of a later batch (see stage2)
-        const bool later_work = n_submitted.load(std::memory_order_relaxed) > s.seq || n_ahead.load(std::memory_order_relaxed) > 0;
-        (void)gr4pm_costas_loop_set_small_footprint(costas, later_work ? costas_form : 0);
+    {   // The PLL's kernel form.  Round 6 measured the 32-VGPR form (k_costas_chains_cap, which starts beside a correlator
+        // workgroup) here too: 6.3 - 6.5 ms per 2^28 samples of packets back to back against 5.9 - 6.0 for the 121- and the
+        // 71-register forms, same box (profiles/r6_dense_ab.txt) -- behind PayloadMetadataInsert this stage is the
+        // pipeline's longest, and the slower kernel (2.6 instead of 1.2 ms) lengthens it.  GR4PM_COSTAS_SMALL_DECODE: A/B.
+        static const char* form = experiment_env("GR4PM_COSTAS_SMALL_DECODE", false);
+        (void)gr4pm_costas_loop_set_small_footprint(costas, form ? atoi(form) : 0);
     }
-    GR4PM_TRY(gr4pm_costas_loop_process_packets(costas, s.pm.p, produced, s.out_symbols, s.packet_tags.data(), n_pt));
+    GR4PM_TRY(gr4pm::costas_loop_process_packets_from(costas, pmi_in, s.pm_spans.data(), s.pm_spans.size(), produced,
+                                                      s.out_symbols, s.packet_tags.data(), n_pt));
     T2_MARK("costas");
     s.n_symbols = produced;
     size_t n_dt = 0, n_data = 0, n_lt = 0, n_llr = 0;
@@ -1265,7 +1271,7 @@ try {
         sl.sym_tags.resize(tags_cap + 64);
         if ((st = sl.sym.alloc(sym_cap)) != GR4PM_OK) return bail(st);
         if (p->soft_bits) {
-            if ((st = sl.pm.alloc(sym_cap + 1)) != GR4PM_OK) return bail(st);
+            if (!p->decode_headers && (st = sl.pm.alloc(sym_cap + 1)) != GR4PM_OK) return bail(st); // (decode: the PLL gathers)
             if (!p->packets_only && (st = sl.data.alloc(sym_cap + 1)) != GR4PM_OK) return bail(st);
             if (!p->decode_headers && (st = sl.z.alloc(sym_cap + 1)) != GR4PM_OK) return bail(st);
         }

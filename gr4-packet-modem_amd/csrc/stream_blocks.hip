@@ -550,10 +550,12 @@ __global__ __attribute__((amdgpu_num_vgpr(16))) void k_costas_cap(const CostasSe
 // coefficients (syncword: PILOT, header and payload: QPSK with different bandwidths); phase
 // and frequency flow from piece to piece.  One lane per chain.
 struct CostasPiece {
-    unsigned long long start;
+    unsigned long long start; // first item of the piece in the loop's OUTPUT (= its input stream's index)
+    long long in_off;         // its input items are in[start + in_off ...]: 0, or the gather of the block in front folded in
     unsigned len;
     int constellation;
     float k1, k2;
+    unsigned pad;
 };
 struct CostasChain {
     unsigned piece0, n_pieces;
@@ -583,9 +585,10 @@ __device__ __forceinline__ void costas_chains_body(const CostasChain* __restrict
     }
     for (unsigned q = 0; q < ch.n_pieces; ++q) {
         const CostasPiece pc = pieces[ch.piece0 + q];
-        if (pc.constellation == 0) costas_run<0, KV>(in, out, pc.start, pc.len, phase, freq, pc.k1, pc.k2);
-        else if (pc.constellation == 1) costas_run<1, KV>(in, out, pc.start, pc.len, phase, freq, pc.k1, pc.k2);
-        else costas_run<2, KV>(in, out, pc.start, pc.len, phase, freq, pc.k1, pc.k2);
+        const cf* src = in + pc.in_off;
+        if (pc.constellation == 0) costas_run<0, KV>(src, out, pc.start, pc.len, phase, freq, pc.k1, pc.k2);
+        else if (pc.constellation == 1) costas_run<1, KV>(src, out, pc.start, pc.len, phase, freq, pc.k1, pc.k2);
+        else costas_run<2, KV>(src, out, pc.start, pc.len, phase, freq, pc.k1, pc.k2);
     }
     if (ch.last) {
         state_next[0].phase = phase;
@@ -2322,6 +2325,20 @@ GR4PM_ABI_CATCH
 gr4pm_status gr4pm_costas_loop_process_packets(gr4pm_costas_loop* h, const gr4pm_c64* in, size_t n,
                                                gr4pm_c64* out, const gr4pm_packet_tag* tags, size_t n_tags)
 try {
+    return gr4pm::costas_loop_process_packets_from(h, in, nullptr, 0, n, out, tags, n_tags);
+}
+GR4PM_ABI_CATCH
+
+} // extern "C"
+
+// (library-internal: csrc/packet_receiver.hip) gr4pm_costas_loop_process_packets with the gather of the block in front
+// folded in (round 6): the loop's input stream is not in memory as such -- item i of it is `in[spans[k].src + (i -
+// spans[k].dst)]` for the span that holds i (PayloadMetadataInsert's span table, ascending, covering [0, n)).  Saves that
+// block's gather: a read and a write of the whole symbol stream.  spans == nullptr: the stream is `in` itself.
+gr4pm_status gr4pm::costas_loop_process_packets_from(gr4pm_costas_loop* h, const gr4pm_c64* in, const hostlogic::CopySpan* spans,
+                                                     size_t n_spans, size_t n, gr4pm_c64* out, const gr4pm_packet_tag* tags,
+                                                     size_t n_tags)
+{
     if (!h) return GR4PM_ERR_INVALID;
     if (h->n_channels != 1) {
         set_error("process_packets needs a single-channel CostasLoop");
@@ -2338,16 +2355,34 @@ try {
     cur.piece0 = 0;
     cur.mode = 0;
     size_t pos = 0;
+    size_t span_at = 0; // cursor into spans (pieces are closed in ascending order)
     auto close_piece = [&](size_t end) {
-        if (end <= pos) return;
-        CostasPiece pc{};
-        pc.start = pos;
-        pc.len = static_cast<unsigned>(end - pos);
-        pc.constellation = h->constellation;
-        pc.k1 = h->k1;
-        pc.k2 = h->k2;
-        pieces.push_back(pc);
-        pos = end;
+        while (pos < end) {
+            size_t stop = end;
+            long long in_off = 0;
+            if (spans) {
+                while (span_at < n_spans && spans[span_at].dst + spans[span_at].len <= pos) ++span_at;
+                if (span_at >= n_spans || spans[span_at].dst > pos) { // (a hole in the table: the caller's error)
+                    pos = end;
+                    span_at = n_spans + 1;
+                    return;
+                }
+                stop = std::min<size_t>(end, spans[span_at].dst + spans[span_at].len);
+                in_off = static_cast<long long>(spans[span_at].src) - static_cast<long long>(spans[span_at].dst);
+            }
+            while (pos < stop) { // (len is 32 bits wide)
+                const size_t m = std::min<size_t>(stop - pos, 1u << 30);
+                CostasPiece pc{};
+                pc.start = pos;
+                pc.in_off = in_off;
+                pc.len = static_cast<unsigned>(m);
+                pc.constellation = h->constellation;
+                pc.k1 = h->k1;
+                pc.k2 = h->k2;
+                pieces.push_back(pc);
+                pos += m;
+            }
+        }
     };
     auto close_chain = [&]() {
         cur.n_pieces = static_cast<unsigned>(pieces.size()) - cur.piece0;
@@ -2381,6 +2416,10 @@ try {
     }
     close_piece(n);
     close_chain();
+    if (span_at > n_spans) {
+        set_error("process_packets: the span table does not cover the stream");
+        return GR4PM_ERR_INVALID;
+    }
     if (chains.empty()) return GR4PM_OK;
     chains.back().last = 1;
     hipStream_t s = h->stream;
@@ -2404,9 +2443,6 @@ try {
     GR4PM_HIP_TRY(final_sync(s));
     return GR4PM_OK;
 }
-GR4PM_ABI_CATCH
-
-} // extern "C"
 
 // ------------------------------------------------------------------------ SyncwordWipeoff
 struct gr4pm_syncword_wipeoff {
@@ -3479,6 +3515,36 @@ static gr4pm_status llr_runs(gr4pm_constellation_llr_decoder* h, size_t n, size_
     }
     return GR4PM_OK;
 }
+// (library-internal) PayloadMetadataInsert::processBulk's host half: the state machine over the tags (hostlogic/packet_control.hpp)
+gr4pm_status gr4pm::payload_metadata_insert_plan(gr4pm_payload_metadata_insert* h, size_t n_in, size_t out_cap,
+                                                 const gr4pm_tag* tags_in, size_t n_tags_in, const gr4pm_header_msg* headers,
+                                                 size_t n_headers, int headers_per_tag, gr4pm_packet_tag* tags_out, size_t tags_cap,
+                                                 size_t* n_tags_out, size_t* consumed, size_t* produced, size_t* headers_used,
+                                                 size_t* ignored_syncwords, std::vector<hostlogic::CopySpan>& spans)
+{
+    if (!h || !n_tags_out || !consumed || !produced || !headers_used || !ignored_syncwords) return GR4PM_ERR_INVALID;
+    *n_tags_out = *consumed = *produced = *headers_used = *ignored_syncwords = 0;
+    spans.clear();
+    if (headers_per_tag && n_headers != n_tags_in) {
+        set_error("headers_per_tag needs one message per tag (%zu != %zu)", n_headers, n_tags_in);
+        return GR4PM_ERR_INVALID;
+    }
+    if (n_in == 0) return GR4PM_OK;
+    hostlogic::PmiReplay rp;
+    GR4PM_TRY(hostlogic::pmi_replay(*h, n_in, out_cap, tags_in, n_tags_in, headers, n_headers, headers_per_tag, tags_out,
+                                    tags_cap, rp));
+    spans.swap(rp.spans);
+    *n_tags_out = rp.n_pub;
+    *consumed = rp.consumed;
+    *produced = rp.produced;
+    *headers_used = rp.headers_used;
+    *ignored_syncwords = rp.ignored;
+    if (rp.tag_overflow) {
+        set_error("tags_cap too small");
+        return GR4PM_ERR_OVERFLOW;
+    }
+    return GR4PM_OK;
+}
 // (library-internal: csrc/packet_receiver.hip, the packets_only receiver) the host halves alone: state, tags, spans
 gr4pm_status gr4pm::syncword_remove_plan(gr4pm_syncword_remove* h, size_t n, const gr4pm_packet_tag* tags_in, size_t n_tags_in,
                                          gr4pm_packet_tag* tags_out, size_t tags_cap, size_t* n_tags_out, size_t* produced,
@@ -3556,53 +3622,18 @@ gr4pm_status gr4pm_payload_metadata_insert_process(
 try {
     if (!h || !n_tags_out || !consumed || !produced || !headers_used || !ignored_syncwords) return GR4PM_ERR_INVALID;
     *n_tags_out = *consumed = *produced = *headers_used = *ignored_syncwords = 0;
-    if (headers_per_tag && n_headers != n_tags_in) {
-        set_error("headers_per_tag needs one message per tag (%zu != %zu)", n_headers, n_tags_in);
-        return GR4PM_ERR_INVALID;
-    }
-    if (n_in == 0) return GR4PM_OK;
-    if (!in || !out) {
+    if (n_in && (!in || !out)) {
         set_error("null sample pointer");
         return GR4PM_ERR_INVALID;
     }
-#ifdef GR4PM_TIMING
-    const auto t_pmi0 = std::chrono::steady_clock::now();
-#endif
-    gr4pm::hostlogic::PmiReplay rp; // the state machine: hostlogic/packet_control.hpp
-    GR4PM_TRY(gr4pm::hostlogic::pmi_replay(*h, n_in, out_cap, tags_in, n_tags_in, headers, n_headers, headers_per_tag,
-                                           tags_out, tags_cap, rp));
-    const std::vector<CopySpan>& spans = rp.spans;
-    const size_t n_pub = rp.n_pub, hdr = rp.headers_used, ignored = rp.ignored, ipos = rp.consumed, opos = rp.produced;
-    const bool tag_overflow = rp.tag_overflow;
-#ifdef GR4PM_TIMING
-    const auto t_pmi1 = std::chrono::steady_clock::now();
-#endif
+    std::vector<CopySpan> spans;
+    const gr4pm_status st = gr4pm::payload_metadata_insert_plan(h, n_in, out_cap, tags_in, n_tags_in, headers, n_headers,
+                                                                headers_per_tag, tags_out, tags_cap, n_tags_out, consumed,
+                                                                produced, headers_used, ignored_syncwords, spans);
+    if (st != GR4PM_OK && st != GR4PM_ERR_OVERFLOW) return st;
     GR4PM_TRY(launch_gather(h->stream, h->spans, spans, reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(out)));
     GR4PM_HIP_TRY(final_sync(h->stream));
-#ifdef GR4PM_TIMING
-    {
-        static double a = 0, b = 0;
-        static int n = 0;
-        const auto t_pmi2 = std::chrono::steady_clock::now();
-        a += std::chrono::duration<double, std::micro>(t_pmi1 - t_pmi0).count();
-        b += std::chrono::duration<double, std::micro>(t_pmi2 - t_pmi1).count();
-        if (++n % 64 == 0) {
-            fprintf(stderr, "[gr4pm timing] PayloadMetadataInsert: replay %.0f us, upload + launch %.0f us, %zu spans (mean of 64)\n",
-                    a / 64, b / 64, spans.size());
-            a = b = 0;
-        }
-    }
-#endif
-    *n_tags_out = n_pub;
-    *consumed = ipos;
-    *produced = opos;
-    *headers_used = hdr;
-    *ignored_syncwords = ignored;
-    if (tag_overflow) {
-        set_error("tags_cap too small");
-        return GR4PM_ERR_OVERFLOW;
-    }
-    return GR4PM_OK;
+    return st;
 }
 GR4PM_ABI_CATCH
 
