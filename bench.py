@@ -849,7 +849,7 @@ def host_stream_leg(pkg, device, rrc, chunk=1 << 25, host_chunks=4, total=1 << 2
             "note": "PCIe-inclusive; not `value` (inputs of the headline are resident in HBM when the timed region starts)"}
 
 
-def sparse_leg(pkg, device, rrc, n=1 << 28, passes=20):
+def sparse_leg(pkg, device, rrc, n=1 << 28, passes=48):
     """What packet density does to the rate (never `value`): the whole receiver in decode_headers mode -- the reference's
     PacketReceiver wiring, IQ in, CRC-checked packets out; what benchmarks/benchmark_packet_receiver.cpp runs -- over 2^28
     resident samples of (i) zeros (that benchmark's own input, benchmarks/README.md:49-53, results.md:45-51: 6-8 Msps
@@ -894,8 +894,10 @@ def sparse_leg(pkg, device, rrc, n=1 << 28, passes=20):
         ring[1 + hist:] = x
         w, history = ring[1 + hist:], ring[1:1 + hist]
         del x
+        # round 6: packets_only -- what the reference's benchmark measures is packets out; the streams between the Costas loop
+        # and the packer are not written to memory (include/gr4pm_hip.h; same packets as the full form, tests)
         rx = pkg.NativePacketReceiver(SPS, BINS, 9.5, "QPSK", max_items=n, tags_cap=max(4096, 4 * n_pkt), pipelined=True,
-                                      decode_headers=True, output_ring=True)
+                                      decode_headers=True, output_ring=True, packets_only=True)
         stats = {"consumed": 0, "tags": 0, "packets_crc_ok": 0}
 
         def note(r):
@@ -911,13 +913,23 @@ def sparse_leg(pkg, device, rrc, n=1 << 28, passes=20):
                 note(rx.process_bulk(w, None, history=history))
             for r in rx.flush():
                 note(r)
+
+        def timed(k):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run(k)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
         run(2)
+        # The receiver is a pipeline of six stages (detector | pass A | gate + plan | symbol filter | PayloadMetadataInsert +
+        # PLL | header loop + payload tail): a run of k passes costs k steady-state periods + one fill / drain of the
+        # pipeline (~ 3 periods on packets back to back).  Two run lengths separate the two: `value` is the longer run
+        # as a whole (drain included), `steady_state_ms_per_2^28` the difference quotient.
+        short = max(4, passes // 3)
+        dt_short = timed(short)
         stats = {"consumed": 0, "tags": 0, "packets_crc_ok": 0}
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        run(passes)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        dt = timed(passes)
+        steady = (dt - dt_short) / (passes - short)
         del rx
         sd = pkg.SyncwordDetection(rrc, SYNCWORD, bpsk, -BINS, BINS, power_threshold=9.5, max_items=n)
         for _ in range(2):
@@ -937,11 +949,13 @@ def sparse_leg(pkg, device, rrc, n=1 << 28, passes=20):
         if n_pkt and stats["packets_crc_ok"] < passes * (n_pkt - 2) * (0.99 if kind == "dense_packets" else 1.0):
             raise SystemExit(f"bench.py: sparse leg {kind}: {stats['packets_crc_ok']} of {passes * n_pkt} packets came back")
         rows[kind] = {"value": round(stats["consumed"] / dt / 1e6, 2), "unit": "Msamples/s",
-                      "ms_per_2^28": round(dt / passes * 1e3, 3), "tags_per_2^28": stats["tags"] // passes,
+                      "ms_per_2^28": round(dt / passes * 1e3, 3), "passes": passes,
+                      "steady_state_ms_per_2^28": round(steady * 1e3, 3),
+                      "fill_and_drain_ms": round((dt - passes * steady) * 1e3, 2), "tags_per_2^28": stats["tags"] // passes,
                       "packets_crc_ok_per_2^28": stats["packets_crc_ok"] // passes,
                       "detector_alone": round(stats["consumed"] / dt_sd / 1e6, 2),
                       "behind_the_detector_share": round(max(0.0, 1.0 - dt_sd / dt), 3)}
-    return {"workload": "whole receiver (decode_headers: IQ in, CRC-checked packets out), 2^28 resident samples per pass, "
+    return {"workload": "whole receiver (decode_headers, packets_only form: IQ in, CRC-checked packets out), 2^28 resident samples per pass, "
                         "nine templates: zeros (the reference's benchmark_packet_receiver input) / AWGN only / one "
                         "1500-byte packet per 2^20 samples / 1500-byte packets back to back (500-symbol gaps)",
             "reference_benchmark_packet_receiver_msps_ryzen_5800x": "6-8 (nine templates) ... 28-32 (one)",

@@ -43,8 +43,13 @@ inline gr4pm_status pmi_replay(PmiState& h, size_t n_in, size_t out_cap, const g
         ++n_pub;
     };
     size_t ipos = 0, opos = 0; // items consumed / produced so far
+    spans.reserve(n_tags_in + 8);
     auto pass = [&](size_t want) { // move up to `want` items from the input to the output
-        spans.push_back({ ipos, opos, want });
+        // (syncword, header and payload of a packet follow each other on both sides: one span, not three)
+        if (want && !spans.empty() && spans.back().src + spans.back().len == ipos && spans.back().dst + spans.back().len == opos)
+            spans.back().len += want;
+        else
+            spans.push_back({ ipos, opos, want });
         ipos += want;
         opos += want;
         h.position += want;

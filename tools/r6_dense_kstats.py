@@ -33,14 +33,29 @@ rx = pkg.NativePacketReceiver(SPS, BINS, 9.5, "QPSK", max_items=n, tags_cap=4 * 
                               output_ring=True, **kw)
 
 
+T = {"announce": 0.0, "submit": 0.0, "collect": 0.0, "python": 0.0}
+
+
 def run(k):
+    """the caller's thread, piece by piece (R6_CALLER_TIMES=1 prints where it spends a pass)"""
     ok = 0
+    depth = 5
     for i in range(k):
+        t0 = time.perf_counter()
         if i + 1 < k:
             rx.announce(w)
-        r = rx.process_bulk(w, None, history=history)
+        t1 = time.perf_counter()
+        rx.submit(w, None, history, None)
+        t2 = time.perf_counter()
+        r = rx.collect() if pkg.lib().gr4pm_packet_receiver_inflight(rx._h) > depth else None
+        t3 = time.perf_counter()
         if r is not None:
             ok += int(np.sum(r["packet_lengths"] > 0))
+        t4 = time.perf_counter()
+        T["announce"] += t1 - t0
+        T["submit"] += t2 - t1
+        T["collect"] += t3 - t2
+        T["python"] += t4 - t3
     for r in rx.flush():
         ok += int(np.sum(r["packet_lengths"] > 0))
     return ok
@@ -53,4 +68,6 @@ k = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 ok = run(k)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
+if os.environ.get("R6_CALLER_TIMES"):
+    print("caller thread, ms per pass:", {a: round(b / (k + 2) * 1e3, 3) for a, b in T.items()})
 print(f"{k} passes: {dt / k * 1e3:.3f} ms per 2^28, {k * n / dt / 1e9:.2f} Gsps, {ok} of {k * n_pkt} packets")
