@@ -902,7 +902,7 @@ def sparse_leg(pkg, device, rrc, n=1 << 28, passes=48):
         # round 6: packets_only -- what the reference's benchmark measures is packets out; the streams between the Costas loop
         # and the packer are not written to memory (include/gr4pm_hip.h; same packets as the full form, tests)
         rx = pkg.NativePacketReceiver(SPS, BINS, 9.5, "QPSK", max_items=n, tags_cap=max(4096, 4 * n_pkt), pipelined=True,
-                                      decode_headers=True, output_ring=True, packets_only=True)
+                                      decode_headers=True, output_ring=True, packets_only=True, result_fields="packets")
         stats = {"consumed": 0, "tags": 0, "packets_crc_ok": 0}
 
         def note(r):

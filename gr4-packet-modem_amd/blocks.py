@@ -1657,12 +1657,17 @@ class NativePacketReceiver:
 
     def __init__(self, samples_per_symbol=4, syncword_freq_bins=4, syncword_threshold=9.5,
                  costas_constellation="QPSK", max_items=1 << 22, tags_cap=4096, pipelined=False, soft_bits=False,
-                 decode_headers=False, output_ring=False, packets_only=False):
-        """packets_only (a form of decode_headers; include/gr4pm_hip.h): IQ in, CRC-checked packets out, the stream between
+                 decode_headers=False, output_ring=False, packets_only=False, result_fields="all"):
+        """result_fields="packets" (decode_headers): collect() marshals only what a packet sink needs -- consumed, the accepted
+        detections' tags, header messages, packet lengths and bytes -- and leaves the per-symbol tag lists (tens of thousands
+        of 96-byte records per batch on a packet-dense stream) in the library; "all": everything the C result holds.
+        packets_only (a form of decode_headers; include/gr4pm_hip.h): IQ in, CRC-checked packets out, the stream between
         the Costas loop and the packer never written to memory -- the same packets / header messages / tags; the result
         has no "llr", "payload_llr" and "pdu_symbols" arrays (None)"""
         soft_bits = soft_bits or decode_headers
         self.packets_only = bool(packets_only)
+        assert result_fields in ("all", "packets")
+        self.result_fields = result_fields
         self.output_ring = output_ring
         self.samples_per_symbol, self.pipelined, self.soft_bits = samples_per_symbol, pipelined, soft_bits
         self.decode_headers = decode_headers
@@ -1740,6 +1745,14 @@ class NativePacketReceiver:
             buf = (C.c_char * (n * dtype.itemsize)).from_address(ptr)
             return np.frombuffer(buf, dtype=dtype, count=n).copy()
 
+        if self.result_fields == "packets" and self.decode_headers:
+            res = {"status": 0, "consumed": r.consumed, "symbols": sym[: r.n_symbols], "tags": records(r.tags, r.n_tags, TAG_DTYPE),
+                   "n_detector_tags": int(r.n_detector_tags), "n_packet_tags": int(r.n_packet_tags),
+                   "header_messages": records(r.header_messages, r.n_header_messages, _abi.HEADER_MSG_DTYPE),
+                   "header_mismatches": r.header_mismatches, "packets": pk[: r.n_packet_bytes],
+                   "packet_lengths": records(r.packet_lengths, r.n_packets, np.dtype(np.uint64))}
+            res["crc_ok"] = res["packet_lengths"] > 0
+            return res
         res = {"status": 0, "consumed": r.consumed, "symbols": sym[: r.n_symbols],
                "tags": records(r.tags, r.n_tags, TAG_DTYPE),
                "detector_tags": records(r.detector_tags, r.n_detector_tags, TAG_DTYPE),

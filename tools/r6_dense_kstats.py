@@ -28,7 +28,9 @@ ring[1:1 + hist] = x[-hist:]
 ring[1 + hist:] = x
 w, history = ring[1 + hist:], ring[1:1 + hist]
 del x
-kw = {"packets_only": True} if os.environ.get("R6_LEAN") else {}
+kw = {"packets_only": True} if os.environ.get("R6_LEAN", "0") != "0" else {}
+if os.environ.get("R6_FIELDS"):
+    kw["result_fields"] = os.environ["R6_FIELDS"]
 rx = pkg.NativePacketReceiver(SPS, BINS, 9.5, "QPSK", max_items=n, tags_cap=4 * n_pkt, pipelined=True, decode_headers=True,
                               output_ring=True, **kw)
 
