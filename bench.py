@@ -968,6 +968,29 @@ def sparse_leg(pkg, device, rrc, n=1 << 28, passes=48):
             "note": "not `value`: the headline is the packet-dense stream of configs[1]"}
 
 
+def sparse_leg_in_a_fresh_process():
+    """The `sparse` sub-record from a child process (`bench.py --sparse-leg-only`, started the way cpu_baseline starts its
+    workers: a child, never an exec of this process).  Round 6: in THIS process -- minutes of allocating and freeing
+    multi-GiB device buffers behind it -- the packet-dense stream ran at 45 - 52 Gsps depending on which legs had run
+    before it (47 after the host-stream leg, 57 right behind config 5's allocate-and-free of 8 GiB), in a process of its
+    own at 56 - 57: the leg's streaming kernels depend on how the device memory they get is laid out, and a receiver in
+    production is a process that allocates its buffers once.  The parent keeps its context but releases its cached blocks."""
+    import gc
+    import subprocess
+    gc.collect()
+    torch.cuda.empty_cache()
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--sparse-leg-only"], capture_output=True, text=True, env=env)
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise SystemExit(f"bench.py: the sparse leg's child process failed ({r.returncode}):\n{r.stdout[-1500:]}\n{r.stderr[-3000:]}")
+    rec = json.loads(lines[-1])
+    rec["measured_in"] = "a child process of its own (bench.py --sparse-leg-only)"
+    return rec
+
+
 def headline_ring(x, xb):
     """the headline's device ring [.. | window A | window B]: two different stretches of the burst stream that the steps
     present alternately, each preceded in memory by the 2T+1 items "before" it (for A: a copy of B's tail, for B: A's
@@ -1266,6 +1289,8 @@ def main():
     ap.add_argument("--no-per-bins", action="store_true",
                     help="leave out the roofline.per_bins legs (profiling runs: the correlator's rocprof average is then "
                          "the nine-bin launch alone)")
+    ap.add_argument("--sparse-leg-only", action="store_true",
+                    help="(what the default run starts as a child process) the packet-density sub-record alone, printed as JSON")
     ap.add_argument("--selfcheck", action="store_true",
                     help="N-rank first-contact check only (rendezvous, identities, a small scatter, two batches): what "
                          "`bench.py --gpus N` runs by itself before the job")
@@ -1285,6 +1310,12 @@ def main():
                          f"for a different GPU count")
     if args.dry_run:
         return dry_run(args)
+    if args.sparse_leg_only:
+        pkg = ge.load_package()
+        torch.cuda.set_device(0)
+        sys.setswitchinterval(float(os.environ.get("GR4PM_SWITCH_INTERVAL", "5e-5")))
+        print(json.dumps(sparse_leg(pkg, torch.device("cuda", 0), unit_norm_rrc(pkg))))
+        return None
     if args.config == 5:
         return config5(args)
     if args.lookahead_depth is None:
@@ -1548,7 +1579,7 @@ def main():
     # ---- packet density: the whole receiver on zeros / AWGN / one packet per 2^20 samples (N = 1 only; never `value`)
     sparse_rec = None
     if headline and not args.no_sparse_leg and world == 1:
-        sparse_rec = sparse_leg(pkg, device, rrc)
+        sparse_rec = sparse_leg_in_a_fresh_process()
         torch.cuda.empty_cache()
     job = rank_identities(dist, device, world)
     check_distinct_devices(job, world)

@@ -12,6 +12,19 @@ import __graft_entry__ as g
 pkg = g.load_package()
 SPS, BINS = 4, 4
 n = 1 << 28
+if os.environ.get("R6_CHURN"):
+    # what a long-lived process looks like to the device allocator: GiB-sized blocks allocated and freed out of order
+    rng0 = np.random.default_rng(1)
+    blocks = [torch.empty(int(rng0.integers(1 << 26, 1 << 31)), dtype=torch.uint8, device="cuda") for _ in range(48)]
+    for i in rng0.permutation(48)[:30]:
+        blocks[i] = None
+    torch.cuda.empty_cache()
+    small = [torch.empty(int(rng0.integers(1 << 20, 1 << 27)), dtype=torch.uint8, device="cuda") for _ in range(200)]
+    del small
+    keep = [b for b in blocks if b is not None]
+    if os.environ["R6_CHURN"] == "2":
+        del keep, blocks
+        torch.cuda.empty_cache()
 gen = pkg.BurstGenerator()
 burst = (64 + 128 + 1504 * 4 + gen.RAMP_DOWN + gen.FLUSH) * SPS
 period = burst + 500 * SPS
