@@ -973,8 +973,10 @@ def sparse_leg_in_a_fresh_process():
     workers: a child, never an exec of this process).  Round 6: in THIS process -- minutes of allocating and freeing
     multi-GiB device buffers behind it -- the packet-dense stream ran at 45 - 52 Gsps depending on which legs had run
     before it (47 after the host-stream leg, 57 right behind config 5's allocate-and-free of 8 GiB), in a process of its
-    own at 56 - 57: the leg's streaming kernels depend on how the device memory they get is laid out, and a receiver in
-    production is a process that allocates its buffers once.  The parent keeps its context but releases its cached blocks."""
+    own at 56 - 57 (tools/r6_leg_ab.sh).  The cause is NOT established: allocating and freeing GiB-sized blocks out of order in
+    a fresh process did not reproduce it (tools/r6_dense_kstats.py, R6_CHURN: 55.9 - 56.6 Gsps with and without).  What a
+    receiver in production is -- a process that allocates its buffers once -- is what the child process measures; the
+    parent keeps its context and releases its cached blocks first."""
     import gc
     import subprocess
     gc.collect()
