@@ -13,10 +13,12 @@ P3="GRBM_GUI_ACTIVE SQ_INST_LEVEL_LDS SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_
 i=0
 for P in "$P1" "$P2" "$P3" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/p$i -- python3 tools/bench_correlate.py $ITEMS 3 $BINS > $OUT/p$i.log 2>&1
+  WARM=2 timeout 300 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/p$i -- python3 tools/bench_correlate.py $ITEMS 3 $BINS > $OUT/p$i.log 2>&1
   echo "pass $i rc=$?"
 done
 python3 tools/pmc_summary.py k_correlate $OUT/summary.json $OUT/p1 $OUT/p2 $OUT/p3 $OUT/p4 $OUT/p5 > /dev/null
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 tools/bench_correlate.py $ITEMS 5 $BINS > $OUT/stats.log 2>&1
+# kernel statistics of WARM launches (round 6: 30 untimed launches, then 40; the first launches after host work run at the
+# clocks the chip idles at -- bench.py's ROOF_WARM -- and round 5's file averaged six of those)
+WARM=30 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 tools/bench_correlate.py $ITEMS 40 $BINS > $OUT/stats.log 2>&1
 tail -2 $OUT/stats.log
 cat $OUT/summary.json | head -80
