@@ -454,6 +454,12 @@ def scatter_budget(dist, rank, world, per_rank_bytes, device, host_ring):
             free_host = psutil.virtual_memory().available
         except ImportError:
             free_host = 1 << 62
+        # (tests only: what the check sees as available host / free device memory, so that the refusal is exercised at
+        # configs[3]'s real size on machines that do have the memory)
+        if os.environ.get("GR4PM_BENCH_TEST_HOST_AVAILABLE"):
+            free_host = int(os.environ["GR4PM_BENCH_TEST_HOST_AVAILABLE"])
+        if os.environ.get("GR4PM_BENCH_TEST_DEVICE_FREE"):
+            free_dev = int(os.environ["GR4PM_BENCH_TEST_DEVICE_FREE"])
         msg = (f"scatter budget on rank 0: device {need_dev / 2**30:.1f} GiB needed / {free_dev / 2**30:.1f} GiB free, "
                f"host {need_host / 2**30:.1f} GiB needed / {free_host / 2**30:.1f} GiB available")
         print("bench.py:", msg, file=sys.stderr)
@@ -1291,6 +1297,9 @@ def main():
     ap.add_argument("--no-per-bins", action="store_true",
                     help="leave out the roofline.per_bins legs (profiling runs: the correlator's rocprof average is then "
                          "the nine-bin launch alone)")
+    ap.add_argument("--config3-items", type=int, default=1 << 22,
+                    help="samples per channel and batch of the 64-channels-per-GPU leg (configs[2] / configs[3]: 2^22; tests "
+                         "cut the ring down in items, never in shape)")
     ap.add_argument("--sparse-leg-only", action="store_true",
                     help="(what the default run starts as a child process) the packet-density sub-record alone, printed as JSON")
     ap.add_argument("--selfcheck", action="store_true",
@@ -1565,7 +1574,7 @@ def main():
     if headline and not args.no_channels_leg:
         rx = None  # the headline receiver is done: its stage threads and streams go before the next leg starts
         channels_leg = channels64_leg(pkg, dist, device, rank, world, rrc, steps=max(args.steps, 50), warmup=6,
-                                      repeats=min(args.repeats, 3))
+                                      repeats=min(args.repeats, 3), n_items=args.config3_items)
     # ---- BASELINE configs[4] (the 2-Gsps stress shape) as a sub-record of the default line, N = 1 only
     config5_rec = None
     if headline and not args.no_config5_leg and world == 1:

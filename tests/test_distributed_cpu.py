@@ -168,3 +168,37 @@ def test_bench_rank_that_dies_inside_the_job_still_ends_it():
     r = _run_bench(["--gpus", "2", "--dry-run"], {"GR4PM_BENCH_TEST_FAIL_RANK": "0", "GR4PM_BENCH_TEST_FAIL_IN_JOB": "1"})
     assert r.returncode != 0 and "self-check failed" not in r.stderr and "stopping the other ranks" in r.stderr
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def _budget_worker(rank, world, port, out, host_available):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      GR4PM_BENCH_TEST_HOST_AVAILABLE=str(host_available))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    try:
+        # configs[3]'s real slab: 64 channels x 2^22 samples x 8 bytes per rank, rank 0's pinned host ring holds `world` of them
+        bench.scatter_budget(dist, rank, world, 64 * (1 << 22) * 8, torch.device("cpu"), host_ring=True)
+        out[rank] = "passed"
+    except SystemExit as e:
+        out[rank] = str(e)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("host_gib,fits", [(64, True), (16, False)])
+def test_scatter_budget_refuses_the_config3_ring_on_every_rank_before_anything_is_allocated(host_gib, fits):
+    """configs[3] at N = 8: rank 0's pinned host sample ring is 8 x 64 x 2^22 x 8 B = 17.2 GB.  The budget check runs before
+    any allocation and its verdict reaches every rank (broadcast): with 64 GiB available all eight ranks go on, with 16 GiB
+    all eight leave with the same message -- nobody hangs in a scatter that rank 0 cannot feed.  (The first real 8-GPU
+    run should fail on nothing but hardware.)"""
+    world = 8
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_budget_worker, args=(world, _free_port(), out, host_gib << 30), nprocs=world, join=True)
+    assert len(out) == world
+    for r in range(world):
+        if fits:
+            assert out[r] == "passed", out[r]
+        else:
+            assert "cannot hold the sample ring of 8 ranks" in out[r] and "host 16.0 GiB needed / 16.0 GiB available" in out[r], out[r]
+

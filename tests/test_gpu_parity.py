@@ -3453,6 +3453,55 @@ def test_bench_two_ranks_share_the_gpu_through_the_whole_n_gt_1_path(launcher):
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(1500)
+def test_bench_eight_ranks_share_the_gpu_with_the_config3_ring_shape():
+    """the N = 8 job of BASELINE configs[3] as far as ONE GPU allows -- eight ranks started by
+    torch.distributed.run, all on cuda:0, gloo instead of RCCL (GR4PM_BENCH_SHARED_DEVICE_TEST=1): rendezvous, eight
+    identities, the self-check, the headline regions with MAX / SUM aggregation over eight ranks, then the configs[3] leg
+    with the ring in its real SHAPE -- rank 0's host sample ring [8, 64, n] scattered as eight [64, n] slabs, 512 channels
+    in all -- cut down in items only (n = 2^16 per channel instead of 2^22).  One line for eight ranks.  Then the same job
+    where rank 0 is told it has too little host memory for the ring: every rank leaves with the budget's message and the
+    launcher reports it, nobody hangs in the scatter."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n3 = 1 << 16
+    args = ["--gpus", "8", "--steps", "2", "--warmup", "1", "--repeats", "1", "--items", str(1 << 22), "--no-cpu-baseline",
+            "--config3-items", str(n3)]
+    env = dict(os.environ, GR4PM_BENCH_SHARED_DEVICE_TEST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+
+    def run(extra_env):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py")] + args
+        return subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=dict(env, **extra_env), cwd=root)
+
+    r = run({})
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["scaling"] == "weak" and "shared_device_test" in rec
+    assert rec["job"]["world"] == 8 and [x["rank"] for x in rec["job"]["ranks"]] == list(range(8))
+    assert len(rec["ms_per_step_per_rank"]) == 8
+    c3 = rec["config3"]
+    assert "512 channels in all" in c3["workload"] and c3["value"] > 0 and len(c3["ms_per_step_per_rank"]) == 8
+    assert c3["scatter"]["bytes_from_rank0"] == 7 * 8 * 64 * n3  # seven slabs leave rank 0
+    # the ring at its real size would be 8 x 64 x 2^22 x 8 B = 17.2 GB of pinned host memory: refused, by every rank, when
+    # rank 0 does not have it (here: told so)
+    r = run({"GR4PM_BENCH_TEST_HOST_AVAILABLE": str(1 << 20)})
+    assert r.returncode != 0 and "cannot hold the sample ring of 8 ranks" in r.stderr, r.stderr[-3000:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.gpu
 def test_bench_collectives_over_rccl_with_one_rank():
     """RCCL itself, as far as one GPU reaches: a one-rank "nccl" group (init_process_group with device_id and the
     bounded timeout, as bench.init_ranks makes it) carries every collective bench.py uses -- all_gather_object for the
