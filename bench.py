@@ -1610,7 +1610,7 @@ def main():
                 sd = pkg.SyncwordDetection(rrc, SYNCWORD, bpsk, -BINS, BINS, power_threshold=9.5, max_items=n_items,
                                            n_channels=args.channels)
             # untimed launches first: the legs before this one end in host work, and the first launches after a few idle
-            # milliseconds run at the clocks the chip idles at (tools/r5_sustained.py: 2.99 ms for the first ten launches
+            # milliseconds run at the clocks the chip idles at (tools/archive/r5_sustained.py: 2.99 ms for the first ten launches
             # after 3 s of idling against 2.70 - 2.74 ms for every launch of 12 s back to back)
             for _ in range(ROOF_WARM):
                 sd.correlate_only(x)

@@ -3,7 +3,7 @@
 256-byte boundary, as bench.py's headline ring had it until round 5, against 256-byte aligned) or the stream matter?"""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # (tools/archive/ -> the repository root)
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge
 import bench

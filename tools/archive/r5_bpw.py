@@ -3,7 +3,7 @@
 interleaved rounds in one process.  tools/r5_bpw.py [items] [bins] [rounds] [v,v,...]"""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # (tools/archive/ -> the repository root)
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge
 import bench

@@ -5,7 +5,7 @@ import shutil
 import subprocess
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # (tools/archive/ -> the repository root)
 O = os.path.join(ROOT, "gpurun_out", "r5_final")
 P = os.path.join(ROOT, "profiles")
 pairs = [("bench.json", "r5_bench.json"), ("kernel_stats_pipe.csv", "r5_kernel_stats_pipelined.csv"),

@@ -4,7 +4,7 @@ rocprofv3 --kernel-trace --stats to see which kernels a pass waits for (tools/r5
 import os, sys
 import numpy as np
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # (tools/archive/ -> the repository root)
 sys.path.insert(0, ROOT)
 import __graft_entry__ as g
 pkg = g.load_package()

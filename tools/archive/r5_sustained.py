@@ -3,7 +3,7 @@
 chip hold its first seconds' clock under this kernel?)"""
 import os, sys, time
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # (tools/archive/ -> the repository root)
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge
 import bench
