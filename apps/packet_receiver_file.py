@@ -36,8 +36,10 @@ def receive_file(path, syncword_freq_bins=4, syncword_threshold=9.5, chunk_items
     pkg = pkg or ge.load_package()
     n_file = os.path.getsize(path) // 8
     dev = torch.device("cuda", torch.cuda.current_device())
+    # packets_only: nothing between the Costas loop and the packer is written to memory (the app delivers packets); the
+    # symbol tap of --zmq needs SyncwordRemove's output stream, i.e. the full form
     rx = pkg.NativePacketReceiver(4, syncword_freq_bins, syncword_threshold, max_items=chunk_items + 4096,
-                                  tags_cap=chunk_items // 768 + 64, decode_headers=True)
+                                  tags_cap=chunk_items // 768 + 64, decode_headers=True, packets_only=zmq_ports is None)
     if zmq_ports is not None:  # packet_receiver.hpp:163-168
         rx.publish_symbol_pdus(f"tcp://*:{zmq_ports[0]}", f"tcp://*:{zmq_ports[1]}")
     fft = 3072  # smallest batch the receiver takes in this mode (one header window + one FFT block)
