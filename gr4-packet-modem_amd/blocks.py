@@ -1657,7 +1657,7 @@ class NativePacketReceiver:
 
     def __init__(self, samples_per_symbol=4, syncword_freq_bins=4, syncword_threshold=9.5,
                  costas_constellation="QPSK", max_items=1 << 22, tags_cap=4096, pipelined=False, soft_bits=False,
-                 decode_headers=False, output_ring=False, packets_only=False, result_fields="all"):
+                 decode_headers=False, output_ring=False, packets_only=False, result_fields="all", packets_cap=None):
         """result_fields="packets" (decode_headers): collect() marshals only what a packet sink needs -- consumed, the accepted
         detections' tags, header messages, packet lengths and bytes -- and leaves the per-symbol tag lists (tens of thousands
         of 96-byte records per batch on a packet-dense stream) in the library; "all": everything the C result holds.
@@ -1668,6 +1668,7 @@ class NativePacketReceiver:
         self.packets_only = bool(packets_only)
         assert result_fields in ("all", "packets")
         self.result_fields = result_fields
+        self._packets_cap = packets_cap  # (tests: a packet output buffer that is too small for a batch)
         self.output_ring = output_ring
         self.samples_per_symbol, self.pipelined, self.soft_bits = samples_per_symbol, pipelined, soft_bits
         self.decode_headers = decode_headers
@@ -1701,7 +1702,7 @@ class NativePacketReceiver:
             n_sym = n // self.samples_per_symbol + 4160
             return (torch.empty(n_sym, dtype=torch.complex64, device=device),
                     torch.empty(2 * n_sym if self.soft_bits and not self.packets_only else 1, dtype=torch.float32, device=device),
-                    torch.empty(n // 16 + 65536 if self.decode_headers else 1, dtype=torch.uint8, device=device))
+                    torch.empty((self._packets_cap or n // 16 + 65536) if self.decode_headers else 1, dtype=torch.uint8, device=device))
         if getattr(self, "_out_n", -1) < n:
             n_sym = n // self.samples_per_symbol + 4160
             self._out_ring = [(torch.empty(n_sym, dtype=torch.complex64, device=device),
@@ -1738,6 +1739,8 @@ class NativePacketReceiver:
         st = lib().gr4pm_packet_receiver_collect(self._h, C.byref(r))
         x, history, nx, sym, llr, pk = self._keep.pop(0)
         check(st, "PacketReceiver")
+        if st > 0:  # a gr::work::Status the batch ended with (INSUFFICIENT_OUTPUT_ITEMS ...): the batch is lost, the receiver goes on
+            return {"status": int(st), "error": lib().gr4pm_last_error().decode(), "consumed": r.consumed}
 
         def records(ptr, n, dtype):
             if not n:

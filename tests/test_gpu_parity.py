@@ -2961,6 +2961,55 @@ def test_native_packet_receiver_packets_only_equals_the_full_form(pkg, pipelined
         pkg.NativePacketReceiver(max_items=70000, decode_headers=True, packets_only=True).set_symbol_pdu_callback(lambda k, s: None)
 
 
+@pytest.mark.parametrize("packets_only", [False, True])
+def test_native_packet_receiver_goes_on_after_a_batch_whose_packets_did_not_fit(pkg, packets_only):
+    """a batch that fails in the payload tail (here: the caller's packet buffer is too small for the
+    batch's packets: GR4PM_INSUFFICIENT_OUTPUT_ITEMS) has popped packet lengths without consuming their bits; the stage
+    lives on, and the next batch used to index the payload stream below zero (a wild device read).  Now the carried state
+    starts empty again: the failed batch and the packet cut by its end are lost, every later batch delivers its packets,
+    bit for bit those of a receiver that started behind the failed batch would deliver... here: every packet that lies
+    wholly inside a later batch comes back, in both forms of the receiver."""
+    rng = np.random.default_rng(71)
+    payloads = [rng.integers(0, 256, 200).astype(np.uint8).tobytes() for _ in range(120)]
+    x = pkg.BurstGenerator().stream(payloads, np.full(len(payloads), 800), freq_error=0.004, esn0_db=20.0, seed=72)
+    n = 60000
+    chunks, pos = [], 0
+    while pos + n <= x.numel():
+        chunks.append(x[pos:pos + n])
+        pos += ((n - 2048) // 1752 + 1) * 1752
+    assert len(chunks) >= 8
+    # ~ 12 packets of 204 bytes per batch: a 1500-byte buffer holds a quiet batch's packets, not a full one's
+    rx = pkg.NativePacketReceiver(max_items=n, tags_cap=256, pipelined=True, decode_headers=True, packets_only=packets_only,
+                                  packets_cap=1500)
+    ok = pkg.NativePacketReceiver(max_items=n, tags_cap=256, pipelined=True, decode_headers=True, packets_only=packets_only)
+    out, ref = [], []
+    for c in chunks:
+        for rcv, dst in ((rx, out), (ok, ref)):
+            r = rcv.process_bulk(c)
+            if r is not None:
+                dst.append(r)
+    out += rx.flush()
+    ref += ok.flush()
+    assert len(out) == len(ref) == len(chunks)
+    failed = [i for i, r in enumerate(out) if r["status"] != 0]
+    assert failed and all("packets_cap" in out[i]["error"] for i in failed), [r["status"] for r in out]
+    good_after = 0
+    for i, (a, b) in enumerate(zip(out, ref)):
+        if a["status"] != 0:
+            continue
+        assert a["consumed"] == b["consumed"]
+        if i and out[i - 1]["status"] != 0:
+            # the first batch behind a failed one: the packet that the failed batch cut is lost, the others are intact
+            mine = a["packets"].cpu().numpy().tobytes()
+            want = b["packets"].cpu().numpy().tobytes()
+            assert len(mine) % 200 == 0 and all(mine[k:k + 200] in want for k in range(0, len(mine), 200))
+            continue
+        assert np.array_equal(a["packet_lengths"], b["packet_lengths"])
+        assert np.array_equal(a["packets"].cpu().numpy(), b["packets"].cpu().numpy())
+        good_after += int(np.sum(a["packet_lengths"] > 0)) if i > failed[0] else 0
+    assert good_after >= 10  # the receiver did go on delivering
+
+
 @pytest.mark.parametrize("mode", ["one_call", "three_calls", "pipelined"])
 def test_native_packet_receiver_decodes_headers_and_packets(pkg, mode):
     """gr4pm_packet_receiver with decode_headers: the whole receiver inside the C++ library, IQ samples
