@@ -2970,15 +2970,17 @@ def test_native_packet_receiver_goes_on_after_a_batch_whose_packets_did_not_fit(
     bit for bit those of a receiver that started behind the failed batch would deliver... here: every packet that lies
     wholly inside a later batch comes back, in both forms of the receiver."""
     rng = np.random.default_rng(71)
-    payloads = [rng.integers(0, 256, 200).astype(np.uint8).tobytes() for _ in range(120)]
-    x = pkg.BurstGenerator().stream(payloads, np.full(len(payloads), 800), freq_error=0.004, esn0_db=20.0, seed=72)
+    payloads = [rng.integers(0, 256, 200).astype(np.uint8).tobytes() for _ in range(100)]
+    # sparse | dense | sparse: two packets per batch, then eleven (2 244 bytes), then two again
+    gaps = np.concatenate([np.full(20, 6000), np.full(40, 300), np.full(40, 6000)])
+    x = pkg.BurstGenerator().stream(payloads, gaps, freq_error=0.004, esn0_db=20.0, seed=72)
     n = 60000
     chunks, pos = [], 0
     while pos + n <= x.numel():
         chunks.append(x[pos:pos + n])
         pos += ((n - 2048) // 1752 + 1) * 1752
     assert len(chunks) >= 8
-    # ~ 12 packets of 204 bytes per batch: a 1500-byte buffer holds a quiet batch's packets, not a full one's
+    # a 1500-byte buffer holds a sparse batch's packets, not a dense one's
     rx = pkg.NativePacketReceiver(max_items=n, tags_cap=256, pipelined=True, decode_headers=True, packets_only=packets_only,
                                   packets_cap=1500)
     ok = pkg.NativePacketReceiver(max_items=n, tags_cap=256, pipelined=True, decode_headers=True, packets_only=packets_only)
@@ -2992,7 +2994,8 @@ def test_native_packet_receiver_goes_on_after_a_batch_whose_packets_did_not_fit(
     ref += ok.flush()
     assert len(out) == len(ref) == len(chunks)
     failed = [i for i, r in enumerate(out) if r["status"] != 0]
-    assert failed and all("packets_cap" in out[i]["error"] for i in failed), [r["status"] for r in out]
+    assert failed and failed[0] > 0 and failed[-1] < len(out) - 5 and all("packets_cap" in out[i]["error"] for i in failed), \
+        [r["status"] for r in out]
     good_after = 0
     for i, (a, b) in enumerate(zip(out, ref)):
         if a["status"] != 0:
