@@ -23,9 +23,9 @@ for m in pipe one dense_lean dense_full; do cp $(ls -t $(find $O/stats_$m -name 
 bash tools/pmc_correlate.sh r6_final/pmc_corr9 268435456 4 > $O/pmc_corr9.log 2>&1
 bash tools/pmc_correlate.sh r6_final/pmc_corr1 268435456 0 > $O/pmc_corr1.log 2>&1
 hipcc --offload-arch=gfx950 -O3 -o /tmp/osp tools/overlap_save_pattern.hip && /tmp/osp 28 20 > $O/overlap_save_pattern.txt 2>&1
-{ echo "## the correlator alone, grids of whole rounds (default) | round 5's fixed shares (GR4PM_W64_BALANCED=0): tools/r6_balanced_ab.sh";
+{ echo "## the correlator alone, pairs of lines: round 5's fixed shares (GR4PM_W64_BALANCED=0), then grids of whole rounds (the default); three rounds of 2^28 and 2^26 samples at 1 / 3 / 9 bins (tools/r6_balanced_ab.sh)";
   tools/r6_balanced_ab.sh /tmp/bal.txt > /dev/null 2>&1; grep -v amdgpu.ids /tmp/bal.txt;
-  echo "## the whole receiver on packets back to back, 48 passes of 2^28 samples (tools/r6_dense_ab.sh): packets_only | full form";
+  echo "## the whole receiver on packets back to back, 48 passes of 2^28 samples (tools/r6_dense_ab.sh): two rounds of the packets_only receiver (result_fields=packets), then two rounds of the full form";
   R6_FIELDS=packets PASSES=48 tools/r6_dense_ab.sh 2 "-"; R6_LEAN=0 PASSES=48 tools/r6_dense_ab.sh 2 "-";
   echo "## ... packets_only, the PLL's kernel form in the decoding stage: 121 | 71 | 32 VGPRs (GR4PM_COSTAS_SMALL_DECODE)";
   R6_FIELDS=packets PASSES=48 tools/r6_dense_ab.sh 2 "GR4PM_COSTAS_SMALL_DECODE=0" "GR4PM_COSTAS_SMALL_DECODE=1" "GR4PM_COSTAS_SMALL_DECODE=2";
