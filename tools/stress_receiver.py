@@ -1,6 +1,8 @@
 """soak test of gr4pm_packet_receiver: many batches of random sizes (announced up to two ahead) through the pipelined
 native receiver and through the sequential one; symbols, tags and, with a mode argument, LLRs / packets must be
-identical.  python tools/stress_receiver.py [batches] [seed] [plain|soft|decode]"""
+identical.  python tools/stress_receiver.py [batches] [seed] [plain|soft|decode|lean]
+lean (round 6): the pipelined packets_only receiver against the sequential FULL form of the decoding receiver -- packets,
+packet lengths, header messages and tags must be identical (the streams the packets_only form does not write are skipped)."""
 import importlib
 import os
 import sys
@@ -19,6 +21,9 @@ rng = np.random.default_rng(seed)
 dev = torch.device("cuda")
 n_max = 1 << 19
 total = n_max * 6
+lean = mode == "lean"
+if lean:
+    mode = "decode"
 if mode == "decode":
     x, _ = bench.packet_stream(pkg, total, seed=seed, device=dev)
 else:
@@ -26,7 +31,7 @@ else:
 torch.cuda.synchronize()
 kw = dict(max_items=n_max, tags_cap=1024, soft_bits=mode != "plain", decode_headers=mode == "decode")
 seq = pkg.NativePacketReceiver(pipelined=False, **kw)
-pipe = pkg.NativePacketReceiver(pipelined=True, **kw)
+pipe = pkg.NativePacketReceiver(pipelined=True, packets_only=lean, **kw)
 lo = 40000 if mode == "decode" else 4096
 chunks, pos = [], 0
 for b in range(n_batches):
@@ -44,6 +49,8 @@ def keep(r):
             out[k] = r[k].clone()
     if "packet_lengths" in r:
         out["packet_lengths"] = np.array(r["packet_lengths"]).copy()
+    if "header_messages" in r:
+        out["header_messages"] = r["header_messages"].copy()
     return out
 
 
@@ -70,9 +77,12 @@ for b in range(n_batches):
     assert g["tags"].size == w["tags"].size and all(  # field by field: the records carry padding bytes
         g["tags"][f].tobytes() == w["tags"][f].tobytes() for f in w["tags"].dtype.names), (b, "tags")
     for k in ("llr", "packets"):
-        if k in w:
+        if k in w and k in g:
             assert torch.equal(g[k].view(torch.uint8), w[k].view(torch.uint8)), (b, k)
+    if "header_messages" in w:
+        assert all(g["header_messages"][f].tobytes() == w["header_messages"][f].tobytes()
+                   for f in w["header_messages"].dtype.names), (b, "header_messages")
     if "packet_lengths" in w:
         assert np.array_equal(g["packet_lengths"], w["packet_lengths"]), (b, "packet_lengths")
     n_tags += g["tags"].size
-print(f"stress ok ({mode}): {n_batches} batches, {n_tags} tags")
+print(f"stress ok ({'lean' if lean else mode}): {n_batches} batches, {n_tags} tags")
