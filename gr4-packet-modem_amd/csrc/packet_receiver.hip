@@ -291,6 +291,7 @@ struct gr4pm_packet_receiver {
     gr4pm_crc_check* crc = nullptr;
     DevBuf<gr4pm_c64> a_tail, a_head, a_compact, a_sym, a_pm, a_z, a_data;
     DevBuf<float> a_llrbuf;
+    DevBuf<uint8_t> a_packed;
     DevBuf<long long> a_starts;
     std::vector<uint64_t> awaiting_idx;     // detections whose window continues in the next batch
     std::vector<gr4pm_tag> awaiting_tags;
@@ -694,21 +695,37 @@ gr4pm_status gr4pm_packet_receiver::predecode(Slot& s, const gr4pm_c64* y)
         a_fifo -= std::min(a_fifo, n_st);
         std::vector<gr4pm_packet_tag> ptags(3 * n_st + 8), dtags(3 * n_st + 8), ltags(3 * n_st + 8);
         size_t n_pt = 0, c2 = 0, n_pm = 0, used = 0, ignored = 0;
-        GR4PM_TRY(gr4pm_payload_metadata_insert_process(a_pmi, a_sym.p, produced, a_pm.p, cap, sym_tags.data(), n_st,
-                                                        inv.data(), n_st, 1, ptags.data(), ptags.size(), &n_pt, &c2,
-                                                        &n_pm, &used, &ignored));
+        // Round 6: pass A the way the packets_only receiver runs its tail -- every block's state machine on the host, the
+        // PLL reading PayloadMetadataInsert's input through its span table, then ONE kernel (k_tail_fused) from the PLL's
+        // output to the header LLRs: six launches less per batch on the stream whose latency the gate waits for.  Pass A's
+        // streams are nobody's result; the header LLRs are the blocks' bit for bit (the composition is the tested one).
+        std::vector<hostlogic::CopySpan> a_pm_spans, a_sr_spans;
+        GR4PM_TRY(gr4pm::payload_metadata_insert_plan(a_pmi, produced, cap, sym_tags.data(), n_st, inv.data(), n_st, 1,
+                                                      ptags.data(), ptags.size(), &n_pt, &c2, &n_pm, &used, &ignored, a_pm_spans));
         A_LAP(); // 3 pmi
-        GR4PM_TRY(gr4pm_costas_loop_process_packets(a_costas, a_pm.p, n_pm, a_z.p, ptags.data(), n_pt));
+        GR4PM_TRY(gr4pm::costas_loop_process_packets_from(a_costas, a_sym.p, a_pm_spans.data(), a_pm_spans.size(), n_pm, a_z.p,
+                                                          ptags.data(), n_pt));
         A_LAP(); // 4 costas
         size_t n_dt = 0, n_data = 0, n_lt = 0, n_llr = 0;
-        GR4PM_TRY(gr4pm_syncword_remove_process(a_remove, a_z.p, n_pm, a_data.p, ptags.data(), n_pt, dtags.data(),
-                                                dtags.size(), &n_dt, &n_data));
-        GR4PM_TRY(gr4pm_constellation_llr_decoder_process(a_llr, a_data.p, n_data, a_llrbuf.p, a_llrbuf.n, dtags.data(),
-                                                          n_dt, ltags.data(), ltags.size(), &n_lt, &n_llr));
+        GR4PM_TRY(gr4pm::syncword_remove_plan(a_remove, n_pm, ptags.data(), n_pt, dtags.data(), dtags.size(), &n_dt, &n_data,
+                                              a_sr_spans));
+        bool all_qpsk = true;
+        float a_scale = 0.0f;
+        GR4PM_TRY(gr4pm::llr_decoder_plan(a_llr, n_data, dtags.data(), n_dt, ltags.data(), ltags.size(), &n_lt, &n_llr, &all_qpsk,
+                                          &a_scale));
+        if (!all_qpsk) {
+            set_error("pass A: a run behind SyncwordRemove is not QPSK");
+            return GR4PM_ERR_INVALID;
+        }
         A_LAP(); // 5 remove + llr
         std::vector<gr4pm_header_msg> done;
         std::vector<int32_t> ptype;
-        GR4PM_TRY(a_loop.run(a_llrbuf.p, n_llr, ltags.data(), n_lt, done, ptype));
+        if (a_packed.n < 64) GR4PM_TRY(a_packed.alloc(64)); // (pass A's PayloadMetadataInsert passes no payload: nothing is packed)
+        GR4PM_TRY(a_loop.run_fused(a_z.p, a_scale, a_sr_spans, n_llr, ltags.data(), n_lt, a_packed.p, 0, done, ptype));
+        if (a_loop.n_pay != 0) {
+            set_error("pass A: %zu payload LLRs behind a header that was declared invalid", a_loop.n_pay);
+            return GR4PM_ERR_INTERNAL;
+        }
         A_LAP(); // 6 header loop
         for (uint64_t o : order) a_order.push_back(o);
         for (const auto& m : done) {
