@@ -199,11 +199,74 @@ def correlator_kernel():
     return {"wave": "k_correlate", "pair": "k_correlate_pair"}.get(os.environ.get("GR4PM_CORRELATOR", ""), "k_correlate_w64")
 
 
-def pmc_traffic(samples, kernel="k_correlate_w64"):
-    """roofline.traffic: HBM bytes per launch from the PMC passes committed under profiles/ (read at
-    run time; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note + WRITE_SIZE, per sample of
-    the profiled launch, scaled to this launch).  null when the file is missing or describes another kernel."""
+MEASURED_TRAFFIC = None  # measure_traffic_in_run()'s result, when it ran
+
+
+def measure_traffic_in_run(items, bins=BINS, timeout=150):
+    """roofline.traffic measured in THIS run (round 6; VERDICT round 5: "a builder-side number riding in a driver record").
+    Two rocprofv3 passes -- `--kernel-trace --pmc FETCH_SIZE`, then `--pmc WRITE_SIZE`, separately, as
+    MI355X_MICROARCH.md's HBM section prescribes -- over tools/bench_correlate.py (the correlator alone on `items` samples
+    at nine bins: the launch the roofline leg times), started as child processes `rocprofv3 ... -- python3 <program>`
+    BEFORE this process makes any GPU call.  HBM bytes per launch = 2 x FETCH_SIZE (gfx950: the counter reports half of
+    a wide streaming read) + WRITE_SIZE, both in KiB, summed over the XCDs' rows of a dispatch, mean over the launches.
+    None when rocprofv3 is not on PATH, a pass fails or takes too long: the committed PMC file is used then."""
+    import csv
     import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    # (this process is itself running under a profiler: no profiler inside a profiler)
+    if any(k.startswith(("ROCP_", "ROCPROF", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None
+    kernel = correlator_kernel()
+    kib = {}
+    tmp = tempfile.mkdtemp(prefix="gr4pm_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--",
+                   sys.executable, os.path.join(ROOT, "tools", "bench_correlate.py"), str(items), "3", str(bins)]
+            env = dict(os.environ, WARM="2", TMPDIR="/tmp")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+                env.pop(k, None)
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd="/tmp")
+            except (subprocess.TimeoutExpired, OSError):
+                return None
+            if r.returncode != 0:
+                return None
+            per = {}
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if kernel in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                            per[(f, row["Dispatch_Id"])] = per.get((f, row["Dispatch_Id"]), 0.0) + float(row["Counter_Value"])
+            if not per:
+                return None
+            kib[counter] = sum(per.values()) / len(per)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    samples = ((items - N_FFT) // 1752 + 1) * 1752
+    read_b, write_b = 2.0 * kib["FETCH_SIZE"] * 1024.0, kib["WRITE_SIZE"] * 1024.0
+    return {"bytes_per_launch": read_b + write_b, "bytes_per_sample": (read_b + write_b) / samples, "samples": samples,
+            "read_bytes_corrected": read_b, "write_bytes": write_b, "kernel": kernel}
+
+
+def pmc_traffic(samples, kernel="k_correlate_w64"):
+    """roofline.traffic: HBM bytes per launch.  Measured in this run when measure_traffic_in_run() ran (N = 1, the headline
+    workload); else from the PMC passes committed under profiles/ (FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note
+    + WRITE_SIZE, per sample of the profiled launch, scaled to this launch; `traffic_measured: false`).  null when the file
+    is missing or describes another kernel."""
+    import glob
+    if MEASURED_TRAFFIC is not None and MEASURED_TRAFFIC["kernel"] == kernel:
+        t = MEASURED_TRAFFIC
+        return {"traffic": round(t["bytes_per_sample"] * samples), "traffic_measured": True,
+                "traffic_source": f"this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two separate passes over "
+                                  f"tools/bench_correlate.py, {t['samples']} samples per launch, before this process touched the "
+                                  f"GPU): 2 x {t['read_bytes_corrected'] / 2 / t['samples']:.3f} + {t['write_bytes'] / t['samples']:.3f} "
+                                  f"= {t['bytes_per_sample']:.3f} B/sample"}
     # the newest round's file (profiles/r<N>_k_correlate_hbm_traffic.json)
     found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_k_correlate_hbm_traffic.json")),
                    key=lambda f: int(os.path.basename(f)[1:].split("_")[0]))
@@ -1300,6 +1363,9 @@ def main():
     ap.add_argument("--config3-items", type=int, default=1 << 22,
                     help="samples per channel and batch of the 64-channels-per-GPU leg (configs[2] / configs[3]: 2^22; tests "
                          "cut the ring down in items, never in shape)")
+    ap.add_argument("--no-pmc-traffic", action="store_true",
+                    help="do not measure roofline.traffic in this run (two rocprofv3 --pmc passes over the correlator alone, "
+                         "about 20 s, before anything else): the committed PMC file is quoted instead")
     ap.add_argument("--sparse-leg-only", action="store_true",
                     help="(what the default run starts as a child process) the packet-density sub-record alone, printed as JSON")
     ap.add_argument("--selfcheck", action="store_true",
@@ -1331,6 +1397,12 @@ def main():
         return config5(args)
     if args.lookahead_depth is None:
         args.lookahead_depth = 2
+    # roofline.traffic, measured in this run: child processes under rocprofv3, BEFORE this process makes its first GPU call
+    # (N = 1, the default headline workload only; profiling runs of bench.py itself pass --no-pmc-traffic or --no-per-bins)
+    global MEASURED_TRAFFIC
+    if (int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.channels == 1 and not args.no_pmc_traffic and not args.no_per_bins
+            and not args.no_cpu_baseline and not (args.soft_bits or args.decode_headers or args.detector_only or args.no_pipeline)):
+        MEASURED_TRAFFIC = measure_traffic_in_run(args.items)
     # three host threads drive the three pipeline stages and spend most of their time inside the
     # C library (GIL released); when one comes back it should not wait 5 ms (the default switch
     # interval) for whichever thread is running Python glue at that moment
