@@ -233,10 +233,21 @@ def test_bench_roofline_traffic_comes_from_the_committed_counters(monkeypatch):
     assert "_k_correlate_hbm_traffic.json" in t["traffic_source"]
     other = bench.pmc_traffic(samples, "k_correlate")
     assert other["traffic"] is None and "describes" in other["traffic_source"]
+    assert t["traffic_measured"] is False and other["traffic_measured"] is False
     monkeypatch.setenv("GR4PM_CORRELATOR", "wave")
     assert bench.correlator_kernel() == "k_correlate"
     monkeypatch.delenv("GR4PM_CORRELATOR")
     assert bench.correlator_kernel() == "k_correlate_w64"
+    # round 6: what measure_traffic_in_run() measured in the run wins over the committed file -- for its own kernel only
+    monkeypatch.setattr(bench, "MEASURED_TRAFFIC", {"bytes_per_launch": 12.1 * samples, "bytes_per_sample": 12.1, "samples": samples,
+                                                    "read_bytes_corrected": 8.1 * samples, "write_bytes": 4.0 * samples,
+                                                    "kernel": "k_correlate_w64"})
+    m = bench.pmc_traffic(2 * samples, "k_correlate_w64")
+    assert m["traffic_measured"] is True and m["traffic"] == round(12.1 * 2 * samples) and "this run" in m["traffic_source"]
+    assert bench.pmc_traffic(samples, "k_correlate")["traffic_measured"] is False
+    # ... and nothing is measured inside a profiler or without rocprofv3 (the committed file is quoted then)
+    monkeypatch.setenv("ROCP_TOOL_LIBRARIES", "x")
+    assert bench.measure_traffic_in_run(1 << 22) is None
 
 
 def test_m0_guard_catches_a_compiler_written_m0(tmp_path):
