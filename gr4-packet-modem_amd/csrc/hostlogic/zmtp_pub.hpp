@@ -86,7 +86,15 @@ public:
             return st;
         }
         _stop = false;
-        _io = std::thread([this] { run(); });
+        try {
+            _io = std::thread([this] { run(); });
+        } catch (...) { // no thread: nothing is bound
+            ::close(_listen);
+            ::close(_wake[0]);
+            ::close(_wake[1]);
+            _listen = -1;
+            throw;
+        }
         return GR4PM_OK;
     }
 

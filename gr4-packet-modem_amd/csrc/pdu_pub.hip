@@ -1,6 +1,8 @@
 // pdu_pub.hip -- C ABI of the ZeroMQ PUB endpoint (hostlogic/zmtp_pub.hpp): replaces ZmqPduPubSink<T>
 // (zmq_pdu_pub_sink.hpp:11-44), the sink of the receiver's symbol tap (packet_receiver.hpp:159-189).  Host code only
 // (no kernel, no device needed): a .hip file so that it is built and guarded like the other ABI units.
+#include <memory>
+
 #include "common.hpp"
 #include "hostlogic/zmtp_pub.hpp"
 
@@ -16,14 +18,11 @@ gr4pm_status gr4pm_zmq_pub_create(const char* endpoint, gr4pm_zmq_pub** out)
 try {
     if (!out) return GR4PM_ERR_INVALID;
     *out = nullptr;
-    auto* h = new (std::nothrow) gr4pm_zmq_pub;
+    std::unique_ptr<gr4pm_zmq_pub> h(new (std::nothrow) gr4pm_zmq_pub); // (bind() starts a thread: that may throw)
     if (!h) return GR4PM_ERR_NOMEM;
     const gr4pm_status st = h->pub.bind(endpoint); // start(), zmq_pdu_pub_sink.hpp:29
-    if (st != GR4PM_OK) {
-        delete h;
-        return st;
-    }
-    *out = h;
+    if (st != GR4PM_OK) return st;
+    *out = h.release();
     return GR4PM_OK;
 }
 GR4PM_ABI_CATCH
