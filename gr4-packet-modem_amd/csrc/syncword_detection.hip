@@ -1256,46 +1256,67 @@ __global__ __launch_bounds__(256) void k_scan_entries(ChanState* __restrict__ st
 //   k_median_tests  the tests of hpp:273-295 for all visited candidates of a call in parallel, one wave each:
 //                   2T + 1 powers read with all loads in flight, bandwidth- instead of latency-bound
 // zloc points at local position 0 of the channel (and is readable T items before it).
-__global__ __launch_bounds__(64) void k_tile_visit(const unsigned long long* __restrict__ bitmap, size_t bm_stride,
-                                                   uint32_t cnt, uint32_t T, uint32_t n_tiles,
-                                                   const int32_t* __restrict__ entry, ChanState* __restrict__ st,
-                                                   uint32_t* __restrict__ visit, uint32_t visit_cap)
+// Round 6: eight tiles per workgroup (one wave each), and the slots of all eight come from ONE atomic on the channel's
+// counter: a wave per workgroup made 8 192 atomics on one address per 2^28 samples, one behind the other at the L2 (~ 12 ns
+// each) -- 75 of the kernel's 105 us.
+constexpr int kVisitWaves = 8;
+__global__ __launch_bounds__(64 * kVisitWaves) void k_tile_visit(const unsigned long long* __restrict__ bitmap, size_t bm_stride,
+                                                                uint32_t cnt, uint32_t T, uint32_t n_tiles,
+                                                                const int32_t* __restrict__ entry, ChanState* __restrict__ st,
+                                                                uint32_t* __restrict__ visit, uint32_t visit_cap)
 {
 #ifndef GR4PM_NO_SETPRIO
     __builtin_amdgcn_s_setprio(3); // latency-bound, few waves: win the issue arbitration against throughput kernels
 #endif
-    const uint32_t tile = blockIdx.x, ch = blockIdx.y;
-    const int32_t e = entry[ch * n_tiles + tile];
-    if (e < 0) return;
-    const int lane = threadIdx.x;
-    const unsigned long long* bm = bitmap + static_cast<size_t>(ch) * bm_stride;
-    const uint32_t lo = tile * kTileW;
-    const uint32_t hi = min(lo + kTileW, cnt);
-    uint32_t r = lo + static_cast<uint32_t>(e);
-    TileBits tb;
-    tb.load(bm, lo, hi, lane);
-    // lane i keeps the i-th candidate of the current batch of 64; ONE atomic per batch reserves the slots
-    // (one returning atomic per candidate on the channel's single counter cost 0.5 ms per 2^26 items)
+    __shared__ uint32_t wave_cnt[kVisitWaves];
+    __shared__ uint32_t wg_base;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+    const uint32_t tile = blockIdx.x * kVisitWaves + static_cast<uint32_t>(wave), ch = blockIdx.y;
+    const int32_t e = tile < n_tiles ? entry[ch * n_tiles + tile] : -1;
+    // lane i keeps the i-th candidate of the current batch of 64; a batch that fills up inside the walk (more than 64
+    // visits per tile: a short time_threshold) reserves its slots by itself, the last batch of every wave goes through
+    // the workgroup's one atomic
     uint32_t mine = 0, have = 0;
-    auto flush = [&]() {
-        if (have == 0) return;
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&st[ch].vis_cnt, have);
-        base = __shfl(base, 0);
+    if (e >= 0) { // (wave-uniform)
+        const unsigned long long* bm = bitmap + static_cast<size_t>(ch) * bm_stride;
+        const uint32_t lo = tile * kTileW;
+        const uint32_t hi = min(lo + kTileW, cnt);
+        uint32_t r = lo + static_cast<uint32_t>(e);
+        TileBits tb;
+        tb.load(bm, lo, hi, lane);
+        while (r < hi) {
+            const uint32_t p = tb.next(r, hi, lane);
+            if (p >= hi) break;
+            if (static_cast<uint32_t>(lane) == have) mine = p;
+            if (++have == 64) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&st[ch].vis_cnt, 64u);
+                base = __shfl(base, 0);
+                if (base + lane < visit_cap) visit[static_cast<size_t>(ch) * visit_cap + base + lane] = mine;
+                else st[ch].overflow = 1;
+                have = 0;
+            }
+            r = p + T + 1;
+        }
+    }
+    if (lane == 0) wave_cnt[wave] = have;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+#pragma unroll
+        for (int w = 0; w < kVisitWaves; ++w) total += wave_cnt[w];
+        wg_base = total ? atomicAdd(&st[ch].vis_cnt, total) : 0u;
+    }
+    __syncthreads();
+    if (have) {
+        uint32_t base = wg_base;
+        for (int w = 0; w < wave; ++w) base += wave_cnt[w];
         if (static_cast<uint32_t>(lane) < have) {
             if (base + lane < visit_cap) visit[static_cast<size_t>(ch) * visit_cap + base + lane] = mine;
             else st[ch].overflow = 1;
         }
-        have = 0;
-    };
-    while (r < hi) {
-        const uint32_t p = tb.next(r, hi, lane);
-        if (p >= hi) break;
-        if (static_cast<uint32_t>(lane) == have) mine = p;
-        if (++have == 64) flush();
-        r = p + T + 1;
     }
-    flush();
 }
 // hpp:273-279 for one candidate p (wave-uniform; local position), by the whole wave: is count(history < z[p] /
 // power_threshold) at least half of the 2T + 1 powers around p?  Uniform result.
@@ -1428,8 +1449,14 @@ __device__ __forceinline__ cf sample_at(const cf* cur, const cf* carry, uint32_t
 // pos + hist in [E0, E1).  FFT_NOISE: the noise power comes from a forward transform of the block containing pos (same
 // arithmetic as k_correlate); otherwise k_correlate_w64 has left it behind the channel's powers (noise_rel) and the
 // kernel needs neither the transform's LDS nor its registers.
+// Round 6: eight waves per workgroup where the kernel needs no transform (FFT_NOISE = false), and the record slots of a
+// workgroup's eight waves come from ONE atomic -- 2048 atomics with return on the channel's one counter were a sixth of
+// the kernel's 87 us (the same serialisation k_tile_visit had); and only the bins that exist are accumulated (the groups
+// of nine ran all nine for four bins).
 template <bool FFT_NOISE>
-__global__ __launch_bounds__(64) void k_tags(const cf* __restrict__ in, size_t in_stride,
+constexpr int kTagWaves = FFT_NOISE ? 1 : 8;
+template <bool FFT_NOISE>
+__global__ __launch_bounds__(64 * kTagWaves<FFT_NOISE>) void k_tags(const cf* __restrict__ in, size_t in_stride,
                                              const cf* __restrict__ carry, size_t carry_stride,
                                              uint32_t xc, unsigned long long E0, unsigned long long E1,
                                              uint32_t hist, uint32_t stride_s, int n_bins,
@@ -1445,17 +1472,25 @@ __global__ __launch_bounds__(64) void k_tags(const cf* __restrict__ in, size_t i
 #ifndef GR4PM_NO_SETPRIO
     __builtin_amdgcn_s_setprio(3); // latency-bound, few waves: win the issue arbitration against throughput kernels
 #endif
+    constexpr int kW = kTagWaves<FFT_NOISE>;
     __shared__ cf lds[FFT_NOISE ? kExchangeItems : 1];
-    __shared__ cf zbin[kMaxBins];
+    __shared__ cf zbin_all[kW][kMaxBins];
+    __shared__ uint32_t wave_cnt[2][kW]; // (by the parity of the round: a wave may be one round ahead of the slowest)
+    __shared__ uint32_t wg_base;
     const uint32_t ch = blockIdx.y;
     const uint32_t n_det = min(st[ch].det_cnt, det_cap);
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+    cf* zbin = zbin_all[wave];
+    const uint32_t gw = blockIdx.x * kW + static_cast<uint32_t>(wave), n_waves = gridDim.x * kW;
     // The grid strides over the pending detections (a launch of det_cap mostly empty workgroups cost more than the
-    // records themselves): lane l of workgroup g looks at detection g + l * gridDim.x, the wave then works through the
-    // ones that leave in this call one after the other.  The record slots of ALL of them come from ONE atomic per wave
-    // (round 4: one atomicAdd on the same word per record was half of the kernel's time at 10 000 records a call).
-    for (uint32_t first = 0; first < n_det; first += 64u * gridDim.x) {
-    const uint32_t my = first + blockIdx.x + static_cast<uint32_t>(lane) * gridDim.x;
+    // records themselves): lane l of wave g looks at detection g + l * n_waves, the wave then works through the
+    // ones that leave in this call one after the other.  The record slots of ALL of a workgroup's round come from ONE
+    // atomic (round 4: one atomicAdd on the same word per record was half of the kernel's time at 10 000 records a call;
+    // round 6: one per wave still a sixth).
+    uint32_t parity = 0;
+    for (uint32_t first = 0; first < n_det; first += 64u * n_waves, parity ^= 1u) { // (n_det: the same in every wave)
+    const uint32_t my = first + gw + static_cast<uint32_t>(lane) * n_waves;
     unsigned long long my_pos = 0;
     bool leaves = false;
     if (my < n_det) {
@@ -1463,9 +1498,18 @@ __global__ __launch_bounds__(64) void k_tags(const cf* __restrict__ in, size_t i
         leaves = my_pos + hist >= E0 && my_pos + hist < E1;
     }
     unsigned long long todo = __ballot(leaves);
+    if (lane == 0) wave_cnt[parity][wave] = static_cast<uint32_t>(__popcll(todo));
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+#pragma unroll
+        for (int w = 0; w < kW; ++w) total += wave_cnt[parity][w];
+        wg_base = total ? atomicAdd(&st[ch].rec_cnt, total) : 0u;
+    }
+    __syncthreads();
     if (todo == 0) continue;
-    unsigned int slot_base = 0;
-    if (lane == 0) slot_base = atomicAdd(&st[ch].rec_cnt, static_cast<unsigned int>(__popcll(todo)));
+    unsigned int slot_base = wg_base;
+    for (int w = 0; w < wave; ++w) slot_base += wave_cnt[parity][w];
     slot_base = __builtin_amdgcn_readfirstlane(slot_base);
     for (unsigned int taken = 0; todo != 0; ++taken, todo &= todo - 1) {
     const int src = __ffsll(static_cast<long long>(todo)) - 1;
@@ -1530,27 +1574,34 @@ __global__ __launch_bounds__(64) void k_tags(const cf* __restrict__ in, size_t i
             }
 #pragma unroll
             for (int b = 0; b < kBinGroup; ++b) {
-                const cf* tb = td + static_cast<size_t>(min(bin0 + b, n_bins - 1)) * td_len;
+                if (bin0 + b < n_bins) { // (uniform)
+                    const cf* tb = td + static_cast<size_t>(bin0 + b) * td_len;
 #pragma unroll
-                for (int u = 0; u < kU; ++u) {
-                    const uint32_t n = n0 + 64 * u + lane;
-                    t[b][u] = n < td_len ? tb[n] : mk(0.f, 0.f);
+                    for (int u = 0; u < kU; ++u) {
+                        const uint32_t n = n0 + 64 * u + lane;
+                        t[b][u] = n < td_len ? tb[n] : mk(0.f, 0.f);
+                    }
                 }
             }
 #pragma unroll
-            for (int b = 0; b < kBinGroup; ++b)
+            for (int b = 0; b < kBinGroup; ++b) {
+                if (bin0 + b < n_bins) {
 #pragma unroll
-                for (int u = 0; u < kU; ++u) { // same order of accumulation per lane as the loop it replaces
-                    ax[b] += static_cast<double>(x[u].x) * t[b][u].x - static_cast<double>(x[u].y) * t[b][u].y;
-                    ay[b] += static_cast<double>(x[u].x) * t[b][u].y + static_cast<double>(x[u].y) * t[b][u].x;
+                    for (int u = 0; u < kU; ++u) { // same order of accumulation per lane as the loop it replaces
+                        ax[b] += static_cast<double>(x[u].x) * t[b][u].x - static_cast<double>(x[u].y) * t[b][u].y;
+                        ay[b] += static_cast<double>(x[u].x) * t[b][u].y + static_cast<double>(x[u].y) * t[b][u].x;
+                    }
                 }
+            }
         }
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1)
 #pragma unroll
             for (int b = 0; b < kBinGroup; ++b) {
-                ax[b] += __shfl_xor(ax[b], d);
-                ay[b] += __shfl_xor(ay[b], d);
+                if (bin0 + b < n_bins) {
+                    ax[b] += __shfl_xor(ax[b], d);
+                    ay[b] += __shfl_xor(ay[b], d);
+                }
             }
 #pragma unroll
         for (int b = 0; b < kBinGroup; ++b)
@@ -1736,31 +1787,53 @@ __global__ __launch_bounds__(256) void k_tags_generic(const cf* __restrict__ in,
     } // grid-stride loop over the pending detections
 }
 
-// drop emitted detections (pos + hist < E1) from the pending list; one wave per channel
-__global__ __launch_bounds__(64) void k_compact_pending(ChanState* __restrict__ st,
-                                                        ChanState* __restrict__ st_host,
-                                                        unsigned long long* __restrict__ det, uint32_t det_cap,
-                                                        unsigned long long E1, uint32_t hist, int n_channels)
+// drop emitted detections (pos + hist < E1) from the pending list; one workgroup per channel.  Round 6: what stays is
+// what lies in the call's last `hist` items -- a handful of ten thousand -- so the list is read once by 1024 threads, the
+// survivors are collected in LDS and written back to the front behind a barrier (46 -> 5 us per 2^28 samples; the one
+// wave that walked the list 64 entries at a time stays as the path for more survivors than the LDS list holds).
+constexpr int kCompactThreads = 1024, kCompactKeep = 2048;
+__global__ __launch_bounds__(kCompactThreads) void k_compact_pending(ChanState* __restrict__ st,
+                                                                     ChanState* __restrict__ st_host,
+                                                                     unsigned long long* __restrict__ det, uint32_t det_cap,
+                                                                     unsigned long long E1, uint32_t hist, int n_channels)
 {
+    __shared__ unsigned long long kept[kCompactKeep];
+    __shared__ uint32_t n_kept;
     const int ch = blockIdx.x;
     if (ch >= n_channels) return;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     // the host's view of this call (record count, overflow flag) goes straight to pinned memory
-    if (lane == 0) st_host[ch] = st[ch];
+    if (tid == 0) {
+        st_host[ch] = st[ch];
+        n_kept = 0;
+    }
     unsigned long long* d = det + static_cast<size_t>(ch) * det_cap;
     const uint32_t n = min(st[ch].det_cnt, det_cap);
-    uint32_t w = 0;
-    for (uint32_t i0 = 0; i0 < n; i0 += 64) {
-        const uint32_t i = i0 + lane;
-        const unsigned long long p = i < n ? d[i] : 0ull;
-        const bool keep = i < n && p + hist >= E1;
-        const unsigned long long m = __ballot(keep);
-        const uint32_t off = __popcll(m & ((1ull << lane) - 1ull));
-        // all reads of this chunk happened above; writes land at indices <= i
-        if (keep) d[w + off] = p;
-        w += __popcll(m);
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += kCompactThreads) {
+        const unsigned long long p = d[i];
+        if (p + hist >= E1) {
+            const uint32_t at = atomicAdd(&n_kept, 1u); // (LDS; survivors are rare)
+            if (at < kCompactKeep) kept[at] = p;
+        }
     }
-    if (lane == 0) {
+    __syncthreads(); // every read of the list lies in front of the writes below
+    const uint32_t w = n_kept;
+    if (w <= kCompactKeep) {
+        for (uint32_t i = tid; i < w; i += kCompactThreads) d[i] = kept[i];
+    } else if (tid < 64) { // more survivors than the LDS list holds: the in-place walk of rounds 1 - 5, by one wave
+        uint32_t ww = 0;
+        for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            const unsigned long long p = i < n ? d[i] : 0ull;
+            const bool keep = i < n && p + hist >= E1;
+            const unsigned long long m = __ballot(keep);
+            const uint32_t off = __popcll(m & ((1ull << lane) - 1ull));
+            if (keep) d[ww + off] = p; // all reads of this chunk happened above; writes land at indices <= i
+            ww += __popcll(m);
+        }
+    }
+    if (tid == 0) {
         st[ch].det_cnt = w;
         st[ch].rec_cnt = 0; // the host copy of ChanState was written above
         st[ch].vis_cnt = 0;
@@ -2683,7 +2756,8 @@ try {
         hipLaunchKernelGGL(k_scan_entries, dim3(nch), dim3(256), 0, s, h->st.p, static_cast<unsigned long long>(A0),
                            cnt, T, n_tiles, h->table[cur].p, h->table_stride, h->gtable[cur].p, h->gtable_stride,
                            h->gentry.p, n_groups, h->entry.p);
-        hipLaunchKernelGGL(k_tile_visit, dim3(n_tiles, nch), dim3(64), 0, s, h->bitmap[cur].p, h->bm_stride, cnt, T,
+        hipLaunchKernelGGL(k_tile_visit, dim3((n_tiles + kVisitWaves - 1) / kVisitWaves, nch), dim3(64 * kVisitWaves), 0, s,
+                           h->bitmap[cur].p, h->bm_stride, cnt, T,
                            n_tiles, h->entry.p, h->st.p, h->visit.p, h->visit_cap);
         // at most one visited candidate per T + 1 items (+ one per tile): the grids stride over the real count
         const uint32_t n_vis = cnt / (T + 1) + n_tiles + 1;
@@ -2708,7 +2782,8 @@ try {
     if (h->generic && h->fft_size == static_cast<size_t>(kN4k) && !h->force_radix2 && h->hist <= h->S) {
         // k_correlate_4096 has left every block's noise power behind the powers: the tags come from k_tags<false>
         // (correlation at the detection's lag from its definition), as behind k_correlate_w64
-        hipLaunchKernelGGL(k_tags<false>, dim3(std::min<uint32_t>(h->det_cap, 4096u), nch), dim3(64), 0, s,
+        hipLaunchKernelGGL(k_tags<false>, dim3(std::min<uint32_t>(h->det_cap, 4096u) / kTagWaves<false>, nch),
+                           dim3(64 * kTagWaves<false>), 0, s,
                            reinterpret_cast<const cf*>(in), in_stride, carry, static_cast<size_t>(h->xc), h->xc,
                            static_cast<unsigned long long>(E0), static_cast<unsigned long long>(E1),
                            static_cast<uint32_t>(h->hist), static_cast<uint32_t>(h->S), h->n_bins, h->tmpl.p, h->tw.p, h->tw.p,
@@ -2725,8 +2800,10 @@ try {
                            h->g_tmpl.p, h->g_tw.p, zcur + h->zc, h->z_stride, h->st.p, h->det.p, h->det_cap,
                            h->rec_host.p, h->rec_cap);
     } else {
-        auto launch_tags = [&](auto kernel) {
-            hipLaunchKernelGGL(kernel, dim3(std::min<uint32_t>(h->det_cap, 2048u), nch), dim3(64), 0, s,
+        static const uint32_t tags_waves = getenv("GR4PM_TAGS_WAVES") ? static_cast<uint32_t>(std::max(8, atoi(getenv("GR4PM_TAGS_WAVES")))) : 2048u;
+        auto launch_tags = [&](auto kernel, uint32_t waves_per_wg) {
+            hipLaunchKernelGGL(kernel, dim3(std::max<uint32_t>(1u, std::min<uint32_t>(h->det_cap, tags_waves) / waves_per_wg), nch),
+                               dim3(64 * waves_per_wg), 0, s,
                                reinterpret_cast<const cf*>(in), in_stride, carry, static_cast<size_t>(h->xc), h->xc,
                                static_cast<unsigned long long>(E0), static_cast<unsigned long long>(E1),
                                static_cast<uint32_t>(h->hist), static_cast<uint32_t>(h->S), h->n_bins, h->tmpl.p, h->tw.p,
@@ -2740,10 +2817,10 @@ try {
         // cannot lie more than one block before E0, i.e. hist = 2T + 1 <= S.  A longer history (T > 875 at the
         // default S = 1752) puts detections two or more blocks back; their block is then transformed again from the
         // sample carry (xc >= hist + S + 2 covers it).
-        if (h->corr_kind == 0 && !h->use_pair && h->hist <= h->S) launch_tags(k_tags<false>);
-        else launch_tags(k_tags<true>);
+        if (h->corr_kind == 0 && !h->use_pair && h->hist <= h->S) launch_tags(k_tags<false>, kTagWaves<false>);
+        else launch_tags(k_tags<true>, kTagWaves<true>);
     }
-    hipLaunchKernelGGL(k_compact_pending, dim3(nch), dim3(64), 0, s, h->st.p, h->st_host.p, h->det.p,
+    hipLaunchKernelGGL(k_compact_pending, dim3(nch), dim3(kCompactThreads), 0, s, h->st.p, h->st_host.p, h->det.p,
                        h->det_cap, static_cast<unsigned long long>(E1), static_cast<uint32_t>(h->hist),
                        static_cast<int>(nch));
     if (out) {
