@@ -1210,35 +1210,89 @@ __global__ void k_group_tables(uint32_t cnt, uint32_t T, uint32_t n_tiles, const
     gtable[ch * gtable_stride + static_cast<size_t>(grp) * (T + 1) + e] =
         walk_tiles(r0, t0, t1, cnt, T, table + ch * table_stride, nullptr);
 }
-// one workgroup per channel: thread 0 walks the groups (the only truly serial part of a call),
-// then one thread per group walks its tiles from the entry just found
+// where the scan that enters group g0 at local position r leaves group g1 - 1; ge (if given): the entry of each group
+__device__ __forceinline__ unsigned long long walk_groups(unsigned long long r, uint32_t g0, uint32_t g1, uint32_t cnt,
+                                                          uint32_t T, uint32_t n_tiles,
+                                                          const unsigned long long* __restrict__ gtab,
+                                                          unsigned long long* __restrict__ ge)
+{
+    for (uint32_t g = g0; g < g1; ++g) {
+        if (ge) ge[g] = r;
+        const unsigned long long lo = static_cast<unsigned long long>(g) * kGroup * kTileW;
+        const uint32_t t1 = min((g + 1) * kGroup, n_tiles);
+        const unsigned long long hi = min(static_cast<unsigned long long>(t1) * kTileW, static_cast<unsigned long long>(cnt));
+        if (r >= hi) continue;
+        const unsigned long long e = r > lo ? r - lo : 0; // <= T by construction
+        r = gtab[static_cast<size_t>(g) * (T + 1) + e];
+    }
+    return r;
+}
+// Round 6, a third level: for every SUPERGROUP of kSuper groups and every entry offset, where the scan leaves the
+// supergroup.  The walk over the groups was 256 dependent loads by one thread per 2^28 samples (~ 0.4 us each: 100 us,
+// the longest kernel of the detector's tail); with this table it is 16 + 16, the second 16 by 16 threads side by side.
+// Launched with the front (look-ahead stream) behind k_group_tables, only for calls of more than kSuper groups.
+constexpr uint32_t kSuper = 16;
+__global__ void k_super_tables(uint32_t cnt, uint32_t T, uint32_t n_tiles, uint32_t n_groups,
+                               const unsigned long long* __restrict__ gtable, size_t gtable_stride,
+                               unsigned long long* __restrict__ sgtable, size_t sgtable_stride)
+{
+#ifndef GR4PM_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3); // latency-bound, few waves: win the issue arbitration against throughput kernels
+#endif
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t sg = blockIdx.y, ch = blockIdx.z;
+    if (e > T) return;
+    const uint32_t g0 = sg * kSuper, g1 = min(g0 + kSuper, n_groups);
+    const unsigned long long r0 = static_cast<unsigned long long>(g0) * kGroup * kTileW + e;
+    sgtable[ch * sgtable_stride + static_cast<size_t>(sg) * (T + 1) + e] =
+        walk_groups(r0, g0, g1, cnt, T, n_tiles, gtable + ch * gtable_stride, nullptr);
+}
+// one workgroup per channel: thread 0 walks the supergroups (the only truly serial part of a call; sgtable == nullptr:
+// the groups), then one thread per supergroup walks its groups, then one thread per group walks its tiles, each from the
+// entry just found
 __global__ __launch_bounds__(256) void k_scan_entries(ChanState* __restrict__ st, unsigned long long A0,
                                                       uint32_t cnt, uint32_t T, uint32_t n_tiles,
                                                       const uint32_t* __restrict__ table, size_t table_stride,
                                                       const unsigned long long* __restrict__ gtable,
                                                       size_t gtable_stride, unsigned long long* __restrict__ gentry,
-                                                      uint32_t n_groups, int32_t* __restrict__ entry)
+                                                      uint32_t n_groups, int32_t* __restrict__ entry,
+                                                      const unsigned long long* __restrict__ sgtable,
+                                                      size_t sgtable_stride)
 {
 #ifndef GR4PM_NO_SETPRIO
     __builtin_amdgcn_s_setprio(3); // latency-bound, few waves: win the issue arbitration against throughput kernels
 #endif
+    __shared__ unsigned long long sge[256]; // entry of each supergroup (more than 256 of them: the flat walk)
     const uint32_t ch = blockIdx.x;
     unsigned long long* ge = gentry + static_cast<size_t>(ch) * n_groups;
+    const unsigned long long* gtab = gtable + ch * gtable_stride;
+    const uint32_t n_super = (n_groups + kSuper - 1) / kSuper;
+    const bool three_levels = sgtable != nullptr && n_super <= 256;
     if (threadIdx.x == 0) {
         const unsigned long long rabs = st[ch].r;
         unsigned long long r = rabs > A0 ? rabs - A0 : 0; // local; may exceed cnt
-        for (uint32_t g = 0; g < n_groups; ++g) {
-            ge[g] = r;
-            const unsigned long long lo = static_cast<unsigned long long>(g) * kGroup * kTileW;
-            const uint32_t t1 = min((g + 1) * kGroup, n_tiles);
-            const unsigned long long hi = min(static_cast<unsigned long long>(t1) * kTileW,
-                                              static_cast<unsigned long long>(cnt));
-            if (r >= hi) continue;
-            const unsigned long long e = r > lo ? r - lo : 0; // <= T by construction
-            r = gtable[ch * gtable_stride + static_cast<size_t>(g) * (T + 1) + e];
+        if (three_levels) {
+            for (uint32_t sg = 0; sg < n_super; ++sg) {
+                sge[sg] = r;
+                const unsigned long long lo = static_cast<unsigned long long>(sg) * kSuper * kGroup * kTileW;
+                const uint32_t g1 = min((sg + 1) * kSuper, n_groups);
+                const uint32_t t1 = min(g1 * kGroup, n_tiles);
+                const unsigned long long hi = min(static_cast<unsigned long long>(t1) * kTileW,
+                                                  static_cast<unsigned long long>(cnt));
+                if (r >= hi) continue;
+                const unsigned long long e = r > lo ? r - lo : 0; // <= T by construction
+                r = sgtable[ch * sgtable_stride + static_cast<size_t>(sg) * (T + 1) + e];
+            }
+        } else {
+            r = walk_groups(r, 0, n_groups, cnt, T, n_tiles, gtab, ge);
         }
         const unsigned long long rnew = A0 + (r > cnt ? r : cnt);
         st[ch].r = rnew > rabs ? rnew : rabs;
+    }
+    __syncthreads();
+    if (three_levels) {
+        for (uint32_t sg = threadIdx.x; sg < n_super; sg += blockDim.x)
+            walk_groups(sge[sg], sg * kSuper, min((sg + 1) * kSuper, n_groups), cnt, T, n_tiles, gtab, ge);
     }
     __threadfence_block();
     __syncthreads();
@@ -1455,7 +1509,7 @@ __device__ __forceinline__ cf sample_at(const cf* cur, const cf* carry, uint32_t
 // of nine ran all nine for four bins).
 template <bool FFT_NOISE>
 constexpr int kTagWaves = FFT_NOISE ? 1 : 8;
-template <bool FFT_NOISE>
+template <bool FFT_NOISE, int BG = 9>
 __global__ __launch_bounds__(64 * kTagWaves<FFT_NOISE>) void k_tags(const cf* __restrict__ in, size_t in_stride,
                                              const cf* __restrict__ carry, size_t carry_stride,
                                              uint32_t xc, unsigned long long E0, unsigned long long E1,
@@ -1560,11 +1614,13 @@ __global__ __launch_bounds__(64 * kTagWaves<FFT_NOISE>) void k_tags(const cf* __
     // All loads of a group of bins are in flight before the first product (one lane-sample per 64 template samples,
     // the same for every bin; bin by bin every pass of the loop waited for its own two loads: 45 dependent round
     // trips per tag), and the bins' lane sums are reduced side by side.
-    constexpr int kU = 5, kBinGroup = 9; // 320 template samples and 9 bins per round: one round for the defaults
+    constexpr int kU = 5, kBinGroup = BG; // 320 template samples and BG bins per round: one round for the defaults
+    constexpr int kV = 2 * BG <= 8 ? 8 : 2 * BG <= 16 ? 16 : 32; // the sums of a round, padded to a power of two
+    static_assert(2 * BG <= kV, "bin group");
     for (int bin0 = 0; bin0 < n_bins; bin0 += kBinGroup) {
-        double ax[kBinGroup], ay[kBinGroup];
+        double acc[kV]; // [2 b]: real part of bin b's lane sum, [2 b + 1]: imaginary part
 #pragma unroll
-        for (int b = 0; b < kBinGroup; ++b) ax[b] = ay[b] = 0.0;
+        for (int v = 0; v < kV; ++v) acc[v] = 0.0;
         for (uint32_t n0 = 0; n0 < td_len; n0 += 64 * kU) {
             cf x[kU], t[kBinGroup][kU];
 #pragma unroll
@@ -1588,25 +1644,33 @@ __global__ __launch_bounds__(64 * kTagWaves<FFT_NOISE>) void k_tags(const cf* __
                 if (bin0 + b < n_bins) {
 #pragma unroll
                     for (int u = 0; u < kU; ++u) { // same order of accumulation per lane as the loop it replaces
-                        ax[b] += static_cast<double>(x[u].x) * t[b][u].x - static_cast<double>(x[u].y) * t[b][u].y;
-                        ay[b] += static_cast<double>(x[u].x) * t[b][u].y + static_cast<double>(x[u].y) * t[b][u].x;
+                        acc[2 * b] += static_cast<double>(x[u].x) * t[b][u].x - static_cast<double>(x[u].y) * t[b][u].y;
+                        acc[2 * b + 1] += static_cast<double>(x[u].x) * t[b][u].y + static_cast<double>(x[u].y) * t[b][u].x;
                     }
                 }
             }
         }
+        // The lane sums of all kV values across the wave, as the butterfly `v += shfl_xor(v, d)`, d = 32 .. 1, computes
+        // them -- but at every step a lane keeps only the half of the values its bit d selects and hands the other half
+        // to its partner, so that kV values cost kV - 1 + (6 - log2 kV) exchanges instead of 6 kV (8 values: 10, not 48;
+        // the exchanges were 20 of the kernel's 73 us).  Own value + partner's value at every step, like the butterfly:
+        // the same additions in the same order, the same bits.  Value v ends up in the lanes whose top log2 kV bits are v.
+        int d = 32;
 #pragma unroll
-        for (int d = 32; d > 0; d >>= 1)
+        for (int n = kV; n > 1; n >>= 1, d >>= 1) {
+            const bool upper = (lane & d) != 0;
 #pragma unroll
-            for (int b = 0; b < kBinGroup; ++b) {
-                if (bin0 + b < n_bins) {
-                    ax[b] += __shfl_xor(ax[b], d);
-                    ay[b] += __shfl_xor(ay[b], d);
-                }
+            for (int k = 0; k < n / 2; ++k) {
+                const double send = upper ? acc[k] : acc[k + n / 2];
+                const double keep = upper ? acc[k + n / 2] : acc[k];
+                acc[k] = keep + __shfl_xor(send, d);
             }
-#pragma unroll
-        for (int b = 0; b < kBinGroup; ++b)
-            if (lane == 0 && bin0 + b < n_bins)
-                zbin[bin0 + b] = mk(static_cast<float>(ax[b] * fft_n), static_cast<float>(ay[b] * fft_n));
+        }
+        for (; d > 0; d >>= 1) acc[0] += __shfl_xor(acc[0], d);
+        constexpr int kLanesPerValue = 64 / kV;
+        const int v = lane / kLanesPerValue;
+        if (lane % kLanesPerValue == 0 && v < 2 * kBinGroup && bin0 + v / 2 < n_bins)
+            reinterpret_cast<float*>(zbin + bin0 + v / 2)[v & 1] = static_cast<float>(acc[0] * fft_n);
     }
     wave_lds_sync();
     if (lane == 0) {
@@ -1969,8 +2033,9 @@ struct gr4pm_syncword_detection {
     bool fused_median[kSets] = {};             // ... and whether the set's front was made by that kernel
     bool last_fused = false;                   // ... of the set the last process() call scanned (scan_counts)
     DevBuf<uint32_t> table[kSets];
-    DevBuf<unsigned long long> gtable[kSets], gentry;
-    size_t gtable_stride = 0;
+    DevBuf<unsigned long long> gtable[kSets], gentry, sgtable[kSets];
+    size_t gtable_stride = 0, sgtable_stride = 0;
+    bool super_level = true; // (GR4PM_SD_NO_SUPER at creation: the two-level scan of rounds 1 - 5, for A/B)
     uint32_t max_groups = 0;
     DevBuf<int32_t> entry;
     DevBuf<ChanState> st;
@@ -2305,6 +2370,10 @@ gr4pm_status launch_front(gr4pm_syncword_detection* h, hipStream_t stream, int w
     const uint32_t n_groups = (n_tiles + kGroup - 1) / kGroup;
     hipLaunchKernelGGL(k_group_tables, dim3((T + 1 + 127) / 128, n_groups, nch), dim3(128), 0, stream, cnt, T,
                        n_tiles, h->table[which].p, h->table_stride, h->gtable[which].p, h->gtable_stride);
+    if (h->super_level && n_groups > kSuper)
+        hipLaunchKernelGGL(k_super_tables, dim3((T + 1 + 127) / 128, (n_groups + kSuper - 1) / kSuper, nch), dim3(128), 0,
+                           stream, cnt, T, n_tiles, n_groups, h->gtable[which].p, h->gtable_stride, h->sgtable[which].p,
+                           h->sgtable_stride);
     GR4PM_HIP_TRY(hipGetLastError());
     if (ahead) {
         GR4PM_HIP_TRY(hipEventRecord(h->ev_front[which], stream));
@@ -2593,6 +2662,9 @@ try {
     h->gtable_stride = static_cast<size_t>(h->max_groups) * (h->T + 1);
     for (int i = 0; i < kSets; ++i) ok(h->gtable[i].alloc(h->gtable_stride * h->n_channels));
     ok(h->gentry.alloc(static_cast<size_t>(h->max_groups) * h->n_channels));
+    h->super_level = getenv("GR4PM_SD_NO_SUPER") == nullptr;
+    h->sgtable_stride = static_cast<size_t>((h->max_groups + kSuper - 1) / kSuper) * (h->T + 1);
+    for (int i = 0; i < kSets; ++i) ok(h->sgtable[i].alloc(h->sgtable_stride * h->n_channels));
     ok(h->st.alloc(h->n_channels));
     ok(h->det.alloc(static_cast<size_t>(h->det_cap) * h->n_channels));
     h->visit_cap = static_cast<uint32_t>((h->max_items + h->T) / (h->T + 1) + h->max_tiles + 16);
@@ -2755,7 +2827,8 @@ try {
         const uint32_t n_groups = (n_tiles + kGroup - 1) / kGroup;
         hipLaunchKernelGGL(k_scan_entries, dim3(nch), dim3(256), 0, s, h->st.p, static_cast<unsigned long long>(A0),
                            cnt, T, n_tiles, h->table[cur].p, h->table_stride, h->gtable[cur].p, h->gtable_stride,
-                           h->gentry.p, n_groups, h->entry.p);
+                           h->gentry.p, n_groups, h->entry.p,
+                           h->super_level && n_groups > kSuper ? h->sgtable[cur].p : nullptr, h->sgtable_stride);
         hipLaunchKernelGGL(k_tile_visit, dim3((n_tiles + kVisitWaves - 1) / kVisitWaves, nch), dim3(64 * kVisitWaves), 0, s,
                            h->bitmap[cur].p, h->bm_stride, cnt, T,
                            n_tiles, h->entry.p, h->st.p, h->visit.p, h->visit_cap);
@@ -2782,7 +2855,7 @@ try {
     if (h->generic && h->fft_size == static_cast<size_t>(kN4k) && !h->force_radix2 && h->hist <= h->S) {
         // k_correlate_4096 has left every block's noise power behind the powers: the tags come from k_tags<false>
         // (correlation at the detection's lag from its definition), as behind k_correlate_w64
-        hipLaunchKernelGGL(k_tags<false>, dim3(std::min<uint32_t>(h->det_cap, 4096u) / kTagWaves<false>, nch),
+        hipLaunchKernelGGL((k_tags<false, 9>), dim3(std::min<uint32_t>(h->det_cap, 4096u) / kTagWaves<false>, nch),
                            dim3(64 * kTagWaves<false>), 0, s,
                            reinterpret_cast<const cf*>(in), in_stride, carry, static_cast<size_t>(h->xc), h->xc,
                            static_cast<unsigned long long>(E0), static_cast<unsigned long long>(E1),
@@ -2817,8 +2890,12 @@ try {
         // cannot lie more than one block before E0, i.e. hist = 2T + 1 <= S.  A longer history (T > 875 at the
         // default S = 1752) puts detections two or more blocks back; their block is then transformed again from the
         // sample carry (xc >= hist + S + 2 covers it).
-        if (h->corr_kind == 0 && !h->use_pair && h->hist <= h->S) launch_tags(k_tags<false>, kTagWaves<false>);
-        else launch_tags(k_tags<true>, kTagWaves<true>);
+        if (h->corr_kind == 0 && !h->use_pair && h->hist <= h->S) {
+            if (h->n_bins <= 4) launch_tags(k_tags<false, 4>, kTagWaves<false>); // (fewer registers: twice the waves)
+            else launch_tags(k_tags<false, 9>, kTagWaves<false>);
+        } else {
+            launch_tags(k_tags<true, 9>, kTagWaves<true>);
+        }
     }
     hipLaunchKernelGGL(k_compact_pending, dim3(nch), dim3(kCompactThreads), 0, s, h->st.p, h->st_host.p, h->det.p,
                        h->det_cap, static_cast<unsigned long long>(E1), static_cast<uint32_t>(h->hist),
