@@ -2834,6 +2834,9 @@ try {
                            n_tiles, h->entry.p, h->st.p, h->visit.p, h->visit_cap);
         // at most one visited candidate per T + 1 items (+ one per tile): the grids stride over the real count
         const uint32_t n_vis = cnt / (T + 1) + n_tiles + 1;
+        // 16 384 workgroups over ALL channels (round 6: that many per channel were 358 000 workgroups with nothing to do
+        // per step of config 2, 105 us)
+        const uint32_t median_grid = std::max<uint32_t>(64u, 16384u / nch);
         h->last_fused = h->fused_median[cur];
         if (h->fused_median[cur]) {
             // the front's candidate kernel has tested (nearly) every candidate: look the visited ones up; the untested ones
@@ -2842,11 +2845,11 @@ try {
             hipLaunchKernelGGL(k_resolve_visited, dim3((n_vis + 255) / 256, nch), dim3(64), 0, s,
                                static_cast<unsigned long long>(A0), h->st.p, h->visit.p, h->visit_cap, h->passmap[cur].p,
                                h->bm_stride, h->det.p, h->det_cap, h->deferred.p);
-            hipLaunchKernelGGL(k_median_tests<true>, dim3(std::min<uint32_t>(n_vis, 16384u), nch), dim3(64), 0, s, zloc,
+            hipLaunchKernelGGL(k_median_tests<true>, dim3(std::min<uint32_t>(n_vis, median_grid), nch), dim3(64), 0, s, zloc,
                                h->z_stride, static_cast<unsigned long long>(A0), T, h->power_threshold, h->st.p,
                                h->deferred.p, h->visit_cap, h->det.p, h->det_cap);
         } else {
-            hipLaunchKernelGGL(k_median_tests<false>, dim3(std::min<uint32_t>(n_vis, 16384u), nch), dim3(64), 0, s, zloc,
+            hipLaunchKernelGGL(k_median_tests<false>, dim3(std::min<uint32_t>(n_vis, median_grid), nch), dim3(64), 0, s, zloc,
                                h->z_stride, static_cast<unsigned long long>(A0), T, h->power_threshold, h->st.p, h->visit.p,
                                h->visit_cap, h->det.p, h->det_cap);
         }
@@ -2873,7 +2876,11 @@ try {
                            h->g_tmpl.p, h->g_tw.p, zcur + h->zc, h->z_stride, h->st.p, h->det.p, h->det_cap,
                            h->rec_host.p, h->rec_cap);
     } else {
-        static const uint32_t tags_waves = getenv("GR4PM_TAGS_WAVES") ? static_cast<uint32_t>(std::max(8, atoi(getenv("GR4PM_TAGS_WAVES")))) : 2048u;
+        // 2048 waves over ALL channels: what the chip holds of the 9-bin form at once (two per SIMD); more only queue
+        // (measured: 4096 and 8192 per channel are slower on one channel, 2048 per channel took 179 us on 64 channels, 102
+        // with 256)
+        static const uint32_t tags_waves_env = getenv("GR4PM_TAGS_WAVES") ? static_cast<uint32_t>(std::max(8, atoi(getenv("GR4PM_TAGS_WAVES")))) : 0u;
+        const uint32_t tags_waves = tags_waves_env ? tags_waves_env : std::max<uint32_t>(8u, (2048u / nch) & ~7u);
         auto launch_tags = [&](auto kernel, uint32_t waves_per_wg) {
             hipLaunchKernelGGL(kernel, dim3(std::max<uint32_t>(1u, std::min<uint32_t>(h->det_cap, tags_waves) / waves_per_wg), nch),
                                dim3(64 * waves_per_wg), 0, s,
