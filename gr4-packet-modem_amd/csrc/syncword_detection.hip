@@ -1058,6 +1058,20 @@ __device__ __forceinline__ void tile_tables_walks(const TileBits& tb, const unsi
 // closed by pointer jumping (log2 rounds, all candidates at once), and an entry's value is the value of the first
 // candidate at or behind it.  No serial walk: the walking form cost ~1 us per step and 150 us per 2^26 items.
 constexpr uint32_t kListCap = 512, kListEnd = 0xffffffffu;
+// inclusive prefix sum over the 64 lanes on the DPP path (row shifts by 1, 2, 4, 8 inside the rows of 16, then lane 15 of
+// a row onto the next row and lane 31 onto the upper half): six vector adds, no LDS crossbar -- six ds_bpermute round
+// trips per chunk of the bitmap, eight chunks a tile, were a tenth of k_tile_tables
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x)
+{
+    int v = static_cast<int>(x);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false); // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false); // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false); // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false); // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2 and 3
+    return static_cast<uint32_t>(v);
+}
 __global__ __launch_bounds__(64) void k_tile_tables(const unsigned long long* __restrict__ bitmap,
                                                     size_t bm_stride, uint32_t cnt, uint32_t T, uint32_t n_tiles,
                                                     uint32_t* __restrict__ table, size_t table_stride)
@@ -1084,13 +1098,8 @@ __global__ __launch_bounds__(64) void k_tile_tables(const unsigned long long* __
     for (int k = 0; k < kTileChunks; ++k) {
         unsigned long long wd = tb.w[k];
         const uint32_t mine = static_cast<uint32_t>(__popcll(wd));
-        uint32_t incl = mine; // inclusive prefix sum over the lanes
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t up = __shfl_up(incl, d);
-            if (lane >= d) incl += up;
-        }
-        const uint32_t total = __builtin_amdgcn_readfirstlane(__shfl(incl, 63));
+        const uint32_t incl = wave_inclusive_sum(mine); // over the lanes
+        const uint32_t total = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
         if (n + total > kListCap) {
             dense = true;
             break;
@@ -1149,10 +1158,18 @@ __global__ __launch_bounds__(64) void k_tile_tables(const unsigned long long* __
         wave_lds_sync();
         if (!__any(changed)) break;
     }
-    // ---- entries: the value of the first candidate at or behind the entry position, 0 if there is none
+    // ---- entries: the value of the first candidate at or behind the entry position, 0 if there is none.  The search
+    // runs over the candidates of the entry window and the one behind them only (cpos[n_win] >= wend > q): two or three
+    // of a hundred on a packet stream, two steps instead of seven for each of the window's 769 entries.
+    const uint32_t n_win = lower_bound(wend);
     for (uint32_t q = lo + lane; q < wend; q += 64) {
-        const uint32_t nx = lower_bound(q);
-        tab[q - lo] = nx < n ? val[nx] : 0u;
+        uint32_t a = 0, b = n_win;
+        while (a < b) {
+            const uint32_t m = (a + b) >> 1;
+            if (cpos[m] < q) a = m + 1;
+            else b = m;
+        }
+        tab[q - lo] = a < n ? val[a] : 0u;
     }
     (void)n_tiles;
 }
@@ -1429,19 +1446,24 @@ __global__ __launch_bounds__(64) void k_median_tests(const float* __restrict__ z
 // candidate; else nothing.  ONE atomic per wave and list: the channel's counters are single addresses, and an atomic
 // per 64 candidates (5 461 per 2^28 samples, one behind the other at the L2) was most of this kernel's first form.
 // (Inside k_tile_visit's walk the same lookup cost 56 us per 2^28 samples without ever running.)
-__global__ __launch_bounds__(64) void k_resolve_visited(unsigned long long A0, ChanState* __restrict__ st,
+// Round 6: eight waves per workgroup, one atomic per WORKGROUP and list (1366 atomics per list were 15 of the kernel's 23 us).
+constexpr int kResolveWaves = 8;
+__global__ __launch_bounds__(64 * kResolveWaves) void k_resolve_visited(unsigned long long A0, ChanState* __restrict__ st,
                                                         const uint32_t* __restrict__ visit, uint32_t visit_cap,
                                                         const unsigned long long* __restrict__ passmap, size_t bm_stride,
                                                         unsigned long long* __restrict__ det, uint32_t det_cap,
                                                         uint32_t* __restrict__ deferred)
 {
+    __shared__ uint32_t cnt_ok[kResolveWaves], cnt_def[kResolveWaves];
+    __shared__ uint32_t base_ok, base_def;
     const uint32_t ch = blockIdx.y;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     const ulonglong2* pm = reinterpret_cast<const ulonglong2*>(passmap) + static_cast<size_t>(ch) * bm_stride;
     const uint32_t* vis = visit + static_cast<size_t>(ch) * visit_cap;
     const uint32_t n = min(st[ch].vis_cnt, visit_cap);
-    const uint32_t base = blockIdx.x * 256u;
-    if (base >= n) return;
+    if (blockIdx.x * (256u * kResolveWaves) >= n) return; // (the whole workgroup)
+    const uint32_t base = (blockIdx.x * kResolveWaves + static_cast<uint32_t>(wave)) * 256u;
     uint32_t p[4];
     bool ok[4], later[4];
     unsigned long long m[4], md[4];
@@ -1462,10 +1484,25 @@ __global__ __launch_bounds__(64) void k_resolve_visited(unsigned long long A0, C
     const uint32_t n_ok = static_cast<uint32_t>(__popcll(m[0]) + __popcll(m[1]) + __popcll(m[2]) + __popcll(m[3]));
     const uint32_t n_def = static_cast<uint32_t>(__popcll(md[0]) + __popcll(md[1]) + __popcll(md[2]) + __popcll(md[3]));
     const unsigned long long below = (1ull << lane) - 1ull;
+    if (lane == 0) {
+        cnt_ok[wave] = n_ok;
+        cnt_def[wave] = n_def;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t_ok = 0, t_def = 0;
+#pragma unroll
+        for (int w = 0; w < kResolveWaves; ++w) {
+            t_ok += cnt_ok[w];
+            t_def += cnt_def[w];
+        }
+        base_ok = t_ok ? atomicAdd(&st[ch].det_cnt, t_ok) : 0u;
+        base_def = t_def ? atomicAdd(&st[ch].def_cnt, t_def) : 0u;
+    }
+    __syncthreads();
     if (n_ok) {
-        uint32_t slot = 0;
-        if (lane == 0) slot = atomicAdd(&st[ch].det_cnt, n_ok);
-        slot = __shfl(slot, 0);
+        uint32_t slot = base_ok;
+        for (int w = 0; w < wave; ++w) slot += cnt_ok[w];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (ok[k]) {
@@ -1477,9 +1514,8 @@ __global__ __launch_bounds__(64) void k_resolve_visited(unsigned long long A0, C
         }
     }
     if (n_def) {
-        uint32_t slot = 0;
-        if (lane == 0) slot = atomicAdd(&st[ch].def_cnt, n_def);
-        slot = __shfl(slot, 0);
+        uint32_t slot = base_def;
+        for (int w = 0; w < wave; ++w) slot += cnt_def[w];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (later[k]) {
@@ -2842,7 +2878,8 @@ try {
             // the front's candidate kernel has tested (nearly) every candidate: look the visited ones up; the untested ones
             // (constant input) onto a second list and through the test from memory (the grid strides over their real
             // count and leaves at once when there is none)
-            hipLaunchKernelGGL(k_resolve_visited, dim3((n_vis + 255) / 256, nch), dim3(64), 0, s,
+            hipLaunchKernelGGL(k_resolve_visited, dim3((n_vis + 256 * kResolveWaves - 1) / (256 * kResolveWaves), nch),
+                               dim3(64 * kResolveWaves), 0, s,
                                static_cast<unsigned long long>(A0), h->st.p, h->visit.p, h->visit_cap, h->passmap[cur].p,
                                h->bm_stride, h->det.p, h->det_cap, h->deferred.p);
             hipLaunchKernelGGL(k_median_tests<true>, dim3(std::min<uint32_t>(n_vis, median_grid), nch), dim3(64), 0, s, zloc,
