@@ -13,7 +13,9 @@ pairs = [("bench.json", "r6_bench.json"), ("kernel_stats_pipe.csv", "r6_kernel_s
          ("kernel_stats_dense_lean.csv", "r6_kernel_stats_decode_headers.csv"),
          ("kernel_stats_dense_full.csv", "r6_kernel_stats_decode_headers_full_form.csv"),
          ("kernels_hbm_traffic.json", "r6_other_kernels_hbm_traffic.json"),
-         ("overlap_save_pattern.txt", "r6_overlap_save_pattern.txt"), ("ab.txt", "r6_ab.txt"), ("tools.txt", "r6_tools.txt")]
+         ("overlap_save_pattern.txt", "r6_overlap_save_pattern.txt"), ("ab.txt", "r6_ab.txt"), ("tools.txt", "r6_tools.txt"),
+         ("detector_tail.txt", "r6_detector_tail.txt"), ("headline_trace.txt", "r6_headline_trace.txt"),
+         ("soak.txt", "r6_soak.txt")]
 for src, dst in pairs:
     s = os.path.join(O, src)
     if os.path.exists(s):
