@@ -1446,9 +1446,11 @@ __global__ __launch_bounds__(64) void k_median_tests(const float* __restrict__ z
 // candidate; else nothing.  ONE atomic per wave and list: the channel's counters are single addresses, and an atomic
 // per 64 candidates (5 461 per 2^28 samples, one behind the other at the L2) was most of this kernel's first form.
 // (Inside k_tile_visit's walk the same lookup cost 56 us per 2^28 samples without ever running.)
-// Round 6: eight waves per workgroup, one atomic per WORKGROUP and list (1366 atomics per list were 15 of the kernel's 23 us).
-constexpr int kResolveWaves = 8;
-__global__ __launch_bounds__(64 * kResolveWaves) void k_resolve_visited(unsigned long long A0, ChanState* __restrict__ st,
+// Round 6: four waves per workgroup (one per SIMD, <= 32 registers: the workgroup still starts beside a correlator
+// workgroup), one atomic per WORKGROUP and list (1366 atomics per list were 15 of the kernel's 23 us).
+constexpr int kResolveWaves = 4;
+__global__ __attribute__((amdgpu_flat_work_group_size(64 * kResolveWaves, 64 * kResolveWaves), amdgpu_num_vgpr(16))) // (pairs: 32)
+void k_resolve_visited(unsigned long long A0, ChanState* __restrict__ st,
                                                         const uint32_t* __restrict__ visit, uint32_t visit_cap,
                                                         const unsigned long long* __restrict__ passmap, size_t bm_stride,
                                                         unsigned long long* __restrict__ det, uint32_t det_cap,
@@ -1888,10 +1890,13 @@ __global__ __launch_bounds__(256) void k_tags_generic(const cf* __restrict__ in,
 }
 
 // drop emitted detections (pos + hist < E1) from the pending list; one workgroup per channel.  Round 6: what stays is
-// what lies in the call's last `hist` items -- a handful of ten thousand -- so the list is read once by 1024 threads, the
+// what lies in the call's last `hist` items -- a handful of ten thousand -- so the list is read once by 256 threads, the
 // survivors are collected in LDS and written back to the front behind a barrier (46 -> 5 us per 2^28 samples; the one
 // wave that walked the list 64 entries at a time stays as the path for more survivors than the LDS list holds).
-constexpr int kCompactThreads = 1024, kCompactKeep = 2048;
+// 256 threads, 4 KiB of LDS: four waves of <= 16 registers, one per SIMD -- the workgroup starts BESIDE a correlator
+// workgroup (32 VGPRs per SIMD and 11 KiB of LDS are what that leaves: tools/check_occupancy.py), as the one wave of rounds
+// 1 - 5 did.
+constexpr int kCompactThreads = 256, kCompactKeep = 512;
 __global__ __launch_bounds__(kCompactThreads) void k_compact_pending(ChanState* __restrict__ st,
                                                                      ChanState* __restrict__ st_host,
                                                                      unsigned long long* __restrict__ det, uint32_t det_cap,

@@ -102,6 +102,9 @@ BUDGETS = [
     # what runs BESIDE two correlator waves of a SIMD and the correlator's LDS
     (r"k_costas_capILi\dELi2E", dict(vgpr=32, lds=CU_LDS - 151552)),
     (r"k_rot_checkpoints", dict(vgpr=32, lds=CU_LDS - 151552)),
+    # (round 6: the detector tail's workgroups of four waves -- one wave per SIMD, so 32 registers each -- that went
+    # from one wave to several for the sake of one atomic per workgroup and stay beside the correlator as before)
+    (r"k_(compact_pending|resolve_visited|scan_entries)", dict(vgpr=32, lds=CU_LDS - 151552, scratch=0)),
     # (the detector tail's streaming kernel: eight waves per SIMD since round 5)
     (r"k_candidates_waveILi12ELb1E", dict(vgpr=64, scratch=0)),
     # time-sliced against the correlator a CU at a time: their own occupancy targets
