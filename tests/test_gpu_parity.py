@@ -117,6 +117,39 @@ def same_tags(a, b):
     return a.size == b.size and all(a[f].tobytes() == b[f].tobytes() for f in a.dtype.names)
 
 
+def test_scan_with_supergroup_tables_equals_the_two_level_scan(pkg, monkeypatch):
+    """round 6: calls of more than 16 groups of 32 tiles (2^24 items) resolve the greedy scan over THREE levels of jump
+    tables (k_super_tables, k_scan_entries); GR4PM_SD_NO_SUPER=1 at creation keeps the two-level walk of rounds 1 - 5.
+    Identical tags on 2^25 samples -- bursts in noise, a constant stretch (every item a candidate: the tables' dense path),
+    silence -- in one call and in two ragged ones (the second call's scan enters at the position the first one left)"""
+    base, rrc = sig.qa_syncword_stream(75000, [700, 9000, 31000, 52000, 70001], 0.01, seed=21)
+    reps = (1 << 25) // base.size + 1
+    n = 1 << 25
+    x = np.tile(0.6 * base, reps)[:n].astype(np.complex64)
+    x += sig.awgn(n, 0.2, 22)
+    x[5_000_000:5_040_000] = 0.25
+    x[20_000_000:20_300_000] = 0
+    res = {}
+    for kind in ("three", "two"):
+        monkeypatch.delenv("GR4PM_SD_NO_SUPER", raising=False)
+        if kind == "two":
+            monkeypatch.setenv("GR4PM_SD_NO_SUPER", "1")
+        sd = pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, power_threshold=9.5, max_items=n)
+        one = sd.process_bulk(dev(x), want_output=False, tags_cap=8192)
+        sd2 = pkg.SyncwordDetection(rrc, sig.SYNCWORD, sig.BPSK, -4, 4, power_threshold=9.5, max_items=n)
+        cut = 17_000_123
+        parts = [sd2.process_bulk(dev(x[:cut]), want_output=False, tags_cap=8192),
+                 sd2.process_bulk(dev(x[cut:]), want_output=False, tags_cap=8192)]
+        res[kind] = (one, parts, sd.scan_counts())
+    monkeypatch.delenv("GR4PM_SD_NO_SUPER", raising=False)
+    (one3, parts3, counts3), (one2, parts2, counts2) = res["three"], res["two"]
+    assert one3[2].size >= 500 and counts3 == counts2 and counts3[0] >= n // 2000
+    assert same_tags(one3[2], one2[2])
+    for a, b in zip(parts3, parts2):
+        assert same_tags(a[2], b[2])
+    assert parts3[0][2].size + parts3[1][2].size == one3[2].size  # (the two calls find what the one call finds)
+
+
 def test_syncword_detection_lookahead_matches_plain_calls(pkg):
     """gr4pm_syncword_detection_hint_next: announcing the next input (right, wrong, or with a
     different length) never changes out/tags; compared chunk by chunk with a plain handle and
