@@ -15,7 +15,7 @@ pairs = [("bench.json", "r6_bench.json"), ("kernel_stats_pipe.csv", "r6_kernel_s
          ("kernels_hbm_traffic.json", "r6_other_kernels_hbm_traffic.json"),
          ("overlap_save_pattern.txt", "r6_overlap_save_pattern.txt"), ("ab.txt", "r6_ab.txt"), ("tools.txt", "r6_tools.txt"),
          ("detector_tail.txt", "r6_detector_tail.txt"), ("headline_trace.txt", "r6_headline_trace.txt"),
-         ("soak.txt", "r6_soak.txt")]
+         ("soak.txt", "r6_soak.txt"), ("tail_ab.txt", "r6_tail_ab.txt")]
 for src, dst in pairs:
     s = os.path.join(O, src)
     if os.path.exists(s):
@@ -29,8 +29,7 @@ for tag, name, bins, desc in (("r6_final/pmc_corr9", "r6_k_correlate", 4, "k_cor
     else:
         print("missing", tag)
     st = os.path.join(ROOT, "gpurun_out", tag, "stats")
-    for dirpath, _, files in os.walk(st):
-        for f in files:
-            if f.endswith("kernel_stats.csv"):
-                shutil.copy(os.path.join(dirpath, f), os.path.join(P, name + "_kernel_stats.csv"))
+    found = [os.path.join(dirpath, f) for dirpath, _, files in os.walk(st) for f in files if f.endswith("kernel_stats.csv")]
+    if found:  # (gpurun MERGES its output into gpurun_out/: the files of earlier calls are still there -- the newest one)
+        shutil.copy(max(found, key=os.path.getmtime), os.path.join(P, name + "_kernel_stats.csv"))
 print(sorted(f for f in os.listdir(P) if f.startswith("r6_")))
