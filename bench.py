@@ -923,7 +923,10 @@ def host_stream_leg(pkg, device, rrc, chunk=1 << 25, host_chunks=4, total=1 << 2
             "note": "PCIe-inclusive; not `value` (inputs of the headline are resident in HBM when the timed region starts)"}
 
 
-def sparse_leg(pkg, device, rrc, n=1 << 28, passes=48):
+SPARSE_STREAMS = ("zeros", "awgn", "one_packet_per_2^20", "dense_packets")
+
+
+def sparse_leg(pkg, device, rrc, n=1 << 28, passes=48, streams=SPARSE_STREAMS):
     """What packet density does to the rate (never `value`): the whole receiver in decode_headers mode -- the reference's
     PacketReceiver wiring, IQ in, CRC-checked packets out; what benchmarks/benchmark_packet_receiver.cpp runs -- over 2^28
     resident samples of (i) zeros (that benchmark's own input, benchmarks/README.md:49-53, results.md:45-51: 6-8 Msps
@@ -961,7 +964,7 @@ def sparse_leg(pkg, device, rrc, n=1 << 28, passes=48):
             x = torch.cat([x, torch.zeros(n - x.numel(), dtype=x.dtype, device=x.device)])
         return x[:n].contiguous(), n_pkt
 
-    for kind in ("zeros", "awgn", "one_packet_per_2^20", "dense_packets"):
+    for kind in streams:
         x, n_pkt = make(kind)
         ring = torch.empty(hist + 1 + n, dtype=torch.complex64, device=device)
         ring[1:1 + hist] = x[-hist:]
@@ -1053,12 +1056,26 @@ def sparse_leg_in_a_fresh_process():
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--sparse-leg-only"], capture_output=True, text=True, env=env)
-    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
-    if r.returncode != 0 or not lines:
-        raise SystemExit(f"bench.py: the sparse leg's child process failed ({r.returncode}):\n{r.stdout[-1500:]}\n{r.stderr[-3000:]}")
-    rec = json.loads(lines[-1])
+    def child(extra_args, extra_env):
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--sparse-leg-only"] + extra_args, capture_output=True,
+                           text=True, env={**env, **extra_env})
+        lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            raise SystemExit(f"bench.py: the sparse leg's child process failed ({r.returncode}):\n{r.stdout[-1500:]}\n{r.stderr[-3000:]}")
+        return json.loads(lines[-1])
+    rec = child([], {})
     rec["measured_in"] = "a child process of its own (bench.py --sparse-leg-only)"
+    # Round 6: one packet per 2^20 samples again, in a process whose HIP runtime has 32 hardware queues instead of the
+    # default four (GPU_MAX_HW_QUEUES, read when the runtime starts).  There the library runs the phasor chains of
+    # consecutive batches SIDE BY SIDE (each is 2^20 dependent steps, 16.7 ms; csrc/stream_blocks.hip: PlanSync) instead of
+    # one batch's behind the other's -- with four queues a chain kernel holds back whatever shares its queue, and the
+    # library keeps the one-kernel form.  A process-wide setting with a price elsewhere (the front end alone: -1 %, 64
+    # channels: +3 %), so a receiver process chooses it by its traffic; the rows above are the runtime's default.
+    key = "one_packet_per_2^20"
+    if key in rec["streams"]:
+        wide = child(["--sparse-streams", key], {"GPU_MAX_HW_QUEUES": "32"})["streams"][key]
+        wide["process_setting"] = "GPU_MAX_HW_QUEUES=32 (the phasor chains of consecutive batches side by side)"
+        rec["streams"][key + ", 32 hardware queues"] = wide
     return rec
 
 
@@ -1368,6 +1385,8 @@ def main():
                          "about 20 s, before anything else): the committed PMC file is quoted instead")
     ap.add_argument("--sparse-leg-only", action="store_true",
                     help="(what the default run starts as a child process) the packet-density sub-record alone, printed as JSON")
+    ap.add_argument("--sparse-streams", default=",".join(SPARSE_STREAMS),
+                    help="with --sparse-leg-only: which of its streams (comma-separated)")
     ap.add_argument("--selfcheck", action="store_true",
                     help="N-rank first-contact check only (rendezvous, identities, a small scatter, two batches): what "
                          "`bench.py --gpus N` runs by itself before the job")
@@ -1391,7 +1410,8 @@ def main():
         pkg = ge.load_package()
         torch.cuda.set_device(0)
         sys.setswitchinterval(float(os.environ.get("GR4PM_SWITCH_INTERVAL", "5e-5")))
-        print(json.dumps(sparse_leg(pkg, torch.device("cuda", 0), unit_norm_rrc(pkg))))
+        print(json.dumps(sparse_leg(pkg, torch.device("cuda", 0), unit_norm_rrc(pkg),
+                                    streams=tuple(k for k in args.sparse_streams.split(",") if k in SPARSE_STREAMS))))
         return None
     if args.config == 5:
         return config5(args)

@@ -25,8 +25,11 @@ using namespace gr4pm;
 
 namespace {
 
-static_assert(7 <= GR4PM_CFC_PLANS, "a slot keeps its CFC plan from stage 1 to stage 1b: the plan ring must cover every slot");
-constexpr int kSlots = 7; // detector | pass A (decode_headers) | stage 1 | stage 1b | stage 2 | stage 3 (decode_headers) | held by the caller
+// detector | pass A (decode_headers) | stage 1 | stage 1b | stage 2 | stage 3 (decode_headers) | held by the caller, and
+// (round 6) three more that wait in front of stage 1b while their phasor chains run side by side on the CFC's own streams
+// (one packet per 2^20 samples: a chain is 16.7 ms long, a batch every 4 ms)
+constexpr int kSlots = 10;
+static_assert(kSlots <= GR4PM_CFC_PLANS, "a slot keeps its CFC plan from stage 1 to stage 1b: the plan ring must cover every slot");
 
 struct Slot {
     uint64_t seq = 0; // ordinal of the batch (1, 2, ...)

@@ -249,6 +249,13 @@ __global__ __launch_bounds__(64) void k_rot_checkpoints(const RotSeg* __restrict
     }
 }
 
+// (tests only: GR4PM_TEST_ROT_DELAY_US) keeps a stream busy for `us` microseconds
+__global__ void k_test_delay(unsigned us)
+{
+    const unsigned long long t0 = wall_clock64(); // 100 MHz
+    while (wall_clock64() - t0 < 100ull * us) __builtin_amdgcn_s_sleep(64);
+}
+
 // the checkpoints of the segments whose phasor is a fixed point of the recurrence (RotSeg::mode == 2): the constant
 __global__ __launch_bounds__(256) void k_rot_const_fill(const RotSeg* __restrict__ segs, const unsigned* __restrict__ list,
                                                         cf* __restrict__ ck)
@@ -1748,8 +1755,40 @@ struct gr4pm_rotator {
     float phase_incr;
     size_t delay, n_channels;
     hipStream_t stream;
-    DevBuf<RotState> state; // [2][n_channels], st_cur selects the current half
+    // [kStates][n_channels], st_cur selects the row a call reads; it writes the next one (round 6: a ring instead of two
+    // halves -- the chain kernels of several plans are in flight at once, see PlanSync)
+    static constexpr int kStates = GR4PM_CFC_PLANS + 2;
+    DevBuf<RotState> state;
     int st_cur = 0;
+    // Round 6: the chains of CONSECUTIVE ring plans run side by side.  A plan's segments that start at a set_freq event
+    // (or are fixed points) depend on nothing before them: their kernel goes to one of kAux streams of the handle's own.
+    // The segments that continue the carried phasor -- at most one per channel -- need the state the plan before wrote:
+    // their kernel goes to `dep`, one stream for all plans, behind the other kernel of the plan before.  The consumers
+    // (the fused symbol filter) wait for the plan's two events on THEIR stream; the stream the plan was made on carries the
+    // uploads only, so the pipeline stage that makes the plans no longer waits for a chain.  With one packet per 2^20
+    // samples a chain is 2^20 dependent steps (16.7 ms) per 2^28-sample batch: one behind the other they were the
+    // receiver's period (15 Gsps); side by side they are its latency.  GR4PM_ROT_SERIAL=1: one kernel on the handle's stream.
+    // Three kernels a plan, each on a stream of its own (kAux of each kind, taken in turn): `writer` = the channels' LAST
+    // segments where they start at an event (they write the carried state: the plan behind waits for this kernel alone, not
+    // for the other 2^20-step chains of the plan), `indep` = the other event-started segments, `dep` = the continuations.
+    static constexpr int kAux = 4;
+    hipStream_t aux[3 * kAux] = {};
+    bool async_ready = false;
+    struct PlanSync {
+        hipEvent_t up = nullptr, indep = nullptr, writer = nullptr, dep = nullptr;
+        bool async = false;
+        bool dep_writes_state = false; // a continuation is its channel's last segment (no event in the call)
+    } sync[GR4PM_CFC_PLANS];
+    int last_async_plan = -1; // the plan whose kernels wrote the state row st_cur (or -1: written on `stream`)
+    // When: a ring plan whose longest chain is at least kAsyncMinItems long (2 ms of dependent steps; packets back to back
+    // make chains of 26 000 items and gain nothing: 56.6 -> 55 Gsps with three kernels and their events per plan), in a
+    // process whose HIP runtime has at least eight hardware queues (GPU_MAX_HW_QUEUES; its default is four, and a chain
+    // kernel that shares a queue with another stream's work holds that work back for as long as it lives: with four
+    // queues the side-by-side form is SLOWER than one kernel, 14.8 against 18.3 Gsps at one packet per 2^20 samples,
+    // with sixteen it is 41.8).  Read at creation: GR4PM_ROT_SERIAL=1 never, GR4PM_ROT_ASYNC=1 always (tests).
+    static constexpr size_t kAsyncMinItems = size_t{ 1 } << 17;
+    int async_policy = 0; // 0: by chain length and queue count, 1: always, -1: never
+    unsigned test_delay_us = 0; // GR4PM_TEST_ROT_DELAY_US: every chain kernel of an asynchronous plan starts that much later
     // the plan of a call (segment table, phasor checkpoints, increments, counters): a ring of
     // GR4PM_CFC_PLANS sets, so that the next calls can be planned while the consumers of earlier
     // plans are still running (gr4pm_cfc_symbol_filter_plan / _run; buffers are allocated on first use)
@@ -1782,8 +1821,18 @@ struct gr4pm_rotator {
     std::vector<cf> fixed_exp, fixed_incr;
 };
 
+// the handle's own streams idle (the chains of ring plans run there)
+static void rotator_sync_own_streams(gr4pm_rotator* h)
+{
+    for (hipStream_t a : h->aux)
+        if (a) (void)hipStreamSynchronize(a);
+}
+
 static gr4pm_status rotator_reset_impl(gr4pm_rotator* h)
 {
+    rotator_sync_own_streams(h);
+    h->last_async_plan = -1;
+    for (auto& y : h->sync) y.async = false;
     std::vector<RotState> st(h->n_channels);
     for (auto& s : st) {
         s.exp = { 1.0f, 0.0f };
@@ -1821,7 +1870,13 @@ try {
     h->delay = p->delay;
     h->n_channels = p->n_channels;
     h->stream = static_cast<hipStream_t>(p->stream);
-    gr4pm_status s = h->state.alloc(2 * h->n_channels); // ping-pong halves
+    {
+        const char* q = getenv("GPU_MAX_HW_QUEUES");
+        const int hw_queues = q ? atoi(q) : 4;
+        h->async_policy = getenv("GR4PM_ROT_SERIAL") ? -1 : getenv("GR4PM_ROT_ASYNC") ? 1 : hw_queues >= 8 ? 0 : -1;
+        if (const char* d = getenv("GR4PM_TEST_ROT_DELAY_US")) h->test_delay_us = static_cast<unsigned>(std::max(0, atoi(d)));
+    }
+    gr4pm_status s = h->state.alloc(static_cast<size_t>(gr4pm_rotator::kStates) * h->n_channels);
     if (s == GR4PM_OK) s = rotator_reset_impl(h);
     if (s != GR4PM_OK) {
         delete h;
@@ -1835,6 +1890,15 @@ void gr4pm_rotator_destroy(gr4pm_rotator* h)
 try {
     if (!h) return;
     (void)hipStreamSynchronize(h->stream);
+    rotator_sync_own_streams(h);
+    for (auto& y : h->sync) {
+        if (y.up) (void)hipEventDestroy(y.up);
+        if (y.indep) (void)hipEventDestroy(y.indep);
+        if (y.writer) (void)hipEventDestroy(y.writer);
+        if (y.dep) (void)hipEventDestroy(y.dep);
+    }
+    for (hipStream_t a : h->aux)
+        if (a) (void)hipStreamDestroy(a);
     delete h;
 }
 GR4PM_ABI_CATCH_VOID
@@ -1994,6 +2058,11 @@ static gr4pm_status rotator_plan_impl(gr4pm_rotator* h, size_t n, const gr4pm_ta
         GR4PM_TRY(pl.seg_incr.alloc(n_segs * 2));
         GR4PM_TRY(pl.seg_counter0.alloc(n_segs * 2));
     }
+    // order[]: first the segments that depend on nothing before this call (a set_freq event starts them, or they are fixed
+    // points), then the ones that continue the carried phasor (mode 0: at most one per channel); each part by descending
+    // length, so that the long ones (a stream with missed detections) share waves
+    unsigned n_indep = 0, n_writer = 0;
+    bool dep_writes_state = false;
     {
         static thread_local std::vector<unsigned> order;
         order.resize(n_segs);
@@ -2001,32 +2070,101 @@ static gr4pm_status rotator_plan_impl(gr4pm_rotator* h, size_t n, const gr4pm_ta
         static const bool no_sort = gr4pm::experiment_env("GR4PM_ROT_NO_SORT", false) != nullptr;
         if (!no_sort)
             std::stable_sort(order.begin(), order.end(), [&](unsigned a, unsigned b) { return segs[a].len > segs[b].len; });
+        auto part = [&](unsigned a) { return segs[a].mode == 0 ? 2 : segs[a].last ? 1 : 0; }; // indep | writer | dep
+        std::stable_sort(order.begin(), order.end(), [&](unsigned a, unsigned b) { return part(a) < part(b); });
+        for (unsigned i = 0; i < n_segs; ++i) {
+            n_indep += part(i) == 0;
+            n_writer += part(i) == 1;
+            dep_writes_state |= part(i) == 2 && segs[i].last;
+        }
         GR4PM_TRY(upload_vec(pl.order, order, s));
     }
-    static const unsigned wg = gr4pm::experiment_env_wg("GR4PM_ROT_WG", 64u, 1u, 64u); // __launch_bounds__(64)
-    if (!timing_skip("rot")) // GR4PM_TIMING_SKIP: what a kernel costs the pipeline (results are garbage)
-        hipLaunchKernelGGL(k_rot_checkpoints, dim3(grid_for(n_segs, wg)), dim3(wg), 0, s, pl.segs.p, n_segs,
-                           h->state.p + static_cast<size_t>(h->st_cur) * h->n_channels,
-                           h->state.p + static_cast<size_t>(h->st_cur ^ 1) * h->n_channels,
-                           pl.ck.p, pl.seg_incr.p, pl.seg_counter0.p, pl.order.p);
     if (n_const) {
         static thread_local std::vector<unsigned> list;
         list.clear();
-        unsigned long long longest = 0;
         for (unsigned i = 0; i < n_segs; ++i)
-            if (segs[i].mode == 2) {
-                list.push_back(i);
-                longest = std::max(longest, segs[i].len);
-            }
+            if (segs[i].mode == 2) list.push_back(i);
         GR4PM_TRY(upload_vec(pl.const_list, list, s));
-        const unsigned gx = static_cast<unsigned>(std::min<unsigned long long>((longest / kRotChunk + 255) / 256 + 1, 2048));
-        for (size_t first = 0; first < list.size(); first += 65535) {
-            const unsigned rows = static_cast<unsigned>(std::min<size_t>(65535, list.size() - first));
-            hipLaunchKernelGGL(k_rot_const_fill, dim3(gx, rows), dim3(256), 0, s, pl.segs.p, pl.const_list.p + first, pl.ck.p);
+    }
+    unsigned long long longest_const = 0;
+    for (unsigned i = 0; i < n_segs; ++i)
+        if (segs[i].mode == 2) longest_const = std::max(longest_const, segs[i].len);
+    const RotState* st_in = h->state.p + static_cast<size_t>(h->st_cur) * h->n_channels;
+    const int st_next = (h->st_cur + 1) % gr4pm_rotator::kStates;
+    RotState* st_out = h->state.p + static_cast<size_t>(st_next) * h->n_channels;
+    static const unsigned wg = gr4pm::experiment_env_wg("GR4PM_ROT_WG", 64u, 1u, 64u); // __launch_bounds__(64)
+    auto launch_chains = [&](hipStream_t on, unsigned first, unsigned count) {
+        if (count && !timing_skip("rot")) // GR4PM_TIMING_SKIP: what a kernel costs the pipeline (results are garbage)
+            hipLaunchKernelGGL(k_rot_checkpoints, dim3(grid_for(count, wg)), dim3(wg), 0, on, pl.segs.p, count, st_in, st_out,
+                               pl.ck.p, pl.seg_incr.p, pl.seg_counter0.p, pl.order.p + first);
+    };
+    auto launch_const_fill = [&](hipStream_t on) {
+        if (!n_const) return;
+        const unsigned gx = static_cast<unsigned>(std::min<unsigned long long>((longest_const / kRotChunk + 255) / 256 + 1, 2048));
+        for (size_t first = 0; first < n_const; first += 65535) {
+            const unsigned rows = static_cast<unsigned>(std::min<size_t>(65535, n_const - first));
+            hipLaunchKernelGGL(k_rot_const_fill, dim3(gx, rows), dim3(256), 0, on, pl.segs.p, pl.const_list.p + first, pl.ck.p);
         }
+    };
+    // (tests: GR4PM_TEST_ROT_DELAY_US holds every chain kernel of such a plan back by that long, so that a consumer that
+    // does not wait for the plan's events reads checkpoints that are not there yet)
+    const unsigned test_delay_us = h->test_delay_us;
+    unsigned long long longest_chain = 0;
+    for (unsigned i = 0; i < n_segs; ++i)
+        if (segs[i].mode != 2) longest_chain = std::max(longest_chain, segs[i].len);
+    const bool side_by_side = ring && (h->async_policy > 0 || (h->async_policy == 0 && longest_chain >= gr4pm_rotator::kAsyncMinItems));
+    auto& sy = h->sync[h->plan_cur];
+    if (side_by_side) {
+        if (!h->async_ready) { // the handle's own streams (at the priority of the one it was given) and the plans' events
+            int prio = 0;
+            GR4PM_HIP_TRY(hipStreamGetPriority(s, &prio));
+            for (auto& a : h->aux) GR4PM_HIP_TRY(hipStreamCreateWithPriority(&a, hipStreamNonBlocking, prio));
+            for (auto& y : h->sync) {
+                GR4PM_HIP_TRY(hipEventCreateWithFlags(&y.up, hipEventDisableTiming));
+                GR4PM_HIP_TRY(hipEventCreateWithFlags(&y.indep, hipEventDisableTiming));
+                GR4PM_HIP_TRY(hipEventCreateWithFlags(&y.writer, hipEventDisableTiming));
+                GR4PM_HIP_TRY(hipEventCreateWithFlags(&y.dep, hipEventDisableTiming));
+            }
+            h->async_ready = true;
+        }
+        constexpr int K = gr4pm_rotator::kAux;
+        const int turn = h->plan_cur % K;
+        hipStream_t s_indep = h->aux[turn], s_writer = h->aux[K + turn], s_dep = h->aux[2 * K + turn];
+        GR4PM_HIP_TRY(hipEventRecord(sy.up, s)); // tables of this plan on the device, and everything `s` carried before
+        GR4PM_HIP_TRY(hipStreamWaitEvent(s_indep, sy.up, 0));
+        if (test_delay_us) hipLaunchKernelGGL(k_test_delay, dim3(1), dim3(64), 0, s_indep, test_delay_us);
+        launch_chains(s_indep, 0, n_indep);
+        launch_const_fill(s_indep);
+        GR4PM_HIP_TRY(hipEventRecord(sy.indep, s_indep));
+        GR4PM_HIP_TRY(hipStreamWaitEvent(s_writer, sy.up, 0));
+        if (test_delay_us) hipLaunchKernelGGL(k_test_delay, dim3(1), dim3(64), 0, s_writer, test_delay_us / 3);
+        launch_chains(s_writer, n_indep, n_writer);
+        GR4PM_HIP_TRY(hipEventRecord(sy.writer, s_writer));
+        // the continuations read the carried phasor: behind the kernels of the plan before that wrote it
+        GR4PM_HIP_TRY(hipStreamWaitEvent(s_dep, sy.up, 0));
+        if (h->last_async_plan >= 0) {
+            const auto& before = h->sync[h->last_async_plan];
+            GR4PM_HIP_TRY(hipStreamWaitEvent(s_dep, before.writer, 0));
+            if (before.dep_writes_state) GR4PM_HIP_TRY(hipStreamWaitEvent(s_dep, before.dep, 0));
+        }
+        if (test_delay_us) hipLaunchKernelGGL(k_test_delay, dim3(1), dim3(64), 0, s_dep, test_delay_us / 2);
+        launch_chains(s_dep, n_indep + n_writer, n_segs - n_indep - n_writer);
+        GR4PM_HIP_TRY(hipEventRecord(sy.dep, s_dep));
+        sy.async = true;
+        sy.dep_writes_state = dep_writes_state;
+        h->last_async_plan = h->plan_cur;
+    } else {
+        if (h->last_async_plan >= 0) { // (a plain call behind ring plans: their kernels wrote the state this one reads)
+            GR4PM_HIP_TRY(hipStreamWaitEvent(s, h->sync[h->last_async_plan].writer, 0));
+            GR4PM_HIP_TRY(hipStreamWaitEvent(s, h->sync[h->last_async_plan].dep, 0));
+            h->last_async_plan = -1;
+        }
+        launch_chains(s, 0, n_segs);
+        launch_const_fill(s);
+        sy.async = false;
     }
     GR4PM_HIP_TRY(hipGetLastError());
-    h->st_cur ^= 1;
+    h->st_cur = st_next;
     return GR4PM_OK;
 }
 
@@ -2130,7 +2268,7 @@ try {
     h->n_channels = p->n_channels;
     h->stream = static_cast<hipStream_t>(p->stream);
     costas_coeffs(h);
-    gr4pm_status s = h->state.alloc(2 * h->n_channels); // ping-pong halves
+    gr4pm_status s = h->state.alloc(static_cast<size_t>(gr4pm_rotator::kStates) * h->n_channels);
     if (s == GR4PM_OK) s = h->state.zero(h->stream);
     if (s == GR4PM_OK && hipStreamSynchronize(h->stream) != hipSuccess) s = GR4PM_ERR_HIP;
     if (s != GR4PM_OK) {
@@ -2976,6 +3114,18 @@ try {
 }
 GR4PM_ABI_CATCH
 
+// the chains of a ring plan run on the rotator's own streams (gr4pm_rotator::PlanSync): what reads its checkpoints waits
+// for them on its own stream, not on the host
+static gr4pm_status cfc_wait_plan(gr4pm_rotator* cfc, int plan, hipStream_t consumer)
+{
+    const auto& y = cfc->sync[plan];
+    if (!y.async) return GR4PM_OK;
+    GR4PM_HIP_TRY(hipStreamWaitEvent(consumer, y.indep, 0));
+    GR4PM_HIP_TRY(hipStreamWaitEvent(consumer, y.writer, 0));
+    GR4PM_HIP_TRY(hipStreamWaitEvent(consumer, y.dep, 0));
+    return GR4PM_OK;
+}
+
 static gr4pm_status cfc_plan_impl(gr4pm_rotator* cfc, size_t n_in, const gr4pm_tag* tags_in,
                                   const uint32_t* tag_channel, size_t n_tags_in, int* plan, bool ring)
 {
@@ -3057,6 +3207,7 @@ try {
         set_error("channel %zu outside the rotation plan", channel);
         return GR4PM_ERR_INVALID;
     }
+    GR4PM_TRY(cfc_wait_plan(cfc, plan, sf->stream));
     // the channel's own segments (they tile its [0, n_in)); checkpoint slots are plan-wide
     const unsigned first = pl.seg_first[channel];
     CfcDev f;
@@ -3156,6 +3307,7 @@ try {
         n_tags_out[c] = rp.n_pub;
     }
     hipStream_t s = h0->stream;
+    GR4PM_TRY(cfc_wait_plan(cfc, plan, s));
     const size_t chan_words = n_channels * sizeof(SymChan) / 8, run_words = runs.size() * sizeof(SymRun) / 8;
     cfc->mc_host.resize(chan_words + run_words);
     std::memcpy(cfc->mc_host.data(), chans.data(), chan_words * 8);

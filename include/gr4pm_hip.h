@@ -350,7 +350,7 @@ gr4pm_status gr4pm_cfc_symbol_filter_process(gr4pm_rotator* cfc, gr4pm_symbol_fi
  * and runs each in stream order).  GR4PM_CFC_PLANS plans exist (a ring): a plan stays valid until
  * GR4PM_CFC_PLANS - 1 further plans have been made, so that many calls may sit between the two
  * halves.  `plan` is the value _plan returned. */
-#define GR4PM_CFC_PLANS 8
+#define GR4PM_CFC_PLANS 12
 gr4pm_status gr4pm_cfc_symbol_filter_plan(gr4pm_rotator* cfc, size_t n_in, const gr4pm_tag* tags_in,
                                           size_t n_tags_in, int* plan);
 /* many channels: ONE CoarseFrequencyCorrection handle with n_channels channels plans all of them
