@@ -2982,6 +2982,70 @@ def test_native_packet_receiver_decode_many_batches_pipelined_equals_sequential(
             assert np.array_equal(a["packets"].cpu().numpy(), b["packets"].cpu().numpy())
 
 
+@pytest.mark.parametrize("decode", [False, True])
+def test_phasor_chains_of_consecutive_batches_side_by_side(pkg, monkeypatch, decode):
+    """round 6: the CoarseFrequencyCorrection chains of consecutive batches on the rotator's own streams (independent
+    segments | the channels' last segments | the continuations of the carried phasor, a ring of state rows, three events a
+    plan that the fused symbol filter waits for on ITS stream) against one chain kernel per batch on the stage's stream.
+    GR4PM_ROT_ASYNC=1 forces the form the library otherwise chooses for chains of >= 2^17 items in a process with >= 8
+    hardware queues; GR4PM_TEST_ROT_DELAY_US starts every chain kernel 2.5 ms late (its three kernels by different amounts),
+    so that a consumer that does not wait, or a continuation that reads the state before the batch in front wrote it,
+    gives different bits.  Thirty batches with cuts inside packets and gaps, batches without any packet in between
+    (continuations that are their channel's last segment), pipelined and batch by batch, two receivers each"""
+    rng = np.random.default_rng(61)
+    payloads = [rng.integers(0, 256, int(n)).astype(np.uint8).tobytes() for n in rng.integers(20, 400, 220)]
+    gaps = rng.integers(800, 3000, len(payloads))
+    gaps[40] = 200000  # three batches in a row without a tag
+    gaps[41] = 1
+    x = pkg.BurstGenerator().stream(payloads, gaps, freq_error=0.011, esn0_db=20.0, seed=62)
+    n_total = x.numel()
+    chunks, pos = [], 0
+    while pos + 40000 <= n_total:
+        take = min(int(rng.integers(30000, 70000)), n_total - pos)
+        chunks.append(x[pos:pos + take])
+        pos += ((take - 2048) // 1752 + 1) * 1752
+    assert len(chunks) >= 25
+
+    def run(pipelined, side_by_side):
+        monkeypatch.delenv("GR4PM_ROT_ASYNC", raising=False)
+        monkeypatch.delenv("GR4PM_TEST_ROT_DELAY_US", raising=False)
+        monkeypatch.setenv("GR4PM_ROT_SERIAL", "1")
+        if side_by_side:
+            monkeypatch.delenv("GR4PM_ROT_SERIAL")
+            monkeypatch.setenv("GR4PM_ROT_ASYNC", "1")
+            monkeypatch.setenv("GR4PM_TEST_ROT_DELAY_US", "2500")
+        res = []
+        for rep in range(2):
+            rx = pkg.NativePacketReceiver(max_items=70000, tags_cap=1024, pipelined=pipelined, decode_headers=decode)
+            out, announced = [], 0
+            for k, c in enumerate(chunks):
+                while pipelined and announced < min(k + 2, len(chunks) - 1):
+                    announced += 1
+                    rx.announce(chunks[announced])
+                r = rx.process_bulk(c) if decode else rx.process_bulk(c, 100)
+                if r is not None:
+                    out.append(r)
+            res.append(out + rx.flush())
+            del rx
+        return res
+
+    want = run(False, False)
+    assert sum(r["tags"].size for r in want[0]) >= 100
+    for pipelined in (False, True):
+        got = run(pipelined, True)
+        for w_rep, g_rep in zip(want, got):
+            assert len(w_rep) == len(g_rep)
+            for a, b in zip(w_rep, g_rep):
+                assert a["consumed"] == b["consumed"] and same_tags(a["tags"], b["tags"])
+                if decode:
+                    assert np.array_equal(a["packet_lengths"], b["packet_lengths"])
+                    assert np.array_equal(a["packets"].cpu().numpy(), b["packets"].cpu().numpy())
+                else:
+                    assert np.array_equal(bits(host(a["symbols"])), bits(host(b["symbols"])))
+    monkeypatch.delenv("GR4PM_ROT_ASYNC", raising=False)
+    monkeypatch.delenv("GR4PM_TEST_ROT_DELAY_US", raising=False)
+
+
 @pytest.mark.parametrize("pipelined", [False, True])
 def test_native_packet_receiver_packets_only_equals_the_full_form(pkg, pipelined):
     """round 6: gr4pm_packet_receiver_params::packets_only -- SyncwordRemove, the LLR decoder, the descrambler,
