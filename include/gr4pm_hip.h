@@ -349,7 +349,12 @@ gr4pm_status gr4pm_cfc_symbol_filter_process(gr4pm_rotator* cfc, gr4pm_symbol_fi
  * SymbolFilter's stream.  The caller orders them (a _run after its _plan has completed; plans
  * and runs each in stream order).  GR4PM_CFC_PLANS plans exist (a ring): a plan stays valid until
  * GR4PM_CFC_PLANS - 1 further plans have been made, so that many calls may sit between the two
- * halves.  `plan` is the value _plan returned. */
+ * halves.  `plan` is the value _plan returned.
+ * Round 6: where chains are long (>= 2^17 items between two syncword_freq events) and the process has at least eight
+ * hardware queues (GPU_MAX_HW_QUEUES), _plan leaves the chains running on streams of the CFC handle's own when it
+ * returns -- those of consecutive plans side by side -- and _run makes the SymbolFilter's stream wait for them
+ * (events); the caller's ordering rule is unchanged, what it gains is that the stage which makes the plans does not
+ * wait for a chain.  GR4PM_ROT_SERIAL=1 (read when the handle is created): never. */
 #define GR4PM_CFC_PLANS 12
 gr4pm_status gr4pm_cfc_symbol_filter_plan(gr4pm_rotator* cfc, size_t n_in, const gr4pm_tag* tags_in,
                                           size_t n_tags_in, int* plan);
