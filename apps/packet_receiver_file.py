@@ -23,8 +23,13 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# A recording is mostly silence between packets: the stretch between two detections is one serial phasor chain, and the
+# library runs the chains of consecutive batches side by side where the HIP runtime has hardware queues to spare
+# ("Process settings"; read when the runtime starts, i.e. before torch is imported)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
