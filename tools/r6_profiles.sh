@@ -31,6 +31,14 @@ hipcc --offload-arch=gfx950 -O3 -o /tmp/osp tools/overlap_save_pattern.hip && /t
   R6_FIELDS=packets PASSES=48 tools/r6_dense_ab.sh 2 "GR4PM_COSTAS_SMALL_DECODE=0" "GR4PM_COSTAS_SMALL_DECODE=1" "GR4PM_COSTAS_SMALL_DECODE=2";
   echo "## ... run length (fill and drain of the six-stage pipeline against the steady state)";
   for p in 6 12 24 48 96; do R6_FIELDS=packets R6_LEAN=1 python3 tools/r6_dense_kstats.py $p 2>/dev/null | tail -1; done;
+  echo "## CrcCheck inside the packets_only receiver, packets back to back, 48 passes: slicing by eight (default) against the byte-wise kernel";
+  R6_FIELDS=packets PASSES=48 tools/r6_dense_ab.sh 3 "-" "GR4PM_CRC_BYTEWISE=1";
+  echo "## one packet per 2^20 samples (bench.py --sparse-leg-only): value Msps, steady-state ms per 2^28 -- hardware queues of the process x the phasor chains of consecutive batches one kernel per batch (GR4PM_ROT_SERIAL=1) | side by side";
+  for q in 4 16 32; do for ser in 1 0; do
+    if [ $ser = 1 ]; then export GR4PM_ROT_SERIAL=1; else unset GR4PM_ROT_SERIAL; fi
+    echo -n "GPU_MAX_HW_QUEUES=$q $([ $ser = 1 ] && echo 'one kernel per batch' || echo 'side by side (where the library chooses it)'): ";
+    GPU_MAX_HW_QUEUES=$q python3 bench.py --sparse-leg-only --sparse-streams "one_packet_per_2^20" 2>/dev/null | tail -1 | python3 -c "import json,sys; v=json.loads(sys.stdin.read())['streams']['one_packet_per_2^20']; print(v['value'], v['steady_state_ms_per_2^28'])";
+  done; done; unset GR4PM_ROT_SERIAL;
 } > $O/ab.txt 2>/dev/null
 { python3 tools/benchmark_syncword_detection.py 4 9.5 | tail -1; python3 tools/benchmark_syncword_detection.py 0 9.5 | tail -1;
   python3 tools/benchmark_packet_receiver.py all 9.5 268435456 2 | tail -1;
