@@ -151,14 +151,12 @@ __device__ __forceinline__ cf rot_chunk_pk(cf e, cf inc)
 // correlator waves (2 x 240 registers) has exactly 32 left, so a wave of this kernel fits BESIDE them instead of keeping
 // the next correlator workgroup off its CU (HISTORY.md section 9).  Hence: segment fields are re-read where they are
 // needed instead of kept, chunk counts are 32 bit (a segment is shorter than 2^35 items), one running pointer.
-__global__ __launch_bounds__(64) void k_rot_checkpoints(const RotSeg* __restrict__ segs, unsigned n_segs,
+__device__ __forceinline__ void rot_checkpoints_generic(unsigned lane_seg, const RotSeg* __restrict__ segs, unsigned n_segs,
                                                         const RotState* __restrict__ state,
                                                         RotState* __restrict__ state_next, cf* __restrict__ ck,
                                                         cf* __restrict__ seg_incr, unsigned* __restrict__ seg_counter0,
                                                         const unsigned* __restrict__ order)
 {
-    __builtin_amdgcn_s_setprio(GR4PM_ROT_PRIO); // latency-bound, few waves
-    const unsigned lane_seg = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane_seg >= n_segs) return;
     // order[]: the segments by descending length, so that the long ones (a stream with missed detections) share
     // waves -- a wave lives as long as its longest lane (see costas_process_impl); the array itself stays sorted by
@@ -195,8 +193,17 @@ __global__ __launch_bounds__(64) void k_rot_checkpoints(const RotSeg* __restrict
     seg_counter0[s] = counter;
     cf* ckp = ck + gp->ck0;
     unsigned left = static_cast<unsigned>(gp->len / kRotChunk);
-    while (left != 0) {
-        if (left >= 4 && (counter & 511u) < 512u - 4 * kRotChunk && !(reinterpret_cast<size_t>(ckp) & 8)) {
+    // Round 6 (see k_rot_checkpoints_fresh): whole periods of 64 chunks in a loop without per-chunk decisions.  The
+    // renormalisation falls into every 64th chunk, always the same one: the chunk loop below runs up to it (`lead` chunks),
+    // then every period is that chunk item by item + 63 plain chunks under a scalar counter; what is left (less than a
+    // period) goes through the chunk loop again.  Checkpoints leave 8 bytes at a time here: a continuation's slot has any
+    // alignment, and there is one such segment per channel.
+    const unsigned lead = ((512u - (counter & 511u)) - 1u) / kRotChunk; // plain chunks in front of the renormalising one
+    const bool periods = left > lead && left - lead >= 64u;
+    for (int phase = 0; phase < 2; ++phase) {
+    const unsigned stop = phase == 0 && periods ? left - lead : 0u; // chunks still to do when this phase ends
+    while (left != stop) {
+        if (left - stop >= 4 && (counter & 511u) < 512u - 4 * kRotChunk && !(reinterpret_cast<size_t>(ckp) & 8)) {
             // four chunks per pass while no renormalisation falls into them: the chain itself (3 instructions a step)
             // with one counter test and one branch per 32 steps instead of per 8.  The four checkpoints leave as two
             // 16-byte stores (round 5; hence the alignment test -- a single chunk below flips it): every lane writes to
@@ -233,6 +240,20 @@ __global__ __launch_bounds__(64) void k_rot_checkpoints(const RotSeg* __restrict
             for (unsigned j = 0; j < kRotChunk; ++j) rot_step(e, inc, counter);
         }
     }
+    if (phase == 0 && periods) {
+        for (; left >= 64u; left -= 64u) {
+            *ckp++ = e;
+#pragma unroll 1
+            for (unsigned j = 0; j < kRotChunk; ++j) rot_step(e, inc, counter); // the period's renormalising chunk
+#pragma unroll 1
+            for (int k = 0; k < 63; ++k) {
+                *ckp++ = e;
+                e = rot_chunk_pk(e, inc);
+            }
+            counter += 63 * kRotChunk;
+        }
+    }
+    } // phases
     gp = segs + s; // (recomputed: one register kept across the loop instead of two)
     const unsigned rem = static_cast<unsigned>(gp->len) & (kRotChunk - 1);
     if (rem) {
@@ -245,8 +266,127 @@ __global__ __launch_bounds__(64) void k_rot_checkpoints(const RotSeg* __restrict
         st.incr = inc;
         st.counter = counter;
         st.pad = 0;
-        state_next[gp->channel] = st; // ping-pong: another lane may still have to read `state`
+        state_next[gp->channel] = st; // (another row of the ring: another lane may still have to read `state`)
     }
+}
+__global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_num_vgpr(16))) // (register pairs: 32)
+void k_rot_checkpoints(const RotSeg* __restrict__ segs, unsigned n_segs,
+                                                        const RotState* __restrict__ state,
+                                                        RotState* __restrict__ state_next, cf* __restrict__ ck,
+                                                        cf* __restrict__ seg_incr, unsigned* __restrict__ seg_counter0,
+                                                        const unsigned* __restrict__ order)
+{
+    __builtin_amdgcn_s_setprio(GR4PM_ROT_PRIO); // latency-bound, few waves
+    rot_checkpoints_generic(blockIdx.x * blockDim.x + threadIdx.x, segs, n_segs, state, state_next, ck, seg_incr, seg_counter0,
+                            order);
+}
+
+// Round 6: the segments that START at a set_freq event (mode 1; the host gives them an even checkpoint slot) in a loop
+// without per-chunk decisions.  tools/lone_wave_issue.hip: the chain's three packed instructions cost a lone wave 5.2 core
+// clocks each, 6.5 ns a step -- the kernel above takes 12 - 16: every chunk of eight steps it tests the renormalisation
+// counter and the slot's alignment per LANE (the lanes of a wave disagree, so both paths run), and the renormalisation's
+// chunk goes through a rolled loop.  A fresh segment's counter starts at 0: a period of 512 steps is 31 pairs of chunks
+// (one 16-byte store each), one more chunk, seven plain steps and the step that renormalises -- the same operations in
+// the same order, under a SCALAR loop counter.  The continuations (mode 0: any counter, any alignment) stay above.
+__device__ __forceinline__ void rot_checkpoints_fresh(unsigned lane_seg, const RotSeg* __restrict__ segs, unsigned n_segs,
+                                                      RotState* __restrict__ state_next, cf* __restrict__ ck,
+                                                      cf* __restrict__ seg_incr, unsigned* __restrict__ seg_counter0,
+                                                      const unsigned* __restrict__ order)
+{
+    if (lane_seg >= n_segs) return;
+    const unsigned s = order[lane_seg];
+    const RotSeg* gp = segs + s;
+    if (gp->mode == 2) { // a fixed point of the recurrence: no chain (k_rot_checkpoints)
+        seg_incr[s] = gp->incr;
+        seg_counter0[s] = 0;
+        if (gp->last) {
+            RotState st;
+            st.exp = gp->exp0;
+            st.incr = gp->incr;
+            st.counter = 0;
+            st.pad = 0;
+            state_next[gp->channel] = st;
+        }
+        return;
+    }
+    cf e = gp->exp0;
+    const cf inc = gp->incr;
+    seg_incr[s] = inc;
+    seg_counter0[s] = 0;
+    float4* ckp = reinterpret_cast<float4*>(ck + gp->ck0); // (an even slot)
+    unsigned chunks = static_cast<unsigned>(gp->len / kRotChunk);
+    unsigned counter = 0;
+    constexpr unsigned kPeriodChunks = 512 / kRotChunk;
+    for (; chunks >= kPeriodChunks; chunks -= kPeriodChunks) {
+#pragma unroll 1
+        for (int pair = 0; pair < static_cast<int>(kPeriodChunks / 2) - 1; ++pair) {
+            const cf e0 = e;
+            e = rot_chunk_pk(e, inc);
+            *ckp++ = make_float4(e0.x, e0.y, e.x, e.y);
+            e = rot_chunk_pk(e, inc);
+        }
+        const cf e0 = e;
+        e = rot_chunk_pk(e, inc);
+        *ckp++ = make_float4(e0.x, e0.y, e.x, e.y);
+        counter += 512 - kRotChunk;
+#pragma unroll 1
+        for (unsigned j = 0; j < kRotChunk; ++j) rot_step(e, inc, counter); // (its last step renormalises)
+    }
+    // less than a period is left: no renormalisation any more
+    for (; chunks >= 2; chunks -= 2) {
+        const cf e0 = e;
+        e = rot_chunk_pk(e, inc);
+        *ckp++ = make_float4(e0.x, e0.y, e.x, e.y);
+        e = rot_chunk_pk(e, inc);
+        counter += 2 * kRotChunk;
+    }
+    cf* ck1 = reinterpret_cast<cf*>(ckp);
+    if (chunks) {
+        *ck1++ = e;
+        e = rot_chunk_pk(e, inc);
+        counter += kRotChunk;
+    }
+    gp = segs + s; // (recomputed: one register kept across the loops instead of two)
+    const unsigned rem = static_cast<unsigned>(gp->len) & (kRotChunk - 1);
+    if (rem) {
+        *ck1 = e;
+        for (unsigned j = 0; j < rem; ++j) rot_step(e, inc, counter);
+    }
+    if (gp->last) {
+        RotState st;
+        st.exp = e;
+        st.incr = inc;
+        st.counter = counter;
+        st.pad = 0;
+        state_next[gp->channel] = st;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_rot_checkpoints_fresh(const RotSeg* __restrict__ segs, unsigned n_segs,
+                                                              RotState* __restrict__ state_next, cf* __restrict__ ck,
+                                                              cf* __restrict__ seg_incr, unsigned* __restrict__ seg_counter0,
+                                                              const unsigned* __restrict__ order)
+{
+    __builtin_amdgcn_s_setprio(GR4PM_ROT_PRIO); // latency-bound, few waves
+    rot_checkpoints_fresh(blockIdx.x * blockDim.x + threadIdx.x, segs, n_segs, state_next, ck, seg_incr, seg_counter0, order);
+}
+// one launch for a whole plan on one stream: the first `fresh_blocks` workgroups take the n_fresh event-started entries of
+// order[], the others the continuations behind them -- side by side, as in the one kernel of rounds 1 - 5 (two launches on
+// one stream would run the continuation's chain BEHIND the others: 240 + 390 us per 2^28 samples where one kernel took 420)
+__global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_num_vgpr(16))) // (register pairs: 32)
+void k_rot_checkpoints_both(const RotSeg* __restrict__ segs, unsigned n_fresh,
+                                                             unsigned fresh_blocks, unsigned n_rest,
+                                                             const RotState* __restrict__ state,
+                                                             RotState* __restrict__ state_next, cf* __restrict__ ck,
+                                                             cf* __restrict__ seg_incr, unsigned* __restrict__ seg_counter0,
+                                                             const unsigned* __restrict__ order)
+{
+    __builtin_amdgcn_s_setprio(GR4PM_ROT_PRIO); // latency-bound, few waves
+    if (blockIdx.x < fresh_blocks) // (uniform)
+        rot_checkpoints_fresh(blockIdx.x * blockDim.x + threadIdx.x, segs, n_fresh, state_next, ck, seg_incr, seg_counter0, order);
+    else
+        rot_checkpoints_generic((blockIdx.x - fresh_blocks) * blockDim.x + threadIdx.x, segs, n_rest, state, state_next, ck,
+                                seg_incr, seg_counter0, order + n_fresh);
 }
 
 // (tests only: GR4PM_TEST_ROT_DELAY_US) keeps a stream busy for `us` microseconds
@@ -1993,6 +2133,7 @@ static gr4pm_status rotator_plan_impl(gr4pm_rotator* h, size_t n, const gr4pm_ta
             g.start = start;
             g.len = end - start;
             g.channel = static_cast<unsigned>(c);
+            ck = (ck + 1u) & ~1u; // an even slot: 16-byte checkpoint stores without a test (k_rot_checkpoints_fresh)
             g.ck0 = ck;
             g.mode = mode;
             g.last = 0;
@@ -2093,10 +2234,25 @@ static gr4pm_status rotator_plan_impl(gr4pm_rotator* h, size_t n, const gr4pm_ta
     const int st_next = (h->st_cur + 1) % gr4pm_rotator::kStates;
     RotState* st_out = h->state.p + static_cast<size_t>(st_next) * h->n_channels;
     static const unsigned wg = gr4pm::experiment_env_wg("GR4PM_ROT_WG", 64u, 1u, 64u); // __launch_bounds__(64)
+    // the entries of order[] in front of n_indep + n_writer start at an event (or are fixed points): k_rot_checkpoints_fresh;
+    // GR4PM_ROT_GENERIC=1: the one kernel of rounds 1 - 5 for everything (A/B)
+    static const bool generic_only = getenv("GR4PM_ROT_GENERIC") != nullptr;
     auto launch_chains = [&](hipStream_t on, unsigned first, unsigned count) {
-        if (count && !timing_skip("rot")) // GR4PM_TIMING_SKIP: what a kernel costs the pipeline (results are garbage)
+        if (!count || timing_skip("rot")) return; // GR4PM_TIMING_SKIP: what a kernel costs the pipeline (results are garbage)
+        const unsigned n_fresh = generic_only ? 0u : n_indep + n_writer;
+        const unsigned fresh = first < n_fresh ? std::min(count, n_fresh - first) : 0u;
+        if (fresh && count > fresh) {
+            const unsigned fresh_blocks = grid_for(fresh, wg);
+            hipLaunchKernelGGL(k_rot_checkpoints_both, dim3(fresh_blocks + grid_for(count - fresh, wg)), dim3(wg), 0, on,
+                               pl.segs.p, fresh, fresh_blocks, count - fresh, st_in, st_out, pl.ck.p, pl.seg_incr.p,
+                               pl.seg_counter0.p, pl.order.p + first);
+        } else if (fresh) {
+            hipLaunchKernelGGL(k_rot_checkpoints_fresh, dim3(grid_for(fresh, wg)), dim3(wg), 0, on, pl.segs.p, fresh, st_out,
+                               pl.ck.p, pl.seg_incr.p, pl.seg_counter0.p, pl.order.p + first);
+        } else {
             hipLaunchKernelGGL(k_rot_checkpoints, dim3(grid_for(count, wg)), dim3(wg), 0, on, pl.segs.p, count, st_in, st_out,
                                pl.ck.p, pl.seg_incr.p, pl.seg_counter0.p, pl.order.p + first);
+        }
     };
     auto launch_const_fill = [&](hipStream_t on) {
         if (!n_const) return;
