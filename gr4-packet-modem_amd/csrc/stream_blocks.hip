@@ -203,33 +203,8 @@ __device__ __forceinline__ void rot_checkpoints_generic(unsigned lane_seg, const
     for (int phase = 0; phase < 2; ++phase) {
     const unsigned stop = phase == 0 && periods ? left - lead : 0u; // chunks still to do when this phase ends
     while (left != stop) {
-        if (left - stop >= 4 && (counter & 511u) < 512u - 4 * kRotChunk && !(reinterpret_cast<size_t>(ckp) & 8)) {
-            // four chunks per pass while no renormalisation falls into them: the chain itself (3 instructions a step)
-            // with one counter test and one branch per 32 steps instead of per 8.  The four checkpoints leave as two
-            // 16-byte stores (round 5; hence the alignment test -- a single chunk below flips it): every lane writes to
-            // its own segment, i.e. every store instruction touches 64 cache lines, and those transactions queue in front
-            // of the memory operations of the correlator waves this kernel shares its compute units with (leave-outs:
-            // the kernel costs the chain 0.15 ms a step, 0.065 of them its stores).
-#ifdef GR4PM_ROT_NO_STORES // (timing experiment: EXTRA=-DGR4PM_ROT_NO_STORES, wrong results)
-            e = rot_chunk_pk(e, inc);
-            e = rot_chunk_pk(e, inc);
-            e = rot_chunk_pk(e, inc);
-            e = rot_chunk_pk(e, inc);
-            if (left == 0xffffffffu) ckp[0] = e;
-#else
-            cf e0 = e;
-            e = rot_chunk_pk(e, inc);
-            reinterpret_cast<float4*>(ckp)[0] = make_float4(e0.x, e0.y, e.x, e.y);
-            e0 = rot_chunk_pk(e, inc);
-            e = rot_chunk_pk(e0, inc);
-            reinterpret_cast<float4*>(ckp)[1] = make_float4(e0.x, e0.y, e.x, e.y);
-            e = rot_chunk_pk(e, inc);
-#endif
-            counter += 4 * kRotChunk;
-            ckp += 4;
-            left -= 4;
-            continue;
-        }
+        // (rounds 3 - 5 took four chunks per pass here while no renormalisation fell into them, with 16-byte stores where the
+        // slot was aligned -- decided per lane; the periods below have taken that over, this loop sees less than 64 chunks)
         *ckp++ = e;
         --left;
         if ((counter & 511u) < 512u - kRotChunk) { // no renormalisation inside this chunk
@@ -269,8 +244,7 @@ __device__ __forceinline__ void rot_checkpoints_generic(unsigned lane_seg, const
         state_next[gp->channel] = st; // (another row of the ring: another lane may still have to read `state`)
     }
 }
-__global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_num_vgpr(16))) // (register pairs: 32)
-void k_rot_checkpoints(const RotSeg* __restrict__ segs, unsigned n_segs,
+__global__ __launch_bounds__(64) void k_rot_checkpoints(const RotSeg* __restrict__ segs, unsigned n_segs,
                                                         const RotState* __restrict__ state,
                                                         RotState* __restrict__ state_next, cf* __restrict__ ck,
                                                         cf* __restrict__ seg_incr, unsigned* __restrict__ seg_counter0,
@@ -373,8 +347,7 @@ __global__ __launch_bounds__(64) void k_rot_checkpoints_fresh(const RotSeg* __re
 // one launch for a whole plan on one stream: the first `fresh_blocks` workgroups take the n_fresh event-started entries of
 // order[], the others the continuations behind them -- side by side, as in the one kernel of rounds 1 - 5 (two launches on
 // one stream would run the continuation's chain BEHIND the others: 240 + 390 us per 2^28 samples where one kernel took 420)
-__global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_num_vgpr(16))) // (register pairs: 32)
-void k_rot_checkpoints_both(const RotSeg* __restrict__ segs, unsigned n_fresh,
+__global__ __launch_bounds__(64) void k_rot_checkpoints_both(const RotSeg* __restrict__ segs, unsigned n_fresh,
                                                              unsigned fresh_blocks, unsigned n_rest,
                                                              const RotState* __restrict__ state,
                                                              RotState* __restrict__ state_next, cf* __restrict__ ck,
